@@ -1,0 +1,142 @@
+/* raftx.h -- C-ABI of the MI355X-native RAFT hot path (libraftx_hip.so).
+ *
+ * The reference (WISDEM/RAFT, pure Python) has no FFI; the boundary a
+ * maintainer binds is the Python method surface
+ *     raft/raft_model.py:966   Model.solveDynamics(case, tol=0.01, ...)
+ *     raft/raft_fowt.py:1732   FOWT.calcHydroExcitation(case, memberList)
+ *     raft/raft_fowt.py:1891   FOWT.calcHydroLinearization(Xi)
+ *     raft/raft_fowt.py:1940   FOWT.calcDragExcitation(ih)
+ * Each entry point below names the reference lines it replaces.  Plain C,
+ * plain pointers and sizes; no C++ / torch types cross this boundary.
+ *
+ * Conventions
+ *   - return 0 = ok, <0 = error (text via raftx_last_error()).
+ *   - all pointers are caller-owned C-contiguous host buffers (NumPy
+ *     arrays); raftx_upload_* copy to HBM, nothing is retained past a call.
+ *   - complex numbers are interleaved (re, im) doubles == numpy complex128
+ *     == C99 double _Complex.
+ *   - frequency is the last (contiguous) axis of every array, as in the
+ *     reference.
+ *   - calls on one ctx are stream-ordered; different ctxs are independent;
+ *     there is no global state.  One ctx per process per GPU.
+ *   - all arithmetic is IEEE fp64.
+ *
+ * The same header is implemented twice: libraftx_hip.so (gfx950, the
+ * product) and oracle/libraftx_oracle.so (plain C restatement of the
+ * reference algorithm; TEST INFRASTRUCTURE ONLY).
+ */
+#ifndef RAFTX_H
+#define RAFTX_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RAFTX_VERSION 100          /* 0.1.0 */
+#define RAFTX_NFIELD  32           /* doubles per strip record (256 B) */
+
+/* strip record field offsets (doubles); packer: raft_amd/strips.py */
+#define RAFTX_F_X     0   /* absolute position x,y,z      (raft_member.py:362 mem.r[il]) */
+#define RAFTX_F_AX    3   /* arm about reduced-DOF ref pt  (raft_fowt.py:1919-1929 folded) */
+#define RAFTX_F_Q     6   /* axial unit vector             (raft_member.py:370) */
+#define RAFTX_F_P1    9   /* transverse unit vector 1      (raft_member.py:371) */
+#define RAFTX_F_P2    12  /* transverse unit vector 2      (raft_member.py:372) */
+#define RAFTX_F_IQ    15  /* rho*v_end*Ca_End              (raft_member.py:1442) */
+#define RAFTX_F_IP1   16  /* rho*v_side*Cm_p1              (raft_member.py:1423) */
+#define RAFTX_F_IP2   17  /* rho*v_side*Cm_p2 */
+#define RAFTX_F_AI    18  /* signed end area a_i           (raft_member.py:1343,1347) */
+#define RAFTX_F_DQ    19  /* sqrt(8/pi)*rho/2*a_q*Cd_q     (raft_member.py:2070,2093) */
+#define RAFTX_F_DP1   20  /* ... a_p1*Cd_p1                (raft_member.py:2071,2094) */
+#define RAFTX_F_DP2   21  /* ... a_p2*Cd_p2                (raft_member.py:2072,2095) */
+#define RAFTX_F_DEND  22  /* ... |a_end|*Cd_End            (raft_member.py:2105-2110) */
+#define RAFTX_F_CIRC  23  /* 1 circular, 0 rectangular     (raft_member.py:2085-2090) */
+#define RAFTX_F_MCF   24  /* -1, or row in the complex Cm table (raft_member.py:1984-1985) */
+#define RAFTX_F_RHOV  25  /* rho*v_side (times complex Cm when MCF) */
+
+/* flags[] bits written by raftx_solve_dynamics */
+#define RAFTX_FLAG_CONVERGED 1    /* raft_model.py:1104 test passed */
+#define RAFTX_FLAG_NAN       2    /* raft_model.py:1098-1099 would have raised */
+
+typedef struct raftx_ctx raftx_ctx;
+typedef struct { double re, im; } raftx_c128;
+
+int         raftx_version(void);
+/* 1 if this library computes on a GPU (libraftx_hip), 0 for the CPU oracle */
+int         raftx_is_device(void);
+int         raftx_ctx_create(int device_id, raftx_ctx **out);
+void        raftx_ctx_destroy(raftx_ctx *ctx);
+const char *raftx_last_error(raftx_ctx *ctx);
+
+/* Designs = independent floating units (sweep candidates, or the N units of
+ * a farm).  stripOffsets[nDesign+1] indexes rows of strips[.,32].
+ * M0/B0/C0 [nDesign,6,6] are the frequency-independent sums of
+ * raft_model.py:1045-1047 (M_struc+A_hydro_morison(+moor), B_struc+sum B_gyro,
+ * C_struc+C_hydro+C_moor+C_elast).  MBw (optional, may be NULL)
+ * [nDesign,2,6,6,nw] carries the frequency-dependent parts (M_turb+A_BEM,
+ * B_turb+B_BEM).  cmOffsets/CmMCF (optional) are the MacCamy-Fuchs complex
+ * (Cm_p1,Cm_p2) rows [nRows,2,nw] (raft_member.py:1415-1420,1467-1484). */
+int raftx_upload_designs(raftx_ctx *ctx, int nDesign, const int64_t *stripOffsets,
+                         const double *strips, int nStripFields,
+                         const double *M0, const double *B0, const double *C0,
+                         int nw, const double *MBw,
+                         const int64_t *cmOffsets, const raftx_c128 *CmMCF);
+
+/* Sea states.  w,k [nw] come from the host (the reference's own dispersion
+ * solve, helpers.py:377-392, tolerance 1e-3 -- never re-solved on device).
+ * zeta [nCase,nHead,nw] = sqrt(2 S dw) (raft_fowt.py:1763-1769), beta
+ * [nCase,nHead] in rad.  rho,g feed the dynamic pressure (helpers.py:231). */
+int raftx_upload_cases(raftx_ctx *ctx, int nCase, int nHead, int nw,
+                       const double *w, const double *k,
+                       double depth, double rho, double g,
+                       const double *zeta, const double *beta);
+
+/* Strip-theory inertial excitation for every (design, case, heading):
+ * raft_fowt.py:1854-1857,1888 + raft_member.py:1940-1992 + helpers.py:188-236.
+ * F_iner [nDesign,nCase,nHead,6,nw]. */
+int raftx_excitation(raftx_ctx *ctx, raftx_c128 *F_iner);
+
+/* One drag linearisation about a given response: raft_fowt.py:1891-1957 +
+ * raft_member.py:1995-2152.  Xi [nDesign,nCase,6,nw] ->
+ * B_drag [nDesign,nCase,6,6], F_drag [nDesign,nCase,nHead,6,nw] (heading 0 is
+ * what calcHydroLinearization stores; the others are calcDragExcitation(ih)).
+ * Either output may be NULL. */
+int raftx_linearize(raftx_ctx *ctx, const raftx_c128 *Xi, double *B_drag, raftx_c128 *F_drag);
+
+/* The fused fixed-point solve, raft_model.py:994-1155 per unit plus the
+ * per-heading response of :1189-1236 for an uncoupled unit:
+ *   XiLast <- XiStart; repeat <= nIter+1 times { linearise about XiLast;
+ *   Z = -w^2 M + i w (B + B_drag) + C; Xi = Z^-1 (F_lin + F_drag); converged if
+ *   |Xi-XiLast|/(|Xi|+tol) < tol everywhere, else XiLast <- 0.2 XiLast + 0.8 Xi }
+ * then for each heading ih  Xi[ih] = Z^-1 (F_extra[ih] + F_iner[ih] + F_drag(ih)).
+ * nIter is the YAML setting (the loop runs nIter+1 times, raft_model.py:977).
+ * F_extra (optional) [nDesign,nCase,nHead,6,nw] = F_BEM + Fhydro_2nd.
+ * Outputs (any may be NULL): Xi [nDesign,nCase,nHead,6,nw]; niter, flags
+ * [nDesign,nCase]; B_drag [nDesign,nCase,6,6]; F_wave [nDesign,nCase,nHead,6,nw]
+ * (total excitation per heading, raft_model.py:1212); Z [nDesign,nCase,6,6,nw]. */
+int raftx_solve_dynamics(raftx_ctx *ctx, int nIter, double tol, double XiStart,
+                         const raftx_c128 *F_extra,
+                         raftx_c128 *Xi, int32_t *niter, int32_t *flags,
+                         double *B_drag, raftx_c128 *F_wave, raftx_c128 *Z);
+
+/* Coupled array solve, raft_model.py:1164-1236: for each system s and bin w
+ *   Z_sys = blockdiag_i(Zblk[s,i]) + (-w^2 Mc[s] + i w Bc[s] + Cc[s]);
+ *   Xi[s,r] = Z_sys^-1 F[s,r].
+ * Zblk [nSys,nUnit,6,6,nw]; Mc,Bc,Cc [nSys,6nUnit,6nUnit] or NULL;
+ * F, Xi [nSys,nRhs,6nUnit,nw]. */
+int raftx_solve_system(raftx_ctx *ctx, int nSys, int nUnit, int nRhs, int nw,
+                       const double *w, const raftx_c128 *Zblk,
+                       const double *Mc, const double *Bc, const double *Cc,
+                       const raftx_c128 *F, raftx_c128 *Xi);
+
+/* Duration (ms) of the device work of the last raftx_excitation /
+ * raftx_linearize / raftx_solve_dynamics / raftx_solve_system call on this
+ * ctx, measured with HIP events on the ctx's own stream (excludes H2D/D2H).
+ * The oracle returns host wall time of the compute loop. */
+double raftx_last_kernel_ms(raftx_ctx *ctx);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RAFTX_H */

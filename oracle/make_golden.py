@@ -1,0 +1,179 @@
+"""TEST INFRASTRUCTURE ONLY -- generates tests/golden/*.npz from the LIVE
+reference (/root/reference, imported unmodified through oracle/ref_harness.py)
+and converts the reference's own golden pickles for this path
+(tests/test_data/*_true_hydroExcitation.pkl, *_true_hydroLinearization.pkl;
+tests/test_fowt.py:111-175) into the same container format.
+
+Run in the build container only:   python oracle/make_golden.py [names...]
+The GPU box never runs this; it reads the committed .npz files.
+"""
+import copy
+import os
+import pickle
+import sys
+import time
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+sys.path.insert(0, ROOT)
+
+from oracle import ref_harness as rh          # noqa: E402
+from tests import standin                     # noqa: E402
+
+REF = rh.REFERENCE_ROOT
+GOLD = standin.GOLDEN_DIR
+
+
+def run_case(model, case):
+    """Reference solveDynamics + the by-products the parity tests compare."""
+    counts = []
+    for f in model.fowtList:
+        cnt = {"n": 0}
+        orig = f.calcHydroLinearization
+
+        def wrapped(Xi, _orig=orig, _cnt=cnt):
+            _cnt["n"] += 1
+            return _orig(Xi)
+        f.calcHydroLinearization = wrapped
+        counts.append((f, cnt, orig))
+    c = copy.deepcopy(case)
+    t0 = time.time()
+    Xi = model.solveDynamics(c).copy()
+    dt = time.time() - t0
+    out = {"case": {k: (list(v) if isinstance(v, (list, tuple, np.ndarray)) else v) for k, v in case.items()},
+           "Xi": Xi, "ref_seconds": dt, "units": []}
+    for f, cnt, orig in counts:
+        del f.calcHydroLinearization          # restore class method
+        out["units"].append({
+            "niter": cnt["n"],
+            "Z": np.array(f.Z), "F_hydro_iner": np.array(f.F_hydro_iner),
+            "B_hydro_drag": np.array(f.B_hydro_drag), "zeta": np.array(f.zeta),
+            "beta": np.array(f.beta), "S": np.array(f.S),
+        })
+    return out
+
+
+def fixture_c1():
+    d = rh.load_design(os.path.join(REF, "designs/OC3spar.yaml"))
+    d = rh.prepare_design(d, settings=dict(min_freq=0.008, max_freq=0.4, nIter=10, XiStart=0))
+    m = rh.build_model(d)
+    cases = [rh.make_case(Hs=2.0, Tp=8.0, heading=0.0)]
+    fx = {"config": "C1 OC3spar nw=50", "model": standin.snapshot_model(m),
+          "cases": [run_case(m, c) for c in cases]}
+    standin.save_fixture(os.path.join(GOLD, "c1_oc3spar.npz"), fx)
+
+
+def fixture_c2():
+    d = rh.load_design(os.path.join(REF, "examples/VolturnUS-S_example.yaml"))
+    d = rh.prepare_design(d)
+    m = rh.build_model(d)
+    cases = [rh.make_case(Hs=6.0, Tp=12.0), rh.make_case(Hs=2.0, Tp=8.0), rh.make_case(Hs=10.0, Tp=14.0),
+             rh.make_case(Hs=6.0, Tp=12.0, heading=30.0),
+             rh.make_case(Hs=[6.0, 3.0], Tp=[12.0, 9.0], heading=[0.0, 70.0],
+                          spectrum=["JONSWAP", "JONSWAP"], gamma=[0, 0])]
+    fx = {"config": "C2 VolturnUS-S_example nw=200", "model": standin.snapshot_model(m),
+          "cases": [run_case(m, c) for c in cases]}
+    standin.save_fixture(os.path.join(GOLD, "c2_volturnus.npz"), fx)
+
+
+def fixture_pose():
+    """Non-trivial mean pose + XiStart != 0 + more iterations (exercises the
+    folded member-node -> reduced-DOF arm)."""
+    d = rh.load_design(os.path.join(REF, "tests/test_data/VolturnUS-S.yaml"))
+    d = rh.prepare_design(d, settings=dict(XiStart=0.1, nIter=15))
+    d["platform"]["potSecOrder"] = 0         # keep the QTF re-entry out of this fixture
+    m = rh.build_model(d, r6=[[3.0, -2.0, -0.5, 0.02, -0.03, 0.1]])
+    cases = [rh.make_case(Hs=4.0, Tp=10.0, heading=30.0),
+             rh.make_case(Hs=[4.0, 2.0], Tp=[10.0, 7.0], heading=[30.0, -70.0],
+                          spectrum=["JONSWAP", "JONSWAP"], gamma=[0, 0])]
+    fx = {"config": "VolturnUS-S (MCF columns) at offset pose", "model": standin.snapshot_model(m),
+          "cases": [run_case(m, c) for c in cases]}
+    standin.save_fixture(os.path.join(GOLD, "pose_volturnus_mcf.npz"), fx)
+
+
+def fixture_ref_goldens():
+    """The reference's own goldens for this path: tests/test_fowt.py:111-175."""
+    raft = rh.import_raft()
+    for name in ("OC3spar", "VolturnUS-S", "VolturnUS-S-pointInertia"):
+        d = rh.load_design(os.path.join(REF, "tests/test_data", name + ".yaml"))
+        d = rh.prepare_design(d)
+        model = raft.Model(d)
+        fowt = model.fowtList[0]
+        fowt.setPosition(np.zeros(fowt.nDOF))          # tests/test_fowt.py:46-48
+        fowt.calcStatics()
+        fowt.calcHydroConstants()
+        fowt.calcTurbineConstants(rh.make_case(), ptfm_pitch=0)     # only so that A_aero/B_gyro exist (all zero)
+        fowt.C_moor = np.zeros((6, 6))
+        with open(os.path.join(REF, "tests/test_data", name + "_true_hydroExcitation.pkl"), "rb") as f:
+            exc = pickle.load(f)
+        with open(os.path.join(REF, "tests/test_data", name + "_true_hydroLinearization.pkl"), "rb") as f:
+            lin = pickle.load(f)
+        fx = {"config": "reference goldens " + name,
+              "model": standin.snapshot_model(model),
+              "exc_cases": [dict(wave_heading=e["case"]["wave_heading"], wave_period=e["case"]["wave_period"],
+                                 wave_height=e["case"]["wave_height"]) for e in exc],
+              "exc_F_hydro_iner": np.array([e["F_hydro_iner"] for e in exc]),
+              "exc_w": np.array(exc[0]["w"]),
+              "lin_B_hydro_drag": np.array(lin["B_hydro_drag"]),
+              "lin_F_hydro_drag": np.array(lin["F_hydro_drag"])}
+        standin.save_fixture(os.path.join(GOLD, "refgold_%s.npz" % name), fx)
+
+
+class _FixedArrayMooring:
+    """Stands in for the array-level MoorPy system: a fixed coupling stiffness
+    (raft_model.py:1176 getCoupledStiffnessA)."""
+
+    def __init__(self, C):
+        self.C = C
+
+    def getCoupledStiffnessA(self, lines_only=True):
+        return self.C
+
+
+def farm_coupling(nUnit, k=5e4):
+    """-k between surge/sway DOFs of neighbours (ring), symmetric."""
+    n = 6 * nUnit
+    C = np.zeros((n, n))
+    for a in range(nUnit):
+        b = (a + 1) % nUnit
+        if a == b:
+            continue
+        for dof in (0, 1):
+            C[6 * a + dof, 6 * a + dof] += k
+            C[6 * b + dof, 6 * b + dof] += k
+            C[6 * a + dof, 6 * b + dof] -= k
+            C[6 * b + dof, 6 * a + dof] -= k
+    return C
+
+
+def fixture_c4():
+    d = rh.load_design(os.path.join(REF, "designs/VolturnUS-S_farm.yaml"))
+    d = rh.prepare_design(d, settings=dict(min_freq=0.002, max_freq=0.2))       # nw=100 keeps the fixture small
+    d["array"]["data"] = [[1, 1, 0, 0, 0, 180], [1, 1, 0, 1600, 0, 0],
+                          [1, 1, 0, 0, 1600, 90], [1, 1, 0, 1600, 1600, 270]]
+    m = rh.build_model(d)
+    Cc = farm_coupling(4)
+    m.ms = _FixedArrayMooring(Cc)
+    m.moorMod = 0
+    rng = np.random.default_rng(1)
+    cases = []
+    for _ in range(2):
+        cases.append(rh.make_case(Hs=float(rng.uniform(1, 10)), Tp=float(rng.uniform(6, 16)),
+                                  heading=float(rng.uniform(0, 360))))
+    fx = {"config": "C4 4-unit VolturnUS-S farm nw=100", "model": standin.snapshot_model(m),
+          "coupling_C": Cc, "cases": [run_case(m, c) for c in cases]}
+    standin.save_fixture(os.path.join(GOLD, "c4_farm.npz"), fx)
+
+
+ALL = {"c1": fixture_c1, "c2": fixture_c2, "pose": fixture_pose,
+       "refgold": fixture_ref_goldens, "c4": fixture_c4}
+
+if __name__ == "__main__":
+    names = sys.argv[1:] or list(ALL)
+    os.makedirs(GOLD, exist_ok=True)
+    for n in names:
+        t0 = time.time()
+        ALL[n]()
+        print("fixture %s done in %.1f s" % (n, time.time() - t0))

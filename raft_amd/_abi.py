@@ -1,0 +1,239 @@
+"""ctypes binding of the raftx C-ABI (include/raftx.h).
+
+``RaftxLib(path)`` binds ANY shared object that implements the header; the
+product only ever binds ``raft_amd/csrc/libraftx_hip.so`` (see backend.py).
+The test-suite binds ``oracle/libraftx_oracle.so`` through the same class so
+parity tests drive both implementations with identical calls.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+NFIELD = 32
+FLAG_CONVERGED = 1
+FLAG_NAN = 2
+
+_c_double_p = C.POINTER(C.c_double)
+_c_i64_p = C.POINTER(C.c_int64)
+_c_i32_p = C.POINTER(C.c_int32)
+_vp = C.c_void_p
+
+EXPORTS = (
+    "raftx_version", "raftx_is_device", "raftx_ctx_create", "raftx_ctx_destroy",
+    "raftx_last_error", "raftx_upload_designs", "raftx_upload_cases",
+    "raftx_excitation", "raftx_linearize", "raftx_solve_dynamics",
+    "raftx_solve_system", "raftx_last_kernel_ms",
+)
+
+
+class RaftxError(RuntimeError):
+    pass
+
+
+def _f64(a, shape=None, name="array"):
+    a = np.ascontiguousarray(a, dtype=np.float64)
+    if shape is not None and tuple(a.shape) != tuple(shape):
+        raise ValueError("%s has shape %s, expected %s" % (name, a.shape, tuple(shape)))
+    return a
+
+
+def _c128(a, shape=None, name="array"):
+    a = np.ascontiguousarray(a, dtype=np.complex128)
+    if shape is not None and tuple(a.shape) != tuple(shape):
+        raise ValueError("%s has shape %s, expected %s" % (name, a.shape, tuple(shape)))
+    return a
+
+
+def _ptr(a):
+    return None if a is None else a.ctypes.data_as(_vp)
+
+
+class RaftxLib:
+    def __init__(self, path):
+        if not os.path.exists(path):
+            raise RaftxError("shared library not found: %s" % path)
+        self.path = path
+        self.lib = C.CDLL(path)
+        missing = [s for s in EXPORTS if not hasattr(self.lib, s)]
+        if missing:
+            raise RaftxError("%s does not export %s" % (path, missing))
+        L = self.lib
+        L.raftx_version.restype = C.c_int
+        L.raftx_is_device.restype = C.c_int
+        L.raftx_ctx_create.argtypes = [C.c_int, C.POINTER(_vp)]
+        L.raftx_ctx_create.restype = C.c_int
+        L.raftx_ctx_destroy.argtypes = [_vp]
+        L.raftx_ctx_destroy.restype = None
+        L.raftx_last_error.argtypes = [_vp]
+        L.raftx_last_error.restype = C.c_char_p
+        L.raftx_upload_designs.argtypes = [_vp, C.c_int, _vp, _vp, C.c_int, _vp, _vp, _vp,
+                                           C.c_int, _vp, _vp, _vp]
+        L.raftx_upload_designs.restype = C.c_int
+        L.raftx_upload_cases.argtypes = [_vp, C.c_int, C.c_int, C.c_int, _vp, _vp,
+                                         C.c_double, C.c_double, C.c_double, _vp, _vp]
+        L.raftx_upload_cases.restype = C.c_int
+        L.raftx_excitation.argtypes = [_vp, _vp]
+        L.raftx_excitation.restype = C.c_int
+        L.raftx_linearize.argtypes = [_vp, _vp, _vp, _vp]
+        L.raftx_linearize.restype = C.c_int
+        L.raftx_solve_dynamics.argtypes = [_vp, C.c_int, C.c_double, C.c_double, _vp,
+                                           _vp, _vp, _vp, _vp, _vp, _vp]
+        L.raftx_solve_dynamics.restype = C.c_int
+        L.raftx_solve_system.argtypes = [_vp, C.c_int, C.c_int, C.c_int, C.c_int, _vp, _vp,
+                                         _vp, _vp, _vp, _vp, _vp]
+        L.raftx_solve_system.restype = C.c_int
+        L.raftx_last_kernel_ms.argtypes = [_vp]
+        L.raftx_last_kernel_ms.restype = C.c_double
+
+    @property
+    def version(self):
+        return int(self.lib.raftx_version())
+
+    @property
+    def is_device(self):
+        return bool(self.lib.raftx_is_device())
+
+    def context(self, device_id=0):
+        return Context(self, device_id)
+
+
+class Context:
+    """One raftx_ctx: owns a stream and the device-resident design/case tables."""
+
+    def __init__(self, rlib, device_id=0):
+        self.rlib = rlib
+        self._h = _vp()
+        rc = rlib.lib.raftx_ctx_create(int(device_id), C.byref(self._h))
+        if rc != 0 or not self._h:
+            raise RaftxError("raftx_ctx_create(device=%d) failed (rc=%d) in %s"
+                             % (device_id, rc, rlib.path))
+        self.nDesign = self.nCase = self.nHead = self.nw = 0
+
+    def close(self):
+        if self._h:
+            self.rlib.lib.raftx_ctx_destroy(self._h)
+            self._h = _vp()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def _check(self, rc, what):
+        if rc != 0:
+            msg = self.rlib.lib.raftx_last_error(self._h)
+            raise RaftxError("%s failed (rc=%d): %s" % (what, rc, (msg or b"").decode()))
+
+    # ------------------------------------------------------------- uploads
+    def upload_designs(self, strip_tables, M0, B0, C0, nw, MBw=None):
+        """strip_tables: list of raft_amd.strips.StripTable (one per design)."""
+        nD = len(strip_tables)
+        off = np.zeros(nD + 1, dtype=np.int64)
+        cmoff = np.zeros(nD + 1, dtype=np.int64)
+        for i, t in enumerate(strip_tables):
+            off[i + 1] = off[i] + t.n
+            cmoff[i + 1] = cmoff[i] + (0 if t.cm_mcf is None else t.cm_mcf.shape[0])
+        strips = np.concatenate([t.strips for t in strip_tables], axis=0) if nD else np.zeros((0, NFIELD))
+        strips = _f64(strips.reshape(-1, NFIELD))
+        cm = None
+        if cmoff[-1] > 0:
+            cm = _c128(np.concatenate([t.cm_mcf for t in strip_tables if t.cm_mcf is not None], axis=0),
+                       (cmoff[-1], 2, nw), "CmMCF")
+        return self.upload_designs_raw(off, strips, M0, B0, C0, nw, MBw, cmoff if cm is not None else None, cm)
+
+    def upload_designs_raw(self, off, strips, M0, B0, C0, nw, MBw=None, cmoff=None, cm=None):
+        off = np.ascontiguousarray(off, dtype=np.int64)
+        nD = len(off) - 1
+        strips = _f64(strips)
+        if strips.size != off[-1] * NFIELD:
+            raise ValueError("strips has %d values, offsets imply %d" % (strips.size, off[-1] * NFIELD))
+        M0 = _f64(M0, (nD, 6, 6), "M0")
+        B0 = _f64(B0, (nD, 6, 6), "B0")
+        C0 = _f64(C0, (nD, 6, 6), "C0")
+        if MBw is not None:
+            MBw = _f64(MBw, (nD, 2, 6, 6, nw), "MBw")
+        if cm is not None:
+            cmoff = np.ascontiguousarray(cmoff, dtype=np.int64)
+            cm = _c128(cm, (cmoff[-1], 2, nw), "CmMCF")
+        rc = self.rlib.lib.raftx_upload_designs(self._h, nD, _ptr(off), _ptr(strips), NFIELD,
+                                                _ptr(M0), _ptr(B0), _ptr(C0), int(nw), _ptr(MBw),
+                                                _ptr(cmoff) if cm is not None else None, _ptr(cm))
+        self._check(rc, "raftx_upload_designs")
+        self.nDesign = nD
+        self._nw_designs = int(nw)
+
+    def upload_cases(self, w, k, depth, rho, g, zeta, beta):
+        w = _f64(w)
+        nw = w.shape[0]
+        k = _f64(k, (nw,), "k")
+        zeta = _f64(zeta)
+        if zeta.ndim != 3 or zeta.shape[2] != nw:
+            raise ValueError("zeta must be [nCase,nHead,nw]")
+        nC, nH = zeta.shape[0], zeta.shape[1]
+        beta = _f64(beta, (nC, nH), "beta")
+        rc = self.rlib.lib.raftx_upload_cases(self._h, nC, nH, nw, _ptr(w), _ptr(k),
+                                              float(depth), float(rho), float(g), _ptr(zeta), _ptr(beta))
+        self._check(rc, "raftx_upload_cases")
+        self.nCase, self.nHead, self.nw = nC, nH, nw
+
+    # ------------------------------------------------------------- compute
+    def excitation(self):
+        F = np.empty((self.nDesign, self.nCase, self.nHead, 6, self.nw), dtype=np.complex128)
+        self._check(self.rlib.lib.raftx_excitation(self._h, _ptr(F)), "raftx_excitation")
+        return F
+
+    def linearize(self, Xi, want_F=True):
+        Xi = _c128(Xi, (self.nDesign, self.nCase, 6, self.nw), "Xi")
+        B = np.empty((self.nDesign, self.nCase, 6, 6), dtype=np.float64)
+        F = np.empty((self.nDesign, self.nCase, self.nHead, 6, self.nw), dtype=np.complex128) if want_F else None
+        self._check(self.rlib.lib.raftx_linearize(self._h, _ptr(Xi), _ptr(B), _ptr(F)), "raftx_linearize")
+        return B, F
+
+    def solve_dynamics(self, nIter, tol=0.01, XiStart=0.1, F_extra=None,
+                       want_Xi=True, want_B=False, want_F=False, want_Z=False):
+        nD, nC, nH, nw = self.nDesign, self.nCase, self.nHead, self.nw
+        if F_extra is not None:
+            F_extra = _c128(F_extra, (nD, nC, nH, 6, nw), "F_extra")
+        out = {}
+        Xi = np.empty((nD, nC, nH, 6, nw), dtype=np.complex128) if want_Xi else None
+        niter = np.zeros((nD, nC), dtype=np.int32)
+        flags = np.zeros((nD, nC), dtype=np.int32)
+        B = np.empty((nD, nC, 6, 6), dtype=np.float64) if want_B else None
+        F = np.empty((nD, nC, nH, 6, nw), dtype=np.complex128) if want_F else None
+        Z = np.empty((nD, nC, 6, 6, nw), dtype=np.complex128) if want_Z else None
+        rc = self.rlib.lib.raftx_solve_dynamics(self._h, int(nIter), float(tol), float(XiStart),
+                                                _ptr(F_extra), _ptr(Xi), _ptr(niter), _ptr(flags),
+                                                _ptr(B), _ptr(F), _ptr(Z))
+        self._check(rc, "raftx_solve_dynamics")
+        out.update(Xi=Xi, niter=niter, flags=flags, B_drag=B, F_wave=F, Z=Z)
+        return out
+
+    def solve_system(self, w, Zblk, F, Mc=None, Bc=None, Cc=None):
+        Zblk = _c128(Zblk)
+        nS, nU = Zblk.shape[0], Zblk.shape[1]
+        nw = Zblk.shape[-1]
+        n = 6 * nU
+        F = _c128(F)
+        nR = F.shape[1]
+        if F.shape != (nS, nR, n, nw):
+            raise ValueError("F must be [nSys,nRhs,6*nUnit,nw]")
+        w = _f64(w, (nw,), "w")
+        Mc = None if Mc is None else _f64(Mc, (nS, n, n), "Mc")
+        Bc = None if Bc is None else _f64(Bc, (nS, n, n), "Bc")
+        Cc = None if Cc is None else _f64(Cc, (nS, n, n), "Cc")
+        Xi = np.empty((nS, nR, n, nw), dtype=np.complex128)
+        rc = self.rlib.lib.raftx_solve_system(self._h, nS, nU, nR, nw, _ptr(w), _ptr(Zblk),
+                                              _ptr(Mc), _ptr(Bc), _ptr(Cc), _ptr(F), _ptr(Xi))
+        self._check(rc, "raftx_solve_system")
+        return Xi
+
+    def last_kernel_ms(self):
+        return float(self.rlib.lib.raftx_last_kernel_ms(self._h))

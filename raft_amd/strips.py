@@ -1,0 +1,235 @@
+"""Strip-table packer: the host-side feeder of the hot path.
+
+Walks a FOWT's ``memberList`` (the reference's objects, or any duck-typed
+stand-in exposing the same attributes) and emits one 32-double record per
+*submerged* Morison strip -- the "LDS-staged member geometry" the kernels
+consume -- plus the optional MacCamy-Fuchs complex Cm table.
+
+It restates, on the host, the per-strip constants of
+    raft/raft_member.py:1261-1368  Member.calcHydroConstants  (a_i, volumes)
+    raft/raft_member.py:1370-1448  Member.calcImat            (Imat scalars)
+    raft/raft_member.py:1451-1486  Member.getCmSides          (Cm, MCF ramp)
+    raft/raft_member.py:2058-2110  drag areas / coefficients of
+                                   Member.calcHydroLinearization
+and folds the member-node -> reduced-DOF map (raft/raft_fowt.py:1919-1929,
+node.T) into a single arm per strip, which is exact for rigid 6-DOF FOWTs
+(SURVEY.md Appendix A).
+
+Record layout (doubles; see include/raftx.h RAFTX_F_*):
+   0..2   x y z        absolute strip position (wave phase, depth decay)
+   3..5   ax ay az     arm from the reduced-DOF reference point
+   6..8   q            axial unit vector
+   9..11  p1           transverse unit vector 1
+  12..14  p2           transverse unit vector 2
+  15      Iq           rho*v_end*Ca_End
+  16      Ip1          rho*v_side*Cm_p1   (0 when the strip uses the MCF table)
+  17      Ip2          rho*v_side*Cm_p2   (0 when the strip uses the MCF table)
+  18      a_i          signed end area for the dynamic-pressure force
+  19..22  dq dp1 dp2 dEnd   sqrt(8/pi)*0.5*rho*area*Cd  (times vRMS on device)
+  23      circ         1.0 circular (total transverse vRMS), 0.0 rectangular
+  24      mcf          -1.0, or row index into the complex Cm table
+  25      rhoV         rho*v_side (multiplies the complex Cm of the MCF table)
+  26      member index (diagnostic)
+  27      strip index within member (diagnostic)
+  28..31  reserved (0)
+"""
+import numpy as np
+
+NFIELD = 32
+(F_X, F_Y, F_Z, F_AX, F_AY, F_AZ) = range(6)
+F_Q, F_P1, F_P2 = 6, 9, 12
+F_IQ, F_IP1, F_IP2, F_AI = 15, 16, 17, 18
+F_DQ, F_DP1, F_DP2, F_DEND = 19, 20, 21, 22
+F_CIRC, F_MCF, F_RHOV, F_MEM, F_IL = 23, 24, 25, 26, 27
+
+
+class UnsupportedFOWT(Exception):
+    """Raised when a FOWT is outside what the device path covers (flexible
+    members / more than 6 reduced DOFs); callers fall back loudly, never
+    silently."""
+
+
+def node_arm(T):
+    """Arm (r_node - rP) encoded in a rigid node's 6x6 map T (raft_node.py:262-290):
+    T = [[I, H(arm)], [0, I]] with H as raft/helpers.py:428-437."""
+    T = np.asarray(T, dtype=float)
+    if T.shape != (6, 6):
+        raise UnsupportedFOWT("node.T is %s, expected (6, 6): not a rigid 6-DOF FOWT" % (T.shape,))
+    I3 = np.eye(3)
+    if not (np.allclose(T[:3, :3], I3, atol=1e-12) and np.allclose(T[3:, 3:], I3, atol=1e-12)
+            and np.allclose(T[3:, :3], 0.0, atol=1e-12)):
+        raise UnsupportedFOWT("node.T is not a rigid-body translation map")
+    arm = np.array([T[1, 5], T[2, 3], T[0, 4]])
+    H = np.array([[0, arm[2], -arm[1]], [-arm[2], 0, arm[0]], [arm[1], -arm[0], 0]])
+    if not np.allclose(T[:3, 3:], H, atol=1e-9):
+        raise UnsupportedFOWT("node.T translation block is not an alternator matrix")
+    return arm
+
+
+def _interp(x, xp, fp):
+    return float(np.interp(x, xp, fp))
+
+
+def cm_sides(mem, il, k):
+    """Complex (Cm_p1, Cm_p2) of strip ``il`` at wave number ``k`` with the
+    MacCamy-Fuchs correction and its cosine ramp: raft_member.py:1459-1484."""
+    from scipy.special import hankel1
+    Ca_p1 = _interp(mem.ls[il], mem.stations, mem.Ca_p1)
+    Ca_p2 = _interp(mem.ls[il], mem.stations, mem.Ca_p2)
+    Cm1_0, Cm2_0 = 1.0 + Ca_p1, 1.0 + Ca_p2
+    R = mem.ds[il] / 2
+    Hp1 = 0.5 * (hankel1(0, k * R) - hankel1(2, k * R))
+    Cm = 4j / (np.pi * (k * R) ** 2 * Hp1)
+    Tr = np.pi / 5 / R
+    T0 = 0
+    ramp = 0.5 * (1 - np.cos(np.pi * (k - T0) / Tr)) if k < Tr else 1
+    ramp = 0 if k <= T0 else ramp
+    return Cm * ramp + Cm1_0 * (1 - ramp), Cm * ramp + Cm2_0 * (1 - ramp)
+
+
+def pack_member(mem, imem, rho, k_array=None, arm_node=None):
+    """Records for the submerged strips of one rigid member.
+
+    Returns (records [n,32], cm rows list of complex [2,nw])."""
+    if getattr(mem, "type", "rigid") != "rigid":
+        raise UnsupportedFOWT("member '%s' is type '%s' (only rigid members are on the device path)"
+                              % (getattr(mem, "name", "?"), mem.type))
+    circ = (mem.shape == "circular")
+    potMod = bool(getattr(mem, "potMod", False))
+    MCF = bool(getattr(mem, "MCF", False)) and circ and (k_array is not None)
+    node = mem.nodeList[0]
+    if arm_node is None:
+        arm_node = node_arm(node.T)
+    r_node = np.asarray(node.r, dtype=float)[:3]
+    q = np.asarray(mem.q, dtype=float)
+    p1 = np.asarray(mem.p1, dtype=float)
+    p2 = np.asarray(mem.p2, dtype=float)
+    c_drag = np.sqrt(8 / np.pi)
+
+    recs, cms = [], []
+    for il in range(mem.ns):
+        r = np.asarray(mem.r[il], dtype=float)
+        if not (r[2] < 0):                       # raft_member.py:1979,2058
+            continue
+        rec = np.zeros(NFIELD)
+        rec[F_X:F_X + 3] = r
+        rec[F_AX:F_AX + 3] = (r - r_node) + arm_node
+        rec[F_Q:F_Q + 3] = q
+        rec[F_P1:F_P1 + 3] = p1
+        rec[F_P2:F_P2 + 3] = p2
+        rec[F_CIRC] = 1.0 if circ else 0.0
+        rec[F_MCF] = -1.0
+        rec[F_MEM] = imem
+        rec[F_IL] = il
+        d = mem.ds[il]
+        dr = mem.drs[il]
+        dl = float(mem.dls[il])
+
+        # ---- inertial-excitation scalars (raft_member.py:1395-1448, :1340-1348)
+        if not potMod:
+            Ca_End = _interp(mem.ls[il], mem.stations, mem.Ca_End)
+            if circ:
+                v_i = 0.25 * np.pi * d ** 2 * dl
+            else:
+                v_i = d[0] * d[1] * dl
+            if r[2] + 0.5 * dl > 0:              # strip pierces the waterline
+                v_i = v_i * (0.5 * dl - r[2]) / dl
+            if circ:
+                v_end = np.pi / 12.0 * abs((d + dr) ** 3 - (d - dr) ** 3)
+                a_i = np.pi * d * dr
+            else:
+                v_end = np.pi / 12.0 * ((np.mean(d + dr)) ** 3 - (np.mean(d - dr)) ** 3)
+                a_i = ((d[0] + dr[0]) * (d[1] + dr[1]) - (d[0] - dr[0]) * (d[1] - dr[1]))
+            rec[F_IQ] = rho * v_end * Ca_End
+            rec[F_AI] = a_i
+            rec[F_RHOV] = rho * v_i
+            if MCF:
+                row = np.empty((2, len(k_array)), dtype=complex)
+                for ik, k in enumerate(k_array):
+                    row[0, ik], row[1, ik] = cm_sides(mem, il, k)
+                rec[F_MCF] = float(len(cms))
+                cms.append(row)
+            else:
+                Ca_p1 = _interp(mem.ls[il], mem.stations, mem.Ca_p1)
+                Ca_p2 = _interp(mem.ls[il], mem.stations, mem.Ca_p2)
+                rec[F_IP1] = rho * v_i * (1.0 + Ca_p1)
+                rec[F_IP2] = rho * v_i * (1.0 + Ca_p2)
+
+        # ---- drag scalars (raft_member.py:2061-2110); note the reference's
+        # rectangular axial area 2*(ds0+ds0)*dl (sic, :2070)
+        Cd_q = _interp(mem.ls[il], mem.stations, mem.Cd_q)
+        Cd_p1 = _interp(mem.ls[il], mem.stations, mem.Cd_p1)
+        Cd_p2 = _interp(mem.ls[il], mem.stations, mem.Cd_p2)
+        Cd_End = _interp(mem.ls[il], mem.stations, mem.Cd_End)
+        if circ:
+            a_q = np.pi * d * dl
+            a_p1 = d * dl
+            a_p2 = d * dl
+            a_end = abs(np.pi * d * dr)
+        else:
+            a_q = 2 * (d[0] + d[0]) * dl
+            a_p1 = d[0] * dl
+            a_p2 = d[1] * dl
+            a_end = abs((d[0] + dr[0]) * (d[1] + dr[1]) - (d[0] - dr[0]) * (d[1] - dr[1]))
+        rec[F_DQ] = c_drag * 0.5 * rho * a_q * Cd_q
+        rec[F_DP1] = c_drag * 0.5 * rho * a_p1 * Cd_p1
+        rec[F_DP2] = c_drag * 0.5 * rho * a_p2 * Cd_p2
+        rec[F_DEND] = c_drag * 0.5 * rho * a_end * Cd_End
+        recs.append(rec)
+    if recs:
+        return np.array(recs), cms
+    return np.zeros((0, NFIELD)), cms
+
+
+class StripTable:
+    """Packed submerged strips of one FOWT ("design")."""
+
+    def __init__(self, strips, cm_mcf=None):
+        self.strips = np.ascontiguousarray(strips, dtype=np.float64).reshape(-1, NFIELD)
+        self.cm_mcf = None if cm_mcf is None or len(cm_mcf) == 0 else \
+            np.ascontiguousarray(cm_mcf, dtype=np.complex128)
+
+    @property
+    def n(self):
+        return self.strips.shape[0]
+
+
+def pack_fowt(fowt, memberList=None):
+    """StripTable for a rigid 6-DOF FOWT (reference object or stand-in)."""
+    if int(getattr(fowt, "nDOF", 6)) != 6:
+        raise UnsupportedFOWT("FOWT has %d reduced DOFs; the device path covers rigid 6-DOF units"
+                              % fowt.nDOF)
+    members = fowt.memberList if memberList is None else memberList
+    rho = float(fowt.rho_water)
+    recs, cms = [], []
+    for imem, mem in enumerate(members):
+        k_array = np.asarray(fowt.k, dtype=float) if getattr(mem, "MCF", False) else None
+        r, c = pack_member(mem, imem, rho, k_array=k_array)
+        if len(c):
+            r = r.copy()
+            sel = r[:, F_MCF] >= 0
+            r[sel, F_MCF] += len(cms)
+            cms.extend(c)
+        recs.append(r)
+    strips = np.concatenate(recs, axis=0) if recs else np.zeros((0, NFIELD))
+    return StripTable(strips, np.array(cms) if cms else None)
+
+
+def added_mass_morison(strips):
+    """A_hydro_morison [6,6] from a strip table -- raft_member.py:1333-1361 and
+    raft/helpers.py:537-560 (translateMatrix3to6DOF), in the folded frame.
+    Only valid for non-MCF tables when used to cross-check Ca (Cm-1)."""
+    A = np.zeros((6, 6))
+    for rec in strips:
+        q, p1, p2 = rec[F_Q:F_Q + 3], rec[F_P1:F_P1 + 3], rec[F_P2:F_P2 + 3]
+        rhoV = rec[F_RHOV]
+        ca1 = rec[F_IP1] - rhoV
+        ca2 = rec[F_IP2] - rhoV
+        Amat = ca1 * np.outer(p1, p1) + ca2 * np.outer(p2, p2) + rec[F_IQ] * np.outer(q, q)
+        a = rec[F_AX:F_AX + 3]
+        H = np.array([[0, a[2], -a[1]], [-a[2], 0, a[0]], [a[1], -a[0], 0]])
+        A[:3, :3] += Amat
+        A[:3, 3:] += Amat @ H
+        A[3:, :3] += (Amat @ H).T
+        A[3:, 3:] += H @ Amat @ H.T
+    return A

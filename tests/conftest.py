@@ -1,0 +1,51 @@
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+ORACLE_SO = os.path.join(ROOT, "oracle", "libraftx_oracle.so")
+HIP_SO = os.path.join(ROOT, "raft_amd", "csrc", "libraftx_hip.so")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+def _build_oracle():
+    src = os.path.join(ROOT, "oracle", "raftx_oracle.c")
+    if (not os.path.exists(ORACLE_SO)) or os.path.getmtime(ORACLE_SO) < os.path.getmtime(src):
+        subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle")], stdout=subprocess.DEVNULL)
+    return ORACLE_SO
+
+
+@pytest.fixture(scope="session")
+def oracle_lib():
+    """The CPU oracle bound through the same ctypes class as the product."""
+    from raft_amd._abi import RaftxLib
+    return RaftxLib(_build_oracle())
+
+
+@pytest.fixture()
+def oracle_ctx(oracle_lib):
+    ctx = oracle_lib.context(0)
+    yield ctx
+    ctx.close()
+
+
+@pytest.fixture(scope="session")
+def hip_lib():
+    """The product library; GPU tests fail (not skip) if it is missing."""
+    from raft_amd import backend
+    return backend.hip_library()
+
+
+@pytest.fixture()
+def hip_ctx(hip_lib):
+    ctx = hip_lib.context(0)
+    yield ctx
+    ctx.close()

@@ -1,0 +1,75 @@
+"""CPU suite: pins the oracle (oracle/raftx_oracle.c) -- driven through the
+product's own host layer (raft_amd.dropin / strips / waves) -- against
+
+  * the reference's OWN golden vectors for this path
+    (tests/test_fowt.py:111-175 pickles, converted by oracle/make_golden.py), and
+  * live-reference Model.solveDynamics outputs committed under tests/golden/.
+
+Tolerances: the reference's tests use rtol 1e-5; we hold 1e-9 against goldens
+and 1e-10 (group-relative) against the live reference vectors.
+"""
+import numpy as np
+import pytest
+
+from raft_amd import dropin
+from tests.util import group_rel_err, rel_err, case_from_fixture, load_model_fixture
+
+REFGOLD = ["refgold_OC3spar.npz", "refgold_VolturnUS-S.npz", "refgold_VolturnUS-S-pointInertia.npz"]
+
+
+@pytest.mark.parametrize("name", REFGOLD)
+def test_reference_golden_hydroExcitation(name, oracle_ctx):
+    """72 cases: headings 0..360 step 45, T in {5,10,15,20}, H in {1,2}."""
+    fx, model = load_model_fixture(name)
+    eng = dropin.Engine(oracle_ctx)
+    fowt = model.fowtList[0]
+    assert len(fx["exc_cases"]) == 72
+    worst = 0.0
+    for i, c in enumerate(fx["exc_cases"]):
+        eng.calcHydroExcitation(fowt, dict(c), memberList=fowt.memberList)
+        true = fx["exc_F_hydro_iner"][i]
+        np.testing.assert_allclose(fowt.F_hydro_iner, true, rtol=1e-5, atol=1e-3)   # the reference's own gate
+        worst = max(worst, rel_err(fowt.F_hydro_iner, true))
+    assert worst < 1e-9, worst
+
+
+@pytest.mark.parametrize("name", REFGOLD)
+def test_reference_golden_hydroLinearization(name, oracle_ctx):
+    fx, model = load_model_fixture(name)
+    eng = dropin.Engine(oracle_ctx)
+    fowt = model.fowtList[0]
+    case = {'wave_spectrum': 'unit', 'wave_heading': 0, 'wave_period': 10, 'wave_height': 2}
+    eng.calcHydroExcitation(fowt, case, memberList=fowt.memberList)
+    phase = np.linspace(0, 2 * np.pi, fowt.nw * fowt.nDOF).reshape(fowt.nDOF, fowt.nw)
+    Xi = 0.1 * np.exp(1j * phase)
+    B = eng.calcHydroLinearization(fowt, Xi)
+    F = eng.calcDragExcitation(fowt, 0)
+    np.testing.assert_allclose(B, fx["lin_B_hydro_drag"], rtol=1e-5, atol=1e-10)     # reference's gate
+    np.testing.assert_allclose(F, fx["lin_F_hydro_drag"], rtol=1e-5)
+    assert rel_err(B, fx["lin_B_hydro_drag"]) < 1e-9
+    assert rel_err(F, fx["lin_F_hydro_drag"]) < 1e-9
+
+
+@pytest.mark.parametrize("name", ["c1_oc3spar.npz", "c2_volturnus.npz", "pose_volturnus_mcf.npz", "c4_farm.npz"])
+def test_live_reference_solveDynamics(name, oracle_ctx):
+    fx, model = load_model_fixture(name)
+    if "coupling_C" in fx:
+        class _MS:
+            def getCoupledStiffnessA(self, lines_only=True):
+                return fx["coupling_C"]
+        model.ms = _MS()
+        model.moorMod = 0
+    eng = dropin.Engine(oracle_ctx)
+    for c in fx["cases"]:
+        Xi = eng.solveDynamics(model, case_from_fixture(c))
+        assert Xi.shape == c["Xi"].shape
+        nH = Xi.shape[0] - 1
+        assert np.all(Xi[nH] == 0)                                   # rotor-excitation row stays zero
+        assert group_rel_err(Xi[:nH], c["Xi"][:nH]) < 1e-10
+        for i, fowt in enumerate(model.fowtList):
+            u = c["units"][i]
+            assert int(model._raftx_niter[i]) == int(u["niter"])
+            assert rel_err(fowt.Z, u["Z"]) < 1e-12
+            assert rel_err(fowt.F_hydro_iner, u["F_hydro_iner"]) < 1e-12
+            assert rel_err(fowt.B_hydro_drag, u["B_hydro_drag"]) < 1e-10
+            assert rel_err(fowt.zeta, u["zeta"]) < 1e-14
