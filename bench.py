@@ -1,0 +1,200 @@
+#!/usr/bin/env python
+"""bench.py -- design-case-frequency (dcf) solves / second on MI355X.
+
+Workload (BASELINE.json configs[2], the one the north-star target is quoted
+on): a VolturnUS-S geometry sweep, nDesign designs x 1 sea state (JONSWAP
+Hs 6 m, Tp 12 s, head seas) x 200 frequency bins, nIter=4 (5 fixed-point
+iterations), all fp64.  A "step" is one pass of the whole hot path
+(raftx_solve_dynamics_device: strip sweep + drag-linearisation fixed point +
+per-bin 6x6 complex solves) over every design of this rank; inputs are resident
+in HBM before the timed region starts and the responses stay in HBM.
+
+Multi-GPU: one process per GPU (torch.distributed / RCCL is plumbing only:
+barrier + max-over-ranks of the timing + result checksums).  Designs are
+independent, so ranks shard them with no data-path collective -> weak scaling
+(nDesign per rank is fixed).
+
+Prints ONE JSON line (rank 0).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8 TB/s spec
+FP64_VALU_PEAK_TF = 78.6       # MI355X vector fp64 peak
+
+
+def load_sweep(n_design, rank=0):
+    """Strip tables / matrices of the sweep.  The GPU box has no reference
+    tree, so the designs come from the committed C3 sample
+    (tests/golden/c3_variants.npz: 64 true parametersweep variants built by
+    the live reference) tiled round-robin, each rank starting at a different
+    offset."""
+    from tests import standin
+    fx = standin.load_fixture("c3_variants.npz")
+    off = fx["strip_offsets"]
+    nV = len(off) - 1
+    idx = (np.arange(n_design) + rank * 7) % nV
+    counts = (off[1:] - off[:-1])[idx]
+    new_off = np.concatenate([[0], np.cumsum(counts)]).astype(np.int64)
+    strips = np.concatenate([fx["strips"][off[i]:off[i + 1]] for i in idx], axis=0)
+    return dict(off=new_off, strips=strips, M0=fx["M0"][idx], B0=fx["B0"][idx], C0=fx["C0"][idx],
+                w=fx["w"], k=fx["k"], depth=fx["depth"], zeta=fx["zeta"], beta=fx["beta"],
+                nIter=int(fx["nIter"]), XiStart=float(fx["XiStart"]), idx=idx, fx=fx)
+
+
+def algorithmic_bytes(sw):
+    """A_min = 256*S + 3*288 + 8*nw + 96*nw per (design, case)."""
+    nw = len(sw["w"])
+    S = (sw["off"][1:] - sw["off"][:-1]).astype(np.float64)
+    return float(np.sum(256.0 * S + 864.0 + 104.0 * nw))
+
+
+def algorithmic_flops(sw, niter):
+    """N_it*(175*S + 2000) + 160*S fp64 flops per dcf (transcendentals not counted)."""
+    nw = len(sw["w"])
+    S = (sw["off"][1:] - sw["off"][:-1]).astype(np.float64)
+    return float(np.sum(niter.reshape(-1) * (175.0 * S + 2000.0) + 160.0 * S) * nw)
+
+
+def cpu_baseline(sw, seconds_target=12.0):
+    """The oracle (oracle/raftx_oracle.c, kind="port") timed on this host's
+    cores on a bounded sample of the same workload."""
+    import subprocess
+    from raft_amd._abi import RaftxLib
+    so = os.path.join(ROOT, "oracle", "libraftx_oracle.so")
+    if not os.path.exists(so):
+        subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle")], stdout=subprocess.DEVNULL)
+    lib = RaftxLib(so)
+    lib.lib.raftx_oracle_threads.restype = int
+    threads = int(lib.lib.raftx_oracle_threads())
+    nw = len(sw["w"])
+
+    def run(n):
+        ctx = lib.context(0)
+        ctx.upload_designs_raw(sw["off"][:n + 1], sw["strips"][:sw["off"][n]], sw["M0"][:n], sw["B0"][:n],
+                               sw["C0"][:n], nw)
+        ctx.upload_cases(sw["w"], sw["k"], sw["depth"], 1025.0, 9.81, sw["zeta"][None], sw["beta"][None])
+        t0 = time.perf_counter()
+        ctx.solve_dynamics_device(sw["nIter"], 0.01, sw["XiStart"])
+        dt = time.perf_counter() - t0
+        ctx.close()
+        return dt
+
+    n0 = min(len(sw["off"]) - 1, max(threads, 8))
+    dt0 = run(n0)
+    n = int(min(len(sw["off"]) - 1, max(n0, n0 * seconds_target / max(dt0, 1e-3))))
+    dt = run(n)
+    return {"value": n * nw / dt, "unit": "dcf solves/s", "cores": threads, "kind": "port",
+            "sample": "%d of the sweep's designs x 1 sea state x %d bins, oracle/raftx_oracle.c (OpenMP, %d threads), %.1f s"
+                      % (n, nw, threads, dt)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--designs", type=int, default=10000, help="designs per GPU (weak scaling)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    dist = None
+    if world > 1:
+        import torch
+        import torch.distributed as dist
+        torch.cuda.set_device(local)
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local))
+
+    from raft_amd import backend
+    ctx = backend.hip_library().context(local)
+
+    sw = load_sweep(args.designs, rank)
+    nw = len(sw["w"])
+    ctx.upload_designs_raw(sw["off"], sw["strips"], sw["M0"], sw["B0"], sw["C0"], nw)
+    ctx.upload_cases(sw["w"], sw["k"], sw["depth"], 1025.0, 9.81, sw["zeta"][None], sw["beta"][None])
+
+    def barrier():
+        if dist is not None:
+            import torch
+            torch.cuda.synchronize()
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        ctx.solve_dynamics_device(sw["nIter"], 0.01, sw["XiStart"])
+    barrier()
+    t0 = time.perf_counter()
+    kern_ms = []
+    for _ in range(args.steps):
+        ctx.solve_dynamics_device(sw["nIter"], 0.01, sw["XiStart"])      # synchronous: returns after the stream drains
+        kern_ms.append(ctx.last_kernel_ms())                             # HIP events on the ctx stream
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        import torch
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    # correctness spot check of what was just timed (outside the timed region)
+    res = ctx.fetch_results(want_Xi=True)
+    niter = res["niter"]
+    nan = int(np.count_nonzero(res["flags"] & 2))
+    from tests.util import group_rel_err
+    errs = []
+    for j, sol in enumerate(sw["fx"]["solved"]):
+        hits = np.nonzero(sw["idx"] == j)[0]
+        if len(hits):
+            errs.append(group_rel_err(res["Xi"][hits[0], 0, :1], sol["Xi"][:1]))
+            assert int(niter[hits[0], 0]) == int(sol["units"][0]["niter"]), "iteration count differs from the reference"
+    max_err = float(max(errs)) if errs else None
+    assert nan == 0 and (max_err is None or max_err < 1e-6), "bench results fail parity (err=%r, nan=%d)" % (max_err, nan)
+
+    n_dcf_rank = args.designs * 1 * nw
+    total_dcf = n_dcf_rank * world * args.steps
+    value = total_dcf / elapsed
+    k_ms = float(np.mean(kern_ms))
+    A = algorithmic_bytes(sw)
+    flops = algorithmic_flops(sw, niter)
+    out = {
+        "metric": "design-case-frequency solves/sec (whole node)",
+        "value": value, "unit": "dcf solves/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": 1e3 * elapsed / args.steps,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f64", "data": "synthetic",
+        "config": {"workload": "C3 VolturnUS-S parameter sweep: %d designs/GPU x 1 sea state (JONSWAP Hs6 Tp12, 0 deg) x %d bins, "
+                               "nIter=4, tol=0.01; designs = 64 reference-built sweep variants tiled" % (args.designs, nw),
+                   "designs_per_gpu": args.designs, "cases": 1, "nw": nw, "sharding": "designs over ranks, no collective"},
+        "rao_max_rel_err_vs_reference": max_err,
+        "mean_iterations": float(np.mean(niter)),
+        "roofline": {"bound": "hbm", "achieved": A / (k_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": A / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None,
+                     "kernel": "k_solve_dynamics", "kernel_ms": k_ms, "algorithmic_bytes_per_launch": A,
+                     "note": "fused kernel is fp64-VALU-bound (SURVEY.md 8d): see roofline_fp64_valu"},
+        "roofline_fp64_valu": {"achieved": flops / (k_ms * 1e-3) / 1e12, "peak": FP64_VALU_PEAK_TF, "unit": "TFLOP/s",
+                               "frac": flops / (k_ms * 1e-3) / 1e12 / FP64_VALU_PEAK_TF,
+                               "algorithmic_flops_per_launch": flops},
+    }
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(sw)
+    if rank == 0:
+        print(json.dumps(out))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

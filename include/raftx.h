@@ -120,6 +120,20 @@ int raftx_solve_dynamics(raftx_ctx *ctx, int nIter, double tol, double XiStart,
                          raftx_c128 *Xi, int32_t *niter, int32_t *flags,
                          double *B_drag, raftx_c128 *F_wave, raftx_c128 *Z);
 
+/* Device-resident form of raftx_solve_dynamics for sweeps: identical maths,
+ * but every output stays in ctx-owned HBM buffers (no D2H inside the call), so
+ * a 10k-design batch is one kernel launch.  want_mask selects the optional
+ * outputs to keep (RAFTX_WANT_*; Xi/niter/flags are always kept).  F_extra, if
+ * given, is a host buffer uploaded before the launch.  Results are copied out
+ * on demand with raftx_fetch_results (any pointer may be NULL). */
+#define RAFTX_WANT_BDRAG 1
+#define RAFTX_WANT_FWAVE 2
+#define RAFTX_WANT_Z     4
+int raftx_solve_dynamics_device(raftx_ctx *ctx, int nIter, double tol, double XiStart,
+                                const raftx_c128 *F_extra, int want_mask);
+int raftx_fetch_results(raftx_ctx *ctx, raftx_c128 *Xi, int32_t *niter, int32_t *flags,
+                        double *B_drag, raftx_c128 *F_wave, raftx_c128 *Z);
+
 /* Coupled array solve, raft_model.py:1164-1236: for each system s and bin w
  *   Z_sys = blockdiag_i(Zblk[s,i]) + (-w^2 Mc[s] + i w Bc[s] + Cc[s]);
  *   Xi[s,r] = Z_sys^-1 F[s,r].

@@ -167,8 +167,69 @@ def fixture_c4():
     standin.save_fixture(os.path.join(GOLD, "c4_farm.npz"), fx)
 
 
+def volturnus_variant(design, scales):
+    """C3 sweep variant: the five parameters of
+    raft/parametersweep.py:33-37 (centre-column d, outer-column d, draft,
+    outer-column radius, pontoon height) times ``scales``, with the dependent
+    geometry edits of :56-87 applied consistently."""
+    d = copy.deepcopy(design)
+    mem = d["platform"]["members"]
+    s_cc, s_oc, s_T, s_R, s_pH = [float(x) for x in scales]
+    ccD, ocD, T, ocR, pH = 10.0 * s_cc, 12.5 * s_oc, -20.0 * s_T, 51.75 * s_R, 7.0 * s_pH
+    mem[0]["d"] = ccD
+    mem[0]["rA"] = [0, 0, T]
+    mem[1]["d"] = ocD
+    mem[1]["rA"] = [ocR, 0, T]
+    mem[1]["rB"] = [ocR, 0, 15]
+    mem[2]["rA"] = [ccD / 2, 0, T + pH / 2]
+    mem[2]["rB"] = [ocR - ocD / 2, 0, T + pH / 2]
+    mem[2]["d"] = [12.4, pH]
+    mem[3]["rA"] = [ccD / 2, 0, 14.545]
+    mem[3]["rB"] = [ocR - ocD / 2, 0, 14.545]
+    return d
+
+
+def fixture_c3(n_variants=64, n_solved=8):
+    """C3 sample: packed strip tables + system matrices of n_variants sweep
+    points (default_rng(0), U[0.75,1.25]), reference solveDynamics for the first
+    n_solved.  bench.py tiles these to the 10k-design sweep on the GPU box."""
+    from raft_amd.strips import pack_fowt
+    base = rh.load_design(os.path.join(REF, "examples/VolturnUS-S_example.yaml"))
+    base = rh.prepare_design(base)
+    rng = np.random.default_rng(0)
+    scales = rng.uniform(0.75, 1.25, size=(n_variants, 5))
+    case = rh.make_case(Hs=6.0, Tp=12.0, heading=0.0)
+    tabs, M0, B0, C0, sols = [], [], [], [], []
+    model0 = None
+    for i in range(n_variants):
+        m = rh.build_model(volturnus_variant(base, scales[i]))
+        f = m.fowtList[0]
+        if i < n_solved:
+            sols.append(run_case(m, case))
+        else:
+            f.calcHydroExcitation(copy.deepcopy(case), memberList=f.memberList)   # sets zeta/beta only
+        t = pack_fowt(f)
+        assert t.cm_mcf is None
+        tabs.append(t.strips)
+        M0.append(f.M_struc + f.A_hydro_morison)
+        B0.append(f.B_struc + np.sum(f.B_gyro, axis=2))
+        C0.append(f.C_struc + f.C_hydro + f.C_moor + f.C_elast)
+        if model0 is None:
+            model0 = m
+            zeta, beta = np.array(f.zeta), np.array(f.beta)
+    f0 = model0.fowtList[0]
+    off = np.concatenate([[0], np.cumsum([len(t) for t in tabs])]).astype(np.int64)
+    fx = {"config": "C3 VolturnUS-S sweep sample (%d variants, default_rng(0), U[0.75,1.25])" % n_variants,
+          "scales": scales, "strip_offsets": off, "strips": np.concatenate(tabs, axis=0),
+          "M0": np.array(M0), "B0": np.array(B0), "C0": np.array(C0),
+          "w": np.array(f0.w), "k": np.array(f0.k), "depth": float(f0.depth),
+          "zeta": zeta, "beta": beta, "nIter": int(model0.nIter), "XiStart": float(model0.XiStart),
+          "solved": sols}
+    standin.save_fixture(os.path.join(GOLD, "c3_variants.npz"), fx)
+
+
 ALL = {"c1": fixture_c1, "c2": fixture_c2, "pose": fixture_pose,
-       "refgold": fixture_ref_goldens, "c4": fixture_c4}
+       "refgold": fixture_ref_goldens, "c4": fixture_c4, "c3": fixture_c3}
 
 if __name__ == "__main__":
     names = sys.argv[1:] or list(ALL)

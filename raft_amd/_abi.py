@@ -24,7 +24,9 @@ EXPORTS = (
     "raftx_last_error", "raftx_upload_designs", "raftx_upload_cases",
     "raftx_excitation", "raftx_linearize", "raftx_solve_dynamics",
     "raftx_solve_system", "raftx_last_kernel_ms",
+    "raftx_solve_dynamics_device", "raftx_fetch_results",
 )
+WANT_BDRAG, WANT_FWAVE, WANT_Z = 1, 2, 4
 
 
 class RaftxError(RuntimeError):
@@ -83,6 +85,10 @@ class RaftxLib:
         L.raftx_solve_system.argtypes = [_vp, C.c_int, C.c_int, C.c_int, C.c_int, _vp, _vp,
                                          _vp, _vp, _vp, _vp, _vp]
         L.raftx_solve_system.restype = C.c_int
+        L.raftx_solve_dynamics_device.argtypes = [_vp, C.c_int, C.c_double, C.c_double, _vp, C.c_int]
+        L.raftx_solve_dynamics_device.restype = C.c_int
+        L.raftx_fetch_results.argtypes = [_vp, _vp, _vp, _vp, _vp, _vp, _vp]
+        L.raftx_fetch_results.restype = C.c_int
         L.raftx_last_kernel_ms.argtypes = [_vp]
         L.raftx_last_kernel_ms.restype = C.c_double
 
@@ -215,6 +221,26 @@ class Context:
         self._check(rc, "raftx_solve_dynamics")
         out.update(Xi=Xi, niter=niter, flags=flags, B_drag=B, F_wave=F, Z=Z)
         return out
+
+    def solve_dynamics_device(self, nIter, tol=0.01, XiStart=0.1, F_extra=None, want_mask=0):
+        """Launch only; results stay in HBM (see fetch_results)."""
+        if F_extra is not None:
+            F_extra = _c128(F_extra, (self.nDesign, self.nCase, self.nHead, 6, self.nw), "F_extra")
+        rc = self.rlib.lib.raftx_solve_dynamics_device(self._h, int(nIter), float(tol), float(XiStart),
+                                                       _ptr(F_extra), int(want_mask))
+        self._check(rc, "raftx_solve_dynamics_device")
+
+    def fetch_results(self, want_Xi=True, want_B=False, want_F=False, want_Z=False):
+        nD, nC, nH, nw = self.nDesign, self.nCase, self.nHead, self.nw
+        Xi = np.empty((nD, nC, nH, 6, nw), dtype=np.complex128) if want_Xi else None
+        niter = np.zeros((nD, nC), dtype=np.int32)
+        flags = np.zeros((nD, nC), dtype=np.int32)
+        B = np.empty((nD, nC, 6, 6), dtype=np.float64) if want_B else None
+        F = np.empty((nD, nC, nH, 6, nw), dtype=np.complex128) if want_F else None
+        Z = np.empty((nD, nC, 6, 6, nw), dtype=np.complex128) if want_Z else None
+        rc = self.rlib.lib.raftx_fetch_results(self._h, _ptr(Xi), _ptr(niter), _ptr(flags), _ptr(B), _ptr(F), _ptr(Z))
+        self._check(rc, "raftx_fetch_results")
+        return dict(Xi=Xi, niter=niter, flags=flags, B_drag=B, F_wave=F, Z=Z)
 
     def solve_system(self, w, Zblk, F, Mc=None, Bc=None, Cc=None):
         Zblk = _c128(Zblk)

@@ -39,3 +39,71 @@ def case_from_fixture(c):
 def load_model_fixture(name):
     fx = standin.load_fixture(name)
     return fx, standin.build_model(fx["model"])
+
+
+# ------------------------------------------------------------------ synthetic inputs
+def random_strips(rng, S, nw=0, mcf_frac=0.0):
+    """Seeded synthetic strip table: random orthonormal triads, mixed
+    circular/rectangular strips, realistic magnitudes."""
+    from raft_amd.strips import StripTable, NFIELD
+    from raft_amd import strips as st
+    rec = np.zeros((S, NFIELD))
+    cms = []
+    for s in range(S):
+        A = rng.normal(size=(3, 3))
+        Q, _ = np.linalg.qr(A)
+        if np.linalg.det(Q) < 0:
+            Q[:, 2] *= -1
+        r = np.array([rng.uniform(-40, 40), rng.uniform(-40, 40), rng.uniform(-30, -0.3)])
+        rec[s, st.F_X:st.F_X + 3] = r
+        rec[s, st.F_AX:st.F_AX + 3] = r - np.array([1.0, -2.0, 0.5])
+        rec[s, st.F_Q:st.F_Q + 3] = Q[:, 0]
+        rec[s, st.F_P1:st.F_P1 + 3] = Q[:, 1]
+        rec[s, st.F_P2:st.F_P2 + 3] = Q[:, 2]
+        rho_v = rng.uniform(1e4, 4e5)
+        rec[s, st.F_IQ] = rng.uniform(0, 1e5)
+        rec[s, st.F_IP1] = rho_v * rng.uniform(1.5, 2.0)
+        rec[s, st.F_IP2] = rho_v * rng.uniform(1.5, 2.0)
+        rec[s, st.F_AI] = rng.uniform(-30, 30)
+        rec[s, st.F_DQ:st.F_DEND + 1] = rng.uniform(0, 4e4, size=4)
+        rec[s, st.F_CIRC] = float(rng.integers(0, 2))
+        rec[s, st.F_MCF] = -1.0
+        rec[s, st.F_RHOV] = rho_v
+        if nw and rng.uniform() < mcf_frac:
+            rec[s, st.F_MCF] = float(len(cms))
+            rec[s, st.F_IP1] = rec[s, st.F_IP2] = 0.0
+            cms.append((rng.uniform(1.2, 2.2, size=(2, nw)) + 1j * rng.uniform(-0.5, 0.5, size=(2, nw))))
+    return StripTable(rec, np.array(cms) if cms else None)
+
+
+def random_matrices(rng, nD, nw=0, freq_dep=False):
+    M0 = np.zeros((nD, 6, 6))
+    B0 = np.zeros((nD, 6, 6))
+    C0 = np.zeros((nD, 6, 6))
+    for d in range(nD):
+        m = rng.uniform(1.5e7, 3e7)
+        M0[d] = np.diag([m, m, m, m * 1500, m * 1500, m * 900])
+        M0[d, 0, 4] = M0[d, 4, 0] = -m * 8.0
+        M0[d, 1, 3] = M0[d, 3, 1] = m * 8.0
+        B0[d] = np.diag(rng.uniform(1e4, 1e5, size=6)) * np.array([1, 1, 1, 1e3, 1e3, 1e3])
+        B0[d, 3, 4], B0[d, 4, 3] = 2e6, -2e6            # gyroscopic-like antisymmetric part
+        C0[d] = np.diag([7e4, 7e4, 4e6, 2e9, 2e9, 1e8]) * rng.uniform(0.8, 1.2)
+        C0[d, 2, 4] = C0[d, 4, 2] = 1e5
+    MBw = None
+    if freq_dep:
+        MBw = rng.uniform(0, 1, size=(nD, 2, 6, 6, nw)) * np.array([1e5, 1e4])[None, :, None, None, None]
+    return M0, B0, C0, MBw
+
+
+def synthetic_cases(rng, nC, nH, nw, depth=200.0, wmin=0.05, wmax=2.0):
+    from raft_amd import waves
+    w = np.linspace(wmin, wmax, nw) if nw > 1 else np.array([0.7])
+    k = np.array([waves.wave_number(x, depth) for x in w])
+    dw = (w[1] - w[0]) if nw > 1 else 0.1
+    zeta = np.zeros((nC, nH, nw))
+    beta = rng.uniform(0, 2 * np.pi, size=(nC, nH))
+    for c in range(nC):
+        for h in range(nH):
+            S = waves.jonswap(w, rng.uniform(1, 10), rng.uniform(6, 16))
+            zeta[c, h] = np.sqrt(2 * S * dw)
+    return w, k, zeta, beta
