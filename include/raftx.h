@@ -54,6 +54,11 @@ extern "C" {
 #define RAFTX_F_CIRC  23  /* 1 circular, 0 rectangular     (raft_member.py:2085-2090) */
 #define RAFTX_F_MCF   24  /* -1, or row in the complex Cm table (raft_member.py:1984-1985) */
 #define RAFTX_F_RHOV  25  /* rho*v_side (times complex Cm when MCF) */
+/* 26,27: member / strip indices (diagnostic).  28,29: optional run hints for the device
+ * kinematics: strip = previous strip + STEP*UNIT*q (STEP in 1..4; 0 = start of a run,
+ * evaluated exactly).  Verified against x,y,z at upload; the oracle ignores them. */
+#define RAFTX_F_STEP  28
+#define RAFTX_F_UNIT  29
 
 /* flags[] bits written by raftx_solve_dynamics */
 #define RAFTX_FLAG_CONVERGED 1    /* raft_model.py:1104 test passed */
@@ -149,6 +154,10 @@ int raftx_solve_system(raftx_ctx *ctx, int nSys, int nUnit, int nRhs, int nw,
  * ctx, measured with HIP events on the ctx's own stream (excludes H2D/D2H).
  * The oracle returns host wall time of the compute loop. */
 double raftx_last_kernel_ms(raftx_ctx *ctx);
+
+/* Diagnostics: evaluates the device's own fp64 sincos/exp on n host values (the
+ * oracle answers with libm), so the elementary functions are testable alone. */
+int raftx_debug_math(raftx_ctx *ctx, int n, const double *x, double *sin_out, double *cos_out, double *exp_out);
 
 #ifdef __cplusplus
 }

@@ -24,7 +24,7 @@ EXPORTS = (
     "raftx_last_error", "raftx_upload_designs", "raftx_upload_cases",
     "raftx_excitation", "raftx_linearize", "raftx_solve_dynamics",
     "raftx_solve_system", "raftx_last_kernel_ms",
-    "raftx_solve_dynamics_device", "raftx_fetch_results",
+    "raftx_solve_dynamics_device", "raftx_fetch_results", "raftx_debug_math",
 )
 WANT_BDRAG, WANT_FWAVE, WANT_Z = 1, 2, 4
 
@@ -89,6 +89,8 @@ class RaftxLib:
         L.raftx_solve_dynamics_device.restype = C.c_int
         L.raftx_fetch_results.argtypes = [_vp, _vp, _vp, _vp, _vp, _vp, _vp]
         L.raftx_fetch_results.restype = C.c_int
+        L.raftx_debug_math.argtypes = [_vp, C.c_int, _vp, _vp, _vp, _vp]
+        L.raftx_debug_math.restype = C.c_int
         L.raftx_last_kernel_ms.argtypes = [_vp]
         L.raftx_last_kernel_ms.restype = C.c_double
 
@@ -260,6 +262,13 @@ class Context:
                                               _ptr(Mc), _ptr(Bc), _ptr(Cc), _ptr(F), _ptr(Xi))
         self._check(rc, "raftx_solve_system")
         return Xi
+
+    def debug_math(self, x):
+        x = _f64(x).ravel()
+        s, c, e = np.empty_like(x), np.empty_like(x), np.empty_like(x)
+        rc = self.rlib.lib.raftx_debug_math(self._h, len(x), _ptr(x), _ptr(s), _ptr(c), _ptr(e))
+        self._check(rc, "raftx_debug_math")
+        return s, c, e
 
     def last_kernel_ms(self):
         return float(self.rlib.lib.raftx_last_kernel_ms(self._h))

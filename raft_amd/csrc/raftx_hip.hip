@@ -9,12 +9,12 @@
 // Mapping:
 //   * frequency is the contiguous axis of every reference array, so lane <-> w
 //     makes every global load/store of a [6,nw] / [6,6,nw] slab coalesced;
-//   * strip records (256 B each) are wave-uniform: they are read through the
-//     scalar cache / LDS, never per lane;
+//   * strip records (256 B each) are wave-uniform: they are staged once per
+//     workgroup into LDS and read as broadcasts, never per lane from HBM;
 //   * the only cross-frequency couplings -- the per-strip vRMS sums
 //     (raft_member.py:2084-2090, helpers.py:684) and the convergence test
-//     (raft_model.py:1104) -- are wave shuffles + a few LDS words inside one
-//     workgroup; nothing crosses workgroups or devices;
+//     (raft_model.py:1104) -- go through per-wave LDS transposition tiles
+//     inside one workgroup; nothing crosses workgroups or devices;
 //   * the 6x6 complex impedance is factorised per lane in registers with
 //     LAPACK-style partial pivoting (pivot on |re|+|im|, as izamax).
 //
@@ -31,650 +31,7 @@
 
 #include "../../include/raftx.h"
 
-#define NF RAFTX_NFIELD
-#define BLOCK 256
-#define NWAVE (BLOCK / 64)
-
-struct cplx {
-    double re, im;
-};
-__device__ __forceinline__ cplx cmul(cplx a, cplx b) { return {a.re * b.re - a.im * b.im, a.re * b.im + a.im * b.re}; }
-__device__ __forceinline__ cplx cscale(cplx a, double s) { return {a.re * s, a.im * s}; }
-__device__ __forceinline__ cplx cadd(cplx a, cplx b) { return {a.re + b.re, a.im + b.im}; }
-__device__ __forceinline__ cplx csub(cplx a, cplx b) { return {a.re - b.re, a.im - b.im}; }
-__device__ __forceinline__ double cabs2(cplx a) { return a.re * a.re + a.im * a.im; }
-
-// ------------------------------------------------------------------ device tables
-struct DevTables {
-    // designs
-    int nDesign;
-    const int64_t *off;     // [nDesign+1]
-    const double *strips;   // [nStrips,32]
-    const double *M0, *B0, *C0;   // [nDesign,36]
-    const double *MBw;      // [nDesign,2,36,nw] or null
-    const int64_t *cmoff;   // [nDesign+1] or null
-    const cplx *cm;         // [nRows,2,nw] or null
-    // cases
-    int nCase, nHead, nw;
-    const double *w, *k;    // [nw]
-    const double *csh, *cch, *e2kh;   // per-bin depth constants (host-computed)
-    const int *mode;        // 0 finite depth, 1 deep (k h > 89.4), 2 k==0   (helpers.py:211-222)
-    const double *zeta;     // [nCase,nHead,nw]
-    const double *beta;     // [nCase,nHead]
-    double depth, rho, g;
-};
-
-// per-lane (per frequency bin) wave constants
-struct Bin {
-    double w, k, csh, cch, e2kh;
-    int mode;
-};
-
-// Depth-decay ratios of helpers.py:208-223, evaluated in the overflow-free
-// exponential form: with E = e^{kz}, Q = e^{-k(z+2h)} = e^{-2kh}/E
-//   sinh k(z+h)/sinh kh = (E-Q)/(1-e^{-2kh}),  cosh k(z+h)/sinh kh = (E+Q)/(1-e^{-2kh}),
-//   cosh k(z+h)/cosh kh = (E+Q)/(1+e^{-2kh}).
-__device__ __forceinline__ void depth_ratios(const Bin &b, double z, double depth, double &Sh, double &Ch, double &Cc) {
-    if (b.mode == 0) {
-        double E = exp(b.k * z);
-        double Q = b.e2kh / E;
-        Sh = (E - Q) * b.csh;
-        Ch = (E + Q) * b.csh;
-        Cc = (E + Q) * b.cch;
-    } else if (b.mode == 1) {
-        double E = exp(b.k * z);
-        Sh = E;
-        Ch = E;
-        Cc = E + exp(-b.k * (z + 2.0 * depth));
-    } else {
-        Sh = 1.0;
-        Ch = 99999.0;
-        Cc = 99999.0;
-    }
-}
-
-// Local wave elevation phasor zeta*exp(-i k (x cos b + y sin b))  (helpers.py:201)
-__device__ __forceinline__ cplx local_elevation(double zeta0, double k, double xi) {
-    double s, c;
-    sincos(-(k * xi), &s, &c);
-    return {zeta0 * c, zeta0 * s};
-}
-
-// wave-level sum of one double over 64 lanes (result in every lane)
-__device__ __forceinline__ double wave_sum(double v) {
-#pragma unroll
-    for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
-    return v;
-}
-
-// ------------------------------------------------------------------ shared layout
-// LDS carve (doubles).  W[S][18] = [n_c ; a x n_c] for c = q,p1,p2 (geometry only);
-// bc[S][4] = (Bq, Bp1, Bp2, -) linearised coefficients of the live iteration;
-// uv[S][12] = heading-projected drag excitation vectors; red[...] reduction scratch.
-struct Lds {
-    double *W;      // S*18
-    double *bc;     // S*4
-    double *uv;     // S*12
-    double *red;    // S*NWAVE*3 per-wave partial sums of pass A
-    double *Bd;     // 36
-};
-
-__device__ __forceinline__ Lds carve(double *base, int S) {
-    Lds l;
-    l.W = base;
-    l.bc = l.W + (size_t)S * 18;
-    l.uv = l.bc + (size_t)S * 4;
-    l.red = l.uv + (size_t)S * 12;
-    l.Bd = l.red + (size_t)S * NWAVE * 3;
-    return l;
-}
-static size_t lds_bytes(int S) { return sizeof(double) * ((size_t)S * (18 + 4 + 12 + NWAVE * 3) + 36 + 8); }
-
-// W_{s,c} = [n_c ; a_s x n_c]  -- the 6-vector that both projects the body
-// velocity on direction c (helpers.py:178-181,396-402 folded with raft_member.py:2078-2081)
-// and translates a force along n_c to the reference point (helpers.py:468-483).
-__device__ __forceinline__ void build_W(const double *__restrict__ strips, int S, const Lds &l) {
-    for (int s = threadIdx.x; s < S; s += blockDim.x) {
-        const double *rec = strips + (size_t)s * NF;
-        double ax = rec[RAFTX_F_AX], ay = rec[RAFTX_F_AX + 1], az = rec[RAFTX_F_AX + 2];
-#pragma unroll
-        for (int c = 0; c < 3; c++) {
-            const double *n = rec + RAFTX_F_Q + 3 * c;
-            double *W = l.W + (size_t)s * 18 + c * 6;
-            W[0] = n[0];
-            W[1] = n[1];
-            W[2] = n[2];
-            W[3] = ay * n[2] - az * n[1];
-            W[4] = az * n[0] - ax * n[2];
-            W[5] = ax * n[1] - ay * n[0];
-        }
-    }
-}
-
-// uv[s] for heading (cb,sb): U = sum_c b_c alpha_c W_c, V = sum_c b_c gamma_c W_c,
-// alpha_c = n_c.x cb + n_c.y sb, gamma_c = n_c.z.  Then the strip's drag
-// excitation (raft_member.py:2122-2124 / :2146-2151) is  t1*U + t2*V  with
-// t1 = w zeta_s Ch, t2 = i w zeta_s Sh.
-__device__ __forceinline__ void build_uv(int S, const Lds &l, double cb, double sb) {
-    for (int s = threadIdx.x; s < S; s += blockDim.x) {
-        double U[6] = {0, 0, 0, 0, 0, 0}, V[6] = {0, 0, 0, 0, 0, 0};
-#pragma unroll
-        for (int c = 0; c < 3; c++) {
-            const double *W = l.W + (size_t)s * 18 + c * 6;
-            double b = l.bc[(size_t)s * 4 + c];
-            double al = b * (W[0] * cb + W[1] * sb);
-            double ga = b * W[2];
-#pragma unroll
-            for (int j = 0; j < 6; j++) {
-                U[j] += al * W[j];
-                V[j] += ga * W[j];
-            }
-        }
-#pragma unroll
-        for (int j = 0; j < 6; j++) {
-            l.uv[(size_t)s * 12 + j] = U[j];
-            l.uv[(size_t)s * 12 + 6 + j] = V[j];
-        }
-    }
-}
-
-// B_drag[6][6] = sum_{s,c} b_{s,c} W W^T  == sum_s translateMatrix3to6DOF(Bmat_s, a_s)
-// (raft_member.py:2117-2118, helpers.py:537-560).  36 lanes, one entry each.
-__device__ __forceinline__ void build_Bdrag(int S, const Lds &l) {
-    int e = threadIdx.x;
-    if (e < 36) {
-        int i = e / 6, j = e % 6;
-        double acc = 0.0;
-        for (int s = 0; s < S; s++) {
-#pragma unroll
-            for (int c = 0; c < 3; c++) {
-                const double *W = l.W + (size_t)s * 18 + c * 6;
-                acc += l.bc[(size_t)s * 4 + c] * (W[i] * W[j]);
-            }
-        }
-        l.Bd[e] = acc;
-    }
-}
-
-// Inertial excitation of one heading, accumulated over the strips
-// (raft_member.py:1965-1991; helpers.py:188-236).  F[6] per lane.
-__device__ __forceinline__ void inertial_excitation(const DevTables &T, const double *__restrict__ strips, int S,
-                                                    const cplx *__restrict__ cm, const Bin &b, bool active, int iw,
-                                                    double zeta0, double cb, double sb, cplx F[6]) {
-#pragma unroll
-    for (int j = 0; j < 6; j++) F[j] = {0.0, 0.0};
-    if (!active) return;
-    for (int s = 0; s < S; s++) {
-        const double *__restrict__ rec = strips + (size_t)s * NF;
-        double x = rec[RAFTX_F_X], y = rec[RAFTX_F_X + 1], z = rec[RAFTX_F_X + 2];
-        cplx zs = local_elevation(zeta0, b.k, cb * x + sb * y);
-        double Sh, Ch, Cc;
-        depth_ratios(b, z, T.depth, Sh, Ch, Cc);
-        // u = (w zs Ch cb, w zs Ch sb, i w zs Sh);  ud = i w u   (helpers.py:225-231)
-        cplx wz = cscale(zs, b.w);
-        cplx uh = cscale(wz, Ch);
-        cplx u0 = cscale(uh, cb), u1 = cscale(uh, sb);
-        cplx u2 = {-wz.im * Sh, wz.re * Sh};
-        cplx ud0 = {-b.w * u0.im, b.w * u0.re};
-        cplx ud1 = {-b.w * u1.im, b.w * u1.re};
-        cplx ud2 = {-b.w * u2.im, b.w * u2.re};
-        cplx pd = cscale(zs, T.rho * T.g);
-        pd = cscale(pd, Cc);
-        const double *q = rec + RAFTX_F_Q, *p1 = rec + RAFTX_F_P1, *p2 = rec + RAFTX_F_P2;
-        // projections of ud on q, p1, p2
-        cplx aq = cadd(cadd(cscale(ud0, q[0]), cscale(ud1, q[1])), cscale(ud2, q[2]));
-        cplx a1 = cadd(cadd(cscale(ud0, p1[0]), cscale(ud1, p1[1])), cscale(ud2, p1[2]));
-        cplx a2 = cadd(cadd(cscale(ud0, p2[0]), cscale(ud1, p2[1])), cscale(ud2, p2[2]));
-        cplx c1, c2;
-        int mcf = (int)rec[RAFTX_F_MCF];
-        if (mcf >= 0) {   // MacCamy-Fuchs: complex per-bin Cm (raft_member.py:1415-1420)
-            double rv = rec[RAFTX_F_RHOV];
-            cplx m1 = cm[((size_t)mcf * 2 + 0) * T.nw + iw];
-            cplx m2 = cm[((size_t)mcf * 2 + 1) * T.nw + iw];
-            c1 = cmul(cscale(m1, rv), a1);
-            c2 = cmul(cscale(m2, rv), a2);
-        } else {
-            c1 = cscale(a1, rec[RAFTX_F_IP1]);
-            c2 = cscale(a2, rec[RAFTX_F_IP2]);
-        }
-        cplx cq = cadd(cscale(aq, rec[RAFTX_F_IQ]), cscale(pd, rec[RAFTX_F_AI]));   // + pDyn*a_i along q (:1988)
-        cplx f0 = cadd(cadd(cscale(cq, q[0]), cscale(c1, p1[0])), cscale(c2, p2[0]));
-        cplx f1 = cadd(cadd(cscale(cq, q[1]), cscale(c1, p1[1])), cscale(c2, p2[1]));
-        cplx f2 = cadd(cadd(cscale(cq, q[2]), cscale(c1, p1[2])), cscale(c2, p2[2]));
-        double ax = rec[RAFTX_F_AX], ay = rec[RAFTX_F_AX + 1], az = rec[RAFTX_F_AX + 2];
-        F[0] = cadd(F[0], f0);
-        F[1] = cadd(F[1], f1);
-        F[2] = cadd(F[2], f2);
-        F[3] = cadd(F[3], csub(cscale(f2, ay), cscale(f1, az)));    // a x f  (helpers.py:481)
-        F[4] = cadd(F[4], csub(cscale(f0, az), cscale(f2, ax)));
-        F[5] = cadd(F[5], csub(cscale(f1, ax), cscale(f0, ay)));
-    }
-}
-
-// Pass A of one linearisation: per strip, RMS over all bins of the relative
-// velocity components (raft_member.py:2075-2090, helpers.py:684) -> bc[S][3].
-// Xi[6] is this lane's response amplitude (zero contribution for inactive lanes).
-__device__ __forceinline__ void linearize_passA(const DevTables &T, const double *__restrict__ strips, int S,
-                                                const Lds &l, const Bin &b, bool active, double zeta0,
-                                                double cb, double sb, const cplx Xi[6]) {
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    for (int s = 0; s < S; s++) {
-        const double *__restrict__ rec = strips + (size_t)s * NF;
-        double vq2 = 0.0, v12 = 0.0, v22 = 0.0;
-        if (active) {
-            double x = rec[RAFTX_F_X], y = rec[RAFTX_F_X + 1], z = rec[RAFTX_F_X + 2];
-            cplx zs = local_elevation(zeta0, b.k, cb * x + sb * y);
-            double Sh, Ch, Cc;
-            depth_ratios(b, z, T.depth, Sh, Ch, Cc);
-            cplx wz = cscale(zs, b.w);
-            cplx t1 = cscale(wz, Ch);                 // horizontal velocity phasor
-            cplx t2 = {-wz.im * Sh, wz.re * Sh};      // vertical   velocity phasor (i w zs Sh)
-            const double *W = l.W + (size_t)s * 18;
-#pragma unroll
-            for (int c = 0; c < 3; c++) {
-                const double *Wc = W + c * 6;
-                double al = Wc[0] * cb + Wc[1] * sb, ga = Wc[2];
-                cplx G = cadd(cscale(t1, al), cscale(t2, ga));           // n_c . u
-                cplx P = {0.0, 0.0};                                       // W_c . Xi  (body displacement along c)
-#pragma unroll
-                for (int j = 0; j < 6; j++) P = cadd(P, cscale(Xi[j], Wc[j]));
-                cplx v = {G.re + b.w * P.im, G.im - b.w * P.re};           // G - i w P
-                double m = cabs2(v);
-                if (c == 0) vq2 = m;
-                else if (c == 1) v12 = m;
-                else v22 = m;
-            }
-        }
-        vq2 = wave_sum(vq2);
-        v12 = wave_sum(v12);
-        v22 = wave_sum(v22);
-        if (lane == 0) {
-            double *r = l.red + ((size_t)s * NWAVE + wv) * 3;
-            r[0] = vq2;
-            r[1] = v12;
-            r[2] = v22;
-        }
-    }
-    __syncthreads();
-    for (int s = threadIdx.x; s < S; s += blockDim.x) {
-        const double *__restrict__ rec = strips + (size_t)s * NF;
-        double a = 0, c1 = 0, c2 = 0;
-        for (int i = 0; i < NWAVE; i++) {
-            const double *r = l.red + ((size_t)s * NWAVE + i) * 3;
-            a += r[0];
-            c1 += r[1];
-            c2 += r[2];
-        }
-        double vRq = sqrt(0.5 * a), vR1, vR2;
-        if (rec[RAFTX_F_CIRC] != 0.0) {        // circular: total transverse velocity (:2085-2087)
-            vR1 = sqrt(0.5 * (c1 + c2));
-            vR2 = vR1;
-        } else {
-            vR1 = sqrt(0.5 * c1);
-            vR2 = sqrt(0.5 * c2);
-        }
-        l.bc[(size_t)s * 4 + 0] = rec[RAFTX_F_DQ] * vRq + rec[RAFTX_F_DEND] * vRq;   // Bprime_q + Bprime_End (:2093,:2110)
-        l.bc[(size_t)s * 4 + 1] = rec[RAFTX_F_DP1] * vR1;
-        l.bc[(size_t)s * 4 + 2] = rec[RAFTX_F_DP2] * vR2;
-    }
-    __syncthreads();
-}
-
-// Pass B: drag excitation of one heading with the live coefficients (uv built
-// for that heading): F[6] per lane.  raft_member.py:2122-2124, :2146-2151.
-__device__ __forceinline__ void drag_excitation(const DevTables &T, const double *__restrict__ strips, int S,
-                                                const Lds &l, const Bin &b, bool active, double zeta0,
-                                                double cb, double sb, cplx F[6]) {
-#pragma unroll
-    for (int j = 0; j < 6; j++) F[j] = {0.0, 0.0};
-    if (!active) return;
-    for (int s = 0; s < S; s++) {
-        const double *__restrict__ rec = strips + (size_t)s * NF;
-        double x = rec[RAFTX_F_X], y = rec[RAFTX_F_X + 1], z = rec[RAFTX_F_X + 2];
-        cplx zs = local_elevation(zeta0, b.k, cb * x + sb * y);
-        double Sh, Ch, Cc;
-        depth_ratios(b, z, T.depth, Sh, Ch, Cc);
-        cplx wz = cscale(zs, b.w);
-        cplx t1 = cscale(wz, Ch);
-        cplx t2 = {-wz.im * Sh, wz.re * Sh};
-        const double *uv = l.uv + (size_t)s * 12;
-#pragma unroll
-        for (int j = 0; j < 6; j++) {
-            F[j].re += t1.re * uv[j] + t2.re * uv[6 + j];
-            F[j].im += t1.im * uv[j] + t2.im * uv[6 + j];
-        }
-    }
-}
-
-// ------------------------------------------------------------------ 6x6 complex LU in registers
-struct Lu6 {
-    double ar[6][6], ai[6][6];
-    int piv[6];
-};
-
-// zgetrf-style: partial pivoting on |re|+|im| (izamax), full row interchanges.
-__device__ __forceinline__ void lu6_factor(Lu6 &A) {
-#pragma unroll
-    for (int k = 0; k < 6; k++) {
-        int p = k;
-        double best = fabs(A.ar[k][k]) + fabs(A.ai[k][k]);
-#pragma unroll
-        for (int r = k + 1; r < 6; r++) {
-            double v = fabs(A.ar[r][k]) + fabs(A.ai[r][k]);
-            if (v > best) {
-                best = v;
-                p = r;
-            }
-        }
-        A.piv[k] = p;
-        if (__any(p != k)) {
-#pragma unroll
-            for (int r = k + 1; r < 6; r++) {
-                bool sw = (p == r);
-#pragma unroll
-                for (int c = 0; c < 6; c++) {
-                    double tr = A.ar[k][c], ti = A.ai[k][c];
-                    A.ar[k][c] = sw ? A.ar[r][c] : tr;
-                    A.ai[k][c] = sw ? A.ai[r][c] : ti;
-                    A.ar[r][c] = sw ? tr : A.ar[r][c];
-                    A.ai[r][c] = sw ? ti : A.ai[r][c];
-                }
-            }
-        }
-        // reciprocal of the pivot
-        double pr = A.ar[k][k], pi = A.ai[k][k];
-        double d = pr * pr + pi * pi;
-        double ir = pr / d, ii = -pi / d;
-#pragma unroll
-        for (int r = k + 1; r < 6; r++) {
-            double lr = A.ar[r][k] * ir - A.ai[r][k] * ii;
-            double li = A.ar[r][k] * ii + A.ai[r][k] * ir;
-            A.ar[r][k] = lr;
-            A.ai[r][k] = li;
-#pragma unroll
-            for (int c = k + 1; c < 6; c++) {
-                A.ar[r][c] -= lr * A.ar[k][c] - li * A.ai[k][c];
-                A.ai[r][c] -= lr * A.ai[k][c] + li * A.ar[k][c];
-            }
-        }
-    }
-}
-
-__device__ __forceinline__ void lu6_solve(const Lu6 &A, cplx b[6]) {
-#pragma unroll
-    for (int k = 0; k < 6; k++) {   // zlaswp
-        int p = A.piv[k];
-#pragma unroll
-        for (int r = k + 1; r < 6; r++) {
-            bool sw = (p == r);
-            cplx t = b[k];
-            b[k] = sw ? b[r] : t;
-            b[r] = sw ? t : b[r];
-        }
-    }
-#pragma unroll
-    for (int k = 0; k < 6; k++)
-#pragma unroll
-        for (int r = k + 1; r < 6; r++) {
-            double lr = A.ar[r][k], li = A.ai[r][k];
-            b[r].re -= lr * b[k].re - li * b[k].im;
-            b[r].im -= lr * b[k].im + li * b[k].re;
-        }
-#pragma unroll
-    for (int k = 5; k >= 0; k--) {
-        cplx s = b[k];
-#pragma unroll
-        for (int c = k + 1; c < 6; c++) {
-            s.re -= A.ar[k][c] * b[c].re - A.ai[k][c] * b[c].im;
-            s.im -= A.ar[k][c] * b[c].im + A.ai[k][c] * b[c].re;
-        }
-        double pr = A.ar[k][k], pi = A.ai[k][k];
-        double d = pr * pr + pi * pi;
-        b[k] = {(s.re * pr + s.im * pi) / d, (s.im * pr - s.re * pi) / d};
-    }
-}
-
-// ------------------------------------------------------------------ kernels
-__device__ __forceinline__ Bin load_bin(const DevTables &T, int iw, bool active) {
-    Bin b;
-    int i = active ? iw : 0;
-    b.w = T.w[i];
-    b.k = T.k[i];
-    b.csh = T.csh[i];
-    b.cch = T.cch[i];
-    b.e2kh = T.e2kh[i];
-    b.mode = T.mode[i];
-    return b;
-}
-
-// F_iner [nDesign,nCase,nHead,6,nw]   (raft_fowt.py:1854-1857,1888)
-__global__ void __launch_bounds__(BLOCK) k_excitation(DevTables T, cplx *__restrict__ F_iner) {
-    const int pair = blockIdx.x / T.nHead, ih = blockIdx.x % T.nHead;
-    const int d = pair / T.nCase, ic = pair % T.nCase;
-    const int S = (int)(T.off[d + 1] - T.off[d]);
-    const double *strips = T.strips + (size_t)T.off[d] * NF;
-    const cplx *cm = T.cm ? T.cm + (size_t)T.cmoff[d] * 2 * T.nw : nullptr;
-    const int iw = threadIdx.x;
-    const bool active = iw < T.nw;
-    Bin b = load_bin(T, iw, active);
-    const double beta = T.beta[(size_t)ic * T.nHead + ih];
-    const double cb = cos(beta), sb = sin(beta);
-    const double zeta0 = active ? T.zeta[((size_t)ic * T.nHead + ih) * T.nw + iw] : 0.0;
-    cplx F[6];
-    inertial_excitation(T, strips, S, cm, b, active, iw, zeta0, cb, sb, F);
-    if (active) {
-        cplx *out = F_iner + (((size_t)pair * T.nHead + ih) * 6) * T.nw + iw;
-#pragma unroll
-        for (int j = 0; j < 6; j++) out[(size_t)j * T.nw] = F[j];
-    }
-}
-
-// One linearisation about a given Xi (raft_fowt.py:1891-1957).
-__global__ void __launch_bounds__(BLOCK) k_linearize(DevTables T, const cplx *__restrict__ Xi_in,
-                                                     double *__restrict__ B_drag, cplx *__restrict__ F_drag) {
-    extern __shared__ __attribute__((aligned(16))) double smem[];
-    const int pair = blockIdx.x;
-    const int d = pair / T.nCase, ic = pair % T.nCase;
-    const int S = (int)(T.off[d + 1] - T.off[d]);
-    const double *strips = T.strips + (size_t)T.off[d] * NF;
-    Lds l = carve(smem, S);
-    const int iw = threadIdx.x;
-    const bool active = iw < T.nw;
-    Bin b = load_bin(T, iw, active);
-    build_W(strips, S, l);
-    __syncthreads();
-    cplx Xi[6];
-#pragma unroll
-    for (int j = 0; j < 6; j++) Xi[j] = active ? Xi_in[((size_t)pair * 6 + j) * T.nw + iw] : cplx{0.0, 0.0};
-    {
-        const double beta = T.beta[(size_t)ic * T.nHead + 0];
-        const double zeta0 = active ? T.zeta[((size_t)ic * T.nHead + 0) * T.nw + iw] : 0.0;
-        linearize_passA(T, strips, S, l, b, active, zeta0, cos(beta), sin(beta), Xi);
-    }
-    if (B_drag) {
-        build_Bdrag(S, l);
-        __syncthreads();
-        if (threadIdx.x < 36) B_drag[(size_t)pair * 36 + threadIdx.x] = l.Bd[threadIdx.x];
-    }
-    if (F_drag) {
-        for (int ih = 0; ih < T.nHead; ih++) {
-            const double beta = T.beta[(size_t)ic * T.nHead + ih];
-            const double cb = cos(beta), sb = sin(beta);
-            const double zeta0 = active ? T.zeta[((size_t)ic * T.nHead + ih) * T.nw + iw] : 0.0;
-            __syncthreads();
-            build_uv(S, l, cb, sb);
-            __syncthreads();
-            cplx F[6];
-            drag_excitation(T, strips, S, l, b, active, zeta0, cb, sb, F);
-            if (active) {
-                cplx *out = F_drag + (((size_t)pair * T.nHead + ih) * 6) * T.nw + iw;
-#pragma unroll
-                for (int j = 0; j < 6; j++) out[(size_t)j * T.nw] = F[j];
-            }
-        }
-    }
-}
-
-struct SolveArgs {
-    int nIter;          // loop bound = YAML nIter + 1 (raft_model.py:977)
-    double tol, XiStart;
-    const cplx *F_extra;    // [pair,nHead,6,nw] or null
-    cplx *Xi;               // [pair,nHead,6,nw] or null
-    int *niter, *flags;     // [pair]
-    double *B_drag;         // [pair,36] or null
-    cplx *F_wave;           // [pair,nHead,6,nw] or null
-    cplx *Z;                // [pair,36,nw] or null
-};
-
-// The fused fixed point (raft_model.py:1052-1142) + per-heading response (:1189-1236).
-__global__ void __launch_bounds__(BLOCK) k_solve_dynamics(DevTables T, SolveArgs A) {
-    extern __shared__ __attribute__((aligned(16))) double smem[];
-    const int pair = blockIdx.x;
-    const int d = pair / T.nCase, ic = pair % T.nCase;
-    const int S = (int)(T.off[d + 1] - T.off[d]);
-    const double *strips = T.strips + (size_t)T.off[d] * NF;
-    const cplx *cm = T.cm ? T.cm + (size_t)T.cmoff[d] * 2 * T.nw : nullptr;
-    Lds l = carve(smem, S);
-    const int iw = threadIdx.x;
-    const bool active = iw < T.nw;
-    const int nw = T.nw, nH = T.nHead;
-    Bin b = load_bin(T, iw, active);
-    build_W(strips, S, l);
-
-    const double beta0 = T.beta[(size_t)ic * nH];
-    const double cb0 = cos(beta0), sb0 = sin(beta0);
-    const double zeta00 = active ? T.zeta[((size_t)ic * nH) * nw + iw] : 0.0;
-
-    // F_lin = F_extra[0] + F_iner[0]   (raft_model.py:1048)
-    cplx Flin[6];
-    inertial_excitation(T, strips, S, cm, b, active, iw, zeta00, cb0, sb0, Flin);
-    if (A.F_extra && active) {
-#pragma unroll
-        for (int j = 0; j < 6; j++) {
-            cplx fe = A.F_extra[(((size_t)pair * nH) * 6 + j) * nw + iw];
-            Flin[j] = cadd(fe, Flin[j]);
-        }
-    }
-    cplx XiLast[6], Xi[6];
-#pragma unroll
-    for (int j = 0; j < 6; j++) {
-        XiLast[j] = active ? cplx{A.XiStart, 0.0} : cplx{0.0, 0.0};   // :999
-        Xi[j] = {0.0, 0.0};
-    }
-    // frequency-dependent + constant system matrices of this lane's bin (:1045-1047)
-    const double *M0 = T.M0 + (size_t)d * 36, *B0 = T.B0 + (size_t)d * 36, *C0 = T.C0 + (size_t)d * 36;
-    const double *Mw = T.MBw ? T.MBw + ((size_t)d * 2 + 0) * 36 * nw : nullptr;
-    const double *Bw = T.MBw ? T.MBw + ((size_t)d * 2 + 1) * 36 * nw : nullptr;
-    __syncthreads();
-
-    Lu6 lu;
-    int iiter = 0, done = 0, converged = 0, nan = 0;
-    while (iiter < A.nIter) {
-        linearize_passA(T, strips, S, l, b, active, zeta00, cb0, sb0, XiLast);   // :1063
-        build_Bdrag(S, l);
-        build_uv(S, l, cb0, sb0);
-        __syncthreads();
-        cplx Fd[6];
-        drag_excitation(T, strips, S, l, b, active, zeta00, cb0, sb0, Fd);      // :1064
-        // Z = -w^2 M + i w B + C   (:1086)
-        const int iwc = active ? iw : 0;
-        const double w = b.w, w2 = b.w * b.w;
-#pragma unroll
-        for (int r = 0; r < 6; r++)
-#pragma unroll
-            for (int c = 0; c < 6; c++) {
-                int e = r * 6 + c;
-                double M = M0[e], B = B0[e];
-                if (Mw) {
-                    M += Mw[(size_t)e * nw + iwc];
-                    B += Bw[(size_t)e * nw + iwc];
-                }
-                B += l.Bd[e];
-                lu.ar[r][c] = -w2 * M + C0[e];
-                lu.ai[r][c] = w * B;
-            }
-        if (A.Z && active) {      // last iterate wins (fowt.Z, :1155)
-#pragma unroll
-            for (int r = 0; r < 6; r++)
-#pragma unroll
-                for (int c = 0; c < 6; c++)
-                    A.Z[((size_t)pair * 36 + r * 6 + c) * nw + iw] = cplx{lu.ar[r][c], lu.ai[r][c]};
-        }
-        lu6_factor(lu);
-#pragma unroll
-        for (int j = 0; j < 6; j++) Xi[j] = cadd(Flin[j], Fd[j]);               // :1081
-        lu6_solve(lu, Xi);                                                       // :1089
-        done = iiter + 1;
-        // NaN check (:1098) and convergence (:1103-1104)
-        int bad = 0, ok = 1;
-        if (active) {
-#pragma unroll
-            for (int j = 0; j < 6; j++) {
-                if (isnan(Xi[j].re) || isnan(Xi[j].im)) bad = 1;
-                double dr = Xi[j].re - XiLast[j].re, di = Xi[j].im - XiLast[j].im;
-                double tc = hypot(dr, di) / (hypot(Xi[j].re, Xi[j].im) + A.tol);
-                if (!(tc < A.tol)) ok = 0;
-            }
-        }
-        nan = __syncthreads_or(bad);
-        if (nan) break;
-        converged = __syncthreads_and(ok);
-        if (converged) break;
-#pragma unroll
-        for (int j = 0; j < 6; j++) {                                            // :1133
-            XiLast[j].re = 0.2 * XiLast[j].re + 0.8 * Xi[j].re;
-            XiLast[j].im = 0.2 * XiLast[j].im + 0.8 * Xi[j].im;
-        }
-        iiter++;
-    }
-
-    // per-heading response with the last impedance and the last coefficients (:1200-1236)
-    for (int ih = 0; ih < nH; ih++) {
-        const double beta = T.beta[(size_t)ic * nH + ih];
-        const double cb = cos(beta), sb = sin(beta);
-        const double zeta0 = active ? T.zeta[((size_t)ic * nH + ih) * nw + iw] : 0.0;
-        cplx Fi[6], Fd[6];
-        if (ih == 0) {
-#pragma unroll
-            for (int j = 0; j < 6; j++) Fi[j] = Flin[j];
-        } else {
-            inertial_excitation(T, strips, S, cm, b, active, iw, zeta0, cb, sb, Fi);
-            if (A.F_extra && active) {
-#pragma unroll
-                for (int j = 0; j < 6; j++) {
-                    cplx fe = A.F_extra[(((size_t)pair * nH + ih) * 6 + j) * nw + iw];
-                    Fi[j] = cadd(fe, Fi[j]);
-                }
-            }
-        }
-        __syncthreads();
-        build_uv(S, l, cb, sb);
-        __syncthreads();
-        drag_excitation(T, strips, S, l, b, active, zeta0, cb, sb, Fd);          // :1209
-        cplx f[6];
-#pragma unroll
-        for (int j = 0; j < 6; j++) f[j] = cadd(Fi[j], Fd[j]);                   // :1212
-        if (active) {
-            if (A.F_wave) {
-#pragma unroll
-                for (int j = 0; j < 6; j++) A.F_wave[(((size_t)pair * nH + ih) * 6 + j) * nw + iw] = f[j];
-            }
-            if (A.Xi) {
-                lu6_solve(lu, f);                                                // Zinv @ F_wave (:1216)
-#pragma unroll
-                for (int j = 0; j < 6; j++) {
-                    cplx v = nan ? cplx{NAN, NAN} : f[j];
-                    A.Xi[(((size_t)pair * nH + ih) * 6 + j) * nw + iw] = v;
-                }
-            }
-        }
-    }
-    if (threadIdx.x < 36 && A.B_drag) A.B_drag[(size_t)pair * 36 + threadIdx.x] = l.Bd[threadIdx.x];
-    if (threadIdx.x == 0) {
-        if (A.niter) A.niter[pair] = done;
-        if (A.flags) A.flags[pair] = (converged ? RAFTX_FLAG_CONVERGED : 0) | (nan ? RAFTX_FLAG_NAN : 0);
-    }
-}
+#include "raftx_device.h"
 
 // Coupled array solve (raft_model.py:1164-1236): one 64-lane workgroup per
 // (system, bin); the augmented matrix [Z_sys | F] lives in LDS, lane r owns
@@ -872,11 +229,41 @@ extern "C" int raftx_upload_designs(raftx_ctx *c, int nDesign, const int64_t *st
         if (S < 0) FAIL(c, "strip offsets not monotone at design %d", d);
         if (S > maxS) maxS = (int)S;
     }
+    // The run hints (RAFTX_F_STEP / RAFTX_F_UNIT) only accelerate the wave-kinematics
+    // evaluation; verify each against the absolute strip positions and demote anything
+    // inconsistent to an exact evaluation, so a bad hint can never change results.
+    std::vector<double> clean(strips, strips + (size_t)stripOffsets[nDesign] * NF);
+    for (int d = 0; d < nDesign; d++) {
+        int run = 0;
+        for (int64_t s = stripOffsets[d]; s < stripOffsets[d + 1]; s++) {
+            double *r = clean.data() + (size_t)s * NF;
+            double unit = r[RAFTX_F_UNIT];
+            if (!(unit > 0.0) || !std::isfinite(unit)) unit = 0.0;
+            r[RAFTX_F_UNIT] = unit;
+            int m = (int)r[RAFTX_F_STEP];
+            bool ok = (s > stripOffsets[d]) && m >= 1 && m <= 4 && (double)m == r[RAFTX_F_STEP] && unit > 0.0 && run < 24;
+            if (ok) {
+                const double *p = r - NF;
+                ok = p[RAFTX_F_UNIT] == unit;
+                for (int j = 0; j < 3 && ok; j++) {
+                    ok = p[RAFTX_F_Q + j] == r[RAFTX_F_Q + j];
+                    double pred = p[RAFTX_F_X + j] + (double)m * unit * r[RAFTX_F_Q + j];
+                    if (std::fabs(pred - r[RAFTX_F_X + j]) > 1e-10 * (1.0 + std::fabs(r[RAFTX_F_X + j]))) ok = false;
+                }
+            }
+            if (ok) {
+                run++;
+            } else {
+                r[RAFTX_F_STEP] = 0.0;
+                run = 0;
+            }
+        }
+    }
     DevTables &T = c->T;
     T.nDesign = nDesign;
     int rc = 0;
     rc |= upload(c, c->design_allocs, stripOffsets, (size_t)nDesign + 1, &T.off);
-    rc |= upload(c, c->design_allocs, strips, (size_t)stripOffsets[nDesign] * NF, &T.strips);
+    rc |= upload(c, c->design_allocs, clean.data(), clean.size(), &T.strips);
     rc |= upload(c, c->design_allocs, M0, (size_t)nDesign * 36, &T.M0);
     rc |= upload(c, c->design_allocs, B0, (size_t)nDesign * 36, &T.B0);
     rc |= upload(c, c->design_allocs, C0, (size_t)nDesign * 36, &T.C0);
@@ -913,10 +300,10 @@ extern "C" int raftx_upload_cases(raftx_ctx *c, int nCase, int nHead, int nw, co
         if (k[i] == 0.0) {
             mode[i] = 2;
             csh[i] = cch[i] = e2kh[i] = 0.0;
-        } else if (kh > 89.4) {
+        } else if (kh > 89.4) {   // deep-water branch of helpers.py:215-218: Sh = Ch = e^{kz}, Cc = e^{kz} + e^{-k(z+2h)}
             mode[i] = 1;
             csh[i] = cch[i] = 1.0;
-            e2kh[i] = 0.0;
+            e2kh[i] = exp(-2.0 * kh);
         } else {
             mode[i] = 0;
             e2kh[i] = exp(-2.0 * kh);
@@ -1005,8 +392,11 @@ extern "C" int raftx_excitation(raftx_ctx *c, raftx_c128 *F_iner) {
     Scratch sc(c);
     cplx *dF = sc.alloc<cplx>(n);
     if (n && !dF) FAIL(c, "excitation: device allocation failed");
+    if (prep_lds(c, k_excitation, lds_bytes(c->maxS, c->T.nw))) return -1;
     HIPCHK(c, hipEventRecord(c->ev0, c->stream));
-    if (npair) hipLaunchKernelGGL(k_excitation, dim3((unsigned)(npair * T.nHead)), dim3(BLOCK), 0, c->stream, T, dF);
+    if (npair)
+        hipLaunchKernelGGL(k_excitation, dim3((unsigned)(npair * T.nHead)), dim3(BLOCK), lds_bytes(c->maxS, c->T.nw), c->stream, T,
+                           dF);
     if (finish_timed(c)) return -2;
     if (n) D2H(c, F_iner, dF, n * sizeof(cplx));
     HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -1025,10 +415,10 @@ extern "C" int raftx_linearize(raftx_ctx *c, const raftx_c128 *Xi, double *B_dra
     cplx *dF = F_drag ? sc.alloc<cplx>(npair * T.nHead * 6 * T.nw) : nullptr;
     if (npair && (!dXi || (B_drag && !dB) || (F_drag && !dF))) FAIL(c, "linearize: device allocation failed");
     if (npair) H2D(c, dXi, Xi, npair * 6 * T.nw * sizeof(cplx));
-    if (prep_lds(c, k_linearize, lds_bytes(c->maxS))) return -1;
+    if (prep_lds(c, k_linearize, lds_bytes(c->maxS, c->T.nw))) return -1;
     HIPCHK(c, hipEventRecord(c->ev0, c->stream));
     if (npair)
-        hipLaunchKernelGGL(k_linearize, dim3((unsigned)npair), dim3(BLOCK), lds_bytes(c->maxS), c->stream, T, dXi, dB,
+        hipLaunchKernelGGL(k_linearize, dim3((unsigned)npair), dim3(BLOCK), lds_bytes(c->maxS, c->T.nw), c->stream, T, dXi, dB,
                            dF);
     if (finish_timed(c)) return -2;
     if (dB) D2H(c, B_drag, dB, npair * 36 * sizeof(double));
@@ -1099,11 +489,27 @@ extern "C" int raftx_solve_dynamics_device(raftx_ctx *c, int nIter, double tol, 
     A.F_wave = (want_mask & RAFTX_WANT_FWAVE) ? c->rFw : nullptr;
     A.Z = (want_mask & RAFTX_WANT_Z) ? c->rZ : nullptr;
     if (F_extra && c->r_nx) H2D(c, c->rFe, F_extra, c->r_nx * sizeof(cplx));
-    if (prep_lds(c, k_solve_dynamics, lds_bytes(c->maxS))) return -1;
-    HIPCHK(c, hipEventRecord(c->ev0, c->stream));
-    if (c->r_npair)
-        hipLaunchKernelGGL(k_solve_dynamics, dim3((unsigned)c->r_npair), dim3(BLOCK), lds_bytes(c->maxS), c->stream, T,
-                           A);
+    // pick the leanest specialisation that covers what this call needs
+    int need = (T.MBw ? KF_FDEP : 0) | (A.Z ? KF_OUTZ : 0) | (A.F_wave ? KF_OUTF : 0) | (A.F_extra ? KF_EXTRA : 0) |
+               (T.cm ? KF_MCF : 0) | (T.nHead > 1 ? KF_MULTI : 0);
+    const size_t lds = lds_bytes(c->maxS, T.nw);
+#define LAUNCH_SOLVE(FL)                                                                                          \
+    do {                                                                                                          \
+        if (prep_lds(c, k_solve_dynamics<FL>, lds)) return -1;                                                    \
+        HIPCHK(c, hipEventRecord(c->ev0, c->stream));                                                             \
+        if (c->r_npair)                                                                                           \
+            hipLaunchKernelGGL(k_solve_dynamics<FL>, dim3((unsigned)c->r_npair), dim3(BLOCK), lds, c->stream, T, A); \
+    } while (0)
+    static const bool wide = getenv("RAFTX_WIDE") != nullptr;   // tuning knob (register budget of the lean kernel)
+    if (need == 0 && wide)
+        LAUNCH_SOLVE(KF_WIDE);
+    else if (need == 0)
+        LAUNCH_SOLVE(0);
+    else if ((need & ~(KF_OUTZ | KF_OUTF | KF_MULTI)) == 0)
+        LAUNCH_SOLVE(KF_OUTZ | KF_OUTF | KF_MULTI);
+    else
+        LAUNCH_SOLVE(KF_ALL);
+#undef LAUNCH_SOLVE
     return finish_timed(c);
 }
 
@@ -1169,6 +575,33 @@ extern "C" int raftx_solve_system(raftx_ctx *c, int nSys, int nUnit, int nRhs, i
     }
     if (finish_timed(c)) return -2;
     if (nSys) D2H(c, Xi, dX, nf * sizeof(cplx));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+// ------------------------------------------------------------------ diagnostics
+__global__ void k_debug_math(int n, const double *__restrict__ x, double *__restrict__ s, double *__restrict__ c,
+                             double *__restrict__ e) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) {
+        fast_sincos(x[i], s[i], c[i]);
+        e[i] = fast_exp(x[i]);
+    }
+}
+
+extern "C" int raftx_debug_math(raftx_ctx *c, int n, const double *x, double *sin_out, double *cos_out, double *exp_out) {
+    if (!c || n < 0 || !x || !sin_out || !cos_out || !exp_out) return -1;
+    HIPCHK(c, hipSetDevice(c->device));
+    Scratch sc(c);
+    double *dx = sc.alloc<double>(n), *ds = sc.alloc<double>(n), *dc = sc.alloc<double>(n), *de = sc.alloc<double>(n);
+    if (n && (!dx || !ds || !dc || !de)) FAIL(c, "debug_math: device allocation failed");
+    if (n) {
+        H2D(c, dx, x, n * sizeof(double));
+        hipLaunchKernelGGL(k_debug_math, dim3((n + 255) / 256), dim3(256), 0, c->stream, n, dx, ds, dc, de);
+        D2H(c, sin_out, ds, n * sizeof(double));
+        D2H(c, cos_out, dc, n * sizeof(double));
+        D2H(c, exp_out, de, n * sizeof(double));
+    }
     HIPCHK(c, hipStreamSynchronize(c->stream));
     return 0;
 }

@@ -31,7 +31,12 @@ Record layout (doubles; see include/raftx.h RAFTX_F_*):
   25      rhoV         rho*v_side (multiplies the complex Cm of the MCF table)
   26      member index (diagnostic)
   27      strip index within member (diagnostic)
-  28..31  reserved (0)
+  28      run hint STEP: this strip = previous strip + STEP*UNIT*q (1..4), 0 = run start
+  29      run hint UNIT: smallest strip spacing of the member [m]
+  30..31  reserved (0)
+The run hints let the device advance the wave kinematics along a member with
+rotors instead of re-evaluating sincos/exp per strip; they are verified against
+x,y,z when uploaded (include/raftx.h) and ignored by the oracle.
 """
 import numpy as np
 
@@ -41,6 +46,8 @@ F_Q, F_P1, F_P2 = 6, 9, 12
 F_IQ, F_IP1, F_IP2, F_AI = 15, 16, 17, 18
 F_DQ, F_DP1, F_DP2, F_DEND = 19, 20, 21, 22
 F_CIRC, F_MCF, F_RHOV, F_MEM, F_IL = 23, 24, 25, 26, 27
+F_STEP, F_UNIT = 28, 29
+MAX_RUN = 16
 
 
 class UnsupportedFOWT(Exception):
@@ -107,11 +114,25 @@ def pack_member(mem, imem, rho, k_array=None, arm_node=None):
     c_drag = np.sqrt(8 / np.pi)
 
     recs, cms = [], []
-    for il in range(mem.ns):
+    wet = [il for il in range(mem.ns) if np.asarray(mem.r[il], dtype=float)[2] < 0]   # raft_member.py:1979,2058
+    gaps = [float(mem.ls[b]) - float(mem.ls[a]) for a, b in zip(wet[:-1], wet[1:]) if b == a + 1]
+    gaps = [g for g in gaps if g > 0]
+    unit = min(gaps) if gaps else 0.0
+    run = 0
+    prev_il = None
+    for il in wet:
         r = np.asarray(mem.r[il], dtype=float)
-        if not (r[2] < 0):                       # raft_member.py:1979,2058
-            continue
         rec = np.zeros(NFIELD)
+        step = 0
+        if prev_il is not None and il == prev_il + 1 and unit > 0 and run < MAX_RUN:
+            ratio = (float(mem.ls[il]) - float(mem.ls[prev_il])) / unit
+            m = int(round(ratio))
+            if 1 <= m <= 4 and abs(ratio - m) < 1e-9:
+                step = m
+        run = run + 1 if step else 0
+        prev_il = il
+        rec[F_STEP] = step
+        rec[F_UNIT] = unit
         rec[F_X:F_X + 3] = r
         rec[F_AX:F_AX + 3] = (r - r_node) + arm_node
         rec[F_Q:F_Q + 3] = q

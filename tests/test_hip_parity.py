@@ -218,3 +218,97 @@ def test_solve_system_parity(hip_ctx, oracle_ctx, nUnit, nRhs, nw, coupled):
                 A += -w[i] ** 2 * Mc[s] + 1j * w[i] * Bc[s] + Cc[s]
             X = np.linalg.solve(A, F[s, :, :, i].T).T
             assert rel_err(Xh[s, :, :, i], X) < 1e-9
+
+
+def test_device_sincos_exp_accuracy(hip_ctx):
+    """The kernels' own straight-line fp64 sincos/exp vs libm: <= 4 ulp-ish over the problem's range."""
+    rng = np.random.default_rng(0)
+    x = np.concatenate([rng.uniform(-50, 50, 20000), rng.uniform(-5000, 5000, 20000),
+                        np.linspace(-1e-3, 1e-3, 101), [0.0, np.pi / 4, -np.pi / 4, np.pi / 2, 1e5, -1e5]])
+    s, c, _ = hip_ctx.debug_math(x)
+    assert np.max(np.abs(s - np.sin(x))) < 4e-16
+    assert np.max(np.abs(c - np.cos(x))) < 4e-16
+    xe = np.concatenate([rng.uniform(-700, 0, 20000), rng.uniform(0, 60, 20000), [0.0, -1e-300, 1e-9, -745.0]])
+    _, _, e = hip_ctx.debug_math(xe)
+    ref = np.exp(np.maximum(xe, -740.0))
+    assert np.max(np.abs(e - ref) / ref) < 5e-16
+
+
+def _member_run_table(rng, n_members=6, n_per=14):
+    """Strips laid out along straight members with (1,2,4)-multiples of a unit spacing:
+    exercises the rotor recurrence (RAFTX_F_STEP/UNIT) incl. vertical and horizontal members."""
+    from raft_amd import strips as st
+    base = random_strips(rng, n_members * n_per)
+    rec = base.strips
+    for mbr in range(n_members):
+        A = np.array([rng.uniform(-40, 40), rng.uniform(-40, 40), rng.uniform(-28, -22)])
+        if mbr == 0:
+            q = np.array([0.0, 0.0, 1.0])
+        elif mbr == 1:
+            q = np.array([np.cos(0.7), np.sin(0.7), 0.0])
+        else:
+            q = rng.normal(size=3)
+            q[2] = abs(q[2]) * 0.1
+            q /= np.linalg.norm(q)
+        B = np.linalg.qr(np.column_stack([q, rng.normal(size=3), rng.normal(size=3)]))[0]
+        p1 = B[:, 1] - q * (q @ B[:, 1])
+        p1 /= np.linalg.norm(p1)
+        p2 = np.cross(q, p1)
+        unit = rng.uniform(0.2, 0.6)
+        pos = 0.0
+        for j in range(n_per):
+            i = mbr * n_per + j
+            step = 0 if j == 0 else int(rng.choice([1, 2, 2, 4]))
+            pos += step * unit
+            r = A + pos * q
+            rec[i, st.F_AX:st.F_AX + 3] += r - rec[i, st.F_X:st.F_X + 3]
+            rec[i, st.F_X:st.F_X + 3] = r
+            rec[i, st.F_Q:st.F_Q + 3] = q
+            rec[i, st.F_P1:st.F_P1 + 3] = p1
+            rec[i, st.F_P2:st.F_P2 + 3] = p2
+            rec[i, st.F_STEP] = step
+            rec[i, st.F_UNIT] = unit
+        assert rec[mbr * n_per + n_per - 1, st.F_X + 2] < 0, "synthetic member left the water"
+    return base
+
+
+def test_member_runs_use_rotors_and_match_exact_evaluation(hip_ctx, oracle_ctx):
+    rng = np.random.default_rng(21)
+    tables = [_member_run_table(rng) for _ in range(3)]
+    mats = random_matrices(rng, 3)
+    cases = synthetic_cases(rng, 2, 2, 200)
+    _both(hip_ctx, oracle_ctx, tables, mats, cases)
+    assert rel_err(hip_ctx.excitation(), oracle_ctx.excitation()) < TOL
+    oh = hip_ctx.solve_dynamics(8, want_B=True, want_F=True)
+    oo = oracle_ctx.solve_dynamics(8, want_B=True, want_F=True)
+    assert np.array_equal(oh["niter"], oo["niter"])
+    for d in range(3):
+        assert group_rel_err(oh["Xi"][d], oo["Xi"][d]) < TOL
+    assert rel_err(oh["F_wave"], oo["F_wave"]) < TOL
+    # the same tables with the hints stripped (every strip evaluated exactly) agree to round-off
+    from raft_amd import strips as st
+    from raft_amd.strips import StripTable
+    plain = []
+    for t in tables:
+        r = t.strips.copy()
+        r[:, st.F_STEP] = 0
+        plain.append(StripTable(r))
+    M0, B0, C0, _ = mats
+    hip_ctx.upload_designs(plain, M0, B0, C0, 200)
+    op = hip_ctx.solve_dynamics(8)
+    for d in range(3):
+        assert group_rel_err(op["Xi"][d], oh["Xi"][d]) < 1e-12
+
+
+def test_bad_run_hints_are_demoted_not_trusted(hip_ctx, oracle_ctx):
+    """A wrong STEP/UNIT hint must not change results (verified at upload)."""
+    from raft_amd import strips as st
+    rng = np.random.default_rng(22)
+    t = _member_run_table(rng, 3, 10)
+    t.strips[5, st.F_STEP] = 3          # inconsistent with the actual spacing
+    t.strips[17, st.F_UNIT] = 9.0
+    t.strips[0, st.F_STEP] = 2          # first strip can never be a step
+    mats = random_matrices(rng, 1)
+    cases = synthetic_cases(rng, 1, 1, 64)
+    _both(hip_ctx, oracle_ctx, [t], mats, cases)
+    assert rel_err(hip_ctx.excitation(), oracle_ctx.excitation()) < TOL
