@@ -12,6 +12,7 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", "-fno
 
 def build(force=False, verbose=False, extra=()):
     deps = [SRC, os.path.join(HERE, "..", "..", "include", "raftx.h"), os.path.abspath(__file__)]
+    deps += [os.path.join(HERE, f) for f in os.listdir(HERE) if f.endswith(".h")]
     if (not force) and os.path.exists(OUT) and all(os.path.getmtime(OUT) >= os.path.getmtime(d) for d in deps):
         return OUT
     hipcc = os.environ.get("HIPCC", "hipcc")

@@ -3,14 +3,15 @@
 // Hot path of WISDEM/RAFT: Morison strip sweep + stochastic drag linearisation
 // fixed point + per-frequency 6x6 complex solve (raft/raft_model.py:994-1236,
 // raft/raft_fowt.py:1732-1957, raft/raft_member.py:1899-2152), written
-// directly for CDNA4: fp64 VALU, wave64, one 256-thread workgroup per
-// (design, sea state), one lane per frequency bin.
+// directly for CDNA4: fp64 VALU, wave64, one workgroup per (design, sea state),
+// NB frequency bins per lane.
 //
 // Mapping:
 //   * frequency is the contiguous axis of every reference array, so lane <-> w
 //     makes every global load/store of a [6,nw] / [6,6,nw] slab coalesced;
-//   * strip records (256 B each) are wave-uniform: they are staged once per
-//     workgroup into LDS and read as broadcasts, never per lane from HBM;
+//   * strip records (256 B each) are wave-uniform: the kernels read them with
+//     scalar loads (constant cache -> SGPRs) and use them as the scalar operand
+//     of v_fma_f64, amortised over the NB bins a lane owns;
 //   * the only cross-frequency couplings -- the per-strip vRMS sums
 //     (raft_member.py:2084-2090, helpers.py:684) and the convergence test
 //     (raft_model.py:1104) -- go through per-wave LDS transposition tiles
@@ -31,7 +32,7 @@
 
 #include "../../include/raftx.h"
 
-#include "raftx_device.h"
+#include "raftx_kernels.h"
 
 // Coupled array solve (raft_model.py:1164-1236): one 64-lane workgroup per
 // (system, bin); the augmented matrix [Z_sys | F] lives in LDS, lane r owns
@@ -131,6 +132,7 @@ struct raftx_ctx {
     int nw_designs;
 };
 
+#define MAX_NW 2048
 #define HIPCHK(ctx, call)                                                                              \
     do {                                                                                               \
         hipError_t e_ = (call);                                                                        \
@@ -201,8 +203,8 @@ extern "C" void raftx_ctx_destroy(raftx_ctx *c) {
 extern "C" const char *raftx_last_error(raftx_ctx *c) { return c ? c->err : "null ctx"; }
 extern "C" double raftx_last_kernel_ms(raftx_ctx *c) { return c ? c->last_ms : 0.0; }
 
-template <typename Tp>
-static int upload(raftx_ctx *c, std::vector<void *> &bag, const Tp *host, size_t n, const Tp **dev) {
+template <typename Tp, typename Dp>
+static int upload(raftx_ctx *c, std::vector<void *> &bag, const Tp *host, size_t n, Dp *dev) {
     *dev = nullptr;
     if (!host || n == 0) return 0;
     void *p = nullptr;
@@ -229,41 +231,91 @@ extern "C" int raftx_upload_designs(raftx_ctx *c, int nDesign, const int64_t *st
         if (S < 0) FAIL(c, "strip offsets not monotone at design %d", d);
         if (S > maxS) maxS = (int)S;
     }
-    // The run hints (RAFTX_F_STEP / RAFTX_F_UNIT) only accelerate the wave-kinematics
-    // evaluation; verify each against the absolute strip positions and demote anything
-    // inconsistent to an exact evaluation, so a bad hint can never change results.
-    std::vector<double> clean(strips, strips + (size_t)stripOffsets[nDesign] * NF);
+    // Device strip table.  Straight runs of equally spaced strips (members) are detected here,
+    // from the absolute positions alone, so that the kernels can advance the wave kinematics
+    // along a run with rotors instead of re-evaluating sincos/exp per strip.  The optional
+    // RAFTX_F_STEP / RAFTX_F_UNIT hints of the ABI record are not trusted (nor needed).
+    std::vector<double> dsv((size_t)stripOffsets[nDesign] * DS_N, 0.0);
+    std::vector<int> dsf((size_t)stripOffsets[nDesign], 0);
     for (int d = 0; d < nDesign; d++) {
-        int run = 0;
-        for (int64_t s = stripOffsets[d]; s < stripOffsets[d + 1]; s++) {
-            double *r = clean.data() + (size_t)s * NF;
-            double unit = r[RAFTX_F_UNIT];
-            if (!(unit > 0.0) || !std::isfinite(unit)) unit = 0.0;
-            r[RAFTX_F_UNIT] = unit;
-            int m = (int)r[RAFTX_F_STEP];
-            bool ok = (s > stripOffsets[d]) && m >= 1 && m <= 4 && (double)m == r[RAFTX_F_STEP] && unit > 0.0 && run < 24;
-            if (ok) {
-                const double *p = r - NF;
-                ok = p[RAFTX_F_UNIT] == unit;
-                for (int j = 0; j < 3 && ok; j++) {
-                    ok = p[RAFTX_F_Q + j] == r[RAFTX_F_Q + j];
-                    double pred = p[RAFTX_F_X + j] + (double)m * unit * r[RAFTX_F_Q + j];
-                    if (std::fabs(pred - r[RAFTX_F_X + j]) > 1e-10 * (1.0 + std::fabs(r[RAFTX_F_X + j]))) ok = false;
+        const int64_t i0 = stripOffsets[d], i1 = stripOffsets[d + 1];
+        int64_t s = i0;
+        while (s < i1) {
+            // maximal collinear sequence [s, e): same q, displacement along +q
+            const double *r0 = strips + (size_t)s * NF;
+            int64_t e = s + 1;
+            std::vector<double> proj;
+            while (e < i1 && (e - s) < 64) {
+                const double *pr = strips + (size_t)(e - 1) * NF, *cr = strips + (size_t)e * NF;
+                bool same = true;
+                double dv[3], pj = 0.0;
+                for (int j = 0; j < 3; j++) {
+                    same = same && (pr[RAFTX_F_Q + j] == cr[RAFTX_F_Q + j]);
+                    dv[j] = cr[RAFTX_F_X + j] - pr[RAFTX_F_X + j];
+                    pj += dv[j] * cr[RAFTX_F_Q + j];
                 }
+                if (!same || !(pj > 0.0) || !std::isfinite(pj)) break;
+                double perp2 = 0.0, scale = 1.0;
+                for (int j = 0; j < 3; j++) {
+                    double t = dv[j] - pj * cr[RAFTX_F_Q + j];
+                    perp2 += t * t;
+                    scale += std::fabs(cr[RAFTX_F_X + j]);
+                }
+                if (std::sqrt(perp2) > 1e-10 * scale) break;
+                proj.push_back(pj);
+                e++;
             }
-            if (ok) {
-                run++;
-            } else {
-                r[RAFTX_F_STEP] = 0.0;
-                run = 0;
+            double unit = 0.0;
+            for (double pj : proj) unit = (unit == 0.0 || pj < unit) ? pj : unit;
+            // emit records; break the run wherever a step is not 1 or 2 units (re-anchored exactly)
+            for (int64_t i = s; i < e; i++) {
+                const double *rec = strips + (size_t)i * NF;
+                double *o = dsv.data() + (size_t)i * DS_N;
+                int m = 0;
+                if (i > s && unit > 0.0) {
+                    double ratio = proj[i - s - 1] / unit;
+                    int mi = (int)std::llround(ratio);
+                    if (mi >= 1 && mi <= 2 && std::fabs(ratio - mi) < 1e-9) {
+                        // verify the prediction from the previous strip
+                        const double *pr = strips + (size_t)(i - 1) * NF;
+                        bool ok = true;
+                        for (int j = 0; j < 3; j++) {
+                            double pred = pr[RAFTX_F_X + j] + (double)mi * unit * rec[RAFTX_F_Q + j];
+                            if (std::fabs(pred - rec[RAFTX_F_X + j]) > 1e-10 * (1.0 + std::fabs(rec[RAFTX_F_X + j]))) ok = false;
+                        }
+                        if (ok) m = mi;
+                    }
+                }
+                dsf[(size_t)i] = m | (rec[RAFTX_F_CIRC] != 0.0 ? DSI_CIRC : 0);
+                o[DS_MCF] = rec[RAFTX_F_MCF];
+                for (int j = 0; j < 3; j++) {
+                    o[DS_X + j] = rec[RAFTX_F_X + j];
+                    o[DS_U + j] = unit * rec[RAFTX_F_Q + j];
+                    o[DS_A + j] = rec[RAFTX_F_AX + j];
+                    o[DS_Q + j] = rec[RAFTX_F_Q + j];
+                    o[DS_P1 + j] = rec[RAFTX_F_P1 + j];
+                    o[DS_P2 + j] = rec[RAFTX_F_P2 + j];
+                }
+                o[DS_IQ] = rec[RAFTX_F_IQ];
+                o[DS_IQ + 1] = rec[RAFTX_F_IP1];
+                o[DS_IQ + 2] = rec[RAFTX_F_IP2];
+                o[DS_IQ + 3] = rec[RAFTX_F_AI];
+                o[DS_IQ + 4] = rec[RAFTX_F_RHOV];
+                o[DS_DQ] = rec[RAFTX_F_DQ];
+                o[DS_DQ + 1] = rec[RAFTX_F_DP1];
+                o[DS_DQ + 2] = rec[RAFTX_F_DP2];
+                o[DS_DQ + 3] = rec[RAFTX_F_DEND];
             }
+            (void)r0;
+            s = e;
         }
     }
     DevTables &T = c->T;
     T.nDesign = nDesign;
     int rc = 0;
     rc |= upload(c, c->design_allocs, stripOffsets, (size_t)nDesign + 1, &T.off);
-    rc |= upload(c, c->design_allocs, clean.data(), clean.size(), &T.strips);
+    rc |= upload(c, c->design_allocs, dsv.data(), dsv.size(), &T.ds);
+    rc |= upload(c, c->design_allocs, dsf.data(), dsf.size(), &T.dsi);
     rc |= upload(c, c->design_allocs, M0, (size_t)nDesign * 36, &T.M0);
     rc |= upload(c, c->design_allocs, B0, (size_t)nDesign * 36, &T.B0);
     rc |= upload(c, c->design_allocs, C0, (size_t)nDesign * 36, &T.C0);
@@ -287,7 +339,7 @@ extern "C" int raftx_upload_cases(raftx_ctx *c, int nCase, int nHead, int nw, co
                                   double depth, double rho, double g, const double *zeta, const double *beta) {
     if (!c) return -1;
     if (nCase < 0 || nHead < 1 || nw < 1 || !w || !k || !zeta || !beta) FAIL(c, "upload_cases: bad arguments");
-    if (nw > BLOCK) FAIL(c, "nw=%d exceeds the %d bins per workgroup supported by this build", nw, BLOCK);
+    if (nw > MAX_NW) FAIL(c, "nw=%d exceeds the %d bins per workgroup supported by this build", nw, MAX_NW);
     HIPCHK(c, hipSetDevice(c->device));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     free_list(c->case_allocs);
@@ -298,8 +350,9 @@ extern "C" int raftx_upload_cases(raftx_ctx *c, int nCase, int nHead, int nw, co
     for (int i = 0; i < nw; i++) {
         double kh = k[i] * depth;
         if (k[i] == 0.0) {
-            mode[i] = 2;
-            csh[i] = cch[i] = e2kh[i] = 0.0;
+            mode[i] = 2;                  // Sh = 1, Ch = Cc = 99999: the kernels set P + Q = 99999, P - Q = 1
+            csh[i] = cch[i] = 1.0;
+            e2kh[i] = 0.0;
         } else if (kh > 89.4) {   // deep-water branch of helpers.py:215-218: Sh = Ch = e^{kz}, Cc = e^{kz} + e^{-k(z+2h)}
             mode[i] = 1;
             csh[i] = cch[i] = 1.0;
@@ -335,14 +388,48 @@ extern "C" int raftx_upload_cases(raftx_ctx *c, int nCase, int nHead, int nw, co
 
 #define LDS_LIMIT (160 * 1024)
 
+// Launch shape: NB bins per lane x threads per workgroup (one workgroup per pair).
+//   nw <= 256 : one wave64 per pair, NB = ceil(nw/64)   (no s_barrier anywhere in the kernel)
+//   larger    : 512 threads with NB = 2..4
+// RAFTX_SHAPE="nb,threads" overrides (tuning only; must be one of the instantiated shapes).
+struct Shape {
+    int nb, threads;
+};
+#define SHAPES(X) X(1, 64, 1) X(2, 64, 1) X(3, 64, 1) X(4, 64, 1) X(2, 128, 2) X(1, 256, 2) X(2, 512, 1) X(3, 512, 1) X(4, 512, 1)
+static bool shape_ok(Shape sh, int nw) {
+#define X(NB_, MT_, MB_) if (sh.nb == NB_ && sh.threads == MT_) return (long)NB_ * MT_ >= nw;
+    SHAPES(X)
+#undef X
+    return false;
+}
+static Shape pick_shape(int nw) {
+    static const char *env = getenv("RAFTX_SHAPE");
+    if (env) {
+        Shape sh = {0, 0};
+        if (sscanf(env, "%d,%d", &sh.nb, &sh.threads) == 2 && shape_ok(sh, nw)) return sh;
+    }
+    if (nw <= 256) return {(nw + 63) / 64, 64};
+    int nb = (nw + 511) / 512;
+    return {nb < 2 ? 2 : nb, 512};
+}
+
 template <typename K>
 static int prep_lds(raftx_ctx *c, K kernel, size_t bytes) {
-    if (bytes > LDS_LIMIT) FAIL(c, "a design has %d submerged strips: exceeds the LDS-resident strip budget", c->maxS);
+    if (bytes > LDS_LIMIT)
+        FAIL(c, "a design has %d submerged strips / nw=%d: %zu B of LDS needed, 160 KiB available", c->maxS, c->T.nw, bytes);
     if (bytes > 64 * 1024)
         HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                       (int)bytes));
     return 0;
 }
+
+// expands BODY(NB, MAXT, MINB) for the shape sh
+#define DISPATCH_SHAPE(sh, BODY)                                                     \
+    do {                                                                             \
+        bool hit_ = false;                                                           \
+        SHAPES(DISPATCH_ONE_)                                                        \
+        if (!hit_) FAIL(c, "no kernel for shape %d x %d", (sh).nb, (sh).threads);    \
+    } while (0)
 
 static int check_ready(raftx_ctx *c) {
     if (!c) return -1;
@@ -392,11 +479,16 @@ extern "C" int raftx_excitation(raftx_ctx *c, raftx_c128 *F_iner) {
     Scratch sc(c);
     cplx *dF = sc.alloc<cplx>(n);
     if (n && !dF) FAIL(c, "excitation: device allocation failed");
-    if (prep_lds(c, k_excitation, lds_bytes(c->maxS, c->T.nw))) return -1;
+    const Shape sh = pick_shape(T.nw);
     HIPCHK(c, hipEventRecord(c->ev0, c->stream));
-    if (npair)
-        hipLaunchKernelGGL(k_excitation, dim3((unsigned)(npair * T.nHead)), dim3(BLOCK), lds_bytes(c->maxS, c->T.nw), c->stream, T,
-                           dF);
+#define DISPATCH_ONE_(NB_, MT_, MB_)                                                                                  \
+    if (!hit_ && sh.nb == NB_ && sh.threads == MT_) {                                                                 \
+        hit_ = true;                                                                                                  \
+        hipLaunchKernelGGL((k_excitation<NB_, MT_, MB_>), dim3((unsigned)(npair * T.nHead)), dim3(sh.threads), 0,     \
+                           c->stream, T, dF);                                                                         \
+    }
+    if (npair) DISPATCH_SHAPE(sh, _);
+#undef DISPATCH_ONE_
     if (finish_timed(c)) return -2;
     if (n) D2H(c, F_iner, dF, n * sizeof(cplx));
     HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -415,11 +507,19 @@ extern "C" int raftx_linearize(raftx_ctx *c, const raftx_c128 *Xi, double *B_dra
     cplx *dF = F_drag ? sc.alloc<cplx>(npair * T.nHead * 6 * T.nw) : nullptr;
     if (npair && (!dXi || (B_drag && !dB) || (F_drag && !dF))) FAIL(c, "linearize: device allocation failed");
     if (npair) H2D(c, dXi, Xi, npair * 6 * T.nw * sizeof(cplx));
-    if (prep_lds(c, k_linearize, lds_bytes(c->maxS, c->T.nw))) return -1;
-    HIPCHK(c, hipEventRecord(c->ev0, c->stream));
-    if (npair)
-        hipLaunchKernelGGL(k_linearize, dim3((unsigned)npair), dim3(BLOCK), lds_bytes(c->maxS, c->T.nw), c->stream, T, dXi, dB,
-                           dF);
+    const Shape sh = pick_shape(T.nw);
+    const size_t lds = lds_bytes(c->maxS, T.nw, sh.threads / 64);
+#define DISPATCH_ONE_(NB_, MT_, MB_)                                                                                  \
+    if (!hit_ && sh.nb == NB_ && sh.threads == MT_) {                                                                 \
+        hit_ = true;                                                                                                  \
+        if (prep_lds(c, k_linearize<NB_, MT_, MB_>, lds)) return -1;                                                  \
+        HIPCHK(c, hipEventRecord(c->ev0, c->stream));                                                                 \
+        if (npair)                                                                                                    \
+            hipLaunchKernelGGL((k_linearize<NB_, MT_, MB_>), dim3(grid_for_pairs(npair)), dim3(sh.threads), lds,      \
+                               c->stream, T, dXi, dB, dF);                                                            \
+    }
+    DISPATCH_SHAPE(sh, _);
+#undef DISPATCH_ONE_
     if (finish_timed(c)) return -2;
     if (dB) D2H(c, B_drag, dB, npair * 36 * sizeof(double));
     if (dF) D2H(c, F_drag, dF, npair * T.nHead * 6 * T.nw * sizeof(cplx));
@@ -489,26 +589,27 @@ extern "C" int raftx_solve_dynamics_device(raftx_ctx *c, int nIter, double tol, 
     A.F_wave = (want_mask & RAFTX_WANT_FWAVE) ? c->rFw : nullptr;
     A.Z = (want_mask & RAFTX_WANT_Z) ? c->rZ : nullptr;
     if (F_extra && c->r_nx) H2D(c, c->rFe, F_extra, c->r_nx * sizeof(cplx));
-    // pick the leanest specialisation that covers what this call needs
-    int need = (T.MBw ? KF_FDEP : 0) | (A.Z ? KF_OUTZ : 0) | (A.F_wave ? KF_OUTF : 0) | (A.F_extra ? KF_EXTRA : 0) |
-               (T.cm ? KF_MCF : 0) | (T.nHead > 1 ? KF_MULTI : 0);
-    const size_t lds = lds_bytes(c->maxS, T.nw);
-#define LAUNCH_SOLVE(FL)                                                                                          \
-    do {                                                                                                          \
-        if (prep_lds(c, k_solve_dynamics<FL>, lds)) return -1;                                                    \
-        HIPCHK(c, hipEventRecord(c->ev0, c->stream));                                                             \
-        if (c->r_npair)                                                                                           \
-            hipLaunchKernelGGL(k_solve_dynamics<FL>, dim3((unsigned)c->r_npair), dim3(BLOCK), lds, c->stream, T, A); \
+    // the lean specialisation (no optional inputs / outputs) is the sweep path
+    const int need = (T.MBw ? KF_FDEP : 0) | (A.Z ? KF_OUTZ : 0) | (A.F_wave ? KF_OUTF : 0) | (A.F_extra ? KF_EXTRA : 0) |
+                     (T.cm ? KF_MCF : 0) | (T.nHead > 1 ? KF_MULTI : 0);
+    const Shape sh = pick_shape(T.nw);
+    const size_t lds = lds_bytes(c->maxS, T.nw, sh.threads / 64);
+#define LAUNCH_SOLVE(NB_, MT_, MB_, FL)                                                                              \
+    do {                                                                                                             \
+        if (prep_lds(c, k_solve_dynamics<NB_, FL, MT_, MB_>, lds)) return -1;                                        \
+        HIPCHK(c, hipEventRecord(c->ev0, c->stream));                                                                \
+        if (c->r_npair)                                                                                              \
+            hipLaunchKernelGGL((k_solve_dynamics<NB_, FL, MT_, MB_>), dim3(grid_for_pairs(c->r_npair)),              \
+                               dim3(sh.threads), lds, c->stream, T, A);                                              \
     } while (0)
-    static const bool wide = getenv("RAFTX_WIDE") != nullptr;   // tuning knob (register budget of the lean kernel)
-    if (need == 0 && wide)
-        LAUNCH_SOLVE(KF_WIDE);
-    else if (need == 0)
-        LAUNCH_SOLVE(0);
-    else if ((need & ~(KF_OUTZ | KF_OUTF | KF_MULTI)) == 0)
-        LAUNCH_SOLVE(KF_OUTZ | KF_OUTF | KF_MULTI);
-    else
-        LAUNCH_SOLVE(KF_ALL);
+#define DISPATCH_ONE_(NB_, MT_, MB_)                                                                                 \
+    if (!hit_ && sh.nb == NB_ && sh.threads == MT_) {                                                                \
+        hit_ = true;                                                                                                 \
+        if (need == 0) LAUNCH_SOLVE(NB_, MT_, MB_, 0);                                                               \
+        else LAUNCH_SOLVE(NB_, MT_, MB_, KF_ALL);                                                                    \
+    }
+    DISPATCH_SHAPE(sh, _);
+#undef DISPATCH_ONE_
 #undef LAUNCH_SOLVE
     return finish_timed(c);
 }

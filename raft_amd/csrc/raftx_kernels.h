@@ -1,0 +1,1081 @@
+// raftx_kernels.h -- gfx950 device code of the RAFT hot path, kernel generation 4
+// (included by raftx_hip.hip).
+//
+// Work decomposition:
+//   workgroup <-> one (design, sea state) pair; 64*NWV threads (NWV waves, run time)
+//   lane      <-> NB frequency bins (compile time, 1..4): bin(j) = j*blockDim.x + tid,
+//                 so every global access of a [.,nw] slab is coalesced
+//   strip loop <-> sequential; the strip record index is wave-uniform, so the static
+//                 strip constants are read with SCALAR loads (s_load_dwordx8/16 through
+//                 the constant cache) straight into SGPRs and feed v_fma_f64 as the
+//                 scalar operand: no LDS bandwidth, no VGPRs, amortised over the NB
+//                 bins of the lane.  Only data produced inside the workgroup (linearised
+//                 drag vectors U,V, XiLast, reduction tiles) lives in LDS.
+//
+// Maths (reference lines in the function comments): per strip s and bin w the Airy
+// kinematics reduce to two phasors
+//   t1 = w zeta e^{-i k xi} cosh k(z+h)/sinh kh,   t2 = i w zeta e^{-i k xi} sinh k(z+h)/sinh kh
+// (helpers.py:201-228), u = (cb t1, sb t1, t2).  They are advanced strip-to-strip along
+// straight members by rotors (e^{-i k du}, e^{+-k dz}); run starts are evaluated exactly.
+// Runs are detected by the library at upload from the absolute strip positions.
+#pragma once
+
+#define NF RAFTX_NFIELD
+
+struct cplx {
+    double re, im;
+};
+__device__ __forceinline__ cplx cmul(cplx a, cplx b) { return {a.re * b.re - a.im * b.im, a.re * b.im + a.im * b.re}; }
+__device__ __forceinline__ cplx cscale(cplx a, double s) { return {a.re * s, a.im * s}; }
+__device__ __forceinline__ cplx cadd(cplx a, cplx b) { return {a.re + b.re, a.im + b.im}; }
+__device__ __forceinline__ cplx csub(cplx a, cplx b) { return {a.re - b.re, a.im - b.im}; }
+
+// ------------------------------------------------------------------ fp64 elementary functions
+// Straight-line sincos / exp for the moderate arguments of this problem
+// (|k xi| < 1e5, |k z| < 700): Cody-Waite reduction + Taylor polynomials whose
+// truncation error is < 2^-55 on the reduced interval.  No tables, no branches.
+__device__ __forceinline__ void fast_sincos(double x, double &s, double &c) {
+    const double two_over_pi = 6.36619772367581382433e-01;
+    const double pio2_1 = 1.57079632673412561417e+00;    // first 33 bits of pi/2
+    const double pio2_2 = 6.07710050630396597660e-11;    // second 33 bits
+    const double pio2_2t = 2.02226624879595063154e-21;   // pi/2 - (pio2_1 + pio2_2)
+    double fn = rint(x * two_over_pi);
+    double r = fma(-fn, pio2_1, x);
+    r = fma(-fn, pio2_2, r);
+    r = fma(-fn, pio2_2t, r);
+    int n = (int)fn;
+    double z = r * r;
+    double ps = -1.0 / 1307674368000.0;                  // -1/15!
+    ps = fma(ps, z, 1.0 / 6227020800.0);                 //  1/13!
+    ps = fma(ps, z, -1.0 / 39916800.0);                  // -1/11!
+    ps = fma(ps, z, 1.0 / 362880.0);                     //  1/9!
+    ps = fma(ps, z, -1.0 / 5040.0);                      // -1/7!
+    ps = fma(ps, z, 1.0 / 120.0);                        //  1/5!
+    ps = fma(ps, z, -1.0 / 6.0);                         // -1/3!
+    double sr = fma(r * z, ps, r);
+    double pc = 1.0 / 20922789888000.0;                  //  1/16!
+    pc = fma(pc, z, -1.0 / 87178291200.0);               // -1/14!
+    pc = fma(pc, z, 1.0 / 479001600.0);                  //  1/12!
+    pc = fma(pc, z, -1.0 / 3628800.0);                   // -1/10!
+    pc = fma(pc, z, 1.0 / 40320.0);                      //  1/8!
+    pc = fma(pc, z, -1.0 / 720.0);                       // -1/6!
+    pc = fma(pc, z, 1.0 / 24.0);                         //  1/4!
+    double cr = fma(z * z, pc, fma(-0.5, z, 1.0));
+    double ss = (n & 1) ? cr : sr;
+    double cc = (n & 1) ? sr : cr;
+    s = (n & 2) ? -ss : ss;
+    c = ((n + 1) & 2) ? -cc : cc;
+}
+
+__device__ __forceinline__ double fast_exp(double x) {
+    const double log2e = 1.44269504088896338700e+00;
+    const double ln2_hi = 6.93147180369123816490e-01;
+    const double ln2_lo = 1.90821492927058770002e-10;
+    x = fmin(fmax(x, -740.0), 700.0);
+    double fn = rint(x * log2e);
+    double r = fma(-fn, ln2_hi, x);
+    r = fma(-fn, ln2_lo, r);
+    double p = 1.0 / 6227020800.0;                       // 1/13!
+    p = fma(p, r, 1.0 / 479001600.0);
+    p = fma(p, r, 1.0 / 39916800.0);
+    p = fma(p, r, 1.0 / 3628800.0);
+    p = fma(p, r, 1.0 / 362880.0);
+    p = fma(p, r, 1.0 / 40320.0);
+    p = fma(p, r, 1.0 / 5040.0);
+    p = fma(p, r, 1.0 / 720.0);
+    p = fma(p, r, 1.0 / 120.0);
+    p = fma(p, r, 1.0 / 24.0);
+    p = fma(p, r, 1.0 / 6.0);
+    p = fma(p, r, 0.5);
+    p = fma(p, r, 1.0);
+    p = fma(p, r, 1.0);
+    return ldexp(p, (int)fn);
+}
+
+// ------------------------------------------------------------------ device tables
+// Device strip record (doubles), built at upload from the 32-double ABI record.
+#define DS_N 32
+#define DS_MCF 2     // -1 or row of the complex Cm table
+#define DS_X 4       // x, y, z (absolute)
+#define DS_U 7       // unit step vector of the run (unit * q)
+#define DS_A 10      // arm about the reduced-DOF reference point
+#define DS_Q 13
+#define DS_P1 16
+#define DS_P2 19
+#define DS_IQ 22     // Iq, Ip1, Ip2, a_i, rhoV
+#define DS_DQ 27     // dq, dp1, dp2, dend
+#define DSI_M 3
+#define DSI_CIRC 4
+
+struct DevTables {
+    int nDesign;
+    const int64_t *__restrict__ off;     // [nDesign+1]
+    const double *__restrict__ ds;       // [nStrips,DS_N] device strip records
+    const int *__restrict__ dsi;         // [nStrips] flags: bits 0-1 rotor steps from the previous strip (0 = run
+                                         // start, evaluated exactly; 1, 2 = unit steps), bit 2 circular section
+    const double *__restrict__ M0, *__restrict__ B0, *__restrict__ C0;   // [nDesign,36]
+    const double *__restrict__ MBw;      // [nDesign,2,36,nw] or null
+    const int64_t *__restrict__ cmoff;   // [nDesign+1] or null
+    const cplx *__restrict__ cm;         // [nRows,2,nw] or null
+    int nCase, nHead, nw;
+    const double *__restrict__ w, *__restrict__ k;    // [nw]
+    const double *__restrict__ csh, *__restrict__ cch, *__restrict__ e2kh;   // per-bin depth constants (host, libm)
+    const int *__restrict__ mode;        // 0 finite depth, 1 deep (k h > 89.4), 2 k == 0   (helpers.py:211-222)
+    const double *__restrict__ zeta;     // [nCase,nHead,nw]
+    const double *__restrict__ beta;     // [nCase,nHead]
+    double depth, rho, g;
+};
+
+// XCD-aware pair mapping: workgroups are dealt round-robin to the 8 XCDs, so give each
+// XCD a contiguous slab of pairs (the sea states of one design then share one L2).
+__device__ __forceinline__ int pair_of_block(int b, int npair) {
+    const int per = (npair + 7) >> 3;
+    return (b & 7) * per + (b >> 3);
+}
+static inline unsigned grid_for_pairs(size_t npair) { return (unsigned)(((npair + 7) / 8) * 8); }
+
+// ------------------------------------------------------------------ LDS layout
+#define TR_ROWS 16           // rows of a reduction tile
+#define TR_STRIDE 68         // doubles per row (4 segments of 17; 68 mod 16 == 4: conflict-free)
+#define SB 5                 // strips per reduction batch of pass A (3 rows each)
+
+struct Lds {
+    double *xl;      // [12][nxl]    XiLast (re/im split), nxl = nw rounded up to even
+    double *uv;      // [S][12]      linearised drag vectors of the current heading
+    double *vsq;     // [NWV][S][3]  per-wave sums over bins of |v_q|^2, |v_p1|^2 (|v_perp|^2), |v_p2|^2
+    double *bc;      // [S][3]       live linearised coefficients (kept for the other headings)
+    double *tile;    // [NWV][TR_ROWS][TR_STRIDE]
+    double *bdw;     // [NWV][24]    per-wave partials of the 21 unique B_drag entries
+    double *Bd;      // [36]
+    double *mat;     // [108]        M0, B0, C0
+    int nxl;
+};
+
+static __host__ __device__ inline int xl_row(int nw) { return (nw + 1) & ~1; }
+__device__ __forceinline__ Lds carve(double *base, int S, int nw, int nwv) {
+    Lds l;
+    l.nxl = xl_row(nw);
+    l.xl = base;
+    l.uv = l.xl + (size_t)12 * l.nxl;
+    l.vsq = l.uv + (size_t)S * 12;
+    l.bc = l.vsq + (size_t)nwv * S * 3;
+    l.tile = l.bc + (size_t)S * 3;
+    l.bdw = l.tile + (size_t)nwv * TR_ROWS * TR_STRIDE;
+    l.Bd = l.bdw + (size_t)nwv * 24;
+    l.mat = l.Bd + 36;
+    return l;
+}
+static size_t lds_bytes(int S, int nw, int nwv) {
+    return sizeof(double) * ((size_t)12 * xl_row(nw) + (size_t)S * (12 + 3 + 3 * nwv) + (size_t)nwv * (TR_ROWS * TR_STRIDE + 24) +
+                             36 + 108 + 2);
+}
+
+// LDS traffic between lanes of ONE wave needs no s_barrier (a wave's LDS instructions
+// execute in order); it only needs the compiler to keep the order.
+__device__ __forceinline__ void wave_lds_fence() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+__device__ __forceinline__ void wg_sync(bool multi) {
+    if (multi) __syncthreads();
+    else wave_lds_fence();
+}
+
+// quad butterflies on doubles (DPP quad_perm: pure VALU, no LDS crossbar)
+__device__ __forceinline__ double quad_xor(double v, const int ctrl_is_xor1) {
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    if (ctrl_is_xor1) {
+        lo = __builtin_amdgcn_mov_dpp(lo, 0xB1, 0xf, 0xf, true);   // quad_perm [1,0,3,2]
+        hi = __builtin_amdgcn_mov_dpp(hi, 0xB1, 0xf, 0xf, true);
+    } else {
+        lo = __builtin_amdgcn_mov_dpp(lo, 0x4E, 0xf, 0xf, true);   // quad_perm [2,3,0,1]
+        hi = __builtin_amdgcn_mov_dpp(hi, 0x4E, 0xf, 0xf, true);
+    }
+    return __hiloint2double(hi, lo);
+}
+
+// Sum `rows` (<= TR_ROWS) rows of this wave's tile over its 64 lanes.  Lane L wrote its
+// value of row r at tile[r*TR_STRIDE + tile_pos(L)].  Returns, on lanes with (L & 3) == 0,
+// the total of row L >> 2 (other lanes: undefined).
+__device__ __forceinline__ int tile_pos(int lane) { return (lane >> 4) * 17 + (lane & 15); }
+__device__ __forceinline__ double tile_reduce(const double *tile, int lane) {
+    const double *p = tile + (lane >> 2) * TR_STRIDE + (lane & 3) * 17;
+    double a0 = p[0], a1 = p[1], a2 = p[2], a3 = p[3];
+#pragma unroll
+    for (int e = 4; e < 16; e += 4) {
+        a0 += p[e];
+        a1 += p[e + 1];
+        a2 += p[e + 2];
+        a3 += p[e + 3];
+    }
+    double a = (a0 + a1) + (a2 + a3);
+    a += quad_xor(a, 1);
+    a += quad_xor(a, 0);
+    return a;
+}
+
+// ------------------------------------------------------------------ per-bin data
+template <int NB>
+struct Bins {
+    double k[NB], e2kh[NB];
+    double c1[NB];        // w * zeta0 * csh of the current heading (0 for inactive bins)
+    int mode[NB];
+    bool act[NB];
+    int iw[NB];           // clamped bin index (valid address even when inactive)
+};
+
+template <int NB>
+__device__ __forceinline__ void load_bins(const DevTables &T, Bins<NB> &b) {
+#pragma unroll
+    for (int j = 0; j < NB; j++) {
+        const int i = j * blockDim.x + threadIdx.x;
+        b.act[j] = i < T.nw;
+        b.iw[j] = b.act[j] ? i : 0;
+        b.k[j] = b.act[j] ? T.k[b.iw[j]] : 0.0;
+        b.e2kh[j] = T.e2kh[b.iw[j]];
+        b.mode[j] = b.act[j] ? T.mode[b.iw[j]] : 2;
+        b.c1[j] = 0.0;
+    }
+}
+template <int NB>
+__device__ __forceinline__ void set_heading_amp(const DevTables &T, Bins<NB> &b, int ic, int ih) {
+#pragma unroll
+    for (int j = 0; j < NB; j++) {
+        const double z0 = T.zeta[((size_t)ic * T.nHead + ih) * T.nw + b.iw[j]];
+        b.c1[j] = b.act[j] ? T.w[b.iw[j]] * z0 * T.csh[b.iw[j]] : 0.0;
+    }
+}
+
+// ------------------------------------------------------------------ wave kinematics along a run
+// State per bin: a = amp * e^{-i k xi_s};  P = e^{k z_s};  Q = e^{-k (z_s + 2h)}  (Q = 0 in the
+// deep-water branch, helpers.py:215-218, unless KEEPQ);  rotors of one and of two unit steps.
+template <int NB>
+struct Kin {
+    double ar[NB], ai[NB], P[NB], Q[NB];
+    double r1r[NB], r1i[NB], r1p[NB], r1q[NB];
+    double r2r[NB], r2i[NB], r2p[NB], r2q[NB];
+};
+
+// Run start: exact evaluation from the absolute position (helpers.py:201,211-222).
+//   amp[j] multiplies the phase factor (c1 for the velocity sweeps, 1 for the pressure sweep).
+template <int NB, bool KEEPQ>
+__device__ __forceinline__ void kin_start(Kin<NB> &K, const double *__restrict__ rec, const Bins<NB> &b,
+                                          const double (&amp)[NB], double cb, double sb) {
+    const double x = rec[DS_X], y = rec[DS_X + 1], z = rec[DS_X + 2];
+    const double ux = rec[DS_U], uy = rec[DS_U + 1], uz = rec[DS_U + 2];
+    const double xi = cb * x + sb * y;
+    const double du = cb * ux + sb * uy;
+#pragma unroll
+    for (int j = 0; j < NB; j++) {
+        double s, c;
+        fast_sincos(-(b.k[j] * xi), s, c);
+        K.ar[j] = amp[j] * c;
+        K.ai[j] = amp[j] * s;
+        const double kz = b.k[j] * z;
+        double P = fast_exp(kz);
+        double Q = b.e2kh[j] * fast_exp(-kz);
+        if (!KEEPQ) Q = (b.mode[j] == 1) ? 0.0 : Q;
+        // k == 0 (helpers.py:211-214): Sh = 1, Ch = Cc = 99999  <=>  P + Q = 99999, P - Q = 1 with csh = cch = 1
+        K.P[j] = (b.mode[j] == 2) ? 50000.0 : P;
+        K.Q[j] = (b.mode[j] == 2) ? 49999.0 : Q;
+    }
+    const bool rot = du != 0.0, dec = uz != 0.0;     // wave-uniform: vertical members skip the phase rotor,
+#pragma unroll                                       // horizontal ones the depth-decay rotors
+    for (int j = 0; j < NB; j++) {
+        double s = 0.0, c = 1.0, p = 1.0, q = 1.0;
+        if (rot) fast_sincos(-(b.k[j] * du), s, c);
+        if (dec) {
+            p = fast_exp(b.k[j] * uz);
+            q = fast_exp(-(b.k[j] * uz));
+        }
+        K.r1r[j] = c;
+        K.r1i[j] = s;
+        K.r2r[j] = c * c - s * s;
+        K.r2i[j] = 2.0 * c * s;
+        K.r1p[j] = p;
+        K.r1q[j] = q;
+        K.r2p[j] = p * p;
+        K.r2q[j] = q * q;
+    }
+}
+
+template <int NB>
+__device__ __forceinline__ void kin_step1(Kin<NB> &K) {
+#pragma unroll
+    for (int j = 0; j < NB; j++) {
+        const double t = K.ar[j] * K.r1r[j] - K.ai[j] * K.r1i[j];
+        K.ai[j] = K.ar[j] * K.r1i[j] + K.ai[j] * K.r1r[j];
+        K.ar[j] = t;
+        K.P[j] *= K.r1p[j];
+        K.Q[j] *= K.r1q[j];
+    }
+}
+template <int NB>
+__device__ __forceinline__ void kin_step2(Kin<NB> &K) {
+#pragma unroll
+    for (int j = 0; j < NB; j++) {
+        const double t = K.ar[j] * K.r2r[j] - K.ai[j] * K.r2i[j];
+        K.ai[j] = K.ar[j] * K.r2i[j] + K.ai[j] * K.r2r[j];
+        K.ar[j] = t;
+        K.P[j] *= K.r2p[j];
+        K.Q[j] *= K.r2q[j];
+    }
+}
+// advance to the strip described by (fl, rec) -- wave-uniform control flow
+template <int NB, bool KEEPQ>
+__device__ __forceinline__ void kin_advance(Kin<NB> &K, int fl, const double *__restrict__ rec, const Bins<NB> &b,
+                                            const double (&amp)[NB], double cb, double sb) {
+    const int m = fl & DSI_M;
+    if (m == 0) {
+        kin_start<NB, KEEPQ>(K, rec, b, amp, cb, sb);
+    } else if (m == 1) {
+        kin_step1(K);
+    } else {
+        kin_step2(K);
+    }
+}
+template <int NB>
+__device__ __forceinline__ void kin_reset(Kin<NB> &K) {
+#pragma unroll
+    for (int j = 0; j < NB; j++) {
+        K.ar[j] = 0.0; K.ai[j] = 0.0; K.P[j] = 1.0; K.Q[j] = 0.0;
+        K.r1r[j] = K.r2r[j] = K.r1p[j] = K.r1q[j] = K.r2p[j] = K.r2q[j] = 1.0;
+        K.r1i[j] = K.r2i[j] = 0.0;
+    }
+}
+
+// ------------------------------------------------------------------ strip sweeps
+// Inertial excitation of one heading (raft_member.py:1965-1991), ACCUMULATED into F:
+//   f3 = Imat ud + pDyn a_i q,  ud = i w u,  F += [f3 ; a x f3]     (helpers.py:468-483)
+// Imat = Iq qq^T + Ip1 p1p1^T + Ip2 p2p2^T (raft_member.py:1423-1448), or rhoV Cm(w) for
+// MacCamy-Fuchs strips (complex, per bin; raft_member.py:1415-1420).
+template <int NB, bool MCF>
+__device__ __forceinline__ void inertial_excitation(const DevTables &T, const double *__restrict__ ds,
+                                                    const int *__restrict__ dsi, int S, const cplx *__restrict__ cm,
+                                                    const Bins<NB> &b, int ic, int ih, double cb, double sb,
+                                                    cplx (&F)[NB][6]) {
+    double one[NB], w[NB], s1[NB], sp[NB], qm[NB];
+#pragma unroll
+    for (int j = 0; j < NB; j++) {
+        one[j] = 1.0;
+        w[j] = b.act[j] ? T.w[b.iw[j]] : 0.0;
+        s1[j] = b.c1[j];                                                   // w zeta0 csh
+        const double z0 = b.act[j] ? T.zeta[((size_t)ic * T.nHead + ih) * T.nw + b.iw[j]] : 0.0;
+        sp[j] = T.rho * T.g * z0 * T.cch[b.iw[j]];                         // rho g zeta0 / cosh kh scaling (helpers.py:231)
+        qm[j] = (b.mode[j] == 1) ? 0.0 : 1.0;                              // deep water: Sh = Ch = e^{kz}
+    }
+    Kin<NB> K;
+    kin_reset(K);
+#pragma unroll 1
+    for (int s = 0; s < S; s++) {
+        const double *__restrict__ rec = ds + (size_t)s * DS_N;
+        kin_advance<NB, true>(K, dsi[s], rec, b, one, cb, sb);
+        const double ax = rec[DS_A], ay = rec[DS_A + 1], az = rec[DS_A + 2];
+        const double ai_ = rec[DS_IQ + 3], rhoV = rec[DS_IQ + 4];
+        const int mcf = MCF ? (int)rec[DS_MCF] : -1;
+        double al[3], ga[3], I[3], n[3][3];
+#pragma unroll
+        for (int c = 0; c < 3; c++) {
+            n[c][0] = rec[DS_Q + 3 * c];
+            n[c][1] = rec[DS_Q + 3 * c + 1];
+            n[c][2] = rec[DS_Q + 3 * c + 2];
+            al[c] = n[c][0] * cb + n[c][1] * sb;
+            ga[c] = n[c][2];
+            I[c] = rec[DS_IQ + c];
+        }
+#pragma unroll
+        for (int j = 0; j < NB; j++) {
+            const double pq = K.P[j] + K.Q[j];
+            const double Qk = qm[j] * K.Q[j];
+            const double hs = s1[j] * (K.P[j] + Qk), hd = s1[j] * (K.P[j] - Qk);
+            const cplx t1 = {hs * K.ar[j], hs * K.ai[j]};
+            const cplx t2 = {-hd * K.ai[j], hd * K.ar[j]};
+            const double pp = sp[j] * pq;
+            const cplx pd = {pp * K.ar[j], pp * K.ai[j]};                  // rho g zeta_s Cc
+            cplx f3[3] = {{0, 0}, {0, 0}, {0, 0}};
+#pragma unroll
+            for (int c = 0; c < 3; c++) {
+                const cplx G = {al[c] * t1.re + ga[c] * t2.re, al[c] * t1.im + ga[c] * t2.im};   // n_c . u
+                const cplx a = {-w[j] * G.im, w[j] * G.re};                                       // n_c . ud
+                cplx g;
+                if (c == 0) {
+                    g = {I[0] * a.re + pd.re * ai_, I[0] * a.im + pd.im * ai_};
+                } else if (MCF && mcf >= 0) {
+                    const cplx m = cm[((size_t)mcf * 2 + (c - 1)) * T.nw + b.iw[j]];
+                    g = cmul(cscale(m, rhoV), a);
+                } else {
+                    g = cscale(a, I[c]);
+                }
+#pragma unroll
+                for (int q = 0; q < 3; q++) {
+                    f3[q].re = fma(g.re, n[c][q], f3[q].re);
+                    f3[q].im = fma(g.im, n[c][q], f3[q].im);
+                }
+            }
+            F[j][0] = cadd(F[j][0], f3[0]);
+            F[j][1] = cadd(F[j][1], f3[1]);
+            F[j][2] = cadd(F[j][2], f3[2]);
+            F[j][3].re += ay * f3[2].re - az * f3[1].re;
+            F[j][3].im += ay * f3[2].im - az * f3[1].im;
+            F[j][4].re += az * f3[0].re - ax * f3[2].re;
+            F[j][4].im += az * f3[0].im - ax * f3[2].im;
+            F[j][5].re += ax * f3[1].re - ay * f3[0].re;
+            F[j][5].im += ax * f3[1].im - ay * f3[0].im;
+        }
+    }
+}
+
+// hot per-strip constants of pass A, fetched one strip ahead (scalar loads -> SGPRs)
+struct RecA {
+    double ax, ay, az, qx, qy, qz, p1x, p1y, p1z, p2x, p2y, p2z;
+    int fl;
+};
+__device__ __forceinline__ RecA load_recA(const double *__restrict__ ds, const int *__restrict__ dsi, int s) {
+    const double *__restrict__ r = ds + (size_t)s * DS_N;
+    RecA o;
+    o.ax = r[DS_A]; o.ay = r[DS_A + 1]; o.az = r[DS_A + 2];
+    o.qx = r[DS_Q]; o.qy = r[DS_Q + 1]; o.qz = r[DS_Q + 2];
+    o.p1x = r[DS_P1]; o.p1y = r[DS_P1 + 1]; o.p1z = r[DS_P1 + 2];
+    o.p2x = r[DS_P2]; o.p2y = r[DS_P2 + 1]; o.p2z = r[DS_P2 + 2];
+    o.fl = dsi[s];
+    return o;
+}
+
+// Pass A of one linearisation (raft_member.py:2039-2090, helpers.py:149-184,684): per strip,
+// the sums over ALL bins of |v_rel . q|^2 and of the transverse squares, v_rel = u - i w (Xi_t + theta x a).
+// X[j][.] = w * XiLast (re/im), so that i w V = i (X_t + X_theta x a).
+// Cross-lane sums go through this wave's LDS transposition tile (no barrier, no shuffles);
+// per-wave results land in vsq[wave][s][3].
+template <int NB>
+__device__ __forceinline__ void linearize_passA(const double *__restrict__ ds, const int *__restrict__ dsi, int S,
+                                                const Lds &l, const Bins<NB> &b, double cb, double sb,
+                                                const cplx (&X)[NB][6]) {
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    double *tile = l.tile + (size_t)wv * TR_ROWS * TR_STRIDE;
+    double *wr = tile + tile_pos(lane);
+    double *vout = l.vsq + (size_t)wv * S * 3;
+    Kin<NB> K;
+    kin_reset(K);
+    if (S <= 0) return;
+    RecA nx = load_recA(ds, dsi, 0);
+#pragma unroll 1
+    for (int s0 = 0; s0 < S; s0 += SB) {
+        const int nb = min(SB, S - s0);
+#pragma unroll 1
+        for (int jj = 0; jj < nb; jj++) {
+            const int s = s0 + jj;
+            const RecA r = nx;
+            nx = load_recA(ds, dsi, min(s + 1, S - 1));
+            kin_advance<NB, false>(K, r.fl, ds + (size_t)s * DS_N, b, b.c1, cb, sb);
+            double v0 = 0.0, v1 = 0.0, v2 = 0.0;
+            const bool circ = (r.fl & DSI_CIRC) != 0;
+#pragma unroll
+            for (int j = 0; j < NB; j++) {
+                const double ps = K.P[j] + K.Q[j], pd = K.P[j] - K.Q[j];
+                const double t1r = K.ar[j] * ps, t1i = K.ai[j] * ps, t2r = -K.ai[j] * pd, t2i = K.ar[j] * pd;
+                double rxr = fma(cb, t1r, X[j][0].im), rxi = fma(cb, t1i, -X[j][0].re);
+                double ryr = fma(sb, t1r, X[j][1].im), ryi = fma(sb, t1i, -X[j][1].re);
+                double rzr = t2r + X[j][2].im, rzi = t2i - X[j][2].re;
+                rxr = fma(X[j][4].im, r.az, rxr); rxr = fma(-X[j][5].im, r.ay, rxr);
+                rxi = fma(-X[j][4].re, r.az, rxi); rxi = fma(X[j][5].re, r.ay, rxi);
+                ryr = fma(X[j][5].im, r.ax, ryr); ryr = fma(-X[j][3].im, r.az, ryr);
+                ryi = fma(-X[j][5].re, r.ax, ryi); ryi = fma(X[j][3].re, r.az, ryi);
+                rzr = fma(X[j][3].im, r.ay, rzr); rzr = fma(-X[j][4].im, r.ax, rzr);
+                rzi = fma(-X[j][3].re, r.ay, rzi); rzi = fma(X[j][4].re, r.ax, rzi);
+                const double vqr = fma(r.qz, rzr, fma(r.qy, ryr, r.qx * rxr));
+                const double vqi = fma(r.qz, rzi, fma(r.qy, ryi, r.qx * rxi));
+                if (circ) {                 // |v_perp|^2 = |v|^2 - |v_q|^2   (raft_member.py:2084-2087)
+                    const double q2 = fma(vqi, vqi, vqr * vqr);
+                    double n2 = fma(rxi, rxi, rxr * rxr);
+                    n2 = fma(ryr, ryr, n2); n2 = fma(ryi, ryi, n2);
+                    n2 = fma(rzr, rzr, n2); n2 = fma(rzi, rzi, n2);
+                    v0 += q2;
+                    v1 += n2 - q2;
+                } else {
+                    const double v1r = fma(r.p1z, rzr, fma(r.p1y, ryr, r.p1x * rxr));
+                    const double v1i = fma(r.p1z, rzi, fma(r.p1y, ryi, r.p1x * rxi));
+                    const double v2r = fma(r.p2z, rzr, fma(r.p2y, ryr, r.p2x * rxr));
+                    const double v2i = fma(r.p2z, rzi, fma(r.p2y, ryi, r.p2x * rxi));
+                    v0 = fma(vqr, vqr, fma(vqi, vqi, v0));
+                    v1 = fma(v1r, v1r, fma(v1i, v1i, v1));
+                    v2 = fma(v2r, v2r, fma(v2i, v2i, v2));
+                }
+            }
+            wr[(jj * 3 + 0) * TR_STRIDE] = v0;
+            wr[(jj * 3 + 1) * TR_STRIDE] = v1;
+            wr[(jj * 3 + 2) * TR_STRIDE] = v2;
+        }
+        wave_lds_fence();
+        {
+            const double a = tile_reduce(tile, lane);
+            const int row = lane >> 2;
+            if ((lane & 3) == 0 && row < nb * 3) vout[(size_t)s0 * 3 + row] = a;
+        }
+        wave_lds_fence();
+    }
+}
+
+// Strip-lane phase of a linearisation: one lane per strip turns the velocity sums into the
+// linearised coefficients (raft_member.py:2093-2110), the heading-projected drag vectors
+//   U = sum_c b_c al_c W_c,  V = sum_c b_c ga_c W_c,  W_c = [n_c ; a x n_c]
+// (so that translate(Bmat u) = t1 U + t2 V; raft_member.py:2122-2124, helpers.py:468-483) and its
+// share of B_drag = sum_{s,c} b_c W_c W_c^T (raft_member.py:2117-2118, helpers.py:537-560).
+// FRESH: recompute b_c from vsq; otherwise reuse l.bc (other headings of the same linearisation).
+template <bool FRESH>
+__device__ __forceinline__ void strip_phase(const double *__restrict__ ds, const int *__restrict__ dsi, int S,
+                                            const Lds &l, double cb, double sb, bool multi) {
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, nwv = blockDim.x >> 6;
+    double b6[21];
+#pragma unroll
+    for (int e = 0; e < 21; e++) b6[e] = 0.0;
+    for (int s = threadIdx.x; s < S; s += blockDim.x) {
+        const double *__restrict__ rec = ds + (size_t)s * DS_N;
+        double bc[3];
+        if (FRESH) {
+            double a = 0, c1 = 0, c2 = 0;
+            for (int i = 0; i < nwv; i++) {
+                const double *r = l.vsq + ((size_t)i * S + s) * 3;
+                a += r[0];
+                c1 += r[1];
+                c2 += r[2];
+            }
+            const double vRq = sqrt(0.5 * a);
+            double vR1, vR2;
+            if (dsi[s] & DSI_CIRC) {
+                vR1 = vR2 = sqrt(0.5 * fmax(c1, 0.0));
+            } else {
+                vR1 = sqrt(0.5 * c1);
+                vR2 = sqrt(0.5 * c2);
+            }
+            bc[0] = rec[DS_DQ] * vRq + rec[DS_DQ + 3] * vRq;     // Bprime_q + Bprime_End (:2093,:2110)
+            bc[1] = rec[DS_DQ + 1] * vR1;
+            bc[2] = rec[DS_DQ + 2] * vR2;
+            l.bc[(size_t)s * 3 + 0] = bc[0];
+            l.bc[(size_t)s * 3 + 1] = bc[1];
+            l.bc[(size_t)s * 3 + 2] = bc[2];
+        } else {
+            bc[0] = l.bc[(size_t)s * 3 + 0];
+            bc[1] = l.bc[(size_t)s * 3 + 1];
+            bc[2] = l.bc[(size_t)s * 3 + 2];
+        }
+        const double ax = rec[DS_A], ay = rec[DS_A + 1], az = rec[DS_A + 2];
+        double U[6] = {0, 0, 0, 0, 0, 0}, V[6] = {0, 0, 0, 0, 0, 0};
+#pragma unroll
+        for (int c = 0; c < 3; c++) {
+            double W[6];
+            W[0] = rec[DS_Q + 3 * c];
+            W[1] = rec[DS_Q + 3 * c + 1];
+            W[2] = rec[DS_Q + 3 * c + 2];
+            W[3] = ay * W[2] - az * W[1];
+            W[4] = az * W[0] - ax * W[2];
+            W[5] = ax * W[1] - ay * W[0];
+            const double al = bc[c] * (W[0] * cb + W[1] * sb), ga = bc[c] * W[2];
+#pragma unroll
+            for (int j = 0; j < 6; j++) {
+                U[j] += al * W[j];
+                V[j] += ga * W[j];
+            }
+            if (FRESH) {
+                int e = 0;
+#pragma unroll
+                for (int i = 0; i < 6; i++)
+#pragma unroll
+                    for (int j = i; j < 6; j++) b6[e++] += bc[c] * (W[i] * W[j]);
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 6; j++) {
+            l.uv[(size_t)s * 12 + j] = U[j];
+            l.uv[(size_t)s * 12 + 6 + j] = V[j];
+        }
+    }
+    if (FRESH) {
+        // B_drag: reduce the 21 unique entries over the lanes of each wave (two tile rounds), then over waves
+        double *tile = l.tile + (size_t)wv * TR_ROWS * TR_STRIDE;
+        double *wr = tile + tile_pos(lane);
+        wave_lds_fence();
+#pragma unroll
+        for (int e = 0; e < 16; e++) wr[e * TR_STRIDE] = b6[e];
+        wave_lds_fence();
+        double a = tile_reduce(tile, lane);
+        if ((lane & 3) == 0) l.bdw[wv * 24 + (lane >> 2)] = a;
+        wave_lds_fence();
+#pragma unroll
+        for (int e = 16; e < 21; e++) wr[(e - 16) * TR_STRIDE] = b6[e];
+        wave_lds_fence();
+        a = tile_reduce(tile, lane);
+        if ((lane & 3) == 0 && (lane >> 2) < 5) l.bdw[wv * 24 + 16 + (lane >> 2)] = a;
+        wg_sync(multi);
+        if (threadIdx.x < 36) {
+            const int i = threadIdx.x / 6, j = threadIdx.x % 6;
+            const int lo = i < j ? i : j, hi = i < j ? j : i;
+            const int e = lo * 6 - (lo * (lo - 1)) / 2 + (hi - lo);
+            double acc = 0.0;
+            for (int q = 0; q < nwv; q++) acc += l.bdw[q * 24 + e];
+            l.Bd[threadIdx.x] = acc;
+        }
+    }
+    wg_sync(multi);
+}
+
+// Pass B: drag excitation of one heading with the live coefficients (raft_member.py:2122-2124,
+// :2146-2151), ACCUMULATED into F: F += sum_s t1 U_s + t2 V_s.  U,V of the next strip are
+// fetched from LDS one strip ahead.
+template <int NB>
+__device__ __forceinline__ void drag_excitation(const double *__restrict__ ds, const int *__restrict__ dsi, int S,
+                                                const Lds &l, const Bins<NB> &b, double cb, double sb,
+                                                cplx (&F)[NB][6]) {
+    Kin<NB> K;
+    kin_reset(K);
+    if (S <= 0) return;
+    double Un[6], Vn[6];
+#pragma unroll
+    for (int q = 0; q < 6; q++) {
+        Un[q] = l.uv[q];
+        Vn[q] = l.uv[6 + q];
+    }
+    int fn = dsi[0];
+#pragma unroll 1
+    for (int s = 0; s < S; s++) {
+        double U[6], V[6];
+#pragma unroll
+        for (int q = 0; q < 6; q++) {
+            U[q] = Un[q];
+            V[q] = Vn[q];
+        }
+        const int fl = fn;
+        {
+            const int sn = min(s + 1, S - 1);
+            const double *uv = l.uv + (size_t)sn * 12;
+            fn = dsi[sn];
+#pragma unroll
+            for (int q = 0; q < 6; q++) {
+                Un[q] = uv[q];
+                Vn[q] = uv[6 + q];
+            }
+        }
+        kin_advance<NB, false>(K, fl, ds + (size_t)s * DS_N, b, b.c1, cb, sb);
+#pragma unroll
+        for (int j = 0; j < NB; j++) {
+            const double ps = K.P[j] + K.Q[j], pd = K.P[j] - K.Q[j];
+            const double t1r = K.ar[j] * ps, t1i = K.ai[j] * ps, t2r = -K.ai[j] * pd, t2i = K.ar[j] * pd;
+#pragma unroll
+            for (int q = 0; q < 6; q++) {
+                F[j][q].re = fma(t1r, U[q], fma(t2r, V[q], F[j][q].re));
+                F[j][q].im = fma(t1i, U[q], fma(t2i, V[q], F[j][q].im));
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------ 6x6 complex solve in registers
+struct Lu6 {
+    double ar[6][6], ai[6][6];
+};
+
+// x <- A^-1 x by Gaussian elimination with partial pivoting on the augmented system [A | x]:
+// the pivot rule of LAPACK zgetrf/zgesv (np.linalg.solve, raft_model.py:1089): largest
+// |re|+|im| in the column (izamax), full row interchange.  Everything stays in registers:
+// row swaps are predicated selects (wave-uniformly skipped when no lane needs one).
+__device__ __forceinline__ void solve6(Lu6 &A, cplx x[6]) {
+#pragma unroll
+    for (int k = 0; k < 6; k++) {
+        int p = k;
+        double best = fabs(A.ar[k][k]) + fabs(A.ai[k][k]);
+#pragma unroll
+        for (int r = k + 1; r < 6; r++) {
+            double v = fabs(A.ar[r][k]) + fabs(A.ai[r][k]);
+            if (v > best) {
+                best = v;
+                p = r;
+            }
+        }
+        if (__any(p != k)) {
+#pragma unroll
+            for (int r = k + 1; r < 6; r++) {
+                const bool sw = (p == r);
+#pragma unroll
+                for (int c = k; c < 6; c++) {
+                    double tr = A.ar[k][c], ti = A.ai[k][c];
+                    A.ar[k][c] = sw ? A.ar[r][c] : tr;
+                    A.ai[k][c] = sw ? A.ai[r][c] : ti;
+                    A.ar[r][c] = sw ? tr : A.ar[r][c];
+                    A.ai[r][c] = sw ? ti : A.ai[r][c];
+                }
+                double tr = x[k].re, ti = x[k].im;
+                x[k].re = sw ? x[r].re : tr;
+                x[k].im = sw ? x[r].im : ti;
+                x[r].re = sw ? tr : x[r].re;
+                x[r].im = sw ? ti : x[r].im;
+            }
+        }
+        double pr = A.ar[k][k], pi = A.ai[k][k];
+        double d = 1.0 / (pr * pr + pi * pi);
+        double ir = pr * d, ii = -pi * d;
+        A.ar[k][k] = ir;            // keep the reciprocal pivot for the back substitution
+        A.ai[k][k] = ii;
+#pragma unroll
+        for (int r = k + 1; r < 6; r++) {
+            double lr = A.ar[r][k] * ir - A.ai[r][k] * ii;
+            double li = A.ar[r][k] * ii + A.ai[r][k] * ir;
+#pragma unroll
+            for (int c = k + 1; c < 6; c++) {
+                A.ar[r][c] -= lr * A.ar[k][c] - li * A.ai[k][c];
+                A.ai[r][c] -= lr * A.ai[k][c] + li * A.ar[k][c];
+            }
+            x[r].re -= lr * x[k].re - li * x[k].im;
+            x[r].im -= lr * x[k].im + li * x[k].re;
+        }
+    }
+#pragma unroll
+    for (int k = 5; k >= 0; k--) {
+        cplx s = x[k];
+#pragma unroll
+        for (int c = k + 1; c < 6; c++) {
+            s.re -= A.ar[k][c] * x[c].re - A.ai[k][c] * x[c].im;
+            s.im -= A.ar[k][c] * x[c].im + A.ai[k][c] * x[c].re;
+        }
+        x[k] = {s.re * A.ar[k][k] - s.im * A.ai[k][k], s.re * A.ai[k][k] + s.im * A.ar[k][k]};
+    }
+}
+
+// kernel specialisation flags
+#define KF_FDEP 1    // frequency-dependent M(w), B(w)
+#define KF_OUTZ 2    // export Z
+#define KF_OUTF 4    // export F_wave
+#define KF_EXTRA 8   // F_extra input
+#define KF_MCF 16    // MacCamy-Fuchs complex Cm table
+#define KF_MULTI 32  // more than one wave heading
+#define KF_ALL 63
+
+// Assemble and solve one bin's 6x6 system: x <- Z^-1 x  (raft_model.py:1086-1089)
+template <int FLAGS>
+__device__ __forceinline__ void assemble_and_solve(const Lds &l, const double *__restrict__ Mw, const double *__restrict__ Bw,
+                                                   int nw, int iw, double w, cplx x[6], cplx *__restrict__ Zout,
+                                                   bool active) {
+    Lu6 lu;
+    const double w2 = w * w;
+#pragma unroll
+    for (int r = 0; r < 6; r++) {
+#pragma unroll
+        for (int c = 0; c < 6; c++) {
+            const int e = r * 6 + c;
+            double M = l.mat[e], B = l.mat[36 + e];
+            if constexpr ((FLAGS & KF_FDEP) != 0) {
+                if (Mw) {
+                    M += Mw[(size_t)e * nw + iw];
+                    B += Bw[(size_t)e * nw + iw];
+                }
+            }
+            B += l.Bd[e];
+            lu.ar[r][c] = fma(-w2, M, l.mat[72 + e]);     // Z = -w^2 M + i w B + C  (:1086)
+            lu.ai[r][c] = w * B;
+        }
+    }
+    if constexpr ((FLAGS & KF_OUTZ) != 0) {
+        if (active && Zout) {      // last iterate wins (fowt.Z, :1155)
+#pragma unroll
+            for (int r = 0; r < 6; r++)
+#pragma unroll
+                for (int c = 0; c < 6; c++) Zout[(size_t)(r * 6 + c) * nw + iw] = cplx{lu.ar[r][c], lu.ai[r][c]};
+        }
+    }
+    solve6(lu, x);
+}
+
+// ------------------------------------------------------------------ kernels
+// workgroup-wide OR / AND of a per-thread predicate
+__device__ __forceinline__ int wg_or(int v, bool multi) {
+    if (!multi) return __any(v) ? 1 : 0;
+    return __syncthreads_or(v);
+}
+__device__ __forceinline__ int wg_and(int v, bool multi) {
+    if (!multi) return __all(v) ? 1 : 0;
+    return __syncthreads_and(v);
+}
+
+struct PairCtx {
+    int pair, d, ic, S;
+    const double *__restrict__ ds;
+    const int *__restrict__ dsi;
+    const cplx *__restrict__ cm;
+};
+__device__ __forceinline__ bool pair_ctx(const DevTables &T, PairCtx &p, int pair) {
+    const int npair = T.nDesign * T.nCase;
+    p.pair = pair;
+    if (p.pair >= npair) return false;
+    p.d = p.pair / T.nCase;
+    p.ic = p.pair % T.nCase;
+    p.S = (int)(T.off[p.d + 1] - T.off[p.d]);
+    p.ds = T.ds + (size_t)T.off[p.d] * DS_N;
+    p.dsi = T.dsi + (size_t)T.off[p.d];
+    p.cm = T.cm ? T.cm + (size_t)T.cmoff[p.d] * 2 * T.nw : nullptr;
+    return true;
+}
+
+template <int NB>
+__device__ __forceinline__ void zero6(cplx (&F)[NB][6]) {
+#pragma unroll
+    for (int j = 0; j < NB; j++)
+#pragma unroll
+        for (int q = 0; q < 6; q++) F[j][q] = {0.0, 0.0};
+}
+template <int NB>
+__device__ __forceinline__ void store6(cplx *__restrict__ base, int nw, const Bins<NB> &b, const cplx (&F)[NB][6]) {
+#pragma unroll
+    for (int j = 0; j < NB; j++)
+        if (b.act[j]) {
+#pragma unroll
+            for (int q = 0; q < 6; q++) base[(size_t)q * nw + b.iw[j]] = F[j][q];
+        }
+}
+
+// F_iner [nDesign,nCase,nHead,6,nw]   (raft_fowt.py:1854-1857,1888); one workgroup per (pair, heading)
+template <int NB, int MAXT, int MINB>
+__global__ void __launch_bounds__(MAXT, MINB) k_excitation(DevTables T, cplx *__restrict__ F_iner) {
+    PairCtx p;
+    const int ih = blockIdx.x % T.nHead;
+    if (!pair_ctx(T, p, blockIdx.x / T.nHead)) return;
+    Bins<NB> b;
+    load_bins(T, b);
+    set_heading_amp(T, b, p.ic, ih);
+    const double beta = T.beta[(size_t)p.ic * T.nHead + ih];
+    const double cb = cos(beta), sb = sin(beta);
+    cplx F[NB][6];
+    zero6(F);
+    inertial_excitation<NB, true>(T, p.ds, p.dsi, p.S, p.cm, b, p.ic, ih, cb, sb, F);
+    store6(F_iner + (((size_t)p.pair * T.nHead + ih) * 6) * T.nw, T.nw, b, F);
+}
+
+// One linearisation about a given Xi (raft_fowt.py:1891-1957).
+template <int NB, int MAXT, int MINB>
+__global__ void __launch_bounds__(MAXT, MINB) k_linearize(DevTables T, const cplx *__restrict__ Xi_in,
+                                                           double *__restrict__ B_drag, cplx *__restrict__ F_drag) {
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    PairCtx p;
+    if (!pair_ctx(T, p, pair_of_block(blockIdx.x, T.nDesign * T.nCase))) return;
+    const bool multi = blockDim.x > 64;
+    Lds l = carve(smem, p.S, T.nw, blockDim.x >> 6);
+    Bins<NB> b;
+    load_bins(T, b);
+    {
+        set_heading_amp(T, b, p.ic, 0);
+        const double beta = T.beta[(size_t)p.ic * T.nHead];
+        const double cb = cos(beta), sb = sin(beta);
+        cplx X[NB][6];
+#pragma unroll
+        for (int j = 0; j < NB; j++) {
+            const double w = b.act[j] ? T.w[b.iw[j]] : 0.0;
+#pragma unroll
+            for (int q = 0; q < 6; q++) {
+                const cplx xi = Xi_in[((size_t)p.pair * 6 + q) * T.nw + b.iw[j]];
+                X[j][q] = {w * xi.re, w * xi.im};
+            }
+        }
+        linearize_passA<NB>(p.ds, p.dsi, p.S, l, b, cb, sb, X);
+        wg_sync(multi);
+        strip_phase<true>(p.ds, p.dsi, p.S, l, cb, sb, multi);
+    }
+    if (B_drag && threadIdx.x < 36) B_drag[(size_t)p.pair * 36 + threadIdx.x] = l.Bd[threadIdx.x];
+    if (F_drag) {
+        for (int ih = 0; ih < T.nHead; ih++) {
+            const double beta = T.beta[(size_t)p.ic * T.nHead + ih];
+            const double cb = cos(beta), sb = sin(beta);
+            set_heading_amp(T, b, p.ic, ih);
+            if (ih > 0) {
+                wg_sync(multi);
+                strip_phase<false>(p.ds, p.dsi, p.S, l, cb, sb, multi);
+            }
+            cplx F[NB][6];
+            zero6(F);
+            drag_excitation<NB>(p.ds, p.dsi, p.S, l, b, cb, sb, F);
+            store6(F_drag + (((size_t)p.pair * T.nHead + ih) * 6) * T.nw, T.nw, b, F);
+        }
+    }
+}
+
+struct SolveArgs {
+    int nIter;          // loop bound = YAML nIter + 1 (raft_model.py:977)
+    double tol, XiStart;
+    const cplx *__restrict__ F_extra;    // [pair,nHead,6,nw] or null
+    cplx *Xi;               // [pair,nHead,6,nw]
+    int *__restrict__ niter, *__restrict__ flags;     // [pair]
+    double *__restrict__ B_drag;         // [pair,36] or null
+    cplx *__restrict__ F_wave;           // [pair,nHead,6,nw] or null
+    cplx *__restrict__ Z;                // [pair,36,nw] or null
+};
+
+// The fused fixed point (raft_model.py:1052-1142) + per-heading response (:1189-1236).
+// Storage plan: XiLast lives in LDS (read once per pass A, once per convergence test).
+// F_lin (raft_model.py:1048) is parked in the pair's own heading-0 slab of the Xi OUTPUT
+// buffer until the final iterate overwrites it -- each lane re-reads only what it wrote,
+// so no extra HBM footprint and no synchronisation is needed.  The 6x6 systems of a lane's
+// NB bins are factorised one after the other.
+template <int NB, int FLAGS, int MAXT, int MINB>
+__global__ void __launch_bounds__(MAXT, MINB) k_solve_dynamics(DevTables T, SolveArgs A) {
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    constexpr bool FDEP = (FLAGS & KF_FDEP) != 0, OUTZ = (FLAGS & KF_OUTZ) != 0, OUTF = (FLAGS & KF_OUTF) != 0;
+    constexpr bool EXTRA = (FLAGS & KF_EXTRA) != 0, MCF = (FLAGS & KF_MCF) != 0, MULTI = (FLAGS & KF_MULTI) != 0;
+    PairCtx p;
+    if (!pair_ctx(T, p, pair_of_block(blockIdx.x, T.nDesign * T.nCase))) return;
+    const bool multi = blockDim.x > 64;
+    const int nw = T.nw, nHs = T.nHead, nH = MULTI ? T.nHead : 1;
+    const int pair = p.pair, S = p.S;
+    const cplx *cm = (MCF && T.cm) ? p.cm : nullptr;
+    Lds l = carve(smem, S, nw, blockDim.x >> 6);
+    Bins<NB> b;
+    load_bins(T, b);
+    set_heading_amp(T, b, p.ic, 0);
+    for (int i = threadIdx.x; i < 108; i += blockDim.x) {
+        const int e = i % 36, wh = i / 36;
+        const double *src = wh == 0 ? T.M0 : (wh == 1 ? T.B0 : T.C0);
+        l.mat[i] = src[(size_t)p.d * 36 + e];
+    }
+    const double beta0 = T.beta[(size_t)p.ic * nHs];
+    const double cb0 = cos(beta0), sb0 = sin(beta0);
+    cplx *xio = A.Xi + ((size_t)pair * nHs) * 6 * nw;      // heading-0 slab: F_lin until the end, then Xi
+
+    {   // F_lin = F_extra[0] + F_iner[0]   (raft_model.py:1048)
+        cplx Flin[NB][6];
+        zero6(Flin);
+        if constexpr (EXTRA) {
+            if (A.F_extra) {
+#pragma unroll
+                for (int j = 0; j < NB; j++)
+#pragma unroll
+                    for (int q = 0; q < 6; q++)
+                        Flin[j][q] = A.F_extra[(((size_t)pair * nHs) * 6 + q) * nw + b.iw[j]];
+            }
+        }
+        inertial_excitation<NB, MCF>(T, p.ds, p.dsi, S, cm, b, p.ic, 0, cb0, sb0, Flin);
+        store6(xio, nw, b, Flin);
+    }
+    // XiLast <- XiStart (:999), kept as xl[2q][bin] = re, xl[2q+1][bin] = im
+#pragma unroll
+    for (int j = 0; j < NB; j++)
+        if (b.act[j]) {
+#pragma unroll
+            for (int q = 0; q < 6; q++) {
+                l.xl[(2 * q) * l.nxl + b.iw[j]] = A.XiStart;
+                l.xl[(2 * q + 1) * l.nxl + b.iw[j]] = 0.0;
+            }
+        }
+    const double *Mw = (FDEP && T.MBw) ? T.MBw + ((size_t)p.d * 2 + 0) * 36 * nw : nullptr;
+    const double *Bw = (FDEP && T.MBw) ? T.MBw + ((size_t)p.d * 2 + 1) * 36 * nw : nullptr;
+    cplx *Zout = (OUTZ && A.Z) ? A.Z + (size_t)pair * 36 * nw : nullptr;
+    wg_sync(multi);
+
+    int iiter = 0, done = 0, converged = 0, nan = 0;
+#pragma unroll 1
+    while (true) {
+        {
+            cplx X[NB][6];
+#pragma unroll
+            for (int j = 0; j < NB; j++) {
+                const double w = b.act[j] ? T.w[b.iw[j]] : 0.0;
+#pragma unroll
+                for (int q = 0; q < 6; q++) {
+                    X[j][q].re = b.act[j] ? w * l.xl[(2 * q) * l.nxl + b.iw[j]] : 0.0;
+                    X[j][q].im = b.act[j] ? w * l.xl[(2 * q + 1) * l.nxl + b.iw[j]] : 0.0;
+                }
+            }
+            linearize_passA<NB>(p.ds, p.dsi, S, l, b, cb0, sb0, X);          // :1063
+        }
+        wg_sync(multi);
+        strip_phase<true>(p.ds, p.dsi, S, l, cb0, sb0, multi);
+        cplx x[NB][6];
+#pragma unroll
+        for (int j = 0; j < NB; j++)
+#pragma unroll
+            for (int q = 0; q < 6; q++) x[j][q] = b.act[j] ? xio[(size_t)q * nw + b.iw[j]] : cplx{0.0, 0.0};   // F_lin
+        drag_excitation<NB>(p.ds, p.dsi, S, l, b, cb0, sb0, x);               // + F_drag (:1064,:1081)
+        int bad = 0, ok = 1;
+        const bool last_chance = iiter + 1 >= A.nIter;
+#pragma unroll
+        for (int j = 0; j < NB; j++) {
+            if constexpr (OUTF) {                                     // total excitation, heading 0 (:1212)
+                if (b.act[j] && A.F_wave) {
+#pragma unroll
+                    for (int q = 0; q < 6; q++) A.F_wave[(((size_t)pair * nHs) * 6 + q) * nw + b.iw[j]] = x[j][q];
+                }
+            }
+            const double w = b.act[j] ? T.w[b.iw[j]] : 0.0;
+            assemble_and_solve<FLAGS>(l, Mw, Bw, nw, b.iw[j], w, x[j], Zout, b.act[j]);   // :1086-1089
+            // NaN check (:1098), convergence (:1103-1104) and relaxation (:1133)
+            if (b.act[j]) {
+#pragma unroll
+                for (int q = 0; q < 6; q++) {
+                    const double lr = l.xl[(2 * q) * l.nxl + b.iw[j]], li = l.xl[(2 * q + 1) * l.nxl + b.iw[j]];
+                    if (isnan(x[j][q].re) || isnan(x[j][q].im)) bad = 1;
+                    const double dr = x[j][q].re - lr, di = x[j][q].im - li;
+                    const double tc = sqrt(dr * dr + di * di) / (sqrt(x[j][q].re * x[j][q].re + x[j][q].im * x[j][q].im) + A.tol);
+                    if (!(tc < A.tol)) ok = 0;
+                    l.xl[(2 * q) * l.nxl + b.iw[j]] = 0.2 * lr + 0.8 * x[j][q].re;
+                    l.xl[(2 * q + 1) * l.nxl + b.iw[j]] = 0.2 * li + 0.8 * x[j][q].im;
+                }
+            }
+        }
+        done = iiter + 1;
+        nan = wg_or(bad, multi);
+        converged = nan ? 0 : wg_and(ok, multi);
+        if (nan || converged || last_chance) {
+            // Heading 0 of the final response, Zinv (F_lin + F_drag(0)), is exactly this solve (:1216)
+#pragma unroll
+            for (int j = 0; j < NB; j++)
+                if (b.act[j]) {
+#pragma unroll
+                    for (int q = 0; q < 6; q++) xio[(size_t)q * nw + b.iw[j]] = nan ? cplx{NAN, NAN} : x[j][q];
+                }
+            break;
+        }
+        iiter++;
+        wg_sync(multi);
+    }
+
+    // remaining headings: same impedance, same linearised coefficients (:1200-1236)
+    if constexpr (MULTI) {
+#pragma unroll 1
+        for (int ih = 1; ih < nH; ih++) {
+            const double beta = T.beta[(size_t)p.ic * nHs + ih];
+            const double cb = cos(beta), sb = sin(beta);
+            set_heading_amp(T, b, p.ic, ih);
+            wg_sync(multi);
+            strip_phase<false>(p.ds, p.dsi, S, l, cb, sb, multi);
+            cplx x[NB][6];
+            zero6(x);
+            if constexpr (EXTRA) {
+                if (A.F_extra) {
+#pragma unroll
+                    for (int j = 0; j < NB; j++)
+#pragma unroll
+                        for (int q = 0; q < 6; q++)
+                            x[j][q] = A.F_extra[(((size_t)pair * nHs + ih) * 6 + q) * nw + b.iw[j]];
+                }
+            }
+            inertial_excitation<NB, MCF>(T, p.ds, p.dsi, S, cm, b, p.ic, ih, cb, sb, x);
+            drag_excitation<NB>(p.ds, p.dsi, S, l, b, cb, sb, x);               // :1209,:1212
+            cplx *xo = A.Xi + ((size_t)pair * nHs + ih) * 6 * nw;
+#pragma unroll
+            for (int j = 0; j < NB; j++) {
+                if constexpr (OUTF) {
+                    if (b.act[j] && A.F_wave) {
+#pragma unroll
+                        for (int q = 0; q < 6; q++) A.F_wave[(((size_t)pair * nHs + ih) * 6 + q) * nw + b.iw[j]] = x[j][q];
+                    }
+                }
+                const double w = b.act[j] ? T.w[b.iw[j]] : 0.0;
+                assemble_and_solve<(FLAGS & ~KF_OUTZ)>(l, Mw, Bw, nw, b.iw[j], w, x[j], nullptr, b.act[j]);   // Zinv @ F_wave (:1216)
+                if (b.act[j]) {
+#pragma unroll
+                    for (int q = 0; q < 6; q++) xo[(size_t)q * nw + b.iw[j]] = nan ? cplx{NAN, NAN} : x[j][q];
+                }
+            }
+        }
+    }
+    if (threadIdx.x < 36 && A.B_drag) A.B_drag[(size_t)pair * 36 + threadIdx.x] = l.Bd[threadIdx.x];
+    if (threadIdx.x == 0) {
+        if (A.niter) A.niter[pair] = done;
+        if (A.flags) A.flags[pair] = (converged ? RAFTX_FLAG_CONVERGED : 0) | (nan ? RAFTX_FLAG_NAN : 0);
+    }
+}

@@ -186,7 +186,7 @@ def test_deep_water_and_zero_wavenumber_branches(hip_ctx, oracle_ctx):
 
 def test_bins_beyond_workgroup_capacity_fail_loudly(hip_ctx):
     rng = np.random.default_rng(2)
-    w, k, zeta, beta = synthetic_cases(rng, 1, 1, 300)
+    w, k, zeta, beta = synthetic_cases(rng, 1, 1, 3000)
     with pytest.raises(RaftxError):
         hip_ctx.upload_cases(w, k, 200.0, 1025.0, 9.81, zeta, beta)
 
