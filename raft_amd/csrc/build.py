@@ -23,6 +23,19 @@ def build(force=False, verbose=False, extra=()):
     return OUT
 
 
+def build_timing(verbose=False):
+    """Instrumented tuning build (per-phase cycle counters): libraftx_hip_timing.so.  Never loaded by the product."""
+    out = os.path.join(HERE, "libraftx_hip_timing.so")
+    cmd = [os.environ.get("HIPCC", "hipcc")] + FLAGS + ["-DRAFTX_PHASE_TIMING", "-o", out, SRC]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd)
+    return out
+
+
 if __name__ == "__main__":
+    if "--timing" in sys.argv:
+        print(build_timing(verbose=True))
+        sys.exit(0)
     print(build(force="--force" in sys.argv, verbose=True,
                 extra=["-Rpass-analysis=kernel-resource-usage"] if "--usage" in sys.argv else []))

@@ -121,12 +121,13 @@ struct raftx_ctx {
     std::vector<void *> design_allocs, case_allocs, result_allocs;
     // resident results of the last raftx_solve_dynamics_device
     cplx *rXi, *rFw, *rZ, *rFe;
-    double *rB;
+    double *rB, *rXl;
     int *rNi, *rFl;
     size_t r_npair, r_nx, r_nz;
     int r_mask;
     bool r_fe;
     int maxS;
+    unsigned long long *dbg;
     double last_ms;
     bool have_designs, have_cases;
     int nw_designs;
@@ -163,11 +164,12 @@ extern "C" int raftx_ctx_create(int device_id, raftx_ctx **out) {
     c->device = device_id;
     c->err[0] = 0;
     c->maxS = 0;
+    c->dbg = nullptr;
     c->last_ms = 0.0;
     c->have_designs = c->have_cases = false;
     c->nw_designs = 0;
     c->rXi = c->rFw = c->rZ = c->rFe = nullptr;
-    c->rB = nullptr;
+    c->rB = c->rXl = nullptr;
     c->rNi = c->rFl = nullptr;
     c->r_npair = c->r_nx = c->r_nz = 0;
     c->r_mask = 0;
@@ -388,14 +390,19 @@ extern "C" int raftx_upload_cases(raftx_ctx *c, int nCase, int nHead, int nw, co
 
 #define LDS_LIMIT (160 * 1024)
 
-// Launch shape: NB bins per lane x threads per workgroup (one workgroup per pair).
-//   nw <= 256 : one wave64 per pair, NB = ceil(nw/64)   (no s_barrier anywhere in the kernel)
-//   larger    : 512 threads with NB = 2..4
+// Launch shape: NB bins per lane x threads per workgroup (one workgroup per pair).  Defaults
+// (measured on MI355X, profiles/): two waves per SIMD with 2 bins per lane beat both the
+// 4-bins-per-lane / 1-wave-per-SIMD and the 1-bin-per-lane shapes at nw = 200.
+//   nw <=  64 : (1,  64)    one wave per pair, no s_barrier anywhere in the kernel
+//   nw <= 128 : (2,  64)
+//   nw <= 256 : (2, 128)
+//   nw <= 512 : (2, 256)
+//   larger    : (2..4, 512)
 // RAFTX_SHAPE="nb,threads" overrides (tuning only; must be one of the instantiated shapes).
 struct Shape {
     int nb, threads;
 };
-#define SHAPES(X) X(1, 64, 1) X(2, 64, 1) X(3, 64, 1) X(4, 64, 1) X(2, 128, 2) X(1, 256, 2) X(2, 512, 1) X(3, 512, 1) X(4, 512, 1)
+#define SHAPES(X) X(1, 64, 1) X(2, 64, 1) X(4, 64, 1) X(2, 128, 2) X(1, 256, 2) X(2, 256, 2) X(2, 512, 1) X(3, 512, 1) X(4, 512, 1)
 static bool shape_ok(Shape sh, int nw) {
 #define X(NB_, MT_, MB_) if (sh.nb == NB_ && sh.threads == MT_) return (long)NB_ * MT_ >= nw;
     SHAPES(X)
@@ -408,7 +415,10 @@ static Shape pick_shape(int nw) {
         Shape sh = {0, 0};
         if (sscanf(env, "%d,%d", &sh.nb, &sh.threads) == 2 && shape_ok(sh, nw)) return sh;
     }
-    if (nw <= 256) return {(nw + 63) / 64, 64};
+    if (nw <= 64) return {1, 64};
+    if (nw <= 128) return {2, 64};
+    if (nw <= 256) return {2, 128};
+    if (nw <= 512) return {2, 256};
     int nb = (nw + 511) / 512;
     return {nb < 2 ? 2 : nb, 512};
 }
@@ -508,7 +518,7 @@ extern "C" int raftx_linearize(raftx_ctx *c, const raftx_c128 *Xi, double *B_dra
     if (npair && (!dXi || (B_drag && !dB) || (F_drag && !dF))) FAIL(c, "linearize: device allocation failed");
     if (npair) H2D(c, dXi, Xi, npair * 6 * T.nw * sizeof(cplx));
     const Shape sh = pick_shape(T.nw);
-    const size_t lds = lds_bytes(c->maxS, T.nw, sh.threads / 64);
+    const size_t lds = lds_bytes(c->maxS, T.nw, sh.threads / 64, sh.threads == 64);
 #define DISPATCH_ONE_(NB_, MT_, MB_)                                                                                  \
     if (!hit_ && sh.nb == NB_ && sh.threads == MT_) {                                                                 \
         hit_ = true;                                                                                                  \
@@ -547,7 +557,7 @@ static int ensure_results(raftx_ctx *c, int want_mask, bool need_fe) {
     HIPCHK(c, hipStreamSynchronize(c->stream));
     free_list(c->result_allocs);
     c->rXi = c->rFw = c->rZ = c->rFe = nullptr;
-    c->rB = nullptr;
+    c->rB = c->rXl = nullptr;
     c->rNi = c->rFl = nullptr;
     c->rXi = dev_alloc<cplx>(c, nx);
     c->rNi = dev_alloc<int>(c, npair);
@@ -588,12 +598,22 @@ extern "C" int raftx_solve_dynamics_device(raftx_ctx *c, int nIter, double tol, 
     A.B_drag = (want_mask & RAFTX_WANT_BDRAG) ? c->rB : nullptr;
     A.F_wave = (want_mask & RAFTX_WANT_FWAVE) ? c->rFw : nullptr;
     A.Z = (want_mask & RAFTX_WANT_Z) ? c->rZ : nullptr;
+    A.dbg = nullptr;
+#ifdef RAFTX_PHASE_TIMING
+    if (!c->dbg) {
+        void *p_ = nullptr;
+        HIPCHK(c, hipMalloc(&p_, 8 * sizeof(unsigned long long)));
+        c->dbg = reinterpret_cast<unsigned long long *>(p_);
+    }
+    HIPCHK(c, hipMemsetAsync(c->dbg, 0, 8 * sizeof(unsigned long long), c->stream));
+    A.dbg = c->dbg;
+#endif
     if (F_extra && c->r_nx) H2D(c, c->rFe, F_extra, c->r_nx * sizeof(cplx));
     // the lean specialisation (no optional inputs / outputs) is the sweep path
     const int need = (T.MBw ? KF_FDEP : 0) | (A.Z ? KF_OUTZ : 0) | (A.F_wave ? KF_OUTF : 0) | (A.F_extra ? KF_EXTRA : 0) |
                      (T.cm ? KF_MCF : 0) | (T.nHead > 1 ? KF_MULTI : 0);
     const Shape sh = pick_shape(T.nw);
-    const size_t lds = lds_bytes(c->maxS, T.nw, sh.threads / 64);
+    const size_t lds = lds_bytes(c->maxS, T.nw, sh.threads / 64, sh.threads == 64);
 #define LAUNCH_SOLVE(NB_, MT_, MB_, FL)                                                                              \
     do {                                                                                                             \
         if (prep_lds(c, k_solve_dynamics<NB_, FL, MT_, MB_>, lds)) return -1;                                        \
@@ -681,6 +701,17 @@ extern "C" int raftx_solve_system(raftx_ctx *c, int nSys, int nUnit, int nRhs, i
 }
 
 // ------------------------------------------------------------------ diagnostics
+#ifdef RAFTX_PHASE_TIMING
+// Tuning builds only (csrc/build.py --timing): cycles of the last raftx_solve_dynamics_device,
+// summed over the first lane of every workgroup, per phase (set-up+inertial, pass A, strip
+// phase, pass B, solve, tail).
+extern "C" int raftx_debug_phase_cycles(raftx_ctx *c, unsigned long long *out8) {
+    if (!c || !out8 || !c->dbg) return -1;
+    HIPCHK(c, hipMemcpy(out8, c->dbg, 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    return 0;
+}
+#endif
+
 __global__ void k_debug_math(int n, const double *__restrict__ x, double *__restrict__ s, double *__restrict__ c,
                              double *__restrict__ e) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;

@@ -30,6 +30,19 @@ __device__ __forceinline__ cplx cscale(cplx a, double s) { return {a.re * s, a.i
 __device__ __forceinline__ cplx cadd(cplx a, cplx b) { return {a.re + b.re, a.im + b.im}; }
 __device__ __forceinline__ cplx csub(cplx a, cplx b) { return {a.re - b.re, a.im - b.im}; }
 
+// Strip tables are read-only for the whole launch.  Reading them through the CONSTANT address
+// space lets the compiler use scalar loads (s_load_dwordx8/16 -> SGPRs) even after the kernel
+// has stored to global memory (plain global pointers lose that once any store may alias).
+#define CONST_AS __attribute__((address_space(4)))
+typedef const CONST_AS double *cdptr;
+typedef const CONST_AS int *ciptr;
+// LDS pointers carry their address space: 32-bit addresses, always ds_* instructions
+#define LDS_AS __attribute__((address_space(3)))
+typedef LDS_AS double *ldptr;
+typedef LDS_AS int *liptr;
+__device__ __forceinline__ cdptr as_const(const double *p) { return (cdptr)p; }
+__device__ __forceinline__ ciptr as_const(const int *p) { return (ciptr)p; }
+
 // ------------------------------------------------------------------ fp64 elementary functions
 // Straight-line sincos / exp for the moderate arguments of this problem
 // (|k xi| < 1e5, |k z| < 700): Cody-Waite reduction + Taylor polynomials whose
@@ -135,39 +148,47 @@ __device__ __forceinline__ int pair_of_block(int b, int npair) {
 static inline unsigned grid_for_pairs(size_t npair) { return (unsigned)(((npair + 7) / 8) * 8); }
 
 // ------------------------------------------------------------------ LDS layout
-#define TR_ROWS 16           // rows of a reduction tile
-#define TR_STRIDE 68         // doubles per row (4 segments of 17; 68 mod 16 == 4: conflict-free)
-#define SB 5                 // strips per reduction batch of pass A (3 rows each)
+#define RA_N 18              // doubles per staged record: arm, q, p1, p2 (pass A) + x, y, z, unit step (run starts)
+#define TR_ROWS 8            // rows of a reduction tile
+#define TR_STRIDE 72         // doubles per row (8 segments of 9: conflict-free)
+#define SB 2                 // strips per reduction batch of pass A (3 rows each)
 
+// Per-pair LDS (bytes at S = 53, nw = 200, 2 waves): xl 19.2 K + uv 5.1 K + vsq 2.5 K + tiles 8.7 K
+// + 1.5 K  ~= 37 K  ->  four pairs per CU (160 KiB).  The one-wave-per-SIMD shapes additionally
+// stage the hot strip constants (ra, +7.6 K).
 struct Lds {
-    double *xl;      // [12][nxl]    XiLast (re/im split), nxl = nw rounded up to even
-    double *uv;      // [S][12]      linearised drag vectors of the current heading
-    double *vsq;     // [NWV][S][3]  per-wave sums over bins of |v_q|^2, |v_p1|^2 (|v_perp|^2), |v_p2|^2
-    double *bc;      // [S][3]       live linearised coefficients (kept for the other headings)
-    double *tile;    // [NWV][TR_ROWS][TR_STRIDE]
-    double *bdw;     // [NWV][24]    per-wave partials of the 21 unique B_drag entries
-    double *Bd;      // [36]
-    double *mat;     // [108]        M0, B0, C0
+    ldptr xl;      // [12][nxl]    XiLast (re/im rows), nxl = nw rounded up to even
+    ldptr ra;      // [S][RA_N]    hot strip constants (STAGE shapes only)
+    ldptr uv;      // [S][12]      linearised drag vectors of the current heading
+    ldptr vsq;     // [NWV][S][3]  per-wave sums over bins of |v_q|^2, |v_p1|^2 (|v_perp|^2), |v_p2|^2;
+                     //              row 0 is overwritten by the live coefficients b_c (strip_phase)
+    ldptr tile;    // [NWV][TR_ROWS][TR_STRIDE]
+    ldptr bdw;     // [NWV][24]    per-wave partials of the 21 unique B_drag entries
+    ldptr Bd;      // [36]
+    ldptr mat;     // [108]        M0, B0, C0
+    liptr fl;         // [S]          strip flags (STAGE shapes only)
     int nxl;
 };
-
 static __host__ __device__ inline int xl_row(int nw) { return (nw + 1) & ~1; }
-__device__ __forceinline__ Lds carve(double *base, int S, int nw, int nwv) {
+__device__ __forceinline__ Lds carve(double *base_, int S, int nw, int nwv, bool stage) {
     Lds l;
+    ldptr base = (ldptr)base_;
     l.nxl = xl_row(nw);
     l.xl = base;
-    l.uv = l.xl + (size_t)12 * l.nxl;
+    l.ra = l.xl + (size_t)12 * l.nxl;
+    l.uv = l.ra + (stage ? (size_t)S * RA_N : 0);
     l.vsq = l.uv + (size_t)S * 12;
-    l.bc = l.vsq + (size_t)nwv * S * 3;
-    l.tile = l.bc + (size_t)S * 3;
+    l.tile = l.vsq + (size_t)nwv * S * 3;
     l.bdw = l.tile + (size_t)nwv * TR_ROWS * TR_STRIDE;
     l.Bd = l.bdw + (size_t)nwv * 24;
     l.mat = l.Bd + 36;
+    l.fl = (liptr)(l.mat + 108);
     return l;
 }
-static size_t lds_bytes(int S, int nw, int nwv) {
-    return sizeof(double) * ((size_t)12 * xl_row(nw) + (size_t)S * (12 + 3 + 3 * nwv) + (size_t)nwv * (TR_ROWS * TR_STRIDE + 24) +
-                             36 + 108 + 2);
+static size_t lds_bytes(int S, int nw, int nwv, bool stage) {
+    return sizeof(double) * ((size_t)12 * xl_row(nw) + (size_t)S * ((stage ? RA_N : 0) + 12 + 3 * nwv) +
+                             (size_t)nwv * (TR_ROWS * TR_STRIDE + 24) + 36 + 108 + 2) +
+           sizeof(int) * (size_t)(stage ? S + 2 : 2);
 }
 
 // LDS traffic between lanes of ONE wave needs no s_barrier (a wave's LDS instructions
@@ -182,59 +203,59 @@ __device__ __forceinline__ void wg_sync(bool multi) {
     else wave_lds_fence();
 }
 
-// quad butterflies on doubles (DPP quad_perm: pure VALU, no LDS crossbar)
-__device__ __forceinline__ double quad_xor(double v, const int ctrl_is_xor1) {
+// DPP moves on doubles (pure VALU, no LDS crossbar): quad_perm butterflies and row_shl:4
+template <int CTRL>
+__device__ __forceinline__ double dpp_mov(double v) {
     int lo = __double2loint(v), hi = __double2hiint(v);
-    if (ctrl_is_xor1) {
-        lo = __builtin_amdgcn_mov_dpp(lo, 0xB1, 0xf, 0xf, true);   // quad_perm [1,0,3,2]
-        hi = __builtin_amdgcn_mov_dpp(hi, 0xB1, 0xf, 0xf, true);
-    } else {
-        lo = __builtin_amdgcn_mov_dpp(lo, 0x4E, 0xf, 0xf, true);   // quad_perm [2,3,0,1]
-        hi = __builtin_amdgcn_mov_dpp(hi, 0x4E, 0xf, 0xf, true);
-    }
+    lo = __builtin_amdgcn_mov_dpp(lo, CTRL, 0xf, 0xf, true);
+    hi = __builtin_amdgcn_mov_dpp(hi, CTRL, 0xf, 0xf, true);
     return __hiloint2double(hi, lo);
 }
 
-// Sum `rows` (<= TR_ROWS) rows of this wave's tile over its 64 lanes.  Lane L wrote its
-// value of row r at tile[r*TR_STRIDE + tile_pos(L)].  Returns, on lanes with (L & 3) == 0,
-// the total of row L >> 2 (other lanes: undefined).
-__device__ __forceinline__ int tile_pos(int lane) { return (lane >> 4) * 17 + (lane & 15); }
-__device__ __forceinline__ double tile_reduce(const double *tile, int lane) {
-    const double *p = tile + (lane >> 2) * TR_STRIDE + (lane & 3) * 17;
-    double a0 = p[0], a1 = p[1], a2 = p[2], a3 = p[3];
-#pragma unroll
-    for (int e = 4; e < 16; e += 4) {
-        a0 += p[e];
-        a1 += p[e + 1];
-        a2 += p[e + 2];
-        a3 += p[e + 3];
-    }
+// Reduction tile of one wave: TR_ROWS rows; lane L writes its value of row r at
+// tile[r*TR_STRIDE + tile_pos(L)].  tile_reduce returns, on lanes with (L & 7) == 0, the sum
+// over the 64 lanes of row L >> 3 (other lanes: partial sums).  Reader lane (row, seg) adds
+// the 8 entries of its segment, then three DPP steps fold the 8 segments.
+__device__ __forceinline__ int tile_pos(int lane) { return (lane >> 3) * 9 + (lane & 7); }
+__device__ __forceinline__ double tile_reduce(ldptr tile, int lane) {
+    ldptr p = tile + (lane >> 3) * TR_STRIDE + (lane & 7) * 9;
+    double a0 = p[0] + p[4], a1 = p[1] + p[5], a2 = p[2] + p[6], a3 = p[3] + p[7];
     double a = (a0 + a1) + (a2 + a3);
-    a += quad_xor(a, 1);
-    a += quad_xor(a, 0);
+    a += dpp_mov<0xB1>(a);      // quad_perm [1,0,3,2]
+    a += dpp_mov<0x4E>(a);      // quad_perm [2,3,0,1]
+    a += dpp_mov<0x104>(a);     // row_shl:4
     return a;
+}
+
+// Hides a value's provenance from the optimiser: address arithmetic based on it is redone at
+// the use instead of being hoisted out of the fixed-point loop and spilled.
+__device__ __forceinline__ int opaque(int x) {
+    asm volatile("" : "+v"(x));
+    return x;
 }
 
 // ------------------------------------------------------------------ per-bin data
 template <int NB>
 struct Bins {
-    double k[NB], e2kh[NB];
+    double k[NB];
+    double depth;         // water depth (uniform)
+    double w[NB];         // angular frequency (0 for inactive bins)
     double c1[NB];        // w * zeta0 * csh of the current heading (0 for inactive bins)
-    int mode[NB];
     bool act[NB];
     int iw[NB];           // clamped bin index (valid address even when inactive)
 };
 
 template <int NB>
-__device__ __forceinline__ void load_bins(const DevTables &T, Bins<NB> &b) {
+__device__ __forceinline__ void load_bins(const DevTables &T, Bins<NB> &b, int tid) {
+    b.depth = T.depth;
 #pragma unroll
     for (int j = 0; j < NB; j++) {
-        const int i = j * blockDim.x + threadIdx.x;
+        const int i = j * blockDim.x + tid;
         b.act[j] = i < T.nw;
         b.iw[j] = b.act[j] ? i : 0;
-        b.k[j] = b.act[j] ? T.k[b.iw[j]] : 0.0;
-        b.e2kh[j] = T.e2kh[b.iw[j]];
-        b.mode[j] = b.act[j] ? T.mode[b.iw[j]] : 2;
+        const double kk = T.k[b.iw[j]], ww = T.w[b.iw[j]];       // unconditional loads, then selects
+        b.k[j] = b.act[j] ? kk : 0.0;
+        b.w[j] = b.act[j] ? ww : 0.0;
         b.c1[j] = 0.0;
     }
 }
@@ -243,9 +264,13 @@ __device__ __forceinline__ void set_heading_amp(const DevTables &T, Bins<NB> &b,
 #pragma unroll
     for (int j = 0; j < NB; j++) {
         const double z0 = T.zeta[((size_t)ic * T.nHead + ih) * T.nw + b.iw[j]];
-        b.c1[j] = b.act[j] ? T.w[b.iw[j]] * z0 * T.csh[b.iw[j]] : 0.0;
+        b.c1[j] = b.w[j] * z0 * T.csh[b.iw[j]];
     }
 }
+
+// depth regime of a bin, derived from k exactly as the host derives DevTables::mode
+// (helpers.py:211-218): 2 = k == 0, 1 = deep water (k h > 89.4), 0 = finite depth
+__device__ __forceinline__ int depth_mode(double k, double depth) { return k == 0.0 ? 2 : (k * depth > 89.4 ? 1 : 0); }
 
 // ------------------------------------------------------------------ wave kinematics along a run
 // State per bin: a = amp * e^{-i k xi_s};  P = e^{k z_s};  Q = e^{-k (z_s + 2h)}  (Q = 0 in the
@@ -259,11 +284,19 @@ struct Kin {
 
 // Run start: exact evaluation from the absolute position (helpers.py:201,211-222).
 //   amp[j] multiplies the phase factor (c1 for the velocity sweeps, 1 for the pressure sweep).
+struct RunStart {
+    double x, y, z, ux, uy, uz;
+};
+__device__ __forceinline__ RunStart run_start_of(cdptr rec) {
+    return {rec[DS_X], rec[DS_X + 1], rec[DS_X + 2], rec[DS_U], rec[DS_U + 1], rec[DS_U + 2]};
+}
+__device__ __forceinline__ RunStart run_start_of(ldptr r) {              // staged LDS record
+    return {r[12], r[13], r[14], r[15], r[16], r[17]};
+}
 template <int NB, bool KEEPQ>
-__device__ __forceinline__ void kin_start(Kin<NB> &K, const double *__restrict__ rec, const Bins<NB> &b,
+__device__ __forceinline__ void kin_start(Kin<NB> &K, const RunStart rs, const Bins<NB> &b,
                                           const double (&amp)[NB], double cb, double sb) {
-    const double x = rec[DS_X], y = rec[DS_X + 1], z = rec[DS_X + 2];
-    const double ux = rec[DS_U], uy = rec[DS_U + 1], uz = rec[DS_U + 2];
+    const double x = rs.x, y = rs.y, z = rs.z, ux = rs.ux, uy = rs.uy, uz = rs.uz;
     const double xi = cb * x + sb * y;
     const double du = cb * ux + sb * uy;
 #pragma unroll
@@ -274,11 +307,12 @@ __device__ __forceinline__ void kin_start(Kin<NB> &K, const double *__restrict__
         K.ai[j] = amp[j] * s;
         const double kz = b.k[j] * z;
         double P = fast_exp(kz);
-        double Q = b.e2kh[j] * fast_exp(-kz);
-        if (!KEEPQ) Q = (b.mode[j] == 1) ? 0.0 : Q;
+        double Q = fast_exp(-(b.k[j] * (z + 2.0 * b.depth)));       // e^{-k (z + 2h)}
+        const int mode = depth_mode(b.k[j], b.depth);
+        if (!KEEPQ) Q = (mode == 1) ? 0.0 : Q;
         // k == 0 (helpers.py:211-214): Sh = 1, Ch = Cc = 99999  <=>  P + Q = 99999, P - Q = 1 with csh = cch = 1
-        K.P[j] = (b.mode[j] == 2) ? 50000.0 : P;
-        K.Q[j] = (b.mode[j] == 2) ? 49999.0 : Q;
+        K.P[j] = (mode == 2) ? 50000.0 : P;
+        K.Q[j] = (mode == 2) ? 49999.0 : Q;
     }
     const bool rot = du != 0.0, dec = uz != 0.0;     // wave-uniform: vertical members skip the phase rotor,
 #pragma unroll                                       // horizontal ones the depth-decay rotors
@@ -322,13 +356,14 @@ __device__ __forceinline__ void kin_step2(Kin<NB> &K) {
         K.Q[j] *= K.r2q[j];
     }
 }
-// advance to the strip described by (fl, rec) -- wave-uniform control flow
-template <int NB, bool KEEPQ>
-__device__ __forceinline__ void kin_advance(Kin<NB> &K, int fl, const double *__restrict__ rec, const Bins<NB> &b,
+// advance to the strip described by (fl, rec) -- wave-uniform control flow; rec is either the
+// global device record (scalar loads) or the staged LDS record
+template <int NB, bool KEEPQ, typename RecPtr>
+__device__ __forceinline__ void kin_advance(Kin<NB> &K, int fl, RecPtr rec, const Bins<NB> &b,
                                             const double (&amp)[NB], double cb, double sb) {
     const int m = fl & DSI_M;
     if (m == 0) {
-        kin_start<NB, KEEPQ>(K, rec, b, amp, cb, sb);
+        kin_start<NB, KEEPQ>(K, run_start_of(rec), b, amp, cb, sb);
     } else if (m == 1) {
         kin_step1(K);
     } else {
@@ -346,30 +381,54 @@ __device__ __forceinline__ void kin_reset(Kin<NB> &K) {
 }
 
 // ------------------------------------------------------------------ strip sweeps
+#ifdef RAFTX_PHASE_TIMING
+#define PT_DECL unsigned long long pt_[8] = {0, 0, 0, 0, 0, 0, 0, 0}, pt_t = __builtin_readcyclecounter()
+#define PT_MARK(i)                                              \
+    do {                                                        \
+        unsigned long long n_ = __builtin_readcyclecounter();   \
+        pt_[i] += n_ - pt_t;                                    \
+        pt_t = n_;                                              \
+    } while (0)
+#define PT_FLUSH(A)                                                                    \
+    do {                                                                               \
+        if ((A).dbg && threadIdx.x == 0)                                               \
+            for (int i_ = 0; i_ < 8; i_++) atomicAdd((A).dbg + i_, pt_[i_]);          \
+    } while (0)
+#define PT_ARG , unsigned long long *pt_, unsigned long long &pt_t
+#define PT_PASS , pt_, pt_t
+#else
+#define PT_ARG
+#define PT_PASS
+#define PT_DECL
+#define PT_MARK(i)
+#define PT_FLUSH(A)
+#endif
+
 // Inertial excitation of one heading (raft_member.py:1965-1991), ACCUMULATED into F:
 //   f3 = Imat ud + pDyn a_i q,  ud = i w u,  F += [f3 ; a x f3]     (helpers.py:468-483)
 // Imat = Iq qq^T + Ip1 p1p1^T + Ip2 p2p2^T (raft_member.py:1423-1448), or rhoV Cm(w) for
 // MacCamy-Fuchs strips (complex, per bin; raft_member.py:1415-1420).
 template <int NB, bool MCF>
-__device__ __forceinline__ void inertial_excitation(const DevTables &T, const double *__restrict__ ds,
-                                                    const int *__restrict__ dsi, int S, const cplx *__restrict__ cm,
+__device__ __forceinline__ void inertial_excitation(const DevTables &T, cdptr ds,
+                                                    ciptr dsi, int S, const cplx *__restrict__ cm,
                                                     const Bins<NB> &b, int ic, int ih, double cb, double sb,
                                                     cplx (&F)[NB][6]) {
     double one[NB], w[NB], s1[NB], sp[NB], qm[NB];
 #pragma unroll
     for (int j = 0; j < NB; j++) {
         one[j] = 1.0;
-        w[j] = b.act[j] ? T.w[b.iw[j]] : 0.0;
+        w[j] = b.w[j];
         s1[j] = b.c1[j];                                                   // w zeta0 csh
-        const double z0 = b.act[j] ? T.zeta[((size_t)ic * T.nHead + ih) * T.nw + b.iw[j]] : 0.0;
+        const double z0r = T.zeta[((size_t)ic * T.nHead + ih) * T.nw + b.iw[j]];
+        const double z0 = b.act[j] ? z0r : 0.0;
         sp[j] = T.rho * T.g * z0 * T.cch[b.iw[j]];                         // rho g zeta0 / cosh kh scaling (helpers.py:231)
-        qm[j] = (b.mode[j] == 1) ? 0.0 : 1.0;                              // deep water: Sh = Ch = e^{kz}
+        qm[j] = (depth_mode(b.k[j], b.depth) == 1) ? 0.0 : 1.0;                              // deep water: Sh = Ch = e^{kz}
     }
     Kin<NB> K;
     kin_reset(K);
 #pragma unroll 1
     for (int s = 0; s < S; s++) {
-        const double *__restrict__ rec = ds + (size_t)s * DS_N;
+        cdptr rec = ds + (size_t)s * DS_N;
         kin_advance<NB, true>(K, dsi[s], rec, b, one, cb, sb);
         const double ax = rec[DS_A], ay = rec[DS_A + 1], az = rec[DS_A + 2];
         const double ai_ = rec[DS_IQ + 3], rhoV = rec[DS_IQ + 4];
@@ -426,91 +485,139 @@ __device__ __forceinline__ void inertial_excitation(const DevTables &T, const do
     }
 }
 
-// hot per-strip constants of pass A, fetched one strip ahead (scalar loads -> SGPRs)
+// Hot per-strip constants of pass A.  Two sources (template STAGE):
+//  * one-wave-per-SIMD shapes stage them once per workgroup into LDS and read them back as
+//    wave-wide broadcasts (~100 cycles, nothing else hides latency there);
+//  * the two-waves-per-SIMD shapes read them with scalar loads straight into SGPRs (no LDS
+//    space, no VGPRs; the sibling wave covers the constant-cache miss latency).
 struct RecA {
     double ax, ay, az, qx, qy, qz, p1x, p1y, p1z, p2x, p2y, p2z;
-    int fl;
 };
-__device__ __forceinline__ RecA load_recA(const double *__restrict__ ds, const int *__restrict__ dsi, int s) {
-    const double *__restrict__ r = ds + (size_t)s * DS_N;
-    RecA o;
-    o.ax = r[DS_A]; o.ay = r[DS_A + 1]; o.az = r[DS_A + 2];
-    o.qx = r[DS_Q]; o.qy = r[DS_Q + 1]; o.qz = r[DS_Q + 2];
-    o.p1x = r[DS_P1]; o.p1y = r[DS_P1 + 1]; o.p1z = r[DS_P1 + 2];
-    o.p2x = r[DS_P2]; o.p2y = r[DS_P2 + 1]; o.p2z = r[DS_P2 + 2];
-    o.fl = dsi[s];
-    return o;
+__device__ __forceinline__ void stage_recA(cdptr ds, ciptr dsi, int S, const Lds &l) {
+    for (int i = threadIdx.x; i < S * RA_N; i += blockDim.x) {
+        const int s = i / RA_N, f = i % RA_N;
+        // DS_A .. DS_P2+2 are contiguous (12), then DS_X .. DS_U+2 (6)
+        l.ra[i] = ds[(size_t)s * DS_N + (f < 12 ? DS_A + f : DS_X + (f - 12))];
+    }
+    for (int i = threadIdx.x; i < S; i += blockDim.x) l.fl[i] = dsi[i];
+}
+__device__ __forceinline__ RecA load_recA(ldptr r) {              // staged LDS record
+    return {r[0], r[1], r[2], r[3], r[4], r[5], r[6], r[7], r[8], r[9], r[10], r[11]};
+}
+__device__ __forceinline__ RecA load_recA(cdptr rec) {             // global device record (scalar loads)
+    return {rec[DS_A], rec[DS_A + 1], rec[DS_A + 2], rec[DS_Q], rec[DS_Q + 1], rec[DS_Q + 2],
+            rec[DS_P1], rec[DS_P1 + 1], rec[DS_P1 + 2], rec[DS_P2], rec[DS_P2 + 1], rec[DS_P2 + 2]};
+}
+// Per-strip source of flags and records for the sweeps
+template <bool STAGE>
+struct StripSrc;
+template <>
+struct StripSrc<true> {
+    const Lds &l;
+    int fnv;                                   // flag word of the next strip (VGPR, fetched one strip ahead)
+    __device__ __forceinline__ StripSrc(const Lds &l_, cdptr, ciptr) : l(l_), fnv(l_.fl[0]) {}
+    __device__ __forceinline__ ldptr rec(int s) const { return l.ra + s * RA_N; }
+    __device__ __forceinline__ int flags(int s_next) {
+        const int f = __builtin_amdgcn_readfirstlane(fnv);
+        fnv = l.fl[s_next];
+        return f;
+    }
+};
+template <>
+struct StripSrc<false> {
+    cdptr ds;
+    ciptr dsi;
+    int s_cur;
+    __device__ __forceinline__ StripSrc(const Lds &, cdptr ds_, ciptr dsi_) : ds(ds_), dsi(dsi_), s_cur(0) {}
+    __device__ __forceinline__ cdptr rec(int s) const { return ds + (size_t)s * DS_N; }
+    __device__ __forceinline__ int flags(int s_next) {
+        const int f = dsi[s_cur];
+        s_cur = s_next;
+        return f;
+    }
+};
+
+// one strip of pass A: advances K, returns the three sums over this lane's bins
+template <int NB, typename RecPtr>
+__device__ __forceinline__ void passA_strip(Kin<NB> &K, const RecA &r, int fl, RecPtr rec, const Bins<NB> &b,
+                                            double cb, double sb, const cplx (&X)[NB][6], double &v0, double &v1,
+                                            double &v2) {
+    kin_advance<NB, false>(K, fl, rec, b, b.c1, cb, sb);
+    v0 = 0.0; v1 = 0.0; v2 = 0.0;
+    const bool circ = (fl & DSI_CIRC) != 0;
+#pragma unroll
+    for (int j = 0; j < NB; j++) {
+        const double ps = K.P[j] + K.Q[j], pd = K.P[j] - K.Q[j];
+        const double t1r = K.ar[j] * ps, t1i = K.ai[j] * ps, t2r = -K.ai[j] * pd, t2i = K.ar[j] * pd;
+        double rxr = fma(cb, t1r, X[j][0].im), rxi = fma(cb, t1i, -X[j][0].re);
+        double ryr = fma(sb, t1r, X[j][1].im), ryi = fma(sb, t1i, -X[j][1].re);
+        double rzr = t2r + X[j][2].im, rzi = t2i - X[j][2].re;
+        rxr = fma(X[j][4].im, r.az, rxr); rxr = fma(-X[j][5].im, r.ay, rxr);
+        rxi = fma(-X[j][4].re, r.az, rxi); rxi = fma(X[j][5].re, r.ay, rxi);
+        ryr = fma(X[j][5].im, r.ax, ryr); ryr = fma(-X[j][3].im, r.az, ryr);
+        ryi = fma(-X[j][5].re, r.ax, ryi); ryi = fma(X[j][3].re, r.az, ryi);
+        rzr = fma(X[j][3].im, r.ay, rzr); rzr = fma(-X[j][4].im, r.ax, rzr);
+        rzi = fma(-X[j][3].re, r.ay, rzi); rzi = fma(X[j][4].re, r.ax, rzi);
+        const double vqr = fma(r.qz, rzr, fma(r.qy, ryr, r.qx * rxr));
+        const double vqi = fma(r.qz, rzi, fma(r.qy, ryi, r.qx * rxi));
+        if (circ) {                 // |v_perp|^2 = |v|^2 - |v_q|^2   (raft_member.py:2084-2087)
+            const double q2 = fma(vqi, vqi, vqr * vqr);
+            double n2 = fma(rxi, rxi, rxr * rxr);
+            n2 = fma(ryr, ryr, n2); n2 = fma(ryi, ryi, n2);
+            n2 = fma(rzr, rzr, n2); n2 = fma(rzi, rzi, n2);
+            v0 += q2;
+            v1 += n2 - q2;
+        } else {
+            const double v1r = fma(r.p1z, rzr, fma(r.p1y, ryr, r.p1x * rxr));
+            const double v1i = fma(r.p1z, rzi, fma(r.p1y, ryi, r.p1x * rxi));
+            const double v2r = fma(r.p2z, rzr, fma(r.p2y, ryr, r.p2x * rxr));
+            const double v2i = fma(r.p2z, rzi, fma(r.p2y, ryi, r.p2x * rxi));
+            v0 = fma(vqr, vqr, fma(vqi, vqi, v0));
+            v1 = fma(v1r, v1r, fma(v1i, v1i, v1));
+            v2 = fma(v2r, v2r, fma(v2i, v2i, v2));
+        }
+    }
 }
 
 // Pass A of one linearisation (raft_member.py:2039-2090, helpers.py:149-184,684): per strip,
 // the sums over ALL bins of |v_rel . q|^2 and of the transverse squares, v_rel = u - i w (Xi_t + theta x a).
 // X[j][.] = w * XiLast (re/im), so that i w V = i (X_t + X_theta x a).
-// Cross-lane sums go through this wave's LDS transposition tile (no barrier, no shuffles);
-// per-wave results land in vsq[wave][s][3].
-template <int NB>
-__device__ __forceinline__ void linearize_passA(const double *__restrict__ ds, const int *__restrict__ dsi, int S,
+// Cross-lane sums go through
+// this wave's LDS transposition tile (no barrier, no shuffles); per-wave results land in
+// vsq[wave][s][3].
+template <int NB, bool STAGE>
+__device__ __forceinline__ void linearize_passA(cdptr ds, ciptr dsi, int S,
                                                 const Lds &l, const Bins<NB> &b, double cb, double sb,
-                                                const cplx (&X)[NB][6]) {
+                                                const cplx (&X)[NB][6] PT_ARG) {
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    double *tile = l.tile + (size_t)wv * TR_ROWS * TR_STRIDE;
-    double *wr = tile + tile_pos(lane);
-    double *vout = l.vsq + (size_t)wv * S * 3;
+    ldptr tile = l.tile + wv * TR_ROWS * TR_STRIDE;
+    ldptr wr = tile + tile_pos(lane);
+    ldptr vout = l.vsq + wv * S * 3;
     Kin<NB> K;
     kin_reset(K);
     if (S <= 0) return;
-    RecA nx = load_recA(ds, dsi, 0);
+    StripSrc<STAGE> src(l, ds, dsi);
 #pragma unroll 1
     for (int s0 = 0; s0 < S; s0 += SB) {
         const int nb = min(SB, S - s0);
 #pragma unroll 1
         for (int jj = 0; jj < nb; jj++) {
             const int s = s0 + jj;
-            const RecA r = nx;
-            nx = load_recA(ds, dsi, min(s + 1, S - 1));
-            kin_advance<NB, false>(K, r.fl, ds + (size_t)s * DS_N, b, b.c1, cb, sb);
-            double v0 = 0.0, v1 = 0.0, v2 = 0.0;
-            const bool circ = (r.fl & DSI_CIRC) != 0;
-#pragma unroll
-            for (int j = 0; j < NB; j++) {
-                const double ps = K.P[j] + K.Q[j], pd = K.P[j] - K.Q[j];
-                const double t1r = K.ar[j] * ps, t1i = K.ai[j] * ps, t2r = -K.ai[j] * pd, t2i = K.ar[j] * pd;
-                double rxr = fma(cb, t1r, X[j][0].im), rxi = fma(cb, t1i, -X[j][0].re);
-                double ryr = fma(sb, t1r, X[j][1].im), ryi = fma(sb, t1i, -X[j][1].re);
-                double rzr = t2r + X[j][2].im, rzi = t2i - X[j][2].re;
-                rxr = fma(X[j][4].im, r.az, rxr); rxr = fma(-X[j][5].im, r.ay, rxr);
-                rxi = fma(-X[j][4].re, r.az, rxi); rxi = fma(X[j][5].re, r.ay, rxi);
-                ryr = fma(X[j][5].im, r.ax, ryr); ryr = fma(-X[j][3].im, r.az, ryr);
-                ryi = fma(-X[j][5].re, r.ax, ryi); ryi = fma(X[j][3].re, r.az, ryi);
-                rzr = fma(X[j][3].im, r.ay, rzr); rzr = fma(-X[j][4].im, r.ax, rzr);
-                rzi = fma(-X[j][3].re, r.ay, rzi); rzi = fma(X[j][4].re, r.ax, rzi);
-                const double vqr = fma(r.qz, rzr, fma(r.qy, ryr, r.qx * rxr));
-                const double vqi = fma(r.qz, rzi, fma(r.qy, ryi, r.qx * rxi));
-                if (circ) {                 // |v_perp|^2 = |v|^2 - |v_q|^2   (raft_member.py:2084-2087)
-                    const double q2 = fma(vqi, vqi, vqr * vqr);
-                    double n2 = fma(rxi, rxi, rxr * rxr);
-                    n2 = fma(ryr, ryr, n2); n2 = fma(ryi, ryi, n2);
-                    n2 = fma(rzr, rzr, n2); n2 = fma(rzi, rzi, n2);
-                    v0 += q2;
-                    v1 += n2 - q2;
-                } else {
-                    const double v1r = fma(r.p1z, rzr, fma(r.p1y, ryr, r.p1x * rxr));
-                    const double v1i = fma(r.p1z, rzi, fma(r.p1y, ryi, r.p1x * rxi));
-                    const double v2r = fma(r.p2z, rzr, fma(r.p2y, ryr, r.p2x * rxr));
-                    const double v2i = fma(r.p2z, rzi, fma(r.p2y, ryi, r.p2x * rxi));
-                    v0 = fma(vqr, vqr, fma(vqi, vqi, v0));
-                    v1 = fma(v1r, v1r, fma(v1i, v1i, v1));
-                    v2 = fma(v2r, v2r, fma(v2i, v2i, v2));
-                }
-            }
+            const auto rec = src.rec(s);
+            const RecA r = load_recA(rec);                  // issued before the (branchy) kinematics update
+            const int fl = src.flags(min(s + 1, S - 1));
+            double v0, v1, v2;
+            passA_strip<NB>(K, r, fl, rec, b, cb, sb, X, v0, v1, v2);
             wr[(jj * 3 + 0) * TR_STRIDE] = v0;
             wr[(jj * 3 + 1) * TR_STRIDE] = v1;
             wr[(jj * 3 + 2) * TR_STRIDE] = v2;
         }
+        PT_MARK(6);   // strips of pass A
         wave_lds_fence();
         {
             const double a = tile_reduce(tile, lane);
-            const int row = lane >> 2;
-            if ((lane & 3) == 0 && row < nb * 3) vout[(size_t)s0 * 3 + row] = a;
+            const int row = lane >> 3;
+            if ((lane & 7) == 0 && row < nb * 3) vout[s0 * 3 + row] = a;
         }
         wave_lds_fence();
     }
@@ -521,21 +628,22 @@ __device__ __forceinline__ void linearize_passA(const double *__restrict__ ds, c
 //   U = sum_c b_c al_c W_c,  V = sum_c b_c ga_c W_c,  W_c = [n_c ; a x n_c]
 // (so that translate(Bmat u) = t1 U + t2 V; raft_member.py:2122-2124, helpers.py:468-483) and its
 // share of B_drag = sum_{s,c} b_c W_c W_c^T (raft_member.py:2117-2118, helpers.py:537-560).
-// FRESH: recompute b_c from vsq; otherwise reuse l.bc (other headings of the same linearisation).
+// FRESH: recompute b_c from vsq (and park them in vsq row 0); otherwise reuse the parked b_c (other
+// headings of the same linearisation).
 template <bool FRESH>
-__device__ __forceinline__ void strip_phase(const double *__restrict__ ds, const int *__restrict__ dsi, int S,
+__device__ __forceinline__ void strip_phase(cdptr ds, ciptr dsi, int S,
                                             const Lds &l, double cb, double sb, bool multi) {
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, nwv = blockDim.x >> 6;
     double b6[21];
 #pragma unroll
     for (int e = 0; e < 21; e++) b6[e] = 0.0;
     for (int s = threadIdx.x; s < S; s += blockDim.x) {
-        const double *__restrict__ rec = ds + (size_t)s * DS_N;
+        cdptr rec = ds + (size_t)s * DS_N;
         double bc[3];
         if (FRESH) {
             double a = 0, c1 = 0, c2 = 0;
             for (int i = 0; i < nwv; i++) {
-                const double *r = l.vsq + ((size_t)i * S + s) * 3;
+                ldptr r = l.vsq + (i * S + s) * 3;
                 a += r[0];
                 c1 += r[1];
                 c2 += r[2];
@@ -551,13 +659,13 @@ __device__ __forceinline__ void strip_phase(const double *__restrict__ ds, const
             bc[0] = rec[DS_DQ] * vRq + rec[DS_DQ + 3] * vRq;     // Bprime_q + Bprime_End (:2093,:2110)
             bc[1] = rec[DS_DQ + 1] * vR1;
             bc[2] = rec[DS_DQ + 2] * vR2;
-            l.bc[(size_t)s * 3 + 0] = bc[0];
-            l.bc[(size_t)s * 3 + 1] = bc[1];
-            l.bc[(size_t)s * 3 + 2] = bc[2];
+            l.vsq[s * 3 + 0] = bc[0];
+            l.vsq[s * 3 + 1] = bc[1];
+            l.vsq[s * 3 + 2] = bc[2];
         } else {
-            bc[0] = l.bc[(size_t)s * 3 + 0];
-            bc[1] = l.bc[(size_t)s * 3 + 1];
-            bc[2] = l.bc[(size_t)s * 3 + 2];
+            bc[0] = l.vsq[s * 3 + 0];
+            bc[1] = l.vsq[s * 3 + 1];
+            bc[2] = l.vsq[s * 3 + 2];
         }
         const double ax = rec[DS_A], ay = rec[DS_A + 1], az = rec[DS_A + 2];
         double U[6] = {0, 0, 0, 0, 0, 0}, V[6] = {0, 0, 0, 0, 0, 0};
@@ -586,26 +694,24 @@ __device__ __forceinline__ void strip_phase(const double *__restrict__ ds, const
         }
 #pragma unroll
         for (int j = 0; j < 6; j++) {
-            l.uv[(size_t)s * 12 + j] = U[j];
-            l.uv[(size_t)s * 12 + 6 + j] = V[j];
+            l.uv[s * 12 + j] = U[j];
+            l.uv[s * 12 + 6 + j] = V[j];
         }
     }
     if (FRESH) {
-        // B_drag: reduce the 21 unique entries over the lanes of each wave (two tile rounds), then over waves
-        double *tile = l.tile + (size_t)wv * TR_ROWS * TR_STRIDE;
-        double *wr = tile + tile_pos(lane);
-        wave_lds_fence();
+        // B_drag: reduce the 21 unique entries over the lanes of each wave (three tile rounds), then over waves
+        ldptr tile = l.tile + wv * TR_ROWS * TR_STRIDE;
+        ldptr wr = tile + tile_pos(lane);
 #pragma unroll
-        for (int e = 0; e < 16; e++) wr[e * TR_STRIDE] = b6[e];
-        wave_lds_fence();
-        double a = tile_reduce(tile, lane);
-        if ((lane & 3) == 0) l.bdw[wv * 24 + (lane >> 2)] = a;
-        wave_lds_fence();
+        for (int r0 = 0; r0 < 21; r0 += TR_ROWS) {
+            wave_lds_fence();
 #pragma unroll
-        for (int e = 16; e < 21; e++) wr[(e - 16) * TR_STRIDE] = b6[e];
-        wave_lds_fence();
-        a = tile_reduce(tile, lane);
-        if ((lane & 3) == 0 && (lane >> 2) < 5) l.bdw[wv * 24 + 16 + (lane >> 2)] = a;
+            for (int e = 0; e < TR_ROWS; e++)
+                if (r0 + e < 21) wr[e * TR_STRIDE] = b6[r0 + e];
+            wave_lds_fence();
+            const double a = tile_reduce(tile, lane);
+            if ((lane & 7) == 0 && r0 + (lane >> 3) < 21) l.bdw[wv * 24 + r0 + (lane >> 3)] = a;
+        }
         wg_sync(multi);
         if (threadIdx.x < 36) {
             const int i = threadIdx.x / 6, j = threadIdx.x % 6;
@@ -622,50 +728,42 @@ __device__ __forceinline__ void strip_phase(const double *__restrict__ ds, const
 // Pass B: drag excitation of one heading with the live coefficients (raft_member.py:2122-2124,
 // :2146-2151), ACCUMULATED into F: F += sum_s t1 U_s + t2 V_s.  U,V of the next strip are
 // fetched from LDS one strip ahead.
-template <int NB>
-__device__ __forceinline__ void drag_excitation(const double *__restrict__ ds, const int *__restrict__ dsi, int S,
-                                                const Lds &l, const Bins<NB> &b, double cb, double sb,
-                                                cplx (&F)[NB][6]) {
+template <int NB, typename RecPtr>
+__device__ __forceinline__ void passB_strip(Kin<NB> &K, int fl, RecPtr rec, const Bins<NB> &b,
+                                            double cb, double sb, const double (&U)[6], const double (&V)[6],
+                                            cplx (&F)[NB][6]) {
+    kin_advance<NB, false>(K, fl, rec, b, b.c1, cb, sb);
+#pragma unroll
+    for (int j = 0; j < NB; j++) {
+        const double ps = K.P[j] + K.Q[j], pd = K.P[j] - K.Q[j];
+        const double t1r = K.ar[j] * ps, t1i = K.ai[j] * ps, t2r = -K.ai[j] * pd, t2i = K.ar[j] * pd;
+#pragma unroll
+        for (int q = 0; q < 6; q++) {
+            F[j][q].re = fma(t1r, U[q], fma(t2r, V[q], F[j][q].re));
+            F[j][q].im = fma(t1i, U[q], fma(t2i, V[q], F[j][q].im));
+        }
+    }
+}
+__device__ __forceinline__ void load_uv(ldptr uv, double (&U)[6], double (&V)[6]) {
+#pragma unroll
+    for (int q = 0; q < 6; q++) {
+        U[q] = uv[q];
+        V[q] = uv[6 + q];
+    }
+}
+template <int NB, bool STAGE>
+__device__ __forceinline__ void drag_excitation(cdptr ds, ciptr dsi, int S, const Lds &l, const Bins<NB> &b, double cb,
+                                                double sb, cplx (&F)[NB][6]) {
     Kin<NB> K;
     kin_reset(K);
     if (S <= 0) return;
-    double Un[6], Vn[6];
-#pragma unroll
-    for (int q = 0; q < 6; q++) {
-        Un[q] = l.uv[q];
-        Vn[q] = l.uv[6 + q];
-    }
-    int fn = dsi[0];
+    StripSrc<STAGE> src(l, ds, dsi);
 #pragma unroll 1
     for (int s = 0; s < S; s++) {
         double U[6], V[6];
-#pragma unroll
-        for (int q = 0; q < 6; q++) {
-            U[q] = Un[q];
-            V[q] = Vn[q];
-        }
-        const int fl = fn;
-        {
-            const int sn = min(s + 1, S - 1);
-            const double *uv = l.uv + (size_t)sn * 12;
-            fn = dsi[sn];
-#pragma unroll
-            for (int q = 0; q < 6; q++) {
-                Un[q] = uv[q];
-                Vn[q] = uv[6 + q];
-            }
-        }
-        kin_advance<NB, false>(K, fl, ds + (size_t)s * DS_N, b, b.c1, cb, sb);
-#pragma unroll
-        for (int j = 0; j < NB; j++) {
-            const double ps = K.P[j] + K.Q[j], pd = K.P[j] - K.Q[j];
-            const double t1r = K.ar[j] * ps, t1i = K.ai[j] * ps, t2r = -K.ai[j] * pd, t2i = K.ar[j] * pd;
-#pragma unroll
-            for (int q = 0; q < 6; q++) {
-                F[j][q].re = fma(t1r, U[q], fma(t2r, V[q], F[j][q].re));
-                F[j][q].im = fma(t1i, U[q], fma(t2i, V[q], F[j][q].im));
-            }
-        }
+        load_uv(l.uv + s * 12, U, V);               // issued before the (branchy) kinematics update
+        const int fl = src.flags(min(s + 1, S - 1));
+        passB_strip<NB>(K, fl, src.rec(s), b, cb, sb, U, V, F);
     }
 }
 
@@ -772,6 +870,7 @@ __device__ __forceinline__ void assemble_and_solve(const Lds &l, const double *_
             lu.ar[r][c] = fma(-w2, M, l.mat[72 + e]);     // Z = -w^2 M + i w B + C  (:1086)
             lu.ai[r][c] = w * B;
         }
+        __builtin_amdgcn_sched_barrier(0);               // assemble row by row: bounds the LDS loads in flight
     }
     if constexpr ((FLAGS & KF_OUTZ) != 0) {
         if (active && Zout) {      // last iterate wins (fowt.Z, :1155)
@@ -797,8 +896,8 @@ __device__ __forceinline__ int wg_and(int v, bool multi) {
 
 struct PairCtx {
     int pair, d, ic, S;
-    const double *__restrict__ ds;
-    const int *__restrict__ dsi;
+    cdptr ds;
+    ciptr dsi;
     const cplx *__restrict__ cm;
 };
 __device__ __forceinline__ bool pair_ctx(const DevTables &T, PairCtx &p, int pair) {
@@ -808,8 +907,8 @@ __device__ __forceinline__ bool pair_ctx(const DevTables &T, PairCtx &p, int pai
     p.d = p.pair / T.nCase;
     p.ic = p.pair % T.nCase;
     p.S = (int)(T.off[p.d + 1] - T.off[p.d]);
-    p.ds = T.ds + (size_t)T.off[p.d] * DS_N;
-    p.dsi = T.dsi + (size_t)T.off[p.d];
+    p.ds = as_const(T.ds + (size_t)T.off[p.d] * DS_N);
+    p.dsi = as_const(T.dsi + (size_t)T.off[p.d]);
     p.cm = T.cm ? T.cm + (size_t)T.cmoff[p.d] * 2 * T.nw : nullptr;
     return true;
 }
@@ -838,7 +937,7 @@ __global__ void __launch_bounds__(MAXT, MINB) k_excitation(DevTables T, cplx *__
     const int ih = blockIdx.x % T.nHead;
     if (!pair_ctx(T, p, blockIdx.x / T.nHead)) return;
     Bins<NB> b;
-    load_bins(T, b);
+    load_bins(T, b, threadIdx.x);
     set_heading_amp(T, b, p.ic, ih);
     const double beta = T.beta[(size_t)p.ic * T.nHead + ih];
     const double cb = cos(beta), sb = sin(beta);
@@ -856,9 +955,12 @@ __global__ void __launch_bounds__(MAXT, MINB) k_linearize(DevTables T, const cpl
     PairCtx p;
     if (!pair_ctx(T, p, pair_of_block(blockIdx.x, T.nDesign * T.nCase))) return;
     const bool multi = blockDim.x > 64;
-    Lds l = carve(smem, p.S, T.nw, blockDim.x >> 6);
+    constexpr bool STAGE = (MAXT == 64);
+    Lds l = carve(smem, p.S, T.nw, blockDim.x >> 6, STAGE);
+    if (STAGE) stage_recA(p.ds, p.dsi, p.S, l);
     Bins<NB> b;
-    load_bins(T, b);
+    load_bins(T, b, threadIdx.x);
+    wg_sync(multi);
     {
         set_heading_amp(T, b, p.ic, 0);
         const double beta = T.beta[(size_t)p.ic * T.nHead];
@@ -866,14 +968,17 @@ __global__ void __launch_bounds__(MAXT, MINB) k_linearize(DevTables T, const cpl
         cplx X[NB][6];
 #pragma unroll
         for (int j = 0; j < NB; j++) {
-            const double w = b.act[j] ? T.w[b.iw[j]] : 0.0;
+            const double w = b.w[j];
 #pragma unroll
             for (int q = 0; q < 6; q++) {
                 const cplx xi = Xi_in[((size_t)p.pair * 6 + q) * T.nw + b.iw[j]];
                 X[j][q] = {w * xi.re, w * xi.im};
             }
         }
-        linearize_passA<NB>(p.ds, p.dsi, p.S, l, b, cb, sb, X);
+#ifdef RAFTX_PHASE_TIMING
+        unsigned long long pt_[8], pt_t = 0;
+#endif
+        linearize_passA<NB, STAGE>(p.ds, p.dsi, p.S, l, b, cb, sb, X PT_PASS);
         wg_sync(multi);
         strip_phase<true>(p.ds, p.dsi, p.S, l, cb, sb, multi);
     }
@@ -889,7 +994,7 @@ __global__ void __launch_bounds__(MAXT, MINB) k_linearize(DevTables T, const cpl
             }
             cplx F[NB][6];
             zero6(F);
-            drag_excitation<NB>(p.ds, p.dsi, p.S, l, b, cb, sb, F);
+            drag_excitation<NB, STAGE>(p.ds, p.dsi, p.S, l, b, cb, sb, F);
             store6(F_drag + (((size_t)p.pair * T.nHead + ih) * 6) * T.nw, T.nw, b, F);
         }
     }
@@ -904,6 +1009,7 @@ struct SolveArgs {
     double *__restrict__ B_drag;         // [pair,36] or null
     cplx *__restrict__ F_wave;           // [pair,nHead,6,nw] or null
     cplx *__restrict__ Z;                // [pair,36,nw] or null
+    unsigned long long *dbg;             // RAFTX_PHASE_TIMING builds: [8] accumulated wave-0 cycles per phase
 };
 
 // The fused fixed point (raft_model.py:1052-1142) + per-heading response (:1189-1236).
@@ -919,13 +1025,16 @@ __global__ void __launch_bounds__(MAXT, MINB) k_solve_dynamics(DevTables T, Solv
     constexpr bool EXTRA = (FLAGS & KF_EXTRA) != 0, MCF = (FLAGS & KF_MCF) != 0, MULTI = (FLAGS & KF_MULTI) != 0;
     PairCtx p;
     if (!pair_ctx(T, p, pair_of_block(blockIdx.x, T.nDesign * T.nCase))) return;
+    PT_DECL;
     const bool multi = blockDim.x > 64;
     const int nw = T.nw, nHs = T.nHead, nH = MULTI ? T.nHead : 1;
     const int pair = p.pair, S = p.S;
     const cplx *cm = (MCF && T.cm) ? p.cm : nullptr;
-    Lds l = carve(smem, S, nw, blockDim.x >> 6);
+    constexpr bool STAGE = (MAXT == 64);
+    Lds l = carve(smem, S, nw, blockDim.x >> 6, STAGE);
+    if (STAGE) stage_recA(p.ds, p.dsi, S, l);
     Bins<NB> b;
-    load_bins(T, b);
+    load_bins(T, b, threadIdx.x);
     set_heading_amp(T, b, p.ic, 0);
     for (int i = threadIdx.x; i < 108; i += blockDim.x) {
         const int e = i % 36, wh = i / 36;
@@ -965,68 +1074,89 @@ __global__ void __launch_bounds__(MAXT, MINB) k_solve_dynamics(DevTables T, Solv
     const double *Bw = (FDEP && T.MBw) ? T.MBw + ((size_t)p.d * 2 + 1) * 36 * nw : nullptr;
     cplx *Zout = (OUTZ && A.Z) ? A.Z + (size_t)pair * 36 * nw : nullptr;
     wg_sync(multi);
+    PT_MARK(0);   // set-up + inertial excitation
 
     int iiter = 0, done = 0, converged = 0, nan = 0;
 #pragma unroll 1
     while (true) {
+        // The per-bin constants are re-read (L1/L2 hits) at the top of every iteration from an
+        // opaque thread id, so that they do not stay live -- and get spilled -- across the solve.
+        load_bins(T, b, opaque((int)threadIdx.x));
+        set_heading_amp(T, b, p.ic, 0);
         {
             cplx X[NB][6];
 #pragma unroll
             for (int j = 0; j < NB; j++) {
-                const double w = b.act[j] ? T.w[b.iw[j]] : 0.0;
+                const double w = b.w[j];
+                const int iw = opaque(b.iw[j]);
 #pragma unroll
                 for (int q = 0; q < 6; q++) {
-                    X[j][q].re = b.act[j] ? w * l.xl[(2 * q) * l.nxl + b.iw[j]] : 0.0;
-                    X[j][q].im = b.act[j] ? w * l.xl[(2 * q + 1) * l.nxl + b.iw[j]] : 0.0;
+                    const double vr = l.xl[(2 * q) * l.nxl + iw], vi = l.xl[(2 * q + 1) * l.nxl + iw];
+                    X[j][q].re = b.act[j] ? w * vr : 0.0;          // unconditional loads (clamped bin), then select
+                    X[j][q].im = b.act[j] ? w * vi : 0.0;
                 }
             }
-            linearize_passA<NB>(p.ds, p.dsi, S, l, b, cb0, sb0, X);          // :1063
+            PT_MARK(7);   // XiLast fetch
+            linearize_passA<NB, STAGE>(p.ds, p.dsi, S, l, b, cb0, sb0, X PT_PASS);          // :1063
         }
         wg_sync(multi);
+        PT_MARK(1);   // pass A
         strip_phase<true>(p.ds, p.dsi, S, l, cb0, sb0, multi);
+        PT_MARK(2);   // strip-lane phase
         cplx x[NB][6];
 #pragma unroll
-        for (int j = 0; j < NB; j++)
+        for (int j = 0; j < NB; j++) {
+            const int iw = opaque(b.iw[j]);
 #pragma unroll
-            for (int q = 0; q < 6; q++) x[j][q] = b.act[j] ? xio[(size_t)q * nw + b.iw[j]] : cplx{0.0, 0.0};   // F_lin
-        drag_excitation<NB>(p.ds, p.dsi, S, l, b, cb0, sb0, x);               // + F_drag (:1064,:1081)
+            for (int q = 0; q < 6; q++) x[j][q] = xio[(size_t)q * nw + iw];   // F_lin (clamped bin when inactive)
+        }
+        drag_excitation<NB, STAGE>(p.ds, p.dsi, S, l, b, cb0, sb0, x);               // + F_drag (:1064,:1081)
+        PT_MARK(3);   // pass B
         int bad = 0, ok = 1;
         const bool last_chance = iiter + 1 >= A.nIter;
+        const int tid_s = opaque((int)threadIdx.x);                  // bin bookkeeping re-derived: nothing of b stays live here
 #pragma unroll
         for (int j = 0; j < NB; j++) {
+            const int ib = j * blockDim.x + tid_s;
+            const bool act = ib < nw;
+            const int iw = act ? ib : 0;
+            const double wl = T.w[iw];
+            const double w = act ? wl : 0.0;
             if constexpr (OUTF) {                                     // total excitation, heading 0 (:1212)
-                if (b.act[j] && A.F_wave) {
+                if (act && A.F_wave) {
 #pragma unroll
-                    for (int q = 0; q < 6; q++) A.F_wave[(((size_t)pair * nHs) * 6 + q) * nw + b.iw[j]] = x[j][q];
+                    for (int q = 0; q < 6; q++) A.F_wave[(((size_t)pair * nHs) * 6 + q) * nw + iw] = x[j][q];
                 }
             }
-            const double w = b.act[j] ? T.w[b.iw[j]] : 0.0;
-            assemble_and_solve<FLAGS>(l, Mw, Bw, nw, b.iw[j], w, x[j], Zout, b.act[j]);   // :1086-1089
+            assemble_and_solve<FLAGS>(l, Mw, Bw, nw, iw, w, x[j], Zout, act);   // :1086-1089
             // NaN check (:1098), convergence (:1103-1104) and relaxation (:1133)
-            if (b.act[j]) {
+            if (act) {
 #pragma unroll
                 for (int q = 0; q < 6; q++) {
-                    const double lr = l.xl[(2 * q) * l.nxl + b.iw[j]], li = l.xl[(2 * q + 1) * l.nxl + b.iw[j]];
+                    const double lr = l.xl[(2 * q) * l.nxl + iw], li = l.xl[(2 * q + 1) * l.nxl + iw];
                     if (isnan(x[j][q].re) || isnan(x[j][q].im)) bad = 1;
                     const double dr = x[j][q].re - lr, di = x[j][q].im - li;
                     const double tc = sqrt(dr * dr + di * di) / (sqrt(x[j][q].re * x[j][q].re + x[j][q].im * x[j][q].im) + A.tol);
                     if (!(tc < A.tol)) ok = 0;
-                    l.xl[(2 * q) * l.nxl + b.iw[j]] = 0.2 * lr + 0.8 * x[j][q].re;
-                    l.xl[(2 * q + 1) * l.nxl + b.iw[j]] = 0.2 * li + 0.8 * x[j][q].im;
+                    l.xl[(2 * q) * l.nxl + iw] = 0.2 * lr + 0.8 * x[j][q].re;
+                    l.xl[(2 * q + 1) * l.nxl + iw] = 0.2 * li + 0.8 * x[j][q].im;
                 }
             }
         }
+        PT_MARK(4);   // assemble + solve + convergence
         done = iiter + 1;
         nan = wg_or(bad, multi);
         converged = nan ? 0 : wg_and(ok, multi);
         if (nan || converged || last_chance) {
             // Heading 0 of the final response, Zinv (F_lin + F_drag(0)), is exactly this solve (:1216)
 #pragma unroll
-            for (int j = 0; j < NB; j++)
-                if (b.act[j]) {
+            for (int j = 0; j < NB; j++) {
+                const int ib = j * blockDim.x + tid_s;
+                if (ib < nw) {
 #pragma unroll
-                    for (int q = 0; q < 6; q++) xio[(size_t)q * nw + b.iw[j]] = nan ? cplx{NAN, NAN} : x[j][q];
+                    for (int q = 0; q < 6; q++) xio[(size_t)q * nw + ib] = nan ? cplx{NAN, NAN} : x[j][q];
                 }
+            }
             break;
         }
         iiter++;
@@ -1054,7 +1184,7 @@ __global__ void __launch_bounds__(MAXT, MINB) k_solve_dynamics(DevTables T, Solv
                 }
             }
             inertial_excitation<NB, MCF>(T, p.ds, p.dsi, S, cm, b, p.ic, ih, cb, sb, x);
-            drag_excitation<NB>(p.ds, p.dsi, S, l, b, cb, sb, x);               // :1209,:1212
+            drag_excitation<NB, STAGE>(p.ds, p.dsi, S, l, b, cb, sb, x);               // :1209,:1212
             cplx *xo = A.Xi + ((size_t)pair * nHs + ih) * 6 * nw;
 #pragma unroll
             for (int j = 0; j < NB; j++) {
@@ -1064,7 +1194,7 @@ __global__ void __launch_bounds__(MAXT, MINB) k_solve_dynamics(DevTables T, Solv
                         for (int q = 0; q < 6; q++) A.F_wave[(((size_t)pair * nHs + ih) * 6 + q) * nw + b.iw[j]] = x[j][q];
                     }
                 }
-                const double w = b.act[j] ? T.w[b.iw[j]] : 0.0;
+                const double w = b.w[j];
                 assemble_and_solve<(FLAGS & ~KF_OUTZ)>(l, Mw, Bw, nw, b.iw[j], w, x[j], nullptr, b.act[j]);   // Zinv @ F_wave (:1216)
                 if (b.act[j]) {
 #pragma unroll
@@ -1073,6 +1203,8 @@ __global__ void __launch_bounds__(MAXT, MINB) k_solve_dynamics(DevTables T, Solv
             }
         }
     }
+    PT_MARK(5);       // vote, final stores, other headings
+    PT_FLUSH(A);
     if (threadIdx.x < 36 && A.B_drag) A.B_drag[(size_t)pair * 36 + threadIdx.x] = l.Bd[threadIdx.x];
     if (threadIdx.x == 0) {
         if (A.niter) A.niter[pair] = done;
