@@ -51,6 +51,21 @@ def load_sweep(n_design, rank=0):
                 nIter=int(fx["nIter"]), XiStart=float(fx["XiStart"]), idx=idx, fx=fx)
 
 
+def measured_traffic(n_design):
+    """HBM-side bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes
+    (profiles/traffic_latest.json, written by scripts/gpu_traffic.sh + scripts/traffic_summary.py;
+    FETCH_SIZE and WRITE_SIZE are collected in separate passes and FETCH_SIZE is doubled as
+    MI355X_MICROARCH.md prescribes for gfx950).  None if no profile matches this workload."""
+    path = os.path.join(ROOT, "profiles", "traffic_latest.json")
+    if not os.path.exists(path):
+        return None
+    with open(path) as f:
+        t = json.load(f)
+    if int(t.get("designs_per_gpu", -1)) != int(n_design):
+        return None
+    return float(t["hbm_bytes_per_launch"])
+
+
 def algorithmic_bytes(sw):
     """A_min = 256*S + 3*288 + 8*nw + 96*nw per (design, case)."""
     nw = len(sw["w"])
@@ -162,6 +177,15 @@ def main():
     max_err = float(max(errs)) if errs else None
     assert nan == 0 and (max_err is None or max_err < 1e-6), "bench results fail parity (err=%r, nan=%d)" % (max_err, nan)
 
+    # PCIe-inclusive rate of one whole boundary crossing (H2D of the tables + launch + D2H of Xi): informational,
+    # never `value`
+    t0 = time.perf_counter()
+    ctx.upload_designs_raw(sw["off"], sw["strips"], sw["M0"], sw["B0"], sw["C0"], nw)
+    ctx.upload_cases(sw["w"], sw["k"], sw["depth"], 1025.0, 9.81, sw["zeta"][None], sw["beta"][None])
+    ctx.solve_dynamics_device(sw["nIter"], 0.01, sw["XiStart"])
+    ctx.fetch_results(want_Xi=True)
+    pcie_rate = args.designs * nw / (time.perf_counter() - t0)
+
     n_dcf_rank = args.designs * 1 * nw
     total_dcf = n_dcf_rank * world * args.steps
     value = total_dcf / elapsed
@@ -179,9 +203,10 @@ def main():
                                "nIter=4, tol=0.01; designs = 64 reference-built sweep variants tiled" % (args.designs, nw),
                    "designs_per_gpu": args.designs, "cases": 1, "nw": nw, "sharding": "designs over ranks, no collective"},
         "rao_max_rel_err_vs_reference": max_err,
+        "pcie_inclusive_dcf_per_s_per_gpu": pcie_rate,
         "mean_iterations": float(np.mean(niter)),
         "roofline": {"bound": "hbm", "achieved": A / (k_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": A / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None,
+                     "frac": A / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": measured_traffic(args.designs),
                      "kernel": "k_solve_dynamics", "kernel_ms": k_ms, "algorithmic_bytes_per_launch": A,
                      "note": "fused kernel is fp64-VALU-bound (SURVEY.md 8d): see roofline_fp64_valu"},
         "roofline_fp64_valu": {"achieved": flops / (k_ms * 1e-3) / 1e12, "peak": FP64_VALU_PEAK_TF, "unit": "TFLOP/s",

@@ -346,24 +346,17 @@ extern "C" int raftx_upload_cases(raftx_ctx *c, int nCase, int nHead, int nw, co
     HIPCHK(c, hipStreamSynchronize(c->stream));
     free_list(c->case_allocs);
     c->have_cases = false;
-    // per-bin depth constants, computed once on the host in full libm precision
-    std::vector<double> csh(nw), cch(nw), e2kh(nw);
-    std::vector<int> mode(nw);
+    // per-bin depth constants, computed once on the host in full libm precision.  The kernels derive
+    // the depth regime (k == 0 / deep / finite) from k themselves, with the same rule.
+    std::vector<double> csh(nw), cch(nw);
     for (int i = 0; i < nw; i++) {
         double kh = k[i] * depth;
-        if (k[i] == 0.0) {
-            mode[i] = 2;                  // Sh = 1, Ch = Cc = 99999: the kernels set P + Q = 99999, P - Q = 1
+        if (k[i] == 0.0 || kh > 89.4) {   // helpers.py:211-218: Sh = 1, Ch = Cc = 99999  /  Sh = Ch = e^{kz}, Cc = e^{kz} + e^{-k(z+2h)}
             csh[i] = cch[i] = 1.0;
-            e2kh[i] = 0.0;
-        } else if (kh > 89.4) {   // deep-water branch of helpers.py:215-218: Sh = Ch = e^{kz}, Cc = e^{kz} + e^{-k(z+2h)}
-            mode[i] = 1;
-            csh[i] = cch[i] = 1.0;
-            e2kh[i] = exp(-2.0 * kh);
-        } else {
-            mode[i] = 0;
-            e2kh[i] = exp(-2.0 * kh);
+        } else {                          // helpers.py:219-222 written with decaying exponentials only
+            double e2kh = exp(-2.0 * kh);
             csh[i] = 1.0 / (-expm1(-2.0 * kh));
-            cch[i] = 1.0 / (1.0 + e2kh[i]);
+            cch[i] = 1.0 / (1.0 + e2kh);
         }
     }
     DevTables &T = c->T;
@@ -378,8 +371,6 @@ extern "C" int raftx_upload_cases(raftx_ctx *c, int nCase, int nHead, int nw, co
     rc |= upload(c, c->case_allocs, k, (size_t)nw, &T.k);
     rc |= upload(c, c->case_allocs, csh.data(), (size_t)nw, &T.csh);
     rc |= upload(c, c->case_allocs, cch.data(), (size_t)nw, &T.cch);
-    rc |= upload(c, c->case_allocs, e2kh.data(), (size_t)nw, &T.e2kh);
-    rc |= upload(c, c->case_allocs, mode.data(), (size_t)nw, &T.mode);
     rc |= upload(c, c->case_allocs, zeta, (size_t)nCase * nHead * nw, &T.zeta);
     rc |= upload(c, c->case_allocs, beta, (size_t)nCase * nHead, &T.beta);
     if (rc) return -2;

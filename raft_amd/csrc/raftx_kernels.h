@@ -132,8 +132,8 @@ struct DevTables {
     const cplx *__restrict__ cm;         // [nRows,2,nw] or null
     int nCase, nHead, nw;
     const double *__restrict__ w, *__restrict__ k;    // [nw]
-    const double *__restrict__ csh, *__restrict__ cch, *__restrict__ e2kh;   // per-bin depth constants (host, libm)
-    const int *__restrict__ mode;        // 0 finite depth, 1 deep (k h > 89.4), 2 k == 0   (helpers.py:211-222)
+    const double *__restrict__ csh, *__restrict__ cch;   // per-bin 1/(1 - e^{-2kh}), 1/(1 + e^{-2kh}) (host, libm);
+                                                         // 1 in the deep-water and k == 0 branches (helpers.py:211-222)
     const double *__restrict__ zeta;     // [nCase,nHead,nw]
     const double *__restrict__ beta;     // [nCase,nHead]
     double depth, rho, g;

@@ -1,0 +1,192 @@
+"""Batched (design x sea state) sweeps and their sharding over the GPUs of a node.
+
+The reference runs the sweep as nested Python loops in one process
+(raft/parametersweep.py:39-100; raft/omdao_raft.py:746-792 builds one Model per
+optimiser iterate; raft/raft_model.py:290-337 loops the cases).  Here a sweep is
+one launch of the fused kernel per rank:
+
+  * ``Sweep`` holds the packed strip tables + 6x6 matrices of the designs and
+    the sea states they are all solved for;
+  * ``Sweep.shard(rank, world)`` block-partitions the DESIGN axis -- (design,
+    case) items are independent, nothing is exchanged while solving;
+  * ``run_sharded`` is the one-process-per-GPU driver: rank 0 broadcasts the
+    shared case tables (w, k, zeta, beta: a few KB), every rank solves its own
+    designs, and the responses are gathered to rank 0.  With the ``nccl`` backend
+    (RCCL over xGMI) the collectives move device tensors; with ``gloo`` (CPU tests)
+    host tensors.  No collective sits inside the timed solve.
+"""
+import numpy as np
+
+from ._abi import NFIELD
+
+
+def shard_bounds(n, rank, world):
+    """Contiguous block partition of range(n): the first n % world ranks get one extra item."""
+    if world < 1 or not (0 <= rank < world):
+        raise ValueError("bad rank/world %r/%r" % (rank, world))
+    base, rem = divmod(int(n), int(world))
+    lo = rank * base + min(rank, rem)
+    return lo, lo + base + (1 if rank < rem else 0)
+
+
+class Sweep:
+    """Packed inputs of a (design x case) batch.
+
+    off [nD+1], strips [nS,32], M0/B0/C0 [nD,6,6], optional MBw [nD,2,6,6,nw],
+    optional (cmoff [nD+1], cm [nRows,2,nw]); cases: w,k [nw], zeta [nC,nH,nw],
+    beta [nC,nH]; settings nIter, tol, XiStart (raft_model.py:49-58,966)."""
+
+    def __init__(self, off, strips, M0, B0, C0, w, k, depth, zeta, beta, nIter, XiStart,
+                 tol=0.01, MBw=None, cmoff=None, cm=None, rho=1025.0, g=9.81):
+        self.off = np.ascontiguousarray(off, dtype=np.int64)
+        self.strips = np.ascontiguousarray(strips, dtype=np.float64).reshape(-1, NFIELD)
+        self.M0, self.B0, self.C0 = (np.ascontiguousarray(a, dtype=np.float64) for a in (M0, B0, C0))
+        self.w = np.ascontiguousarray(w, dtype=np.float64)
+        self.k = np.ascontiguousarray(k, dtype=np.float64)
+        self.depth, self.rho, self.g = float(depth), float(rho), float(g)
+        zeta = np.asarray(zeta, dtype=np.float64)
+        beta = np.asarray(beta, dtype=np.float64)
+        if zeta.ndim == 2:
+            zeta, beta = zeta[None], beta[None]
+        self.zeta, self.beta = np.ascontiguousarray(zeta), np.ascontiguousarray(beta)
+        self.nIter, self.XiStart, self.tol = int(nIter), float(XiStart), float(tol)
+        self.MBw = None if MBw is None else np.ascontiguousarray(MBw, dtype=np.float64)
+        self.cmoff = None if cm is None else np.ascontiguousarray(cmoff, dtype=np.int64)
+        self.cm = None if cm is None else np.ascontiguousarray(cm, dtype=np.complex128)
+        if len(self.off) - 1 != self.M0.shape[0]:
+            raise ValueError("strip offsets describe %d designs, matrices %d" % (len(self.off) - 1, self.M0.shape[0]))
+
+    # ------------------------------------------------------------------ sizes
+    @property
+    def n_design(self):
+        return len(self.off) - 1
+
+    @property
+    def n_case(self):
+        return self.zeta.shape[0]
+
+    @property
+    def n_head(self):
+        return self.zeta.shape[1]
+
+    @property
+    def nw(self):
+        return len(self.w)
+
+    @classmethod
+    def from_fowts(cls, fowts_mats, w, k, depth, zeta, beta, nIter, XiStart, tol=0.01):
+        """fowts_mats: iterable of (StripTable, M0, B0, C0[, MBw]) -- e.g. from raft_amd.strips.pack_fowt
+        and the sums of raft_model.py:1045-1047."""
+        tables = [t[0] for t in fowts_mats]
+        off = np.concatenate([[0], np.cumsum([t.n for t in tables])]).astype(np.int64)
+        strips = np.concatenate([t.strips for t in tables], axis=0) if tables else np.zeros((0, NFIELD))
+        M0 = np.array([t[1] for t in fowts_mats])
+        B0 = np.array([t[2] for t in fowts_mats])
+        C0 = np.array([t[3] for t in fowts_mats])
+        MBw = None
+        if any(len(t) > 4 and t[4] is not None for t in fowts_mats):
+            nw = len(w)
+            MBw = np.array([t[4] if len(t) > 4 and t[4] is not None else np.zeros((2, 6, 6, nw)) for t in fowts_mats])
+        cmoff = cm = None
+        if any(t.cm_mcf is not None for t in tables):
+            cmoff = np.concatenate([[0], np.cumsum([0 if t.cm_mcf is None else t.cm_mcf.shape[0] for t in tables])])
+            cm = np.concatenate([t.cm_mcf for t in tables if t.cm_mcf is not None], axis=0)
+        return cls(off, strips, M0, B0, C0, w, k, depth, zeta, beta, nIter, XiStart, tol, MBw, cmoff, cm)
+
+    # ------------------------------------------------------------------ sharding
+    def take(self, lo, hi):
+        """The sub-sweep of designs [lo, hi) (all cases)."""
+        s0, s1 = self.off[lo], self.off[hi]
+        cmoff = cm = None
+        if self.cm is not None:
+            c0, c1 = self.cmoff[lo], self.cmoff[hi]
+            cmoff, cm = self.cmoff[lo:hi + 1] - c0, self.cm[c0:c1]
+        return Sweep(self.off[lo:hi + 1] - s0, self.strips[s0:s1], self.M0[lo:hi], self.B0[lo:hi], self.C0[lo:hi],
+                     self.w, self.k, self.depth, self.zeta, self.beta, self.nIter, self.XiStart, self.tol,
+                     None if self.MBw is None else self.MBw[lo:hi], cmoff, cm, self.rho, self.g)
+
+    def shard(self, rank, world):
+        return self.take(*shard_bounds(self.n_design, rank, world))
+
+    # ------------------------------------------------------------------ solve
+    def upload(self, ctx):
+        ctx.upload_designs_raw(self.off, self.strips, self.M0, self.B0, self.C0, self.nw, self.MBw, self.cmoff, self.cm)
+        ctx.upload_cases(self.w, self.k, self.depth, self.rho, self.g, self.zeta, self.beta)
+
+    def solve(self, ctx, upload=True):
+        """One launch over every (design, case) of this sweep; results stay on the device until fetched."""
+        if upload:
+            self.upload(ctx)
+        ctx.solve_dynamics_device(self.nIter, self.tol, self.XiStart)
+        return ctx.last_kernel_ms()
+
+    def run(self, ctx):
+        self.solve(ctx)
+        r = ctx.fetch_results(want_Xi=True)
+        return {"Xi": r["Xi"], "niter": r["niter"], "flags": r["flags"]}
+
+
+# ---------------------------------------------------------------------- multi-GPU driver
+def _device_for(dist):
+    import torch
+    return torch.device("cuda", torch.cuda.current_device()) if dist.get_backend() == "nccl" else torch.device("cpu")
+
+
+def broadcast_cases(cases, dist, src=0):
+    """Rank ``src`` broadcasts the shared sea-state tables (dict of small float64 arrays + scalars)."""
+    import torch
+    dev = _device_for(dist)
+    keys = ["w", "k", "zeta", "beta"]
+    shapes = [None]
+    if dist.get_rank() == src:
+        shapes = [{k_: tuple(np.asarray(cases[k_]).shape) for k_ in keys}]
+        shapes[0]["scalars"] = {k_: cases[k_] for k_ in cases if k_ not in keys}
+    dist.broadcast_object_list(shapes, src=src)
+    out = dict(shapes[0]["scalars"])
+    for k_ in keys:
+        if dist.get_rank() == src:
+            t = torch.as_tensor(np.ascontiguousarray(cases[k_], dtype=np.float64)).to(dev)
+        else:
+            t = torch.empty(shapes[0][k_], dtype=torch.float64, device=dev)
+        dist.broadcast(t, src=src)
+        out[k_] = t.cpu().numpy()
+    return out
+
+
+def gather_rows(local, counts, dist, dst=0):
+    """Gather per-rank row blocks (first axis; counts[r] rows on rank r) to ``dst``; None elsewhere.
+    Blocks are padded to the largest count so every rank contributes an equal-size tensor."""
+    import torch
+    dev = _device_for(dist)
+    local = np.ascontiguousarray(local)
+    is_c = np.iscomplexobj(local)
+    arr = local.view(np.float64) if is_c else local
+    pad = max(counts)
+    buf = np.zeros((pad,) + arr.shape[1:], dtype=arr.dtype)
+    buf[:arr.shape[0]] = arr
+    t = torch.as_tensor(buf).to(dev)
+    rank, world = dist.get_rank(), dist.get_world_size()
+    if dist.get_backend() == "nccl":
+        parts = [torch.empty_like(t) for _ in range(world)]
+        dist.all_gather(parts, t)                     # RCCL has no gather-to-root primitive; ring all-gather
+    else:
+        parts = [torch.empty_like(t) for _ in range(world)] if rank == dst else None
+        dist.gather(t, parts, dst=dst)
+    if rank != dst:
+        return None
+    full = np.concatenate([p.cpu().numpy()[:c] for p, c in zip(parts, counts)], axis=0)
+    return full.view(np.complex128) if is_c else full
+
+
+def run_sharded(sweep, ctx, dist=None, gather=True):
+    """Every rank solves its block of designs; rank 0 gets the assembled results
+    ({"Xi","niter","flags"}), the others their local block only."""
+    if dist is None or dist.get_world_size() == 1:
+        return sweep.run(ctx)
+    rank, world = dist.get_rank(), dist.get_world_size()
+    local = sweep.shard(rank, world).run(ctx)
+    if not gather:
+        return local
+    counts = [shard_bounds(sweep.n_design, r, world)[1] - shard_bounds(sweep.n_design, r, world)[0] for r in range(world)]
+    out = {k_: gather_rows(v, counts, dist) for k_, v in local.items()}
+    return out if rank == 0 else local

@@ -1,0 +1,126 @@
+"""CPU suite: the C-ABI boundary (header <-> shared objects) and the multi-rank sweep driver
+(gloo, world_size 2).  No GPU compute: the HIP library is only loaded and its symbols checked;
+the sharded runs use the CPU oracle as the per-rank backend."""
+import ctypes
+import os
+import re
+import socket
+
+import numpy as np
+import pytest
+
+from raft_amd import sweep as sw
+from raft_amd._abi import EXPORTS
+from tests.conftest import HIP_SO, ORACLE_SO, ROOT
+from tests import standin
+
+
+def _header_functions():
+    src = open(os.path.join(ROOT, "include", "raftx.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(raftx_[a-z_0-9]+)\s*\(", src)))
+
+
+def test_header_and_binding_agree():
+    names = _header_functions()
+    assert len(names) >= 15
+    assert set(names) == set(EXPORTS), set(names) ^ set(EXPORTS)
+
+
+@pytest.mark.parametrize("path", [HIP_SO, ORACLE_SO])
+def test_shared_objects_export_every_header_symbol(path, oracle_lib):
+    """libraftx_hip.so must load on a GPU-less host and export the whole header (no compute call)."""
+    assert os.path.exists(path), "%s missing: run __graft_entry__.build()" % path
+    lib = ctypes.CDLL(path)
+    for name in _header_functions():
+        assert hasattr(lib, name), "%s does not export %s" % (path, name)
+    lib.raftx_version.restype = ctypes.c_int
+    lib.raftx_is_device.restype = ctypes.c_int
+    assert lib.raftx_version() == 100
+    assert lib.raftx_is_device() == (1 if path == HIP_SO else 0)
+
+
+def test_product_fails_loudly_without_a_gpu():
+    """No CPU fallback: on a host without an MI355X the device library refuses to create a context."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is visible")
+    from raft_amd import backend
+    from raft_amd._abi import RaftxError
+    with pytest.raises(RaftxError):
+        backend.hip_library().context(0)
+
+
+def test_shard_bounds_cover_and_balance():
+    for n in (0, 1, 7, 8, 10000):
+        for world in (1, 2, 3, 8):
+            b = [sw.shard_bounds(n, r, world) for r in range(world)]
+            assert b[0][0] == 0 and b[-1][1] == n
+            assert all(b[i][1] == b[i + 1][0] for i in range(world - 1))
+            sizes = [hi - lo for lo, hi in b]
+            assert max(sizes) - min(sizes) <= 1
+
+
+def _c3_sweep(n):
+    fx = standin.load_fixture("c3_variants.npz")
+    off = fx["strip_offsets"]
+    return sw.Sweep(off[:n + 1], fx["strips"][:off[n]], fx["M0"][:n], fx["B0"][:n], fx["C0"][:n], fx["w"], fx["k"],
+                    fx["depth"], fx["zeta"][None], fx["beta"][None], int(fx["nIter"]), float(fx["XiStart"])), fx
+
+
+def test_take_is_a_pure_slice(oracle_lib):
+    s, _ = _c3_sweep(5)
+    ctx = oracle_lib.context(0)
+    full = s.run(ctx)
+    part = s.take(2, 5).run(ctx)
+    ctx.close()
+    assert np.array_equal(full["Xi"][2:5].view(np.uint64), part["Xi"].view(np.uint64))
+    assert np.array_equal(full["niter"][2:5], part["niter"])
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _rank_main(rank, world, port, n, out_path):
+    import torch.distributed as dist
+    from raft_amd._abi import RaftxLib
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        s, _ = _c3_sweep(n)
+        cases = {"w": s.w, "k": s.k, "zeta": s.zeta, "beta": s.beta, "depth": s.depth} if rank == 0 else None
+        cases = sw.broadcast_cases(cases, dist, src=0)          # shared tables come from rank 0
+        if rank != 0:                                            # prove the broadcast carried them
+            s.w, s.k, s.zeta, s.beta = cases["w"], cases["k"], cases["zeta"], cases["beta"]
+        ctx = RaftxLib(ORACLE_SO).context(0)
+        res = sw.run_sharded(s, ctx, dist)
+        ctx.close()
+        if rank == 0:
+            np.savez(out_path, Xi=res["Xi"], niter=res["niter"], flags=res["flags"])
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_rank_gloo_sweep_matches_single_process(tmp_path, oracle_lib):
+    """world_size 2 over gloo: broadcast of the case tables, design sharding, gather to rank 0 --
+    bitwise identical to the single-process run, and equal to the live-reference vectors."""
+    import torch.multiprocessing as mp
+    n, world = 7, 2                      # odd count: ragged shards (4 + 3)
+    out = str(tmp_path / "gathered.npz")
+    mp.spawn(_rank_main, args=(world, _free_port(), n, out), nprocs=world, join=True)
+    got = np.load(out)
+    s, fx = _c3_sweep(n)
+    ctx = oracle_lib.context(0)
+    ref = s.run(ctx)
+    ctx.close()
+    assert got["Xi"].shape == ref["Xi"].shape == (n, 1, 1, 6, s.nw)
+    assert np.array_equal(got["Xi"].view(np.uint64), ref["Xi"].view(np.uint64))
+    assert np.array_equal(got["niter"], ref["niter"]) and np.array_equal(got["flags"], ref["flags"])
+    from tests.util import group_rel_err
+    for j, sol in enumerate(fx["solved"]):
+        if j < n:
+            assert group_rel_err(got["Xi"][j, 0, :1], sol["Xi"][:1]) < 1e-10
+            assert int(got["niter"][j, 0]) == int(sol["units"][0]["niter"])
