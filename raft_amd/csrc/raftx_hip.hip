@@ -122,6 +122,7 @@ struct raftx_ctx {
     // resident results of the last raftx_solve_dynamics_device
     cplx *rXi, *rFw, *rZ, *rFe;
     double *rB, *rXl;
+    size_t rXl_n;
     int *rNi, *rFl;
     size_t r_npair, r_nx, r_nz;
     int r_mask;
@@ -170,6 +171,7 @@ extern "C" int raftx_ctx_create(int device_id, raftx_ctx **out) {
     c->nw_designs = 0;
     c->rXi = c->rFw = c->rZ = c->rFe = nullptr;
     c->rB = c->rXl = nullptr;
+    c->rXl_n = 0;
     c->rNi = c->rFl = nullptr;
     c->r_npair = c->r_nx = c->r_nz = 0;
     c->r_mask = 0;
@@ -196,6 +198,7 @@ extern "C" void raftx_ctx_destroy(raftx_ctx *c) {
     free_list(c->design_allocs);
     free_list(c->case_allocs);
     free_list(c->result_allocs);
+    if (c->rXl) (void)hipFree(c->rXl);
     (void)hipEventDestroy(c->ev0);
     (void)hipEventDestroy(c->ev1);
     (void)hipStreamDestroy(c->stream);
@@ -509,7 +512,7 @@ extern "C" int raftx_linearize(raftx_ctx *c, const raftx_c128 *Xi, double *B_dra
     if (npair && (!dXi || (B_drag && !dB) || (F_drag && !dF))) FAIL(c, "linearize: device allocation failed");
     if (npair) H2D(c, dXi, Xi, npair * 6 * T.nw * sizeof(cplx));
     const Shape sh = pick_shape(T.nw);
-    const size_t lds = lds_bytes(c->maxS, T.nw, sh.threads / 64, sh.threads == 64);
+    const size_t lds = lds_bytes(c->maxS, 0, sh.threads / 64, sh.threads == 64);
 #define DISPATCH_ONE_(NB_, MT_, MB_)                                                                                  \
     if (!hit_ && sh.nb == NB_ && sh.threads == MT_) {                                                                 \
         hit_ = true;                                                                                                  \
@@ -548,7 +551,7 @@ static int ensure_results(raftx_ctx *c, int want_mask, bool need_fe) {
     HIPCHK(c, hipStreamSynchronize(c->stream));
     free_list(c->result_allocs);
     c->rXi = c->rFw = c->rZ = c->rFe = nullptr;
-    c->rB = c->rXl = nullptr;
+    c->rB = nullptr;
     c->rNi = c->rFl = nullptr;
     c->rXi = dev_alloc<cplx>(c, nx);
     c->rNi = dev_alloc<int>(c, npair);
@@ -604,7 +607,18 @@ extern "C" int raftx_solve_dynamics_device(raftx_ctx *c, int nIter, double tol, 
     const int need = (T.MBw ? KF_FDEP : 0) | (A.Z ? KF_OUTZ : 0) | (A.F_wave ? KF_OUTF : 0) | (A.F_extra ? KF_EXTRA : 0) |
                      (T.cm ? KF_MCF : 0) | (T.nHead > 1 ? KF_MULTI : 0);
     const Shape sh = pick_shape(T.nw);
-    const size_t lds = lds_bytes(c->maxS, T.nw, sh.threads / 64, sh.threads == 64);
+    const bool xlg = sh.threads == 512 && sh.nb >= 3;        // XiLast in a global scratch slab (raftx_kernels.h XlStore)
+    const size_t lds = lds_bytes(c->maxS, xlg ? 0 : T.nw, sh.threads / 64, sh.threads == 64);
+    if (xlg && (!c->rXl || c->rXl_n < c->r_npair * 12 * (size_t)T.nw)) {
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        if (c->rXl) (void)hipFree(c->rXl);
+        c->rXl = nullptr;
+        c->rXl_n = c->r_npair * 12 * (size_t)T.nw;
+        void *p_ = nullptr;
+        HIPCHK(c, hipMalloc(&p_, (c->rXl_n ? c->rXl_n : 1) * sizeof(double)));
+        c->rXl = reinterpret_cast<double *>(p_);
+    }
+    A.Xl = c->rXl;
 #define LAUNCH_SOLVE(NB_, MT_, MB_, FL)                                                                              \
     do {                                                                                                             \
         if (prep_lds(c, k_solve_dynamics<NB_, FL, MT_, MB_>, lds)) return -1;                                        \
@@ -617,7 +631,7 @@ extern "C" int raftx_solve_dynamics_device(raftx_ctx *c, int nIter, double tol, 
     if (!hit_ && sh.nb == NB_ && sh.threads == MT_) {                                                                \
         hit_ = true;                                                                                                 \
         if (need == 0) LAUNCH_SOLVE(NB_, MT_, MB_, 0);                                                               \
-        else LAUNCH_SOLVE(NB_, MT_, MB_, KF_ALL);                                                                    \
+        else LAUNCH_SOLVE(NB_, MT_, 1, KF_ALL);   /* full-featured variant: trade occupancy for registers (no spills) */                                                                    \
     }
     DISPATCH_SHAPE(sh, _);
 #undef DISPATCH_ONE_

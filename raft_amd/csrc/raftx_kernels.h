@@ -854,6 +854,7 @@ __device__ __forceinline__ void assemble_and_solve(const Lds &l, const double *_
                                                    bool active) {
     Lu6 lu;
     const double w2 = w * w;
+    if constexpr ((FLAGS & (KF_FDEP | KF_OUTZ)) != 0) iw = opaque(iw);   // per-entry addresses are formed here, not hoisted
 #pragma unroll
     for (int r = 0; r < 6; r++) {
 #pragma unroll
@@ -862,8 +863,8 @@ __device__ __forceinline__ void assemble_and_solve(const Lds &l, const double *_
             double M = l.mat[e], B = l.mat[36 + e];
             if constexpr ((FLAGS & KF_FDEP) != 0) {
                 if (Mw) {
-                    M += Mw[(size_t)e * nw + iw];
-                    B += Bw[(size_t)e * nw + iw];
+                    M += (Mw + (size_t)e * nw)[iw];          // uniform row base + lane offset: SGPR base + VGPR offset
+                    B += (Bw + (size_t)e * nw)[iw];
                 }
             }
             B += l.Bd[e];
@@ -877,11 +878,30 @@ __device__ __forceinline__ void assemble_and_solve(const Lds &l, const double *_
 #pragma unroll
             for (int r = 0; r < 6; r++)
 #pragma unroll
-                for (int c = 0; c < 6; c++) Zout[(size_t)(r * 6 + c) * nw + iw] = cplx{lu.ar[r][c], lu.ai[r][c]};
+                for (int c = 0; c < 6; c++) (Zout + (size_t)(r * 6 + c) * nw)[iw] = cplx{lu.ar[r][c], lu.ai[r][c]};
         }
     }
     solve6(lu, x);
 }
+
+// XiLast storage: LDS rows [12][nxl] for every shape whose bins fit there; the largest shapes
+// (more than 1024 bins) keep it in a per-pair global scratch slab instead (coalesced rows).
+template <bool XLG>
+struct XlStore;
+template <>
+struct XlStore<false> {
+    ldptr p;
+    int n;
+    __device__ __forceinline__ double get(int row, int iw) const { return p[row * n + iw]; }
+    __device__ __forceinline__ void put(int row, int iw, double v) const { p[row * n + iw] = v; }
+};
+template <>
+struct XlStore<true> {
+    double *p;
+    int n;
+    __device__ __forceinline__ double get(int row, int iw) const { return p[(size_t)row * n + iw]; }
+    __device__ __forceinline__ void put(int row, int iw, double v) const { p[(size_t)row * n + iw] = v; }
+};
 
 // ------------------------------------------------------------------ kernels
 // workgroup-wide OR / AND of a per-thread predicate
@@ -956,7 +976,7 @@ __global__ void __launch_bounds__(MAXT, MINB) k_linearize(DevTables T, const cpl
     if (!pair_ctx(T, p, pair_of_block(blockIdx.x, T.nDesign * T.nCase))) return;
     const bool multi = blockDim.x > 64;
     constexpr bool STAGE = (MAXT == 64);
-    Lds l = carve(smem, p.S, T.nw, blockDim.x >> 6, STAGE);
+    Lds l = carve(smem, p.S, 0, blockDim.x >> 6, STAGE);        // no XiLast storage in this kernel
     if (STAGE) stage_recA(p.ds, p.dsi, p.S, l);
     Bins<NB> b;
     load_bins(T, b, threadIdx.x);
@@ -1009,6 +1029,7 @@ struct SolveArgs {
     double *__restrict__ B_drag;         // [pair,36] or null
     cplx *__restrict__ F_wave;           // [pair,nHead,6,nw] or null
     cplx *__restrict__ Z;                // [pair,36,nw] or null
+    double *Xl;                          // [pair,12,nw] XiLast scratch (shapes with more than 1024 bins only)
     unsigned long long *dbg;             // RAFTX_PHASE_TIMING builds: [8] accumulated wave-0 cycles per phase
 };
 
@@ -1031,8 +1052,17 @@ __global__ void __launch_bounds__(MAXT, MINB) k_solve_dynamics(DevTables T, Solv
     const int pair = p.pair, S = p.S;
     const cplx *cm = (MCF && T.cm) ? p.cm : nullptr;
     constexpr bool STAGE = (MAXT == 64);
-    Lds l = carve(smem, S, nw, blockDim.x >> 6, STAGE);
+    constexpr bool XLG = (MAXT == 512 && NB >= 3);
+    Lds l = carve(smem, S, XLG ? 0 : nw, blockDim.x >> 6, STAGE);
     if (STAGE) stage_recA(p.ds, p.dsi, S, l);
+    XlStore<XLG> xl;
+    if constexpr (XLG) {
+        xl.p = A.Xl + (size_t)pair * 12 * nw;
+        xl.n = nw;
+    } else {
+        xl.p = l.xl;
+        xl.n = l.nxl;
+    }
     Bins<NB> b;
     load_bins(T, b, threadIdx.x);
     set_heading_amp(T, b, p.ic, 0);
@@ -1066,8 +1096,8 @@ __global__ void __launch_bounds__(MAXT, MINB) k_solve_dynamics(DevTables T, Solv
         if (b.act[j]) {
 #pragma unroll
             for (int q = 0; q < 6; q++) {
-                l.xl[(2 * q) * l.nxl + b.iw[j]] = A.XiStart;
-                l.xl[(2 * q + 1) * l.nxl + b.iw[j]] = 0.0;
+                xl.put(2 * q, b.iw[j], A.XiStart);
+                xl.put(2 * q + 1, b.iw[j], 0.0);
             }
         }
     const double *Mw = (FDEP && T.MBw) ? T.MBw + ((size_t)p.d * 2 + 0) * 36 * nw : nullptr;
@@ -1091,7 +1121,7 @@ __global__ void __launch_bounds__(MAXT, MINB) k_solve_dynamics(DevTables T, Solv
                 const int iw = opaque(b.iw[j]);
 #pragma unroll
                 for (int q = 0; q < 6; q++) {
-                    const double vr = l.xl[(2 * q) * l.nxl + iw], vi = l.xl[(2 * q + 1) * l.nxl + iw];
+                    const double vr = xl.get(2 * q, iw), vi = xl.get(2 * q + 1, iw);
                     X[j][q].re = b.act[j] ? w * vr : 0.0;          // unconditional loads (clamped bin), then select
                     X[j][q].im = b.act[j] ? w * vi : 0.0;
                 }
@@ -1133,13 +1163,13 @@ __global__ void __launch_bounds__(MAXT, MINB) k_solve_dynamics(DevTables T, Solv
             if (act) {
 #pragma unroll
                 for (int q = 0; q < 6; q++) {
-                    const double lr = l.xl[(2 * q) * l.nxl + iw], li = l.xl[(2 * q + 1) * l.nxl + iw];
+                    const double lr = xl.get(2 * q, iw), li = xl.get(2 * q + 1, iw);
                     if (isnan(x[j][q].re) || isnan(x[j][q].im)) bad = 1;
                     const double dr = x[j][q].re - lr, di = x[j][q].im - li;
                     const double tc = sqrt(dr * dr + di * di) / (sqrt(x[j][q].re * x[j][q].re + x[j][q].im * x[j][q].im) + A.tol);
                     if (!(tc < A.tol)) ok = 0;
-                    l.xl[(2 * q) * l.nxl + iw] = 0.2 * lr + 0.8 * x[j][q].re;
-                    l.xl[(2 * q + 1) * l.nxl + iw] = 0.2 * li + 0.8 * x[j][q].im;
+                    xl.put(2 * q, iw, 0.2 * lr + 0.8 * x[j][q].re);
+                    xl.put(2 * q + 1, iw, 0.2 * li + 0.8 * x[j][q].im);
                 }
             }
         }

@@ -85,8 +85,13 @@ def _both(hip_ctx, oracle_ctx, tables, mats, cases, depth=200.0):
     ([0, 1, 5], 7, 2, 1, False, 0.0),          # empty design, single strip, tiny nw
     ([63, 64, 65], 64, 1, 2, True, 0.3),       # around one wave of strips, freq-dependent M/B, MCF rows
     ([130, 17], 200, 2, 3, False, 0.2),        # ragged, three headings
-    ([53], 256, 1, 1, True, 0.0),              # maximum bins per workgroup
+    ([53], 256, 1, 1, True, 0.0),              # last size of the 2-wave shape
     ([26], 1, 1, 1, False, 0.0),               # single frequency bin
+    ([40, 3], 100, 2, 1, False, 0.0),          # one wave, two bins per lane
+    ([31], 300, 1, 2, False, 0.2),             # 4 waves x 2 bins per lane
+    ([45, 9], 600, 1, 1, True, 0.0),           # 8 waves x 2 bins per lane
+    ([22], 1100, 1, 1, False, 0.0),            # 8 waves x 3 bins per lane
+    ([12], 2048, 1, 2, False, 0.0),            # maximum bins per workgroup (8 waves x 4)
 ])
 def test_synthetic_parity(hip_ctx, oracle_ctx, S_list, nw, nC, nH, fdep, mcf):
     rng = np.random.default_rng(1234 + nw + len(S_list))
@@ -112,6 +117,24 @@ def test_synthetic_parity(hip_ctx, oracle_ctx, S_list, nw, nC, nH, fdep, mcf):
     assert rel_err(oh["Z"], oo["Z"]) < TOL
     assert rel_err(oh["F_wave"], oo["F_wave"]) < TOL
     assert rel_err(oh["B_drag"], oo["B_drag"]) < TOL
+
+
+@pytest.mark.parametrize("S_list,nw,nC", [([53, 44, 63, 0, 17], 200, 2), ([30], 64, 1), ([30, 31], 128, 3), ([20], 700, 1)])
+def test_lean_sweep_kernel_parity(hip_ctx, oracle_ctx, S_list, nw, nC):
+    """The specialisation the sweeps run (no optional inputs/outputs, results fetched from HBM)."""
+    rng = np.random.default_rng(77 + nw)
+    tables = [_member_run_table(rng, max(1, S // 10), 10) if S else random_strips(rng, 0) for S in S_list]
+    mats = random_matrices(rng, len(S_list))
+    cases = synthetic_cases(rng, nC, 1, nw)
+    _both(hip_ctx, oracle_ctx, tables, mats, cases)
+    res = []
+    for ctx in (hip_ctx, oracle_ctx):
+        ctx.solve_dynamics_device(6, 0.01, 0.1)
+        res.append(ctx.fetch_results(want_Xi=True))
+    assert np.array_equal(res[0]["niter"], res[1]["niter"])
+    assert np.array_equal(res[0]["flags"], res[1]["flags"])
+    for d in range(len(S_list)):
+        assert group_rel_err(res[0]["Xi"][d], res[1]["Xi"][d]) < TOL
 
 
 def test_repeat_runs_are_bitwise_identical(hip_ctx):
