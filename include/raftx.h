@@ -139,6 +139,15 @@ int raftx_solve_dynamics_device(raftx_ctx *ctx, int nIter, double tol, double Xi
 int raftx_fetch_results(raftx_ctx *ctx, raftx_c128 *Xi, int32_t *niter, int32_t *flags,
                         double *B_drag, raftx_c128 *F_wave, raftx_c128 *Z);
 
+/* Response statistics of the resident results of the last raftx_solve_dynamics_device -- the motion
+ * block of FOWT.saveTurbineOutputs (raft/raft_fowt.py:2310-2357) with getRMS / getPSD
+ * (raft/helpers.py:678-700), for rigid units whose reduced DOFs are the platform reference point:
+ *   std[d,c,j]   = sqrt(0.5 * sum_{ih,w} |Xi[d,c,ih,j,w]|^2)           (j = 3..5 in degrees, :2332-2354)
+ *   psd[d,c,j,w] = sum_ih 0.5 |Xi[d,c,ih,j,w]|^2 / dw                   (optional, may be NULL)
+ * so that a sweep can return ~48 B per (design, case) instead of 19 KB.  std [nDesign,nCase,6],
+ * psd [nDesign,nCase,6,nw]; dw = w[1]-w[0] (raft_fowt.py:169). */
+int raftx_motion_stats(raftx_ctx *ctx, double dw, double *std, double *psd);
+
 /* Coupled array solve, raft_model.py:1164-1236: for each system s and bin w
  *   Z_sys = blockdiag_i(Zblk[s,i]) + (-w^2 Mc[s] + i w Bc[s] + Cc[s]);
  *   Xi[s,r] = Z_sys^-1 F[s,r].

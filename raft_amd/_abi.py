@@ -24,7 +24,7 @@ EXPORTS = (
     "raftx_last_error", "raftx_upload_designs", "raftx_upload_cases",
     "raftx_excitation", "raftx_linearize", "raftx_solve_dynamics",
     "raftx_solve_system", "raftx_last_kernel_ms",
-    "raftx_solve_dynamics_device", "raftx_fetch_results", "raftx_debug_math",
+    "raftx_solve_dynamics_device", "raftx_fetch_results", "raftx_debug_math", "raftx_motion_stats",
 )
 WANT_BDRAG, WANT_FWAVE, WANT_Z = 1, 2, 4
 
@@ -89,6 +89,8 @@ class RaftxLib:
         L.raftx_solve_dynamics_device.restype = C.c_int
         L.raftx_fetch_results.argtypes = [_vp, _vp, _vp, _vp, _vp, _vp, _vp]
         L.raftx_fetch_results.restype = C.c_int
+        L.raftx_motion_stats.argtypes = [_vp, C.c_double, _vp, _vp]
+        L.raftx_motion_stats.restype = C.c_int
         L.raftx_debug_math.argtypes = [_vp, C.c_int, _vp, _vp, _vp, _vp]
         L.raftx_debug_math.restype = C.c_int
         L.raftx_last_kernel_ms.argtypes = [_vp]
@@ -243,6 +245,13 @@ class Context:
         rc = self.rlib.lib.raftx_fetch_results(self._h, _ptr(Xi), _ptr(niter), _ptr(flags), _ptr(B), _ptr(F), _ptr(Z))
         self._check(rc, "raftx_fetch_results")
         return dict(Xi=Xi, niter=niter, flags=flags, B_drag=B, F_wave=F, Z=Z)
+
+    def motion_stats(self, dw, want_psd=False):
+        """std [nDesign,nCase,6] (rotations in deg) and optionally PSD [nDesign,nCase,6,nw] of the resident results."""
+        std = np.empty((self.nDesign, self.nCase, 6), dtype=np.float64)
+        psd = np.empty((self.nDesign, self.nCase, 6, self.nw), dtype=np.float64) if want_psd else None
+        self._check(self.rlib.lib.raftx_motion_stats(self._h, float(dw), _ptr(std), _ptr(psd)), "raftx_motion_stats")
+        return std, psd
 
     def solve_system(self, w, Zblk, F, Mc=None, Bc=None, Cc=None):
         Zblk = _c128(Zblk)

@@ -111,6 +111,46 @@ __global__ void __launch_bounds__(64) k_solve_system(int nSys, int nUnit, int nR
     }
 }
 
+// Motion statistics of the resident responses (raft_fowt.py:2310-2357; helpers.py:678-700): one
+// workgroup per (design, case), lanes stride the frequency axis (coalesced 16 B/lane reads of the
+// Xi slab: a pure HBM stream, 19.2 KB in -> 48 B out per pair at C3).
+__global__ void __launch_bounds__(256) k_motion_stats(int npair, int nHead, int nw, double inv_dw,
+                                                      const cplx *__restrict__ Xi, double *__restrict__ sd,
+                                                      double *__restrict__ psd) {
+    __shared__ double part[4][6];
+    const int p = blockIdx.x;
+    if (p >= npair) return;
+    const double r2d = 180.0 / 3.14159265358979323846;
+    double acc[6] = {0, 0, 0, 0, 0, 0};
+    for (int i = threadIdx.x; i < nw; i += blockDim.x) {
+#pragma unroll
+        for (int j = 0; j < 6; j++) {
+            const double scale = j >= 3 ? r2d : 1.0;
+            double a2 = 0.0;
+            for (int ih = 0; ih < nHead; ih++) {
+                const cplx x = Xi[(((size_t)p * nHead + ih) * 6 + j) * nw + i];
+                const double xr = x.re * scale, xi = x.im * scale;
+                a2 += xr * xr + xi * xi;
+            }
+            acc[j] += a2;
+            if (psd) psd[((size_t)p * 6 + j) * nw + i] = 0.5 * a2 * inv_dw;
+        }
+    }
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+#pragma unroll
+    for (int j = 0; j < 6; j++) {
+        double a = acc[j];
+        for (int o = 32; o > 0; o >>= 1) a += __shfl_xor(a, o, 64);
+        if (lane == 0) part[wv][j] = a;
+    }
+    __syncthreads();
+    if (threadIdx.x < 6) {
+        double a = 0.0;
+        for (int q = 0; q < (int)(blockDim.x >> 6); q++) a += part[q][threadIdx.x];
+        sd[(size_t)p * 6 + threadIdx.x] = sqrt(0.5 * a);
+    }
+}
+
 // ------------------------------------------------------------------ host side
 struct raftx_ctx {
     int device;
@@ -664,6 +704,29 @@ extern "C" int raftx_solve_dynamics(raftx_ctx *c, int nIter, double tol, double 
     int rc = raftx_solve_dynamics_device(c, nIter, tol, XiStart, F_extra, mask);
     if (rc) return rc;
     return raftx_fetch_results(c, Xi, niter, flags, B_drag, F_wave, Z);
+}
+
+extern "C" int raftx_motion_stats(raftx_ctx *c, double dw, double *sd, double *psd) {
+    if (!c) return -1;
+    if (!c->rXi) FAIL(c, "motion_stats: no resident results");
+    if (!sd) FAIL(c, "motion_stats: std is NULL");
+    if (!(dw > 0.0)) FAIL(c, "motion_stats: dw must be positive");
+    HIPCHK(c, hipSetDevice(c->device));
+    const DevTables &T = c->T;
+    const size_t npair = c->r_npair;
+    Scratch sc(c);
+    double *dS = sc.alloc<double>(npair * 6);
+    double *dP = psd ? sc.alloc<double>(npair * 6 * T.nw) : nullptr;
+    if (npair && (!dS || (psd && !dP))) FAIL(c, "motion_stats: device allocation failed");
+    HIPCHK(c, hipEventRecord(c->ev0, c->stream));
+    if (npair)
+        hipLaunchKernelGGL(k_motion_stats, dim3((unsigned)npair), dim3(T.nw > 128 ? 256 : (T.nw > 64 ? 128 : 64)), 0,
+                           c->stream, (int)npair, T.nHead, T.nw, 1.0 / dw, c->rXi, dS, dP);
+    if (finish_timed(c)) return -2;
+    if (npair) D2H(c, sd, dS, npair * 6 * sizeof(double));
+    if (npair && psd) D2H(c, psd, dP, npair * 6 * T.nw * sizeof(double));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return 0;
 }
 
 extern "C" int raftx_solve_system(raftx_ctx *c, int nSys, int nUnit, int nRhs, int nw, const double *w,

@@ -120,6 +120,15 @@ class Sweep:
         ctx.solve_dynamics_device(self.nIter, self.tol, self.XiStart)
         return ctx.last_kernel_ms()
 
+    def run_stats(self, ctx, want_psd=False):
+        """Solve and return only the response statistics (std [nD,nC,6], optional PSD) + niter/flags:
+        ~60 B per (design, case) cross the bus instead of 19 KB (raft_fowt.py:2310-2357)."""
+        self.solve(ctx)
+        dw = float(self.w[1] - self.w[0]) if self.nw > 1 else float(self.w[0])
+        std, psd = ctx.motion_stats(dw, want_psd)
+        r = ctx.fetch_results(want_Xi=False)
+        return {"std": std, "psd": psd, "niter": r["niter"], "flags": r["flags"]}
+
     def run(self, ctx):
         self.solve(ctx)
         r = ctx.fetch_results(want_Xi=True)

@@ -137,6 +137,22 @@ def test_lean_sweep_kernel_parity(hip_ctx, oracle_ctx, S_list, nw, nC):
         assert group_rel_err(res[0]["Xi"][d], res[1]["Xi"][d]) < TOL
 
 
+def test_motion_stats_parity(hip_ctx, oracle_ctx):
+    rng = np.random.default_rng(5150)
+    tables = [random_strips(rng, S) for S in (40, 53, 7)]
+    mats = random_matrices(rng, 3)
+    cases = synthetic_cases(rng, 2, 3, 200)
+    _both(hip_ctx, oracle_ctx, tables, mats, cases)
+    out = []
+    for ctx in (hip_ctx, oracle_ctx):
+        ctx.solve_dynamics_device(5, 0.01, 0.1)
+        out.append(ctx.motion_stats(0.031, want_psd=True))
+    assert rel_err(out[0][0], out[1][0]) < TOL
+    assert rel_err(out[0][1], out[1][1]) < TOL
+    std_only, none = hip_ctx.motion_stats(0.031)
+    assert none is None and np.array_equal(std_only, out[0][0])
+
+
 def test_repeat_runs_are_bitwise_identical(hip_ctx):
     rng = np.random.default_rng(7)
     tables = [random_strips(rng, 53) for _ in range(4)]

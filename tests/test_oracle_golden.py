@@ -73,3 +73,23 @@ def test_live_reference_solveDynamics(name, oracle_ctx):
             assert rel_err(fowt.F_hydro_iner, u["F_hydro_iner"]) < 1e-12
             assert rel_err(fowt.B_hydro_drag, u["B_hydro_drag"]) < 1e-10
             assert rel_err(fowt.zeta, u["zeta"]) < 1e-14
+
+
+def test_motion_stats_follow_getRMS_getPSD(oracle_ctx):
+    """raft_fowt.py:2310-2357 with helpers.py:678-700, against the NumPy formulae of the reference
+    evaluated on the live-reference response of C2 (three sea states -> one batch)."""
+    from raft_amd import waves
+    fx, model = load_model_fixture("pose_volturnus_mcf.npz")      # two headings: the sums over ih matter
+    eng = dropin.Engine(oracle_ctx)
+    c = fx["cases"][0]
+    Xi = eng.solveDynamics(model, case_from_fixture(c))
+    f = model.fowtList[0]
+    nH = Xi.shape[0] - 1
+    std, psd = oracle_ctx.motion_stats(f.dw, want_psd=True)
+    for j in range(6):
+        x = Xi[:nH, j, :] * (np.rad2deg(1.0) if j >= 3 else 1.0)
+        assert abs(std[0, 0, j] - np.sqrt(0.5 * np.sum(np.abs(x) ** 2))) <= 1e-13 * max(1.0, std[0, 0, j])
+        np.testing.assert_allclose(psd[0, 0, j], waves.get_psd(x, f.dw), rtol=1e-13, atol=1e-300)
+        # and against the reference's own amplitudes
+        xr = c["Xi"][:nH, j, :] * (np.rad2deg(1.0) if j >= 3 else 1.0)
+        assert abs(std[0, 0, j] - np.sqrt(0.5 * np.sum(np.abs(xr) ** 2))) <= 1e-9 * max(1e-12, std[0, 0, j])
