@@ -280,6 +280,10 @@ struct Kin {
     double ar[NB], ai[NB], P[NB], Q[NB];
     double r1r[NB], r1i[NB], r1p[NB], r1q[NB];
     double r2r[NB], r2i[NB], r2p[NB], r2q[NB];
+    // memo of the previous run start (wave-uniform keys, per-bin values): members that start at
+    // the same depth share P, Q; members with the same step vector share the rotors
+    double P0[NB], Q0[NB];
+    double mz, mux, muy, muz;
 };
 
 // Run start: exact evaluation from the absolute position (helpers.py:201,211-222).
@@ -299,38 +303,50 @@ __device__ __forceinline__ void kin_start(Kin<NB> &K, const RunStart rs, const B
     const double x = rs.x, y = rs.y, z = rs.z, ux = rs.ux, uy = rs.uy, uz = rs.uz;
     const double xi = cb * x + sb * y;
     const double du = cb * ux + sb * uy;
+    const bool same_z = (z == K.mz);                      // wave-uniform
+    const bool same_u = (ux == K.mux) && (uy == K.muy) && (uz == K.muz);
 #pragma unroll
     for (int j = 0; j < NB; j++) {
         double s, c;
         fast_sincos(-(b.k[j] * xi), s, c);
         K.ar[j] = amp[j] * c;
         K.ai[j] = amp[j] * s;
-        const double kz = b.k[j] * z;
-        double P = fast_exp(kz);
-        double Q = fast_exp(-(b.k[j] * (z + 2.0 * b.depth)));       // e^{-k (z + 2h)}
-        const int mode = depth_mode(b.k[j], b.depth);
-        if (!KEEPQ) Q = (mode == 1) ? 0.0 : Q;
-        // k == 0 (helpers.py:211-214): Sh = 1, Ch = Cc = 99999  <=>  P + Q = 99999, P - Q = 1 with csh = cch = 1
-        K.P[j] = (mode == 2) ? 50000.0 : P;
-        K.Q[j] = (mode == 2) ? 49999.0 : Q;
-    }
-    const bool rot = du != 0.0, dec = uz != 0.0;     // wave-uniform: vertical members skip the phase rotor,
-#pragma unroll                                       // horizontal ones the depth-decay rotors
-    for (int j = 0; j < NB; j++) {
-        double s = 0.0, c = 1.0, p = 1.0, q = 1.0;
-        if (rot) fast_sincos(-(b.k[j] * du), s, c);
-        if (dec) {
-            p = fast_exp(b.k[j] * uz);
-            q = fast_exp(-(b.k[j] * uz));
+        if (!same_z) {
+            const double kz = b.k[j] * z;
+            double P = fast_exp(kz);
+            double Q = fast_exp(-(b.k[j] * (z + 2.0 * b.depth)));       // e^{-k (z + 2h)}
+            const int mode = depth_mode(b.k[j], b.depth);
+            if (!KEEPQ) Q = (mode == 1) ? 0.0 : Q;
+            // k == 0 (helpers.py:211-214): Sh = 1, Ch = Cc = 99999  <=>  P + Q = 99999, P - Q = 1 with csh = cch = 1
+            K.P0[j] = (mode == 2) ? 50000.0 : P;
+            K.Q0[j] = (mode == 2) ? 49999.0 : Q;
         }
-        K.r1r[j] = c;
-        K.r1i[j] = s;
-        K.r2r[j] = c * c - s * s;
-        K.r2i[j] = 2.0 * c * s;
-        K.r1p[j] = p;
-        K.r1q[j] = q;
-        K.r2p[j] = p * p;
-        K.r2q[j] = q * q;
+        K.P[j] = K.P0[j];
+        K.Q[j] = K.Q0[j];
+    }
+    K.mz = z;
+    if (!same_u) {
+        const bool rot = du != 0.0, dec = uz != 0.0;  // wave-uniform: vertical members skip the phase rotor,
+#pragma unroll                                        // horizontal ones the depth-decay rotors
+        for (int j = 0; j < NB; j++) {
+            double s = 0.0, c = 1.0, p = 1.0, q = 1.0;
+            if (rot) fast_sincos(-(b.k[j] * du), s, c);
+            if (dec) {
+                p = fast_exp(b.k[j] * uz);
+                q = fast_exp(-(b.k[j] * uz));
+            }
+            K.r1r[j] = c;
+            K.r1i[j] = s;
+            K.r2r[j] = c * c - s * s;
+            K.r2i[j] = 2.0 * c * s;
+            K.r1p[j] = p;
+            K.r1q[j] = q;
+            K.r2p[j] = p * p;
+            K.r2q[j] = q * q;
+        }
+        K.mux = ux;
+        K.muy = uy;
+        K.muz = uz;
     }
 }
 
@@ -377,7 +393,10 @@ __device__ __forceinline__ void kin_reset(Kin<NB> &K) {
         K.ar[j] = 0.0; K.ai[j] = 0.0; K.P[j] = 1.0; K.Q[j] = 0.0;
         K.r1r[j] = K.r2r[j] = K.r1p[j] = K.r1q[j] = K.r2p[j] = K.r2q[j] = 1.0;
         K.r1i[j] = K.r2i[j] = 0.0;
+        K.P0[j] = 1.0;
+        K.Q0[j] = 0.0;
     }
+    K.mz = K.mux = K.muy = K.muz = __builtin_nan("");      // never equal: the first run start computes everything
 }
 
 // ------------------------------------------------------------------ strip sweeps
@@ -527,12 +546,12 @@ template <>
 struct StripSrc<false> {
     cdptr ds;
     ciptr dsi;
-    int s_cur;
-    __device__ __forceinline__ StripSrc(const Lds &, cdptr ds_, ciptr dsi_) : ds(ds_), dsi(dsi_), s_cur(0) {}
+    int fn;                                    // flag word of the next strip (SGPR, fetched one strip ahead)
+    __device__ __forceinline__ StripSrc(const Lds &, cdptr ds_, ciptr dsi_) : ds(ds_), dsi(dsi_), fn(dsi_[0]) {}
     __device__ __forceinline__ cdptr rec(int s) const { return ds + (size_t)s * DS_N; }
     __device__ __forceinline__ int flags(int s_next) {
-        const int f = dsi[s_cur];
-        s_cur = s_next;
+        const int f = fn;
+        fn = dsi[s_next];
         return f;
     }
 };
@@ -604,7 +623,7 @@ __device__ __forceinline__ void linearize_passA(cdptr ds, ciptr dsi, int S,
         for (int jj = 0; jj < nb; jj++) {
             const int s = s0 + jj;
             const auto rec = src.rec(s);
-            const RecA r = load_recA(rec);                  // issued before the (branchy) kinematics update
+            const RecA r = load_recA(rec);
             const int fl = src.flags(min(s + 1, S - 1));
             double v0, v1, v2;
             passA_strip<NB>(K, r, fl, rec, b, cb, sb, X, v0, v1, v2);
