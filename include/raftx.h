@@ -158,6 +158,14 @@ int raftx_solve_system(raftx_ctx *ctx, int nSys, int nUnit, int nRhs, int nw,
                        const double *Mc, const double *Bc, const double *Cc,
                        const raftx_c128 *F, raftx_c128 *Xi);
 
+/* The same coupled solve fed from the RESIDENT results of raftx_solve_dynamics_device (which must have
+ * kept Z and F_wave): consecutive groups of nUnit designs are the units of one array; for group g,
+ * case c: Z_sys = blockdiag_u(Z[g*nUnit+u, c]) + (-w^2 Mc[g] + i w Bc[g] + Cc[g]),
+ * Xi[g,c,ih] = Z_sys^-1 F_wave[., c, ih].  Mc,Bc,Cc [nGroup,6nUnit,6nUnit] or NULL;
+ * Xi [nGroup,nCase,nHead,6nUnit,nw].  A 4-unit x 50-sea-state x 200-bin batch is two launches. */
+int raftx_solve_system_resident(raftx_ctx *ctx, int nUnit, const double *Mc, const double *Bc, const double *Cc,
+                                raftx_c128 *Xi);
+
 /* Duration (ms) of the device work of the last raftx_excitation /
  * raftx_linearize / raftx_solve_dynamics / raftx_solve_system call on this
  * ctx, measured with HIP events on the ctx's own stream (excludes H2D/D2H).

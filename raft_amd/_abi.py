@@ -24,7 +24,7 @@ EXPORTS = (
     "raftx_last_error", "raftx_upload_designs", "raftx_upload_cases",
     "raftx_excitation", "raftx_linearize", "raftx_solve_dynamics",
     "raftx_solve_system", "raftx_last_kernel_ms",
-    "raftx_solve_dynamics_device", "raftx_fetch_results", "raftx_debug_math", "raftx_motion_stats",
+    "raftx_solve_dynamics_device", "raftx_fetch_results", "raftx_debug_math", "raftx_motion_stats", "raftx_solve_system_resident",
 )
 WANT_BDRAG, WANT_FWAVE, WANT_Z = 1, 2, 4
 
@@ -89,6 +89,8 @@ class RaftxLib:
         L.raftx_solve_dynamics_device.restype = C.c_int
         L.raftx_fetch_results.argtypes = [_vp, _vp, _vp, _vp, _vp, _vp, _vp]
         L.raftx_fetch_results.restype = C.c_int
+        L.raftx_solve_system_resident.argtypes = [_vp, C.c_int, _vp, _vp, _vp, _vp]
+        L.raftx_solve_system_resident.restype = C.c_int
         L.raftx_motion_stats.argtypes = [_vp, C.c_double, _vp, _vp]
         L.raftx_motion_stats.restype = C.c_int
         L.raftx_debug_math.argtypes = [_vp, C.c_int, _vp, _vp, _vp, _vp]
@@ -245,6 +247,17 @@ class Context:
         rc = self.rlib.lib.raftx_fetch_results(self._h, _ptr(Xi), _ptr(niter), _ptr(flags), _ptr(B), _ptr(F), _ptr(Z))
         self._check(rc, "raftx_fetch_results")
         return dict(Xi=Xi, niter=niter, flags=flags, B_drag=B, F_wave=F, Z=Z)
+
+    def solve_system_resident(self, nUnit, Mc=None, Bc=None, Cc=None):
+        """Coupled array response from the resident Z / F_wave (solve_dynamics_device with WANT_Z|WANT_FWAVE)."""
+        nG, n = self.nDesign // nUnit, 6 * nUnit
+        Mc = None if Mc is None else _f64(Mc, (nG, n, n), "Mc")
+        Bc = None if Bc is None else _f64(Bc, (nG, n, n), "Bc")
+        Cc = None if Cc is None else _f64(Cc, (nG, n, n), "Cc")
+        Xi = np.empty((nG, self.nCase, self.nHead, n, self.nw), dtype=np.complex128)
+        rc = self.rlib.lib.raftx_solve_system_resident(self._h, int(nUnit), _ptr(Mc), _ptr(Bc), _ptr(Cc), _ptr(Xi))
+        self._check(rc, "raftx_solve_system_resident")
+        return Xi
 
     def motion_stats(self, dw, want_psd=False):
         """std [nDesign,nCase,6] (rotations in deg) and optionally PSD [nDesign,nCase,6,nw] of the resident results."""

@@ -37,7 +37,8 @@
 // Coupled array solve (raft_model.py:1164-1236): one 64-lane workgroup per
 // (system, bin); the augmented matrix [Z_sys | F] lives in LDS, lane r owns
 // row r during the elimination.
-__global__ void __launch_bounds__(64) k_solve_system(int nSys, int nUnit, int nRhs, int nw,
+template <bool RESIDENT>
+__global__ void __launch_bounds__(64) k_solve_system(int nSys, int nUnit, int nRhs, int nw, int nCase,
                                                      const double *__restrict__ w, const cplx *__restrict__ Zblk,
                                                      const double *__restrict__ Mc, const double *__restrict__ Bc,
                                                      const double *__restrict__ Cc, const cplx *__restrict__ F,
@@ -47,18 +48,28 @@ __global__ void __launch_bounds__(64) k_solve_system(int nSys, int nUnit, int nR
     cplx *A = reinterpret_cast<cplx *>(smem);              // [n][ld]
     __shared__ int s_p;
     const int s = blockIdx.x / nw, iw = blockIdx.x % nw;
+    // host layout: Zblk [nSys,nUnit,36,nw], F [nSys,nRhs,n,nw], coupling per system.
+    // resident layout (results of k_solve_dynamics): unit u of system (g, c) is pair (g*nUnit+u)*nCase + c;
+    // Z [pair,36,nw], F_wave [pair,nRhs,6,nw], coupling per group g.
+    const int g = RESIDENT ? s / nCase : s, ic = RESIDENT ? s % nCase : 0;
     const double ww = w[iw];
     for (int e = threadIdx.x; e < n * ld; e += 64) {
         int r = e / ld, c = e % ld;
         cplx v = {0.0, 0.0};
         if (c < n) {
-            if (r / 6 == c / 6) v = Zblk[((((size_t)s * nUnit + r / 6) * 6 + r % 6) * 6 + c % 6) * nw + iw];
-            size_t o = (size_t)s * n * n + (size_t)r * n + c;
+            if (r / 6 == c / 6) {
+                const size_t pair = RESIDENT ? ((size_t)g * nUnit + r / 6) * nCase + ic : (size_t)s * nUnit + r / 6;
+                v = Zblk[((pair * 6 + r % 6) * 6 + c % 6) * nw + iw];
+            }
+            size_t o = (size_t)g * n * n + (size_t)r * n + c;
             double m = Mc ? Mc[o] : 0.0, bb = Bc ? Bc[o] : 0.0, kk = Cc ? Cc[o] : 0.0;
             if (Mc || Bc || Cc) {
                 v.re += -(ww * ww) * m + kk;
                 v.im += ww * bb;
             }
+        } else if (RESIDENT) {
+            const size_t pair = ((size_t)g * nUnit + r / 6) * nCase + ic;
+            v = F[((pair * nRhs + (c - n)) * 6 + r % 6) * nw + iw];
         } else {
             v = F[(((size_t)s * nRhs + (c - n)) * n + r) * nw + iw];
         }
@@ -757,10 +768,44 @@ extern "C" int raftx_solve_system(raftx_ctx *c, int nSys, int nUnit, int nRhs, i
     HIPCHK(c, hipEventRecord(c->ev0, c->stream));
     if (nSys) {
         if (lds > 64 * 1024)
-            HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void *>(k_solve_system),
+            HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void *>(k_solve_system<false>),
                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL(k_solve_system, dim3((unsigned)((size_t)nSys * nw)), dim3(64), lds, c->stream, nSys, nUnit,
-                           nRhs, nw, dw, dZ, dM, dB, dC, dF, dX);
+        hipLaunchKernelGGL(k_solve_system<false>, dim3((unsigned)((size_t)nSys * nw)), dim3(64), lds, c->stream, nSys,
+                           nUnit, nRhs, nw, 1, dw, dZ, dM, dB, dC, dF, dX);
+    }
+    if (finish_timed(c)) return -2;
+    if (nSys) D2H(c, Xi, dX, nf * sizeof(cplx));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+extern "C" int raftx_solve_system_resident(raftx_ctx *c, int nUnit, const double *Mc, const double *Bc, const double *Cc,
+                                           raftx_c128 *Xi) {
+    if (!c) return -1;
+    if (!c->rXi || !c->rZ || !c->rFw)
+        FAIL(c, "solve_system_resident: needs resident Z and F_wave (raftx_solve_dynamics_device with RAFTX_WANT_Z|RAFTX_WANT_FWAVE)");
+    const DevTables &T = c->T;
+    if (nUnit < 1 || T.nDesign % nUnit != 0 || !Xi) FAIL(c, "solve_system_resident: bad arguments (nDesign=%d, nUnit=%d)", T.nDesign, nUnit);
+    HIPCHK(c, hipSetDevice(c->device));
+    const int nGroup = T.nDesign / nUnit, nSys = nGroup * T.nCase, n = 6 * nUnit, nRhs = T.nHead, nw = T.nw;
+    size_t lds = sizeof(cplx) * (size_t)n * (n + nRhs);
+    if (lds > 150 * 1024) FAIL(c, "solve_system: %d DOFs x %d rhs does not fit the LDS-resident solver", n, nRhs);
+    Scratch sc(c);
+    size_t nf = (size_t)nSys * nRhs * n * nw, nc = (size_t)nGroup * n * n;
+    cplx *dX = sc.alloc<cplx>(nf);
+    double *dM = Mc ? sc.alloc<double>(nc) : nullptr, *dB = Bc ? sc.alloc<double>(nc) : nullptr,
+           *dC = Cc ? sc.alloc<double>(nc) : nullptr;
+    if (nSys && (!dX || (Mc && !dM) || (Bc && !dB) || (Cc && !dC))) FAIL(c, "solve_system_resident: device allocation failed");
+    if (dM) H2D(c, dM, Mc, nc * sizeof(double));
+    if (dB) H2D(c, dB, Bc, nc * sizeof(double));
+    if (dC) H2D(c, dC, Cc, nc * sizeof(double));
+    HIPCHK(c, hipEventRecord(c->ev0, c->stream));
+    if (nSys) {
+        if (lds > 64 * 1024)
+            HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void *>(k_solve_system<true>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(k_solve_system<true>, dim3((unsigned)((size_t)nSys * nw)), dim3(64), lds, c->stream, nSys, nUnit,
+                           nRhs, nw, T.nCase, T.w, c->rZ, dM, dB, dC, c->rFw, dX);
     }
     if (finish_timed(c)) return -2;
     if (nSys) D2H(c, Xi, dX, nf * sizeof(cplx));

@@ -243,6 +243,60 @@ class Engine:
         return model.Xi
 
 
+def unit_matrices(fowt, nw):
+    """(M0, B0, C0, MBw) of one unit: the sums of raft_model.py:1005-1010,1045-1047."""
+    if fowt.nrotors > 0:
+        M_turb = np.sum(fowt.A_aero, axis=3)
+        B_turb = np.sum(fowt.B_aero, axis=3)
+    else:
+        M_turb = np.zeros([6, 6, nw])
+        B_turb = np.zeros([6, 6, nw])
+    A_BEM, B_BEM = np.asarray(fowt.A_BEM), np.asarray(fowt.B_BEM)
+    B_gyro = np.sum(fowt.B_gyro, axis=2)
+    C_lin = fowt.C_struc + fowt.C_hydro + fowt.C_moor + fowt.C_elast
+    if np.any(M_turb) or np.any(B_turb) or np.any(A_BEM) or np.any(B_BEM):
+        M_lin = M_turb + fowt.M_struc[:, :, None] + A_BEM + fowt.A_hydro_morison[:, :, None]
+        B_lin = B_turb + fowt.B_struc[:, :, None] + B_BEM + B_gyro[:, :, None]
+        return np.zeros((6, 6)), np.zeros((6, 6)), C_lin, np.array([M_lin, B_lin])
+    return fowt.M_struc + fowt.A_hydro_morison, fowt.B_struc + B_gyro, C_lin, None
+
+
+def sweep_from_models(models, cases, tol=0.01):
+    """One batched ``raft_amd.sweep.Sweep`` for the first FOWT of every model (design candidates)
+    x every load case (all with the same number of wave headings): what an optimisation driver
+    launches instead of ``for model: for case: model.solveDynamics(case)``."""
+    from .sweep import Sweep
+    f0 = models[0].fowtList[0]
+    zeta, beta = [], []
+    for case in cases:
+        _, b, _, z = waves.sea_state(dict(case), f0.w, f0.dw)
+        zeta.append(z)
+        beta.append(b)
+    rows = []
+    for m in models:
+        f = m.fowtList[0]
+        if int(f.nDOF) != 6:
+            raise UnsupportedFOWT("device path covers rigid 6-DOF FOWTs (nDOF=%d)" % f.nDOF)
+        rows.append((pack_fowt(f),) + unit_matrices(f, m.nw))
+    return Sweep.from_fowts(rows, f0.w, f0.k, f0.depth, np.array(zeta), np.array(beta),
+                            nIter=int(models[0].nIter), XiStart=models[0].XiStart, tol=tol)
+
+
+def sweep_from_units(model, cases, tol=0.01):
+    """The units of ONE array model as the designs of a Sweep (for ``Sweep.run_farm``): every unit keeps its
+    own absolute strip positions, so the wave phase across the farm is carried by the strip table."""
+    from .sweep import Sweep
+    f0 = model.fowtList[0]
+    zeta, beta = [], []
+    for case in cases:
+        _, b, _, z = waves.sea_state(dict(case), f0.w, f0.dw)
+        zeta.append(z)
+        beta.append(b)
+    rows = [(pack_fowt(f),) + unit_matrices(f, model.nw) for f in model.fowtList]
+    return Sweep.from_fowts(rows, f0.w, f0.k, f0.depth, np.array(zeta), np.array(beta),
+                            nIter=int(model.nIter), XiStart=model.XiStart, tol=tol)
+
+
 _default_engine = Engine()
 
 

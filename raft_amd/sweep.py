@@ -129,6 +129,18 @@ class Sweep:
         r = ctx.fetch_results(want_Xi=False)
         return {"std": std, "psd": psd, "niter": r["niter"], "flags": r["flags"]}
 
+    def run_farm(self, ctx, n_unit, Cc=None, Mc=None, Bc=None):
+        """Arrays: consecutive groups of ``n_unit`` designs are the units of one farm (raft_model.py:1164-1236).
+        Two launches: the per-unit fixed points, then the coupled 6N x 6N solves fed from the resident Z / F_wave.
+        Returns Xi [nGroup,nCase,nHead,6*n_unit,nw] plus per-unit niter/flags."""
+        from ._abi import WANT_FWAVE, WANT_Z
+        self.upload(ctx)
+        ctx.solve_dynamics_device(self.nIter, self.tol, self.XiStart, want_mask=WANT_Z | WANT_FWAVE)
+        t_units = ctx.last_kernel_ms()
+        Xi = ctx.solve_system_resident(n_unit, Mc, Bc, Cc)
+        r = ctx.fetch_results(want_Xi=False)
+        return {"Xi": Xi, "niter": r["niter"], "flags": r["flags"], "kernel_ms": (t_units, ctx.last_kernel_ms())}
+
     def run(self, ctx):
         self.solve(ctx)
         r = ctx.fetch_results(want_Xi=True)

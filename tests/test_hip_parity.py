@@ -137,6 +137,59 @@ def test_lean_sweep_kernel_parity(hip_ctx, oracle_ctx, S_list, nw, nC):
         assert group_rel_err(res[0]["Xi"][d], res[1]["Xi"][d]) < TOL
 
 
+def test_c2_sea_states_as_one_batch(hip_ctx):
+    """BASELINE configs[1]: the sea states of VolturnUS-S_example solved as ONE launch of the sweep kernel
+    (cases axis), against the live-reference response of each case."""
+    fx, model = load_model_fixture("c2_volturnus.npz")
+    single = [c for c in fx["cases"] if np.isscalar(c["case"]["wave_heading"]) or len(np.atleast_1d(c["case"]["wave_heading"])) == 1]
+    assert len(single) >= 3
+    sweep = dropin.sweep_from_models([model], [case_from_fixture(c) for c in single])
+    out = sweep.run(hip_ctx)
+    assert out["Xi"].shape == (1, len(single), 1, 6, model.nw)
+    for i, c in enumerate(single):
+        assert int(out["niter"][0, i]) == int(c["units"][0]["niter"])
+        assert group_rel_err(out["Xi"][0, i, :1], c["Xi"][:1]) < TOL
+    st = sweep.run_stats(hip_ctx)
+    f = model.fowtList[0]
+    for i, c in enumerate(single):
+        ref = np.sqrt(0.5 * np.sum(np.abs(c["Xi"][:1, 0, :]) ** 2))
+        assert abs(st["std"][0, i, 0] - ref) < 1e-9 * ref
+
+
+def test_c4_farm_as_one_batch(hip_ctx, oracle_ctx):
+    """BASELINE configs[3]: 4-unit array, all sea states in one batch: per-unit fixed points (one launch) +
+    coupled 24x24 solves fed from the resident Z / F_wave (second launch)."""
+    fx, model = load_model_fixture("c4_farm.npz")
+    sweep = dropin.sweep_from_units(model, [case_from_fixture(c) for c in fx["cases"]])
+    out = sweep.run_farm(hip_ctx, 4, Cc=fx["coupling_C"][None])
+    ref = sweep.run_farm(oracle_ctx, 4, Cc=fx["coupling_C"][None])
+    assert np.array_equal(out["niter"], ref["niter"])
+    for i, c in enumerate(fx["cases"]):
+        nH = c["Xi"].shape[0] - 1
+        assert group_rel_err(out["Xi"][0, i, :nH], c["Xi"][:nH]) < TOL
+        assert group_rel_err(out["Xi"][0, i], ref["Xi"][0, i]) < TOL
+
+
+def test_resident_system_solve_many_groups(hip_ctx, oracle_ctx):
+    """Three arrays of two synthetic units x 3 cases x 2 headings, full coupling matrices."""
+    rng = np.random.default_rng(404)
+    tables = [random_strips(rng, S) for S in (20, 31, 9, 40, 17, 25)]
+    mats = random_matrices(rng, 6)
+    cases = synthetic_cases(rng, 3, 2, 48)
+    _both(hip_ctx, oracle_ctx, tables, mats, cases)
+    n = 12
+    Cc = rng.normal(size=(3, n, n)) * 1e5
+    Cc = Cc + np.transpose(Cc, (0, 2, 1))
+    Bc = 1e3 * rng.normal(size=(3, n, n))
+    Mc = 1e4 * rng.normal(size=(3, n, n))
+    res = []
+    for ctx in (hip_ctx, oracle_ctx):
+        ctx.solve_dynamics_device(5, 0.01, 0.1, want_mask=6)
+        res.append(ctx.solve_system_resident(2, Mc, Bc, Cc))
+    assert res[0].shape == (3, 3, 2, 12, 48)
+    assert rel_err(res[0], res[1]) < TOL
+
+
 def test_motion_stats_parity(hip_ctx, oracle_ctx):
     rng = np.random.default_rng(5150)
     tables = [random_strips(rng, S) for S in (40, 53, 7)]

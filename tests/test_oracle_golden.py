@@ -93,3 +93,15 @@ def test_motion_stats_follow_getRMS_getPSD(oracle_ctx):
         # and against the reference's own amplitudes
         xr = c["Xi"][:nH, j, :] * (np.rad2deg(1.0) if j >= 3 else 1.0)
         assert abs(std[0, 0, j] - np.sqrt(0.5 * np.sum(np.abs(xr) ** 2))) <= 1e-9 * max(1e-12, std[0, 0, j])
+
+
+def test_farm_batch_matches_live_reference(oracle_ctx):
+    """BASELINE configs[3] shape: units of an array as designs, sea states as cases, coupled 24x24 solve fed
+    from the resident per-unit results (raft_model.py:1164-1236) -- against the live 4-unit reference run."""
+    fx, model = load_model_fixture("c4_farm.npz")
+    sweep = dropin.sweep_from_units(model, [case_from_fixture(c) for c in fx["cases"]])
+    out = sweep.run_farm(oracle_ctx, 4, Cc=fx["coupling_C"][None])
+    for i, c in enumerate(fx["cases"]):
+        nH = c["Xi"].shape[0] - 1
+        assert group_rel_err(out["Xi"][0, i, :nH], c["Xi"][:nH]) < 1e-10
+        assert [int(out["niter"][u, i]) for u in range(4)] == [int(c["units"][u]["niter"]) for u in range(4)]
