@@ -227,6 +227,14 @@ __device__ __forceinline__ double tile_reduce(ldptr tile, int lane) {
     return a;
 }
 
+// A wave-uniform double computed with vector instructions (e.g. cos of the heading) moved into
+// SGPRs: frees two VGPRs for the whole kernel and feeds v_fma_f64 as its scalar operand.
+__device__ __forceinline__ double to_sgpr(double v) {
+    const int lo = __builtin_amdgcn_readfirstlane(__double2loint(v));
+    const int hi = __builtin_amdgcn_readfirstlane(__double2hiint(v));
+    return __hiloint2double(hi, lo);
+}
+
 // Hides a value's provenance from the optimiser: address arithmetic based on it is redone at
 // the use instead of being hoisted out of the fixed-point loop and spilled.
 __device__ __forceinline__ int opaque(int x) {
@@ -608,7 +616,8 @@ template <int NB, bool STAGE>
 __device__ __forceinline__ void linearize_passA(cdptr ds, ciptr dsi, int S,
                                                 const Lds &l, const Bins<NB> &b, double cb, double sb,
                                                 const cplx (&X)[NB][6] PT_ARG) {
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int tid = opaque((int)threadIdx.x);
+    const int lane = tid & 63, wv = tid >> 6;
     ldptr tile = l.tile + wv * TR_ROWS * TR_STRIDE;
     ldptr wr = tile + tile_pos(lane);
     ldptr vout = l.vsq + wv * S * 3;
@@ -652,11 +661,12 @@ __device__ __forceinline__ void linearize_passA(cdptr ds, ciptr dsi, int S,
 template <bool FRESH>
 __device__ __forceinline__ void strip_phase(cdptr ds, ciptr dsi, int S,
                                             const Lds &l, double cb, double sb, bool multi) {
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, nwv = blockDim.x >> 6;
+    const int tid = opaque((int)threadIdx.x);       // per-lane LDS addresses of this phase are formed here, not hoisted
+    const int lane = tid & 63, wv = tid >> 6, nwv = blockDim.x >> 6;
     double b6[21];
 #pragma unroll
     for (int e = 0; e < 21; e++) b6[e] = 0.0;
-    for (int s = threadIdx.x; s < S; s += blockDim.x) {
+    for (int s = tid; s < S; s += blockDim.x) {
         cdptr rec = ds + (size_t)s * DS_N;
         double bc[3];
         if (FRESH) {
@@ -732,13 +742,13 @@ __device__ __forceinline__ void strip_phase(cdptr ds, ciptr dsi, int S,
             if ((lane & 7) == 0 && r0 + (lane >> 3) < 21) l.bdw[wv * 24 + r0 + (lane >> 3)] = a;
         }
         wg_sync(multi);
-        if (threadIdx.x < 36) {
-            const int i = threadIdx.x / 6, j = threadIdx.x % 6;
+        if (tid < 36) {
+            const int i = tid / 6, j = tid % 6;
             const int lo = i < j ? i : j, hi = i < j ? j : i;
             const int e = lo * 6 - (lo * (lo - 1)) / 2 + (hi - lo);
             double acc = 0.0;
             for (int q = 0; q < nwv; q++) acc += l.bdw[q * 24 + e];
-            l.Bd[threadIdx.x] = acc;
+            l.Bd[tid] = acc;
         }
     }
     wg_sync(multi);
@@ -979,7 +989,7 @@ __global__ void __launch_bounds__(MAXT, MINB) k_excitation(DevTables T, cplx *__
     load_bins(T, b, threadIdx.x);
     set_heading_amp(T, b, p.ic, ih);
     const double beta = T.beta[(size_t)p.ic * T.nHead + ih];
-    const double cb = cos(beta), sb = sin(beta);
+    const double cb = to_sgpr(cos(beta)), sb = to_sgpr(sin(beta));
     cplx F[NB][6];
     zero6(F);
     inertial_excitation<NB, true>(T, p.ds, p.dsi, p.S, p.cm, b, p.ic, ih, cb, sb, F);
@@ -1003,7 +1013,7 @@ __global__ void __launch_bounds__(MAXT, MINB) k_linearize(DevTables T, const cpl
     {
         set_heading_amp(T, b, p.ic, 0);
         const double beta = T.beta[(size_t)p.ic * T.nHead];
-        const double cb = cos(beta), sb = sin(beta);
+        const double cb = to_sgpr(cos(beta)), sb = to_sgpr(sin(beta));
         cplx X[NB][6];
 #pragma unroll
         for (int j = 0; j < NB; j++) {
@@ -1025,7 +1035,7 @@ __global__ void __launch_bounds__(MAXT, MINB) k_linearize(DevTables T, const cpl
     if (F_drag) {
         for (int ih = 0; ih < T.nHead; ih++) {
             const double beta = T.beta[(size_t)p.ic * T.nHead + ih];
-            const double cb = cos(beta), sb = sin(beta);
+            const double cb = to_sgpr(cos(beta)), sb = to_sgpr(sin(beta));
             set_heading_amp(T, b, p.ic, ih);
             if (ih > 0) {
                 wg_sync(multi);
@@ -1091,7 +1101,7 @@ __global__ void __launch_bounds__(MAXT, MINB) k_solve_dynamics(DevTables T, Solv
         l.mat[i] = src[(size_t)p.d * 36 + e];
     }
     const double beta0 = T.beta[(size_t)p.ic * nHs];
-    const double cb0 = cos(beta0), sb0 = sin(beta0);
+    const double cb0 = to_sgpr(cos(beta0)), sb0 = to_sgpr(sin(beta0));
     cplx *xio = A.Xi + ((size_t)pair * nHs) * 6 * nw;      // heading-0 slab: F_lin until the end, then Xi
 
     {   // F_lin = F_extra[0] + F_iner[0]   (raft_model.py:1048)
@@ -1217,7 +1227,7 @@ __global__ void __launch_bounds__(MAXT, MINB) k_solve_dynamics(DevTables T, Solv
 #pragma unroll 1
         for (int ih = 1; ih < nH; ih++) {
             const double beta = T.beta[(size_t)p.ic * nHs + ih];
-            const double cb = cos(beta), sb = sin(beta);
+            const double cb = to_sgpr(cos(beta)), sb = to_sgpr(sin(beta));
             set_heading_amp(T, b, p.ic, ih);
             wg_sync(multi);
             strip_phase<false>(p.ds, p.dsi, S, l, cb, sb, multi);
