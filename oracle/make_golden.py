@@ -228,7 +228,50 @@ def fixture_c3(n_variants=64, n_solved=8):
     standin.save_fixture(os.path.join(GOLD, "c3_variants.npz"), fx)
 
 
-ALL = {"c1": fixture_c1, "c2": fixture_c2, "pose": fixture_pose,
+def fixture_qtf():
+    """Slender-body QTF goldens (tests/test_fowt.py:192-216): the reference's own pickles (fixed body, heading
+    30 deg, 23x23 grid) for VolturnUS-S and VolturnUS-S-pointInertia, plus LIVE reference QTFs of the same decks
+    with body motions (Xi0 = smooth synthetic RAOs) and heading -20 deg, which exercise every motion term."""
+    raft = rh.import_raft()
+    for name in ("VolturnUS-S", "VolturnUS-S-pointInertia"):
+        d = rh.load_design(os.path.join(REF, "tests/test_data", name + ".yaml"))
+        d = rh.prepare_design(d)
+        model = raft.Model(d)
+        fowt = model.fowtList[0]
+        assert fowt.potSecOrder == 1
+        fowt.setPosition(np.zeros(fowt.nDOF))
+        fowt.calcStatics()
+        fowt.calcHydroConstants()
+        fowt.calcTurbineConstants(rh.make_case(), ptfm_pitch=0)     # only so that A_aero/B_gyro exist (all zero)
+        fowt.C_moor = np.zeros((6, 6))
+        with open(os.path.join(REF, "tests/test_data", name + "_true_calcQTF_slenderBody.pkl"), "rb") as f:
+            tv = pickle.load(f)
+        case = {'wave_heading': 30, 'wave_period': 12, 'wave_height': 6}
+        fowt.calcHydroExcitation(dict(case), memberList=fowt.memberList)
+        beta_fixed = float(fowt.beta[0])
+        # live run with motions
+        case2 = {'wave_heading': -20, 'wave_period': 10, 'wave_height': 4}
+        fowt.calcHydroExcitation(dict(case2), memberList=fowt.memberList)
+        w = fowt.w
+        ph = np.linspace(0, 3.0, 6)[:, None] + 2.0 * w[None, :]
+        amp = np.array([1.2, 0.4, 0.8, 0.01, 0.02, 0.005])[:, None] / (1.0 + (w[None, :] / 0.5) ** 2)
+        Xi0 = amp * np.exp(1j * ph)
+        fowt.outFolderQTF = None
+        fowt.calcQTF_slenderBody(0, Xi0=Xi0)
+        Xi2 = np.zeros([6, len(fowt.w1_2nd)], dtype=complex)
+        for i in range(6):
+            Xi2[i] = np.interp(fowt.w1_2nd, fowt.w, Xi0[i], left=0, right=0)
+        S0 = np.array(fowt.S[0])
+        f_mean, f2 = fowt.calcHydroForce_2ndOrd(fowt.beta[0], S0)
+        fx = {"config": "slender-body QTF goldens " + name, "model": standin.snapshot_model(model),
+              "fixed_beta": beta_fixed, "fixed_qtf": np.array(tv["qtf"][:, :, 0, :]),
+              "motion_beta": float(fowt.beta[0]), "motion_Xi0": Xi0, "motion_Xi2": Xi2,
+              "motion_qtf": np.array(fowt.qtf[:, :, 0, :]), "motion_S0": S0,
+              "motion_f_mean": np.array(f_mean), "motion_f2": np.array(f2)}
+        standin.save_fixture(os.path.join(GOLD, "refgold_qtf_%s.npz" % name), fx)
+
+
+ALL = {"qtf": fixture_qtf, "c1": fixture_c1, "c2": fixture_c2, "pose": fixture_pose,
        "refgold": fixture_ref_goldens, "c4": fixture_c4, "c3": fixture_c3}
 
 if __name__ == "__main__":

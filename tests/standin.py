@@ -33,6 +33,8 @@ def snapshot_member(mem):
          "potMod": bool(mem.potMod), "MCF": bool(mem.MCF), "ns": int(mem.ns)}
     for a in MEMBER_ARRAYS:
         d[a] = np.array(getattr(mem, a), dtype=float)
+    d["rA"] = np.array(mem.rA, dtype=float)
+    d["rB"] = np.array(mem.rB, dtype=float)
     d["node_r"] = np.array(mem.nodeList[0].r, dtype=float)
     d["node_T"] = np.array(mem.nodeList[0].T, dtype=float)
     # reference products kept for packer checks (not read by raft_amd)
@@ -56,6 +58,9 @@ def snapshot_fowt(fowt):
             d[a] = np.array(v, dtype=float)
         else:
             d[a + "_zero_shape"] = np.array(v.shape, dtype=np.int64)
+    if getattr(fowt, "potSecOrder", 0) == 1:
+        d["w1_2nd"] = np.array(fowt.w1_2nd, dtype=float)
+        d["k1_2nd"] = np.array(fowt.k1_2nd, dtype=float)
     d["members"] = [snapshot_member(m) for m in fowt.memberList]
     return d
 
@@ -121,6 +126,8 @@ def build_member(d):
         setattr(m, k, d[k])
     for a in MEMBER_ARRAYS:
         setattr(m, a, d[a])
+    if "rA" in d:
+        m.rA, m.rB = d["rA"], d["rB"]
     node = Obj()
     node.r = d["node_r"]
     node.T = d["node_T"]
@@ -143,6 +150,8 @@ def build_fowt(d):
             setattr(f, a, d[a])
         else:
             setattr(f, a, np.zeros(tuple(int(x) for x in d[a + "_zero_shape"])))
+    if "w1_2nd" in d:
+        f.w1_2nd, f.k1_2nd = d["w1_2nd"], d["k1_2nd"]
     f.memberList = [build_member(m) for m in d["members"]]
     f.rotorList = []
     f.ms = None
