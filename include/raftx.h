@@ -166,6 +166,20 @@ int raftx_solve_system(raftx_ctx *ctx, int nSys, int nUnit, int nRhs, int nw,
 int raftx_solve_system_resident(raftx_ctx *ctx, int nUnit, const double *Mc, const double *Bc, const double *Cc,
                                 raftx_c128 *Xi);
 
+/* Second-order (difference-frequency) slender-body QTF -- raft/raft_fowt.py:1988-2078
+ * (FOWT.calcQTF_slenderBody: Pinkster IV term, member loop, Hermitian fill) and
+ * raft/raft_member.py:1488-1674 (Member.calcQTF_slenderBody) with the helpers of raft/helpers.py:239-373 --
+ * for nSet independent (strip table, motion RAOs, heading) sets on a common second-order grid w2,k2 [nw2].
+ * strips [stripOff[nSet],24] / members [memOff[nSet],16]: records of raft_amd/qtf.py (QS_N, QM_N);
+ * Xi [nSet,6,nw2] motion RAOs on that grid (zeros = fixed body); beta [nSet] rad; Mstruc [nSet,6,6];
+ * kay [nSet,nw2,nw2,6] optional Kim & Yue table (raft_member.py:1676-1791; upper triangle, host feeder);
+ * qtf [nSet,nw2,nw2,6] out, Hermitian-completed.  Independent of the upload_* state of the ctx. */
+int raftx_qtf_slender(raftx_ctx *ctx, int nSet, int nw2, const double *w2, const double *k2,
+                      double depth, double rho, double g,
+                      const int64_t *stripOff, const double *strips, const int64_t *memOff, const double *members,
+                      const raftx_c128 *Xi, const double *beta, const double *Mstruc,
+                      const raftx_c128 *kay, raftx_c128 *qtf);
+
 /* Duration (ms) of the device work of the last raftx_excitation /
  * raftx_linearize / raftx_solve_dynamics / raftx_solve_system call on this
  * ctx, measured with HIP events on the ctx's own stream (excludes H2D/D2H).

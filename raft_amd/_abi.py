@@ -24,7 +24,7 @@ EXPORTS = (
     "raftx_last_error", "raftx_upload_designs", "raftx_upload_cases",
     "raftx_excitation", "raftx_linearize", "raftx_solve_dynamics",
     "raftx_solve_system", "raftx_last_kernel_ms",
-    "raftx_solve_dynamics_device", "raftx_fetch_results", "raftx_debug_math", "raftx_motion_stats", "raftx_solve_system_resident",
+    "raftx_solve_dynamics_device", "raftx_fetch_results", "raftx_debug_math", "raftx_motion_stats", "raftx_solve_system_resident", "raftx_qtf_slender",
 )
 WANT_BDRAG, WANT_FWAVE, WANT_Z = 1, 2, 4
 
@@ -91,6 +91,9 @@ class RaftxLib:
         L.raftx_fetch_results.restype = C.c_int
         L.raftx_solve_system_resident.argtypes = [_vp, C.c_int, _vp, _vp, _vp, _vp]
         L.raftx_solve_system_resident.restype = C.c_int
+        L.raftx_qtf_slender.argtypes = [_vp, C.c_int, C.c_int, _vp, _vp, C.c_double, C.c_double, C.c_double,
+                                        _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]
+        L.raftx_qtf_slender.restype = C.c_int
         L.raftx_motion_stats.argtypes = [_vp, C.c_double, _vp, _vp]
         L.raftx_motion_stats.restype = C.c_int
         L.raftx_debug_math.argtypes = [_vp, C.c_int, _vp, _vp, _vp, _vp]
@@ -258,6 +261,31 @@ class Context:
         rc = self.rlib.lib.raftx_solve_system_resident(self._h, int(nUnit), _ptr(Mc), _ptr(Bc), _ptr(Cc), _ptr(Xi))
         self._check(rc, "raftx_solve_system_resident")
         return Xi
+
+    def qtf_slender(self, tables, Xi, beta, w2, k2, depth, rho, g, Mstruc, kay=None):
+        """Batch of slender-body QTFs: tables = list of raft_amd.qtf.QtfTable (one per set), Xi [nSet,6,nw2],
+        beta [nSet], Mstruc [nSet,6,6], kay [nSet,nw2,nw2,6] or None -> qtf [nSet,nw2,nw2,6]."""
+        nS = len(tables)
+        w2 = _f64(w2)
+        nw2 = len(w2)
+        k2 = _f64(k2, (nw2,), "k2")
+        soff = np.zeros(nS + 1, dtype=np.int64)
+        moff = np.zeros(nS + 1, dtype=np.int64)
+        for i, t in enumerate(tables):
+            soff[i + 1] = soff[i] + t.strips.shape[0]
+            moff[i + 1] = moff[i] + t.members.shape[0]
+        strips = _f64(np.concatenate([t.strips for t in tables], axis=0)) if nS else np.zeros((0, 24))
+        members = _f64(np.concatenate([t.members for t in tables], axis=0)) if nS else np.zeros((0, 16))
+        Xi = _c128(Xi, (nS, 6, nw2), "Xi")
+        beta = _f64(beta, (nS,), "beta")
+        Mstruc = _f64(Mstruc, (nS, 6, 6), "Mstruc")
+        kay = None if kay is None else _c128(kay, (nS, nw2, nw2, 6), "kay")
+        qtf = np.empty((nS, nw2, nw2, 6), dtype=np.complex128)
+        rc = self.rlib.lib.raftx_qtf_slender(self._h, nS, nw2, _ptr(w2), _ptr(k2), float(depth), float(rho), float(g),
+                                             _ptr(soff), _ptr(strips), _ptr(moff), _ptr(members), _ptr(Xi), _ptr(beta),
+                                             _ptr(Mstruc), _ptr(kay), _ptr(qtf))
+        self._check(rc, "raftx_qtf_slender")
+        return qtf
 
     def motion_stats(self, dw, want_psd=False):
         """std [nDesign,nCase,6] (rotations in deg) and optionally PSD [nDesign,nCase,6,nw] of the resident results."""

@@ -33,6 +33,7 @@
 #include "../../include/raftx.h"
 
 #include "raftx_kernels.h"
+#include "raftx_qtf.h"
 
 // Coupled array solve (raft_model.py:1164-1236): one 64-lane workgroup per
 // (system, bin); the augmented matrix [Z_sys | F] lives in LDS, lane r owns
@@ -809,6 +810,68 @@ extern "C" int raftx_solve_system_resident(raftx_ctx *c, int nUnit, const double
     }
     if (finish_timed(c)) return -2;
     if (nSys) D2H(c, Xi, dX, nf * sizeof(cplx));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+extern "C" int raftx_qtf_slender(raftx_ctx *c, int nSet, int nw2, const double *w2, const double *k2, double depth,
+                                 double rho, double g, const int64_t *stripOff, const double *strips,
+                                 const int64_t *memOff, const double *members, const raftx_c128 *Xi,
+                                 const double *beta, const double *Mstruc, const raftx_c128 *kay, raftx_c128 *qtf) {
+    if (!c) return -1;
+    if (nSet < 0 || nw2 < 1 || !w2 || !k2 || !stripOff || !memOff || !Xi || !beta || !Mstruc || !qtf)
+        FAIL(c, "qtf_slender: bad arguments");
+    HIPCHK(c, hipSetDevice(c->device));
+    const size_t nStrip = (size_t)stripOff[nSet], nMem = (size_t)memOff[nSet];
+    if ((nStrip && !strips) || (nMem && !members)) FAIL(c, "qtf_slender: missing tables");
+    std::vector<int> sset(nStrip), mset(nMem);
+    for (int s = 0; s < nSet; s++) {
+        if (stripOff[s + 1] < stripOff[s] || memOff[s + 1] < memOff[s]) FAIL(c, "qtf_slender: offsets not monotone");
+        for (int64_t i = stripOff[s]; i < stripOff[s + 1]; i++) sset[(size_t)i] = s;
+        for (int64_t i = memOff[s]; i < memOff[s + 1]; i++) mset[(size_t)i] = s;
+    }
+    Scratch sc(c);
+    const size_t nq = (size_t)nSet * nw2 * nw2 * 6;
+    QtfArgs A;
+    A.nSet = nSet;
+    A.nw = nw2;
+    A.depth = depth;
+    A.rho = rho;
+    A.g = g;
+    double *dw = sc.alloc<double>(nw2), *dk = sc.alloc<double>(nw2), *dS = sc.alloc<double>(nStrip * QS_N),
+           *dM = sc.alloc<double>(nMem * QM_N), *dB = sc.alloc<double>(nSet), *dMs = sc.alloc<double>((size_t)nSet * 36);
+    int64_t *dso = sc.alloc<int64_t>(nSet + 1), *dmo = sc.alloc<int64_t>(nSet + 1);
+    int *dss = sc.alloc<int>(nStrip), *dms = sc.alloc<int>(nMem);
+    cplx *dXi = sc.alloc<cplx>((size_t)nSet * 6 * nw2), *dK = kay ? sc.alloc<cplx>(nq) : nullptr;
+    cplx *dT = sc.alloc<cplx>(nStrip * QT_N * nw2), *dTM = sc.alloc<cplx>(nMem * QTM_N * nw2),
+         *dTS = sc.alloc<cplx>((size_t)nSet * QTS_N * nw2), *dQ = sc.alloc<cplx>(nq);
+    if (nSet && (!dw || !dk || (nStrip && (!dS || !dss || !dT)) || (nMem && (!dM || !dms || !dTM)) || !dB || !dMs || !dso ||
+                 !dmo || !dXi || (kay && !dK) || !dTS || !dQ))
+        FAIL(c, "qtf_slender: device allocation failed");
+    if (nSet) {
+        H2D(c, dw, w2, nw2 * sizeof(double));
+        H2D(c, dk, k2, nw2 * sizeof(double));
+        if (nStrip) H2D(c, dS, strips, nStrip * QS_N * sizeof(double));
+        if (nMem) H2D(c, dM, members, nMem * QM_N * sizeof(double));
+        H2D(c, dB, beta, nSet * sizeof(double));
+        H2D(c, dMs, Mstruc, (size_t)nSet * 36 * sizeof(double));
+        H2D(c, dso, stripOff, (nSet + 1) * sizeof(int64_t));
+        H2D(c, dmo, memOff, (nSet + 1) * sizeof(int64_t));
+        if (nStrip) H2D(c, dss, sset.data(), nStrip * sizeof(int));
+        if (nMem) H2D(c, dms, mset.data(), nMem * sizeof(int));
+        H2D(c, dXi, Xi, (size_t)nSet * 6 * nw2 * sizeof(cplx));
+        if (kay) H2D(c, dK, kay, nq * sizeof(cplx));
+    }
+    A.w = dw; A.k = dk; A.soff = dso; A.strips = dS; A.moff = dmo; A.members = dM; A.sset = dss; A.mset = dms;
+    A.Xi = dXi; A.beta = dB; A.Ms = dMs; A.kay = dK; A.T = dT; A.TM = dTM; A.TS = dTS; A.qtf = dQ;
+    HIPCHK(c, hipEventRecord(c->ev0, c->stream));
+    if (nSet) {
+        hipLaunchKernelGGL(k_qtf_tables, dim3((unsigned)(nStrip + nMem + nSet)), dim3(nw2 > 128 ? 256 : 128), 0, c->stream, A,
+                           (int)nStrip, (int)nMem);
+        hipLaunchKernelGGL(k_qtf_pairs, dim3((unsigned)((size_t)nSet * nw2)), dim3(nw2 > 64 ? 128 : 64), 0, c->stream, A);
+    }
+    if (finish_timed(c)) return -2;
+    if (nSet) D2H(c, qtf, dQ, nq * sizeof(cplx));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     return 0;
 }

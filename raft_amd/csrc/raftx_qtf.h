@@ -1,0 +1,393 @@
+// raftx_qtf.h -- gfx950 kernels of the second-order slender-body QTF (included by raftx_hip.hip).
+//
+// Reference: raft/raft_member.py:1488-1674 (Member.calcQTF_slenderBody), raft/raft_fowt.py:2044-2070
+// (Pinkster IV term, member loop, Hermitian fill), raft/helpers.py:239-373 (gradient / second-order
+// potential helpers), raft/helpers.py:149-236 (getKinematics, getWaveKin).
+//
+// Two launches per batch of "sets" (one set = one strip table + motion RAOs + heading):
+//   k_qtf_tables : per (strip | member | set, frequency) the first-order quantities every pair needs
+//                  (wave velocity, its gradient, body displacement/velocity, pressure gradient ...),
+//                  evaluated ONCE per frequency with full-precision device libm; 24 complex per strip-bin.
+//   k_qtf_pairs  : one thread per (w1, w2 >= w1) pair, one workgroup row per w1; loops the strips, reads
+//                  the two table columns (the w1 column is wave-uniform, the w2 column coalesced) and
+//                  evaluates the bilinear Rainey / Pinkster terms, the second-order-potential term
+//                  (two exp per strip-pair) and the waterline term; writes Q[i1,i2] and conj to Q[i2,i1].
+// The reference's quirks are kept (see oracle/qtf_oracle.py, which documents each one).
+#pragma once
+
+#define QS_N 24        // doubles per QTF strip record (raft_amd/qtf.py)
+#define QM_N 16        // doubles per QTF member record
+#define QT_N 24        // complex table entries per (strip, frequency)
+#define QTM_N 12       // complex table entries per (member, frequency)
+#define QTS_N 12       // complex table entries per (set, frequency)
+
+// strip table fields
+#define QT_U 0         // u[3]
+#define QT_G 3         // grad_u distinct entries: g00 g01 g02 g11 g12 g22
+#define QT_DR 9        // dr[3]
+#define QT_VT 12       // u - nodeV_t [3]  (nodeV_t = node velocity with its axial part removed)
+#define QT_GP 15       // grad_pres1st[3]
+#define QT_NAR 18      // nodeV_axial_rel
+#define QT_DWDZ 19     // q . grad_u q
+#define QT_E2 20       // exp(-i k (cos(deg2rad b) x + sin(deg2rad b) y)): phase of the 2nd-order potential
+#define QT_UT 21       // (u - (q.u) q) - nodeV_t  [3]: the transverse relative velocity of axdivAcc
+// member table fields
+#define QTM_UD 0       // ud_wl[3]
+#define QTM_ETAR 3     // eta_r
+#define QTM_AB 4       // body acceleration at the waterline [3]
+#define QTM_GE 7       // g_e1[3]
+// set table fields
+#define QTS_TH 0       // theta[3]
+#define QTS_F1 3       // F1st[6]
+
+struct c3 {
+    cplx x, y, z;
+};
+__device__ __forceinline__ cplx cconj(cplx a) { return {a.re, -a.im}; }
+__device__ __forceinline__ cplx cmuli(cplx a) { return {-a.im, a.re}; }                 // i a
+__device__ __forceinline__ cplx cfma(cplx a, cplx b, cplx c) { return {fma(a.re, b.re, fma(-a.im, b.im, c.re)), fma(a.re, b.im, fma(a.im, b.re, c.im))}; }
+__device__ __forceinline__ c3 c3add(c3 a, c3 b) { return {cadd(a.x, b.x), cadd(a.y, b.y), cadd(a.z, b.z)}; }
+__device__ __forceinline__ c3 c3sub(c3 a, c3 b) { return {csub(a.x, b.x), csub(a.y, b.y), csub(a.z, b.z)}; }
+__device__ __forceinline__ c3 c3scale(c3 a, double s) { return {cscale(a.x, s), cscale(a.y, s), cscale(a.z, s)}; }
+__device__ __forceinline__ c3 c3cmul(c3 a, cplx s) { return {cmul(a.x, s), cmul(a.y, s), cmul(a.z, s)}; }
+__device__ __forceinline__ c3 c3conj(c3 a) { return {cconj(a.x), cconj(a.y), cconj(a.z)}; }
+__device__ __forceinline__ cplx rdot(const double *n, c3 v) {                          // real n . complex v
+    return {n[0] * v.x.re + n[1] * v.y.re + n[2] * v.z.re, n[0] * v.x.im + n[1] * v.y.im + n[2] * v.z.im};
+}
+__device__ __forceinline__ cplx cdot(c3 a, c3 b) {                                     // sum a_i b_i (no conjugation)
+    return cadd(cadd(cmul(a.x, b.x), cmul(a.y, b.y)), cmul(a.z, b.z));
+}
+__device__ __forceinline__ c3 rvec(const double *n, cplx s) { return {cscale(s, n[0]), cscale(s, n[1]), cscale(s, n[2])}; }
+__device__ __forceinline__ c3 ccross(c3 a, c3 b) {
+    return {csub(cmul(a.y, b.z), cmul(a.z, b.y)), csub(cmul(a.z, b.x), cmul(a.x, b.z)), csub(cmul(a.x, b.y), cmul(a.y, b.x))};
+}
+// symmetric-with-a-twist gradient matrix of helpers.py:239-277: [[g00,g01,g02],[g01,g11,g12],[g02,g01,g22]]
+struct g6 {
+    cplx g00, g01, g02, g11, g12, g22;
+};
+__device__ __forceinline__ c3 gmul(const g6 &G, c3 v) {
+    return {cadd(cadd(cmul(G.g00, v.x), cmul(G.g01, v.y)), cmul(G.g02, v.z)),
+            cadd(cadd(cmul(G.g01, v.x), cmul(G.g11, v.y)), cmul(G.g12, v.z)),
+            cadd(cadd(cmul(G.g02, v.x), cmul(G.g01, v.y)), cmul(G.g22, v.z))};
+}
+__device__ __forceinline__ g6 gconj(const g6 &G) { return {cconj(G.g00), cconj(G.g01), cconj(G.g02), cconj(G.g11), cconj(G.g12), cconj(G.g22)}; }
+__device__ __forceinline__ g6 gscale(const g6 &G, cplx s) { return {cmul(G.g00, s), cmul(G.g01, s), cmul(G.g02, s), cmul(G.g11, s), cmul(G.g12, s), cmul(G.g22, s)}; }
+// P v = a1 (p1.v) p1 + a2 (p2.v) p2
+__device__ __forceinline__ c3 proj2(const double *p1, const double *p2, double a1, double a2, c3 v) {
+    cplx s1 = cscale(rdot(p1, v), a1), s2 = cscale(rdot(p2, v), a2);
+    return c3add(rvec(p1, s1), rvec(p2, s2));
+}
+
+struct QtfArgs {
+    int nSet, nw;
+    const double *__restrict__ w, *__restrict__ k;
+    double depth, rho, g;
+    const int64_t *__restrict__ soff;      // [nSet+1]
+    const double *__restrict__ strips;     // [nStrip,QS_N]
+    const int64_t *__restrict__ moff;      // [nSet+1]
+    const double *__restrict__ members;    // [nMem,QM_N]
+    const int *__restrict__ sset;          // [nStrip] set of each strip
+    const int *__restrict__ mset;          // [nMem]   set of each member
+    const cplx *__restrict__ Xi;           // [nSet,6,nw]
+    const double *__restrict__ beta;       // [nSet]
+    const double *__restrict__ Ms;         // [nSet,36]
+    const cplx *__restrict__ kay;          // [nSet,nw,nw,6] or null
+    cplx *T;                               // [nStrip,QT_N,nw]
+    cplx *TM;                              // [nMem,QTM_N,nw]
+    cplx *TS;                              // [nSet,QTS_N,nw]
+    cplx *qtf;                             // [nSet,nw,nw,6]
+};
+
+// getWaveKin with zeta0 = 1 (helpers.py:188-236): u, and Cc for the pressure/elevation
+__device__ __forceinline__ void qtf_wavekin(double w, double k, double h, double beta, const double *r, c3 &u, cplx &zCc) {
+    double s, c;
+    sincos(-(k * (cos(beta) * r[0] + sin(beta) * r[1])), &s, &c);
+    const cplx zeta = {c, s};
+    const double z = r[2];
+    u = {{0, 0}, {0, 0}, {0, 0}};
+    zCc = {0, 0};
+    if (z <= 0) {
+        double Sh, Ch, Cc;
+        if (k == 0.0) {
+            Sh = 1.0; Ch = 99999.0; Cc = 99999.0;
+        } else if (k * h > 89.4) {
+            Sh = exp(k * z); Ch = Sh; Cc = exp(k * z) + exp(-k * (z + 2.0 * h));
+        } else {
+            Sh = sinh(k * (z + h)) / sinh(k * h);
+            Ch = cosh(k * (z + h)) / sinh(k * h);
+            Cc = cosh(k * (z + h)) / cosh(k * h);
+        }
+        u.x = cscale(zeta, w * Ch * cos(beta));
+        u.y = cscale(zeta, w * Ch * sin(beta));
+        u.z = cmuli(cscale(zeta, w * Sh));
+        zCc = cscale(zeta, Cc);
+    }
+}
+
+__device__ __forceinline__ c3 load3(const cplx *T, int f, int nw, int i) { return {T[(size_t)f * nw + i], T[(size_t)(f + 1) * nw + i], T[(size_t)(f + 2) * nw + i]}; }
+__device__ __forceinline__ void store3(cplx *T, int f, int nw, int i, c3 v) {
+    T[(size_t)f * nw + i] = v.x;
+    T[(size_t)(f + 1) * nw + i] = v.y;
+    T[(size_t)(f + 2) * nw + i] = v.z;
+}
+
+// ---- first-order tables: grid.x = nStrip + nMem + nSet, threads over frequency
+__global__ void __launch_bounds__(256) k_qtf_tables(QtfArgs A, int nStrip, int nMem) {
+    const int b = blockIdx.x, nw = A.nw;
+    for (int i = threadIdx.x; i < nw; i += blockDim.x) {
+        const double w = A.w[i], k = A.k[i], h = A.depth;
+        if (b < nStrip) {
+            const double *rec = A.strips + (size_t)b * QS_N;
+            const int set = A.sset[b];
+            const double beta = A.beta[set];
+            const double r[3] = {rec[0], rec[1], rec[2]}, q[3] = {rec[3], rec[4], rec[5]};
+            const cplx *X = A.Xi + (size_t)set * 6 * nw;
+            c3 xt = {X[0 * nw + i], X[1 * nw + i], X[2 * nw + i]}, th = {X[3 * nw + i], X[4 * nw + i], X[5 * nw + i]};
+            // dr = Xi_t + th x r (helpers.py:178, 396-402); nodeV = i w dr
+            c3 rr = {{r[0], 0}, {r[1], 0}, {r[2], 0}};
+            c3 dr = c3add(xt, ccross(th, rr));
+            c3 nodeV = c3cmul(dr, cplx{0.0, w});
+            c3 u;
+            cplx zc;
+            qtf_wavekin(w, k, h, beta, r, u, zc);
+            // grad_u1 (helpers.py:239-277)
+            g6 G = {{0, 0}, {0, 0}, {0, 0}, {0, 0}, {0, 0}, {0, 0}};
+            c3 gp = {{0, 0}, {0, 0}, {0, 0}};
+            cplx e2 = {1.0, 0.0};
+            const double cB = cos(beta * (M_PI / 180.0)), sB = sin(beta * (M_PI / 180.0));        // (sic) deg2rad of a radian heading
+            if (r[2] <= 0 && k > 0) {
+                double xy, zz, pxy, pzz;
+                if (k * h >= 10) {
+                    xy = zz = pxy = pzz = exp(k * r[2]);
+                } else {
+                    xy = cosh(k * (r[2] + h)) / sinh(k * h);
+                    zz = sinh(k * (r[2] + h)) / sinh(k * h);
+                    pxy = cosh(k * (r[2] + h)) / cosh(k * h);
+                    pzz = sinh(k * (r[2] + h)) / cosh(k * h);
+                }
+                double s, c;
+                sincos(-(k * (cos(beta) * r[0] + sin(beta) * r[1])), &s, &c);
+                const cplx ph = {c, s};
+                cplx aux = cscale(ph, w * cB);
+                G.g00 = cscale(cmuli(aux), -xy * k * cB);
+                G.g01 = cscale(cmuli(aux), -xy * k * sB);
+                G.g02 = cscale(aux, k * zz);
+                aux = cscale(ph, w * sB);
+                G.g11 = cscale(cmuli(aux), -xy * k * sB);
+                G.g12 = cscale(aux, k * zz);
+                aux = cmuli(cscale(ph, w));
+                G.g22 = cscale(aux, k * xy);
+                // grad_pres1st (helpers.py:283-308): deg2rad'ed heading also in the phase
+                sincos(-(k * (cB * r[0] + sB * r[1])), &s, &c);
+                const cplx ph2 = {c, s};
+                const double rg = A.rho * A.g;
+                gp.x = cscale(cmuli(ph2), -rg * pxy * k * cB);
+                gp.y = cscale(cmuli(ph2), -rg * pxy * k * sB);
+                gp.z = cscale(ph2, rg * pzz * k);
+            }
+            {
+                double s, c;
+                sincos(-(k * (cB * r[0] + sB * r[1])), &s, &c);                                   // helpers.py:343-361 phase factor
+                e2 = {c, s};
+            }
+            const cplx nar = rdot(q, c3sub(u, nodeV));
+            const c3 nodeVt = c3sub(nodeV, rvec(q, rdot(q, nodeV)));
+            const c3 ut = c3sub(u, rvec(q, rdot(q, u)));
+            const cplx dwdz = rdot(q, gmul(G, c3{{q[0], 0}, {q[1], 0}, {q[2], 0}}));
+            cplx *T = A.T + (size_t)b * QT_N * nw;
+            store3(T, QT_U, nw, i, u);
+            T[(size_t)(QT_G + 0) * nw + i] = G.g00; T[(size_t)(QT_G + 1) * nw + i] = G.g01; T[(size_t)(QT_G + 2) * nw + i] = G.g02;
+            T[(size_t)(QT_G + 3) * nw + i] = G.g11; T[(size_t)(QT_G + 4) * nw + i] = G.g12; T[(size_t)(QT_G + 5) * nw + i] = G.g22;
+            store3(T, QT_DR, nw, i, dr);
+            store3(T, QT_VT, nw, i, c3sub(u, nodeVt));
+            store3(T, QT_GP, nw, i, gp);
+            T[(size_t)QT_NAR * nw + i] = nar;
+            T[(size_t)QT_DWDZ * nw + i] = dwdz;
+            T[(size_t)QT_E2 * nw + i] = e2;
+            store3(T, QT_UT, nw, i, c3sub(ut, nodeVt));
+        } else if (b < nStrip + nMem) {
+            const int m = b - nStrip;
+            const double *rec = A.members + (size_t)m * QM_N;
+            const int set = A.mset[m];
+            cplx *T = A.TM + (size_t)m * QTM_N * nw;
+            if (rec[0] != 0.0) {
+                const double beta = A.beta[set];
+                const double r[3] = {rec[1], rec[2], rec[3]};
+                const double *p1 = rec + 7, *p2 = rec + 10;
+                const cplx *X = A.Xi + (size_t)set * 6 * nw;
+                c3 xt = {X[0 * nw + i], X[1 * nw + i], X[2 * nw + i]}, th = {X[3 * nw + i], X[4 * nw + i], X[5 * nw + i]};
+                c3 rr = {{r[0], 0}, {r[1], 0}, {r[2], 0}};
+                c3 dr = c3add(xt, ccross(th, rr));
+                c3 u;
+                cplx eta;
+                qtf_wavekin(w, k, h, beta, r, u, eta);                     // rho = g = 1: pDyn is the elevation (:1525)
+                c3 ud = c3cmul(u, cplx{0.0, w});
+                c3 ab = c3scale(dr, -w * w);
+                // g_e1 = -g ( (th x p1)_z p1 + (th x p2)_z p2 )   (:1531-1532)
+                cplx c1 = csub(cscale(th.x, p1[1]), cscale(th.y, p1[0])), c2 = csub(cscale(th.x, p2[1]), cscale(th.y, p2[0]));
+                c3 ge = c3scale(c3add(rvec(p1, c1), rvec(p2, c2)), -A.g);
+                store3(T, QTM_UD, nw, i, ud);
+                T[(size_t)QTM_ETAR * nw + i] = csub(eta, dr.z);
+                store3(T, QTM_AB, nw, i, ab);
+                store3(T, QTM_GE, nw, i, ge);
+            } else {
+                for (int f = 0; f < QTM_N; f++) T[(size_t)f * nw + i] = {0, 0};
+            }
+        } else {
+            const int set = b - nStrip - nMem;
+            const cplx *X = A.Xi + (size_t)set * 6 * nw;
+            cplx *T = A.TS + (size_t)set * QTS_N * nw;
+            const double *M = A.Ms + (size_t)set * 36;
+            for (int j = 0; j < 3; j++) T[(size_t)(QTS_TH + j) * nw + i] = X[(3 + j) * nw + i];
+            for (int r = 0; r < 6; r++) {                                  // F1st = M_struc (-w^2 Xi)  (raft_fowt.py:2045)
+                cplx a = {0, 0};
+                for (int c = 0; c < 6; c++) a = cadd(a, cscale(X[c * nw + i], -w * w * M[r * 6 + c]));
+                T[(size_t)(QTS_F1 + r) * nw + i] = a;
+            }
+        }
+    }
+}
+
+// ---- pair kernel: grid (nSet * nw) rows of w1; threads stride w2 >= w1
+__global__ void __launch_bounds__(128) k_qtf_pairs(QtfArgs A) {
+    const int nw = A.nw;
+    const int set = blockIdx.x / nw, i1 = blockIdx.x % nw;
+    const double h = A.depth, rho = A.rho, g = A.g;
+    const double w1 = A.w[i1], k1 = A.k[i1];
+    const double beta = A.beta[set];
+    const double cB = cos(beta * (M_PI / 180.0)), sB = sin(beta * (M_PI / 180.0));
+    const cplx *TS = A.TS + (size_t)set * QTS_N * nw;
+    const c3 th1 = load3(TS, QTS_TH, nw, i1);
+    const c3 Om1 = c3cmul(th1, cplx{0.0, w1});                             // i w1 theta1: OMEGA1 v = Om1 x v
+    for (int i2 = i1 + threadIdx.x; i2 < nw; i2 += blockDim.x) {
+        const double w2 = A.w[i2], k2 = A.k[i2];
+        const c3 th2 = load3(TS, QTS_TH, nw, i2);
+        const c3 Om2c = c3conj(c3cmul(th2, cplx{0.0, w2}));
+        cplx F[6] = {{0, 0}, {0, 0}, {0, 0}, {0, 0}, {0, 0}, {0, 0}};
+        // Pinkster IV (raft_fowt.py:2053-2062)
+        {
+            c3 fa1 = load3(TS, QTS_F1, nw, i1), fb1 = load3(TS, QTS_F1 + 3, nw, i1);
+            c3 fa2 = load3(TS, QTS_F1, nw, i2), fb2 = load3(TS, QTS_F1 + 3, nw, i2);
+            c3 t = c3scale(c3add(ccross(th1, c3conj(fa2)), ccross(c3conj(th2), fa1)), 0.25);
+            c3 m = c3scale(c3add(ccross(th1, c3conj(fb2)), ccross(c3conj(th2), fb1)), 0.25);
+            F[0] = t.x; F[1] = t.y; F[2] = t.z; F[3] = m.x; F[4] = m.y; F[5] = m.z;
+        }
+        // second-order potential coefficients of this pair (helpers.py:337-358)
+        const bool pot = (w1 != w2) && (k1 > 0) && (k2 > 0);
+        double nrm = 0.0, kx = 0.0, ky = 0.0;
+        cplx paux = {0, 0};
+        if (pot) {
+            kx = (k1 - k2) * cB;
+            ky = (k1 - k2) * sB;
+            nrm = sqrt(kx * kx + ky * ky);
+            const double t1 = tanh(k1 * h), t2 = tanh(k2 * h);
+            const double den = (w1 - w2) * (w1 - w2) / g - nrm * tanh(nrm * h);
+            // gamma = (-i g / (2 w)) * num / den  ->  purely imaginary
+            const double g12 = (-g / (2 * w1)) * ((k1 * k1) * (1 - t1 * t1) - 2 * k1 * k2 * (1 + t1 * t2)) / den;
+            const double g21 = (-g / (2 * w2)) * ((k2 * k2) * (1 - t2 * t2) - 2 * k2 * k1 * (1 + t2 * t1)) / den;
+            paux = {0.0, 0.5 * (g21 - g12)};                               // 0.5 (gamma_21 + conj(gamma_12))
+        }
+        for (int64_t s = A.soff[set]; s < A.soff[set + 1]; s++) {
+            const double *rec = A.strips + (size_t)s * QS_N;
+            const double r[3] = {rec[0], rec[1], rec[2]};
+            const double *q = rec + 3, *p1 = rec + 6, *p2 = rec + 9;
+            const double Ca1 = rec[12], Ca2 = rec[13], CaE = rec[14], v_i = rec[15], v_e = rec[16], a_i = rec[17];
+            const cplx *T = A.T + (size_t)s * QT_N * nw;
+            const c3 u1 = load3(T, QT_U, nw, i1), u2 = load3(T, QT_U, nw, i2);
+            const g6 G1 = {T[(size_t)(QT_G + 0) * nw + i1], T[(size_t)(QT_G + 1) * nw + i1], T[(size_t)(QT_G + 2) * nw + i1],
+                           T[(size_t)(QT_G + 3) * nw + i1], T[(size_t)(QT_G + 4) * nw + i1], T[(size_t)(QT_G + 5) * nw + i1]};
+            const g6 G2 = {T[(size_t)(QT_G + 0) * nw + i2], T[(size_t)(QT_G + 1) * nw + i2], T[(size_t)(QT_G + 2) * nw + i2],
+                           T[(size_t)(QT_G + 3) * nw + i2], T[(size_t)(QT_G + 4) * nw + i2], T[(size_t)(QT_G + 5) * nw + i2]};
+            const g6 G2c = gconj(G2);
+            const c3 dr1 = load3(T, QT_DR, nw, i1), dr2 = load3(T, QT_DR, nw, i2);
+            const c3 ua1 = load3(T, QT_VT, nw, i1), ua2 = load3(T, QT_VT, nw, i2);     // u - nodeV_t
+            const c3 gp1 = load3(T, QT_GP, nw, i1), gp2 = load3(T, QT_GP, nw, i2);
+            const cplx nar1 = T[(size_t)QT_NAR * nw + i1], nar2 = T[(size_t)QT_NAR * nw + i2];
+            const cplx dz1 = T[(size_t)QT_DWDZ * nw + i1], dz2 = T[(size_t)QT_DWDZ * nw + i2];
+            const c3 ut1 = load3(T, QT_UT, nw, i1), ut2 = load3(T, QT_UT, nw, i2);
+
+            // second-order potential: acceleration and pressure (helpers.py:360-372)
+            c3 acc2 = {{0, 0}, {0, 0}, {0, 0}};
+            cplx p2nd = {0, 0};
+            if (pot && r[2] <= 0) {
+                const double den = cosh(nrm * h);
+                const double xy = cosh(nrm * (r[2] + h)) / den, zz = sinh(nrm * (r[2] + h)) / den;
+                const cplx ph = cmul(T[(size_t)QT_E2 * nw + i1], cconj(T[(size_t)QT_E2 * nw + i2]));   // e^{-i (k1-k2)(cB x + sB y)}
+                const cplx base = cmul(paux, ph);
+                acc2.x = cscale(base, xy * (w1 - w2) * kx);
+                acc2.y = cscale(base, xy * (w1 - w2) * ky);
+                acc2.z = cmuli(cscale(base, zz * (w1 - w2) * nrm));
+                p2nd = cscale(cmuli(base), -xy * rho * (w1 - w2));
+            }
+            // convective acceleration (:1575) and the body-motion-in-the-wave-field term (:1582)
+            const c3 conv = c3scale(c3add(gmul(G1, c3conj(u2)), gmul(G2c, u1)), 0.25);
+            const g6 Gd1 = gscale(G1, cplx{0.0, w1}), Gd2c = gconj(gscale(G2, cplx{0.0, w2}));
+            const c3 nab = c3scale(c3add(gmul(Gd1, c3conj(dr2)), gmul(Gd2c, dr1)), 0.25);
+            // axial-divergence acceleration (helpers.py:311-335)
+            c3 ax = c3scale(c3add(c3cmul(c3conj(ut2), dz1), c3cmul(ut1, cconj(dz2))), 0.25);
+            ax = c3sub(ax, rvec(q, rdot(q, ax)));
+            // Rainey body-rotation terms (:1587-1609)
+            const c3 qn2c = rvec(q, cconj(nar2)), qn1 = rvec(q, nar1);
+            const c3 rs = c3add(ccross(Om1, qn2c), ccross(Om2c, qn1));
+            c3 f_rslb = c3scale(proj2(p1, p2, Ca1, Ca2, rs), -0.5);
+            const c3 Pu1 = proj2(p1, p2, Ca1, Ca2, ua1), Pu2c = c3conj(proj2(p1, p2, Ca1, Ca2, ua2));
+            c3 aux = c3add(c3add(gmul(G1, Pu2c), ccross(Om1, Pu2c)), c3add(gmul(G2c, Pu1), ccross(Om2c, Pu1)));
+            aux = c3scale(aux, 0.25);
+            aux = c3sub(aux, rvec(q, rdot(q, aux)));
+            f_rslb = c3add(f_rslb, aux);
+            const c3 u1t = c3sub(ua1, rvec(q, rdot(q, ua1))), u2t = c3sub(ua2, rvec(q, rdot(q, ua2)));
+            const c3 u2tc = c3conj(u2t);
+            c3 aux2 = c3add(c3add(gmul(G1, u2tc), ccross(Om1, u2tc)), c3add(gmul(G2c, u1t), ccross(Om2c, u1t)));
+            aux2 = c3scale(proj2(p1, p2, Ca1, Ca2, aux2), 0.25);
+            f_rslb = c3sub(f_rslb, aux2);
+            // assemble the strip force
+            c3 f = c3scale(proj2(p1, p2, 1.0 + Ca1, 1.0 + Ca2, c3add(c3add(acc2, conv), nab)), rho * v_i);
+            f = c3add(f, c3scale(proj2(p1, p2, Ca1, Ca2, ax), rho * v_i));
+            f = c3add(f, c3scale(f_rslb, rho * v_i));
+            // end effects (:1611-1627)
+            const cplx qsum = rdot(q, c3add(c3add(acc2, conv), nab));
+            cplx qs = cscale(qsum, rho * v_e * CaE);
+            const cplx p_nab = cscale(cadd(cdot(gp1, c3conj(dr2)), cdot(c3conj(gp2), dr1)), 0.25);
+            const c3 pp1 = proj2(p1, p2, 1.0, 1.0, ua1);
+            const cplx p_drop = cscale(cdot(pp1, Pu2c), -0.25 * rho);
+            qs = cadd(qs, cscale(cadd(cadd(p2nd, p_nab), p_drop), a_i));
+            f = c3add(f, rvec(q, qs));
+            const c3 Pu1t = proj2(p1, p2, Ca1, Ca2, u1t), Pu2t = proj2(p1, p2, Ca1, Ca2, u2t);
+            f = c3add(f, c3scale(c3add(c3cmul(c3conj(Pu1t), nar2), c3cmul(Pu2t, cconj(nar1))), 0.25 * a_i * rho));
+            // translateForce3to6DOF about the global origin (helpers.py:468-483)
+            F[0] = cadd(F[0], f.x); F[1] = cadd(F[1], f.y); F[2] = cadd(F[2], f.z);
+            F[3] = cadd(F[3], csub(cscale(f.z, r[1]), cscale(f.y, r[2])));
+            F[4] = cadd(F[4], csub(cscale(f.x, r[2]), cscale(f.z, r[0])));
+            F[5] = cadd(F[5], csub(cscale(f.y, r[0]), cscale(f.x, r[1])));
+        }
+        // waterline term (:1635-1668)
+        for (int64_t m = A.moff[set]; m < A.moff[set + 1]; m++) {
+            const double *rec = A.members + (size_t)m * QM_N;
+            if (rec[0] == 0.0) continue;
+            const double r[3] = {rec[1], rec[2], rec[3]};
+            const double a_wl = rec[4], Ca1 = rec[5], Ca2 = rec[6];
+            const double *p1 = rec + 7, *p2 = rec + 10;
+            const cplx *T = A.TM + (size_t)m * QTM_N * nw;
+            const c3 ud1 = load3(T, QTM_UD, nw, i1), ud2c = c3conj(load3(T, QTM_UD, nw, i2));
+            const cplx e1 = T[(size_t)QTM_ETAR * nw + i1], e2c = cconj(T[(size_t)QTM_ETAR * nw + i2]);
+            const c3 ab1 = load3(T, QTM_AB, nw, i1), ab2c = c3conj(load3(T, QTM_AB, nw, i2));
+            const c3 ge1 = load3(T, QTM_GE, nw, i1), ge2c = c3conj(load3(T, QTM_GE, nw, i2));
+            c3 f = proj2(p1, p2, 1.0 + Ca1, 1.0 + Ca2, c3scale(c3add(c3cmul(ud1, e2c), c3cmul(ud2c, e1)), 0.25));
+            f = c3sub(f, proj2(p1, p2, Ca1, Ca2, c3scale(c3add(c3cmul(ab1, e2c), c3cmul(ab2c, e1)), 0.25)));
+            f = c3sub(f, c3scale(c3add(c3cmul(ge1, e2c), c3cmul(ge2c, e1)), 0.25));
+            f = c3scale(f, rho * a_wl);
+            F[0] = cadd(F[0], f.x); F[1] = cadd(F[1], f.y); F[2] = cadd(F[2], f.z);
+            F[3] = cadd(F[3], csub(cscale(f.z, r[1]), cscale(f.y, r[2])));
+            F[4] = cadd(F[4], csub(cscale(f.x, r[2]), cscale(f.z, r[0])));
+            F[5] = cadd(F[5], csub(cscale(f.y, r[0]), cscale(f.x, r[1])));
+        }
+        // Kim & Yue table, then Hermitian completion (raft_fowt.py:2069-2070)
+        cplx *out = A.qtf + (size_t)set * nw * nw * 6;
+        for (int j = 0; j < 6; j++) {
+            cplx v = F[j];
+            if (A.kay) v = cadd(v, A.kay[(((size_t)set * nw + i1) * nw + i2) * 6 + j]);
+            out[((size_t)i1 * nw + i2) * 6 + j] = v;
+            if (i2 != i1) out[((size_t)i2 * nw + i1) * 6 + j] = cconj(v);
+        }
+    }
+}
