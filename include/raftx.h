@@ -148,6 +148,15 @@ int raftx_fetch_results(raftx_ctx *ctx, raftx_c128 *Xi, int32_t *niter, int32_t 
  * psd [nDesign,nCase,6,nw]; dw = w[1]-w[0] (raft_fowt.py:169). */
 int raftx_motion_stats(raftx_ctx *ctx, double dw, double *std, double *psd);
 
+/* Restart / export of the fixed point's linearisation point, for the re-entry of raft_model.py:1108-1131
+ * (internal QTFs: converge once, add the second-order force, iterate again FROM THE SAME Xi_last).
+ * XiLast0 [nDesign,nCase,6,nw] (or NULL): the next raftx_solve_dynamics[_device] call starts from it
+ * instead of XiStart (one-shot).  keep_last != 0: solve calls also keep the linearisation point of their
+ * last iteration (the Xi_last the reference holds when its loop exits), readable with
+ * raftx_fetch_linearisation_point (XiLast [nDesign,nCase,6,nw]). */
+int raftx_set_linearisation_point(raftx_ctx *ctx, const raftx_c128 *XiLast0, int keep_last);
+int raftx_fetch_linearisation_point(raftx_ctx *ctx, raftx_c128 *XiLast);
+
 /* Coupled array solve, raft_model.py:1164-1236: for each system s and bin w
  *   Z_sys = blockdiag_i(Zblk[s,i]) + (-w^2 Mc[s] + i w Bc[s] + Cc[s]);
  *   Xi[s,r] = Z_sys^-1 F[s,r].

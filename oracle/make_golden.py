@@ -271,7 +271,29 @@ def fixture_qtf():
         standin.save_fixture(os.path.join(GOLD, "refgold_qtf_%s.npz" % name), fx)
 
 
-ALL = {"qtf": fixture_qtf, "c1": fixture_c1, "c2": fixture_c2, "pose": fixture_pose,
+def fixture_c5():
+    """C5-style: solveDynamics with INTERNAL slender-body QTFs (potSecOrder == 1): converge, compute the QTFs from the
+    converged motions, add the second-order force, iterate again (raft_model.py:1108-1131).  VolturnUS-S test deck
+    (23-point second-order grid) with the mooring replaced by the fixed C_moor, one and two wave headings."""
+    d = rh.load_design(os.path.join(REF, "tests/test_data", "VolturnUS-S.yaml"))
+    d = rh.prepare_design(d, settings=dict(nIter=10))
+    m = rh.build_model(d)
+    assert m.fowtList[0].potSecOrder == 1
+    cases = [rh.make_case(Hs=6.0, Tp=12.0, heading=30.0), rh.make_case(Hs=4.0, Tp=9.0, heading=0.0)]
+    runs = []
+    for c in cases:
+        r = run_case(m, c)
+        f = m.fowtList[0]
+        r["units"][0]["Fhydro_2nd"] = np.array(f.Fhydro_2nd)
+        r["units"][0]["Fhydro_2nd_mean"] = np.array(f.Fhydro_2nd_mean)
+        r["units"][0]["qtf"] = np.array(f.qtf[:, :, 0, :])
+        runs.append(r)
+    fx = {"config": "C5-style VolturnUS-S internal QTF (potSecOrder=1) solveDynamics", "model": standin.snapshot_model(m),
+          "cases": runs}
+    standin.save_fixture(os.path.join(GOLD, "c5_internal_qtf.npz"), fx)
+
+
+ALL = {"c5": fixture_c5, "qtf": fixture_qtf, "c1": fixture_c1, "c2": fixture_c2, "pose": fixture_pose,
        "refgold": fixture_ref_goldens, "c4": fixture_c4, "c3": fixture_c3}
 
 if __name__ == "__main__":

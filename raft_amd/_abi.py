@@ -24,7 +24,7 @@ EXPORTS = (
     "raftx_last_error", "raftx_upload_designs", "raftx_upload_cases",
     "raftx_excitation", "raftx_linearize", "raftx_solve_dynamics",
     "raftx_solve_system", "raftx_last_kernel_ms",
-    "raftx_solve_dynamics_device", "raftx_fetch_results", "raftx_debug_math", "raftx_motion_stats", "raftx_solve_system_resident", "raftx_qtf_slender",
+    "raftx_solve_dynamics_device", "raftx_fetch_results", "raftx_debug_math", "raftx_motion_stats", "raftx_solve_system_resident", "raftx_qtf_slender", "raftx_set_linearisation_point", "raftx_fetch_linearisation_point",
 )
 WANT_BDRAG, WANT_FWAVE, WANT_Z = 1, 2, 4
 
@@ -94,6 +94,10 @@ class RaftxLib:
         L.raftx_qtf_slender.argtypes = [_vp, C.c_int, C.c_int, _vp, _vp, C.c_double, C.c_double, C.c_double,
                                         _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]
         L.raftx_qtf_slender.restype = C.c_int
+        L.raftx_set_linearisation_point.argtypes = [_vp, _vp, C.c_int]
+        L.raftx_set_linearisation_point.restype = C.c_int
+        L.raftx_fetch_linearisation_point.argtypes = [_vp, _vp]
+        L.raftx_fetch_linearisation_point.restype = C.c_int
         L.raftx_motion_stats.argtypes = [_vp, C.c_double, _vp, _vp]
         L.raftx_motion_stats.restype = C.c_int
         L.raftx_debug_math.argtypes = [_vp, C.c_int, _vp, _vp, _vp, _vp]
@@ -286,6 +290,19 @@ class Context:
                                              _ptr(Mstruc), _ptr(kay), _ptr(qtf))
         self._check(rc, "raftx_qtf_slender")
         return qtf
+
+    def set_linearisation_point(self, XiLast0=None, keep_last=True):
+        """Next solve starts from XiLast0 [nDesign,nCase,6,nw] (one-shot); keep_last: solves export their last
+        linearisation point (fetch_linearisation_point)."""
+        if XiLast0 is not None:
+            XiLast0 = _c128(XiLast0, (self.nDesign, self.nCase, 6, self.nw), "XiLast0")
+        rc = self.rlib.lib.raftx_set_linearisation_point(self._h, _ptr(XiLast0), 1 if keep_last else 0)
+        self._check(rc, "raftx_set_linearisation_point")
+
+    def fetch_linearisation_point(self):
+        X = np.empty((self.nDesign, self.nCase, 6, self.nw), dtype=np.complex128)
+        self._check(self.rlib.lib.raftx_fetch_linearisation_point(self._h, _ptr(X)), "raftx_fetch_linearisation_point")
+        return X
 
     def motion_stats(self, dw, want_psd=False):
         """std [nDesign,nCase,6] (rotations in deg) and optionally PSD [nDesign,nCase,6,nw] of the resident results."""

@@ -175,6 +175,9 @@ struct raftx_ctx {
     cplx *rXi, *rFw, *rZ, *rFe;
     double *rB, *rXl;
     size_t rXl_n;
+    cplx *rXl0, *rXlOut;                 // optional restart point / exported linearisation point [npair,6,nw]
+    size_t rXlio_n;
+    bool have_xl0, want_xlout;
     int *rNi, *rFl;
     size_t r_npair, r_nx, r_nz;
     int r_mask;
@@ -224,6 +227,9 @@ extern "C" int raftx_ctx_create(int device_id, raftx_ctx **out) {
     c->rXi = c->rFw = c->rZ = c->rFe = nullptr;
     c->rB = c->rXl = nullptr;
     c->rXl_n = 0;
+    c->rXl0 = c->rXlOut = nullptr;
+    c->rXlio_n = 0;
+    c->have_xl0 = c->want_xlout = false;
     c->rNi = c->rFl = nullptr;
     c->r_npair = c->r_nx = c->r_nz = 0;
     c->r_mask = 0;
@@ -251,6 +257,8 @@ extern "C" void raftx_ctx_destroy(raftx_ctx *c) {
     free_list(c->case_allocs);
     free_list(c->result_allocs);
     if (c->rXl) (void)hipFree(c->rXl);
+    if (c->rXl0) (void)hipFree(c->rXl0);
+    if (c->rXlOut) (void)hipFree(c->rXlOut);
     (void)hipEventDestroy(c->ev0);
     (void)hipEventDestroy(c->ev1);
     (void)hipStreamDestroy(c->stream);
@@ -656,7 +664,7 @@ extern "C" int raftx_solve_dynamics_device(raftx_ctx *c, int nIter, double tol, 
 #endif
     if (F_extra && c->r_nx) H2D(c, c->rFe, F_extra, c->r_nx * sizeof(cplx));
     // the lean specialisation (no optional inputs / outputs) is the sweep path
-    const int need = (T.MBw ? KF_FDEP : 0) | (A.Z ? KF_OUTZ : 0) | (A.F_wave ? KF_OUTF : 0) | (A.F_extra ? KF_EXTRA : 0) |
+    int need = (T.MBw ? KF_FDEP : 0) | (A.Z ? KF_OUTZ : 0) | (A.F_wave ? KF_OUTF : 0) | (A.F_extra ? KF_EXTRA : 0) |
                      (T.cm ? KF_MCF : 0) | (T.nHead > 1 ? KF_MULTI : 0);
     const Shape sh = pick_shape(T.nw);
     const bool xlg = sh.threads == 512 && sh.nb >= 3;        // XiLast in a global scratch slab (raftx_kernels.h XlStore)
@@ -671,6 +679,29 @@ extern "C" int raftx_solve_dynamics_device(raftx_ctx *c, int nIter, double tol, 
         c->rXl = reinterpret_cast<double *>(p_);
     }
     A.Xl = c->rXl;
+    // restart / export of the linearisation point (the re-entry of raft_model.py:1108-1131)
+    const size_t nxl = c->r_npair * 6 * (size_t)T.nw;
+    A.Xl0 = nullptr;
+    A.XlOut = nullptr;
+    if (c->have_xl0 || c->want_xlout) {
+        if (c->rXlio_n != nxl || !c->rXlOut) {
+            if (c->have_xl0) FAIL(c, "solve_dynamics: the linearisation point was set for a different batch shape");
+            HIPCHK(c, hipStreamSynchronize(c->stream));
+            if (c->rXl0) (void)hipFree(c->rXl0);
+            if (c->rXlOut) (void)hipFree(c->rXlOut);
+            c->rXl0 = c->rXlOut = nullptr;
+            void *p0 = nullptr, *p1 = nullptr;
+            HIPCHK(c, hipMalloc(&p0, (nxl ? nxl : 1) * sizeof(cplx)));
+            HIPCHK(c, hipMalloc(&p1, (nxl ? nxl : 1) * sizeof(cplx)));
+            c->rXl0 = reinterpret_cast<cplx *>(p0);
+            c->rXlOut = reinterpret_cast<cplx *>(p1);
+            c->rXlio_n = nxl;
+        }
+        if (c->have_xl0) A.Xl0 = c->rXl0;
+        A.XlOut = c->rXlOut;
+        need |= KF_XLIO;
+        c->have_xl0 = false;                  // one-shot
+    }
 #define LAUNCH_SOLVE(NB_, MT_, MB_, FL)                                                                              \
     do {                                                                                                             \
         if (prep_lds(c, k_solve_dynamics<NB_, FL, MT_, MB_>, lds)) return -1;                                        \
@@ -689,6 +720,43 @@ extern "C" int raftx_solve_dynamics_device(raftx_ctx *c, int nIter, double tol, 
 #undef DISPATCH_ONE_
 #undef LAUNCH_SOLVE
     return finish_timed(c);
+}
+
+extern "C" int raftx_set_linearisation_point(raftx_ctx *c, const raftx_c128 *XiLast0, int keep_last) {
+    if (!c) return -1;
+    if (check_ready(c)) return -1;
+    HIPCHK(c, hipSetDevice(c->device));
+    c->want_xlout = keep_last != 0;
+    c->have_xl0 = false;
+    if (XiLast0) {
+        const DevTables &T = c->T;
+        const size_t nxl = (size_t)T.nDesign * T.nCase * 6 * T.nw;
+        if (c->rXlio_n != nxl || !c->rXl0) {
+            HIPCHK(c, hipStreamSynchronize(c->stream));
+            if (c->rXl0) (void)hipFree(c->rXl0);
+            if (c->rXlOut) (void)hipFree(c->rXlOut);
+            c->rXl0 = c->rXlOut = nullptr;
+            void *p0 = nullptr, *p1 = nullptr;
+            HIPCHK(c, hipMalloc(&p0, (nxl ? nxl : 1) * sizeof(cplx)));
+            HIPCHK(c, hipMalloc(&p1, (nxl ? nxl : 1) * sizeof(cplx)));
+            c->rXl0 = reinterpret_cast<cplx *>(p0);
+            c->rXlOut = reinterpret_cast<cplx *>(p1);
+            c->rXlio_n = nxl;
+        }
+        if (nxl) H2D(c, c->rXl0, XiLast0, nxl * sizeof(cplx));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        c->have_xl0 = true;
+    }
+    return 0;
+}
+
+extern "C" int raftx_fetch_linearisation_point(raftx_ctx *c, raftx_c128 *XiLast) {
+    if (!c) return -1;
+    if (!c->rXlOut || !XiLast) FAIL(c, "fetch_linearisation_point: nothing kept (call raftx_set_linearisation_point(ctx, ., 1) first)");
+    HIPCHK(c, hipSetDevice(c->device));
+    if (c->rXlio_n) D2H(c, XiLast, c->rXlOut, c->rXlio_n * sizeof(cplx));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return 0;
 }
 
 extern "C" int raftx_fetch_results(raftx_ctx *c, raftx_c128 *Xi, int32_t *niter, int32_t *flags, double *B_drag,

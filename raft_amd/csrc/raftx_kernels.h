@@ -874,7 +874,8 @@ __device__ __forceinline__ void solve6(Lu6 &A, cplx x[6]) {
 #define KF_EXTRA 8   // F_extra input
 #define KF_MCF 16    // MacCamy-Fuchs complex Cm table
 #define KF_MULTI 32  // more than one wave heading
-#define KF_ALL 63
+#define KF_XLIO 64   // linearisation point given (restart) / exported (raft_model.py:1108-1131 re-entry)
+#define KF_ALL 127
 
 // Assemble and solve one bin's 6x6 system: x <- Z^-1 x  (raft_model.py:1086-1089)
 template <int FLAGS>
@@ -1059,6 +1060,8 @@ struct SolveArgs {
     cplx *__restrict__ F_wave;           // [pair,nHead,6,nw] or null
     cplx *__restrict__ Z;                // [pair,36,nw] or null
     double *Xl;                          // [pair,12,nw] XiLast scratch (shapes with more than 1024 bins only)
+    const cplx *__restrict__ Xl0;        // [pair,6,nw] or null: initial linearisation point instead of XiStart
+    cplx *__restrict__ XlOut;            // [pair,6,nw] or null: linearisation point of the LAST iteration
     unsigned long long *dbg;             // RAFTX_PHASE_TIMING builds: [8] accumulated wave-0 cycles per phase
 };
 
@@ -1073,6 +1076,7 @@ __global__ void __launch_bounds__(MAXT, MINB) k_solve_dynamics(DevTables T, Solv
     extern __shared__ __attribute__((aligned(16))) double smem[];
     constexpr bool FDEP = (FLAGS & KF_FDEP) != 0, OUTZ = (FLAGS & KF_OUTZ) != 0, OUTF = (FLAGS & KF_OUTF) != 0;
     constexpr bool EXTRA = (FLAGS & KF_EXTRA) != 0, MCF = (FLAGS & KF_MCF) != 0, MULTI = (FLAGS & KF_MULTI) != 0;
+    constexpr bool XLIO = (FLAGS & KF_XLIO) != 0;
     PairCtx p;
     if (!pair_ctx(T, p, pair_of_block(blockIdx.x, T.nDesign * T.nCase))) return;
     PT_DECL;
@@ -1125,8 +1129,12 @@ __global__ void __launch_bounds__(MAXT, MINB) k_solve_dynamics(DevTables T, Solv
         if (b.act[j]) {
 #pragma unroll
             for (int q = 0; q < 6; q++) {
-                xl.put(2 * q, b.iw[j], A.XiStart);
-                xl.put(2 * q + 1, b.iw[j], 0.0);
+                cplx x0 = {A.XiStart, 0.0};
+                if constexpr (XLIO) {
+                    if (A.Xl0) x0 = A.Xl0[((size_t)pair * 6 + q) * nw + b.iw[j]];
+                }
+                xl.put(2 * q, b.iw[j], x0.re);
+                xl.put(2 * q + 1, b.iw[j], x0.im);
             }
         }
     const double *Mw = (FDEP && T.MBw) ? T.MBw + ((size_t)p.d * 2 + 0) * 36 * nw : nullptr;
@@ -1193,6 +1201,9 @@ __global__ void __launch_bounds__(MAXT, MINB) k_solve_dynamics(DevTables T, Solv
 #pragma unroll
                 for (int q = 0; q < 6; q++) {
                     const double lr = xl.get(2 * q, iw), li = xl.get(2 * q + 1, iw);
+                    if constexpr (XLIO) {
+                        if (A.XlOut) A.XlOut[((size_t)pair * 6 + q) * nw + iw] = cplx{lr, li};
+                    }
                     if (isnan(x[j][q].re) || isnan(x[j][q].im)) bad = 1;
                     const double dr = x[j][q].re - lr, di = x[j][q].im - li;
                     const double tc = sqrt(dr * dr + di * di) / (sqrt(x[j][q].re * x[j][q].re + x[j][q].im * x[j][q].im) + A.tol);

@@ -11,9 +11,13 @@ of include/raftx.h.  ``install()`` monkey-patches a loaded ``raft`` package;
 the functions also work on any duck-typed stand-ins exposing the attributes
 read here (that is how the GPU-box tests run without /root/reference).
 
+    raft/raft_fowt.py:1988    FOWT.calcQTF_slenderBody(waveHeadInd, Xi0=None, verbose=False, iCase=None, iWT=None)
+    raft/raft_fowt.py:2158    FOWT.calcHydroForce_2ndOrd(beta, S0, iCase=None, iWT=None, interpMode='qtf')
+are mirrored too (internal slender-body QTFs, potSecOrder == 1, incl. the re-entry of the drag iteration with the
+second-order force, raft_model.py:1108-1131).
+
 Not covered by the device path (raises, never falls back silently):
-flexible / >6-DOF FOWTs, moorMod==2 per-iteration mooring damping,
-potSecOrder==1 (internal slender-body QTF re-entry), submerged rotors.
+flexible / >6-DOF FOWTs, moorMod==2 per-iteration mooring damping, submerged rotors.
 Per-member intermediates (mem.u, mem.ud, mem.pDyn, mem.Bmat, mem.F_exc_drag)
 are consumed only inside the replaced methods and are not materialised.
 """
@@ -27,8 +31,11 @@ from . import backend
 class Engine:
     """Binds the host mirror to one raftx context (default: the HIP library)."""
 
-    def __init__(self, ctx=None):
+    def __init__(self, ctx=None, qtf_backend=None):
         self._ctx = ctx
+        # qtf_backend(tables, Xi, beta, w2, k2, depth, rho, g, Mstruc, kay) -> qtf [nSet,nw2,nw2,6]; default: the
+        # device kernels through the C-ABI (tests inject the numpy oracle to exercise the host logic on CPU)
+        self._qtf_backend = qtf_backend
 
     @property
     def ctx(self):
@@ -145,6 +152,62 @@ class Engine:
         fowt.F_hydro_drag = fowt._raftx_Fdrag[ih].copy()
         return fowt.F_hydro_drag
 
+    # ------------------------------------------------------------------ second-order loads
+    def calcQTF_slenderBody(self, fowt, waveHeadInd, Xi0=None, verbose=False, iCase=None, iWT=None):
+        """raft_fowt.py:1988-2078: fowt.qtf [nw2,nw2,1,nDOF] for heading fowt.beta[waveHeadInd]."""
+        import os
+        from . import qtf as rq
+        w2, k2 = np.asarray(fowt.w1_2nd, dtype=float), np.asarray(fowt.k1_2nd, dtype=float)
+        if Xi0 is None:
+            Xi0 = np.zeros([fowt.nDOF, len(fowt.w)], dtype=complex)
+        beta = float(fowt.beta[waveHeadInd])
+        fowt.heads_2nd = [beta]
+        fowt.qtf = np.zeros([len(w2), len(w2), 1, fowt.nDOF], dtype=complex)
+        if fowt.nDOF > 6:
+            print("Function calcQTF_slenderBody() is not implemented for flexible/multibody FOWTs yet. "
+                  "Considering null qtf matrices for now.")
+            return
+        Xi = np.zeros([6, len(w2)], dtype=complex)
+        for iDoF in range(6):
+            Xi[iDoF, :] = np.interp(w2, fowt.w, Xi0[iDoF, :], left=0, right=0)          # :2022-2024
+        whead = f"{np.degrees(beta) % 360:.2f}".replace('.', 'p')
+        out_dir = getattr(fowt, "outFolderQTF", None)
+        tag = f"_Case{iCase + 1}_WT{iWT}" if isinstance(iCase, int) and isinstance(iWT, int) else ""
+        if out_dir is not None and verbose:
+            rq.write_rao4(os.path.join(out_dir, f"raos-slender_body_Head{whead}{tag}.4"), w2, beta, Xi)
+        tab = rq.pack_qtf(fowt)
+        kay = rq.kay_correction(tab.kay_geom, w2, k2, beta, fowt.depth, rho=fowt.rho_water, g=fowt.g)
+        backend_fn = self._qtf_backend or (lambda *a: self.ctx.qtf_slender(*a))
+        q = backend_fn([tab], Xi[None], np.array([beta]), w2, k2, fowt.depth, fowt.rho_water, fowt.g,
+                       np.asarray(fowt.M_struc, dtype=float)[None], kay[None])[0]
+        fowt.qtf[:, :, 0, :] = q          # NB: like the reference, slot 0 is written whatever waveHeadInd is asked (:2014)
+        if out_dir is not None and verbose:
+            rq.write_qtf12d(os.path.join(out_dir, f"qtf-slender_body-total_Head{whead}{tag}.12d"), fowt.qtf, w2,
+                            fowt.heads_2nd, fowt.rho_water, fowt.g)
+
+    def calcHydroForce_2ndOrd(self, fowt, beta, S0, iCase=None, iWT=None, interpMode='qtf'):
+        """raft_fowt.py:2158-2253 (host: interpolation + reductions over the QTF diagonals)."""
+        import os
+        from . import qtf as rq
+        heads = list(fowt.heads_2nd)
+        if beta < heads[0]:
+            print(f"Warning in calcHydroForce_2ndOrd: angle {beta} is less than the minimum incidence angle in the QTF. "
+                  f"An incidence of {heads[0]} will be considered for 2nd order loads.")
+        if beta > heads[-1]:
+            print(f"Warning in calcHydroForce_2ndOrd: angle {beta} is more than the maximum incidence angle in the QTF. "
+                  f"An incidence of {heads[-1]} will be considered for 2nd order loads.")
+        q = rq.interp_heading(fowt.qtf, heads, beta)
+        if interpMode == 'spectrum':
+            f_mean, f = rq.hydro_force_2nd_spectrum(q, np.asarray(fowt.w1_2nd), fowt.w, fowt.dw, S0)
+        else:
+            f_mean, f = rq.hydro_force_2nd(q, np.asarray(fowt.w1_2nd), fowt.w, fowt.dw, S0)
+        out_dir = getattr(fowt, "outFolderQTF", None)
+        if out_dir is not None:
+            with open(os.path.join(out_dir, f'f_2nd-_Case{ iCase+1 }_WT{ iWT }.txt'), 'w') as file:
+                for w, frow in zip(fowt.w, f.T):
+                    file.write(f'{w:.5f} {frow[0]:.5f} {frow[1]:.5f} {frow[2]:.5f} {frow[3]:.5f} {frow[4]:.5f} {frow[5]:.5f}\n')
+        return f_mean, f
+
     # ------------------------------------------------------------------
     def solveDynamics(self, model, case, tol=0.01, conv_plot=0, RAO_plot=0, display=0):
         """raft_model.py:966-1302."""
@@ -157,9 +220,6 @@ class Engine:
             self._check_supported(fowt)
             if getattr(fowt, "ms", None) and getattr(fowt, "moorMod", 0) == 2:
                 raise UnsupportedFOWT("moorMod==2 (raft_model.py:1023-1030,1069-1072) is not on the device path")
-            if getattr(fowt, "potSecOrder", 0) == 1:
-                raise UnsupportedFOWT("potSecOrder==1 (internal QTF re-entry, raft_model.py:1108-1131) "
-                                      "is not on the device path yet")
             # sea state + excitation inputs (raft_model.py:1002)
             self._sea_state(fowt, case)
             fowt.F_BEM, fowt.F_BEM_fullDOF = self._F_BEM(fowt, case)
@@ -197,9 +257,41 @@ class Engine:
         ctx = self.ctx
         F_extra = np.array(F_extras)[:, None]                               # [nF,1,nH,6,nw]
         F_iner = ctx.excitation()                                            # side effect of :1002
+        internal_qtf = [getattr(f, "potSecOrder", 0) == 1 for f in fowts]
+        if any(internal_qtf):
+            ctx.set_linearisation_point(None, keep_last=True)
         out = ctx.solve_dynamics(int(model.nIter), tol=tol, XiStart=model.XiStart,
                                  F_extra=F_extra if np.any(F_extra) else None,
                                  want_Xi=True, want_B=True, want_F=True, want_Z=True)
+        if any(internal_qtf) and not np.any(out['flags'] & 2):
+            # raft_model.py:1108-1131: units that converged get their QTFs from the converged first-order motions,
+            # the second-order force joins F_lin and the drag iteration continues FROM THE SAME Xi_last with the
+            # iteration counter reset to 1.  Units without internal QTFs (or unconverged) simply keep their state:
+            # restarting them from their own last linearisation point reproduces their converged solve.
+            XiLast = ctx.fetch_linearisation_point()
+            rerun = False
+            for i, fowt in enumerate(fowts):
+                if internal_qtf[i] and (out['flags'][i, 0] & 1):
+                    if display > 1:
+                        print("Resolving for system response in primary wave direction, now with second-order wave loads.")
+                    Xi0 = waves.get_rao(out['Xi'][i, 0, 0], fowt.zeta[0, :])
+                    self.calcQTF_slenderBody(fowt, waveHeadInd=0, Xi0=Xi0, verbose=True, iCase=iCase, iWT=i)
+                    fowt.Fhydro_2nd_mean[0, :], fowt.Fhydro_2nd[0, :, :] = \
+                        self.calcHydroForce_2ndOrd(fowt, fowt.beta[0], fowt.S[0, :], iCase=iCase, iWT=i)
+                    for ih in range(1, fowt.nWaves):                                       # :1210-1211
+                        fowt.Fhydro_2nd_mean[ih, :], fowt.Fhydro_2nd[ih, :, :] = \
+                            self.calcHydroForce_2ndOrd(fowt, fowt.beta[ih], fowt.S[ih, :])
+                    F_extras[i] = fowt.F_BEM + fowt.Fhydro_2nd
+                    rerun = True
+            if rerun:
+                if any(not (internal_qtf[i] and (out['flags'][i, 0] & 1)) for i in range(nF)):
+                    raise UnsupportedFOWT("mixed arrays (units with and without converged internal QTFs) are not on the device path")
+                F_extra = np.array(F_extras)[:, None]
+                ctx.set_linearisation_point(XiLast, keep_last=False)
+                niter1 = out['niter'].copy()
+                out = ctx.solve_dynamics(max(int(model.nIter) - 1, 0), tol=tol, XiStart=model.XiStart, F_extra=F_extra,
+                                         want_Xi=True, want_B=True, want_F=True, want_Z=True)
+                out['niter'] = out['niter'] + niter1
         if np.any(out['flags'] & 2):
             raise Exception("Nan detected in response vector Xi.")          # :1098-1099
         nH = f0.nWaves
@@ -320,6 +412,14 @@ def calcDragExcitation(fowt, ih):
     return _default_engine.calcDragExcitation(fowt, ih)
 
 
+def calcQTF_slenderBody(fowt, waveHeadInd, Xi0=None, verbose=False, iCase=None, iWT=None):
+    return _default_engine.calcQTF_slenderBody(fowt, waveHeadInd, Xi0=Xi0, verbose=verbose, iCase=iCase, iWT=iWT)
+
+
+def calcHydroForce_2ndOrd(fowt, beta, S0, iCase=None, iWT=None, interpMode='qtf'):
+    return _default_engine.calcHydroForce_2ndOrd(fowt, beta, S0, iCase=iCase, iWT=iWT, interpMode=interpMode)
+
+
 def solveDynamics(model, case, tol=0.01, conv_plot=0, RAO_plot=0, display=0):
     return _default_engine.solveDynamics(model, case, tol=tol, conv_plot=conv_plot,
                                          RAO_plot=RAO_plot, display=display)
@@ -334,11 +434,15 @@ def install(raft_module=None):
     saved = dict(solveDynamics=raft_model.Model.solveDynamics,
                  calcHydroExcitation=raft_fowt.FOWT.calcHydroExcitation,
                  calcHydroLinearization=raft_fowt.FOWT.calcHydroLinearization,
-                 calcDragExcitation=raft_fowt.FOWT.calcDragExcitation)
+                 calcDragExcitation=raft_fowt.FOWT.calcDragExcitation,
+                 calcQTF_slenderBody=raft_fowt.FOWT.calcQTF_slenderBody,
+                 calcHydroForce_2ndOrd=raft_fowt.FOWT.calcHydroForce_2ndOrd)
     raft_model.Model.solveDynamics = solveDynamics
     raft_fowt.FOWT.calcHydroExcitation = calcHydroExcitation
     raft_fowt.FOWT.calcHydroLinearization = calcHydroLinearization
     raft_fowt.FOWT.calcDragExcitation = calcDragExcitation
+    raft_fowt.FOWT.calcQTF_slenderBody = calcQTF_slenderBody
+    raft_fowt.FOWT.calcHydroForce_2ndOrd = calcHydroForce_2ndOrd
     return saved
 
 
@@ -348,3 +452,5 @@ def uninstall(saved):
     raft_fowt.FOWT.calcHydroExcitation = saved['calcHydroExcitation']
     raft_fowt.FOWT.calcHydroLinearization = saved['calcHydroLinearization']
     raft_fowt.FOWT.calcDragExcitation = saved['calcDragExcitation']
+    raft_fowt.FOWT.calcQTF_slenderBody = saved['calcQTF_slenderBody']
+    raft_fowt.FOWT.calcHydroForce_2ndOrd = saved['calcHydroForce_2ndOrd']

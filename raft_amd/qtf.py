@@ -198,3 +198,82 @@ def hydro_force_2nd(qtf, w2nd, w, dw, S0):
     f[:, 0:-1] = f[:, 1:]
     f[:, -1] = 0
     return f_mean, f
+
+
+def hydro_force_2nd_spectrum(qtf, w2nd, w, dw, S0):
+    """interpMode='spectrum' branch of FOWT.calcHydroForce_2ndOrd (raft_fowt.py:2186-2207)."""
+    nw, nw1 = len(w), len(w2nd)
+    S = np.interp(w2nd, w, S0, left=0, right=0)
+    mu = w2nd - w2nd[0]
+    Sf = np.zeros([6, nw1])
+    f = np.zeros([6, nw], dtype=complex)
+    f_mean = np.zeros(6)
+    for idof in range(6):
+        for imu in range(1, nw1):
+            Saux = np.zeros(nw1)
+            Saux[0:nw1 - imu] = S[imu:]
+            Qaux = np.zeros(nw1, dtype=complex)
+            Qaux[0:nw1 - imu] = np.diag(qtf[:, :, idof], imu)
+            Sf[idof, imu] = 8 * np.sum(S * Saux * np.abs(Qaux) ** 2) * (w2nd[1] - w2nd[0])
+        f_mean[idof] = 2 * np.sum(S * np.diag(qtf[:, :, idof].real, 0)) * (w2nd[1] - w2nd[0])
+        f[idof, :] = np.sqrt(2 * np.interp(w - w[0], mu, Sf[idof, :], left=0, right=0) * dw)
+    f[:, 0:-1] = f[:, 1:]
+    f[:, -1] = 0
+    return f_mean, f
+
+
+def interp_heading(qtf4, heads, beta):
+    """Heading interpolation of raft_fowt.py:2173-2178: qtf4 [n,n,nHeads,6] -> [n,n,6]."""
+    if len(heads) == 1:
+        return qtf4[:, :, 0, :]
+    from scipy.interpolate import interp1d
+    re = interp1d(heads, qtf4.real, assume_sorted=True, axis=2, bounds_error=False,
+                  fill_value=(qtf4[:, :, 0, :].real, qtf4[:, :, -1, :].real))(beta)
+    im = interp1d(heads, qtf4.imag, assume_sorted=True, axis=2, bounds_error=False,
+                  fill_value=(qtf4[:, :, 0, :].imag, qtf4[:, :, -1, :].imag))(beta)
+    return re + 1j * im
+
+
+# ---------------------------------------------------------------------- WAMIT-format files next to the path
+def write_qtf12d(path, qtf4, w, heads, rho, g):
+    """FOWT.writeQTF (raft_fowt.py:2131-2155): WAMIT .12d, upper triangle, periods, ULEN = 1."""
+    with open(path, "w") as f:
+        for ih in range(len(heads)):
+            for iDoF in range(qtf4.shape[3]):
+                q = qtf4[:, :, ih, iDoF]
+                for i1 in range(len(w)):
+                    for i2 in range(i1, len(w)):
+                        F = q[i1, i2] / (rho * g)
+                        f.write(f"{2*np.pi/w[i1]: 8.4e} {2*np.pi/w[i2]: 8.4e} {np.rad2deg(heads[ih]): 8.4e} {np.rad2deg(heads[ih]): 8.4e} "
+                                f"{iDoF+1} {np.abs(F): 8.4e} {np.angle(F): 8.4e} {F.real: 8.4e} {F.imag: 8.4e}\n")
+
+
+def read_qtf12d(path, rho, g, nDOF=6, ULEN=1):
+    """FOWT.readQTF (raft_fowt.py:2081-2128): returns (heads_2nd [rad], w_2nd, qtf [n,n,nHeads,nDOF])."""
+    data = np.loadtxt(path)
+    data[:, 0:2] = 2. * np.pi / data[:, 0:2]
+    if not (data[:, 2] == data[:, 3]).all():
+        raise ValueError("Only unidirectional QTFs are supported for now.")
+    heads = np.deg2rad(np.sort(np.unique(data[:, 2])))
+    w1, w2 = np.unique(data[:, 0]), np.unique(data[:, 1])
+    if not (len(w1) == len(w2) and (w1 == w2).all()):
+        raise ValueError("Both frequency columns in the input QTF must contain the same values.")
+    qtf = np.zeros([len(w1), len(w2), len(heads), nDOF], dtype=complex)
+    for row in data:
+        i1, = np.where(w1 == row[0])
+        i2, = np.where(w2 == row[1])
+        ih, = np.where(heads == np.deg2rad(row[2]))
+        idof = round(row[4] - 1)
+        factor = rho * g * ULEN * (ULEN if idof >= 3 else 1)
+        qtf[i1[0], i2[0], ih[0], idof] = factor * (row[7] + 1j * row[8])
+        if i1[0] != i2[0]:
+            qtf[i2[0], i1[0], ih[0], idof] = factor * (row[7] - 1j * row[8])
+    return heads, w1, qtf
+
+
+def write_rao4(path, w, beta, Xi):
+    """The WAMIT .4 motion-RAO dump of raft_fowt.py:2027-2040."""
+    with open(path, "w") as f:
+        for iDoF in range(Xi.shape[0]):
+            for w1, x in zip(w, Xi[iDoF, :]):
+                f.write(f"{2*np.pi/w1: 8.4e} {beta: 8.4e} {iDoF+1} {np.abs(x): 8.4e} {np.angle(x): 8.4e} {x.real: 8.4e} {x.imag: 8.4e}\n")

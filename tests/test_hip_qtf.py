@@ -63,3 +63,48 @@ def test_qtf_batch_against_numpy_oracle(hip_ctx):
         assert rel_err(q[s], ref) < TOL
         off = ~np.eye(nw2, dtype=bool)                                  # the diagonal is left as computed (raft_fowt.py:2070)
         assert np.array_equal(q[s][off], np.conj(np.transpose(q[s], (1, 0, 2)))[off])
+
+
+def test_c5_internal_qtf_solveDynamics(hip_ctx):
+    """BASELINE configs[4] path end to end on the device: first-order fixed point, slender-body QTF kernels fed with
+    the converged motions, second-order force, restarted fixed point (raft_model.py:1108-1131)."""
+    from raft_amd import dropin
+    from tests.util import load_model_fixture, case_from_fixture, group_rel_err
+    fx, model = load_model_fixture("c5_internal_qtf.npz")
+    eng = dropin.Engine(hip_ctx)
+    for c in fx["cases"]:
+        Xi = eng.solveDynamics(model, case_from_fixture(c))
+        u = c["units"][0]
+        f = model.fowtList[0]
+        assert int(model._raftx_niter[0]) == int(u["niter"])
+        assert rel_err(f.qtf[:, :, 0, :], u["qtf"]) < TOL
+        assert rel_err(f.Fhydro_2nd, u["Fhydro_2nd"]) < TOL
+        nH = Xi.shape[0] - 1
+        assert group_rel_err(Xi[:nH], c["Xi"][:nH]) < TOL
+        assert rel_err(f.Z, u["Z"]) < TOL
+
+
+def test_restart_from_linearisation_point(hip_ctx, oracle_ctx):
+    """raftx_set/fetch_linearisation_point: a restarted solve from the exported Xi_last reproduces the converged
+    response in one iteration, identically on both libraries."""
+    from tests.util import random_strips, random_matrices, synthetic_cases
+    rng = np.random.default_rng(31)
+    tables = [random_strips(rng, S) for S in (30, 12)]
+    M0, B0, C0, _ = random_matrices(rng, 2)
+    w, k, zeta, beta = synthetic_cases(rng, 2, 1, 90)
+    res = []
+    for ctx in (hip_ctx, oracle_ctx):
+        ctx.upload_designs(tables, M0, B0, C0, len(w))
+        ctx.upload_cases(w, k, 200.0, 1025.0, 9.81, zeta, beta)
+        ctx.set_linearisation_point(None, keep_last=True)
+        a = ctx.solve_dynamics(8)
+        xl = ctx.fetch_linearisation_point()
+        ctx.set_linearisation_point(xl, keep_last=False)
+        b = ctx.solve_dynamics(8)
+        assert np.all(a["flags"] & 1) and np.all(b["niter"] == 1)
+        res.append((a, b, xl))
+    assert rel_err(res[0][2], res[1][2]) < TOL
+    for d in range(2):
+        from tests.util import group_rel_err
+        assert group_rel_err(res[0][1]["Xi"][d], res[0][0]["Xi"][d]) < 1e-13
+        assert group_rel_err(res[0][1]["Xi"][d], res[1][1]["Xi"][d]) < TOL

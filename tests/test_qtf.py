@@ -41,3 +41,39 @@ def test_live_reference_qtf_with_motions(name):
     f_mean, f2 = rq.hydro_force_2nd(q, w2, f.w, f.dw, fx["motion_S0"])
     assert rel_err(f_mean, fx["motion_f_mean"]) < 1e-9
     assert rel_err(f2, fx["motion_f2"]) < 1e-9
+
+
+def _numpy_qtf_backend(tabs, Xi, beta, w2, k2, depth, rho, g, Ms, kay):
+    return np.array([qtf_oracle.qtf_slender_body(t, Xi[i], beta[i], w2, k2, depth, rho, g, Ms[i], kay[i])
+                     for i, t in enumerate(tabs)])
+
+
+def test_c5_internal_qtf_solveDynamics(oracle_ctx):
+    """potSecOrder == 1 through the drop-in Model.solveDynamics: converge, QTFs from the converged motions,
+    second-order force into F_lin, iterate again from the same Xi_last (raft_model.py:1108-1131) -- against the
+    live reference (host logic + CPU oracle + numpy QTF oracle)."""
+    from raft_amd import dropin
+    from tests.util import load_model_fixture, case_from_fixture, group_rel_err
+    fx, model = load_model_fixture("c5_internal_qtf.npz")
+    eng = dropin.Engine(oracle_ctx, qtf_backend=_numpy_qtf_backend)
+    for c in fx["cases"]:
+        Xi = eng.solveDynamics(model, case_from_fixture(c))
+        u = c["units"][0]
+        f = model.fowtList[0]
+        assert int(model._raftx_niter[0]) == int(u["niter"])
+        assert rel_err(f.qtf[:, :, 0, :], u["qtf"]) < 1e-9
+        assert rel_err(f.Fhydro_2nd, u["Fhydro_2nd"]) < 1e-9
+        assert rel_err(f.Fhydro_2nd_mean, u["Fhydro_2nd_mean"]) < 1e-9
+        nH = Xi.shape[0] - 1
+        assert group_rel_err(Xi[:nH], c["Xi"][:nH]) < 1e-9
+        assert rel_err(f.Z, u["Z"]) < 1e-9
+
+
+def test_qtf_12d_file_round_trip(tmp_path):
+    fx, f, tab = _setup("VolturnUS-S")
+    q4 = fx["motion_qtf"][:, :, None, :]
+    path = str(tmp_path / "q.12d")
+    rq.write_qtf12d(path, q4, f.w1_2nd, [fx["motion_beta"] % (2 * np.pi)], f.rho_water, f.g)
+    heads, w, q = rq.read_qtf12d(path, f.rho_water, f.g)
+    assert len(w) == len(f.w1_2nd) and np.allclose(w, f.w1_2nd, rtol=1e-4)
+    assert rel_err(q[:, :, 0, :], fx["motion_qtf"]) < 2e-4          # the file carries 5 significant digits
