@@ -1,0 +1,39 @@
+"""Config-5-shaped measurement of the slender-body QTF kernels: VolturnUS-S strip table, 200 x 200 second-order grid,
+nSet independent (heading, motion) sets per launch.  Prints one JSON line (kernel time from HIP events on the ctx
+stream; the numpy oracle timed on a 40 x 40 sub-grid as the CPU datapoint)."""
+import json, os, sys, time
+import numpy as np
+sys.path.insert(0, os.getcwd())
+from raft_amd import backend, qtf as rq, waves
+from tests import standin
+
+n_set = int(sys.argv[1]) if len(sys.argv) > 1 else 16
+fx = standin.load_fixture("refgold_qtf_VolturnUS-S.npz")
+f = standin.build_model(fx["model"]).fowtList[0]
+tab = rq.pack_qtf(f)
+nw2 = 200
+w2 = np.arange(1, nw2 + 1) * 0.0025 * 2 * np.pi
+k2 = np.array([waves.wave_number(x, f.depth) for x in w2])
+rng = np.random.default_rng(0)
+amp = np.array([1.0, 0.3, 0.7, 0.01, 0.02, 0.004])[:, None] / (1.0 + (w2[None, :] / 0.6) ** 2)
+Xi = np.array([amp * np.exp(1j * (rng.uniform(0, 6, 6)[:, None] + 1.5 * w2[None, :])) for _ in range(n_set)])
+betas = rng.uniform(0, 2 * np.pi, n_set)
+Ms = np.array([f.M_struc] * n_set)
+ctx = backend.default_context(0)
+for _ in range(2):
+    q = ctx.qtf_slender([tab] * n_set, Xi, betas, w2, k2, f.depth, f.rho_water, f.g, Ms)
+ms = ctx.last_kernel_ms()
+pairs = n_set * nw2 * (nw2 + 1) // 2
+S = tab.strips.shape[0]
+# CPU datapoint: numpy oracle on a 40-bin sub-grid
+from oracle import qtf_oracle
+sub = slice(0, nw2, 5)
+t0 = time.perf_counter()
+qtf_oracle.qtf_slender_body(tab, Xi[0][:, sub], betas[0], w2[sub], k2[sub], f.depth, f.rho_water, f.g, f.M_struc)
+t_cpu = time.perf_counter() - t0
+n_sub = len(w2[sub])
+print(json.dumps({"metric": "QTF strip-pairs per second", "sets": n_set, "nw2": nw2, "strips": int(S),
+                  "kernel_ms": ms, "strip_pairs_per_s": pairs * S / (ms * 1e-3),
+                  "numpy_oracle_strip_pairs_per_s_1core": (n_sub * (n_sub + 1) // 2) * S / t_cpu,
+                  "reference_strip_pairs_per_s_1core": 1.0 / 0.58e-3,
+                  "hermitian_ok": bool(np.allclose(q[0], np.conj(np.transpose(q[0], (1, 0, 2))), atol=1e-6 * np.abs(q[0]).max()))}))
