@@ -293,7 +293,31 @@ def fixture_c5():
     standin.save_fixture(os.path.join(GOLD, "c5_internal_qtf.npz"), fx)
 
 
-ALL = {"c5": fixture_c5, "qtf": fixture_qtf, "c1": fixture_c1, "c2": fixture_c2, "pose": fixture_pose,
+def fixture_c5_oc4():
+    """BASELINE configs[4] deck itself: examples/OC4semi-RAFT_QTF.yaml (potSecOrder = 1, MacCamy-Fuchs columns with
+    heave plates, inclined cross braces), its shipped 40-point second-order grid, first-order grid coarsened to
+    min_freq 0.005 Hz (nw = 50) so that the reference finishes in minutes."""
+    d = rh.load_design(os.path.join(REF, "examples", "OC4semi-RAFT_QTF.yaml"))
+    d = rh.prepare_design(d, settings=dict(min_freq=0.005, max_freq=0.25, nIter=10))
+    d["platform"].pop("outFolderQTF", None)            # no WAMIT-format dumps from the generator
+    m = rh.build_model(d)
+    f = m.fowtList[0]
+    f.outFolderQTF = None
+    assert f.potSecOrder == 1
+    cases = [rh.make_case(Hs=6.0, Tp=12.0, heading=0.0), rh.make_case(Hs=3.0, Tp=8.0, heading=30.0)]
+    runs = []
+    for c in cases:
+        r = run_case(m, c)
+        r["units"][0]["Fhydro_2nd"] = np.array(f.Fhydro_2nd)
+        r["units"][0]["Fhydro_2nd_mean"] = np.array(f.Fhydro_2nd_mean)
+        r["units"][0]["qtf"] = np.array(f.qtf[:, :, 0, :])
+        runs.append(r)
+    fx = {"config": "C5 OC4semi-RAFT_QTF internal QTF solveDynamics (nw=50, 40-point 2nd-order grid)",
+          "model": standin.snapshot_model(m), "cases": runs}
+    standin.save_fixture(os.path.join(GOLD, "c5_oc4semi_qtf.npz"), fx)
+
+
+ALL = {"c5oc4": fixture_c5_oc4, "c5": fixture_c5, "qtf": fixture_qtf, "c1": fixture_c1, "c2": fixture_c2, "pose": fixture_pose,
        "refgold": fixture_ref_goldens, "c4": fixture_c4, "c3": fixture_c3}
 
 if __name__ == "__main__":

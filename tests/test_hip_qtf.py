@@ -65,12 +65,13 @@ def test_qtf_batch_against_numpy_oracle(hip_ctx):
         assert np.array_equal(q[s][off], np.conj(np.transpose(q[s], (1, 0, 2)))[off])
 
 
-def test_c5_internal_qtf_solveDynamics(hip_ctx):
+@pytest.mark.parametrize("fixture", ["c5_internal_qtf.npz", "c5_oc4semi_qtf.npz"])
+def test_c5_internal_qtf_solveDynamics(hip_ctx, fixture):
     """BASELINE configs[4] path end to end on the device: first-order fixed point, slender-body QTF kernels fed with
     the converged motions, second-order force, restarted fixed point (raft_model.py:1108-1131)."""
     from raft_amd import dropin
     from tests.util import load_model_fixture, case_from_fixture, group_rel_err
-    fx, model = load_model_fixture("c5_internal_qtf.npz")
+    fx, model = load_model_fixture(fixture)
     eng = dropin.Engine(hip_ctx)
     for c in fx["cases"]:
         Xi = eng.solveDynamics(model, case_from_fixture(c))

@@ -48,13 +48,14 @@ def _numpy_qtf_backend(tabs, Xi, beta, w2, k2, depth, rho, g, Ms, kay):
                      for i, t in enumerate(tabs)])
 
 
-def test_c5_internal_qtf_solveDynamics(oracle_ctx):
+@pytest.mark.parametrize("fixture", ["c5_internal_qtf.npz", "c5_oc4semi_qtf.npz"])
+def test_c5_internal_qtf_solveDynamics(oracle_ctx, fixture):
     """potSecOrder == 1 through the drop-in Model.solveDynamics: converge, QTFs from the converged motions,
     second-order force into F_lin, iterate again from the same Xi_last (raft_model.py:1108-1131) -- against the
     live reference (host logic + CPU oracle + numpy QTF oracle)."""
     from raft_amd import dropin
     from tests.util import load_model_fixture, case_from_fixture, group_rel_err
-    fx, model = load_model_fixture("c5_internal_qtf.npz")
+    fx, model = load_model_fixture(fixture)
     eng = dropin.Engine(oracle_ctx, qtf_backend=_numpy_qtf_backend)
     for c in fx["cases"]:
         Xi = eng.solveDynamics(model, case_from_fixture(c))
