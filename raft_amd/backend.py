@@ -23,6 +23,13 @@ def hip_library():
     global _lib
     with _lock:
         if _lib is None:
+            path = os.environ.get("RAFTX_HIP_LIB", HIP_LIB_PATH)      # tuning builds only; must still be a device library
+            if path != HIP_LIB_PATH:
+                lib = RaftxLib(path)
+                if not lib.is_device:
+                    raise RaftxError("%s is not a device library" % path)
+                _lib = lib
+                return _lib
             if not os.path.exists(HIP_LIB_PATH):
                 raise RaftxError(
                     "HIP extension not built: %s is missing. Run "

@@ -572,7 +572,7 @@ extern "C" int raftx_linearize(raftx_ctx *c, const raftx_c128 *Xi, double *B_dra
     if (npair && (!dXi || (B_drag && !dB) || (F_drag && !dF))) FAIL(c, "linearize: device allocation failed");
     if (npair) H2D(c, dXi, Xi, npair * 6 * T.nw * sizeof(cplx));
     const Shape sh = pick_shape(T.nw);
-    const size_t lds = lds_bytes(c->maxS, 0, sh.threads / 64, sh.threads == 64);
+    const size_t lds = lds_bytes(c->maxS, 0, sh.threads / 64, stage_policy(sh.nb, sh.threads == 64 ? 64 : (sh.threads <= 256 && sh.nb == 1 ? 256 : 512)));
 #define DISPATCH_ONE_(NB_, MT_, MB_)                                                                                  \
     if (!hit_ && sh.nb == NB_ && sh.threads == MT_) {                                                                 \
         hit_ = true;                                                                                                  \
@@ -668,7 +668,7 @@ extern "C" int raftx_solve_dynamics_device(raftx_ctx *c, int nIter, double tol, 
                      (T.cm ? KF_MCF : 0) | (T.nHead > 1 ? KF_MULTI : 0);
     const Shape sh = pick_shape(T.nw);
     const bool xlg = sh.threads == 512 && sh.nb >= 3;        // XiLast in a global scratch slab (raftx_kernels.h XlStore)
-    const size_t lds = lds_bytes(c->maxS, xlg ? 0 : T.nw, sh.threads / 64, sh.threads == 64);
+    const size_t lds = lds_bytes(c->maxS, xlg ? 0 : T.nw, sh.threads / 64, stage_policy(sh.nb, sh.threads == 64 ? 64 : (sh.threads <= 256 && sh.nb == 1 ? 256 : 512)));
     if (xlg && (!c->rXl || c->rXl_n < c->r_npair * 12 * (size_t)T.nw)) {
         HIPCHK(c, hipStreamSynchronize(c->stream));
         if (c->rXl) (void)hipFree(c->rXl);

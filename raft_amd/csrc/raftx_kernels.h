@@ -512,6 +512,13 @@ __device__ __forceinline__ void inertial_excitation(const DevTables &T, cdptr ds
     }
 }
 
+// Which shapes stage the strip constants in LDS (host and device must agree): the one-wave-per-SIMD shapes and the
+// 4-wave / 1-bin shape, whose 2 pairs per CU leave the LDS room (RAFTX_STAGE256 tuning switch at build time).
+#ifndef RAFTX_STAGE256
+#define RAFTX_STAGE256 0
+#endif
+static __host__ __device__ constexpr bool stage_policy(int nb, int maxt) { return maxt == 64 || (RAFTX_STAGE256 && maxt == 256 && nb == 1); }
+
 // Hot per-strip constants of pass A.  Two sources (template STAGE):
 //  * one-wave-per-SIMD shapes stage them once per workgroup into LDS and read them back as
 //    wave-wide broadcasts (~100 cycles, nothing else hides latency there);
@@ -1005,7 +1012,7 @@ __global__ void __launch_bounds__(MAXT, MINB) k_linearize(DevTables T, const cpl
     PairCtx p;
     if (!pair_ctx(T, p, pair_of_block(blockIdx.x, T.nDesign * T.nCase))) return;
     const bool multi = blockDim.x > 64;
-    constexpr bool STAGE = (MAXT == 64);
+    constexpr bool STAGE = stage_policy(NB, MAXT);
     Lds l = carve(smem, p.S, 0, blockDim.x >> 6, STAGE);        // no XiLast storage in this kernel
     if (STAGE) stage_recA(p.ds, p.dsi, p.S, l);
     Bins<NB> b;
@@ -1084,7 +1091,7 @@ __global__ void __launch_bounds__(MAXT, MINB) k_solve_dynamics(DevTables T, Solv
     const int nw = T.nw, nHs = T.nHead, nH = MULTI ? T.nHead : 1;
     const int pair = p.pair, S = p.S;
     const cplx *cm = (MCF && T.cm) ? p.cm : nullptr;
-    constexpr bool STAGE = (MAXT == 64);
+    constexpr bool STAGE = stage_policy(NB, MAXT);
     constexpr bool XLG = (MAXT == 512 && NB >= 3);
     Lds l = carve(smem, S, XLG ? 0 : nw, blockDim.x >> 6, STAGE);
     if (STAGE) stage_recA(p.ds, p.dsi, S, l);

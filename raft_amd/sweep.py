@@ -211,3 +211,20 @@ def run_sharded(sweep, ctx, dist=None, gather=True):
     counts = [shard_bounds(sweep.n_design, r, world)[1] - shard_bounds(sweep.n_design, r, world)[0] for r in range(world)]
     out = {k_: gather_rows(v, counts, dist) for k_, v in local.items()}
     return out if rank == 0 else local
+
+
+def run_qtf_sharded(qtf_fn, tables, Xi, beta, w2, k2, depth, rho, g, Mstruc, kay=None, dist=None):
+    """Slender-body QTFs of many (table, motion, heading) sets, sharded by set over the ranks (sets are independent:
+    no collective while computing); rank 0 gets [nSet,nw2,nw2,6], the others their own block.
+    qtf_fn = ctx.qtf_slender of the rank's context (tests pass the numpy oracle)."""
+    n = len(tables)
+    Xi, beta, Mstruc = np.asarray(Xi), np.asarray(beta), np.asarray(Mstruc)
+    if dist is None or dist.get_world_size() == 1:
+        return qtf_fn(tables, Xi, beta, w2, k2, depth, rho, g, Mstruc, kay)
+    rank, world = dist.get_rank(), dist.get_world_size()
+    lo, hi = shard_bounds(n, rank, world)
+    local = qtf_fn(tables[lo:hi], Xi[lo:hi], beta[lo:hi], w2, k2, depth, rho, g, Mstruc[lo:hi],
+                   None if kay is None else np.asarray(kay)[lo:hi])
+    counts = [shard_bounds(n, r, world)[1] - shard_bounds(n, r, world)[0] for r in range(world)]
+    full = gather_rows(local, counts, dist)
+    return full if rank == 0 else local

@@ -124,3 +124,45 @@ def test_two_rank_gloo_sweep_matches_single_process(tmp_path, oracle_lib):
         if j < n:
             assert group_rel_err(got["Xi"][j, 0, :1], sol["Xi"][:1]) < 1e-10
             assert int(got["niter"][j, 0]) == int(sol["units"][0]["niter"])
+
+
+def _qtf_sets():
+    from raft_amd import qtf as rq
+    fx = standin.load_fixture("refgold_qtf_VolturnUS-S.npz")
+    f = standin.build_model(fx["model"]).fowtList[0]
+    tab = rq.pack_qtf(f)
+    w2, k2 = f.w1_2nd[:9], f.k1_2nd[:9]
+    rng = np.random.default_rng(3)
+    Xi = 0.1 * (rng.normal(size=(3, 6, 9)) + 1j * rng.normal(size=(3, 6, 9)))
+    return [tab] * 3, Xi, np.array([0.0, 0.5, -1.0]), w2, k2, f
+
+
+def _numpy_qtf(t, X, b, w, k, h, rho, g, Ms, kay):
+    from oracle import qtf_oracle
+    return np.array([qtf_oracle.qtf_slender_body(t[i], X[i], b[i], w, k, h, rho, g, Ms[i]) for i in range(len(t))]
+                    ).reshape(len(t), len(w), len(w), 6)
+
+
+def _qtf_rank_main(rank, world, port, out_path):
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        tabs, Xi, beta, w2, k2, f = _qtf_sets()
+        q = sw.run_qtf_sharded(_numpy_qtf, tabs, Xi, beta, w2, k2, f.depth, f.rho_water, f.g,
+                               np.array([f.M_struc] * len(tabs)), dist=dist)
+        if rank == 0:
+            np.save(out_path, q)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_rank_gloo_qtf_sets(tmp_path):
+    """QTF sets sharded over two ranks (2 + 1) and gathered: identical to the single-process batch."""
+    import torch.multiprocessing as mp
+    out = str(tmp_path / "q.npy")
+    mp.spawn(_qtf_rank_main, args=(2, _free_port(), out), nprocs=2, join=True)
+    got = np.load(out)
+    tabs, Xi, beta, w2, k2, f = _qtf_sets()
+    ref = _numpy_qtf(tabs, Xi, beta, w2, k2, f.depth, f.rho_water, f.g, np.array([f.M_struc] * 3), None)
+    assert got.shape == ref.shape and np.array_equal(got.view(np.float64), ref.view(np.float64))
