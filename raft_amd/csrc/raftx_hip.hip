@@ -457,6 +457,13 @@ struct Shape {
     int nb, threads;
 };
 #define SHAPES(X) X(1, 64, 1) X(2, 64, 1) X(4, 64, 1) X(2, 128, 2) X(1, 256, 2) X(2, 256, 2) X(2, 512, 1) X(3, 512, 1) X(4, 512, 1)
+// MAXT template value of the kernel instantiated for a shape
+static int shape_maxt(Shape sh) {
+#define X(NB_, MT_, MB_) if (sh.nb == NB_ && sh.threads == MT_) return MT_;
+    SHAPES(X)
+#undef X
+    return 0;
+}
 static bool shape_ok(Shape sh, int nw) {
 #define X(NB_, MT_, MB_) if (sh.nb == NB_ && sh.threads == MT_) return (long)NB_ * MT_ >= nw;
     SHAPES(X)
@@ -572,7 +579,7 @@ extern "C" int raftx_linearize(raftx_ctx *c, const raftx_c128 *Xi, double *B_dra
     if (npair && (!dXi || (B_drag && !dB) || (F_drag && !dF))) FAIL(c, "linearize: device allocation failed");
     if (npair) H2D(c, dXi, Xi, npair * 6 * T.nw * sizeof(cplx));
     const Shape sh = pick_shape(T.nw);
-    const size_t lds = lds_bytes(c->maxS, 0, sh.threads / 64, stage_policy(sh.nb, sh.threads == 64 ? 64 : (sh.threads <= 256 && sh.nb == 1 ? 256 : 512)));
+    const size_t lds = lds_bytes(c->maxS, 0, sh.threads / 64, stage_policy(sh.nb, shape_maxt(sh)));
 #define DISPATCH_ONE_(NB_, MT_, MB_)                                                                                  \
     if (!hit_ && sh.nb == NB_ && sh.threads == MT_) {                                                                 \
         hit_ = true;                                                                                                  \
@@ -668,7 +675,7 @@ extern "C" int raftx_solve_dynamics_device(raftx_ctx *c, int nIter, double tol, 
                      (T.cm ? KF_MCF : 0) | (T.nHead > 1 ? KF_MULTI : 0);
     const Shape sh = pick_shape(T.nw);
     const bool xlg = sh.threads == 512 && sh.nb >= 3;        // XiLast in a global scratch slab (raftx_kernels.h XlStore)
-    const size_t lds = lds_bytes(c->maxS, xlg ? 0 : T.nw, sh.threads / 64, stage_policy(sh.nb, sh.threads == 64 ? 64 : (sh.threads <= 256 && sh.nb == 1 ? 256 : 512)));
+    const size_t lds = lds_bytes(c->maxS, xlg ? 0 : T.nw, sh.threads / 64, stage_policy(sh.nb, shape_maxt(sh)));
     if (xlg && (!c->rXl || c->rXl_n < c->r_npair * 12 * (size_t)T.nw)) {
         HIPCHK(c, hipStreamSynchronize(c->stream));
         if (c->rXl) (void)hipFree(c->rXl);

@@ -149,7 +149,7 @@ static inline unsigned grid_for_pairs(size_t npair) { return (unsigned)(((npair 
 
 // ------------------------------------------------------------------ LDS layout
 #define RA_N 18              // doubles per staged record: arm, q, p1, p2 (pass A) + x, y, z, unit step (run starts)
-#define TR_ROWS 8            // rows of a reduction tile
+#define TR_ROWS 6            // rows of a reduction tile (pass A: 2 strips x 3 sums per batch)
 #define TR_STRIDE 72         // doubles per row (8 segments of 9: conflict-free)
 #define SB 2                 // strips per reduction batch of pass A (3 rows each)
 
@@ -158,7 +158,7 @@ static inline unsigned grid_for_pairs(size_t npair) { return (unsigned)(((npair 
 // stage the hot strip constants (ra, +7.6 K).
 struct Lds {
     ldptr xl;      // [12][nxl]    XiLast (re/im rows), nxl = nw rounded up to even
-    ldptr ra;      // [S][RA_N]    hot strip constants (STAGE shapes only)
+    ldptr ra;      // [S][stage_n] hot strip constants: all RA_N, the first 6 (arm, q), or none -- see stage_policy
     ldptr uv;      // [S][12]      linearised drag vectors of the current heading
     ldptr vsq;     // [NWV][S][3]  per-wave sums over bins of |v_q|^2, |v_p1|^2 (|v_perp|^2), |v_p2|^2;
                      //              row 0 is overwritten by the live coefficients b_c (strip_phase)
@@ -170,13 +170,13 @@ struct Lds {
     int nxl;
 };
 static __host__ __device__ inline int xl_row(int nw) { return (nw + 1) & ~1; }
-__device__ __forceinline__ Lds carve(double *base_, int S, int nw, int nwv, bool stage) {
+__device__ __forceinline__ Lds carve(double *base_, int S, int nw, int nwv, int stage_n) {
     Lds l;
     ldptr base = (ldptr)base_;
     l.nxl = xl_row(nw);
     l.xl = base;
     l.ra = l.xl + (size_t)12 * l.nxl;
-    l.uv = l.ra + (stage ? (size_t)S * RA_N : 0);
+    l.uv = l.ra + (size_t)S * stage_n;
     l.vsq = l.uv + (size_t)S * 12;
     l.tile = l.vsq + (size_t)nwv * S * 3;
     l.bdw = l.tile + (size_t)nwv * TR_ROWS * TR_STRIDE;
@@ -185,10 +185,10 @@ __device__ __forceinline__ Lds carve(double *base_, int S, int nw, int nwv, bool
     l.fl = (liptr)(l.mat + 108);
     return l;
 }
-static size_t lds_bytes(int S, int nw, int nwv, bool stage) {
-    return sizeof(double) * ((size_t)12 * xl_row(nw) + (size_t)S * ((stage ? RA_N : 0) + 12 + 3 * nwv) +
+static size_t lds_bytes(int S, int nw, int nwv, int stage_n) {
+    return sizeof(double) * ((size_t)12 * xl_row(nw) + (size_t)S * (stage_n + 12 + 3 * nwv) +
                              (size_t)nwv * (TR_ROWS * TR_STRIDE + 24) + 36 + 108 + 2) +
-           sizeof(int) * (size_t)(stage ? S + 2 : 2);
+           sizeof(int) * (size_t)(stage_n == RA_N ? S + 2 : 2);
 }
 
 // LDS traffic between lanes of ONE wave needs no s_barrier (a wave's LDS instructions
@@ -212,13 +212,13 @@ __device__ __forceinline__ double dpp_mov(double v) {
     return __hiloint2double(hi, lo);
 }
 
-// Reduction tile of one wave: TR_ROWS rows; lane L writes its value of row r at
+// Reduction tile of one wave: TR_ROWS (<= 8) rows; lane L writes its value of row r at
 // tile[r*TR_STRIDE + tile_pos(L)].  tile_reduce returns, on lanes with (L & 7) == 0, the sum
 // over the 64 lanes of row L >> 3 (other lanes: partial sums).  Reader lane (row, seg) adds
 // the 8 entries of its segment, then three DPP steps fold the 8 segments.
 __device__ __forceinline__ int tile_pos(int lane) { return (lane >> 3) * 9 + (lane & 7); }
 __device__ __forceinline__ double tile_reduce(ldptr tile, int lane) {
-    ldptr p = tile + (lane >> 3) * TR_STRIDE + (lane & 7) * 9;
+    ldptr p = tile + min(lane >> 3, TR_ROWS - 1) * TR_STRIDE + (lane & 7) * 9;     // lanes 48..63 redo row 5 (unused)
     double a0 = p[0] + p[4], a1 = p[1] + p[5], a2 = p[2] + p[6], a3 = p[3] + p[7];
     double a = (a0 + a1) + (a2 + a3);
     a += dpp_mov<0xB1>(a);      // quad_perm [1,0,3,2]
@@ -512,12 +512,18 @@ __device__ __forceinline__ void inertial_excitation(const DevTables &T, cdptr ds
     }
 }
 
-// Which shapes stage the strip constants in LDS (host and device must agree): the one-wave-per-SIMD shapes and the
-// 4-wave / 1-bin shape, whose 2 pairs per CU leave the LDS room (RAFTX_STAGE256 tuning switch at build time).
+// How many doubles of each strip record a shape stages in LDS (host and device must agree):
+//   RA_N (all 18)  one-wave-per-SIMD shapes: nothing else hides latency there
+//   6 (arm, q)     the 2-wave shape: what every strip of pass A needs first; p1/p2 (rectangular strips only) and the
+//                  run-start fields keep coming through scalar loads, whose latency the kinematics update covers.
+//                  Four pairs per CU leave no LDS for more.
+//   0              larger shapes: scalar loads only
 #ifndef RAFTX_STAGE256
 #define RAFTX_STAGE256 0
 #endif
-static __host__ __device__ constexpr bool stage_policy(int nb, int maxt) { return maxt == 64 || (RAFTX_STAGE256 && maxt == 256 && nb == 1); }
+static __host__ __device__ constexpr int stage_policy(int nb, int maxt) {
+    return maxt == 64 ? RA_N : (maxt == 128 ? 6 : ((RAFTX_STAGE256 && maxt == 256 && nb == 1) ? RA_N : 0));
+}
 
 // Hot per-strip constants of pass A.  Two sources (template STAGE):
 //  * one-wave-per-SIMD shapes stage them once per workgroup into LDS and read them back as
@@ -527,13 +533,14 @@ static __host__ __device__ constexpr bool stage_policy(int nb, int maxt) { retur
 struct RecA {
     double ax, ay, az, qx, qy, qz, p1x, p1y, p1z, p2x, p2y, p2z;
 };
-__device__ __forceinline__ void stage_recA(cdptr ds, ciptr dsi, int S, const Lds &l) {
-    for (int i = threadIdx.x; i < S * RA_N; i += blockDim.x) {
-        const int s = i / RA_N, f = i % RA_N;
+__device__ __forceinline__ void stage_recA(cdptr ds, ciptr dsi, int S, const Lds &l, int n) {
+    for (int i = threadIdx.x; i < S * n; i += blockDim.x) {
+        const int s = i / n, f = i % n;
         // DS_A .. DS_P2+2 are contiguous (12), then DS_X .. DS_U+2 (6)
         l.ra[i] = ds[(size_t)s * DS_N + (f < 12 ? DS_A + f : DS_X + (f - 12))];
     }
-    for (int i = threadIdx.x; i < S; i += blockDim.x) l.fl[i] = dsi[i];
+    if (n == RA_N)
+        for (int i = threadIdx.x; i < S; i += blockDim.x) l.fl[i] = dsi[i];
 }
 __device__ __forceinline__ RecA load_recA(ldptr r) {              // staged LDS record
     return {r[0], r[1], r[2], r[3], r[4], r[5], r[6], r[7], r[8], r[9], r[10], r[11]};
@@ -542,11 +549,11 @@ __device__ __forceinline__ RecA load_recA(cdptr rec) {             // global dev
     return {rec[DS_A], rec[DS_A + 1], rec[DS_A + 2], rec[DS_Q], rec[DS_Q + 1], rec[DS_Q + 2],
             rec[DS_P1], rec[DS_P1 + 1], rec[DS_P1 + 2], rec[DS_P2], rec[DS_P2 + 1], rec[DS_P2 + 2]};
 }
-// Per-strip source of flags and records for the sweeps
-template <bool STAGE>
+// Per-strip source of flags and records for the sweeps (STAGE = stage_policy value)
+template <int STAGE>
 struct StripSrc;
 template <>
-struct StripSrc<true> {
+struct StripSrc<RA_N> {
     const Lds &l;
     int fnv;                                   // flag word of the next strip (VGPR, fetched one strip ahead)
     __device__ __forceinline__ StripSrc(const Lds &l_, cdptr, ciptr) : l(l_), fnv(l_.fl[0]) {}
@@ -558,12 +565,36 @@ struct StripSrc<true> {
     }
 };
 template <>
-struct StripSrc<false> {
+struct StripSrc<0> {
     cdptr ds;
     ciptr dsi;
     int fn;                                    // flag word of the next strip (SGPR, fetched one strip ahead)
     __device__ __forceinline__ StripSrc(const Lds &, cdptr ds_, ciptr dsi_) : ds(ds_), dsi(dsi_), fn(dsi_[0]) {}
     __device__ __forceinline__ cdptr rec(int s) const { return ds + (size_t)s * DS_N; }
+    __device__ __forceinline__ int flags(int s_next) {
+        const int f = fn;
+        fn = dsi[s_next];
+        return f;
+    }
+};
+// arm and q from LDS, the rest from the global record
+struct RecSplit {
+    ldptr lr;
+    cdptr gr;
+};
+__device__ __forceinline__ RecA load_recA(RecSplit r) {
+    return {r.lr[0], r.lr[1], r.lr[2], r.lr[3], r.lr[4], r.lr[5],
+            r.gr[DS_P1], r.gr[DS_P1 + 1], r.gr[DS_P1 + 2], r.gr[DS_P2], r.gr[DS_P2 + 1], r.gr[DS_P2 + 2]};
+}
+__device__ __forceinline__ RunStart run_start_of(RecSplit r) { return run_start_of(r.gr); }
+template <>
+struct StripSrc<6> {
+    const Lds &l;
+    cdptr ds;
+    ciptr dsi;
+    int fn;
+    __device__ __forceinline__ StripSrc(const Lds &l_, cdptr ds_, ciptr dsi_) : l(l_), ds(ds_), dsi(dsi_), fn(dsi_[0]) {}
+    __device__ __forceinline__ RecSplit rec(int s) const { return {l.ra + s * 6, ds + (size_t)s * DS_N}; }
     __device__ __forceinline__ int flags(int s_next) {
         const int f = fn;
         fn = dsi[s_next];
@@ -619,7 +650,7 @@ __device__ __forceinline__ void passA_strip(Kin<NB> &K, const RecA &r, int fl, R
 // Cross-lane sums go through
 // this wave's LDS transposition tile (no barrier, no shuffles); per-wave results land in
 // vsq[wave][s][3].
-template <int NB, bool STAGE>
+template <int NB, int STAGE>
 __device__ __forceinline__ void linearize_passA(cdptr ds, ciptr dsi, int S,
                                                 const Lds &l, const Bins<NB> &b, double cb, double sb,
                                                 const cplx (&X)[NB][6] PT_ARG) {
@@ -632,32 +663,57 @@ __device__ __forceinline__ void linearize_passA(cdptr ds, ciptr dsi, int S,
     kin_reset(K);
     if (S <= 0) return;
     StripSrc<STAGE> src(l, ds, dsi);
+    // Two strips per batch (6 tile rows).  The cross-lane reduction of batch k is software-pipelined into batch
+    // k+1: its 8 tile reads are issued before the first strip of batch k+1 and consumed after it, so neither the
+    // write->read turnaround nor the read latency of the tile is exposed.
+    ldptr rp = tile + min(lane >> 3, TR_ROWS - 1) * TR_STRIDE + (lane & 7) * 9;
+    const int row = lane >> 3;
+    const bool writer = (lane & 7) == 0;
+    int prev_s0 = -1, prev_nb = 0;
 #pragma unroll 1
     for (int s0 = 0; s0 < S; s0 += SB) {
         const int nb = min(SB, S - s0);
-#pragma unroll 1
-        for (int jj = 0; jj < nb; jj++) {
-            const int s = s0 + jj;
-            const auto rec = src.rec(s);
-            const RecA r = load_recA(rec);
-            const int fl = src.flags(min(s + 1, S - 1));
-            double v0, v1, v2;
-            passA_strip<NB>(K, r, fl, rec, b, cb, sb, X, v0, v1, v2);
-            wr[(jj * 3 + 0) * TR_STRIDE] = v0;
-            wr[(jj * 3 + 1) * TR_STRIDE] = v1;
-            wr[(jj * 3 + 2) * TR_STRIDE] = v2;
+        double pend[8];
+        if (prev_s0 >= 0) {
+#pragma unroll
+            for (int e = 0; e < 8; e++) pend[e] = rp[e];
         }
-        PT_MARK(6);   // strips of pass A
-        wave_lds_fence();
+        double va[3], vb[3] = {0.0, 0.0, 0.0};
         {
-            const double a = tile_reduce(tile, lane);
-            const int row = lane >> 3;
-            if ((lane & 7) == 0 && row < nb * 3) vout[s0 * 3 + row] = a;
+            const auto rec = src.rec(s0);
+            const RecA r = load_recA(rec);
+            const int fl = src.flags(min(s0 + 1, S - 1));
+            passA_strip<NB>(K, r, fl, rec, b, cb, sb, X, va[0], va[1], va[2]);
+        }
+        if (prev_s0 >= 0) {
+            double a = ((pend[0] + pend[4]) + (pend[1] + pend[5])) + ((pend[2] + pend[6]) + (pend[3] + pend[7]));
+            a += dpp_mov<0xB1>(a);
+            a += dpp_mov<0x4E>(a);
+            a += dpp_mov<0x104>(a);
+            if (writer && row < prev_nb * 3) vout[prev_s0 * 3 + row] = a;
+        }
+        if (nb > 1) {
+            const auto rec = src.rec(s0 + 1);
+            const RecA r = load_recA(rec);
+            const int fl = src.flags(min(s0 + 2, S - 1));
+            passA_strip<NB>(K, r, fl, rec, b, cb, sb, X, vb[0], vb[1], vb[2]);
+        }
+#pragma unroll
+        for (int c = 0; c < 3; c++) {
+            wr[c * TR_STRIDE] = va[c];
+            wr[(3 + c) * TR_STRIDE] = vb[c];
         }
         wave_lds_fence();
+        prev_s0 = s0;
+        prev_nb = nb;
+        PT_MARK(6);   // strips of pass A
     }
+    {   // drain: the last batch
+        const double a = tile_reduce(tile, lane);
+        if (writer && row < prev_nb * 3) vout[prev_s0 * 3 + row] = a;
+    }
+    wave_lds_fence();
 }
-
 // Strip-lane phase of a linearisation: one lane per strip turns the velocity sums into the
 // linearised coefficients (raft_member.py:2093-2110), the heading-projected drag vectors
 //   U = sum_c b_c al_c W_c,  V = sum_c b_c ga_c W_c,  W_c = [n_c ; a x n_c]
@@ -787,7 +843,7 @@ __device__ __forceinline__ void load_uv(ldptr uv, double (&U)[6], double (&V)[6]
         V[q] = uv[6 + q];
     }
 }
-template <int NB, bool STAGE>
+template <int NB, int STAGE>
 __device__ __forceinline__ void drag_excitation(cdptr ds, ciptr dsi, int S, const Lds &l, const Bins<NB> &b, double cb,
                                                 double sb, cplx (&F)[NB][6]) {
     Kin<NB> K;
@@ -1012,9 +1068,9 @@ __global__ void __launch_bounds__(MAXT, MINB) k_linearize(DevTables T, const cpl
     PairCtx p;
     if (!pair_ctx(T, p, pair_of_block(blockIdx.x, T.nDesign * T.nCase))) return;
     const bool multi = blockDim.x > 64;
-    constexpr bool STAGE = stage_policy(NB, MAXT);
+    constexpr int STAGE = stage_policy(NB, MAXT);
     Lds l = carve(smem, p.S, 0, blockDim.x >> 6, STAGE);        // no XiLast storage in this kernel
-    if (STAGE) stage_recA(p.ds, p.dsi, p.S, l);
+    if (STAGE) stage_recA(p.ds, p.dsi, p.S, l, STAGE);
     Bins<NB> b;
     load_bins(T, b, threadIdx.x);
     wg_sync(multi);
@@ -1091,10 +1147,10 @@ __global__ void __launch_bounds__(MAXT, MINB) k_solve_dynamics(DevTables T, Solv
     const int nw = T.nw, nHs = T.nHead, nH = MULTI ? T.nHead : 1;
     const int pair = p.pair, S = p.S;
     const cplx *cm = (MCF && T.cm) ? p.cm : nullptr;
-    constexpr bool STAGE = stage_policy(NB, MAXT);
+    constexpr int STAGE = stage_policy(NB, MAXT);
     constexpr bool XLG = (MAXT == 512 && NB >= 3);
     Lds l = carve(smem, S, XLG ? 0 : nw, blockDim.x >> 6, STAGE);
-    if (STAGE) stage_recA(p.ds, p.dsi, S, l);
+    if (STAGE) stage_recA(p.ds, p.dsi, S, l, STAGE);
     XlStore<XLG> xl;
     if constexpr (XLG) {
         xl.p = A.Xl + (size_t)pair * 12 * nw;
