@@ -453,10 +453,12 @@ __device__ __forceinline__ void inertial_excitation(const DevTables &T, cdptr ds
     }
     Kin<NB> K;
     kin_reset(K);
+    if (S <= 0) return;
+    int fn = dsi[0];
 #pragma unroll 1
     for (int s = 0; s < S; s++) {
         cdptr rec = ds + (size_t)s * DS_N;
-        kin_advance<NB, true>(K, dsi[s], rec, b, one, cb, sb);
+        // fetch the whole record (one burst of scalar loads) before the branchy kinematics update
         const double ax = rec[DS_A], ay = rec[DS_A + 1], az = rec[DS_A + 2];
         const double ai_ = rec[DS_IQ + 3], rhoV = rec[DS_IQ + 4];
         const int mcf = MCF ? (int)rec[DS_MCF] : -1;
@@ -466,9 +468,15 @@ __device__ __forceinline__ void inertial_excitation(const DevTables &T, cdptr ds
             n[c][0] = rec[DS_Q + 3 * c];
             n[c][1] = rec[DS_Q + 3 * c + 1];
             n[c][2] = rec[DS_Q + 3 * c + 2];
+            I[c] = rec[DS_IQ + c];
+        }
+        const int fl = fn;
+        fn = dsi[min(s + 1, S - 1)];
+        kin_advance<NB, true>(K, fl, rec, b, one, cb, sb);
+#pragma unroll
+        for (int c = 0; c < 3; c++) {
             al[c] = n[c][0] * cb + n[c][1] * sb;
             ga[c] = n[c][2];
-            I[c] = rec[DS_IQ + c];
         }
 #pragma unroll
         for (int j = 0; j < NB; j++) {
