@@ -94,8 +94,25 @@ def cm_sides(mem, il, k):
     return Cm * ramp + Cm1_0 * (1 - ramp), Cm * ramp + Cm2_0 * (1 - ramp)
 
 
+def cm_sides_array(mem, il, k):
+    """cm_sides for a whole wave-number array at once (raft_member.py:1459-1484): [2,nk] complex."""
+    from scipy.special import hankel1
+    k = np.asarray(k, dtype=float)
+    Ca_p1 = _interp(mem.ls[il], mem.stations, mem.Ca_p1)
+    Ca_p2 = _interp(mem.ls[il], mem.stations, mem.Ca_p2)
+    R = mem.ds[il] / 2
+    with np.errstate(divide="ignore", invalid="ignore"):
+        Hp1 = 0.5 * (hankel1(0, k * R) - hankel1(2, k * R))
+        Cm = 4j / (np.pi * (k * R) ** 2 * Hp1)
+    Tr = np.pi / 5 / R
+    ramp = np.where(k < Tr, 0.5 * (1 - np.cos(np.pi * k / Tr)), 1.0)
+    ramp = np.where(k <= 0, 0.0, ramp)
+    Cm = np.where(ramp == 0.0, 0.0, Cm)                       # k <= 0: the ramp removes the (singular) MCF value
+    return np.array([Cm * ramp + (1.0 + Ca_p1) * (1 - ramp), Cm * ramp + (1.0 + Ca_p2) * (1 - ramp)])
+
+
 def pack_member(mem, imem, rho, k_array=None, arm_node=None):
-    """Records for the submerged strips of one rigid member.
+    """Records for the submerged strips of one rigid member (vectorised over the member's strips).
 
     Returns (records [n,32], cm rows list of complex [2,nw])."""
     if getattr(mem, "type", "rigid") != "rigid":
@@ -113,93 +130,88 @@ def pack_member(mem, imem, rho, k_array=None, arm_node=None):
     p2 = np.asarray(mem.p2, dtype=float)
     c_drag = np.sqrt(8 / np.pi)
 
-    recs, cms = [], []
-    wet = [il for il in range(mem.ns) if np.asarray(mem.r[il], dtype=float)[2] < 0]   # raft_member.py:1979,2058
-    gaps = [float(mem.ls[b]) - float(mem.ls[a]) for a, b in zip(wet[:-1], wet[1:]) if b == a + 1]
-    gaps = [g for g in gaps if g > 0]
-    unit = min(gaps) if gaps else 0.0
+    r_all = np.asarray(mem.r, dtype=float).reshape(-1, 3)
+    wet = np.nonzero(r_all[:, 2] < 0)[0]                      # raft_member.py:1979,2058
+    n = len(wet)
+    if n == 0:
+        return np.zeros((0, NFIELD)), []
+    ls = np.asarray(mem.ls, dtype=float)[wet]
+    dls = np.asarray(mem.dls, dtype=float)[wet]
+    r = r_all[wet]
+    stations = np.asarray(mem.stations, dtype=float)
+    coef = lambda name: np.interp(ls, stations, np.asarray(getattr(mem, name), dtype=float))
+    rec = np.zeros((n, NFIELD))
+
+    # run hints (optional: the library re-derives and verifies them at upload)
+    consecutive = np.diff(wet) == 1
+    gaps = np.diff(ls)[consecutive]
+    gaps = gaps[gaps > 0]
+    unit = float(gaps.min()) if len(gaps) else 0.0
     run = 0
-    prev_il = None
-    for il in wet:
-        r = np.asarray(mem.r[il], dtype=float)
-        rec = np.zeros(NFIELD)
+    for i in range(1, n):
         step = 0
-        if prev_il is not None and il == prev_il + 1 and unit > 0 and run < MAX_RUN:
-            ratio = (float(mem.ls[il]) - float(mem.ls[prev_il])) / unit
+        if consecutive[i - 1] and unit > 0 and run < MAX_RUN:
+            ratio = (ls[i] - ls[i - 1]) / unit
             m = int(round(ratio))
             if 1 <= m <= 4 and abs(ratio - m) < 1e-9:
                 step = m
         run = run + 1 if step else 0
-        prev_il = il
-        rec[F_STEP] = step
-        rec[F_UNIT] = unit
-        rec[F_X:F_X + 3] = r
-        rec[F_AX:F_AX + 3] = (r - r_node) + arm_node
-        rec[F_Q:F_Q + 3] = q
-        rec[F_P1:F_P1 + 3] = p1
-        rec[F_P2:F_P2 + 3] = p2
-        rec[F_CIRC] = 1.0 if circ else 0.0
-        rec[F_MCF] = -1.0
-        rec[F_MEM] = imem
-        rec[F_IL] = il
-        d = mem.ds[il]
-        dr = mem.drs[il]
-        dl = float(mem.dls[il])
+        rec[i, F_STEP] = step
+    rec[:, F_UNIT] = unit
+    rec[:, F_X:F_X + 3] = r
+    rec[:, F_AX:F_AX + 3] = (r - r_node) + arm_node
+    rec[:, F_Q:F_Q + 3] = q
+    rec[:, F_P1:F_P1 + 3] = p1
+    rec[:, F_P2:F_P2 + 3] = p2
+    rec[:, F_CIRC] = 1.0 if circ else 0.0
+    rec[:, F_MCF] = -1.0
+    rec[:, F_MEM] = imem
+    rec[:, F_IL] = wet
+    ds = np.asarray(mem.ds, dtype=float)[wet]
+    drs = np.asarray(mem.drs, dtype=float)[wet]
 
-        # ---- inertial-excitation scalars (raft_member.py:1395-1448, :1340-1348)
-        if not potMod:
-            Ca_End = _interp(mem.ls[il], mem.stations, mem.Ca_End)
-            if circ:
-                v_i = 0.25 * np.pi * d ** 2 * dl
-            else:
-                v_i = d[0] * d[1] * dl
-            if r[2] + 0.5 * dl > 0:              # strip pierces the waterline
-                v_i = v_i * (0.5 * dl - r[2]) / dl
-            if circ:
-                v_end = np.pi / 12.0 * abs((d + dr) ** 3 - (d - dr) ** 3)
-                a_i = np.pi * d * dr
-            else:
-                v_end = np.pi / 12.0 * ((np.mean(d + dr)) ** 3 - (np.mean(d - dr)) ** 3)
-                a_i = ((d[0] + dr[0]) * (d[1] + dr[1]) - (d[0] - dr[0]) * (d[1] - dr[1]))
-            rec[F_IQ] = rho * v_end * Ca_End
-            rec[F_AI] = a_i
-            rec[F_RHOV] = rho * v_i
-            if MCF:
-                row = np.empty((2, len(k_array)), dtype=complex)
-                for ik, k in enumerate(k_array):
-                    row[0, ik], row[1, ik] = cm_sides(mem, il, k)
-                rec[F_MCF] = float(len(cms))
-                cms.append(row)
-            else:
-                Ca_p1 = _interp(mem.ls[il], mem.stations, mem.Ca_p1)
-                Ca_p2 = _interp(mem.ls[il], mem.stations, mem.Ca_p2)
-                rec[F_IP1] = rho * v_i * (1.0 + Ca_p1)
-                rec[F_IP2] = rho * v_i * (1.0 + Ca_p2)
-
-        # ---- drag scalars (raft_member.py:2061-2110); note the reference's
-        # rectangular axial area 2*(ds0+ds0)*dl (sic, :2070)
-        Cd_q = _interp(mem.ls[il], mem.stations, mem.Cd_q)
-        Cd_p1 = _interp(mem.ls[il], mem.stations, mem.Cd_p1)
-        Cd_p2 = _interp(mem.ls[il], mem.stations, mem.Cd_p2)
-        Cd_End = _interp(mem.ls[il], mem.stations, mem.Cd_End)
+    # ---- inertial-excitation scalars (raft_member.py:1395-1448, :1340-1348)
+    cms = []
+    if not potMod:
         if circ:
-            a_q = np.pi * d * dl
-            a_p1 = d * dl
-            a_p2 = d * dl
-            a_end = abs(np.pi * d * dr)
+            v_i = 0.25 * np.pi * ds ** 2 * dls
+            v_end = np.pi / 12.0 * np.abs((ds + drs) ** 3 - (ds - drs) ** 3)
+            a_i = np.pi * ds * drs
         else:
-            a_q = 2 * (d[0] + d[0]) * dl
-            a_p1 = d[0] * dl
-            a_p2 = d[1] * dl
-            a_end = abs((d[0] + dr[0]) * (d[1] + dr[1]) - (d[0] - dr[0]) * (d[1] - dr[1]))
-        rec[F_DQ] = c_drag * 0.5 * rho * a_q * Cd_q
-        rec[F_DP1] = c_drag * 0.5 * rho * a_p1 * Cd_p1
-        rec[F_DP2] = c_drag * 0.5 * rho * a_p2 * Cd_p2
-        rec[F_DEND] = c_drag * 0.5 * rho * a_end * Cd_End
-        recs.append(rec)
-    if recs:
-        return np.array(recs), cms
-    return np.zeros((0, NFIELD)), cms
+            v_i = ds[:, 0] * ds[:, 1] * dls
+            v_end = np.pi / 12.0 * (np.mean(ds + drs, axis=1) ** 3 - np.mean(ds - drs, axis=1) ** 3)
+            a_i = (ds[:, 0] + drs[:, 0]) * (ds[:, 1] + drs[:, 1]) - (ds[:, 0] - drs[:, 0]) * (ds[:, 1] - drs[:, 1])
+        pierce = r[:, 2] + 0.5 * dls > 0                      # strip pierces the waterline
+        with np.errstate(divide="ignore", invalid="ignore"):
+            v_i = np.where(pierce, v_i * (0.5 * dls - r[:, 2]) / dls, v_i)
+        rec[:, F_IQ] = rho * v_end * coef("Ca_End")
+        rec[:, F_AI] = a_i
+        rec[:, F_RHOV] = rho * v_i
+        if MCF:
+            for i, il in enumerate(wet):
+                rec[i, F_MCF] = float(len(cms))
+                cms.append(cm_sides_array(mem, il, k_array))
+        else:
+            rec[:, F_IP1] = rho * v_i * (1.0 + coef("Ca_p1"))
+            rec[:, F_IP2] = rho * v_i * (1.0 + coef("Ca_p2"))
+
+    # ---- drag scalars (raft_member.py:2061-2110); note the reference's
+    # rectangular axial area 2*(ds0+ds0)*dl (sic, :2070)
+    if circ:
+        a_q = np.pi * ds * dls
+        a_p1 = ds * dls
+        a_p2 = ds * dls
+        a_end = np.abs(np.pi * ds * drs)
+    else:
+        a_q = 2 * (ds[:, 0] + ds[:, 0]) * dls
+        a_p1 = ds[:, 0] * dls
+        a_p2 = ds[:, 1] * dls
+        a_end = np.abs((ds[:, 0] + drs[:, 0]) * (ds[:, 1] + drs[:, 1]) - (ds[:, 0] - drs[:, 0]) * (ds[:, 1] - drs[:, 1]))
+    rec[:, F_DQ] = c_drag * 0.5 * rho * a_q * coef("Cd_q")
+    rec[:, F_DP1] = c_drag * 0.5 * rho * a_p1 * coef("Cd_p1")
+    rec[:, F_DP2] = c_drag * 0.5 * rho * a_p2 * coef("Cd_p2")
+    rec[:, F_DEND] = c_drag * 0.5 * rho * a_end * coef("Cd_End")
+    return rec, cms
 
 
 class StripTable:
