@@ -157,6 +157,17 @@ int raftx_motion_stats(raftx_ctx *ctx, double dw, double *std, double *psd);
 int raftx_set_linearisation_point(raftx_ctx *ctx, const raftx_c128 *XiLast0, int keep_last);
 int raftx_fetch_linearisation_point(raftx_ctx *ctx, raftx_c128 *XiLast);
 
+/* Statistics of LINEAR OUTPUT CHANNELS of the resident responses: channel c of design d is
+ *   y_c(w) = w^pow[c] * sum_j L[d,c,j] Xi[d,case,ih,j,w]
+ * (real L: a rigid-body transfer to another point, a tension Jacobian row, a unit conversion ...), and
+ *   std[d,case,c] = sqrt(0.5 sum_{ih,w} |y_c|^2),   psd[d,case,c,w] = sum_ih 0.5 |y_c|^2 / dw   (optional).
+ * This is the getRMS/getPSD pattern of FOWT.saveTurbineOutputs for the nacelle accelerations
+ * (raft/raft_fowt.py:2422-2444: hub rows of T, pow = 2) and the quasi-static mooring tensions
+ * (:2367-2373: rows of J_moor, pow = 0); raftx_motion_stats is the special case L = diag(1,1,1,deg,deg,deg).
+ * L [nDesign,nChan,6], pow [nChan] (0..4), std [nDesign,nCase,nChan], psd [nDesign,nCase,nChan,nw] or NULL. */
+int raftx_channel_stats(raftx_ctx *ctx, int nChan, const double *L, const int32_t *pow, double dw,
+                        double *std, double *psd);
+
 /* Coupled array solve, raft_model.py:1164-1236: for each system s and bin w
  *   Z_sys = blockdiag_i(Zblk[s,i]) + (-w^2 Mc[s] + i w Bc[s] + Cc[s]);
  *   Xi[s,r] = Z_sys^-1 F[s,r].

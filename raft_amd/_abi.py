@@ -24,7 +24,7 @@ EXPORTS = (
     "raftx_last_error", "raftx_upload_designs", "raftx_upload_cases",
     "raftx_excitation", "raftx_linearize", "raftx_solve_dynamics",
     "raftx_solve_system", "raftx_last_kernel_ms",
-    "raftx_solve_dynamics_device", "raftx_fetch_results", "raftx_debug_math", "raftx_motion_stats", "raftx_solve_system_resident", "raftx_qtf_slender", "raftx_set_linearisation_point", "raftx_fetch_linearisation_point",
+    "raftx_solve_dynamics_device", "raftx_fetch_results", "raftx_debug_math", "raftx_motion_stats", "raftx_solve_system_resident", "raftx_qtf_slender", "raftx_channel_stats", "raftx_set_linearisation_point", "raftx_fetch_linearisation_point",
 )
 WANT_BDRAG, WANT_FWAVE, WANT_Z = 1, 2, 4
 
@@ -98,6 +98,8 @@ class RaftxLib:
         L.raftx_set_linearisation_point.restype = C.c_int
         L.raftx_fetch_linearisation_point.argtypes = [_vp, _vp]
         L.raftx_fetch_linearisation_point.restype = C.c_int
+        L.raftx_channel_stats.argtypes = [_vp, C.c_int, _vp, _vp, C.c_double, _vp, _vp]
+        L.raftx_channel_stats.restype = C.c_int
         L.raftx_motion_stats.argtypes = [_vp, C.c_double, _vp, _vp]
         L.raftx_motion_stats.restype = C.c_int
         L.raftx_debug_math.argtypes = [_vp, C.c_int, _vp, _vp, _vp, _vp]
@@ -303,6 +305,22 @@ class Context:
         X = np.empty((self.nDesign, self.nCase, 6, self.nw), dtype=np.complex128)
         self._check(self.rlib.lib.raftx_fetch_linearisation_point(self._h, _ptr(X)), "raftx_fetch_linearisation_point")
         return X
+
+    def channel_stats(self, L, pow, dw, want_psd=False):
+        """std [nDesign,nCase,nChan] (and PSD) of the linear channels y_c = w^pow[c] * L[d,c,:] . Xi of the resident results."""
+        L = _f64(L)
+        if L.ndim == 2:
+            L = np.ascontiguousarray(np.broadcast_to(L, (self.nDesign,) + L.shape))
+        nCh = L.shape[1]
+        L = _f64(L, (self.nDesign, nCh, 6), "L")
+        pw = np.ascontiguousarray(pow, dtype=np.int32)
+        if pw.shape != (nCh,):
+            raise ValueError("pow must have one entry per channel")
+        std = np.empty((self.nDesign, self.nCase, nCh), dtype=np.float64)
+        psd = np.empty((self.nDesign, self.nCase, nCh, self.nw), dtype=np.float64) if want_psd else None
+        rc = self.rlib.lib.raftx_channel_stats(self._h, nCh, _ptr(L), _ptr(pw), float(dw), _ptr(std), _ptr(psd))
+        self._check(rc, "raftx_channel_stats")
+        return std, psd
 
     def motion_stats(self, dw, want_psd=False):
         """std [nDesign,nCase,6] (rotations in deg) and optionally PSD [nDesign,nCase,6,nw] of the resident results."""

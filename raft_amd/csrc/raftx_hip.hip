@@ -163,6 +163,47 @@ __global__ void __launch_bounds__(256) k_motion_stats(int npair, int nHead, int 
     }
 }
 
+// Statistics of linear output channels y_c = w^p sum_j L[c,j] Xi_j (hub accelerations, tension Jacobian rows ...):
+// one workgroup per (design, case); the Xi slab is streamed once per channel (L2-resident after the first).
+__global__ void __launch_bounds__(256) k_channel_stats(int nCase, int nHead, int nw, int nChan, double inv_dw,
+                                                       const double *__restrict__ w, const cplx *__restrict__ Xi,
+                                                       const double *__restrict__ L, const int *__restrict__ pw,
+                                                       double *__restrict__ sd, double *__restrict__ psd) {
+    __shared__ double part[4];
+    const int p = blockIdx.x, d = p / nCase;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    for (int ch = 0; ch < nChan; ch++) {
+        const double *row = L + ((size_t)d * nChan + ch) * 6;
+        const double l0 = row[0], l1 = row[1], l2 = row[2], l3 = row[3], l4 = row[4], l5 = row[5];
+        const int pe = pw[ch];
+        double acc = 0.0;
+        for (int i = threadIdx.x; i < nw; i += blockDim.x) {
+            double ws = 1.0;
+            for (int e = 0; e < pe; e++) ws *= w[i];
+            double a2 = 0.0;
+            for (int ih = 0; ih < nHead; ih++) {
+                const cplx *x = Xi + (((size_t)p * nHead + ih) * 6) * nw + i;
+                const cplx x0 = x[0], x1 = x[(size_t)nw], x2 = x[(size_t)2 * nw], x3 = x[(size_t)3 * nw], x4 = x[(size_t)4 * nw],
+                           x5 = x[(size_t)5 * nw];
+                const double yr = ws * (l0 * x0.re + l1 * x1.re + l2 * x2.re + l3 * x3.re + l4 * x4.re + l5 * x5.re);
+                const double yi = ws * (l0 * x0.im + l1 * x1.im + l2 * x2.im + l3 * x3.im + l4 * x4.im + l5 * x5.im);
+                a2 += yr * yr + yi * yi;
+            }
+            acc += a2;
+            if (psd) psd[((size_t)p * nChan + ch) * nw + i] = 0.5 * a2 * inv_dw;
+        }
+        for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
+        __syncthreads();
+        if (lane == 0) part[wv] = acc;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            double a = 0.0;
+            for (int q = 0; q < (int)(blockDim.x >> 6); q++) a += part[q];
+            sd[(size_t)p * nChan + ch] = sqrt(0.5 * a);
+        }
+    }
+}
+
 // ------------------------------------------------------------------ host side
 struct raftx_ctx {
     int device;
@@ -812,6 +853,37 @@ extern "C" int raftx_motion_stats(raftx_ctx *c, double dw, double *sd, double *p
     if (finish_timed(c)) return -2;
     if (npair) D2H(c, sd, dS, npair * 6 * sizeof(double));
     if (npair && psd) D2H(c, psd, dP, npair * 6 * T.nw * sizeof(double));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+extern "C" int raftx_channel_stats(raftx_ctx *c, int nChan, const double *L, const int32_t *pw, double dw, double *sd,
+                                   double *psd) {
+    if (!c) return -1;
+    if (!c->rXi) FAIL(c, "channel_stats: no resident results");
+    if (nChan < 0 || (nChan && (!L || !pw)) || !sd) FAIL(c, "channel_stats: bad arguments");
+    if (!(dw > 0.0)) FAIL(c, "channel_stats: dw must be positive");
+    for (int i = 0; i < nChan; i++)
+        if (pw[i] < 0 || pw[i] > 4) FAIL(c, "channel_stats: pow[%d]=%d outside 0..4", i, pw[i]);
+    HIPCHK(c, hipSetDevice(c->device));
+    const DevTables &T = c->T;
+    const size_t npair = c->r_npair;
+    Scratch sc(c);
+    double *dL = sc.alloc<double>((size_t)T.nDesign * nChan * 6), *dS = sc.alloc<double>(npair * nChan);
+    int *dP = sc.alloc<int>(nChan);
+    double *dPsd = psd ? sc.alloc<double>(npair * nChan * T.nw) : nullptr;
+    if (npair && nChan && (!dL || !dS || !dP || (psd && !dPsd))) FAIL(c, "channel_stats: device allocation failed");
+    if (npair && nChan) {
+        H2D(c, dL, L, (size_t)T.nDesign * nChan * 6 * sizeof(double));
+        H2D(c, dP, pw, nChan * sizeof(int));
+    }
+    HIPCHK(c, hipEventRecord(c->ev0, c->stream));
+    if (npair && nChan)
+        hipLaunchKernelGGL(k_channel_stats, dim3((unsigned)npair), dim3(T.nw > 128 ? 256 : (T.nw > 64 ? 128 : 64)), 0,
+                           c->stream, T.nCase, T.nHead, T.nw, nChan, 1.0 / dw, T.w, c->rXi, dL, dP, dS, dPsd);
+    if (finish_timed(c)) return -2;
+    if (npair && nChan) D2H(c, sd, dS, npair * nChan * sizeof(double));
+    if (npair && nChan && psd) D2H(c, psd, dPsd, npair * nChan * T.nw * sizeof(double));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     return 0;
 }

@@ -206,6 +206,22 @@ def test_motion_stats_parity(hip_ctx, oracle_ctx):
     assert none is None and np.array_equal(std_only, out[0][0])
 
 
+def test_channel_stats_parity(hip_ctx, oracle_ctx):
+    rng = np.random.default_rng(808)
+    tables = [random_strips(rng, S) for S in (40, 53, 7)]
+    mats = random_matrices(rng, 3)
+    cases = synthetic_cases(rng, 2, 2, 200)
+    _both(hip_ctx, oracle_ctx, tables, mats, cases)
+    L = rng.normal(size=(3, 5, 6)) * np.array([1, 1, 1, 50, 50, 50])
+    pw = [0, 2, 2, 1, 4]
+    out = []
+    for ctx in (hip_ctx, oracle_ctx):
+        ctx.solve_dynamics_device(5, 0.01, 0.1)
+        out.append(ctx.channel_stats(L, pw, 0.031, want_psd=True))
+    assert rel_err(out[0][0], out[1][0]) < TOL
+    assert rel_err(out[0][1], out[1][1]) < TOL
+
+
 def test_repeat_runs_are_bitwise_identical(hip_ctx):
     rng = np.random.default_rng(7)
     tables = [random_strips(rng, 53) for _ in range(4)]

@@ -105,3 +105,28 @@ def test_farm_batch_matches_live_reference(oracle_ctx):
         nH = c["Xi"].shape[0] - 1
         assert group_rel_err(out["Xi"][0, i, :nH], c["Xi"][:nH]) < 1e-10
         assert [int(out["niter"][u, i]) for u in range(4)] == [int(c["units"][u]["niter"]) for u in range(4)]
+
+
+def test_channel_stats_reproduce_nacelle_acceleration_formulae(oracle_ctx):
+    """raft_fowt.py:2422-2444: AxRNA/AyRNA/AzRNA std and PSD = getRMS/getPSD of (hub motion) * w^2, the hub motion
+    being the rigid transfer T_hub @ Xi (helpers.py:396-402) -- evaluated with NumPy on the live-reference response."""
+    from raft_amd import waves
+    fx, model = load_model_fixture("pose_volturnus_mcf.npz")
+    eng = dropin.Engine(oracle_ctx)
+    c = fx["cases"][0]
+    Xi = eng.solveDynamics(model, case_from_fixture(c))
+    f = model.fowtList[0]
+    nH = Xi.shape[0] - 1
+    arm = np.array([-12.0, 0.0, 150.0])                       # hub relative to the platform reference point
+    H = np.array([[0, arm[2], -arm[1]], [-arm[2], 0, arm[0]], [arm[1], -arm[0], 0]])
+    L = np.hstack([np.eye(3), H])                             # translation rows of T_hub
+    std, psd = oracle_ctx.channel_stats(L, [2, 2, 2], f.dw, want_psd=True)
+    for j in range(3):
+        hub = c["Xi"][:nH, :3, :][:, j, :] + np.einsum("k,hkw->hw", H[j], c["Xi"][:nH, 3:, :])
+        acc = hub * f.w ** 2
+        assert abs(std[0, 0, j] - np.sqrt(0.5 * np.sum(np.abs(acc) ** 2))) < 1e-9 * std[0, 0, j]
+        np.testing.assert_allclose(psd[0, 0, j], waves.get_psd(acc, f.dw), rtol=1e-8, atol=1e-300)
+    m_std, _ = oracle_ctx.motion_stats(f.dw)
+    r2d = np.rad2deg(1.0)
+    c_std, _ = oracle_ctx.channel_stats(np.diag([1, 1, 1, r2d, r2d, r2d]), [0] * 6, f.dw)
+    assert np.allclose(m_std, c_std, rtol=1e-13)
