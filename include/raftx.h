@@ -193,12 +193,23 @@ int raftx_solve_system_resident(raftx_ctx *ctx, int nUnit, const double *Mc, con
  * strips [stripOff[nSet],24] / members [memOff[nSet],16]: records of raft_amd/qtf.py (QS_N, QM_N);
  * Xi [nSet,6,nw2] motion RAOs on that grid (zeros = fixed body); beta [nSet] rad; Mstruc [nSet,6,6];
  * kay [nSet,nw2,nw2,6] optional Kim & Yue table (raft_member.py:1676-1791; upper triangle, host feeder);
- * qtf [nSet,nw2,nw2,6] out, Hermitian-completed.  Independent of the upload_* state of the ctx. */
+ * qtf [nSet,nw2,nw2,6] out, Hermitian-completed (may be NULL: the result then only stays resident in HBM
+ * for raftx_qtf_force).  Independent of the upload_* state of the ctx. */
 int raftx_qtf_slender(raftx_ctx *ctx, int nSet, int nw2, const double *w2, const double *k2,
                       double depth, double rho, double g,
                       const int64_t *stripOff, const double *strips, const int64_t *memOff, const double *members,
                       const raftx_c128 *Xi, const double *beta, const double *Mstruc,
                       const raftx_c128 *kay, raftx_c128 *qtf);
+
+/* Second-order difference-frequency force amplitudes from QTFs -- FOWT.calcHydroForce_2ndOrd with
+ * interpMode='qtf' (raft/raft_fowt.py:2209-2245): for every set, bilinear interpolation of the QTF from the
+ * second-order grid w2 onto the first-order grid w (outside the grid: 0, like RegularGridInterpolator with
+ * fill_value=0), then  f[j,mu] = 4 sqrt(sum_i S0[i] S0[i+mu] |Q_j(w_i, w_{i+mu})|^2) dw,
+ * f_mean[j] = 2 sum_i S0[i] Re Q_j(w_i,w_i) dw, and the one-bin shift of :2241-2245.
+ * qtf [nSet,nw2,nw2,6] host buffer, or NULL to use the QTFs left resident by the last raftx_qtf_slender
+ * call on this ctx (same nSet, nw2).  S0 [nSet,nw]; f_mean [nSet,6]; f [nSet,6,nw] (real amplitudes). */
+int raftx_qtf_force(raftx_ctx *ctx, int nSet, int nw2, const double *w2, const raftx_c128 *qtf,
+                    int nw, const double *w, double dw, const double *S0, double *f_mean, double *f);
 
 /* Duration (ms) of the device work of the last raftx_excitation /
  * raftx_linearize / raftx_solve_dynamics / raftx_solve_system call on this

@@ -24,7 +24,7 @@ EXPORTS = (
     "raftx_last_error", "raftx_upload_designs", "raftx_upload_cases",
     "raftx_excitation", "raftx_linearize", "raftx_solve_dynamics",
     "raftx_solve_system", "raftx_last_kernel_ms",
-    "raftx_solve_dynamics_device", "raftx_fetch_results", "raftx_debug_math", "raftx_motion_stats", "raftx_solve_system_resident", "raftx_qtf_slender", "raftx_channel_stats", "raftx_set_linearisation_point", "raftx_fetch_linearisation_point",
+    "raftx_solve_dynamics_device", "raftx_fetch_results", "raftx_debug_math", "raftx_motion_stats", "raftx_solve_system_resident", "raftx_qtf_slender", "raftx_channel_stats", "raftx_qtf_force", "raftx_set_linearisation_point", "raftx_fetch_linearisation_point",
 )
 WANT_BDRAG, WANT_FWAVE, WANT_Z = 1, 2, 4
 
@@ -98,6 +98,8 @@ class RaftxLib:
         L.raftx_set_linearisation_point.restype = C.c_int
         L.raftx_fetch_linearisation_point.argtypes = [_vp, _vp]
         L.raftx_fetch_linearisation_point.restype = C.c_int
+        L.raftx_qtf_force.argtypes = [_vp, C.c_int, C.c_int, _vp, _vp, C.c_int, _vp, C.c_double, _vp, _vp, _vp]
+        L.raftx_qtf_force.restype = C.c_int
         L.raftx_channel_stats.argtypes = [_vp, C.c_int, _vp, _vp, C.c_double, _vp, _vp]
         L.raftx_channel_stats.restype = C.c_int
         L.raftx_motion_stats.argtypes = [_vp, C.c_double, _vp, _vp]
@@ -268,7 +270,23 @@ class Context:
         self._check(rc, "raftx_solve_system_resident")
         return Xi
 
-    def qtf_slender(self, tables, Xi, beta, w2, k2, depth, rho, g, Mstruc, kay=None):
+    def qtf_force(self, w2, w, dw, S0, qtf=None, n_set=None):
+        """(f_mean [nSet,6], f [nSet,6,nw]) from QTFs: qtf [nSet,nw2,nw2,6], or None to use the QTFs left resident by
+        the last qtf_slender call (give n_set)."""
+        w2, w = _f64(w2), _f64(w)
+        S0 = _f64(S0)
+        nS = S0.shape[0] if n_set is None else int(n_set)
+        S0 = _f64(S0, (nS, len(w)), "S0")
+        if qtf is not None:
+            qtf = _c128(qtf, (nS, len(w2), len(w2), 6), "qtf")
+        f_mean = np.empty((nS, 6))
+        f = np.empty((nS, 6, len(w)))
+        rc = self.rlib.lib.raftx_qtf_force(self._h, nS, len(w2), _ptr(w2), _ptr(qtf), len(w), _ptr(w), float(dw), _ptr(S0),
+                                           _ptr(f_mean), _ptr(f))
+        self._check(rc, "raftx_qtf_force")
+        return f_mean, f
+
+    def qtf_slender(self, tables, Xi, beta, w2, k2, depth, rho, g, Mstruc, kay=None, fetch=True):
         """Batch of slender-body QTFs: tables = list of raft_amd.qtf.QtfTable (one per set), Xi [nSet,6,nw2],
         beta [nSet], Mstruc [nSet,6,6], kay [nSet,nw2,nw2,6] or None -> qtf [nSet,nw2,nw2,6]."""
         nS = len(tables)
@@ -286,7 +304,7 @@ class Context:
         beta = _f64(beta, (nS,), "beta")
         Mstruc = _f64(Mstruc, (nS, 6, 6), "Mstruc")
         kay = None if kay is None else _c128(kay, (nS, nw2, nw2, 6), "kay")
-        qtf = np.empty((nS, nw2, nw2, 6), dtype=np.complex128)
+        qtf = np.empty((nS, nw2, nw2, 6), dtype=np.complex128) if fetch else None
         rc = self.rlib.lib.raftx_qtf_slender(self._h, nS, nw2, _ptr(w2), _ptr(k2), float(depth), float(rho), float(g),
                                              _ptr(soff), _ptr(strips), _ptr(moff), _ptr(members), _ptr(Xi), _ptr(beta),
                                              _ptr(Mstruc), _ptr(kay), _ptr(qtf))

@@ -216,6 +216,9 @@ struct raftx_ctx {
     cplx *rXi, *rFw, *rZ, *rFe;
     double *rB, *rXl;
     size_t rXl_n;
+    cplx *rQtf;                          // QTFs of the last raftx_qtf_slender call, kept for raftx_qtf_force
+    size_t rQtf_n;
+    int rQtf_sets, rQtf_nw2;
     cplx *rXl0, *rXlOut;                 // optional restart point / exported linearisation point [npair,6,nw]
     size_t rXlio_n;
     bool have_xl0, want_xlout;
@@ -268,6 +271,9 @@ extern "C" int raftx_ctx_create(int device_id, raftx_ctx **out) {
     c->rXi = c->rFw = c->rZ = c->rFe = nullptr;
     c->rB = c->rXl = nullptr;
     c->rXl_n = 0;
+    c->rQtf = nullptr;
+    c->rQtf_n = 0;
+    c->rQtf_sets = c->rQtf_nw2 = 0;
     c->rXl0 = c->rXlOut = nullptr;
     c->rXlio_n = 0;
     c->have_xl0 = c->want_xlout = false;
@@ -300,6 +306,7 @@ extern "C" void raftx_ctx_destroy(raftx_ctx *c) {
     if (c->rXl) (void)hipFree(c->rXl);
     if (c->rXl0) (void)hipFree(c->rXl0);
     if (c->rXlOut) (void)hipFree(c->rXlOut);
+    if (c->rQtf) (void)hipFree(c->rQtf);
     (void)hipEventDestroy(c->ev0);
     (void)hipEventDestroy(c->ev1);
     (void)hipStreamDestroy(c->stream);
@@ -966,7 +973,7 @@ extern "C" int raftx_qtf_slender(raftx_ctx *c, int nSet, int nw2, const double *
                                  const int64_t *memOff, const double *members, const raftx_c128 *Xi,
                                  const double *beta, const double *Mstruc, const raftx_c128 *kay, raftx_c128 *qtf) {
     if (!c) return -1;
-    if (nSet < 0 || nw2 < 1 || !w2 || !k2 || !stripOff || !memOff || !Xi || !beta || !Mstruc || !qtf)
+    if (nSet < 0 || nw2 < 1 || !w2 || !k2 || !stripOff || !memOff || !Xi || !beta || !Mstruc)
         FAIL(c, "qtf_slender: bad arguments");
     HIPCHK(c, hipSetDevice(c->device));
     const size_t nStrip = (size_t)stripOff[nSet], nMem = (size_t)memOff[nSet];
@@ -991,7 +998,19 @@ extern "C" int raftx_qtf_slender(raftx_ctx *c, int nSet, int nw2, const double *
     int *dss = sc.alloc<int>(nStrip), *dms = sc.alloc<int>(nMem);
     cplx *dXi = sc.alloc<cplx>((size_t)nSet * 6 * nw2), *dK = kay ? sc.alloc<cplx>(nq) : nullptr;
     cplx *dT = sc.alloc<cplx>(nStrip * QT_N * nw2), *dTM = sc.alloc<cplx>(nMem * QTM_N * nw2),
-         *dTS = sc.alloc<cplx>((size_t)nSet * QTS_N * nw2), *dQ = sc.alloc<cplx>(nq);
+         *dTS = sc.alloc<cplx>((size_t)nSet * QTS_N * nw2);
+    if (c->rQtf_n < nq || !c->rQtf) {                    // the result stays resident (raftx_qtf_force can reuse it)
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        if (c->rQtf) (void)hipFree(c->rQtf);
+        c->rQtf = nullptr;
+        void *p_ = nullptr;
+        HIPCHK(c, hipMalloc(&p_, (nq ? nq : 1) * sizeof(cplx)));
+        c->rQtf = reinterpret_cast<cplx *>(p_);
+        c->rQtf_n = nq;
+    }
+    c->rQtf_sets = nSet;
+    c->rQtf_nw2 = nw2;
+    cplx *dQ = c->rQtf;
     if (nSet && (!dw || !dk || (nStrip && (!dS || !dss || !dT)) || (nMem && (!dM || !dms || !dTM)) || !dB || !dMs || !dso ||
                  !dmo || !dXi || (kay && !dK) || !dTS || !dQ))
         FAIL(c, "qtf_slender: device allocation failed");
@@ -1018,7 +1037,48 @@ extern "C" int raftx_qtf_slender(raftx_ctx *c, int nSet, int nw2, const double *
         hipLaunchKernelGGL(k_qtf_pairs, dim3((unsigned)((size_t)nSet * nw2)), dim3(nw2 > 64 ? 128 : 64), 0, c->stream, A);
     }
     if (finish_timed(c)) return -2;
-    if (nSet) D2H(c, qtf, dQ, nq * sizeof(cplx));
+    if (nSet && qtf) D2H(c, qtf, dQ, nq * sizeof(cplx));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+extern "C" int raftx_qtf_force(raftx_ctx *c, int nSet, int nw2, const double *w2, const raftx_c128 *qtf, int nw,
+                               const double *w, double dw, const double *S0, double *f_mean, double *f) {
+    if (!c) return -1;
+    if (nSet < 0 || nw2 < 2 || nw < 1 || !w2 || !w || !S0 || !f_mean || !f) FAIL(c, "qtf_force: bad arguments");
+    HIPCHK(c, hipSetDevice(c->device));
+    const size_t nq = (size_t)nSet * nw2 * nw2 * 6;
+    Scratch sc(c);
+    const cplx *dQ = nullptr;
+    if (qtf) {
+        cplx *t = sc.alloc<cplx>(nq);
+        if (nq && !t) FAIL(c, "qtf_force: device allocation failed");
+        if (nq) H2D(c, t, qtf, nq * sizeof(cplx));
+        dQ = t;
+    } else {
+        if (!c->rQtf || c->rQtf_sets != nSet || c->rQtf_nw2 != nw2)
+            FAIL(c, "qtf_force: no resident QTFs of this shape (run raftx_qtf_slender first or pass qtf)");
+        dQ = c->rQtf;
+    }
+    double *dw2 = sc.alloc<double>(nw2), *dwv = sc.alloc<double>(nw), *dS = sc.alloc<double>((size_t)nSet * nw),
+           *dfm = sc.alloc<double>((size_t)nSet * 6), *df = sc.alloc<double>((size_t)nSet * 6 * nw);
+    if (nSet && (!dw2 || !dwv || !dS || !dfm || !df)) FAIL(c, "qtf_force: device allocation failed");
+    if (nSet) {
+        H2D(c, dw2, w2, nw2 * sizeof(double));
+        H2D(c, dwv, w, nw * sizeof(double));
+        H2D(c, dS, S0, (size_t)nSet * nw * sizeof(double));
+    }
+    HIPCHK(c, hipEventRecord(c->ev0, c->stream));
+    if (nSet) {
+        const size_t lds = sizeof(double) * ((size_t)nw + (nw + 1) / 2 + 8);
+        hipLaunchKernelGGL(k_qtf_force, dim3((unsigned)(nSet * 6)), dim3(256), lds, c->stream, nSet, nw2, dw2, dQ, nw, dwv, dw,
+                           dS, dfm, df);
+    }
+    if (finish_timed(c)) return -2;
+    if (nSet) {
+        D2H(c, f_mean, dfm, (size_t)nSet * 6 * sizeof(double));
+        D2H(c, f, df, (size_t)nSet * 6 * nw * sizeof(double));
+    }
     HIPCHK(c, hipStreamSynchronize(c->stream));
     return 0;
 }

@@ -391,3 +391,63 @@ __global__ void __launch_bounds__(128) k_qtf_pairs(QtfArgs A) {
         }
     }
 }
+
+
+// ---- second-order force amplitudes from the QTF (raft_fowt.py:2209-2245): grid (nSet * 6), threads stride the
+// difference-frequency index mu.  Interpolation indices / weights of the first-order bins on the second-order grid
+// are built once per workgroup in LDS (np.searchsorted - 1 clipped to [0, n-2], RegularGridInterpolator rules).
+__global__ void __launch_bounds__(256) k_qtf_force(int nSet, int nw2, const double *__restrict__ w2,
+                                                   const cplx *__restrict__ qtf, int nw, const double *__restrict__ w,
+                                                   double dw, const double *__restrict__ S0, double *__restrict__ f_mean,
+                                                   double *__restrict__ f) {
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    double *tw = smem;                                    // [nw] norm. distance, < 0 marks "outside the grid"
+    int *ix = reinterpret_cast<int *>(smem + nw);        // [nw]
+    double *red = smem + nw + (nw + 1) / 2;               // [4]
+    const int set = blockIdx.x / 6, j = blockIdx.x % 6;
+    for (int i = threadIdx.x; i < nw; i += blockDim.x) {
+        const double x = w[i];
+        int lo = 0, hi = nw2;                             // searchsorted(w2, x, side='left')
+        while (lo < hi) {
+            int mid = (lo + hi) >> 1;
+            if (w2[mid] < x) lo = mid + 1; else hi = mid;
+        }
+        int k = lo - 1;
+        k = k < 0 ? 0 : (k > nw2 - 2 ? nw2 - 2 : k);
+        ix[i] = k;
+        tw[i] = (x < w2[0] || x > w2[nw2 - 1]) ? -1.0 : (x - w2[k]) / (w2[k + 1] - w2[k]);
+    }
+    __syncthreads();
+    const cplx *Q = qtf + (size_t)set * nw2 * nw2 * 6 + j;
+    const double *S = S0 + (size_t)set * nw;
+    auto interp = [&](int a, int b) -> cplx {             // Q_j(w_a, w_b)
+        const double ta = tw[a], tb = tw[b];
+        if (ta < 0.0 || tb < 0.0) return cplx{0.0, 0.0};
+        const int ia = ix[a], ib = ix[b];
+        const cplx q00 = Q[((size_t)ia * nw2 + ib) * 6], q01 = Q[((size_t)ia * nw2 + ib + 1) * 6];
+        const cplx q10 = Q[((size_t)(ia + 1) * nw2 + ib) * 6], q11 = Q[((size_t)(ia + 1) * nw2 + ib + 1) * 6];
+        const double w00 = (1.0 - ta) * (1.0 - tb), w01 = (1.0 - ta) * tb, w10 = ta * (1.0 - tb), w11 = ta * tb;
+        return cplx{w00 * q00.re + w01 * q01.re + w10 * q10.re + w11 * q11.re,
+                    w00 * q00.im + w01 * q01.im + w10 * q10.im + w11 * q11.im};
+    };
+    double *fo = f + ((size_t)set * 6 + j) * nw;
+    for (int mu = 1 + threadIdx.x; mu < nw; mu += blockDim.x) {
+        double acc = 0.0;
+        for (int i = 0; i + mu < nw; i++) {
+            const cplx q = interp(i, i + mu);
+            acc += S[i] * S[i + mu] * (q.re * q.re + q.im * q.im);
+        }
+        fo[mu - 1] = 4.0 * sqrt(acc) * dw;                // written one bin lower: the shift of :2241-2245
+    }
+    if (threadIdx.x == 0) fo[nw - 1] = 0.0;
+    double m = 0.0;
+    for (int i = threadIdx.x; i < nw; i += blockDim.x) m += S[i] * interp(i, i).re;
+    for (int o = 32; o > 0; o >>= 1) m += __shfl_xor(m, o, 64);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double a = 0.0;
+        for (int q = 0; q < (int)(blockDim.x >> 6); q++) a += red[q];
+        f_mean[(size_t)set * 6 + j] = 2.0 * a * dw;
+    }
+}

@@ -199,6 +199,10 @@ class Engine:
         q = rq.interp_heading(fowt.qtf, heads, beta)
         if interpMode == 'spectrum':
             f_mean, f = rq.hydro_force_2nd_spectrum(q, np.asarray(fowt.w1_2nd), fowt.w, fowt.dw, S0)
+        elif self._qtf_backend is None:                     # device: bilinear interpolation + diagonal sums (raftx_qtf_force)
+            fm, ff = self.ctx.qtf_force(np.asarray(fowt.w1_2nd), fowt.w, fowt.dw, np.asarray(S0, dtype=float)[None],
+                                        qtf=np.ascontiguousarray(q)[None])
+            f_mean, f = fm[0], ff[0]
         else:
             f_mean, f = rq.hydro_force_2nd(q, np.asarray(fowt.w1_2nd), fowt.w, fowt.dw, S0)
         out_dir = getattr(fowt, "outFolderQTF", None)

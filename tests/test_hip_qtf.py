@@ -109,3 +109,23 @@ def test_restart_from_linearisation_point(hip_ctx, oracle_ctx):
         from tests.util import group_rel_err
         assert group_rel_err(res[0][1]["Xi"][d], res[0][0]["Xi"][d]) < 1e-13
         assert group_rel_err(res[0][1]["Xi"][d], res[1][1]["Xi"][d]) < TOL
+
+
+def test_qtf_force_kernel(hip_ctx):
+    """raftx_qtf_force against the SciPy restatement of calcHydroForce_2ndOrd (pinned on the live reference in
+    tests/test_qtf.py), from a host QTF and from the QTFs left resident by raftx_qtf_slender."""
+    fx, f, tab = _setup("VolturnUS-S")
+    w2, k2 = f.w1_2nd, f.k1_2nd
+    beta = fx["motion_beta"]
+    S0 = fx["motion_S0"]
+    fm, ff = hip_ctx.qtf_force(w2, f.w, f.dw, np.array([S0, 0.5 * S0]), qtf=np.array([fx["motion_qtf"], fx["fixed_qtf"]]))
+    assert rel_err(ff[0], fx["motion_f2"]) < TOL and rel_err(fm[0], fx["motion_f_mean"]) < TOL
+    r_mean, r_f = rq.hydro_force_2nd(fx["fixed_qtf"], w2, f.w, f.dw, 0.5 * S0)
+    assert rel_err(ff[1], r_f) < TOL and rel_err(fm[1], r_mean) < TOL
+    # resident path: QTFs never leave the device
+    kay = rq.kay_correction(tab.kay_geom, w2, k2, beta, f.depth, rho=f.rho_water, g=f.g)
+    none = hip_ctx.qtf_slender([tab], fx["motion_Xi2"][None], [beta], w2, k2, f.depth, f.rho_water, f.g, f.M_struc[None],
+                               kay[None], fetch=False)
+    assert none is None
+    fm2, ff2 = hip_ctx.qtf_force(w2, f.w, f.dw, S0[None], qtf=None, n_set=1)
+    assert rel_err(ff2[0], fx["motion_f2"]) < TOL and rel_err(fm2[0], fx["motion_f_mean"]) < TOL
