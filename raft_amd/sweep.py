@@ -141,6 +141,47 @@ class Sweep:
         r = ctx.fetch_results(want_Xi=False)
         return {"Xi": Xi, "niter": r["niter"], "flags": r["flags"], "kernel_ms": (t_units, ctx.last_kernel_ms())}
 
+    def run_second_order(self, ctx, qtf_tables, Mstruc, w2, k2, S0, rho_water=1025.0, kay=None):
+        """potSecOrder == 1 for a whole batch (single wave heading): first-order fixed point, slender-body QTFs from the
+        converged motions, second-order force, restarted fixed point (raft_model.py:1108-1131) -- five launches in total,
+        QTFs never leave the device.  qtf_tables: one raft_amd.qtf.QtfTable per design; Mstruc [nD,6,6];
+        S0 [nCase,nw] wave spectra; kay: optional list (per design) of Kim & Yue tables for the sea states' heading,
+        [nCase][nw2,nw2,6] each.  Returns Xi, niter (both stages), flags, Fhydro_2nd [nD,nCase,6,nw]."""
+        from . import waves
+        if self.n_head != 1:
+            raise ValueError("run_second_order handles single-heading sea states")
+        nD, nC, nw, n2 = self.n_design, self.n_case, self.nw, len(w2)
+        self.upload(ctx)
+        ctx.set_linearisation_point(None, keep_last=True)
+        ctx.solve_dynamics_device(self.nIter, self.tol, self.XiStart)
+        r1 = ctx.fetch_results(want_Xi=True)
+        XiLast = ctx.fetch_linearisation_point()
+        # motion RAOs on the second-order grid (helpers.py:762-784, raft_fowt.py:2022-2024)
+        Xi2 = np.zeros((nD * nC, 6, n2), dtype=complex)
+        for d in range(nD):
+            for c in range(nC):
+                rao = waves.get_rao(r1["Xi"][d, c, 0], self.zeta[c, 0])
+                for j in range(6):
+                    Xi2[d * nC + c, j] = np.interp(w2, self.w, rao[j], left=0, right=0)
+        tabs = [qtf_tables[d] for d in range(nD) for _ in range(nC)]
+        beta = np.array([self.beta[c, 0] for _ in range(nD) for c in range(nC)])
+        Ms = np.array([Mstruc[d] for d in range(nD) for _ in range(nC)])
+        kt = None if kay is None else np.array([kay[d][c] for d in range(nD) for c in range(nC)])
+        ctx.qtf_slender(tabs, Xi2, beta, w2, k2, self.depth, rho_water, self.g, Ms, kt, fetch=False)
+        dw = float(self.w[1] - self.w[0])
+        _, f2 = ctx.qtf_force(w2, self.w, dw, np.array([S0[c] for _ in range(nD) for c in range(nC)]), qtf=None,
+                              n_set=nD * nC)
+        F2 = f2.reshape(nD, nC, 6, nw)
+        ok = (r1["flags"] & 1).astype(bool)                      # only converged pairs take the second stage
+        F_extra = np.where(ok[:, :, None, None], F2, 0.0)[:, :, None].astype(complex)
+        ctx.set_linearisation_point(XiLast, keep_last=False)
+        ctx.solve_dynamics_device(max(self.nIter - 1, 0), self.tol, self.XiStart, F_extra=F_extra)
+        r2 = ctx.fetch_results(want_Xi=True)
+        Xi = np.where(ok[:, :, None, None, None], r2["Xi"], r1["Xi"])
+        niter = np.where(ok, r1["niter"] + r2["niter"], r1["niter"])
+        flags = np.where(ok, r2["flags"], r1["flags"])
+        return {"Xi": Xi, "niter": niter, "flags": flags, "Fhydro_2nd": np.where(ok[:, :, None, None], F2, 0.0)}
+
     def run(self, ctx):
         self.solve(ctx)
         r = ctx.fetch_results(want_Xi=True)

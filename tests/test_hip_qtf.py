@@ -129,3 +129,27 @@ def test_qtf_force_kernel(hip_ctx):
     assert none is None
     fm2, ff2 = hip_ctx.qtf_force(w2, f.w, f.dw, S0[None], qtf=None, n_set=1)
     assert rel_err(ff2[0], fx["motion_f2"]) < TOL and rel_err(fm2[0], fx["motion_f_mean"]) < TOL
+
+
+def test_second_order_sweep_matches_dropin(hip_ctx):
+    """Sweep.run_second_order (batch: 2 copies of the design x 2 sea states) against the live-reference
+    potSecOrder == 1 solveDynamics results of the same deck."""
+    from raft_amd import dropin
+    from tests.util import load_model_fixture, case_from_fixture, group_rel_err
+    fx, model = load_model_fixture("c5_internal_qtf.npz")
+    f = model.fowtList[0]
+    cases = [case_from_fixture(c) for c in fx["cases"]]
+    sweep = dropin.sweep_from_models([model, model], cases)
+    tab = rq.pack_qtf(f)
+    w2, k2 = f.w1_2nd, f.k1_2nd
+    from raft_amd import waves
+    S0 = np.array([waves.sea_state(dict(c), f.w, f.dw)[2][0] for c in cases])
+    kay = [[rq.kay_correction(tab.kay_geom, w2, k2, sweep.beta[c, 0], f.depth, rho=f.rho_water, g=f.g) for c in range(2)]] * 2
+    out = sweep.run_second_order(hip_ctx, [tab, tab], np.array([f.M_struc, f.M_struc]), w2, k2, S0,
+                                 rho_water=f.rho_water, kay=kay)
+    for d in range(2):
+        for i, c in enumerate(fx["cases"]):
+            u = c["units"][0]
+            assert int(out["niter"][d, i]) == int(u["niter"])
+            assert rel_err(out["Fhydro_2nd"][d, i], u["Fhydro_2nd"][0].real) < TOL
+            assert group_rel_err(out["Xi"][d, i, :1], c["Xi"][:1]) < TOL
