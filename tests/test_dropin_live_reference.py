@@ -1,0 +1,117 @@
+"""CPU suite, only where /root/reference is present (skipped on the GPU box): the drop-in methods installed INTO the
+live, unmodified reference package (raft_amd.dropin.install) and driven through the reference's own objects --
+Model / FOWT / Member instances, not the stand-ins -- with the CPU oracle as the backend.  Proves that the binding
+of INTEGRATION.md works on the real attribute surface, and that results equal the reference's NumPy path (computed
+with the package un-patched)."""
+import contextlib
+import copy
+import os
+
+import numpy as np
+import pytest
+
+from oracle import ref_harness as rh
+from tests.util import group_rel_err, rel_err
+
+pytestmark = pytest.mark.skipif(not rh.reference_available(), reason="reference tree not present")
+
+
+def _numpy_qtf_backend(tabs, Xi, beta, w2, k2, depth, rho, g, Ms, kay):
+    from oracle import qtf_oracle
+    return np.array([qtf_oracle.qtf_slender_body(t, Xi[i], beta[i], w2, k2, depth, rho, g, Ms[i], kay[i])
+                     for i, t in enumerate(tabs)])
+
+
+class Patch:
+    def __init__(self, oracle_ctx):
+        from raft_amd import dropin
+        rh.import_raft()
+        self.dropin = dropin
+        dropin._default_engine = dropin.Engine(oracle_ctx, qtf_backend=_numpy_qtf_backend)
+        self.saved = dropin.install()
+
+    @contextlib.contextmanager
+    def unpatched(self):
+        """The reference's own NumPy methods, temporarily restored."""
+        self.dropin.uninstall(self.saved)
+        try:
+            yield
+        finally:
+            self.dropin.install()
+
+    def close(self):
+        self.dropin.uninstall(self.saved)
+        self.dropin._default_engine = self.dropin.Engine()
+
+
+@pytest.fixture()
+def patch(oracle_ctx):
+    p = Patch(oracle_ctx)
+    yield p
+    p.close()
+
+
+def _model(deck, settings):
+    d = rh.prepare_design(rh.load_design(os.path.join(rh.REFERENCE_ROOT, deck)), settings=settings)
+    d["platform"].pop("outFolderQTF", None)
+    m = rh.build_model(d)
+    for f in m.fowtList:
+        f.outFolderQTF = None
+    return m
+
+
+def test_installed_solveDynamics_equals_numpy_path(patch):
+    """OC3spar (C1 settings): the patched Model.solveDynamics on live objects vs the reference's NumPy path."""
+    from raft import raft_model
+    settings = dict(min_freq=0.008, max_freq=0.4, nIter=10, XiStart=0)
+    case = rh.make_case(Hs=2.0, Tp=8.0, heading=20.0)
+    m_new, m_old = _model("designs/OC3spar.yaml", settings), _model("designs/OC3spar.yaml", settings)
+    assert raft_model.Model.solveDynamics is patch.dropin.solveDynamics
+    Xi_new = m_new.solveDynamics(copy.deepcopy(case)).copy()
+    with patch.unpatched():
+        assert raft_model.Model.solveDynamics is not patch.dropin.solveDynamics
+        Xi_old = m_old.solveDynamics(copy.deepcopy(case)).copy()
+    assert Xi_new.shape == Xi_old.shape
+    assert group_rel_err(Xi_new[:1], Xi_old[:1]) < 1e-10
+    fn, fo = m_new.fowtList[0], m_old.fowtList[0]
+    assert rel_err(fn.Z, fo.Z) < 1e-12
+    assert rel_err(fn.B_hydro_drag, fo.B_hydro_drag) < 1e-10
+    assert rel_err(fn.Xi_fullDOF, fo.Xi_fullDOF) < 1e-10
+    assert m_new.results['response'] == {}
+
+
+def test_installed_fowt_methods_on_live_objects(patch):
+    """FOWT.calcHydroExcitation / calcHydroLinearization / calcDragExcitation patched into the live package,
+    against the reference's NumPy methods on a twin model (VolturnUS-S test deck: MacCamy-Fuchs columns)."""
+    settings = dict(nIter=4)
+    case = {'wave_spectrum': 'JONSWAP', 'wave_heading': [10, -35], 'wave_period': [9, 13], 'wave_height': [3, 5]}
+    m_new = _model("tests/test_data/VolturnUS-S.yaml", settings)
+    m_old = _model("tests/test_data/VolturnUS-S.yaml", settings)
+    fn, fo = m_new.fowtList[0], m_old.fowtList[0]
+    Xi = 0.2 * np.exp(1j * np.linspace(0, 5, 6 * fn.nw).reshape(6, fn.nw))
+    fn.calcHydroExcitation(copy.deepcopy(case), memberList=fn.memberList)
+    Bn = fn.calcHydroLinearization(Xi)
+    Fn = [fn.calcDragExcitation(ih).copy() for ih in (0, 1)]
+    with patch.unpatched():
+        fo.calcHydroExcitation(copy.deepcopy(case), memberList=fo.memberList)
+        Bo = fo.calcHydroLinearization(Xi)
+        Fo = [fo.calcDragExcitation(ih).copy() for ih in (0, 1)]
+    assert rel_err(fn.F_hydro_iner, fo.F_hydro_iner) < 1e-12
+    assert np.array_equal(fn.zeta, fo.zeta) and np.array_equal(fn.beta, fo.beta)
+    assert rel_err(Bn, Bo) < 1e-10
+    for a, b in zip(Fn, Fo):
+        assert rel_err(a, b) < 1e-10
+
+
+def test_installed_internal_qtf_on_live_objects(patch):
+    """potSecOrder == 1 through the patched live package (QTF + second-order force + restarted drag iteration)."""
+    settings = dict(nIter=10)
+    case = rh.make_case(Hs=5.0, Tp=11.0, heading=15.0)
+    m_new = _model("tests/test_data/VolturnUS-S.yaml", settings)
+    m_old = _model("tests/test_data/VolturnUS-S.yaml", settings)
+    Xi_new = m_new.solveDynamics(copy.deepcopy(case)).copy()
+    with patch.unpatched():
+        Xi_old = m_old.solveDynamics(copy.deepcopy(case)).copy()
+    assert group_rel_err(Xi_new[:1], Xi_old[:1]) < 1e-9
+    assert rel_err(m_new.fowtList[0].qtf, m_old.fowtList[0].qtf) < 1e-9
+    assert rel_err(m_new.fowtList[0].Fhydro_2nd, m_old.fowtList[0].Fhydro_2nd) < 1e-9
