@@ -59,6 +59,10 @@ extern "C" {
  * evaluated exactly).  Verified against x,y,z at upload; the oracle ignores them. */
 #define RAFTX_F_STEP  28
 #define RAFTX_F_UNIT  29
+/* 30,31: Morison added-mass scalars rho*v_side*Ca_p1, rho*v_side*Ca_p2 (raft_member.py:1333); written by
+ * raftx_build_designs, optional (0) in hand-packed tables -- only raftx_fetch_statics reads them. */
+#define RAFTX_F_AP1   30
+#define RAFTX_F_AP2   31
 
 /* flags[] bits written by raftx_solve_dynamics */
 #define RAFTX_FLAG_CONVERGED 1    /* raft_model.py:1104 test passed */
@@ -210,6 +214,73 @@ int raftx_qtf_slender(raftx_ctx *ctx, int nSet, int nw2, const double *w2, const
  * call on this ctx (same nSet, nw2).  S0 [nSet,nw]; f_mean [nSet,6]; f [nSet,6,nw] (real amplitudes). */
 int raftx_qtf_force(raftx_ctx *ctx, int nSet, int nw2, const double *w2, const raftx_c128 *qtf,
                     int nw, const double *w, double dw, const double *S0, double *f_mean, double *f);
+
+/* ------------------------------------------------------------------------------------------------
+ * Geometry -> strip tables + statics on the device (the step BEFORE the hot path).
+ *
+ * A design is a rigid 6-DOF floating unit described by its members, exactly as the reference's YAML does
+ * (docs/usage.rst "platform: members"): end points, stations, diameters / side pairs, coefficients.
+ * raftx_build_designs discretises every member into Morison strips, places them at the unit's mean pose,
+ * evaluates the per-strip hydrodynamic constants and leaves the result resident as the ctx's design set --
+ * the equivalent of Member.__init__ (strip discretisation, raft/raft_member.py:190-271), Member.setPosition
+ * (:312-377), Member.calcHydroConstants / calcImat / getCmSides (:1261-1486), the drag areas of
+ * Member.calcHydroLinearization (:2061-2110) and FOWT.calcHydroConstants (raft/raft_fowt.py:1589-1625),
+ * followed by raftx_upload_designs -- without the 256 B/strip host packing and upload.
+ *
+ * Member descriptor (RAFTX_GM_N doubles), host feeder raft_amd/geometry.py: */
+#define RAFTX_GM_N        16
+#define RAFTX_GM_RA       0   /* end A relative to the unit's reference point, member heading applied (raft_member.py:41,75-77) */
+#define RAFTX_GM_RB       3   /* end B */
+#define RAFTX_GM_GAMMA    6   /* twist about the axis [deg]; 0 for circular (raft_member.py:70,79-80,106) */
+#define RAFTX_GM_SHAPE    7   /* 1 circular, 0 rectangular (raft_member.py:102-114) */
+#define RAFTX_GM_DLSMAX   8   /* maximum strip length (raft_member.py:202) */
+#define RAFTX_GM_FLAGS    9   /* bit 0: potMod (no strip-theory inertia/added mass), bit 1: MacCamy-Fuchs */
+#define RAFTX_GM_L        10  /* member length |rB - rA| (raft_member.py:72) */
+#define RAFTX_GM_RHOSHELL 11  /* shell density (raft_member.py:124) */
+#define RAFTX_GM_FLAG_POTMOD 1
+#define RAFTX_GM_FLAG_MCF    2
+/* Station record (RAFTX_GS_N doubles); stations of member m are rows stationOff[m]..stationOff[m+1]: */
+#define RAFTX_GS_N        16
+#define RAFTX_GS_S        0   /* position along the axis from end A [m] (raft_member.py:99) */
+#define RAFTX_GS_D        1   /* diameter, or the two side lengths (1,2) (raft_member.py:104,111) */
+#define RAFTX_GS_T        3   /* shell thickness (raft_member.py:123) */
+#define RAFTX_GS_CD       4   /* Cd_q, Cd_p1, Cd_p2, Cd_End (raft_member.py:178-181) */
+#define RAFTX_GS_CA       8   /* Ca_q, Ca_p1, Ca_p2, Ca_End (raft_member.py:184-187) */
+#define RAFTX_GS_LFILL    12  /* ballast fill length of the section that STARTS at this station [m] (:143) */
+#define RAFTX_GS_RHOFILL  13  /* ballast density of that section (:146-155) */
+/* add_mask: what the call adds to the caller's M0 / C0 before installing them (0 = M0/B0/C0 used as given,
+ * exactly like raftx_upload_designs) */
+#define RAFTX_ADD_MORISON     1   /* M0 += A_hydro_morison (raft_fowt.py:1625) */
+#define RAFTX_ADD_HYDROSTATIC 2   /* C0 += C_hydro         (raft_fowt.py:1214-1256) */
+#define RAFTX_ADD_INERTIA     4   /* M0 += M_struc, C0 += C_struc of the described members (raft_fowt.py:841-1120) */
+/* memberOff [nDesign+1] rows of members[.,RAFTX_GM_N]; stationOff [nMember+1] rows of stations[.,RAFTX_GS_N];
+ * pose [nDesign,6] = mean position of the reduced DOFs (x,y,z,roll,pitch,yaw; FOWT.setPosition's argument,
+ * raft_fowt.py:754) or NULL for zeros; rho, g: water density and gravity (raft_fowt.py:172-173);
+ * k [nw] wave numbers for the MacCamy-Fuchs Cm table (required iff a member carries RAFTX_GM_FLAG_MCF);
+ * M0,B0,C0,MBw as in raftx_upload_designs.  stripOffsets [nDesign+1] (out): submerged strips per design.
+ * Only strips below the mean waterline are kept (raft_member.py:1310,1979,2058). */
+int raftx_build_designs(raftx_ctx *ctx, int nDesign, const int64_t *memberOff, const double *members,
+                        const int64_t *stationOff, const double *stations, const double *pose,
+                        double rho, double g, int nw, const double *k, int add_mask,
+                        const double *M0, const double *B0, const double *C0, const double *MBw,
+                        int64_t *stripOffsets);
+/* The strip records (ABI layout, [nStrips,RAFTX_NFIELD]) and MacCamy-Fuchs rows ([nRows,2,nw], may be NULL)
+ * that raftx_build_designs generated -- what raft_amd/strips.py would have packed on the host. */
+int raftx_fetch_strips(raftx_ctx *ctx, double *strips, raftx_c128 *cm);
+/* Per-design statics of the last raftx_build_designs call (any pointer may be NULL):
+ *   A_morison [nDesign,6,6]  FOWT.A_hydro_morison (raft_fowt.py:1589-1625), about the unit's reference point
+ *   C_hydro   [nDesign,6,6]  hydrostatic stiffness (raft_member.py:838-1010, raft_fowt.py:1214-1256)
+ *   W_hydro   [nDesign,6]    buoyancy force/moment vector (same lines)
+ *   M_struc   [nDesign,6,6]  mass/inertia of the described members (raft_member.py:380-836)
+ *   props     [nDesign,8]    V (displaced volume), AWP, rCB x,y,z, mass, zCG ... (RAFTX_SP_*) */
+#define RAFTX_SP_N     8
+#define RAFTX_SP_V     0
+#define RAFTX_SP_AWP   1
+#define RAFTX_SP_RCB   2   /* x,y,z of the centre of buoyancy */
+#define RAFTX_SP_MASS  5
+#define RAFTX_SP_ZCG   6
+int raftx_fetch_statics(raftx_ctx *ctx, double *A_morison, double *C_hydro, double *W_hydro,
+                        double *M_struc, double *props);
 
 /* Duration (ms) of the device work of the last raftx_excitation /
  * raftx_linearize / raftx_solve_dynamics / raftx_solve_system call on this

@@ -317,7 +317,82 @@ def fixture_c5_oc4():
     standin.save_fixture(os.path.join(GOLD, "c5_oc4semi_qtf.npz"), fx)
 
 
-ALL = {"c5oc4": fixture_c5_oc4, "c5": fixture_c5, "qtf": fixture_qtf, "c1": fixture_c1, "c2": fixture_c2, "pose": fixture_pose,
+def _design_subset(design):
+    """JSON of the parts of a design dict the member descriptors are parsed from (taken BEFORE the reference
+    mutates the dict)."""
+    import json
+    sub = {"site": design.get("site", {}), "platform": design["platform"]}
+    if design.get("turbine") is not None:
+        t = design["turbine"]
+        sub["turbine"] = {k: t[k] for k in ("tower", "nacelle", "nrotors") if k in t}
+    return json.dumps(sub, default=lambda o: o.tolist() if hasattr(o, "tolist") else float(o))
+
+
+def _geom_unit(fowt, design_json, heading_adjust=0.0):
+    """Everything raftx_build_designs must reproduce for one live FOWT (already positioned, calcStatics and
+    calcHydroConstants done)."""
+    from raft_amd.strips import pack_fowt
+    t = pack_fowt(fowt)
+    platform = [m for m in fowt.memberList if m.part_of != "nacelle"]
+    out = {"design_json": design_json, "heading_adjust": float(heading_adjust),
+           "pose": np.array(fowt.rReducedDOF, dtype=float), "rho": float(fowt.rho_water), "g": float(fowt.g),
+           "w": np.array(fowt.w), "k": np.array(fowt.k),
+           "strips": t.strips, "cm": t.cm_mcf if t.cm_mcf is not None else np.zeros((0, 2, fowt.nw), dtype=complex),
+           "A_hydro_morison": np.array(fowt.A_hydro_morison), "C_hydro": np.array(fowt.C_hydro),
+           "W_hydro": np.array(fowt.W_hydro), "V": float(fowt.V), "AWP": float(fowt.AWP), "rCB": np.array(fowt.rCB),
+           "M_struc": np.array(fowt.M_struc), "C_struc": np.array(fowt.C_struc), "W_struc": np.array(fowt.W_struc),
+           "m": float(fowt.m), "rCG": np.array(fowt.rCG),
+           "member_ns": np.array([m.ns for m in fowt.memberList]),
+           "member_mass": np.array([getattr(m, "mass", 0.0) for m in platform]),
+           "member_M_struc": np.array([m.M_struc for m in platform])}
+    return out
+
+
+def fixture_geom():
+    """Goldens for the device geometry generator (raftx_build_designs): member description in, strip tables /
+    Morison added mass / hydrostatics / inertia of the LIVE reference out.  Decks: OC3spar (tapered spar),
+    VolturnUS-S test deck (MacCamy-Fuchs columns, rectangular pontoons) at a non-trivial pose, OC4semi-RAFT_QTF
+    (heave plates, inclined braces, MCF) upright and heeled, three C3 sweep variants, and the four units of
+    the C4 farm (heading_adjust 180/0/90/270 with array offsets)."""
+    units = []
+
+    def add(name, design, r6=None, label=None):
+        dj = _design_subset(design)
+        m = rh.build_model(copy.deepcopy(design), r6=None if r6 is None else [r6])
+        u = _geom_unit(m.fowtList[0], dj)
+        u["name"] = label or name
+        units.append(u)
+
+    d = rh.prepare_design(rh.load_design(os.path.join(REF, "designs/OC3spar.yaml")))
+    add("OC3spar", d)
+    d = rh.prepare_design(rh.load_design(os.path.join(REF, "tests/test_data/VolturnUS-S.yaml")))
+    add("VolturnUS-S-test", d, r6=[3.0, -2.0, -0.5, 0.02, -0.03, 0.1], label="VolturnUS-S-test@pose")
+    d = rh.prepare_design(rh.load_design(os.path.join(REF, "examples/OC4semi-RAFT_QTF.yaml")))
+    d["platform"].pop("outFolderQTF", None)
+    add("OC4semi", d)
+    add("OC4semi", d, r6=[-1.0, 4.0, 0.3, -0.05, 0.04, -0.2], label="OC4semi@heel")
+    base = rh.prepare_design(rh.load_design(os.path.join(REF, "examples/VolturnUS-S_example.yaml")))
+    rng = np.random.default_rng(0)
+    scales = rng.uniform(0.75, 1.25, size=(3, 5))
+    for i in range(3):
+        add("C3", volturnus_variant(base, scales[i]), label="C3-variant-%d" % i)
+    # farm units: heading_adjust + array offsets
+    d = rh.prepare_design(rh.load_design(os.path.join(REF, "designs/VolturnUS-S_farm.yaml")),
+                          settings=dict(min_freq=0.002, max_freq=0.2))
+    d["array"]["data"] = [[1, 1, 0, 0, 0, 180], [1, 1, 0, 1600, 0, 0],
+                          [1, 1, 0, 0, 1600, 90], [1, 1, 0, 1600, 1600, 270]]
+    unit_design = {"site": d["site"], "platform": d["platform"], "turbine": d["turbine"]}
+    dj = _design_subset(unit_design)
+    m = rh.build_model(copy.deepcopy(d))
+    for i, f in enumerate(m.fowtList):
+        u = _geom_unit(f, dj, heading_adjust=d["array"]["data"][i][5])
+        u["name"] = "farm-unit-%d" % i
+        units.append(u)
+    fx = {"config": "geometry generator goldens (live reference)", "units": units}
+    standin.save_fixture(os.path.join(GOLD, "geom_units.npz"), fx)
+
+
+ALL = {"geom": fixture_geom, "c5oc4": fixture_c5_oc4, "c5": fixture_c5, "qtf": fixture_qtf, "c1": fixture_c1, "c2": fixture_c2, "pose": fixture_pose,
        "refgold": fixture_ref_goldens, "c4": fixture_c4, "c3": fixture_c3}
 
 if __name__ == "__main__":

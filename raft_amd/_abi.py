@@ -25,6 +25,7 @@ EXPORTS = (
     "raftx_excitation", "raftx_linearize", "raftx_solve_dynamics",
     "raftx_solve_system", "raftx_last_kernel_ms",
     "raftx_solve_dynamics_device", "raftx_fetch_results", "raftx_debug_math", "raftx_motion_stats", "raftx_solve_system_resident", "raftx_qtf_slender", "raftx_channel_stats", "raftx_qtf_force", "raftx_set_linearisation_point", "raftx_fetch_linearisation_point",
+    "raftx_build_designs", "raftx_fetch_strips", "raftx_fetch_statics",
 )
 WANT_BDRAG, WANT_FWAVE, WANT_Z = 1, 2, 4
 
@@ -106,6 +107,13 @@ class RaftxLib:
         L.raftx_motion_stats.restype = C.c_int
         L.raftx_debug_math.argtypes = [_vp, C.c_int, _vp, _vp, _vp, _vp]
         L.raftx_debug_math.restype = C.c_int
+        L.raftx_build_designs.argtypes = [_vp, C.c_int, _vp, _vp, _vp, _vp, _vp, C.c_double, C.c_double, C.c_int, _vp,
+                                          C.c_int, _vp, _vp, _vp, _vp, _vp]
+        L.raftx_build_designs.restype = C.c_int
+        L.raftx_fetch_strips.argtypes = [_vp, _vp, _vp]
+        L.raftx_fetch_strips.restype = C.c_int
+        L.raftx_fetch_statics.argtypes = [_vp, _vp, _vp, _vp, _vp, _vp]
+        L.raftx_fetch_statics.restype = C.c_int
         L.raftx_last_kernel_ms.argtypes = [_vp]
         L.raftx_last_kernel_ms.restype = C.c_double
 
@@ -192,6 +200,53 @@ class Context:
         self._check(rc, "raftx_upload_designs")
         self.nDesign = nD
         self._nw_designs = int(nw)
+
+    def build_designs(self, member_off, members, station_off, stations, M0, B0, C0, nw, pose=None, rho=1025.0,
+                      g=9.81, k=None, add_mask=0, MBw=None):
+        """Geometry -> resident strip tables (+ statics) on the device: raftx_build_designs.  Member / station
+        records as raft_amd/geometry.py packs them.  Returns the strip offsets [nDesign+1]."""
+        member_off = np.ascontiguousarray(member_off, dtype=np.int64)
+        station_off = np.ascontiguousarray(station_off, dtype=np.int64)
+        nD = len(member_off) - 1
+        members = _f64(members, (member_off[-1], 16), "members")
+        if len(station_off) != member_off[-1] + 1:
+            raise ValueError("station_off has %d entries, expected %d" % (len(station_off), member_off[-1] + 1))
+        stations = _f64(stations, (station_off[-1], 16), "stations")
+        M0 = _f64(M0, (nD, 6, 6), "M0")
+        B0 = _f64(B0, (nD, 6, 6), "B0")
+        C0 = _f64(C0, (nD, 6, 6), "C0")
+        if pose is not None:
+            pose = _f64(pose, (nD, 6), "pose")
+        if k is not None:
+            k = _f64(k, (nw,), "k")
+        if MBw is not None:
+            MBw = _f64(MBw, (nD, 2, 6, 6, nw), "MBw")
+        off = np.zeros(nD + 1, dtype=np.int64)
+        rc = self.rlib.lib.raftx_build_designs(self._h, nD, _ptr(member_off), _ptr(members), _ptr(station_off),
+                                               _ptr(stations), _ptr(pose), float(rho), float(g), int(nw), _ptr(k),
+                                               int(add_mask), _ptr(M0), _ptr(B0), _ptr(C0), _ptr(MBw), _ptr(off))
+        self._check(rc, "raftx_build_designs")
+        self.nDesign = nD
+        self._nw_designs = int(nw)
+        self._strip_off = off
+        return off
+
+    def fetch_strips(self, n_strips, n_cm_rows=0):
+        """(strips [n,32], cm [rows,2,nw] or None) generated by the last build_designs."""
+        strips = np.empty((int(n_strips), NFIELD))
+        cm = np.empty((int(n_cm_rows), 2, self._nw_designs), dtype=np.complex128) if n_cm_rows else None
+        self._check(self.rlib.lib.raftx_fetch_strips(self._h, _ptr(strips), _ptr(cm)), "raftx_fetch_strips")
+        return strips, cm
+
+    def fetch_statics(self):
+        """dict(A_morison [nD,6,6], C_hydro [nD,6,6], W_hydro [nD,6], M_struc [nD,6,6], props [nD,8])."""
+        nD = self.nDesign
+        out = dict(A_morison=np.empty((nD, 6, 6)), C_hydro=np.empty((nD, 6, 6)), W_hydro=np.empty((nD, 6)),
+                   M_struc=np.empty((nD, 6, 6)), props=np.empty((nD, 8)))
+        rc = self.rlib.lib.raftx_fetch_statics(self._h, _ptr(out["A_morison"]), _ptr(out["C_hydro"]),
+                                               _ptr(out["W_hydro"]), _ptr(out["M_struc"]), _ptr(out["props"]))
+        self._check(rc, "raftx_fetch_statics")
+        return out
 
     def upload_cases(self, w, k, depth, rho, g, zeta, beta):
         w = _f64(w)

@@ -34,6 +34,7 @@
 
 #include "raftx_kernels.h"
 #include "raftx_qtf.h"
+#include "raftx_geom.h"
 
 // Coupled array solve (raft_model.py:1164-1236): one 64-lane workgroup per
 // (system, bin); the augmented matrix [Z_sys | F] lives in LDS, lane r owns
@@ -231,6 +232,11 @@ struct raftx_ctx {
     double last_ms;
     bool have_designs, have_cases;
     int nw_designs;
+    // results of the last raftx_build_designs (device pointers owned by design_allocs)
+    int g_n;
+    size_t g_nStrips, g_nRows;
+    double *g_abi, *g_A, *g_Ch, *g_Wh, *g_props;
+    cplx *g_cm;
 };
 
 #define MAX_NW 2048
@@ -268,6 +274,7 @@ extern "C" int raftx_ctx_create(int device_id, raftx_ctx **out) {
     c->last_ms = 0.0;
     c->have_designs = c->have_cases = false;
     c->nw_designs = 0;
+    c->g_n = 0;
     c->rXi = c->rFw = c->rZ = c->rFe = nullptr;
     c->rB = c->rXl = nullptr;
     c->rXl_n = 0;
@@ -350,79 +357,8 @@ extern "C" int raftx_upload_designs(raftx_ctx *c, int nDesign, const int64_t *st
     // RAFTX_F_STEP / RAFTX_F_UNIT hints of the ABI record are not trusted (nor needed).
     std::vector<double> dsv((size_t)stripOffsets[nDesign] * DS_N, 0.0);
     std::vector<int> dsf((size_t)stripOffsets[nDesign], 0);
-    for (int d = 0; d < nDesign; d++) {
-        const int64_t i0 = stripOffsets[d], i1 = stripOffsets[d + 1];
-        int64_t s = i0;
-        while (s < i1) {
-            // maximal collinear sequence [s, e): same q, displacement along +q
-            const double *r0 = strips + (size_t)s * NF;
-            int64_t e = s + 1;
-            std::vector<double> proj;
-            while (e < i1 && (e - s) < 64) {
-                const double *pr = strips + (size_t)(e - 1) * NF, *cr = strips + (size_t)e * NF;
-                bool same = true;
-                double dv[3], pj = 0.0;
-                for (int j = 0; j < 3; j++) {
-                    same = same && (pr[RAFTX_F_Q + j] == cr[RAFTX_F_Q + j]);
-                    dv[j] = cr[RAFTX_F_X + j] - pr[RAFTX_F_X + j];
-                    pj += dv[j] * cr[RAFTX_F_Q + j];
-                }
-                if (!same || !(pj > 0.0) || !std::isfinite(pj)) break;
-                double perp2 = 0.0, scale = 1.0;
-                for (int j = 0; j < 3; j++) {
-                    double t = dv[j] - pj * cr[RAFTX_F_Q + j];
-                    perp2 += t * t;
-                    scale += std::fabs(cr[RAFTX_F_X + j]);
-                }
-                if (std::sqrt(perp2) > 1e-10 * scale) break;
-                proj.push_back(pj);
-                e++;
-            }
-            double unit = 0.0;
-            for (double pj : proj) unit = (unit == 0.0 || pj < unit) ? pj : unit;
-            // emit records; break the run wherever a step is not 1 or 2 units (re-anchored exactly)
-            for (int64_t i = s; i < e; i++) {
-                const double *rec = strips + (size_t)i * NF;
-                double *o = dsv.data() + (size_t)i * DS_N;
-                int m = 0;
-                if (i > s && unit > 0.0) {
-                    double ratio = proj[i - s - 1] / unit;
-                    int mi = (int)std::llround(ratio);
-                    if (mi >= 1 && mi <= 2 && std::fabs(ratio - mi) < 1e-9) {
-                        // verify the prediction from the previous strip
-                        const double *pr = strips + (size_t)(i - 1) * NF;
-                        bool ok = true;
-                        for (int j = 0; j < 3; j++) {
-                            double pred = pr[RAFTX_F_X + j] + (double)mi * unit * rec[RAFTX_F_Q + j];
-                            if (std::fabs(pred - rec[RAFTX_F_X + j]) > 1e-10 * (1.0 + std::fabs(rec[RAFTX_F_X + j]))) ok = false;
-                        }
-                        if (ok) m = mi;
-                    }
-                }
-                dsf[(size_t)i] = m | (rec[RAFTX_F_CIRC] != 0.0 ? DSI_CIRC : 0);
-                o[DS_MCF] = rec[RAFTX_F_MCF];
-                for (int j = 0; j < 3; j++) {
-                    o[DS_X + j] = rec[RAFTX_F_X + j];
-                    o[DS_U + j] = unit * rec[RAFTX_F_Q + j];
-                    o[DS_A + j] = rec[RAFTX_F_AX + j];
-                    o[DS_Q + j] = rec[RAFTX_F_Q + j];
-                    o[DS_P1 + j] = rec[RAFTX_F_P1 + j];
-                    o[DS_P2 + j] = rec[RAFTX_F_P2 + j];
-                }
-                o[DS_IQ] = rec[RAFTX_F_IQ];
-                o[DS_IQ + 1] = rec[RAFTX_F_IP1];
-                o[DS_IQ + 2] = rec[RAFTX_F_IP2];
-                o[DS_IQ + 3] = rec[RAFTX_F_AI];
-                o[DS_IQ + 4] = rec[RAFTX_F_RHOV];
-                o[DS_DQ] = rec[RAFTX_F_DQ];
-                o[DS_DQ + 1] = rec[RAFTX_F_DP1];
-                o[DS_DQ + 2] = rec[RAFTX_F_DP2];
-                o[DS_DQ + 3] = rec[RAFTX_F_DEND];
-            }
-            (void)r0;
-            s = e;
-        }
-    }
+    for (int d = 0; d < nDesign; d++)
+        derive_design_tables(strips, stripOffsets[d], stripOffsets[d + 1], dsv.data(), dsf.data());
     DevTables &T = c->T;
     T.nDesign = nDesign;
     int rc = 0;
@@ -445,6 +381,165 @@ extern "C" int raftx_upload_designs(raftx_ctx *c, int nDesign, const int64_t *st
     c->maxS = maxS;
     c->nw_designs = nw;
     c->have_designs = true;
+    c->g_n = 0;
+    return 0;
+}
+
+// ---- geometry -> strip tables + statics on the device (raftx_geom.h)
+template <typename Tp>
+static int dev_alloc(raftx_ctx *c, std::vector<void *> &bag, size_t n, Tp **out, bool zero = false) {
+    *out = nullptr;
+    void *p = nullptr;
+    HIPCHK(c, hipMalloc(&p, (n ? n : 1) * sizeof(Tp)));
+    bag.push_back(p);
+    if (zero) HIPCHK(c, hipMemsetAsync(p, 0, (n ? n : 1) * sizeof(Tp), c->stream));
+    *out = reinterpret_cast<Tp *>(p);
+    return 0;
+}
+
+extern "C" int raftx_build_designs(raftx_ctx *c, int nDesign, const int64_t *memberOff, const double *members,
+                                   const int64_t *stationOff, const double *stations, const double *pose, double rho,
+                                   double g, int nw, const double *k, int add_mask, const double *M0, const double *B0,
+                                   const double *C0, const double *MBw, int64_t *stripOffsets) {
+    if (!c) return -1;
+    if (nDesign < 0 || !memberOff || !members || !stationOff || !stations || !M0 || !B0 || !C0 || !stripOffsets)
+        FAIL(c, "build_designs: bad arguments");
+    if (add_mask & RAFTX_ADD_INERTIA) FAIL(c, "build_designs: RAFTX_ADD_INERTIA is not available in this build");
+    if (nw < 1 || nw > MAX_NW) FAIL(c, "build_designs: nw=%d outside 1..%d", nw, MAX_NW);
+    const int64_t nMember = memberOff[nDesign];
+    bool any_mcf = false;
+    std::vector<int> mdesign((size_t)nMember);
+    for (int d = 0; d < nDesign; d++) {
+        if (memberOff[d + 1] < memberOff[d]) FAIL(c, "member offsets not monotone at design %d", d);
+        for (int64_t m = memberOff[d]; m < memberOff[d + 1]; m++) {
+            mdesign[(size_t)m] = d;
+            const int64_t n = stationOff[m + 1] - stationOff[m];
+            if (n < 2) FAIL(c, "member %lld has %lld stations (< 2)", (long long)m, (long long)n);
+            const double *gm = members + (size_t)m * RAFTX_GM_N;
+            if (!(gm[RAFTX_GM_DLSMAX] > 0.0) || !(gm[RAFTX_GM_L] > 0.0))
+                FAIL(c, "member %lld: dlsMax and length must be positive", (long long)m);
+            if (((int)gm[RAFTX_GM_FLAGS] & RAFTX_GM_FLAG_MCF) && gm[RAFTX_GM_SHAPE] != 0.0) any_mcf = true;
+        }
+    }
+    if (any_mcf && !k) FAIL(c, "build_designs: a member is MacCamy-Fuchs but no wave numbers were given");
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    free_list(c->design_allocs);
+    c->have_designs = false;
+    c->g_n = 0;
+    std::vector<void *> tmp;                       // descriptor uploads and per-member scratch, freed on return
+    struct Guard { std::vector<void *> &v; ~Guard() { free_list(v); } } guard{tmp};
+    GeomArgs A;
+    memset(&A, 0, sizeof(A));
+    A.nDesign = nDesign;
+    A.nMember = nMember;
+    A.rho = rho; A.g = g; A.nw = nw; A.add_mask = add_mask;
+    int rc = 0;
+    rc |= upload(c, tmp, memberOff, (size_t)nDesign + 1, &A.memberOff);
+    rc |= upload(c, tmp, members, (size_t)nMember * RAFTX_GM_N, &A.gm);
+    rc |= upload(c, tmp, stationOff, (size_t)nMember + 1, &A.stationOff);
+    rc |= upload(c, tmp, stations, (size_t)stationOff[nMember] * RAFTX_GS_N, &A.gs);
+    rc |= upload(c, tmp, pose, pose ? (size_t)nDesign * 6 : 0, &A.pose);
+    rc |= upload(c, tmp, mdesign.data(), (size_t)nMember, &A.mdesign);
+    rc |= upload(c, c->design_allocs, k, k ? (size_t)nw : 0, &A.k);
+    if (rc) return -2;
+    if (dev_alloc(c, tmp, (size_t)nMember, &A.cnt) || dev_alloc(c, tmp, (size_t)nMember, &A.cntm) ||
+        dev_alloc(c, tmp, (size_t)nMember + 1, &A.soff) || dev_alloc(c, tmp, (size_t)nMember + 1, &A.cmsoff) ||
+        dev_alloc(c, tmp, (size_t)nMember * MP_N, &A.mpose) || dev_alloc(c, tmp, (size_t)nMember * MH_N, &A.mhyd) ||
+        dev_alloc(c, c->design_allocs, (size_t)nDesign + 1, &A.off) ||
+        dev_alloc(c, c->design_allocs, (size_t)nDesign + 1, &A.cmoff))
+        return -2;
+    HIPCHK(c, hipEventRecord(c->ev0, c->stream));
+    if (nMember > 0) {
+        hipLaunchKernelGGL(k_geom_member, dim3((unsigned)((nMember + 127) / 128)), dim3(128), 0, c->stream, A);
+        hipLaunchKernelGGL(k_geom_scan, dim3(1), dim3(1024), 0, c->stream, A);
+    } else {
+        HIPCHK(c, hipMemsetAsync(A.soff, 0, sizeof(int64_t), c->stream));
+        HIPCHK(c, hipMemsetAsync(A.cmsoff, 0, sizeof(int64_t), c->stream));
+    }
+    hipLaunchKernelGGL(k_geom_offsets, dim3((unsigned)(nDesign / 256 + 1)), dim3(256), 0, c->stream, A);
+    std::vector<int64_t> cmoffh((size_t)nDesign + 1);
+    HIPCHK(c, hipMemcpyAsync(stripOffsets, A.off, ((size_t)nDesign + 1) * sizeof(int64_t), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(cmoffh.data(), A.cmoff, ((size_t)nDesign + 1) * sizeof(int64_t), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, hipGetLastError());
+    const size_t nStrips = (size_t)stripOffsets[nDesign], nRows = (size_t)cmoffh[(size_t)nDesign];
+    int maxS = 0;
+    for (int d = 0; d < nDesign; d++) {
+        const int64_t S = stripOffsets[d + 1] - stripOffsets[d];
+        if (S > maxS) maxS = (int)S;
+    }
+    double *M0d = nullptr, *C0d = nullptr;
+    if (dev_alloc(c, c->design_allocs, nStrips * NF, &A.abi) || dev_alloc(c, c->design_allocs, nStrips * DS_N, &A.ds) ||
+        dev_alloc(c, c->design_allocs, nStrips, &A.dsi) || dev_alloc(c, c->design_allocs, nRows * 3, &A.mcfaux) ||
+        dev_alloc(c, c->design_allocs, nRows * 2 * (size_t)nw, &A.cm) ||
+        dev_alloc(c, c->design_allocs, (size_t)nDesign * 36, &A.A) || dev_alloc(c, c->design_allocs, (size_t)nDesign * 36, &A.Ch) ||
+        dev_alloc(c, c->design_allocs, (size_t)nDesign * 6, &A.Wh) ||
+        dev_alloc(c, c->design_allocs, (size_t)nDesign * RAFTX_SP_N, &A.props) ||
+        dev_alloc(c, c->design_allocs, (size_t)nDesign * 36, &M0d) || dev_alloc(c, c->design_allocs, (size_t)nDesign * 36, &C0d))
+        return -2;
+    HIPCHK(c, hipMemcpyAsync(M0d, M0, (size_t)nDesign * 36 * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(C0d, C0, (size_t)nDesign * 36 * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    A.M0 = M0d;
+    A.C0 = C0d;
+    if (nMember > 0) hipLaunchKernelGGL(k_geom_fill, dim3((unsigned)nMember), dim3(64), 0, c->stream, A);
+    if (nRows > 0)
+        hipLaunchKernelGGL(k_geom_mcf, dim3((unsigned)nRows, (unsigned)((nw + 63) / 64)), dim3(64), 0, c->stream, A, (int64_t)nRows);
+    if (nDesign > 0) hipLaunchKernelGGL(k_geom_design, dim3((unsigned)((nDesign + 63) / 64)), dim3(64), 0, c->stream, A);
+    HIPCHK(c, hipEventRecord(c->ev1, c->stream));
+    DevTables &T = c->T;
+    T.nDesign = nDesign;
+    T.off = A.off;
+    T.ds = A.ds;
+    T.dsi = A.dsi;
+    T.M0 = M0d;
+    T.C0 = C0d;
+    rc |= upload(c, c->design_allocs, B0, (size_t)nDesign * 36, &T.B0);
+    rc |= upload(c, c->design_allocs, MBw, MBw ? (size_t)nDesign * 72 * nw : 0, &T.MBw);
+    if (rc) return -2;
+    T.cmoff = nRows ? A.cmoff : nullptr;
+    T.cm = nRows ? A.cm : nullptr;
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, hipGetLastError());
+    float ms = 0.f;
+    HIPCHK(c, hipEventElapsedTime(&ms, c->ev0, c->ev1));
+    c->last_ms = ms;
+    c->maxS = maxS;
+    c->nw_designs = nw;
+    c->have_designs = true;
+    c->g_n = nDesign;
+    c->g_nStrips = nStrips;
+    c->g_nRows = nRows;
+    c->g_abi = A.abi;
+    c->g_cm = A.cm;
+    c->g_A = A.A; c->g_Ch = A.Ch; c->g_Wh = A.Wh; c->g_props = A.props;
+    return 0;
+}
+
+extern "C" int raftx_fetch_strips(raftx_ctx *c, double *strips, raftx_c128 *cm) {
+    if (!c) return -1;
+    if (!c->g_n || !c->have_designs) FAIL(c, "fetch_strips: no raftx_build_designs call on this ctx");
+    HIPCHK(c, hipSetDevice(c->device));
+    if (strips && c->g_nStrips)
+        HIPCHK(c, hipMemcpyAsync(strips, c->g_abi, c->g_nStrips * NF * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    if (cm && c->g_nRows)
+        HIPCHK(c, hipMemcpyAsync(cm, c->g_cm, c->g_nRows * 2 * (size_t)c->nw_designs * sizeof(cplx), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+extern "C" int raftx_fetch_statics(raftx_ctx *c, double *A_morison, double *C_hydro, double *W_hydro, double *M_struc,
+                                   double *props) {
+    if (!c) return -1;
+    if (!c->g_n || !c->have_designs) FAIL(c, "fetch_statics: no raftx_build_designs call on this ctx");
+    HIPCHK(c, hipSetDevice(c->device));
+    const size_t n = (size_t)c->g_n;
+    if (A_morison) HIPCHK(c, hipMemcpyAsync(A_morison, c->g_A, n * 36 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    if (C_hydro) HIPCHK(c, hipMemcpyAsync(C_hydro, c->g_Ch, n * 36 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    if (W_hydro) HIPCHK(c, hipMemcpyAsync(W_hydro, c->g_Wh, n * 6 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    if (props) HIPCHK(c, hipMemcpyAsync(props, c->g_props, n * RAFTX_SP_N * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (M_struc) memset(M_struc, 0, n * 36 * sizeof(double));
     return 0;
 }
 

@@ -1,0 +1,225 @@
+"""Member descriptors: the host-side feeder of ``raftx_build_designs``.
+
+The reference turns every entry of a design's ``platform: members`` list (plus
+towers / nacelles) into ``Member`` objects, discretises them into strips and
+evaluates per-strip constants in Python (0.16 s per design).
+Here the host only PARSES the member description -- a few dozen numbers per
+member -- and the device does the rest (``raftx_build_designs``,
+include/raftx.h): strip discretisation, pose, hydrodynamic constants, Morison
+added mass, hydrostatics.
+
+This file restates the input handling of
+    raft/raft_member.py:36-190   Member.__init__ (end points, heading, stations,
+                                  diameters / side pairs, coefficients, ballast)
+    raft/raft_fowt.py:223-272    FOWT.__init__ (potModMaster, dlsMax default,
+                                  one Member per heading; towers, nacelles)
+    raft/helpers.py:828-915      getFromDict (scalar / list broadcasting rules)
+and nothing else: no strips are built on the host.
+
+Record layouts (include/raftx.h): member RAFTX_GM_* (16 doubles), station
+RAFTX_GS_* (16 doubles).
+"""
+import numpy as np
+
+GM_N, GS_N = 16, 16
+GM_RA, GM_RB, GM_GAMMA, GM_SHAPE, GM_DLSMAX, GM_FLAGS, GM_L, GM_RHOSHELL = 0, 3, 6, 7, 8, 9, 10, 11
+GS_S, GS_D, GS_T, GS_CD, GS_CA, GS_LFILL, GS_RHOFILL = 0, 1, 3, 4, 8, 12, 13
+FLAG_POTMOD, FLAG_MCF = 1, 2
+ADD_MORISON, ADD_HYDROSTATIC, ADD_INERTIA = 1, 2, 4
+SP_N, SP_V, SP_AWP, SP_RCB, SP_MASS, SP_ZCG = 8, 0, 1, 2, 5, 6
+
+
+class UnsupportedMember(Exception):
+    """Member outside the device generator's scope (flexible 'beam' members)."""
+
+
+def _get(d, key, shape=0, dtype=float, default=None, index=None):
+    """Value of ``key`` with the reference's broadcasting rules (helpers.py:828-915): scalars tile to ``shape``;
+    1-D lists must match ``shape`` (with ``index``: a 1-D list is one [p1, p2] pair, a 2-D list a column);
+    ``shape`` 0 = scalar, -1 = as given."""
+    if key in d:
+        val = d[key]
+        if shape == 0:
+            if np.isscalar(val):
+                return dtype(val)
+            raise ValueError("Value for key '%s' is expected to be a scalar but instead is: %s" % (key, val))
+        if shape == -1:
+            return dtype(val) if np.isscalar(val) else np.array(val, dtype=dtype)
+        if np.isscalar(val):
+            return np.tile(dtype(val), shape)
+        if np.isscalar(shape):
+            if len(val) != shape:
+                raise ValueError("Value for key '%s' is not the expected size of %s and is instead: %s" % (key, shape, val))
+            if index is None:
+                return np.array([dtype(v) for v in val])
+            a = np.array(val)
+            if a.ndim == 1:
+                if index not in range(a.shape[0]):
+                    raise ValueError("Value for index '%s' is not within the size of %s" % (index, val))
+                return np.tile(val[index], shape)
+            if index not in range(a.shape[1]):
+                raise ValueError("Value for index '%s' is not within the size of %s" % (index, val))
+            return np.array([v[index] for v in val])
+        a = np.array(val, dtype=dtype)
+        if list(a.shape) == list(shape):
+            return a
+        if a.ndim == 1 and len(a) == shape[1]:
+            return np.tile(a, [shape[0], 1])
+        raise ValueError("Value for key '%s' is not a compatible size for target size of %s" % (key, shape))
+    if default is None:
+        raise ValueError("Key '%s' not found in input file..." % key)
+    if shape == 0 or shape == -1:
+        return default
+    if np.isscalar(default):
+        return np.tile(default, shape)
+    return np.tile(default, [shape, 1])
+
+
+def _heading(r, heading):
+    """helpers.py:587-602 applyHeadingToPoint"""
+    if heading == 0.0:
+        return r
+    c, s = np.cos(np.deg2rad(heading)), np.sin(np.deg2rad(heading))
+    return np.matmul(np.array([[c, -s, 0], [s, c, 0], [0, 0, 1]]), r)
+
+
+def describe_member(mi, heading=0.0):
+    """(gm [16], gs [n,16]) of one member copy -- raft_member.py:36-190."""
+    mtype = str(mi.get("type", "rigid"))
+    if mtype != "rigid":
+        raise UnsupportedMember("member '%s' is type '%s'; only rigid members are generated on the device"
+                                % (mi.get("name", "?"), mtype))
+    rA0 = np.array(mi["rA"], dtype=np.double)
+    rB0 = np.array(mi["rB"], dtype=np.double)
+    if rA0[2] == 0 or rB0[2] == 0:
+        raise ValueError("RAFT Members cannot start or end on the waterplane")
+    shape = str(mi["shape"])
+    gamma = _get(mi, "gamma", default=0.)
+    rAB = rB0 - rA0
+    length = np.linalg.norm(rAB)
+    if heading != 0.0:
+        rA0 = _heading(rA0, heading)
+        rB0 = _heading(rB0, heading)
+        if rAB[0] == 0.0 and rAB[1] == 0:
+            gamma += heading
+    st = np.array(mi["stations"], dtype=float)
+    n = len(st)
+    if n < 2:
+        raise ValueError("At least two stations entries must be provided")
+    if not sorted(st) == st.tolist():
+        raise ValueError("Member %s: the station list is not in ascending order." % mi.get("name", "?"))
+    gs = np.zeros((n, GS_N))
+    gs[:, GS_S] = (st - st[0]) / (st[-1] - st[0]) * length
+    if shape[0].lower() == "c":
+        circ = True
+        d = _get(mi, "d", shape=n)
+        gs[:, GS_D] = d
+        gs[:, GS_D + 1] = d
+        gamma = 0
+    elif shape[0].lower() == "r":
+        circ = False
+        gs[:, GS_D:GS_D + 2] = _get(mi, "d", shape=[n, 2])
+    else:
+        raise ValueError("The only allowable shape strings are circular and rectangular")
+    mcf = bool(_get(mi, "MCF", dtype=bool, default=False)) and circ
+    potmod = bool(_get(mi, "potMod", dtype=bool, default=False))
+    gs[:, GS_T] = _get(mi, "t", shape=n, default=0)
+    st_fill = _get(mi, "l_fill", shape=n - 1, default=0)
+    for i in range(n - 1):
+        if st_fill[i] < 0:
+            raise Exception("Member %s: ballast level in section %d is negative." % (mi.get("name", "?"), i + 1))
+        if st_fill[i] > st[i + 1] - st[i]:
+            raise Exception("Member %s: ballast level in section %d exceeds section length." % (mi.get("name", "?"), i + 1))
+    gs[:n - 1, GS_LFILL] = st_fill / (st[-1] - st[0]) * length
+    rho_fill = _get(mi, "rho_fill", shape=-1, default=1025)
+    if np.isscalar(rho_fill):
+        gs[:n - 1, GS_RHOFILL] = rho_fill
+    elif len(rho_fill) == n - 1:
+        gs[:n - 1, GS_RHOFILL] = np.array(rho_fill)
+    else:
+        raise Exception("Member %s: the number of provided ballast densities (rho_fill) must be 1 less than the "
+                        "number of stations." % mi.get("name", "?"))
+    gs[:, GS_CD + 0] = _get(mi, "Cd_q", shape=n, default=0.0)
+    gs[:, GS_CD + 1] = _get(mi, "Cd", shape=n, default=0.6, index=0)
+    gs[:, GS_CD + 2] = _get(mi, "Cd", shape=n, default=0.6, index=1)
+    gs[:, GS_CD + 3] = _get(mi, "CdEnd", shape=n, default=0.6)
+    gs[:, GS_CA + 0] = _get(mi, "Ca_q", shape=n, default=0.0)
+    gs[:, GS_CA + 1] = _get(mi, "Ca", shape=n, default=0.97, index=0)
+    gs[:, GS_CA + 2] = _get(mi, "Ca", shape=n, default=0.97, index=1)
+    gs[:, GS_CA + 3] = _get(mi, "CaEnd", shape=n, default=0.6)
+    gm = np.zeros(GM_N)
+    gm[GM_RA:GM_RA + 3] = rA0
+    gm[GM_RB:GM_RB + 3] = rB0
+    gm[GM_GAMMA] = gamma
+    gm[GM_SHAPE] = 1.0 if circ else 0.0
+    gm[GM_DLSMAX] = _get(mi, "dlsMax", shape=0, default=5)
+    gm[GM_FLAGS] = (FLAG_POTMOD if potmod else 0) | (FLAG_MCF if mcf else 0)
+    gm[GM_L] = length
+    gm[GM_RHOSHELL] = _get(mi, "rho_shell", shape=0, default=8500.)
+    return gm, gs
+
+
+class MemberTable:
+    """Members of one unit: ``members`` [nM,16], ``station_off`` [nM+1], ``stations`` [nSt,16]."""
+
+    def __init__(self, gms, gss):
+        self.members = np.ascontiguousarray(np.array(gms, dtype=np.float64).reshape(-1, GM_N))
+        counts = [len(g) for g in gss]
+        self.station_off = np.concatenate([[0], np.cumsum(counts)]).astype(np.int64)
+        self.stations = np.ascontiguousarray(np.concatenate(gss, axis=0) if gss else np.zeros((0, GS_N)))
+
+    @property
+    def n(self):
+        return self.members.shape[0]
+
+
+def describe_unit(design, heading_adjust=0.0, include_turbine=True):
+    """MemberTable of a unit, in the order of FOWT.memberList (raft_fowt.py:223-272): every platform member once per
+    heading, then towers and nacelle members.  The design dict is not modified."""
+    if "joints" in design:
+        raise UnsupportedMember("designs with explicit joints (multi-body / flexible units) are not generated on the device")
+    plat = design["platform"]
+    pmm = int(_get(plat, "potModMaster", dtype=int, default=0))
+    dls_default = _get(plat, "dlsMax", default=5.0)
+    gms, gss = [], []
+    for mi in plat["members"]:
+        mi = dict(mi)
+        if pmm in [1]:
+            mi["potMod"] = False
+        elif pmm in [2, 3]:
+            mi["potMod"] = True
+        if "dlsMax" not in mi:
+            mi["dlsMax"] = dls_default
+        headings = _get(mi, "heading", shape=-1, default=0.)
+        if np.isscalar(headings):
+            headings = [headings]
+        for h in headings:
+            gm, gs = describe_member(mi, heading=h + heading_adjust)
+            gms.append(gm)
+            gss.append(gs)
+    if include_turbine and "turbine" in design and design["turbine"] is not None:
+        turb = design["turbine"]
+        nrotors = int(_get(turb, "nrotors", dtype=int, shape=0, default=1))
+        for key in ("tower", "nacelle"):
+            if key in turb:
+                items = turb[key]
+                if isinstance(items, dict):
+                    items = [items] * nrotors
+                for mi in items:
+                    gm, gs = describe_member(dict(mi))
+                    gms.append(gm)
+                    gss.append(gs)
+    return MemberTable(gms, gss)
+
+
+def concat_units(tables):
+    """(memberOff [nD+1], members, stationOff [nM+1], stations) of a list of MemberTables (one per design)."""
+    member_off = np.concatenate([[0], np.cumsum([t.n for t in tables])]).astype(np.int64)
+    members = np.ascontiguousarray(np.concatenate([t.members for t in tables], axis=0))
+    stations = np.ascontiguousarray(np.concatenate([t.stations for t in tables], axis=0))
+    so = [np.zeros(1, dtype=np.int64)]
+    base = 0
+    for t in tables:
+        so.append(t.station_off[1:] + base)
+        base += t.station_off[-1]
+    return member_off, members, np.concatenate(so).astype(np.int64), stations

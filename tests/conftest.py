@@ -17,8 +17,9 @@ def pytest_configure(config):
 
 
 def _build_oracle():
-    src = os.path.join(ROOT, "oracle", "raftx_oracle.c")
-    if (not os.path.exists(ORACLE_SO)) or os.path.getmtime(ORACLE_SO) < os.path.getmtime(src):
+    srcs = [os.path.join(ROOT, "oracle", f) for f in ("raftx_oracle.c", "raftx_geom_oracle.h")] + \
+           [os.path.join(ROOT, "include", "raftx.h")]
+    if (not os.path.exists(ORACLE_SO)) or any(os.path.getmtime(ORACLE_SO) < os.path.getmtime(s) for s in srcs):
         subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle")], stdout=subprocess.DEVNULL)
     return ORACLE_SO
 

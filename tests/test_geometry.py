@@ -1,0 +1,181 @@
+"""Geometry -> strip tables + statics (raftx_build_designs).
+
+CPU part (-m "not gpu"): the C oracle (oracle/raftx_geom_oracle.h) and the host descriptor parser
+(raft_amd/geometry.py) against goldens of the LIVE reference (tests/golden/geom_units.npz: strip tables packed
+from the reference's Member objects, MacCamy-Fuchs Cm tables, A_hydro_morison, C_hydro, W_hydro, V, AWP, rCB).
+GPU part (-m gpu): the HIP kernels against the same goldens and against the oracle, and a full solveDynamics
+through device-generated designs against the host-packed upload path."""
+import json
+
+import numpy as np
+import pytest
+
+from raft_amd import geometry as G
+from raft_amd._abi import RaftxError
+from tests import standin
+from tests.util import rel_err, group_rel_err
+
+FX = standin.load_fixture("geom_units.npz")
+UNITS = {u["name"]: u for u in FX["units"]}
+NAMES = list(UNITS)
+TOL = 1e-12        # fp64 restatements: expect ~1e-15 (oracle) / ~1e-14 (device libm)
+
+
+def tables_of(u):
+    return G.describe_unit(json.loads(u["design_json"]), heading_adjust=float(u["heading_adjust"]))
+
+
+def build(ctx, units, add_mask=0, mats=None):
+    tabs = [tables_of(u) for u in units]
+    mo, mem, so, st = G.concat_units(tabs)
+    nD = len(units)
+    nw = len(units[0]["w"])
+    Z = np.zeros((nD, 6, 6))
+    M0, B0, C0 = mats if mats is not None else (Z, Z, Z)
+    pose = np.array([u["pose"] for u in units])
+    off = ctx.build_designs(mo, mem, so, st, M0, B0, C0, nw, pose=pose, rho=units[0]["rho"], g=units[0]["g"],
+                            k=units[0]["k"], add_mask=add_mask)
+    return off
+
+
+def check_unit(ctx, u, tol):
+    off = build(ctx, [u])
+    gold = np.asarray(u["strips"])
+    assert off[-1] == len(gold), (off[-1], len(gold))
+    strips, cm = ctx.fetch_strips(off[-1], len(u["cm"]))
+    # positions / arms / triads / scalars, group-wise relative to the group's largest golden magnitude
+    for c0, c1 in [(0, 3), (3, 6), (6, 15), (15, 18), (18, 19), (19, 23), (23, 26)]:
+        assert rel_err(strips[:, c0:c1], gold[:, c0:c1]) < tol, (u["name"], c0)
+    assert np.array_equal(strips[:, 26:28], gold[:, 26:28])            # member / strip indices
+    if len(u["cm"]):
+        assert rel_err(cm, u["cm"]) < max(tol, 1e-11), u["name"]     # Hankel functions: libm vs scipy
+    S = ctx.fetch_statics()
+    assert rel_err(S["A_morison"][0], u["A_hydro_morison"]) < tol
+    assert rel_err(S["C_hydro"][0], u["C_hydro"]) < tol
+    assert rel_err(S["W_hydro"][0], u["W_hydro"]) < tol
+    assert abs(S["props"][0, G.SP_V] / u["V"] - 1) < tol
+    assert abs(S["props"][0, G.SP_AWP] / u["AWP"] - 1) < tol
+    assert rel_err(S["props"][0, G.SP_RCB:G.SP_RCB + 3], u["rCB"]) < tol
+
+
+# ------------------------------------------------------------------ CPU: parser + oracle pinned on the live reference
+def test_descriptor_parser_matches_reference_member_counts():
+    for u in FX["units"]:
+        t = tables_of(u)
+        assert t.n == len(u["member_ns"])                      # one descriptor per entry of FOWT.memberList
+        assert t.station_off[-1] == len(t.stations)
+
+
+def test_descriptor_broadcasting_rules():
+    mi = dict(name="m", type="rigid", rA=[0, 0, -10], rB=[0, 0, 5], shape="rect", stations=[0, 1], d=[3.0, 2.0],
+              t=0.05, Cd=[0.6, 0.8], Ca=[[1.0, 0.9], [0.8, 0.7]], heading=[0, 90], gamma=10.0)
+    gm, gs = G.describe_member(mi, heading=90.0)
+    assert gm[G.GM_SHAPE] == 0.0 and gm[G.GM_GAMMA] == 100.0            # vertical member: heading becomes twist
+    assert np.allclose(gs[:, G.GS_D:G.GS_D + 2], [[3, 2], [3, 2]])        # side pair tiled over the stations
+    assert np.allclose(gs[:, G.GS_CD + 1], 0.6) and np.allclose(gs[:, G.GS_CD + 2], 0.8)   # 1-D list = [p1, p2]
+    assert np.allclose(gs[:, G.GS_CA + 1], [1.0, 0.8]) and np.allclose(gs[:, G.GS_CA + 2], [0.9, 0.7])
+    assert np.allclose(gs[:, G.GS_S], [0, 15])
+    with pytest.raises(ValueError):
+        G.describe_member(dict(mi, rA=[0, 0, 0]))
+    with pytest.raises(ValueError):
+        G.describe_member(dict(mi, stations=[1, 0]))
+    with pytest.raises(G.UnsupportedMember):
+        G.describe_member(dict(mi, type="beam"))
+
+
+@pytest.mark.parametrize("name", NAMES)
+def test_oracle_geometry_against_live_reference(name, oracle_ctx):
+    check_unit(oracle_ctx, UNITS[name], TOL)
+
+
+def test_oracle_generated_designs_solve_like_uploaded_ones(oracle_lib):
+    """build_designs must leave the ctx in the same state as upload_designs of the host-packed table."""
+    u = UNITS["VolturnUS-S-test@pose"]
+    nw = len(u["w"])
+    rng = np.random.default_rng(5)
+    M0 = (np.eye(6) * [2e7, 2e7, 2e7, 1e10, 1e10, 2e10])[None] + np.asarray(u["A_hydro_morison"])[None]
+    B0 = np.zeros((1, 6, 6))
+    C0 = (np.diag([7e4, 7e4, 0, 0, 0, 1e8]) + np.asarray(u["C_hydro"]))[None]
+    zeta = rng.uniform(0.05, 0.4, size=(1, 1, nw))
+    beta = np.array([[0.3]])
+    out = []
+    for route in ("generated", "uploaded"):
+        ctx = oracle_lib.context(0)
+        if route == "generated":
+            Ms = M0 - np.asarray(u["A_hydro_morison"])[None]
+            Cs = C0 - np.asarray(u["C_hydro"])[None]
+            build(ctx, [u], add_mask=G.ADD_MORISON | G.ADD_HYDROSTATIC, mats=(Ms, B0, Cs))
+        else:
+            off = np.array([0, len(u["strips"])], dtype=np.int64)
+            ctx.upload_designs_raw(off, u["strips"], M0, B0, C0, nw, None, np.array([0, len(u["cm"])]), u["cm"])
+        ctx.upload_cases(u["w"], u["k"], 200.0, u["rho"], u["g"], zeta, beta)
+        out.append(ctx.solve_dynamics(6, 0.01, 0.1))
+        ctx.close()
+    assert np.array_equal(out[0]["niter"], out[1]["niter"])
+    assert group_rel_err(out[0]["Xi"][0, 0], out[1]["Xi"][0, 0]) < 1e-10
+
+
+def test_build_designs_argument_errors(oracle_ctx):
+    u = UNITS["OC4semi"]
+    t = tables_of(u)
+    mo, mem, so, st = G.concat_units([t])
+    Z = np.zeros((1, 6, 6))
+    with pytest.raises(RaftxError):                                     # MacCamy-Fuchs member without wave numbers
+        oracle_ctx.build_designs(mo, mem, so, st, Z, Z, Z, len(u["w"]), k=None)
+    with pytest.raises(RaftxError):
+        oracle_ctx.build_designs(mo, mem, so, st, Z, Z, Z, len(u["w"]), k=u["k"], add_mask=G.ADD_INERTIA)
+
+
+# ------------------------------------------------------------------ GPU: the HIP kernels
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", NAMES)
+def test_hip_geometry_against_live_reference(name, hip_ctx):
+    check_unit(hip_ctx, UNITS[name], 1e-11)
+
+
+@pytest.mark.gpu
+def test_hip_geometry_batch_matches_oracle(hip_ctx, oracle_ctx):
+    """All same-grid units in ONE launch (different member counts, poses, headings): offsets, records, statics."""
+    nw = len(UNITS["C3-variant-0"]["w"])
+    units = [u for u in FX["units"] if len(u["w"]) == nw and not len(u["cm"])] * 3
+    assert len(units) >= 9
+    off_h = build(hip_ctx, units)
+    off_o = build(oracle_ctx, units)
+    assert np.array_equal(off_h, off_o)
+    sh, _ = hip_ctx.fetch_strips(off_h[-1])
+    so, _ = oracle_ctx.fetch_strips(off_o[-1])
+    assert rel_err(sh[:, :26], so[:, :26]) < 1e-12
+    assert np.array_equal(sh[:, 26:28], so[:, 26:28])
+    Sh, So = hip_ctx.fetch_statics(), oracle_ctx.fetch_statics()
+    for key in ("A_morison", "C_hydro", "W_hydro", "props"):
+        assert rel_err(Sh[key], So[key]) < 1e-12, key
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["VolturnUS-S-test@pose", "OC4semi@heel", "C3-variant-1"])
+def test_hip_generated_designs_solve_like_uploaded_ones(name, hip_lib):
+    u = UNITS[name]
+    nw = len(u["w"])
+    rng = np.random.default_rng(7)
+    M0 = (np.eye(6) * [2e7, 2e7, 2e7, 1e10, 1e10, 2e10])[None] + np.asarray(u["A_hydro_morison"])[None]
+    B0 = np.zeros((1, 6, 6))
+    C0 = (np.diag([7e4, 7e4, 0, 0, 0, 1e8]) + np.asarray(u["C_hydro"]))[None]
+    zeta = rng.uniform(0.05, 0.4, size=(2, 2, nw))
+    beta = np.array([[0.3, -1.0], [2.0, 0.0]])
+    out = []
+    for route in ("generated", "uploaded"):
+        ctx = hip_lib.context(0)
+        if route == "generated":
+            Ms = M0 - np.asarray(u["A_hydro_morison"])[None]
+            Cs = C0 - np.asarray(u["C_hydro"])[None]
+            build(ctx, [u], add_mask=G.ADD_MORISON | G.ADD_HYDROSTATIC, mats=(Ms, B0, Cs))
+        else:
+            off = np.array([0, len(u["strips"])], dtype=np.int64)
+            cm = u["cm"] if len(u["cm"]) else None
+            ctx.upload_designs_raw(off, u["strips"], M0, B0, C0, nw, None,
+                                   np.array([0, len(u["cm"])]) if cm is not None else None, cm)
+        ctx.upload_cases(u["w"], u["k"], 200.0, u["rho"], u["g"], zeta, beta)
+        out.append(ctx.solve_dynamics(6, 0.01, 0.1))
+        ctx.close()
+    assert np.array_equal(out[0]["niter"], out[1]["niter"])
+    assert group_rel_err(out[0]["Xi"].reshape(-1, 6, nw), out[1]["Xi"].reshape(-1, 6, nw)) < 1e-9
