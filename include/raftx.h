@@ -237,8 +237,9 @@ int raftx_qtf_force(raftx_ctx *ctx, int nSet, int nw2, const double *w2, const r
 #define RAFTX_GM_FLAGS    9   /* bit 0: potMod (no strip-theory inertia/added mass), bit 1: MacCamy-Fuchs */
 #define RAFTX_GM_L        10  /* member length |rB - rA| (raft_member.py:72) */
 #define RAFTX_GM_RHOSHELL 11  /* shell density (raft_member.py:124) */
-#define RAFTX_GM_FLAG_POTMOD 1
-#define RAFTX_GM_FLAG_MCF    2
+#define RAFTX_GM_FLAG_POTMOD   1
+#define RAFTX_GM_FLAG_MCF      2
+#define RAFTX_GM_FLAG_NOSTATIC 4   /* nacelle members: strips only, left out of the statics (raft_fowt.py:876) */
 /* Station record (RAFTX_GS_N doubles); stations of member m are rows stationOff[m]..stationOff[m+1]: */
 #define RAFTX_GS_N        16
 #define RAFTX_GS_S        0   /* position along the axis from end A [m] (raft_member.py:99) */
@@ -248,11 +249,17 @@ int raftx_qtf_force(raftx_ctx *ctx, int nSet, int nw2, const double *w2, const r
 #define RAFTX_GS_CA       8   /* Ca_q, Ca_p1, Ca_p2, Ca_End (raft_member.py:184-187) */
 #define RAFTX_GS_LFILL    12  /* ballast fill length of the section that STARTS at this station [m] (:143) */
 #define RAFTX_GS_RHOFILL  13  /* ballast density of that section (:146-155) */
+/* End caps / bulkheads (RAFTX_GC_N doubles; caps of member m are rows capOff[m]..capOff[m+1]; raft_member.py:162-175,
+ * 659-810): position along the axis [m], thickness, inner (hole) diameter or side pair. */
+#define RAFTX_GC_N        4
+#define RAFTX_GC_S        0
+#define RAFTX_GC_T        1
+#define RAFTX_GC_DIN      2
 /* add_mask: what the call adds to the caller's M0 / C0 before installing them (0 = M0/B0/C0 used as given,
  * exactly like raftx_upload_designs) */
 #define RAFTX_ADD_MORISON     1   /* M0 += A_hydro_morison (raft_fowt.py:1625) */
 #define RAFTX_ADD_HYDROSTATIC 2   /* C0 += C_hydro         (raft_fowt.py:1214-1256) */
-#define RAFTX_ADD_INERTIA     4   /* M0 += M_struc, C0 += C_struc of the described members (raft_fowt.py:841-1120) */
+#define RAFTX_ADD_INERTIA     4   /* M0 += M_struc, C0 += C_struc of the described members (raft_fowt.py:876-900,1120-1199) */
 /* memberOff [nDesign+1] rows of members[.,RAFTX_GM_N]; stationOff [nMember+1] rows of stations[.,RAFTX_GS_N];
  * pose [nDesign,6] = mean position of the reduced DOFs (x,y,z,roll,pitch,yaw; FOWT.setPosition's argument,
  * raft_fowt.py:754) or NULL for zeros; rho, g: water density and gravity (raft_fowt.py:172-173);
@@ -260,7 +267,8 @@ int raftx_qtf_force(raftx_ctx *ctx, int nSet, int nw2, const double *w2, const r
  * M0,B0,C0,MBw as in raftx_upload_designs.  stripOffsets [nDesign+1] (out): submerged strips per design.
  * Only strips below the mean waterline are kept (raft_member.py:1310,1979,2058). */
 int raftx_build_designs(raftx_ctx *ctx, int nDesign, const int64_t *memberOff, const double *members,
-                        const int64_t *stationOff, const double *stations, const double *pose,
+                        const int64_t *stationOff, const double *stations,
+                        const int64_t *capOff, const double *caps, const double *pose,
                         double rho, double g, int nw, const double *k, int add_mask,
                         const double *M0, const double *B0, const double *C0, const double *MBw,
                         int64_t *stripOffsets);
@@ -271,16 +279,19 @@ int raftx_fetch_strips(raftx_ctx *ctx, double *strips, raftx_c128 *cm);
  *   A_morison [nDesign,6,6]  FOWT.A_hydro_morison (raft_fowt.py:1589-1625), about the unit's reference point
  *   C_hydro   [nDesign,6,6]  hydrostatic stiffness (raft_member.py:838-1010, raft_fowt.py:1214-1256)
  *   W_hydro   [nDesign,6]    buoyancy force/moment vector (same lines)
- *   M_struc   [nDesign,6,6]  mass/inertia of the described members (raft_member.py:380-836)
- *   props     [nDesign,8]    V (displaced volume), AWP, rCB x,y,z, mass, zCG ... (RAFTX_SP_*) */
-#define RAFTX_SP_N     8
+ *   M_struc   [nDesign,6,6]  mass/inertia of the described members: shells, ballast, caps (raft_member.py:380-836)
+ *   C_struc   [nDesign,6,6]  weight part of the stiffness (raft_member.py:1179-1181, raft_fowt.py:1123,1191,1200)
+ *   W_struc   [nDesign,6]    weight force/moment vector (helpers.py:1060-1082)
+ *   props     [nDesign,12]   V (displaced volume), AWP, rCB x,y,z, mass, rCG x,y,z (RAFTX_SP_*)
+ * Rotor-nacelle assemblies, point inertias and moorings are not geometry: the caller adds them through M0/C0. */
+#define RAFTX_SP_N     12
 #define RAFTX_SP_V     0
 #define RAFTX_SP_AWP   1
-#define RAFTX_SP_RCB   2   /* x,y,z of the centre of buoyancy */
+#define RAFTX_SP_RCB   2   /* x,y,z of the centre of buoyancy (raft_fowt.py:1245) */
 #define RAFTX_SP_MASS  5
-#define RAFTX_SP_ZCG   6
+#define RAFTX_SP_RCG   6   /* x,y,z of the centre of mass (raft_fowt.py:1210) */
 int raftx_fetch_statics(raftx_ctx *ctx, double *A_morison, double *C_hydro, double *W_hydro,
-                        double *M_struc, double *props);
+                        double *M_struc, double *C_struc, double *W_struc, double *props);
 
 /* Duration (ms) of the device work of the last raftx_excitation /
  * raftx_linearize / raftx_solve_dynamics / raftx_solve_system call on this

@@ -348,6 +348,24 @@ def _geom_unit(fowt, design_json, heading_adjust=0.0):
     return out
 
 
+def _bare(design):
+    """The same design with a massless rotor-nacelle assembly and no additional effects: FOWT.calcStatics then returns
+    the mass / weight-stiffness of the MEMBERS alone (what raftx_build_designs generates)."""
+    d = copy.deepcopy(design)
+    for t in ([d["turbine"]] if d.get("turbine") else []) + list(d.get("turbines", [])):
+        for k in ("mRNA", "IxRNA", "IrRNA"):
+            if k in t:
+                t[k] = 0.0 if np.isscalar(t[k]) else [0.0] * len(t[k])
+    for pl in ([d["platform"]] if d.get("platform") else []) + list(d.get("platforms", [])):
+        pl.pop("additional_effects", None)
+    return d
+
+
+def _bare_statics(fowt):
+    return {"M_struc_bare": np.array(fowt.M_struc), "C_struc_bare": np.array(fowt.C_struc),
+            "W_struc_bare": np.array(fowt.W_struc), "m_bare": float(fowt.m), "rCG_bare": np.array(fowt.rCG)}
+
+
 def fixture_geom():
     """Goldens for the device geometry generator (raftx_build_designs): member description in, strip tables /
     Morison added mass / hydrostatics / inertia of the LIVE reference out.  Decks: OC3spar (tapered spar),
@@ -360,6 +378,8 @@ def fixture_geom():
         dj = _design_subset(design)
         m = rh.build_model(copy.deepcopy(design), r6=None if r6 is None else [r6])
         u = _geom_unit(m.fowtList[0], dj)
+        mb = rh.build_model(_bare(design), r6=None if r6 is None else [r6])
+        u.update(_bare_statics(mb.fowtList[0]))
         u["name"] = label or name
         units.append(u)
 
@@ -384,8 +404,10 @@ def fixture_geom():
     unit_design = {"site": d["site"], "platform": d["platform"], "turbine": d["turbine"]}
     dj = _design_subset(unit_design)
     m = rh.build_model(copy.deepcopy(d))
+    mb = rh.build_model(_bare(d))
     for i, f in enumerate(m.fowtList):
         u = _geom_unit(f, dj, heading_adjust=d["array"]["data"][i][5])
+        u.update(_bare_statics(mb.fowtList[i]))
         u["name"] = "farm-unit-%d" % i
         units.append(u)
     fx = {"config": "geometry generator goldens (live reference)", "units": units}

@@ -107,12 +107,12 @@ class RaftxLib:
         L.raftx_motion_stats.restype = C.c_int
         L.raftx_debug_math.argtypes = [_vp, C.c_int, _vp, _vp, _vp, _vp]
         L.raftx_debug_math.restype = C.c_int
-        L.raftx_build_designs.argtypes = [_vp, C.c_int, _vp, _vp, _vp, _vp, _vp, C.c_double, C.c_double, C.c_int, _vp,
-                                          C.c_int, _vp, _vp, _vp, _vp, _vp]
+        L.raftx_build_designs.argtypes = [_vp, C.c_int, _vp, _vp, _vp, _vp, _vp, _vp, _vp, C.c_double, C.c_double, C.c_int,
+                                          _vp, C.c_int, _vp, _vp, _vp, _vp, _vp]
         L.raftx_build_designs.restype = C.c_int
         L.raftx_fetch_strips.argtypes = [_vp, _vp, _vp]
         L.raftx_fetch_strips.restype = C.c_int
-        L.raftx_fetch_statics.argtypes = [_vp, _vp, _vp, _vp, _vp, _vp]
+        L.raftx_fetch_statics.argtypes = [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]
         L.raftx_fetch_statics.restype = C.c_int
         L.raftx_last_kernel_ms.argtypes = [_vp]
         L.raftx_last_kernel_ms.restype = C.c_double
@@ -202,8 +202,8 @@ class Context:
         self._nw_designs = int(nw)
 
     def build_designs(self, member_off, members, station_off, stations, M0, B0, C0, nw, pose=None, rho=1025.0,
-                      g=9.81, k=None, add_mask=0, MBw=None):
-        """Geometry -> resident strip tables (+ statics) on the device: raftx_build_designs.  Member / station
+                      g=9.81, k=None, add_mask=0, MBw=None, cap_off=None, caps=None):
+        """Geometry -> resident strip tables (+ statics) on the device: raftx_build_designs.  Member / station / cap
         records as raft_amd/geometry.py packs them.  Returns the strip offsets [nDesign+1]."""
         member_off = np.ascontiguousarray(member_off, dtype=np.int64)
         station_off = np.ascontiguousarray(station_off, dtype=np.int64)
@@ -221,9 +221,17 @@ class Context:
             k = _f64(k, (nw,), "k")
         if MBw is not None:
             MBw = _f64(MBw, (nD, 2, 6, 6, nw), "MBw")
+        if cap_off is not None:
+            cap_off = np.ascontiguousarray(cap_off, dtype=np.int64)
+            if len(cap_off) != member_off[-1] + 1:
+                raise ValueError("cap_off has %d entries, expected %d" % (len(cap_off), member_off[-1] + 1))
+            caps = _f64(caps, (cap_off[-1], 4), "caps")
+            if caps.size == 0:
+                caps = np.zeros((1, 4))
         off = np.zeros(nD + 1, dtype=np.int64)
         rc = self.rlib.lib.raftx_build_designs(self._h, nD, _ptr(member_off), _ptr(members), _ptr(station_off),
-                                               _ptr(stations), _ptr(pose), float(rho), float(g), int(nw), _ptr(k),
+                                               _ptr(stations), _ptr(cap_off), _ptr(caps if cap_off is not None else None),
+                                               _ptr(pose), float(rho), float(g), int(nw), _ptr(k),
                                                int(add_mask), _ptr(M0), _ptr(B0), _ptr(C0), _ptr(MBw), _ptr(off))
         self._check(rc, "raftx_build_designs")
         self.nDesign = nD
@@ -239,12 +247,14 @@ class Context:
         return strips, cm
 
     def fetch_statics(self):
-        """dict(A_morison [nD,6,6], C_hydro [nD,6,6], W_hydro [nD,6], M_struc [nD,6,6], props [nD,8])."""
+        """dict(A_morison, C_hydro, M_struc, C_struc [nD,6,6]; W_hydro, W_struc [nD,6]; props [nD,12])."""
         nD = self.nDesign
         out = dict(A_morison=np.empty((nD, 6, 6)), C_hydro=np.empty((nD, 6, 6)), W_hydro=np.empty((nD, 6)),
-                   M_struc=np.empty((nD, 6, 6)), props=np.empty((nD, 8)))
+                   M_struc=np.empty((nD, 6, 6)), C_struc=np.empty((nD, 6, 6)), W_struc=np.empty((nD, 6)),
+                   props=np.empty((nD, 12)))
         rc = self.rlib.lib.raftx_fetch_statics(self._h, _ptr(out["A_morison"]), _ptr(out["C_hydro"]),
-                                               _ptr(out["W_hydro"]), _ptr(out["M_struc"]), _ptr(out["props"]))
+                                               _ptr(out["W_hydro"]), _ptr(out["M_struc"]), _ptr(out["C_struc"]),
+                                               _ptr(out["W_struc"]), _ptr(out["props"]))
         self._check(rc, "raftx_fetch_statics")
         return out
 

@@ -21,6 +21,7 @@
 
 #define MP_N 24      // member pose scratch: rA0(3) rA(3) q(3) p1(3) p2(3) R00 R01 R10 R11 L
 #define MH_N 48      // member hydrostatics: Cmat(36) Fvec(6) V rcV(3) AWP  (about the member's own node)
+#define MI_N 48      // member inertia: M(36) mass centre(3) W(6) c33  (about the member's own node)
 
 // ---------------------------------------------------------------------------------------------------------
 // Run detection shared by raftx_upload_designs (host) and raftx_build_designs (device): turns the ABI strip
@@ -110,6 +111,11 @@ struct GeomArgs {
     const double *gs;            // [nStation,RAFTX_GS_N]
     const double *pose;          // [nDesign,6] or null
     const int *mdesign;          // [nMember] design of each member
+    const int64_t *capOff;       // [nMember+1] or null
+    const double *caps;          // [nCap,RAFTX_GC_N]
+    double *minert;              // [nMember,MI_N]
+    int *err;                    // first unsupported cap layout: (member+1), 0 = none
+    double *Ms, *Cs, *Ws;        // [nDesign,36] [nDesign,36] [nDesign,6]
     double rho, g;
     int nw;
     const double *k;             // [nw] or null
@@ -212,7 +218,244 @@ __device__ inline void geom_frustum(double a0, double a1, double b0, double b1, 
     hc = ((A1 + 2 * Am + 3 * A2) / (A1 + Am + A2)) * H / 4;
 }
 
-// one thread per member: pose, wet-strip count, hydrostatics about the member's own node
+
+// r^5 to (almost always) the correctly rounded double, via double-double products.  FrustumMOI's tapered branch
+// divides (r2^5 - r1^5) by (r2 - r1) (helpers.py:81-82); when a cap's hole is "tapered" by one rounding error
+// (dAi = dA*(dBi/dB), raft_member.py:691) the last bit of r**5 decides the quotient, and CPython's r**5 is libm pow.
+__device__ inline double geom_pow5(double r) {
+    GEOM_NOFMA                     // the error-free transformations below must not be re-contracted
+    const double h2 = r * r, l2 = fma(r, r, -h2);
+    double h4 = h2 * h2, l4 = fma(h2, h2, -h4) + 2.0 * h2 * l2;
+    const double s = h4 + l4;
+    l4 = l4 - (s - h4);
+    h4 = s;
+    const double h5 = h4 * r, l5 = fma(h4, r, -h5) + l4 * r;
+    return h5 + l5;
+}
+// FrustumMOI (helpers.py:65-84): radial (about the end) and axial moments of inertia of a circular frustum
+__device__ inline void geom_frustum_moi(double dA, double dB, double H, double p, double &Irad, double &Iax) {
+    GEOM_NOFMA
+    if (H == 0) { Irad = 0; Iax = 0; return; }
+    const double r1 = dA / 2, r2 = dB / 2;
+    if (dA == dB) {
+        Irad = (1.0 / 12) * (p * H * M_PI * r1 * r1) * (3 * r1 * r1 + 4 * H * H);
+        Iax = (1.0 / 2) * p * M_PI * H * r1 * r1 * r1 * r1;
+    } else {
+        const double q5 = (geom_pow5(r2) - geom_pow5(r1)) / (r2 - r1);
+        Irad = (1.0 / 20) * p * M_PI * H * q5 + (1.0 / 30) * p * M_PI * H * H * H * (r1 * r1 + 3 * r1 * r2 + 6 * r2 * r2);
+        Iax = (1.0 / 10) * p * M_PI * H * q5;
+    }
+}
+// RectangularFrustumMOI (helpers.py:86-148)
+__device__ inline void geom_rect_moi(double La, double Wa, double Lb, double Wb, double H, double p, double (&Iv)[3]) {
+    GEOM_NOFMA
+    if (H == 0) { Iv[0] = Iv[1] = Iv[2] = 0; return; }
+    double x2, y2, z2;
+    if (La == Lb && Wa == Wb) {
+        const double M = p * La * Wa * H;
+        Iv[0] = (1.0 / 12) * M * (Wa * Wa + 4 * H * H);
+        Iv[1] = (1.0 / 12) * M * (La * La + 4 * H * H);
+        Iv[2] = (1.0 / 12) * M * (La * La + Wa * Wa);
+        return;
+    } else if (La != Lb && Wa != Wb) {
+        const double dL = Lb - La, dW = Wb - Wa;
+        x2 = (1.0 / 12) * p * (dL * dL * dL * H * (Wb / 5 + Wa / 20) + dL * dL * La * H * (3 * Wb / 4 + Wa / 4) +
+                               dL * La * La * H * (Wb + Wa / 2) + La * La * La * H * (Wb / 2 + Wa / 2));
+        y2 = (1.0 / 12) * p * (dW * dW * dW * H * (Lb / 5 + La / 20) + dW * dW * Wa * H * (3 * Lb / 4 + La / 4) +
+                               dW * Wa * Wa * H * (Lb + La / 2) + Wa * Wa * Wa * H * (Lb / 2 + La / 2));
+        z2 = p * (Wb * Lb / 5 + Wa * Lb / 20 + La * Wb / 20 + Wa * La * (1.0 / 30)) * H * H * H;
+    } else if (La == Lb) {
+        x2 = (1.0 / 24) * p * (La * La * La) * H * (Wb + Wa);
+        y2 = (1.0 / 48) * p * La * H * (Wb * Wb * Wb + Wa * Wb * Wb + Wa * Wa * Wb + Wa * Wa * Wa);
+        z2 = (1.0 / 12) * p * La * (H * H * H) * (3 * Wb + Wa);
+    } else {
+        x2 = (1.0 / 48) * p * Wa * H * (Lb * Lb * Lb + La * Lb * Lb + La * La * Lb + La * La * La);
+        y2 = (1.0 / 24) * p * (Wa * Wa * Wa) * H * (Lb + La);
+        z2 = (1.0 / 12) * p * Wa * (H * H * H) * (3 * Lb + La);
+    }
+    Iv[0] = y2 + z2; Iv[1] = x2 + z2; Iv[2] = x2 + y2;
+}
+// inner diameter / side length (d - 2t) along the member, np.interp semantics (raft_member.py:667,727)
+__device__ inline double geom_interp_inner(double x, const double *gs, int n, int c) {
+    GEOM_NOFMA
+#define DIN_(j) (gs[(size_t)(j) * RAFTX_GS_N + RAFTX_GS_D + c] - 2 * gs[(size_t)(j) * RAFTX_GS_N + RAFTX_GS_T])
+    if (x < gs[RAFTX_GS_S]) return DIN_(0);
+    if (x > gs[(size_t)(n - 1) * RAFTX_GS_N + RAFTX_GS_S]) return DIN_(n - 1);
+    int j = 0;
+    for (int i = 0; i < n; i++)
+        if (gs[(size_t)i * RAFTX_GS_N + RAFTX_GS_S] <= x) j = i;
+    const double fj = DIN_(j);
+    if (j == n - 1) return fj;
+    const double xj = gs[(size_t)j * RAFTX_GS_N + RAFTX_GS_S];
+    if (xj == x) return fj;
+    const double slope = (DIN_(j + 1) - fj) / (gs[(size_t)(j + 1) * RAFTX_GS_N + RAFTX_GS_S] - xj);
+    return slope * (x - xj) + fj;
+#undef DIN_
+}
+// M += translateMatrix6to6DOF(diag(m,m,m) (+) I_rot, r) with I_rot = Ix p1p1^T + Iy p2p2^T + Iz qq^T
+// (helpers.py:563-585, raft_member.py:507-516): [[m I, m H],[m H^T, m H H^T + I_rot]], H = getH(r)
+__device__ inline void geom_add_submember(double *M, double mass, const double (&Iv)[3], const double *p1, const double *p2,
+                                          const double *q, const double (&r)[3]) {
+    GEOM_NOFMA
+    const double H[3][3] = {{0, r[2], -r[1]}, {-r[2], 0, r[0]}, {r[1], -r[0], 0}};
+    for (int i = 0; i < 3; i++)
+        for (int j = 0; j < 3; j++) {
+            double hh = 0.0;
+            for (int l = 0; l < 3; l++) hh += H[i][l] * mass * H[j][l];
+            M[i * 6 + j] += (i == j) ? mass : 0.0;
+            M[i * 6 + 3 + j] += mass * H[i][j];
+            M[(3 + i) * 6 + j] += mass * H[j][i];
+            M[(3 + i) * 6 + 3 + j] += hh + (p1[i] * Iv[0] * p1[j] + p2[i] * Iv[1] * p2[j] + q[i] * Iv[2] * q[j]);
+        }
+}
+
+// Member.getInertia + getWeight, rigid branch, about the member's own node (raft_member.py:380-836, 1179-1181).
+// Zero-length sections re-add the local inertia tensor of the previous section with zero mass, as the reference
+// does (Ixx, Iyy, Izz are not reset between sections, :420-513).  Returns a non-zero code for cap layouts the
+// reference itself cannot handle.
+__device__ inline int geom_member_inertia(const double *gm, const double *gs, int n, const double *gc, int ncap,
+                                          const double *rA, const double *q, const double *p1, const double *p2, double g,
+                                          double *out) {
+    GEOM_NOFMA
+    const bool circ = gm[RAFTX_GM_SHAPE] != 0.0;
+    const int c1 = circ ? 0 : 1;
+    const double rho_shell = gm[RAFTX_GM_RHOSHELL];
+    double M[36], mc[3] = {0, 0, 0}, I3[3] = {0, 0, 0};
+    for (int i = 0; i < 36; i++) M[i] = 0.0;
+    for (int i = 1; i < n; i++) {
+        const double *a = gs + (size_t)(i - 1) * RAFTX_GS_N, *b = gs + (size_t)i * RAFTX_GS_N;
+        const double l = b[RAFTX_GS_S] - a[RAFTX_GS_S];
+        double mass = 0.0, center[3] = {0, 0, 0};
+        if (l > 0) {
+            const double l_fill = a[RAFTX_GS_LFILL], rho_fill = a[RAFTX_GS_RHOFILL];
+            const double dA0 = a[RAFTX_GS_D], dA1 = a[RAFTX_GS_D + c1], dB0 = b[RAFTX_GS_D], dB1 = b[RAFTX_GS_D + c1];
+            const double iA0 = dA0 - 2 * a[RAFTX_GS_T], iA1 = dA1 - 2 * a[RAFTX_GS_T];
+            const double iB0 = dB0 - 2 * b[RAFTX_GS_T], iB1 = dB1 - 2 * b[RAFTX_GS_T];
+            const double f0 = (iB0 - iA0) * (l_fill / l) + iA0, f1 = (iB1 - iA1) * (l_fill / l) + iA1;
+            double Vo, hco, Vi, hci, vf, hcf;
+            geom_frustum(dA0, dA1, dB0, dB1, circ, l, Vo, hco);
+            geom_frustum(iA0, iA1, iB0, iB1, circ, l, Vi, hci);
+            const double m_shell = (Vo - Vi) * rho_shell;
+            const double hc_shell = (Vo - Vi != 0) ? ((hco * Vo) - (hci * Vi)) / (Vo - Vi) : 0.0;
+            geom_frustum(iA0, iA1, f0, f1, circ, l_fill, vf, hcf);
+            const double m_fill = vf * rho_fill;
+            mass = m_shell + m_fill;
+            const double hc = (mass != 0) ? ((hcf * m_fill) + (hc_shell * m_shell)) / mass : 0.0;
+            if (circ) {
+                double Iro, Iao, Iri, Iai, Irf, Iaf;
+                geom_frustum_moi(dA0, dB0, l, rho_shell, Iro, Iao);
+                geom_frustum_moi(iA0, iB0, l, rho_shell, Iri, Iai);
+                geom_frustum_moi(iA0, f0, l_fill, rho_fill, Irf, Iaf);
+                I3[0] = I3[1] = ((Iro - Iri) + Irf) - mass * hc * hc;
+                I3[2] = (Iao - Iai) + Iaf;
+            } else {
+                double Io[3], Ii[3], If[3];
+                geom_rect_moi(dA0, dA1, dB0, dB1, l, rho_shell, Io);
+                geom_rect_moi(iA0, iA1, iB0, iB1, l, rho_shell, Ii);
+                geom_rect_moi(iA0, iA1, f0, f1, l_fill, rho_fill, If);
+                I3[0] = ((Io[0] - Ii[0]) + If[0]) - mass * hc * hc;
+                I3[1] = ((Io[1] - Ii[1]) + If[1]) - mass * hc * hc;
+                I3[2] = (Io[2] - Ii[2]) + If[2];
+            }
+            for (int c = 0; c < 3; c++) center[c] = rA[c] + q[c] * (a[RAFTX_GS_S] + hc);
+        }
+        double rel[3];
+        for (int c = 0; c < 3; c++) { mc[c] += mass * center[c]; rel[c] = center[c] - rA[c]; }
+        geom_add_submember(M, mass, I3, p1, p2, q, rel);
+    }
+    const double s0 = gs[RAFTX_GS_S], s1 = gs[(size_t)(n - 1) * RAFTX_GS_N + RAFTX_GS_S];
+    for (int i = 0; i < ncap; i++) {
+        const double *cp = gc + (size_t)i * RAFTX_GC_N;
+        const double Lc = cp[RAFTX_GC_S], h = cp[RAFTX_GC_T];
+        double dA[2] = {0, 0}, dB[2] = {0, 0}, dAi[2] = {0, 0}, dBi[2] = {0, 0};
+        int where;                                       // 0 bottom, 1 top, 2 middle
+        if (Lc == s0) {
+            where = 0;
+            for (int c = 0; c <= c1; c++) {
+                dA[c] = gs[RAFTX_GS_D + c] - 2 * gs[RAFTX_GS_T];
+                dB[c] = geom_interp_inner(Lc + h, gs, n, c);
+                dAi[c] = cp[RAFTX_GC_DIN + c];
+                dBi[c] = dB[c] * (dAi[c] / dA[c]);
+            }
+        } else if (Lc == s1) {
+            where = 1;
+            if (!circ) return 2;                         // the reference fails here (slBi used before assignment, :731-735)
+            dA[0] = geom_interp_inner(Lc - h, gs, n, 0);
+            dB[0] = gs[(size_t)(n - 1) * RAFTX_GS_N + RAFTX_GS_D] - 2 * gs[(size_t)(n - 1) * RAFTX_GS_N + RAFTX_GS_T];
+            dBi[0] = cp[RAFTX_GC_DIN];
+            dAi[0] = dA[0] * (dBi[0] / dB[0]);
+        } else if ((Lc > s0 && Lc < s0 + h) || (Lc < s1 && Lc > s1 - h)) {
+            return 3;                                    // ValueError('This setup cannot be handled by getIneria yet')
+        } else {
+            where = 2;
+            if (!circ) return 2;                         // np.interp on a 2-D table raises in the reference (:741-755)
+            if (i < ncap - 1 && Lc == gc[(size_t)(i + 1) * RAFTX_GC_N + RAFTX_GC_S]) {         // discontinuity: cap going down
+                if (i >= n) return 4;
+                dA[0] = geom_interp_inner(Lc - h, gs, n, 0);
+                dB[0] = gs[(size_t)i * RAFTX_GS_N + RAFTX_GS_D] - 2 * gs[(size_t)i * RAFTX_GS_N + RAFTX_GS_T];   // (sic) d[i] with the CAP index, :690
+                dBi[0] = cp[RAFTX_GC_DIN];
+                dAi[0] = dA[0] * (dBi[0] / dB[0]);
+            } else if (i > 0 && Lc == gc[(size_t)(i - 1) * RAFTX_GC_N + RAFTX_GC_S]) {       // ... and one going up
+                if (i >= n) return 4;
+                dA[0] = gs[(size_t)i * RAFTX_GS_N + RAFTX_GS_D] - 2 * gs[(size_t)i * RAFTX_GS_N + RAFTX_GS_T];
+                dB[0] = geom_interp_inner(Lc + h, gs, n, 0);
+                dAi[0] = cp[RAFTX_GC_DIN];
+                dBi[0] = dB[0] * (dAi[0] / dA[0]);
+            } else {
+                dA[0] = geom_interp_inner(Lc - h / 2, gs, n, 0);
+                dB[0] = geom_interp_inner(Lc + h / 2, gs, n, 0);
+                const double dM = geom_interp_inner(Lc, gs, n, 0);
+                dAi[0] = dA[0] * (cp[RAFTX_GC_DIN] / dM);
+                dBi[0] = dB[0] * (cp[RAFTX_GC_DIN] / dM);
+            }
+        }
+        double Vo, hco, Vi, hci;
+        geom_frustum(dA[0], dA[1], dB[0], dB[1], circ, h, Vo, hco);
+        geom_frustum(dAi[0], dAi[1], dBi[0], dBi[1], circ, h, Vi, hci);
+        const double m_cap = (Vo - Vi) * rho_shell;
+        const double hc_cap = (Vo - Vi != 0) ? ((hco * Vo) - (hci * Vi)) / (Vo - Vi) : 0.0;
+        double Ic[3];
+        if (circ) {
+            double Iro, Iao, Iri, Iai;
+            geom_frustum_moi(dA[0], dB[0], h, rho_shell, Iro, Iao);
+            geom_frustum_moi(dAi[0], dBi[0], h, rho_shell, Iri, Iai);
+            Ic[0] = Ic[1] = (Iro - Iri) - m_cap * hc_cap * hc_cap;
+            Ic[2] = Iao - Iai;
+        } else {
+            double Io[3], Ii[3];
+            geom_rect_moi(dA[0], dA[1], dB[0], dB[1], h, rho_shell, Io);
+            geom_rect_moi(dAi[0], dAi[1], dBi[0], dBi[1], h, rho_shell, Ii);
+            Ic[0] = (Io[0] - Ii[0]) - m_cap * hc_cap * hc_cap;
+            Ic[1] = (Io[1] - Ii[1]) - m_cap * hc_cap * hc_cap;
+            Ic[2] = Io[2] - Ii[2];
+        }
+        double rel[3];
+        for (int c = 0; c < 3; c++) {
+            const double pos = rA[c] + q[c] * Lc;                                       // :772-778
+            const double cc = (where == 0) ? pos + q[c] * hc_cap : (where == 1 ? pos - q[c] * (h - hc_cap) : pos - q[c] * ((h / 2) - hc_cap));
+            rel[c] = cc - rA[c];
+            mc[c] += m_cap * cc;
+        }
+        geom_add_submember(M, m_cap, Ic, p1, p2, q, rel);
+    }
+    const double mass = M[0];
+    for (int i = 0; i < 36; i++) out[i] = M[i];
+    out[36] = mass;
+    double dR[3];
+    for (int c = 0; c < 3; c++) {
+        const double cen = (mass != 0) ? mc[c] / mass : 0.0;
+        out[37 + c] = cen;
+        dR[c] = cen - rA[c];
+    }
+    // getWeightOfPointMass(mass, rCoG - node) (helpers.py:1060-1082)
+    const double Fz = -g * mass;
+    out[40] = 0.0; out[41] = 0.0; out[42] = Fz;
+    out[43] = dR[1] * Fz; out[44] = -dR[0] * Fz; out[45] = 0.0;
+    out[46] = -mass * g * dR[2];
+    return 0;
+}
+
+// one thread per member: pose, wet-strip count, hydrostatics and inertia about the member's own node
 __global__ __launch_bounds__(128) void k_geom_member(GeomArgs A) {
     GEOM_NOFMA
     const int64_t m = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -366,10 +609,23 @@ __global__ __launch_bounds__(128) void k_geom_member(GeomArgs A) {
             for (int c = 0; c < 3; c++) rcV[c] += rc[c] * V;
         }
     }
-    double *mh = A.mhyd + (size_t)m * MH_N;
+    double *mh = A.mhyd + (size_t)m * MH_N, *mi = A.minert + (size_t)m * MI_N;
+    if (flags & RAFTX_GM_FLAG_NOSTATIC) {                // nacelle members stay out of the statics (raft_fowt.py:876)
+        for (int i = 0; i < MH_N; i++) mh[i] = 0.0;
+        for (int i = 0; i < MI_N; i++) mi[i] = 0.0;
+        return;
+    }
     for (int i = 0; i < 36; i++) mh[i] = C[i];
     for (int i = 0; i < 6; i++) mh[36 + i] = F[i];
-    mh[42] = Vt; mh[43] = rcV[0]; mh[44] = rcV[1]; mh[45] = rcV[2]; mh[46] = AWPm;
+    mh[42] = Vt; mh[43] = rcV[0]; mh[44] = rcV[1]; mh[45] = rcV[2]; mh[46] = AWPm; mh[47] = 0.0;
+    const int ncap = A.capOff ? (int)(A.capOff[m + 1] - A.capOff[m]) : 0;
+    const double *gc = A.capOff ? A.caps + (size_t)A.capOff[m] * RAFTX_GC_N : nullptr;
+    mi[47] = 0.0;
+    const int code = geom_member_inertia(gm, gs, n, gc, ncap, rA, q, p1, p2, A.g, mi);
+    if (code) {
+        for (int i = 0; i < MI_N; i++) mi[i] = 0.0;
+        atomicCAS(A.err, 0, (int)(m + 1));
+    }
 }
 
 // exclusive scans of the per-member counts (one workgroup; nMember is ~1e5 for a 10k-design sweep)
@@ -542,7 +798,54 @@ __global__ __launch_bounds__(64) void k_geom_mcf(GeomArgs A, int64_t nRows) {
     A.cm[((size_t)row * 2 + 1) * A.nw + iw] = cplx{cr * ramp + (1.0 + Ca2) * (1 - ramp), ci * ramp};
 }
 
-// one thread per design: device strip records + run flags, Morison added mass, hydrostatic reduction
+
+// out += T^T C T for the rigid map T = [[I, H(a)],[0, I]] of a member node (raft_fowt.py:1120-1123; H: helpers.py:428-437)
+__device__ inline void geom_reduce_matrix(const double *C, const double (&a)[3], double *out) {
+    GEOM_NOFMA
+    const double H[3][3] = {{0, a[2], -a[1]}, {-a[2], 0, a[0]}, {a[1], -a[0], 0}};
+    double t12[3][3], t21[3][3];
+    for (int i = 0; i < 3; i++)
+        for (int j = 0; j < 3; j++) {
+            double s12 = C[i * 6 + 3 + j], s21 = C[(3 + i) * 6 + j];
+            for (int l = 0; l < 3; l++) {
+                s12 += C[i * 6 + l] * H[l][j];                 // C11 H + C12
+                s21 += H[l][i] * C[l * 6 + j];                 // H^T C11 + C21
+            }
+            t12[i][j] = s12;
+            t21[i][j] = s21;
+        }
+    for (int i = 0; i < 3; i++)
+        for (int j = 0; j < 3; j++) {
+            out[i * 6 + j] += C[i * 6 + j];
+            out[i * 6 + 3 + j] += t12[i][j];
+            out[(3 + i) * 6 + j] += t21[i][j];
+            double s = C[(3 + i) * 6 + 3 + j];
+            for (int l = 0; l < 3; l++) s += H[l][i] * t12[l][j] + C[(3 + i) * 6 + l] * H[l][j];   // H^T (C11 H + C12) + C21 H
+            out[(3 + i) * 6 + 3 + j] += s;
+        }
+}
+// Wout += T^T W, and the geometric stiffness of the varying T added to Cout (raft_fowt.py:1181-1192): dT of a unit
+// rotation applied LINEARLY from the undisplaced arm (:640-666) moves the arm to arm0 + (theta + e_j) x arm, and
+// C[3+i,3+j] -= (dArm_j x F)_i for the node force F = W[0:3]
+__device__ inline void geom_reduce_vector(const double *W, const double (&a)[3], const double *arm0, const double (&th)[3],
+                                          double *Wout, double *Cout) {
+    GEOM_NOFMA
+    Wout[0] += W[0]; Wout[1] += W[1]; Wout[2] += W[2];
+    Wout[3] += W[3] + (a[1] * W[2] - a[2] * W[1]);
+    Wout[4] += W[4] + (a[2] * W[0] - a[0] * W[2]);
+    Wout[5] += W[5] + (a[0] * W[1] - a[1] * W[0]);
+    for (int j = 0; j < 3; j++) {
+        double tj[3] = {th[0], th[1], th[2]};
+        tj[j] += 1.0;
+        const double dA[3] = {arm0[0] + (tj[1] * a[2] - tj[2] * a[1]) - a[0], arm0[1] + (tj[2] * a[0] - tj[0] * a[2]) - a[1],
+                              arm0[2] + (tj[0] * a[1] - tj[1] * a[0]) - a[2]};
+        Cout[3 * 6 + 3 + j] -= dA[1] * W[2] - dA[2] * W[1];
+        Cout[4 * 6 + 3 + j] -= dA[2] * W[0] - dA[0] * W[2];
+        Cout[5 * 6 + 3 + j] -= dA[0] * W[1] - dA[1] * W[0];
+    }
+}
+
+// one thread per design: device strip records + run flags, Morison added mass, hydrostatic and inertia reduction
 __global__ __launch_bounds__(64) void k_geom_design(GeomArgs A) {
     GEOM_NOFMA
     const int d = blockIdx.x * blockDim.x + threadIdx.x;
@@ -571,48 +874,22 @@ __global__ __launch_bounds__(64) void k_geom_design(GeomArgs A) {
     double th[3] = {0, 0, 0}, rP[3] = {0, 0, 0};
     if (A.pose)
         for (int i = 0; i < 3; i++) { rP[i] = A.pose[(size_t)d * 6 + i]; th[i] = A.pose[(size_t)d * 6 + 3 + i]; }
+    double Ms[36], Cs[36], Ws[6] = {0, 0, 0, 0, 0, 0}, sMr[3] = {0, 0, 0};
+    for (int i = 0; i < 36; i++) { Ms[i] = 0.0; Cs[i] = 0.0; }
     for (int64_t m = A.memberOff[d]; m < A.memberOff[d + 1]; m++) {
-        const double *mp = A.mpose + (size_t)m * MP_N, *mh = A.mhyd + (size_t)m * MH_N;
+        const double *mp = A.mpose + (size_t)m * MP_N, *mh = A.mhyd + (size_t)m * MH_N, *mi = A.minert + (size_t)m * MI_N;
         const double a[3] = {mp[3] - rP[0], mp[4] - rP[1], mp[5] - rP[2]};
-        const double H[3][3] = {{0, a[2], -a[1]}, {-a[2], 0, a[0]}, {a[1], -a[0], 0}};          // helpers.py:428-437
-        // blocks of the member matrix C = [[C11, C12],[C21, C22]]
-        double t12[3][3], t21[3][3];
-        for (int i = 0; i < 3; i++)
-            for (int j = 0; j < 3; j++) {
-                double s12 = mh[i * 6 + 3 + j], s21 = mh[(3 + i) * 6 + j];
-                for (int l = 0; l < 3; l++) {
-                    s12 += mh[i * 6 + l] * H[l][j];                 // C11 H + C12
-                    s21 += H[l][i] * mh[l * 6 + j];                 // H^T C11 + C21
-                }
-                t12[i][j] = s12;
-                t21[i][j] = s21;
-            }
-        for (int i = 0; i < 3; i++)
-            for (int j = 0; j < 3; j++) {
-                Ch[i * 6 + j] += mh[i * 6 + j];
-                Ch[i * 6 + 3 + j] += t12[i][j];
-                Ch[(3 + i) * 6 + j] += t21[i][j];
-                double s = mh[(3 + i) * 6 + 3 + j];
-                for (int l = 0; l < 3; l++) s += H[l][i] * t12[l][j] + mh[(3 + i) * 6 + l] * H[l][j];   // H^T (C11 H + C12) + C21 H
-                Ch[(3 + i) * 6 + 3 + j] += s;
-            }
-        const double *F = mh + 36;
-        Wh[0] += F[0]; Wh[1] += F[1]; Wh[2] += F[2];
-        Wh[3] += F[3] + (a[1] * F[2] - a[2] * F[1]);
-        Wh[4] += F[4] + (a[2] * F[0] - a[0] * F[2]);
-        Wh[5] += F[5] + (a[0] * F[1] - a[1] * F[0]);
-        // dT of a unit rotation applied LINEARLY from the undisplaced arm (raft_fowt.py:640-666): column j moves the
-        // arm to arm0 + (theta + e_j) x arm
-        for (int j = 0; j < 3; j++) {
-            double tj[3] = {th[0], th[1], th[2]};
-            tj[j] += 1.0;
-            const double dA[3] = {mp[0] + (tj[1] * a[2] - tj[2] * a[1]) - a[0], mp[1] + (tj[2] * a[0] - tj[0] * a[2]) - a[1],
-                                  mp[2] + (tj[0] * a[1] - tj[1] * a[0]) - a[2]};
-            // -(H(dA)^T F)_i = -(dA x F)_i
-            Ch[3 * 6 + 3 + j] -= dA[1] * F[2] - dA[2] * F[1];
-            Ch[4 * 6 + 3 + j] -= dA[2] * F[0] - dA[0] * F[2];
-            Ch[5 * 6 + 3 + j] -= dA[0] * F[1] - dA[1] * F[0];
+        geom_reduce_matrix(mh, a, Ch);
+        geom_reduce_vector(mh + 36, a, mp, th, Wh, Ch);
+        geom_reduce_matrix(mi, a, Ms);
+        {   // weight stiffness of the member about its node: C[3,3] = C[4,4] = -m g dR_z (helpers.py:1076-1078)
+            double Cm[36];
+            for (int i = 0; i < 36; i++) Cm[i] = 0.0;
+            Cm[3 * 6 + 3] = Cm[4 * 6 + 4] = mi[46];
+            geom_reduce_matrix(Cm, a, Cs);
         }
+        geom_reduce_vector(mi + 40, a, mp, th, Ws, Cs);
+        for (int c = 0; c < 3; c++) sMr[c] += ((mi[37 + c] - mp[3 + c]) + mp[c]) * mi[36];        // raft_fowt.py:902-903
         const double V = mh[42];
         Vt += V;
         AWPt += mh[46];
@@ -621,19 +898,27 @@ __global__ __launch_bounds__(64) void k_geom_design(GeomArgs A) {
     }
     for (int i = 0; i < 6; i++)
         for (int j = i + 1; j < 6; j++) {
-            const double s = (Ch[i * 6 + j] + Ch[j * 6 + i]) / 2;
+            const double s = (Ch[i * 6 + j] + Ch[j * 6 + i]) / 2, sm = (Ms[i * 6 + j] + Ms[j * 6 + i]) / 2,
+                         sc = (Cs[i * 6 + j] + Cs[j * 6 + i]) / 2;
             Ch[i * 6 + j] = Ch[j * 6 + i] = s;
+            Ms[i * 6 + j] = Ms[j * 6 + i] = sm;
+            Cs[i * 6 + j] = Cs[j * 6 + i] = sc;
         }
     for (int i = 0; i < 36; i++) {
         A.A[(size_t)d * 36 + i] = Am[i];
         A.Ch[(size_t)d * 36 + i] = Ch[i];
+        A.Ms[(size_t)d * 36 + i] = Ms[i];
+        A.Cs[(size_t)d * 36 + i] = Cs[i];
         if (A.add_mask & RAFTX_ADD_MORISON) A.M0[(size_t)d * 36 + i] += Am[i];
         if (A.add_mask & RAFTX_ADD_HYDROSTATIC) A.C0[(size_t)d * 36 + i] += Ch[i];
+        if (A.add_mask & RAFTX_ADD_INERTIA) { A.M0[(size_t)d * 36 + i] += Ms[i]; A.C0[(size_t)d * 36 + i] += Cs[i]; }
     }
-    for (int i = 0; i < 6; i++) A.Wh[(size_t)d * 6 + i] = Wh[i];
+    for (int i = 0; i < 6; i++) { A.Wh[(size_t)d * 6 + i] = Wh[i]; A.Ws[(size_t)d * 6 + i] = Ws[i]; }
     double *pr = A.props + (size_t)d * RAFTX_SP_N;
     for (int i = 0; i < RAFTX_SP_N; i++) pr[i] = 0.0;
     pr[RAFTX_SP_V] = Vt;
+    pr[RAFTX_SP_MASS] = Ms[0];                                                            // raft_fowt.py:1206-1207
+    for (int c = 0; c < 3; c++) pr[RAFTX_SP_RCG + c] = Ms[0] != 0.0 ? sMr[c] / Ms[0] : 0.0;
     pr[RAFTX_SP_AWP] = AWPt;
     for (int c = 0; c < 3; c++) pr[RAFTX_SP_RCB + c] = Vt != 0.0 ? sVr[c] / Vt : 0.0;
 }

@@ -235,7 +235,7 @@ struct raftx_ctx {
     // results of the last raftx_build_designs (device pointers owned by design_allocs)
     int g_n;
     size_t g_nStrips, g_nRows;
-    double *g_abi, *g_A, *g_Ch, *g_Wh, *g_props;
+    double *g_abi, *g_A, *g_Ch, *g_Wh, *g_props, *g_Ms, *g_Cs, *g_Ws;
     cplx *g_cm;
 };
 
@@ -398,13 +398,14 @@ static int dev_alloc(raftx_ctx *c, std::vector<void *> &bag, size_t n, Tp **out,
 }
 
 extern "C" int raftx_build_designs(raftx_ctx *c, int nDesign, const int64_t *memberOff, const double *members,
-                                   const int64_t *stationOff, const double *stations, const double *pose, double rho,
-                                   double g, int nw, const double *k, int add_mask, const double *M0, const double *B0,
-                                   const double *C0, const double *MBw, int64_t *stripOffsets) {
+                                   const int64_t *stationOff, const double *stations, const int64_t *capOff,
+                                   const double *caps, const double *pose, double rho, double g, int nw, const double *k,
+                                   int add_mask, const double *M0, const double *B0, const double *C0, const double *MBw,
+                                   int64_t *stripOffsets) {
     if (!c) return -1;
     if (nDesign < 0 || !memberOff || !members || !stationOff || !stations || !M0 || !B0 || !C0 || !stripOffsets)
         FAIL(c, "build_designs: bad arguments");
-    if (add_mask & RAFTX_ADD_INERTIA) FAIL(c, "build_designs: RAFTX_ADD_INERTIA is not available in this build");
+    if ((capOff == nullptr) != (caps == nullptr)) FAIL(c, "build_designs: capOff and caps must be given together");
     if (nw < 1 || nw > MAX_NW) FAIL(c, "build_designs: nw=%d outside 1..%d", nw, MAX_NW);
     const int64_t nMember = memberOff[nDesign];
     bool any_mcf = false;
@@ -441,11 +442,16 @@ extern "C" int raftx_build_designs(raftx_ctx *c, int nDesign, const int64_t *mem
     rc |= upload(c, tmp, stations, (size_t)stationOff[nMember] * RAFTX_GS_N, &A.gs);
     rc |= upload(c, tmp, pose, pose ? (size_t)nDesign * 6 : 0, &A.pose);
     rc |= upload(c, tmp, mdesign.data(), (size_t)nMember, &A.mdesign);
+    if (capOff) {
+        rc |= upload(c, tmp, capOff, (size_t)nMember + 1, &A.capOff);
+        rc |= upload(c, tmp, caps, (size_t)(capOff[nMember] > 0 ? capOff[nMember] : 1) * RAFTX_GC_N, &A.caps);
+    }
     rc |= upload(c, c->design_allocs, k, k ? (size_t)nw : 0, &A.k);
     if (rc) return -2;
     if (dev_alloc(c, tmp, (size_t)nMember, &A.cnt) || dev_alloc(c, tmp, (size_t)nMember, &A.cntm) ||
         dev_alloc(c, tmp, (size_t)nMember + 1, &A.soff) || dev_alloc(c, tmp, (size_t)nMember + 1, &A.cmsoff) ||
         dev_alloc(c, tmp, (size_t)nMember * MP_N, &A.mpose) || dev_alloc(c, tmp, (size_t)nMember * MH_N, &A.mhyd) ||
+        dev_alloc(c, tmp, (size_t)nMember * MI_N, &A.minert) || dev_alloc(c, tmp, 1, &A.err, true) ||
         dev_alloc(c, c->design_allocs, (size_t)nDesign + 1, &A.off) ||
         dev_alloc(c, c->design_allocs, (size_t)nDesign + 1, &A.cmoff))
         return -2;
@@ -461,8 +467,12 @@ extern "C" int raftx_build_designs(raftx_ctx *c, int nDesign, const int64_t *mem
     std::vector<int64_t> cmoffh((size_t)nDesign + 1);
     HIPCHK(c, hipMemcpyAsync(stripOffsets, A.off, ((size_t)nDesign + 1) * sizeof(int64_t), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipMemcpyAsync(cmoffh.data(), A.cmoff, ((size_t)nDesign + 1) * sizeof(int64_t), hipMemcpyDeviceToHost, c->stream));
+    int bad_member = 0;
+    HIPCHK(c, hipMemcpyAsync(&bad_member, A.err, sizeof(int), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     HIPCHK(c, hipGetLastError());
+    if (bad_member)
+        FAIL(c, "member %d: cap/bulkhead layout not supported (the reference raises here too)", bad_member - 1);
     const size_t nStrips = (size_t)stripOffsets[nDesign], nRows = (size_t)cmoffh[(size_t)nDesign];
     int maxS = 0;
     for (int d = 0; d < nDesign; d++) {
@@ -474,7 +484,8 @@ extern "C" int raftx_build_designs(raftx_ctx *c, int nDesign, const int64_t *mem
         dev_alloc(c, c->design_allocs, nStrips, &A.dsi) || dev_alloc(c, c->design_allocs, nRows * 3, &A.mcfaux) ||
         dev_alloc(c, c->design_allocs, nRows * 2 * (size_t)nw, &A.cm) ||
         dev_alloc(c, c->design_allocs, (size_t)nDesign * 36, &A.A) || dev_alloc(c, c->design_allocs, (size_t)nDesign * 36, &A.Ch) ||
-        dev_alloc(c, c->design_allocs, (size_t)nDesign * 6, &A.Wh) ||
+        dev_alloc(c, c->design_allocs, (size_t)nDesign * 6, &A.Wh) || dev_alloc(c, c->design_allocs, (size_t)nDesign * 36, &A.Ms) ||
+        dev_alloc(c, c->design_allocs, (size_t)nDesign * 36, &A.Cs) || dev_alloc(c, c->design_allocs, (size_t)nDesign * 6, &A.Ws) ||
         dev_alloc(c, c->design_allocs, (size_t)nDesign * RAFTX_SP_N, &A.props) ||
         dev_alloc(c, c->design_allocs, (size_t)nDesign * 36, &M0d) || dev_alloc(c, c->design_allocs, (size_t)nDesign * 36, &C0d))
         return -2;
@@ -513,6 +524,7 @@ extern "C" int raftx_build_designs(raftx_ctx *c, int nDesign, const int64_t *mem
     c->g_abi = A.abi;
     c->g_cm = A.cm;
     c->g_A = A.A; c->g_Ch = A.Ch; c->g_Wh = A.Wh; c->g_props = A.props;
+    c->g_Ms = A.Ms; c->g_Cs = A.Cs; c->g_Ws = A.Ws;
     return 0;
 }
 
@@ -529,7 +541,7 @@ extern "C" int raftx_fetch_strips(raftx_ctx *c, double *strips, raftx_c128 *cm) 
 }
 
 extern "C" int raftx_fetch_statics(raftx_ctx *c, double *A_morison, double *C_hydro, double *W_hydro, double *M_struc,
-                                   double *props) {
+                                   double *C_struc, double *W_struc, double *props) {
     if (!c) return -1;
     if (!c->g_n || !c->have_designs) FAIL(c, "fetch_statics: no raftx_build_designs call on this ctx");
     HIPCHK(c, hipSetDevice(c->device));
@@ -538,8 +550,10 @@ extern "C" int raftx_fetch_statics(raftx_ctx *c, double *A_morison, double *C_hy
     if (C_hydro) HIPCHK(c, hipMemcpyAsync(C_hydro, c->g_Ch, n * 36 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
     if (W_hydro) HIPCHK(c, hipMemcpyAsync(W_hydro, c->g_Wh, n * 6 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
     if (props) HIPCHK(c, hipMemcpyAsync(props, c->g_props, n * RAFTX_SP_N * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    if (M_struc) HIPCHK(c, hipMemcpyAsync(M_struc, c->g_Ms, n * 36 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    if (C_struc) HIPCHK(c, hipMemcpyAsync(C_struc, c->g_Cs, n * 36 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    if (W_struc) HIPCHK(c, hipMemcpyAsync(W_struc, c->g_Ws, n * 6 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
-    if (M_struc) memset(M_struc, 0, n * 36 * sizeof(double));
     return 0;
 }
 

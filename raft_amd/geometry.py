@@ -21,12 +21,12 @@ RAFTX_GS_* (16 doubles).
 """
 import numpy as np
 
-GM_N, GS_N = 16, 16
+GM_N, GS_N, GC_N = 16, 16, 4
 GM_RA, GM_RB, GM_GAMMA, GM_SHAPE, GM_DLSMAX, GM_FLAGS, GM_L, GM_RHOSHELL = 0, 3, 6, 7, 8, 9, 10, 11
 GS_S, GS_D, GS_T, GS_CD, GS_CA, GS_LFILL, GS_RHOFILL = 0, 1, 3, 4, 8, 12, 13
-FLAG_POTMOD, FLAG_MCF = 1, 2
+FLAG_POTMOD, FLAG_MCF, FLAG_NOSTATIC = 1, 2, 4
 ADD_MORISON, ADD_HYDROSTATIC, ADD_INERTIA = 1, 2, 4
-SP_N, SP_V, SP_AWP, SP_RCB, SP_MASS, SP_ZCG = 8, 0, 1, 2, 5, 6
+SP_N, SP_V, SP_AWP, SP_RCB, SP_MASS, SP_RCG = 12, 0, 1, 2, 5, 6
 
 
 class UnsupportedMember(Exception):
@@ -83,8 +83,8 @@ def _heading(r, heading):
     return np.matmul(np.array([[c, -s, 0], [s, c, 0], [0, 0, 1]]), r)
 
 
-def describe_member(mi, heading=0.0):
-    """(gm [16], gs [n,16]) of one member copy -- raft_member.py:36-190."""
+def describe_member(mi, heading=0.0, part_of="platform"):
+    """(gm [16], gs [n,16], caps [ncap,4]) of one member copy -- raft_member.py:36-190."""
     mtype = str(mi.get("type", "rigid"))
     if mtype != "rigid":
         raise UnsupportedMember("member '%s' is type '%s'; only rigid members are generated on the device"
@@ -153,20 +153,37 @@ def describe_member(mi, heading=0.0):
     gm[GM_GAMMA] = gamma
     gm[GM_SHAPE] = 1.0 if circ else 0.0
     gm[GM_DLSMAX] = _get(mi, "dlsMax", shape=0, default=5)
-    gm[GM_FLAGS] = (FLAG_POTMOD if potmod else 0) | (FLAG_MCF if mcf else 0)
+    gm[GM_FLAGS] = (FLAG_POTMOD if potmod else 0) | (FLAG_MCF if mcf else 0) | \
+                   (FLAG_NOSTATIC if part_of == "nacelle" else 0)
     gm[GM_L] = length
     gm[GM_RHOSHELL] = _get(mi, "rho_shell", shape=0, default=8500.)
-    return gm, gs
+    # end caps / bulkheads (raft_member.py:162-175)
+    cap_st = _get(mi, "cap_stations", shape=-1, default=[])
+    cap_st = np.atleast_1d(np.array(cap_st, dtype=float))
+    caps = np.zeros((len(cap_st), GC_N))
+    if len(cap_st):
+        caps[:, 0] = (cap_st - st[0]) / (st[-1] - st[0]) * length
+        caps[:, 1] = _get(mi, "cap_t", shape=len(cap_st))
+        if circ:
+            caps[:, 2] = _get(mi, "cap_d_in", shape=len(cap_st))
+        else:
+            caps[:, 2:4] = _get(mi, "cap_d_in", shape=[len(cap_st), 2])
+    return gm, gs, caps
 
 
 class MemberTable:
-    """Members of one unit: ``members`` [nM,16], ``station_off`` [nM+1], ``stations`` [nSt,16]."""
+    """Members of one unit: ``members`` [nM,16], ``station_off`` [nM+1], ``stations`` [nSt,16], ``cap_off`` [nM+1],
+    ``caps`` [nCap,4]."""
 
-    def __init__(self, gms, gss):
+    def __init__(self, gms, gss, gcs=None):
         self.members = np.ascontiguousarray(np.array(gms, dtype=np.float64).reshape(-1, GM_N))
         counts = [len(g) for g in gss]
         self.station_off = np.concatenate([[0], np.cumsum(counts)]).astype(np.int64)
         self.stations = np.ascontiguousarray(np.concatenate(gss, axis=0) if gss else np.zeros((0, GS_N)))
+        if gcs is None:
+            gcs = [np.zeros((0, GC_N))] * len(gss)
+        self.cap_off = np.concatenate([[0], np.cumsum([len(g) for g in gcs])]).astype(np.int64)
+        self.caps = np.ascontiguousarray(np.concatenate(gcs, axis=0) if gcs else np.zeros((0, GC_N))).reshape(-1, GC_N)
 
     @property
     def n(self):
@@ -181,7 +198,7 @@ def describe_unit(design, heading_adjust=0.0, include_turbine=True):
     plat = design["platform"]
     pmm = int(_get(plat, "potModMaster", dtype=int, default=0))
     dls_default = _get(plat, "dlsMax", default=5.0)
-    gms, gss = [], []
+    gms, gss, gcs = [], [], []
     for mi in plat["members"]:
         mi = dict(mi)
         if pmm in [1]:
@@ -194,9 +211,10 @@ def describe_unit(design, heading_adjust=0.0, include_turbine=True):
         if np.isscalar(headings):
             headings = [headings]
         for h in headings:
-            gm, gs = describe_member(mi, heading=h + heading_adjust)
+            gm, gs, gc = describe_member(mi, heading=h + heading_adjust)
             gms.append(gm)
             gss.append(gs)
+            gcs.append(gc)
     if include_turbine and "turbine" in design and design["turbine"] is not None:
         turb = design["turbine"]
         nrotors = int(_get(turb, "nrotors", dtype=int, shape=0, default=1))
@@ -206,20 +224,43 @@ def describe_unit(design, heading_adjust=0.0, include_turbine=True):
                 if isinstance(items, dict):
                     items = [items] * nrotors
                 for mi in items:
-                    gm, gs = describe_member(dict(mi))
+                    gm, gs, gc = describe_member(dict(mi), part_of=key)
                     gms.append(gm)
                     gss.append(gs)
-    return MemberTable(gms, gss)
+                    gcs.append(gc)
+    return MemberTable(gms, gss, gcs)
+
+
+class DesignTables:
+    """Descriptors of a batch of designs, as raftx_build_designs takes them."""
+
+    def __init__(self, member_off, members, station_off, stations, cap_off, caps):
+        self.member_off, self.members = member_off, members
+        self.station_off, self.stations = station_off, stations
+        self.cap_off, self.caps = cap_off, caps
+
+    @property
+    def n_design(self):
+        return len(self.member_off) - 1
+
+    def __iter__(self):          # (memberOff, members, stationOff, stations): the four mandatory tables
+        return iter((self.member_off, self.members, self.station_off, self.stations))
+
+
+def _chain(offs):
+    out = [np.zeros(1, dtype=np.int64)]
+    base = 0
+    for o in offs:
+        out.append(o[1:] + base)
+        base += o[-1]
+    return np.concatenate(out).astype(np.int64)
 
 
 def concat_units(tables):
-    """(memberOff [nD+1], members, stationOff [nM+1], stations) of a list of MemberTables (one per design)."""
+    """DesignTables of a list of MemberTables (one per design)."""
     member_off = np.concatenate([[0], np.cumsum([t.n for t in tables])]).astype(np.int64)
     members = np.ascontiguousarray(np.concatenate([t.members for t in tables], axis=0))
     stations = np.ascontiguousarray(np.concatenate([t.stations for t in tables], axis=0))
-    so = [np.zeros(1, dtype=np.int64)]
-    base = 0
-    for t in tables:
-        so.append(t.station_off[1:] + base)
-        base += t.station_off[-1]
-    return member_off, members, np.concatenate(so).astype(np.int64), stations
+    caps = np.ascontiguousarray(np.concatenate([t.caps for t in tables], axis=0))
+    return DesignTables(member_off, members, _chain([t.station_off for t in tables]), stations,
+                        _chain([t.cap_off for t in tables]), caps)

@@ -31,14 +31,16 @@ def main():
     t_parse = (time.perf_counter() - t0) / len(units)
     nD = args.designs
     tiled = [tabs[i % len(tabs)] for i in range(nD)]
-    mo, mem, so, st = G.concat_units(tiled)
+    D = G.concat_units(tiled)
+    mo, mem, so, st = D
     nw = len(units[0]["w"])
     Z = np.zeros((nD, 6, 6))
     ctx = backend.hip_library().context(0)
     walls, devs = [], []
     for _ in range(args.reps):
         t0 = time.perf_counter()
-        off = ctx.build_designs(mo, mem, so, st, Z, Z, Z, nw, rho=1025.0, g=9.81, add_mask=G.ADD_MORISON | G.ADD_HYDROSTATIC)
+        off = ctx.build_designs(mo, mem, so, st, Z, Z, Z, nw, rho=1025.0, g=9.81, cap_off=D.cap_off, caps=D.caps,
+                                add_mask=G.ADD_MORISON | G.ADD_HYDROSTATIC | G.ADD_INERTIA)
         walls.append(time.perf_counter() - t0)
         devs.append(ctx.last_kernel_ms())
     strips, _ = ctx.fetch_strips(off[-1])
@@ -49,7 +51,7 @@ def main():
         up.append(time.perf_counter() - t0)
     ctx.close()
     out = {"designs": nD, "members": int(mo[-1]), "stations": int(so[-1]), "strips": int(off[-1]),
-           "descriptor_bytes": int(mem.nbytes + st.nbytes + mo.nbytes + so.nbytes), "strip_table_bytes": int(strips.nbytes),
+           "descriptor_bytes": int(mem.nbytes + st.nbytes + mo.nbytes + so.nbytes + D.caps.nbytes + D.cap_off.nbytes), "strip_table_bytes": int(strips.nbytes),
            "device_ms": float(np.median(devs)), "build_designs_wall_ms": 1e3 * float(np.median(walls)),
            "upload_designs_wall_ms": 1e3 * float(np.median(up)), "host_parse_ms_per_design": 1e3 * t_parse,
            "designs_per_s_device": nD / (1e-3 * float(np.median(devs)))}
