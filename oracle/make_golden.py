@@ -410,7 +410,8 @@ def fixture_geom():
         u.update(_bare_statics(mb.fowtList[i]))
         u["name"] = "farm-unit-%d" % i
         units.append(u)
-    fx = {"config": "geometry generator goldens (live reference)", "units": units}
+    fx = {"config": "geometry generator goldens (live reference)", "units": units,
+          "c3_base_json": _design_subset(base), "c3_scales": scales}
     standin.save_fixture(os.path.join(GOLD, "geom_units.npz"), fx)
 
 

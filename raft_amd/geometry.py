@@ -264,3 +264,69 @@ def concat_units(tables):
     caps = np.ascontiguousarray(np.concatenate([t.caps for t in tables], axis=0))
     return DesignTables(member_off, members, _chain([t.station_off for t in tables]), stations,
                         _chain([t.cap_off for t in tables]), caps)
+
+
+class SweepTables:
+    """Descriptors of nDesign variants of ONE base unit (same members, stations and caps; different numbers), for
+    parametric sweeps without a Python loop over designs: edit the arrays in place with NumPy broadcasting, then
+    hand ``tables()`` to raftx_build_designs.
+
+    ``members`` [nD,nM,16], ``stations`` [nD,nSt,16], ``caps`` [nD,nCap,4] start as copies of the base unit.
+    ``set_ends`` moves a member's end points the way Member.__init__ does (heading rotation, length, station / cap /
+    ballast positions rescaled with the length, raft_member.py:72-77,99,143,173)."""
+
+    def __init__(self, base, n_design):
+        self.base = base
+        self.n = int(n_design)
+        self.members = np.repeat(base.members[None], self.n, axis=0)
+        self.stations = np.repeat(base.stations[None], self.n, axis=0)
+        self.caps = np.repeat(base.caps[None], self.n, axis=0)
+        length = base.members[:, GM_L]
+        # positions as fractions of the member length (what the YAML's arbitrary station units mean)
+        self._st_frac = base.stations[:, GS_S] / np.repeat(length, np.diff(base.station_off))
+        self._fill_frac = base.stations[:, GS_LFILL] / np.repeat(length, np.diff(base.station_off))
+        self._cap_frac = base.caps[:, 0] / np.repeat(length, np.diff(base.cap_off)) if len(base.caps) else np.zeros(0)
+
+    def station_rows(self, m):
+        return slice(int(self.base.station_off[m]), int(self.base.station_off[m + 1]))
+
+    def cap_rows(self, m):
+        return slice(int(self.base.cap_off[m]), int(self.base.cap_off[m + 1]))
+
+    def set_ends(self, m, rA, rB, heading=0.0):
+        """End points of member ``m`` for every design: rA, rB [nD,3] BEFORE the heading rotation [deg]."""
+        rA = np.asarray(rA, dtype=float).reshape(self.n, 3)
+        rB = np.asarray(rB, dtype=float).reshape(self.n, 3)
+        length = np.sqrt(np.sum((rB - rA) ** 2, axis=1))
+        if heading != 0.0:
+            c, s = np.cos(np.deg2rad(heading)), np.sin(np.deg2rad(heading))
+            rot = lambda r: np.stack([c * r[:, 0] + (-s) * r[:, 1], s * r[:, 0] + c * r[:, 1], r[:, 2]], axis=1)
+            rA, rB = rot(rA), rot(rB)
+        self.members[:, m, GM_RA:GM_RA + 3] = rA
+        self.members[:, m, GM_RB:GM_RB + 3] = rB
+        self.members[:, m, GM_L] = length
+        rows = self.station_rows(m)
+        self.stations[:, rows, GS_S] = self._st_frac[rows][None] * length[:, None]
+        self.stations[:, rows, GS_LFILL] = self._fill_frac[rows][None] * length[:, None]
+        crow = self.cap_rows(m)
+        if crow.stop > crow.start:
+            self.caps[:, crow, 0] = self._cap_frac[crow][None] * length[:, None]
+
+    def set_diameter(self, m, d, d2=None):
+        """Diameter (or side pair d, d2) of member ``m`` at all its stations: d [nD] or [nD,nStations]."""
+        rows = self.station_rows(m)
+        d = np.asarray(d, dtype=float)
+        self.stations[:, rows, GS_D] = d[:, None] if d.ndim == 1 else d
+        d2 = d if d2 is None else np.asarray(d2, dtype=float)
+        self.stations[:, rows, GS_D + 1] = d2[:, None] if d2.ndim == 1 else d2
+
+    def tables(self):
+        nM, nSt, nCap = self.base.n, len(self.base.stations), len(self.base.caps)
+        member_off = np.arange(self.n + 1, dtype=np.int64) * nM
+        so = (self.base.station_off[None, :-1] + (np.arange(self.n, dtype=np.int64) * nSt)[:, None]).reshape(-1)
+        co = (self.base.cap_off[None, :-1] + (np.arange(self.n, dtype=np.int64) * nCap)[:, None]).reshape(-1)
+        return DesignTables(member_off, np.ascontiguousarray(self.members.reshape(-1, GM_N)),
+                            np.concatenate([so, [self.n * nSt]]).astype(np.int64),
+                            np.ascontiguousarray(self.stations.reshape(-1, GS_N)),
+                            np.concatenate([co, [self.n * nCap]]).astype(np.int64),
+                            np.ascontiguousarray(self.caps.reshape(-1, GC_N)))

@@ -192,3 +192,70 @@ def test_hip_generated_designs_solve_like_uploaded_ones(name, hip_lib):
         ctx.close()
     assert np.array_equal(out[0]["niter"], out[1]["niter"])
     assert group_rel_err(out[0]["Xi"].reshape(-1, 6, nw), out[1]["Xi"].reshape(-1, 6, nw)) < 1e-9
+
+
+# ------------------------------------------------------------------ the C3 sweep, generated instead of packed
+C3 = standin.load_fixture("c3_variants.npz")
+
+
+def c3_generated(ctx, n=64):
+    """The first n designs of the C3 sweep (the ones the live reference built for c3_variants.npz), generated."""
+    from tests.util import volturnus_sweep
+    base = json.loads(FX["c3_base_json"])
+    scales = np.asarray(C3["scales"])[:n]
+    u0 = UNITS["C3-variant-0"]
+    M_rna = np.asarray(u0["M_struc"]) - np.asarray(u0["M_struc_bare"])
+    C_rest = np.asarray(u0["C_struc"]) - np.asarray(u0["C_struc_bare"]) + np.diag([7e4, 7e4, 0, 0, 0, 1e8])
+    D = volturnus_sweep(base, scales).tables()
+    M0 = np.repeat(M_rna[None], n, axis=0)
+    C0 = np.repeat(C_rest[None], n, axis=0)
+    off = ctx.build_designs(D.member_off, D.members, D.station_off, D.stations, M0, np.asarray(C3["B0"])[:n], C0,
+                            len(C3["w"]), cap_off=D.cap_off, caps=D.caps,
+                            add_mask=G.ADD_MORISON | G.ADD_HYDROSTATIC | G.ADD_INERTIA)
+    return off, M0, C0
+
+
+def test_vectorised_sweep_descriptors_equal_parsed_ones():
+    from tests.util import volturnus_sweep
+    sw = volturnus_sweep(json.loads(FX["c3_base_json"]), np.asarray(FX["c3_scales"]))
+    for i in range(3):
+        t = tables_of(UNITS["C3-variant-%d" % i])
+        assert np.array_equal(sw.members[i], t.members)
+        assert np.array_equal(sw.stations[i], t.stations)
+        assert np.array_equal(sw.caps[i], t.caps)
+    D = sw.tables()
+    assert D.n_design == 3 and D.station_off[-1] == len(D.stations) and D.cap_off[-1] == len(D.caps)
+
+
+def check_c3(ctx, tol):
+    n = 64
+    off, M_extra, C_extra = c3_generated(ctx, n)
+    assert np.array_equal(off, np.asarray(C3["strip_offsets"]))
+    strips, _ = ctx.fetch_strips(off[-1])
+    assert rel_err(strips[:, :26], np.asarray(C3["strips"])[:, :26]) < tol
+    S = ctx.fetch_statics()
+    assert rel_err(S["M_struc"] + S["A_morison"] + M_extra, C3["M0"]) < tol
+    assert rel_err(S["C_struc"] + S["C_hydro"] + C_extra, C3["C0"]) < tol
+
+
+def test_oracle_generates_the_reference_built_c3_variants(oracle_ctx):
+    check_c3(oracle_ctx, TOL)
+
+
+@pytest.mark.gpu
+def test_hip_generates_the_reference_built_c3_variants(hip_ctx):
+    check_c3(hip_ctx, 1e-11)
+
+
+@pytest.mark.gpu
+def test_hip_c3_from_member_descriptions_to_reference_responses(hip_ctx):
+    """Whole device pipeline: member descriptions -> strips + statics -> solveDynamics, against the LIVE reference's
+    solveDynamics of the same variants (group-relative 1e-9, identical iteration counts)."""
+    c3_generated(hip_ctx, 64)
+    hip_ctx.upload_cases(C3["w"], C3["k"], float(C3["depth"]), 1025.0, 9.81, np.asarray(C3["zeta"])[None],
+                         np.asarray(C3["beta"])[None])
+    out = hip_ctx.solve_dynamics(int(C3["nIter"]), 0.01, float(C3["XiStart"]))
+    assert len(C3["solved"]) >= 4
+    for j, sol in enumerate(C3["solved"]):
+        assert int(out["niter"][j, 0]) == int(sol["units"][0]["niter"])
+        assert group_rel_err(out["Xi"][j, 0, :1], np.asarray(sol["Xi"])[:1]) < 1e-9
