@@ -393,6 +393,43 @@ def sweep_from_units(model, cases, tol=0.01):
                             nIter=int(model.nIter), XiStart=model.XiStart, tol=tol)
 
 
+def sweep_from_member_tables(model, base_table, tables, cases, ctx, tol=0.01, pose=None):
+    """A ``raft_amd.sweep.GeometrySweep``: design candidates given as MEMBER DESCRIPTIONS (raft_amd/geometry.py), strip
+    tables and statics generated on the device -- no Model()/calcStatics()/calcHydroConstants() per candidate.
+
+    ``model``: a live (reference) Model of the BASE design, positioned and with its statics computed; ``base_table``: the
+    MemberTable of that same base design (geometry.describe_unit(design)); ``tables``: DesignTables of the candidates.
+    Whatever the generator does not produce -- rotor-nacelle assembly, point inertias, mooring and elastic stiffness,
+    structural damping -- is taken from the base model as (reference total) - (generated for the base design), which
+    is exact as long as those parts do not change across the candidates (the parametersweep.py / omdao_raft.py case)."""
+    from .sweep import GeometrySweep
+    from . import geometry as G
+    f0 = model.fowtList[0]
+    if int(f0.nDOF) != 6:
+        raise UnsupportedFOWT("device path covers rigid 6-DOF FOWTs (nDOF=%d)" % f0.nDOF)
+    M0, B0, C0, MBw = unit_matrices(f0, model.nw)
+    if MBw is not None:
+        raise UnsupportedFOWT("frequency-dependent base matrices: pass them per design through GeometrySweep(MBw=...)")
+    D0 = G.concat_units([base_table])
+    Z = np.zeros((1, 6, 6))
+    r6 = None if pose is None else np.asarray(pose, dtype=float).reshape(1, 6)
+    ctx.build_designs(D0.member_off, D0.members, D0.station_off, D0.stations, Z, Z, Z, model.nw, pose=r6,
+                      rho=float(f0.rho_water), g=float(f0.g), k=np.asarray(f0.k), cap_off=D0.cap_off, caps=D0.caps)
+    S = ctx.fetch_statics()
+    M_extra = M0 - (S["M_struc"][0] + S["A_morison"][0])
+    C_extra = C0 - (S["C_struc"][0] + S["C_hydro"][0])
+    zeta, beta = [], []
+    for case in cases:
+        _, b, _, z = waves.sea_state(dict(case), f0.w, f0.dw)
+        zeta.append(z)
+        beta.append(b)
+    nD = tables.n_design
+    poses = None if pose is None else np.repeat(r6, nD, axis=0)
+    return GeometrySweep(tables, np.repeat(M_extra[None], nD, 0), np.repeat(B0[None], nD, 0), np.repeat(C_extra[None], nD, 0),
+                         f0.w, f0.k, f0.depth, np.array(zeta), np.array(beta), nIter=int(model.nIter),
+                         XiStart=model.XiStart, tol=tol, pose=poses, rho=float(f0.rho_water), g=float(f0.g))
+
+
 _default_engine = Engine()
 
 

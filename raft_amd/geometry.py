@@ -246,6 +246,14 @@ class DesignTables:
     def __iter__(self):          # (memberOff, members, stationOff, stations): the four mandatory tables
         return iter((self.member_off, self.members, self.station_off, self.stations))
 
+    def take(self, lo, hi):
+        """Descriptors of designs [lo, hi): pure slices with re-based offsets."""
+        m0, m1 = int(self.member_off[lo]), int(self.member_off[hi])
+        s0, s1 = int(self.station_off[m0]), int(self.station_off[m1])
+        c0, c1 = int(self.cap_off[m0]), int(self.cap_off[m1])
+        return DesignTables(self.member_off[lo:hi + 1] - m0, self.members[m0:m1], self.station_off[m0:m1 + 1] - s0,
+                            self.stations[s0:s1], self.cap_off[m0:m1 + 1] - c0, self.caps[c0:c1])
+
 
 def _chain(offs):
     out = [np.zeros(1, dtype=np.int64)]

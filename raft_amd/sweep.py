@@ -188,6 +188,52 @@ class Sweep:
         return {"Xi": r["Xi"], "niter": r["niter"], "flags": r["flags"]}
 
 
+class GeometrySweep(Sweep):
+    """A sweep whose designs are MEMBER DESCRIPTIONS (raft_amd/geometry.py DesignTables): ``upload`` generates the
+    strip tables, MacCamy-Fuchs tables, Morison added mass, hydrostatics and member inertia on the device
+    (raftx_build_designs) instead of uploading packed strips.  M_extra / C_extra [nD,6,6] carry what is not geometry
+    (rotor-nacelle assembly, point inertias, mooring stiffness); ``add_mask`` selects what the device adds to them.
+    Everything else -- sharding by design, solve, statistics, farm and second-order paths -- is inherited."""
+
+    def __init__(self, tables, M_extra, B0, C_extra, w, k, depth, zeta, beta, nIter, XiStart, tol=0.01, pose=None,
+                 add_mask=7, MBw=None, rho=1025.0, g=9.81):
+        self.tables = tables
+        nD = tables.n_design
+        self.off = np.zeros(nD + 1, dtype=np.int64)            # filled by upload() (the device counts the strips)
+        self.strips = np.zeros((0, NFIELD))
+        self.M0, self.B0, self.C0 = (np.ascontiguousarray(a, dtype=np.float64).reshape(nD, 6, 6) for a in (M_extra, B0, C_extra))
+        self.w = np.ascontiguousarray(w, dtype=np.float64)
+        self.k = np.ascontiguousarray(k, dtype=np.float64)
+        self.depth, self.rho, self.g = float(depth), float(rho), float(g)
+        zeta = np.asarray(zeta, dtype=np.float64)
+        beta = np.asarray(beta, dtype=np.float64)
+        if zeta.ndim == 2:
+            zeta, beta = zeta[None], beta[None]
+        self.zeta, self.beta = np.ascontiguousarray(zeta), np.ascontiguousarray(beta)
+        self.nIter, self.XiStart, self.tol = int(nIter), float(XiStart), float(tol)
+        self.MBw = None if MBw is None else np.ascontiguousarray(MBw, dtype=np.float64)
+        self.pose = None if pose is None else np.ascontiguousarray(pose, dtype=np.float64).reshape(nD, 6)
+        self.add_mask = int(add_mask)
+        self.cmoff = self.cm = None
+
+    @property
+    def n_design(self):
+        return self.tables.n_design
+
+    def take(self, lo, hi):
+        return GeometrySweep(self.tables.take(lo, hi), self.M0[lo:hi], self.B0[lo:hi], self.C0[lo:hi], self.w, self.k,
+                             self.depth, self.zeta, self.beta, self.nIter, self.XiStart, self.tol,
+                             None if self.pose is None else self.pose[lo:hi], self.add_mask,
+                             None if self.MBw is None else self.MBw[lo:hi], self.rho, self.g)
+
+    def upload(self, ctx):
+        t = self.tables
+        self.off = ctx.build_designs(t.member_off, t.members, t.station_off, t.stations, self.M0, self.B0, self.C0, self.nw,
+                                     pose=self.pose, rho=self.rho, g=self.g, k=self.k, add_mask=self.add_mask, MBw=self.MBw,
+                                     cap_off=t.cap_off, caps=t.caps)
+        ctx.upload_cases(self.w, self.k, self.depth, self.rho, self.g, self.zeta, self.beta)
+
+
 # ---------------------------------------------------------------------- multi-GPU driver
 def _device_for(dist):
     import torch

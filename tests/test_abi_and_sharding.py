@@ -126,6 +126,63 @@ def test_two_rank_gloo_sweep_matches_single_process(tmp_path, oracle_lib):
             assert int(got["niter"][j, 0]) == int(sol["units"][0]["niter"])
 
 
+def _geometry_sweep(n):
+    """The first n C3 variants as MEMBER DESCRIPTIONS (generated on the device / by the oracle at upload)."""
+    import json
+    from tests.util import volturnus_sweep
+    fx = standin.load_fixture("c3_variants.npz")
+    fg = standin.load_fixture("geom_units.npz")
+    u0 = [u for u in fg["units"] if u["name"] == "C3-variant-0"][0]
+    M_rna = np.asarray(u0["M_struc"]) - np.asarray(u0["M_struc_bare"])
+    C_rest = np.asarray(u0["C_struc"]) - np.asarray(u0["C_struc_bare"]) + np.diag([7e4, 7e4, 0, 0, 0, 1e8])
+    D = volturnus_sweep(json.loads(fg["c3_base_json"]), np.asarray(fx["scales"])[:n]).tables()
+    return sw.GeometrySweep(D, np.repeat(M_rna[None], n, 0), np.asarray(fx["B0"])[:n], np.repeat(C_rest[None], n, 0),
+                            fx["w"], fx["k"], float(fx["depth"]), fx["zeta"], fx["beta"], int(fx["nIter"]),
+                            float(fx["XiStart"])), fx
+
+
+def _geom_rank_main(rank, world, port, n, out_path):
+    import torch.distributed as dist
+    from raft_amd._abi import RaftxLib
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        s, _ = _geometry_sweep(n)
+        ctx = RaftxLib(ORACLE_SO).context(0)
+        res = sw.run_sharded(s, ctx, dist)
+        ctx.close()
+        if rank == 0:
+            np.savez(out_path, Xi=res["Xi"], niter=res["niter"])
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_rank_gloo_geometry_sweep(tmp_path, oracle_lib):
+    """Designs given as member descriptions shard by design like packed ones: every rank generates its own block
+    (no collective on the data path), rank 0 gathers; equal to the packed-table sweep and to the live reference."""
+    import torch.multiprocessing as mp
+    n, world = 5, 2
+    out = str(tmp_path / "geom_gathered.npz")
+    mp.spawn(_geom_rank_main, args=(world, _free_port(), n, out), nprocs=world, join=True)
+    got = np.load(out)
+    s, fx = _geometry_sweep(n)
+    assert s.take(1, 4).tables.n_design == 3 and s.take(1, 4).tables.station_off[0] == 0
+    ctx = oracle_lib.context(0)
+    one = s.run(ctx)
+    ctx.close()
+    assert np.array_equal(got["Xi"].view(np.uint64), one["Xi"].view(np.uint64))
+    packed, _ = _c3_sweep(n)
+    ctx = oracle_lib.context(0)
+    ref = packed.run(ctx)
+    ctx.close()
+    from tests.util import group_rel_err
+    assert np.array_equal(got["niter"], ref["niter"])
+    assert group_rel_err(got["Xi"].reshape(-1, 6, s.nw), ref["Xi"].reshape(-1, 6, s.nw)) < 1e-10
+    for j, sol in enumerate(fx["solved"]):
+        if j < n:
+            assert group_rel_err(got["Xi"][j, 0, :1], sol["Xi"][:1]) < 1e-10
+
+
 def _qtf_sets():
     from raft_amd import qtf as rq
     fx = standin.load_fixture("refgold_qtf_VolturnUS-S.npz")

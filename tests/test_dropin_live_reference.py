@@ -115,3 +115,27 @@ def test_installed_internal_qtf_on_live_objects(patch):
     assert group_rel_err(Xi_new[:1], Xi_old[:1]) < 1e-9
     assert rel_err(m_new.fowtList[0].qtf, m_old.fowtList[0].qtf) < 1e-9
     assert rel_err(m_new.fowtList[0].Fhydro_2nd, m_old.fowtList[0].Fhydro_2nd) < 1e-9
+
+
+def test_member_description_sweep_equals_reference_models(oracle_ctx):
+    """Design candidates handed over as member descriptions (no Model per candidate) against the live reference's
+    own Model(...) -> calcStatics -> calcHydroConstants -> solveDynamics of every candidate."""
+    import io
+    from raft_amd import dropin, geometry as G
+    from oracle.make_golden import volturnus_variant
+    base = rh.prepare_design(rh.load_design(os.path.join(rh.REFERENCE_ROOT, "examples/VolturnUS-S_example.yaml")),
+                             settings=dict(min_freq=0.01, max_freq=0.3))          # nw = 30 keeps the reference quick
+    case = rh.make_case(Hs=4.0, Tp=9.0, heading=20.0)
+    scales = np.array([[1.1, 0.9, 1.05, 0.95, 1.2], [0.8, 1.2, 0.9, 1.1, 0.85]])
+    designs = [volturnus_variant(base, s) for s in scales]
+    with contextlib.redirect_stdout(io.StringIO()):
+        m0 = rh.build_model(copy.deepcopy(base))
+        refs = []
+        for d in designs:
+            m = rh.build_model(copy.deepcopy(d))
+            refs.append(m.solveDynamics(copy.deepcopy(case)).copy())
+    tabs = G.concat_units([G.describe_unit(d) for d in designs])
+    sweep = dropin.sweep_from_member_tables(m0, G.describe_unit(base), tabs, [case], oracle_ctx)
+    out = sweep.run(oracle_ctx)
+    for j, Xi_ref in enumerate(refs):
+        assert group_rel_err(out["Xi"][j, 0, :1], Xi_ref[:1]) < 1e-9
