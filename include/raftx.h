@@ -172,6 +172,18 @@ int raftx_fetch_linearisation_point(raftx_ctx *ctx, raftx_c128 *XiLast);
 int raftx_channel_stats(raftx_ctx *ctx, int nChan, const double *L, const int32_t *pow, double dw,
                         double *std, double *psd);
 
+/* The general form: channels that mix displacement, velocity and acceleration terms and (optionally) a complex,
+ * frequency-dependent transfer,
+ *   y_c(w) = sum_{p=0..2} (i w)^p sum_j L[d,c,p,j] Xi[d,case,ih,j,w]  +  sum_j Gw[d,c,j,w] Xi[d,case,ih,j,w],
+ * with the same std / psd definitions as raftx_channel_stats.  This is what the tower-base fore-aft bending moment
+ * of FOWT.saveTurbineOutputs needs for a rigid tower (raft/raft_fowt.py:2500-2537): weight moment m g h Xi_pitch
+ * (p = 0), inertial reaction -m a_CG h - I_CG (-w^2 Xi_pitch) (p = 2) and the aero reaction
+ * -(-w^2 A_aero(w) + i w B_aero(w)) z^2 Xi_pitch (Gw); host feeder: raft_amd/dropin.py tower_base_rows.
+ * L [nDesign,nChan,3,6] real; Gw [nDesign,nChan,6,nw] complex or NULL; std [nDesign,nCase,nChan];
+ * psd [nDesign,nCase,nChan,nw] or NULL. */
+int raftx_channel_stats_poly(raftx_ctx *ctx, int nChan, const double *L, const raftx_c128 *Gw, double dw,
+                             double *std, double *psd);
+
 /* Coupled array solve, raft_model.py:1164-1236: for each system s and bin w
  *   Z_sys = blockdiag_i(Zblk[s,i]) + (-w^2 Mc[s] + i w Bc[s] + Cc[s]);
  *   Xi[s,r] = Z_sys^-1 F[s,r].

@@ -25,7 +25,7 @@ EXPORTS = (
     "raftx_excitation", "raftx_linearize", "raftx_solve_dynamics",
     "raftx_solve_system", "raftx_last_kernel_ms",
     "raftx_solve_dynamics_device", "raftx_fetch_results", "raftx_debug_math", "raftx_motion_stats", "raftx_solve_system_resident", "raftx_qtf_slender", "raftx_channel_stats", "raftx_qtf_force", "raftx_set_linearisation_point", "raftx_fetch_linearisation_point",
-    "raftx_build_designs", "raftx_fetch_strips", "raftx_fetch_statics",
+    "raftx_build_designs", "raftx_fetch_strips", "raftx_fetch_statics", "raftx_channel_stats_poly",
 )
 WANT_BDRAG, WANT_FWAVE, WANT_Z = 1, 2, 4
 
@@ -103,6 +103,8 @@ class RaftxLib:
         L.raftx_qtf_force.restype = C.c_int
         L.raftx_channel_stats.argtypes = [_vp, C.c_int, _vp, _vp, C.c_double, _vp, _vp]
         L.raftx_channel_stats.restype = C.c_int
+        L.raftx_channel_stats_poly.argtypes = [_vp, C.c_int, _vp, _vp, C.c_double, _vp, _vp]
+        L.raftx_channel_stats_poly.restype = C.c_int
         L.raftx_motion_stats.argtypes = [_vp, C.c_double, _vp, _vp]
         L.raftx_motion_stats.restype = C.c_int
         L.raftx_debug_math.argtypes = [_vp, C.c_int, _vp, _vp, _vp, _vp]
@@ -403,6 +405,25 @@ class Context:
         psd = np.empty((self.nDesign, self.nCase, nCh, self.nw), dtype=np.float64) if want_psd else None
         rc = self.rlib.lib.raftx_channel_stats(self._h, nCh, _ptr(L), _ptr(pw), float(dw), _ptr(std), _ptr(psd))
         self._check(rc, "raftx_channel_stats")
+        return std, psd
+
+    def channel_stats_poly(self, L, dw, Gw=None, want_psd=False):
+        """std [nDesign,nCase,nChan] (and PSD) of y_c = sum_p (i w)^p L[d,c,p,:] . Xi + Gw[d,c,:,w] . Xi of the resident
+        results (raftx_channel_stats_poly).  L [nChan,3,6] or [nDesign,nChan,3,6]; Gw [..,nChan,6,nw] complex or None."""
+        L = _f64(L)
+        if L.ndim == 3:
+            L = np.ascontiguousarray(np.broadcast_to(L, (self.nDesign,) + L.shape))
+        nCh = L.shape[1]
+        L = _f64(L, (self.nDesign, nCh, 3, 6), "L")
+        if Gw is not None:
+            Gw = np.asarray(Gw, dtype=np.complex128)
+            if Gw.ndim == 3:
+                Gw = np.broadcast_to(Gw, (self.nDesign,) + Gw.shape)
+            Gw = _c128(np.ascontiguousarray(Gw), (self.nDesign, nCh, 6, self.nw), "Gw")
+        std = np.empty((self.nDesign, self.nCase, nCh), dtype=np.float64)
+        psd = np.empty((self.nDesign, self.nCase, nCh, self.nw), dtype=np.float64) if want_psd else None
+        rc = self.rlib.lib.raftx_channel_stats_poly(self._h, nCh, _ptr(L), _ptr(Gw), float(dw), _ptr(std), _ptr(psd))
+        self._check(rc, "raftx_channel_stats_poly")
         return std, psd
 
     def motion_stats(self, dw, want_psd=False):

@@ -205,6 +205,54 @@ __global__ void __launch_bounds__(256) k_channel_stats(int nCase, int nHead, int
     }
 }
 
+// y_c = sum_p (i w)^p sum_j L[c,p,j] Xi_j + sum_j Gw[c,j,w] Xi_j  (tower-base moment: weight p=0, inertial reaction
+// p=2, complex aero reaction through Gw; raft_fowt.py:2500-2537)
+__global__ void __launch_bounds__(256) k_channel_stats_poly(int nCase, int nHead, int nw, int nChan, double inv_dw,
+                                                            const double *__restrict__ w, const cplx *__restrict__ Xi,
+                                                            const double *__restrict__ L, const cplx *__restrict__ Gw,
+                                                            double *__restrict__ sd, double *__restrict__ psd) {
+    __shared__ double part[4];
+    const int p = blockIdx.x, d = p / nCase;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    for (int ch = 0; ch < nChan; ch++) {
+        const double *row = L + ((size_t)d * nChan + ch) * 18;
+        const cplx *g = Gw ? Gw + ((size_t)d * nChan + ch) * 6 * nw : nullptr;
+        double acc = 0.0;
+        for (int i = threadIdx.x; i < nw; i += blockDim.x) {
+            const double wi = w[i], w2 = wi * wi;
+            double a2 = 0.0;
+            for (int ih = 0; ih < nHead; ih++) {
+                const cplx *x = Xi + (((size_t)p * nHead + ih) * 6) * nw + i;
+                double yr = 0.0, yi = 0.0;
+#pragma unroll
+                for (int j = 0; j < 6; j++) {
+                    const cplx xj = x[(size_t)j * nw];
+                    double cr = row[j] - w2 * row[12 + j], ci = wi * row[6 + j];     // L0 + (i w) L1 + (i w)^2 L2
+                    if (g) {
+                        const cplx gj = g[(size_t)j * nw + i];
+                        cr += gj.re;
+                        ci += gj.im;
+                    }
+                    yr += cr * xj.re - ci * xj.im;
+                    yi += cr * xj.im + ci * xj.re;
+                }
+                a2 += yr * yr + yi * yi;
+            }
+            acc += a2;
+            if (psd) psd[((size_t)p * nChan + ch) * nw + i] = 0.5 * a2 * inv_dw;
+        }
+        for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
+        __syncthreads();
+        if (lane == 0) part[wv] = acc;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            double a = 0.0;
+            for (int q = 0; q < (int)(blockDim.x >> 6); q++) a += part[q];
+            sd[(size_t)p * nChan + ch] = sqrt(0.5 * a);
+        }
+    }
+}
+
 // ------------------------------------------------------------------ host side
 struct raftx_ctx {
     int device;
@@ -1001,6 +1049,36 @@ extern "C" int raftx_channel_stats(raftx_ctx *c, int nChan, const double *L, con
     if (npair && nChan)
         hipLaunchKernelGGL(k_channel_stats, dim3((unsigned)npair), dim3(T.nw > 128 ? 256 : (T.nw > 64 ? 128 : 64)), 0,
                            c->stream, T.nCase, T.nHead, T.nw, nChan, 1.0 / dw, T.w, c->rXi, dL, dP, dS, dPsd);
+    if (finish_timed(c)) return -2;
+    if (npair && nChan) D2H(c, sd, dS, npair * nChan * sizeof(double));
+    if (npair && nChan && psd) D2H(c, psd, dPsd, npair * nChan * T.nw * sizeof(double));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+extern "C" int raftx_channel_stats_poly(raftx_ctx *c, int nChan, const double *L, const raftx_c128 *Gw, double dw, double *sd,
+                                        double *psd) {
+    if (!c) return -1;
+    if (!c->rXi) FAIL(c, "channel_stats_poly: no resident results");
+    if (nChan < 0 || (nChan && !L) || !sd) FAIL(c, "channel_stats_poly: bad arguments");
+    if (!(dw > 0.0)) FAIL(c, "channel_stats_poly: dw must be positive");
+    HIPCHK(c, hipSetDevice(c->device));
+    const DevTables &T = c->T;
+    const size_t npair = c->r_npair;
+    Scratch sc(c);
+    const size_t nL = (size_t)T.nDesign * nChan * 18, nG = (size_t)T.nDesign * nChan * 6 * T.nw;
+    double *dL = sc.alloc<double>(nL), *dS = sc.alloc<double>(npair * nChan);
+    cplx *dG = Gw ? sc.alloc<cplx>(nG) : nullptr;
+    double *dPsd = psd ? sc.alloc<double>(npair * nChan * T.nw) : nullptr;
+    if (npair && nChan && (!dL || !dS || (Gw && !dG) || (psd && !dPsd))) FAIL(c, "channel_stats_poly: device allocation failed");
+    if (npair && nChan) {
+        H2D(c, dL, L, nL * sizeof(double));
+        if (dG) H2D(c, dG, Gw, nG * sizeof(cplx));
+    }
+    HIPCHK(c, hipEventRecord(c->ev0, c->stream));
+    if (npair && nChan)
+        hipLaunchKernelGGL(k_channel_stats_poly, dim3((unsigned)npair), dim3(T.nw > 128 ? 256 : (T.nw > 64 ? 128 : 64)), 0,
+                           c->stream, T.nCase, T.nHead, T.nw, nChan, 1.0 / dw, T.w, c->rXi, dL, dG, dS, dPsd);
     if (finish_timed(c)) return -2;
     if (npair && nChan) D2H(c, sd, dS, npair * nChan * sizeof(double));
     if (npair && nChan && psd) D2H(c, psd, dPsd, npair * nChan * T.nw * sizeof(double));

@@ -213,6 +213,85 @@ class Engine:
         return f_mean, f
 
     # ------------------------------------------------------------------
+    def saveTurbineOutputs(self, fowt, results, case):
+        """raft_fowt.py:2291-2745 for a rigid single unit whose responses are resident on the ctx (i.e. right after
+        solveDynamics): platform motions, nacelle accelerations and the tower-base bending moment -- every
+        getRMS / getPSD of the method -- are ONE statistics launch over the resident responses
+        (raftx_channel_stats_poly); means, +-3 sigma bounds and the response amplitudes are host scalars / views.
+        Mooring-tension and rotor-controller blocks need MoorPy / CCBlade state and are outside the device path."""
+        if getattr(self, "_resident", None) is not fowt:
+            raise UnsupportedFOWT("saveTurbineOutputs: the responses of this FOWT are not resident on the device "
+                                  "(call solveDynamics of its single-unit model first)")
+        if getattr(fowt, "ms", None):
+            raise UnsupportedFOWT("saveTurbineOutputs: mooring-tension outputs need the MoorPy system (raft_fowt.py:2358-2399)")
+        if any(getattr(rot, "aeroServoMod", 0) > 1 for rot in fowt.rotorList):
+            raise UnsupportedFOWT("saveTurbineOutputs: rotor-controller outputs (raft_fowt.py:2640-2680) are not on the device path")
+        if np.any(np.abs(np.asarray(fowt.rigidBodyNode.r0[:3], dtype=float)) > 0):
+            raise UnsupportedFOWT("saveTurbineOutputs: reference node away from the PRP")
+        nr, nw = int(fowt.nrotors), fowt.nw
+        deg = 57.29577951308232                                              # helpers.rad2deg
+        Lt, Gt, info = tower_base_rows(fowt)
+        nCh = 6 + 4 * nr
+        L = np.zeros((nCh, 3, 6))
+        for j in range(6):
+            L[j, 0, j] = 1.0 if j < 3 else deg                               # motions; rotations in degrees (:2332-2354)
+        for ir, rotor in enumerate(fowt.rotorList):
+            T = np.asarray(rotor.nodeList[0].T, dtype=float)                 # hub motion = T Xi (:2423)
+            L[6 + 3 * ir:9 + 3 * ir, 2, :] = T[:3, :]                        # accelerations: w^2 x (:2426-2441)
+            L[6 + 3 * nr + ir] = Lt[ir]
+        Gw = None
+        if Gt is not None:
+            Gw = np.zeros((nCh, 6, nw), dtype=complex)
+            Gw[6 + 3 * nr:] = Gt
+        std, psd = self.ctx.channel_stats_poly(L, fowt.dw, Gw=Gw, want_psd=True)
+        std, psd = std[0, 0], psd[0, 0]
+        Xi0 = np.asarray(fowt.r6, dtype=float) - np.array([fowt.x_ref, fowt.y_ref, 0, 0, 0, 0])
+        Xi = np.asarray(fowt.Xi)
+        for j, name in enumerate(("surge", "sway", "heave", "roll", "pitch", "yaw")):
+            avg = Xi0[j] if j < 3 else Xi0[j] * deg
+            results[name + "_avg"] = avg
+            results[name + "_std"] = std[j]
+            results[name + "_max"] = avg + 3 * std[j]
+            results[name + "_min"] = avg - 3 * std[j]
+            results[name + "_PSD"] = psd[j].copy()
+            results[name + "_RA"] = Xi[:, j, :] if j < 3 else Xi[:, j, :] * deg
+        for ax_i, ax in enumerate("xyz"):
+            key = "A%sRNA" % ax
+            for suffix in ("std", "avg", "max", "min"):
+                results["%s_%s" % (key, suffix)] = np.zeros(nr)
+            results[key + "_PSD"] = np.zeros([nw, nr])
+            for ir, rotor in enumerate(fowt.rotorList):
+                c = 6 + 3 * ir + ax_i
+                rn = rotor.nodeList[0].r
+                avg = abs(np.sin(rn[4]) * fowt.g) if ax == "x" else (abs(np.sin(rn[3]) * fowt.g) if ax == "y" else abs(fowt.g))
+                results[key + "_std"][ir] = std[c]
+                results[key + "_PSD"][:, ir] = psd[c]
+                results[key + "_avg"][ir] = avg
+                results[key + "_max"][ir] = avg + 3 * std[c]
+                results[key + "_min"][ir] = avg - 3 * std[c]
+        for base in ("Mbase", "FbaseX", "FbaseY", "FbaseZ", "MbaseX", "MbaseY", "MbaseZ"):
+            for suffix in ("avg", "std", "max", "min"):
+                results["%s_%s" % (base, suffix)] = np.zeros(nr)
+            results[base + "_PSD"] = np.zeros([nw, nr])
+        for ir, rotor in enumerate(fowt.rotorList):
+            c = 6 + 3 * nr + ir
+            m, hArm = info[ir]
+            f = np.asarray(fowt.rotorList[0].nodeList[0].T, dtype=float) @ np.asarray(fowt.f_aero0)[:, ir]
+            results["Mbase_avg"][ir] = m * fowt.g * hArm * np.sin(fowt.Xi0[4]) + (f[4] + (-hArm) * f[0])     # :2532-2533
+            results["Mbase_std"][ir] = std[c]
+            results["Mbase_PSD"][:, ir] = psd[c]
+            results["Mbase_max"][ir] = results["Mbase_avg"][ir] + 3 * std[c]
+            results["Mbase_min"][ir] = results["Mbase_avg"][ir] - 3 * std[c]
+        zeta = np.asarray(fowt.zeta)
+        results["wave_PSD"] = np.sum(0.5 * np.abs(zeta) ** 2 / fowt.dw, axis=0)                       # getPSD(zeta, dw)
+        for key in ("omega", "torque", "bPitch"):
+            results[key + "_avg"] = np.zeros(nr)
+            results[key + "_std"] = np.zeros(nr)
+            results[key + "_PSD"] = np.zeros([nw, nr])
+        for key in ("omega_max", "omega_min", "power_avg"):
+            results[key] = np.zeros(nr)
+        return results
+
     def solveDynamics(self, model, case, tol=0.01, conv_plot=0, RAO_plot=0, display=0):
         """raft_model.py:966-1302."""
         iCase = case['iCase'] if 'iCase' in case else None
@@ -335,8 +414,43 @@ class Engine:
                 fowt.Xi_fullDOF[ih, :, :] = fowt.T @ fowt.Xi[ih, :, :]
         model.results['response'] = {}                                      # :1300
         model._raftx_niter = out['niter'][:, 0].copy()
+        # single-unit models: the unit's responses stay resident on the ctx, which saveTurbineOutputs reads back as
+        # statistics; a farm's final responses come from the coupled solve, not from the resident per-unit ones
+        self._resident = fowts[0] if nF == 1 else None
         model._raftx_flags = out['flags'][:, 0].copy()
         return model.Xi
+
+
+def tower_base_rows(fowt):
+    """Tower-base fore-aft bending moment of every (rigid) tower as linear channels of the platform response --
+    raft/raft_fowt.py:2500-2528:  M = M_I + M_w + M_X_aero with
+        M_w = m g h Xi_pitch,   M_I = -m a_CG h - I_CG (-w^2 Xi_pitch),  a_CG = -w^2 (Xi_surge + z_CG Xi_pitch),
+        M_X_aero = -(-w^2 A_aero[0,0] + i w B_aero[0,0]) (z_hub - z_base)^2 Xi_pitch.
+    Returns (L [nrotors,3,6] coefficients of (i w)^p, Gw [nrotors,6,nw] complex or None, (m, hArm) per rotor)."""
+    nr = int(fowt.nrotors)
+    L = np.zeros((nr, 3, 6))
+    Gw = np.zeros((nr, 6, fowt.nw), dtype=complex)
+    info = []
+    w = np.asarray(fowt.w)
+    for ir, rotor in enumerate(fowt.rotorList):
+        mem_tower = fowt.memberList[fowt.nplatmems + ir]
+        if getattr(mem_tower, "type", "rigid") != "rigid":
+            raise UnsupportedFOWT("flexible tower: base loads come from the FE stiffness (raft_fowt.py:2540-2601)")
+        m = fowt.mtower[ir] + rotor.mRNA
+        zCG = (fowt.rCG_tow[ir][2] * fowt.mtower[ir] + rotor.r_rel[2] * rotor.mRNA) / m
+        zBase = mem_tower.rA[2]
+        hArm = zCG - zBase
+        r = np.asarray(mem_tower.nodeList[0].r0[:3], dtype=float) - np.array([0.0, 0.0, zCG])
+        H = np.array([[0, r[2], -r[1]], [-r[2], 0, r[0]], [r[1], -r[0], 0]])                      # helpers.py:428-437
+        Ms = np.asarray(mem_tower.M_struc, dtype=float)
+        I44 = (H @ Ms[:3, :3] @ H.T + Ms[3:, :3] @ H + H.T @ Ms[:3, 3:] + Ms[3:, 3:])[1, 1]       # helpers.py:582-583, [4,4]
+        ICG = I44 + rotor.mRNA * (rotor.r_rel[2] - zCG) ** 2 + rotor.IrRNA
+        L[ir, 0, 4] = m * fowt.g * hArm                       # weight moment
+        L[ir, 2, 0] = -m * hArm                               # (i w)^2 = -w^2: inertial reaction, surge part
+        L[ir, 2, 4] = -(m * hArm * zCG + ICG)                 # ... and pitch part
+        Gw[ir, 4, :] = -(-w ** 2 * fowt.A_aero[0, 0, :, ir] + 1j * w * fowt.B_aero[0, 0, :, ir]) * (rotor.r_rel[2] - zBase) ** 2
+        info.append((m, hArm))
+    return L, (Gw if np.any(Gw) else None), info
 
 
 def unit_matrices(fowt, nw):
@@ -461,14 +575,20 @@ def calcHydroForce_2ndOrd(fowt, beta, S0, iCase=None, iWT=None, interpMode='qtf'
     return _default_engine.calcHydroForce_2ndOrd(fowt, beta, S0, iCase=iCase, iWT=iWT, interpMode=interpMode)
 
 
+def saveTurbineOutputs(fowt, results, case):
+    return _default_engine.saveTurbineOutputs(fowt, results, case)
+
+
 def solveDynamics(model, case, tol=0.01, conv_plot=0, RAO_plot=0, display=0):
     return _default_engine.solveDynamics(model, case, tol=tol, conv_plot=conv_plot,
                                          RAO_plot=RAO_plot, display=display)
 
 
-def install(raft_module=None):
+def install(raft_module=None, outputs=False):
     """Monkey-patch a loaded reference package so that Model.analyzeCases & co
-    run the hot path on the GPU.  Returns the originals for un-patching."""
+    run the hot path on the GPU.  Returns the originals for un-patching.
+    outputs=True also routes FOWT.saveTurbineOutputs (statistics of the resident responses; rigid single units
+    without MoorPy / controller outputs -- anything else raises UnsupportedFOWT, never a silent fallback)."""
     if raft_module is None:
         import raft as raft_module
     from raft import raft_model, raft_fowt
@@ -484,6 +604,9 @@ def install(raft_module=None):
     raft_fowt.FOWT.calcDragExcitation = calcDragExcitation
     raft_fowt.FOWT.calcQTF_slenderBody = calcQTF_slenderBody
     raft_fowt.FOWT.calcHydroForce_2ndOrd = calcHydroForce_2ndOrd
+    if outputs:
+        saved["saveTurbineOutputs"] = raft_fowt.FOWT.saveTurbineOutputs
+        raft_fowt.FOWT.saveTurbineOutputs = saveTurbineOutputs
     return saved
 
 
@@ -495,3 +618,5 @@ def uninstall(saved):
     raft_fowt.FOWT.calcDragExcitation = saved['calcDragExcitation']
     raft_fowt.FOWT.calcQTF_slenderBody = saved['calcQTF_slenderBody']
     raft_fowt.FOWT.calcHydroForce_2ndOrd = saved['calcHydroForce_2ndOrd']
+    if 'saveTurbineOutputs' in saved:
+        raft_fowt.FOWT.saveTurbineOutputs = saved['saveTurbineOutputs']

@@ -129,6 +129,17 @@ class Sweep:
         r = ctx.fetch_results(want_Xi=False)
         return {"std": std, "psd": psd, "niter": r["niter"], "flags": r["flags"]}
 
+    def run_channels(self, ctx, L, Gw=None, want_psd=False):
+        """Solve and return the statistics of general linear output channels of every (design, case) --
+        y_c = sum_p (i w)^p L[.,c,p,:] . Xi + Gw[.,c,:,w] . Xi (raftx_channel_stats_poly): platform motions, nacelle
+        accelerations, tower-base bending moment (raft_amd.dropin.tower_base_rows) ... what an optimiser's constraints
+        consume (raft/omdao_raft.py:840-876), a few hundred bytes per (design, case) instead of the responses."""
+        self.solve(ctx)
+        dw = float(self.w[1] - self.w[0]) if self.nw > 1 else float(self.w[0])
+        std, psd = ctx.channel_stats_poly(L, dw, Gw=Gw, want_psd=want_psd)
+        r = ctx.fetch_results(want_Xi=False)
+        return {"std": std, "psd": psd, "niter": r["niter"], "flags": r["flags"]}
+
     def run_farm(self, ctx, n_unit, Cc=None, Mc=None, Bc=None):
         """Arrays: consecutive groups of ``n_unit`` designs are the units of one farm (raft_model.py:1164-1236).
         Two launches: the per-unit fixed points, then the coupled 6N x 6N solves fed from the resident Z / F_wave.

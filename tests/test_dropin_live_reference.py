@@ -139,3 +139,39 @@ def test_member_description_sweep_equals_reference_models(oracle_ctx):
     out = sweep.run(oracle_ctx)
     for j, Xi_ref in enumerate(refs):
         assert group_rel_err(out["Xi"][j, 0, :1], Xi_ref[:1]) < 1e-9
+
+
+@pytest.mark.parametrize("headings", [1, 2])
+def test_saveTurbineOutputs_statistics_equal_reference(oracle_ctx, headings):
+    """FOWT.saveTurbineOutputs (raft_fowt.py:2291-2745) through the statistics entry point: every key the
+    reference writes for a rigid, MoorPy-less unit -- motions, nacelle accelerations, tower-base moment, wave PSD --
+    against the reference's own method run on the reference's own responses."""
+    import io
+    from raft_amd import dropin
+    with contextlib.redirect_stdout(io.StringIO()):
+        m = _model("examples/VolturnUS-S_example.yaml", dict(min_freq=0.01, max_freq=0.3))
+        m2 = _model("examples/VolturnUS-S_example.yaml", dict(min_freq=0.01, max_freq=0.3))
+    case = rh.make_case(Hs=4.0, Tp=9.0, heading=20.0)
+    if headings == 2:
+        case.update(wave_heading=[20.0, -60.0], wave_spectrum=["JONSWAP", "JONSWAP"], wave_period=[9.0, 13.0],
+                    wave_height=[4.0, 2.0], wave_gamma=[0, 0])
+    with contextlib.redirect_stdout(io.StringIO()):
+        m.solveDynamics(copy.deepcopy(case))
+        ref = {}
+        m.fowtList[0].saveTurbineOutputs(ref, copy.deepcopy(case))
+    eng = dropin.Engine(oracle_ctx)
+    eng.solveDynamics(m2, copy.deepcopy(case))
+    got = eng.saveTurbineOutputs(m2.fowtList[0], {}, copy.deepcopy(case))
+    assert set(got) <= set(ref)
+    checked = 0
+    for key, val in got.items():
+        a, b = np.asarray(val), np.asarray(ref[key])
+        assert a.shape == b.shape, key
+        scale = max(np.max(np.abs(b)), 1e-300)
+        assert np.max(np.abs(a - b)) <= 1e-8 * scale + 1e-12, (key, np.max(np.abs(a - b)) / scale)
+        checked += 1
+    assert checked >= 60 and got["Mbase_std"][0] > 1e6 and got["AxRNA_std"][0] > 0
+    missing = set(ref) - set(got)
+    assert all(k.startswith(("Tmoor", "wind_PSD", "cavitation")) for k in missing), missing
+    with pytest.raises(dropin.UnsupportedFOWT):
+        dropin.Engine(oracle_ctx).saveTurbineOutputs(m2.fowtList[0], {}, case)      # nothing resident for that engine

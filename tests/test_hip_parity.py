@@ -222,6 +222,32 @@ def test_channel_stats_parity(hip_ctx, oracle_ctx):
     assert rel_err(out[0][1], out[1][1]) < TOL
 
 
+def test_channel_stats_poly_parity(hip_ctx, oracle_ctx):
+    """Mixed displacement / velocity / acceleration channels with a complex frequency-dependent transfer (the
+    tower-base moment pattern, raft_fowt.py:2500-2537); nw = 90 exercises the ragged last wave."""
+    rng = np.random.default_rng(909)
+    tables = [random_strips(rng, S) for S in (40, 53, 7)]
+    mats = random_matrices(rng, 3)
+    cases = synthetic_cases(rng, 2, 2, 90)
+    _both(hip_ctx, oracle_ctx, tables, mats, cases)
+    L = rng.normal(size=(3, 4, 3, 6)) * np.array([1, 1, 1, 50, 50, 50])
+    Gw = rng.normal(size=(3, 4, 6, 90)) + 1j * rng.normal(size=(3, 4, 6, 90))
+    out, out_nog = [], []
+    for ctx in (hip_ctx, oracle_ctx):
+        ctx.solve_dynamics_device(5, 0.01, 0.1)
+        out.append(ctx.channel_stats_poly(L, 0.031, Gw=Gw, want_psd=True))
+        out_nog.append(ctx.channel_stats_poly(L, 0.031))
+    assert rel_err(out[0][0], out[1][0]) < TOL and rel_err(out[0][1], out[1][1]) < TOL
+    assert rel_err(out_nog[0][0], out_nog[1][0]) < TOL and out_nog[0][1] is None
+    # pure powers reproduce raftx_channel_stats
+    Lp = np.zeros((3, 2, 3, 6))
+    Lp[:, 0, 0] = L[:, 0, 0]
+    Lp[:, 1, 2] = L[:, 1, 2]
+    a, _ = hip_ctx.channel_stats_poly(Lp, 0.031)
+    b, _ = hip_ctx.channel_stats(np.stack([L[:, 0, 0], L[:, 1, 2]], axis=1), [0, 2], 0.031)
+    assert rel_err(a, b) < 1e-12
+
+
 def test_repeat_runs_are_bitwise_identical(hip_ctx):
     rng = np.random.default_rng(7)
     tables = [random_strips(rng, 53) for _ in range(4)]
