@@ -217,6 +217,15 @@ int raftx_qtf_slender(raftx_ctx *ctx, int nSet, int nw2, const double *w2, const
                       const raftx_c128 *Xi, const double *beta, const double *Mstruc,
                       const raftx_c128 *kay, raftx_c128 *qtf);
 
+/* One QTF shared by several ranks: the same call restricted to the rows w1 = w2[row_off + m*row_stride] (and their
+ * Hermitian mirrors); every other entry of qtf is returned as 0, so the partial results of row_stride ranks SUM to the
+ * full matrix.  Rows are interleaved because their cost is triangular (row i1 holds nw2 - i1 pairs). */
+int raftx_qtf_slender_rows(raftx_ctx *ctx, int nSet, int nw2, const double *w2, const double *k2,
+                           double depth, double rho, double g,
+                           const int64_t *stripOff, const double *strips, const int64_t *memOff, const double *members,
+                           const raftx_c128 *Xi, const double *beta, const double *Mstruc,
+                           const raftx_c128 *kay, int row_off, int row_stride, raftx_c128 *qtf);
+
 /* Second-order difference-frequency force amplitudes from QTFs -- FOWT.calcHydroForce_2ndOrd with
  * interpMode='qtf' (raft/raft_fowt.py:2209-2245): for every set, bilinear interpolation of the QTF from the
  * second-order grid w2 onto the first-order grid w (outside the grid: 0, like RegularGridInterpolator with

@@ -25,7 +25,7 @@ EXPORTS = (
     "raftx_excitation", "raftx_linearize", "raftx_solve_dynamics",
     "raftx_solve_system", "raftx_last_kernel_ms",
     "raftx_solve_dynamics_device", "raftx_fetch_results", "raftx_debug_math", "raftx_motion_stats", "raftx_solve_system_resident", "raftx_qtf_slender", "raftx_channel_stats", "raftx_qtf_force", "raftx_set_linearisation_point", "raftx_fetch_linearisation_point",
-    "raftx_build_designs", "raftx_fetch_strips", "raftx_fetch_statics", "raftx_channel_stats_poly",
+    "raftx_build_designs", "raftx_fetch_strips", "raftx_fetch_statics", "raftx_channel_stats_poly", "raftx_qtf_slender_rows",
 )
 WANT_BDRAG, WANT_FWAVE, WANT_Z = 1, 2, 4
 
@@ -95,6 +95,9 @@ class RaftxLib:
         L.raftx_qtf_slender.argtypes = [_vp, C.c_int, C.c_int, _vp, _vp, C.c_double, C.c_double, C.c_double,
                                         _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]
         L.raftx_qtf_slender.restype = C.c_int
+        L.raftx_qtf_slender_rows.argtypes = [_vp, C.c_int, C.c_int, _vp, _vp, C.c_double, C.c_double, C.c_double,
+                                             _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, C.c_int, C.c_int, _vp]
+        L.raftx_qtf_slender_rows.restype = C.c_int
         L.raftx_set_linearisation_point.argtypes = [_vp, _vp, C.c_int]
         L.raftx_set_linearisation_point.restype = C.c_int
         L.raftx_fetch_linearisation_point.argtypes = [_vp, _vp]
@@ -353,9 +356,11 @@ class Context:
         self._check(rc, "raftx_qtf_force")
         return f_mean, f
 
-    def qtf_slender(self, tables, Xi, beta, w2, k2, depth, rho, g, Mstruc, kay=None, fetch=True):
+    def qtf_slender(self, tables, Xi, beta, w2, k2, depth, rho, g, Mstruc, kay=None, fetch=True, rows=None):
         """Batch of slender-body QTFs: tables = list of raft_amd.qtf.QtfTable (one per set), Xi [nSet,6,nw2],
-        beta [nSet], Mstruc [nSet,6,6], kay [nSet,nw2,nw2,6] or None -> qtf [nSet,nw2,nw2,6]."""
+        beta [nSet], Mstruc [nSet,6,6], kay [nSet,nw2,nw2,6] or None -> qtf [nSet,nw2,nw2,6].
+        rows=(offset, stride): only the rows w1 = w2[offset::stride] and their mirrors (zeros elsewhere), the
+        interleaved partition of ONE QTF over ranks (raftx_qtf_slender_rows)."""
         nS = len(tables)
         w2 = _f64(w2)
         nw2 = len(w2)
@@ -372,6 +377,12 @@ class Context:
         Mstruc = _f64(Mstruc, (nS, 6, 6), "Mstruc")
         kay = None if kay is None else _c128(kay, (nS, nw2, nw2, 6), "kay")
         qtf = np.empty((nS, nw2, nw2, 6), dtype=np.complex128) if fetch else None
+        if rows is not None:
+            rc = self.rlib.lib.raftx_qtf_slender_rows(self._h, nS, nw2, _ptr(w2), _ptr(k2), float(depth), float(rho), float(g),
+                                                      _ptr(soff), _ptr(strips), _ptr(moff), _ptr(members), _ptr(Xi),
+                                                      _ptr(beta), _ptr(Mstruc), _ptr(kay), int(rows[0]), int(rows[1]), _ptr(qtf))
+            self._check(rc, "raftx_qtf_slender_rows")
+            return qtf
         rc = self.rlib.lib.raftx_qtf_slender(self._h, nS, nw2, _ptr(w2), _ptr(k2), float(depth), float(rho), float(g),
                                              _ptr(soff), _ptr(strips), _ptr(moff), _ptr(members), _ptr(Xi), _ptr(beta),
                                              _ptr(Mstruc), _ptr(kay), _ptr(qtf))

@@ -1159,13 +1159,15 @@ extern "C" int raftx_solve_system_resident(raftx_ctx *c, int nUnit, const double
     return 0;
 }
 
-extern "C" int raftx_qtf_slender(raftx_ctx *c, int nSet, int nw2, const double *w2, const double *k2, double depth,
-                                 double rho, double g, const int64_t *stripOff, const double *strips,
-                                 const int64_t *memOff, const double *members, const raftx_c128 *Xi,
-                                 const double *beta, const double *Mstruc, const raftx_c128 *kay, raftx_c128 *qtf) {
+static int qtf_slender_impl(raftx_ctx *c, int nSet, int nw2, const double *w2, const double *k2, double depth,
+                            double rho, double g, const int64_t *stripOff, const double *strips,
+                            const int64_t *memOff, const double *members, const raftx_c128 *Xi,
+                            const double *beta, const double *Mstruc, const raftx_c128 *kay, int row_off, int row_stride,
+                            raftx_c128 *qtf) {
     if (!c) return -1;
     if (nSet < 0 || nw2 < 1 || !w2 || !k2 || !stripOff || !memOff || !Xi || !beta || !Mstruc)
         FAIL(c, "qtf_slender: bad arguments");
+    if (row_stride < 1 || row_off < 0 || row_off >= row_stride) FAIL(c, "qtf_slender: bad row partition %d/%d", row_off, row_stride);
     HIPCHK(c, hipSetDevice(c->device));
     const size_t nStrip = (size_t)stripOff[nSet], nMem = (size_t)memOff[nSet];
     if ((nStrip && !strips) || (nMem && !members)) FAIL(c, "qtf_slender: missing tables");
@@ -1221,16 +1223,38 @@ extern "C" int raftx_qtf_slender(raftx_ctx *c, int nSet, int nw2, const double *
     }
     A.w = dw; A.k = dk; A.soff = dso; A.strips = dS; A.moff = dmo; A.members = dM; A.sset = dss; A.mset = dms;
     A.Xi = dXi; A.beta = dB; A.Ms = dMs; A.kay = dK; A.T = dT; A.TM = dTM; A.TS = dTS; A.qtf = dQ;
+    A.row_off = row_off;
+    A.row_stride = row_stride;
+    A.nrow = (nw2 - row_off + row_stride - 1) / row_stride;           // rows w1 = row_off + m*row_stride of this call
+    if (A.nrow < 0) A.nrow = 0;
+    if (nSet && row_stride > 1) HIPCHK(c, hipMemsetAsync(dQ, 0, nq * sizeof(cplx), c->stream));   // other ranks' rows stay 0
     HIPCHK(c, hipEventRecord(c->ev0, c->stream));
     if (nSet) {
         hipLaunchKernelGGL(k_qtf_tables, dim3((unsigned)(nStrip + nMem + nSet)), dim3(nw2 > 128 ? 256 : 128), 0, c->stream, A,
                            (int)nStrip, (int)nMem);
-        hipLaunchKernelGGL(k_qtf_pairs, dim3((unsigned)((size_t)nSet * nw2)), dim3(nw2 > 64 ? 128 : 64), 0, c->stream, A);
+        if (A.nrow)
+            hipLaunchKernelGGL(k_qtf_pairs, dim3((unsigned)((size_t)nSet * A.nrow)), dim3(nw2 > 64 ? 128 : 64), 0, c->stream, A);
     }
     if (finish_timed(c)) return -2;
     if (nSet && qtf) D2H(c, qtf, dQ, nq * sizeof(cplx));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     return 0;
+}
+
+extern "C" int raftx_qtf_slender(raftx_ctx *c, int nSet, int nw2, const double *w2, const double *k2, double depth,
+                                 double rho, double g, const int64_t *stripOff, const double *strips,
+                                 const int64_t *memOff, const double *members, const raftx_c128 *Xi,
+                                 const double *beta, const double *Mstruc, const raftx_c128 *kay, raftx_c128 *qtf) {
+    return qtf_slender_impl(c, nSet, nw2, w2, k2, depth, rho, g, stripOff, strips, memOff, members, Xi, beta, Mstruc, kay, 0, 1, qtf);
+}
+
+extern "C" int raftx_qtf_slender_rows(raftx_ctx *c, int nSet, int nw2, const double *w2, const double *k2, double depth,
+                                      double rho, double g, const int64_t *stripOff, const double *strips,
+                                      const int64_t *memOff, const double *members, const raftx_c128 *Xi,
+                                      const double *beta, const double *Mstruc, const raftx_c128 *kay, int row_off,
+                                      int row_stride, raftx_c128 *qtf) {
+    return qtf_slender_impl(c, nSet, nw2, w2, k2, depth, rho, g, stripOff, strips, memOff, members, Xi, beta, Mstruc, kay,
+                            row_off, row_stride, qtf);
 }
 
 extern "C" int raftx_qtf_force(raftx_ctx *c, int nSet, int nw2, const double *w2, const raftx_c128 *qtf, int nw,

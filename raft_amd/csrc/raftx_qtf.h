@@ -96,6 +96,8 @@ struct QtfArgs {
     cplx *TM;                              // [nMem,QTM_N,nw]
     cplx *TS;                              // [nSet,QTS_N,nw]
     cplx *qtf;                             // [nSet,nw,nw,6]
+    int row_off, row_stride, nrow;         // this call computes rows w1 = row_off + m*row_stride (m < nrow): the interleaved
+                                           // row partition of one QTF over ranks (row cost ~ nw - i1: triangular)
 };
 
 // getWaveKin with zeta0 = 1 (helpers.py:188-236): u, and Cc for the pressure/elevation
@@ -251,7 +253,7 @@ __global__ void __launch_bounds__(256) k_qtf_tables(QtfArgs A, int nStrip, int n
 // ---- pair kernel: grid (nSet * nw) rows of w1; threads stride w2 >= w1
 __global__ void __launch_bounds__(128) k_qtf_pairs(QtfArgs A) {
     const int nw = A.nw;
-    const int set = blockIdx.x / nw, i1 = blockIdx.x % nw;
+    const int set = blockIdx.x / A.nrow, i1 = A.row_off + (blockIdx.x % A.nrow) * A.row_stride;
     const double h = A.depth, rho = A.rho, g = A.g;
     const double w1 = A.w[i1], k1 = A.k[i1];
     const double beta = A.beta[set];

@@ -108,6 +108,14 @@ class Sweep:
     def shard(self, rank, world):
         return self.take(*shard_bounds(self.n_design, rank, world))
 
+    def take_cases(self, lo, hi):
+        """The same designs for the sea states [lo, hi) only (shallow copy; used to shard one farm's load cases)."""
+        import copy
+        s = copy.copy(self)
+        s.zeta = np.ascontiguousarray(self.zeta[lo:hi])
+        s.beta = np.ascontiguousarray(self.beta[lo:hi])
+        return s
+
     # ------------------------------------------------------------------ solve
     def upload(self, ctx):
         ctx.upload_designs_raw(self.off, self.strips, self.M0, self.B0, self.C0, self.nw, self.MBw, self.cmoff, self.cm)
@@ -326,3 +334,39 @@ def run_qtf_sharded(qtf_fn, tables, Xi, beta, w2, k2, depth, rho, g, Mstruc, kay
     counts = [shard_bounds(n, r, world)[1] - shard_bounds(n, r, world)[0] for r in range(world)]
     full = gather_rows(local, counts, dist)
     return full if rank == 0 else local
+
+
+def run_qtf_rows_sharded(qtf_fn, tables, Xi, beta, w2, k2, depth, rho, g, Mstruc, kay=None, dist=None):
+    """ONE QTF (or a few) shared by all ranks -- SURVEY.md 8e C5: every rank computes the INTERLEAVED rows
+    w1 = w2[rank::world] of every set (row i1 holds nw2 - i1 pairs, so contiguous blocks would be unbalanced) with
+    ``qtf_fn(..., rows=(rank, world))`` (ctx.qtf_slender -> raftx_qtf_slender_rows), which returns zeros elsewhere;
+    the partial matrices are SUMMED onto rank 0 (one reduce of nSet*nw2^2*6 complex: 3.8 MB for the 200-point grid).
+    Rank 0 gets the full [nSet,nw2,nw2,6]; the others their partial."""
+    if dist is None or dist.get_world_size() == 1:
+        return qtf_fn(tables, Xi, beta, w2, k2, depth, rho, g, Mstruc, kay)
+    import torch
+    rank, world = dist.get_rank(), dist.get_world_size()
+    part = np.ascontiguousarray(qtf_fn(tables, Xi, beta, w2, k2, depth, rho, g, Mstruc, kay, rows=(rank, world)))
+    t = torch.as_tensor(part.view(np.float64)).to(_device_for(dist))
+    dist.reduce(t, dst=0, op=dist.ReduceOp.SUM)
+    return t.cpu().numpy().view(np.complex128) if rank == 0 else part
+
+
+def run_farm_sharded(sweep, ctx, n_unit, Cc=None, Mc=None, Bc=None, dist=None):
+    """ONE farm (or a few) and many sea states -- SURVEY.md 8e C4: the CASES are block-partitioned over the ranks
+    (every rank holds all units' tables: 54 KB for four VolturnUS-S), each rank runs ``Sweep.run_farm`` on its sea
+    states, and the responses are gathered along the case axis onto rank 0.  No collective while solving."""
+    if dist is None or dist.get_world_size() == 1:
+        return sweep.run_farm(ctx, n_unit, Cc=Cc, Mc=Mc, Bc=Bc)
+    rank, world = dist.get_rank(), dist.get_world_size()
+    lo, hi = shard_bounds(sweep.n_case, rank, world)
+    local = sweep.take_cases(lo, hi).run_farm(ctx, n_unit, Cc=Cc, Mc=Mc, Bc=Bc)
+    counts = [shard_bounds(sweep.n_case, r, world)[1] - shard_bounds(sweep.n_case, r, world)[0] for r in range(world)]
+    out = {}
+    for key, v in local.items():                         # case axis is axis 1 of every array result
+        if np.ndim(v) < 2:                               # kernel_ms etc.: per-rank scalars
+            out[key] = v
+            continue
+        g = gather_rows(np.ascontiguousarray(np.moveaxis(v, 1, 0)), counts, dist)
+        out[key] = None if g is None else np.moveaxis(g, 0, 1)
+    return out if rank == 0 else local

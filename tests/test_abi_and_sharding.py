@@ -194,10 +194,18 @@ def _qtf_sets():
     return [tab] * 3, Xi, np.array([0.0, 0.5, -1.0]), w2, k2, f
 
 
-def _numpy_qtf(t, X, b, w, k, h, rho, g, Ms, kay):
+def _numpy_qtf(t, X, b, w, k, h, rho, g, Ms, kay, rows=None):
+    """numpy oracle; rows=(off, stride) keeps only those rows and their Hermitian mirrors (zeros elsewhere), like
+    raftx_qtf_slender_rows."""
     from oracle import qtf_oracle
-    return np.array([qtf_oracle.qtf_slender_body(t[i], X[i], b[i], w, k, h, rho, g, Ms[i]) for i in range(len(t))]
-                    ).reshape(len(t), len(w), len(w), 6)
+    q = np.array([qtf_oracle.qtf_slender_body(t[i], X[i], b[i], w, k, h, rho, g, Ms[i]) for i in range(len(t))]
+                 ).reshape(len(t), len(w), len(w), 6)
+    if rows is not None:
+        n = len(w)
+        i1, i2 = np.meshgrid(np.arange(n), np.arange(n), indexing="ij")
+        keep = (np.minimum(i1, i2) % rows[1]) == rows[0]              # entry (i1,i2) belongs to row min(i1,i2)
+        q = q * keep[None, :, :, None]
+    return q
 
 
 def _qtf_rank_main(rank, world, port, out_path):
@@ -212,6 +220,67 @@ def _qtf_rank_main(rank, world, port, out_path):
             np.save(out_path, q)
     finally:
         dist.destroy_process_group()
+
+
+def _qtf_rows_rank_main(rank, world, port, out_path):
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        tabs, Xi, beta, w2, k2, f = _qtf_sets()
+        q = sw.run_qtf_rows_sharded(_numpy_qtf, tabs[:1], Xi[:1], beta[:1], w2, k2, f.depth, f.rho_water, f.g,
+                                    np.array([f.M_struc]), dist=dist)
+        if rank == 0:
+            np.save(out_path, q)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_rank_gloo_qtf_rows_of_one_matrix(tmp_path):
+    """ONE QTF split by interleaved rows over two ranks and summed onto rank 0."""
+    import torch.multiprocessing as mp
+    out = str(tmp_path / "qrows.npy")
+    mp.spawn(_qtf_rows_rank_main, args=(2, _free_port(), out), nprocs=2, join=True)
+    got = np.load(out)
+    tabs, Xi, beta, w2, k2, f = _qtf_sets()
+    ref = _numpy_qtf(tabs[:1], Xi[:1], beta[:1], w2, k2, f.depth, f.rho_water, f.g, np.array([f.M_struc]), None)
+    assert got.shape == ref.shape and np.array_equal(got.view(np.float64), ref.view(np.float64))
+
+
+def _farm_rank_main(rank, world, port, out_path):
+    import torch.distributed as dist
+    from raft_amd import dropin
+    from raft_amd._abi import RaftxLib
+    from tests.util import load_model_fixture, case_from_fixture
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        fx, model = load_model_fixture("c4_farm.npz")
+        cases = [case_from_fixture(c) for c in fx["cases"]]
+        sweep = dropin.sweep_from_units(model, cases + cases[:1])            # 3 sea states: ragged 2 + 1
+        ctx = RaftxLib(ORACLE_SO).context(0)
+        res = sw.run_farm_sharded(sweep, ctx, 4, Cc=fx["coupling_C"][None], dist=dist)
+        ctx.close()
+        if rank == 0:
+            np.savez(out_path, Xi=res["Xi"], niter=res["niter"])
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_rank_gloo_farm_cases(tmp_path):
+    """ONE 4-unit farm, its sea states block-partitioned over two ranks and gathered along the case axis
+    (SURVEY.md 8e, C4): equal to the live reference's coupled responses."""
+    import torch.multiprocessing as mp
+    from tests.util import load_model_fixture, group_rel_err
+    out = str(tmp_path / "farm.npz")
+    mp.spawn(_farm_rank_main, args=(2, _free_port(), out), nprocs=2, join=True)
+    got = np.load(out)
+    fx, _ = load_model_fixture("c4_farm.npz")
+    assert got["Xi"].shape[:2] == (1, 3) and got["niter"].shape == (4, 3)
+    for i, c in enumerate(list(fx["cases"]) + list(fx["cases"])[:1]):
+        nH = c["Xi"].shape[0] - 1
+        assert group_rel_err(got["Xi"][0, i, :nH], c["Xi"][:nH]) < 1e-10
+        assert [int(got["niter"][u, i]) for u in range(4)] == [int(c["units"][u]["niter"]) for u in range(4)]
 
 
 def test_two_rank_gloo_qtf_sets(tmp_path):

@@ -65,6 +65,31 @@ def test_qtf_batch_against_numpy_oracle(hip_ctx):
         assert np.array_equal(q[s][off], np.conj(np.transpose(q[s], (1, 0, 2)))[off])
 
 
+def test_qtf_interleaved_row_partition_sums_to_the_full_matrix(hip_ctx):
+    """raftx_qtf_slender_rows: the rows rank::world of one 200-point QTF for world = 3; the partial matrices have
+    disjoint support (rows + Hermitian mirrors) and add up, bit for bit, to the unpartitioned result."""
+    fx, f, tab = _setup("VolturnUS-S")
+    rng = np.random.default_rng(21)
+    nw2 = 200
+    w2 = np.arange(1, nw2 + 1) * 0.0025 * 2 * np.pi
+    from raft_amd import waves
+    k2 = np.array([waves.wave_number(x, f.depth) for x in w2])
+    amp = np.array([1.0, 0.3, 0.7, 0.01, 0.02, 0.004])[:, None] / (1.0 + (w2[None, :] / 0.6) ** 2)
+    Xi = (amp * np.exp(1j * (rng.uniform(0, 6, 6)[:, None] + 1.5 * w2[None, :])))[None]
+    args = ([tab], Xi, [np.deg2rad(30.0)], w2, k2, f.depth, f.rho_water, f.g, np.array([f.M_struc]))
+    full = hip_ctx.qtf_slender(*args)
+    world = 3
+    parts = [hip_ctx.qtf_slender(*args, rows=(r, world)) for r in range(world)]
+    support = sum((np.abs(p) > 0).astype(int) for p in parts)
+    assert support.max() == 1                                         # no entry computed twice
+    total = parts[0] + parts[1] + parts[2]
+    assert np.array_equal(total.view(np.float64), full.view(np.float64))
+    rows0 = np.nonzero(np.any(np.abs(parts[0][0]) > 0, axis=(1, 2)))[0]
+    assert set(range(0, nw2, world)) <= set(rows0)
+    with pytest.raises(Exception):
+        hip_ctx.qtf_slender(*args, rows=(3, 3))
+
+
 @pytest.mark.parametrize("fixture", ["c5_internal_qtf.npz", "c5_oc4semi_qtf.npz"])
 def test_c5_internal_qtf_solveDynamics(hip_ctx, fixture):
     """BASELINE configs[4] path end to end on the device: first-order fixed point, slender-body QTF kernels fed with
