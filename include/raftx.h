@@ -143,6 +143,21 @@ int raftx_solve_dynamics_device(raftx_ctx *ctx, int nIter, double tol, double Xi
 int raftx_fetch_results(raftx_ctx *ctx, raftx_c128 *Xi, int32_t *niter, int32_t *flags,
                         double *B_drag, raftx_c128 *F_wave, raftx_c128 *Z);
 
+/* Potential-flow (BEM) wave excitation with heading interpolation, the first block of FOWT.calcHydroExcitation
+ * (raft/raft_fowt.py:1796-1849), for every (design, case, heading) of the uploaded designs and sea states:
+ *   beta' = (deg(beta) - heading_adjust[d]) mod 360;  X' = X_BEM[d,i1] f1 + X_BEM[d,i2] f2  (neighbouring BEM headings,
+ *   wrapping around 360);  rotate surge/sway and roll/pitch back by beta (:1838-1844);
+ *   F_BEM = X zeta exp(-i k (x_ref cos beta + y_ref sin beta))                        (:1800-1801, 1847)
+ * X_BEM [nDesign,nHeadBEM,6,nw]: excitation coefficients per unit wave amplitude in the wave-heading frame, as
+ * FOWT.readHydro leaves them (:1485-1501; host feeder raft_amd/bem.py); headings_deg [nHeadBEM] ascending in [0,360);
+ * heading_adjust [nDesign] deg and xy_ref [nDesign,2] m may be NULL (zeros).  F_add (optional host buffer
+ * [nDesign,nCase,nHead,6,nw], e.g. second-order forces) is added.  The result stays RESIDENT and is the F_extra of
+ * every following raftx_solve_dynamics[_device] call that passes F_extra == NULL (until designs or cases are
+ * re-uploaded); F_out (optional) receives a host copy. */
+int raftx_bem_excitation(raftx_ctx *ctx, int nHeadBEM, const double *headings_deg, const raftx_c128 *X_BEM,
+                         const double *heading_adjust, const double *xy_ref, const raftx_c128 *F_add,
+                         raftx_c128 *F_out);
+
 /* Response statistics of the resident results of the last raftx_solve_dynamics_device -- the motion
  * block of FOWT.saveTurbineOutputs (raft/raft_fowt.py:2310-2357) with getRMS / getPSD
  * (raft/helpers.py:678-700), for rigid units whose reduced DOFs are the platform reference point:

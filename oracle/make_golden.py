@@ -317,6 +317,66 @@ def fixture_c5_oc4():
     standin.save_fixture(os.path.join(GOLD, "c5_oc4semi_qtf.npz"), fx)
 
 
+def synth_bem_files(stem):
+    """A small synthetic WAMIT .1/.3 pair (smooth analytic coefficients, 24 periods, 5 headings, the zero- and
+    infinite-frequency sets first) written with raft_amd/bem.py; committed under tests/golden/bem/."""
+    from raft_amd import bem
+    w = np.linspace(0.1, 2.4, 24)
+    dg = np.array([8.0e3, 8.0e3, 2.5e2, 9.0e6, 9.0e6, 1.2e3])
+    A = np.zeros((6, 6, len(w)))
+    B = np.zeros((6, 6, len(w)))
+    for i, wi in enumerate(w):
+        A[:, :, i] = np.diag(dg * (1 + 0.3 * np.cos(1.3 * wi)))
+        A[0, 4, i] = A[4, 0, i] = -2.0e5 * (1 + 0.2 * np.sin(wi))
+        A[1, 3, i] = A[3, 1, i] = 2.0e5 * (1 + 0.2 * np.sin(wi))
+        B[:, :, i] = np.diag(dg * 0.4 * wi * np.exp(-1.1 * wi))
+        B[0, 4, i] = B[4, 0, i] = -3.0e4 * wi * np.exp(-wi)
+        B[1, 3, i] = B[3, 1, i] = 3.0e4 * wi * np.exp(-wi)
+    A0 = np.diag(dg * 1.3)
+    Ainf = np.diag(dg * 0.8)
+    heads = [0.0, 45.0, 90.0, 180.0, 270.0]
+    X = np.zeros((len(heads), 6, len(w)), dtype=complex)
+    amp = np.array([60.0, 25.0, 90.0, 700.0, 900.0, 40.0])
+    for ih, h in enumerate(heads):
+        for j in range(6):
+            X[ih, j] = amp[j] * (1 + 0.2 * np.cos(np.radians(h) + j)) * np.exp(-0.8 * w) * \
+                       np.exp(1j * (0.5 * j + 0.9 * w + 0.3 * np.sin(np.radians(h))))
+    os.makedirs(os.path.dirname(stem), exist_ok=True)
+    bem.write_wamit1(stem + ".1", w, A, B, A0=A0, Ainf=Ainf)
+    bem.write_wamit3(stem + ".3", w, heads, X)
+    return w, A, B, A0, Ainf, heads, X
+
+
+def fixture_bem():
+    """Potential-flow deck: OC3spar with potModMaster = 3 and pre-computed first-order
+    coefficients (potFirstOrder = 1) read from the synthetic WAMIT pair.  The LIVE reference's readHydro runs on top of
+    raft_amd/bem.py's parsers (pyhams stub), then its own BEM-excitation block with heading interpolation
+    (raft_fowt.py:1796-1849) and solveDynamics with frequency-dependent A_BEM / B_BEM."""
+    stem = os.path.join(GOLD, "bem", "synth")
+    synth_bem_files(stem)
+    d = rh.prepare_design(rh.load_design(os.path.join(REF, "designs/OC3spar.yaml")),
+                          settings=dict(min_freq=0.01, max_freq=0.3, nIter=10, XiStart=0.1))
+    d["platform"]["potModMaster"] = 3
+    d["platform"]["potFirstOrder"] = 1
+    d["platform"]["hydroPath"] = stem
+    m = rh.build_model(d)
+    f = m.fowtList[0]
+    assert np.any(f.A_BEM) and np.any(f.B_BEM) and f.X_BEM.shape[0] == 5
+    cases = [rh.make_case(Hs=5.0, Tp=10.0, heading=30.0),
+             dict(rh.make_case(Hs=3.0, Tp=8.0, heading=-70.0), wave_heading=[-70.0, 200.0], wave_spectrum=["JONSWAP"] * 2,
+                  wave_period=[8.0, 13.0], wave_height=[3.0, 1.5], wave_gamma=[0, 0]),
+             rh.make_case(Hs=4.0, Tp=9.0, heading=300.0)]          # beyond the last BEM heading: wraps around 360
+    runs = []
+    for c in cases:
+        r = run_case(m, c)
+        r["units"][0]["F_BEM"] = np.array(f.F_BEM)
+        runs.append(r)
+    fx = {"config": "OC3spar + synthetic WAMIT .1/.3 (potModMaster 3, potFirstOrder 1)", "model": standin.snapshot_model(m),
+          "A_BEM": np.array(f.A_BEM), "B_BEM": np.array(f.B_BEM), "X_BEM": np.array(f.X_BEM),
+          "BEM_headings": np.array(f.BEM_headings), "cases": runs}
+    standin.save_fixture(os.path.join(GOLD, "bem_oc3spar.npz"), fx)
+
+
 def _design_subset(design):
     """JSON of the parts of a design dict the member descriptors are parsed from (taken BEFORE the reference
     mutates the dict)."""
@@ -415,7 +475,7 @@ def fixture_geom():
     standin.save_fixture(os.path.join(GOLD, "geom_units.npz"), fx)
 
 
-ALL = {"geom": fixture_geom, "c5oc4": fixture_c5_oc4, "c5": fixture_c5, "qtf": fixture_qtf, "c1": fixture_c1, "c2": fixture_c2, "pose": fixture_pose,
+ALL = {"bem": fixture_bem, "geom": fixture_geom, "c5oc4": fixture_c5_oc4, "c5": fixture_c5, "qtf": fixture_qtf, "c1": fixture_c1, "c2": fixture_c2, "pose": fixture_pose,
        "refgold": fixture_ref_goldens, "c4": fixture_c4, "c3": fixture_c3}
 
 if __name__ == "__main__":

@@ -51,6 +51,17 @@ def install_stubs():
         cc.ccblade = ccc
         sys.modules["ccblade"] = cc
         sys.modules["ccblade.ccblade"] = ccc
+    if "pyhams" not in sys.modules:
+        # pyHAMS (un-vendored, absent) is only asked for its two WAMIT-file readers by FOWT.readHydro
+        # (raft_fowt.py:1452-1456): raft_amd/bem.py provides them, so the REFERENCE's readHydro / BEM excitation run
+        # unmodified on top of our parsers (the parsers themselves stay "parity unpinned", see raft_amd/bem.py)
+        from raft_amd import bem
+        ph = types.ModuleType("pyhams")
+        php = types.ModuleType("pyhams.pyhams")
+        php.read_wamit1, php.read_wamit3 = bem.read_wamit1, bem.read_wamit3
+        ph.pyhams = php
+        sys.modules["pyhams"] = ph
+        sys.modules["pyhams.pyhams"] = php
     if REFERENCE_ROOT not in sys.path:
         sys.path.insert(0, REFERENCE_ROOT)
 

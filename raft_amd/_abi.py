@@ -25,7 +25,7 @@ EXPORTS = (
     "raftx_excitation", "raftx_linearize", "raftx_solve_dynamics",
     "raftx_solve_system", "raftx_last_kernel_ms",
     "raftx_solve_dynamics_device", "raftx_fetch_results", "raftx_debug_math", "raftx_motion_stats", "raftx_solve_system_resident", "raftx_qtf_slender", "raftx_channel_stats", "raftx_qtf_force", "raftx_set_linearisation_point", "raftx_fetch_linearisation_point",
-    "raftx_build_designs", "raftx_fetch_strips", "raftx_fetch_statics", "raftx_channel_stats_poly", "raftx_qtf_slender_rows",
+    "raftx_build_designs", "raftx_fetch_strips", "raftx_fetch_statics", "raftx_channel_stats_poly", "raftx_qtf_slender_rows", "raftx_bem_excitation",
 )
 WANT_BDRAG, WANT_FWAVE, WANT_Z = 1, 2, 4
 
@@ -106,6 +106,8 @@ class RaftxLib:
         L.raftx_qtf_force.restype = C.c_int
         L.raftx_channel_stats.argtypes = [_vp, C.c_int, _vp, _vp, C.c_double, _vp, _vp]
         L.raftx_channel_stats.restype = C.c_int
+        L.raftx_bem_excitation.argtypes = [_vp, C.c_int, _vp, _vp, _vp, _vp, _vp, _vp]
+        L.raftx_bem_excitation.restype = C.c_int
         L.raftx_channel_stats_poly.argtypes = [_vp, C.c_int, _vp, _vp, C.c_double, _vp, _vp]
         L.raftx_channel_stats_poly.restype = C.c_int
         L.raftx_motion_stats.argtypes = [_vp, C.c_double, _vp, _vp]
@@ -417,6 +419,22 @@ class Context:
         rc = self.rlib.lib.raftx_channel_stats(self._h, nCh, _ptr(L), _ptr(pw), float(dw), _ptr(std), _ptr(psd))
         self._check(rc, "raftx_channel_stats")
         return std, psd
+
+    def bem_excitation(self, headings_deg, X_BEM, heading_adjust=None, xy_ref=None, F_add=None, fetch=False):
+        """Potential-flow excitation with heading interpolation for every (design, case, heading) of the uploaded
+        designs / sea states (raftx_bem_excitation); stays resident as the F_extra of the following solves.
+        X_BEM [nDesign,nHeadBEM,6,nw] (wave-heading frame, per unit amplitude)."""
+        heads = _f64(headings_deg)
+        nHB = len(heads)
+        X = _c128(X_BEM, (self.nDesign, nHB, 6, self.nw), "X_BEM")
+        ha = None if heading_adjust is None else _f64(heading_adjust, (self.nDesign,), "heading_adjust")
+        xy = None if xy_ref is None else _f64(xy_ref, (self.nDesign, 2), "xy_ref")
+        shape = (self.nDesign, self.nCase, self.nHead, 6, self.nw)
+        Fa = None if F_add is None else _c128(F_add, shape, "F_add")
+        out = np.empty(shape, dtype=np.complex128) if fetch else None
+        rc = self.rlib.lib.raftx_bem_excitation(self._h, nHB, _ptr(heads), _ptr(X), _ptr(ha), _ptr(xy), _ptr(Fa), _ptr(out))
+        self._check(rc, "raftx_bem_excitation")
+        return out
 
     def channel_stats_poly(self, L, dw, Gw=None, want_psd=False):
         """std [nDesign,nCase,nChan] (and PSD) of y_c = sum_p (i w)^p L[d,c,p,:] . Xi + Gw[d,c,:,w] . Xi of the resident

@@ -205,6 +205,69 @@ __global__ void __launch_bounds__(256) k_channel_stats(int nCase, int nHead, int
     }
 }
 
+// BEM excitation with heading interpolation (raft_fowt.py:1796-1849): one workgroup per (pair, heading), lanes over w
+__global__ void __launch_bounds__(256) k_bem_excitation(DevTables T, int nHB, const double *__restrict__ heads,
+                                                        const cplx *__restrict__ X, const double *__restrict__ hadj,
+                                                        const double *__restrict__ xy, const cplx *__restrict__ Fadd,
+                                                        cplx *__restrict__ F) {
+    const int ih = blockIdx.x % T.nHead, p = blockIdx.x / T.nHead;
+    const int d = p / T.nCase, ic = p % T.nCase;
+    const double beta = T.beta[(size_t)ic * T.nHead + ih];
+    double bdeg = fmod(beta * (180.0 / M_PI) - (hadj ? hadj[d] : 0.0), 360.0);        // Python's % : result in [0, 360)
+    if (bdeg < 0.0) bdeg += 360.0;
+    int i1 = nHB - 1, i2 = 0;
+    double f2;
+    if (bdeg <= heads[0]) {
+        const double hlast = heads[nHB - 1] - 360.0;
+        f2 = (bdeg - hlast) / (heads[0] - hlast);
+    } else if (bdeg >= heads[nHB - 1]) {
+        const double hfirst = heads[0] + 360.0;
+        f2 = (bdeg - heads[nHB - 1]) / (hfirst - heads[nHB - 1]);
+    } else {
+        f2 = 0.0;
+        for (int i = 0; i < nHB - 1; i++)
+            if (heads[i + 1] > bdeg) {
+                i1 = i;
+                i2 = i + 1;
+                f2 = (bdeg - heads[i]) / (heads[i + 1] - heads[i]);
+                break;
+            }
+    }
+    const double f1 = 1.0 - f2, sb = sin(beta), cb = cos(beta);
+    const double xr = xy ? xy[2 * d] : 0.0, yr = xy ? xy[2 * d + 1] : 0.0;
+    const cplx *X1 = X + ((size_t)d * nHB + i1) * 6 * T.nw, *X2 = X + ((size_t)d * nHB + i2) * 6 * T.nw;
+    const size_t base = ((size_t)p * T.nHead + ih) * 6 * T.nw;
+    for (int i = threadIdx.x; i < T.nw; i += blockDim.x) {
+        cplx xp[6];
+#pragma unroll
+        for (int j = 0; j < 6; j++) {
+            const cplx a = X1[(size_t)j * T.nw + i], b = X2[(size_t)j * T.nw + i];
+            xp[j] = {a.re * f1 + b.re * f2, a.im * f1 + b.im * f2};
+        }
+        cplx g[6];
+        g[0] = {xp[0].re * cb - xp[1].re * sb, xp[0].im * cb - xp[1].im * sb};
+        g[1] = {xp[0].re * sb + xp[1].re * cb, xp[0].im * sb + xp[1].im * cb};
+        g[2] = xp[2];
+        g[3] = {xp[3].re * cb - xp[4].re * sb, xp[3].im * cb - xp[4].im * sb};
+        g[4] = {xp[3].re * sb + xp[4].re * cb, xp[3].im * sb + xp[4].im * cb};
+        g[5] = xp[5];
+        double ps, pc;
+        sincos(-(T.k[i] * (xr * cos(beta) + yr * sin(beta))), &ps, &pc);
+        const double z = T.zeta[((size_t)ic * T.nHead + ih) * T.nw + i];
+#pragma unroll
+        for (int j = 0; j < 6; j++) {
+            const double gr = g[j].re * z, gi = g[j].im * z;
+            cplx o = {gr * pc - gi * ps, gr * ps + gi * pc};
+            if (Fadd) {
+                const cplx a = Fadd[base + (size_t)j * T.nw + i];
+                o.re += a.re;
+                o.im += a.im;
+            }
+            F[base + (size_t)j * T.nw + i] = o;
+        }
+    }
+}
+
 // y_c = sum_p (i w)^p sum_j L[c,p,j] Xi_j + sum_j Gw[c,j,w] Xi_j  (tower-base moment: weight p=0, inertial reaction
 // p=2, complex aero reaction through Gw; raft_fowt.py:2500-2537)
 __global__ void __launch_bounds__(256) k_channel_stats_poly(int nCase, int nHead, int nw, int nChan, double inv_dw,
@@ -280,6 +343,9 @@ struct raftx_ctx {
     double last_ms;
     bool have_designs, have_cases;
     int nw_designs;
+    cplx *bemF;                          // resident BEM (+ added) excitation of raftx_bem_excitation [npair,nHead,6,nw]
+    size_t bemF_n;
+    bool bem_ready;
     // results of the last raftx_build_designs (device pointers owned by design_allocs)
     int g_n;
     size_t g_nStrips, g_nRows;
@@ -323,6 +389,9 @@ extern "C" int raftx_ctx_create(int device_id, raftx_ctx **out) {
     c->have_designs = c->have_cases = false;
     c->nw_designs = 0;
     c->g_n = 0;
+    c->bemF = nullptr;
+    c->bemF_n = 0;
+    c->bem_ready = false;
     c->rXi = c->rFw = c->rZ = c->rFe = nullptr;
     c->rB = c->rXl = nullptr;
     c->rXl_n = 0;
@@ -362,6 +431,7 @@ extern "C" void raftx_ctx_destroy(raftx_ctx *c) {
     if (c->rXl0) (void)hipFree(c->rXl0);
     if (c->rXlOut) (void)hipFree(c->rXlOut);
     if (c->rQtf) (void)hipFree(c->rQtf);
+    if (c->bemF) (void)hipFree(c->bemF);
     (void)hipEventDestroy(c->ev0);
     (void)hipEventDestroy(c->ev1);
     (void)hipStreamDestroy(c->stream);
@@ -393,6 +463,7 @@ extern "C" int raftx_upload_designs(raftx_ctx *c, int nDesign, const int64_t *st
     HIPCHK(c, hipStreamSynchronize(c->stream));
     free_list(c->design_allocs);
     c->have_designs = false;
+    c->bem_ready = false;
     int maxS = 0;
     for (int d = 0; d < nDesign; d++) {
         int64_t S = stripOffsets[d + 1] - stripOffsets[d];
@@ -475,6 +546,7 @@ extern "C" int raftx_build_designs(raftx_ctx *c, int nDesign, const int64_t *mem
     HIPCHK(c, hipStreamSynchronize(c->stream));
     free_list(c->design_allocs);
     c->have_designs = false;
+    c->bem_ready = false;
     c->g_n = 0;
     std::vector<void *> tmp;                       // descriptor uploads and per-member scratch, freed on return
     struct Guard { std::vector<void *> &v; ~Guard() { free_list(v); } } guard{tmp};
@@ -618,6 +690,7 @@ extern "C" int raftx_upload_cases(raftx_ctx *c, int nCase, int nHead, int nw, co
     HIPCHK(c, hipStreamSynchronize(c->stream));
     free_list(c->case_allocs);
     c->have_cases = false;
+    c->bem_ready = false;
     // per-bin depth constants, computed once on the host in full libm precision.  The kernels derive
     // the depth regime (k == 0 / deep / finite) from k themselves, with the same rule.
     std::vector<double> csh(nw), cch(nw);
@@ -665,7 +738,10 @@ extern "C" int raftx_upload_cases(raftx_ctx *c, int nCase, int nHead, int nw, co
 struct Shape {
     int nb, threads;
 };
-#define SHAPES(X) X(1, 64, 1) X(2, 64, 1) X(4, 64, 1) X(2, 128, 2) X(1, 256, 2) X(2, 256, 2) X(2, 512, 1) X(3, 512, 1) X(4, 512, 1)
+#ifndef RAFTX_MINB128
+#define RAFTX_MINB128 2          // waves per SIMD the default 200-bin shape is compiled for (tuning builds override)
+#endif
+#define SHAPES(X) X(1, 64, 1) X(2, 64, 1) X(4, 64, 1) X(2, 128, RAFTX_MINB128) X(1, 256, 2) X(2, 256, 2) X(2, 512, 1) X(3, 512, 1) X(4, 512, 1)
 // MAXT template value of the kernel instantiated for a shape
 static int shape_maxt(Shape sh) {
 #define X(NB_, MT_, MB_) if (sh.nb == NB_ && sh.threads == MT_) return MT_;
@@ -861,7 +937,7 @@ extern "C" int raftx_solve_dynamics_device(raftx_ctx *c, int nIter, double tol, 
     A.nIter = nIter + 1;
     A.tol = tol;
     A.XiStart = XiStart;
-    A.F_extra = F_extra ? c->rFe : nullptr;
+    A.F_extra = F_extra ? c->rFe : (c->bem_ready ? c->bemF : nullptr);
     A.Xi = c->rXi;
     A.niter = c->rNi;
     A.flags = c->rFl;
@@ -1000,6 +1076,52 @@ extern "C" int raftx_solve_dynamics(raftx_ctx *c, int nIter, double tol, double 
     int rc = raftx_solve_dynamics_device(c, nIter, tol, XiStart, F_extra, mask);
     if (rc) return rc;
     return raftx_fetch_results(c, Xi, niter, flags, B_drag, F_wave, Z);
+}
+
+extern "C" int raftx_bem_excitation(raftx_ctx *c, int nHeadBEM, const double *headings_deg, const raftx_c128 *X_BEM,
+                                    const double *heading_adjust, const double *xy_ref, const raftx_c128 *F_add,
+                                    raftx_c128 *F_out) {
+    if (check_ready(c)) return -1;
+    if (nHeadBEM < 1 || !headings_deg || !X_BEM) FAIL(c, "bem_excitation: bad arguments");
+    for (int i = 0; i < nHeadBEM; i++)
+        if (!(headings_deg[i] >= 0.0 && headings_deg[i] < 360.0) || (i && !(headings_deg[i] > headings_deg[i - 1])))
+            FAIL(c, "bem_excitation: headings must be ascending in [0, 360)");
+    HIPCHK(c, hipSetDevice(c->device));
+    const DevTables &T = c->T;
+    const size_t npair = (size_t)T.nDesign * T.nCase, nx = npair * T.nHead * 6 * T.nw;
+    const size_t nX = (size_t)T.nDesign * nHeadBEM * 6 * T.nw;
+    c->bem_ready = false;
+    if (c->bemF_n < nx || !c->bemF) {
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        if (c->bemF) (void)hipFree(c->bemF);
+        c->bemF = nullptr;
+        void *p_ = nullptr;
+        HIPCHK(c, hipMalloc(&p_, (nx ? nx : 1) * sizeof(cplx)));
+        c->bemF = reinterpret_cast<cplx *>(p_);
+        c->bemF_n = nx;
+    }
+    Scratch sc(c);
+    double *dH = sc.alloc<double>(nHeadBEM), *dA = heading_adjust ? sc.alloc<double>(T.nDesign) : nullptr,
+           *dXY = xy_ref ? sc.alloc<double>((size_t)T.nDesign * 2) : nullptr;
+    cplx *dX = sc.alloc<cplx>(nX), *dAdd = F_add ? sc.alloc<cplx>(nx) : nullptr;
+    if (nx && (!dH || !dX || (heading_adjust && !dA) || (xy_ref && !dXY) || (F_add && !dAdd)))
+        FAIL(c, "bem_excitation: device allocation failed");
+    if (nx) {
+        H2D(c, dH, headings_deg, nHeadBEM * sizeof(double));
+        H2D(c, dX, X_BEM, nX * sizeof(cplx));
+        if (dA) H2D(c, dA, heading_adjust, T.nDesign * sizeof(double));
+        if (dXY) H2D(c, dXY, xy_ref, (size_t)T.nDesign * 2 * sizeof(double));
+        if (dAdd) H2D(c, dAdd, F_add, nx * sizeof(cplx));
+    }
+    HIPCHK(c, hipEventRecord(c->ev0, c->stream));
+    if (nx)
+        hipLaunchKernelGGL(k_bem_excitation, dim3((unsigned)(npair * T.nHead)), dim3(T.nw > 128 ? 256 : (T.nw > 64 ? 128 : 64)), 0,
+                           c->stream, T, nHeadBEM, dH, dX, dA, dXY, dAdd, c->bemF);
+    if (finish_timed(c)) return -2;
+    if (nx && F_out) D2H(c, F_out, c->bemF, nx * sizeof(cplx));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    c->bem_ready = true;
+    return 0;
 }
 
 extern "C" int raftx_motion_stats(raftx_ctx *c, double dw, double *sd, double *psd) {

@@ -93,6 +93,31 @@ class Sweep:
             cm = np.concatenate([t.cm_mcf for t in tables if t.cm_mcf is not None], axis=0)
         return cls(off, strips, M0, B0, C0, w, k, depth, zeta, beta, nIter, XiStart, tol, MBw, cmoff, cm)
 
+    # ------------------------------------------------------------------ potential-flow excitation
+    def set_bem(self, headings_deg, X_BEM, heading_adjust=None, xy_ref=None):
+        """Potential-flow excitation coefficients of the designs, X_BEM [nD,nHeadBEM,6,nw] in the wave-heading frame as
+        FOWT.readHydro leaves them (raft_amd/bem.py read_hydro): ``upload`` then evaluates F_BEM for every (design,
+        case, heading) on the device (raftx_bem_excitation, raft_fowt.py:1796-1849) and the solves use it as their
+        F_extra -- nothing of size nCase x nHead x 6 x nw is built or uploaded by the host.  The frequency-dependent
+        A_BEM / B_BEM enter through MBw."""
+        self.bem = dict(heads=np.ascontiguousarray(headings_deg, dtype=np.float64),
+                        X=np.ascontiguousarray(X_BEM, dtype=np.complex128),
+                        hadj=None if heading_adjust is None else np.ascontiguousarray(heading_adjust, dtype=np.float64),
+                        xy=None if xy_ref is None else np.ascontiguousarray(xy_ref, dtype=np.float64))
+        return self
+
+    def _take_bem(self, dst, lo, hi):
+        b = getattr(self, "bem", None)
+        if b is not None:
+            dst.bem = dict(heads=b["heads"], X=b["X"][lo:hi], hadj=None if b["hadj"] is None else b["hadj"][lo:hi],
+                           xy=None if b["xy"] is None else b["xy"][lo:hi])
+        return dst
+
+    def _upload_bem(self, ctx):
+        b = getattr(self, "bem", None)
+        if b is not None:
+            ctx.bem_excitation(b["heads"], b["X"], b["hadj"], b["xy"])
+
     # ------------------------------------------------------------------ sharding
     def take(self, lo, hi):
         """The sub-sweep of designs [lo, hi) (all cases)."""
@@ -101,9 +126,9 @@ class Sweep:
         if self.cm is not None:
             c0, c1 = self.cmoff[lo], self.cmoff[hi]
             cmoff, cm = self.cmoff[lo:hi + 1] - c0, self.cm[c0:c1]
-        return Sweep(self.off[lo:hi + 1] - s0, self.strips[s0:s1], self.M0[lo:hi], self.B0[lo:hi], self.C0[lo:hi],
-                     self.w, self.k, self.depth, self.zeta, self.beta, self.nIter, self.XiStart, self.tol,
-                     None if self.MBw is None else self.MBw[lo:hi], cmoff, cm, self.rho, self.g)
+        return self._take_bem(Sweep(self.off[lo:hi + 1] - s0, self.strips[s0:s1], self.M0[lo:hi], self.B0[lo:hi], self.C0[lo:hi],
+                                    self.w, self.k, self.depth, self.zeta, self.beta, self.nIter, self.XiStart, self.tol,
+                                    None if self.MBw is None else self.MBw[lo:hi], cmoff, cm, self.rho, self.g), lo, hi)
 
     def shard(self, rank, world):
         return self.take(*shard_bounds(self.n_design, rank, world))
@@ -120,6 +145,7 @@ class Sweep:
     def upload(self, ctx):
         ctx.upload_designs_raw(self.off, self.strips, self.M0, self.B0, self.C0, self.nw, self.MBw, self.cmoff, self.cm)
         ctx.upload_cases(self.w, self.k, self.depth, self.rho, self.g, self.zeta, self.beta)
+        self._upload_bem(ctx)
 
     def solve(self, ctx, upload=True):
         """One launch over every (design, case) of this sweep; results stay on the device until fetched."""
@@ -240,10 +266,10 @@ class GeometrySweep(Sweep):
         return self.tables.n_design
 
     def take(self, lo, hi):
-        return GeometrySweep(self.tables.take(lo, hi), self.M0[lo:hi], self.B0[lo:hi], self.C0[lo:hi], self.w, self.k,
-                             self.depth, self.zeta, self.beta, self.nIter, self.XiStart, self.tol,
-                             None if self.pose is None else self.pose[lo:hi], self.add_mask,
-                             None if self.MBw is None else self.MBw[lo:hi], self.rho, self.g)
+        return self._take_bem(GeometrySweep(self.tables.take(lo, hi), self.M0[lo:hi], self.B0[lo:hi], self.C0[lo:hi], self.w,
+                                            self.k, self.depth, self.zeta, self.beta, self.nIter, self.XiStart, self.tol,
+                                            None if self.pose is None else self.pose[lo:hi], self.add_mask,
+                                            None if self.MBw is None else self.MBw[lo:hi], self.rho, self.g), lo, hi)
 
     def upload(self, ctx):
         t = self.tables
@@ -251,6 +277,7 @@ class GeometrySweep(Sweep):
                                      pose=self.pose, rho=self.rho, g=self.g, k=self.k, add_mask=self.add_mask, MBw=self.MBw,
                                      cap_off=t.cap_off, caps=t.caps)
         ctx.upload_cases(self.w, self.k, self.depth, self.rho, self.g, self.zeta, self.beta)
+        self._upload_bem(ctx)
 
 
 # ---------------------------------------------------------------------- multi-GPU driver

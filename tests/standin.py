@@ -58,6 +58,9 @@ def snapshot_fowt(fowt):
             d[a] = np.array(v, dtype=float)
         else:
             d[a + "_zero_shape"] = np.array(v.shape, dtype=np.int64)
+    if hasattr(fowt, "X_BEM"):
+        d["X_BEM"] = np.array(fowt.X_BEM, dtype=complex)
+        d["BEM_headings"] = np.array(fowt.BEM_headings, dtype=float)
     if getattr(fowt, "potSecOrder", 0) == 1:
         d["w1_2nd"] = np.array(fowt.w1_2nd, dtype=float)
         d["k1_2nd"] = np.array(fowt.k1_2nd, dtype=float)
@@ -150,6 +153,8 @@ def build_fowt(d):
             setattr(f, a, d[a])
         else:
             setattr(f, a, np.zeros(tuple(int(x) for x in d[a + "_zero_shape"])))
+    if "X_BEM" in d:
+        f.X_BEM, f.BEM_headings = d["X_BEM"], d["BEM_headings"]
     if "w1_2nd" in d:
         f.w1_2nd, f.k1_2nd = d["w1_2nd"], d["k1_2nd"]
     f.memberList = [build_member(m) for m in d["members"]]
