@@ -246,6 +246,17 @@ def main():
     ctx.solve_dynamics_device(sw["nIter"], 0.01, sw["XiStart"])
     ctx.fetch_results(want_Xi=True)
     pcie_rate = args.designs * nw / (time.perf_counter() - t0)
+    # ... and of the optimiser-style crossing: descriptors in, response statistics out (no 19 KB/design-case download)
+    t0 = time.perf_counter()
+    if args.tiled:
+        ctx.upload_designs_raw(sw["off"], sw["strips"], sw["M0"], sw["B0"], sw["C0"], nw)
+    else:
+        sw["rebuild"]()
+    ctx.upload_cases(sw["w"], sw["k"], sw["depth"], 1025.0, 9.81, sw["zeta"][None], sw["beta"][None])
+    ctx.solve_dynamics_device(sw["nIter"], 0.01, sw["XiStart"])
+    ctx.motion_stats(float(sw["w"][1] - sw["w"][0]))
+    ctx.fetch_results(want_Xi=False)
+    stats_rate = args.designs * nw / (time.perf_counter() - t0)
 
     n_dcf_rank = args.designs * 1 * nw
     total_dcf = n_dcf_rank * world * args.steps
@@ -268,6 +279,7 @@ def main():
                                    "distinct variants, strip tables + statics generated on the device (raftx_build_designs)"},
         "rao_max_rel_err_vs_reference": max_err,
         "pcie_inclusive_dcf_per_s_per_gpu": pcie_rate,
+        "pcie_inclusive_stats_only_dcf_per_s_per_gpu": stats_rate,
         "mean_iterations": float(np.mean(niter)),
         "roofline": {"bound": "hbm", "achieved": A / (k_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": A / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": measured_traffic(args.designs),
