@@ -456,6 +456,29 @@ def fixture_geom():
     scales = rng.uniform(0.75, 1.25, size=(3, 5))
     for i in range(3):
         add("C3", volturnus_variant(base, scales[i]), label="C3-variant-%d" % i)
+    # a synthetic platform that exercises what the shipped decks do not: a tapered, twisted, inclined RECTANGULAR member
+    # repeated over headings with a bottom cap and partial ballast; a tapered circular column with ballast, a ring
+    # bulkhead in mid-section and a top cap; per-station coefficient variation; a potMod member; a surface-piercing
+    # inclined brace -- at a heeled pose
+    t = copy.deepcopy(rh.prepare_design(rh.load_design(os.path.join(REF, "designs/OC3spar.yaml"))))
+    t["platform"]["members"] = [
+        dict(name="col", type="rigid", rA=[0, 0, -30], rB=[0, 0, 12], shape="circ", gamma=0.0, potMod=False,
+             stations=[0, 10, 25, 42], d=[14.0, 14.0, 9.0, 7.5], t=[0.05, 0.05, 0.04, 0.03], l_fill=[8.0, 5.0, 0.0],
+             rho_fill=[1800.0, 1025.0, 0.0], rho_shell=7850, Cd=[0.8, 0.7, 0.6, 0.6], Ca=[1.0, 0.95, 0.9, 0.9],
+             CdEnd=0.7, CaEnd=0.65, Cd_q=0.05, Ca_q=0.0, cap_stations=[0, 17, 42], cap_t=[0.08, 0.05, 0.04],
+             cap_d_in=[0, 4.0, 0], dlsMax=3.0),
+        dict(name="arm", type="rigid", rA=[6, 0, -26], rB=[38, 4, -18], shape="rect", gamma=25.0, potMod=False,
+             heading=[0, 120, 240], stations=[0, 1], d=[[9.0, 5.0], [6.0, 3.5]], t=0.04, l_fill=[0.35], rho_fill=[1025.0],
+             rho_shell=7850, Cd=[1.4, 1.9], Ca=[1.1, 2.0], CdEnd=1.0, CaEnd=0.8, cap_stations=[0], cap_t=[0.06],
+             cap_d_in=[[0, 0]], dlsMax=4.0),
+        dict(name="brace", type="rigid", rA=[36, 0, -17], rB=[10, 0, 9], shape="circ", gamma=0.0, potMod=False,
+             heading=[0, 120, 240], stations=[0, 1], d=2.2, t=0.025, rho_shell=7850, Cd=0.9, Ca=1.0, CdEnd=0.6, CaEnd=0.6,
+             dlsMax=2.5),
+        dict(name="skirt", type="rigid", rA=[0, 0, -31.5], rB=[0, 0, -30], shape="circ", gamma=0.0, potMod=True,
+             stations=[0, 1], d=22.0, t=0.05, rho_shell=7850, Cd=2.0, Ca=1.0, CdEnd=2.5, CaEnd=1.2),
+    ]
+    add("synthetic", t, r6=[2.0, -1.0, 0.4, 0.06, -0.04, 0.3], label="synthetic@heel")
+    add("synthetic", t, label="synthetic")
     # farm units: heading_adjust + array offsets
     d = rh.prepare_design(rh.load_design(os.path.join(REF, "designs/VolturnUS-S_farm.yaml")),
                           settings=dict(min_freq=0.002, max_freq=0.2))
