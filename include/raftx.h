@@ -232,6 +232,21 @@ int raftx_qtf_slender(raftx_ctx *ctx, int nSet, int nw2, const double *w2, const
                       const raftx_c128 *Xi, const double *beta, const double *Mstruc,
                       const raftx_c128 *kay, raftx_c128 *qtf);
 
+/* Kim & Yue second-order diffraction correction of the MacCamy-Fuchs members on the device --
+ * Member.correction_KAY, raft/raft_member.py:1676-1791 -- for nSet sets on the grid w2,k2 [nw2]:
+ *   waterline term  F = Re( sum_{n=0..Nm} -rho g R 2i/(pi k1R k2R) Omega_n ) e^{-i (k1-k2)(x cosB + y sinB)},
+ *   segment terms   the same sum weighted by the depth integrals I-, I+ of :1757-1779,
+ *   Omega_n = 1/(H'_{n+1}(k1R) conj H'_n(k2R)) - 1/(H'_n(k1R) conj H'_{n+1}(k2R)),  H'_n = (H_{n-1} - H_{n+1})/2,
+ * each applied along the member's unit force direction at its moment arm, conjugated where k1 < k2 (:1787-1788);
+ * upper triangle (w2 >= w1) only, like the host table it replaces.
+ * items [itemOff[nSet], RAFTX_QK_N]: records of raft_amd/qtf.py kay_items (R, kind, z1, z2, arm, pforce, phase x y);
+ * beta [nSet] rad.  The table [nSet,nw2,nw2,6] stays resident and is CONSUMED by the next raftx_qtf_slender[_rows]
+ * call on this ctx that passes kay == NULL with the same nSet, nw2 (one-shot); kay_out (optional) receives a copy. */
+#define RAFTX_QK_N 12
+int raftx_qtf_kay(raftx_ctx *ctx, int nSet, int nw2, const double *w2, const double *k2, double depth, double rho,
+                  double g, const int64_t *itemOff, const double *items, const double *beta, int Nm,
+                  raftx_c128 *kay_out);
+
 /* One QTF shared by several ranks: the same call restricted to the rows w1 = w2[row_off + m*row_stride] (and their
  * Hermitian mirrors); every other entry of qtf is returned as 0, so the partial results of row_stride ranks SUM to the
  * full matrix.  Rows are interleaved because their cost is triangular (row i1 holds nw2 - i1 pairs). */

@@ -25,7 +25,7 @@ EXPORTS = (
     "raftx_excitation", "raftx_linearize", "raftx_solve_dynamics",
     "raftx_solve_system", "raftx_last_kernel_ms",
     "raftx_solve_dynamics_device", "raftx_fetch_results", "raftx_debug_math", "raftx_motion_stats", "raftx_solve_system_resident", "raftx_qtf_slender", "raftx_channel_stats", "raftx_qtf_force", "raftx_set_linearisation_point", "raftx_fetch_linearisation_point",
-    "raftx_build_designs", "raftx_fetch_strips", "raftx_fetch_statics", "raftx_channel_stats_poly", "raftx_qtf_slender_rows", "raftx_bem_excitation",
+    "raftx_build_designs", "raftx_fetch_strips", "raftx_fetch_statics", "raftx_channel_stats_poly", "raftx_qtf_slender_rows", "raftx_bem_excitation", "raftx_qtf_kay",
 )
 WANT_BDRAG, WANT_FWAVE, WANT_Z = 1, 2, 4
 
@@ -106,6 +106,8 @@ class RaftxLib:
         L.raftx_qtf_force.restype = C.c_int
         L.raftx_channel_stats.argtypes = [_vp, C.c_int, _vp, _vp, C.c_double, _vp, _vp]
         L.raftx_channel_stats.restype = C.c_int
+        L.raftx_qtf_kay.argtypes = [_vp, C.c_int, C.c_int, _vp, _vp, C.c_double, C.c_double, C.c_double, _vp, _vp, _vp, C.c_int, _vp]
+        L.raftx_qtf_kay.restype = C.c_int
         L.raftx_bem_excitation.argtypes = [_vp, C.c_int, _vp, _vp, _vp, _vp, _vp, _vp]
         L.raftx_bem_excitation.restype = C.c_int
         L.raftx_channel_stats_poly.argtypes = [_vp, C.c_int, _vp, _vp, C.c_double, _vp, _vp]
@@ -357,6 +359,26 @@ class Context:
                                            _ptr(f_mean), _ptr(f))
         self._check(rc, "raftx_qtf_force")
         return f_mean, f
+
+    def qtf_kay(self, tables, beta, w2, k2, depth, rho, g, Nm=10, fetch=False):
+        """Kim & Yue correction tables of the sets' MacCamy-Fuchs members on the device (raftx_qtf_kay); the result is
+        consumed by the next qtf_slender call that passes kay=None.  Returns the table [nSet,nw2,nw2,6] if fetch."""
+        from .qtf import kay_items, QK_N
+        nS = len(tables)
+        w2 = _f64(w2)
+        nw2 = len(w2)
+        k2 = _f64(k2, (nw2,), "k2")
+        beta = _f64(beta, (nS,), "beta")
+        items = [kay_items(t.kay_geom, float(b)) for t, b in zip(tables, beta)]
+        ioff = np.concatenate([[0], np.cumsum([len(i) for i in items])]).astype(np.int64)
+        flat = _f64(np.concatenate(items, axis=0)) if nS else np.zeros((0, QK_N))
+        if flat.size == 0:
+            flat = np.zeros((1, QK_N))
+        out = np.empty((nS, nw2, nw2, 6), dtype=np.complex128) if fetch else None
+        rc = self.rlib.lib.raftx_qtf_kay(self._h, nS, nw2, _ptr(w2), _ptr(k2), float(depth), float(rho), float(g),
+                                         _ptr(ioff), _ptr(flat), _ptr(beta), int(Nm), _ptr(out))
+        self._check(rc, "raftx_qtf_kay")
+        return out
 
     def qtf_slender(self, tables, Xi, beta, w2, k2, depth, rho, g, Mstruc, kay=None, fetch=True, rows=None):
         """Batch of slender-body QTFs: tables = list of raft_amd.qtf.QtfTable (one per set), Xi [nSet,6,nw2],

@@ -343,6 +343,10 @@ struct raftx_ctx {
     double last_ms;
     bool have_designs, have_cases;
     int nw_designs;
+    cplx *rKay;                          // Kim & Yue table of raftx_qtf_kay, consumed by the next raftx_qtf_slender call
+    size_t rKay_n;
+    int rKay_sets, rKay_nw2;
+    bool kay_ready;
     cplx *bemF;                          // resident BEM (+ added) excitation of raftx_bem_excitation [npair,nHead,6,nw]
     size_t bemF_n;
     bool bem_ready;
@@ -392,6 +396,10 @@ extern "C" int raftx_ctx_create(int device_id, raftx_ctx **out) {
     c->bemF = nullptr;
     c->bemF_n = 0;
     c->bem_ready = false;
+    c->rKay = nullptr;
+    c->rKay_n = 0;
+    c->rKay_sets = c->rKay_nw2 = 0;
+    c->kay_ready = false;
     c->rXi = c->rFw = c->rZ = c->rFe = nullptr;
     c->rB = c->rXl = nullptr;
     c->rXl_n = 0;
@@ -432,6 +440,7 @@ extern "C" void raftx_ctx_destroy(raftx_ctx *c) {
     if (c->rXlOut) (void)hipFree(c->rXlOut);
     if (c->rQtf) (void)hipFree(c->rQtf);
     if (c->bemF) (void)hipFree(c->bemF);
+    if (c->rKay) (void)hipFree(c->rKay);
     (void)hipEventDestroy(c->ev0);
     (void)hipEventDestroy(c->ev1);
     (void)hipStreamDestroy(c->stream);
@@ -1281,6 +1290,54 @@ extern "C" int raftx_solve_system_resident(raftx_ctx *c, int nUnit, const double
     return 0;
 }
 
+extern "C" int raftx_qtf_kay(raftx_ctx *c, int nSet, int nw2, const double *w2, const double *k2, double depth, double rho,
+                             double g, const int64_t *itemOff, const double *items, const double *beta, int Nm,
+                             raftx_c128 *kay_out) {
+    if (!c) return -1;
+    if (nSet < 0 || nw2 < 1 || !w2 || !k2 || !itemOff || !beta) FAIL(c, "qtf_kay: bad arguments");
+    if (Nm < 0 || Nm + 2 > KAY_MAXN) FAIL(c, "qtf_kay: Nm=%d outside 0..%d", Nm, KAY_MAXN - 2);
+    HIPCHK(c, hipSetDevice(c->device));
+    const size_t nItem = (size_t)itemOff[nSet], nq = (size_t)nSet * nw2 * nw2 * 6;
+    if (nItem && !items) FAIL(c, "qtf_kay: missing items");
+    c->kay_ready = false;
+    if (c->rKay_n < nq || !c->rKay) {
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        if (c->rKay) (void)hipFree(c->rKay);
+        c->rKay = nullptr;
+        void *p_ = nullptr;
+        HIPCHK(c, hipMalloc(&p_, (nq ? nq : 1) * sizeof(cplx)));
+        c->rKay = reinterpret_cast<cplx *>(p_);
+        c->rKay_n = nq;
+    }
+    Scratch sc(c);
+    double *dw = sc.alloc<double>(nw2), *dk = sc.alloc<double>(nw2), *dI = sc.alloc<double>(nItem * QK_N),
+           *dB = sc.alloc<double>(nSet);
+    int64_t *dio = sc.alloc<int64_t>(nSet + 1);
+    cplx *dH = sc.alloc<cplx>(nItem * KAY_MAXN * nw2);
+    if (nSet && (!dw || !dk || !dB || !dio || (nItem && (!dI || !dH)))) FAIL(c, "qtf_kay: device allocation failed");
+    if (nSet) {
+        H2D(c, dw, w2, nw2 * sizeof(double));
+        H2D(c, dk, k2, nw2 * sizeof(double));
+        H2D(c, dB, beta, nSet * sizeof(double));
+        H2D(c, dio, itemOff, (nSet + 1) * sizeof(int64_t));
+        if (nItem) H2D(c, dI, items, nItem * QK_N * sizeof(double));
+        HIPCHK(c, hipMemsetAsync(c->rKay, 0, nq * sizeof(cplx), c->stream));       // lower triangle stays zero
+    }
+    HIPCHK(c, hipEventRecord(c->ev0, c->stream));
+    if (nSet) {
+        if (nItem) hipLaunchKernelGGL(k_kay_tables, dim3((unsigned)nItem), dim3(128), 0, c->stream, nw2, Nm + 2, dk, dI, dH);
+        hipLaunchKernelGGL(k_kay_pairs, dim3((unsigned)((size_t)nSet * nw2)), dim3(nw2 > 64 ? 128 : 64), 0, c->stream, nw2, Nm,
+                           depth, rho, g, dw, dk, dio, dI, dB, dH, c->rKay);
+    }
+    if (finish_timed(c)) return -2;
+    if (nSet && kay_out) D2H(c, kay_out, c->rKay, nq * sizeof(cplx));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    c->rKay_sets = nSet;
+    c->rKay_nw2 = nw2;
+    c->kay_ready = true;
+    return 0;
+}
+
 static int qtf_slender_impl(raftx_ctx *c, int nSet, int nw2, const double *w2, const double *k2, double depth,
                             double rho, double g, const int64_t *stripOff, const double *strips,
                             const int64_t *memOff, const double *members, const raftx_c128 *Xi,
@@ -1311,7 +1368,9 @@ static int qtf_slender_impl(raftx_ctx *c, int nSet, int nw2, const double *w2, c
            *dM = sc.alloc<double>(nMem * QM_N), *dB = sc.alloc<double>(nSet), *dMs = sc.alloc<double>((size_t)nSet * 36);
     int64_t *dso = sc.alloc<int64_t>(nSet + 1), *dmo = sc.alloc<int64_t>(nSet + 1);
     int *dss = sc.alloc<int>(nStrip), *dms = sc.alloc<int>(nMem);
-    cplx *dXi = sc.alloc<cplx>((size_t)nSet * 6 * nw2), *dK = kay ? sc.alloc<cplx>(nq) : nullptr;
+    const bool use_resident_kay = !kay && c->kay_ready && c->rKay_sets == nSet && c->rKay_nw2 == nw2;
+    c->kay_ready = false;                                // one-shot: a table never outlives the call it was made for
+    cplx *dXi = sc.alloc<cplx>((size_t)nSet * 6 * nw2), *dK = kay ? sc.alloc<cplx>(nq) : (use_resident_kay ? c->rKay : nullptr);
     cplx *dT = sc.alloc<cplx>(nStrip * QT_N * nw2), *dTM = sc.alloc<cplx>(nMem * QTM_N * nw2),
          *dTS = sc.alloc<cplx>((size_t)nSet * QTS_N * nw2);
     if (c->rQtf_n < nq || !c->rQtf) {                    // the result stays resident (raftx_qtf_force can reuse it)

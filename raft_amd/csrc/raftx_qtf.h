@@ -453,3 +453,91 @@ __global__ void __launch_bounds__(256) k_qtf_force(int nSet, int nw2, const doub
         f_mean[(size_t)set * 6 + j] = 2.0 * a * dw;
     }
 }
+
+
+// ---------------------------------------------------------------------------------------------------------
+// Kim & Yue correction (Member.correction_KAY, raft_member.py:1676-1791) as a device table.
+//   k_kay_tables : per (item, frequency) the Hankel-derivative values H'_n(k R), n = 0 .. Nm+1
+//   k_kay_pairs  : per (set, w1 row) threads over w2 >= w1: the n-sums for every item of the set
+#define QK_N 12
+#define KAY_MAXN 12          // Nm + 2 <= 12 stored orders (Nm = 10 upstream)
+
+__global__ void __launch_bounds__(128) k_kay_tables(int nw, int nOrd, const double *__restrict__ k,
+                                                    const double *__restrict__ items, cplx *__restrict__ HK) {
+    const int item = blockIdx.x;
+    const double R = items[(size_t)item * QK_N];
+    for (int i = threadIdx.x; i < nw; i += blockDim.x) {
+        const double x = k[i] * R;
+        // H_n = J_n + i Y_n for n = -1 .. nOrd; H_{-1} = -H_1
+        double jm = -j1(x), ym = -y1(x);              // n - 1
+        double jc = j0(x), yc = y0(x);                // n
+        for (int n = 0; n < nOrd; n++) {
+            const double jp = jn(n + 1, x), yp = yn(n + 1, x);
+            HK[((size_t)item * KAY_MAXN + n) * nw + i] = cplx{0.5 * (jm - jp), 0.5 * (ym - yp)};   // H'_n
+            jm = jc; ym = yc;
+            jc = jp; yc = yp;
+        }
+    }
+}
+
+__global__ void __launch_bounds__(128) k_kay_pairs(int nw, int Nm, double h, double rho, double g,
+                                                   const double *__restrict__ w, const double *__restrict__ k,
+                                                   const int64_t *__restrict__ ioff, const double *__restrict__ items,
+                                                   const double *__restrict__ beta, const cplx *__restrict__ HK,
+                                                   cplx *__restrict__ kay) {
+    const int set = blockIdx.x / nw, i1 = blockIdx.x % nw;
+    const double w1 = w[i1], k1 = k[i1];
+    const double cB = cos(beta[set]), sB = sin(beta[set]);
+    for (int i2 = i1 + threadIdx.x; i2 < nw; i2 += blockDim.x) {
+        const double w2 = w[i2], k2 = k[i2];
+        double Fr[6] = {0, 0, 0, 0, 0, 0}, Fi[6] = {0, 0, 0, 0, 0, 0};
+        for (int64_t it = ioff[set]; it < ioff[set + 1]; it++) {
+            const double *rec = items + (size_t)it * QK_N;
+            const double R = rec[0];
+            const bool seg = rec[1] != 0.0;
+            const double k1R = k1 * R, k2R = k2 * R;
+            const cplx *H1 = HK + (size_t)it * KAY_MAXN * nw + i1, *H2 = HK + (size_t)it * KAY_MAXN * nw + i2;
+            double wgtA = 1.0, wgtB = 0.0;             // term_n = omega_n * (wgtA + wgtB n(n+1))
+            if (seg) {
+                const double z1 = rec[2], z2 = rec[3];
+                const double Hh = h / R, k1h = k1R * Hh, k2h = k2R * Hh, ks = k1 + k2, kdh = k1h - k2h;
+                const double sp2 = sinh(ks * (z2 + h)) / (k1h + k2h), sp1 = sinh(ks * (z1 + h)) / (k1h + k2h);
+                const double sm2 = (w1 == w2) ? (z2 + h) / h : sinh((k1 - k2) * (z2 + h)) / kdh;
+                const double sm1 = (w1 == w2) ? (z1 + h) / h : sinh((k1 - k2) * (z1 + h)) / kdh;
+                const double Im = 0.5 * (sp2 - sm2 - sp1 + sm1), Ip = 0.5 * (sp2 + sm2 - sp1 - sm1);
+                const double pre = k1h * k2h / sqrt(k1h * tanh(k1h)) / sqrt(k2h * tanh(k2h));
+                const double c1 = cosh(k1h), c2 = cosh(k2h);
+                wgtA = pre * Im / c1 / c2;
+                wgtB = pre * Ip / k1R / k2R / c1 / c2;
+            }
+            // sum_n (+-) rho g R 2i/pi/(k1R k2R) omega_n weight_n ; only the real part is kept (:1747,1783)
+            double acc = 0.0;                           // Re( 2i * sum omega_n weight_n ) = -2 * Im( sum )
+            double sr = 0.0, si = 0.0;
+            for (int n = 0; n <= Nm; n++) {
+                const cplx a0 = H1[(size_t)n * nw], a1 = H1[(size_t)(n + 1) * nw];        // H'_n(k1R), H'_{n+1}(k1R)
+                const cplx b0 = cconj(H2[(size_t)n * nw]), b1 = cconj(H2[(size_t)(n + 1) * nw]);
+                const cplx d1 = cmul(a1, b0), d2 = cmul(a0, b1);
+                const double n1 = d1.re * d1.re + d1.im * d1.im, n2 = d2.re * d2.re + d2.im * d2.im;
+                const double orr = d1.re / n1 - d2.re / n2, oii = -d1.im / n1 + d2.im / n2;   // 1/d1 - 1/d2
+                const double wn = wgtA + wgtB * (double)(n * (n + 1));
+                sr += orr * wn;
+                si += oii * wn;
+            }
+            (void)sr;
+            acc = -2.0 * si;
+            double Fs = rho * g * R / M_PI / (k1R * k2R) * acc;
+            if (!seg) Fs = -Fs;                                                          // waterline term carries the minus sign (:1745)
+            double ps, pc;
+            sincos(-((k1 - k2) * (cB * rec[10] + sB * rec[11])), &ps, &pc);
+            const double fr = Fs * pc, fi = Fs * ps;
+            const double px = rec[7], py = rec[8], pz = rec[9], ax = rec[4], ay = rec[5], az = rec[6];
+            const double g6[6] = {px, py, pz, ay * pz - az * py, az * px - ax * pz, ax * py - ay * px};
+#pragma unroll
+            for (int j = 0; j < 6; j++) { Fr[j] += fr * g6[j]; Fi[j] += fi * g6[j]; }
+        }
+        const bool cj = k1 < k2;                                                          // :1787-1788
+        cplx *o = kay + (((size_t)set * nw + i1) * nw + i2) * 6;
+#pragma unroll
+        for (int j = 0; j < 6; j++) o[j] = cplx{Fr[j], cj ? -Fi[j] : Fi[j]};
+    }
+}

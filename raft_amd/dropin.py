@@ -176,10 +176,18 @@ class Engine:
         if out_dir is not None and verbose:
             rq.write_rao4(os.path.join(out_dir, f"raos-slender_body_Head{whead}{tag}.4"), w2, beta, Xi)
         tab = rq.pack_qtf(fowt)
-        kay = rq.kay_correction(tab.kay_geom, w2, k2, beta, fowt.depth, rho=fowt.rho_water, g=fowt.g)
-        backend_fn = self._qtf_backend or (lambda *a: self.ctx.qtf_slender(*a))
-        q = backend_fn([tab], Xi[None], np.array([beta]), w2, k2, fowt.depth, fowt.rho_water, fowt.g,
-                       np.asarray(fowt.M_struc, dtype=float)[None], kay[None])[0]
+        args = ([tab], Xi[None], np.array([beta]), w2, k2, fowt.depth, fowt.rho_water, fowt.g,
+                np.asarray(fowt.M_struc, dtype=float)[None])
+        if self._qtf_backend is None and self.ctx.rlib.is_device:
+            # Kim & Yue table of the MacCamy-Fuchs members on the device too (raftx_qtf_kay; 1.4 s of SciPy Hankel
+            # sums per 200 x 200 grid on the host), consumed by the QTF launch that follows
+            if tab.kay_geom:
+                self.ctx.qtf_kay([tab], np.array([beta]), w2, k2, fowt.depth, fowt.rho_water, fowt.g)
+            q = self.ctx.qtf_slender(*args, None)[0]
+        else:
+            kay = rq.kay_correction(tab.kay_geom, w2, k2, beta, fowt.depth, rho=fowt.rho_water, g=fowt.g)
+            backend_fn = self._qtf_backend or (lambda *a: self.ctx.qtf_slender(*a))
+            q = backend_fn(*args, kay[None])[0]
         fowt.qtf[:, :, 0, :] = q          # NB: like the reference, slot 0 is written whatever waveHeadInd is asked (:2014)
         if out_dir is not None and verbose:
             rq.write_qtf12d(os.path.join(out_dir, f"qtf-slender_body-total_Head{whead}{tag}.12d"), fowt.qtf, w2,

@@ -99,6 +99,38 @@ def pack_qtf(fowt, memberList=None):
 
 
 # ---------------------------------------------------------------------- Kim & Yue correction (host feeder)
+QK_N = 12          # doubles per Kim & Yue item (include/raftx.h RAFTX_QK_*)
+
+
+def kay_items(kay_geom, beta):
+    """Geometry of Member.correction_KAY (raft_member.py:1676-1791) as flat records for raftx_qtf_kay: for every
+    MacCamy-Fuchs member that crosses the waterline one WATERLINE item and one item per submerged segment between
+    consecutive strip nodes.  Record: R, kind (0 waterline / 1 segment), z1, z2, moment arm (3), unit force direction
+    pforce (3, depends on the heading), waterline point x, y (the phase reference of ALL items of the member, :1783)."""
+    cosB, sinB = np.cos(beta), np.sin(beta)
+    rows = []
+    for gm in kay_geom:
+        rA, rB, r, ds, dls, p1, p2 = (gm[x] for x in ("rA", "rB", "r", "ds", "dls", "p1", "p2"))
+        if rA[2] * rB[2] >= 0:
+            continue
+        bvec = np.array([cosB, sinB, 0.0])
+        pforce = np.dot(bvec, p1) * p1 + np.dot(bvec, p2) * p2
+        pforce = pforce / np.linalg.norm(pforce)
+        rwl = rA + (rB - rA) * (0 - rA[2]) / (rB[2] - rA[2])
+        R = np.interp(0, r[:, 2], 0.5 * ds)
+        rows.append([R, 0.0, 0.0, 0.0, rwl[0], rwl[1], rwl[2], pforce[0], pforce[1], pforce[2], rwl[0], rwl[1]])
+        for il in range(len(r) - 1):
+            z1 = r[il, 2]
+            if z1 > 0:
+                continue
+            z2 = min(r[il + 1, 2], 0.0)
+            R1 = ds[il] / 2 if dls[il] != 0 else ds[il]
+            R2 = ds[il + 1] / 2 if dls[il + 1] != 0 else ds[il]
+            mid = 0.5 * (r[il] + r[il + 1])
+            rows.append([0.5 * (R1 + R2), 1.0, z1, z2, mid[0], mid[1], mid[2], pforce[0], pforce[1], pforce[2], rwl[0], rwl[1]])
+    return np.array(rows, dtype=np.float64).reshape(-1, QK_N)
+
+
 def kay_correction(kay_geom, w, k, beta, h, rho=1025.0, g=9.81, Nm=10):
     """Sum over the MCF members of Member.correction_KAY (raft_member.py:1676-1791) for every pair i2 >= i1:
     [nw,nw,6] complex, zero below the diagonal.  Independent of the body motions -> a per-design table."""

@@ -190,7 +190,8 @@ class Sweep:
         """potSecOrder == 1 for a whole batch (single wave heading): first-order fixed point, slender-body QTFs from the
         converged motions, second-order force, restarted fixed point (raft_model.py:1108-1131) -- five launches in total,
         QTFs never leave the device.  qtf_tables: one raft_amd.qtf.QtfTable per design; Mstruc [nD,6,6];
-        S0 [nCase,nw] wave spectra; kay: optional list (per design) of Kim & Yue tables for the sea states' heading,
+        S0 [nCase,nw] wave spectra; kay: optional list (per design) of HOST Kim & Yue tables for the sea states' heading
+        (default: built on the device, raftx_qtf_kay, when the tables carry MacCamy-Fuchs members),
         [nCase][nw2,nw2,6] each.  Returns Xi, niter (both stages), flags, Fhydro_2nd [nD,nCase,6,nw]."""
         from . import waves
         if self.n_head != 1:
@@ -212,6 +213,8 @@ class Sweep:
         beta = np.array([self.beta[c, 0] for _ in range(nD) for c in range(nC)])
         Ms = np.array([Mstruc[d] for d in range(nD) for _ in range(nC)])
         kt = None if kay is None else np.array([kay[d][c] for d in range(nD) for c in range(nC)])
+        if kt is None and ctx.rlib.is_device and any(len(t.kay_geom) for t in tabs):
+            ctx.qtf_kay(tabs, beta, w2, k2, self.depth, rho_water, self.g)        # Kim & Yue tables built on the device
         ctx.qtf_slender(tabs, Xi2, beta, w2, k2, self.depth, rho_water, self.g, Ms, kt, fetch=False)
         dw = float(self.w[1] - self.w[0])
         _, f2 = ctx.qtf_force(w2, self.w, dw, np.array([S0[c] for _ in range(nD) for c in range(nC)]), qtf=None,

@@ -37,3 +37,21 @@ print(json.dumps({"metric": "QTF strip-pairs per second", "sets": n_set, "nw2": 
                   "numpy_oracle_strip_pairs_per_s_1core": (n_sub * (n_sub + 1) // 2) * S / t_cpu,
                   "reference_strip_pairs_per_s_1core": 1.0 / 0.58e-3,
                   "hermitian_ok": bool(np.allclose(q[0], np.conj(np.transpose(q[0], (1, 0, 2))), atol=1e-6 * np.abs(q[0]).max()))}))
+
+# Kim & Yue correction table: OC4semi (MacCamy-Fuchs columns with heave plates), same 200 x 200 grid, device vs the
+# host SciPy implementation it replaces on the batched path
+fx5 = standin.load_fixture("c5_oc4semi_qtf.npz")
+f5 = standin.build_model(fx5["model"]).fowtList[0]
+tab5 = rq.pack_qtf(f5)
+k5 = np.array([waves.wave_number(x, f5.depth) for x in w2])
+n_k = 4
+bet5 = np.array([0.0, 0.5, 1.0, 2.0])
+for _ in range(2):
+    ctx.qtf_kay([tab5] * n_k, bet5, w2, k5, f5.depth, f5.rho_water, f5.g)
+ms_kay = ctx.last_kernel_ms()
+t0 = time.perf_counter()
+rq.kay_correction(tab5.kay_geom, w2, k5, 0.5, f5.depth, rho=f5.rho_water, g=f5.g)
+t_host = time.perf_counter() - t0
+print(json.dumps({"metric": "Kim & Yue table", "sets": n_k, "nw2": nw2, "items_per_set": int(len(rq.kay_items(tab5.kay_geom, 0.5))),
+                  "device_ms_all_sets": ms_kay, "host_scipy_s_per_set": t_host,
+                  "speedup_per_set": t_host / (ms_kay * 1e-3 / n_k)}))

@@ -65,6 +65,33 @@ def test_qtf_batch_against_numpy_oracle(hip_ctx):
         assert np.array_equal(q[s][off], np.conj(np.transpose(q[s], (1, 0, 2)))[off])
 
 
+def test_kim_yue_table_on_device_matches_host_scipy(hip_ctx):
+    """raftx_qtf_kay (device j0/y0/jn/yn Hankel sums) against raft_amd.qtf.kay_correction (SciPy hankel1), which the
+    live-reference C5 goldens pin; OC4semi's MacCamy-Fuchs columns with heave plates, two headings, 60-point grid; then
+    the QTF that consumes the resident table against the one fed with the host table."""
+    from raft_amd import qtf as rq, waves
+    fx = standin.load_fixture("c5_oc4semi_qtf.npz")
+    f = standin.build_model(fx["model"]).fowtList[0]
+    tab = rq.pack_qtf(f)
+    assert len(tab.kay_geom) >= 3
+    nw2 = 60
+    w2 = np.arange(1, nw2 + 1) * 0.008 * 2 * np.pi
+    k2 = np.array([waves.wave_number(x, f.depth) for x in w2])
+    betas = np.array([0.0, np.deg2rad(30.0)])
+    host = np.array([rq.kay_correction(tab.kay_geom, w2, k2, b, f.depth, rho=f.rho_water, g=f.g) for b in betas])
+    dev = hip_ctx.qtf_kay([tab, tab], betas, w2, k2, f.depth, f.rho_water, f.g, fetch=True)
+    assert rel_err(dev, host) < 1e-10
+    assert not np.any(dev[:, np.tril_indices(nw2, -1)[0], np.tril_indices(nw2, -1)[1]])     # upper triangle only
+    rng = np.random.default_rng(3)
+    Xi = 0.2 * (rng.normal(size=(2, 6, nw2)) + 1j * rng.normal(size=(2, 6, nw2))) / (1 + w2[None, None, :] ** 2)
+    Ms = np.array([f.M_struc, f.M_struc])
+    a = hip_ctx.qtf_slender([tab, tab], Xi, betas, w2, k2, f.depth, f.rho_water, f.g, Ms, None)      # consumes the table
+    b = hip_ctx.qtf_slender([tab, tab], Xi, betas, w2, k2, f.depth, f.rho_water, f.g, Ms, host)
+    c = hip_ctx.qtf_slender([tab, tab], Xi, betas, w2, k2, f.depth, f.rho_water, f.g, Ms, None)      # one-shot: gone now
+    assert rel_err(a, b) < 1e-10
+    assert rel_err(c, b) > 1e-6
+
+
 def test_qtf_interleaved_row_partition_sums_to_the_full_matrix(hip_ctx):
     """raftx_qtf_slender_rows: the rows rank::world of one 200-point QTF for world = 3; the partial matrices have
     disjoint support (rows + Hermitian mirrors) and add up, bit for bit, to the unpartitioned result."""
