@@ -222,7 +222,11 @@ int raftx_solve_system_resident(raftx_ctx *ctx, int nUnit, const double *Mc, con
  * raft/raft_member.py:1488-1674 (Member.calcQTF_slenderBody) with the helpers of raft/helpers.py:239-373 --
  * for nSet independent (strip table, motion RAOs, heading) sets on a common second-order grid w2,k2 [nw2].
  * strips [stripOff[nSet],24] / members [memOff[nSet],16]: records of raft_amd/qtf.py (QS_N, QM_N);
- * Xi [nSet,6,nw2] motion RAOs on that grid (zeros = fixed body); beta [nSet] rad; Mstruc [nSet,6,6];
+ * Xi [nSet,6,nw2] motion RAOs on that grid (zeros = fixed body), or NULL: the RAOs are then taken on the device from
+ * the RESIDENT first-order responses of the last raftx_solve_dynamics_device (set s = (design, case) pair s, heading
+ * 0): RAO = Xi / zeta where |zeta| > 1e-6 (raft/helpers.py:762-784), interpolated to w2 and zero outside the
+ * first-order grid (raft_fowt.py:2022-2024) -- the internal-QTF flow of raft_model.py:1108-1131 without a round trip;
+ * beta [nSet] rad; Mstruc [nSet,6,6];
  * kay [nSet,nw2,nw2,6] optional Kim & Yue table (raft_member.py:1676-1791; upper triangle, host feeder);
  * qtf [nSet,nw2,nw2,6] out, Hermitian-completed (may be NULL: the result then only stays resident in HBM
  * for raftx_qtf_force).  Independent of the upload_* state of the ctx. */

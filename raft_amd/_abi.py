@@ -396,7 +396,7 @@ class Context:
             moff[i + 1] = moff[i] + t.members.shape[0]
         strips = _f64(np.concatenate([t.strips for t in tables], axis=0)) if nS else np.zeros((0, 24))
         members = _f64(np.concatenate([t.members for t in tables], axis=0)) if nS else np.zeros((0, 16))
-        Xi = _c128(Xi, (nS, 6, nw2), "Xi")
+        Xi = None if Xi is None else _c128(Xi, (nS, 6, nw2), "Xi")      # None: RAOs of the resident responses (device)
         beta = _f64(beta, (nS,), "beta")
         Mstruc = _f64(Mstruc, (nS, 6, 6), "Mstruc")
         kay = None if kay is None else _c128(kay, (nS, nw2, nw2, 6), "kay")

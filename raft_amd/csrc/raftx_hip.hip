@@ -1344,8 +1344,11 @@ static int qtf_slender_impl(raftx_ctx *c, int nSet, int nw2, const double *w2, c
                             const double *beta, const double *Mstruc, const raftx_c128 *kay, int row_off, int row_stride,
                             raftx_c128 *qtf) {
     if (!c) return -1;
-    if (nSet < 0 || nw2 < 1 || !w2 || !k2 || !stripOff || !memOff || !Xi || !beta || !Mstruc)
+    if (nSet < 0 || nw2 < 1 || !w2 || !k2 || !stripOff || !memOff || !beta || !Mstruc)
         FAIL(c, "qtf_slender: bad arguments");
+    if (!Xi && (!c->rXi || !c->have_cases || c->r_npair != (size_t)nSet))
+        FAIL(c, "qtf_slender: Xi == NULL asks for the RAOs of the resident responses, but %s",
+             !c->rXi ? "nothing is resident" : "the number of sets differs from the resident (design, case) pairs");
     if (row_stride < 1 || row_off < 0 || row_off >= row_stride) FAIL(c, "qtf_slender: bad row partition %d/%d", row_off, row_stride);
     HIPCHK(c, hipSetDevice(c->device));
     const size_t nStrip = (size_t)stripOff[nSet], nMem = (size_t)memOff[nSet];
@@ -1399,7 +1402,7 @@ static int qtf_slender_impl(raftx_ctx *c, int nSet, int nw2, const double *w2, c
         H2D(c, dmo, memOff, (nSet + 1) * sizeof(int64_t));
         if (nStrip) H2D(c, dss, sset.data(), nStrip * sizeof(int));
         if (nMem) H2D(c, dms, mset.data(), nMem * sizeof(int));
-        H2D(c, dXi, Xi, (size_t)nSet * 6 * nw2 * sizeof(cplx));
+        if (Xi) H2D(c, dXi, Xi, (size_t)nSet * 6 * nw2 * sizeof(cplx));
         if (kay) H2D(c, dK, kay, nq * sizeof(cplx));
     }
     A.w = dw; A.k = dk; A.soff = dso; A.strips = dS; A.moff = dmo; A.members = dM; A.sset = dss; A.mset = dms;
@@ -1410,6 +1413,9 @@ static int qtf_slender_impl(raftx_ctx *c, int nSet, int nw2, const double *w2, c
     if (A.nrow < 0) A.nrow = 0;
     if (nSet && row_stride > 1) HIPCHK(c, hipMemsetAsync(dQ, 0, nq * sizeof(cplx), c->stream));   // other ranks' rows stay 0
     HIPCHK(c, hipEventRecord(c->ev0, c->stream));
+    if (nSet && !Xi)                                     // motion RAOs straight from the resident first-order responses
+        hipLaunchKernelGGL(k_rao_to_grid, dim3((unsigned)((size_t)nSet * 6)), dim3(128), 0, c->stream, c->T.nCase, c->T.nHead,
+                           c->T.nw, nw2, c->T.w, c->T.zeta, dw, c->rXi, dXi);
     if (nSet) {
         hipLaunchKernelGGL(k_qtf_tables, dim3((unsigned)(nStrip + nMem + nSet)), dim3(nw2 > 128 ? 256 : 128), 0, c->stream, A,
                            (int)nStrip, (int)nMem);

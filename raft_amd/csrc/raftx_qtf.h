@@ -541,3 +541,40 @@ __global__ void __launch_bounds__(128) k_kay_pairs(int nw, int Nm, double h, dou
         for (int j = 0; j < 6; j++) o[j] = cplx{Fr[j], cj ? -Fi[j] : Fi[j]};
     }
 }
+
+
+// Motion RAOs of the resident first-order responses on the second-order grid: RAO = Xi / zeta where |zeta| > 1e-6
+// (helpers.py:762-784), then np.interp(w2, w, RAO, left=0, right=0) per DOF (raft_fowt.py:2022-2024).  Set = (design,
+// case) pair, heading 0.
+__global__ void __launch_bounds__(128) k_rao_to_grid(int nCase, int nHead, int nw, int nw2, const double *__restrict__ w,
+                                                     const double *__restrict__ zeta, const double *__restrict__ w2,
+                                                     const cplx *__restrict__ Xi, cplx *__restrict__ out) {
+    const int p = blockIdx.x / 6, j = blockIdx.x % 6, ic = p % nCase;
+    const cplx *x = Xi + (((size_t)p * nHead + 0) * 6 + j) * nw;
+    const double *z = zeta + ((size_t)ic * nHead + 0) * nw;
+    for (int i2 = threadIdx.x; i2 < nw2; i2 += blockDim.x) {
+        const double t = w2[i2];
+        cplx r = {0.0, 0.0};
+        if (t >= w[0] && t <= w[nw - 1]) {
+            int lo = 0, hi = nw - 1;                        // largest lo with w[lo] <= t
+            while (hi - lo > 1) {
+                const int mid = (lo + hi) >> 1;
+                if (w[mid] <= t) lo = mid; else hi = mid;
+            }
+            if (w[hi] <= t) lo = hi;
+            auto rao = [&](int i) -> cplx {
+                const double zz = z[i];
+                return fabs(zz) > 1e-6 ? cplx{x[i].re / zz, x[i].im / zz} : cplx{0.0, 0.0};
+            };
+            const cplx a = rao(lo);
+            if (lo == nw - 1 || w[lo] == t) {
+                r = a;
+            } else {
+                const cplx b = rao(lo + 1);
+                const double dx = w[lo + 1] - w[lo], f = t - w[lo];
+                r = cplx{(b.re - a.re) / dx * f + a.re, (b.im - a.im) / dx * f + a.im};      // numpy: slope*(x - xp) + fp
+            }
+        }
+        out[((size_t)p * 6 + j) * nw2 + i2] = r;
+    }
+}

@@ -202,13 +202,16 @@ class Sweep:
         ctx.solve_dynamics_device(self.nIter, self.tol, self.XiStart)
         r1 = ctx.fetch_results(want_Xi=True)
         XiLast = ctx.fetch_linearisation_point()
-        # motion RAOs on the second-order grid (helpers.py:762-784, raft_fowt.py:2022-2024)
-        Xi2 = np.zeros((nD * nC, 6, n2), dtype=complex)
-        for d in range(nD):
-            for c in range(nC):
-                rao = waves.get_rao(r1["Xi"][d, c, 0], self.zeta[c, 0])
-                for j in range(6):
-                    Xi2[d * nC + c, j] = np.interp(w2, self.w, rao[j], left=0, right=0)
+        # motion RAOs on the second-order grid (helpers.py:762-784, raft_fowt.py:2022-2024): on the device straight from
+        # the resident responses; the CPU oracle (tests) takes the host loop
+        Xi2 = None
+        if not ctx.rlib.is_device:
+            Xi2 = np.zeros((nD * nC, 6, n2), dtype=complex)
+            for d in range(nD):
+                for c in range(nC):
+                    rao = waves.get_rao(r1["Xi"][d, c, 0], self.zeta[c, 0])
+                    for j in range(6):
+                        Xi2[d * nC + c, j] = np.interp(w2, self.w, rao[j], left=0, right=0)
         tabs = [qtf_tables[d] for d in range(nD) for _ in range(nC)]
         beta = np.array([self.beta[c, 0] for _ in range(nD) for c in range(nC)])
         Ms = np.array([Mstruc[d] for d in range(nD) for _ in range(nC)])

@@ -197,11 +197,44 @@ def test_second_order_sweep_matches_dropin(hip_ctx):
     from raft_amd import waves
     S0 = np.array([waves.sea_state(dict(c), f.w, f.dw)[2][0] for c in cases])
     kay = [[rq.kay_correction(tab.kay_geom, w2, k2, sweep.beta[c, 0], f.depth, rho=f.rho_water, g=f.g) for c in range(2)]] * 2
-    out = sweep.run_second_order(hip_ctx, [tab, tab], np.array([f.M_struc, f.M_struc]), w2, k2, S0,
-                                 rho_water=f.rho_water, kay=kay)
-    for d in range(2):
-        for i, c in enumerate(fx["cases"]):
-            u = c["units"][0]
-            assert int(out["niter"][d, i]) == int(u["niter"])
-            assert rel_err(out["Fhydro_2nd"][d, i], u["Fhydro_2nd"][0].real) < TOL
-            assert group_rel_err(out["Xi"][d, i, :1], c["Xi"][:1]) < TOL
+    # host Kim & Yue tables, then everything on the device (RAOs from the resident responses, Kim & Yue tables, QTFs,
+    # force spectra): both against the live reference
+    for kw in (dict(kay=kay), dict()):
+        out = sweep.run_second_order(hip_ctx, [tab, tab], np.array([f.M_struc, f.M_struc]), w2, k2, S0,
+                                     rho_water=f.rho_water, **kw)
+        for d in range(2):
+            for i, c in enumerate(fx["cases"]):
+                u = c["units"][0]
+                assert int(out["niter"][d, i]) == int(u["niter"])
+                assert rel_err(out["Fhydro_2nd"][d, i], u["Fhydro_2nd"][0].real) < TOL
+                assert group_rel_err(out["Xi"][d, i, :1], c["Xi"][:1]) < TOL
+
+
+def test_resident_rao_path_equals_host_interpolation(hip_ctx):
+    """raftx_qtf_slender with Xi == NULL: RAOs of the resident responses, interpolated on the device, against the same
+    QTF fed with np.interp'ed RAOs (grid points inside, on and outside the first-order grid; a zero-amplitude bin)."""
+    from raft_amd import dropin, waves
+    from tests.util import load_model_fixture, case_from_fixture
+    fx, model = load_model_fixture("c5_internal_qtf.npz")
+    f = model.fowtList[0]
+    cases = [case_from_fixture(c) for c in fx["cases"]]
+    sweep = dropin.sweep_from_models([model], cases)
+    sweep.zeta = sweep.zeta.copy()
+    sweep.zeta[:, :, 7] = 0.0                                    # RAO := 0 where |zeta| <= 1e-6
+    sweep.solve(hip_ctx)
+    r = hip_ctx.fetch_results(want_Xi=True)
+    tab = rq.pack_qtf(f)
+    w2 = np.concatenate([[0.5 * f.w[0]], f.w[3:9], np.linspace(f.w[10], f.w[-1] * 1.2, 25)])      # below, on, between, above
+    k2 = np.array([waves.wave_number(x, f.depth) for x in w2])
+    nC = len(cases)
+    Xi2 = np.zeros((nC, 6, len(w2)), dtype=complex)
+    for c in range(nC):
+        rao = waves.get_rao(r["Xi"][0, c, 0], sweep.zeta[c, 0])
+        for j in range(6):
+            Xi2[c, j] = np.interp(w2, f.w, rao[j], left=0, right=0)
+    args = ([tab] * nC, sweep.beta[:, 0], w2, k2, f.depth, f.rho_water, f.g, np.array([f.M_struc] * nC))
+    a = hip_ctx.qtf_slender(args[0], None, *args[1:])
+    b = hip_ctx.qtf_slender(args[0], Xi2, *args[1:])
+    assert rel_err(a, b) < 1e-12
+    with pytest.raises(Exception):
+        hip_ctx.qtf_slender(args[0][:1], None, sweep.beta[:1, 0], w2, k2, f.depth, f.rho_water, f.g, np.array([f.M_struc]))
