@@ -969,7 +969,8 @@ extern "C" int raftx_solve_dynamics_device(raftx_ctx *c, int nIter, double tol, 
                      (T.cm ? KF_MCF : 0) | (T.nHead > 1 ? KF_MULTI : 0);
     const Shape sh = pick_shape(T.nw);
     const bool xlg = sh.threads == 512 && sh.nb >= 3;        // XiLast in a global scratch slab (raftx_kernels.h XlStore)
-    const size_t lds = lds_bytes(c->maxS, xlg ? 0 : T.nw, sh.threads / 64, stage_policy(sh.nb, shape_maxt(sh)));
+    const size_t lds = lds_bytes(c->maxS, xlg ? 0 : T.nw, sh.threads / 64, stage_policy(sh.nb, shape_maxt(sh)),
+                                 park_policy(sh.nb, shape_maxt(sh)));
     if (xlg && (!c->rXl || c->rXl_n < c->r_npair * 12 * (size_t)T.nw)) {
         HIPCHK(c, hipStreamSynchronize(c->stream));
         if (c->rXl) (void)hipFree(c->rXl);

@@ -163,6 +163,7 @@ struct Lds {
     ldptr vsq;     // [NWV][S][3]  per-wave sums over bins of |v_q|^2, |v_p1|^2 (|v_perp|^2), |v_p2|^2;
                      //              row 0 is overwritten by the live coefficients b_c (strip_phase)
     ldptr tile;    // [NWV][TR_ROWS][TR_STRIDE]
+    ldptr park;    // start of the span (vsq rows >= 1 | uv | tile) the solve phase may reuse, see park_policy
     ldptr bdw;     // [NWV][24]    per-wave partials of the 21 unique B_drag entries
     ldptr Bd;      // [36]
     ldptr mat;     // [108]        M0, B0, C0
@@ -170,24 +171,30 @@ struct Lds {
     int nxl;
 };
 static __host__ __device__ inline int xl_row(int nw) { return (nw + 1) & ~1; }
-__device__ __forceinline__ Lds carve(double *base_, int S, int nw, int nwv, int stage_n) {
+// park_n: doubles of the [uv | vsq | tile] span that the solve phase reuses as a per-lane parking column (0 = none);
+// the span is padded up to that size for designs with few strips
+static __host__ __device__ constexpr int park_policy(int nb, int maxt) { return (nb == 2 && maxt == 128) ? 12 * 128 : 0; }
+__device__ __forceinline__ Lds carve(double *base_, int S, int nw, int nwv, int stage_n, int park_n = 0) {
     Lds l;
     ldptr base = (ldptr)base_;
     l.nxl = xl_row(nw);
     l.xl = base;
     l.ra = l.xl + (size_t)12 * l.nxl;
-    l.uv = l.ra + (size_t)S * stage_n;
-    l.vsq = l.uv + (size_t)S * 12;
-    l.tile = l.vsq + (size_t)nwv * S * 3;
+    l.vsq = l.ra + (size_t)S * stage_n;
+    l.uv = l.vsq + (size_t)nwv * S * 3;
+    l.tile = l.uv + (size_t)S * 12;
     l.bdw = l.tile + (size_t)nwv * TR_ROWS * TR_STRIDE;
+    l.park = l.vsq + (size_t)S * 3;        // row 0 of vsq keeps the drag coefficients b_c for the other headings
+    if (park_n && l.bdw < l.park + park_n) l.bdw = l.park + park_n;
     l.Bd = l.bdw + (size_t)nwv * 24;
     l.mat = l.Bd + 36;
     l.fl = (liptr)(l.mat + 108);
     return l;
 }
-static size_t lds_bytes(int S, int nw, int nwv, int stage_n) {
-    return sizeof(double) * ((size_t)12 * xl_row(nw) + (size_t)S * (stage_n + 12 + 3 * nwv) +
-                             (size_t)nwv * (TR_ROWS * TR_STRIDE + 24) + 36 + 108 + 2) +
+static size_t lds_bytes(int S, int nw, int nwv, int stage_n, int park_n = 0) {
+    size_t span = (size_t)S * (12 + 3 * nwv) + (size_t)nwv * TR_ROWS * TR_STRIDE;          // vsq | uv | tile
+    if (park_n && span < (size_t)S * 3 + (size_t)park_n) span = (size_t)S * 3 + (size_t)park_n;
+    return sizeof(double) * ((size_t)12 * xl_row(nw) + (size_t)S * stage_n + span + (size_t)nwv * 24 + 36 + 108 + 2) +
            sizeof(int) * (size_t)(stage_n == RA_N ? S + 2 : 2);
 }
 
@@ -1157,7 +1164,8 @@ __global__ void __launch_bounds__(MAXT, MINB) k_solve_dynamics(DevTables T, Solv
     const cplx *cm = (MCF && T.cm) ? p.cm : nullptr;
     constexpr int STAGE = stage_policy(NB, MAXT);
     constexpr bool XLG = (MAXT == 512 && NB >= 3);
-    Lds l = carve(smem, S, XLG ? 0 : nw, blockDim.x >> 6, STAGE);
+    constexpr int PARK = park_policy(NB, MAXT);
+    Lds l = carve(smem, S, XLG ? 0 : nw, blockDim.x >> 6, STAGE, PARK);
     if (STAGE) stage_recA(p.ds, p.dsi, S, l, STAGE);
     XlStore<XLG> xl;
     if constexpr (XLG) {
@@ -1253,8 +1261,9 @@ __global__ void __launch_bounds__(MAXT, MINB) k_solve_dynamics(DevTables T, Solv
         int bad = 0, ok = 1;
         const bool last_chance = iiter + 1 >= A.nIter;
         const int tid_s = opaque((int)threadIdx.x);                  // bin bookkeeping re-derived: nothing of b stays live here
-#pragma unroll
-        for (int j = 0; j < NB; j++) {
+        // one bin: total excitation out, Z assembly + 6x6 solve (:1086-1089), NaN check (:1098), convergence
+        // (:1103-1104) and relaxation (:1133)
+        auto solve_bin = [&](int j, cplx (&xx)[6]) {
             const int ib = j * blockDim.x + tid_s;
             const bool act = ib < nw;
             const int iw = act ? ib : 0;
@@ -1263,11 +1272,10 @@ __global__ void __launch_bounds__(MAXT, MINB) k_solve_dynamics(DevTables T, Solv
             if constexpr (OUTF) {                                     // total excitation, heading 0 (:1212)
                 if (act && A.F_wave) {
 #pragma unroll
-                    for (int q = 0; q < 6; q++) A.F_wave[(((size_t)pair * nHs) * 6 + q) * nw + iw] = x[j][q];
+                    for (int q = 0; q < 6; q++) A.F_wave[(((size_t)pair * nHs) * 6 + q) * nw + iw] = xx[q];
                 }
             }
-            assemble_and_solve<FLAGS>(l, Mw, Bw, nw, iw, w, x[j], Zout, act);   // :1086-1089
-            // NaN check (:1098), convergence (:1103-1104) and relaxation (:1133)
+            assemble_and_solve<FLAGS>(l, Mw, Bw, nw, iw, w, xx, Zout, act);
             if (act) {
 #pragma unroll
                 for (int q = 0; q < 6; q++) {
@@ -1275,30 +1283,74 @@ __global__ void __launch_bounds__(MAXT, MINB) k_solve_dynamics(DevTables T, Solv
                     if constexpr (XLIO) {
                         if (A.XlOut) A.XlOut[((size_t)pair * 6 + q) * nw + iw] = cplx{lr, li};
                     }
-                    if (isnan(x[j][q].re) || isnan(x[j][q].im)) bad = 1;
-                    const double dr = x[j][q].re - lr, di = x[j][q].im - li;
-                    const double tc = sqrt(dr * dr + di * di) / (sqrt(x[j][q].re * x[j][q].re + x[j][q].im * x[j][q].im) + A.tol);
+                    if (isnan(xx[q].re) || isnan(xx[q].im)) bad = 1;
+                    const double dr = xx[q].re - lr, di = xx[q].im - li;
+                    const double tc = sqrt(dr * dr + di * di) / (sqrt(xx[q].re * xx[q].re + xx[q].im * xx[q].im) + A.tol);
                     if (!(tc < A.tol)) ok = 0;
-                    xl.put(2 * q, iw, 0.2 * lr + 0.8 * x[j][q].re);
-                    xl.put(2 * q + 1, iw, 0.2 * li + 0.8 * x[j][q].im);
+                    xl.put(2 * q, iw, 0.2 * lr + 0.8 * xx[q].re);
+                    xl.put(2 * q + 1, iw, 0.2 * li + 0.8 * xx[q].im);
                 }
             }
-        }
-        PT_MARK(4);   // assemble + solve + convergence
-        done = iiter + 1;
-        nan = wg_or(bad, multi);
-        converged = nan ? 0 : wg_and(ok, multi);
-        if (nan || converged || last_chance) {
-            // Heading 0 of the final response, Zinv (F_lin + F_drag(0)), is exactly this solve (:1216)
+        };
+        if constexpr (PARK != 0) {
+            // Two bins per lane: while one bin's 6x6 complex system (72 doubles) is being factorised, the other
+            // bin's right-hand side / solution waits in a per-lane LDS column carved out of the sweep buffers
+            // (vsq rows >= 1 | uv | tile are dead between pass B and the next strip phase; vsq row 0 holds b_c) instead of being spilled to scratch.
+            wg_sync(multi);                                           // the other wave may still read uv / vsq in pass B
+            ldptr park = l.park + tid_s;
+            const int nt = blockDim.x;
 #pragma unroll
-            for (int j = 0; j < NB; j++) {
-                const int ib = j * blockDim.x + tid_s;
-                if (ib < nw) {
-#pragma unroll
-                    for (int q = 0; q < 6; q++) xio[(size_t)q * nw + ib] = nan ? cplx{NAN, NAN} : x[j][q];
-                }
+            for (int q = 0; q < 6; q++) {
+                park[(2 * q) * nt] = x[1][q].re;
+                park[(2 * q + 1) * nt] = x[1][q].im;
             }
-            break;
+            solve_bin(0, x[0]);
+            ldptr park2 = l.park + opaque(tid_s);                       // opaque: no store-to-load forwarding back into VGPRs
+            cplx r1[6];
+#pragma unroll
+            for (int q = 0; q < 6; q++) {
+                r1[q] = cplx{park2[(2 * q) * nt], park2[(2 * q + 1) * nt]};
+                park2[(2 * q) * nt] = x[0][q].re;
+                park2[(2 * q + 1) * nt] = x[0][q].im;
+            }
+            solve_bin(1, r1);
+            PT_MARK(4);   // assemble + solve + convergence
+            done = iiter + 1;
+            nan = wg_or(bad, multi);
+            converged = nan ? 0 : wg_and(ok, multi);
+            if (nan || converged || last_chance) {
+                // Heading 0 of the final response, Zinv (F_lin + F_drag(0)), is exactly this solve (:1216)
+                ldptr park3 = l.park + opaque(tid_s);
+                if (tid_s < nw) {
+#pragma unroll
+                    for (int q = 0; q < 6; q++)
+                        xio[(size_t)q * nw + tid_s] = nan ? cplx{NAN, NAN} : cplx{park3[(2 * q) * nt], park3[(2 * q + 1) * nt]};
+                }
+                if (nt + tid_s < nw) {
+#pragma unroll
+                    for (int q = 0; q < 6; q++) xio[(size_t)q * nw + nt + tid_s] = nan ? cplx{NAN, NAN} : r1[q];
+                }
+                break;
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < NB; j++) solve_bin(j, x[j]);
+            PT_MARK(4);   // assemble + solve + convergence
+            done = iiter + 1;
+            nan = wg_or(bad, multi);
+            converged = nan ? 0 : wg_and(ok, multi);
+            if (nan || converged || last_chance) {
+                // Heading 0 of the final response, Zinv (F_lin + F_drag(0)), is exactly this solve (:1216)
+#pragma unroll
+                for (int j = 0; j < NB; j++) {
+                    const int ib = j * blockDim.x + tid_s;
+                    if (ib < nw) {
+#pragma unroll
+                        for (int q = 0; q < 6; q++) xio[(size_t)q * nw + ib] = nan ? cplx{NAN, NAN} : x[j][q];
+                    }
+                }
+                break;
+            }
         }
         iiter++;
         wg_sync(multi);
