@@ -315,18 +315,25 @@ int raftx_qtf_force(raftx_ctx *ctx, int nSet, int nw2, const double *w2, const r
 #define RAFTX_ADD_MORISON     1   /* M0 += A_hydro_morison (raft_fowt.py:1625) */
 #define RAFTX_ADD_HYDROSTATIC 2   /* C0 += C_hydro         (raft_fowt.py:1214-1256) */
 #define RAFTX_ADD_INERTIA     4   /* M0 += M_struc, C0 += C_struc of the described members (raft_fowt.py:876-900,1120-1199) */
+/* Ballast trim in heave BEFORE the statics are taken, Model.adjustBallastDensity (raft/raft_model.py:1772-1827, the
+ * ballast == 2 option of analyzeUnloaded :247-248): sections with zero fill density lose their fill length; with
+ *   sumFz = -(M_struc[0,0] + M0[0,0]) g + V rho g + Fz_moor,   drho = sumFz / g / (total ballast volume),
+ * every ballasted section's density is raised by drho and the inertia / weight terms are recomputed (M0[0,0] is the
+ * mass that is not geometry: rotor-nacelle assembly, point masses).  props[RAFTX_SP_DRHO] returns drho. */
+#define RAFTX_TRIM_BALLAST    8
 /* memberOff [nDesign+1] rows of members[.,RAFTX_GM_N]; stationOff [nMember+1] rows of stations[.,RAFTX_GS_N];
  * pose [nDesign,6] = mean position of the reduced DOFs (x,y,z,roll,pitch,yaw; FOWT.setPosition's argument,
  * raft_fowt.py:754) or NULL for zeros; rho, g: water density and gravity (raft_fowt.py:172-173);
  * k [nw] wave numbers for the MacCamy-Fuchs Cm table (required iff a member carries RAFTX_GM_FLAG_MCF);
- * M0,B0,C0,MBw as in raftx_upload_designs.  stripOffsets [nDesign+1] (out): submerged strips per design.
+ * M0,B0,C0,MBw as in raftx_upload_designs; Fz_moor [nDesign] vertical mooring force at the undisplaced position for
+ * RAFTX_TRIM_BALLAST (NULL = 0).  stripOffsets [nDesign+1] (out): submerged strips per design.
  * Only strips below the mean waterline are kept (raft_member.py:1310,1979,2058). */
 int raftx_build_designs(raftx_ctx *ctx, int nDesign, const int64_t *memberOff, const double *members,
                         const int64_t *stationOff, const double *stations,
                         const int64_t *capOff, const double *caps, const double *pose,
                         double rho, double g, int nw, const double *k, int add_mask,
                         const double *M0, const double *B0, const double *C0, const double *MBw,
-                        int64_t *stripOffsets);
+                        const double *Fz_moor, int64_t *stripOffsets);
 /* The strip records (ABI layout, [nStrips,RAFTX_NFIELD]) and MacCamy-Fuchs rows ([nRows,2,nw], may be NULL)
  * that raftx_build_designs generated -- what raft_amd/strips.py would have packed on the host. */
 int raftx_fetch_strips(raftx_ctx *ctx, double *strips, raftx_c128 *cm);
@@ -345,6 +352,8 @@ int raftx_fetch_strips(raftx_ctx *ctx, double *strips, raftx_c128 *cm);
 #define RAFTX_SP_RCB   2   /* x,y,z of the centre of buoyancy (raft_fowt.py:1245) */
 #define RAFTX_SP_MASS  5
 #define RAFTX_SP_RCG   6   /* x,y,z of the centre of mass (raft_fowt.py:1210) */
+#define RAFTX_SP_DRHO  9   /* ballast density change of RAFTX_TRIM_BALLAST [kg/m^3] */
+#define RAFTX_SP_VFILL 10  /* total ballast volume [m^3] */
 int raftx_fetch_statics(raftx_ctx *ctx, double *A_morison, double *C_hydro, double *W_hydro,
                         double *M_struc, double *C_struc, double *W_struc, double *props);
 

@@ -421,6 +421,21 @@ def _bare(design):
     return d
 
 
+def _trimmed_statics(design, r6, Fz):
+    """Model.adjustBallastDensity (raft_model.py:1772-1827) on a fresh live model with F_moor0[2] = Fz: the density
+    correction and the statics the reference holds afterwards (full model: RNA included)."""
+    import io, contextlib
+    m = rh.build_model(copy.deepcopy(design), r6=None if r6 is None else [r6])
+    f = m.fowtList[0]
+    m.F_moor0 = np.zeros(6)
+    m.F_moor0[2] = Fz
+    with contextlib.redirect_stdout(io.StringIO()):
+        drho = m.adjustBallastDensity(f)
+    return {"trim_Fz": float(Fz), "trim_drho": float(drho), "trim_M_struc": np.array(f.M_struc),
+            "trim_C_struc": np.array(f.C_struc), "trim_W_struc": np.array(f.W_struc), "trim_m": float(f.m),
+            "trim_rCG": np.array(f.rCG), "trim_vfill": float(sum(sum(mem.vfill) for mem in f.memberList if hasattr(mem, "vfill")))}
+
+
 def _bare_statics(fowt):
     return {"M_struc_bare": np.array(fowt.M_struc), "C_struc_bare": np.array(fowt.C_struc),
             "W_struc_bare": np.array(fowt.W_struc), "m_bare": float(fowt.m), "rCG_bare": np.array(fowt.rCG)}
@@ -440,6 +455,10 @@ def fixture_geom():
         u = _geom_unit(m.fowtList[0], dj)
         mb = rh.build_model(_bare(design), r6=None if r6 is None else [r6])
         u.update(_bare_statics(mb.fowtList[0]))
+        try:
+            u.update(_trimmed_statics(design, r6, Fz=-1.9e6))
+        except Exception as e:                        # platforms without ballast: the reference raises (:1801-1802)
+            u["trim_error"] = str(e)
         u["name"] = label or name
         units.append(u)
 

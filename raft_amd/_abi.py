@@ -117,7 +117,7 @@ class RaftxLib:
         L.raftx_debug_math.argtypes = [_vp, C.c_int, _vp, _vp, _vp, _vp]
         L.raftx_debug_math.restype = C.c_int
         L.raftx_build_designs.argtypes = [_vp, C.c_int, _vp, _vp, _vp, _vp, _vp, _vp, _vp, C.c_double, C.c_double, C.c_int,
-                                          _vp, C.c_int, _vp, _vp, _vp, _vp, _vp]
+                                          _vp, C.c_int, _vp, _vp, _vp, _vp, _vp, _vp]
         L.raftx_build_designs.restype = C.c_int
         L.raftx_fetch_strips.argtypes = [_vp, _vp, _vp]
         L.raftx_fetch_strips.restype = C.c_int
@@ -211,7 +211,7 @@ class Context:
         self._nw_designs = int(nw)
 
     def build_designs(self, member_off, members, station_off, stations, M0, B0, C0, nw, pose=None, rho=1025.0,
-                      g=9.81, k=None, add_mask=0, MBw=None, cap_off=None, caps=None):
+                      g=9.81, k=None, add_mask=0, MBw=None, cap_off=None, caps=None, Fz_moor=None):
         """Geometry -> resident strip tables (+ statics) on the device: raftx_build_designs.  Member / station / cap
         records as raft_amd/geometry.py packs them.  Returns the strip offsets [nDesign+1]."""
         member_off = np.ascontiguousarray(member_off, dtype=np.int64)
@@ -237,11 +237,13 @@ class Context:
             caps = _f64(caps, (cap_off[-1], 4), "caps")
             if caps.size == 0:
                 caps = np.zeros((1, 4))
+        if Fz_moor is not None:
+            Fz_moor = _f64(Fz_moor, (nD,), "Fz_moor")
         off = np.zeros(nD + 1, dtype=np.int64)
         rc = self.rlib.lib.raftx_build_designs(self._h, nD, _ptr(member_off), _ptr(members), _ptr(station_off),
                                                _ptr(stations), _ptr(cap_off), _ptr(caps if cap_off is not None else None),
                                                _ptr(pose), float(rho), float(g), int(nw), _ptr(k),
-                                               int(add_mask), _ptr(M0), _ptr(B0), _ptr(C0), _ptr(MBw), _ptr(off))
+                                               int(add_mask), _ptr(M0), _ptr(B0), _ptr(C0), _ptr(MBw), _ptr(Fz_moor), _ptr(off))
         self._check(rc, "raftx_build_designs")
         self.nDesign = nD
         self._nw_designs = int(nw)

@@ -116,6 +116,8 @@ struct GeomArgs {
     double *minert;              // [nMember,MI_N]
     int *err;                    // first unsupported cap layout: (member+1), 0 = none
     double *Ms, *Cs, *Ws;        // [nDesign,36] [nDesign,36] [nDesign,6]
+    const double *Fz;            // [nDesign] vertical mooring force for the ballast trim, or null
+    double *drho;                // [nDesign] ballast density correction (RAFTX_TRIM_BALLAST)
     double rho, g;
     int nw;
     const double *k;             // [nw] or null
@@ -315,19 +317,22 @@ __device__ inline void geom_add_submember(double *M, double mass, const double (
 // reference itself cannot handle.
 __device__ inline int geom_member_inertia(const double *gm, const double *gs, int n, const double *gc, int ncap,
                                           const double *rA, const double *q, const double *p1, const double *p2, double g,
-                                          double *out) {
+                                          bool trim, double drho, double *out) {
     GEOM_NOFMA
     const bool circ = gm[RAFTX_GM_SHAPE] != 0.0;
     const int c1 = circ ? 0 : 1;
     const double rho_shell = gm[RAFTX_GM_RHOSHELL];
-    double M[36], mc[3] = {0, 0, 0}, I3[3] = {0, 0, 0};
+    double M[36], mc[3] = {0, 0, 0}, I3[3] = {0, 0, 0}, vfill = 0.0;
     for (int i = 0; i < 36; i++) M[i] = 0.0;
     for (int i = 1; i < n; i++) {
         const double *a = gs + (size_t)(i - 1) * RAFTX_GS_N, *b = gs + (size_t)i * RAFTX_GS_N;
         const double l = b[RAFTX_GS_S] - a[RAFTX_GS_S];
         double mass = 0.0, center[3] = {0, 0, 0};
         if (l > 0) {
-            const double l_fill = a[RAFTX_GS_LFILL], rho_fill = a[RAFTX_GS_RHOFILL];
+            // ballast trim (Model.adjustBallastDensity, raft_model.py:1780-1787,1810-1817): zero-density sections lose
+            // their fill, every ballasted section gets the design's density correction
+            const double l_fill = (trim && a[RAFTX_GS_RHOFILL] == 0.0) ? 0.0 : a[RAFTX_GS_LFILL];
+            const double rho_fill = a[RAFTX_GS_RHOFILL] + (l_fill > 0.0 ? drho : 0.0);
             const double dA0 = a[RAFTX_GS_D], dA1 = a[RAFTX_GS_D + c1], dB0 = b[RAFTX_GS_D], dB1 = b[RAFTX_GS_D + c1];
             const double iA0 = dA0 - 2 * a[RAFTX_GS_T], iA1 = dA1 - 2 * a[RAFTX_GS_T];
             const double iB0 = dB0 - 2 * b[RAFTX_GS_T], iB1 = dB1 - 2 * b[RAFTX_GS_T];
@@ -338,6 +343,7 @@ __device__ inline int geom_member_inertia(const double *gm, const double *gs, in
             const double m_shell = (Vo - Vi) * rho_shell;
             const double hc_shell = (Vo - Vi != 0) ? ((hco * Vo) - (hci * Vi)) / (Vo - Vi) : 0.0;
             geom_frustum(iA0, iA1, f0, f1, circ, l_fill, vf, hcf);
+            vfill += vf;
             const double m_fill = vf * rho_fill;
             mass = m_shell + m_fill;
             const double hc = (mass != 0) ? ((hcf * m_fill) + (hc_shell * m_shell)) / mass : 0.0;
@@ -452,6 +458,7 @@ __device__ inline int geom_member_inertia(const double *gm, const double *gs, in
     out[40] = 0.0; out[41] = 0.0; out[42] = Fz;
     out[43] = dR[1] * Fz; out[44] = -dR[0] * Fz; out[45] = 0.0;
     out[46] = -mass * g * dR[2];
+    out[47] = vfill;                                                                 // member.vfill summed (raft_member.py:506)
     return 0;
 }
 
@@ -620,12 +627,48 @@ __global__ __launch_bounds__(128) void k_geom_member(GeomArgs A) {
     mh[42] = Vt; mh[43] = rcV[0]; mh[44] = rcV[1]; mh[45] = rcV[2]; mh[46] = AWPm; mh[47] = 0.0;
     const int ncap = A.capOff ? (int)(A.capOff[m + 1] - A.capOff[m]) : 0;
     const double *gc = A.capOff ? A.caps + (size_t)A.capOff[m] * RAFTX_GC_N : nullptr;
-    mi[47] = 0.0;
-    const int code = geom_member_inertia(gm, gs, n, gc, ncap, rA, q, p1, p2, A.g, mi);
+    const int code = geom_member_inertia(gm, gs, n, gc, ncap, rA, q, p1, p2, A.g, (A.add_mask & RAFTX_TRIM_BALLAST) != 0, 0.0, mi);
     if (code) {
         for (int i = 0; i < MI_N; i++) mi[i] = 0.0;
         atomicCAS(A.err, 0, (int)(m + 1));
     }
+}
+
+// Model.adjustBallastDensity (raft_model.py:1789-1805), one thread per design: heave imbalance of the untrimmed unit ->
+// density correction of all ballasted sections
+__global__ void k_geom_trim(GeomArgs A) {
+    GEOM_NOFMA
+    const int d = blockIdx.x * blockDim.x + threadIdx.x;
+    if (d >= A.nDesign) return;
+    double mass = A.M0[(size_t)d * 36], V = 0.0, vol = 0.0;
+    for (int64_t m = A.memberOff[d]; m < A.memberOff[d + 1]; m++) {
+        mass += A.minert[(size_t)m * MI_N + 36];
+        vol += A.minert[(size_t)m * MI_N + 47];
+        V += A.mhyd[(size_t)m * MH_N + 42];
+    }
+    if (!(vol > 0.0)) {
+        A.drho[d] = 0.0;
+        atomicCAS(A.err + 1, 0, d + 1);                       // "can only be used for platforms that have some ballast volume"
+        return;
+    }
+    const double sumFz = -mass * A.g + V * A.rho * A.g + (A.Fz ? A.Fz[d] : 0.0);
+    A.drho[d] = sumFz / A.g / vol;
+}
+// ... and the statics recomputed with the corrected densities (:1820), one thread per member
+__global__ __launch_bounds__(128) void k_geom_reinertia(GeomArgs A) {
+    GEOM_NOFMA
+    const int64_t m = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (m >= A.nMember) return;
+    const double *gm = A.gm + (size_t)m * RAFTX_GM_N;
+    if ((int)gm[RAFTX_GM_FLAGS] & RAFTX_GM_FLAG_NOSTATIC) return;
+    const double *gs = A.gs + (size_t)A.stationOff[m] * RAFTX_GS_N;
+    const int n = (int)(A.stationOff[m + 1] - A.stationOff[m]);
+    const double *mp = A.mpose + (size_t)m * MP_N;
+    const int ncap = A.capOff ? (int)(A.capOff[m + 1] - A.capOff[m]) : 0;
+    const double *gc = A.capOff ? A.caps + (size_t)A.capOff[m] * RAFTX_GC_N : nullptr;
+    double *mi = A.minert + (size_t)m * MI_N;
+    if (geom_member_inertia(gm, gs, n, gc, ncap, mp + 3, mp + 6, mp + 9, mp + 12, A.g, true, A.drho[A.mdesign[m]], mi))
+        for (int i = 0; i < MI_N; i++) mi[i] = 0.0;
 }
 
 // exclusive scans of the per-member counts (one workgroup; nMember is ~1e5 for a 10k-design sweep)
@@ -916,6 +959,10 @@ __global__ __launch_bounds__(64) void k_geom_design(GeomArgs A) {
     for (int i = 0; i < 6; i++) { A.Wh[(size_t)d * 6 + i] = Wh[i]; A.Ws[(size_t)d * 6 + i] = Ws[i]; }
     double *pr = A.props + (size_t)d * RAFTX_SP_N;
     for (int i = 0; i < RAFTX_SP_N; i++) pr[i] = 0.0;
+    double vfill = 0.0;
+    for (int64_t m = A.memberOff[d]; m < A.memberOff[d + 1]; m++) vfill += A.minert[(size_t)m * MI_N + 47];
+    pr[RAFTX_SP_VFILL] = vfill;
+    pr[RAFTX_SP_DRHO] = (A.add_mask & RAFTX_TRIM_BALLAST) ? A.drho[d] : 0.0;
     pr[RAFTX_SP_V] = Vt;
     pr[RAFTX_SP_MASS] = Ms[0];                                                            // raft_fowt.py:1206-1207
     for (int c = 0; c < 3; c++) pr[RAFTX_SP_RCG + c] = Ms[0] != 0.0 ? sMr[c] / Ms[0] : 0.0;

@@ -529,7 +529,7 @@ extern "C" int raftx_build_designs(raftx_ctx *c, int nDesign, const int64_t *mem
                                    const int64_t *stationOff, const double *stations, const int64_t *capOff,
                                    const double *caps, const double *pose, double rho, double g, int nw, const double *k,
                                    int add_mask, const double *M0, const double *B0, const double *C0, const double *MBw,
-                                   int64_t *stripOffsets) {
+                                   const double *Fz_moor, int64_t *stripOffsets) {
     if (!c) return -1;
     if (nDesign < 0 || !memberOff || !members || !stationOff || !stations || !M0 || !B0 || !C0 || !stripOffsets)
         FAIL(c, "build_designs: bad arguments");
@@ -580,13 +580,27 @@ extern "C" int raftx_build_designs(raftx_ctx *c, int nDesign, const int64_t *mem
     if (dev_alloc(c, tmp, (size_t)nMember, &A.cnt) || dev_alloc(c, tmp, (size_t)nMember, &A.cntm) ||
         dev_alloc(c, tmp, (size_t)nMember + 1, &A.soff) || dev_alloc(c, tmp, (size_t)nMember + 1, &A.cmsoff) ||
         dev_alloc(c, tmp, (size_t)nMember * MP_N, &A.mpose) || dev_alloc(c, tmp, (size_t)nMember * MH_N, &A.mhyd) ||
-        dev_alloc(c, tmp, (size_t)nMember * MI_N, &A.minert) || dev_alloc(c, tmp, 1, &A.err, true) ||
+        dev_alloc(c, tmp, (size_t)nMember * MI_N, &A.minert) || dev_alloc(c, tmp, 2, &A.err, true) ||
+        dev_alloc(c, tmp, (size_t)nDesign, &A.drho, true) ||
         dev_alloc(c, c->design_allocs, (size_t)nDesign + 1, &A.off) ||
         dev_alloc(c, c->design_allocs, (size_t)nDesign + 1, &A.cmoff))
         return -2;
+    double *M0d = nullptr, *C0d = nullptr;
+    if (dev_alloc(c, c->design_allocs, (size_t)nDesign * 36, &M0d) || dev_alloc(c, c->design_allocs, (size_t)nDesign * 36, &C0d))
+        return -2;
+    HIPCHK(c, hipMemcpyAsync(M0d, M0, (size_t)nDesign * 36 * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(C0d, C0, (size_t)nDesign * 36 * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    A.M0 = M0d;
+    A.C0 = C0d;
+    if (Fz_moor) rc |= upload(c, tmp, Fz_moor, (size_t)nDesign, &A.Fz);
+    if (rc) return -2;
     HIPCHK(c, hipEventRecord(c->ev0, c->stream));
     if (nMember > 0) {
         hipLaunchKernelGGL(k_geom_member, dim3((unsigned)((nMember + 127) / 128)), dim3(128), 0, c->stream, A);
+        if (add_mask & RAFTX_TRIM_BALLAST) {              // heave trim: density correction, then the inertia again
+            hipLaunchKernelGGL(k_geom_trim, dim3((unsigned)(nDesign / 128 + 1)), dim3(128), 0, c->stream, A);
+            hipLaunchKernelGGL(k_geom_reinertia, dim3((unsigned)((nMember + 127) / 128)), dim3(128), 0, c->stream, A);
+        }
         hipLaunchKernelGGL(k_geom_scan, dim3(1), dim3(1024), 0, c->stream, A);
     } else {
         HIPCHK(c, hipMemsetAsync(A.soff, 0, sizeof(int64_t), c->stream));
@@ -596,35 +610,29 @@ extern "C" int raftx_build_designs(raftx_ctx *c, int nDesign, const int64_t *mem
     std::vector<int64_t> cmoffh((size_t)nDesign + 1);
     HIPCHK(c, hipMemcpyAsync(stripOffsets, A.off, ((size_t)nDesign + 1) * sizeof(int64_t), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipMemcpyAsync(cmoffh.data(), A.cmoff, ((size_t)nDesign + 1) * sizeof(int64_t), hipMemcpyDeviceToHost, c->stream));
-    int bad_member = 0;
-    HIPCHK(c, hipMemcpyAsync(&bad_member, A.err, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    int bad[2] = {0, 0};
+    HIPCHK(c, hipMemcpyAsync(bad, A.err, 2 * sizeof(int), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipEventRecord(c->ev1, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     HIPCHK(c, hipGetLastError());
     float ms_a = 0.f;                              // first segment: member pass + scans (+ the small D2H of the offsets)
     HIPCHK(c, hipEventElapsedTime(&ms_a, c->ev0, c->ev1));
-    if (bad_member)
-        FAIL(c, "member %d: cap/bulkhead layout not supported (the reference raises here too)", bad_member - 1);
+    if (bad[0]) FAIL(c, "member %d: cap/bulkhead layout not supported (the reference raises here too)", bad[0] - 1);
+    if (bad[1]) FAIL(c, "design %d: ballast trim needs some ballast volume", bad[1] - 1);
     const size_t nStrips = (size_t)stripOffsets[nDesign], nRows = (size_t)cmoffh[(size_t)nDesign];
     int maxS = 0;
     for (int d = 0; d < nDesign; d++) {
         const int64_t S = stripOffsets[d + 1] - stripOffsets[d];
         if (S > maxS) maxS = (int)S;
     }
-    double *M0d = nullptr, *C0d = nullptr;
     if (dev_alloc(c, c->design_allocs, nStrips * NF, &A.abi) || dev_alloc(c, c->design_allocs, nStrips * DS_N, &A.ds) ||
         dev_alloc(c, c->design_allocs, nStrips, &A.dsi) || dev_alloc(c, c->design_allocs, nRows * 3, &A.mcfaux) ||
         dev_alloc(c, c->design_allocs, nRows * 2 * (size_t)nw, &A.cm) ||
         dev_alloc(c, c->design_allocs, (size_t)nDesign * 36, &A.A) || dev_alloc(c, c->design_allocs, (size_t)nDesign * 36, &A.Ch) ||
         dev_alloc(c, c->design_allocs, (size_t)nDesign * 6, &A.Wh) || dev_alloc(c, c->design_allocs, (size_t)nDesign * 36, &A.Ms) ||
         dev_alloc(c, c->design_allocs, (size_t)nDesign * 36, &A.Cs) || dev_alloc(c, c->design_allocs, (size_t)nDesign * 6, &A.Ws) ||
-        dev_alloc(c, c->design_allocs, (size_t)nDesign * RAFTX_SP_N, &A.props) ||
-        dev_alloc(c, c->design_allocs, (size_t)nDesign * 36, &M0d) || dev_alloc(c, c->design_allocs, (size_t)nDesign * 36, &C0d))
+        dev_alloc(c, c->design_allocs, (size_t)nDesign * RAFTX_SP_N, &A.props))
         return -2;
-    HIPCHK(c, hipMemcpyAsync(M0d, M0, (size_t)nDesign * 36 * sizeof(double), hipMemcpyHostToDevice, c->stream));
-    HIPCHK(c, hipMemcpyAsync(C0d, C0, (size_t)nDesign * 36 * sizeof(double), hipMemcpyHostToDevice, c->stream));
-    A.M0 = M0d;
-    A.C0 = C0d;
     HIPCHK(c, hipEventRecord(c->ev0, c->stream));
     if (nMember > 0) hipLaunchKernelGGL(k_geom_fill, dim3((unsigned)nMember), dim3(64), 0, c->stream, A);
     if (nRows > 0)

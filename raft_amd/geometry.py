@@ -25,8 +25,8 @@ GM_N, GS_N, GC_N = 16, 16, 4
 GM_RA, GM_RB, GM_GAMMA, GM_SHAPE, GM_DLSMAX, GM_FLAGS, GM_L, GM_RHOSHELL = 0, 3, 6, 7, 8, 9, 10, 11
 GS_S, GS_D, GS_T, GS_CD, GS_CA, GS_LFILL, GS_RHOFILL = 0, 1, 3, 4, 8, 12, 13
 FLAG_POTMOD, FLAG_MCF, FLAG_NOSTATIC = 1, 2, 4
-ADD_MORISON, ADD_HYDROSTATIC, ADD_INERTIA = 1, 2, 4
-SP_N, SP_V, SP_AWP, SP_RCB, SP_MASS, SP_RCG = 12, 0, 1, 2, 5, 6
+ADD_MORISON, ADD_HYDROSTATIC, ADD_INERTIA, TRIM_BALLAST = 1, 2, 4, 8
+SP_N, SP_V, SP_AWP, SP_RCB, SP_MASS, SP_RCG, SP_DRHO, SP_VFILL = 12, 0, 1, 2, 5, 6, 9, 10
 
 
 class UnsupportedMember(Exception):

@@ -259,3 +259,55 @@ def test_hip_c3_from_member_descriptions_to_reference_responses(hip_ctx):
     for j, sol in enumerate(C3["solved"]):
         assert int(out["niter"][j, 0]) == int(sol["units"][0]["niter"])
         assert group_rel_err(out["Xi"][j, 0, :1], np.asarray(sol["Xi"])[:1]) < 1e-9
+
+
+# ------------------------------------------------------------------ ballast trim (Model.adjustBallastDensity)
+TRIM_NAMES = [n for n in NAMES if "trim_drho" in UNITS[n]]
+
+
+def check_trim(ctx, u, tol):
+    """RAFTX_TRIM_BALLAST against the live reference's adjustBallastDensity on the full model: the density change,
+    the total ballast volume, and the statics after the trim (M_extra carries the rotor-nacelle assembly)."""
+    D = G.concat_units([tables_of(u)])
+    M_rna = (np.asarray(u["M_struc"]) - np.asarray(u["M_struc_bare"]))[None]
+    C_rna = (np.asarray(u["C_struc"]) - np.asarray(u["C_struc_bare"]))[None]
+    W_rna = np.asarray(u["W_struc"]) - np.asarray(u["W_struc_bare"])
+    Z = np.zeros((1, 6, 6))
+    ctx.build_designs(D.member_off, D.members, D.station_off, D.stations, M_rna, Z, C_rna, len(u["w"]),
+                      pose=np.array(u["pose"])[None], rho=u["rho"], g=u["g"], k=u["k"], cap_off=D.cap_off, caps=D.caps,
+                      add_mask=G.TRIM_BALLAST, Fz_moor=np.array([u["trim_Fz"]]))
+    S = ctx.fetch_statics()
+    assert abs(S["props"][0, G.SP_VFILL] / u["trim_vfill"] - 1) < tol
+    assert abs(S["props"][0, G.SP_DRHO] - u["trim_drho"]) < 1e-9 * max(1.0, abs(u["trim_drho"])) + 1e-7
+    assert rel_err(S["M_struc"][0] + M_rna[0], u["trim_M_struc"]) < max(tol, 2e-9)
+    assert rel_err(S["C_struc"][0] + C_rna[0], u["trim_C_struc"]) < max(tol, 1e-10)
+    assert rel_err(S["W_struc"][0] + W_rna, u["trim_W_struc"]) < max(tol, 1e-10)
+    m_rna = M_rna[0, 0, 0]
+    assert abs((S["props"][0, G.SP_MASS] + m_rna) / u["trim_m"] - 1) < max(tol, 1e-11)
+    # heave balance after the trim: weight = buoyancy + mooring
+    assert abs(-(S["props"][0, G.SP_MASS] + m_rna) * u["g"] + S["props"][0, G.SP_V] * u["rho"] * u["g"] + u["trim_Fz"]) \
+        < 1e-9 * u["trim_m"] * u["g"]
+
+
+@pytest.mark.parametrize("name", TRIM_NAMES)
+def test_oracle_ballast_trim_against_live_reference(name, oracle_ctx):
+    check_trim(oracle_ctx, UNITS[name], TOL)
+
+
+def test_ballast_trim_needs_ballast(oracle_ctx):
+    u = UNITS["OC3spar"]
+    t = tables_of(u)
+    st = t.stations.copy()
+    st[:, G.GS_LFILL] = 0.0
+    D = G.concat_units([G.MemberTable(list(t.members), [st[t.station_off[i]:t.station_off[i + 1]] for i in range(t.n)],
+                                      [t.caps[t.cap_off[i]:t.cap_off[i + 1]] for i in range(t.n)])])
+    Z = np.zeros((1, 6, 6))
+    with pytest.raises(RaftxError):                   # the reference raises too (raft_model.py:1801-1802)
+        oracle_ctx.build_designs(D.member_off, D.members, D.station_off, D.stations, Z, Z, Z, 4, cap_off=D.cap_off,
+                                 caps=D.caps, add_mask=G.TRIM_BALLAST)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", TRIM_NAMES)
+def test_hip_ballast_trim_against_live_reference(name, hip_ctx):
+    check_trim(hip_ctx, UNITS[name], 1e-11)
