@@ -311,3 +311,42 @@ def test_ballast_trim_needs_ballast(oracle_ctx):
 @pytest.mark.parametrize("name", TRIM_NAMES)
 def test_hip_ballast_trim_against_live_reference(name, hip_ctx):
     check_trim(hip_ctx, UNITS[name], 1e-11)
+
+
+# ------------------------------------------------------------------ empty / ragged inputs
+def check_ragged(ctx):
+    """No designs at all; a design whose only member is dry (no strips, no buoyancy); that design in the middle of a
+    batch, solved: its response to waves is exactly zero and its neighbours are unaffected."""
+    Z0 = np.zeros((0, 6, 6))
+    off = ctx.build_designs(np.zeros(1, dtype=np.int64), np.zeros((0, 16)), np.zeros(1, dtype=np.int64), np.zeros((0, 16)),
+                            Z0, Z0, Z0, 8)
+    assert off.tolist() == [0]
+    u = UNITS["OC3spar"]
+    t = tables_of(u)
+    tower = G.MemberTable([t.members[1]], [t.stations[t.station_off[1]:t.station_off[2]]], [t.caps[t.cap_off[1]:t.cap_off[2]]])
+    assert tower.members[0, G.GM_RA + 2] > 0                        # the tower starts above the waterline
+    D = G.concat_units([t, tower, t])
+    nw = len(u["w"])
+    M0 = np.repeat((np.eye(6) * [8e6, 8e6, 8e6, 7e9, 7e9, 2e8])[None], 3, 0)
+    C0 = np.repeat(np.diag([4e4, 4e4, 3e5, 1e9, 1e9, 1e8])[None], 3, 0)
+    off = ctx.build_designs(D.member_off, D.members, D.station_off, D.stations, M0, np.zeros((3, 6, 6)), C0, nw,
+                            rho=u["rho"], g=u["g"], cap_off=D.cap_off, caps=D.caps, add_mask=G.ADD_MORISON)
+    assert off[1] == off[2] and off[1] - off[0] == off[3] - off[2] == len(u["strips"])
+    S = ctx.fetch_statics()
+    assert not np.any(S["A_morison"][1]) and not np.any(S["C_hydro"][1]) and S["props"][1, G.SP_V] == 0.0
+    assert S["props"][1, G.SP_MASS] > 1e5                            # ... but it has mass
+    rng = np.random.default_rng(2)
+    zeta = rng.uniform(0.1, 0.5, size=(1, 1, nw))
+    ctx.upload_cases(u["w"], u["k"], 320.0, u["rho"], u["g"], zeta, np.array([[0.4]]))
+    out = ctx.solve_dynamics(5, 0.01, 0.1)
+    assert not np.any(out["Xi"][1]) and not np.any(out["flags"] & 2)
+    assert np.array_equal(out["Xi"][0].view(np.uint64), out["Xi"][2].view(np.uint64)) and np.any(out["Xi"][0])
+
+
+def test_oracle_empty_and_ragged_batches(oracle_ctx):
+    check_ragged(oracle_ctx)
+
+
+@pytest.mark.gpu
+def test_hip_empty_and_ragged_batches(hip_ctx):
+    check_ragged(hip_ctx)
