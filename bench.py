@@ -180,11 +180,19 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     dist = None
+    # RAFTX_BENCH_BACKEND=gloo + RAFTX_BENCH_DEVICE=0: rehearsal of the multi-rank path on a single-GPU box (all ranks
+    # share device 0, host tensors for the two collectives); the driver's runs use RCCL with one GPU per rank
+    backend_name = os.environ.get("RAFTX_BENCH_BACKEND", "nccl")
+    if "RAFTX_BENCH_DEVICE" in os.environ:
+        local = int(os.environ["RAFTX_BENCH_DEVICE"])
     if world > 1:
         import torch
         import torch.distributed as dist
         torch.cuda.set_device(local)
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local))
+        if backend_name == "nccl":
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group(backend=backend_name)
 
     from raft_amd import backend
     ctx = backend.hip_library().context(local)
@@ -217,7 +225,7 @@ def main():
     elapsed = time.perf_counter() - t0
     if dist is not None:
         import torch
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if backend_name == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
