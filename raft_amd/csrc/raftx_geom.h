@@ -7,7 +7,8 @@
 // (:811-1201) -- runs here as five small kernels over ALL designs of a sweep at once:
 //
 //   k_geom_member   one thread per member : pose (q, p1, p2, R, end A), wet-strip count, member hydrostatics
-//   k_geom_scan     one workgroup         : exclusive scans of the wet / MacCamy-Fuchs strip counts
+//   k_geom_design_counts / k_geom_scan / k_geom_offsets : exclusive scans of the wet / MacCamy-Fuchs strip counts
+//                   (per-design totals, one-workgroup scan over designs, member offsets inside each design)
 //   k_geom_fill     one wavefront / member: lanes = strips; compacted with ballots into the design's strip table
 //   k_geom_mcf      (row, bin)            : MacCamy-Fuchs complex Cm table (Hankel functions)
 //   k_geom_design   one thread per design : run detection for the rotor recurrences (the same routine the host
@@ -671,40 +672,53 @@ __global__ __launch_bounds__(128) void k_geom_reinertia(GeomArgs A) {
         for (int i = 0; i < MI_N; i++) mi[i] = 0.0;
 }
 
-// exclusive scans of the per-member counts (one workgroup; nMember is ~1e5 for a 10k-design sweep)
+// Exclusive scans of the per-member wet-strip / MacCamy-Fuchs-row counts, in three steps that all run wide: per-design
+// totals (thread per design), a scan over the DESIGNS (one workgroup; 10^4 entries instead of 10^5 members), and the
+// member offsets inside every design (thread per design).
+__global__ void k_geom_design_counts(GeomArgs A) {
+    const int d = blockIdx.x * blockDim.x + threadIdx.x;
+    if (d >= A.nDesign) return;
+    long long a = 0, b = 0;
+    for (int64_t m = A.memberOff[d]; m < A.memberOff[d + 1]; m++) { a += A.cnt[m]; b += A.cntm[m]; }
+    A.off[d + 1] = a;                                    // totals parked one slot up; k_geom_scan turns them into offsets
+    A.cmoff[d + 1] = b;
+}
 __global__ __launch_bounds__(1024) void k_geom_scan(GeomArgs A) {
     __shared__ long long part[2][1024];
     const int t = threadIdx.x, T = blockDim.x;
-    const int64_t n = A.nMember;
-    const int64_t per = (n + T - 1) / T, lo = (int64_t)t * per, hi = (lo + per < n) ? lo + per : n;
+    const int n = A.nDesign;
+    const int per = (n + T - 1) / T, lo = t * per, hi = (lo + per < n) ? lo + per : n;
     long long a = 0, b = 0;
-    for (int64_t i = lo; i < hi; i++) { a += A.cnt[i]; b += A.cntm[i]; }
+    for (int i = lo; i < hi; i++) { a += A.off[i + 1]; b += A.cmoff[i + 1]; }
     part[0][t] = a; part[1][t] = b;
     __syncthreads();
     if (t == 0) {
         long long sa = 0, sb = 0;
         for (int i = 0; i < T; i++) {
-            long long x = part[0][i], y = part[1][i];
+            const long long x = part[0][i], y = part[1][i];
             part[0][i] = sa; part[1][i] = sb;
             sa += x; sb += y;
         }
-        A.soff[n] = sa;
-        A.cmsoff[n] = sb;
+        A.off[0] = 0;
+        A.cmoff[0] = 0;
     }
     __syncthreads();
     a = part[0][t]; b = part[1][t];
-    for (int64_t i = lo; i < hi; i++) {
-        A.soff[i] = a; A.cmsoff[i] = b;
-        a += A.cnt[i]; b += A.cntm[i];
+    for (int i = lo; i < hi; i++) {                      // inclusive running totals -> offsets of design i+1
+        a += A.off[i + 1]; b += A.cmoff[i + 1];
+        A.off[i + 1] = a; A.cmoff[i + 1] = b;
     }
 }
-// per-design offsets from the per-member scans
+// member offsets from the design offsets
 __global__ void k_geom_offsets(GeomArgs A) {
     const int d = blockIdx.x * blockDim.x + threadIdx.x;
-    if (d > A.nDesign) return;
-    const int64_t m = A.memberOff[d];
-    A.off[d] = A.soff[m];
-    A.cmoff[d] = A.cmsoff[m];
+    if (d >= A.nDesign) return;
+    int64_t a = A.off[d], b = A.cmoff[d];
+    for (int64_t m = A.memberOff[d]; m < A.memberOff[d + 1]; m++) {
+        A.soff[m] = a; A.cmsoff[m] = b;
+        a += A.cnt[m]; b += A.cntm[m];
+    }
+    if (d == A.nDesign - 1) { A.soff[A.nMember] = a; A.cmsoff[A.nMember] = b; }
 }
 
 // one wavefront per member: lanes = strips of a group; wet strips are compacted with ballots

@@ -601,12 +601,17 @@ extern "C" int raftx_build_designs(raftx_ctx *c, int nDesign, const int64_t *mem
             hipLaunchKernelGGL(k_geom_trim, dim3((unsigned)(nDesign / 128 + 1)), dim3(128), 0, c->stream, A);
             hipLaunchKernelGGL(k_geom_reinertia, dim3((unsigned)((nMember + 127) / 128)), dim3(128), 0, c->stream, A);
         }
-        hipLaunchKernelGGL(k_geom_scan, dim3(1), dim3(1024), 0, c->stream, A);
     } else {
         HIPCHK(c, hipMemsetAsync(A.soff, 0, sizeof(int64_t), c->stream));
         HIPCHK(c, hipMemsetAsync(A.cmsoff, 0, sizeof(int64_t), c->stream));
     }
-    hipLaunchKernelGGL(k_geom_offsets, dim3((unsigned)(nDesign / 256 + 1)), dim3(256), 0, c->stream, A);
+    HIPCHK(c, hipMemsetAsync(A.off, 0, sizeof(int64_t), c->stream));
+    HIPCHK(c, hipMemsetAsync(A.cmoff, 0, sizeof(int64_t), c->stream));
+    if (nDesign > 0) {
+        hipLaunchKernelGGL(k_geom_design_counts, dim3((unsigned)(nDesign / 256 + 1)), dim3(256), 0, c->stream, A);
+        hipLaunchKernelGGL(k_geom_scan, dim3(1), dim3(1024), 0, c->stream, A);
+        hipLaunchKernelGGL(k_geom_offsets, dim3((unsigned)(nDesign / 256 + 1)), dim3(256), 0, c->stream, A);
+    }
     std::vector<int64_t> cmoffh((size_t)nDesign + 1);
     HIPCHK(c, hipMemcpyAsync(stripOffsets, A.off, ((size_t)nDesign + 1) * sizeof(int64_t), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipMemcpyAsync(cmoffh.data(), A.cmoff, ((size_t)nDesign + 1) * sizeof(int64_t), hipMemcpyDeviceToHost, c->stream));
