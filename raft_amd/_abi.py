@@ -323,9 +323,16 @@ class Context:
                                                        _ptr(F_extra), int(want_mask))
         self._check(rc, "raftx_solve_dynamics_device")
 
-    def fetch_results(self, want_Xi=True, want_B=False, want_F=False, want_Z=False):
+    def fetch_results(self, want_Xi=True, want_B=False, want_F=False, want_Z=False, Xi_out=None):
+        """Xi_out: optional preallocated C-contiguous complex128 [nDesign,nCase,nHead,6,nw] buffer (e.g. a slice of a
+        larger array along the design axis) the responses are copied into instead of a fresh array."""
         nD, nC, nH, nw = self.nDesign, self.nCase, self.nHead, self.nw
-        Xi = np.empty((nD, nC, nH, 6, nw), dtype=np.complex128) if want_Xi else None
+        if Xi_out is not None:
+            if Xi_out.dtype != np.complex128 or Xi_out.shape != (nD, nC, nH, 6, nw) or not Xi_out.flags["C_CONTIGUOUS"]:
+                raise ValueError("Xi_out must be a C-contiguous complex128 array of shape %s" % ((nD, nC, nH, 6, nw),))
+            Xi = Xi_out
+        else:
+            Xi = np.empty((nD, nC, nH, 6, nw), dtype=np.complex128) if want_Xi else None
         niter = np.zeros((nD, nC), dtype=np.int32)
         flags = np.zeros((nD, nC), dtype=np.int32)
         B = np.empty((nD, nC, 6, 6), dtype=np.float64) if want_B else None

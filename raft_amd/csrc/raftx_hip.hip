@@ -28,6 +28,8 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <map>
+#include <unordered_map>
 #include <vector>
 
 #include "../../include/raftx.h"
@@ -317,12 +319,65 @@ __global__ void __launch_bounds__(256) k_channel_stats_poly(int nCase, int nHead
 }
 
 // ------------------------------------------------------------------ host side
+// Per-context device-memory pool: every call of the C-ABI needs a handful of device buffers (tables, results, scratch);
+// hipMalloc / hipFree cost 0.1-1 ms each and hipFree synchronises the whole device, which serialises contexts that
+// otherwise overlap copies and kernels on their own streams.  Blocks are rounded up (powers of two below 1 MiB, 1 MiB
+// multiples above), cached on release and handed out again; everything goes back to the driver in raftx_ctx_destroy.
+// Callers return blocks only after their stream has drained.
+struct DevPool {
+    std::multimap<size_t, void *> free_;
+    std::unordered_map<void *, size_t> size_;
+    static size_t round_up(size_t b) {
+        if (b < 256) b = 256;
+        if (b <= ((size_t)1 << 20)) {
+            size_t p = 256;
+            while (p < b) p <<= 1;
+            return p;
+        }
+        return (b + ((size_t)1 << 20) - 1) & ~(((size_t)1 << 20) - 1);
+    }
+    hipError_t get(size_t bytes, void **out) {
+        const size_t cap = round_up(bytes);
+        auto it = free_.lower_bound(cap);
+        if (it != free_.end() && it->first <= cap + cap / 2 + ((size_t)1 << 20)) {
+            *out = it->second;
+            free_.erase(it);
+            return hipSuccess;
+        }
+        hipError_t e = hipMalloc(out, cap);
+        if (e != hipSuccess) {                      // make room and retry once
+            (void)hipGetLastError();
+            trim();
+            e = hipMalloc(out, cap);
+        }
+        if (e == hipSuccess) size_[*out] = cap;
+        return e;
+    }
+    void put(void *p) {
+        if (!p) return;
+        auto it = size_.find(p);
+        if (it == size_.end()) {
+            (void)hipFree(p);
+            return;
+        }
+        free_.emplace(it->second, p);
+    }
+    void trim() {
+        for (auto &kv : free_) {
+            size_.erase(kv.second);
+            (void)hipFree(kv.second);
+        }
+        free_.clear();
+    }
+};
+
 struct raftx_ctx {
     int device;
     hipStream_t stream;
     hipEvent_t ev0, ev1;
     char err[512];
     DevTables T;
+    DevPool pool;
     std::vector<void *> design_allocs, case_allocs, result_allocs;
     // resident results of the last raftx_solve_dynamics_device
     cplx *rXi, *rFw, *rZ, *rFe;
@@ -422,9 +477,8 @@ extern "C" int raftx_ctx_create(int device_id, raftx_ctx **out) {
     return 0;
 }
 
-static void free_list(std::vector<void *> &v) {
-    for (void *p : v)
-        if (p) (void)hipFree(p);
+static void free_list(raftx_ctx *c, std::vector<void *> &v) {
+    for (void *p : v) c->pool.put(p);
     v.clear();
 }
 
@@ -432,9 +486,10 @@ extern "C" void raftx_ctx_destroy(raftx_ctx *c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
-    free_list(c->design_allocs);
-    free_list(c->case_allocs);
-    free_list(c->result_allocs);
+    free_list(c, c->design_allocs);
+    free_list(c, c->case_allocs);
+    free_list(c, c->result_allocs);
+    c->pool.trim();
     if (c->rXl) (void)hipFree(c->rXl);
     if (c->rXl0) (void)hipFree(c->rXl0);
     if (c->rXlOut) (void)hipFree(c->rXlOut);
@@ -455,7 +510,7 @@ static int upload(raftx_ctx *c, std::vector<void *> &bag, const Tp *host, size_t
     *dev = nullptr;
     if (!host || n == 0) return 0;
     void *p = nullptr;
-    HIPCHK(c, hipMalloc(&p, n * sizeof(Tp)));
+    HIPCHK(c, c->pool.get(n * sizeof(Tp), &p));
     bag.push_back(p);
     HIPCHK(c, hipMemcpyAsync(p, host, n * sizeof(Tp), hipMemcpyHostToDevice, c->stream));
     *dev = reinterpret_cast<const Tp *>(p);
@@ -470,7 +525,7 @@ extern "C" int raftx_upload_designs(raftx_ctx *c, int nDesign, const int64_t *st
     if (nDesign < 0 || !stripOffsets || !M0 || !B0 || !C0) FAIL(c, "upload_designs: bad arguments");
     HIPCHK(c, hipSetDevice(c->device));
     HIPCHK(c, hipStreamSynchronize(c->stream));
-    free_list(c->design_allocs);
+    free_list(c, c->design_allocs);
     c->have_designs = false;
     c->bem_ready = false;
     int maxS = 0;
@@ -518,7 +573,7 @@ template <typename Tp>
 static int dev_alloc(raftx_ctx *c, std::vector<void *> &bag, size_t n, Tp **out, bool zero = false) {
     *out = nullptr;
     void *p = nullptr;
-    HIPCHK(c, hipMalloc(&p, (n ? n : 1) * sizeof(Tp)));
+    HIPCHK(c, c->pool.get((n ? n : 1) * sizeof(Tp), &p));
     bag.push_back(p);
     if (zero) HIPCHK(c, hipMemsetAsync(p, 0, (n ? n : 1) * sizeof(Tp), c->stream));
     *out = reinterpret_cast<Tp *>(p);
@@ -553,12 +608,19 @@ extern "C" int raftx_build_designs(raftx_ctx *c, int nDesign, const int64_t *mem
     if (any_mcf && !k) FAIL(c, "build_designs: a member is MacCamy-Fuchs but no wave numbers were given");
     HIPCHK(c, hipSetDevice(c->device));
     HIPCHK(c, hipStreamSynchronize(c->stream));
-    free_list(c->design_allocs);
+    free_list(c, c->design_allocs);
     c->have_designs = false;
     c->bem_ready = false;
     c->g_n = 0;
     std::vector<void *> tmp;                       // descriptor uploads and per-member scratch, freed on return
-    struct Guard { std::vector<void *> &v; ~Guard() { free_list(v); } } guard{tmp};
+    struct Guard {
+        raftx_ctx *c;
+        std::vector<void *> &v;
+        ~Guard() {
+            (void)hipStreamSynchronize(c->stream);
+            free_list(c, v);
+        }
+    } guard{c, tmp};
     GeomArgs A;
     memset(&A, 0, sizeof(A));
     A.nDesign = nDesign;
@@ -710,7 +772,7 @@ extern "C" int raftx_upload_cases(raftx_ctx *c, int nCase, int nHead, int nw, co
     if (nw > MAX_NW) FAIL(c, "nw=%d exceeds the %d bins per workgroup supported by this build", nw, MAX_NW);
     HIPCHK(c, hipSetDevice(c->device));
     HIPCHK(c, hipStreamSynchronize(c->stream));
-    free_list(c->case_allocs);
+    free_list(c, c->case_allocs);
     c->have_cases = false;
     c->bem_ready = false;
     // per-bin depth constants, computed once on the host in full libm precision.  The kernels derive
@@ -823,12 +885,15 @@ struct Scratch {
     raftx_ctx *c;
     std::vector<void *> bag;
     explicit Scratch(raftx_ctx *c_) : c(c_) {}
-    ~Scratch() { free_list(bag); }
+    ~Scratch() {
+        (void)hipStreamSynchronize(c->stream);      // blocks go back to the pool only when nothing in flight uses them
+        free_list(c, bag);
+    }
     template <typename Tp>
     Tp *alloc(size_t n) {
         void *p = nullptr;
         if (n == 0) return nullptr;
-        if (hipMalloc(&p, n * sizeof(Tp)) != hipSuccess) return nullptr;
+        if (c->pool.get(n * sizeof(Tp), &p) != hipSuccess) return nullptr;
         bag.push_back(p);
         return reinterpret_cast<Tp *>(p);
     }
@@ -909,7 +974,7 @@ template <typename Tp>
 static Tp *dev_alloc(raftx_ctx *c, size_t n) {
     void *p = nullptr;
     if (n == 0) n = 1;
-    if (hipMalloc(&p, n * sizeof(Tp)) != hipSuccess) return nullptr;
+    if (c->pool.get(n * sizeof(Tp), &p) != hipSuccess) return nullptr;
     c->result_allocs.push_back(p);
     return reinterpret_cast<Tp *>(p);
 }
@@ -923,7 +988,7 @@ static int ensure_results(raftx_ctx *c, int want_mask, bool need_fe) {
               (c->r_mask & want_mask) == want_mask && (!need_fe || c->r_fe);
     if (ok) return 0;
     HIPCHK(c, hipStreamSynchronize(c->stream));
-    free_list(c->result_allocs);
+    free_list(c, c->result_allocs);
     c->rXi = c->rFw = c->rZ = c->rFe = nullptr;
     c->rB = nullptr;
     c->rNi = c->rFl = nullptr;
@@ -936,7 +1001,7 @@ static int ensure_results(raftx_ctx *c, int want_mask, bool need_fe) {
     if (need_fe) c->rFe = dev_alloc<cplx>(c, nx);
     if (!c->rXi || !c->rNi || !c->rFl || ((want_mask & RAFTX_WANT_BDRAG) && !c->rB) ||
         ((want_mask & RAFTX_WANT_FWAVE) && !c->rFw) || ((want_mask & RAFTX_WANT_Z) && !c->rZ) || (need_fe && !c->rFe)) {
-        free_list(c->result_allocs);
+        free_list(c, c->result_allocs);
         c->rXi = nullptr;
         FAIL(c, "solve_dynamics: device allocation of result buffers failed");
     }

@@ -403,3 +403,67 @@ def run_farm_sharded(sweep, ctx, n_unit, Cc=None, Mc=None, Bc=None, dist=None):
         g = gather_rows(np.ascontiguousarray(np.moveaxis(v, 1, 0)), counts, dist)
         out[key] = None if g is None else np.moveaxis(g, 0, 1)
     return out if rank == 0 else local
+
+
+class Pipeline:
+    """Host-buffer boundary with copies overlapped with compute.  ``n_workers`` raftx contexts (= HIP streams with their
+    own device buffers and memory pools) live as long as the Pipeline; ``run`` cuts the designs of a sweep into blocks
+    that the workers -- one Python thread per context -- take round-robin: upload / generate, solve, download.  ctypes
+    releases the GIL inside every C call, so while one worker's stream runs the fused kernel the other workers' H2D /
+    D2H copies are in flight.  Results come back in design order, bit-identical to ``sweep.run``."""
+
+    def __init__(self, lib, n_workers=2, device_id=0):
+        self.ctxs = [lib.context(device_id) for _ in range(max(1, int(n_workers)))]
+
+    def close(self):
+        for c in self.ctxs:
+            c.close()
+        self.ctxs = []
+
+    def run(self, sweep, n_chunks=None, fetch="Xi"):
+        """fetch: "Xi" (full responses) or "stats" (motion std + iteration counts only)."""
+        import threading
+        nD, nW = sweep.n_design, len(self.ctxs)
+        n_chunks = max(1, min(int(n_chunks or 4 * nW), nD))
+        bounds = [shard_bounds(nD, i, n_chunks) for i in range(n_chunks)]
+        parts = [None] * n_chunks
+        errors = []
+        # full responses land straight in their block of ONE preallocated array (no concatenation of 19 KB x nD x nC)
+        Xi_all = np.empty((nD, sweep.n_case, sweep.n_head, 6, sweep.nw), dtype=np.complex128) if fetch != "stats" else None
+
+        def worker(wid):
+            ctx = self.ctxs[wid]
+            try:
+                for i in range(wid, n_chunks, nW):
+                    lo, hi = bounds[i]
+                    sub = sweep.take(lo, hi)
+                    if fetch == "stats":
+                        parts[i] = sub.run_stats(ctx)
+                    else:
+                        sub.solve(ctx)
+                        r = ctx.fetch_results(Xi_out=Xi_all[lo:hi])
+                        parts[i] = {"niter": r["niter"], "flags": r["flags"]}
+            except Exception as e:                               # surfaced after the join
+                errors.append(e)
+
+        threads = [threading.Thread(target=worker, args=(w,)) for w in range(nW)]
+        for t in threads:
+            t.start()
+        for t in threads:
+            t.join()
+        if errors:
+            raise errors[0]
+        keys = [k_ for k_ in parts[0] if parts[0][k_] is not None and np.ndim(parts[0][k_]) >= 1]
+        out = {k_: np.concatenate([p[k_] for p in parts], axis=0) for k_ in keys}
+        if Xi_all is not None:
+            out["Xi"] = Xi_all
+        return out
+
+
+def run_pipelined(sweep, lib, n_chunks=8, n_workers=2, device_id=0, fetch="Xi"):
+    """One-shot form of Pipeline (contexts created and destroyed inside: cold memory pools)."""
+    pipe = Pipeline(lib, n_workers, device_id)
+    try:
+        return pipe.run(sweep, n_chunks, fetch)
+    finally:
+        pipe.close()

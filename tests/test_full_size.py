@@ -83,3 +83,33 @@ def test_c2_full_size_three_sea_states(hip_ctx):
     assert out["Xi"].shape == (1, 3, 1, 6, 200)
     for i, c in enumerate(single):
         assert group_rel_err(out["Xi"][0, i, :1], c["Xi"][:1]) < 1e-9
+
+
+def test_pipelined_boundary_is_bit_identical(hip_lib, hip_ctx):
+    """sweep.Pipeline: designs cut into ragged blocks, three contexts (streams) working concurrently from Python
+    threads, results written straight into one output array -- bit-identical to the single-launch sweep."""
+    from raft_amd.sweep import Pipeline, GeometrySweep
+    c3 = standin.load_fixture("c3_variants.npz")
+    fg = standin.load_fixture("geom_units.npz")
+    n = 333
+    scales = np.random.default_rng(9).uniform(0.75, 1.25, size=(n, 5))
+    u0 = [u for u in fg["units"] if u["name"] == "C3-variant-0"][0]
+    M_rna = np.asarray(u0["M_struc"]) - np.asarray(u0["M_struc_bare"])
+    C_rest = np.asarray(u0["C_struc"]) - np.asarray(u0["C_struc_bare"]) + np.diag([7e4, 7e4, 0, 0, 0, 1e8])
+    tables = volturnus_sweep(json.loads(fg["c3_base_json"]), scales).tables()
+    zeta = np.stack([np.asarray(c3["zeta"]), 0.5 * np.asarray(c3["zeta"])])
+    beta = np.array([[0.0], [0.7]])
+    sweep = GeometrySweep(tables, np.repeat(M_rna[None], n, 0), np.zeros((n, 6, 6)), np.repeat(C_rest[None], n, 0), c3["w"],
+                          c3["k"], float(c3["depth"]), zeta, beta, int(c3["nIter"]), float(c3["XiStart"]))
+    ref = sweep.run(hip_ctx)
+    pipe = Pipeline(hip_lib, n_workers=3)
+    try:
+        got = pipe.run(sweep, n_chunks=7)
+        st = pipe.run(sweep, n_chunks=5, fetch="stats")
+    finally:
+        pipe.close()
+    assert np.array_equal(got["Xi"].view(np.uint64), ref["Xi"].view(np.uint64))
+    assert np.array_equal(got["niter"], ref["niter"]) and np.array_equal(got["flags"], ref["flags"])
+    want = np.sqrt(0.5 * np.sum(np.abs(ref["Xi"][:, :, 0]) ** 2, axis=3))
+    want[:, :, 3:] *= 57.29577951308232
+    assert rel_err(st["std"], want) < 1e-12
