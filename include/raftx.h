@@ -28,6 +28,7 @@
 #ifndef RAFTX_H
 #define RAFTX_H
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -356,6 +357,13 @@ int raftx_fetch_strips(raftx_ctx *ctx, double *strips, raftx_c128 *cm);
 #define RAFTX_SP_VFILL 10  /* total ballast volume [m^3] */
 int raftx_fetch_statics(raftx_ctx *ctx, double *A_morison, double *C_hydro, double *W_hydro,
                         double *M_struc, double *C_struc, double *W_struc, double *props);
+
+/* Page-locked host buffers for the bulk outputs (the 19 KB per design-case of raftx_fetch_results): copies into
+ * them run at full PCIe rate and asynchronously to other streams, which pageable NumPy memory does not.  The caller
+ * wraps the pointer in an array (raft_amd/_abi.py Context.pinned_empty) and must return it with raftx_host_free before
+ * the ctx is destroyed.  The oracle hands out ordinary malloc memory. */
+int raftx_host_alloc(raftx_ctx *ctx, size_t bytes, void **out);
+int raftx_host_free(raftx_ctx *ctx, void *ptr);
 
 /* Duration (ms) of the device work of the last raftx_excitation /
  * raftx_linearize / raftx_solve_dynamics / raftx_solve_system call on this

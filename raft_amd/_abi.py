@@ -25,7 +25,7 @@ EXPORTS = (
     "raftx_excitation", "raftx_linearize", "raftx_solve_dynamics",
     "raftx_solve_system", "raftx_last_kernel_ms",
     "raftx_solve_dynamics_device", "raftx_fetch_results", "raftx_debug_math", "raftx_motion_stats", "raftx_solve_system_resident", "raftx_qtf_slender", "raftx_channel_stats", "raftx_qtf_force", "raftx_set_linearisation_point", "raftx_fetch_linearisation_point",
-    "raftx_build_designs", "raftx_fetch_strips", "raftx_fetch_statics", "raftx_channel_stats_poly", "raftx_qtf_slender_rows", "raftx_bem_excitation", "raftx_qtf_kay",
+    "raftx_build_designs", "raftx_fetch_strips", "raftx_fetch_statics", "raftx_channel_stats_poly", "raftx_qtf_slender_rows", "raftx_bem_excitation", "raftx_qtf_kay", "raftx_host_alloc", "raftx_host_free",
 )
 WANT_BDRAG, WANT_FWAVE, WANT_Z = 1, 2, 4
 
@@ -106,6 +106,10 @@ class RaftxLib:
         L.raftx_qtf_force.restype = C.c_int
         L.raftx_channel_stats.argtypes = [_vp, C.c_int, _vp, _vp, C.c_double, _vp, _vp]
         L.raftx_channel_stats.restype = C.c_int
+        L.raftx_host_alloc.argtypes = [_vp, C.c_size_t, C.POINTER(_vp)]
+        L.raftx_host_alloc.restype = C.c_int
+        L.raftx_host_free.argtypes = [_vp, _vp]
+        L.raftx_host_free.restype = C.c_int
         L.raftx_qtf_kay.argtypes = [_vp, C.c_int, C.c_int, _vp, _vp, C.c_double, C.c_double, C.c_double, _vp, _vp, _vp, C.c_int, _vp]
         L.raftx_qtf_kay.restype = C.c_int
         L.raftx_bem_excitation.argtypes = [_vp, C.c_int, _vp, _vp, _vp, _vp, _vp, _vp]
@@ -152,6 +156,9 @@ class Context:
 
     def close(self):
         if self._h:
+            for ptr in list(getattr(self, "_pinned", {}).values()):       # page-locked buffers still out: release them
+                self.rlib.lib.raftx_host_free(self._h, _vp(ptr))
+            self._pinned = {}
             self.rlib.lib.raftx_ctx_destroy(self._h)
             self._h = _vp()
 
@@ -322,6 +329,26 @@ class Context:
         rc = self.rlib.lib.raftx_solve_dynamics_device(self._h, int(nIter), float(tol), float(XiStart),
                                                        _ptr(F_extra), int(want_mask))
         self._check(rc, "raftx_solve_dynamics_device")
+
+    def pinned_empty(self, shape, dtype=np.complex128):
+        """An uninitialised array in page-locked host memory (raftx_host_alloc): D2H copies into it run at full PCIe
+        rate.  Release it with ``free_pinned(array)`` (before the context is closed); do not keep views past that."""
+        dtype = np.dtype(dtype)
+        n = int(np.prod(shape)) * dtype.itemsize
+        ptr = _vp()
+        self._check(self.rlib.lib.raftx_host_alloc(self._h, n, C.byref(ptr)), "raftx_host_alloc")
+        buf = (C.c_char * max(n, 1)).from_address(ptr.value)
+        arr = np.frombuffer(buf, dtype=dtype, count=int(np.prod(shape))).reshape(shape)
+        self._pinned = getattr(self, "_pinned", {})
+        self._pinned[arr.__array_interface__["data"][0]] = ptr.value
+        return arr
+
+    def free_pinned(self, arr):
+        addr = arr.__array_interface__["data"][0]
+        ptr = getattr(self, "_pinned", {}).pop(addr, None)
+        if ptr is None:
+            raise ValueError("not an array of pinned_empty of this context")
+        self._check(self.rlib.lib.raftx_host_free(self._h, _vp(ptr)), "raftx_host_free")
 
     def fetch_results(self, want_Xi=True, want_B=False, want_F=False, want_Z=False, Xi_out=None):
         """Xi_out: optional preallocated C-contiguous complex128 [nDesign,nCase,nHead,6,nw] buffer (e.g. a slice of a

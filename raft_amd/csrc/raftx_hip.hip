@@ -502,6 +502,19 @@ extern "C" void raftx_ctx_destroy(raftx_ctx *c) {
     delete c;
 }
 
+extern "C" int raftx_host_alloc(raftx_ctx *c, size_t bytes, void **out) {
+    if (!c || !out) return -1;
+    *out = nullptr;
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipHostMalloc(out, bytes ? bytes : 1, hipHostMallocDefault));
+    return 0;
+}
+extern "C" int raftx_host_free(raftx_ctx *c, void *ptr) {
+    if (!c) return -1;
+    if (ptr) HIPCHK(c, hipHostFree(ptr));
+    return 0;
+}
+
 extern "C" const char *raftx_last_error(raftx_ctx *c) { return c ? c->err : "null ctx"; }
 extern "C" double raftx_last_kernel_ms(raftx_ctx *c) { return c ? c->last_ms : 0.0; }
 

@@ -416,12 +416,15 @@ class Pipeline:
         self.ctxs = [lib.context(device_id) for _ in range(max(1, int(n_workers)))]
 
     def close(self):
+        self._pinned_out = None
         for c in self.ctxs:
             c.close()
         self.ctxs = []
 
-    def run(self, sweep, n_chunks=None, fetch="Xi"):
-        """fetch: "Xi" (full responses) or "stats" (motion std + iteration counts only)."""
+    def run(self, sweep, n_chunks=None, fetch="Xi", pinned=False):
+        """fetch: "Xi" (full responses) or "stats" (motion std + iteration counts only).  pinned=True: the responses are
+        downloaded into a page-locked array of the first context (faster D2H); it is recycled by the next pinned run
+        and released by close(), so copy what must outlive them."""
         import threading
         nD, nW = sweep.n_design, len(self.ctxs)
         n_chunks = max(1, min(int(n_chunks or 4 * nW), nD))
@@ -429,7 +432,18 @@ class Pipeline:
         parts = [None] * n_chunks
         errors = []
         # full responses land straight in their block of ONE preallocated array (no concatenation of 19 KB x nD x nC)
-        Xi_all = np.empty((nD, sweep.n_case, sweep.n_head, 6, sweep.nw), dtype=np.complex128) if fetch != "stats" else None
+        Xi_all = None
+        if fetch != "stats":
+            shape = (nD, sweep.n_case, sweep.n_head, 6, sweep.nw)
+            if pinned:
+                old = getattr(self, "_pinned_out", None)
+                if old is None or old.shape != shape:
+                    if old is not None:
+                        self.ctxs[0].free_pinned(old)
+                    self._pinned_out = self.ctxs[0].pinned_empty(shape)
+                Xi_all = self._pinned_out
+            else:
+                Xi_all = np.empty(shape, dtype=np.complex128)
 
         def worker(wid):
             ctx = self.ctxs[wid]

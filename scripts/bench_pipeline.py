@@ -28,6 +28,13 @@ ref = sweep.run(ctx)
 for label, fn in (("serial_full", lambda: sweep.run(ctx)), ("serial_stats", lambda: sweep.run_stats(ctx))):
     fn()
     t0 = time.perf_counter(); fn(); out[label + "_Mdcf_s"] = n * nw / (time.perf_counter() - t0) / 1e6
+Xp = ctx.pinned_empty(ref["Xi"].shape)
+for _ in range(2):
+    t0 = time.perf_counter()
+    sweep.solve(ctx); ctx.fetch_results(Xi_out=Xp)
+    out["serial_full_pinned_Mdcf_s"] = n * nw / (time.perf_counter() - t0) / 1e6
+assert np.array_equal(Xp.view(np.uint64), ref["Xi"].view(np.uint64))
+ctx.free_pinned(Xp)
 ctx.close()
 for workers, chunks in ((2, 4), (2, 8), (3, 6), (4, 8)):
     pipe = Pipeline(lib, workers)
@@ -39,5 +46,10 @@ for workers, chunks in ((2, 4), (2, 8), (3, 6), (4, 8)):
         out["pipelined_%s_w%d_c%d_Mdcf_s" % (fetch, workers, chunks)] = n * nw / (time.perf_counter() - t0) / 1e6
         if fetch == "Xi":
             assert np.array_equal(got["Xi"].view(np.uint64), ref["Xi"].view(np.uint64))
+    pipe.run(sweep, chunks, pinned=True)
+    t0 = time.perf_counter()
+    got = pipe.run(sweep, chunks, pinned=True)
+    out["pipelined_Xi_pinned_w%d_c%d_Mdcf_s" % (workers, chunks)] = n * nw / (time.perf_counter() - t0) / 1e6
+    assert np.array_equal(got["Xi"].view(np.uint64), ref["Xi"].view(np.uint64))
     pipe.close()
 print(json.dumps(out))

@@ -105,10 +105,12 @@ def test_pipelined_boundary_is_bit_identical(hip_lib, hip_ctx):
     pipe = Pipeline(hip_lib, n_workers=3)
     try:
         got = pipe.run(sweep, n_chunks=7)
+        pin = pipe.run(sweep, n_chunks=4, pinned=True)["Xi"].copy()       # page-locked landing buffer (raftx_host_alloc)
         st = pipe.run(sweep, n_chunks=5, fetch="stats")
     finally:
         pipe.close()
     assert np.array_equal(got["Xi"].view(np.uint64), ref["Xi"].view(np.uint64))
+    assert np.array_equal(pin.view(np.uint64), ref["Xi"].view(np.uint64))
     assert np.array_equal(got["niter"], ref["niter"]) and np.array_equal(got["flags"], ref["flags"])
     want = np.sqrt(0.5 * np.sum(np.abs(ref["Xi"][:, :, 0]) ** 2, axis=3))
     want[:, :, 3:] *= 57.29577951308232
