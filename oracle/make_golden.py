@@ -377,6 +377,37 @@ def fixture_bem():
     standin.save_fixture(os.path.join(GOLD, "bem_oc3spar.npz"), fx)
 
 
+def fixture_ref_members():
+    """The reference's OWN known-answer tests for the member-level geometry / statics chain (tests/test_member.py:
+    desired_inertiaBasic, desired_inertiaMatrix, desired_hydrostatics_*, desired_Ahydro, desired_Ihydro; :604-623) for the
+    ten rigid single-member decks tests/test_data/mem_*.yaml -- converted to the container format together with the
+    member descriptions (the two 'beam' decks are outside the generator's scope)."""
+    import importlib.util
+    import json
+    rh.import_raft()
+    spec = importlib.util.spec_from_file_location("ref_test_member", os.path.join(REF, "tests", "test_member.py"))
+    tm = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(tm)
+    cases = []
+    for i, path in enumerate(tm.list_files):
+        d = rh.load_design(path)
+        mi = d["members"][0]
+        if str(mi.get("type", "rigid")) != "rigid":
+            continue
+        cases.append({"file": os.path.basename(path),
+                      "member_json": json.dumps(mi, default=lambda o: o.tolist() if hasattr(o, "tolist") else float(o)),
+                      "inertiaBasic": np.array(tm.desired_inertiaBasic[i], dtype=float),
+                      "inertiaMatrix": np.array(tm.desired_inertiaMatrix[i], dtype=float),
+                      "Fvec": np.array(tm.desired_hydrostatics_Fvec[i], dtype=float),
+                      "Cmat": np.array(tm.desired_hydrostatics_Cmat[i], dtype=float),
+                      "r_center": np.array(tm.desired_hydrostatics_r_center[i], dtype=float),
+                      "WP": np.array(tm.desired_hydrostatics_WP[i], dtype=float),
+                      "Ahydro": np.array(tm.desired_Ahydro[i], dtype=float),
+                      "Ihydro": np.array(tm.desired_Ihydro[i], dtype=float)})
+    fx = {"config": "reference tests/test_member.py known answers (rigid members)", "cases": cases}
+    standin.save_fixture(os.path.join(GOLD, "refgold_members.npz"), fx)
+
+
 def _design_subset(design):
     """JSON of the parts of a design dict the member descriptors are parsed from (taken BEFORE the reference
     mutates the dict)."""
@@ -517,7 +548,7 @@ def fixture_geom():
     standin.save_fixture(os.path.join(GOLD, "geom_units.npz"), fx)
 
 
-ALL = {"bem": fixture_bem, "geom": fixture_geom, "c5oc4": fixture_c5_oc4, "c5": fixture_c5, "qtf": fixture_qtf, "c1": fixture_c1, "c2": fixture_c2, "pose": fixture_pose,
+ALL = {"refmembers": fixture_ref_members, "bem": fixture_bem, "geom": fixture_geom, "c5oc4": fixture_c5_oc4, "c5": fixture_c5, "qtf": fixture_qtf, "c1": fixture_c1, "c2": fixture_c2, "pose": fixture_pose,
        "refgold": fixture_ref_goldens, "c4": fixture_c4, "c3": fixture_c3}
 
 if __name__ == "__main__":
