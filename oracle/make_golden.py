@@ -408,6 +408,36 @@ def fixture_ref_members():
     standin.save_fixture(os.path.join(GOLD, "refgold_members.npz"), fx)
 
 
+def fixture_ref_statics():
+    """The reference's OWN unit-level goldens for the statics / hydro-constants chain: tests/test_data/
+    *_true_statics.pkl (tests/test_fowt.py:63-89) and *_true_hydroConstants.pkl (:92-108) for its four rigid decks,
+    with the member description they were computed from.  M_struc / C_struc / W_struc of the pickles include the
+    rotor-nacelle assembly and point inertias, which are not geometry: their share (live reference: full model minus
+    its massless-RNA twin) is stored next to them."""
+    cases = []
+    for name in ("OC3spar", "VolturnUS-S", "VolturnUS-S-pointInertia", "OC4semi-WAMIT_Coefs"):
+        d = rh.prepare_design(rh.load_design(os.path.join(REF, "tests/test_data", name + ".yaml")))
+        d["platform"]["potFirstOrder"] = 0            # coefficient files are not needed for the statics
+        if d["platform"].get("potSecOrder", 0) == 2:
+            d["platform"]["potSecOrder"] = 0
+        dj = _design_subset(d)
+        full = rh.build_model(copy.deepcopy(d)).fowtList[0]
+        bare = rh.build_model(_bare(d)).fowtList[0]
+        with open(os.path.join(REF, "tests/test_data", name + "_true_statics.pkl"), "rb") as f:
+            st = pickle.load(f)
+        with open(os.path.join(REF, "tests/test_data", name + "_true_hydroConstants.pkl"), "rb") as f:
+            hc = pickle.load(f)
+        c = {"name": name, "design_json": dj, "rho": float(full.rho_water), "g": float(full.g), "k": np.array(full.k),
+             "M_rest": np.array(full.M_struc - bare.M_struc), "C_rest": np.array(full.C_struc - bare.C_struc),
+             "W_rest": np.array(full.W_struc - bare.W_struc), "m_rest": float(full.m - bare.m),
+             "A_hydro_morison": np.array(hc["A_hydro_morison"])}
+        for key in ("rCG", "M_struc", "C_struc", "W_struc", "rCB", "C_hydro", "W_hydro"):
+            c["true_" + key] = np.array(st[key], dtype=float)
+        cases.append(c)
+    standin.save_fixture(os.path.join(GOLD, "refgold_statics.npz"),
+                         {"config": "reference *_true_statics.pkl / *_true_hydroConstants.pkl (rigid decks)", "cases": cases})
+
+
 def _design_subset(design):
     """JSON of the parts of a design dict the member descriptors are parsed from (taken BEFORE the reference
     mutates the dict)."""
@@ -548,7 +578,7 @@ def fixture_geom():
     standin.save_fixture(os.path.join(GOLD, "geom_units.npz"), fx)
 
 
-ALL = {"refmembers": fixture_ref_members, "bem": fixture_bem, "geom": fixture_geom, "c5oc4": fixture_c5_oc4, "c5": fixture_c5, "qtf": fixture_qtf, "c1": fixture_c1, "c2": fixture_c2, "pose": fixture_pose,
+ALL = {"refstatics": fixture_ref_statics, "refmembers": fixture_ref_members, "bem": fixture_bem, "geom": fixture_geom, "c5oc4": fixture_c5_oc4, "c5": fixture_c5, "qtf": fixture_qtf, "c1": fixture_c1, "c2": fixture_c2, "pose": fixture_pose,
        "refgold": fixture_ref_goldens, "c4": fixture_c4, "c3": fixture_c3}
 
 if __name__ == "__main__":

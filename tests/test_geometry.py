@@ -406,3 +406,36 @@ def test_oracle_against_reference_member_known_answers(i, oracle_ctx):
 @pytest.mark.parametrize("i", range(len(REFMEM)))
 def test_hip_against_reference_member_known_answers(i, hip_ctx):
     check_ref_member(hip_ctx, REFMEM[i], 2e-5)
+
+
+# ------------------------------------------------------------------ the reference's OWN unit-level statics goldens
+REFSTAT = standin.load_fixture("refgold_statics.npz")["cases"]
+
+
+def check_ref_statics(ctx, c):
+    """tests/test_fowt.py:63-108 of the reference (test_statics, test_hydroConstants; same rtol 1e-5 / atol 1e-3)."""
+    t = G.describe_unit(json.loads(c["design_json"]))
+    D = G.concat_units([t])
+    Z = np.zeros((1, 6, 6))
+    ctx.build_designs(D.member_off, D.members, D.station_off, D.stations, Z, Z, Z, len(c["k"]), rho=c["rho"], g=c["g"],
+                      k=c["k"], cap_off=D.cap_off, caps=D.caps)
+    S = ctx.fetch_statics()
+    close = lambda a, b: np.testing.assert_allclose(a, b, rtol=1e-5, atol=1e-3)
+    close(S["A_morison"][0], c["A_hydro_morison"])
+    close(S["C_hydro"][0], c["true_C_hydro"])
+    close(S["W_hydro"][0], c["true_W_hydro"])
+    close(S["props"][0, G.SP_RCB:G.SP_RCB + 3], c["true_rCB"])
+    close(S["M_struc"][0] + c["M_rest"], c["true_M_struc"])
+    close(S["C_struc"][0] + c["C_rest"], c["true_C_struc"])
+    close(S["W_struc"][0] + c["W_rest"], c["true_W_struc"])
+
+
+@pytest.mark.parametrize("i", range(len(REFSTAT)))
+def test_oracle_against_reference_statics_pickles(i, oracle_ctx):
+    check_ref_statics(oracle_ctx, REFSTAT[i])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("i", range(len(REFSTAT)))
+def test_hip_against_reference_statics_pickles(i, hip_ctx):
+    check_ref_statics(hip_ctx, REFSTAT[i])
