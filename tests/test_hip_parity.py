@@ -11,7 +11,8 @@ from tests.util import (group_rel_err, rel_err, case_from_fixture, load_model_fi
 
 pytestmark = pytest.mark.gpu
 TOL = 1e-9
-REFGOLD = ["refgold_OC3spar.npz", "refgold_VolturnUS-S.npz", "refgold_VolturnUS-S-pointInertia.npz"]
+REFGOLD = ["refgold_OC3spar.npz", "refgold_VolturnUS-S.npz", "refgold_VolturnUS-S-pointInertia.npz",
+           "refgold_OC4semi-WAMIT_Coefs.npz"]
 
 
 def test_device_library_is_the_product(hip_lib):

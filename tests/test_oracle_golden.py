@@ -14,7 +14,8 @@ import pytest
 from raft_amd import dropin
 from tests.util import group_rel_err, rel_err, case_from_fixture, load_model_fixture
 
-REFGOLD = ["refgold_OC3spar.npz", "refgold_VolturnUS-S.npz", "refgold_VolturnUS-S-pointInertia.npz"]
+REFGOLD = ["refgold_OC3spar.npz", "refgold_VolturnUS-S.npz", "refgold_VolturnUS-S-pointInertia.npz",
+           "refgold_OC4semi-WAMIT_Coefs.npz"]
 
 
 @pytest.mark.parametrize("name", REFGOLD)
