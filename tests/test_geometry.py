@@ -439,3 +439,39 @@ def test_oracle_against_reference_statics_pickles(i, oracle_ctx):
 @pytest.mark.parametrize("i", range(len(REFSTAT)))
 def test_hip_against_reference_statics_pickles(i, hip_ctx):
     check_ref_statics(hip_ctx, REFSTAT[i])
+
+
+# ------------------------------------------------------------------ member description -> reference response, MCF + pose
+def check_pose_mcf_end_to_end(ctx, tol):
+    """VolturnUS-S test deck (MacCamy-Fuchs columns) at an offset, heeled pose: member descriptions in, device-generated
+    strips + complex Cm tables + statics, solveDynamics for one and two wave headings -- against the LIVE reference's
+    solveDynamics of that deck (tests/golden/pose_volturnus_mcf.npz)."""
+    fx = standin.load_fixture("pose_volturnus_mcf.npz")
+    fm = fx["model"]["fowts"][0]
+    u = UNITS["VolturnUS-S-test@pose"]
+    assert np.allclose(u["w"], fm["w"])
+    D = G.concat_units([tables_of(u)])
+    M_extra = (np.asarray(u["M_struc"]) - np.asarray(u["M_struc_bare"]))[None]
+    C_extra = (np.asarray(u["C_struc"]) - np.asarray(u["C_struc_bare"]) + np.asarray(fm["C_moor"]) + np.asarray(fm["C_elast"]))[None]
+    B0 = (np.asarray(fm["B_struc"]) + np.sum(np.asarray(fm["B_gyro"]), axis=2))[None]
+    nw = len(u["w"])
+    for c in fx["cases"]:
+        un = c["units"][0]
+        ctx.build_designs(D.member_off, D.members, D.station_off, D.stations, M_extra, B0, C_extra, nw,
+                          pose=np.array(u["pose"])[None], rho=u["rho"], g=u["g"], k=u["k"], cap_off=D.cap_off, caps=D.caps,
+                          add_mask=G.ADD_MORISON | G.ADD_HYDROSTATIC | G.ADD_INERTIA)
+        ctx.upload_cases(u["w"], u["k"], float(fm["depth"]), u["rho"], u["g"], np.asarray(un["zeta"])[None],
+                         np.asarray(un["beta"])[None])
+        out = ctx.solve_dynamics(int(fx["model"]["nIter"]), 0.01, float(fx["model"]["XiStart"]))
+        nH = len(un["beta"])
+        assert int(out["niter"][0, 0]) == int(un["niter"])
+        assert group_rel_err(out["Xi"][0, 0], np.asarray(c["Xi"])[:nH]) < tol
+
+
+def test_oracle_member_descriptions_to_reference_response_mcf_pose(oracle_ctx):
+    check_pose_mcf_end_to_end(oracle_ctx, 1e-9)
+
+
+@pytest.mark.gpu
+def test_hip_member_descriptions_to_reference_response_mcf_pose(hip_ctx):
+    check_pose_mcf_end_to_end(hip_ctx, 1e-9)
