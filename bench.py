@@ -233,12 +233,12 @@ def main():
     res = ctx.fetch_results(want_Xi=True)
     niter = res["niter"]
     nan = int(np.count_nonzero(res["flags"] & 2))
-    from tests.util import group_rel_err
+    from tests.util import rao_group_err
     errs = []
     for j, sol in enumerate(sw["fx"]["solved"]):
         hits = np.nonzero(sw["idx"] == j)[0][:1]
-        if len(hits):
-            errs.append(group_rel_err(res["Xi"][hits[0], 0, :1], sol["Xi"][:1]))
+        if len(hits):                 # SURVEY.md 8d metric: group-relative error of the RAOs (Xi / zeta)
+            errs.append(rao_group_err(res["Xi"][hits[0], 0, 0], sol["Xi"][0], sw["zeta"][0]))
             assert int(niter[hits[0], 0]) == int(sol["units"][0]["niter"]), "iteration count differs from the reference"
     max_err = float(max(errs)) if errs else None
     assert nan == 0 and (max_err is None or max_err < 1e-6), "bench results fail parity (err=%r, nan=%d)" % (max_err, nan)

@@ -8,7 +8,8 @@ import pytest
 
 from raft_amd import dropin, geometry as G
 from tests import standin
-from tests.util import group_rel_err, rel_err, case_from_fixture, load_model_fixture, volturnus_sweep
+from tests.util import group_rel_err, rel_err, case_from_fixture, load_model_fixture, volturnus_sweep, rao_group_err, \
+    psd_group_err
 
 pytestmark = pytest.mark.gpu
 
@@ -42,10 +43,13 @@ def test_c3_full_size_10k_designs_generated_on_device(hip_ctx):
     for k in range(1, nD // 64):
         assert np.array_equal(Xi[64 * k:64 * (k + 1)].view(np.uint64), base.view(np.uint64)), k
     assert np.array_equal(r["niter"].reshape(-1)[:nD - nD % 64].reshape(-1, 64), np.tile(r["niter"].reshape(-1)[:64], (nD // 64, 1)))
+    dw = float(c3["w"][1] - c3["w"][0])
     for j, sol in enumerate(c3["solved"]):
         assert int(r["niter"][j, 0]) == int(sol["units"][0]["niter"])
         assert group_rel_err(r["Xi"][j, 0, :1], np.asarray(sol["Xi"])[:1]) < 1e-9
-    dw = float(c3["w"][1] - c3["w"][0])
+        # the north-star metric: RAOs and motion PSDs, gate 1e-6, expected ~1e-12
+        assert rao_group_err(r["Xi"][j, 0, 0], np.asarray(sol["Xi"])[0], np.asarray(c3["zeta"])[0]) < 1e-9
+        assert psd_group_err(r["Xi"][j, 0, :1], np.asarray(sol["Xi"])[:1], dw) < 1e-9
     std, _ = hip_ctx.motion_stats(dw)
     want = np.sqrt(0.5 * np.sum(np.abs(Xi) ** 2, axis=2))
     want[:, 3:] *= 57.29577951308232

@@ -22,6 +22,21 @@ def group_rel_err(a, b):
     return max(errs)
 
 
+def rao_group_err(Xi_a, Xi_b, zeta):
+    """SURVEY.md 8d parity metric proper: RAO = getRAO(Xi, zeta) (helpers.py:762-784: Xi / zeta where |zeta| > 1e-6,
+    zero elsewhere), then max|RAO_a - RAO_b| / max|RAO_b| jointly over {surge, sway, heave} and over {roll, pitch, yaw}.
+    Xi_* [..., 6, nw], zeta [nw]."""
+    from raft_amd import waves
+    return group_rel_err(waves.get_rao(np.asarray(Xi_a), np.asarray(zeta)), waves.get_rao(np.asarray(Xi_b), np.asarray(zeta)))
+
+
+def psd_group_err(Xi_a, Xi_b, dw):
+    """The same on the motion PSDs (getPSD, helpers.py:687-700), Xi_* [nHead, 6, nw]."""
+    pa = np.sum(0.5 * np.abs(np.asarray(Xi_a)) ** 2 / dw, axis=0)
+    pb = np.sum(0.5 * np.abs(np.asarray(Xi_b)) ** 2 / dw, axis=0)
+    return group_rel_err(pa, pb)
+
+
 def rel_err(a, b):
     a = np.asarray(a)
     b = np.asarray(b)
