@@ -300,6 +300,13 @@ def main():
                                "frac": flops / (k_ms * 1e-3) / 1e12 / FP64_VALU_PEAK_TF,
                                "algorithmic_flops_per_launch": flops},
     }
+    ref_path = os.path.join(ROOT, "profiles", "reference_cpu_timing.json")
+    if os.path.exists(ref_path):      # the unmodified NumPy reference, timed in the BUILD container (it cannot travel to the GPU box)
+        with open(ref_path) as f:
+            rt = json.load(f)
+        out["reference_numpy_build_container"] = {"dcf_per_s_one_core": rt.get("dcf_per_s_per_core"),
+                                                  "dcf_per_s_pool": rt.get("pool", {}).get("dcf_per_s_all_cores_solve_only"),
+                                                  "pool_cores": rt.get("pool", {}).get("cores")}
     if not args.tiled:
         out["geometry"] = sw["geometry"]
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
