@@ -955,6 +955,11 @@ __device__ __forceinline__ void solve6(Lu6 &A, cplx x[6]) {
 #define KF_XLIO 64   // linearisation point given (restart) / exported (raft_model.py:1108-1131 re-entry)
 #define KF_ALL 127
 
+#ifndef RAFTX_EQ_ORDER
+#define RAFTX_EQ_ORDER 4, 3, 2, 1, 0, 5
+#endif
+__device__ constexpr int EQ_ORDER[6] = {RAFTX_EQ_ORDER};
+
 // Assemble and solve one bin's 6x6 system: x <- Z^-1 x  (raft_model.py:1086-1089)
 template <int FLAGS>
 __device__ __forceinline__ void assemble_and_solve(const Lds &l, const double *__restrict__ Mw, const double *__restrict__ Bw,
@@ -963,11 +968,18 @@ __device__ __forceinline__ void assemble_and_solve(const Lds &l, const double *_
     Lu6 lu;
     const double w2 = w * w;
     if constexpr ((FLAGS & (KF_FDEP | KF_OUTZ)) != 0) iw = opaque(iw);   // per-entry addresses are formed here, not hoisted
+    // The equations enter the elimination in the order EQ_ORDER (register row i holds equation EQ_ORDER[i]): a
+    // compile-time renaming, free.  Partial pivoting chooses rows by magnitude, so the same pivot rows, multipliers and
+    // updates follow whatever the starting order (it only decides exact ties); what changes is how often a row
+    // interchange is needed.  For a floating body referred to a point near the waterline the surge-pitch / sway-roll
+    // inertia coupling m z_g w^2 exceeds m w^2, and LAPACK's first two interchanges are 0<->4 and 1<->3 in ~94 % of
+    // the bins of the VolturnUS-S sweep; starting from that arrangement makes the predicated swap blocks of the two
+    // largest steps wave-uniformly skippable.
 #pragma unroll
     for (int r = 0; r < 6; r++) {
 #pragma unroll
         for (int c = 0; c < 6; c++) {
-            const int e = r * 6 + c;
+            const int e = EQ_ORDER[r] * 6 + c;
             double M = l.mat[e], B = l.mat[36 + e];
             if constexpr ((FLAGS & KF_FDEP) != 0) {
                 if (Mw) {
@@ -986,10 +998,15 @@ __device__ __forceinline__ void assemble_and_solve(const Lds &l, const double *_
 #pragma unroll
             for (int r = 0; r < 6; r++)
 #pragma unroll
-                for (int c = 0; c < 6; c++) (Zout + (size_t)(r * 6 + c) * nw)[iw] = cplx{lu.ar[r][c], lu.ai[r][c]};
+                for (int c = 0; c < 6; c++) (Zout + (size_t)(EQ_ORDER[r] * 6 + c) * nw)[iw] = cplx{lu.ar[r][c], lu.ai[r][c]};
         }
     }
-    solve6(lu, x);
+    cplx y[6];
+#pragma unroll
+    for (int r = 0; r < 6; r++) y[r] = x[EQ_ORDER[r]];
+    solve6(lu, y);
+#pragma unroll
+    for (int r = 0; r < 6; r++) x[r] = y[r];          // unknowns keep their order
 }
 
 // XiLast storage: LDS rows [12][nxl] for every shape whose bins fit there; the largest shapes
