@@ -874,6 +874,99 @@ __device__ __forceinline__ void drag_excitation(cdptr ds, ciptr dsi, int S, cons
     }
 }
 
+// Inertial excitation for real (frequency-independent) inertia coefficients, in the same factored form as pass B:
+//   Imat ud = sum_c I_c n_c (n_c . ud),  n_c . ud = i w (al_c t1 + ga_c t2)   (al_c = n_c . (cb, sb, 0), ga_c = n_cz)
+//   => F += i w (t1 U' + t2 V') + pDyn A',   U' = sum_c I_c al_c W_c,  V' = sum_c I_c ga_c W_c,  A' = a_i W_q,
+//   W_c = [n_c ; a x n_c]   (raft_member.py:1984-1991, helpers.py:468-483).
+// U', V' are built once per strip by one lane each (into the uv rows, free before the first linearisation); the bin
+// sweep then costs 36 FMAs per strip and bin instead of the ~60 of the direct form.  MacCamy-Fuchs strips (complex
+// per-bin Cm) cannot be factored this way: kernels with KF_MCF keep inertial_excitation<.., true>.
+template <int NB>
+__device__ __forceinline__ void inertial_excitation_uv(const DevTables &T, cdptr ds, ciptr dsi, int S, const Lds &l,
+                                                       const Bins<NB> &b, int ic, int ih, double cb, double sb,
+                                                       cplx (&F)[NB][6], bool multi) {
+    for (int s = threadIdx.x; s < S; s += blockDim.x) {
+        cdptr rec = ds + (size_t)s * DS_N;
+        const double ax = rec[DS_A], ay = rec[DS_A + 1], az = rec[DS_A + 2];
+        double U[6] = {0, 0, 0, 0, 0, 0}, V[6] = {0, 0, 0, 0, 0, 0};
+#pragma unroll
+        for (int c = 0; c < 3; c++) {
+            double W[6];
+            W[0] = rec[DS_Q + 3 * c];
+            W[1] = rec[DS_Q + 3 * c + 1];
+            W[2] = rec[DS_Q + 3 * c + 2];
+            W[3] = ay * W[2] - az * W[1];
+            W[4] = az * W[0] - ax * W[2];
+            W[5] = ax * W[1] - ay * W[0];
+            const double I = rec[DS_IQ + c];
+            const double al = I * (W[0] * cb + W[1] * sb), ga = I * W[2];
+#pragma unroll
+            for (int j = 0; j < 6; j++) {
+                U[j] += al * W[j];
+                V[j] += ga * W[j];
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 6; j++) {
+            l.uv[s * 12 + j] = U[j];
+            l.uv[s * 12 + 6 + j] = V[j];
+        }
+    }
+    wg_sync(multi);
+    double ws[NB], wd[NB], sp[NB];
+#pragma unroll
+    for (int j = 0; j < NB; j++) {
+        const double z0r = T.zeta[((size_t)ic * T.nHead + ih) * T.nw + b.iw[j]];
+        const double z0 = b.act[j] ? z0r : 0.0;
+        sp[j] = T.rho * T.g * z0 * T.cch[b.iw[j]];                         // rho g zeta0 / cosh kh scaling (helpers.py:231)
+        const double qm = (depth_mode(b.k[j], b.depth) == 1) ? 0.0 : 1.0;   // deep water: Sh = Ch = e^{kz}
+        ws[j] = b.w[j] * b.c1[j];                                           // w . (w zeta0 csh)
+        wd[j] = ws[j] * qm;
+    }
+    double one[NB];
+#pragma unroll
+    for (int j = 0; j < NB; j++) one[j] = 1.0;
+    Kin<NB> K;
+    kin_reset(K);
+    if (S > 0) {
+        int fn = dsi[0];
+#pragma unroll 1
+        for (int s = 0; s < S; s++) {
+            cdptr rec = ds + (size_t)s * DS_N;
+            double U[6], V[6];
+            load_uv(l.uv + s * 12, U, V);
+            const double ax = rec[DS_A], ay = rec[DS_A + 1], az = rec[DS_A + 2];
+            const double qx = rec[DS_Q], qy = rec[DS_Q + 1], qz = rec[DS_Q + 2];
+            const double ai_ = rec[DS_IQ + 3];
+            const int fl = fn;
+            fn = dsi[min(s + 1, S - 1)];
+            kin_advance<NB, true>(K, fl, rec, b, one, cb, sb);
+            double Aq[6];
+            Aq[0] = ai_ * qx;
+            Aq[1] = ai_ * qy;
+            Aq[2] = ai_ * qz;
+            Aq[3] = ai_ * (ay * qz - az * qy);
+            Aq[4] = ai_ * (az * qx - ax * qz);
+            Aq[5] = ai_ * (ax * qy - ay * qx);
+#pragma unroll
+            for (int j = 0; j < NB; j++) {
+                // i w t1 = i w s1 (P + Qk) a,  i w t2 = -w s1 (P - Qk) a   (a = e^{-i k xi}; Qk = 0 in deep water)
+                const double hs = fma(wd[j], K.Q[j], ws[j] * K.P[j]), hd = fma(-wd[j], K.Q[j], ws[j] * K.P[j]);
+                const double pp = sp[j] * (K.P[j] + K.Q[j]);                  // rho g zeta_s Cc
+                const double t1r = -hs * K.ai[j], t1i = hs * K.ar[j];
+                const double t2r = -hd * K.ar[j], t2i = -hd * K.ai[j];
+                const double pr = pp * K.ar[j], pi = pp * K.ai[j];
+#pragma unroll
+                for (int q = 0; q < 6; q++) {
+                    F[j][q].re = fma(t1r, U[q], fma(t2r, V[q], fma(pr, Aq[q], F[j][q].re)));
+                    F[j][q].im = fma(t1i, U[q], fma(t2i, V[q], fma(pi, Aq[q], F[j][q].im)));
+                }
+            }
+        }
+    }
+    // (the caller's barrier before the first linearisation also orders these uv reads before the strip phase's writes)
+}
+
 // ------------------------------------------------------------------ 6x6 complex solve in registers
 struct Lu6 {
     double ar[6][6], ai[6][6];
@@ -1216,7 +1309,10 @@ __global__ void __launch_bounds__(MAXT, MINB) k_solve_dynamics(DevTables T, Solv
                         Flin[j][q] = A.F_extra[(((size_t)pair * nHs) * 6 + q) * nw + b.iw[j]];
             }
         }
-        inertial_excitation<NB, MCF>(T, p.ds, p.dsi, S, cm, b, p.ic, 0, cb0, sb0, Flin);
+        if constexpr (MCF)
+            inertial_excitation<NB, true>(T, p.ds, p.dsi, S, cm, b, p.ic, 0, cb0, sb0, Flin);
+        else
+            inertial_excitation_uv<NB>(T, p.ds, p.dsi, S, l, b, p.ic, 0, cb0, sb0, Flin, multi);
         store6(xio, nw, b, Flin);
     }
     // XiLast <- XiStart (:999), kept as xl[2q][bin] = re, xl[2q+1][bin] = im
