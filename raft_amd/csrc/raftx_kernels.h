@@ -1018,12 +1018,14 @@ __device__ __forceinline__ void solve6(Lu6 &A, cplx x[6]) {
             double lr = A.ar[r][k] * ir - A.ai[r][k] * ii;
             double li = A.ar[r][k] * ii + A.ai[r][k] * ir;
 #pragma unroll
-            for (int c = k + 1; c < 6; c++) {
-                A.ar[r][c] -= lr * A.ar[k][c] - li * A.ai[k][c];
-                A.ai[r][c] -= lr * A.ai[k][c] + li * A.ar[k][c];
+            for (int c = k + 1; c < 6; c++) {      // two FMAs per part (a -= l u written as a difference costs three)
+                const double ur = A.ar[k][c], ui = A.ai[k][c];
+                A.ar[r][c] = fma(-lr, ur, fma(li, ui, A.ar[r][c]));
+                A.ai[r][c] = fma(-lr, ui, fma(-li, ur, A.ai[r][c]));
             }
-            x[r].re -= lr * x[k].re - li * x[k].im;
-            x[r].im -= lr * x[k].im + li * x[k].re;
+            const double xr = x[k].re, xi = x[k].im;
+            x[r].re = fma(-lr, xr, fma(li, xi, x[r].re));
+            x[r].im = fma(-lr, xi, fma(-li, xr, x[r].im));
         }
     }
 #pragma unroll
@@ -1031,8 +1033,8 @@ __device__ __forceinline__ void solve6(Lu6 &A, cplx x[6]) {
         cplx s = x[k];
 #pragma unroll
         for (int c = k + 1; c < 6; c++) {
-            s.re -= A.ar[k][c] * x[c].re - A.ai[k][c] * x[c].im;
-            s.im -= A.ar[k][c] * x[c].im + A.ai[k][c] * x[c].re;
+            s.re = fma(-A.ar[k][c], x[c].re, fma(A.ai[k][c], x[c].im, s.re));
+            s.im = fma(-A.ar[k][c], x[c].im, fma(-A.ai[k][c], x[c].re, s.im));
         }
         x[k] = {s.re * A.ar[k][k] - s.im * A.ai[k][k], s.re * A.ai[k][k] + s.im * A.ar[k][k]};
     }
