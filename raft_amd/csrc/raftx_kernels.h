@@ -1123,6 +1123,21 @@ struct XlStore<true> {
     __device__ __forceinline__ void put(int row, int iw, double v) const { p[(size_t)row * n + iw] = v; }
 };
 
+// Convergence test of one response entry (raft_model.py:1103): |d| / (|x| + tol) < tol.
+// Two IEEE square roots and a division per entry are ~50 instructions; almost every entry is far from the
+// threshold, so the test is first decided on |d|^2 against tol^2 (|x| (1 -+ 1e-6) + tol)^2 with the hardware
+// approximation of sqrt (v_sqrt_f64, relative error ~2^-23): inside the band between the two bounds (and for
+// NaNs) the reference expression itself decides, so every decision is the one that expression makes.
+__device__ __forceinline__ bool conv_test(double dr, double di, double xr, double xi, double tol) {
+    const double a = fma(dr, dr, di * di), bb = fma(xr, xr, xi * xi);
+    const double s = __builtin_amdgcn_sqrt(bb);
+    const double lo = tol * fma(s, 1.0 - 1e-6, tol), hi = tol * fma(s, 1.0 + 1e-6, tol);
+    const bool sure_ok = a < lo * lo, sure_not = a >= hi * hi;
+    bool ok = sure_ok;
+    if (!(sure_ok || sure_not)) ok = sqrt(dr * dr + di * di) / (sqrt(xr * xr + xi * xi) + tol) < tol;
+    return ok;
+}
+
 // ------------------------------------------------------------------ kernels
 // workgroup-wide OR / AND of a per-thread predicate
 __device__ __forceinline__ int wg_or(int v, bool multi) {
@@ -1400,8 +1415,7 @@ __global__ void __launch_bounds__(MAXT, MINB) k_solve_dynamics(DevTables T, Solv
                     }
                     if (isnan(xx[q].re) || isnan(xx[q].im)) bad = 1;
                     const double dr = xx[q].re - lr, di = xx[q].im - li;
-                    const double tc = sqrt(dr * dr + di * di) / (sqrt(xx[q].re * xx[q].re + xx[q].im * xx[q].im) + A.tol);
-                    if (!(tc < A.tol)) ok = 0;
+                    if (!conv_test(dr, di, xx[q].re, xx[q].im, A.tol)) ok = 0;
                     xl.put(2 * q, iw, 0.2 * lr + 0.8 * xx[q].re);
                     xl.put(2 * q + 1, iw, 0.2 * li + 0.8 * xx[q].im);
                 }
