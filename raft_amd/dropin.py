@@ -17,7 +17,9 @@ are mirrored too (internal slender-body QTFs, potSecOrder == 1, incl. the re-ent
 second-order force, raft_model.py:1108-1131).
 
 Not covered by the device path (raises, never falls back silently):
-flexible / >6-DOF FOWTs, moorMod==2 per-iteration mooring damping, submerged rotors.
+flexible / >6-DOF FOWTs, submerged rotors, array-level moorMod==2.
+A unit's own moorMod==2 mooring (per-iteration line damping from MoorPy, raft_model.py:1022-1030,1069-1072) is
+honoured by stepping the fixed point one device launch per iteration (Engine._solve_stepped).
 Per-member intermediates (mem.u, mem.ud, mem.pDyn, mem.Bmat, mem.F_exc_drag)
 are consumed only inside the replaced methods and are not materialised.
 """
@@ -300,6 +302,48 @@ class Engine:
             results[key] = np.zeros(nr)
         return results
 
+    def _solve_stepped(self, model, fowts, mats, F_extra, tol, display):
+        """The drag fixed point with a host step between iterations -- raft_model.py:1069-1072: with ``moorMod == 2``
+        the mooring system's linearised damping is re-evaluated (by MoorPy, on the host) about every iterate.  One
+        device launch per iteration (loop bound 1) from an explicit linearisation point; the relaxation (:1133) is done
+        here.  A unit that has converged keeps its linearisation point (:1104-1106 ``break``), so the launches that
+        the slower units of a farm still need reproduce its converged iterate unchanged."""
+        ctx = self.ctx
+        nF, nw = len(fowts), model.nw
+        f0 = fowts[0]
+        nIter = int(model.nIter) + 1                                        # :977
+        XiLast = np.zeros([nF, 1, 6, nw], dtype=complex) + model.XiStart    # :999
+        B_base = [np.array(m[1], dtype=float) for m in mats]
+        conv = np.zeros(nF, dtype=bool)
+        niter = np.zeros(nF, dtype=np.int32)
+        out = None
+        for iiter in range(nIter):
+            for i, fowt in enumerate(fowts):
+                if _dynamic_mooring(fowt) and not conv[i]:
+                    fowt.updateMooringDynamicMatrices(XiLast[i, 0, :6, :], fowt.S[0, :])        # :1070
+                    _, _, B6, _ = fowt.ms.getCoupledDynamicMatrices(lines_only=True)
+                    mats[i][1] = B_base[i] + translate_matrix_6to6(B6, _mooring_arm(fowt))        # :1072,:1079
+            self._upload(fowts, f0.zeta, f0.beta, mats)
+            ctx.set_linearisation_point(XiLast, keep_last=False)
+            out = ctx.solve_dynamics(0, tol=tol, XiStart=model.XiStart,
+                                     F_extra=F_extra if np.any(F_extra) else None,
+                                     want_Xi=True, want_B=True, want_F=True, want_Z=True)
+            if np.any(out['flags'] & 2):
+                break                                                       # NaN: raised by the caller (:1098-1099)
+            for i in range(nF):
+                if conv[i]:
+                    continue
+                niter[i] = iiter + 1
+                if out['flags'][i, 0] & 1:
+                    conv[i] = True
+                else:
+                    XiLast[i, 0] = 0.2 * XiLast[i, 0] + 0.8 * out['Xi'][i, 0, 0]               # :1133
+            if conv.all():
+                break
+        out['niter'] = niter[:, None].copy()
+        out['flags'] = (out['flags'] & ~1) | conv[:, None].astype(np.int32)
+        return out
+
     def solveDynamics(self, model, case, tol=0.01, conv_plot=0, RAO_plot=0, display=0):
         """raft_model.py:966-1302."""
         iCase = case['iCase'] if 'iCase' in case else None
@@ -309,8 +353,6 @@ class Engine:
         mats, F_extras = [], []
         for i, fowt in enumerate(fowts):
             self._check_supported(fowt)
-            if getattr(fowt, "ms", None) and getattr(fowt, "moorMod", 0) == 2:
-                raise UnsupportedFOWT("moorMod==2 (raft_model.py:1023-1030,1069-1072) is not on the device path")
             # sea state + excitation inputs (raft_model.py:1002)
             self._sea_state(fowt, case)
             fowt.F_BEM, fowt.F_BEM_fullDOF = self._F_BEM(fowt, case)
@@ -331,6 +373,16 @@ class Engine:
                     fowt.Fhydro_2nd_mean[ih, :], fowt.Fhydro_2nd[ih, :, :] = \
                         fowt.calcHydroForce_2ndOrd(fowt.beta[ih], fowt.S[ih, :])
             C_moor = fowt.C_moor
+            MA_moor = None
+            if _dynamic_mooring(fowt):                                      # :1022-1030
+                if getattr(fowt, "potSecOrder", 0) == 1:
+                    raise UnsupportedFOWT("moorMod==2 together with internal QTFs is not on the device path")
+                XiLast0 = np.zeros([fowt.nDOF, nw], dtype=complex) + model.XiStart
+                fowt.updateMooringDynamicMatrices(XiLast0[:6], fowt.S[0, :])
+                M6, A6, _, C6 = fowt.ms.getCoupledDynamicMatrices(lines_only=True)
+                r_moor = _mooring_arm(fowt)
+                MA_moor = translate_matrix_6to6(M6, r_moor) + translate_matrix_6to6(A6, r_moor)
+                C_moor = translate_matrix_6to6(C6, r_moor)
             A_BEM = np.asarray(fowt.A_BEM)
             B_BEM = np.asarray(fowt.B_BEM)
             B_gyro = np.sum(fowt.B_gyro, axis=2)
@@ -338,9 +390,11 @@ class Engine:
             if np.any(M_turb) or np.any(B_turb) or np.any(A_BEM) or np.any(B_BEM):
                 M_lin = M_turb + fowt.M_struc[:, :, None] + A_BEM + fowt.A_hydro_morison[:, :, None]   # :1045
                 B_lin = B_turb + fowt.B_struc[:, :, None] + B_BEM + B_gyro[:, :, None]                 # :1046
-                mats.append((np.zeros((6, 6)), np.zeros((6, 6)), C_lin, np.array([M_lin, B_lin])))
+                mats.append([np.zeros((6, 6)) if MA_moor is None else MA_moor, np.zeros((6, 6)), C_lin,
+                             np.array([M_lin, B_lin])])
             else:
-                mats.append((fowt.M_struc + fowt.A_hydro_morison, fowt.B_struc + B_gyro, C_lin, None))
+                mats.append([fowt.M_struc + fowt.A_hydro_morison + (0.0 if MA_moor is None else MA_moor),
+                             fowt.B_struc + B_gyro, C_lin, None])
             F_extras.append(fowt.F_BEM + fowt.Fhydro_2nd)
 
         f0 = fowts[0]
@@ -351,9 +405,12 @@ class Engine:
         internal_qtf = [getattr(f, "potSecOrder", 0) == 1 for f in fowts]
         if any(internal_qtf):
             ctx.set_linearisation_point(None, keep_last=True)
-        out = ctx.solve_dynamics(int(model.nIter), tol=tol, XiStart=model.XiStart,
-                                 F_extra=F_extra if np.any(F_extra) else None,
-                                 want_Xi=True, want_B=True, want_F=True, want_Z=True)
+        if any(_dynamic_mooring(f) for f in fowts):
+            out = self._solve_stepped(model, fowts, mats, F_extra, tol, display)
+        else:
+            out = ctx.solve_dynamics(int(model.nIter), tol=tol, XiStart=model.XiStart,
+                                     F_extra=F_extra if np.any(F_extra) else None,
+                                     want_Xi=True, want_B=True, want_F=True, want_Z=True)
         if any(internal_qtf) and not np.any(out['flags'] & 2):
             # raft_model.py:1108-1131: units that converged get their QTFs from the converged first-order motions,
             # the second-order force joins F_lin and the drag iteration continues FROM THE SAME Xi_last with the
@@ -427,6 +484,28 @@ class Engine:
         self._resident = fowts[0] if nF == 1 else None
         model._raftx_flags = out['flags'][:, 0].copy()
         return model.Xi
+
+
+def _dynamic_mooring(fowt):
+    """raft_model.py:1020-1023: the unit has its own mooring system with lumped-mass line dynamics."""
+    return bool(getattr(fowt, "ms", None)) and getattr(fowt, "moorMod", 0) == 2
+
+
+def _mooring_arm(fowt):
+    """raft_model.py:1027: from the unit's reduced-DOF reference node to the mooring body's reference point."""
+    return np.asarray(fowt.ms.bodyList[0].r6[:3], dtype=float) - np.asarray(fowt.nodeList[fowt.reducedDOF[0][0]].r[:3], dtype=float)
+
+
+def translate_matrix_6to6(Min, r):
+    """helpers.py:563-585 translateMatrix6to6DOF (H of helpers.py:428-437)."""
+    Min = np.asarray(Min, dtype=float)
+    H = np.array([[0.0, r[2], -r[1]], [-r[2], 0.0, r[0]], [r[1], -r[0], 0.0]])
+    out = np.zeros((6, 6))
+    out[:3, :3] = Min[:3, :3]
+    out[:3, 3:] = Min[:3, :3] @ H + Min[:3, 3:]
+    out[3:, :3] = out[:3, 3:].T
+    out[3:, 3:] = H @ Min[:3, :3] @ H.T + Min[3:, :3] @ H + H.T @ Min[:3, 3:] + Min[3:, 3:]
+    return out
 
 
 def tower_base_rows(fowt):

@@ -11,7 +11,7 @@ import numpy as np
 import pytest
 
 from oracle import ref_harness as rh
-from tests.util import group_rel_err, rel_err
+from tests.util import group_rel_err, rel_err, attach_fake_lines
 
 pytestmark = pytest.mark.skipif(not rh.reference_available(), reason="reference tree not present")
 
@@ -175,3 +175,25 @@ def test_saveTurbineOutputs_statistics_equal_reference(oracle_ctx, headings):
     assert all(k.startswith(("Tmoor", "wind_PSD", "cavitation")) for k in missing), missing
     with pytest.raises(dropin.UnsupportedFOWT):
         dropin.Engine(oracle_ctx).saveTurbineOutputs(m2.fowtList[0], {}, case)      # nothing resident for that engine
+
+
+@pytest.mark.parametrize("nIter", [10, 2])
+def test_installed_dynamic_mooring_hook(patch, nIter):
+    """moorMod == 2 (raft_model.py:1022-1030,1069-1072): the mooring damping is re-evaluated on the host about every
+    iterate; the patched solveDynamics steps the device fixed point one launch per iteration and must make the same
+    calls, in the same order, with the same arguments as the NumPy path (a motion-dependent stand-in for MoorPy)."""
+    settings = dict(min_freq=0.008, max_freq=0.4, nIter=nIter, XiStart=0.1)
+    case = rh.make_case(Hs=4.0, Tp=9.0, heading=-25.0)
+    m_new, m_old = _model("designs/OC3spar.yaml", settings), _model("designs/OC3spar.yaml", settings)
+    attach_fake_lines(m_new)
+    attach_fake_lines(m_old)
+    Xi_new = m_new.solveDynamics(copy.deepcopy(case)).copy()
+    with patch.unpatched():
+        Xi_old = m_old.solveDynamics(copy.deepcopy(case)).copy()
+    fn, fo = m_new.fowtList[0], m_old.fowtList[0]
+    assert fn.ms.calls == fo.ms.calls and fn.ms.calls >= 3
+    assert fn.ms.level == pytest.approx(fo.ms.level, rel=1e-10)
+    assert group_rel_err(Xi_new[:1], Xi_old[:1]) < 1e-10
+    assert rel_err(fn.Z, fo.Z) < 1e-10
+    assert rel_err(fn.B_hydro_drag, fo.B_hydro_drag) < 1e-9
+    assert rel_err(fn.Xi_fullDOF, fo.Xi_fullDOF) < 1e-10

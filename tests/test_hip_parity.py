@@ -74,6 +74,35 @@ def test_live_reference_solveDynamics(name, hip_ctx):
             assert rel_err(fowt.B_hydro_drag, u["B_hydro_drag"]) < TOL
 
 
+@pytest.mark.parametrize("name,nIter", [("c1_oc3spar.npz", 10), ("c2_volturnus.npz", 2), ("c4_farm.npz", 6)])
+def test_dynamic_mooring_stepped_solve(name, nIter, hip_ctx, oracle_ctx):
+    """moorMod == 2 (raft_model.py:1022-1030,1069-1072): one launch per iteration with the host's mooring-damping
+    update in between; device vs oracle through the same drop-in code, same host call sequence (the NumPy path is
+    compared with it on live objects in tests/test_dropin_live_reference.py)."""
+    from tests.util import attach_fake_lines
+    fx, m_gpu = load_model_fixture(name)
+    _, m_cpu = load_model_fixture(name)
+    for m in (m_gpu, m_cpu):
+        m.nIter = nIter
+        attach_fake_lines(m)
+        if "coupling_C" in fx:
+            class _MS:
+                def getCoupledStiffnessA(self, lines_only=True):
+                    return fx["coupling_C"]
+            m.ms = _MS()
+            m.moorMod = 0
+    case = fx["cases"][0]
+    Xi_gpu = dropin.Engine(hip_ctx).solveDynamics(m_gpu, case_from_fixture(case)).copy()
+    Xi_cpu = dropin.Engine(oracle_ctx).solveDynamics(m_cpu, case_from_fixture(case)).copy()
+    nH = Xi_gpu.shape[0] - 1
+    assert group_rel_err(Xi_gpu[:nH], Xi_cpu[:nH]) < TOL
+    assert np.array_equal(m_gpu._raftx_niter, m_cpu._raftx_niter)
+    for fg, fc in zip(m_gpu.fowtList, m_cpu.fowtList):
+        assert fg.ms.calls == fc.ms.calls and fg.ms.calls >= 3
+        assert rel_err(fg.Z, fc.Z) < TOL
+        assert rel_err(fg.B_hydro_drag, fc.B_hydro_drag) < TOL
+
+
 def _both(hip_ctx, oracle_ctx, tables, mats, cases, depth=200.0):
     M0, B0, C0, MBw = mats
     w, k, zeta, beta = cases

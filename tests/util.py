@@ -152,3 +152,47 @@ def volturnus_sweep(base_design, scales, heading_adjust=0.0):
         sw.set_diameter(4 + c, np.full(nD, 12.4), pH)
         sw.set_ends(7 + c, col(ccD / 2, z0, 14.545), col(ocR - ocD / 2, z0, 14.545), heading=heads[3][c] + heading_adjust)
     return sw
+
+
+# ------------------------------------------------------------------ moorMod == 2 stand-in
+class FakeLines:
+    """Stand-in for the MoorPy system of a ``moorMod == 2`` unit (MoorPy itself is absent here): the same call
+    surface the reference uses (raft_model.py:1023-1030,1069-1072; raft_fowt.py:2281-2289) with matrices that
+    depend on the motion amplitudes handed to updateMooringDynamicMatrices, the way the lumped-mass line drag does."""
+
+    class _Body:
+        def __init__(self, r6):
+            self.r6 = np.asarray(r6, dtype=float)
+
+    def __init__(self, r6, w):
+        self.bodyList = [self._Body(r6)]
+        self.lineList = []
+        self.w = np.asarray(w)
+        self.level = 0.0
+        self.calls = 0
+
+    def update(self, Xi, S):
+        self.calls += 1
+        v = self.w[None, :] * np.abs(np.asarray(Xi)[:3])
+        self.level = float(np.sqrt(np.sum(v ** 2 * (1.0 + S[None, :]))))
+
+    def getCoupledDynamicMatrices(self, lines_only=True):
+        assert lines_only
+        sym = lambda a: 0.5 * (a + a.T)
+        rng = np.random.default_rng(7)
+        M = sym(rng.uniform(0, 1, (6, 6))) * 2e4 + np.diag([3e5, 3e5, 2e5, 1e7, 1e7, 2e7])
+        A = sym(rng.uniform(0, 1, (6, 6))) * 1e4 + np.diag([1e5, 1e5, 1e5, 5e6, 5e6, 5e6])
+        B = (sym(rng.uniform(0, 1, (6, 6))) * 2e4 + np.diag([4e5, 4e5, 2e5, 3e7, 3e7, 6e7])) * (0.2 + self.level)
+        C = sym(rng.uniform(0, 1, (6, 6))) * 1e3 + np.diag([8e4, 8e4, 2e4, 2e8, 2e8, 1.5e8])
+        return M, A, B, C
+
+
+def attach_fake_lines(model):
+    for f in model.fowtList:
+        if not hasattr(f, "nodeList"):                      # stand-in units (tests/standin.py): PRP-referred rigid body
+            node = standin.Obj()
+            node.r = np.array([f.x_ref, f.y_ref, 0.0])
+            f.nodeList, f.reducedDOF, f.r6 = [node], [[0, 0]], np.r_[node.r, 0.0, 0.0, 0.0]
+        f.ms = FakeLines(np.r_[f.r6[:3] + np.array([0.3, -0.2, -1.5]), 0, 0, 0], f.w)
+        f.moorMod = 2
+        f.updateMooringDynamicMatrices = (lambda Xi, S, ms=f.ms: ms.update(Xi, S))
