@@ -19,6 +19,7 @@
 // straight members by rotors (e^{-i k du}, e^{+-k dz}); run starts are evaluated exactly.
 // Runs are detected by the library at upload from the absolute strip positions.
 #pragma once
+#include <type_traits>
 
 #define NF RAFTX_NFIELD
 
@@ -148,6 +149,13 @@ __device__ __forceinline__ int pair_of_block(int b, int npair) {
 static inline unsigned grid_for_pairs(size_t npair) { return (unsigned)(((npair + 7) / 8) * 8); }
 
 // ------------------------------------------------------------------ LDS layout
+#ifndef RAFTX_RUN_LOOPS
+#define RAFTX_RUN_LOOPS 1    // sweeps iterate over runs with run-type-specialised inner loops (0: one flag-switched loop over strips)
+#endif
+// ... for the shapes with up to two bins per lane; the larger ones (more than 1024 bins) keep the single loop, whose
+// register footprint is smaller there
+template <int NB>
+constexpr bool RUN_LOOPS = RAFTX_RUN_LOOPS && NB <= 2;
 #define RA_N 18              // doubles per staged record: arm, q, p1, p2 (pass A) + x, y, z, unit step (run starts)
 #define TR_ROWS 6            // rows of a reduction tile (pass A: 2 strips x 3 sums per batch)
 #define TR_STRIDE 72         // doubles per row (8 segments of 9: conflict-free)
@@ -299,6 +307,7 @@ struct Kin {
     // the same depth share P, Q; members with the same step vector share the rotors
     double P0[NB], Q0[NB];
     double mz, mux, muy, muz;
+    bool rot, dec;        // of the current step vector (wave-uniform): the phase rotor / the depth-decay rotors differ from 1
 };
 
 // Run start: exact evaluation from the absolute position (helpers.py:201,211-222).
@@ -342,7 +351,9 @@ __device__ __forceinline__ void kin_start(Kin<NB> &K, const RunStart rs, const B
     K.mz = z;
     if (!same_u) {
         const bool rot = du != 0.0, dec = uz != 0.0;  // wave-uniform: vertical members skip the phase rotor,
-#pragma unroll                                        // horizontal ones the depth-decay rotors
+        K.rot = rot;                                  // horizontal ones the depth-decay rotors
+        K.dec = dec;
+#pragma unroll
         for (int j = 0; j < NB; j++) {
             double s = 0.0, c = 1.0, p = 1.0, q = 1.0;
             if (rot) fast_sincos(-(b.k[j] * du), s, c);
@@ -412,6 +423,7 @@ __device__ __forceinline__ void kin_reset(Kin<NB> &K) {
         K.Q0[j] = 0.0;
     }
     K.mz = K.mux = K.muy = K.muz = __builtin_nan("");      // never equal: the first run start computes everything
+    K.rot = K.dec = false;
 }
 
 // ------------------------------------------------------------------ strip sweeps
@@ -617,18 +629,16 @@ struct StripSrc<6> {
     }
 };
 
-// one strip of pass A: advances K, returns the three sums over this lane's bins
-template <int NB, typename RecPtr>
-__device__ __forceinline__ void passA_strip(Kin<NB> &K, const RecA &r, int fl, RecPtr rec, const Bins<NB> &b,
-                                            double cb, double sb, const cplx (&X)[NB][6], double &v0, double &v1,
-                                            double &v2) {
-    kin_advance<NB, false>(K, fl, rec, b, b.c1, cb, sb);
+// one strip of pass A at the kinematic state (ar, ai, ps = P + Q, pd = P - Q): the three sums over this lane's bins
+template <int NB>
+__device__ __forceinline__ void passA_core(const double (&ar)[NB], const double (&ai)[NB], const double (&psv)[NB],
+                                           const double (&pdv)[NB], const RecA &r, bool circ, double cb, double sb,
+                                           const cplx (&X)[NB][6], double &v0, double &v1, double &v2) {
     v0 = 0.0; v1 = 0.0; v2 = 0.0;
-    const bool circ = (fl & DSI_CIRC) != 0;
 #pragma unroll
     for (int j = 0; j < NB; j++) {
-        const double ps = K.P[j] + K.Q[j], pd = K.P[j] - K.Q[j];
-        const double t1r = K.ar[j] * ps, t1i = K.ai[j] * ps, t2r = -K.ai[j] * pd, t2i = K.ar[j] * pd;
+        const double ps = psv[j], pd = pdv[j];
+        const double t1r = ar[j] * ps, t1i = ai[j] * ps, t2r = -ai[j] * pd, t2i = ar[j] * pd;
         double rxr = fma(cb, t1r, X[j][0].im), rxi = fma(cb, t1i, -X[j][0].re);
         double ryr = fma(sb, t1r, X[j][1].im), ryi = fma(sb, t1i, -X[j][1].re);
         double rzr = t2r + X[j][2].im, rzi = t2i - X[j][2].re;
@@ -655,6 +665,42 @@ __device__ __forceinline__ void passA_strip(Kin<NB> &K, const RecA &r, int fl, R
             v0 = fma(vqr, vqr, fma(vqi, vqi, v0));
             v1 = fma(v1r, v1r, fma(v1i, v1i, v1));
             v2 = fma(v2r, v2r, fma(v2i, v2i, v2));
+        }
+    }
+}
+// one strip of pass A: advances K, returns the three sums over this lane's bins
+template <int NB, typename RecPtr>
+__device__ __forceinline__ void passA_strip(Kin<NB> &K, const RecA &r, int fl, RecPtr rec, const Bins<NB> &b,
+                                            double cb, double sb, const cplx (&X)[NB][6], double &v0, double &v1,
+                                            double &v2) {
+    kin_advance<NB, false>(K, fl, rec, b, b.c1, cb, sb);
+    double ps[NB], pd[NB];
+#pragma unroll
+    for (int j = 0; j < NB; j++) {
+        ps[j] = K.P[j] + K.Q[j];
+        pd[j] = K.P[j] - K.Q[j];
+    }
+    passA_core<NB>(K.ar, K.ai, ps, pd, r, (fl & DSI_CIRC) != 0, cb, sb, X, v0, v1, v2);
+}
+
+// Run-type-specialised step of the kinematic state (RT: 0 inclined, 1 vertical = no phase rotation, 2 horizontal = no
+// depth decay); m = 1 or 2 unit steps (wave-uniform)
+template <int NB, int RT>
+__device__ __forceinline__ void kin_step_rt(Kin<NB> &K, int m) {
+    if (RT != 1) {
+#pragma unroll
+        for (int j = 0; j < NB; j++) {
+            const double rr = (m == 1) ? K.r1r[j] : K.r2r[j], ri = (m == 1) ? K.r1i[j] : K.r2i[j];
+            const double t = K.ar[j] * rr - K.ai[j] * ri;
+            K.ai[j] = K.ar[j] * ri + K.ai[j] * rr;
+            K.ar[j] = t;
+        }
+    }
+    if (RT != 2) {
+#pragma unroll
+        for (int j = 0; j < NB; j++) {
+            K.P[j] *= (m == 1) ? K.r1p[j] : K.r2p[j];
+            K.Q[j] *= (m == 1) ? K.r1q[j] : K.r2q[j];
         }
     }
 }
@@ -685,6 +731,92 @@ __device__ __forceinline__ void linearize_passA(cdptr ds, ciptr dsi, int S,
     const int row = lane >> 3;
     const bool writer = (lane & 7) == 0;
     int prev_s0 = -1, prev_nb = 0;
+    if constexpr (RUN_LOOPS<NB>) {
+    // Loop over RUNS; batches of up to two strips of the same run form the inner loop, specialised by run type (see
+    // drag_excitation): a vertical run steps P, Q only, a horizontal run the phasor only and keeps P + Q, P - Q out of
+    // the loop.  The run-start evaluation (sincos / exp) is outside the batch loop's body.
+    int s = 0;
+    int fl = src.flags(min(1, S - 1));              // flags of strip 0; strip 1's are on their way
+    auto run = [&](auto rt_tag) {
+        constexpr int RT = decltype(rt_tag)::value;
+        double psh[NB], pdh[NB];                    // RT == 2: P + Q, P - Q of the whole run
+#pragma unroll
+        for (int j = 0; j < NB; j++) {
+            psh[j] = K.P[j] + K.Q[j];
+            pdh[j] = K.P[j] - K.Q[j];
+        }
+        auto strip = [&](int si, int fls, double (&v)[3]) {
+            const auto rec = src.rec(si);
+            const RecA r = load_recA(rec);
+            if (RT == 2) {
+                passA_core<NB>(K.ar, K.ai, psh, pdh, r, (fls & DSI_CIRC) != 0, cb, sb, X, v[0], v[1], v[2]);
+            } else {
+                double ps[NB], pd[NB];
+#pragma unroll
+                for (int j = 0; j < NB; j++) {
+                    ps[j] = K.P[j] + K.Q[j];
+                    pd[j] = K.P[j] - K.Q[j];
+                }
+                passA_core<NB>(K.ar, K.ai, ps, pd, r, (fls & DSI_CIRC) != 0, cb, sb, X, v[0], v[1], v[2]);
+            }
+        };
+#pragma unroll 1
+        while (true) {
+            const int s0 = s;
+            double pend[8];
+            if (prev_s0 >= 0) {
+#pragma unroll
+                for (int e = 0; e < 8; e++) pend[e] = rp[e];
+            }
+            double va[3], vb[3] = {0.0, 0.0, 0.0};
+            strip(s0, fl, va);
+            if (prev_s0 >= 0) {
+                double a = ((pend[0] + pend[4]) + (pend[1] + pend[5])) + ((pend[2] + pend[6]) + (pend[3] + pend[7]));
+                a += dpp_mov<0xB1>(a);
+                a += dpp_mov<0x4E>(a);
+                a += dpp_mov<0x104>(a);
+                if (writer && row < prev_nb * 3) vout[prev_s0 * 3 + row] = a;
+            }
+            int nb = 1;
+            bool more = false;                      // does the run go on after this batch?
+            if (s0 + 1 < S) {
+                fl = src.flags(min(s0 + 2, S - 1)); // flags of strip s0 + 1
+                const int m1 = fl & DSI_M;
+                if (m1 != 0) {
+                    kin_step_rt<NB, RT>(K, m1);
+                    strip(s0 + 1, fl, vb);
+                    nb = 2;
+                    if (s0 + 2 < S) {
+                        fl = src.flags(min(s0 + 3, S - 1));     // flags of strip s0 + 2
+                        const int m2 = fl & DSI_M;
+                        if (m2 != 0) {
+                            kin_step_rt<NB, RT>(K, m2);
+                            more = true;
+                        }
+                    }
+                }
+            }
+#pragma unroll
+            for (int c = 0; c < 3; c++) {
+                wr[c * TR_STRIDE] = va[c];
+                wr[(3 + c) * TR_STRIDE] = vb[c];
+            }
+            wave_lds_fence();
+            prev_s0 = s0;
+            prev_nb = nb;
+            s = s0 + nb;
+            PT_MARK(6);   // strips of pass A
+            if (!more) break;
+        }
+    };
+#pragma unroll 1
+    while (s < S) {
+        kin_start<NB, false>(K, run_start_of(src.rec(s)), b, b.c1, cb, sb);
+        if (!K.rot) run(std::integral_constant<int, 1>{});
+        else if (!K.dec) run(std::integral_constant<int, 2>{});
+        else run(std::integral_constant<int, 0>{});
+    }
+    } else {
 #pragma unroll 1
     for (int s0 = 0; s0 < S; s0 += SB) {
         const int nb = min(SB, S - s0);
@@ -722,6 +854,7 @@ __device__ __forceinline__ void linearize_passA(cdptr ds, ciptr dsi, int S,
         prev_s0 = s0;
         prev_nb = nb;
         PT_MARK(6);   // strips of pass A
+    }
     }
     {   // drain: the last batch
         const double a = tile_reduce(tile, lane);
@@ -835,11 +968,8 @@ __device__ __forceinline__ void strip_phase(cdptr ds, ciptr dsi, int S,
 // Pass B: drag excitation of one heading with the live coefficients (raft_member.py:2122-2124,
 // :2146-2151), ACCUMULATED into F: F += sum_s t1 U_s + t2 V_s.  U,V of the next strip are
 // fetched from LDS one strip ahead.
-template <int NB, typename RecPtr>
-__device__ __forceinline__ void passB_strip(Kin<NB> &K, int fl, RecPtr rec, const Bins<NB> &b,
-                                            double cb, double sb, const double (&U)[6], const double (&V)[6],
-                                            cplx (&F)[NB][6]) {
-    kin_advance<NB, false>(K, fl, rec, b, b.c1, cb, sb);
+template <int NB>
+__device__ __forceinline__ void passB_core(const Kin<NB> &K, const double (&U)[6], const double (&V)[6], cplx (&F)[NB][6]) {
 #pragma unroll
     for (int j = 0; j < NB; j++) {
         const double ps = K.P[j] + K.Q[j], pd = K.P[j] - K.Q[j];
@@ -850,6 +980,13 @@ __device__ __forceinline__ void passB_strip(Kin<NB> &K, int fl, RecPtr rec, cons
             F[j][q].im = fma(t1i, U[q], fma(t2i, V[q], F[j][q].im));
         }
     }
+}
+template <int NB, typename RecPtr>
+__device__ __forceinline__ void passB_strip(Kin<NB> &K, int fl, RecPtr rec, const Bins<NB> &b,
+                                            double cb, double sb, const double (&U)[6], const double (&V)[6],
+                                            cplx (&F)[NB][6]) {
+    kin_advance<NB, false>(K, fl, rec, b, b.c1, cb, sb);
+    passB_core<NB>(K, U, V, F);
 }
 __device__ __forceinline__ void load_uv(ldptr uv, double (&U)[6], double (&V)[6]) {
 #pragma unroll
@@ -865,12 +1002,110 @@ __device__ __forceinline__ void drag_excitation(cdptr ds, ciptr dsi, int S, cons
     kin_reset(K);
     if (S <= 0) return;
     StripSrc<STAGE> src(l, ds, dsi);
+    if constexpr (RUN_LOOPS<NB>) {
+    // Loop over RUNS; the strips of a run form the inner loop, specialised by what changes along the run:
+    //  * vertical run (no phase rotation: a = e^{-i k xi} is the same for every strip): the sums G1 = sum (P+Q) U_s,
+    //    G2 = sum (P-Q) V_s are REAL (12 FMAs per strip and bin instead of 24 + 4) and meet the phasor once per run,
+    //    F += a G1 + i a G2; the step is two multiplies;
+    //  * horizontal run (no depth decay: P, Q are the same for every strip): P+Q, P-Q leave the loop, the step is the
+    //    phase rotation alone;
+    //  * inclined run: the general form.
+    int s = 0;
+    int fl = src.flags(min(1, S - 1));              // flags of strip 0; strip 1's are on their way
+#pragma unroll 1
+    while (s < S) {
+        kin_start<NB, false>(K, run_start_of(src.rec(s)), b, b.c1, cb, sb);
+        if (!K.rot) {
+            double G1[NB][6], G2[NB][6];
+#pragma unroll
+            for (int j = 0; j < NB; j++)
+#pragma unroll
+                for (int q = 0; q < 6; q++) G1[j][q] = G2[j][q] = 0.0;
+#pragma unroll 1
+            while (true) {
+                double U[6], V[6];
+                load_uv(l.uv + s * 12, U, V);
+#pragma unroll
+                for (int j = 0; j < NB; j++) {
+                    const double ps = K.P[j] + K.Q[j], pd = K.P[j] - K.Q[j];
+#pragma unroll
+                    for (int q = 0; q < 6; q++) {
+                        G1[j][q] = fma(ps, U[q], G1[j][q]);
+                        G2[j][q] = fma(pd, V[q], G2[j][q]);
+                    }
+                }
+                if (++s >= S) break;
+                fl = src.flags(min(s + 1, S - 1));  // flags of the new strip s
+                const int m = fl & DSI_M;
+                if (m == 0) break;                  // it starts the next run
+#pragma unroll
+                for (int j = 0; j < NB; j++) {
+                    K.P[j] *= (m == 1) ? K.r1p[j] : K.r2p[j];
+                    K.Q[j] *= (m == 1) ? K.r1q[j] : K.r2q[j];
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < NB; j++)
+#pragma unroll
+                for (int q = 0; q < 6; q++) {
+                    F[j][q].re = fma(K.ar[j], G1[j][q], fma(-K.ai[j], G2[j][q], F[j][q].re));
+                    F[j][q].im = fma(K.ai[j], G1[j][q], fma(K.ar[j], G2[j][q], F[j][q].im));
+                }
+        } else if (!K.dec) {
+            double ps[NB], pd[NB];
+#pragma unroll
+            for (int j = 0; j < NB; j++) {
+                ps[j] = K.P[j] + K.Q[j];
+                pd[j] = K.P[j] - K.Q[j];
+            }
+#pragma unroll 1
+            while (true) {
+                double U[6], V[6];
+                load_uv(l.uv + s * 12, U, V);
+#pragma unroll
+                for (int j = 0; j < NB; j++) {
+                    const double t1r = K.ar[j] * ps[j], t1i = K.ai[j] * ps[j], t2r = -K.ai[j] * pd[j], t2i = K.ar[j] * pd[j];
+#pragma unroll
+                    for (int q = 0; q < 6; q++) {
+                        F[j][q].re = fma(t1r, U[q], fma(t2r, V[q], F[j][q].re));
+                        F[j][q].im = fma(t1i, U[q], fma(t2i, V[q], F[j][q].im));
+                    }
+                }
+                if (++s >= S) break;
+                fl = src.flags(min(s + 1, S - 1));
+                const int m = fl & DSI_M;
+                if (m == 0) break;
+#pragma unroll
+                for (int j = 0; j < NB; j++) {
+                    const double rr = (m == 1) ? K.r1r[j] : K.r2r[j], ri = (m == 1) ? K.r1i[j] : K.r2i[j];
+                    const double t = K.ar[j] * rr - K.ai[j] * ri;
+                    K.ai[j] = K.ar[j] * ri + K.ai[j] * rr;
+                    K.ar[j] = t;
+                }
+            }
+        } else {
+#pragma unroll 1
+            while (true) {
+                double U[6], V[6];
+                load_uv(l.uv + s * 12, U, V);
+                passB_core<NB>(K, U, V, F);
+                if (++s >= S) break;
+                fl = src.flags(min(s + 1, S - 1));
+                const int m = fl & DSI_M;
+                if (m == 0) break;
+                if (m == 1) kin_step1(K);
+                else kin_step2(K);
+            }
+        }
+    }
+    } else {
 #pragma unroll 1
     for (int s = 0; s < S; s++) {
         double U[6], V[6];
         load_uv(l.uv + s * 12, U, V);               // issued before the (branchy) kinematics update
         const int fl = src.flags(min(s + 1, S - 1));
         passB_strip<NB>(K, fl, src.rec(s), b, cb, sb, U, V, F);
+    }
     }
 }
 
