@@ -308,6 +308,7 @@ struct Kin {
     double P0[NB], Q0[NB];
     double mz, mux, muy, muz;
     bool rot, dec;        // of the current step vector (wave-uniform): the phase rotor / the depth-decay rotors differ from 1
+    bool vert;            // the step vector has no horizontal part (a vertical member, or a run of one strip)
 };
 
 // Run start: exact evaluation from the absolute position (helpers.py:201,211-222).
@@ -353,6 +354,7 @@ __device__ __forceinline__ void kin_start(Kin<NB> &K, const RunStart rs, const B
         const bool rot = du != 0.0, dec = uz != 0.0;  // wave-uniform: vertical members skip the phase rotor,
         K.rot = rot;                                  // horizontal ones the depth-decay rotors
         K.dec = dec;
+        K.vert = (ux == 0.0) && (uy == 0.0);
 #pragma unroll
         for (int j = 0; j < NB; j++) {
             double s = 0.0, c = 1.0, p = 1.0, q = 1.0;
@@ -424,6 +426,7 @@ __device__ __forceinline__ void kin_reset(Kin<NB> &K) {
     }
     K.mz = K.mux = K.muy = K.muz = __builtin_nan("");      // never equal: the first run start computes everything
     K.rot = K.dec = false;
+    K.vert = true;
 }
 
 // ------------------------------------------------------------------ strip sweeps
@@ -629,28 +632,81 @@ struct StripSrc<6> {
     }
 };
 
+__device__ __forceinline__ double src_qz(cdptr rec) { return rec[DS_Q + 2]; }
+__device__ __forceinline__ double src_qz(ldptr r) { return r[5]; }
+__device__ __forceinline__ double src_qz(RecSplit r) { return r.lr[5]; }
 // one strip of pass A at the kinematic state (ar, ai, ps = P + Q, pd = P - Q): the three sums over this lane's bins
+// Body-velocity terms that do not change along a run (the strips of a run share the arm components across its axis):
+//   RT 1 (vertical run: arm x, y fixed)   x: X0 - X5 ay,  y: X1 + X5 ax,  z: X2 + X3 ay - X4 ax   (all of z)
+//   RT 2 (horizontal run: arm z fixed)    x: X0 + X4 az,  y: X1 - X3 az
+// in the rotated form of pass A (re <- im, im <- -re of i w V).
 template <int NB>
+struct BodyHoist {
+    double xr[NB], xi[NB], yr[NB], yi[NB], zr[NB], zi[NB];
+};
+template <int NB, int RT>
+__device__ __forceinline__ void body_hoist(BodyHoist<NB> &H, const cplx (&X)[NB][6], double ax, double ay, double az) {
+#pragma unroll
+    for (int j = 0; j < NB; j++) {
+        if (RT == 1) {
+            H.xr[j] = fma(-X[j][5].im, ay, X[j][0].im);
+            H.xi[j] = fma(X[j][5].re, ay, -X[j][0].re);
+            H.yr[j] = fma(X[j][5].im, ax, X[j][1].im);
+            H.yi[j] = fma(-X[j][5].re, ax, -X[j][1].re);
+            H.zr[j] = fma(-X[j][4].im, ax, fma(X[j][3].im, ay, X[j][2].im));
+            H.zi[j] = fma(X[j][4].re, ax, fma(-X[j][3].re, ay, -X[j][2].re));
+        } else if (RT == 2) {
+            H.xr[j] = fma(X[j][4].im, az, X[j][0].im);
+            H.xi[j] = fma(-X[j][4].re, az, -X[j][0].re);
+            H.yr[j] = fma(-X[j][3].im, az, X[j][1].im);
+            H.yi[j] = fma(X[j][3].re, az, -X[j][1].re);
+        }
+    }
+}
+template <int NB, int RT = 0>
 __device__ __forceinline__ void passA_core(const double (&ar)[NB], const double (&ai)[NB], const double (&psv)[NB],
                                            const double (&pdv)[NB], const RecA &r, bool circ, double cb, double sb,
-                                           const cplx (&X)[NB][6], double &v0, double &v1, double &v2) {
+                                           const cplx (&X)[NB][6], const BodyHoist<NB> &H, double &v0, double &v1, double &v2) {
     v0 = 0.0; v1 = 0.0; v2 = 0.0;
 #pragma unroll
     for (int j = 0; j < NB; j++) {
         const double ps = psv[j], pd = pdv[j];
         const double t1r = ar[j] * ps, t1i = ai[j] * ps, t2r = -ai[j] * pd, t2i = ar[j] * pd;
-        double rxr = fma(cb, t1r, X[j][0].im), rxi = fma(cb, t1i, -X[j][0].re);
-        double ryr = fma(sb, t1r, X[j][1].im), ryi = fma(sb, t1i, -X[j][1].re);
-        double rzr = t2r + X[j][2].im, rzi = t2i - X[j][2].re;
-        rxr = fma(X[j][4].im, r.az, rxr); rxr = fma(-X[j][5].im, r.ay, rxr);
-        rxi = fma(-X[j][4].re, r.az, rxi); rxi = fma(X[j][5].re, r.ay, rxi);
-        ryr = fma(X[j][5].im, r.ax, ryr); ryr = fma(-X[j][3].im, r.az, ryr);
-        ryi = fma(-X[j][5].re, r.ax, ryi); ryi = fma(X[j][3].re, r.az, ryi);
-        rzr = fma(X[j][3].im, r.ay, rzr); rzr = fma(-X[j][4].im, r.ax, rzr);
-        rzi = fma(-X[j][3].re, r.ay, rzi); rzi = fma(X[j][4].re, r.ax, rzi);
-        const double vqr = fma(r.qz, rzr, fma(r.qy, ryr, r.qx * rxr));
-        const double vqi = fma(r.qz, rzi, fma(r.qy, ryi, r.qx * rxi));
-        if (circ) {                 // |v_perp|^2 = |v|^2 - |v_q|^2   (raft_member.py:2084-2087)
+        double rxr, rxi, ryr, ryi, rzr, rzi;
+        if (RT == 1) {
+            rxr = fma(X[j][4].im, r.az, fma(cb, t1r, H.xr[j]));
+            rxi = fma(-X[j][4].re, r.az, fma(cb, t1i, H.xi[j]));
+            ryr = fma(-X[j][3].im, r.az, fma(sb, t1r, H.yr[j]));
+            ryi = fma(X[j][3].re, r.az, fma(sb, t1i, H.yi[j]));
+            rzr = t2r + H.zr[j];
+            rzi = t2i + H.zi[j];
+        } else if (RT == 2) {
+            rxr = fma(-X[j][5].im, r.ay, fma(cb, t1r, H.xr[j]));
+            rxi = fma(X[j][5].re, r.ay, fma(cb, t1i, H.xi[j]));
+            ryr = fma(X[j][5].im, r.ax, fma(sb, t1r, H.yr[j]));
+            ryi = fma(-X[j][5].re, r.ax, fma(sb, t1i, H.yi[j]));
+            rzr = fma(-X[j][4].im, r.ax, fma(X[j][3].im, r.ay, t2r + X[j][2].im));
+            rzi = fma(X[j][4].re, r.ax, fma(-X[j][3].re, r.ay, t2i - X[j][2].re));
+        } else {
+            rxr = fma(cb, t1r, X[j][0].im); rxi = fma(cb, t1i, -X[j][0].re);
+            ryr = fma(sb, t1r, X[j][1].im); ryi = fma(sb, t1i, -X[j][1].re);
+            rzr = t2r + X[j][2].im; rzi = t2i - X[j][2].re;
+            rxr = fma(X[j][4].im, r.az, rxr); rxr = fma(-X[j][5].im, r.ay, rxr);
+            rxi = fma(-X[j][4].re, r.az, rxi); rxi = fma(X[j][5].re, r.ay, rxi);
+            ryr = fma(X[j][5].im, r.ax, ryr); ryr = fma(-X[j][3].im, r.az, ryr);
+            ryi = fma(-X[j][5].re, r.ax, ryi); ryi = fma(X[j][3].re, r.az, ryi);
+            rzr = fma(X[j][3].im, r.ay, rzr); rzr = fma(-X[j][4].im, r.ax, rzr);
+            rzi = fma(-X[j][3].re, r.ay, rzi); rzi = fma(X[j][4].re, r.ax, rzi);
+        }
+        // the axis of a run of two or more strips is its step direction: q = (0, 0, +-1) on a vertical run, q_z = 0 on a
+        // horizontal one (the step vector is unit * q with unit > 0, so these are exact zeros and so are the dropped products)
+        const double vqr = RT == 1 ? r.qz * rzr : (RT == 2 ? fma(r.qy, ryr, r.qx * rxr) : fma(r.qz, rzr, fma(r.qy, ryr, r.qx * rxr)));
+        const double vqi = RT == 1 ? r.qz * rzi : (RT == 2 ? fma(r.qy, ryi, r.qx * rxi) : fma(r.qz, rzi, fma(r.qy, ryi, r.qx * rxi)));
+        if (RT == 1 && circ) {      // q = (0, 0, +-1): v_q is the z component, v_perp the horizontal part
+            v0 = fma(rzr, rzr, fma(rzi, rzi, v0));
+            v1 = fma(rxr, rxr, fma(rxi, rxi, v1));
+            v1 = fma(ryr, ryr, fma(ryi, ryi, v1));
+        } else if (circ) {          // |v_perp|^2 = |v|^2 - |v_q|^2   (raft_member.py:2084-2087)
             const double q2 = fma(vqi, vqi, vqr * vqr);
             double n2 = fma(rxi, rxi, rxr * rxr);
             n2 = fma(ryr, ryr, n2); n2 = fma(ryi, ryi, n2);
@@ -680,7 +736,8 @@ __device__ __forceinline__ void passA_strip(Kin<NB> &K, const RecA &r, int fl, R
         ps[j] = K.P[j] + K.Q[j];
         pd[j] = K.P[j] - K.Q[j];
     }
-    passA_core<NB>(K.ar, K.ai, ps, pd, r, (fl & DSI_CIRC) != 0, cb, sb, X, v0, v1, v2);
+    BodyHoist<NB> H;      // unused by the general form
+    passA_core<NB, 0>(K.ar, K.ai, ps, pd, r, (fl & DSI_CIRC) != 0, cb, sb, X, H, v0, v1, v2);
 }
 
 // Run-type-specialised step of the kinematic state (RT: 0 inclined, 1 vertical = no phase rotation, 2 horizontal = no
@@ -745,11 +802,16 @@ __device__ __forceinline__ void linearize_passA(cdptr ds, ciptr dsi, int S,
             psh[j] = K.P[j] + K.Q[j];
             pdh[j] = K.P[j] - K.Q[j];
         }
+        BodyHoist<NB> H;
+        {
+            const RecA r0 = load_recA(src.rec(s));
+            body_hoist<NB, RT>(H, X, r0.ax, r0.ay, r0.az);
+        }
         auto strip = [&](int si, int fls, double (&v)[3]) {
             const auto rec = src.rec(si);
             const RecA r = load_recA(rec);
             if (RT == 2) {
-                passA_core<NB>(K.ar, K.ai, psh, pdh, r, (fls & DSI_CIRC) != 0, cb, sb, X, v[0], v[1], v[2]);
+                passA_core<NB, RT>(K.ar, K.ai, psh, pdh, r, (fls & DSI_CIRC) != 0, cb, sb, X, H, v[0], v[1], v[2]);
             } else {
                 double ps[NB], pd[NB];
 #pragma unroll
@@ -757,7 +819,7 @@ __device__ __forceinline__ void linearize_passA(cdptr ds, ciptr dsi, int S,
                     ps[j] = K.P[j] + K.Q[j];
                     pd[j] = K.P[j] - K.Q[j];
                 }
-                passA_core<NB>(K.ar, K.ai, ps, pd, r, (fls & DSI_CIRC) != 0, cb, sb, X, v[0], v[1], v[2]);
+                passA_core<NB, RT>(K.ar, K.ai, ps, pd, r, (fls & DSI_CIRC) != 0, cb, sb, X, H, v[0], v[1], v[2]);
             }
         };
 #pragma unroll 1
@@ -812,8 +874,9 @@ __device__ __forceinline__ void linearize_passA(cdptr ds, ciptr dsi, int S,
 #pragma unroll 1
     while (s < S) {
         kin_start<NB, false>(K, run_start_of(src.rec(s)), b, b.c1, cb, sb);
-        if (!K.rot) run(std::integral_constant<int, 1>{});
-        else if (!K.dec) run(std::integral_constant<int, 2>{});
+        // a run of one strip has a zero step vector and says nothing about the member's axis: general form
+        if (K.vert && K.dec && fabs(src_qz(src.rec(s))) == 1.0) run(std::integral_constant<int, 1>{});   // vertical (implies no phase rotation)
+        else if (!K.vert && !K.dec) run(std::integral_constant<int, 2>{});   // horizontal
         else run(std::integral_constant<int, 0>{});
     }
     } else {
