@@ -464,6 +464,60 @@ def test_member_runs_use_rotors_and_match_exact_evaluation(hip_ctx, oracle_ctx):
         assert group_rel_err(op["Xi"][d], oh["Xi"][d]) < 1e-12
 
 
+def _oriented_run_table(rng, axes, n_per=9):
+    """Members along the given axes (None = one-strip members with random triads), circular and rectangular mixed."""
+    from raft_amd import strips as st
+    n = sum(n_per if a is not None else 3 for a in axes)
+    base = random_strips(rng, n)
+    rec = base.strips
+    i = 0
+    for a in axes:
+        if a is None:                       # three unrelated strips: runs of one
+            i += 3
+            continue
+        q = np.asarray(a, dtype=float)
+        q = q / np.linalg.norm(q)
+        h = np.array([0.0, 0.0, 1.0]) if abs(q[2]) < 0.9 else np.array([1.0, 0.0, 0.0])
+        p1 = np.cross(h, q)
+        p1 /= np.linalg.norm(p1)
+        p2 = np.cross(q, p1)
+        A = np.array([rng.uniform(-30, 30), rng.uniform(-30, 30), rng.uniform(-28, -22)])
+        unit, pos = rng.uniform(0.3, 0.7), 0.0
+        for j in range(n_per):
+            pos += 0 if j == 0 else int(rng.choice([1, 2])) * unit
+            r = A + pos * q
+            rec[i, st.F_AX:st.F_AX + 3] += r - rec[i, st.F_X:st.F_X + 3]
+            rec[i, st.F_X:st.F_X + 3] = r
+            rec[i, st.F_Q:st.F_Q + 3], rec[i, st.F_P1:st.F_P1 + 3], rec[i, st.F_P2:st.F_P2 + 3] = q, p1, p2
+            rec[i, st.F_CIRC] = float(j % 3 != 0)
+            i += 1
+    return base
+
+
+@pytest.mark.parametrize("nw", [200, 64, 300])
+def test_run_type_loops_of_the_lean_kernel(hip_ctx, oracle_ctx, nw):
+    """The sweeps iterate over runs with inner loops specialised by run type (vertical / horizontal / inclined):
+    every type, runs of one strip, a horizontal member square to the waves (no phase rotation without being vertical),
+    members pointing down and against the axes, circular and rectangular strips, two headings -- lean kernel vs oracle."""
+    rng = np.random.default_rng(77 + nw)
+    axes_a = [(0, 0, 1), (1, 0, 0), (0, 1, 0), None, (0.3, -0.5, 0.4), (0, 0, -1), (-1, 0, 0), (0.6, 0.8, 0), (0, 0, 1)]
+    axes_b = [None, (0, -1, 0), (0, 0, 1), (0.2, 0.1, -0.9), None]
+    tables = [_oriented_run_table(rng, axes_a), _oriented_run_table(rng, axes_b)]
+    mats = random_matrices(rng, 2)
+    w, k, zeta, beta = synthetic_cases(rng, 2, 1, nw)
+    beta = np.array([[0.0], [0.4]])                       # sin(0) = 0 exactly: the y-aligned member gets no phase rotation
+    _both(hip_ctx, oracle_ctx, tables, mats, (w, k, zeta, beta))
+    oh = hip_ctx.solve_dynamics(6)                         # no optional outputs: the lean specialisation
+    oo = oracle_ctx.solve_dynamics(6)
+    assert np.array_equal(oh["niter"], oo["niter"])
+    assert np.array_equal(oh["flags"], oo["flags"])
+    for d in range(2):
+        assert group_rel_err(oh["Xi"][d], oo["Xi"][d]) < TOL
+    B, F = hip_ctx.linearize(oo["Xi"][:, :, 0])             # k_linearize shares the pass-A / pass-B loops
+    Bo, Fo = oracle_ctx.linearize(oo["Xi"][:, :, 0])
+    assert rel_err(B, Bo) < TOL and rel_err(F, Fo) < TOL
+
+
 def test_bad_run_hints_are_demoted_not_trusted(hip_ctx, oracle_ctx):
     """A wrong STEP/UNIT hint must not change results (verified at upload)."""
     from raft_amd import strips as st
