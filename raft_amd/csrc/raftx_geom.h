@@ -77,6 +77,11 @@ __host__ __device__ inline void derive_design_tables(const double *strips, int64
                     if (ok) m = mi;
                 }
             }
+            if (m != 0) {     // a run keeps ONE unit triad: collinear members with different cross-section axes start a new run
+                const double *pr = strips + (size_t)(i - 1) * NF;
+                for (int j = 0; j < 3; j++)
+                    if (pr[RAFTX_F_P1 + j] != rec[RAFTX_F_P1 + j] || pr[RAFTX_F_P2 + j] != rec[RAFTX_F_P2 + j]) m = 0;
+            }
             dsf[(size_t)i] = m | (rec[RAFTX_F_CIRC] != 0.0 ? DSI_CIRC : 0);
             for (int j = 0; j < DS_N; j++) o[j] = 0.0;
             o[DS_MCF] = rec[RAFTX_F_MCF];
@@ -88,6 +93,10 @@ __host__ __device__ inline void derive_design_tables(const double *strips, int64
                 o[DS_P1 + j] = rec[RAFTX_F_P1 + j];
                 o[DS_P2 + j] = rec[RAFTX_F_P2 + j];
             }
+            // Upright cross-section: p1 = (0, 0, +-1) and p2 horizontal up to the rounding dust of the member's rotation
+            // matrix (cos(pi/2) = 6e-17 and the like, raft_member.py:355-372).  Pass A may then leave the dust products
+            // out of its velocity SQUARES (1e-17 of a positive sum); the records themselves keep the reference's values.
+            if (fabs(o[DS_P1]) < 1e-15 && fabs(o[DS_P1 + 1]) < 1e-15 && fabs(o[DS_P2 + 2]) < 1e-15) dsf[(size_t)i] |= DSI_AXAL;
             o[DS_IQ] = rec[RAFTX_F_IQ];
             o[DS_IQ + 1] = rec[RAFTX_F_IP1];
             o[DS_IQ + 2] = rec[RAFTX_F_IP2];

@@ -120,6 +120,7 @@ __device__ __forceinline__ double fast_exp(double x) {
 #define DS_DQ 27     // dq, dp1, dp2, dend
 #define DSI_M 3
 #define DSI_CIRC 4
+#define DSI_AXAL 8       // upright cross-section: p1 = (0, 0, +-1), p2 horizontal, up to rounding dust (< 1e-15)
 
 struct DevTables {
     int nDesign;
@@ -632,6 +633,9 @@ struct StripSrc<6> {
     }
 };
 
+__device__ __forceinline__ void load_arm(cdptr rec, RecA &r) { r.ax = rec[DS_A]; r.ay = rec[DS_A + 1]; r.az = rec[DS_A + 2]; }
+__device__ __forceinline__ void load_arm(ldptr p, RecA &r) { r.ax = p[0]; r.ay = p[1]; r.az = p[2]; }
+__device__ __forceinline__ void load_arm(RecSplit p, RecA &r) { r.ax = p.lr[0]; r.ay = p.lr[1]; r.az = p.lr[2]; }
 __device__ __forceinline__ double src_qz(cdptr rec) { return rec[DS_Q + 2]; }
 __device__ __forceinline__ double src_qz(ldptr r) { return r[5]; }
 __device__ __forceinline__ double src_qz(RecSplit r) { return r.lr[5]; }
@@ -655,7 +659,7 @@ __device__ __forceinline__ void body_hoist(BodyHoist<NB> &H, const cplx (&X)[NB]
             H.yi[j] = fma(-X[j][5].re, ax, -X[j][1].re);
             H.zr[j] = fma(-X[j][4].im, ax, fma(X[j][3].im, ay, X[j][2].im));
             H.zi[j] = fma(X[j][4].re, ax, fma(-X[j][3].re, ay, -X[j][2].re));
-        } else if (RT == 2) {
+        } else if (RT == 2 || RT == 3) {
             H.xr[j] = fma(X[j][4].im, az, X[j][0].im);
             H.xi[j] = fma(-X[j][4].re, az, -X[j][0].re);
             H.yr[j] = fma(-X[j][3].im, az, X[j][1].im);
@@ -680,7 +684,7 @@ __device__ __forceinline__ void passA_core(const double (&ar)[NB], const double 
             ryi = fma(X[j][3].re, r.az, fma(sb, t1i, H.yi[j]));
             rzr = t2r + H.zr[j];
             rzi = t2i + H.zi[j];
-        } else if (RT == 2) {
+        } else if (RT == 2 || RT == 3) {
             rxr = fma(-X[j][5].im, r.ay, fma(cb, t1r, H.xr[j]));
             rxi = fma(X[j][5].re, r.ay, fma(cb, t1i, H.xi[j]));
             ryr = fma(X[j][5].im, r.ax, fma(sb, t1r, H.yr[j]));
@@ -700,8 +704,8 @@ __device__ __forceinline__ void passA_core(const double (&ar)[NB], const double 
         }
         // the axis of a run of two or more strips is its step direction: q = (0, 0, +-1) on a vertical run, q_z = 0 on a
         // horizontal one (the step vector is unit * q with unit > 0, so these are exact zeros and so are the dropped products)
-        const double vqr = RT == 1 ? r.qz * rzr : (RT == 2 ? fma(r.qy, ryr, r.qx * rxr) : fma(r.qz, rzr, fma(r.qy, ryr, r.qx * rxr)));
-        const double vqi = RT == 1 ? r.qz * rzi : (RT == 2 ? fma(r.qy, ryi, r.qx * rxi) : fma(r.qz, rzi, fma(r.qy, ryi, r.qx * rxi)));
+        const double vqr = RT == 1 ? r.qz * rzr : ((RT == 2 || RT == 3) ? fma(r.qy, ryr, r.qx * rxr) : fma(r.qz, rzr, fma(r.qy, ryr, r.qx * rxr)));
+        const double vqi = RT == 1 ? r.qz * rzi : ((RT == 2 || RT == 3) ? fma(r.qy, ryi, r.qx * rxi) : fma(r.qz, rzi, fma(r.qy, ryi, r.qx * rxi)));
         if (RT == 1 && circ) {      // q = (0, 0, +-1): v_q is the z component, v_perp the horizontal part
             v0 = fma(rzr, rzr, fma(rzi, rzi, v0));
             v1 = fma(rxr, rxr, fma(rxi, rxi, v1));
@@ -713,6 +717,13 @@ __device__ __forceinline__ void passA_core(const double (&ar)[NB], const double 
             n2 = fma(rzr, rzr, n2); n2 = fma(rzi, rzi, n2);
             v0 += q2;
             v1 += n2 - q2;
+        } else if (RT == 3) {       // horizontal member with an upright cross-section (pontoons): p1 = (0, 0, +-1), p2z = 0 up to
+                                    // 1e-15 -- the dust products are left out of the squares (DSI_AXAL)
+            const double v1r = r.p1z * rzr, v1i = r.p1z * rzi;
+            const double v2r = fma(r.p2y, ryr, r.p2x * rxr), v2i = fma(r.p2y, ryi, r.p2x * rxi);
+            v0 = fma(vqr, vqr, fma(vqi, vqi, v0));
+            v1 = fma(v1r, v1r, fma(v1i, v1i, v1));
+            v2 = fma(v2r, v2r, fma(v2i, v2i, v2));
         } else {
             const double v1r = fma(r.p1z, rzr, fma(r.p1y, ryr, r.p1x * rxr));
             const double v1i = fma(r.p1z, rzi, fma(r.p1y, ryi, r.p1x * rxi));
@@ -743,7 +754,7 @@ __device__ __forceinline__ void passA_strip(Kin<NB> &K, const RecA &r, int fl, R
 // Run-type-specialised step of the kinematic state (RT: 0 inclined, 1 vertical = no phase rotation, 2 horizontal = no
 // depth decay); m = 1 or 2 unit steps (wave-uniform)
 template <int NB, int RT>
-__device__ __forceinline__ void kin_step_rt(Kin<NB> &K, int m) {
+__device__ __forceinline__ void kin_step_rt(Kin<NB> &K, int m) {      // RT 3 = RT 2 with an upright cross-section
     if (RT != 1) {
 #pragma unroll
         for (int j = 0; j < NB; j++) {
@@ -753,7 +764,7 @@ __device__ __forceinline__ void kin_step_rt(Kin<NB> &K, int m) {
             K.ar[j] = t;
         }
     }
-    if (RT != 2) {
+    if (RT != 2 && RT != 3) {
 #pragma unroll
         for (int j = 0; j < NB; j++) {
             K.P[j] *= (m == 1) ? K.r1p[j] : K.r2p[j];
@@ -803,14 +814,12 @@ __device__ __forceinline__ void linearize_passA(cdptr ds, ciptr dsi, int S,
             pdh[j] = K.P[j] - K.Q[j];
         }
         BodyHoist<NB> H;
-        {
-            const RecA r0 = load_recA(src.rec(s));
-            body_hoist<NB, RT>(H, X, r0.ax, r0.ay, r0.az);
-        }
+        RecA r = load_recA(src.rec(s));             // a run has one unit triad (derive_design_tables); the arm is per strip
+        body_hoist<NB, RT>(H, X, r.ax, r.ay, r.az);
+        const int s_start = s;
         auto strip = [&](int si, int fls, double (&v)[3]) {
-            const auto rec = src.rec(si);
-            const RecA r = load_recA(rec);
-            if (RT == 2) {
+            if (si != s_start) load_arm(src.rec(si), r);
+            if (RT == 2 || RT == 3) {
                 passA_core<NB, RT>(K.ar, K.ai, psh, pdh, r, (fls & DSI_CIRC) != 0, cb, sb, X, H, v[0], v[1], v[2]);
             } else {
                 double ps[NB], pd[NB];
@@ -876,7 +885,10 @@ __device__ __forceinline__ void linearize_passA(cdptr ds, ciptr dsi, int S,
         kin_start<NB, false>(K, run_start_of(src.rec(s)), b, b.c1, cb, sb);
         // a run of one strip has a zero step vector and says nothing about the member's axis: general form
         if (K.vert && K.dec && fabs(src_qz(src.rec(s))) == 1.0) run(std::integral_constant<int, 1>{});   // vertical (implies no phase rotation)
-        else if (!K.vert && !K.dec) run(std::integral_constant<int, 2>{});   // horizontal
+        else if (!K.vert && !K.dec) {                                        // horizontal
+            if (fl & DSI_AXAL) run(std::integral_constant<int, 3>{});        // ... with an upright cross-section (a run has one triad)
+            else run(std::integral_constant<int, 2>{});
+        }
         else run(std::integral_constant<int, 0>{});
     }
     } else {
