@@ -77,10 +77,11 @@ __host__ __device__ inline void derive_design_tables(const double *strips, int64
                     if (ok) m = mi;
                 }
             }
-            if (m != 0) {     // a run keeps ONE unit triad: collinear members with different cross-section axes start a new run
+            if (m != 0) {     // a run keeps ONE unit triad and one kind of cross-section: collinear members that differ start a new run
                 const double *pr = strips + (size_t)(i - 1) * NF;
                 for (int j = 0; j < 3; j++)
                     if (pr[RAFTX_F_P1 + j] != rec[RAFTX_F_P1 + j] || pr[RAFTX_F_P2 + j] != rec[RAFTX_F_P2 + j]) m = 0;
+                if ((pr[RAFTX_F_CIRC] != 0.0) != (rec[RAFTX_F_CIRC] != 0.0)) m = 0;      // ... and one kind of cross-section
             }
             dsf[(size_t)i] = m | (rec[RAFTX_F_CIRC] != 0.0 ? DSI_CIRC : 0);
             for (int j = 0; j < DS_N; j++) o[j] = 0.0;

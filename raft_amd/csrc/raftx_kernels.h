@@ -649,9 +649,27 @@ struct BodyHoist {
     double xr[NB], xi[NB], yr[NB], yi[NB], zr[NB], zi[NB];
 };
 template <int NB, int RT>
-__device__ __forceinline__ void body_hoist(BodyHoist<NB> &H, const cplx (&X)[NB][6], double ax, double ay, double az) {
+__device__ __forceinline__ void body_hoist(BodyHoist<NB> &H, const cplx (&X)[NB][6], const RecA &r0) {
+    const double ax = r0.ax, ay = r0.ay, az = r0.az;
 #pragma unroll
     for (int j = 0; j < NB; j++) {
+        if (RT == 3) {
+            // Upright pontoon, in the member's own frame (q and p2 horizontal): with R(X) = -i X (the rotated form of pass A)
+            //   v_q  = al_q t1 + R(q.(X0,X1) + az (qx X4 - qy X3) + (qy ax - qx ay) X5)
+            //   v_p2 = al_2 t1 + R(p2.(X0,X1) + az (p2x X4 - p2y X3)) + (p2y ax - p2x ay) R(X5)
+            // and (qy ax - qx ay) = -(arm x q)_z does not change along the run (the arm moves along q), so all of v_q's body
+            // part is a run constant (xr, xi); v_p2 keeps one strip-dependent term, w2 R(X5); v_p1 = +-v_z.
+            const double wq = r0.qy * ax - r0.qx * ay;
+            const double cr = fma(wq, X[j][5].re, fma(az, r0.qx * X[j][4].re - r0.qy * X[j][3].re, fma(r0.qy, X[j][1].re, r0.qx * X[j][0].re)));
+            const double ci = fma(wq, X[j][5].im, fma(az, r0.qx * X[j][4].im - r0.qy * X[j][3].im, fma(r0.qy, X[j][1].im, r0.qx * X[j][0].im)));
+            H.xr[j] = ci;
+            H.xi[j] = -cr;
+            const double dr = fma(az, r0.p2x * X[j][4].re - r0.p2y * X[j][3].re, fma(r0.p2y, X[j][1].re, r0.p2x * X[j][0].re));
+            const double di = fma(az, r0.p2x * X[j][4].im - r0.p2y * X[j][3].im, fma(r0.p2y, X[j][1].im, r0.p2x * X[j][0].im));
+            H.yr[j] = di;
+            H.yi[j] = -dr;
+            continue;
+        }
         if (RT == 1) {
             H.xr[j] = fma(-X[j][5].im, ay, X[j][0].im);
             H.xi[j] = fma(X[j][5].re, ay, -X[j][0].re);
@@ -659,7 +677,7 @@ __device__ __forceinline__ void body_hoist(BodyHoist<NB> &H, const cplx (&X)[NB]
             H.yi[j] = fma(-X[j][5].re, ax, -X[j][1].re);
             H.zr[j] = fma(-X[j][4].im, ax, fma(X[j][3].im, ay, X[j][2].im));
             H.zi[j] = fma(X[j][4].re, ax, fma(-X[j][3].re, ay, -X[j][2].re));
-        } else if (RT == 2 || RT == 3) {
+        } else if (RT == 2) {
             H.xr[j] = fma(X[j][4].im, az, X[j][0].im);
             H.xi[j] = fma(-X[j][4].re, az, -X[j][0].re);
             H.yr[j] = fma(-X[j][3].im, az, X[j][1].im);
@@ -672,6 +690,23 @@ __device__ __forceinline__ void passA_core(const double (&ar)[NB], const double 
                                            const double (&pdv)[NB], const RecA &r, bool circ, double cb, double sb,
                                            const cplx (&X)[NB][6], const BodyHoist<NB> &H, double &v0, double &v1, double &v2) {
     v0 = 0.0; v1 = 0.0; v2 = 0.0;
+    if constexpr (RT == 3) {            // upright pontoon in its own frame (see body_hoist)
+        const double alq = r.qx * cb + r.qy * sb, al2 = r.p2x * cb + r.p2y * sb;     // wave-uniform
+        const double w2 = r.p2y * r.ax - r.p2x * r.ay;
+#pragma unroll
+        for (int j = 0; j < NB; j++) {
+            const double ps = psv[j], pd = pdv[j];
+            const double t1r = ar[j] * ps, t1i = ai[j] * ps, t2r = -ai[j] * pd, t2i = ar[j] * pd;
+            const double vqr = fma(alq, t1r, H.xr[j]), vqi = fma(alq, t1i, H.xi[j]);
+            const double v2r = fma(w2, X[j][5].im, fma(al2, t1r, H.yr[j])), v2i = fma(-w2, X[j][5].re, fma(al2, t1i, H.yi[j]));
+            const double rzr = fma(-X[j][4].im, r.ax, fma(X[j][3].im, r.ay, t2r + X[j][2].im));
+            const double rzi = fma(X[j][4].re, r.ax, fma(-X[j][3].re, r.ay, t2i - X[j][2].re));
+            v0 = fma(vqr, vqr, fma(vqi, vqi, v0));
+            v1 = fma(rzr, rzr, fma(rzi, rzi, v1));
+            v2 = fma(v2r, v2r, fma(v2i, v2i, v2));
+        }
+        return;
+    }
 #pragma unroll
     for (int j = 0; j < NB; j++) {
         const double ps = psv[j], pd = pdv[j];
@@ -815,7 +850,7 @@ __device__ __forceinline__ void linearize_passA(cdptr ds, ciptr dsi, int S,
         }
         BodyHoist<NB> H;
         RecA r = load_recA(src.rec(s));             // a run has one unit triad (derive_design_tables); the arm is per strip
-        body_hoist<NB, RT>(H, X, r.ax, r.ay, r.az);
+        body_hoist<NB, RT>(H, X, r);
         const int s_start = s;
         auto strip = [&](int si, int fls, double (&v)[3]) {
             if (si != s_start) load_arm(src.rec(si), r);
@@ -886,7 +921,7 @@ __device__ __forceinline__ void linearize_passA(cdptr ds, ciptr dsi, int S,
         // a run of one strip has a zero step vector and says nothing about the member's axis: general form
         if (K.vert && K.dec && fabs(src_qz(src.rec(s))) == 1.0) run(std::integral_constant<int, 1>{});   // vertical (implies no phase rotation)
         else if (!K.vert && !K.dec) {                                        // horizontal
-            if (fl & DSI_AXAL) run(std::integral_constant<int, 3>{});        // ... with an upright cross-section (a run has one triad)
+            if ((fl & (DSI_AXAL | DSI_CIRC)) == DSI_AXAL) run(std::integral_constant<int, 3>{});   // ... rectangular with an upright cross-section (a run has one triad and shape)
             else run(std::integral_constant<int, 2>{});
         }
         else run(std::integral_constant<int, 0>{});
