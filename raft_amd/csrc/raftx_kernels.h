@@ -1161,6 +1161,69 @@ __device__ __forceinline__ void drag_excitation(cdptr ds, ciptr dsi, int S, cons
                     F[j][q].re = fma(K.ar[j], G1[j][q], fma(-K.ai[j], G2[j][q], F[j][q].re));
                     F[j][q].im = fma(K.ai[j], G1[j][q], fma(K.ar[j], G2[j][q], F[j][q].im));
                 }
+        } else if (!K.dec && !K.vert && (fl & (DSI_AXAL | DSI_CIRC)) == DSI_AXAL) {
+            // Upright pontoon (see linearize_passA): q, p2 horizontal, p1 = +-z.  With W_c = [n_c ; arm x n_c] and the arm moving
+            // along q, W_q is the same for every strip of the run, W_p2 changes in its last component only
+            // (w2 = (arm x p2)_z) and V_s = b_1 [0, 0, 1, a_y, -a_x, 0]: the strips add to SIX complex scalars per bin
+            //   Sq = sum b_q al_q t1,  S2 = sum b_2 al_2 t1,  S26 = sum b_2 al_2 w2 t1,  S1 = sum b_1 t2,  S1y, S1x = sum b_1 a_y|a_x t2
+            // (12 FMAs per strip and bin instead of 24, from the drag coefficients b_c the strip phase left in vsq row 0 --
+            // the U, V rows are not read) and meet the constant vectors once per run.
+            RecA r = load_recA(src.rec(s));
+            const double alq = r.qx * cb + r.qy * sb, al2 = r.p2x * cb + r.p2y * sb;
+            const double wq = r.ax * r.qy - r.ay * r.qx, az = r.az;
+            double ps[NB], pd[NB], Sq[NB][2], S2[NB][2], S26[NB][2], S1[NB][2], S1y[NB][2], S1x[NB][2];
+#pragma unroll
+            for (int j = 0; j < NB; j++) {
+                ps[j] = K.P[j] + K.Q[j];
+                pd[j] = K.P[j] - K.Q[j];
+                Sq[j][0] = Sq[j][1] = S2[j][0] = S2[j][1] = S26[j][0] = S26[j][1] = 0.0;
+                S1[j][0] = S1[j][1] = S1y[j][0] = S1y[j][1] = S1x[j][0] = S1x[j][1] = 0.0;
+            }
+            const int s_start = s;
+#pragma unroll 1
+            while (true) {
+                if (s != s_start) load_arm(src.rec(s), r);
+                ldptr bc = l.vsq + s * 3;
+                const double bq = bc[0] * alq, b1 = bc[1], b2 = bc[2] * al2;
+                const double b2w = b2 * (r.p2y * r.ax - r.p2x * r.ay), b1y = b1 * r.ay, b1x = b1 * r.ax;
+#pragma unroll
+                for (int j = 0; j < NB; j++) {
+                    const double t1r = K.ar[j] * ps[j], t1i = K.ai[j] * ps[j], t2r = -K.ai[j] * pd[j], t2i = K.ar[j] * pd[j];
+                    Sq[j][0] = fma(bq, t1r, Sq[j][0]);    Sq[j][1] = fma(bq, t1i, Sq[j][1]);
+                    S2[j][0] = fma(b2, t1r, S2[j][0]);    S2[j][1] = fma(b2, t1i, S2[j][1]);
+                    S26[j][0] = fma(b2w, t1r, S26[j][0]); S26[j][1] = fma(b2w, t1i, S26[j][1]);
+                    S1[j][0] = fma(b1, t2r, S1[j][0]);    S1[j][1] = fma(b1, t2i, S1[j][1]);
+                    S1y[j][0] = fma(b1y, t2r, S1y[j][0]); S1y[j][1] = fma(b1y, t2i, S1y[j][1]);
+                    S1x[j][0] = fma(b1x, t2r, S1x[j][0]); S1x[j][1] = fma(b1x, t2i, S1x[j][1]);
+                }
+                if (++s >= S) break;
+                fl = src.flags(min(s + 1, S - 1));
+                const int m = fl & DSI_M;
+                if (m == 0) break;
+#pragma unroll
+                for (int j = 0; j < NB; j++) {
+                    const double rr = (m == 1) ? K.r1r[j] : K.r2r[j], ri = (m == 1) ? K.r1i[j] : K.r2i[j];
+                    const double t = K.ar[j] * rr - K.ai[j] * ri;
+                    K.ai[j] = K.ar[j] * ri + K.ai[j] * rr;
+                    K.ar[j] = t;
+                }
+            }
+            const double c3q = -az * r.qy, c3p = -az * r.p2y, c4q = az * r.qx, c4p = az * r.p2x;
+#pragma unroll
+            for (int j = 0; j < NB; j++) {
+                F[j][0].re = fma(r.qx, Sq[j][0], fma(r.p2x, S2[j][0], F[j][0].re));
+                F[j][0].im = fma(r.qx, Sq[j][1], fma(r.p2x, S2[j][1], F[j][0].im));
+                F[j][1].re = fma(r.qy, Sq[j][0], fma(r.p2y, S2[j][0], F[j][1].re));
+                F[j][1].im = fma(r.qy, Sq[j][1], fma(r.p2y, S2[j][1], F[j][1].im));
+                F[j][2].re += S1[j][0];
+                F[j][2].im += S1[j][1];
+                F[j][3].re = fma(c3q, Sq[j][0], fma(c3p, S2[j][0], F[j][3].re + S1y[j][0]));
+                F[j][3].im = fma(c3q, Sq[j][1], fma(c3p, S2[j][1], F[j][3].im + S1y[j][1]));
+                F[j][4].re = fma(c4q, Sq[j][0], fma(c4p, S2[j][0], F[j][4].re - S1x[j][0]));
+                F[j][4].im = fma(c4q, Sq[j][1], fma(c4p, S2[j][1], F[j][4].im - S1x[j][1]));
+                F[j][5].re = fma(wq, Sq[j][0], F[j][5].re + S26[j][0]);
+                F[j][5].im = fma(wq, Sq[j][1], F[j][5].im + S26[j][1]);
+            }
         } else if (!K.dec) {
             double ps[NB], pd[NB];
 #pragma unroll
