@@ -518,6 +518,46 @@ def test_run_type_loops_of_the_lean_kernel(hip_ctx, oracle_ctx, nw):
     assert rel_err(B, Bo) < TOL and rel_err(F, Fo) < TOL
 
 
+def test_collinear_members_with_different_sections_do_not_share_a_run(hip_ctx, oracle_ctx):
+    """The sweeps load the unit triad once per run and pick the run's inner loop from its first strip, so the library
+    must start a new run where collinear, equally spaced members differ in their cross-section axes or shape
+    (derive_design_tables): three members end to end on one horizontal line and on one vertical line -- rectangular,
+    the same twisted by 35 degrees, circular."""
+    from raft_amd import strips as st
+    rng = np.random.default_rng(5)
+    n_per = 5
+    tabs = []
+    for q in (np.array([0.6, 0.8, 0.0]), np.array([0.0, 0.0, 1.0])):
+        base = random_strips(rng, 3 * n_per)
+        rec = base.strips
+        h = np.array([0.0, 0.0, 1.0]) if abs(q[2]) < 0.9 else np.array([1.0, 0.0, 0.0])
+        p1 = np.cross(h, q) / np.linalg.norm(np.cross(h, q))
+        p2 = np.cross(q, p1)
+        A = np.array([3.0, -7.0, -26.0])
+        for i in range(3 * n_per):
+            mbr = i // n_per
+            r = A + 0.5 * (i + 1) * q                  # one spacing all along the line
+            ang = 0.0 if mbr != 1 else np.deg2rad(35.0)
+            rec[i, st.F_AX:st.F_AX + 3] += r - rec[i, st.F_X:st.F_X + 3]
+            rec[i, st.F_X:st.F_X + 3] = r
+            rec[i, st.F_Q:st.F_Q + 3] = q
+            rec[i, st.F_P1:st.F_P1 + 3] = np.cos(ang) * p1 + np.sin(ang) * p2
+            rec[i, st.F_P2:st.F_P2 + 3] = -np.sin(ang) * p1 + np.cos(ang) * p2
+            rec[i, st.F_CIRC] = float(mbr == 2)
+        tabs.append(base)
+    mats = random_matrices(rng, 2)
+    cases = synthetic_cases(rng, 1, 1, 200)
+    _both(hip_ctx, oracle_ctx, tabs, mats, cases)
+    oh = hip_ctx.solve_dynamics(6)
+    oo = oracle_ctx.solve_dynamics(6)
+    assert np.array_equal(oh["niter"], oo["niter"])
+    for d in range(2):
+        assert group_rel_err(oh["Xi"][d], oo["Xi"][d]) < TOL
+    B, F = hip_ctx.linearize(oo["Xi"][:, :, 0])
+    Bo, Fo = oracle_ctx.linearize(oo["Xi"][:, :, 0])
+    assert rel_err(B, Bo) < TOL and rel_err(F, Fo) < TOL
+
+
 def test_bad_run_hints_are_demoted_not_trusted(hip_ctx, oracle_ctx):
     """A wrong STEP/UNIT hint must not change results (verified at upload)."""
     from raft_amd import strips as st
