@@ -1401,6 +1401,7 @@ __device__ __forceinline__ void solve6(Lu6 &A, cplx x[6]) {
 #pragma unroll
             for (int r = k + 1; r < 6; r++) {
                 const bool sw = (p == r);
+                if (!__any(sw)) continue;           // neighbouring bins mostly agree on the pivot row: one or two candidates per wave
 #pragma unroll
                 for (int c = k; c < 6; c++) {
                     double tr = A.ar[k][c], ti = A.ai[k][c];
