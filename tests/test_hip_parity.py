@@ -494,20 +494,20 @@ def _oriented_run_table(rng, axes, n_per=9):
     return base
 
 
-@pytest.mark.parametrize("nw", [200, 64, 300])
-def test_run_type_loops_of_the_lean_kernel(hip_ctx, oracle_ctx, nw):
+@pytest.mark.parametrize("nw,nH", [(200, 1), (200, 2), (64, 1), (300, 1)])
+def test_run_type_loops_of_the_lean_kernel(hip_ctx, oracle_ctx, nw, nH):
     """The sweeps iterate over runs with inner loops specialised by run type (vertical / horizontal / inclined):
     every type, runs of one strip, a horizontal member square to the waves (no phase rotation without being vertical),
-    members pointing down and against the axes, circular and rectangular strips, two headings -- lean kernel vs oracle."""
+    members pointing down and against the axes, circular and rectangular strips, two sea states -- lean kernel (one heading) and the multi-heading one vs the oracle."""
     rng = np.random.default_rng(77 + nw)
     axes_a = [(0, 0, 1), (1, 0, 0), (0, 1, 0), None, (0.3, -0.5, 0.4), (0, 0, -1), (-1, 0, 0), (0.6, 0.8, 0), (0, 0, 1)]
     axes_b = [None, (0, -1, 0), (0, 0, 1), (0.2, 0.1, -0.9), None]
     tables = [_oriented_run_table(rng, axes_a), _oriented_run_table(rng, axes_b)]
     mats = random_matrices(rng, 2)
-    w, k, zeta, beta = synthetic_cases(rng, 2, 1, nw)
-    beta = np.array([[0.0], [0.4]])                       # sin(0) = 0 exactly: the y-aligned member gets no phase rotation
+    w, k, zeta, beta = synthetic_cases(rng, 2, nH, nw)
+    beta = np.array([[0.0, 1.1], [0.4, -2.0]])[:, :nH]    # sin(0) = 0 exactly: the y-aligned member gets no phase rotation
     _both(hip_ctx, oracle_ctx, tables, mats, (w, k, zeta, beta))
-    oh = hip_ctx.solve_dynamics(6)                         # no optional outputs: the lean specialisation
+    oh = hip_ctx.solve_dynamics(6)                         # no optional outputs: with one heading the lean specialisation
     oo = oracle_ctx.solve_dynamics(6)
     assert np.array_equal(oh["niter"], oo["niter"])
     assert np.array_equal(oh["flags"], oo["flags"])
