@@ -82,6 +82,12 @@ __host__ __device__ inline void derive_design_tables(const double *strips, int64
                 for (int j = 0; j < 3; j++)
                     if (pr[RAFTX_F_P1 + j] != rec[RAFTX_F_P1 + j] || pr[RAFTX_F_P2 + j] != rec[RAFTX_F_P2 + j]) m = 0;
                 if ((pr[RAFTX_F_CIRC] != 0.0) != (rec[RAFTX_F_CIRC] != 0.0)) m = 0;      // ... and one kind of cross-section
+                // ... and the arm moves with the strip (the run-type loops keep arm components that cannot change along the
+                // run's axis out of the strip loop): a table whose arms do not follow the positions gets no runs
+                for (int j = 0; j < 3; j++) {
+                    const double da = rec[RAFTX_F_AX + j] - pr[RAFTX_F_AX + j], dx = rec[RAFTX_F_X + j] - pr[RAFTX_F_X + j];
+                    if (!(fabs(da - dx) <= 1e-9 * (1.0 + fabs(rec[RAFTX_F_X + j]) + fabs(rec[RAFTX_F_AX + j])))) m = 0;
+                }
             }
             dsf[(size_t)i] = m | (rec[RAFTX_F_CIRC] != 0.0 ? DSI_CIRC : 0);
             for (int j = 0; j < DS_N; j++) o[j] = 0.0;

@@ -558,6 +558,22 @@ def test_collinear_members_with_different_sections_do_not_share_a_run(hip_ctx, o
     assert rel_err(B, Bo) < TOL and rel_err(F, Fo) < TOL
 
 
+def test_arms_that_do_not_follow_the_positions_get_no_runs(hip_ctx, oracle_ctx):
+    """The run-type loops keep arm components that cannot change along a run's axis out of the strip loop; a table whose
+    arms are not position minus one reference point (the C-ABI does not forbid it) must therefore not form runs."""
+    from raft_amd import strips as st
+    rng = np.random.default_rng(9)
+    axes = [(0, 0, 1), (1, 0, 0), (0.6, 0.8, 0)]
+    tab = _oriented_run_table(rng, axes, n_per=7)
+    tab.strips[:, st.F_AX:st.F_AX + 3] += rng.normal(scale=0.3, size=(tab.strips.shape[0], 3))     # per-strip offsets
+    mats = random_matrices(rng, 1)
+    w, k, zeta, beta = synthetic_cases(rng, 1, 1, 200)
+    _both(hip_ctx, oracle_ctx, [tab], mats, (w, k, zeta, np.array([[0.0]])))
+    oh, oo = hip_ctx.solve_dynamics(6), oracle_ctx.solve_dynamics(6)
+    assert np.array_equal(oh["niter"], oo["niter"])
+    assert group_rel_err(oh["Xi"][0], oo["Xi"][0]) < TOL
+
+
 def test_bad_run_hints_are_demoted_not_trusted(hip_ctx, oracle_ctx):
     """A wrong STEP/UNIT hint must not change results (verified at upload)."""
     from raft_amd import strips as st
