@@ -23,8 +23,8 @@ sys.path.insert(0, ROOT)
 
 from raft_amd import backend, geometry as G, waves                      # noqa: E402
 from raft_amd.sweep import GeometrySweep                                 # noqa: E402
-from tests import standin                                                # noqa: E402
-from tests.util import volturnus_sweep                                   # noqa: E402
+from raft_amd import snapshot as standin                                                # noqa: E402
+from raft_amd.geometry import volturnus_sweep                                   # noqa: E402
 
 
 def main():

@@ -358,6 +358,31 @@ int raftx_fetch_strips(raftx_ctx *ctx, double *strips, raftx_c128 *cm);
 int raftx_fetch_statics(raftx_ctx *ctx, double *A_morison, double *C_hydro, double *W_hydro,
                         double *M_struc, double *C_struc, double *W_struc, double *props);
 
+/* One whole SWEEP CROSSING in one call ("H2D of the tables + kernels + D2H"): member descriptions of
+ * nDesign candidates in, response statistics (and optionally the responses) out -- raftx_build_designs +
+ * raftx_upload_cases + raftx_solve_dynamics_device + raftx_motion_stats + raftx_fetch_results, with the designs cut
+ * into nChunk contiguous blocks that nWorker internal streams (each with its own device buffers and memory pool, kept
+ * for the life of ctx) take round-robin, so that the descriptor H2D and the table generation of one block overlap the
+ * fixed-point kernel of another and the statistics D2H of a third.  What the reference does per candidate in
+ * raft/parametersweep.py:39-100 / raft/omdao_raft.py:746-792 (build a Model, analyzeCases, read the statistics).
+ * Descriptor arguments as raftx_build_designs (MBw not supported here; k doubles as the wave numbers of the
+ * MacCamy-Fuchs table); sea-state arguments as raftx_upload_cases (rho_wave, g_wave scale the dynamic pressure:
+ * the reference hard-wires 1025 / 9.81 there, raft_fowt.py:1857); nIter, tol, XiStart as raftx_solve_dynamics.
+ * nChunk <= 0 / nWorker <= 0: library defaults.  Page-locked descriptor arrays (raftx_host_alloc) copy at full PCIe rate.
+ * Outputs: std [nDesign,nCase,6] (raftx_motion_stats; required), niter / flags [nDesign,nCase] (required),
+ * Xi [nDesign,nCase,nHead,6,nw] or NULL, stripOffsets [nDesign+1] or NULL, timing_ms [4] or NULL
+ * (wall, sum of generation kernels, sum of solve kernels, sum of statistics kernels).
+ * Results are bit-identical to the unchunked sequence of calls: designs do not interact. */
+int raftx_sweep_stats(raftx_ctx *ctx, int nDesign, const int64_t *memberOff, const double *members,
+                      const int64_t *stationOff, const double *stations, const int64_t *capOff, const double *caps,
+                      const double *pose, double rho, double g, int add_mask,
+                      const double *M0, const double *B0, const double *C0, const double *Fz_moor,
+                      int nCase, int nHead, int nw, const double *w, const double *k, double depth,
+                      double rho_wave, double g_wave, const double *zeta, const double *beta,
+                      int nIter, double tol, double XiStart, int nChunk, int nWorker,
+                      double *std, int32_t *niter, int32_t *flags, raftx_c128 *Xi, int64_t *stripOffsets,
+                      double *timing_ms);
+
 /* Page-locked host buffers for the bulk outputs (the 19 KB per design-case of raftx_fetch_results): copies into
  * them run at full PCIe rate and asynchronously to other streams, which pageable NumPy memory does not.  The caller
  * wraps the pointer in an array (raft_amd/_abi.py Context.pinned_empty) and must return it with raftx_host_free before

@@ -26,8 +26,9 @@ REF = rh.REFERENCE_ROOT
 GOLD = standin.GOLDEN_DIR
 
 
-def run_case(model, case):
-    """Reference solveDynamics + the by-products the parity tests compare."""
+def run_case(model, case, lean=False):
+    """Reference solveDynamics + the by-products the parity tests compare (lean: responses, iteration counts and
+    the drag matrix only -- keeps the many-case fixtures small)."""
     counts = []
     for f in model.fowtList:
         cnt = {"n": 0}
@@ -46,6 +47,11 @@ def run_case(model, case):
            "Xi": Xi, "ref_seconds": dt, "units": []}
     for f, cnt, orig in counts:
         del f.calcHydroLinearization          # restore class method
+        if lean:
+            out["units"].append({"niter": cnt["n"], "B_hydro_drag": np.array(f.B_hydro_drag),
+                                 "zeta": np.array(f.zeta), "beta": np.array(f.beta)})
+            out["Xi"] = Xi[:-1]                   # row nWaves is zero by construction (raft_model.py:1236)
+            continue
         out["units"].append({
             "niter": cnt["n"],
             "Z": np.array(f.Z), "F_hydro_iner": np.array(f.F_hydro_iner),
@@ -157,22 +163,23 @@ def farm_coupling(nUnit, k=5e4):
     return C
 
 
-def fixture_c4():
+def fixture_c4(n_cases=50):
     d = rh.load_design(os.path.join(REF, "designs/VolturnUS-S_farm.yaml"))
-    d = rh.prepare_design(d, settings=dict(min_freq=0.002, max_freq=0.2))       # nw=100 keeps the fixture small
+    d = rh.prepare_design(d, settings=dict(min_freq=0.001, max_freq=0.2))       # nw=200: BASELINE configs[3]
     d["array"]["data"] = [[1, 1, 0, 0, 0, 180], [1, 1, 0, 1600, 0, 0],
                           [1, 1, 0, 0, 1600, 90], [1, 1, 0, 1600, 1600, 270]]
     m = rh.build_model(d)
+    assert m.nw == 200
     Cc = farm_coupling(4)
     m.ms = _FixedArrayMooring(Cc)
     m.moorMod = 0
     rng = np.random.default_rng(1)
     cases = []
-    for _ in range(2):
+    for _ in range(n_cases):                     # the 50 sea states of default_rng(1)
         cases.append(rh.make_case(Hs=float(rng.uniform(1, 10)), Tp=float(rng.uniform(6, 16)),
                                   heading=float(rng.uniform(0, 360))))
-    fx = {"config": "C4 4-unit VolturnUS-S farm nw=100", "model": standin.snapshot_model(m),
-          "coupling_C": Cc, "cases": [run_case(m, c) for c in cases]}
+    fx = {"config": "C4 4-unit VolturnUS-S farm nw=200, %d seeded sea states" % n_cases, "model": standin.snapshot_model(m),
+          "coupling_C": Cc, "cases": [run_case(m, c, lean=(i >= 2)) for i, c in enumerate(cases)]}
     standin.save_fixture(os.path.join(GOLD, "c4_farm.npz"), fx)
 
 
@@ -198,10 +205,11 @@ def volturnus_variant(design, scales):
     return d
 
 
-def fixture_c3(n_variants=64, n_solved=8):
+def fixture_c3(n_variants=64, n_solved=64, n_full=8):
     """C3 sample: packed strip tables + system matrices of n_variants sweep
     points (default_rng(0), U[0.75,1.25]), reference solveDynamics for the first
-    n_solved.  bench.py tiles these to the 10k-design sweep on the GPU box."""
+    n_solved (all by-products for the first n_full, responses + iteration counts for the rest).  The first 64 designs
+    of bench.py's 10k-design sweep are these."""
     from raft_amd.strips import pack_fowt
     base = rh.load_design(os.path.join(REF, "examples/VolturnUS-S_example.yaml"))
     base = rh.prepare_design(base)
@@ -214,7 +222,7 @@ def fixture_c3(n_variants=64, n_solved=8):
         m = rh.build_model(volturnus_variant(base, scales[i]))
         f = m.fowtList[0]
         if i < n_solved:
-            sols.append(run_case(m, case))
+            sols.append(run_case(m, case, lean=(i >= n_full)))
         else:
             f.calcHydroExcitation(copy.deepcopy(case), memberList=f.memberList)   # sets zeta/beta only
         t = pack_fowt(f)
@@ -324,6 +332,37 @@ def fixture_c5_oc4():
     fx = {"config": "C5 OC4semi-RAFT_QTF internal QTF solveDynamics (nw=50, 40-point 2nd-order grid)",
           "model": standin.snapshot_model(m), "cases": runs}
     standin.save_fixture(os.path.join(GOLD, "c5_oc4semi_qtf.npz"), fx)
+
+
+def fixture_c5_full():
+    """BASELINE configs[4] at its real shape: examples/OC4semi-RAFT_QTF.yaml, second-order grid
+    min_freq2nd = df_freq2nd = 0.0025 Hz, max_freq2nd = 0.5 Hz -> 200 x 200 (20 100 upper-triangle pairs), first-order
+    grid min_freq 0.00125 Hz -> nw = 200; sea state (6 m, 12 s), headings 0 and 30 deg; internal QTF (potSecOrder = 1)
+    from the converged motions, second-order force, restarted drag iteration (raft_model.py:1108-1131).  About
+    7 minutes of reference time per case.  The QTFs are stored as their upper triangles (raft_fowt.py:2069-2070
+    mirrors them)."""
+    d = rh.load_design(os.path.join(REF, "examples", "OC4semi-RAFT_QTF.yaml"))
+    d = rh.prepare_design(d, settings=dict(min_freq=0.00125, max_freq=0.25, nIter=10))
+    d["platform"].pop("outFolderQTF", None)
+    d["platform"].update(min_freq2nd=0.0025, df_freq2nd=0.0025, max_freq2nd=0.5)
+    m = rh.build_model(d)
+    f = m.fowtList[0]
+    f.outFolderQTF = None
+    assert f.potSecOrder == 1 and m.nw == 200 and len(f.w1_2nd) == 200, (m.nw, len(f.w1_2nd))
+    iu = np.triu_indices(200)
+    runs = []
+    for c in (rh.make_case(Hs=6.0, Tp=12.0, heading=0.0), rh.make_case(Hs=6.0, Tp=12.0, heading=30.0)):
+        r = run_case(m, c, lean=True)
+        r["units"][0]["Fhydro_2nd"] = np.array(f.Fhydro_2nd)
+        r["units"][0]["Fhydro_2nd_mean"] = np.array(f.Fhydro_2nd_mean)
+        q = np.array(f.qtf[:, :, 0, :])
+        assert np.allclose(q, np.conj(np.transpose(q, (1, 0, 2))))
+        r["units"][0]["qtf_triu"] = q[iu]
+        runs.append(r)
+        print("c5full case done in %.0f s" % r["ref_seconds"], flush=True)
+    fx = {"config": "C5 OC4semi-RAFT_QTF internal QTF solveDynamics at the configs[4] shape (nw=200, 200x200 grid)",
+          "model": standin.snapshot_model(m), "cases": runs}
+    standin.save_fixture(os.path.join(GOLD, "c5_oc4semi_full.npz"), fx)
 
 
 def synth_bem_files(stem):
@@ -587,7 +626,7 @@ def fixture_geom():
     standin.save_fixture(os.path.join(GOLD, "geom_units.npz"), fx)
 
 
-ALL = {"refstatics": fixture_ref_statics, "refmembers": fixture_ref_members, "bem": fixture_bem, "geom": fixture_geom, "c5oc4": fixture_c5_oc4, "c5": fixture_c5, "qtf": fixture_qtf, "c1": fixture_c1, "c2": fixture_c2, "pose": fixture_pose,
+ALL = {"c5full": fixture_c5_full, "refstatics": fixture_ref_statics, "refmembers": fixture_ref_members, "bem": fixture_bem, "geom": fixture_geom, "c5oc4": fixture_c5_oc4, "c5": fixture_c5, "qtf": fixture_qtf, "c1": fixture_c1, "c2": fixture_c2, "pose": fixture_pose,
        "refgold": fixture_ref_goldens, "c4": fixture_c4, "c3": fixture_c3}
 
 if __name__ == "__main__":

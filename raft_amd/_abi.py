@@ -26,6 +26,7 @@ EXPORTS = (
     "raftx_solve_system", "raftx_last_kernel_ms",
     "raftx_solve_dynamics_device", "raftx_fetch_results", "raftx_debug_math", "raftx_motion_stats", "raftx_solve_system_resident", "raftx_qtf_slender", "raftx_channel_stats", "raftx_qtf_force", "raftx_set_linearisation_point", "raftx_fetch_linearisation_point",
     "raftx_build_designs", "raftx_fetch_strips", "raftx_fetch_statics", "raftx_channel_stats_poly", "raftx_qtf_slender_rows", "raftx_bem_excitation", "raftx_qtf_kay", "raftx_host_alloc", "raftx_host_free",
+    "raftx_sweep_stats",
 )
 WANT_BDRAG, WANT_FWAVE, WANT_Z = 1, 2, 4
 
@@ -129,6 +130,11 @@ class RaftxLib:
         L.raftx_fetch_statics.restype = C.c_int
         L.raftx_last_kernel_ms.argtypes = [_vp]
         L.raftx_last_kernel_ms.restype = C.c_double
+        L.raftx_sweep_stats.argtypes = [_vp, C.c_int, _vp, _vp, _vp, _vp, _vp, _vp, _vp, C.c_double, C.c_double, C.c_int,
+                                        _vp, _vp, _vp, _vp, C.c_int, C.c_int, C.c_int, _vp, _vp, C.c_double, C.c_double,
+                                        C.c_double, _vp, _vp, C.c_int, C.c_double, C.c_double, C.c_int, C.c_int,
+                                        _vp, _vp, _vp, _vp, _vp, _vp]
+        L.raftx_sweep_stats.restype = C.c_int
 
     @property
     def version(self):
@@ -256,6 +262,57 @@ class Context:
         self._nw_designs = int(nw)
         self._strip_off = off
         return off
+
+    def sweep_stats(self, tables, M0, B0, C0, w, k, depth, zeta, beta, nIter, tol=0.01, XiStart=0.1, pose=None,
+                    rho=1025.0, g=9.81, rho_wave=1025.0, g_wave=9.81, add_mask=7, Fz_moor=None, n_chunk=0, n_worker=0,
+                    want_Xi=False, Xi_out=None):
+        """One whole sweep crossing in ONE library call (raftx_sweep_stats): member descriptions (``tables``: a
+        raft_amd.geometry.DesignTables) in, motion statistics + iteration counts (+ responses) out; inside the library the
+        designs are cut into blocks whose descriptor upload, table generation, fixed-point kernel and downloads overlap
+        on internal streams.  Returns dict(std [nD,nC,6], niter, flags [nD,nC], Xi or None, strip_off [nD+1],
+        timing_ms [wall, generation kernels, solve kernels, statistics kernels]).  Unlike build_designs + solve, nothing
+        stays resident on this context afterwards."""
+        member_off = np.ascontiguousarray(tables.member_off, dtype=np.int64)
+        station_off = np.ascontiguousarray(tables.station_off, dtype=np.int64)
+        nD = len(member_off) - 1
+        members = _f64(tables.members, (member_off[-1], 16), "members")
+        stations = _f64(tables.stations, (station_off[-1], 16), "stations")
+        cap_off = caps = None
+        if getattr(tables, "cap_off", None) is not None:
+            cap_off = np.ascontiguousarray(tables.cap_off, dtype=np.int64)
+            caps = _f64(tables.caps, (cap_off[-1], 4), "caps")
+            if caps.size == 0:
+                caps = np.zeros((1, 4))
+        M0, B0, C0 = _f64(M0, (nD, 6, 6), "M0"), _f64(B0, (nD, 6, 6), "B0"), _f64(C0, (nD, 6, 6), "C0")
+        pose = None if pose is None else _f64(pose, (nD, 6), "pose")
+        Fz = None if Fz_moor is None else _f64(Fz_moor, (nD,), "Fz_moor")
+        w = _f64(w)
+        nw = len(w)
+        k = _f64(k, (nw,), "k")
+        zeta = _f64(zeta)
+        if zeta.ndim == 2:
+            zeta, beta = zeta[None], np.asarray(beta, dtype=np.float64)[None]
+        nC, nH = zeta.shape[0], zeta.shape[1]
+        zeta = _f64(zeta, (nC, nH, nw), "zeta")
+        beta = _f64(beta, (nC, nH), "beta")
+        std = np.empty((nD, nC, 6))
+        niter = np.zeros((nD, nC), dtype=np.int32)
+        flags = np.zeros((nD, nC), dtype=np.int32)
+        Xi = Xi_out
+        if Xi is None and want_Xi:
+            Xi = np.empty((nD, nC, nH, 6, nw), dtype=np.complex128)
+        if Xi is not None and (Xi.dtype != np.complex128 or Xi.shape != (nD, nC, nH, 6, nw) or not Xi.flags["C_CONTIGUOUS"]):
+            raise ValueError("Xi_out must be a C-contiguous complex128 array of shape %s" % ((nD, nC, nH, 6, nw),))
+        off = np.zeros(nD + 1, dtype=np.int64)
+        timing = np.zeros(4)
+        rc = self.rlib.lib.raftx_sweep_stats(self._h, nD, _ptr(member_off), _ptr(members), _ptr(station_off), _ptr(stations),
+                                             _ptr(cap_off), _ptr(caps), _ptr(pose), float(rho), float(g), int(add_mask),
+                                             _ptr(M0), _ptr(B0), _ptr(C0), _ptr(Fz), nC, nH, nw, _ptr(w), _ptr(k), float(depth),
+                                             float(rho_wave), float(g_wave), _ptr(zeta), _ptr(beta), int(nIter), float(tol),
+                                             float(XiStart), int(n_chunk), int(n_worker), _ptr(std), _ptr(niter), _ptr(flags),
+                                             _ptr(Xi), _ptr(off), _ptr(timing))
+        self._check(rc, "raftx_sweep_stats")
+        return dict(std=std, niter=niter, flags=flags, Xi=Xi, strip_off=off, timing_ms=timing)
 
     def fetch_strips(self, n_strips, n_cm_rows=0):
         """(strips [n,32], cm [rows,2,nw] or None) generated by the last build_designs."""

@@ -28,7 +28,9 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <chrono>
 #include <map>
+#include <thread>
 #include <unordered_map>
 #include <vector>
 
@@ -410,6 +412,7 @@ struct raftx_ctx {
     size_t g_nStrips, g_nRows;
     double *g_abi, *g_A, *g_Ch, *g_Wh, *g_props, *g_Ms, *g_Cs, *g_Ws;
     cplx *g_cm;
+    std::vector<raftx_ctx *> workers;    // sub-contexts of raftx_sweep_stats (own stream, buffers, pool), kept for reuse
 };
 
 #define MAX_NW 2048
@@ -484,6 +487,8 @@ static void free_list(raftx_ctx *c, std::vector<void *> &v) {
 
 extern "C" void raftx_ctx_destroy(raftx_ctx *c) {
     if (!c) return;
+    for (raftx_ctx *w : c->workers) raftx_ctx_destroy(w);
+    c->workers.clear();
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
     free_list(c, c->design_allocs);
@@ -1574,6 +1579,145 @@ extern "C" int raftx_qtf_force(raftx_ctx *c, int nSet, int nw2, const double *w2
         D2H(c, f, df, (size_t)nSet * 6 * nw * sizeof(double));
     }
     HIPCHK(c, hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+// ------------------------------------------------------------------ one-call sweep crossing
+// raftx_sweep_stats: the designs are cut into blocks; worker threads -- one per internal sub-context (= HIP stream +
+// device buffers + memory pool, created on first use and kept by the parent ctx) -- take the blocks round-robin and run
+// the ordinary entry points on them.  Every entry point blocks only its own thread on its own stream, so the
+// descriptor H2D / table generation of one block overlaps the fixed-point kernel of another and the D2H of a third.
+struct SweepJob {
+    int nDesign;
+    const int64_t *memberOff, *stationOff, *capOff;
+    const double *members, *stations, *caps, *pose, *M0, *B0, *C0, *Fz;
+    double rho, g;
+    int add_mask, nCase, nHead, nw;
+    const double *w, *k, *zeta, *beta;
+    double depth, rho_wave, g_wave;
+    int nIter;
+    double tol, XiStart;
+    int nChunk;
+    double *sd;
+    int32_t *niter, *flags;
+    raftx_c128 *Xi;
+    int64_t *stripCount;               // [nDesign] strips per design (scanned by the caller afterwards)
+};
+static void chunk_bounds(int n, int i, int parts, int &lo, int &hi) {
+    const int base = n / parts, rem = n % parts;
+    lo = i * base + (i < rem ? i : rem);
+    hi = lo + base + (i < rem ? 1 : 0);
+}
+static int sweep_worker(raftx_ctx *sub, const SweepJob &J, int wid, int nWorker, double *tsum) {
+    bool cases_up = false;
+    std::vector<int64_t> mo, so, co, offs;
+    const double dw = J.nw > 1 ? J.w[1] - J.w[0] : J.w[0];
+    for (int ch = wid; ch < J.nChunk; ch += nWorker) {
+        int lo, hi;
+        chunk_bounds(J.nDesign, ch, J.nChunk, lo, hi);
+        const int n = hi - lo;
+        if (n <= 0) continue;
+        const int64_t m0 = J.memberOff[lo], m1 = J.memberOff[hi];
+        mo.resize((size_t)n + 1);
+        for (int i = 0; i <= n; i++) mo[(size_t)i] = J.memberOff[lo + i] - m0;
+        so.resize((size_t)(m1 - m0) + 1);
+        const int64_t s0 = J.stationOff[m0];
+        for (int64_t j = 0; j <= m1 - m0; j++) so[(size_t)j] = J.stationOff[m0 + j] - s0;
+        int64_t c0 = 0;
+        if (J.capOff) {
+            co.resize((size_t)(m1 - m0) + 1);
+            c0 = J.capOff[m0];
+            for (int64_t j = 0; j <= m1 - m0; j++) co[(size_t)j] = J.capOff[m0 + j] - c0;
+        }
+        offs.resize((size_t)n + 1);
+        int rc = raftx_build_designs(sub, n, mo.data(), J.members + (size_t)m0 * RAFTX_GM_N, so.data(),
+                                     J.stations + (size_t)s0 * RAFTX_GS_N, J.capOff ? co.data() : nullptr,
+                                     J.capOff ? J.caps + (size_t)c0 * RAFTX_GC_N : nullptr,
+                                     J.pose ? J.pose + (size_t)lo * 6 : nullptr, J.rho, J.g, J.nw, J.k, J.add_mask,
+                                     J.M0 + (size_t)lo * 36, J.B0 + (size_t)lo * 36, J.C0 + (size_t)lo * 36, nullptr,
+                                     J.Fz ? J.Fz + lo : nullptr, offs.data());
+        if (rc) return rc;
+        tsum[0] += sub->last_ms;
+        if (J.stripCount)
+            for (int i = 0; i < n; i++) J.stripCount[lo + i] = offs[(size_t)i + 1] - offs[(size_t)i];
+        if (!cases_up) {
+            rc = raftx_upload_cases(sub, J.nCase, J.nHead, J.nw, J.w, J.k, J.depth, J.rho_wave, J.g_wave, J.zeta, J.beta);
+            if (rc) return rc;
+            cases_up = true;
+        }
+        rc = raftx_solve_dynamics_device(sub, J.nIter, J.tol, J.XiStart, nullptr, 0);
+        if (rc) return rc;
+        tsum[1] += sub->last_ms;
+        const size_t p0 = (size_t)lo * J.nCase;
+        rc = raftx_motion_stats(sub, dw, J.sd + p0 * 6, nullptr);
+        if (rc) return rc;
+        tsum[2] += sub->last_ms;
+        rc = raftx_fetch_results(sub, J.Xi ? J.Xi + p0 * J.nHead * 6 * J.nw : nullptr, J.niter + p0, J.flags + p0, nullptr,
+                                 nullptr, nullptr);
+        if (rc) return rc;
+    }
+    return 0;
+}
+
+extern "C" int raftx_sweep_stats(raftx_ctx *c, int nDesign, const int64_t *memberOff, const double *members,
+                                 const int64_t *stationOff, const double *stations, const int64_t *capOff,
+                                 const double *caps, const double *pose, double rho, double g, int add_mask,
+                                 const double *M0, const double *B0, const double *C0, const double *Fz_moor, int nCase,
+                                 int nHead, int nw, const double *w, const double *k, double depth, double rho_wave,
+                                 double g_wave, const double *zeta, const double *beta, int nIter, double tol,
+                                 double XiStart, int nChunk, int nWorker, double *sd, int32_t *niter, int32_t *flags,
+                                 raftx_c128 *Xi, int64_t *stripOffsets, double *timing_ms) {
+    if (!c) return -1;
+    if (nDesign < 0 || !memberOff || !members || !stationOff || !stations || !M0 || !B0 || !C0)
+        FAIL(c, "sweep_stats: bad design arguments");
+    if (nCase < 1 || nHead < 1 || nw < 1 || !w || !k || !zeta || !beta) FAIL(c, "sweep_stats: bad sea-state arguments");
+    if (!sd || !niter || !flags) FAIL(c, "sweep_stats: std, niter and flags are required");
+    if ((capOff == nullptr) != (caps == nullptr)) FAIL(c, "sweep_stats: capOff and caps must be given together");
+    if (nIter < 0) FAIL(c, "sweep_stats: nIter < 0");
+    // defaults: three streams; blocks of about two residency rounds of the fused kernel (1024 pairs fit on 256 CUs)
+    if (nWorker <= 0) nWorker = 3;
+    if (nWorker > 8) nWorker = 8;
+    if (nChunk <= 0) {
+        const long pairs = (long)nDesign * nCase;
+        nChunk = (int)((pairs + 1024) / 2048);          // blocks of ~2 residency rounds: short tails, enough blocks to overlap
+        if (nChunk < 1) nChunk = 1;
+    }
+    if (nChunk > nDesign) nChunk = nDesign > 0 ? nDesign : 1;
+    if (nWorker > nChunk) nWorker = nChunk;
+    const auto t0 = std::chrono::steady_clock::now();
+    while ((int)c->workers.size() < nWorker) {
+        raftx_ctx *sub = nullptr;
+        const int rc = raftx_ctx_create(c->device, &sub);
+        if (rc) FAIL(c, "sweep_stats: cannot create worker context (rc=%d)", rc);
+        c->workers.push_back(sub);
+    }
+    std::vector<int64_t> counts((size_t)(stripOffsets ? nDesign : 0));
+    SweepJob J{nDesign, memberOff, stationOff, capOff, members, stations, caps, pose, M0, B0, C0, Fz_moor, rho, g,
+               add_mask, nCase, nHead, nw, w, k, zeta, beta, depth, rho_wave, g_wave, nIter, tol, XiStart, nChunk, sd,
+               niter, flags, Xi, stripOffsets ? counts.data() : nullptr};
+    std::vector<int> rcs((size_t)nWorker, 0);
+    std::vector<double> tsum((size_t)nWorker * 3, 0.0);
+    if (nDesign > 0) {
+        std::vector<std::thread> th;
+        for (int wkr = 1; wkr < nWorker; wkr++)
+            th.emplace_back([&, wkr]() { rcs[(size_t)wkr] = sweep_worker(c->workers[(size_t)wkr], J, wkr, nWorker, &tsum[(size_t)wkr * 3]); });
+        rcs[0] = sweep_worker(c->workers[0], J, 0, nWorker, &tsum[0]);
+        for (auto &t : th) t.join();
+    }
+    for (int wkr = 0; wkr < nWorker; wkr++)
+        if (rcs[(size_t)wkr]) {
+            snprintf(c->err, sizeof(c->err), "sweep_stats (worker %d): %s", wkr, c->workers[(size_t)wkr]->err);
+            return rcs[(size_t)wkr];
+        }
+    if (stripOffsets) {
+        stripOffsets[0] = 0;
+        for (int d = 0; d < nDesign; d++) stripOffsets[d + 1] = stripOffsets[d] + counts[(size_t)d];
+    }
+    double tb = 0, ts = 0, tst = 0;
+    for (int wkr = 0; wkr < nWorker; wkr++) { tb += tsum[(size_t)wkr * 3]; ts += tsum[(size_t)wkr * 3 + 1]; tst += tsum[(size_t)wkr * 3 + 2]; }
+    const double wall = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    if (timing_ms) { timing_ms[0] = wall; timing_ms[1] = tb; timing_ms[2] = ts; timing_ms[3] = tst; }
+    c->last_ms = ts;
     return 0;
 }
 

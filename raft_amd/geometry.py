@@ -338,3 +338,31 @@ class SweepTables:
                             np.ascontiguousarray(self.stations.reshape(-1, GS_N)),
                             np.concatenate([co, [self.n * nCap]]).astype(np.int64),
                             np.ascontiguousarray(self.caps.reshape(-1, GC_N)))
+
+
+# ---------------------------------------------------------------------- C3 workload (BASELINE configs[2])
+def volturnus_sweep(base_design, scales, heading_adjust=0.0):
+    """Member descriptors of the C3 sweep, vectorised over designs: the five parameters of
+    raft/parametersweep.py:33-37 (centre-column d, outer-column d, draft, outer-column radius, pontoon height)
+    times ``scales`` [nD,5], with the dependent-geometry edits of :56-87 -- applied straight to the
+    descriptor arrays (no per-design Python).  ``base_design``: examples/VolturnUS-S_example.yaml (members: centre column,
+    outer column x3, pontoon x3, upper beam x3, tower)."""
+    scales = np.asarray(scales, dtype=float)
+    nD = len(scales)
+    base = describe_unit(base_design, heading_adjust=heading_adjust)
+    heads = [np.atleast_1d(np.array(m.get("heading", 0.0), dtype=float)) for m in base_design["platform"]["members"]]
+    assert [len(h) for h in heads] == [1, 3, 3, 3], "not the VolturnUS-S member layout"
+    sw = SweepTables(base, nD)
+    ccD, ocD, T, ocR, pH = 10.0 * scales[:, 0], 12.5 * scales[:, 1], -20.0 * scales[:, 2], 51.75 * scales[:, 3], 7.0 * scales[:, 4]
+    z0 = np.zeros(nD)
+    col = lambda *xs: np.stack([np.broadcast_to(np.asarray(x, dtype=float), (nD,)) for x in xs], axis=1)
+    sw.set_ends(0, col(z0, z0, T), col(z0, z0, 15.0), heading=heads[0][0] + heading_adjust)
+    sw.set_diameter(0, ccD)
+    for c in range(3):
+        h = heads[1][c] + heading_adjust
+        sw.set_ends(1 + c, col(ocR, z0, T), col(ocR, z0, 15.0), heading=h)
+        sw.set_diameter(1 + c, ocD)
+        sw.set_ends(4 + c, col(ccD / 2, z0, T + pH / 2), col(ocR - ocD / 2, z0, T + pH / 2), heading=heads[2][c] + heading_adjust)
+        sw.set_diameter(4 + c, np.full(nD, 12.4), pH)
+        sw.set_ends(7 + c, col(ccD / 2, z0, 14.545), col(ocR - ocD / 2, z0, 14.545), heading=heads[3][c] + heading_adjust)
+    return sw

@@ -19,6 +19,8 @@ import numpy as np
 
 from ._abi import NFIELD
 
+WAVE_RHO, WAVE_G = 1025.0, 9.81        # hard-wired defaults of Member.calcHydroExcitation (raft_member.py:1940)
+
 
 def shard_bounds(n, rank, world):
     """Contiguous block partition of range(n): the first n % world ranks get one extra item."""
@@ -277,12 +279,26 @@ class GeometrySweep(Sweep):
                                             None if self.pose is None else self.pose[lo:hi], self.add_mask,
                                             None if self.MBw is None else self.MBw[lo:hi], self.rho, self.g), lo, hi)
 
+    def run_crossing(self, ctx, n_chunk=0, n_worker=0, want_Xi=False, Xi_out=None):
+        """The whole boundary crossing in ONE library call (raftx_sweep_stats): descriptors in, motion statistics +
+        iteration counts (+ responses) out, with upload / generation / solve / download of consecutive design blocks
+        overlapped on the library's internal streams.  Nothing stays resident on ``ctx``."""
+        t = self.tables
+        r = ctx.sweep_stats(t, self.M0, self.B0, self.C0, self.w, self.k, self.depth, self.zeta, self.beta, self.nIter,
+                            self.tol, self.XiStart, pose=self.pose, rho=self.rho, g=self.g, add_mask=self.add_mask,
+                            n_chunk=n_chunk, n_worker=n_worker, want_Xi=want_Xi, Xi_out=Xi_out)
+        self.off = r["strip_off"]
+        return r
+
     def upload(self, ctx):
         t = self.tables
         self.off = ctx.build_designs(t.member_off, t.members, t.station_off, t.stations, self.M0, self.B0, self.C0, self.nw,
                                      pose=self.pose, rho=self.rho, g=self.g, k=self.k, add_mask=self.add_mask, MBw=self.MBw,
                                      cap_off=t.cap_off, caps=t.caps)
-        ctx.upload_cases(self.w, self.k, self.depth, self.rho, self.g, self.zeta, self.beta)
+        # the dynamic-pressure scale of the wave kinematics is NOT the site's density: FOWT.calcHydroExcitation never
+        # forwards rho / g to Member.calcHydroExcitation (raft_fowt.py:1857), whose defaults are 1025 / 9.81
+        # (raft_member.py:1940); self.rho / self.g are the site values the strip constants and statics are built with
+        ctx.upload_cases(self.w, self.k, self.depth, WAVE_RHO, WAVE_G, self.zeta, self.beta)
         self._upload_bem(ctx)
 
 

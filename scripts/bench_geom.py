@@ -23,7 +23,7 @@ def main():
     ap.add_argument("--tag", default="")
     args = ap.parse_args()
     from raft_amd import backend, geometry as G
-    from tests import standin
+    from raft_amd import snapshot as standin
     fx = standin.load_fixture("geom_units.npz")
     units = [u for u in fx["units"] if u["name"].startswith("C3-variant")]
     t0 = time.perf_counter()

@@ -7,8 +7,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from raft_amd import backend, geometry as G
 from raft_amd.sweep import GeometrySweep, Pipeline
-from tests import standin
-from tests.util import volturnus_sweep
+from raft_amd import snapshot as standin
+from raft_amd.geometry import volturnus_sweep
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 10000
 fg = standin.load_fixture("geom_units.npz")

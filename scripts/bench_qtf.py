@@ -5,7 +5,7 @@ import json, os, sys, time
 import numpy as np
 sys.path.insert(0, os.getcwd())
 from raft_amd import backend, qtf as rq, waves
-from tests import standin
+from raft_amd import snapshot as standin
 
 n_set = int(sys.argv[1]) if len(sys.argv) > 1 else 16
 fx = standin.load_fixture("refgold_qtf_VolturnUS-S.npz")

@@ -256,7 +256,7 @@ def _farm_rank_main(rank, world, port, out_path):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         fx, model = load_model_fixture("c4_farm.npz")
-        cases = [case_from_fixture(c) for c in fx["cases"]]
+        cases = [case_from_fixture(c) for c in fx["cases"][:2]]
         sweep = dropin.sweep_from_units(model, cases + cases[:1])            # 3 sea states: ragged 2 + 1
         ctx = RaftxLib(ORACLE_SO).context(0)
         res = sw.run_farm_sharded(sweep, ctx, 4, Cc=fx["coupling_C"][None], dist=dist)
@@ -277,9 +277,10 @@ def test_two_rank_gloo_farm_cases(tmp_path):
     got = np.load(out)
     fx, _ = load_model_fixture("c4_farm.npz")
     assert got["Xi"].shape[:2] == (1, 3) and got["niter"].shape == (4, 3)
-    for i, c in enumerate(list(fx["cases"]) + list(fx["cases"])[:1]):
-        nH = c["Xi"].shape[0] - 1
-        assert group_rel_err(got["Xi"][0, i, :nH], c["Xi"][:nH]) < 1e-10
+    from tests.util import ref_headings
+    for i, c in enumerate(list(fx["cases"])[:2] + list(fx["cases"])[:1]):
+        Xr, nH = ref_headings(c)
+        assert group_rel_err(got["Xi"][0, i, :nH], Xr) < 1e-10
         assert [int(got["niter"][u, i]) for u in range(4)] == [int(c["units"][u]["niter"]) for u in range(4)]
 
 

@@ -57,65 +57,52 @@ def test_c3_full_size_10k_designs_generated_on_device(hip_ctx):
 
 
 def test_c4_full_size_four_units_fifty_sea_states(hip_ctx):
-    """configs[3]: 4-unit farm (24-DOF block solve) x 50 sea states in two launches.  Sea states are a random
-    permutation-with-repeats of the two the live reference solved: every copy must equal its original bit for bit and
-    the originals the reference."""
+    """configs[3] at its real shape: 4-unit farm (24-DOF block solve) x 200 bins x the 50 seeded sea states of
+    default_rng(1), in two launches (per-unit fixed points, coupled 24 x 24 solves) -- EVERY sea state against the live
+    reference's own solveDynamics of the farm (tests/golden/c4_farm.npz), and position-independence: the same sea states
+    in reversed order give bit-identical responses."""
+    from tests.util import ref_headings
     fx, model = load_model_fixture("c4_farm.npz")
-    base_cases = [case_from_fixture(c) for c in fx["cases"]]
-    rng = np.random.default_rng(50)
-    pick = rng.integers(0, len(base_cases), size=50)
-    pick[:2] = [0, 1]
-    sweep = dropin.sweep_from_units(model, [base_cases[i] for i in pick])
+    cases = [case_from_fixture(c) for c in fx["cases"]]
+    assert len(cases) == 50 and model.nw == 200
+    sweep = dropin.sweep_from_units(model, cases)
     out = sweep.run_farm(hip_ctx, 4, Cc=fx["coupling_C"][None])
-    assert out["Xi"].shape[:2] == (1, 50) and out["Xi"].shape[3] == 24
-    first = {int(p): int(np.nonzero(pick == p)[0][0]) for p in set(pick.tolist())}
-    for i, p in enumerate(pick):
-        assert np.array_equal(out["Xi"][0, i].view(np.uint64), out["Xi"][0, first[int(p)]].view(np.uint64))
-    for p, i in first.items():
-        c = fx["cases"][p]
-        nH = c["Xi"].shape[0] - 1
-        assert group_rel_err(out["Xi"][0, i, :nH], c["Xi"][:nH]) < 1e-9
+    assert out["Xi"].shape == (1, 50, 1, 24, 200)
+    assert not np.any(out["flags"] & 2)
+    for i, c in enumerate(fx["cases"]):
+        Xr, nH = ref_headings(c)
+        assert group_rel_err(out["Xi"][0, i, :nH], Xr) < 1e-9
+        assert [int(out["niter"][u, i]) for u in range(4)] == [int(c["units"][u]["niter"]) for u in range(4)]
+        zeta = np.asarray(c["units"][0]["zeta"])[0]
+        for u in range(4):                                 # SURVEY 8d metric per unit: RAOs
+            assert rao_group_err(out["Xi"][0, i, 0, 6 * u:6 * u + 6], Xr[0, 6 * u:6 * u + 6], zeta) < 1e-9
+    rev = dropin.sweep_from_units(model, cases[::-1]).run_farm(hip_ctx, 4, Cc=fx["coupling_C"][None])
+    assert np.array_equal(rev["Xi"][0, ::-1].view(np.uint64), out["Xi"][0].view(np.uint64))
+    assert np.array_equal(rev["niter"][:, ::-1], out["niter"])
 
 
-def test_c2_full_size_three_sea_states(hip_ctx):
-    """configs[1]: VolturnUS-S_example, 3 sea states x 200 bins, one launch -- responses and statistics against the live
-    reference (the deck's own size is the full size)."""
-    fx, model = load_model_fixture("c2_volturnus.npz")
-    single = [c for c in fx["cases"] if len(np.atleast_1d(c["case"]["wave_heading"])) == 1][:3]
-    sweep = dropin.sweep_from_models([model], [case_from_fixture(c) for c in single])
-    out = sweep.run(hip_ctx)
-    assert out["Xi"].shape == (1, 3, 1, 6, 200)
-    for i, c in enumerate(single):
-        assert group_rel_err(out["Xi"][0, i, :1], c["Xi"][:1]) < 1e-9
-
-
-def test_pipelined_boundary_is_bit_identical(hip_lib, hip_ctx):
-    """sweep.Pipeline: designs cut into ragged blocks, three contexts (streams) working concurrently from Python
-    threads, results written straight into one output array -- bit-identical to the single-launch sweep."""
-    from raft_amd.sweep import Pipeline, GeometrySweep
-    c3 = standin.load_fixture("c3_variants.npz")
-    fg = standin.load_fixture("geom_units.npz")
-    n = 333
-    scales = np.random.default_rng(9).uniform(0.75, 1.25, size=(n, 5))
-    u0 = [u for u in fg["units"] if u["name"] == "C3-variant-0"][0]
-    M_rna = np.asarray(u0["M_struc"]) - np.asarray(u0["M_struc_bare"])
-    C_rest = np.asarray(u0["C_struc"]) - np.asarray(u0["C_struc_bare"]) + np.diag([7e4, 7e4, 0, 0, 0, 1e8])
-    tables = volturnus_sweep(json.loads(fg["c3_base_json"]), scales).tables()
-    zeta = np.stack([np.asarray(c3["zeta"]), 0.5 * np.asarray(c3["zeta"])])
-    beta = np.array([[0.0], [0.7]])
-    sweep = GeometrySweep(tables, np.repeat(M_rna[None], n, 0), np.zeros((n, 6, 6)), np.repeat(C_rest[None], n, 0), c3["w"],
-                          c3["k"], float(c3["depth"]), zeta, beta, int(c3["nIter"]), float(c3["XiStart"]))
-    ref = sweep.run(hip_ctx)
-    pipe = Pipeline(hip_lib, n_workers=3)
-    try:
-        got = pipe.run(sweep, n_chunks=7)
-        pin = pipe.run(sweep, n_chunks=4, pinned=True)["Xi"].copy()       # page-locked landing buffer (raftx_host_alloc)
-        st = pipe.run(sweep, n_chunks=5, fetch="stats")
-    finally:
-        pipe.close()
-    assert np.array_equal(got["Xi"].view(np.uint64), ref["Xi"].view(np.uint64))
-    assert np.array_equal(pin.view(np.uint64), ref["Xi"].view(np.uint64))
-    assert np.array_equal(got["niter"], ref["niter"]) and np.array_equal(got["flags"], ref["flags"])
-    want = np.sqrt(0.5 * np.sum(np.abs(ref["Xi"][:, :, 0]) ** 2, axis=3))
-    want[:, :, 3:] *= 57.29577951308232
-    assert rel_err(st["std"], want) < 1e-12
+def test_c5_full_size_oc4semi_200x200_against_the_live_reference(hip_ctx):
+    """configs[4] at its real shape: examples/OC4semi-RAFT_QTF.yaml (MacCamy-Fuchs columns with heave plates, inclined
+    braces), nw = 200, second-order grid 200 x 200 (20 100 upper-triangle pairs), sea state (6 m, 12 s) at 0 and 30 deg:
+    first-order fixed point, Kim & Yue tables, slender-body QTF from the converged motions, second-order force,
+    restarted fixed point -- all on the device through the drop-in Model.solveDynamics, against the LIVE reference
+    run of oracle/make_golden.py:fixture_c5_full (7 minutes of reference time per case)."""
+    from tests.util import load_model_fixture
+    fx, model = load_model_fixture("c5_oc4semi_full.npz")
+    f = model.fowtList[0]
+    assert model.nw == 200 and len(f.w1_2nd) == 200
+    eng = dropin.Engine(hip_ctx)
+    iu = np.triu_indices(200)
+    for c in fx["cases"]:
+        Xi = eng.solveDynamics(model, case_from_fixture(c))
+        u = c["units"][0]
+        nH = len(np.atleast_1d(u["beta"]))
+        assert int(model._raftx_niter[0]) == int(u["niter"])
+        q = f.qtf[:, :, 0, :]
+        assert rel_err(q[iu], u["qtf_triu"]) < 1e-9
+        off = ~np.eye(200, dtype=bool)                                  # Hermitian completion (raft_fowt.py:2069-2070)
+        assert np.array_equal(q[off], np.conj(np.transpose(q, (1, 0, 2)))[off])
+        assert rel_err(f.Fhydro_2nd, u["Fhydro_2nd"]) < 1e-9
+        assert rel_err(f.Fhydro_2nd_mean, u["Fhydro_2nd_mean"]) < 1e-9
+        assert group_rel_err(Xi[:nH], np.asarray(c["Xi"])[:nH]) < 1e-9
+        assert rao_group_err(Xi[0], np.asarray(c["Xi"])[0], np.asarray(u["zeta"])[0]) < 1e-9

@@ -261,6 +261,70 @@ def test_hip_c3_from_member_descriptions_to_reference_responses(hip_ctx):
         assert group_rel_err(out["Xi"][j, 0, :1], np.asarray(sol["Xi"])[:1]) < 1e-9
 
 
+# ------------------------------------------------------------------ one-call sweep crossing (raftx_sweep_stats)
+def _c3_crossing_inputs(n):
+    from tests.util import volturnus_sweep
+    base = json.loads(FX["c3_base_json"])
+    scales = np.random.default_rng(0).uniform(0.75, 1.25, size=(n, 5))
+    u0 = UNITS["C3-variant-0"]
+    M_rna = np.asarray(u0["M_struc"]) - np.asarray(u0["M_struc_bare"])
+    C_rest = np.asarray(u0["C_struc"]) - np.asarray(u0["C_struc_bare"]) + np.diag([7e4, 7e4, 0, 0, 0, 1e8])
+    D = volturnus_sweep(base, scales).tables()
+    return D, np.repeat(M_rna[None], n, axis=0), np.repeat(np.asarray(C3["B0"])[:1], n, axis=0), np.repeat(C_rest[None], n, axis=0)
+
+
+def check_crossing(ctx, n, n_chunk, n_worker):
+    """raftx_sweep_stats == build_designs + upload_cases + solve + motion_stats + fetch_results, bit for bit, whatever
+    the chunking; the first 64 designs against the live reference's solveDynamics."""
+    D, M0, B0, C0 = _c3_crossing_inputs(n)
+    zeta2 = np.stack([np.asarray(C3["zeta"]), 0.5 * np.asarray(C3["zeta"])])          # two sea states
+    beta2 = np.stack([np.asarray(C3["beta"]), np.asarray(C3["beta"]) + 0.4])
+    nw = len(C3["w"])
+    got = ctx.sweep_stats(D, M0, B0, C0, C3["w"], C3["k"], float(C3["depth"]), zeta2, beta2, int(C3["nIter"]), 0.01,
+                          float(C3["XiStart"]), n_chunk=n_chunk, n_worker=n_worker, want_Xi=True)
+    off = ctx.build_designs(D.member_off, D.members, D.station_off, D.stations, M0, B0, C0, nw, cap_off=D.cap_off,
+                            caps=D.caps, add_mask=7)
+    ctx.upload_cases(C3["w"], C3["k"], float(C3["depth"]), 1025.0, 9.81, zeta2, beta2)
+    ctx.solve_dynamics_device(int(C3["nIter"]), 0.01, float(C3["XiStart"]))
+    std, _ = ctx.motion_stats(float(C3["w"][1] - C3["w"][0]))
+    ref = ctx.fetch_results(want_Xi=True)
+    assert np.array_equal(got["strip_off"], off)
+    assert np.array_equal(got["Xi"].view(np.uint64), ref["Xi"].view(np.uint64))
+    assert np.array_equal(got["std"].view(np.uint64), std.view(np.uint64))
+    assert np.array_equal(got["niter"], ref["niter"]) and np.array_equal(got["flags"], ref["flags"])
+    for j, sol in enumerate(C3["solved"][:min(n, 64)]):
+        assert int(got["niter"][j, 0]) == int(sol["units"][0]["niter"])
+        assert group_rel_err(got["Xi"][j, 0, :1], np.asarray(sol["Xi"])[:1]) < 1e-9
+    return got
+
+
+def test_oracle_sweep_crossing_is_the_plain_sequence(oracle_ctx):
+    check_crossing(oracle_ctx, 6, 0, 0)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n,n_chunk,n_worker", [(70, 0, 0), (70, 1, 1), (333, 7, 3), (5, 9, 4), (1, 0, 0)])
+def test_hip_sweep_crossing_chunked_equals_the_plain_sequence(hip_ctx, n, n_chunk, n_worker):
+    got = check_crossing(hip_ctx, n, n_chunk, n_worker)
+    assert got["timing_ms"][0] > 0 and got["timing_ms"][2] > 0
+
+
+@pytest.mark.gpu
+def test_hip_sweep_crossing_reuses_its_worker_streams_and_reports_errors(hip_ctx):
+    """Several crossings on one context (worker contexts and their memory pools are kept), then a bad batch: the error of
+    the failing worker comes back through raftx_last_error, and the context still works afterwards."""
+    from raft_amd._abi import RaftxError
+    for n in (40, 9, 40):
+        check_crossing(hip_ctx, n, 4, 2)
+    D, M0, B0, C0 = _c3_crossing_inputs(8)
+    bad = G.DesignTables(D.member_off, D.members.copy(), D.station_off, D.stations, D.cap_off, D.caps)
+    bad.members[int(D.member_off[5]), G.GM_DLSMAX] = -1.0                 # design 5: invalid strip length
+    with pytest.raises(RaftxError, match="dlsMax"):
+        hip_ctx.sweep_stats(bad, M0, B0, C0, C3["w"], C3["k"], float(C3["depth"]), C3["zeta"], C3["beta"], int(C3["nIter"]),
+                            n_chunk=4, n_worker=2)
+    check_crossing(hip_ctx, 12, 3, 3)
+
+
 # ------------------------------------------------------------------ ballast trim (Model.adjustBallastDensity)
 TRIM_NAMES = [n for n in NAMES if "trim_drho" in UNITS[n]]
 

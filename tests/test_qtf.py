@@ -70,6 +70,26 @@ def test_c5_internal_qtf_solveDynamics(oracle_ctx, fixture):
         assert rel_err(f.Z, u["Z"]) < 1e-9
 
 
+def test_c5_full_size_oc4semi_200x200(oracle_ctx):
+    """BASELINE configs[4] at its real shape (OC4semi-RAFT_QTF, nw = 200, 200 x 200 second-order grid, 0 and 30 deg):
+    the oracle chain (C restatement + numpy QTF restatement + host logic) against the live reference's potSecOrder == 1
+    solveDynamics (tests/golden/c5_oc4semi_full.npz, 7 minutes of reference time per case)."""
+    from raft_amd import dropin
+    from tests.util import load_model_fixture, case_from_fixture, group_rel_err
+    fx, model = load_model_fixture("c5_oc4semi_full.npz")
+    eng = dropin.Engine(oracle_ctx, qtf_backend=_numpy_qtf_backend)
+    iu = np.triu_indices(200)
+    for c in fx["cases"]:
+        Xi = eng.solveDynamics(model, case_from_fixture(c))
+        u = c["units"][0]
+        f = model.fowtList[0]
+        assert int(model._raftx_niter[0]) == int(u["niter"])
+        assert rel_err(f.qtf[:, :, 0, :][iu], u["qtf_triu"]) < 1e-9
+        assert rel_err(f.Fhydro_2nd, u["Fhydro_2nd"]) < 1e-9
+        assert rel_err(f.Fhydro_2nd_mean, u["Fhydro_2nd_mean"]) < 1e-9
+        assert group_rel_err(Xi[:1], np.asarray(c["Xi"])[:1]) < 1e-9
+
+
 def test_qtf_12d_file_round_trip(tmp_path):
     fx, f, tab = _setup("VolturnUS-S")
     q4 = fx["motion_qtf"][:, :, None, :]

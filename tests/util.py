@@ -5,43 +5,8 @@ import numpy as np
 from tests import standin
 
 
-def group_rel_err(a, b):
-    """SURVEY.md 8d parity metric: max|a-b| / max|b|, jointly over the
-    translational DOFs and jointly over the rotational DOFs (never per-DOF:
-    un-excited DOFs are round-off in the reference itself).  The DOF axis is
-    the second-to-last axis; systems with 6N DOFs are grouped per unit."""
-    a = np.asarray(a)
-    b = np.asarray(b)
-    n = a.shape[-2]
-    errs = []
-    for u in range(n // 6):
-        for sl in (slice(6 * u, 6 * u + 3), slice(6 * u + 3, 6 * u + 6)):
-            den = np.max(np.abs(b[..., sl, :]))
-            num = np.max(np.abs(a[..., sl, :] - b[..., sl, :]))
-            errs.append(num / den if den > 0 else num)
-    return max(errs)
-
-
-def rao_group_err(Xi_a, Xi_b, zeta):
-    """SURVEY.md 8d parity metric proper: RAO = getRAO(Xi, zeta) (helpers.py:762-784: Xi / zeta where |zeta| > 1e-6,
-    zero elsewhere), then max|RAO_a - RAO_b| / max|RAO_b| jointly over {surge, sway, heave} and over {roll, pitch, yaw}.
-    Xi_* [..., 6, nw], zeta [nw]."""
-    from raft_amd import waves
-    return group_rel_err(waves.get_rao(np.asarray(Xi_a), np.asarray(zeta)), waves.get_rao(np.asarray(Xi_b), np.asarray(zeta)))
-
-
-def psd_group_err(Xi_a, Xi_b, dw):
-    """The same on the motion PSDs (getPSD, helpers.py:687-700), Xi_* [nHead, 6, nw]."""
-    pa = np.sum(0.5 * np.abs(np.asarray(Xi_a)) ** 2 / dw, axis=0)
-    pb = np.sum(0.5 * np.abs(np.asarray(Xi_b)) ** 2 / dw, axis=0)
-    return group_rel_err(pa, pb)
-
-
-def rel_err(a, b):
-    a = np.asarray(a)
-    b = np.asarray(b)
-    den = np.max(np.abs(b))
-    return np.max(np.abs(a - b)) / (den if den > 0 else 1.0)
+from raft_amd.metrics import group_rel_err, rao_group_err, psd_group_err, rel_err     # noqa: F401,E402
+from raft_amd.geometry import volturnus_sweep                                            # noqa: F401,E402
 
 
 def case_from_fixture(c):
@@ -49,6 +14,13 @@ def case_from_fixture(c):
     for k, v in c["case"].items():
         case[k] = list(v) if isinstance(v, (list, np.ndarray)) else v
     return copy.deepcopy(case)
+
+
+def ref_headings(c):
+    """(reference responses of the wave headings [nH,6N,nw], nH) of a fixture case.  Full cases store the reference's
+    Xi with its zero rotor-excitation row (raft_model.py:1236), lean ones (many-case fixtures) without it."""
+    nH = len(np.atleast_1d(np.asarray(c["case"]["wave_heading"], dtype=float)))
+    return np.asarray(c["Xi"])[:nH], nH
 
 
 def load_model_fixture(name):
@@ -122,36 +94,6 @@ def synthetic_cases(rng, nC, nH, nw, depth=200.0, wmin=0.05, wmax=2.0):
             S = waves.jonswap(w, rng.uniform(1, 10), rng.uniform(6, 16))
             zeta[c, h] = np.sqrt(2 * S * dw)
     return w, k, zeta, beta
-
-
-# ------------------------------------------------------------------ C3 workload
-def volturnus_sweep(base_design, scales, heading_adjust=0.0):
-    """Member descriptors of the C3 sweep, vectorised over designs: the five parameters of
-    raft/parametersweep.py:33-37 (centre-column d, outer-column d, draft, outer-column radius, pontoon height)
-    times ``scales`` [nD,5], with the dependent-geometry edits of :56-87 -- the same edits
-    oracle/make_golden.py:volturnus_variant applies to the design dict, here applied straight to the descriptor
-    arrays (no per-design Python).  ``base_design``: examples/VolturnUS-S_example.yaml (members: centre column,
-    outer column x3, pontoon x3, upper beam x3, tower)."""
-    from raft_amd import geometry as G
-    scales = np.asarray(scales, dtype=float)
-    nD = len(scales)
-    base = G.describe_unit(base_design, heading_adjust=heading_adjust)
-    heads = [np.atleast_1d(np.array(m.get("heading", 0.0), dtype=float)) for m in base_design["platform"]["members"]]
-    assert [len(h) for h in heads] == [1, 3, 3, 3], "not the VolturnUS-S member layout"
-    sw = G.SweepTables(base, nD)
-    ccD, ocD, T, ocR, pH = 10.0 * scales[:, 0], 12.5 * scales[:, 1], -20.0 * scales[:, 2], 51.75 * scales[:, 3], 7.0 * scales[:, 4]
-    z0 = np.zeros(nD)
-    col = lambda *xs: np.stack([np.broadcast_to(np.asarray(x, dtype=float), (nD,)) for x in xs], axis=1)
-    sw.set_ends(0, col(z0, z0, T), col(z0, z0, 15.0), heading=heads[0][0] + heading_adjust)
-    sw.set_diameter(0, ccD)
-    for c in range(3):
-        h = heads[1][c] + heading_adjust
-        sw.set_ends(1 + c, col(ocR, z0, T), col(ocR, z0, 15.0), heading=h)
-        sw.set_diameter(1 + c, ocD)
-        sw.set_ends(4 + c, col(ccD / 2, z0, T + pH / 2), col(ocR - ocD / 2, z0, T + pH / 2), heading=heads[2][c] + heading_adjust)
-        sw.set_diameter(4 + c, np.full(nD, 12.4), pH)
-        sw.set_ends(7 + c, col(ccD / 2, z0, 14.545), col(ocR - ocD / 2, z0, 14.545), heading=heads[3][c] + heading_adjust)
-    return sw
 
 
 # ------------------------------------------------------------------ moorMod == 2 stand-in
