@@ -383,6 +383,37 @@ int raftx_sweep_stats(raftx_ctx *ctx, int nDesign, const int64_t *memberOff, con
                       double *std, int32_t *niter, int32_t *flags, raftx_c128 *Xi, int64_t *stripOffsets,
                       double *timing_ms);
 
+/* ------------------------------------------------------------------------------------------------
+ * Multi-GPU exchange steps: one process per GPU, one RCCL communicator per ctx, xGMI underneath.
+ * The path shards with NO collective while kernels run; these calls are the once-per-batch exchanges around it:
+ * the shared sea-state tables out (broadcast), the responses / statistics / QTF partials back (gather, reduce).
+ * Every rank of the communicator must make the same call.  All calls are enqueued on the ctx's stream and return
+ * after it has drained.  (The CPU oracle does not implement them: its tests use the host transport of
+ * raft_amd/comm.py.)
+ *
+ * raftx_comm_unique_id: rank 0 creates the 128-byte RCCL unique id and hands it to the other ranks by any host
+ *   channel (raft_amd/comm.py: a TCP rendezvous on MASTER_ADDR);  raftx_comm_init: collective, binds ctx to
+ *   (rank, world);  raftx_comm_destroy: releases the communicator (also done by raftx_ctx_destroy). */
+#define RAFTX_COMM_ID_BYTES 128
+int raftx_comm_unique_id(raftx_ctx *ctx, char *id128);
+int raftx_comm_init(raftx_ctx *ctx, int rank, int world, const char *id128);
+int raftx_comm_destroy(raftx_ctx *ctx);
+/* Host buffers, staged through HBM inside the call: buf [bytes] is sent by root and overwritten everywhere else
+ * (ncclBroadcast) -- the shared case tables w, k, zeta, beta of a sweep (a few KB). */
+int raftx_comm_broadcast(raftx_ctx *ctx, void *buf, size_t bytes, int root);
+/* Gather-to-root of ragged row blocks: rank r contributes counts[r] rows of row_bytes bytes (send, host);
+ * root receives them back to back in rank order (recv, host, sum(counts) rows; ignored elsewhere).  Point-to-point
+ * ncclSend/ncclRecv inside one group: only root's links carry data (no all-gather of 24 MB per rank to everyone). */
+int raftx_comm_gather_rows(raftx_ctx *ctx, const void *send, const int64_t *counts, size_t row_bytes, void *recv,
+                           int root);
+/* The same for the RESIDENT responses of the last raftx_solve_dynamics_device: rank r's Xi
+ * [counts[r] (= its nDesign*nCase), nHead,6,nw] goes straight from its HBM buffer to root's HBM and from there to
+ * root's host array Xi_all (page-locked for full PCIe rate); no host bounce on the sending ranks. */
+int raftx_comm_gather_xi(raftx_ctx *ctx, const int64_t *counts, raftx_c128 *Xi_all, int root);
+/* Element-wise SUM of n doubles onto root (ncclReduce; buf host, overwritten on root only): the partial QTFs of the
+ * interleaved row partition (raftx_qtf_slender_rows), 3.8 MB for the 200-point grid. */
+int raftx_comm_reduce_sum(raftx_ctx *ctx, double *buf, size_t n, int root);
+
 /* Page-locked host buffers for the bulk outputs (the 19 KB per design-case of raftx_fetch_results): copies into
  * them run at full PCIe rate and asynchronously to other streams, which pageable NumPy memory does not.  The caller
  * wraps the pointer in an array (raft_amd/_abi.py Context.pinned_empty) and must return it with raftx_host_free before

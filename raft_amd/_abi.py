@@ -27,6 +27,8 @@ EXPORTS = (
     "raftx_solve_dynamics_device", "raftx_fetch_results", "raftx_debug_math", "raftx_motion_stats", "raftx_solve_system_resident", "raftx_qtf_slender", "raftx_channel_stats", "raftx_qtf_force", "raftx_set_linearisation_point", "raftx_fetch_linearisation_point",
     "raftx_build_designs", "raftx_fetch_strips", "raftx_fetch_statics", "raftx_channel_stats_poly", "raftx_qtf_slender_rows", "raftx_bem_excitation", "raftx_qtf_kay", "raftx_host_alloc", "raftx_host_free",
     "raftx_sweep_stats",
+    "raftx_comm_unique_id", "raftx_comm_init", "raftx_comm_destroy", "raftx_comm_broadcast", "raftx_comm_gather_rows",
+    "raftx_comm_gather_xi", "raftx_comm_reduce_sum",
 )
 WANT_BDRAG, WANT_FWAVE, WANT_Z = 1, 2, 4
 
@@ -135,6 +137,16 @@ class RaftxLib:
                                         C.c_double, _vp, _vp, C.c_int, C.c_double, C.c_double, C.c_int, C.c_int,
                                         _vp, _vp, _vp, _vp, _vp, _vp]
         L.raftx_sweep_stats.restype = C.c_int
+        L.raftx_comm_unique_id.argtypes = [_vp, _vp]
+        L.raftx_comm_init.argtypes = [_vp, C.c_int, C.c_int, _vp]
+        L.raftx_comm_destroy.argtypes = [_vp]
+        L.raftx_comm_broadcast.argtypes = [_vp, _vp, C.c_size_t, C.c_int]
+        L.raftx_comm_gather_rows.argtypes = [_vp, _vp, _vp, C.c_size_t, _vp, C.c_int]
+        L.raftx_comm_gather_xi.argtypes = [_vp, _vp, _vp, C.c_int]
+        L.raftx_comm_reduce_sum.argtypes = [_vp, _vp, C.c_size_t, C.c_int]
+        for f in (L.raftx_comm_unique_id, L.raftx_comm_init, L.raftx_comm_destroy, L.raftx_comm_broadcast,
+                  L.raftx_comm_gather_rows, L.raftx_comm_gather_xi, L.raftx_comm_reduce_sum):
+            f.restype = C.c_int
 
     @property
     def version(self):
@@ -602,6 +614,63 @@ class Context:
         rc = self.rlib.lib.raftx_debug_math(self._h, len(x), _ptr(x), _ptr(s), _ptr(c), _ptr(e))
         self._check(rc, "raftx_debug_math")
         return s, c, e
+
+    # ------------------------------------------------------------- multi-GPU exchange steps (RCCL, raftx_comm_*)
+    def comm_unique_id(self):
+        buf = C.create_string_buffer(128)
+        self._check(self.rlib.lib.raftx_comm_unique_id(self._h, buf), "raftx_comm_unique_id")
+        return buf.raw
+
+    def comm_init(self, rank, world, unique_id):
+        if len(unique_id) != 128:
+            raise ValueError("the RCCL unique id is 128 bytes")
+        self._check(self.rlib.lib.raftx_comm_init(self._h, int(rank), int(world), C.c_char_p(bytes(unique_id))), "raftx_comm_init")
+        self._comm = (int(rank), int(world))
+
+    def comm_destroy(self):
+        self._check(self.rlib.lib.raftx_comm_destroy(self._h), "raftx_comm_destroy")
+        self._comm = None
+
+    def comm_broadcast(self, arr, root=0):
+        """In place: ``arr`` (C-contiguous NumPy array) is sent by ``root`` and overwritten on every other rank."""
+        if not arr.flags["C_CONTIGUOUS"]:
+            raise ValueError("comm_broadcast needs a C-contiguous array")
+        self._check(self.rlib.lib.raftx_comm_broadcast(self._h, _ptr(arr), arr.nbytes, int(root)), "raftx_comm_broadcast")
+        return arr
+
+    def comm_gather_rows(self, local, counts, root=0):
+        """Row blocks of every rank (counts[r] rows each, same trailing shape and dtype) back to back on root."""
+        local = np.ascontiguousarray(local)
+        counts = np.ascontiguousarray(counts, dtype=np.int64)
+        rank, _ = self._comm
+        if local.shape[0] != counts[rank]:
+            raise ValueError("this rank holds %d rows, counts says %d" % (local.shape[0], counts[rank]))
+        row_bytes = int(np.prod(local.shape[1:], dtype=np.int64)) * local.dtype.itemsize
+        out = np.empty((int(counts.sum()),) + local.shape[1:], dtype=local.dtype) if rank == root else None
+        self._check(self.rlib.lib.raftx_comm_gather_rows(self._h, _ptr(local), _ptr(counts), row_bytes, _ptr(out), int(root)),
+                    "raftx_comm_gather_rows")
+        return out
+
+    def comm_gather_xi(self, counts, root=0, out=None):
+        """The resident responses of every rank's last solve -> [sum(counts), nHead, 6, nw] on root, HBM to HBM."""
+        counts = np.ascontiguousarray(counts, dtype=np.int64)
+        rank, _ = self._comm
+        if rank == root:
+            shape = (int(counts.sum()), self.nHead, 6, self.nw)
+            if out is None:
+                out = np.empty(shape, dtype=np.complex128)
+            elif out.dtype != np.complex128 or out.size != int(np.prod(shape)) or not out.flags["C_CONTIGUOUS"]:
+                raise ValueError("out must be a C-contiguous complex128 array with %d elements" % int(np.prod(shape)))
+        self._check(self.rlib.lib.raftx_comm_gather_xi(self._h, _ptr(counts), _ptr(out) if rank == root else None, int(root)),
+                    "raftx_comm_gather_xi")
+        return out if rank == root else None
+
+    def comm_reduce_sum(self, buf, root=0):
+        """In place on root: element-wise sum over ranks of a float64 array."""
+        if buf.dtype != np.float64 or not buf.flags["C_CONTIGUOUS"]:
+            raise ValueError("comm_reduce_sum needs a C-contiguous float64 array")
+        self._check(self.rlib.lib.raftx_comm_reduce_sum(self._h, _ptr(buf), buf.size, int(root)), "raftx_comm_reduce_sum")
+        return buf
 
     def last_kernel_ms(self):
         return float(self.rlib.lib.raftx_last_kernel_ms(self._h))

@@ -22,6 +22,8 @@
 // No fallback paths: every entry point either runs on the GPU or fails.
 
 #include <hip/hip_runtime.h>
+#include <rccl/rccl.h>        // types only: the library is dlopen'ed on the first raftx_comm_* call
+#include <dlfcn.h>
 
 #include <cmath>
 #include <cstdint>
@@ -30,6 +32,7 @@
 #include <cstring>
 #include <chrono>
 #include <map>
+#include <mutex>
 #include <thread>
 #include <unordered_map>
 #include <vector>
@@ -412,6 +415,8 @@ struct raftx_ctx {
     size_t g_nStrips, g_nRows;
     double *g_abi, *g_A, *g_Ch, *g_Wh, *g_props, *g_Ms, *g_Cs, *g_Ws;
     cplx *g_cm;
+    void *comm;                          // ncclComm_t of raftx_comm_init (RCCL), or null
+    int comm_rank, comm_world;
     std::vector<raftx_ctx *> workers;    // sub-contexts of raftx_sweep_stats (own stream, buffers, pool), kept for reuse
 };
 
@@ -471,6 +476,9 @@ extern "C" int raftx_ctx_create(int device_id, raftx_ctx **out) {
     c->r_npair = c->r_nx = c->r_nz = 0;
     c->r_mask = 0;
     c->r_fe = false;
+    c->comm = nullptr;
+    c->comm_rank = 0;
+    c->comm_world = 1;
     if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess ||
         hipEventCreate(&c->ev0) != hipSuccess || hipEventCreate(&c->ev1) != hipSuccess) {
         delete c;
@@ -487,6 +495,7 @@ static void free_list(raftx_ctx *c, std::vector<void *> &v) {
 
 extern "C" void raftx_ctx_destroy(raftx_ctx *c) {
     if (!c) return;
+    (void)raftx_comm_destroy(c);
     for (raftx_ctx *w : c->workers) raftx_ctx_destroy(w);
     c->workers.clear();
     (void)hipSetDevice(c->device);
@@ -1718,6 +1727,218 @@ extern "C" int raftx_sweep_stats(raftx_ctx *c, int nDesign, const int64_t *membe
     const double wall = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     if (timing_ms) { timing_ms[0] = wall; timing_ms[1] = tb; timing_ms[2] = ts; timing_ms[3] = tst; }
     c->last_ms = ts;
+    return 0;
+}
+
+// ------------------------------------------------------------------ RCCL exchange steps
+// librccl is bound at run time (dlopen on the first raftx_comm_* call): single-GPU users never load it.
+struct RcclApi {
+    void *h = nullptr;
+    ncclResult_t (*GetUniqueId)(ncclUniqueId *) = nullptr;
+    ncclResult_t (*CommInitRank)(ncclComm_t *, int, ncclUniqueId, int) = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    const char *(*GetErrorString)(ncclResult_t) = nullptr;
+    ncclResult_t (*Broadcast)(const void *, void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*Reduce)(const void *, void *, size_t, ncclDataType_t, ncclRedOp_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*Send)(const void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*Recv)(void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*GroupStart)() = nullptr;
+    ncclResult_t (*GroupEnd)() = nullptr;
+};
+static RcclApi *rccl_api(raftx_ctx *c) {
+    static RcclApi api;
+    static std::mutex mu;
+    std::lock_guard<std::mutex> lk(mu);
+    if (api.h) return &api;
+    const char *names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+    void *h = nullptr;
+    for (const char *n : names)
+        if ((h = dlopen(n, RTLD_NOW | RTLD_GLOBAL))) break;
+    if (!h) {
+        snprintf(c->err, sizeof(c->err), "cannot load librccl: %s", dlerror());
+        return nullptr;
+    }
+#define RCCL_SYM(field, name)                                                             \
+    *reinterpret_cast<void **>(&api.field) = dlsym(h, name);                              \
+    if (!api.field) {                                                                     \
+        snprintf(c->err, sizeof(c->err), "librccl does not export %s", name);             \
+        return nullptr;                                                                   \
+    }
+    RCCL_SYM(GetUniqueId, "ncclGetUniqueId")
+    RCCL_SYM(CommInitRank, "ncclCommInitRank")
+    RCCL_SYM(CommDestroy, "ncclCommDestroy")
+    RCCL_SYM(GetErrorString, "ncclGetErrorString")
+    RCCL_SYM(Broadcast, "ncclBroadcast")
+    RCCL_SYM(Reduce, "ncclReduce")
+    RCCL_SYM(Send, "ncclSend")
+    RCCL_SYM(Recv, "ncclRecv")
+    RCCL_SYM(GroupStart, "ncclGroupStart")
+    RCCL_SYM(GroupEnd, "ncclGroupEnd")
+#undef RCCL_SYM
+    api.h = h;
+    return &api;
+}
+#define NCCLCHK(ctx, api, call)                                                                               \
+    do {                                                                                                      \
+        ncclResult_t r_ = (call);                                                                             \
+        if (r_ != ncclSuccess) {                                                                              \
+            snprintf((ctx)->err, sizeof((ctx)->err), "%s failed: %s (%s:%d)", #call, (api)->GetErrorString(r_), \
+                     __FILE__, __LINE__);                                                                     \
+            return -7;                                                                                        \
+        }                                                                                                     \
+    } while (0)
+
+extern "C" int raftx_comm_unique_id(raftx_ctx *c, char *id128) {
+    if (!c || !id128) return -1;
+    RcclApi *R = rccl_api(c);
+    if (!R) return -7;
+    HIPCHK(c, hipSetDevice(c->device));
+    ncclUniqueId id;
+    NCCLCHK(c, R, R->GetUniqueId(&id));
+    static_assert(sizeof(id) == RAFTX_COMM_ID_BYTES, "RCCL unique id size");
+    memcpy(id128, &id, sizeof(id));
+    return 0;
+}
+
+extern "C" int raftx_comm_destroy(raftx_ctx *c) {
+    if (!c) return -1;
+    if (c->comm) {
+        RcclApi *R = rccl_api(c);
+        if (R) {
+            (void)hipSetDevice(c->device);
+            (void)hipStreamSynchronize(c->stream);
+            (void)R->CommDestroy(reinterpret_cast<ncclComm_t>(c->comm));
+        }
+        c->comm = nullptr;
+    }
+    c->comm_rank = 0;
+    c->comm_world = 1;
+    return 0;
+}
+
+extern "C" int raftx_comm_init(raftx_ctx *c, int rank, int world, const char *id128) {
+    if (!c || !id128) return -1;
+    if (world < 1 || rank < 0 || rank >= world) FAIL(c, "comm_init: bad rank/world %d/%d", rank, world);
+    if (c->comm) FAIL(c, "comm_init: this ctx already has a communicator");
+    RcclApi *R = rccl_api(c);
+    if (!R) return -7;
+    HIPCHK(c, hipSetDevice(c->device));
+    ncclUniqueId id;
+    memcpy(&id, id128, sizeof(id));
+    ncclComm_t comm = nullptr;
+    NCCLCHK(c, R, R->CommInitRank(&comm, world, id, rank));
+    c->comm = comm;
+    c->comm_rank = rank;
+    c->comm_world = world;
+    return 0;
+}
+
+static int comm_ready(raftx_ctx *c, RcclApi **R, int root) {
+    if (!c) return -1;
+    if (!c->comm) FAIL(c, "no communicator on this ctx (raftx_comm_init)");
+    if (root < 0 || root >= c->comm_world) FAIL(c, "root %d outside the communicator (%d ranks)", root, c->comm_world);
+    *R = rccl_api(c);
+    return *R ? 0 : -7;
+}
+
+extern "C" int raftx_comm_broadcast(raftx_ctx *c, void *buf, size_t bytes, int root) {
+    RcclApi *R = nullptr;
+    if (int rc = comm_ready(c, &R, root)) return rc;
+    if (!buf && bytes) FAIL(c, "comm_broadcast: buf is NULL");
+    if (!bytes) return 0;
+    HIPCHK(c, hipSetDevice(c->device));
+    Scratch sc(c);
+    char *d = sc.alloc<char>(bytes);
+    if (!d) FAIL(c, "comm_broadcast: device allocation failed");
+    if (c->comm_rank == root) H2D(c, d, buf, bytes);
+    NCCLCHK(c, R, R->Broadcast(d, d, bytes, ncclChar, root, reinterpret_cast<ncclComm_t>(c->comm), c->stream));
+    if (c->comm_rank != root) D2H(c, buf, d, bytes);
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+// rows of every rank onto root, point to point; dsend: this rank's rows already in HBM
+static int gather_rows_dev(raftx_ctx *c, RcclApi *R, const void *dsend, const int64_t *counts, size_t row_bytes, void *recv_host,
+                           int root, Scratch &sc) {
+    const int me = c->comm_rank, world = c->comm_world;
+    ncclComm_t comm = reinterpret_cast<ncclComm_t>(c->comm);
+    size_t total = 0;
+    for (int r = 0; r < world; r++) {
+        if (counts[r] < 0) FAIL(c, "comm_gather: negative count for rank %d", r);
+        total += (size_t)counts[r];
+    }
+    char *dall = nullptr;
+    if (me == root) {
+        if (!recv_host && total) FAIL(c, "comm_gather: recv is NULL on root");
+        dall = sc.alloc<char>(total * row_bytes);
+        if (total && !dall) FAIL(c, "comm_gather: device allocation failed");
+    }
+    NCCLCHK(c, R, R->GroupStart());
+    if (me == root) {
+        size_t o = 0;
+        for (int r = 0; r < world; r++) {
+            const size_t nb = (size_t)counts[r] * row_bytes;
+            if (nb) {
+                if (r == me) HIPCHK(c, hipMemcpyAsync(dall + o, dsend, nb, hipMemcpyDeviceToDevice, c->stream));
+                else NCCLCHK(c, R, R->Recv(dall + o, nb, ncclChar, r, comm, c->stream));
+            }
+            o += nb;
+        }
+    } else {
+        const size_t nb = (size_t)counts[me] * row_bytes;
+        if (nb) NCCLCHK(c, R, R->Send(dsend, nb, ncclChar, root, comm, c->stream));
+    }
+    NCCLCHK(c, R, R->GroupEnd());
+    if (me == root && total) D2H(c, recv_host, dall, total * row_bytes);
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+extern "C" int raftx_comm_gather_rows(raftx_ctx *c, const void *send, const int64_t *counts, size_t row_bytes, void *recv,
+                                      int root) {
+    RcclApi *R = nullptr;
+    if (int rc = comm_ready(c, &R, root)) return rc;
+    if (!counts || !row_bytes) FAIL(c, "comm_gather_rows: bad arguments");
+    HIPCHK(c, hipSetDevice(c->device));
+    Scratch sc(c);
+    const size_t nb = (size_t)counts[c->comm_rank] * row_bytes;
+    char *d = nullptr;
+    if (nb) {
+        if (!send) FAIL(c, "comm_gather_rows: send is NULL");
+        d = sc.alloc<char>(nb);
+        if (!d) FAIL(c, "comm_gather_rows: device allocation failed");
+        H2D(c, d, send, nb);
+    }
+    return gather_rows_dev(c, R, d, counts, row_bytes, recv, root, sc);
+}
+
+extern "C" int raftx_comm_gather_xi(raftx_ctx *c, const int64_t *counts, raftx_c128 *Xi_all, int root) {
+    RcclApi *R = nullptr;
+    if (int rc = comm_ready(c, &R, root)) return rc;
+    if (!counts) FAIL(c, "comm_gather_xi: counts is NULL");
+    if (!c->rXi) FAIL(c, "comm_gather_xi: no resident results");
+    if ((size_t)counts[c->comm_rank] != c->r_npair)
+        FAIL(c, "comm_gather_xi: counts[%d] = %lld but %zu (design, case) pairs are resident", c->comm_rank,
+             (long long)counts[c->comm_rank], c->r_npair);
+    HIPCHK(c, hipSetDevice(c->device));
+    Scratch sc(c);
+    const size_t row_bytes = (size_t)c->T.nHead * 6 * c->T.nw * sizeof(cplx);
+    return gather_rows_dev(c, R, c->rXi, counts, row_bytes, Xi_all, root, sc);
+}
+
+extern "C" int raftx_comm_reduce_sum(raftx_ctx *c, double *buf, size_t n, int root) {
+    RcclApi *R = nullptr;
+    if (int rc = comm_ready(c, &R, root)) return rc;
+    if (!buf && n) FAIL(c, "comm_reduce_sum: buf is NULL");
+    if (!n) return 0;
+    HIPCHK(c, hipSetDevice(c->device));
+    Scratch sc(c);
+    double *d = sc.alloc<double>(n);
+    if (!d) FAIL(c, "comm_reduce_sum: device allocation failed");
+    H2D(c, d, buf, n * sizeof(double));
+    NCCLCHK(c, R, R->Reduce(d, d, n, ncclDouble, ncclSum, root, reinterpret_cast<ncclComm_t>(c->comm), c->stream));
+    if (c->comm_rank == root) D2H(c, buf, d, n * sizeof(double));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
     return 0;
 }
 

@@ -11,9 +11,10 @@ one launch of the fused kernel per rank:
     case) items are independent, nothing is exchanged while solving;
   * ``run_sharded`` is the one-process-per-GPU driver: rank 0 broadcasts the
     shared case tables (w, k, zeta, beta: a few KB), every rank solves its own
-    designs, and the responses are gathered to rank 0.  With the ``nccl`` backend
-    (RCCL over xGMI) the collectives move device tensors; with ``gloo`` (CPU tests)
-    host tensors.  No collective sits inside the timed solve.
+    designs, and the responses are gathered to rank 0 through a raft_amd.comm
+    communicator: the library's own RCCL communicator over xGMI on the GPUs
+    (responses leave from the HBM buffers they were solved into), a TCP hub in
+    the CPU tests.  No collective sits inside the solve.
 """
 import numpy as np
 
@@ -302,121 +303,101 @@ class GeometrySweep(Sweep):
         self._upload_bem(ctx)
 
 
-# ---------------------------------------------------------------------- multi-GPU driver
-def _device_for(dist):
-    import torch
-    return torch.device("cuda", torch.cuda.current_device()) if dist.get_backend() == "nccl" else torch.device("cpu")
+# ---------------------------------------------------------------------- multi-GPU drivers
+# ``comm`` is a raft_amd.comm communicator (RcclComm on the GPUs, HostComm in CPU tests / rehearsals): rank, world,
+# broadcast_arrays, gather_rows, gather_xi, reduce_sum.  No collective is issued while a kernel runs.
+def _counts(n, world):
+    return np.array([shard_bounds(n, r, world)[1] - shard_bounds(n, r, world)[0] for r in range(world)], dtype=np.int64)
 
 
-def broadcast_cases(cases, dist, src=0):
-    """Rank ``src`` broadcasts the shared sea-state tables (dict of small float64 arrays + scalars)."""
-    import torch
-    dev = _device_for(dist)
-    keys = ["w", "k", "zeta", "beta"]
-    shapes = [None]
-    if dist.get_rank() == src:
-        shapes = [{k_: tuple(np.asarray(cases[k_]).shape) for k_ in keys}]
-        shapes[0]["scalars"] = {k_: cases[k_] for k_ in cases if k_ not in keys}
-    dist.broadcast_object_list(shapes, src=src)
-    out = dict(shapes[0]["scalars"])
-    for k_ in keys:
-        if dist.get_rank() == src:
-            t = torch.as_tensor(np.ascontiguousarray(cases[k_], dtype=np.float64)).to(dev)
-        else:
-            t = torch.empty(shapes[0][k_], dtype=torch.float64, device=dev)
-        dist.broadcast(t, src=src)
-        out[k_] = t.cpu().numpy()
-    return out
+def broadcast_cases(cases, comm):
+    """Rank 0 broadcasts the shared sea-state tables (dict of small float64 arrays + scalars: w, k, zeta, beta, depth)."""
+    if comm is None or comm.world == 1:
+        return cases
+    if comm.rank == 0:
+        cases = {k_: (np.ascontiguousarray(v, dtype=np.float64) if isinstance(v, (np.ndarray, list, tuple)) else v)
+                 for k_, v in cases.items()}
+    return comm.broadcast_arrays(cases if comm.rank == 0 else None)
 
 
-def gather_rows(local, counts, dist, dst=0):
-    """Gather per-rank row blocks (first axis; counts[r] rows on rank r) to ``dst``; None elsewhere.
-    Blocks are padded to the largest count so every rank contributes an equal-size tensor."""
-    import torch
-    dev = _device_for(dist)
-    local = np.ascontiguousarray(local)
-    is_c = np.iscomplexobj(local)
-    arr = local.view(np.float64) if is_c else local
-    pad = max(counts)
-    buf = np.zeros((pad,) + arr.shape[1:], dtype=arr.dtype)
-    buf[:arr.shape[0]] = arr
-    t = torch.as_tensor(buf).to(dev)
-    rank, world = dist.get_rank(), dist.get_world_size()
-    if dist.get_backend() == "nccl":
-        parts = [torch.empty_like(t) for _ in range(world)]
-        dist.all_gather(parts, t)                     # RCCL has no gather-to-root primitive; ring all-gather
-    else:
-        parts = [torch.empty_like(t) for _ in range(world)] if rank == dst else None
-        dist.gather(t, parts, dst=dst)
-    if rank != dst:
-        return None
-    full = np.concatenate([p.cpu().numpy()[:c] for p, c in zip(parts, counts)], axis=0)
-    return full.view(np.complex128) if is_c else full
-
-
-def run_sharded(sweep, ctx, dist=None, gather=True):
+def run_sharded(sweep, ctx, comm=None, gather=True):
     """Every rank solves its block of designs; rank 0 gets the assembled results
-    ({"Xi","niter","flags"}), the others their local block only."""
-    if dist is None or dist.get_world_size() == 1:
+    ({"Xi","niter","flags"}), the others their local block only.  The responses travel from the HBM buffers they
+    were solved into (comm.gather_xi), the small integer arrays as rows."""
+    if comm is None or comm.world == 1:
         return sweep.run(ctx)
-    rank, world = dist.get_rank(), dist.get_world_size()
-    local = sweep.shard(rank, world).run(ctx)
+    rank, world = comm.rank, comm.world
+    sub = sweep.shard(rank, world)
+    sub.solve(ctx)
+    r = ctx.fetch_results(want_Xi=not gather or rank != 0)
+    local = {"Xi": r["Xi"], "niter": r["niter"], "flags": r["flags"]}
     if not gather:
         return local
-    counts = [shard_bounds(sweep.n_design, r, world)[1] - shard_bounds(sweep.n_design, r, world)[0] for r in range(world)]
-    out = {k_: gather_rows(v, counts, dist) for k_, v in local.items()}
-    return out if rank == 0 else local
+    cd = _counts(sweep.n_design, world)
+    Xi = comm.gather_xi(ctx, cd * sweep.n_case)
+    ni = comm.gather_rows(local["niter"], cd)
+    fl = comm.gather_rows(local["flags"], cd)
+    if rank != 0:
+        return local
+    return {"Xi": Xi.reshape((sweep.n_design, sweep.n_case) + Xi.shape[1:]), "niter": ni, "flags": fl}
 
 
-def run_qtf_sharded(qtf_fn, tables, Xi, beta, w2, k2, depth, rho, g, Mstruc, kay=None, dist=None):
+def run_stats_sharded(sweep, ctx, comm=None):
+    """The optimiser-style exchange: every rank solves its designs and only the motion statistics (48 B per design-case)
+    and iteration counts are gathered onto rank 0."""
+    if comm is None or comm.world == 1:
+        return sweep.run_stats(ctx)
+    local = sweep.shard(comm.rank, comm.world).run_stats(ctx)
+    cd = _counts(sweep.n_design, comm.world)
+    out = {k_: comm.gather_rows(local[k_], cd) for k_ in ("std", "niter", "flags")}
+    return out if comm.rank == 0 else local
+
+
+def run_qtf_sharded(qtf_fn, tables, Xi, beta, w2, k2, depth, rho, g, Mstruc, kay=None, comm=None):
     """Slender-body QTFs of many (table, motion, heading) sets, sharded by set over the ranks (sets are independent:
     no collective while computing); rank 0 gets [nSet,nw2,nw2,6], the others their own block.
     qtf_fn = ctx.qtf_slender of the rank's context (tests pass the numpy oracle)."""
     n = len(tables)
     Xi, beta, Mstruc = np.asarray(Xi), np.asarray(beta), np.asarray(Mstruc)
-    if dist is None or dist.get_world_size() == 1:
+    if comm is None or comm.world == 1:
         return qtf_fn(tables, Xi, beta, w2, k2, depth, rho, g, Mstruc, kay)
-    rank, world = dist.get_rank(), dist.get_world_size()
+    rank, world = comm.rank, comm.world
     lo, hi = shard_bounds(n, rank, world)
     local = qtf_fn(tables[lo:hi], Xi[lo:hi], beta[lo:hi], w2, k2, depth, rho, g, Mstruc[lo:hi],
                    None if kay is None else np.asarray(kay)[lo:hi])
-    counts = [shard_bounds(n, r, world)[1] - shard_bounds(n, r, world)[0] for r in range(world)]
-    full = gather_rows(local, counts, dist)
+    full = comm.gather_rows(local, _counts(n, world))
     return full if rank == 0 else local
 
 
-def run_qtf_rows_sharded(qtf_fn, tables, Xi, beta, w2, k2, depth, rho, g, Mstruc, kay=None, dist=None):
+def run_qtf_rows_sharded(qtf_fn, tables, Xi, beta, w2, k2, depth, rho, g, Mstruc, kay=None, comm=None):
     """ONE QTF (or a few) shared by all ranks -- SURVEY.md 8e C5: every rank computes the INTERLEAVED rows
     w1 = w2[rank::world] of every set (row i1 holds nw2 - i1 pairs, so contiguous blocks would be unbalanced) with
     ``qtf_fn(..., rows=(rank, world))`` (ctx.qtf_slender -> raftx_qtf_slender_rows), which returns zeros elsewhere;
     the partial matrices are SUMMED onto rank 0 (one reduce of nSet*nw2^2*6 complex: 3.8 MB for the 200-point grid).
     Rank 0 gets the full [nSet,nw2,nw2,6]; the others their partial."""
-    if dist is None or dist.get_world_size() == 1:
+    if comm is None or comm.world == 1:
         return qtf_fn(tables, Xi, beta, w2, k2, depth, rho, g, Mstruc, kay)
-    import torch
-    rank, world = dist.get_rank(), dist.get_world_size()
-    part = np.ascontiguousarray(qtf_fn(tables, Xi, beta, w2, k2, depth, rho, g, Mstruc, kay, rows=(rank, world)))
-    t = torch.as_tensor(part.view(np.float64)).to(_device_for(dist))
-    dist.reduce(t, dst=0, op=dist.ReduceOp.SUM)
-    return t.cpu().numpy().view(np.complex128) if rank == 0 else part
+    part = np.ascontiguousarray(qtf_fn(tables, Xi, beta, w2, k2, depth, rho, g, Mstruc, kay, rows=(comm.rank, comm.world)))
+    total = comm.reduce_sum(part)
+    return total if comm.rank == 0 else part
 
 
-def run_farm_sharded(sweep, ctx, n_unit, Cc=None, Mc=None, Bc=None, dist=None):
+def run_farm_sharded(sweep, ctx, n_unit, Cc=None, Mc=None, Bc=None, comm=None):
     """ONE farm (or a few) and many sea states -- SURVEY.md 8e C4: the CASES are block-partitioned over the ranks
     (every rank holds all units' tables: 54 KB for four VolturnUS-S), each rank runs ``Sweep.run_farm`` on its sea
     states, and the responses are gathered along the case axis onto rank 0.  No collective while solving."""
-    if dist is None or dist.get_world_size() == 1:
+    if comm is None or comm.world == 1:
         return sweep.run_farm(ctx, n_unit, Cc=Cc, Mc=Mc, Bc=Bc)
-    rank, world = dist.get_rank(), dist.get_world_size()
+    rank, world = comm.rank, comm.world
     lo, hi = shard_bounds(sweep.n_case, rank, world)
     local = sweep.take_cases(lo, hi).run_farm(ctx, n_unit, Cc=Cc, Mc=Mc, Bc=Bc)
-    counts = [shard_bounds(sweep.n_case, r, world)[1] - shard_bounds(sweep.n_case, r, world)[0] for r in range(world)]
+    counts = _counts(sweep.n_case, world)
     out = {}
     for key, v in local.items():                         # case axis is axis 1 of every array result
         if np.ndim(v) < 2:                               # kernel_ms etc.: per-rank scalars
             out[key] = v
             continue
-        g = gather_rows(np.ascontiguousarray(np.moveaxis(v, 1, 0)), counts, dist)
+        g = comm.gather_rows(np.ascontiguousarray(np.moveaxis(v, 1, 0)), counts)
         out[key] = None if g is None else np.moveaxis(g, 0, 1)
     return out if rank == 0 else local
 

@@ -1,6 +1,7 @@
-"""CPU suite: the C-ABI boundary (header <-> shared objects) and the multi-rank sweep driver
-(gloo, world_size 2).  No GPU compute: the HIP library is only loaded and its symbols checked;
-the sharded runs use the CPU oracle as the per-rank backend."""
+"""CPU suite: the C-ABI boundary (header <-> shared objects) and the multi-rank sweep drivers, world_size 2, over
+both host transports: torch.distributed gloo (tests/torch_comm.py) and the product's own TCP hub
+(raft_amd.comm.HostComm, the channel that also carries the RCCL unique id on the GPUs).  No GPU compute: the HIP
+library is only loaded and its symbols checked; the sharded runs use the CPU oracle as the per-rank backend."""
 import ctypes
 import os
 import re
@@ -38,6 +39,16 @@ def test_shared_objects_export_every_header_symbol(path, oracle_lib):
     lib.raftx_is_device.restype = ctypes.c_int
     assert lib.raftx_version() == 100
     assert lib.raftx_is_device() == (1 if path == HIP_SO else 0)
+
+
+def test_product_does_not_import_torch():
+    """PyTorch is plumbing of bench.py's launcher contract and of these tests only: nothing under raft_amd/ imports it
+    (the multi-GPU exchange steps are the library's own RCCL binding, raft_amd/comm.py)."""
+    pkg = os.path.join(ROOT, "raft_amd")
+    for fn in sorted(os.listdir(pkg)):
+        if fn.endswith(".py"):
+            src = open(os.path.join(pkg, fn)).read()
+            assert not re.search(r"^\s*(import torch|from torch)", src, flags=re.M), fn
 
 
 def test_product_fails_loudly_without_a_gpu():
@@ -84,38 +95,58 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _rank_main(rank, world, port, n, out_path):
-    import torch.distributed as dist
+TRANSPORTS = ["gloo", "host"]
+
+
+def _make_comm(kind, rank, world, port):
+    """world_size-2 communicator of the requested kind for a spawned rank process"""
+    if kind == "gloo":
+        import torch.distributed as dist
+        from tests.torch_comm import GlooComm
+        os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        return GlooComm(dist)
+    from raft_amd.comm import from_env
+    comm, how = from_env(None, prefer="host", environ={"RANK": str(rank), "WORLD_SIZE": str(world), "MASTER_ADDR": "127.0.0.1",
+                                                       "RAFTX_COMM_PORT": str(port)})
+    assert how == "host-tcp"
+    return comm
+
+
+def _rank_main(rank, world, port, n, out_path, kind):
     from raft_amd._abi import RaftxLib
-    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    comm = _make_comm(kind, rank, world, port)
     try:
         s, _ = _c3_sweep(n)
         cases = {"w": s.w, "k": s.k, "zeta": s.zeta, "beta": s.beta, "depth": s.depth} if rank == 0 else None
-        cases = sw.broadcast_cases(cases, dist, src=0)          # shared tables come from rank 0
+        cases = sw.broadcast_cases(cases, comm)                 # shared tables come from rank 0
         if rank != 0:                                            # prove the broadcast carried them
             s.w, s.k, s.zeta, s.beta = cases["w"], cases["k"], cases["zeta"], cases["beta"]
         ctx = RaftxLib(ORACLE_SO).context(0)
-        res = sw.run_sharded(s, ctx, dist)
+        res = sw.run_sharded(s, ctx, comm)
+        st = sw.run_stats_sharded(s, ctx, comm)
         ctx.close()
         if rank == 0:
-            np.savez(out_path, Xi=res["Xi"], niter=res["niter"], flags=res["flags"])
+            np.savez(out_path, Xi=res["Xi"], niter=res["niter"], flags=res["flags"], std=st["std"])
     finally:
-        dist.destroy_process_group()
+        comm.close()
 
 
-def test_two_rank_gloo_sweep_matches_single_process(tmp_path, oracle_lib):
-    """world_size 2 over gloo: broadcast of the case tables, design sharding, gather to rank 0 --
+@pytest.mark.parametrize("kind", TRANSPORTS)
+def test_two_rank_sweep_matches_single_process(tmp_path, oracle_lib, kind):
+    """world_size 2: broadcast of the case tables, design sharding, gather of responses and of statistics to rank 0 --
     bitwise identical to the single-process run, and equal to the live-reference vectors."""
     import torch.multiprocessing as mp
     n, world = 7, 2                      # odd count: ragged shards (4 + 3)
     out = str(tmp_path / "gathered.npz")
-    mp.spawn(_rank_main, args=(world, _free_port(), n, out), nprocs=world, join=True)
+    mp.spawn(_rank_main, args=(world, _free_port(), n, out, kind), nprocs=world, join=True)
     got = np.load(out)
     s, fx = _c3_sweep(n)
     ctx = oracle_lib.context(0)
     ref = s.run(ctx)
+    ref_std = s.run_stats(ctx)["std"]
     ctx.close()
+    assert np.array_equal(got["std"].view(np.uint64), ref_std.view(np.uint64))
     assert got["Xi"].shape == ref["Xi"].shape == (n, 1, 1, 6, s.nw)
     assert np.array_equal(got["Xi"].view(np.uint64), ref["Xi"].view(np.uint64))
     assert np.array_equal(got["niter"], ref["niter"]) and np.array_equal(got["flags"], ref["flags"])
@@ -141,29 +172,28 @@ def _geometry_sweep(n):
                             float(fx["XiStart"])), fx
 
 
-def _geom_rank_main(rank, world, port, n, out_path):
-    import torch.distributed as dist
+def _geom_rank_main(rank, world, port, n, out_path, kind):
     from raft_amd._abi import RaftxLib
-    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    comm = _make_comm(kind, rank, world, port)
     try:
         s, _ = _geometry_sweep(n)
         ctx = RaftxLib(ORACLE_SO).context(0)
-        res = sw.run_sharded(s, ctx, dist)
+        res = sw.run_sharded(s, ctx, comm)
         ctx.close()
         if rank == 0:
             np.savez(out_path, Xi=res["Xi"], niter=res["niter"])
     finally:
-        dist.destroy_process_group()
+        comm.close()
 
 
-def test_two_rank_gloo_geometry_sweep(tmp_path, oracle_lib):
+@pytest.mark.parametrize("kind", TRANSPORTS)
+def test_two_rank_geometry_sweep(tmp_path, oracle_lib, kind):
     """Designs given as member descriptions shard by design like packed ones: every rank generates its own block
     (no collective on the data path), rank 0 gathers; equal to the packed-table sweep and to the live reference."""
     import torch.multiprocessing as mp
     n, world = 5, 2
     out = str(tmp_path / "geom_gathered.npz")
-    mp.spawn(_geom_rank_main, args=(world, _free_port(), n, out), nprocs=world, join=True)
+    mp.spawn(_geom_rank_main, args=(world, _free_port(), n, out, kind), nprocs=world, join=True)
     got = np.load(out)
     s, fx = _geometry_sweep(n)
     assert s.take(1, 4).tables.n_design == 3 and s.take(1, 4).tables.station_off[0] == 0
@@ -208,72 +238,68 @@ def _numpy_qtf(t, X, b, w, k, h, rho, g, Ms, kay, rows=None):
     return q
 
 
-def _qtf_rank_main(rank, world, port, out_path):
-    import torch.distributed as dist
-    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+def _qtf_rank_main(rank, world, port, out_path, kind):
+    comm = _make_comm(kind, rank, world, port)
     try:
         tabs, Xi, beta, w2, k2, f = _qtf_sets()
         q = sw.run_qtf_sharded(_numpy_qtf, tabs, Xi, beta, w2, k2, f.depth, f.rho_water, f.g,
-                               np.array([f.M_struc] * len(tabs)), dist=dist)
+                               np.array([f.M_struc] * len(tabs)), comm=comm)
         if rank == 0:
             np.save(out_path, q)
     finally:
-        dist.destroy_process_group()
+        comm.close()
 
 
-def _qtf_rows_rank_main(rank, world, port, out_path):
-    import torch.distributed as dist
-    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+def _qtf_rows_rank_main(rank, world, port, out_path, kind):
+    comm = _make_comm(kind, rank, world, port)
     try:
         tabs, Xi, beta, w2, k2, f = _qtf_sets()
         q = sw.run_qtf_rows_sharded(_numpy_qtf, tabs[:1], Xi[:1], beta[:1], w2, k2, f.depth, f.rho_water, f.g,
-                                    np.array([f.M_struc]), dist=dist)
+                                    np.array([f.M_struc]), comm=comm)
         if rank == 0:
             np.save(out_path, q)
     finally:
-        dist.destroy_process_group()
+        comm.close()
 
 
-def test_two_rank_gloo_qtf_rows_of_one_matrix(tmp_path):
+@pytest.mark.parametrize("kind", TRANSPORTS)
+def test_two_rank_qtf_rows_of_one_matrix(tmp_path, kind):
     """ONE QTF split by interleaved rows over two ranks and summed onto rank 0."""
     import torch.multiprocessing as mp
     out = str(tmp_path / "qrows.npy")
-    mp.spawn(_qtf_rows_rank_main, args=(2, _free_port(), out), nprocs=2, join=True)
+    mp.spawn(_qtf_rows_rank_main, args=(2, _free_port(), out, kind), nprocs=2, join=True)
     got = np.load(out)
     tabs, Xi, beta, w2, k2, f = _qtf_sets()
     ref = _numpy_qtf(tabs[:1], Xi[:1], beta[:1], w2, k2, f.depth, f.rho_water, f.g, np.array([f.M_struc]), None)
     assert got.shape == ref.shape and np.array_equal(got.view(np.float64), ref.view(np.float64))
 
 
-def _farm_rank_main(rank, world, port, out_path):
-    import torch.distributed as dist
+def _farm_rank_main(rank, world, port, out_path, kind):
     from raft_amd import dropin
     from raft_amd._abi import RaftxLib
     from tests.util import load_model_fixture, case_from_fixture
-    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    comm = _make_comm(kind, rank, world, port)
     try:
         fx, model = load_model_fixture("c4_farm.npz")
         cases = [case_from_fixture(c) for c in fx["cases"][:2]]
         sweep = dropin.sweep_from_units(model, cases + cases[:1])            # 3 sea states: ragged 2 + 1
         ctx = RaftxLib(ORACLE_SO).context(0)
-        res = sw.run_farm_sharded(sweep, ctx, 4, Cc=fx["coupling_C"][None], dist=dist)
+        res = sw.run_farm_sharded(sweep, ctx, 4, Cc=fx["coupling_C"][None], comm=comm)
         ctx.close()
         if rank == 0:
             np.savez(out_path, Xi=res["Xi"], niter=res["niter"])
     finally:
-        dist.destroy_process_group()
+        comm.close()
 
 
-def test_two_rank_gloo_farm_cases(tmp_path):
+@pytest.mark.parametrize("kind", TRANSPORTS)
+def test_two_rank_farm_cases(tmp_path, kind):
     """ONE 4-unit farm, its sea states block-partitioned over two ranks and gathered along the case axis
     (SURVEY.md 8e, C4): equal to the live reference's coupled responses."""
     import torch.multiprocessing as mp
     from tests.util import load_model_fixture, group_rel_err
     out = str(tmp_path / "farm.npz")
-    mp.spawn(_farm_rank_main, args=(2, _free_port(), out), nprocs=2, join=True)
+    mp.spawn(_farm_rank_main, args=(2, _free_port(), out, kind), nprocs=2, join=True)
     got = np.load(out)
     fx, _ = load_model_fixture("c4_farm.npz")
     assert got["Xi"].shape[:2] == (1, 3) and got["niter"].shape == (4, 3)
@@ -284,11 +310,12 @@ def test_two_rank_gloo_farm_cases(tmp_path):
         assert [int(got["niter"][u, i]) for u in range(4)] == [int(c["units"][u]["niter"]) for u in range(4)]
 
 
-def test_two_rank_gloo_qtf_sets(tmp_path):
+@pytest.mark.parametrize("kind", TRANSPORTS)
+def test_two_rank_qtf_sets(tmp_path, kind):
     """QTF sets sharded over two ranks (2 + 1) and gathered: identical to the single-process batch."""
     import torch.multiprocessing as mp
     out = str(tmp_path / "q.npy")
-    mp.spawn(_qtf_rank_main, args=(2, _free_port(), out), nprocs=2, join=True)
+    mp.spawn(_qtf_rank_main, args=(2, _free_port(), out, kind), nprocs=2, join=True)
     got = np.load(out)
     tabs, Xi, beta, w2, k2, f = _qtf_sets()
     ref = _numpy_qtf(tabs, Xi, beta, w2, k2, f.depth, f.rho_water, f.g, np.array([f.M_struc] * 3), None)

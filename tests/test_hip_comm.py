@@ -1,0 +1,125 @@
+"""GPU suite for the multi-GPU exchange steps (include/raftx.h raftx_comm_*, raft_amd/comm.py).  The GPU box has ONE
+MI355X: the RCCL binding is exercised with a single-rank communicator (every entry point, real librccl calls), and the
+whole sharded driver with two processes sharing the GPU -- RCCL refuses two ranks on one device, so that run must land on
+the host transport AND say so."""
+import os
+import socket
+
+import numpy as np
+import pytest
+
+from raft_amd import sweep as sw
+from tests import standin
+
+pytestmark = pytest.mark.gpu
+
+
+def _c3_sweep(n):
+    fx = standin.load_fixture("c3_variants.npz")
+    off = fx["strip_offsets"]
+    return sw.Sweep(off[:n + 1], fx["strips"][:off[n]], fx["M0"][:n], fx["B0"][:n], fx["C0"][:n], fx["w"], fx["k"],
+                    fx["depth"], fx["zeta"][None], fx["beta"][None], int(fx["nIter"]), float(fx["XiStart"])), fx
+
+
+def test_single_rank_rccl_communicator_every_entry_point(hip_ctx):
+    uid = hip_ctx.comm_unique_id()
+    assert len(uid) == 128 and any(uid)
+    hip_ctx.comm_init(0, 1, uid)
+    try:
+        a = np.arange(12.0).reshape(3, 4)
+        assert np.array_equal(hip_ctx.comm_broadcast(a.copy(), 0), a)
+        rows = (np.arange(15.0).reshape(5, 3) + 1j * np.arange(15.0).reshape(5, 3)[::-1])
+        got = hip_ctx.comm_gather_rows(rows, [5], 0)
+        assert got.dtype == rows.dtype and np.array_equal(got, rows)
+        ints = np.arange(6, dtype=np.int32).reshape(6, 1)
+        assert np.array_equal(hip_ctx.comm_gather_rows(ints, [6], 0), ints)
+        s, _ = _c3_sweep(5)
+        s.solve(hip_ctx)
+        Xi = hip_ctx.fetch_results(want_Xi=True)["Xi"]
+        g = hip_ctx.comm_gather_xi([5], 0)
+        assert g.shape == (5, 1, 6, s.nw) and np.array_equal(g.view(np.uint64), Xi.reshape(g.shape).view(np.uint64))
+        pinned = hip_ctx.pinned_empty((5, 1, 6, s.nw))
+        hip_ctx.comm_gather_xi([5], 0, out=pinned)
+        assert np.array_equal(pinned.view(np.uint64), g.view(np.uint64))
+        hip_ctx.free_pinned(pinned)
+        b = np.linspace(0, 1, 1000)
+        assert np.array_equal(hip_ctx.comm_reduce_sum(b.copy(), 0), b)
+        from raft_amd._abi import RaftxError
+        with pytest.raises(RaftxError):
+            hip_ctx.comm_gather_xi([4], 0)                      # counts must match the resident batch
+        with pytest.raises(RaftxError):
+            hip_ctx.comm_init(0, 1, uid)                        # one communicator per ctx
+    finally:
+        hip_ctx.comm_destroy()
+    hip_ctx.comm_init(0, 1, hip_ctx.comm_unique_id())           # a ctx can be re-bound after destroy
+    hip_ctx.comm_destroy()
+
+
+def test_single_rank_rccl_comm_object_drives_the_sharded_sweep(hip_ctx, oracle_ctx):
+    """raft_amd.comm.RcclComm (world 1) through every driver call of raft_amd.sweep."""
+    from raft_amd.comm import HostComm, RcclComm
+    comm = RcclComm(hip_ctx, HostComm(0, 1))
+    try:
+        assert comm.kind == "rccl" and comm.world == 1
+        s, _ = _c3_sweep(6)
+        cases = comm.broadcast_arrays({"w": s.w, "zeta": s.zeta, "depth": s.depth})
+        assert np.array_equal(cases["w"], s.w) and cases["depth"] == s.depth
+        s.solve(hip_ctx)
+        Xi = comm.gather_xi(hip_ctx)
+        ref = s.run(oracle_ctx)
+        from tests.util import group_rel_err
+        assert group_rel_err(Xi.reshape(6, 6, s.nw), ref["Xi"].reshape(6, 6, s.nw)) < 1e-9
+        st = hip_ctx.motion_stats(float(s.w[1] - s.w[0]))[0]
+        assert np.array_equal(comm.gather_rows(st.reshape(6, 6)), st.reshape(6, 6))
+        q = np.arange(24.0).reshape(2, 3, 4) * (1 + 2j)
+        assert np.array_equal(comm.reduce_sum(q), q)
+    finally:
+        comm.close()
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _rank_main(rank, world, port, n, out_path):
+    from raft_amd import backend
+    from raft_amd.comm import from_env
+    ctx = backend.hip_library().context(0)                      # both ranks on the one GPU of the box
+    comm, how = from_env(ctx, prefer="rccl", environ={"RANK": str(rank), "WORLD_SIZE": str(world), "MASTER_ADDR": "127.0.0.1",
+                                                      "RAFTX_COMM_PORT": str(port)})
+    try:
+        s, _ = _c3_sweep(n)
+        res = sw.run_sharded(s, ctx, comm)
+        st = sw.run_stats_sharded(s, ctx, comm)
+        if rank == 0:
+            np.savez(out_path, Xi=res["Xi"], niter=res["niter"], std=st["std"], how=np.array(how))
+    finally:
+        comm.close()
+        ctx.close()
+
+
+def test_two_processes_on_one_gpu_shard_and_gather(tmp_path, hip_ctx):
+    """Two rank processes, one GPU: designs sharded 4 + 3, responses and statistics gathered on rank 0, bit-identical to
+    the single-process run.  from_env asks for RCCL; with both ranks on one device it reports what it used."""
+    import multiprocessing as mp
+    n = 7
+    out = str(tmp_path / "g.npz")
+    port = _free_port()
+    mpc = mp.get_context("spawn")
+    procs = [mpc.Process(target=_rank_main, args=(r, 2, port, n, out)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(300)
+        assert p.exitcode == 0
+    got = np.load(out)
+    how = str(got["how"])
+    assert how == "rccl" or how.startswith("host-tcp (RCCL unavailable"), how
+    print("two ranks on one GPU used:", how)
+    s, _ = _c3_sweep(n)
+    one = s.run(hip_ctx)
+    std = s.run_stats(hip_ctx)["std"]
+    assert np.array_equal(got["Xi"].view(np.uint64), one["Xi"].view(np.uint64))
+    assert np.array_equal(got["niter"], one["niter"]) and np.array_equal(got["std"].view(np.uint64), std.view(np.uint64))
