@@ -76,15 +76,21 @@ def make_sweep(ctx, n_design, rank=0, pinned=True):
     D = G.volturnus_sweep(base, scales).tables()
     t_desc = time.perf_counter() - t0
     if pinned:                                          # page-locked staging (raftx_host_alloc): full-rate, asynchronous H2D
-        for name in ("members", "stations", "caps"):
-            a = getattr(D, name)
-            if a.size:
-                b = ctx.pinned_empty(a.shape, dtype=np.float64)
+        for name in ("members", "stations", "caps", "member_off", "station_off", "cap_off"):
+            a = getattr(D, name, None)
+            if a is not None and a.size:
+                b = ctx.pinned_empty(a.shape, dtype=a.dtype)
                 b[...] = a
                 setattr(D, name, b)
     M0 = np.repeat(M_rna[None], n_design, axis=0)
     B0 = np.repeat(np.asarray(fx["B0"])[:1], n_design, axis=0)
     C0 = np.repeat(C_rest[None], n_design, axis=0)
+    if pinned:
+        def _pin(a):
+            b = ctx.pinned_empty(a.shape, dtype=np.float64)
+            b[...] = a
+            return b
+        M0, B0, C0 = _pin(M0), _pin(B0), _pin(C0)
     sw = GeometrySweep(D, M0, B0, C0, fx["w"], fx["k"], float(fx["depth"]), np.asarray(fx["zeta"])[None], np.asarray(fx["beta"])[None],
                        int(fx["nIter"]), float(fx["XiStart"]), tol=0.01, add_mask=G.ADD_MORISON | G.ADD_HYDROSTATIC | G.ADD_INERTIA)
     geo = {"designs": int(n_design), "members": int(D.member_off[-1]), "host_descriptor_ms": 1e3 * t_desc,

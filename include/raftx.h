@@ -361,14 +361,19 @@ int raftx_fetch_statics(raftx_ctx *ctx, double *A_morison, double *C_hydro, doub
 /* One whole SWEEP CROSSING in one call ("H2D of the tables + kernels + D2H"): member descriptions of
  * nDesign candidates in, response statistics (and optionally the responses) out -- raftx_build_designs +
  * raftx_upload_cases + raftx_solve_dynamics_device + raftx_motion_stats + raftx_fetch_results, with the designs cut
- * into nChunk contiguous blocks that nWorker internal streams (each with its own device buffers and memory pool, kept
- * for the life of ctx) take round-robin, so that the descriptor H2D and the table generation of one block overlap the
- * fixed-point kernel of another and the statistics D2H of a third.  What the reference does per candidate in
- * raft/parametersweep.py:39-100 / raft/omdao_raft.py:746-792 (build a Model, analyzeCases, read the statistics).
+ * into a few contiguous blocks (device buffers and memory pool per block, kept for the life of ctx) that one host thread
+ * drives over internal streams: the descriptor H2D of every block back to back on a copy stream, the member pass and
+ * the scans of a block on a preparation stream as soon as its descriptors have landed, and strip generation, the fused
+ * fixed point and the statistics of block 0, 1, 2, ... one after the other on the ctx stream (so the HIP events around
+ * each fixed-point launch time that launch alone); the responses, if asked for, follow on a download stream.  What the
+ * reference does per candidate in raft/parametersweep.py:39-100 / raft/omdao_raft.py:746-792 (build a Model,
+ * analyzeCases, read the statistics).
  * Descriptor arguments as raftx_build_designs (MBw not supported here; k doubles as the wave numbers of the
  * MacCamy-Fuchs table); sea-state arguments as raftx_upload_cases (rho_wave, g_wave scale the dynamic pressure:
  * the reference hard-wires 1025 / 9.81 there, raft_fowt.py:1857); nIter, tol, XiStart as raftx_solve_dynamics.
- * nChunk <= 0 / nWorker <= 0: library defaults.  Page-locked descriptor arrays (raftx_host_alloc) copy at full PCIe rate.
+ * nChunk > 0: that many equal blocks; nChunk <= 0: library default (a small first block that hides the descriptor upload
+ * of the rest, then growing ones).  nWorker is reserved (ignored).  Page-locked descriptor and M0/B0/C0 arrays
+ * (raftx_host_alloc) copy at full PCIe rate and without blocking the host; a page-locked Xi likewise.
  * Outputs: std [nDesign,nCase,6] (raftx_motion_stats; required), niter / flags [nDesign,nCase] (required),
  * Xi [nDesign,nCase,nHead,6,nw] or NULL, stripOffsets [nDesign+1] or NULL, timing_ms [4] or NULL
  * (wall, sum of generation kernels, sum of solve kernels, sum of statistics kernels).

@@ -11,8 +11,9 @@
 //                   (per-design totals, one-workgroup scan over designs, member offsets inside each design)
 //   k_geom_fill     one wavefront / member: lanes = strips; compacted with ballots into the design's strip table
 //   k_geom_mcf      (row, bin)            : MacCamy-Fuchs complex Cm table (Hankel functions)
-//   k_geom_design   one thread per design : run detection for the rotor recurrences (the same routine the host
-//                                           upload path uses), Morison added mass, hydrostatic reduction
+//   k_geom_reduce   thread per (design, role): member -> platform reduction of hydrostatics / weight stiffness / inertia
+//   k_geom_design   one wavefront / design: run detection for the rotor recurrences (the rules of the routine the host
+//                                           upload path uses), device strip records, Morison added mass
 //
 // The work is tiny next to the solve (a 10k-design sweep has ~110k members / ~530k strips); it exists to remove
 // the host packing and the 256 B/strip upload from the sweep's critical path, not to reach a roofline.
@@ -131,7 +132,8 @@ struct GeomArgs {
     const int64_t *capOff;       // [nMember+1] or null
     const double *caps;          // [nCap,RAFTX_GC_N]
     double *minert;              // [nMember,MI_N]
-    int *err;                    // first unsupported cap layout: (member+1), 0 = none
+    int *err;                    // [4] first unsupported cap layout (member+1) | ballast trim without ballast (design+1) |
+                                 //     bad member offsets (design+1) | bad member description (+-(member+1)); 0 = none
     double *Ms, *Cs, *Ws;        // [nDesign,36] [nDesign,36] [nDesign,6]
     const double *Fz;            // [nDesign] vertical mooring force for the ballast trim, or null
     double *drho;                // [nDesign] ballast density correction (RAFTX_TRIM_BALLAST)
@@ -150,6 +152,14 @@ struct GeomArgs {
     double *A, *Ch, *Wh, *props; // [nDesign,36] [nDesign,36] [nDesign,6] [nDesign,RAFTX_SP_N]
     double *M0, *C0;             // [nDesign,36] design matrices, updated in place per add_mask
     int add_mask;
+    long long *tot;              // [3] wet strips, MacCamy-Fuchs rows, strips of the largest design (zeroed before the scans)
+    // A block of a larger batch reads the batch's own offset arrays (uploaded once, shared by its blocks): the pointers
+    // are shifted to the block's first design / member and the bases make the values block-relative.
+    int64_t mbase, sbase, cbase;
+    int *mdesign_w;              // mdesign, writable (filled on the device by k_geom_mdesign)
+    __device__ int64_t mo(int d) const { return memberOff[d] - mbase; }
+    __device__ int64_t so(int64_t m) const { return stationOff[m] - sbase; }
+    __device__ int64_t co(int64_t m) const { return capOff[m] - cbase; }
 };
 
 #define GEOM_NOFMA _Pragma("clang fp contract(off)")
@@ -480,13 +490,36 @@ __device__ inline int geom_member_inertia(const double *gm, const double *gs, in
 }
 
 // one thread per member: pose, wet-strip count, hydrostatics and inertia about the member's own node
+// design of every member (thread per design); also rejects non-monotone member offsets (err[2] = design + 1)
+__global__ void k_geom_mdesign(GeomArgs A) {
+    const int d = blockIdx.x * blockDim.x + threadIdx.x;
+    if (d >= A.nDesign) return;
+    const int64_t m0 = A.mo(d), m1 = A.mo(d + 1);
+    if (m1 < m0 || m0 < 0 || m1 > A.nMember) {
+        atomicCAS(A.err + 2, 0, d + 1);
+        return;
+    }
+    for (int64_t m = m0; m < m1; m++) A.mdesign_w[m] = d;
+}
+#define GEOM_MAX_STATIONS 1024
 __global__ __launch_bounds__(128) void k_geom_member(GeomArgs A) {
     GEOM_NOFMA
     const int64_t m = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (m >= A.nMember) return;
     const double *gm = A.gm + (size_t)m * RAFTX_GM_N;
-    const double *gs = A.gs + (size_t)A.stationOff[m] * RAFTX_GS_N;
-    const int n = (int)(A.stationOff[m + 1] - A.stationOff[m]);
+    const double *gs = A.gs + (size_t)A.so(m) * RAFTX_GS_N;
+    const int n = (int)(A.so(m + 1) - A.so(m));
+    A.cnt[m] = 0;
+    A.cntm[m] = 0;
+    if (A.err[2]) return;                                 // member offsets rejected: mdesign is not valid
+    if (n < 2 || n > GEOM_MAX_STATIONS || !(gm[RAFTX_GM_DLSMAX] > 0.0) || !(gm[RAFTX_GM_L] > 0.0)) {
+        atomicCAS(A.err + 3, 0, (int)(m + 1));            // bad station count / dlsMax / length: the member is skipped
+        return;
+    }
+    if (((int)gm[RAFTX_GM_FLAGS] & RAFTX_GM_FLAG_MCF) && gm[RAFTX_GM_SHAPE] != 0.0 && !A.k) {
+        atomicCAS(A.err + 3, 0, -(int)(m + 1));           // MacCamy-Fuchs member without wave numbers
+        return;
+    }
     const int d = A.mdesign[m];
     double ps[6] = {0, 0, 0, 0, 0, 0};
     if (A.pose)
@@ -642,8 +675,8 @@ __global__ __launch_bounds__(128) void k_geom_member(GeomArgs A) {
     for (int i = 0; i < 36; i++) mh[i] = C[i];
     for (int i = 0; i < 6; i++) mh[36 + i] = F[i];
     mh[42] = Vt; mh[43] = rcV[0]; mh[44] = rcV[1]; mh[45] = rcV[2]; mh[46] = AWPm; mh[47] = 0.0;
-    const int ncap = A.capOff ? (int)(A.capOff[m + 1] - A.capOff[m]) : 0;
-    const double *gc = A.capOff ? A.caps + (size_t)A.capOff[m] * RAFTX_GC_N : nullptr;
+    const int ncap = A.capOff ? (int)(A.co(m + 1) - A.co(m)) : 0;
+    const double *gc = A.capOff ? A.caps + (size_t)A.co(m) * RAFTX_GC_N : nullptr;
     const int code = geom_member_inertia(gm, gs, n, gc, ncap, rA, q, p1, p2, A.g, (A.add_mask & RAFTX_TRIM_BALLAST) != 0, 0.0, mi);
     if (code) {
         for (int i = 0; i < MI_N; i++) mi[i] = 0.0;
@@ -655,10 +688,11 @@ __global__ __launch_bounds__(128) void k_geom_member(GeomArgs A) {
 // density correction of all ballasted sections
 __global__ void k_geom_trim(GeomArgs A) {
     GEOM_NOFMA
+    if (A.err[2] | A.err[3]) return;                      // rejected descriptors: phase 2 reports them
     const int d = blockIdx.x * blockDim.x + threadIdx.x;
     if (d >= A.nDesign) return;
     double mass = A.M0[(size_t)d * 36], V = 0.0, vol = 0.0;
-    for (int64_t m = A.memberOff[d]; m < A.memberOff[d + 1]; m++) {
+    for (int64_t m = A.mo(d); m < A.mo(d + 1); m++) {
         mass += A.minert[(size_t)m * MI_N + 36];
         vol += A.minert[(size_t)m * MI_N + 47];
         V += A.mhyd[(size_t)m * MH_N + 42];
@@ -674,15 +708,16 @@ __global__ void k_geom_trim(GeomArgs A) {
 // ... and the statics recomputed with the corrected densities (:1820), one thread per member
 __global__ __launch_bounds__(128) void k_geom_reinertia(GeomArgs A) {
     GEOM_NOFMA
+    if (A.err[2] | A.err[3]) return;                      // rejected descriptors: phase 2 reports them
     const int64_t m = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (m >= A.nMember) return;
     const double *gm = A.gm + (size_t)m * RAFTX_GM_N;
     if ((int)gm[RAFTX_GM_FLAGS] & RAFTX_GM_FLAG_NOSTATIC) return;
-    const double *gs = A.gs + (size_t)A.stationOff[m] * RAFTX_GS_N;
-    const int n = (int)(A.stationOff[m + 1] - A.stationOff[m]);
+    const double *gs = A.gs + (size_t)A.so(m) * RAFTX_GS_N;
+    const int n = (int)(A.so(m + 1) - A.so(m));
     const double *mp = A.mpose + (size_t)m * MP_N;
-    const int ncap = A.capOff ? (int)(A.capOff[m + 1] - A.capOff[m]) : 0;
-    const double *gc = A.capOff ? A.caps + (size_t)A.capOff[m] * RAFTX_GC_N : nullptr;
+    const int ncap = A.capOff ? (int)(A.co(m + 1) - A.co(m)) : 0;
+    const double *gc = A.capOff ? A.caps + (size_t)A.co(m) * RAFTX_GC_N : nullptr;
     double *mi = A.minert + (size_t)m * MI_N;
     if (geom_member_inertia(gm, gs, n, gc, ncap, mp + 3, mp + 6, mp + 9, mp + 12, A.g, true, A.drho[A.mdesign[m]], mi))
         for (int i = 0; i < MI_N; i++) mi[i] = 0.0;
@@ -692,12 +727,14 @@ __global__ __launch_bounds__(128) void k_geom_reinertia(GeomArgs A) {
 // totals (thread per design), a scan over the DESIGNS (one workgroup; 10^4 entries instead of 10^5 members), and the
 // member offsets inside every design (thread per design).
 __global__ void k_geom_design_counts(GeomArgs A) {
+    if (A.err[2] | A.err[3]) return;                      // rejected descriptors: phase 2 reports them
     const int d = blockIdx.x * blockDim.x + threadIdx.x;
     if (d >= A.nDesign) return;
     long long a = 0, b = 0;
-    for (int64_t m = A.memberOff[d]; m < A.memberOff[d + 1]; m++) { a += A.cnt[m]; b += A.cntm[m]; }
+    for (int64_t m = A.mo(d); m < A.mo(d + 1); m++) { a += A.cnt[m]; b += A.cntm[m]; }
     A.off[d + 1] = a;                                    // totals parked one slot up; k_geom_scan turns them into offsets
     A.cmoff[d + 1] = b;
+    atomicMax(reinterpret_cast<unsigned long long *>(A.tot + 2), (unsigned long long)a);
 }
 __global__ __launch_bounds__(1024) void k_geom_scan(GeomArgs A) {
     __shared__ long long part[2][1024];
@@ -717,6 +754,8 @@ __global__ __launch_bounds__(1024) void k_geom_scan(GeomArgs A) {
         }
         A.off[0] = 0;
         A.cmoff[0] = 0;
+        A.tot[0] = sa;
+        A.tot[1] = sb;
     }
     __syncthreads();
     a = part[0][t]; b = part[1][t];
@@ -727,24 +766,25 @@ __global__ __launch_bounds__(1024) void k_geom_scan(GeomArgs A) {
 }
 // member offsets from the design offsets
 __global__ void k_geom_offsets(GeomArgs A) {
+    if (A.err[2] | A.err[3]) return;                      // rejected descriptors: phase 2 reports them
     const int d = blockIdx.x * blockDim.x + threadIdx.x;
     if (d >= A.nDesign) return;
     int64_t a = A.off[d], b = A.cmoff[d];
-    for (int64_t m = A.memberOff[d]; m < A.memberOff[d + 1]; m++) {
+    for (int64_t m = A.mo(d); m < A.mo(d + 1); m++) {
         A.soff[m] = a; A.cmsoff[m] = b;
         a += A.cnt[m]; b += A.cntm[m];
     }
     if (d == A.nDesign - 1) { A.soff[A.nMember] = a; A.cmsoff[A.nMember] = b; }
 }
 
-// one wavefront per member: lanes = strips of a group; wet strips are compacted with ballots
+// one wavefront per member: lanes = the member's strips in order; wet strips are compacted with ballots
 __global__ __launch_bounds__(64) void k_geom_fill(GeomArgs A) {
     GEOM_NOFMA
     const int64_t m = blockIdx.x;
     const int lane = threadIdx.x;
     const double *gm = A.gm + (size_t)m * RAFTX_GM_N;
-    const double *gs = A.gs + (size_t)A.stationOff[m] * RAFTX_GS_N;
-    const int n = (int)(A.stationOff[m + 1] - A.stationOff[m]);
+    const double *gs = A.gs + (size_t)A.so(m) * RAFTX_GS_N;
+    const int n = (int)(A.so(m + 1) - A.so(m));
     const int d = A.mdesign[m];
     const double *mp = A.mpose + (size_t)m * MP_N;
     const bool circ = gm[RAFTX_GM_SHAPE] != 0.0;
@@ -761,21 +801,38 @@ __global__ __launch_bounds__(64) void k_geom_fill(GeomArgs A) {
     }
     const double armN[3] = {rA[0] - rP[0], rA[1] - rP[1], rA[2] - rP[2]};
     const int64_t out0 = A.soff[m];
-    const int64_t cmrow0 = A.cmsoff[m], cmbase = A.cmsoff[A.memberOff[d]];
-    const int64_t mlocal = m - A.memberOff[d];
+    const int64_t cmrow0 = A.cmsoff[m], cmbase = A.cmsoff[A.mo(d)];
+    const int64_t mlocal = m - A.mo(d);
     const double rho = A.rho, cdrag = sqrt(8 / M_PI);
-    int nwet = 0, il0 = 0;
-    for (int g = 0; g <= n; g++) {
-        int cntg = 1, nsub = 1;
-        if (g > 0 && g < n) {
+    // strips of the member in order: group g = 0 and g = n are the end plates (one strip each), 0 < g < n the station
+    // intervals (geom_interval_strips sub-strips each).  Lanes take the flattened (group, sub-strip) list 64 at a time.
+    __shared__ int cum[GEOM_MAX_STATIONS + 2];
+    int nwet = 0;
+    for (int g = lane; g <= n; g += 64) {
+        int cntg = 1;
+        if (g > 0 && g < n)
             cntg = geom_interval_strips(gs[(size_t)g * RAFTX_GS_N + RAFTX_GS_S] - gs[(size_t)(g - 1) * RAFTX_GS_N + RAFTX_GS_S],
                                         gm[RAFTX_GM_DLSMAX]);
-            nsub = cntg;
-        }
-        for (int j0 = 0; j0 < cntg; j0 += 64) {
-            const int j = j0 + lane;
-            const bool act = j < cntg;
-            GStrip s = geom_strip(gs, n, g, act ? j : 0, nsub, circ);
+        cum[g + 1] = cntg;
+    }
+    __syncthreads();
+    if (lane == 0) {
+        int a = 0;
+        cum[0] = 0;
+        for (int g = 0; g <= n; g++) { a += cum[g + 1]; cum[g + 1] = a; }
+    }
+    __syncthreads();
+    const int total = cum[n + 1];
+    for (int t0 = 0; t0 < total; t0 += 64) {
+        {                                               // (block kept: the strip code below is shared with the oracle's layout)
+            const int t = t0 + lane;
+            const bool act = t < total;
+            const int tt = act ? t : 0;
+            int g = 0;
+            while (g < n && cum[g + 1] <= tt) g++;
+            const int j = tt - cum[g];
+            const int nsub = (g > 0 && g < n) ? cum[g + 1] - cum[g] : 1;
+            GStrip s = geom_strip(gs, n, g, j, nsub, circ);
             double r[3];
             for (int c = 0; c < 3; c++) r[c] = geom_along(rA[c], rB[c], s.ls, L);
             const bool wet = act && (r[2] < 0);
@@ -795,7 +852,7 @@ __global__ __launch_bounds__(64) void k_geom_fill(GeomArgs A) {
             rec[RAFTX_F_CIRC] = circ ? 1.0 : 0.0;
             rec[RAFTX_F_MCF] = -1.0;
             rec[26] = (double)mlocal;
-            rec[27] = (double)(il0 + j);
+            rec[27] = (double)t;
             const double ds0 = s.ds0, ds1 = s.ds1, dr0 = s.drs0, dr1 = s.drs1, dls = s.dls;
             if (!potMod) {
                 double v_i, v_end, a_i;
@@ -839,7 +896,6 @@ __global__ __launch_bounds__(64) void k_geom_fill(GeomArgs A) {
             rec[RAFTX_F_DP2] = cdrag * 0.5 * rho * a_p2 * geom_interp(s.ls, gs, n, RAFTX_GS_CD + 2);
             rec[RAFTX_F_DEND] = cdrag * 0.5 * rho * a_end * geom_interp(s.ls, gs, n, RAFTX_GS_CD + 3);
         }
-        il0 += cntg;
     }
 }
 
@@ -918,84 +974,236 @@ __device__ inline void geom_reduce_vector(const double *W, const double (&a)[3],
     }
 }
 
-// one thread per design: device strip records + run flags, Morison added mass, hydrostatic and inertia reduction
+// The per-design step after the strip records exist (it used to be one thread per design: 0.6-0.9 ms of latency for
+// 10 k designs).  Every sum keeps the order of that serial form (and of the oracle), so the tables and statics are
+// bit-identical to it.
+//   k_geom_reduce   thread per (design, role): member -> platform reduction of hydrostatics | weight stiffness | inertia
+//   k_geom_design   one wavefront per design; the design's ABI strip records are staged in LDS (coalesced reads), then
+//                   run flags (lane per strip), device strip records (lanes over (strip, field): coalesced 256 B rows),
+//                   Morison added mass (lane per matrix entry, strips in table order, LDS broadcasts) and the updates
+//                   of the design matrices M0 / C0 (add_mask)
+// Field j of a device strip record comes from ABI field DS_SRC[j] (-1: zero, -2 - c: unit step x q_c)
+__device__ constexpr int DS_SRC[DS_N] = {
+    -1, -1, RAFTX_F_MCF, -1,
+    RAFTX_F_X, RAFTX_F_X + 1, RAFTX_F_X + 2,
+    -2, -3, -4,
+    RAFTX_F_AX, RAFTX_F_AX + 1, RAFTX_F_AX + 2,
+    RAFTX_F_Q, RAFTX_F_Q + 1, RAFTX_F_Q + 2,
+    RAFTX_F_P1, RAFTX_F_P1 + 1, RAFTX_F_P1 + 2,
+    RAFTX_F_P2, RAFTX_F_P2 + 1, RAFTX_F_P2 + 2,
+    RAFTX_F_IQ, RAFTX_F_IP1, RAFTX_F_IP2, RAFTX_F_AI, RAFTX_F_RHOV,
+    RAFTX_F_DQ, RAFTX_F_DP1, RAFTX_F_DP2, RAFTX_F_DEND, -1};
+static_assert(DS_MCF == 2 && DS_X == 4 && DS_U == 7 && DS_A == 10 && DS_Q == 13 && DS_P1 == 16 && DS_P2 == 19 &&
+              DS_IQ == 22 && DS_DQ == 27 && DS_N == 32, "DS_SRC follows the device record layout");
+#define GD_ROW (NF + 1)      // LDS row stride of a staged record (odd: lane-per-strip column reads are conflict-free)
 __global__ __launch_bounds__(64) void k_geom_design(GeomArgs A) {
     GEOM_NOFMA
-    const int d = blockIdx.x * blockDim.x + threadIdx.x;
+    extern __shared__ double gd_lds[];
+    const int d = blockIdx.x, lane = threadIdx.x;
     if (d >= A.nDesign) return;
     const int64_t i0 = A.off[d], i1 = A.off[d + 1];
-    derive_design_tables(A.abi, i0, i1, A.ds, A.dsi);
-    // ---- A_hydro_morison (raft_member.py:1333-1361 + helpers.py:537-560, raft_fowt.py:1625): every strip adds
-    // c_n g g^T with g = [n ; arm x n] for its three directions n = p1, p2, q
-    double Am[36];
-    for (int i = 0; i < 36; i++) Am[i] = 0.0;
-    for (int64_t s = i0; s < i1; s++) {
-        const double *rec = A.abi + (size_t)s * NF;
-        const double ax = rec[RAFTX_F_AX], ay = rec[RAFTX_F_AX + 1], az = rec[RAFTX_F_AX + 2];
-        const double cs[3] = {rec[RAFTX_F_AP1], rec[RAFTX_F_AP2], rec[RAFTX_F_IQ]};
-        const int fs[3] = {RAFTX_F_P1, RAFTX_F_P2, RAFTX_F_Q};
-        for (int t = 0; t < 3; t++) {
-            const double nx = rec[fs[t]], ny = rec[fs[t] + 1], nz = rec[fs[t] + 2];
-            const double g6[6] = {nx, ny, nz, ay * nz - az * ny, az * nx - ax * nz, ax * ny - ay * nx};
-            for (int i = 0; i < 6; i++)
-                for (int j = 0; j < 6; j++) Am[i * 6 + j] += cs[t] * g6[i] * g6[j];
+    const int S = (int)(i1 - i0);
+    double *rec = gd_lds;                                 // [S][GD_ROW]
+    double *pjv = rec + (size_t)S * GD_ROW, *unv = pjv + S;
+    int *okv = reinterpret_cast<int *>(unv + S), *rsv = okv + S, *mfl = rsv + S;
+    const double *src = A.abi + (size_t)i0 * NF;
+    for (int t = lane; t < S * NF; t += 64) rec[(t / NF) * GD_ROW + (t % NF)] = src[t];
+    __syncthreads();
+    // ---- run detection (derive_design_tables, same expressions and order; see there for the rules)
+    for (int t = lane; t < S; t += 64) {
+        bool pass = false;
+        double pj = 0.0;
+        if (t > 0) {
+            const double *pr = rec + (size_t)(t - 1) * GD_ROW, *cr = rec + (size_t)t * GD_ROW;
+            bool same = true;
+            double dv[3];
+            for (int j = 0; j < 3; j++) {
+                same = same && (pr[RAFTX_F_Q + j] == cr[RAFTX_F_Q + j]);
+                dv[j] = cr[RAFTX_F_X + j] - pr[RAFTX_F_X + j];
+                pj += dv[j] * cr[RAFTX_F_Q + j];
+            }
+            if (same && (pj > 0.0) && (fabs(pj) <= 1.797e308)) {
+                double perp2 = 0.0, scale = 1.0;
+                for (int j = 0; j < 3; j++) {
+                    double tt = dv[j] - pj * cr[RAFTX_F_Q + j];
+                    perp2 += tt * tt;
+                    scale += fabs(cr[RAFTX_F_X + j]);
+                }
+                pass = !(sqrt(perp2) > 1e-10 * scale);
+            }
+        }
+        okv[t] = pass ? 1 : 0;
+        pjv[t] = pj;
+    }
+    __syncthreads();
+    if (lane == 0) {                                      // pair tests -> runs: 64-strip cap, smallest step of the run
+        int s = 0;
+        double unit = 0.0;
+        for (int t = 0; t < S; t++) {
+            if (t == 0 || !okv[t] || (t - s) >= 64) {
+                if (t > 0) unv[s] = unit;
+                s = t;
+                unit = 0.0;
+            } else {
+                const double pj = pjv[t];
+                unit = (unit == 0.0 || pj < unit) ? pj : unit;
+            }
+            rsv[t] = s;
+        }
+        if (S > 0) unv[s] = unit;
+    }
+    __syncthreads();
+    for (int t = lane; t < S; t += 64) {
+        const int s = rsv[t];
+        const double unit = unv[s];
+        const double *cr = rec + (size_t)t * GD_ROW;
+        int m = 0;
+        if (t > s && unit > 0.0) {
+            double ratio = pjv[t] / unit;
+            int mi = (int)floor(ratio + 0.5);
+            if (mi >= 1 && mi <= 2 && fabs(ratio - mi) < 1e-9) {
+                const double *pr = cr - GD_ROW;
+                bool ok = true;
+                for (int j = 0; j < 3; j++) {
+                    double pred = pr[RAFTX_F_X + j] + (double)mi * unit * cr[RAFTX_F_Q + j];
+                    if (fabs(pred - cr[RAFTX_F_X + j]) > 1e-10 * (1.0 + fabs(cr[RAFTX_F_X + j]))) ok = false;
+                }
+                if (ok) m = mi;
+            }
+        }
+        if (m != 0) {
+            const double *pr = cr - GD_ROW;
+            for (int j = 0; j < 3; j++)
+                if (pr[RAFTX_F_P1 + j] != cr[RAFTX_F_P1 + j] || pr[RAFTX_F_P2 + j] != cr[RAFTX_F_P2 + j]) m = 0;
+            if ((pr[RAFTX_F_CIRC] != 0.0) != (cr[RAFTX_F_CIRC] != 0.0)) m = 0;
+            for (int j = 0; j < 3; j++) {
+                const double da = cr[RAFTX_F_AX + j] - pr[RAFTX_F_AX + j], dx = cr[RAFTX_F_X + j] - pr[RAFTX_F_X + j];
+                if (!(fabs(da - dx) <= 1e-9 * (1.0 + fabs(cr[RAFTX_F_X + j]) + fabs(cr[RAFTX_F_AX + j])))) m = 0;
+            }
+        }
+        int fl = m | (cr[RAFTX_F_CIRC] != 0.0 ? DSI_CIRC : 0);
+        if (fabs(cr[RAFTX_F_P1]) < 1e-15 && fabs(cr[RAFTX_F_P1 + 1]) < 1e-15 && fabs(cr[RAFTX_F_P2 + 2]) < 1e-15) fl |= DSI_AXAL;
+        A.dsi[(size_t)i0 + t] = fl;
+    }
+    // ---- device strip records, one 256 B row per strip, written by consecutive lanes (a lane keeps its field)
+    {
+        double *dso = A.ds + (size_t)i0 * DS_N;
+        const int j = lane % DS_N, f = DS_SRC[j];
+        for (int t = lane; t < S * DS_N; t += 64) {
+            const int i = t / DS_N;
+            const double *cr = rec + (size_t)i * GD_ROW;
+            double v = 0.0;
+            if (f >= 0) v = cr[f];
+            else if (f <= -2) v = unv[rsv[i]] * cr[RAFTX_F_Q + (-2 - f)];
+            dso[t] = v;
         }
     }
-    // ---- hydrostatics: T^T C T + the geometric stiffness of the varying T, symmetrised (raft_fowt.py:1122,1181-1199)
-    double Ch[36], Wh[6] = {0, 0, 0, 0, 0, 0}, Vt = 0.0, AWPt = 0.0, sVr[3] = {0, 0, 0};
-    for (int i = 0; i < 36; i++) Ch[i] = 0.0;
+    // ---- A_hydro_morison (raft_member.py:1333-1361 + helpers.py:537-560, raft_fowt.py:1625): every strip adds
+    // c_n g g^T with g = [n ; arm x n] for its three directions n = p1, p2, q.  The 3 x (c, g) of every strip are formed
+    // once (lane per strip) and parked over the staged records; lane (i, j) then sums c g_i g_j over the strips in order.
+    constexpr int GV = 21;                                // doubles per strip: 3 x (c, g[6])
+    for (int t0 = 0; t0 < S; t0 += 64) {
+        const int t = t0 + lane;
+        double gv[GV];
+        if (t < S) {
+            const double *cr = rec + (size_t)t * GD_ROW;
+            const double ax = cr[RAFTX_F_AX], ay = cr[RAFTX_F_AX + 1], az = cr[RAFTX_F_AX + 2];
+            const double cs[3] = {cr[RAFTX_F_AP1], cr[RAFTX_F_AP2], cr[RAFTX_F_IQ]};
+            const int fs[3] = {RAFTX_F_P1, RAFTX_F_P2, RAFTX_F_Q};
+            for (int tt = 0; tt < 3; tt++) {
+                const double nx = cr[fs[tt]], ny = cr[fs[tt] + 1], nz = cr[fs[tt] + 2];
+                gv[tt * 7] = cs[tt];
+                gv[tt * 7 + 1] = nx; gv[tt * 7 + 2] = ny; gv[tt * 7 + 3] = nz;
+                gv[tt * 7 + 4] = ay * nz - az * ny;
+                gv[tt * 7 + 5] = az * nx - ax * nz;
+                gv[tt * 7 + 6] = ax * ny - ay * nx;
+            }
+        }
+        __syncthreads();                                  // every record of this round is in registers (and the emission is done)
+        if (t < S)
+            for (int e = 0; e < GV; e++) rec[(size_t)t * GV + e] = gv[e];
+    }
+    __syncthreads();
+    if (lane < 36) {
+        const int i = lane / 6, j = lane % 6;
+        double am = 0.0;
+        for (int s = 0; s < S; s++) {
+            const double *g = rec + (size_t)s * GV;
+            for (int tt = 0; tt < 3; tt++) am += g[tt * 7] * g[tt * 7 + 1 + i] * g[tt * 7 + 1 + j];
+        }
+        const size_t o = (size_t)d * 36 + lane;
+        A.A[o] = am;
+        if (A.add_mask & RAFTX_ADD_MORISON) A.M0[o] += am;
+        if (A.add_mask & RAFTX_ADD_HYDROSTATIC) A.C0[o] += A.Ch[o];
+        if (A.add_mask & RAFTX_ADD_INERTIA) { A.M0[o] += A.Ms[o]; A.C0[o] += A.Cs[o]; }
+    }
+    (void)mfl;
+}
+// dynamic LDS of k_geom_design for designs of up to maxS strips
+static size_t geom_design_lds(int maxS) {
+    const size_t S = (size_t)(maxS > 0 ? maxS : 1);
+    return sizeof(double) * (S * GD_ROW + 2 * S) + sizeof(int) * 3 * S + 16;
+}
+
+__global__ __launch_bounds__(64) void k_geom_reduce(GeomArgs A) {
+    GEOM_NOFMA
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    const int d = t / 3, role = t % 3;        // 0: C_hydro, W_hydro, V, AWP, rCB;  1: C_struc, W_struc;  2: M_struc, mass, rCG
+    if (d >= A.nDesign) return;
+    // ---- hydrostatics: T^T C T + the geometric stiffness of the varying T, symmetrised (raft_fowt.py:1122,1181-1199);
+    // weight stiffness and inertia of the members the same way (raft_fowt.py:876-900)
     double th[3] = {0, 0, 0}, rP[3] = {0, 0, 0};
     if (A.pose)
         for (int i = 0; i < 3; i++) { rP[i] = A.pose[(size_t)d * 6 + i]; th[i] = A.pose[(size_t)d * 6 + 3 + i]; }
-    double Ms[36], Cs[36], Ws[6] = {0, 0, 0, 0, 0, 0}, sMr[3] = {0, 0, 0};
-    for (int i = 0; i < 36; i++) { Ms[i] = 0.0; Cs[i] = 0.0; }
-    for (int64_t m = A.memberOff[d]; m < A.memberOff[d + 1]; m++) {
+    double out[36], Wv[6] = {0, 0, 0, 0, 0, 0}, sc0 = 0.0, sc1 = 0.0, sr[3] = {0, 0, 0};
+    for (int i = 0; i < 36; i++) out[i] = 0.0;
+    for (int64_t m = A.mo(d); m < A.mo(d + 1); m++) {
         const double *mp = A.mpose + (size_t)m * MP_N, *mh = A.mhyd + (size_t)m * MH_N, *mi = A.minert + (size_t)m * MI_N;
         const double a[3] = {mp[3] - rP[0], mp[4] - rP[1], mp[5] - rP[2]};
-        geom_reduce_matrix(mh, a, Ch);
-        geom_reduce_vector(mh + 36, a, mp, th, Wh, Ch);
-        geom_reduce_matrix(mi, a, Ms);
-        {   // weight stiffness of the member about its node: C[3,3] = C[4,4] = -m g dR_z (helpers.py:1076-1078)
-            double Cm[36];
-            for (int i = 0; i < 36; i++) Cm[i] = 0.0;
-            Cm[3 * 6 + 3] = Cm[4 * 6 + 4] = mi[46];
-            geom_reduce_matrix(Cm, a, Cs);
+        double C[36];
+        if (role == 1) {                      // weight stiffness of the member about its node: C[3,3] = C[4,4] = -m g dR_z (helpers.py:1076-1078)
+            for (int i = 0; i < 36; i++) C[i] = 0.0;
+            C[3 * 6 + 3] = C[4 * 6 + 4] = mi[46];
+        } else {
+            const double *src = role == 0 ? mh : mi;
+            for (int i = 0; i < 36; i++) C[i] = src[i];
         }
-        geom_reduce_vector(mi + 40, a, mp, th, Ws, Cs);
-        for (int c = 0; c < 3; c++) sMr[c] += ((mi[37 + c] - mp[3 + c]) + mp[c]) * mi[36];        // raft_fowt.py:902-903
-        const double V = mh[42];
-        Vt += V;
-        AWPt += mh[46];
-        if (V > 0)
-            for (int c = 0; c < 3; c++) sVr[c] += ((mh[43 + c] / V - mp[3 + c]) + mp[c]) * V;   // raft_member.py:1006, raft_fowt.py:938
+        geom_reduce_matrix(C, a, out);
+        if (role < 2) {
+            const double *W = role == 0 ? mh + 36 : mi + 40;
+            geom_reduce_vector(W, a, mp, th, Wv, out);
+        }
+        if (role == 2) {
+            for (int c = 0; c < 3; c++) sr[c] += ((mi[37 + c] - mp[3 + c]) + mp[c]) * mi[36];        // raft_fowt.py:902-903
+            sc0 += mi[47];                                                                              // ballast volume
+        } else if (role == 0) {
+            const double V = mh[42];
+            sc0 += V;
+            sc1 += mh[46];
+            if (V > 0)
+                for (int c = 0; c < 3; c++) sr[c] += ((mh[43 + c] / V - mp[3 + c]) + mp[c]) * V;      // raft_member.py:1006, raft_fowt.py:938
+        }
     }
     for (int i = 0; i < 6; i++)
         for (int j = i + 1; j < 6; j++) {
-            const double s = (Ch[i * 6 + j] + Ch[j * 6 + i]) / 2, sm = (Ms[i * 6 + j] + Ms[j * 6 + i]) / 2,
-                         sc = (Cs[i * 6 + j] + Cs[j * 6 + i]) / 2;
-            Ch[i * 6 + j] = Ch[j * 6 + i] = s;
-            Ms[i * 6 + j] = Ms[j * 6 + i] = sm;
-            Cs[i * 6 + j] = Cs[j * 6 + i] = sc;
+            const double s = (out[i * 6 + j] + out[j * 6 + i]) / 2;
+            out[i * 6 + j] = out[j * 6 + i] = s;
         }
-    for (int i = 0; i < 36; i++) {
-        A.A[(size_t)d * 36 + i] = Am[i];
-        A.Ch[(size_t)d * 36 + i] = Ch[i];
-        A.Ms[(size_t)d * 36 + i] = Ms[i];
-        A.Cs[(size_t)d * 36 + i] = Cs[i];
-        if (A.add_mask & RAFTX_ADD_MORISON) A.M0[(size_t)d * 36 + i] += Am[i];
-        if (A.add_mask & RAFTX_ADD_HYDROSTATIC) A.C0[(size_t)d * 36 + i] += Ch[i];
-        if (A.add_mask & RAFTX_ADD_INERTIA) { A.M0[(size_t)d * 36 + i] += Ms[i]; A.C0[(size_t)d * 36 + i] += Cs[i]; }
-    }
-    for (int i = 0; i < 6; i++) { A.Wh[(size_t)d * 6 + i] = Wh[i]; A.Ws[(size_t)d * 6 + i] = Ws[i]; }
+    double *dst = (role == 0 ? A.Ch : role == 1 ? A.Cs : A.Ms) + (size_t)d * 36;
+    for (int i = 0; i < 36; i++) dst[i] = out[i];
     double *pr = A.props + (size_t)d * RAFTX_SP_N;
-    for (int i = 0; i < RAFTX_SP_N; i++) pr[i] = 0.0;
-    double vfill = 0.0;
-    for (int64_t m = A.memberOff[d]; m < A.memberOff[d + 1]; m++) vfill += A.minert[(size_t)m * MI_N + 47];
-    pr[RAFTX_SP_VFILL] = vfill;
-    pr[RAFTX_SP_DRHO] = (A.add_mask & RAFTX_TRIM_BALLAST) ? A.drho[d] : 0.0;
-    pr[RAFTX_SP_V] = Vt;
-    pr[RAFTX_SP_MASS] = Ms[0];                                                            // raft_fowt.py:1206-1207
-    for (int c = 0; c < 3; c++) pr[RAFTX_SP_RCG + c] = Ms[0] != 0.0 ? sMr[c] / Ms[0] : 0.0;
-    pr[RAFTX_SP_AWP] = AWPt;
-    for (int c = 0; c < 3; c++) pr[RAFTX_SP_RCB + c] = Vt != 0.0 ? sVr[c] / Vt : 0.0;
+    if (role == 0) {
+        for (int i = 0; i < 6; i++) A.Wh[(size_t)d * 6 + i] = Wv[i];
+        pr[RAFTX_SP_V] = sc0;
+        pr[RAFTX_SP_AWP] = sc1;
+        for (int c = 0; c < 3; c++) pr[RAFTX_SP_RCB + c] = sc0 != 0.0 ? sr[c] / sc0 : 0.0;
+    } else if (role == 1) {
+        for (int i = 0; i < 6; i++) A.Ws[(size_t)d * 6 + i] = Wv[i];
+    } else {
+        pr[RAFTX_SP_VFILL] = sc0;
+        pr[RAFTX_SP_DRHO] = (A.add_mask & RAFTX_TRIM_BALLAST) ? A.drho[d] : 0.0;
+        pr[RAFTX_SP_MASS] = out[0];                                                               // raft_fowt.py:1206-1207
+        for (int c = 0; c < 3; c++) pr[RAFTX_SP_RCG + c] = out[0] != 0.0 ? sr[c] / out[0] : 0.0;
+        pr[11] = 0.0;
+    }
 }

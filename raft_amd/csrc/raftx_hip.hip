@@ -376,10 +376,32 @@ struct DevPool {
     }
 };
 
+// A raftx_build_designs in flight: phase 1 (descriptor H2D, member pass, scans, totals to the host) has been enqueued,
+// phase 2 (strip tables, statics) follows once the totals are known.  The sweep crossing keeps several of them in flight.
+struct BuildJob {
+    GeomArgs A;
+    std::vector<void *> tmp;            // descriptor uploads and per-member scratch: back to the pool when the job retires
+    int nDesign = 0, nw = 0, add_mask = 0;
+    int64_t nMember = 0;
+    double *M0d = nullptr, *C0d = nullptr;
+    const double *B0d = nullptr, *MBwd = nullptr;
+    bool active = false;
+};
+
 struct raftx_ctx {
     int device;
     hipStream_t stream;
+    bool owns_stream;                    // false for the block contexts of raftx_sweep_stats (they run on the parent's stream)
     hipEvent_t ev0, ev1;
+    hipEvent_t evUp, evTot, evG0, evG1, evG2, evG3, evS0, evS1, evDone;   // build phases, statistics, block finished
+    BuildJob job;
+    long long *pin;                      // page-locked landing area of the build totals and offsets [8 + nDesign + 1]
+    size_t pin_n;
+    double *pinRes;                      // page-locked landing area of a block's statistics (sweep crossing)
+    size_t pinRes_n;
+    hipStream_t sCopy, sPrep, sD2H;      // internal streams of raftx_sweep_stats (created on first use)
+    std::vector<double> case_key;        // the sea-state tables resident for the sweep crossing (skip identical re-uploads)
+    std::vector<void *> sweep_allocs;    // offset arrays of the last sweep crossing, shared by its blocks
     char err[512];
     DevTables T;
     DevPool pool;
@@ -479,8 +501,17 @@ extern "C" int raftx_ctx_create(int device_id, raftx_ctx **out) {
     c->comm = nullptr;
     c->comm_rank = 0;
     c->comm_world = 1;
-    if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess ||
-        hipEventCreate(&c->ev0) != hipSuccess || hipEventCreate(&c->ev1) != hipSuccess) {
+    c->owns_stream = true;
+    c->pin = nullptr;
+    c->pin_n = 0;
+    c->pinRes = nullptr;
+    c->pinRes_n = 0;
+    c->sCopy = c->sPrep = c->sD2H = nullptr;
+    bool ok = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) == hipSuccess;
+    for (hipEvent_t *e : {&c->ev0, &c->ev1, &c->evUp, &c->evTot, &c->evG0, &c->evG1, &c->evG2, &c->evG3, &c->evS0,
+                          &c->evS1, &c->evDone})
+        ok = ok && hipEventCreate(e) == hipSuccess;
+    if (!ok) {
         delete c;
         return -6;
     }
@@ -510,9 +541,16 @@ extern "C" void raftx_ctx_destroy(raftx_ctx *c) {
     if (c->rQtf) (void)hipFree(c->rQtf);
     if (c->bemF) (void)hipFree(c->bemF);
     if (c->rKay) (void)hipFree(c->rKay);
-    (void)hipEventDestroy(c->ev0);
-    (void)hipEventDestroy(c->ev1);
-    (void)hipStreamDestroy(c->stream);
+    free_list(c, c->job.tmp);
+    free_list(c, c->sweep_allocs);
+    c->pool.trim();
+    if (c->pin) (void)hipHostFree(c->pin);
+    if (c->pinRes) (void)hipHostFree(c->pinRes);
+    for (hipEvent_t e : {c->ev0, c->ev1, c->evUp, c->evTot, c->evG0, c->evG1, c->evG2, c->evG3, c->evS0, c->evS1, c->evDone})
+        (void)hipEventDestroy(e);
+    for (hipStream_t st : {c->sCopy, c->sPrep, c->sD2H})
+        if (st) (void)hipStreamDestroy(st);
+    if (c->owns_stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }
 
@@ -607,118 +645,187 @@ static int dev_alloc(raftx_ctx *c, std::vector<void *> &bag, size_t n, Tp **out,
     return 0;
 }
 
-extern "C" int raftx_build_designs(raftx_ctx *c, int nDesign, const int64_t *memberOff, const double *members,
-                                   const int64_t *stationOff, const double *stations, const int64_t *capOff,
-                                   const double *caps, const double *pose, double rho, double g, int nw, const double *k,
-                                   int add_mask, const double *M0, const double *B0, const double *C0, const double *MBw,
-                                   const double *Fz_moor, int64_t *stripOffsets) {
-    if (!c) return -1;
-    if (nDesign < 0 || !memberOff || !members || !stationOff || !stations || !M0 || !B0 || !C0 || !stripOffsets)
+// ---- raftx_build_designs in two phases, so that the sweep crossing can keep several design blocks in flight.
+// Phase 1 enqueues the descriptor H2D on sCopy and, behind it on sPrep, the member pass and the scans; the totals
+// (wet strips, MacCamy-Fuchs rows, strips of the largest design, error flags) and the design offsets land in page-locked
+// memory and evTot marks them.  Nothing here waits for the device.
+static int pin_reserve(raftx_ctx *c, size_t n) {
+    if (c->pin && c->pin_n >= n) return 0;
+    if (c->pin) HIPCHK(c, hipHostFree(c->pin));
+    c->pin = nullptr;
+    void *p_ = nullptr;
+    HIPCHK(c, hipHostMalloc(&p_, n * sizeof(long long), hipHostMallocDefault));
+    c->pin = reinterpret_cast<long long *>(p_);
+    c->pin_n = n;
+    return 0;
+}
+template <typename Tp, typename Dp>
+static int upload_on(raftx_ctx *c, hipStream_t st, std::vector<void *> &bag, const Tp *host, size_t n, Dp *dev) {
+    *dev = nullptr;
+    if (!host || n == 0) return 0;
+    void *p = nullptr;
+    HIPCHK(c, c->pool.get(n * sizeof(Tp), &p));
+    bag.push_back(p);
+    HIPCHK(c, hipMemcpyAsync(p, host, n * sizeof(Tp), hipMemcpyHostToDevice, st));
+    *dev = reinterpret_cast<const Tp *>(p);
+    return 0;
+}
+// Offset arrays of a whole batch, resident on the device (uploaded once by the sweep crossing, shared by its blocks).
+struct DevOffsets {
+    const int64_t *memberOff, *stationOff, *capOff;      // device copies of the caller's arrays, absolute values
+};
+// Designs [lo, lo + nDesign) of the caller's batch: memberOff / stationOff / capOff are the batch's own (absolute) host
+// arrays, the descriptor arrays are sliced here.  shared == NULL: the offsets of the slice are uploaded by this call.
+static int build_phase1(raftx_ctx *c, hipStream_t sCopy, hipStream_t sPrep, int lo, int nDesign, const int64_t *memberOff,
+                        const double *members, const int64_t *stationOff, const double *stations, const int64_t *capOff,
+                        const double *caps, const double *pose, double rho, double g, int nw, const double *k, int add_mask,
+                        const double *M0, const double *B0, const double *C0, const double *MBw, const double *Fz_moor,
+                        const DevOffsets *shared, const double *k_dev = nullptr) {
+    BuildJob &J = c->job;
+    if (nDesign < 0 || lo < 0 || !memberOff || !members || !stationOff || !stations || !M0 || !B0 || !C0)
         FAIL(c, "build_designs: bad arguments");
     if ((capOff == nullptr) != (caps == nullptr)) FAIL(c, "build_designs: capOff and caps must be given together");
     if (nw < 1 || nw > MAX_NW) FAIL(c, "build_designs: nw=%d outside 1..%d", nw, MAX_NW);
-    const int64_t nMember = memberOff[nDesign];
-    bool any_mcf = false;
-    std::vector<int> mdesign((size_t)nMember);
-    for (int d = 0; d < nDesign; d++) {
-        if (memberOff[d + 1] < memberOff[d]) FAIL(c, "member offsets not monotone at design %d", d);
-        for (int64_t m = memberOff[d]; m < memberOff[d + 1]; m++) {
-            mdesign[(size_t)m] = d;
-            const int64_t n = stationOff[m + 1] - stationOff[m];
-            if (n < 2) FAIL(c, "member %lld has %lld stations (< 2)", (long long)m, (long long)n);
-            const double *gm = members + (size_t)m * RAFTX_GM_N;
-            if (!(gm[RAFTX_GM_DLSMAX] > 0.0) || !(gm[RAFTX_GM_L] > 0.0))
-                FAIL(c, "member %lld: dlsMax and length must be positive", (long long)m);
-            if (((int)gm[RAFTX_GM_FLAGS] & RAFTX_GM_FLAG_MCF) && gm[RAFTX_GM_SHAPE] != 0.0) any_mcf = true;
-        }
-    }
-    if (any_mcf && !k) FAIL(c, "build_designs: a member is MacCamy-Fuchs but no wave numbers were given");
+    const int64_t m0 = memberOff[lo], m1 = memberOff[lo + nDesign], nMember = m1 - m0;
+    if (nMember < 0 || m0 < 0) FAIL(c, "build_designs: member offsets not monotone");
+    const int64_t s0 = stationOff[m0], s1 = stationOff[m1];
+    if (s1 < s0 || s0 < 0) FAIL(c, "build_designs: station offsets not monotone");
+    const int64_t c0 = capOff ? capOff[m0] : 0, c1 = capOff ? capOff[m1] : 0;
+    if (c1 < c0 || c0 < 0) FAIL(c, "build_designs: cap offsets not monotone");
     HIPCHK(c, hipSetDevice(c->device));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
-    free_list(c, c->design_allocs);
+    free_list(c, c->design_allocs);               // callers guarantee that nothing in flight reads the previous tables
+    free_list(c, J.tmp);
     c->have_designs = false;
     c->bem_ready = false;
     c->g_n = 0;
-    std::vector<void *> tmp;                       // descriptor uploads and per-member scratch, freed on return
-    struct Guard {
-        raftx_ctx *c;
-        std::vector<void *> &v;
-        ~Guard() {
-            (void)hipStreamSynchronize(c->stream);
-            free_list(c, v);
-        }
-    } guard{c, tmp};
-    GeomArgs A;
+    if (pin_reserve(c, (size_t)nDesign + 9)) return -2;
+    std::vector<void *> &tmp = J.tmp;
+    GeomArgs &A = J.A;
     memset(&A, 0, sizeof(A));
     A.nDesign = nDesign;
     A.nMember = nMember;
     A.rho = rho; A.g = g; A.nw = nw; A.add_mask = add_mask;
+    A.mbase = m0; A.sbase = s0; A.cbase = c0;
+    J.nDesign = nDesign; J.nw = nw; J.add_mask = add_mask; J.nMember = nMember;
     int rc = 0;
-    rc |= upload(c, tmp, memberOff, (size_t)nDesign + 1, &A.memberOff);
-    rc |= upload(c, tmp, members, (size_t)nMember * RAFTX_GM_N, &A.gm);
-    rc |= upload(c, tmp, stationOff, (size_t)nMember + 1, &A.stationOff);
-    rc |= upload(c, tmp, stations, (size_t)stationOff[nMember] * RAFTX_GS_N, &A.gs);
-    rc |= upload(c, tmp, pose, pose ? (size_t)nDesign * 6 : 0, &A.pose);
-    rc |= upload(c, tmp, mdesign.data(), (size_t)nMember, &A.mdesign);
-    if (capOff) {
-        rc |= upload(c, tmp, capOff, (size_t)nMember + 1, &A.capOff);
-        rc |= upload(c, tmp, caps, (size_t)(capOff[nMember] > 0 ? capOff[nMember] : 1) * RAFTX_GC_N, &A.caps);
+    if (shared) {
+        A.memberOff = shared->memberOff + lo;
+        A.stationOff = shared->stationOff + m0;
+        A.capOff = capOff ? shared->capOff + m0 : nullptr;
+    } else {
+        rc |= upload_on(c, sCopy, tmp, memberOff + lo, (size_t)nDesign + 1, &A.memberOff);
+        rc |= upload_on(c, sCopy, tmp, stationOff + m0, (size_t)nMember + 1, &A.stationOff);
+        if (capOff) rc |= upload_on(c, sCopy, tmp, capOff + m0, (size_t)nMember + 1, &A.capOff);
     }
-    rc |= upload(c, c->design_allocs, k, k ? (size_t)nw : 0, &A.k);
+    rc |= upload_on(c, sCopy, tmp, members + (size_t)m0 * RAFTX_GM_N, (size_t)nMember * RAFTX_GM_N, &A.gm);
+    rc |= upload_on(c, sCopy, tmp, stations + (size_t)s0 * RAFTX_GS_N, (size_t)(s1 - s0) * RAFTX_GS_N, &A.gs);
+    rc |= upload_on(c, sCopy, tmp, pose ? pose + (size_t)lo * 6 : nullptr, pose ? (size_t)nDesign * 6 : 0, &A.pose);
+    if (capOff) {
+        if (c1 > c0) rc |= upload_on(c, sCopy, tmp, caps + (size_t)c0 * RAFTX_GC_N, (size_t)(c1 - c0) * RAFTX_GC_N, &A.caps);
+        else {                                        // no caps in this slice: a valid, never-read address
+            void *p_ = nullptr;
+            HIPCHK(c, c->pool.get(RAFTX_GC_N * sizeof(double), &p_));
+            tmp.push_back(p_);
+            A.caps = reinterpret_cast<const double *>(p_);
+        }
+    }
+    if (k_dev) A.k = k_dev;                       // wave numbers already resident (the sweep crossing's sea-state tables)
+    else rc |= upload_on(c, sCopy, c->design_allocs, k, k ? (size_t)nw : 0, &A.k);
+    const double *M0c = nullptr, *C0c = nullptr;
+    rc |= upload_on(c, sCopy, c->design_allocs, M0 + (size_t)lo * 36, (size_t)nDesign * 36, &M0c);
+    rc |= upload_on(c, sCopy, c->design_allocs, C0 + (size_t)lo * 36, (size_t)nDesign * 36, &C0c);
+    rc |= upload_on(c, sCopy, c->design_allocs, B0 + (size_t)lo * 36, (size_t)nDesign * 36, &J.B0d);
+    rc |= upload_on(c, sCopy, c->design_allocs, MBw ? MBw + (size_t)lo * 72 * nw : nullptr, MBw ? (size_t)nDesign * 72 * nw : 0, &J.MBwd);
+    if (Fz_moor) rc |= upload_on(c, sCopy, tmp, Fz_moor + lo, (size_t)nDesign, &A.Fz);
     if (rc) return -2;
-    if (dev_alloc(c, tmp, (size_t)nMember, &A.cnt) || dev_alloc(c, tmp, (size_t)nMember, &A.cntm) ||
-        dev_alloc(c, tmp, (size_t)nMember + 1, &A.soff) || dev_alloc(c, tmp, (size_t)nMember + 1, &A.cmsoff) ||
-        dev_alloc(c, tmp, (size_t)nMember * MP_N, &A.mpose) || dev_alloc(c, tmp, (size_t)nMember * MH_N, &A.mhyd) ||
-        dev_alloc(c, tmp, (size_t)nMember * MI_N, &A.minert) || dev_alloc(c, tmp, 2, &A.err, true) ||
-        dev_alloc(c, tmp, (size_t)nDesign, &A.drho, true) ||
-        dev_alloc(c, c->design_allocs, (size_t)nDesign + 1, &A.off) ||
-        dev_alloc(c, c->design_allocs, (size_t)nDesign + 1, &A.cmoff))
-        return -2;
-    double *M0d = nullptr, *C0d = nullptr;
-    if (dev_alloc(c, c->design_allocs, (size_t)nDesign * 36, &M0d) || dev_alloc(c, c->design_allocs, (size_t)nDesign * 36, &C0d))
-        return -2;
-    HIPCHK(c, hipMemcpyAsync(M0d, M0, (size_t)nDesign * 36 * sizeof(double), hipMemcpyHostToDevice, c->stream));
-    HIPCHK(c, hipMemcpyAsync(C0d, C0, (size_t)nDesign * 36 * sizeof(double), hipMemcpyHostToDevice, c->stream));
-    A.M0 = M0d;
-    A.C0 = C0d;
-    if (Fz_moor) rc |= upload(c, tmp, Fz_moor, (size_t)nDesign, &A.Fz);
-    if (rc) return -2;
-    HIPCHK(c, hipEventRecord(c->ev0, c->stream));
+    J.M0d = const_cast<double *>(M0c);
+    J.C0d = const_cast<double *>(C0c);
+    A.M0 = J.M0d;
+    A.C0 = J.C0d;
+    HIPCHK(c, hipEventRecord(c->evUp, sCopy));
+    HIPCHK(c, hipStreamWaitEvent(sPrep, c->evUp, 0));
+    // device-side scratch; on a pooled block a memset on sPrep is ordered before the kernels that use it
+    int *errd = nullptr;
+    {
+        std::vector<void *> &tb = tmp;
+        auto alloc = [&](size_t bytes, void **out, std::vector<void *> &bag) -> int {
+            HIPCHK(c, c->pool.get(bytes ? bytes : 8, out));
+            bag.push_back(*out);
+            return 0;
+        };
+        void *p_[13] = {nullptr};
+        if (alloc((size_t)nMember * sizeof(int), &p_[0], tb) || alloc((size_t)nMember * sizeof(int), &p_[1], tb) ||
+            alloc(((size_t)nMember + 1) * sizeof(int64_t), &p_[2], tb) || alloc(((size_t)nMember + 1) * sizeof(int64_t), &p_[3], tb) ||
+            alloc((size_t)nMember * MP_N * sizeof(double), &p_[4], tb) || alloc((size_t)nMember * MH_N * sizeof(double), &p_[5], tb) ||
+            alloc((size_t)nMember * MI_N * sizeof(double), &p_[6], tb) || alloc(4 * sizeof(int), &p_[7], tb) ||
+            alloc((size_t)nMember * sizeof(int), &p_[12], tb) ||
+            alloc((size_t)nDesign * sizeof(double), &p_[8], tb) || alloc(3 * sizeof(long long), &p_[9], tb) ||
+            alloc(((size_t)nDesign + 1) * sizeof(int64_t), &p_[10], c->design_allocs) ||
+            alloc(((size_t)nDesign + 1) * sizeof(int64_t), &p_[11], c->design_allocs))
+            return -2;
+        A.cnt = (int *)p_[0]; A.cntm = (int *)p_[1];
+        A.soff = (int64_t *)p_[2]; A.cmsoff = (int64_t *)p_[3];
+        A.mpose = (double *)p_[4]; A.mhyd = (double *)p_[5]; A.minert = (double *)p_[6];
+        errd = (int *)p_[7]; A.err = errd;
+        A.drho = (double *)p_[8];
+        A.tot = (long long *)p_[9];
+        A.off = (int64_t *)p_[10]; A.cmoff = (int64_t *)p_[11];
+        A.mdesign_w = (int *)p_[12]; A.mdesign = A.mdesign_w;
+    }
+    HIPCHK(c, hipMemsetAsync(errd, 0, 4 * sizeof(int), sPrep));
+    HIPCHK(c, hipMemsetAsync(A.drho, 0, (size_t)(nDesign ? nDesign : 1) * sizeof(double), sPrep));
+    HIPCHK(c, hipMemsetAsync(A.tot, 0, 3 * sizeof(long long), sPrep));
+    HIPCHK(c, hipEventRecord(c->evG2, sPrep));
+    if (nDesign > 0) hipLaunchKernelGGL(k_geom_mdesign, dim3((unsigned)(nDesign / 256 + 1)), dim3(256), 0, sPrep, A);
     if (nMember > 0) {
-        hipLaunchKernelGGL(k_geom_member, dim3((unsigned)((nMember + 127) / 128)), dim3(128), 0, c->stream, A);
+        hipLaunchKernelGGL(k_geom_member, dim3((unsigned)((nMember + 127) / 128)), dim3(128), 0, sPrep, A);
         if (add_mask & RAFTX_TRIM_BALLAST) {              // heave trim: density correction, then the inertia again
-            hipLaunchKernelGGL(k_geom_trim, dim3((unsigned)(nDesign / 128 + 1)), dim3(128), 0, c->stream, A);
-            hipLaunchKernelGGL(k_geom_reinertia, dim3((unsigned)((nMember + 127) / 128)), dim3(128), 0, c->stream, A);
+            hipLaunchKernelGGL(k_geom_trim, dim3((unsigned)(nDesign / 128 + 1)), dim3(128), 0, sPrep, A);
+            hipLaunchKernelGGL(k_geom_reinertia, dim3((unsigned)((nMember + 127) / 128)), dim3(128), 0, sPrep, A);
         }
     } else {
-        HIPCHK(c, hipMemsetAsync(A.soff, 0, sizeof(int64_t), c->stream));
-        HIPCHK(c, hipMemsetAsync(A.cmsoff, 0, sizeof(int64_t), c->stream));
+        HIPCHK(c, hipMemsetAsync(A.soff, 0, sizeof(int64_t), sPrep));
+        HIPCHK(c, hipMemsetAsync(A.cmsoff, 0, sizeof(int64_t), sPrep));
     }
-    HIPCHK(c, hipMemsetAsync(A.off, 0, sizeof(int64_t), c->stream));
-    HIPCHK(c, hipMemsetAsync(A.cmoff, 0, sizeof(int64_t), c->stream));
+    HIPCHK(c, hipMemsetAsync(A.off, 0, sizeof(int64_t), sPrep));
+    HIPCHK(c, hipMemsetAsync(A.cmoff, 0, sizeof(int64_t), sPrep));
     if (nDesign > 0) {
-        hipLaunchKernelGGL(k_geom_design_counts, dim3((unsigned)(nDesign / 256 + 1)), dim3(256), 0, c->stream, A);
-        hipLaunchKernelGGL(k_geom_scan, dim3(1), dim3(1024), 0, c->stream, A);
-        hipLaunchKernelGGL(k_geom_offsets, dim3((unsigned)(nDesign / 256 + 1)), dim3(256), 0, c->stream, A);
+        hipLaunchKernelGGL(k_geom_design_counts, dim3((unsigned)(nDesign / 256 + 1)), dim3(256), 0, sPrep, A);
+        hipLaunchKernelGGL(k_geom_scan, dim3(1), dim3(1024), 0, sPrep, A);
+        hipLaunchKernelGGL(k_geom_offsets, dim3((unsigned)(nDesign / 256 + 1)), dim3(256), 0, sPrep, A);
     }
-    std::vector<int64_t> cmoffh((size_t)nDesign + 1);
-    HIPCHK(c, hipMemcpyAsync(stripOffsets, A.off, ((size_t)nDesign + 1) * sizeof(int64_t), hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipMemcpyAsync(cmoffh.data(), A.cmoff, ((size_t)nDesign + 1) * sizeof(int64_t), hipMemcpyDeviceToHost, c->stream));
-    int bad[2] = {0, 0};
-    HIPCHK(c, hipMemcpyAsync(bad, A.err, 2 * sizeof(int), hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipEventRecord(c->ev1, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, hipEventRecord(c->evG3, sPrep));
+    HIPCHK(c, hipMemcpyAsync(c->pin, A.tot, 3 * sizeof(long long), hipMemcpyDeviceToHost, sPrep));
+    HIPCHK(c, hipMemcpyAsync(c->pin + 3, errd, 4 * sizeof(int), hipMemcpyDeviceToHost, sPrep));
+    HIPCHK(c, hipMemcpyAsync(c->pin + 8, A.off, ((size_t)nDesign + 1) * sizeof(int64_t), hipMemcpyDeviceToHost, sPrep));
+    HIPCHK(c, hipEventRecord(c->evTot, sPrep));
+    J.active = true;
+    return 0;
+}
+
+// Phase 2: waits (host) for the totals of phase 1, sizes the strip tables, and enqueues strip generation, the MacCamy-
+// Fuchs table and the per-design reduction on the ctx stream, ordered behind phase 1 by evTot.  Does not wait for them.
+static int build_phase2(raftx_ctx *c, int64_t *stripOffsets) {
+    BuildJob &J = c->job;
+    if (!J.active) FAIL(c, "build_designs: phase 2 without phase 1");
+    GeomArgs &A = J.A;
+    const int nDesign = J.nDesign, nw = J.nw;
+    for (;;) {                                        // spin: the blocking wait costs ~0.2 ms of wake-up latency per block
+        const hipError_t q = hipEventQuery(c->evTot);
+        if (q == hipSuccess) break;
+        if (q != hipErrorNotReady) HIPCHK(c, q);
+    }
     HIPCHK(c, hipGetLastError());
-    float ms_a = 0.f;                              // first segment: member pass + scans (+ the small D2H of the offsets)
-    HIPCHK(c, hipEventElapsedTime(&ms_a, c->ev0, c->ev1));
+    const int *bad = reinterpret_cast<const int *>(c->pin + 3);
+    if (bad[2]) FAIL(c, "member offsets not monotone at design %d", bad[2] - 1);
+    if (bad[3] > 0) FAIL(c, "member %d: needs 2..%d stations, dlsMax > 0 and length > 0", bad[3] - 1, GEOM_MAX_STATIONS);
+    if (bad[3] < 0) FAIL(c, "build_designs: member %d is MacCamy-Fuchs but no wave numbers were given", -bad[3] - 1);
     if (bad[0]) FAIL(c, "member %d: cap/bulkhead layout not supported (the reference raises here too)", bad[0] - 1);
     if (bad[1]) FAIL(c, "design %d: ballast trim needs some ballast volume", bad[1] - 1);
-    const size_t nStrips = (size_t)stripOffsets[nDesign], nRows = (size_t)cmoffh[(size_t)nDesign];
-    int maxS = 0;
-    for (int d = 0; d < nDesign; d++) {
-        const int64_t S = stripOffsets[d + 1] - stripOffsets[d];
-        if (S > maxS) maxS = (int)S;
-    }
+    const size_t nStrips = (size_t)c->pin[0], nRows = (size_t)c->pin[1];
+    const int maxS = (int)c->pin[2];
+    if (stripOffsets) memcpy(stripOffsets, c->pin + 8, ((size_t)nDesign + 1) * sizeof(int64_t));
+    std::vector<void *> &tmp = J.tmp;
     if (dev_alloc(c, c->design_allocs, nStrips * NF, &A.abi) || dev_alloc(c, c->design_allocs, nStrips * DS_N, &A.ds) ||
         dev_alloc(c, c->design_allocs, nStrips, &A.dsi) || dev_alloc(c, c->design_allocs, nRows * 3, &A.mcfaux) ||
         dev_alloc(c, c->design_allocs, nRows * 2 * (size_t)nw, &A.cm) ||
@@ -727,29 +834,33 @@ extern "C" int raftx_build_designs(raftx_ctx *c, int nDesign, const int64_t *mem
         dev_alloc(c, c->design_allocs, (size_t)nDesign * 36, &A.Cs) || dev_alloc(c, c->design_allocs, (size_t)nDesign * 6, &A.Ws) ||
         dev_alloc(c, c->design_allocs, (size_t)nDesign * RAFTX_SP_N, &A.props))
         return -2;
-    HIPCHK(c, hipEventRecord(c->ev0, c->stream));
-    if (nMember > 0) hipLaunchKernelGGL(k_geom_fill, dim3((unsigned)nMember), dim3(64), 0, c->stream, A);
+    (void)tmp;
+    const size_t gd_lds = geom_design_lds(maxS);
+    if (gd_lds > 160 * 1024)
+        FAIL(c, "build_designs: a design has %d submerged strips (at most %d supported)", maxS, (int)((160 * 1024 - 16) / (8 * (GD_ROW + 2) + 12)));
+    if (gd_lds > 64 * 1024)
+        HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void *>(k_geom_design), hipFuncAttributeMaxDynamicSharedMemorySize, (int)gd_lds));
+    HIPCHK(c, hipStreamWaitEvent(c->stream, c->evTot, 0));
+    HIPCHK(c, hipEventRecord(c->evG0, c->stream));
+    if (J.nMember > 0) hipLaunchKernelGGL(k_geom_fill, dim3((unsigned)J.nMember), dim3(64), 0, c->stream, A);
     if (nRows > 0)
         hipLaunchKernelGGL(k_geom_mcf, dim3((unsigned)nRows, (unsigned)((nw + 63) / 64)), dim3(64), 0, c->stream, A, (int64_t)nRows);
-    if (nDesign > 0) hipLaunchKernelGGL(k_geom_design, dim3((unsigned)((nDesign + 63) / 64)), dim3(64), 0, c->stream, A);
-    HIPCHK(c, hipEventRecord(c->ev1, c->stream));
+    if (nDesign > 0) {
+        hipLaunchKernelGGL(k_geom_reduce, dim3((unsigned)(((size_t)nDesign * 3 + 63) / 64)), dim3(64), 0, c->stream, A);
+        hipLaunchKernelGGL(k_geom_design, dim3((unsigned)nDesign), dim3(64), gd_lds, c->stream, A);
+    }
+    HIPCHK(c, hipEventRecord(c->evG1, c->stream));
     DevTables &T = c->T;
     T.nDesign = nDesign;
     T.off = A.off;
     T.ds = A.ds;
     T.dsi = A.dsi;
-    T.M0 = M0d;
-    T.C0 = C0d;
-    rc |= upload(c, c->design_allocs, B0, (size_t)nDesign * 36, &T.B0);
-    rc |= upload(c, c->design_allocs, MBw, MBw ? (size_t)nDesign * 72 * nw : 0, &T.MBw);
-    if (rc) return -2;
+    T.M0 = J.M0d;
+    T.C0 = J.C0d;
+    T.B0 = J.B0d;
+    T.MBw = J.MBwd;
     T.cmoff = nRows ? A.cmoff : nullptr;
     T.cm = nRows ? A.cm : nullptr;
-    HIPCHK(c, hipStreamSynchronize(c->stream));
-    HIPCHK(c, hipGetLastError());
-    float ms = 0.f;
-    HIPCHK(c, hipEventElapsedTime(&ms, c->ev0, c->ev1));
-    c->last_ms = ms_a + ms;                         // the five kernels; allocations and table H2D are outside
     c->maxS = maxS;
     c->nw_designs = nw;
     c->have_designs = true;
@@ -760,6 +871,46 @@ extern "C" int raftx_build_designs(raftx_ctx *c, int nDesign, const int64_t *mem
     c->g_cm = A.cm;
     c->g_A = A.A; c->g_Ch = A.Ch; c->g_Wh = A.Wh; c->g_props = A.props;
     c->g_Ms = A.Ms; c->g_Cs = A.Cs; c->g_Ws = A.Ws;
+    return 0;
+}
+// kernel time of a finished build (both phases), and its scratch back to the pool
+static int build_retire(raftx_ctx *c, double *ms_out) {
+    BuildJob &J = c->job;
+    float a = 0.f, b = 0.f;
+    if (J.active) {
+        HIPCHK(c, hipEventElapsedTime(&a, c->evG2, c->evG3));
+        HIPCHK(c, hipEventElapsedTime(&b, c->evG0, c->evG1));
+    }
+    if (ms_out) *ms_out = (double)a + (double)b;
+    free_list(c, J.tmp);
+    J.active = false;
+    return 0;
+}
+
+extern "C" int raftx_build_designs(raftx_ctx *c, int nDesign, const int64_t *memberOff, const double *members,
+                                   const int64_t *stationOff, const double *stations, const int64_t *capOff,
+                                   const double *caps, const double *pose, double rho, double g, int nw, const double *k,
+                                   int add_mask, const double *M0, const double *B0, const double *C0, const double *MBw,
+                                   const double *Fz_moor, int64_t *stripOffsets) {
+    if (!c) return -1;
+    if (!stripOffsets) FAIL(c, "build_designs: bad arguments");
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    int rc = build_phase1(c, c->stream, c->stream, 0, nDesign, memberOff, members, stationOff, stations, capOff, caps, pose, rho,
+                          g, nw, k, add_mask, M0, B0, C0, MBw, Fz_moor, nullptr);
+    if (!rc) rc = build_phase2(c, stripOffsets);
+    const hipError_t e = hipStreamSynchronize(c->stream);     // host buffers may be released after return
+    if (rc) {
+        free_list(c, c->job.tmp);
+        c->job.active = false;
+        c->have_designs = false;
+        return rc;
+    }
+    HIPCHK(c, e);
+    HIPCHK(c, hipGetLastError());
+    double ms = 0.0;
+    if (build_retire(c, &ms)) return -2;
+    c->last_ms = ms;                                 // the kernels; allocations and descriptor H2D are outside
     return 0;
 }
 
@@ -802,6 +953,7 @@ extern "C" int raftx_upload_cases(raftx_ctx *c, int nCase, int nHead, int nw, co
     free_list(c, c->case_allocs);
     c->have_cases = false;
     c->bem_ready = false;
+    c->case_key.clear();
     // per-bin depth constants, computed once on the host in full libm precision.  The kernels derive
     // the depth regime (k == 0 / deep / finite) from k themselves, with the same rule.
     std::vector<double> csh(nw), cch(nw);
@@ -1040,8 +1192,8 @@ static int ensure_results(raftx_ctx *c, int want_mask, bool need_fe) {
     return 0;
 }
 
-extern "C" int raftx_solve_dynamics_device(raftx_ctx *c, int nIter, double tol, double XiStart,
-                                           const raftx_c128 *F_extra, int want_mask) {
+// enqueues the fused fixed point on the ctx stream between ev0 and ev1; does not wait for it
+static int solve_enqueue(raftx_ctx *c, int nIter, double tol, double XiStart, const raftx_c128 *F_extra, int want_mask) {
     if (check_ready(c)) return -1;
     if (nIter < 0) FAIL(c, "solve_dynamics: nIter < 0");
     HIPCHK(c, hipSetDevice(c->device));
@@ -1126,7 +1278,22 @@ extern "C" int raftx_solve_dynamics_device(raftx_ctx *c, int nIter, double tol, 
     DISPATCH_SHAPE(sh, _);
 #undef DISPATCH_ONE_
 #undef LAUNCH_SOLVE
-    return finish_timed(c);
+    HIPCHK(c, hipEventRecord(c->ev1, c->stream));
+    HIPCHK(c, hipGetLastError());
+    return 0;
+}
+static int finish_enqueued(raftx_ctx *c) {
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    float ms = 0.f;
+    HIPCHK(c, hipEventElapsedTime(&ms, c->ev0, c->ev1));
+    c->last_ms = ms;
+    return 0;
+}
+extern "C" int raftx_solve_dynamics_device(raftx_ctx *c, int nIter, double tol, double XiStart,
+                                           const raftx_c128 *F_extra, int want_mask) {
+    const int rc = solve_enqueue(c, nIter, tol, XiStart, F_extra, want_mask);
+    if (rc) return rc;
+    return finish_enqueued(c);
 }
 
 extern "C" int raftx_set_linearisation_point(raftx_ctx *c, const raftx_c128 *XiLast0, int keep_last) {
@@ -1592,80 +1759,63 @@ extern "C" int raftx_qtf_force(raftx_ctx *c, int nSet, int nw2, const double *w2
 }
 
 // ------------------------------------------------------------------ one-call sweep crossing
-// raftx_sweep_stats: the designs are cut into blocks; worker threads -- one per internal sub-context (= HIP stream +
-// device buffers + memory pool, created on first use and kept by the parent ctx) -- take the blocks round-robin and run
-// the ordinary entry points on them.  Every entry point blocks only its own thread on its own stream, so the
-// descriptor H2D / table generation of one block overlaps the fixed-point kernel of another and the D2H of a third.
-struct SweepJob {
-    int nDesign;
-    const int64_t *memberOff, *stationOff, *capOff;
-    const double *members, *stations, *caps, *pose, *M0, *B0, *C0, *Fz;
-    double rho, g;
-    int add_mask, nCase, nHead, nw;
-    const double *w, *k, *zeta, *beta;
-    double depth, rho_wave, g_wave;
-    int nIter;
-    double tol, XiStart;
-    int nChunk;
-    double *sd;
-    int32_t *niter, *flags;
-    raftx_c128 *Xi;
-    int64_t *stripCount;               // [nDesign] strips per design (scanned by the caller afterwards)
-};
-static void chunk_bounds(int n, int i, int parts, int &lo, int &hi) {
-    const int base = n / parts, rem = n % parts;
-    lo = i * base + (i < rem ? i : rem);
-    hi = lo + base + (i < rem ? 1 : 0);
-}
-static int sweep_worker(raftx_ctx *sub, const SweepJob &J, int wid, int nWorker, double *tsum) {
-    bool cases_up = false;
-    std::vector<int64_t> mo, so, co, offs;
-    const double dw = J.nw > 1 ? J.w[1] - J.w[0] : J.w[0];
-    for (int ch = wid; ch < J.nChunk; ch += nWorker) {
-        int lo, hi;
-        chunk_bounds(J.nDesign, ch, J.nChunk, lo, hi);
-        const int n = hi - lo;
-        if (n <= 0) continue;
-        const int64_t m0 = J.memberOff[lo], m1 = J.memberOff[hi];
-        mo.resize((size_t)n + 1);
-        for (int i = 0; i <= n; i++) mo[(size_t)i] = J.memberOff[lo + i] - m0;
-        so.resize((size_t)(m1 - m0) + 1);
-        const int64_t s0 = J.stationOff[m0];
-        for (int64_t j = 0; j <= m1 - m0; j++) so[(size_t)j] = J.stationOff[m0 + j] - s0;
-        int64_t c0 = 0;
-        if (J.capOff) {
-            co.resize((size_t)(m1 - m0) + 1);
-            c0 = J.capOff[m0];
-            for (int64_t j = 0; j <= m1 - m0; j++) co[(size_t)j] = J.capOff[m0 + j] - c0;
-        }
-        offs.resize((size_t)n + 1);
-        int rc = raftx_build_designs(sub, n, mo.data(), J.members + (size_t)m0 * RAFTX_GM_N, so.data(),
-                                     J.stations + (size_t)s0 * RAFTX_GS_N, J.capOff ? co.data() : nullptr,
-                                     J.capOff ? J.caps + (size_t)c0 * RAFTX_GC_N : nullptr,
-                                     J.pose ? J.pose + (size_t)lo * 6 : nullptr, J.rho, J.g, J.nw, J.k, J.add_mask,
-                                     J.M0 + (size_t)lo * 36, J.B0 + (size_t)lo * 36, J.C0 + (size_t)lo * 36, nullptr,
-                                     J.Fz ? J.Fz + lo : nullptr, offs.data());
-        if (rc) return rc;
-        tsum[0] += sub->last_ms;
-        if (J.stripCount)
-            for (int i = 0; i < n; i++) J.stripCount[lo + i] = offs[(size_t)i + 1] - offs[(size_t)i];
-        if (!cases_up) {
-            rc = raftx_upload_cases(sub, J.nCase, J.nHead, J.nw, J.w, J.k, J.depth, J.rho_wave, J.g_wave, J.zeta, J.beta);
-            if (rc) return rc;
-            cases_up = true;
-        }
-        rc = raftx_solve_dynamics_device(sub, J.nIter, J.tol, J.XiStart, nullptr, 0);
-        if (rc) return rc;
-        tsum[1] += sub->last_ms;
-        const size_t p0 = (size_t)lo * J.nCase;
-        rc = raftx_motion_stats(sub, dw, J.sd + p0 * 6, nullptr);
-        if (rc) return rc;
-        tsum[2] += sub->last_ms;
-        rc = raftx_fetch_results(sub, J.Xi ? J.Xi + p0 * J.nHead * 6 * J.nw : nullptr, J.niter + p0, J.flags + p0, nullptr,
-                                 nullptr, nullptr);
-        if (rc) return rc;
+// raftx_sweep_stats: the designs are cut into a few blocks, every block owns a block context (device tables, result
+// buffers, memory pool, events -- created on first use, kept by the parent ctx) and ONE host thread drives four streams:
+//   sCopy   descriptor H2D of every block, back to back (the first block is small, so its tables are ready early)
+//   sPrep   member pass + scans of a block as soon as its descriptors have landed, totals to page-locked memory
+//   stream  (the ctx stream; every kernel that matters) strip generation, per-design reduction, the fused fixed point
+//           and the statistics of block 0, 1, 2, ... strictly one after the other -- the HIP events around each
+//           k_solve_dynamics launch therefore time that launch alone
+//   sD2H    full responses of a finished block (only when the caller asks for Xi)
+// The host waits only for the few bytes of totals that size a block's strip table (they are ready long before the
+// compute stream reaches the block) and, at the end, for the streams to drain.
+static int block_ctx(raftx_ctx *c, size_t i, raftx_ctx **out) {
+    while (c->workers.size() <= i) {
+        raftx_ctx *sub = nullptr;
+        const int rc = raftx_ctx_create(c->device, &sub);
+        if (rc) FAIL(c, "sweep_stats: cannot create a block context (rc=%d)", rc);
+        (void)hipStreamDestroy(sub->stream);          // block contexts run on the parent's stream
+        sub->stream = c->stream;
+        sub->owns_stream = false;
+        c->workers.push_back(sub);
     }
+    *out = c->workers[i];
     return 0;
+}
+// block sizes: RAFTX_SWEEP_SPLIT="f0,f1,..." (fractions, tuning) | nChunk equal blocks | default: a small first block
+// whose kernels hide the descriptor upload of the rest (every further block costs a partial last residency round of the
+// fused kernel plus the fixed latencies of the generation kernels: two blocks measured best)
+static std::vector<int> sweep_bounds(int nDesign, long pairs, int nChunk) {
+    std::vector<double> fr;
+    static const char *env = getenv("RAFTX_SWEEP_SPLIT");
+    if (env && nChunk <= 0) {
+        const char *p = env;
+        while (*p) {
+            char *e = nullptr;
+            const double v = strtod(p, &e);
+            if (e == p) break;
+            if (v > 0) fr.push_back(v);
+            p = (*e == ',') ? e + 1 : e;
+            if (*e != ',') break;
+        }
+    }
+    if (fr.empty()) {
+        if (nChunk > 0) fr.assign((size_t)nChunk, 1.0);
+        else if (pairs >= 3072) fr = {0.2, 0.8};     // measured on MI355X at 10 k pairs (profiles/r02_crossing_splits.txt)
+        else fr = {1.0};
+    }
+    double tot = 0;
+    for (double v : fr) tot += v;
+    std::vector<int> b{0};
+    double acc = 0;
+    for (size_t i = 0; i < fr.size(); i++) {
+        acc += fr[i];
+        int hi = (i + 1 == fr.size()) ? nDesign : (int)llround(acc / tot * nDesign);
+        if (hi > nDesign) hi = nDesign;
+        if (hi > b.back()) b.push_back(hi);
+    }
+    if (b.back() != nDesign) b.push_back(nDesign);
+    return b;
 }
 
 extern "C" int raftx_sweep_stats(raftx_ctx *c, int nDesign, const int64_t *memberOff, const double *members,
@@ -1677,53 +1827,174 @@ extern "C" int raftx_sweep_stats(raftx_ctx *c, int nDesign, const int64_t *membe
                                  double XiStart, int nChunk, int nWorker, double *sd, int32_t *niter, int32_t *flags,
                                  raftx_c128 *Xi, int64_t *stripOffsets, double *timing_ms) {
     if (!c) return -1;
+    (void)nWorker;                                     // reserved (earlier versions drove the blocks from several host threads)
     if (nDesign < 0 || !memberOff || !members || !stationOff || !stations || !M0 || !B0 || !C0)
         FAIL(c, "sweep_stats: bad design arguments");
     if (nCase < 1 || nHead < 1 || nw < 1 || !w || !k || !zeta || !beta) FAIL(c, "sweep_stats: bad sea-state arguments");
     if (!sd || !niter || !flags) FAIL(c, "sweep_stats: std, niter and flags are required");
     if ((capOff == nullptr) != (caps == nullptr)) FAIL(c, "sweep_stats: capOff and caps must be given together");
     if (nIter < 0) FAIL(c, "sweep_stats: nIter < 0");
-    // defaults: three streams; blocks of about two residency rounds of the fused kernel (1024 pairs fit on 256 CUs)
-    if (nWorker <= 0) nWorker = 3;
-    if (nWorker > 8) nWorker = 8;
-    if (nChunk <= 0) {
-        const long pairs = (long)nDesign * nCase;
-        nChunk = (int)((pairs + 1024) / 2048);          // blocks of ~2 residency rounds: short tails, enough blocks to overlap
-        if (nChunk < 1) nChunk = 1;
-    }
-    if (nChunk > nDesign) nChunk = nDesign > 0 ? nDesign : 1;
-    if (nWorker > nChunk) nWorker = nChunk;
+    if (nChunk > 64) nChunk = 64;
+    HIPCHK(c, hipSetDevice(c->device));
     const auto t0 = std::chrono::steady_clock::now();
-    while ((int)c->workers.size() < nWorker) {
-        raftx_ctx *sub = nullptr;
-        const int rc = raftx_ctx_create(c->device, &sub);
-        if (rc) FAIL(c, "sweep_stats: cannot create worker context (rc=%d)", rc);
-        c->workers.push_back(sub);
+    if (!c->sCopy) {
+        HIPCHK(c, hipStreamCreateWithFlags(&c->sCopy, hipStreamNonBlocking));
+        HIPCHK(c, hipStreamCreateWithFlags(&c->sPrep, hipStreamNonBlocking));
+        HIPCHK(c, hipStreamCreateWithFlags(&c->sD2H, hipStreamNonBlocking));
     }
-    std::vector<int64_t> counts((size_t)(stripOffsets ? nDesign : 0));
-    SweepJob J{nDesign, memberOff, stationOff, capOff, members, stations, caps, pose, M0, B0, C0, Fz_moor, rho, g,
-               add_mask, nCase, nHead, nw, w, k, zeta, beta, depth, rho_wave, g_wave, nIter, tol, XiStart, nChunk, sd,
-               niter, flags, Xi, stripOffsets ? counts.data() : nullptr};
-    std::vector<int> rcs((size_t)nWorker, 0);
-    std::vector<double> tsum((size_t)nWorker * 3, 0.0);
-    if (nDesign > 0) {
-        std::vector<std::thread> th;
-        for (int wkr = 1; wkr < nWorker; wkr++)
-            th.emplace_back([&, wkr]() { rcs[(size_t)wkr] = sweep_worker(c->workers[(size_t)wkr], J, wkr, nWorker, &tsum[(size_t)wkr * 3]); });
-        rcs[0] = sweep_worker(c->workers[0], J, 0, nWorker, &tsum[0]);
-        for (auto &t : th) t.join();
-    }
-    for (int wkr = 0; wkr < nWorker; wkr++)
-        if (rcs[(size_t)wkr]) {
-            snprintf(c->err, sizeof(c->err), "sweep_stats (worker %d): %s", wkr, c->workers[(size_t)wkr]->err);
-            return rcs[(size_t)wkr];
+    // sea-state tables: resident on the parent, shared by the blocks; identical tables are not uploaded again
+    {
+        std::vector<double> key;
+        key.reserve((size_t)nw * 2 + (size_t)nCase * nHead * (nw + 1) + 6);
+        key.push_back(nCase); key.push_back(nHead); key.push_back(nw); key.push_back(depth); key.push_back(rho_wave); key.push_back(g_wave);
+        key.insert(key.end(), w, w + nw);
+        key.insert(key.end(), k, k + nw);
+        key.insert(key.end(), zeta, zeta + (size_t)nCase * nHead * nw);
+        key.insert(key.end(), beta, beta + (size_t)nCase * nHead);
+        if (!c->have_cases || key.size() != c->case_key.size() ||
+            memcmp(key.data(), c->case_key.data(), key.size() * sizeof(double)) != 0) {
+            c->case_key.clear();
+            const int rc = raftx_upload_cases(c, nCase, nHead, nw, w, k, depth, rho_wave, g_wave, zeta, beta);
+            if (rc) return rc;
+            c->case_key.swap(key);
         }
-    if (stripOffsets) {
-        stripOffsets[0] = 0;
-        for (int d = 0; d < nDesign; d++) stripOffsets[d + 1] = stripOffsets[d] + counts[(size_t)d];
     }
+    const std::vector<int> bnd = sweep_bounds(nDesign, (long)nDesign * nCase, nChunk);
+    const size_t nB = bnd.size() - 1;
+    const double dw = nw > 1 ? w[1] - w[0] : w[0];
+    HIPCHK(c, hipStreamSynchronize(c->stream));          // nothing of an earlier call may still read the blocks' tables
+    std::vector<raftx_ctx *> blk(nB, nullptr);
+    // ---- the batch's offset arrays: one upload, shared by the blocks
+    free_list(c, c->sweep_allocs);
+    DevOffsets dOff{nullptr, nullptr, nullptr};
+    {
+        const int64_t nMemberAll = memberOff[nDesign];
+        if (nMemberAll < 0) FAIL(c, "sweep_stats: member offsets not monotone");
+        int rc = upload_on(c, c->sCopy, c->sweep_allocs, memberOff, (size_t)nDesign + 1, &dOff.memberOff);
+        rc |= upload_on(c, c->sCopy, c->sweep_allocs, stationOff, (size_t)nMemberAll + 1, &dOff.stationOff);
+        if (capOff) rc |= upload_on(c, c->sCopy, c->sweep_allocs, capOff, (size_t)nMemberAll + 1, &dOff.capOff);
+        if (rc) return -2;
+    }
+    // ---- phase 1 of every block: H2D on sCopy, member pass + scans on sPrep
+    for (size_t b = 0; b < nB; b++) {
+        if (block_ctx(c, b, &blk[b])) return -1;
+        raftx_ctx *sub = blk[b];
+        const int lo = bnd[b], n = bnd[b + 1] - lo;
+        const int rc = build_phase1(sub, c->sCopy, c->sPrep, lo, n, memberOff, members, stationOff, stations, capOff, caps, pose,
+                                    rho, g, nw, k, add_mask, M0, B0, C0, nullptr, Fz_moor, &dOff, c->T.k);
+        if (rc) {
+            snprintf(c->err, sizeof(c->err), "sweep_stats (block %zu): %s", b, sub->err);
+            (void)hipDeviceSynchronize();
+            return rc;
+        }
+    }
+    // ---- phase 2 + fixed point + statistics of every block, in order, on the ctx stream
+    int rc_all = 0;
+    for (size_t b = 0; b < nB && !rc_all; b++) {
+        raftx_ctx *sub = blk[b];
+        const int lo = bnd[b], n = bnd[b + 1] - lo;
+        const size_t npair = (size_t)n * nCase;
+        int rc = build_phase2(sub, nullptr);
+        if (!rc) {                                                      // the sea states of the parent
+            DevTables &T = sub->T;
+            const DevTables &P = c->T;
+            T.nCase = P.nCase; T.nHead = P.nHead; T.nw = P.nw;
+            T.w = P.w; T.k = P.k; T.csh = P.csh; T.cch = P.cch; T.zeta = P.zeta; T.beta = P.beta;
+            T.depth = P.depth; T.rho = P.rho; T.g = P.g;
+            sub->have_cases = true;
+            rc = solve_enqueue(sub, nIter, tol, XiStart, nullptr, 0);
+        }
+        if (!rc) {
+            const size_t need = npair * 7 + 2;                          // std [npair,6] | niter, flags [npair] int32 each
+            if (!sub->pinRes || sub->pinRes_n < need) {
+                if (sub->pinRes) (void)hipHostFree(sub->pinRes);
+                sub->pinRes = nullptr;
+                void *p_ = nullptr;
+                if (hipHostMalloc(&p_, need * sizeof(double), hipHostMallocDefault) != hipSuccess) rc = -2;
+                sub->pinRes = reinterpret_cast<double *>(p_);
+                sub->pinRes_n = need;
+            }
+        }
+        double *dS = nullptr;
+        if (!rc) {
+            void *p_ = nullptr;
+            if (sub->pool.get((npair ? npair : 1) * 6 * sizeof(double), &p_) != hipSuccess) rc = -2;
+            else sub->job.tmp.push_back(p_);
+            dS = reinterpret_cast<double *>(p_);
+        }
+        if (!rc) {
+            hipError_t e = hipEventRecord(sub->evS0, c->stream);
+            if (npair)
+                hipLaunchKernelGGL(k_motion_stats, dim3((unsigned)npair), dim3(nw > 128 ? 256 : (nw > 64 ? 128 : 64)), 0, c->stream,
+                                   (int)npair, nHead, nw, 1.0 / dw, sub->rXi, dS, (double *)nullptr);
+            if (e == hipSuccess) e = hipEventRecord(sub->evS1, c->stream);
+            if (e == hipSuccess && npair) {
+                e = hipMemcpyAsync(sub->pinRes, dS, npair * 6 * sizeof(double), hipMemcpyDeviceToHost, c->stream);
+                if (e == hipSuccess)
+                    e = hipMemcpyAsync(sub->pinRes + npair * 6, sub->rNi, npair * sizeof(int), hipMemcpyDeviceToHost, c->stream);
+                if (e == hipSuccess)
+                    e = hipMemcpyAsync(reinterpret_cast<int *>(sub->pinRes + npair * 6) + npair, sub->rFl, npair * sizeof(int),
+                                       hipMemcpyDeviceToHost, c->stream);
+            }
+            if (e == hipSuccess) e = hipEventRecord(sub->evDone, c->stream);
+            if (e != hipSuccess) {
+                snprintf(sub->err, sizeof(sub->err), "statistics / download of the block: %s", hipGetErrorString(e));
+                rc = -2;
+            }
+        }
+        if (rc) {
+            snprintf(c->err, sizeof(c->err), "sweep_stats (block %zu): %s", b, sub->err);
+            rc_all = rc;
+        }
+    }
+    // ---- full responses, if asked for: block by block behind the block's kernels, on their own stream
+    if (!rc_all && Xi) {
+        for (size_t b = 0; b < nB; b++) {
+            raftx_ctx *sub = blk[b];
+            const size_t p0 = (size_t)bnd[b] * nCase;
+            hipError_t e = hipStreamWaitEvent(c->sD2H, sub->evDone, 0);
+            if (e == hipSuccess && sub->r_nx)
+                e = hipMemcpyAsync(Xi + p0 * nHead * 6 * nw, sub->rXi, sub->r_nx * sizeof(cplx), hipMemcpyDeviceToHost, c->sD2H);
+            if (e != hipSuccess) {
+                snprintf(c->err, sizeof(c->err), "sweep_stats: download of the responses: %s", hipGetErrorString(e));
+                rc_all = -2;
+                break;
+            }
+        }
+    }
+    hipError_t es = hipStreamSynchronize(c->stream);
+    hipError_t e2 = hipStreamSynchronize(c->sD2H);
+    hipError_t e3 = hipStreamSynchronize(c->sPrep);
+    hipError_t e4 = hipStreamSynchronize(c->sCopy);
+    if (rc_all) {
+        for (raftx_ctx *sub : blk) {
+            free_list(sub, sub->job.tmp);
+            sub->job.active = false;
+        }
+        return rc_all;
+    }
+    HIPCHK(c, es); HIPCHK(c, e2); HIPCHK(c, e3); HIPCHK(c, e4);
+    HIPCHK(c, hipGetLastError());
     double tb = 0, ts = 0, tst = 0;
-    for (int wkr = 0; wkr < nWorker; wkr++) { tb += tsum[(size_t)wkr * 3]; ts += tsum[(size_t)wkr * 3 + 1]; tst += tsum[(size_t)wkr * 3 + 2]; }
+    if (stripOffsets) stripOffsets[0] = 0;
+    for (size_t b = 0; b < nB; b++) {
+        raftx_ctx *sub = blk[b];
+        const int lo = bnd[b], n = bnd[b + 1] - lo;
+        const size_t npair = (size_t)n * nCase, p0 = (size_t)lo * nCase;
+        float ms = 0.f;
+        HIPCHK(c, hipEventElapsedTime(&ms, sub->ev0, sub->ev1));
+        ts += ms;
+        HIPCHK(c, hipEventElapsedTime(&ms, sub->evS0, sub->evS1));
+        tst += ms;
+        double g_ms = 0.0;
+        if (stripOffsets)                                               // block-relative offsets of phase 1 -> batch offsets
+            for (int i = 0; i < n; i++) stripOffsets[lo + i + 1] = stripOffsets[lo] + sub->pin[8 + i + 1];
+        if (build_retire(sub, &g_ms)) return -2;
+        tb += g_ms;
+        memcpy(sd + p0 * 6, sub->pinRes, npair * 6 * sizeof(double));
+        memcpy(niter + p0, sub->pinRes + npair * 6, npair * sizeof(int));
+        memcpy(flags + p0, reinterpret_cast<int *>(sub->pinRes + npair * 6) + npair, npair * sizeof(int));
+    }
     const double wall = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     if (timing_ms) { timing_ms[0] = wall; timing_ms[1] = tb; timing_ms[2] = ts; timing_ms[3] = tst; }
     c->last_ms = ts;
