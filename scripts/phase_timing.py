@@ -4,15 +4,13 @@ import numpy as np
 sys.path.insert(0, os.getcwd())
 import bench
 from raft_amd._abi import RaftxLib
-lib = RaftxLib(os.path.join("raft_amd", "csrc", "libraftx_hip_timing.so"))
+lib = RaftxLib(os.environ.get("RAFTX_TIMING_LIB", os.path.join("raft_amd", "csrc", "libraftx_hip_timing.so")))
 ctx = lib.context(0)
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 10000
-sw = bench.load_sweep(n)
-nw = len(sw["w"])
-ctx.upload_designs_raw(sw["off"], sw["strips"], sw["M0"], sw["B0"], sw["C0"], nw)
-ctx.upload_cases(sw["w"], sw["k"], sw["depth"], 1025.0, 9.81, sw["zeta"][None], sw["beta"][None])
+sw, fx, geo = bench.make_sweep(ctx, n, 0, pinned=False)
+sw.upload(ctx)                       # device-generated tables (the bench workload)
 for _ in range(2):
-    ctx.solve_dynamics_device(sw["nIter"], 0.01, sw["XiStart"])
+    ctx.solve_dynamics_device(sw.nIter, sw.tol, sw.XiStart)
 ms = ctx.last_kernel_ms()
 out = (ctypes.c_ulonglong * 8)()
 lib.lib.raftx_debug_phase_cycles.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
