@@ -626,7 +626,57 @@ def fixture_geom():
     standin.save_fixture(os.path.join(GOLD, "geom_units.npz"), fx)
 
 
-ALL = {"c5full": fixture_c5_full, "refstatics": fixture_ref_statics, "refmembers": fixture_ref_members, "bem": fixture_bem, "geom": fixture_geom, "c5oc4": fixture_c5_oc4, "c5": fixture_c5, "qtf": fixture_qtf, "c1": fixture_c1, "c2": fixture_c2, "pose": fixture_pose,
+def fixture_f4():
+    """Row f4 on the files the reference itself ships:
+      * refgold_bem_oc4semi.npz -- the reference's OWN golden for FOWT.calcBEM -> readHydro on
+        tests/test_data/OC4semi-WAMIT_Coefs/marin_semi.1 (tests/test_fowt.py:218-241,
+        OC4semi-WAMIT_Coefs_true_BEM_forces.pkl: A_BEM, B_BEM written by upstream WITH pyHAMS' own parser), plus what
+        raft_amd/bem.py needs to rebuild them: the deck's frequencies, water density and node position;
+      * f4_oc4semi_qtf12d.npz -- FOWT.readQTF (pure Python, raft_fowt.py:2081-2128) run live on marin_semi.12d, and the
+        potSecOrder == 2 flow on top of it: Model.solveDynamics with the external QTF (calcHydroForce_2ndOrd,
+        raft_model.py:1037-1038, raft_fowt.py:2158-2253).  The deck's '.3' file is not in the tree, so first-order
+        potential-flow coefficients are switched off for the solve (potFirstOrder 0, potModMaster 1: strip theory on
+        every member carries the first order)."""
+    raft = rh.import_raft()
+    name = "OC4semi-WAMIT_Coefs"
+    d = rh.prepare_design(rh.load_design(os.path.join(REF, "tests/test_data", name + ".yaml")))
+    d["platform"]["hydroPath"] = os.path.join(REF, "tests/test_data", d["platform"]["hydroPath"])
+    d["platform"]["potFirstOrder"] = 0
+    with open(os.path.join(REF, "tests/test_data", name + "_true_BEM_forces.pkl"), "rb") as f:
+        bem = pickle.load(f)
+    m = raft.Model(copy.deepcopy(d))                      # potSecOrder 2: the constructor reads marin_semi.12d
+    fowt = m.fowtList[0]
+    node = fowt.nodeList[fowt.reducedDOF[0][0]]
+    fx = {"config": "reference golden OC4semi-WAMIT_Coefs_true_BEM_forces.pkl (tests/test_fowt.py:218-241)",
+          "w": np.array(fowt.w), "rho_water": float(fowt.rho_water), "g": float(fowt.g), "r0": np.array(node.r0[:3], dtype=float),
+          "A_BEM": np.array(bem["A_BEM"]), "B_BEM": np.array(bem["B_BEM"]), "X_BEM": np.array(bem["X_BEM"]),
+          "file": "tests/test_data/OC4semi-WAMIT_Coefs/marin_semi.1"}
+    standin.save_fixture(os.path.join(GOLD, "refgold_bem_oc4semi.npz"), fx)
+
+    assert fowt.potSecOrder == 2
+    d["platform"]["potModMaster"] = 1                     # strip theory on every member carries the first order
+    mm = rh.build_model(d)
+    f = mm.fowtList[0]
+    f.outFolderQTF = None
+    # keep the upper triangle only (the matrix is Hermitian by construction, raft_fowt.py:2125-2128): 6 x smaller fixture
+    q = np.array(f.qtf)
+    iu = np.triu_indices(q.shape[0])
+    cases = [rh.make_case(Hs=6.0, Tp=12.0, heading=0.0), rh.make_case(Hs=4.0, Tp=9.0, heading=0.0)]
+    runs = []
+    for c in cases:
+        r = run_case(mm, c)
+        r["units"][0]["Fhydro_2nd"] = np.array(f.Fhydro_2nd)
+        r["units"][0]["Fhydro_2nd_mean"] = np.array(f.Fhydro_2nd_mean)
+        runs.append(r)
+    fx = {"config": "FOWT.readQTF on marin_semi.12d + potSecOrder == 2 solveDynamics (live reference)",
+          "file": "tests/test_data/OC4semi-WAMIT_Coefs/marin_semi.12d",
+          "heads_2nd": np.array(f.heads_2nd), "w1_2nd": np.array(f.w1_2nd), "qtf_upper": q[iu], "qtf_shape": np.array(q.shape),
+          "rho_water": float(f.rho_water), "g": float(f.g),
+          "model": standin.snapshot_model(mm), "cases": runs}
+    standin.save_fixture(os.path.join(GOLD, "f4_oc4semi_qtf12d.npz"), fx)
+
+
+ALL = {"f4": fixture_f4, "c5full": fixture_c5_full, "refstatics": fixture_ref_statics, "refmembers": fixture_ref_members, "bem": fixture_bem, "geom": fixture_geom, "c5oc4": fixture_c5_oc4, "c5": fixture_c5, "qtf": fixture_qtf, "c1": fixture_c1, "c2": fixture_c2, "pose": fixture_pose,
        "refgold": fixture_ref_goldens, "c4": fixture_c4, "c3": fixture_c3}
 
 if __name__ == "__main__":

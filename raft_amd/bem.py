@@ -112,12 +112,29 @@ def _translate6(M, r):
     return out
 
 
+def added_mass_damping(path1, w, rho_water, r0):
+    """A_BEM, B_BEM [6,6,nw] from a WAMIT ``.1`` file as FOWT.readHydro builds them (raft_fowt.py:1455,1469-1478): the
+    sets after the two limiting ones interpolated to the model frequencies ``w`` (the zero-frequency added mass / zero
+    damping appended at w = 0), dimensionalised (rho A, rho w B) and moved by -r0 (translateMatrix6to6DOF)."""
+    from scipy.interpolate import interp1d
+    A, B, w1 = read_wamit1(path1, TFlag=True)
+    w = np.asarray(w, dtype=float)
+    Ai = interp1d(np.hstack([w1[2:], 0.0]), np.dstack([A[:, :, 2:], A[:, :, 0]]), assume_sorted=False, axis=2)(w)
+    Bi = interp1d(np.hstack([w1[2:], 0.0]), np.dstack([B[:, :, 2:], np.zeros([6, 6])]), assume_sorted=False, axis=2)(w)
+    shift = -np.asarray(r0, dtype=float)[:3]
+    A_BEM = np.zeros([6, 6, len(w)])
+    B_BEM = np.zeros([6, 6, len(w)])
+    for iw in range(len(w)):
+        A_BEM[:, :, iw] = _translate6(rho_water * Ai[:, :, iw], shift)
+        B_BEM[:, :, iw] = _translate6(w[iw] * rho_water * Bi[:, :, iw], shift)
+    return A_BEM, B_BEM
+
+
 def read_hydro(fowt, path=None):
     """Host mirror of FOWT.readHydro (raft_fowt.py:1444-1509): sets BEM_headings, A_BEM, B_BEM [6,6,nw] and X_BEM
     [nHeadBEM,nDOF,nw] on ``fowt`` from ``path`` (default fowt.hydroPath) + '.1' / '.3'."""
     from scipy.interpolate import interp1d
     path = fowt.hydroPath if path is None else path
-    A, B, w1 = read_wamit1(path + ".1", TFlag=True)
     M, P, R, Im, w3, heads = read_wamit3(path + ".3", TFlag=True)
     heads = np.array(heads) % 360
     order = np.argsort(heads)
@@ -125,32 +142,24 @@ def read_hydro(fowt, path=None):
     R, Im = R[order], Im[order]
     w = np.asarray(fowt.w)
     nw = len(w)
-    Ai = interp1d(np.hstack([w1[2:], 0.0]), np.dstack([A[:, :, 2:], A[:, :, 0]]), assume_sorted=False, axis=2)(w)
-    Bi = interp1d(np.hstack([w1[2:], 0.0]), np.dstack([B[:, :, 2:], np.zeros([6, 6])]), assume_sorted=False, axis=2)(w)
     Ri = interp1d(np.hstack([w3, 0.0]), np.dstack([R, np.zeros([len(heads), 6])]), assume_sorted=False, axis=2)(w)
     Ii = interp1d(np.hstack([w3, 0.0]), np.dstack([Im, np.zeros([len(heads), 6])]), assume_sorted=False, axis=2)(w)
     node = fowt.nodeList[fowt.reducedDOF[0][0]]
-    r0 = -np.asarray(node.r0[:3], dtype=float)
     fowt.A_BEM = np.zeros([fowt.nDOF, fowt.nDOF, nw])
     fowt.B_BEM = np.zeros([fowt.nDOF, fowt.nDOF, nw])
-    for iw in range(nw):
-        fowt.A_BEM[:6, :6, iw] = _translate6(fowt.rho_water * Ai[:, :, iw], r0)
-        fowt.B_BEM[:6, :6, iw] = _translate6(w[iw] * fowt.rho_water * Bi[:, :, iw], r0)
-    Xt = fowt.rho_water * fowt.g * (Ri + 1j * Ii)
-    X = np.zeros_like(Xt)
-    fowt.X_BEM = np.zeros((Xt.shape[0], fowt.nDOF, nw), dtype=complex)
+    fowt.A_BEM[:6, :6, :], fowt.B_BEM[:6, :6, :] = added_mass_damping(path + ".1", w, fowt.rho_water, node.r0)
+    # dimensional excitation per unit amplitude, rotated into the frame of its own wave heading (surge / roll along the
+    # waves: magnitudes then interpolate smoothly between headings, raft_fowt.py:1480-1496), moved to the node position
+    Xg = fowt.rho_water * fowt.g * (Ri + 1j * Ii)                      # [nHeadBEM, 6, nw], global frame
+    ang = np.radians(fowt.BEM_headings)[:, None, None]
+    c, s = np.cos(ang), np.sin(ang)
+    Xh = Xg.copy()
+    Xh[:, [0, 3], :] = c * Xg[:, [0, 3], :] + s * Xg[:, [1, 4], :]        # (surge, roll) along the waves
+    Xh[:, [1, 4], :] = -s * Xg[:, [0, 3], :] + c * Xg[:, [1, 4], :]       # (sway, pitch) across
     off = -np.asarray(node.r[:3], dtype=float)
-    for ih in range(len(fowt.BEM_headings)):
-        s, c = np.sin(np.radians(fowt.BEM_headings[ih])), np.cos(np.radians(fowt.BEM_headings[ih]))
-        X[ih, 0] = c * Xt[ih, 0] + s * Xt[ih, 1]
-        X[ih, 1] = -s * Xt[ih, 0] + c * Xt[ih, 1]
-        X[ih, 2] = Xt[ih, 2]
-        X[ih, 3] = c * Xt[ih, 3] + s * Xt[ih, 4]
-        X[ih, 4] = -s * Xt[ih, 3] + c * Xt[ih, 4]
-        X[ih, 5] = Xt[ih, 5]
-        f = X[ih].copy()
-        f[3:] += np.cross(off[None, :], X[ih, :3].T).T                   # transformForce(offset=-node.r), helpers.py:529-531
-        fowt.X_BEM[ih, :6, :] = f
+    Xh[:, 3:, :] += np.cross(off[None, None, :], np.moveaxis(Xh[:, :3, :], 1, 2)).transpose(0, 2, 1)   # transformForce(offset=-node.r)
+    fowt.X_BEM = np.zeros((Xh.shape[0], fowt.nDOF, nw), dtype=complex)
+    fowt.X_BEM[:, :6, :] = Xh
     for name in ("A_BEM", "B_BEM", "X_BEM"):
         if np.isnan(getattr(fowt, name)).any():
             raise Exception("NaN values detected in HAMS calculations for %s. Check the geometry."

@@ -57,54 +57,53 @@ class Engine:
             if rot.r3[2] < 0:
                 raise UnsupportedFOWT("submerged rotors (raft_fowt.py:1861-1883) are not on the device path")
 
-    def _F_BEM(self, fowt, case):
-        """raft_fowt.py:1788-1849,1887 -- potential-flow excitation with heading
-        interpolation (host; these are dense per-bin inputs to the solve)."""
-        nw = fowt.nw
-        F_full = np.zeros([fowt.nWaves, fowt.nFullDOF, nw], dtype=complex)
-        if getattr(fowt, "potMod", False) or getattr(fowt, "potModMaster", 1) in [2, 3]:
-            for ih in range(fowt.nWaves):
-                hd = np.deg2rad(case['wave_heading'][ih])
-                phase_offset = np.exp(-1j * fowt.k * (fowt.x_ref * np.cos(hd) + fowt.y_ref * np.sin(hd)))
-                beta = (np.degrees(fowt.beta[ih]) - fowt.heading_adjust) % 360
-                headings = fowt.BEM_headings
-                nhs = len(headings)
-                if beta <= headings[0]:
-                    hlast = headings[-1] - 360
-                    i1, i2 = nhs - 1, 0
-                    f2 = (beta - hlast) / (headings[0] - hlast)
-                elif beta >= headings[nhs - 1]:
-                    hfirst = headings[0] + 360
-                    i1, i2 = nhs - 1, 0
-                    f2 = (beta - headings[-1]) / (hfirst - headings[-1])
-                else:
-                    for i in range(nhs - 1):
-                        if headings[i + 1] > beta:
-                            i1, i2 = i, i + 1
-                            f2 = (beta - headings[i]) / (headings[i + 1] - headings[i])
-                            break
-                f1 = 1.0 - f2
-                Xp = fowt.X_BEM[i1, :, :] * f1 + fowt.X_BEM[i2, :, :] * f2
-                sb, cb = np.sin(fowt.beta[ih]), np.cos(fowt.beta[ih])
-                X = np.zeros([6, nw], dtype=complex)
-                X[0, :] = Xp[0, :] * cb - Xp[1, :] * sb
-                X[1, :] = Xp[0, :] * sb + Xp[1, :] * cb
-                X[2, :] = Xp[2, :]
-                X[3, :] = Xp[3, :] * cb - Xp[4, :] * sb
-                X[4, :] = Xp[3, :] * sb + Xp[4, :] * cb
-                X[5, :] = Xp[5, :]
-                F_full[ih, :6, :] = X * fowt.zeta[ih, :] * phase_offset
-        F = np.zeros([fowt.nWaves, fowt.nDOF, nw], dtype=complex)
-        for ih in range(fowt.nWaves):
-            F[ih] = fowt.T.T @ F_full[ih]
-        return F, F_full
+    def _bem_excitation(self, fowt):
+        """Potential-flow excitation of the sea state just set on ``fowt`` (raft_fowt.py:1788-1849,1887): the blend of the
+        two neighbouring BEM headings, the rotation back out of the wave-heading frame, the wave amplitudes and the
+        array phase run on the device (raftx_bem_excitation) for the unit + sea state currently uploaded; the host only
+        applies the unit's rigid reduction T.  Returns (F_BEM [nWaves,nDOF,nw], F_BEM_fullDOF [nWaves,nFullDOF,nw])."""
+        self._bem_excitation_units([fowt])
+        return fowt.F_BEM, fowt.F_BEM_fullDOF
 
-    def _upload(self, fowts, case_zeta, case_beta, mats=None):
-        """Upload N units + one sea state.  mats: per-unit (M0,B0,C0,MBw)."""
+    def _bem_excitation_units(self, fowts):
+        """F_BEM / F_BEM_fullDOF of the units resident on the context (Model.solveDynamics): one device launch for all
+        units that carry potential-flow coefficients (they must share their BEM heading grid, as the units of a farm do)."""
+        pot = [bool(getattr(f, "potMod", False) or getattr(f, "potModMaster", 1) in [2, 3]) for f in fowts]
+        F6 = None
+        if any(pot):
+            heads = [np.asarray(f.BEM_headings, dtype=float) for f, p in zip(fowts, pot) if p]
+            if any(h.shape != heads[0].shape or not np.array_equal(h, heads[0]) for h in heads):
+                raise UnsupportedFOWT("units with different BEM heading grids are not on the device path")
+            nw = fowts[0].nw
+            X = np.zeros((len(fowts), len(heads[0]), 6, nw), dtype=complex)
+            for i, (f, p) in enumerate(zip(fowts, pot)):
+                if p:
+                    X[i] = np.asarray(f.X_BEM)[:, :6, :]
+            F6 = self.ctx.bem_excitation(heads[0], X, heading_adjust=[float(getattr(f, "heading_adjust", 0.0)) for f in fowts],
+                                         xy_ref=[[float(f.x_ref), float(f.y_ref)] for f in fowts], fetch=True)
+        for i, f in enumerate(fowts):
+            nFull = int(getattr(f, "nFullDOF", f.nDOF))
+            F_full = np.zeros([f.nWaves, nFull, f.nw], dtype=complex)
+            if F6 is not None and pot[i]:
+                F_full[:, :6, :] = F6[i, 0]
+            T = np.asarray(f.T, dtype=float)
+            f.F_BEM = np.einsum("fd,hfw->hdw", T, F_full) if T.shape[0] == nFull else F_full[:, :f.nDOF, :].copy()
+            f.F_BEM_fullDOF = F_full
+
+    def _upload(self, fowts, case_zeta, case_beta, mats=None, tables=None):
+        """Upload N units + one sea state.  mats: per-unit (M0,B0,C0,MBw).  Skipped when exactly these tables, matrices
+        and sea state are the ones resident on the context (repeated calcHydroLinearization calls of one fixed point)."""
         f0 = fowts[0]
         nw = len(f0.w)
-        tables = [f._raftx_table for f in fowts]
-        nD = len(fowts)
+        tables = [f._raftx_table for f in fowts] if tables is None else tables
+        nD = len(tables)
+        zeta, beta = np.asarray(case_zeta, dtype=float), np.asarray(case_beta, dtype=float)
+        key = getattr(self, "_up_key", None)
+        if (mats is None and key is not None and key[0] is self.ctx and len(key[1]) == nD
+                and all(a is b for a, b in zip(key[1], tables)) and key[2].shape == zeta.shape
+                and np.array_equal(key[2], zeta) and np.array_equal(key[3], beta)):
+            return
+        self._up_key = None
         if mats is None:
             M0 = B0 = C0 = np.zeros((nD, 6, 6))
             MBw = None
@@ -120,19 +119,44 @@ class Engine:
         ctx.upload_designs(tables, M0, B0, C0, nw, MBw)
         # pDyn uses Member.computeWaveKinematics' own defaults rho=1025, g=9.81
         # (raft_member.py:1899; raft_fowt.py:1857 does not forward rho/g)
-        ctx.upload_cases(f0.w, f0.k, f0.depth, 1025.0, 9.81,
-                         np.asarray(case_zeta)[None, :, :], np.asarray(case_beta)[None, :])
+        ctx.upload_cases(f0.w, f0.k, f0.depth, 1025.0, 9.81, zeta[None, :, :], beta[None, :])
+        if mats is None:
+            self._up_key = (ctx, list(tables), zeta.copy(), beta.copy())
 
     # ------------------------------------------------------------------
     def calcHydroExcitation(self, fowt, case, memberList=[]):
-        """raft_fowt.py:1732-1888."""
+        """raft_fowt.py:1732-1888.  As upstream, only the members of ``memberList`` contribute strip-theory excitation
+        (the default empty list gives none: Model.solveDynamics passes fowt.memberList, raft_model.py:1017).  Sets nWaves,
+        beta, S, zeta, F_BEM(_fullDOF), F_hydro_iner(_fullDOF)."""
         self._check_supported(fowt)
         self._sea_state(fowt, case)
-        fowt.F_BEM, fowt.F_BEM_fullDOF = self._F_BEM(fowt, case)
-        fowt._raftx_table = pack_fowt(fowt, memberList if len(memberList) else None)
+        members = list(memberList)
+        nw, nFull = fowt.nw, int(getattr(fowt, "nFullDOF", fowt.nDOF))
+        fowt._raftx_table = pack_fowt(fowt, members)
+        # per-member tables about each member's own node give the full-DOF vector (one extra design per member in the
+        # same launch); reference objects number their nodes, stand-ins without node ids get the reduced vector only
+        ids = [getattr(m.nodeList[0], "id", None) for m in members]
+        per_member = []
+        if members and all(i is not None for i in ids):
+            per_member = [pack_fowt(fowt, [m], own_node=True) for m in members]
+        self._upload([fowt], fowt.zeta, fowt.beta, tables=[fowt._raftx_table] + per_member)
+        self._up_key = None                                  # more designs than the unit's own table are resident
+        if members:
+            F = self.ctx.excitation()[:, 0]                  # [1 + nMembers, nWaves, 6, nw]
+        else:
+            F = np.zeros([1, fowt.nWaves, 6, nw], dtype=complex)
+        fowt.F_hydro_iner = np.ascontiguousarray(F[0])
+        fowt.F_hydro_iner_fullDOF = np.zeros([fowt.nWaves, nFull, nw], dtype=complex)
+        if per_member:
+            for i, m in enumerate(members):
+                node = m.nodeList[0]
+                i0 = int(node.id) * int(getattr(node, "nDOF", 6))
+                fowt.F_hydro_iner_fullDOF[:, i0:i0 + 6, :] += F[1 + i]
+        elif nFull == 6:
+            fowt.F_hydro_iner_fullDOF[:] = F[0]
+        # potential-flow part: needs the unit's own table + sea state resident (one design)
         self._upload([fowt], fowt.zeta, fowt.beta)
-        F = self.ctx.excitation()[0, 0]                     # [nWaves,6,nw]
-        fowt.F_hydro_iner = F
+        fowt.F_BEM, fowt.F_BEM_fullDOF = self._bem_excitation(fowt)
         fowt._raftx_fresh = True
         return None
 
@@ -140,7 +164,7 @@ class Engine:
         """raft_fowt.py:1891-1936 (heading 0 only, :1910)."""
         if not hasattr(fowt, "_raftx_table"):
             raise RuntimeError("calcHydroExcitation must be called before calcHydroLinearization")
-        self._upload([fowt], fowt.zeta, fowt.beta)
+        self._upload([fowt], fowt.zeta, fowt.beta)          # no-op while this unit and sea state are resident
         B, F = self.ctx.linearize(np.asarray(Xi, dtype=complex)[None, None, :, :])
         fowt.B_hydro_drag = B[0, 0]
         fowt._raftx_Fdrag = F[0, 0]                         # [nWaves,6,nw]
@@ -355,7 +379,6 @@ class Engine:
             self._check_supported(fowt)
             # sea state + excitation inputs (raft_model.py:1002)
             self._sea_state(fowt, case)
-            fowt.F_BEM, fowt.F_BEM_fullDOF = self._F_BEM(fowt, case)
             fowt._raftx_table = pack_fowt(fowt)
 
             if fowt.nrotors > 0:                                            # :1005-1010
@@ -368,10 +391,10 @@ class Engine:
             fowt.Fhydro_2nd_mean = np.zeros([fowt.nWaves, fowt.nDOF])
             if getattr(fowt, "potSecOrder", 0) == 2:
                 fowt.Fhydro_2nd_mean[0, :], fowt.Fhydro_2nd[0, :, :] = \
-                    fowt.calcHydroForce_2ndOrd(fowt.beta[0], fowt.S[0, :], iCase=iCase, iWT=i)
+                    self.calcHydroForce_2ndOrd(fowt, fowt.beta[0], fowt.S[0, :], iCase=iCase, iWT=i)
                 for ih in range(1, fowt.nWaves):                            # :1210-1211
                     fowt.Fhydro_2nd_mean[ih, :], fowt.Fhydro_2nd[ih, :, :] = \
-                        fowt.calcHydroForce_2ndOrd(fowt.beta[ih], fowt.S[ih, :])
+                        self.calcHydroForce_2ndOrd(fowt, fowt.beta[ih], fowt.S[ih, :])
             C_moor = fowt.C_moor
             MA_moor = None
             if _dynamic_mooring(fowt):                                      # :1022-1030
@@ -395,11 +418,12 @@ class Engine:
             else:
                 mats.append([fowt.M_struc + fowt.A_hydro_morison + (0.0 if MA_moor is None else MA_moor),
                              fowt.B_struc + B_gyro, C_lin, None])
-            F_extras.append(fowt.F_BEM + fowt.Fhydro_2nd)
 
         f0 = fowts[0]
         self._upload(fowts, f0.zeta, f0.beta, mats)
         ctx = self.ctx
+        self._bem_excitation_units(fowts)                                   # F_BEM(_fullDOF) of every unit (:1788-1849,1887)
+        F_extras = [fowt.F_BEM + fowt.Fhydro_2nd for fowt in fowts]
         F_extra = np.array(F_extras)[:, None]                               # [nF,1,nH,6,nw]
         F_iner = ctx.excitation()                                            # side effect of :1002
         internal_qtf = [getattr(f, "potSecOrder", 0) == 1 for f in fowts]

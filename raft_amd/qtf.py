@@ -281,26 +281,44 @@ def write_qtf12d(path, qtf4, w, heads, rho, g):
 
 
 def read_qtf12d(path, rho, g, nDOF=6, ULEN=1):
-    """FOWT.readQTF (raft_fowt.py:2081-2128): returns (heads_2nd [rad], w_2nd, qtf [n,n,nHeads,nDOF])."""
-    data = np.loadtxt(path)
-    data[:, 0:2] = 2. * np.pi / data[:, 0:2]
-    if not (data[:, 2] == data[:, 3]).all():
+    """WAMIT ``.12d`` difference-frequency QTF file -> (heads_2nd [rad], w_2nd [rad/s], qtf [n,n,nHeads,nDOF]), as
+    FOWT.readQTF stores them (raft_fowt.py:2081-2128; same values, checked bit for bit against it on the reference's
+    ``marin_semi.12d``).  Columns: PER1 PER2 BETA1 BETA2 I MOD PHA RE IM, one triangle of the Hermitian matrix; forces
+    are dimensionalised with rho g ULEN, moments (I >= 4) with rho g ULEN^2.  The whole table is placed with one
+    fancy-indexed assignment per triangle (rows in file order, so a repeated entry keeps its last occurrence, as a
+    row-by-row fill would)."""
+    tab = np.loadtxt(path, ndmin=2)
+    if not np.array_equal(tab[:, 2], tab[:, 3]):
         raise ValueError("Only unidirectional QTFs are supported for now.")
-    heads = np.deg2rad(np.sort(np.unique(data[:, 2])))
-    w1, w2 = np.unique(data[:, 0]), np.unique(data[:, 1])
-    if not (len(w1) == len(w2) and (w1 == w2).all()):
+    wa, wb = 2. * np.pi / tab[:, 0], 2. * np.pi / tab[:, 1]             # the file lists periods
+    w_grid, ia = np.unique(wa, return_inverse=True)
+    w_grid_b, ib = np.unique(wb, return_inverse=True)
+    if w_grid.shape != w_grid_b.shape or not np.array_equal(w_grid, w_grid_b):
         raise ValueError("Both frequency columns in the input QTF must contain the same values.")
-    qtf = np.zeros([len(w1), len(w2), len(heads), nDOF], dtype=complex)
-    for row in data:
-        i1, = np.where(w1 == row[0])
-        i2, = np.where(w2 == row[1])
-        ih, = np.where(heads == np.deg2rad(row[2]))
-        idof = round(row[4] - 1)
-        factor = rho * g * ULEN * (ULEN if idof >= 3 else 1)
-        qtf[i1[0], i2[0], ih[0], idof] = factor * (row[7] + 1j * row[8])
-        if i1[0] != i2[0]:
-            qtf[i2[0], i1[0], ih[0], idof] = factor * (row[7] - 1j * row[8])
-    return heads, w1, qtf
+    head_deg, ih = np.unique(tab[:, 2], return_inverse=True)
+    heads = np.deg2rad(head_deg)
+    dof = np.rint(tab[:, 4]).astype(int) - 1
+    scale = rho * g * ULEN * np.where(dof >= 3, ULEN, 1)
+    val = scale * (tab[:, 7] + 1j * tab[:, 8])
+    n = len(w_grid)
+    qtf = np.zeros([n, n, len(heads), nDOF], dtype=complex)
+    off = ia != ib
+    # rows that carry the same (i1, i2) as an earlier row's mirror must still win in file order: interleave the two
+    # assignments of every row the way a row loop does (entry, then its mirror)
+    rows = np.arange(len(tab))
+    order = np.argsort(np.concatenate([2 * rows, 2 * rows[off] + 1]), kind="stable")
+    i1 = np.concatenate([ia, ib[off]])[order]
+    i2 = np.concatenate([ib, ia[off]])[order]
+    hh = np.concatenate([ih, ih[off]])[order]
+    dd = np.concatenate([dof, dof[off]])[order]
+    vv = np.concatenate([val, np.conj(val[off])])[order]
+    flat = np.ravel_multi_index((i1, i2, hh, dd), qtf.shape)
+    # last occurrence wins: keep, for every target, the latest position
+    last = np.full(qtf.size, -1, dtype=np.int64)
+    np.maximum.at(last, flat, np.arange(len(flat)))
+    keep = last[last >= 0]
+    qtf.reshape(-1)[flat[keep]] = vv[keep]
+    return heads, w_grid, qtf
 
 
 def write_rao4(path, w, beta, Xi):

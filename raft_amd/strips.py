@@ -227,8 +227,10 @@ class StripTable:
         return self.strips.shape[0]
 
 
-def pack_fowt(fowt, memberList=None):
-    """StripTable for a rigid 6-DOF FOWT (reference object or stand-in)."""
+def pack_fowt(fowt, memberList=None, own_node=False):
+    """StripTable for a rigid 6-DOF FOWT (reference object or stand-in).  memberList None: every member of the unit;
+    a list (possibly empty): exactly those.  own_node: arms about each member's own node instead of the unit's
+    reduced-DOF point (the per-member vectors of F_hydro_iner_fullDOF, raft_fowt.py:1853-1857)."""
     if int(getattr(fowt, "nDOF", 6)) != 6:
         raise UnsupportedFOWT("FOWT has %d reduced DOFs; the device path covers rigid 6-DOF units"
                               % fowt.nDOF)
@@ -237,7 +239,7 @@ def pack_fowt(fowt, memberList=None):
     recs, cms = [], []
     for imem, mem in enumerate(members):
         k_array = np.asarray(fowt.k, dtype=float) if getattr(mem, "MCF", False) else None
-        r, c = pack_member(mem, imem, rho, k_array=k_array)
+        r, c = pack_member(mem, imem, rho, k_array=k_array, arm_node=np.zeros(3) if own_node else None)
         if len(c):
             r = r.copy()
             sel = r[:, F_MCF] >= 0

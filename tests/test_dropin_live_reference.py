@@ -197,3 +197,33 @@ def test_installed_dynamic_mooring_hook(patch, nIter):
     assert rel_err(fn.Z, fo.Z) < 1e-10
     assert rel_err(fn.B_hydro_drag, fo.B_hydro_drag) < 1e-9
     assert rel_err(fn.Xi_fullDOF, fo.Xi_fullDOF) < 1e-10
+
+
+def test_installed_calcHydroExcitation_full_dof_and_member_list(patch):
+    """FOWT.calcHydroExcitation on live objects: F_hydro_iner_fullDOF (the per-member vectors about each member's own
+    node, raft_fowt.py:1853-1857) and F_BEM_fullDOF are set as upstream sets them, and the member list means what it
+    means upstream: an empty (default) list contributes no strip-theory excitation."""
+    settings = dict(min_freq=0.01, max_freq=0.3)
+    case = rh.make_case(Hs=4.0, Tp=10.0, heading=35.0)
+    m_new = _model("examples/VolturnUS-S_example.yaml", settings)
+    m_old = _model("examples/VolturnUS-S_example.yaml", settings)
+    fn, fo = m_new.fowtList[0], m_old.fowtList[0]
+    fn.calcHydroExcitation(copy.deepcopy(case), memberList=fn.memberList)
+    with patch.unpatched():
+        fo.calcHydroExcitation(copy.deepcopy(case), memberList=fo.memberList)
+    assert fn.F_hydro_iner_fullDOF.shape == fo.F_hydro_iner_fullDOF.shape
+    assert rel_err(fn.F_hydro_iner_fullDOF, fo.F_hydro_iner_fullDOF) < 1e-12
+    assert rel_err(fn.F_hydro_iner, fo.F_hydro_iner) < 1e-12
+    assert fn.F_BEM_fullDOF.shape == fo.F_BEM_fullDOF.shape and not np.any(fn.F_BEM_fullDOF)
+    # a sub-list of members, then the default (empty) list
+    sub_n, sub_o = fn.memberList[:3], fo.memberList[:3]
+    fn.calcHydroExcitation(copy.deepcopy(case), memberList=sub_n)
+    with patch.unpatched():
+        fo.calcHydroExcitation(copy.deepcopy(case), memberList=sub_o)
+    assert rel_err(fn.F_hydro_iner, fo.F_hydro_iner) < 1e-12
+    assert rel_err(fn.F_hydro_iner_fullDOF, fo.F_hydro_iner_fullDOF) < 1e-12
+    fn.calcHydroExcitation(copy.deepcopy(case))
+    with patch.unpatched():
+        fo.calcHydroExcitation(copy.deepcopy(case))
+    assert not np.any(fo.F_hydro_iner) and not np.any(fn.F_hydro_iner)
+    assert fn.F_hydro_iner.shape == fo.F_hydro_iner.shape and not np.any(fn.F_hydro_iner_fullDOF)
