@@ -20,6 +20,8 @@ The heading interpolation that turns X_BEM into F_BEM for every (design, case, h
 """
 import numpy as np
 
+from .rigid import translate_matrix_6to6
+
 
 def _period_to_w(per):
     per = np.asarray(per, dtype=float)
@@ -101,17 +103,6 @@ def write_wamit3(path, w, headings, X):
                             % (2 * np.pi / wi, h, j + 1, abs(x), np.degrees(np.angle(x)), x.real, x.imag))
 
 
-def _translate6(M, r):
-    """helpers.py:563-585 translateMatrix6to6DOF"""
-    H = np.array([[0, r[2], -r[1]], [-r[2], 0, r[0]], [r[1], -r[0], 0]])
-    out = np.zeros((6, 6))
-    out[:3, :3] = M[:3, :3]
-    out[:3, 3:] = M[:3, :3] @ H + M[:3, 3:]
-    out[3:, :3] = out[:3, 3:].T
-    out[3:, 3:] = H @ M[:3, :3] @ H.T + M[3:, :3] @ H + H.T @ M[:3, 3:] + M[3:, 3:]
-    return out
-
-
 def added_mass_damping(path1, w, rho_water, r0):
     """A_BEM, B_BEM [6,6,nw] from a WAMIT ``.1`` file as FOWT.readHydro builds them (raft_fowt.py:1455,1469-1478): the
     sets after the two limiting ones interpolated to the model frequencies ``w`` (the zero-frequency added mass / zero
@@ -125,8 +116,8 @@ def added_mass_damping(path1, w, rho_water, r0):
     A_BEM = np.zeros([6, 6, len(w)])
     B_BEM = np.zeros([6, 6, len(w)])
     for iw in range(len(w)):
-        A_BEM[:, :, iw] = _translate6(rho_water * Ai[:, :, iw], shift)
-        B_BEM[:, :, iw] = _translate6(w[iw] * rho_water * Bi[:, :, iw], shift)
+        A_BEM[:, :, iw] = translate_matrix_6to6(rho_water * Ai[:, :, iw], shift)
+        B_BEM[:, :, iw] = translate_matrix_6to6(w[iw] * rho_water * Bi[:, :, iw], shift)
     return A_BEM, B_BEM
 
 

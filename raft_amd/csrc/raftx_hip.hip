@@ -43,27 +43,41 @@
 #include "raftx_qtf.h"
 #include "raftx_geom.h"
 
-// Coupled array solve (raft_model.py:1164-1236): one 64-lane workgroup per
-// (system, bin); the augmented matrix [Z_sys | F] lives in LDS, lane r owns
-// row r during the elimination.
+// Coupled array solve (raft_model.py:1164-1236): Xi = Z_sys^-1 F for every (system, bin).  One wavefront per
+// (system, bin), NBIN (1, 2 or 4: what fits LDS) consecutive bins per workgroup so that the loads of one matrix entry
+// for the bins of a workgroup are one contiguous segment of the [.., nw] slabs.  The augmented matrix [Z_sys | F] of a
+// wave lives in LDS; Gaussian elimination with partial pivoting (pivot on |re| + |im|, first largest, as izamax):
+// pivot search as a wave reduction, multipliers with a lane per row, the rank-1 update with the lanes over the
+// (row, column) entries, back substitution column by column with a lane per (row, right-hand side).  A wave's LDS
+// traffic needs no s_barrier (wave_lds_fence).
+__device__ __forceinline__ void argmax_step(double &v, int &r, int off) {
+    const double ov = __shfl_xor(v, off, 64);
+    const int orr = __shfl_xor(r, off, 64);
+    if (ov > v || (ov == v && orr < r)) {
+        v = ov;
+        r = orr;
+    }
+}
 template <bool RESIDENT>
-__global__ void __launch_bounds__(64) k_solve_system(int nSys, int nUnit, int nRhs, int nw, int nCase,
-                                                     const double *__restrict__ w, const cplx *__restrict__ Zblk,
-                                                     const double *__restrict__ Mc, const double *__restrict__ Bc,
-                                                     const double *__restrict__ Cc, const cplx *__restrict__ F,
-                                                     cplx *__restrict__ Xi) {
+__global__ void __launch_bounds__(256) k_solve_system(int nSys, int nUnit, int nRhs, int nw, int nCase,
+                                                      const double *__restrict__ w, const cplx *__restrict__ Zblk,
+                                                      const double *__restrict__ Mc, const double *__restrict__ Bc,
+                                                      const double *__restrict__ Cc, const cplx *__restrict__ F,
+                                                      cplx *__restrict__ Xi) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
-    const int n = 6 * nUnit, ld = n + nRhs;
-    cplx *A = reinterpret_cast<cplx *>(smem);              // [n][ld]
-    __shared__ int s_p;
-    const int s = blockIdx.x / nw, iw = blockIdx.x % nw;
+    const int n = 6 * nUnit, ld = n + nRhs, nel = n * ld;
+    const int nbin = blockDim.x >> 6, ngrp = (nw + nbin - 1) / nbin;
+    const int s = blockIdx.x / ngrp, iw0 = (blockIdx.x % ngrp) * nbin;
+    cplx *Aall = reinterpret_cast<cplx *>(smem);           // [nbin][n][ld]
     // host layout: Zblk [nSys,nUnit,36,nw], F [nSys,nRhs,n,nw], coupling per system.
     // resident layout (results of k_solve_dynamics): unit u of system (g, c) is pair (g*nUnit+u)*nCase + c;
     // Z [pair,36,nw], F_wave [pair,nRhs,6,nw], coupling per group g.
     const int g = RESIDENT ? s / nCase : s, ic = RESIDENT ? s % nCase : 0;
-    const double ww = w[iw];
-    for (int e = threadIdx.x; e < n * ld; e += 64) {
-        int r = e / ld, c = e % ld;
+    for (int t = threadIdx.x; t < nel * nbin; t += blockDim.x) {
+        const int e = t / nbin, b = t % nbin;
+        const int iw = min(iw0 + b, nw - 1);
+        const double ww = w[iw];
+        const int r = e / ld, c = e % ld;
         cplx v = {0.0, 0.0};
         if (c < n) {
             if (r / 6 == c / 6) {
@@ -82,53 +96,73 @@ __global__ void __launch_bounds__(64) k_solve_system(int nSys, int nUnit, int nR
         } else {
             v = F[(((size_t)s * nRhs + (c - n)) * n + r) * nw + iw];
         }
-        A[e] = v;
+        Aall[(size_t)b * nel + e] = v;
     }
     __syncthreads();
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    cplx *A = Aall + (size_t)wv * nel;
     for (int k = 0; k < n; k++) {
-        if (threadIdx.x == 0) {
-            int p = k;
-            double best = fabs(A[k * ld + k].re) + fabs(A[k * ld + k].im);
-            for (int r = k + 1; r < n; r++) {
-                double v = fabs(A[r * ld + k].re) + fabs(A[r * ld + k].im);
-                if (v > best) {
-                    best = v;
-                    p = r;
-                }
+        // pivot row: first row of the largest |re| + |im| in column k
+        double best = -1.0;
+        int p = n;
+        for (int r = k + lane; r < n; r += 64) {
+            const double v = fabs(A[r * ld + k].re) + fabs(A[r * ld + k].im);
+            if (v > best) {
+                best = v;
+                p = r;
             }
-            s_p = p;
         }
-        __syncthreads();
-        const int p = s_p;
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) argmax_step(best, p, off);
+        if (p >= n) p = k;                                    // a column of NaNs: no row compares larger
         if (p != k)
-            for (int c = threadIdx.x; c < ld; c += 64) {
-                cplx t = A[k * ld + c];
+            for (int c = lane; c < ld; c += 64) {
+                const cplx t = A[k * ld + c];
                 A[k * ld + c] = A[p * ld + c];
                 A[p * ld + c] = t;
             }
-        __syncthreads();
+        wave_lds_fence();
         const cplx pv = A[k * ld + k];
         const double dd = pv.re * pv.re + pv.im * pv.im;
         const cplx inv = {pv.re / dd, -pv.im / dd};
-        for (int r = k + 1 + threadIdx.x; r < n; r += 64) {
-            cplx lf = cmul(A[r * ld + k], inv);
-            for (int c = k + 1; c < ld; c++) A[r * ld + c] = csub(A[r * ld + c], cmul(lf, A[k * ld + c]));
-            A[r * ld + k] = lf;
+        for (int r = k + 1 + lane; r < n; r += 64) A[r * ld + k] = cmul(A[r * ld + k], inv);
+        wave_lds_fence();
+        const int nc = ld - k - 1, nupd = (n - k - 1) * nc;
+        for (int e = lane; e < nupd; e += 64) {
+            const int r = k + 1 + e / nc, c = k + 1 + e % nc;
+            A[r * ld + c] = csub(A[r * ld + c], cmul(A[r * ld + k], A[k * ld + c]));
         }
-        __syncthreads();
+        wave_lds_fence();
     }
-    // back substitution: lane per right-hand side
-    for (int r = threadIdx.x; r < nRhs; r += 64) {
-        for (int k = n - 1; k >= 0; k--) {
-            cplx sum = A[k * ld + n + r];
-            for (int c = k + 1; c < n; c++) sum = csub(sum, cmul(A[k * ld + c], A[c * ld + n + r]));
-            cplx pv = A[k * ld + k];
-            double dd = pv.re * pv.re + pv.im * pv.im;
-            cplx x = {(sum.re * pv.re + sum.im * pv.im) / dd, (sum.im * pv.re - sum.re * pv.im) / dd};
-            A[k * ld + n + r] = x;
+    // back substitution, column by column: x_k = b_k / u_kk, then b_r -= u_rk x_k for the rows above
+    for (int k = n - 1; k >= 0; k--) {
+        const cplx pv = A[k * ld + k];
+        const double dd = pv.re * pv.re + pv.im * pv.im;
+        for (int j = lane; j < nRhs; j += 64) {
+            const cplx sum = A[k * ld + n + j];
+            A[k * ld + n + j] = cplx{(sum.re * pv.re + sum.im * pv.im) / dd, (sum.im * pv.re - sum.re * pv.im) / dd};
         }
-        for (int k = 0; k < n; k++) Xi[(((size_t)s * nRhs + r) * n + k) * nw + iw] = A[k * ld + n + r];
+        wave_lds_fence();
+        for (int e = lane; e < k * nRhs; e += 64) {
+            const int r = e / nRhs, j = e % nRhs;
+            A[r * ld + n + j] = csub(A[r * ld + n + j], cmul(A[r * ld + k], A[k * ld + n + j]));
+        }
+        wave_lds_fence();
     }
+    __syncthreads();
+    // responses out: the bins of the workgroup side by side
+    for (int t = threadIdx.x; t < n * nRhs * nbin; t += blockDim.x) {
+        const int e = t / nbin, b = t % nbin;
+        const int k = e % n, j = e / n;
+        if (iw0 + b < nw) Xi[(((size_t)s * nRhs + j) * n + k) * nw + iw0 + b] = Aall[(size_t)b * nel + k * ld + n + j];
+    }
+}
+// bins per workgroup and dynamic LDS of k_solve_system
+static int solve_system_shape(int n, int nRhs, size_t *lds) {
+    const size_t per = sizeof(cplx) * (size_t)n * (n + nRhs);
+    const int nbin = per * 4 <= 64 * 1024 ? 4 : (per * 2 <= 64 * 1024 ? 2 : 1);
+    *lds = per * nbin;
+    return nbin;
 }
 
 // Motion statistics of the resident responses (raft_fowt.py:2310-2357; helpers.py:678-700): one
@@ -421,6 +455,9 @@ struct raftx_ctx {
     int r_mask;
     bool r_fe;
     int maxS;
+    std::vector<int> hS;                 // submerged strips of every design (host copy: LDS classes of the fused kernel)
+    int *pairList;                       // device pair lists of a launch split into LDS classes
+    size_t pairList_n;
     unsigned long long *dbg;
     double last_ms;
     bool have_designs, have_cases;
@@ -473,6 +510,8 @@ extern "C" int raftx_ctx_create(int device_id, raftx_ctx **out) {
     c->device = device_id;
     c->err[0] = 0;
     c->maxS = 0;
+    c->pairList = nullptr;
+    c->pairList_n = 0;
     c->dbg = nullptr;
     c->last_ms = 0.0;
     c->have_designs = c->have_cases = false;
@@ -541,6 +580,7 @@ extern "C" void raftx_ctx_destroy(raftx_ctx *c) {
     if (c->rQtf) (void)hipFree(c->rQtf);
     if (c->bemF) (void)hipFree(c->bemF);
     if (c->rKay) (void)hipFree(c->rKay);
+    if (c->pairList) (void)hipFree(c->pairList);
     free_list(c, c->job.tmp);
     free_list(c, c->sweep_allocs);
     c->pool.trim();
@@ -594,10 +634,12 @@ extern "C" int raftx_upload_designs(raftx_ctx *c, int nDesign, const int64_t *st
     c->have_designs = false;
     c->bem_ready = false;
     int maxS = 0;
+    c->hS.assign((size_t)nDesign, 0);
     for (int d = 0; d < nDesign; d++) {
         int64_t S = stripOffsets[d + 1] - stripOffsets[d];
         if (S < 0) FAIL(c, "strip offsets not monotone at design %d", d);
         if (S > maxS) maxS = (int)S;
+        c->hS[(size_t)d] = (int)S;
     }
     // Device strip table.  Straight runs of equally spaced strips (members) are detected here,
     // from the absolute positions alone, so that the kernels can advance the wave kinematics
@@ -825,6 +867,8 @@ static int build_phase2(raftx_ctx *c, int64_t *stripOffsets) {
     const size_t nStrips = (size_t)c->pin[0], nRows = (size_t)c->pin[1];
     const int maxS = (int)c->pin[2];
     if (stripOffsets) memcpy(stripOffsets, c->pin + 8, ((size_t)nDesign + 1) * sizeof(int64_t));
+    c->hS.resize((size_t)nDesign);
+    for (int d = 0; d < nDesign; d++) c->hS[(size_t)d] = (int)(c->pin[8 + d + 1] - c->pin[8 + d]);
     std::vector<void *> &tmp = J.tmp;
     if (dev_alloc(c, c->design_allocs, nStrips * NF, &A.abi) || dev_alloc(c, c->design_allocs, nStrips * DS_N, &A.ds) ||
         dev_alloc(c, c->design_allocs, nStrips, &A.dsi) || dev_alloc(c, c->design_allocs, nRows * 3, &A.mcfaux) ||
@@ -1261,13 +1305,69 @@ static int solve_enqueue(raftx_ctx *c, int nIter, double tol, double XiStart, co
         need |= KF_XLIO;
         c->have_xl0 = false;                  // one-shot
     }
+    // LDS classes: the workgroups of a launch all get the LDS of its largest design, and the number of pairs a CU holds
+    // (4 at C3) falls with it -- one 140-strip candidate would cost a whole 10 k-design sweep a quarter of its
+    // residency.  Designs are therefore grouped by how many of their pairs fit a CU, one launch per group (largest
+    // residency first), through a pair list; a batch of one class (the usual case) is one launch without a list.
+    std::vector<std::vector<int>> cls;
+    std::vector<int> clsS;
+    {
+        auto lds_of = [&](int S_) {
+            return lds_bytes(S_, xlg ? 0 : T.nw, sh.threads / 64, stage_policy(sh.nb, shape_maxt(sh)), park_policy(sh.nb, shape_maxt(sh)));
+        };
+        auto fit = [&](int S_) { return (int)(LDS_LIMIT / lds_of(S_)); };
+        const int kmax = fit(0);
+        bool mixed = false;
+        if ((int)c->hS.size() == T.nDesign && T.nDesign > 0) {
+            const int k0 = fit(c->hS[0]);
+            for (int d = 1; d < T.nDesign && !mixed; d++) mixed = fit(c->hS[(size_t)d]) != k0;
+        }
+        if (mixed) {
+            cls.assign((size_t)kmax + 1, {});
+            clsS.assign((size_t)kmax + 1, 0);
+            for (int d = 0; d < T.nDesign; d++) {
+                const int S_ = c->hS[(size_t)d], kk = fit(S_);
+                for (int ic = 0; ic < T.nCase; ic++) cls[(size_t)kk].push_back(d * T.nCase + ic);
+                if (S_ > clsS[(size_t)kk]) clsS[(size_t)kk] = S_;
+            }
+            if (c->pairList_n < c->r_npair) {
+                HIPCHK(c, hipStreamSynchronize(c->stream));
+                if (c->pairList) (void)hipFree(c->pairList);
+                c->pairList = nullptr;
+                void *p_ = nullptr;
+                HIPCHK(c, hipMalloc(&p_, c->r_npair * sizeof(int)));
+                c->pairList = reinterpret_cast<int *>(p_);
+                c->pairList_n = c->r_npair;
+            }
+            size_t at = 0;
+            for (int kk = kmax; kk >= 0; kk--)
+                if (!cls[(size_t)kk].empty()) {
+                    H2D(c, c->pairList + at, cls[(size_t)kk].data(), cls[(size_t)kk].size() * sizeof(int));
+                    at += cls[(size_t)kk].size();
+                }
+        }
+    }
 #define LAUNCH_SOLVE(NB_, MT_, MB_, FL)                                                                              \
     do {                                                                                                             \
         if (prep_lds(c, k_solve_dynamics<NB_, FL, MT_, MB_>, lds)) return -1;                                        \
         HIPCHK(c, hipEventRecord(c->ev0, c->stream));                                                                \
-        if (c->r_npair)                                                                                              \
+        A.pairs = nullptr;                                                                                           \
+        A.npairs = 0;                                                                                                \
+        if (c->r_npair && cls.empty())                                                                               \
             hipLaunchKernelGGL((k_solve_dynamics<NB_, FL, MT_, MB_>), dim3(grid_for_pairs(c->r_npair)),              \
                                dim3(sh.threads), lds, c->stream, T, A);                                              \
+        size_t at_ = 0;                                                                                              \
+        for (int kk = (int)cls.size() - 1; kk >= 0; kk--) {                                                          \
+            const size_t n_ = cls[(size_t)kk].size();                                                                \
+            if (!n_) continue;                                                                                       \
+            A.pairs = c->pairList + at_;                                                                             \
+            A.npairs = (int)n_;                                                                                      \
+            at_ += n_;                                                                                               \
+            const size_t l_ = lds_bytes(clsS[(size_t)kk], xlg ? 0 : T.nw, sh.threads / 64, stage_policy(sh.nb, shape_maxt(sh)), \
+                                        park_policy(sh.nb, shape_maxt(sh)));                                         \
+            hipLaunchKernelGGL((k_solve_dynamics<NB_, FL, MT_, MB_>), dim3(grid_for_pairs(n_)), dim3(sh.threads),    \
+                               l_, c->stream, T, A);                                                                 \
+        }                                                                                                            \
     } while (0)
 #define DISPATCH_ONE_(NB_, MT_, MB_)                                                                                 \
     if (!hit_ && sh.nb == NB_ && sh.threads == MT_) {                                                                \
@@ -1497,7 +1597,8 @@ extern "C" int raftx_solve_system(raftx_ctx *c, int nSys, int nUnit, int nRhs, i
     if (nSys < 0 || nUnit < 1 || nRhs < 1 || nw < 1 || !w || !Zblk || !F || !Xi) FAIL(c, "solve_system: bad arguments");
     HIPCHK(c, hipSetDevice(c->device));
     const int n = 6 * nUnit;
-    size_t lds = sizeof(cplx) * (size_t)n * (n + nRhs);
+    size_t lds = 0;
+    const int nbin = solve_system_shape(n, nRhs, &lds);
     if (lds > 150 * 1024) FAIL(c, "solve_system: %d DOFs x %d rhs does not fit the LDS-resident solver", n, nRhs);
     Scratch sc(c);
     size_t nz = (size_t)nSys * nUnit * 36 * nw, nf = (size_t)nSys * nRhs * n * nw, nc = (size_t)nSys * n * n;
@@ -1520,8 +1621,8 @@ extern "C" int raftx_solve_system(raftx_ctx *c, int nSys, int nUnit, int nRhs, i
         if (lds > 64 * 1024)
             HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void *>(k_solve_system<false>),
                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL(k_solve_system<false>, dim3((unsigned)((size_t)nSys * nw)), dim3(64), lds, c->stream, nSys,
-                           nUnit, nRhs, nw, 1, dw, dZ, dM, dB, dC, dF, dX);
+        hipLaunchKernelGGL(k_solve_system<false>, dim3((unsigned)((size_t)nSys * ((nw + nbin - 1) / nbin))), dim3(64 * nbin), lds,
+                           c->stream, nSys, nUnit, nRhs, nw, 1, dw, dZ, dM, dB, dC, dF, dX);
     }
     if (finish_timed(c)) return -2;
     if (nSys) D2H(c, Xi, dX, nf * sizeof(cplx));
@@ -1538,7 +1639,8 @@ extern "C" int raftx_solve_system_resident(raftx_ctx *c, int nUnit, const double
     if (nUnit < 1 || T.nDesign % nUnit != 0 || !Xi) FAIL(c, "solve_system_resident: bad arguments (nDesign=%d, nUnit=%d)", T.nDesign, nUnit);
     HIPCHK(c, hipSetDevice(c->device));
     const int nGroup = T.nDesign / nUnit, nSys = nGroup * T.nCase, n = 6 * nUnit, nRhs = T.nHead, nw = T.nw;
-    size_t lds = sizeof(cplx) * (size_t)n * (n + nRhs);
+    size_t lds = 0;
+    const int nbin = solve_system_shape(n, nRhs, &lds);
     if (lds > 150 * 1024) FAIL(c, "solve_system: %d DOFs x %d rhs does not fit the LDS-resident solver", n, nRhs);
     Scratch sc(c);
     size_t nf = (size_t)nSys * nRhs * n * nw, nc = (size_t)nGroup * n * n;
@@ -1554,8 +1656,8 @@ extern "C" int raftx_solve_system_resident(raftx_ctx *c, int nUnit, const double
         if (lds > 64 * 1024)
             HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void *>(k_solve_system<true>),
                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL(k_solve_system<true>, dim3((unsigned)((size_t)nSys * nw)), dim3(64), lds, c->stream, nSys, nUnit,
-                           nRhs, nw, T.nCase, T.w, c->rZ, dM, dB, dC, c->rFw, dX);
+        hipLaunchKernelGGL(k_solve_system<true>, dim3((unsigned)((size_t)nSys * ((nw + nbin - 1) / nbin))), dim3(64 * nbin), lds,
+                           c->stream, nSys, nUnit, nRhs, nw, T.nCase, T.w, c->rZ, dM, dB, dC, c->rFw, dX);
     }
     if (finish_timed(c)) return -2;
     if (nSys) D2H(c, Xi, dX, nf * sizeof(cplx));

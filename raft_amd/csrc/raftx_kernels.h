@@ -1677,6 +1677,8 @@ struct SolveArgs {
     const cplx *__restrict__ Xl0;        // [pair,6,nw] or null: initial linearisation point instead of XiStart
     cplx *__restrict__ XlOut;            // [pair,6,nw] or null: linearisation point of the LAST iteration
     unsigned long long *dbg;             // RAFTX_PHASE_TIMING builds: [8] accumulated wave-0 cycles per phase
+    const int *__restrict__ pairs;       // [npairs] the pairs of this launch, or null: all pairs 0 .. nDesign * nCase - 1
+    int npairs;                          // (batches with very unequal strip counts are launched per LDS class)
 };
 
 // The fused fixed point (raft_model.py:1052-1142) + per-heading response (:1189-1236).
@@ -1692,7 +1694,12 @@ __global__ void __launch_bounds__(MAXT, MINB) k_solve_dynamics(DevTables T, Solv
     constexpr bool EXTRA = (FLAGS & KF_EXTRA) != 0, MCF = (FLAGS & KF_MCF) != 0, MULTI = (FLAGS & KF_MULTI) != 0;
     constexpr bool XLIO = (FLAGS & KF_XLIO) != 0;
     PairCtx p;
-    if (!pair_ctx(T, p, pair_of_block(blockIdx.x, T.nDesign * T.nCase))) return;
+    {
+        const int nl = A.pairs ? A.npairs : T.nDesign * T.nCase;
+        const int idx = pair_of_block(blockIdx.x, nl);
+        if (idx >= nl) return;
+        if (!pair_ctx(T, p, A.pairs ? A.pairs[idx] : idx)) return;
+    }
     PT_DECL;
     const bool multi = blockDim.x > 64;
     const int nw = T.nw, nHs = T.nHead, nH = MULTI ? T.nHead : 1;

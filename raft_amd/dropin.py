@@ -26,6 +26,7 @@ are consumed only inside the replaced methods and are not materialised.
 import numpy as np
 
 from . import waves
+from .rigid import translate_matrix_6to6
 from .strips import pack_fowt, UnsupportedFOWT
 from . import backend
 
@@ -214,7 +215,9 @@ class Engine:
             kay = rq.kay_correction(tab.kay_geom, w2, k2, beta, fowt.depth, rho=fowt.rho_water, g=fowt.g)
             backend_fn = self._qtf_backend or (lambda *a: self.ctx.qtf_slender(*a))
             q = backend_fn(*args, kay[None])[0]
-        fowt.qtf[:, :, 0, :] = q          # NB: like the reference, slot 0 is written whatever waveHeadInd is asked (:2014)
+        # the matrix has ONE heading slot (:2014-2015 allocates [nw2, nw2, 1, nDOF]); upstream indexes it with waveHeadInd
+        # and therefore raises IndexError for waveHeadInd > 0 -- here the single slot holds the heading asked for
+        fowt.qtf[:, :, 0, :] = q
         if out_dir is not None and verbose:
             rq.write_qtf12d(os.path.join(out_dir, f"qtf-slender_body-total_Head{whead}{tag}.12d"), fowt.qtf, w2,
                             fowt.heads_2nd, fowt.rho_water, fowt.g)
@@ -427,6 +430,11 @@ class Engine:
         F_extra = np.array(F_extras)[:, None]                               # [nF,1,nH,6,nw]
         F_iner = ctx.excitation()                                            # side effect of :1002
         internal_qtf = [getattr(f, "potSecOrder", 0) == 1 for f in fowts]
+        if any(internal_qtf) and f0.nWaves > 1:
+            # upstream's own branch for further headings is broken (fowt.qtf has a single heading slot, raft_fowt.py:2014,
+            # and raft_model.py:1210-1211 would reuse the heading-0 matrix): there is no reference behaviour to match
+            raise UnsupportedFOWT("internal slender-body QTFs (potSecOrder == 1) with more than one wave heading are not on "
+                                  "the device path")
         if any(internal_qtf):
             ctx.set_linearisation_point(None, keep_last=True)
         if any(_dynamic_mooring(f) for f in fowts):
@@ -518,18 +526,6 @@ def _dynamic_mooring(fowt):
 def _mooring_arm(fowt):
     """raft_model.py:1027: from the unit's reduced-DOF reference node to the mooring body's reference point."""
     return np.asarray(fowt.ms.bodyList[0].r6[:3], dtype=float) - np.asarray(fowt.nodeList[fowt.reducedDOF[0][0]].r[:3], dtype=float)
-
-
-def translate_matrix_6to6(Min, r):
-    """helpers.py:563-585 translateMatrix6to6DOF (H of helpers.py:428-437)."""
-    Min = np.asarray(Min, dtype=float)
-    H = np.array([[0.0, r[2], -r[1]], [-r[2], 0.0, r[0]], [r[1], -r[0], 0.0]])
-    out = np.zeros((6, 6))
-    out[:3, :3] = Min[:3, :3]
-    out[:3, 3:] = Min[:3, :3] @ H + Min[:3, 3:]
-    out[3:, :3] = out[:3, 3:].T
-    out[3:, 3:] = H @ Min[:3, :3] @ H.T + Min[3:, :3] @ H + H.T @ Min[:3, 3:] + Min[3:, 3:]
-    return out
 
 
 def tower_base_rows(fowt):

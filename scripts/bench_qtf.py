@@ -1,5 +1,6 @@
-"""Config-5-shaped measurement of the slender-body QTF kernels: VolturnUS-S strip table, 200 x 200 second-order grid,
-nSet independent (heading, motion) sets per launch.  Prints one JSON line (kernel time from HIP events on the ctx
+"""Config-5-shaped measurement of the slender-body QTF kernels: 200 x 200 second-order grid, nSet independent (heading,
+motion) sets per launch -- on the VolturnUS-S strip table and on the BASELINE configs[4] deck itself (OC4semi-RAFT_QTF:
+MacCamy-Fuchs columns with heave plates, inclined braces, Kim & Yue correction).  Prints one JSON line (kernel time from HIP events on the ctx
 stream; the numpy oracle timed on a 40 x 40 sub-grid as the CPU datapoint)."""
 import json, os, sys, time
 import numpy as np
@@ -37,6 +38,25 @@ print(json.dumps({"metric": "QTF strip-pairs per second", "sets": n_set, "nw2": 
                   "numpy_oracle_strip_pairs_per_s_1core": (n_sub * (n_sub + 1) // 2) * S / t_cpu,
                   "reference_strip_pairs_per_s_1core": 1.0 / 0.58e-3,
                   "hermitian_ok": bool(np.allclose(q[0], np.conj(np.transpose(q[0], (1, 0, 2))), atol=1e-6 * np.abs(q[0]).max()))}))
+
+# ---- the configs[4] deck: OC4semi strip table (MacCamy-Fuchs + Kim & Yue), same 200 x 200 grid, Kim & Yue table + QTF launch
+fxo = standin.load_fixture("c5_oc4semi_qtf.npz")
+fo = standin.build_model(fxo["model"]).fowtList[0]
+tabo = rq.pack_qtf(fo)
+ko = np.array([waves.wave_number(x, fo.depth) for x in w2])
+Mso = np.array([fo.M_struc] * n_set)
+for _ in range(2):
+    t0 = time.perf_counter()
+    ctx.qtf_kay([tabo] * n_set, betas, w2, ko, fo.depth, fo.rho_water, fo.g)
+    ms_k = ctx.last_kernel_ms()
+    qo = ctx.qtf_slender([tabo] * n_set, Xi, betas, w2, ko, fo.depth, fo.rho_water, fo.g, Mso, None)
+    ms_q = ctx.last_kernel_ms()
+    wall = time.perf_counter() - t0
+So = tabo.strips.shape[0]
+print(json.dumps({"metric": "QTF strip-pairs per second, OC4semi-RAFT_QTF deck (configs[4])", "sets": n_set, "nw2": nw2, "strips": int(So),
+                  "qtf_kernels_ms": ms_q, "kim_yue_kernels_ms": ms_k, "strip_pairs_per_s": pairs * So / (ms_q * 1e-3),
+                  "wall_ms_incl_upload_and_download": 1e3 * wall,
+                  "one_200x200_qtf_ms": (ms_q + ms_k) / n_set, "reference_one_200x200_qtf_s_1core": 20100 * So * 0.58e-3}))
 
 # Kim & Yue correction table: OC4semi (MacCamy-Fuchs columns with heave plates), same 200 x 200 grid, device vs the
 # host SciPy implementation it replaces on the batched path

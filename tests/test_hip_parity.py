@@ -589,3 +589,22 @@ def test_bad_run_hints_are_demoted_not_trusted(hip_ctx, oracle_ctx):
     cases = synthetic_cases(rng, 1, 1, 64)
     _both(hip_ctx, oracle_ctx, [t], mats, cases)
     assert rel_err(hip_ctx.excitation(), oracle_ctx.excitation()) < TOL
+
+
+def test_ragged_batch_is_launched_per_lds_class(hip_ctx, oracle_ctx):
+    """Designs whose strip counts put different numbers of pairs on a CU (5 ... 210 strips at nw = 200) in one batch:
+    the fused kernel is launched once per LDS class through a pair list (raftx_hip.hip: solve_enqueue); every design,
+    wherever its class puts it, gets the response the oracle computes for it."""
+    rng = np.random.default_rng(77)
+    S_list, nw, nC = [20, 150, 53, 53, 97, 5, 210, 53], 200, 2
+    tables = [random_strips(rng, S, nw, 0.0) for S in S_list]
+    mats = random_matrices(rng, len(S_list), nw, False)
+    cases = synthetic_cases(rng, nC, 1, nw)
+    _both(hip_ctx, oracle_ctx, tables, mats, cases)
+    oh = hip_ctx.solve_dynamics(6, 0.01, 0.1)               # no optional outputs: the lean (sweep) specialisation
+    oo = oracle_ctx.solve_dynamics(6, 0.01, 0.1)
+    assert np.array_equal(oh["niter"], oo["niter"]) and np.array_equal(oh["flags"], oo["flags"])
+    for d in range(len(S_list)):
+        assert group_rel_err(oh["Xi"][d], oo["Xi"][d]) < TOL
+    again = hip_ctx.solve_dynamics(6, 0.01, 0.1)
+    assert np.array_equal(oh["Xi"].view(np.uint8), again["Xi"].view(np.uint8))
