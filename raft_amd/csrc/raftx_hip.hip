@@ -847,7 +847,10 @@ static int build_phase1(raftx_ctx *c, hipStream_t sCopy, hipStream_t sPrep, int 
 
 // Phase 2: waits (host) for the totals of phase 1, sizes the strip tables, and enqueues strip generation, the MacCamy-
 // Fuchs table and the per-design reduction on the ctx stream, ordered behind phase 1 by evTot.  Does not wait for them.
-static int build_phase2(raftx_ctx *c, int64_t *stripOffsets) {
+// sGen: the stream the generation kernels go to (null: the ctx stream).  The sweep crossing gives the preparation stream
+// for every block but the first, so that a block's tables are generated WHILE the fused kernel of the block before it
+// runs (they fill the CUs its last residency round leaves idle); the ctx stream is ordered behind them by evG1.
+static int build_phase2(raftx_ctx *c, int64_t *stripOffsets, hipStream_t sGen = nullptr) {
     BuildJob &J = c->job;
     if (!J.active) FAIL(c, "build_designs: phase 2 without phase 1");
     GeomArgs &A = J.A;
@@ -884,16 +887,18 @@ static int build_phase2(raftx_ctx *c, int64_t *stripOffsets) {
         FAIL(c, "build_designs: a design has %d submerged strips (at most %d supported)", maxS, (int)((160 * 1024 - 16) / (8 * (GD_ROW + 2) + 12)));
     if (gd_lds > 64 * 1024)
         HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void *>(k_geom_design), hipFuncAttributeMaxDynamicSharedMemorySize, (int)gd_lds));
-    HIPCHK(c, hipStreamWaitEvent(c->stream, c->evTot, 0));
-    HIPCHK(c, hipEventRecord(c->evG0, c->stream));
-    if (J.nMember > 0) hipLaunchKernelGGL(k_geom_fill, dim3((unsigned)J.nMember), dim3(64), 0, c->stream, A);
+    if (!sGen) sGen = c->stream;
+    HIPCHK(c, hipStreamWaitEvent(sGen, c->evTot, 0));
+    HIPCHK(c, hipEventRecord(c->evG0, sGen));
+    if (J.nMember > 0) hipLaunchKernelGGL(k_geom_fill, dim3((unsigned)J.nMember), dim3(64), 0, sGen, A);
     if (nRows > 0)
-        hipLaunchKernelGGL(k_geom_mcf, dim3((unsigned)nRows, (unsigned)((nw + 63) / 64)), dim3(64), 0, c->stream, A, (int64_t)nRows);
+        hipLaunchKernelGGL(k_geom_mcf, dim3((unsigned)nRows, (unsigned)((nw + 63) / 64)), dim3(64), 0, sGen, A, (int64_t)nRows);
     if (nDesign > 0) {
-        hipLaunchKernelGGL(k_geom_reduce, dim3((unsigned)(((size_t)nDesign * 3 + 63) / 64)), dim3(64), 0, c->stream, A);
-        hipLaunchKernelGGL(k_geom_design, dim3((unsigned)nDesign), dim3(64), gd_lds, c->stream, A);
+        hipLaunchKernelGGL(k_geom_reduce, dim3((unsigned)(((size_t)nDesign * 3 + 63) / 64)), dim3(64), 0, sGen, A);
+        hipLaunchKernelGGL(k_geom_design, dim3((unsigned)nDesign), dim3(64), gd_lds, sGen, A);
     }
-    HIPCHK(c, hipEventRecord(c->evG1, c->stream));
+    HIPCHK(c, hipEventRecord(c->evG1, sGen));
+    if (sGen != c->stream) HIPCHK(c, hipStreamWaitEvent(c->stream, c->evG1, 0));
     DevTables &T = c->T;
     T.nDesign = nDesign;
     T.off = A.off;
@@ -1939,6 +1944,9 @@ extern "C" int raftx_sweep_stats(raftx_ctx *c, int nDesign, const int64_t *membe
     if (nChunk > 64) nChunk = 64;
     HIPCHK(c, hipSetDevice(c->device));
     const auto t0 = std::chrono::steady_clock::now();
+    static const bool dbg_host = getenv("RAFTX_SWEEP_DEBUG") != nullptr;
+    auto since = [&]() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(); };
+    double tl[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     if (!c->sCopy) {
         HIPCHK(c, hipStreamCreateWithFlags(&c->sCopy, hipStreamNonBlocking));
         HIPCHK(c, hipStreamCreateWithFlags(&c->sPrep, hipStreamNonBlocking));
@@ -1966,6 +1974,7 @@ extern "C" int raftx_sweep_stats(raftx_ctx *c, int nDesign, const int64_t *membe
     const double dw = nw > 1 ? w[1] - w[0] : w[0];
     HIPCHK(c, hipStreamSynchronize(c->stream));          // nothing of an earlier call may still read the blocks' tables
     std::vector<raftx_ctx *> blk(nB, nullptr);
+    tl[0] = since();
     // ---- the batch's offset arrays: one upload, shared by the blocks
     free_list(c, c->sweep_allocs);
     DevOffsets dOff{nullptr, nullptr, nullptr};
@@ -1990,13 +1999,18 @@ extern "C" int raftx_sweep_stats(raftx_ctx *c, int nDesign, const int64_t *membe
             return rc;
         }
     }
+    tl[1] = since();
     // ---- phase 2 + fixed point + statistics of every block, in order, on the ctx stream
     int rc_all = 0;
     for (size_t b = 0; b < nB && !rc_all; b++) {
         raftx_ctx *sub = blk[b];
         const int lo = bnd[b], n = bnd[b + 1] - lo;
         const size_t npair = (size_t)n * nCase;
-        int rc = build_phase2(sub, nullptr);
+        // measured (profiles/r02_crossing_splits.txt): generating a block's tables beside the fused kernel of the block
+        // before it gains nothing (the block's descriptor upload is what it waits for) and inflates the kernel's timed
+        // duration, so the default keeps everything on the ctx stream; RAFTX_SWEEP_GEN_OVERLAP=1 turns the overlap on
+        static const bool gen_overlap = getenv("RAFTX_SWEEP_GEN_OVERLAP") && atoi(getenv("RAFTX_SWEEP_GEN_OVERLAP"));
+        int rc = build_phase2(sub, nullptr, (b > 0 && gen_overlap) ? c->sPrep : nullptr);
         if (!rc) {                                                      // the sea states of the parent
             DevTables &T = sub->T;
             const DevTables &P = c->T;
@@ -2064,7 +2078,9 @@ extern "C" int raftx_sweep_stats(raftx_ctx *c, int nDesign, const int64_t *membe
             }
         }
     }
+    tl[2] = since();
     hipError_t es = hipStreamSynchronize(c->stream);
+    tl[3] = since();
     hipError_t e2 = hipStreamSynchronize(c->sD2H);
     hipError_t e3 = hipStreamSynchronize(c->sPrep);
     hipError_t e4 = hipStreamSynchronize(c->sCopy);
@@ -2098,6 +2114,9 @@ extern "C" int raftx_sweep_stats(raftx_ctx *c, int nDesign, const int64_t *membe
         memcpy(flags + p0, reinterpret_cast<int *>(sub->pinRes + npair * 6) + npair, npair * sizeof(int));
     }
     const double wall = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    if (dbg_host)
+        fprintf(stderr, "[raftx_sweep_stats] host ms: pre %.3f | phase-1 enqueued %.3f | phase-2 enqueued %.3f | compute stream drained %.3f | done %.3f\n",
+                tl[0], tl[1], tl[2], tl[3], wall);
     if (timing_ms) { timing_ms[0] = wall; timing_ms[1] = tb; timing_ms[2] = ts; timing_ms[3] = tst; }
     c->last_ms = ts;
     return 0;

@@ -33,46 +33,78 @@ class UnsupportedMember(Exception):
     """Member outside the device generator's scope (flexible 'beam' members)."""
 
 
-def _get(d, key, shape=0, dtype=float, default=None, index=None):
-    """Value of ``key`` with the reference's broadcasting rules (helpers.py:828-915): scalars tile to ``shape``;
-    1-D lists must match ``shape`` (with ``index``: a 1-D list is one [p1, p2] pair, a 2-D list a column);
-    ``shape`` 0 = scalar, -1 = as given."""
-    if key in d:
-        val = d[key]
-        if shape == 0:
-            if np.isscalar(val):
-                return dtype(val)
-            raise ValueError("Value for key '%s' is expected to be a scalar but instead is: %s" % (key, val))
-        if shape == -1:
-            return dtype(val) if np.isscalar(val) else np.array(val, dtype=dtype)
-        if np.isscalar(val):
-            return np.tile(dtype(val), shape)
-        if np.isscalar(shape):
-            if len(val) != shape:
-                raise ValueError("Value for key '%s' is not the expected size of %s and is instead: %s" % (key, shape, val))
-            if index is None:
-                return np.array([dtype(v) for v in val])
-            a = np.array(val)
-            if a.ndim == 1:
-                if index not in range(a.shape[0]):
-                    raise ValueError("Value for index '%s' is not within the size of %s" % (index, val))
-                return np.tile(val[index], shape)
-            if index not in range(a.shape[1]):
-                raise ValueError("Value for index '%s' is not within the size of %s" % (index, val))
-            return np.array([v[index] for v in val])
-        a = np.array(val, dtype=dtype)
-        if list(a.shape) == list(shape):
-            return a
-        if a.ndim == 1 and len(a) == shape[1]:
-            return np.tile(a, [shape[0], 1])
-        raise ValueError("Value for key '%s' is not a compatible size for target size of %s" % (key, shape))
-    if default is None:
-        raise ValueError("Key '%s' not found in input file..." % key)
-    if shape == 0 or shape == -1:
+# ---- reading a member entry of the YAML.  The deck format is upstream's (a member lists its stations and gives
+# every per-station quantity either once or once per station; coefficient pairs are [p1, p2], helpers.py:828-915 is the
+# reader upstream applies); each kind of entry has its own small reader here.
+class DeckError(ValueError):
+    pass
+
+
+def _scalar(entry, key, default=None, kind=float):
+    """A single value; a list where one value is expected is an error of the deck."""
+    if key not in entry:
+        if default is None:
+            raise DeckError("Key '%s' not found in input file..." % key)
         return default
-    if np.isscalar(default):
-        return np.tile(default, shape)
-    return np.tile(default, [shape, 1])
+    v = entry[key]
+    if not np.isscalar(v):
+        raise DeckError("Value for key '%s' is expected to be a scalar but instead is: %s" % (key, v))
+    return kind(v)
+
+
+def _as_given(entry, key, default):
+    """A value of whatever shape the deck gives it (scalar or list)."""
+    if key not in entry:
+        return default
+    v = entry[key]
+    return float(v) if np.isscalar(v) else np.array(v, dtype=float)
+
+
+def _per_station(entry, key, n, default=None):
+    """One value per station: a scalar applies to all n stations, a list must have n items."""
+    if key not in entry:
+        if default is None:
+            raise DeckError("Key '%s' not found in input file..." % key)
+        return np.tile(default, n)
+    v = entry[key]
+    if np.isscalar(v):
+        return np.tile(float(v), n)
+    if len(v) != n:
+        raise DeckError("Value for key '%s' is not the expected size of %s and is instead: %s" % (key, n, v))
+    return np.array([float(x) for x in v])
+
+
+def _per_station_side(entry, key, n, side, default):
+    """Coefficient of cross-section axis ``side`` (0: p1, 1: p2) per station.  The deck may give one number, one
+    [p1, p2] pair for the whole member (a flat list of length n = 2 is read that way, as upstream reads it), or one
+    pair per station."""
+    if key not in entry:
+        return np.tile(default, n)
+    v = entry[key]
+    if np.isscalar(v):
+        return np.tile(float(v), n)
+    if len(v) != n:
+        raise DeckError("Value for key '%s' is not the expected size of %s and is instead: %s" % (key, n, v))
+    a = np.array(v)
+    width = a.shape[0] if a.ndim == 1 else a.shape[1]
+    if side not in range(width):
+        raise DeckError("Value for index '%s' is not within the size of %s" % (side, v))
+    return np.tile(v[side], n) if a.ndim == 1 else np.array([row[side] for row in v])
+
+
+def _per_station_pair(entry, key, n):
+    """[n, 2] side lengths of a rectangular member: one [a, b] pair for all stations or one per station."""
+    if key not in entry:
+        raise DeckError("Key '%s' not found in input file..." % key)
+    v = entry[key]
+    if np.isscalar(v):
+        return np.tile(float(v), [n, 2])
+    a = np.array(v, dtype=float)
+    if list(a.shape) == [n, 2]:
+        return a
+    if a.ndim == 1 and len(a) == 2:
+        return np.tile(a, [n, 1])
+    raise DeckError("Value for key '%s' is not a compatible size for target size of %s" % (key, [n, 2]))
 
 
 def _heading(r, heading):
@@ -94,7 +126,7 @@ def describe_member(mi, heading=0.0, part_of="platform"):
     if rA0[2] == 0 or rB0[2] == 0:
         raise ValueError("RAFT Members cannot start or end on the waterplane")
     shape = str(mi["shape"])
-    gamma = _get(mi, "gamma", default=0.)
+    gamma = _scalar(mi, "gamma", default=0.)
     rAB = rB0 - rA0
     length = np.linalg.norm(rAB)
     if heading != 0.0:
@@ -112,26 +144,26 @@ def describe_member(mi, heading=0.0, part_of="platform"):
     gs[:, GS_S] = (st - st[0]) / (st[-1] - st[0]) * length
     if shape[0].lower() == "c":
         circ = True
-        d = _get(mi, "d", shape=n)
+        d = _per_station(mi, "d", n)
         gs[:, GS_D] = d
         gs[:, GS_D + 1] = d
         gamma = 0
     elif shape[0].lower() == "r":
         circ = False
-        gs[:, GS_D:GS_D + 2] = _get(mi, "d", shape=[n, 2])
+        gs[:, GS_D:GS_D + 2] = _per_station_pair(mi, "d", n)
     else:
         raise ValueError("The only allowable shape strings are circular and rectangular")
-    mcf = bool(_get(mi, "MCF", dtype=bool, default=False)) and circ
-    potmod = bool(_get(mi, "potMod", dtype=bool, default=False))
-    gs[:, GS_T] = _get(mi, "t", shape=n, default=0)
-    st_fill = _get(mi, "l_fill", shape=n - 1, default=0)
+    mcf = bool(_scalar(mi, "MCF", default=False, kind=bool)) and circ
+    potmod = bool(_scalar(mi, "potMod", default=False, kind=bool))
+    gs[:, GS_T] = _per_station(mi, "t", n, default=0)
+    st_fill = _per_station(mi, "l_fill", n - 1, default=0)
     for i in range(n - 1):
         if st_fill[i] < 0:
             raise Exception("Member %s: ballast level in section %d is negative." % (mi.get("name", "?"), i + 1))
         if st_fill[i] > st[i + 1] - st[i]:
             raise Exception("Member %s: ballast level in section %d exceeds section length." % (mi.get("name", "?"), i + 1))
     gs[:n - 1, GS_LFILL] = st_fill / (st[-1] - st[0]) * length
-    rho_fill = _get(mi, "rho_fill", shape=-1, default=1025)
+    rho_fill = _as_given(mi, "rho_fill", 1025)
     if np.isscalar(rho_fill):
         gs[:n - 1, GS_RHOFILL] = rho_fill
     elif len(rho_fill) == n - 1:
@@ -139,35 +171,35 @@ def describe_member(mi, heading=0.0, part_of="platform"):
     else:
         raise Exception("Member %s: the number of provided ballast densities (rho_fill) must be 1 less than the "
                         "number of stations." % mi.get("name", "?"))
-    gs[:, GS_CD + 0] = _get(mi, "Cd_q", shape=n, default=0.0)
-    gs[:, GS_CD + 1] = _get(mi, "Cd", shape=n, default=0.6, index=0)
-    gs[:, GS_CD + 2] = _get(mi, "Cd", shape=n, default=0.6, index=1)
-    gs[:, GS_CD + 3] = _get(mi, "CdEnd", shape=n, default=0.6)
-    gs[:, GS_CA + 0] = _get(mi, "Ca_q", shape=n, default=0.0)
-    gs[:, GS_CA + 1] = _get(mi, "Ca", shape=n, default=0.97, index=0)
-    gs[:, GS_CA + 2] = _get(mi, "Ca", shape=n, default=0.97, index=1)
-    gs[:, GS_CA + 3] = _get(mi, "CaEnd", shape=n, default=0.6)
+    gs[:, GS_CD + 0] = _per_station(mi, "Cd_q", n, default=0.0)
+    gs[:, GS_CD + 1] = _per_station_side(mi, "Cd", n, 0, 0.6)
+    gs[:, GS_CD + 2] = _per_station_side(mi, "Cd", n, 1, 0.6)
+    gs[:, GS_CD + 3] = _per_station(mi, "CdEnd", n, default=0.6)
+    gs[:, GS_CA + 0] = _per_station(mi, "Ca_q", n, default=0.0)
+    gs[:, GS_CA + 1] = _per_station_side(mi, "Ca", n, 0, 0.97)
+    gs[:, GS_CA + 2] = _per_station_side(mi, "Ca", n, 1, 0.97)
+    gs[:, GS_CA + 3] = _per_station(mi, "CaEnd", n, default=0.6)
     gm = np.zeros(GM_N)
     gm[GM_RA:GM_RA + 3] = rA0
     gm[GM_RB:GM_RB + 3] = rB0
     gm[GM_GAMMA] = gamma
     gm[GM_SHAPE] = 1.0 if circ else 0.0
-    gm[GM_DLSMAX] = _get(mi, "dlsMax", shape=0, default=5)
+    gm[GM_DLSMAX] = _scalar(mi, "dlsMax", default=5)
     gm[GM_FLAGS] = (FLAG_POTMOD if potmod else 0) | (FLAG_MCF if mcf else 0) | \
                    (FLAG_NOSTATIC if part_of == "nacelle" else 0)
     gm[GM_L] = length
-    gm[GM_RHOSHELL] = _get(mi, "rho_shell", shape=0, default=8500.)
+    gm[GM_RHOSHELL] = _scalar(mi, "rho_shell", default=8500.)
     # end caps / bulkheads (raft_member.py:162-175)
-    cap_st = _get(mi, "cap_stations", shape=-1, default=[])
+    cap_st = _as_given(mi, "cap_stations", [])
     cap_st = np.atleast_1d(np.array(cap_st, dtype=float))
     caps = np.zeros((len(cap_st), GC_N))
     if len(cap_st):
         caps[:, 0] = (cap_st - st[0]) / (st[-1] - st[0]) * length
-        caps[:, 1] = _get(mi, "cap_t", shape=len(cap_st))
+        caps[:, 1] = _per_station(mi, "cap_t", len(cap_st))
         if circ:
-            caps[:, 2] = _get(mi, "cap_d_in", shape=len(cap_st))
+            caps[:, 2] = _per_station(mi, "cap_d_in", len(cap_st))
         else:
-            caps[:, 2:4] = _get(mi, "cap_d_in", shape=[len(cap_st), 2])
+            caps[:, 2:4] = _per_station_pair(mi, "cap_d_in", len(cap_st))
     return gm, gs, caps
 
 
@@ -196,8 +228,8 @@ def describe_unit(design, heading_adjust=0.0, include_turbine=True):
     if "joints" in design:
         raise UnsupportedMember("designs with explicit joints (multi-body / flexible units) are not generated on the device")
     plat = design["platform"]
-    pmm = int(_get(plat, "potModMaster", dtype=int, default=0))
-    dls_default = _get(plat, "dlsMax", default=5.0)
+    pmm = int(_scalar(plat, "potModMaster", default=0, kind=int))
+    dls_default = _scalar(plat, "dlsMax", default=5.0)
     gms, gss, gcs = [], [], []
     for mi in plat["members"]:
         mi = dict(mi)
@@ -207,7 +239,7 @@ def describe_unit(design, heading_adjust=0.0, include_turbine=True):
             mi["potMod"] = True
         if "dlsMax" not in mi:
             mi["dlsMax"] = dls_default
-        headings = _get(mi, "heading", shape=-1, default=0.)
+        headings = _as_given(mi, "heading", 0.)
         if np.isscalar(headings):
             headings = [headings]
         for h in headings:
@@ -217,7 +249,7 @@ def describe_unit(design, heading_adjust=0.0, include_turbine=True):
             gcs.append(gc)
     if include_turbine and "turbine" in design and design["turbine"] is not None:
         turb = design["turbine"]
-        nrotors = int(_get(turb, "nrotors", dtype=int, shape=0, default=1))
+        nrotors = int(_scalar(turb, "nrotors", default=1, kind=int))
         for key in ("tower", "nacelle"):
             if key in turb:
                 items = turb[key]
