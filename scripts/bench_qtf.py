@@ -4,7 +4,7 @@ MacCamy-Fuchs columns with heave plates, inclined braces, Kim & Yue correction).
 stream; the numpy oracle timed on a 40 x 40 sub-grid as the CPU datapoint)."""
 import json, os, sys, time
 import numpy as np
-sys.path.insert(0, os.getcwd())
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from raft_amd import backend, qtf as rq, waves
 from raft_amd import snapshot as standin
 
