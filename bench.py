@@ -176,6 +176,8 @@ def main():
     ap.add_argument("--xi-out", action="store_true", help="download the full responses inside the step as well")
     ap.add_argument("--pageable", action="store_true", help="descriptors in ordinary NumPy memory instead of page-locked")
     ap.add_argument("--resident", action="store_true", help="also time the fused kernel alone, whole batch resident in HBM")
+    ap.add_argument("--no-stream", action="store_true", help="time isolated blocking calls (raftx_sweep_stats) instead of streaming the "
+                                                             "steps through the library's two slots (raftx_sweep_submit / _wait)")
     ap.add_argument("--no-cpu-baseline", action="store_true", help="skip the oracle leg (cpu_baseline and the all-design check)")
     args = ap.parse_args()
 
@@ -205,17 +207,38 @@ def main():
 
     comm = None
     gather_kind = None
+    ctx_comm = None
     if world > 1:
         from raft_amd import comm as rcomm
-        comm, gather_kind = rcomm.from_env(ctx, prefer="rccl" if backend_name == "nccl" else "host")
+        # the exchange step gets its own context (= its own stream): the gather of step i must not queue behind the
+        # kernels of step i + 1, which are already on the solver context's stream when the steps are streamed
+        ctx_comm = backend.hip_library().context(local)
+        comm, gather_kind = rcomm.from_env(ctx_comm, prefer="rccl" if backend_name == "nccl" else "host")
 
-    Xi_pinned = ctx.pinned_empty((nD, 1, 1, 6, nw)) if args.xi_out else None
+    stream_steps = not args.no_stream
+    Xi_pinned = [ctx.pinned_empty((nD, 1, 1, 6, nw)) for _ in range(2 if stream_steps else 1)] if args.xi_out else [None, None]
 
-    def step():
-        r = sw.run_crossing(ctx, n_chunk=args.chunks, n_worker=args.workers, Xi_out=Xi_pinned)
+    def gather(r):
         if comm is not None:                              # statistics of every rank onto rank 0 (48 B + 8 B per design-case)
             r["std_all"] = comm.gather_rows(np.concatenate([r["std"].reshape(nD, -1), r["niter"].reshape(nD, -1).astype(np.float64)], axis=1))
         return r
+
+    def step():                                           # one isolated, blocking crossing
+        return gather(sw.run_crossing(ctx, n_chunk=args.chunks, n_worker=args.workers, Xi_out=Xi_pinned[0]))
+
+    def run_steps(n):
+        """n whole solver-stage steps; returns the per-step results.  Streamed: step i + 1 is submitted (its descriptor
+        upload and member pass start) before step i is collected, as consecutive batches of a long sweep are; every
+        step still moves its own descriptors in and its own statistics out."""
+        if not stream_steps:
+            return [step() for _ in range(n)]
+        out = []
+        h = sw.submit_crossing(ctx, 0, n_chunk=args.chunks, Xi_out=Xi_pinned[0]) if n > 0 else None
+        for i in range(n):
+            h_next = sw.submit_crossing(ctx, (i + 1) % 2, n_chunk=args.chunks, Xi_out=Xi_pinned[(i + 1) % 2]) if i + 1 < n else None
+            out.append(gather(sw.wait_crossing(ctx, h)))
+            h = h_next
+        return out
 
     def barrier():
         if dist is not None:
@@ -224,16 +247,20 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        step()
+    run_steps(args.warmup)
     barrier()
     t0 = time.perf_counter()
-    tims = []
-    for _ in range(args.steps):
-        r = step()                                        # returns after every stream of the call has drained
-        tims.append(r["timing_ms"])
+    res = run_steps(args.steps)                           # returns after the last step's streams have drained
     barrier()
     elapsed = time.perf_counter() - t0
+    r = res[-1]
+    tims = [x["timing_ms"] for x in res]
+    isolated = None
+    if stream_steps and rank == 0:                        # the same step as an isolated blocking call (outside the timed region)
+        t1 = time.perf_counter()
+        for _ in range(5):                                # (no gather here: only this rank runs it)
+            sw.run_crossing(ctx, n_chunk=args.chunks, n_worker=args.workers, Xi_out=Xi_pinned[0])
+        isolated = (time.perf_counter() - t1) / 5
     if dist is not None:
         import torch
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if backend_name == "nccl" else "cpu")
@@ -248,6 +275,8 @@ def main():
 
     # ---- parity of the timed batch (outside the timed region): one more crossing with the responses downloaded
     chk = sw.run_crossing(ctx, n_chunk=args.chunks, n_worker=args.workers, want_Xi=True)
+    for x in res:                                         # every timed step produced the same bits
+        assert np.array_equal(x["std"].view(np.uint64), r["std"].view(np.uint64)) and np.array_equal(x["niter"], r["niter"])
     assert np.array_equal(chk["std"].view(np.uint64), r["std"].view(np.uint64)) and np.array_equal(chk["niter"], niter), \
         "two crossings of the same batch differ"
     Xi = chk["Xi"]
@@ -303,13 +332,19 @@ def main():
                                "nIter=4, tol=0.01; designs = distinct U[0.75,1.25]^5 variants (default_rng(0))" % (nD, nw),
                    "designs_per_gpu": nD, "cases": 1, "nw": nw,
                    "step": "whole solver stage (SURVEY 8d): descriptor H2D + table/statics generation + fused fixed point + "
-                           "statistics + D2H of %s, one library call (raftx_sweep_stats)"
-                           % ("statistics and full responses" if args.xi_out else "statistics (\"stats out\")"),
+                           "statistics + D2H of %s; %s"
+                           % ("statistics and full responses" if args.xi_out else "statistics (\"stats out\")",
+                              "steps streamed through the library's two slots (raftx_sweep_submit / raftx_sweep_wait): the descriptor "
+                              "upload and member pass of step i+1 run beside the kernels of step i, as consecutive batches of a long "
+                              "sweep do; every step moves its own 66 MB in and its own statistics out" if stream_steps
+                              else "isolated blocking calls (raftx_sweep_stats)"),
+                   "streamed": bool(stream_steps),
                    "state": "xi out" if args.xi_out else "stats out",
                    "sharding": "designs over ranks, no collective while solving; statistics gathered to rank 0 inside the step"
                                if world > 1 else "single GPU",
                    "gather": gather_kind},
-        "step_breakdown_ms": {"wall_in_library": float(np.mean(tims[:, 0])), "generation_kernels_sum": float(np.mean(tims[:, 1])),
+        "step_breakdown_ms": {("latency_submit_to_collected" if stream_steps else "wall_in_library"): float(np.mean(tims[:, 0])),
+                              "generation_kernels_sum": float(np.mean(tims[:, 1])),
                               "solve_kernels_sum": k_sum_ms, "statistics_kernels_sum": float(np.mean(tims[:, 3]))},
         "parity": parity,
         "mean_iterations": float(np.mean(niter)),
@@ -323,6 +358,10 @@ def main():
                                "algorithmic_flops_per_step": flops},
         "geometry": dict(geo, strips=int(off[-1]), strip_table_bytes_not_uploaded=int(off[-1]) * 256),
     }
+    if isolated is not None:
+        out["isolated_call"] = {"ms_per_step": 1e3 * isolated, "dcf_per_s_per_gpu": n_dcf_rank / isolated,
+                                "note": "the same step as one blocking raftx_sweep_stats call with nothing else in flight "
+                                        "(upload of all descriptors on the critical path)"}
     if resident is not None:
         out["kernel_resident"] = resident
     ref_path = os.path.join(ROOT, "profiles", "reference_cpu_timing.json")
@@ -339,6 +378,8 @@ def main():
         print(json.dumps(out))
     if comm is not None:
         comm.close()
+    if ctx_comm is not None:
+        ctx_comm.close()
     if dist is not None:
         dist.destroy_process_group()
 

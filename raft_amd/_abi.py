@@ -27,6 +27,8 @@ EXPORTS = (
     "raftx_solve_dynamics_device", "raftx_fetch_results", "raftx_debug_math", "raftx_motion_stats", "raftx_solve_system_resident", "raftx_qtf_slender", "raftx_channel_stats", "raftx_qtf_force", "raftx_set_linearisation_point", "raftx_fetch_linearisation_point",
     "raftx_build_designs", "raftx_fetch_strips", "raftx_fetch_statics", "raftx_channel_stats_poly", "raftx_qtf_slender_rows", "raftx_bem_excitation", "raftx_qtf_kay", "raftx_host_alloc", "raftx_host_free",
     "raftx_sweep_stats",
+    "raftx_sweep_submit",
+    "raftx_sweep_wait",
     "raftx_comm_unique_id", "raftx_comm_init", "raftx_comm_destroy", "raftx_comm_broadcast", "raftx_comm_gather_rows",
     "raftx_comm_gather_xi", "raftx_comm_reduce_sum",
 )
@@ -137,6 +139,12 @@ class RaftxLib:
                                         C.c_double, _vp, _vp, C.c_int, C.c_double, C.c_double, C.c_int, C.c_int,
                                         _vp, _vp, _vp, _vp, _vp, _vp]
         L.raftx_sweep_stats.restype = C.c_int
+        L.raftx_sweep_submit.argtypes = [_vp, C.c_int, C.c_int, _vp, _vp, _vp, _vp, _vp, _vp, _vp, C.c_double, C.c_double, C.c_int,
+                                         _vp, _vp, _vp, _vp, C.c_int, C.c_int, C.c_int, _vp, _vp, C.c_double, C.c_double, C.c_double,
+                                         _vp, _vp, C.c_int, C.c_double, C.c_double, C.c_int, _vp, _vp, _vp, _vp, _vp]
+        L.raftx_sweep_submit.restype = C.c_int
+        L.raftx_sweep_wait.argtypes = [_vp, C.c_int, _vp]
+        L.raftx_sweep_wait.restype = C.c_int
         L.raftx_comm_unique_id.argtypes = [_vp, _vp]
         L.raftx_comm_init.argtypes = [_vp, C.c_int, C.c_int, _vp]
         L.raftx_comm_destroy.argtypes = [_vp]
@@ -275,15 +283,8 @@ class Context:
         self._strip_off = off
         return off
 
-    def sweep_stats(self, tables, M0, B0, C0, w, k, depth, zeta, beta, nIter, tol=0.01, XiStart=0.1, pose=None,
-                    rho=1025.0, g=9.81, rho_wave=1025.0, g_wave=9.81, add_mask=7, Fz_moor=None, n_chunk=0, n_worker=0,
-                    want_Xi=False, Xi_out=None):
-        """One whole sweep crossing in ONE library call (raftx_sweep_stats): member descriptions (``tables``: a
-        raft_amd.geometry.DesignTables) in, motion statistics + iteration counts (+ responses) out; inside the library the
-        designs are cut into blocks whose descriptor upload, table generation, fixed-point kernel and downloads overlap
-        on internal streams.  Returns dict(std [nD,nC,6], niter, flags [nD,nC], Xi or None, strip_off [nD+1],
-        timing_ms [wall, generation kernels, solve kernels, statistics kernels]).  Unlike build_designs + solve, nothing
-        stays resident on this context afterwards."""
+    def _sweep_prepare(self, tables, M0, B0, C0, w, k, depth, zeta, beta, pose, Fz_moor, want_Xi, Xi_out):
+        """Checked, contiguous views of the inputs of a sweep crossing + freshly allocated outputs."""
         member_off = np.ascontiguousarray(tables.member_off, dtype=np.int64)
         station_off = np.ascontiguousarray(tables.station_off, dtype=np.int64)
         nD = len(member_off) - 1
@@ -307,24 +308,60 @@ class Context:
         nC, nH = zeta.shape[0], zeta.shape[1]
         zeta = _f64(zeta, (nC, nH, nw), "zeta")
         beta = _f64(beta, (nC, nH), "beta")
-        std = np.empty((nD, nC, 6))
-        niter = np.zeros((nD, nC), dtype=np.int32)
-        flags = np.zeros((nD, nC), dtype=np.int32)
         Xi = Xi_out
         if Xi is None and want_Xi:
             Xi = np.empty((nD, nC, nH, 6, nw), dtype=np.complex128)
         if Xi is not None and (Xi.dtype != np.complex128 or Xi.shape != (nD, nC, nH, 6, nw) or not Xi.flags["C_CONTIGUOUS"]):
             raise ValueError("Xi_out must be a C-contiguous complex128 array of shape %s" % ((nD, nC, nH, 6, nw),))
-        off = np.zeros(nD + 1, dtype=np.int64)
-        timing = np.zeros(4)
+        out = dict(std=np.empty((nD, nC, 6)), niter=np.zeros((nD, nC), dtype=np.int32), flags=np.zeros((nD, nC), dtype=np.int32),
+                   Xi=Xi, strip_off=np.zeros(nD + 1, dtype=np.int64), timing_ms=np.zeros(4))
+        inputs = (member_off, members, station_off, stations, cap_off, caps, pose, M0, B0, C0, Fz, w, k, zeta, beta)
+        return nD, nC, nH, nw, inputs, out
+
+    def sweep_submit(self, slot, tables, M0, B0, C0, w, k, depth, zeta, beta, nIter, tol=0.01, XiStart=0.1, pose=None,
+                     rho=1025.0, g=9.81, rho_wave=1025.0, g_wave=9.81, add_mask=7, Fz_moor=None, n_chunk=0, want_Xi=False,
+                     Xi_out=None):
+        """Enqueue one sweep crossing on ``slot`` (0 or 1) and return a handle for ``sweep_wait`` (raftx_sweep_submit): the
+        call returns once the kernels are queued, so the upload of the next batch can overlap them.  The handle keeps the
+        input and output arrays alive; do not modify the inputs before ``sweep_wait``."""
+        nD, nC, nH, nw, inputs, out = self._sweep_prepare(tables, M0, B0, C0, w, k, depth, zeta, beta, pose, Fz_moor, want_Xi, Xi_out)
+        (member_off, members, station_off, stations, cap_off, caps, pose, M0, B0, C0, Fz, w, k, zeta, beta) = inputs
+        rc = self.rlib.lib.raftx_sweep_submit(self._h, int(slot), nD, _ptr(member_off), _ptr(members), _ptr(station_off), _ptr(stations),
+                                              _ptr(cap_off), _ptr(caps), _ptr(pose), float(rho), float(g), int(add_mask),
+                                              _ptr(M0), _ptr(B0), _ptr(C0), _ptr(Fz), nC, nH, nw, _ptr(w), _ptr(k), float(depth),
+                                              float(rho_wave), float(g_wave), _ptr(zeta), _ptr(beta), int(nIter), float(tol),
+                                              float(XiStart), int(n_chunk), _ptr(out["std"]), _ptr(out["niter"]), _ptr(out["flags"]),
+                                              _ptr(out["Xi"]), _ptr(out["strip_off"]))
+        self._check(rc, "raftx_sweep_submit")
+        return dict(slot=int(slot), inputs=inputs, out=out)
+
+    def sweep_wait(self, handle):
+        """Block until the crossing of ``handle`` (from ``sweep_submit``) has finished; returns its results
+        (dict as ``sweep_stats``)."""
+        out = handle["out"]
+        self._check(self.rlib.lib.raftx_sweep_wait(self._h, int(handle["slot"]), _ptr(out["timing_ms"])), "raftx_sweep_wait")
+        handle["inputs"] = None
+        return out
+
+    def sweep_stats(self, tables, M0, B0, C0, w, k, depth, zeta, beta, nIter, tol=0.01, XiStart=0.1, pose=None,
+                    rho=1025.0, g=9.81, rho_wave=1025.0, g_wave=9.81, add_mask=7, Fz_moor=None, n_chunk=0, n_worker=0,
+                    want_Xi=False, Xi_out=None):
+        """One whole sweep crossing in ONE library call (raftx_sweep_stats): member descriptions (``tables``: a
+        raft_amd.geometry.DesignTables) in, motion statistics + iteration counts (+ responses) out; inside the library the
+        designs are cut into blocks whose descriptor upload, table generation, fixed-point kernel and downloads are
+        pipelined over internal streams.  Returns dict(std [nD,nC,6], niter, flags [nD,nC], Xi or None, strip_off [nD+1],
+        timing_ms [wall, generation kernels, solve kernels, statistics kernels]).  Unlike build_designs + solve, nothing
+        stays resident on this context afterwards."""
+        nD, nC, nH, nw, inputs, out = self._sweep_prepare(tables, M0, B0, C0, w, k, depth, zeta, beta, pose, Fz_moor, want_Xi, Xi_out)
+        (member_off, members, station_off, stations, cap_off, caps, pose, M0, B0, C0, Fz, w, k, zeta, beta) = inputs
         rc = self.rlib.lib.raftx_sweep_stats(self._h, nD, _ptr(member_off), _ptr(members), _ptr(station_off), _ptr(stations),
                                              _ptr(cap_off), _ptr(caps), _ptr(pose), float(rho), float(g), int(add_mask),
                                              _ptr(M0), _ptr(B0), _ptr(C0), _ptr(Fz), nC, nH, nw, _ptr(w), _ptr(k), float(depth),
                                              float(rho_wave), float(g_wave), _ptr(zeta), _ptr(beta), int(nIter), float(tol),
-                                             float(XiStart), int(n_chunk), int(n_worker), _ptr(std), _ptr(niter), _ptr(flags),
-                                             _ptr(Xi), _ptr(off), _ptr(timing))
+                                             float(XiStart), int(n_chunk), int(n_worker), _ptr(out["std"]), _ptr(out["niter"]),
+                                             _ptr(out["flags"]), _ptr(out["Xi"]), _ptr(out["strip_off"]), _ptr(out["timing_ms"]))
         self._check(rc, "raftx_sweep_stats")
-        return dict(std=std, niter=niter, flags=flags, Xi=Xi, strip_off=off, timing_ms=timing)
+        return out
 
     def fetch_strips(self, n_strips, n_cm_rows=0):
         """(strips [n,32], cm [rows,2,nw] or None) generated by the last build_designs."""

@@ -435,7 +435,6 @@ struct raftx_ctx {
     size_t pinRes_n;
     hipStream_t sCopy, sPrep, sD2H;      // internal streams of raftx_sweep_stats (created on first use)
     std::vector<double> case_key;        // the sea-state tables resident for the sweep crossing (skip identical re-uploads)
-    std::vector<void *> sweep_allocs;    // offset arrays of the last sweep crossing, shared by its blocks
     char err[512];
     DevTables T;
     DevPool pool;
@@ -476,7 +475,23 @@ struct raftx_ctx {
     cplx *g_cm;
     void *comm;                          // ncclComm_t of raftx_comm_init (RCCL), or null
     int comm_rank, comm_world;
-    std::vector<raftx_ctx *> workers;    // sub-contexts of raftx_sweep_stats (own stream, buffers, pool), kept for reuse
+    std::vector<raftx_ctx *> workers[2]; // block contexts of the sweep crossings (device buffers, pool, events), per slot, kept for reuse
+    struct SweepSlot *slots;             // [2] crossings in flight (raftx_sweep_submit / raftx_sweep_wait)
+};
+// One sweep crossing in flight: everything raftx_sweep_wait needs to finish it.
+struct SweepSlot {
+    bool busy = false;
+    std::vector<raftx_ctx *> blk;
+    std::vector<int> bnd;
+    int nCase = 0, nHead = 0, nw = 0;
+    double *sd = nullptr;
+    int32_t *niter = nullptr, *flags = nullptr;
+    raftx_c128 *Xi = nullptr;
+    int64_t *stripOffsets = nullptr;
+    std::vector<void *> allocs;          // the batch's offset arrays on the device, shared by its blocks
+    hipEvent_t evXi = nullptr;           // download of the responses finished (sD2H)
+    std::chrono::steady_clock::time_point t0;
+    double tl[4] = {0, 0, 0, 0};
 };
 
 #define MAX_NW 2048
@@ -541,6 +556,7 @@ extern "C" int raftx_ctx_create(int device_id, raftx_ctx **out) {
     c->comm_rank = 0;
     c->comm_world = 1;
     c->owns_stream = true;
+    c->slots = new SweepSlot[2];
     c->pin = nullptr;
     c->pin_n = 0;
     c->pinRes = nullptr;
@@ -551,6 +567,7 @@ extern "C" int raftx_ctx_create(int device_id, raftx_ctx **out) {
                           &c->evS1, &c->evDone})
         ok = ok && hipEventCreate(e) == hipSuccess;
     if (!ok) {
+        delete[] c->slots;
         delete c;
         return -6;
     }
@@ -566,8 +583,10 @@ static void free_list(raftx_ctx *c, std::vector<void *> &v) {
 extern "C" void raftx_ctx_destroy(raftx_ctx *c) {
     if (!c) return;
     (void)raftx_comm_destroy(c);
-    for (raftx_ctx *w : c->workers) raftx_ctx_destroy(w);
-    c->workers.clear();
+    for (int sl = 0; sl < 2; sl++) {
+        for (raftx_ctx *w : c->workers[sl]) raftx_ctx_destroy(w);
+        c->workers[sl].clear();
+    }
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
     free_list(c, c->design_allocs);
@@ -582,7 +601,11 @@ extern "C" void raftx_ctx_destroy(raftx_ctx *c) {
     if (c->rKay) (void)hipFree(c->rKay);
     if (c->pairList) (void)hipFree(c->pairList);
     free_list(c, c->job.tmp);
-    free_list(c, c->sweep_allocs);
+    for (int sl = 0; sl < 2; sl++) {
+        free_list(c, c->slots[sl].allocs);
+        if (c->slots[sl].evXi) (void)hipEventDestroy(c->slots[sl].evXi);
+    }
+    delete[] c->slots;
     c->pool.trim();
     if (c->pin) (void)hipHostFree(c->pin);
     if (c->pinRes) (void)hipHostFree(c->pinRes);
@@ -1876,17 +1899,18 @@ extern "C" int raftx_qtf_force(raftx_ctx *c, int nSet, int nw2, const double *w2
 //   sD2H    full responses of a finished block (only when the caller asks for Xi)
 // The host waits only for the few bytes of totals that size a block's strip table (they are ready long before the
 // compute stream reaches the block) and, at the end, for the streams to drain.
-static int block_ctx(raftx_ctx *c, size_t i, raftx_ctx **out) {
-    while (c->workers.size() <= i) {
+static int block_ctx(raftx_ctx *c, int slot, size_t i, raftx_ctx **out) {
+    std::vector<raftx_ctx *> &W = c->workers[slot];
+    while (W.size() <= i) {
         raftx_ctx *sub = nullptr;
         const int rc = raftx_ctx_create(c->device, &sub);
         if (rc) FAIL(c, "sweep_stats: cannot create a block context (rc=%d)", rc);
         (void)hipStreamDestroy(sub->stream);          // block contexts run on the parent's stream
         sub->stream = c->stream;
         sub->owns_stream = false;
-        c->workers.push_back(sub);
+        W.push_back(sub);
     }
-    *out = c->workers[i];
+    *out = W[i];
     return 0;
 }
 // block sizes: RAFTX_SWEEP_SPLIT="f0,f1,..." (fractions, tuning) | nChunk equal blocks | default: a small first block
@@ -1925,16 +1949,18 @@ static std::vector<int> sweep_bounds(int nDesign, long pairs, int nChunk) {
     return b;
 }
 
-extern "C" int raftx_sweep_stats(raftx_ctx *c, int nDesign, const int64_t *memberOff, const double *members,
-                                 const int64_t *stationOff, const double *stations, const int64_t *capOff,
-                                 const double *caps, const double *pose, double rho, double g, int add_mask,
-                                 const double *M0, const double *B0, const double *C0, const double *Fz_moor, int nCase,
-                                 int nHead, int nw, const double *w, const double *k, double depth, double rho_wave,
-                                 double g_wave, const double *zeta, const double *beta, int nIter, double tol,
-                                 double XiStart, int nChunk, int nWorker, double *sd, int32_t *niter, int32_t *flags,
-                                 raftx_c128 *Xi, int64_t *stripOffsets, double *timing_ms) {
+extern "C" int raftx_sweep_submit(raftx_ctx *c, int slot, int nDesign, const int64_t *memberOff, const double *members,
+                                  const int64_t *stationOff, const double *stations, const int64_t *capOff,
+                                  const double *caps, const double *pose, double rho, double g, int add_mask,
+                                  const double *M0, const double *B0, const double *C0, const double *Fz_moor, int nCase,
+                                  int nHead, int nw, const double *w, const double *k, double depth, double rho_wave,
+                                  double g_wave, const double *zeta, const double *beta, int nIter, double tol,
+                                  double XiStart, int nChunk, double *sd, int32_t *niter, int32_t *flags,
+                                  raftx_c128 *Xi, int64_t *stripOffsets) {
     if (!c) return -1;
-    (void)nWorker;                                     // reserved (earlier versions drove the blocks from several host threads)
+    if (slot < 0 || slot > 1) FAIL(c, "sweep_submit: slot must be 0 or 1");
+    SweepSlot &S = c->slots[slot];
+    if (S.busy) FAIL(c, "sweep_submit: slot %d is still in flight (call raftx_sweep_wait first)", slot);
     if (nDesign < 0 || !memberOff || !members || !stationOff || !stations || !M0 || !B0 || !C0)
         FAIL(c, "sweep_stats: bad design arguments");
     if (nCase < 1 || nHead < 1 || nw < 1 || !w || !k || !zeta || !beta) FAIL(c, "sweep_stats: bad sea-state arguments");
@@ -1943,16 +1969,16 @@ extern "C" int raftx_sweep_stats(raftx_ctx *c, int nDesign, const int64_t *membe
     if (nIter < 0) FAIL(c, "sweep_stats: nIter < 0");
     if (nChunk > 64) nChunk = 64;
     HIPCHK(c, hipSetDevice(c->device));
-    const auto t0 = std::chrono::steady_clock::now();
-    static const bool dbg_host = getenv("RAFTX_SWEEP_DEBUG") != nullptr;
-    auto since = [&]() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(); };
-    double tl[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    S.t0 = std::chrono::steady_clock::now();
+    auto since = [&]() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - S.t0).count(); };
     if (!c->sCopy) {
         HIPCHK(c, hipStreamCreateWithFlags(&c->sCopy, hipStreamNonBlocking));
         HIPCHK(c, hipStreamCreateWithFlags(&c->sPrep, hipStreamNonBlocking));
         HIPCHK(c, hipStreamCreateWithFlags(&c->sD2H, hipStreamNonBlocking));
     }
-    // sea-state tables: resident on the parent, shared by the blocks; identical tables are not uploaded again
+    if (!S.evXi) HIPCHK(c, hipEventCreate(&S.evXi));
+    // sea-state tables: resident on the parent, shared by the blocks of both slots; identical tables are not uploaded
+    // again (a change drains the ctx stream first: the other slot may still read the old ones)
     {
         std::vector<double> key;
         key.reserve((size_t)nw * 2 + (size_t)nCase * nHead * (nw + 1) + 6);
@@ -1969,37 +1995,49 @@ extern "C" int raftx_sweep_stats(raftx_ctx *c, int nDesign, const int64_t *membe
             c->case_key.swap(key);
         }
     }
-    const std::vector<int> bnd = sweep_bounds(nDesign, (long)nDesign * nCase, nChunk);
+    S.bnd = sweep_bounds(nDesign, (long)nDesign * nCase, nChunk);
+    const std::vector<int> &bnd = S.bnd;
     const size_t nB = bnd.size() - 1;
     const double dw = nw > 1 ? w[1] - w[0] : w[0];
-    HIPCHK(c, hipStreamSynchronize(c->stream));          // nothing of an earlier call may still read the blocks' tables
-    std::vector<raftx_ctx *> blk(nB, nullptr);
-    tl[0] = since();
+    S.blk.assign(nB, nullptr);
+    std::vector<raftx_ctx *> &blk = S.blk;
+    S.nCase = nCase; S.nHead = nHead; S.nw = nw;
+    S.sd = sd; S.niter = niter; S.flags = flags; S.Xi = Xi; S.stripOffsets = stripOffsets;
+    S.tl[0] = since();
+    // the slot's previous crossing has been waited for: its tables and offset arrays are free
+    free_list(c, S.allocs);
+    auto fail_drain = [&](int rc) {
+        (void)hipDeviceSynchronize();
+        for (raftx_ctx *sub : blk)
+            if (sub) {
+                free_list(sub, sub->job.tmp);
+                sub->job.active = false;
+            }
+        return rc;
+    };
     // ---- the batch's offset arrays: one upload, shared by the blocks
-    free_list(c, c->sweep_allocs);
     DevOffsets dOff{nullptr, nullptr, nullptr};
     {
         const int64_t nMemberAll = memberOff[nDesign];
         if (nMemberAll < 0) FAIL(c, "sweep_stats: member offsets not monotone");
-        int rc = upload_on(c, c->sCopy, c->sweep_allocs, memberOff, (size_t)nDesign + 1, &dOff.memberOff);
-        rc |= upload_on(c, c->sCopy, c->sweep_allocs, stationOff, (size_t)nMemberAll + 1, &dOff.stationOff);
-        if (capOff) rc |= upload_on(c, c->sCopy, c->sweep_allocs, capOff, (size_t)nMemberAll + 1, &dOff.capOff);
-        if (rc) return -2;
+        int rc = upload_on(c, c->sCopy, S.allocs, memberOff, (size_t)nDesign + 1, &dOff.memberOff);
+        rc |= upload_on(c, c->sCopy, S.allocs, stationOff, (size_t)nMemberAll + 1, &dOff.stationOff);
+        if (capOff) rc |= upload_on(c, c->sCopy, S.allocs, capOff, (size_t)nMemberAll + 1, &dOff.capOff);
+        if (rc) return fail_drain(-2);
     }
     // ---- phase 1 of every block: H2D on sCopy, member pass + scans on sPrep
     for (size_t b = 0; b < nB; b++) {
-        if (block_ctx(c, b, &blk[b])) return -1;
+        if (block_ctx(c, slot, b, &blk[b])) return fail_drain(-1);
         raftx_ctx *sub = blk[b];
         const int lo = bnd[b], n = bnd[b + 1] - lo;
         const int rc = build_phase1(sub, c->sCopy, c->sPrep, lo, n, memberOff, members, stationOff, stations, capOff, caps, pose,
                                     rho, g, nw, k, add_mask, M0, B0, C0, nullptr, Fz_moor, &dOff, c->T.k);
         if (rc) {
             snprintf(c->err, sizeof(c->err), "sweep_stats (block %zu): %s", b, sub->err);
-            (void)hipDeviceSynchronize();
-            return rc;
+            return fail_drain(rc);
         }
     }
-    tl[1] = since();
+    S.tl[1] = since();
     // ---- phase 2 + fixed point + statistics of every block, in order, on the ctx stream
     int rc_all = 0;
     for (size_t b = 0; b < nB && !rc_all; b++) {
@@ -2077,49 +2115,81 @@ extern "C" int raftx_sweep_stats(raftx_ctx *c, int nDesign, const int64_t *membe
                 break;
             }
         }
+        if (!rc_all && hipEventRecord(S.evXi, c->sD2H) != hipSuccess) rc_all = -2;
     }
-    tl[2] = since();
-    hipError_t es = hipStreamSynchronize(c->stream);
-    tl[3] = since();
-    hipError_t e2 = hipStreamSynchronize(c->sD2H);
-    hipError_t e3 = hipStreamSynchronize(c->sPrep);
-    hipError_t e4 = hipStreamSynchronize(c->sCopy);
-    if (rc_all) {
-        for (raftx_ctx *sub : blk) {
+    if (rc_all) return fail_drain(rc_all);
+    S.tl[2] = since();
+    S.busy = true;
+    return 0;
+}
+
+extern "C" int raftx_sweep_wait(raftx_ctx *c, int slot, double *timing_ms) {
+    if (!c) return -1;
+    if (slot < 0 || slot > 1) FAIL(c, "sweep_wait: slot must be 0 or 1");
+    SweepSlot &S = c->slots[slot];
+    if (!S.busy) FAIL(c, "sweep_wait: nothing submitted on slot %d", slot);
+    HIPCHK(c, hipSetDevice(c->device));
+    static const bool dbg_host = getenv("RAFTX_SWEEP_DEBUG") != nullptr;
+    auto since = [&]() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - S.t0).count(); };
+    const size_t nB = S.blk.size();
+    S.busy = false;
+    hipError_t es = nB ? hipEventSynchronize(S.blk[nB - 1]->evDone) : hipSuccess;     // the ctx stream is in order: all blocks are done
+    S.tl[3] = since();
+    if (es == hipSuccess && S.Xi) es = hipEventSynchronize(S.evXi);
+    if (es == hipSuccess) es = hipGetLastError();
+    if (es != hipSuccess) {
+        (void)hipDeviceSynchronize();
+        for (raftx_ctx *sub : S.blk) {
             free_list(sub, sub->job.tmp);
             sub->job.active = false;
         }
-        return rc_all;
+        HIPCHK(c, es);
     }
-    HIPCHK(c, es); HIPCHK(c, e2); HIPCHK(c, e3); HIPCHK(c, e4);
-    HIPCHK(c, hipGetLastError());
     double tb = 0, ts = 0, tst = 0;
-    if (stripOffsets) stripOffsets[0] = 0;
+    if (S.stripOffsets) S.stripOffsets[0] = 0;
     for (size_t b = 0; b < nB; b++) {
-        raftx_ctx *sub = blk[b];
-        const int lo = bnd[b], n = bnd[b + 1] - lo;
-        const size_t npair = (size_t)n * nCase, p0 = (size_t)lo * nCase;
+        raftx_ctx *sub = S.blk[b];
+        const int lo = S.bnd[b], n = S.bnd[b + 1] - lo;
+        const size_t npair = (size_t)n * S.nCase, p0 = (size_t)lo * S.nCase;
         float ms = 0.f;
         HIPCHK(c, hipEventElapsedTime(&ms, sub->ev0, sub->ev1));
         ts += ms;
         HIPCHK(c, hipEventElapsedTime(&ms, sub->evS0, sub->evS1));
         tst += ms;
         double g_ms = 0.0;
-        if (stripOffsets)                                               // block-relative offsets of phase 1 -> batch offsets
-            for (int i = 0; i < n; i++) stripOffsets[lo + i + 1] = stripOffsets[lo] + sub->pin[8 + i + 1];
+        if (S.stripOffsets)                                             // block-relative offsets of phase 1 -> batch offsets
+            for (int i = 0; i < n; i++) S.stripOffsets[lo + i + 1] = S.stripOffsets[lo] + sub->pin[8 + i + 1];
         if (build_retire(sub, &g_ms)) return -2;
         tb += g_ms;
-        memcpy(sd + p0 * 6, sub->pinRes, npair * 6 * sizeof(double));
-        memcpy(niter + p0, sub->pinRes + npair * 6, npair * sizeof(int));
-        memcpy(flags + p0, reinterpret_cast<int *>(sub->pinRes + npair * 6) + npair, npair * sizeof(int));
+        memcpy(S.sd + p0 * 6, sub->pinRes, npair * 6 * sizeof(double));
+        memcpy(S.niter + p0, sub->pinRes + npair * 6, npair * sizeof(int));
+        memcpy(S.flags + p0, reinterpret_cast<int *>(sub->pinRes + npair * 6) + npair, npair * sizeof(int));
     }
-    const double wall = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    const double wall = since();
     if (dbg_host)
-        fprintf(stderr, "[raftx_sweep_stats] host ms: pre %.3f | phase-1 enqueued %.3f | phase-2 enqueued %.3f | compute stream drained %.3f | done %.3f\n",
-                tl[0], tl[1], tl[2], tl[3], wall);
+        fprintf(stderr, "[raftx_sweep slot %d] host ms since submit: pre %.3f | phase-1 enqueued %.3f | phase-2 enqueued %.3f | ctx stream "
+                "reached the end %.3f | done %.3f\n", slot, S.tl[0], S.tl[1], S.tl[2], S.tl[3], wall);
     if (timing_ms) { timing_ms[0] = wall; timing_ms[1] = tb; timing_ms[2] = ts; timing_ms[3] = tst; }
     c->last_ms = ts;
     return 0;
+}
+
+extern "C" int raftx_sweep_stats(raftx_ctx *c, int nDesign, const int64_t *memberOff, const double *members,
+                                 const int64_t *stationOff, const double *stations, const int64_t *capOff,
+                                 const double *caps, const double *pose, double rho, double g, int add_mask,
+                                 const double *M0, const double *B0, const double *C0, const double *Fz_moor, int nCase,
+                                 int nHead, int nw, const double *w, const double *k, double depth, double rho_wave,
+                                 double g_wave, const double *zeta, const double *beta, int nIter, double tol,
+                                 double XiStart, int nChunk, int nWorker, double *sd, int32_t *niter, int32_t *flags,
+                                 raftx_c128 *Xi, int64_t *stripOffsets, double *timing_ms) {
+    if (!c) return -1;
+    (void)nWorker;                                     // reserved (earlier versions drove the blocks from several host threads)
+    const int slot = c->slots[0].busy ? 1 : 0;         // a blocking crossing beside a streamed one takes the free slot
+    const int rc = raftx_sweep_submit(c, slot, nDesign, memberOff, members, stationOff, stations, capOff, caps, pose, rho, g, add_mask,
+                                      M0, B0, C0, Fz_moor, nCase, nHead, nw, w, k, depth, rho_wave, g_wave, zeta, beta, nIter, tol,
+                                      XiStart, nChunk, sd, niter, flags, Xi, stripOffsets);
+    if (rc) return rc;
+    return raftx_sweep_wait(c, slot, timing_ms);
 }
 
 // ------------------------------------------------------------------ RCCL exchange steps

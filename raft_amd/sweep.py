@@ -291,6 +291,19 @@ class GeometrySweep(Sweep):
         self.off = r["strip_off"]
         return r
 
+    def submit_crossing(self, ctx, slot, n_chunk=0, want_Xi=False, Xi_out=None):
+        """Streamed form of ``run_crossing`` for back-to-back batches: enqueue this batch on ``slot`` (0 / 1) and return a
+        handle; ``wait_crossing`` collects the results.  With two slots the descriptor upload of one batch overlaps the
+        kernels of the other (raftx_sweep_submit / raftx_sweep_wait)."""
+        return ctx.sweep_submit(slot, self.tables, self.M0, self.B0, self.C0, self.w, self.k, self.depth, self.zeta, self.beta,
+                                self.nIter, self.tol, self.XiStart, pose=self.pose, rho=self.rho, g=self.g, add_mask=self.add_mask,
+                                n_chunk=n_chunk, want_Xi=want_Xi, Xi_out=Xi_out)
+
+    def wait_crossing(self, ctx, handle):
+        r = ctx.sweep_wait(handle)
+        self.off = r["strip_off"]
+        return r
+
     def upload(self, ctx):
         t = self.tables
         self.off = ctx.build_designs(t.member_off, t.members, t.station_off, t.stations, self.M0, self.B0, self.C0, self.nw,

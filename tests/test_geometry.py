@@ -325,6 +325,46 @@ def test_hip_sweep_crossing_reuses_its_worker_streams_and_reports_errors(hip_ctx
     check_crossing(hip_ctx, 12, 3, 3)
 
 
+def check_streamed_crossings(ctx):
+    """Two crossings in flight (raftx_sweep_submit on slots 0 and 1, then raftx_sweep_wait): different batches, the
+    second submitted before the first is collected; each equals its blocking raftx_sweep_stats bit for bit.  Misuse is
+    reported: a busy slot cannot be submitted to, an idle one cannot be waited for."""
+    from raft_amd._abi import RaftxError
+    nw = len(C3["w"])
+    args = (C3["w"], C3["k"], float(C3["depth"]), np.asarray(C3["zeta"])[None], np.asarray(C3["beta"])[None], int(C3["nIter"]), 0.01,
+            float(C3["XiStart"]))
+    batches = [_c3_crossing_inputs(n) for n in (37, 70, 12)]
+    want = [ctx.sweep_stats(D, M0, B0, C0, *args, want_Xi=True) for D, M0, B0, C0 in batches]
+    h = [None, None]
+    got = []
+    h[0] = ctx.sweep_submit(0, *batches[0], *args, want_Xi=True)
+    with pytest.raises(RaftxError, match="still in flight"):
+        ctx.sweep_submit(0, *batches[1], *args)
+    h[1] = ctx.sweep_submit(1, *batches[1], *args, want_Xi=True)
+    got.append(ctx.sweep_wait(h[0]))
+    h[0] = ctx.sweep_submit(0, *batches[2], *args, want_Xi=True)          # slot 0 again while slot 1 is in flight
+    got.append(ctx.sweep_wait(h[1]))
+    got.append(ctx.sweep_wait(h[0]))
+    with pytest.raises(RaftxError, match="nothing submitted"):
+        ctx.sweep_wait(h[0])
+    for g_, w_ in zip(got, want):
+        for key in ("Xi", "std"):
+            assert np.array_equal(g_[key].view(np.uint64), w_[key].view(np.uint64)), key
+        assert np.array_equal(g_["niter"], w_["niter"]) and np.array_equal(g_["flags"], w_["flags"])
+        assert np.array_equal(g_["strip_off"], w_["strip_off"])
+    assert nw == got[0]["Xi"].shape[-1]
+
+
+def test_oracle_streamed_crossings(oracle_ctx):
+    check_streamed_crossings(oracle_ctx)
+
+
+@pytest.mark.gpu
+def test_hip_streamed_crossings(hip_ctx):
+    check_streamed_crossings(hip_ctx)
+    check_crossing(hip_ctx, 20, 0, 0)                     # the blocking call still works on the same context afterwards
+
+
 # ------------------------------------------------------------------ ballast trim (Model.adjustBallastDensity)
 TRIM_NAMES = [n for n in NAMES if "trim_drho" in UNITS[n]]
 
