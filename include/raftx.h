@@ -371,8 +371,8 @@ int raftx_fetch_statics(raftx_ctx *ctx, double *A_morison, double *C_hydro, doub
  * Descriptor arguments as raftx_build_designs (MBw not supported here; k doubles as the wave numbers of the
  * MacCamy-Fuchs table); sea-state arguments as raftx_upload_cases (rho_wave, g_wave scale the dynamic pressure:
  * the reference hard-wires 1025 / 9.81 there, raft_fowt.py:1857); nIter, tol, XiStart as raftx_solve_dynamics.
- * nChunk > 0: that many equal blocks; nChunk <= 0: library default (a small first block that hides the descriptor upload
- * of the rest, then growing ones).  nWorker is reserved (ignored).  Page-locked descriptor and M0/B0/C0 arrays
+ * nChunk > 0: that many equal blocks; nChunk <= 0: library default (an isolated call: a small first block whose kernels hide
+ * the descriptor upload of the rest; a crossing submitted while the other slot is in flight: one block).  nWorker is reserved (ignored).  Page-locked descriptor and M0/B0/C0 arrays
  * (raftx_host_alloc) copy at full PCIe rate and without blocking the host; a page-locked Xi likewise.
  * Outputs: std [nDesign,nCase,6] (raftx_motion_stats; required), niter / flags [nDesign,nCase] (required),
  * Xi [nDesign,nCase,nHead,6,nw] or NULL, stripOffsets [nDesign+1] or NULL, timing_ms [4] or NULL

@@ -840,7 +840,7 @@ __global__ __launch_bounds__(64) void k_geom_fill(GeomArgs A) {
             const int pos = nwet + __popcll(mask & ((1ull << lane) - 1ull));
             nwet += __popcll(mask);
             if (!wet) continue;
-            double *rec = A.abi + (size_t)(out0 + pos) * NF;
+            double rec[NF];                                 // the record is built in registers and stored once
             for (int c = 0; c < NF; c++) rec[c] = 0.0;
             for (int c = 0; c < 3; c++) {
                 rec[RAFTX_F_X + c] = r[c];
@@ -895,6 +895,8 @@ __global__ __launch_bounds__(64) void k_geom_fill(GeomArgs A) {
             rec[RAFTX_F_DP1] = cdrag * 0.5 * rho * a_p1 * geom_interp(s.ls, gs, n, RAFTX_GS_CD + 1);
             rec[RAFTX_F_DP2] = cdrag * 0.5 * rho * a_p2 * geom_interp(s.ls, gs, n, RAFTX_GS_CD + 2);
             rec[RAFTX_F_DEND] = cdrag * 0.5 * rho * a_end * geom_interp(s.ls, gs, n, RAFTX_GS_CD + 3);
+            double *dst = A.abi + (size_t)(out0 + pos) * NF;
+            for (int c = 0; c < NF; c++) dst[c] = rec[c];
         }
     }
 }

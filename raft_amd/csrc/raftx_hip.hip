@@ -1913,10 +1913,11 @@ static int block_ctx(raftx_ctx *c, int slot, size_t i, raftx_ctx **out) {
     *out = W[i];
     return 0;
 }
-// block sizes: RAFTX_SWEEP_SPLIT="f0,f1,..." (fractions, tuning) | nChunk equal blocks | default: a small first block
+// block sizes: RAFTX_SWEEP_SPLIT="f0,f1,..." (fractions, tuning) | nChunk equal blocks | default: ONE block when the other slot
+// has a crossing in flight (streamed batches: that crossing's kernels hide this one's upload), otherwise a small first block
 // whose kernels hide the descriptor upload of the rest (every further block costs a partial last residency round of the
 // fused kernel plus the fixed latencies of the generation kernels: two blocks measured best)
-static std::vector<int> sweep_bounds(int nDesign, long pairs, int nChunk) {
+static std::vector<int> sweep_bounds(int nDesign, long pairs, int nChunk, bool pipelined) {
     std::vector<double> fr;
     static const char *env = getenv("RAFTX_SWEEP_SPLIT");
     if (env && nChunk <= 0) {
@@ -1932,6 +1933,7 @@ static std::vector<int> sweep_bounds(int nDesign, long pairs, int nChunk) {
     }
     if (fr.empty()) {
         if (nChunk > 0) fr.assign((size_t)nChunk, 1.0);
+        else if (pipelined) fr = {1.0};              // the crossing in the other slot hides this one's upload: one launch, no extra tail
         else if (pairs >= 3072) fr = {0.2, 0.8};     // measured on MI355X at 10 k pairs (profiles/r02_crossing_splits.txt)
         else fr = {1.0};
     }
@@ -1995,7 +1997,7 @@ extern "C" int raftx_sweep_submit(raftx_ctx *c, int slot, int nDesign, const int
             c->case_key.swap(key);
         }
     }
-    S.bnd = sweep_bounds(nDesign, (long)nDesign * nCase, nChunk);
+    S.bnd = sweep_bounds(nDesign, (long)nDesign * nCase, nChunk, c->slots[1 - slot].busy);
     const std::vector<int> &bnd = S.bnd;
     const size_t nB = bnd.size() - 1;
     const double dw = nw > 1 ? w[1] - w[0] : w[0];
