@@ -220,7 +220,8 @@ def main():
 
     def gather(r):
         if comm is not None:                              # statistics of every rank onto rank 0 (48 B + 8 B per design-case)
-            r["std_all"] = comm.gather_rows(np.concatenate([r["std"].reshape(nD, -1), r["niter"].reshape(nD, -1).astype(np.float64)], axis=1))
+            r["std_all"] = comm.gather_rows(np.concatenate([r["std"].reshape(nD, -1), r["niter"].reshape(nD, -1).astype(np.float64)], axis=1),
+                                            counts=np.full(world, nD, dtype=np.int64))       # weak scaling: every rank holds nD designs
         return r
 
     def step():                                           # one isolated, blocking crossing

@@ -39,6 +39,38 @@
 
 #include "../../include/raftx.h"
 
+// roctx ranges around the phases of the host side: named spans for `rocprofv3 --marker-trace`.
+// librocprofiler-sdk-roctx is bound at run time on first use; without it (or outside a profiler) the ranges cost a branch.
+struct Roctx {
+    int (*push)(const char *) = nullptr;
+    int (*pop)() = nullptr;
+    Roctx() {
+        if (getenv("RAFTX_NO_ROCTX")) return;
+        for (const char *n : {"librocprofiler-sdk-roctx.so.1", "librocprofiler-sdk-roctx.so", "libroctx64.so.4", "libroctx64.so"}) {
+            if (void *h = dlopen(n, RTLD_NOW | RTLD_LOCAL)) {
+                push = reinterpret_cast<int (*)(const char *)>(dlsym(h, "roctxRangePushA"));
+                pop = reinterpret_cast<int (*)()>(dlsym(h, "roctxRangePop"));
+                if (push && pop) return;
+                push = nullptr;
+                pop = nullptr;
+            }
+        }
+    }
+};
+static Roctx &roctx() {
+    static Roctx r;
+    return r;
+}
+struct RangeScope {
+    bool on;
+    explicit RangeScope(const char *name) : on(roctx().push != nullptr) {
+        if (on) roctx().push(name);
+    }
+    ~RangeScope() {
+        if (on) roctx().pop();
+    }
+};
+
 #include "raftx_kernels.h"
 #include "raftx_qtf.h"
 #include "raftx_geom.h"
@@ -648,6 +680,7 @@ static int upload(raftx_ctx *c, std::vector<void *> &bag, const Tp *host, size_t
 extern "C" int raftx_upload_designs(raftx_ctx *c, int nDesign, const int64_t *stripOffsets, const double *strips,
                                     int nStripFields, const double *M0, const double *B0, const double *C0, int nw,
                                     const double *MBw, const int64_t *cmOffsets, const raftx_c128 *CmMCF) {
+    RangeScope range_("raftx_upload_designs: run detection + H2D");
     if (!c) return -1;
     if (nStripFields != NF) FAIL(c, "nStripFields=%d, expected %d", nStripFields, NF);
     if (nDesign < 0 || !stripOffsets || !M0 || !B0 || !C0) FAIL(c, "upload_designs: bad arguments");
@@ -746,6 +779,7 @@ static int build_phase1(raftx_ctx *c, hipStream_t sCopy, hipStream_t sPrep, int 
                         const double *caps, const double *pose, double rho, double g, int nw, const double *k, int add_mask,
                         const double *M0, const double *B0, const double *C0, const double *MBw, const double *Fz_moor,
                         const DevOffsets *shared, const double *k_dev = nullptr) {
+    RangeScope range_("build phase 1: descriptor H2D, member pass, scans (enqueue)");
     BuildJob &J = c->job;
     if (nDesign < 0 || lo < 0 || !memberOff || !members || !stationOff || !stations || !M0 || !B0 || !C0)
         FAIL(c, "build_designs: bad arguments");
@@ -874,6 +908,7 @@ static int build_phase1(raftx_ctx *c, hipStream_t sCopy, hipStream_t sPrep, int 
 // for every block but the first, so that a block's tables are generated WHILE the fused kernel of the block before it
 // runs (they fill the CUs its last residency round leaves idle); the ctx stream is ordered behind them by evG1.
 static int build_phase2(raftx_ctx *c, int64_t *stripOffsets, hipStream_t sGen = nullptr) {
+    RangeScope range_("build phase 2: wait for totals, strip tables + statics (enqueue)");
     BuildJob &J = c->job;
     if (!J.active) FAIL(c, "build_designs: phase 2 without phase 1");
     GeomArgs &A = J.A;
@@ -1017,6 +1052,7 @@ extern "C" int raftx_fetch_statics(raftx_ctx *c, double *A_morison, double *C_hy
 
 extern "C" int raftx_upload_cases(raftx_ctx *c, int nCase, int nHead, int nw, const double *w, const double *k,
                                   double depth, double rho, double g, const double *zeta, const double *beta) {
+    RangeScope range_("raftx_upload_cases: H2D");
     if (!c) return -1;
     if (nCase < 0 || nHead < 1 || nw < 1 || !w || !k || !zeta || !beta) FAIL(c, "upload_cases: bad arguments");
     if (nw > MAX_NW) FAIL(c, "nw=%d exceeds the %d bins per workgroup supported by this build", nw, MAX_NW);
@@ -1419,6 +1455,7 @@ static int finish_enqueued(raftx_ctx *c) {
 }
 extern "C" int raftx_solve_dynamics_device(raftx_ctx *c, int nIter, double tol, double XiStart,
                                            const raftx_c128 *F_extra, int want_mask) {
+    RangeScope range_("raftx_solve_dynamics_device: fused fixed point");
     const int rc = solve_enqueue(c, nIter, tol, XiStart, F_extra, want_mask);
     if (rc) return rc;
     return finish_enqueued(c);
@@ -1463,6 +1500,7 @@ extern "C" int raftx_fetch_linearisation_point(raftx_ctx *c, raftx_c128 *XiLast)
 
 extern "C" int raftx_fetch_results(raftx_ctx *c, raftx_c128 *Xi, int32_t *niter, int32_t *flags, double *B_drag,
                                    raftx_c128 *F_wave, raftx_c128 *Z) {
+    RangeScope range_("raftx_fetch_results: D2H");
     if (!c) return -1;
     if (!c->rXi) FAIL(c, "fetch_results: no resident results");
     HIPCHK(c, hipSetDevice(c->device));
@@ -1959,6 +1997,7 @@ extern "C" int raftx_sweep_submit(raftx_ctx *c, int slot, int nDesign, const int
                                   double g_wave, const double *zeta, const double *beta, int nIter, double tol,
                                   double XiStart, int nChunk, double *sd, int32_t *niter, int32_t *flags,
                                   raftx_c128 *Xi, int64_t *stripOffsets) {
+    RangeScope range_("raftx_sweep_submit: H2D + member pass + generation + fused fixed point + statistics (enqueue)");
     if (!c) return -1;
     if (slot < 0 || slot > 1) FAIL(c, "sweep_submit: slot must be 0 or 1");
     SweepSlot &S = c->slots[slot];
@@ -2050,7 +2089,8 @@ extern "C" int raftx_sweep_submit(raftx_ctx *c, int slot, int nDesign, const int
         // before it gains nothing (the block's descriptor upload is what it waits for) and inflates the kernel's timed
         // duration, so the default keeps everything on the ctx stream; RAFTX_SWEEP_GEN_OVERLAP=1 turns the overlap on
         static const bool gen_overlap = getenv("RAFTX_SWEEP_GEN_OVERLAP") && atoi(getenv("RAFTX_SWEEP_GEN_OVERLAP"));
-        int rc = build_phase2(sub, nullptr, (b > 0 && gen_overlap) ? c->sPrep : nullptr);
+        const bool pipelined = c->slots[1 - slot].busy;
+        int rc = build_phase2(sub, nullptr, ((b > 0 || pipelined) && gen_overlap) ? c->sPrep : nullptr);
         if (!rc) {                                                      // the sea states of the parent
             DevTables &T = sub->T;
             const DevTables &P = c->T;
@@ -2126,6 +2166,7 @@ extern "C" int raftx_sweep_submit(raftx_ctx *c, int slot, int nDesign, const int
 }
 
 extern "C" int raftx_sweep_wait(raftx_ctx *c, int slot, double *timing_ms) {
+    RangeScope range_("raftx_sweep_wait: drain + outputs");
     if (!c) return -1;
     if (slot < 0 || slot > 1) FAIL(c, "sweep_wait: slot must be 0 or 1");
     SweepSlot &S = c->slots[slot];

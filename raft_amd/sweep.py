@@ -355,15 +355,55 @@ def run_sharded(sweep, ctx, comm=None, gather=True):
     return {"Xi": Xi.reshape((sweep.n_design, sweep.n_case) + Xi.shape[1:]), "niter": ni, "flags": fl}
 
 
-def run_stats_sharded(sweep, ctx, comm=None):
+def run_stats_sharded(sweep, ctx, comm=None, checkpoint_dir=None, shards_per_rank=1):
     """The optimiser-style exchange: every rank solves its designs and only the motion statistics (48 B per design-case)
-    and iteration counts are gathered onto rank 0."""
-    if comm is None or comm.world == 1:
-        return sweep.run_stats(ctx)
-    local = sweep.shard(comm.rank, comm.world).run_stats(ctx)
-    cd = _counts(sweep.n_design, comm.world)
-    out = {k_: comm.gather_rows(local[k_], cd) for k_ in ("std", "niter", "flags")}
-    return out if comm.rank == 0 else local
+    and iteration counts are gathered onto rank 0.
+
+    checkpoint_dir: the sweep is idempotent, so it is made resumable the simple way: the designs are
+    cut into ``world * shards_per_rank`` contiguous shards, a rank writes every shard it finishes as
+    ``shard_<id>_of_<n>.npz`` (atomically: temp file + rename) and, on a re-run with the same directory, loads the shards
+    that are already there instead of solving them -- whichever rank wrote them.  The gathered result is the same
+    arrays either way."""
+    world = 1 if comm is None else comm.world
+    rank = 0 if comm is None else comm.rank
+    keys = ("std", "niter", "flags")
+    if checkpoint_dir is None:
+        if world == 1:
+            return sweep.run_stats(ctx)
+        local = sweep.shard(rank, world).run_stats(ctx)
+        counts = _counts(sweep.n_design, world)
+    else:
+        import os
+        os.makedirs(checkpoint_dir, exist_ok=True)
+        n_shard = world * max(int(shards_per_rank), 1)
+        first = lambda r: r * n_shard // world                      # rank r owns the shards first(r) .. first(r + 1) - 1
+        rows = lambda r: shard_bounds(sweep.n_design, first(r + 1) - 1, n_shard)[1] - shard_bounds(sweep.n_design, first(r), n_shard)[0]
+        parts = []
+        for sid in range(first(rank), first(rank + 1)):
+            path = os.path.join(checkpoint_dir, "shard_%05d_of_%05d.npz" % (sid, n_shard))
+            lo, hi = shard_bounds(sweep.n_design, sid, n_shard)
+            got = None
+            if os.path.exists(path):
+                with np.load(path) as z:
+                    if int(z["lo"]) == lo and int(z["hi"]) == hi:
+                        got = {k_: z[k_] for k_ in keys}
+            if got is None:
+                if hi > lo:
+                    got = sweep.take(lo, hi).run_stats(ctx)
+                else:
+                    got = {"std": np.zeros((0, sweep.n_case, 6)), "niter": np.zeros((0, sweep.n_case), np.int32),
+                           "flags": np.zeros((0, sweep.n_case), np.int32)}
+                tmp = path + ".tmp.%d" % os.getpid()
+                with open(tmp, "wb") as f:
+                    np.savez(f, lo=lo, hi=hi, **{k_: got[k_] for k_ in keys})
+                os.replace(tmp, path)
+            parts.append(got)
+        local = {k_: np.concatenate([p[k_] for p in parts], axis=0) for k_ in keys}
+        if world == 1:
+            return local
+        counts = np.array([rows(r) for r in range(world)], dtype=np.int64)
+    out = {k_: comm.gather_rows(local[k_], counts) for k_ in keys}
+    return out if rank == 0 else local
 
 
 def run_qtf_sharded(qtf_fn, tables, Xi, beta, w2, k2, depth, rho, g, Mstruc, kay=None, comm=None):

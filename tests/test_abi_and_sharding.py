@@ -320,3 +320,51 @@ def test_two_rank_qtf_sets(tmp_path, kind):
     tabs, Xi, beta, w2, k2, f = _qtf_sets()
     ref = _numpy_qtf(tabs, Xi, beta, w2, k2, f.depth, f.rho_water, f.g, np.array([f.M_struc] * 3), None)
     assert got.shape == ref.shape and np.array_equal(got.view(np.float64), ref.view(np.float64))
+
+
+# ------------------------------------------------------------------ shard checkpoints: an interrupted sweep resumes
+def _ckpt_rank_main(rank, world, port, n, ckpt, out_path, kind):
+    from raft_amd._abi import RaftxLib
+    comm = _make_comm(kind, rank, world, port)
+    try:
+        s, _ = _c3_sweep(n)
+        ctx = RaftxLib(ORACLE_SO).context(0)
+        st = sw.run_stats_sharded(s, ctx, comm, checkpoint_dir=ckpt, shards_per_rank=2)
+        ctx.close()
+        if rank == 0:
+            np.savez(out_path, std=st["std"], niter=st["niter"], flags=st["flags"])
+    finally:
+        comm.close()
+
+
+def test_sharded_statistics_resume_from_shard_files(tmp_path, oracle_lib, monkeypatch):
+    """run_stats_sharded(checkpoint_dir=...): shards are written as they finish; a second run loads what is there and
+    solves only what is missing (one shard file deleted, one replaced by a file of another partition); two ranks then
+    complete the same directory.  Every variant returns the bits of the plain run."""
+    import torch.multiprocessing as mp
+    n = 9
+    s, _ = _c3_sweep(n)
+    ctx = oracle_lib.context(0)
+    ref = s.run_stats(ctx)
+    ckpt = str(tmp_path / "ckpt")
+    solved = []
+    orig = sw.Sweep.run_stats
+    monkeypatch.setattr(sw.Sweep, "run_stats", lambda self, c, want_psd=False: (solved.append(self.n_design), orig(self, c, want_psd))[1])
+    first = sw.run_stats_sharded(s, ctx, None, checkpoint_dir=ckpt, shards_per_rank=4)
+    assert sorted(solved) == [2, 2, 2, 3] and len(os.listdir(ckpt)) == 4
+    files = sorted(os.listdir(ckpt))
+    os.remove(os.path.join(ckpt, files[1]))
+    np.savez(os.path.join(ckpt, files[2]), lo=0, hi=1, std=np.zeros((1, 1, 6)), niter=np.zeros((1, 1), np.int32), flags=np.zeros((1, 1), np.int32))
+    solved.clear()
+    second = sw.run_stats_sharded(s, ctx, None, checkpoint_dir=ckpt, shards_per_rank=4)
+    assert len(solved) == 2                                       # only the missing and the mismatching shard
+    ctx.close()
+    for got in (first, second):
+        assert np.array_equal(got["std"].view(np.uint64), ref["std"].view(np.uint64))
+        assert np.array_equal(got["niter"], ref["niter"]) and np.array_equal(got["flags"], ref["flags"])
+    monkeypatch.undo()
+    # two ranks, two shards each, over the same directory (same 4-shard partition: everything is already there)
+    out = str(tmp_path / "two_rank.npz")
+    mp.spawn(_ckpt_rank_main, args=(2, _free_port(), n, ckpt, out, "host"), nprocs=2, join=True)
+    got = np.load(out)
+    assert np.array_equal(got["std"].view(np.uint64), ref["std"].view(np.uint64)) and np.array_equal(got["niter"], ref["niter"])
