@@ -4,7 +4,7 @@
     python examples/c3_sweep.py [n_designs]
 
 1. host: the baseline design's members are parsed once (raft_amd.geometry.describe_unit) and the five sweep parameters of
-   raft/parametersweep.py are applied to the descriptor arrays with NumPy broadcasting (tests/util.py volturnus_sweep);
+   raft/parametersweep.py are applied to the descriptor arrays with NumPy broadcasting (raft_amd/geometry.py volturnus_sweep);
 2. device: strip tables, Morison added mass, hydrostatics, member inertia -- with the ballast density trimmed for heave
    equilibrium (Model.adjustBallastDensity) -- are generated for all designs (raftx_build_designs);
 3. device: the drag-linearised frequency-domain responses of every design in three sea states (one launch);

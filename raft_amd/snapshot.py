@@ -172,3 +172,21 @@ def build_model(d):
     m.ms = None
     m.results = {}
     return m
+
+
+def case_from_fixture(c):
+    """The load-case dict of a fixture case, as a fresh (deep) copy with lists for the per-heading entries."""
+    import copy
+    return copy.deepcopy({k: (list(v) if isinstance(v, (list, np.ndarray)) else v) for k, v in c["case"].items()})
+
+
+def ref_headings(c):
+    """(reference responses of the wave headings [nH,6N,nw], nH) of a fixture case.  Full cases store the reference's
+    Xi with its zero rotor-excitation row (raft_model.py:1236), lean ones (many-case fixtures) without it."""
+    nH = len(np.atleast_1d(np.asarray(c["case"]["wave_heading"], dtype=float)))
+    return np.asarray(c["Xi"])[:nH], nH
+
+
+def load_model_fixture(name):
+    fx = load_fixture(name)
+    return fx, build_model(fx["model"])

@@ -6,7 +6,8 @@ import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from raft_amd import backend, dropin
-from tests.util import load_model_fixture, case_from_fixture, ref_headings, group_rel_err
+from raft_amd.snapshot import load_model_fixture, case_from_fixture, ref_headings
+from raft_amd.metrics import group_rel_err
 
 fx, model = load_model_fixture("c4_farm.npz")            # nw = 200, the 50 seeded sea states of default_rng(1)
 cases = [case_from_fixture(c) for c in fx["cases"]]

@@ -21,11 +21,11 @@ for rep in range(reps):
     for name in libs:
         path = HIP_LIB_PATH if name == "head" else os.path.join(ROOT, name)
         ctx = RaftxLib(path).context(0)
-        sw = bench.generate_sweep(ctx, int(os.environ.get("EXP_DESIGNS", "10000")), 0)
-        ctx.upload_cases(sw["w"], sw["k"], sw["depth"], 1025.0, 9.81, sw["zeta"][None], sw["beta"][None])
+        sw, _, _ = bench.make_sweep(ctx, int(os.environ.get("EXP_DESIGNS", "10000")), 0, pinned=False)
+        sw.upload(ctx)                          # device-generated tables + the sea state (the bench workload)
         ms = []
         for i in range(25):
-            ctx.solve_dynamics_device(sw["nIter"], float(os.environ.get("EXP_TOL", "0.01")), sw["XiStart"])
+            ctx.solve_dynamics_device(sw.nIter, float(os.environ.get("EXP_TOL", "0.01")), sw.XiStart)
             if i >= 5:
                 ms.append(ctx.last_kernel_ms())
         res = ctx.fetch_results(want_Xi=False)

@@ -9,23 +9,7 @@ from raft_amd.metrics import group_rel_err, rao_group_err, psd_group_err, rel_er
 from raft_amd.geometry import volturnus_sweep                                            # noqa: F401,E402
 
 
-def case_from_fixture(c):
-    case = {}
-    for k, v in c["case"].items():
-        case[k] = list(v) if isinstance(v, (list, np.ndarray)) else v
-    return copy.deepcopy(case)
-
-
-def ref_headings(c):
-    """(reference responses of the wave headings [nH,6N,nw], nH) of a fixture case.  Full cases store the reference's
-    Xi with its zero rotor-excitation row (raft_model.py:1236), lean ones (many-case fixtures) without it."""
-    nH = len(np.atleast_1d(np.asarray(c["case"]["wave_heading"], dtype=float)))
-    return np.asarray(c["Xi"])[:nH], nH
-
-
-def load_model_fixture(name):
-    fx = standin.load_fixture(name)
-    return fx, standin.build_model(fx["model"])
+from raft_amd.snapshot import case_from_fixture, ref_headings, load_model_fixture     # noqa: F401,E402
 
 
 # ------------------------------------------------------------------ synthetic inputs
