@@ -155,6 +155,8 @@ struct GeomArgs {
     long long *tot;              // [3] wet strips, MacCamy-Fuchs rows, strips of the largest design (zeroed before the scans)
     // A block of a larger batch reads the batch's own offset arrays (uploaded once, shared by its blocks): the pointers
     // are shifted to the block's first design / member and the bases make the values block-relative.
+    long long *hostOut;          // page-locked host memory the device writes directly (no DMA copy to queue behind a bulk
+                                 // download): [0..2] = tot, [3..4] = err as 4 ints, [8 .. 8 + nDesign] = off
     int64_t mbase, sbase, cbase;
     int *mdesign_w;              // mdesign, writable (filled on the device by k_geom_mdesign)
     __device__ int64_t mo(int d) const { return memberOff[d] - mbase; }
@@ -756,18 +758,29 @@ __global__ __launch_bounds__(1024) void k_geom_scan(GeomArgs A) {
         A.cmoff[0] = 0;
         A.tot[0] = sa;
         A.tot[1] = sb;
+        if (A.hostOut) {
+            A.hostOut[0] = sa;
+            A.hostOut[1] = sb;
+            A.hostOut[2] = A.tot[2];                     // final: k_geom_design_counts has completed
+            A.hostOut[8] = 0;
+        }
     }
     __syncthreads();
     a = part[0][t]; b = part[1][t];
     for (int i = lo; i < hi; i++) {                      // inclusive running totals -> offsets of design i+1
         a += A.off[i + 1]; b += A.cmoff[i + 1];
         A.off[i + 1] = a; A.cmoff[i + 1] = b;
+        if (A.hostOut) A.hostOut[8 + i + 1] = a;
     }
 }
 // member offsets from the design offsets
 __global__ void k_geom_offsets(GeomArgs A) {
-    if (A.err[2] | A.err[3]) return;                      // rejected descriptors: phase 2 reports them
     const int d = blockIdx.x * blockDim.x + threadIdx.x;
+    if (d == 0 && A.hostOut) {                            // the last kernel of phase 1: every error flag is final
+        int *e = reinterpret_cast<int *>(A.hostOut + 3);
+        e[0] = A.err[0]; e[1] = A.err[1]; e[2] = A.err[2]; e[3] = A.err[3];
+    }
+    if (A.err[2] | A.err[3]) return;                      // rejected descriptors: phase 2 reports them
     if (d >= A.nDesign) return;
     int64_t a = A.off[d], b = A.cmoff[d];
     for (int64_t m = A.mo(d); m < A.mo(d + 1); m++) {

@@ -197,6 +197,15 @@ static int solve_system_shape(int n, int nRhs, size_t *lds) {
     return nbin;
 }
 
+// iteration counts and flags of a block straight into page-locked host memory (out[0..n) = a, out[n..2n) = b)
+__global__ void k_ints_to_host(int n, const int *__restrict__ a, const int *__restrict__ b, int *__restrict__ out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) {
+        out[i] = a[i];
+        out[n + i] = b[i];
+    }
+}
+
 // Motion statistics of the resident responses (raft_fowt.py:2310-2357; helpers.py:678-700): one
 // workgroup per (design, case), lanes stride the frequency axis (coalesced 16 B/lane reads of the
 // Xi slab: a pure HBM stream, 19.2 KB in -> 48 B out per pair at C3).
@@ -805,6 +814,8 @@ static int build_phase1(raftx_ctx *c, hipStream_t sCopy, hipStream_t sPrep, int 
     A.nMember = nMember;
     A.rho = rho; A.g = g; A.nw = nw; A.add_mask = add_mask;
     A.mbase = m0; A.sbase = s0; A.cbase = c0;
+    A.hostOut = c->pin;
+    memset(c->pin, 0, 9 * sizeof(long long));
     J.nDesign = nDesign; J.nw = nw; J.add_mask = add_mask; J.nMember = nMember;
     int rc = 0;
     if (shared) {
@@ -894,9 +905,8 @@ static int build_phase1(raftx_ctx *c, hipStream_t sCopy, hipStream_t sPrep, int 
         hipLaunchKernelGGL(k_geom_offsets, dim3((unsigned)(nDesign / 256 + 1)), dim3(256), 0, sPrep, A);
     }
     HIPCHK(c, hipEventRecord(c->evG3, sPrep));
-    HIPCHK(c, hipMemcpyAsync(c->pin, A.tot, 3 * sizeof(long long), hipMemcpyDeviceToHost, sPrep));
-    HIPCHK(c, hipMemcpyAsync(c->pin + 3, errd, 4 * sizeof(int), hipMemcpyDeviceToHost, sPrep));
-    HIPCHK(c, hipMemcpyAsync(c->pin + 8, A.off, ((size_t)nDesign + 1) * sizeof(int64_t), hipMemcpyDeviceToHost, sPrep));
+    // totals, error flags and design offsets reach the host through the kernels' own stores into page-locked memory
+    // (A.hostOut): a D2H copy of them would queue on the DMA engine behind a bulk download of the previous batch
     HIPCHK(c, hipEventRecord(c->evTot, sPrep));
     J.active = true;
     return 0;
@@ -2111,27 +2121,17 @@ extern "C" int raftx_sweep_submit(raftx_ctx *c, int slot, int nDesign, const int
                 sub->pinRes_n = need;
             }
         }
-        double *dS = nullptr;
         if (!rc) {
-            void *p_ = nullptr;
-            if (sub->pool.get((npair ? npair : 1) * 6 * sizeof(double), &p_) != hipSuccess) rc = -2;
-            else sub->job.tmp.push_back(p_);
-            dS = reinterpret_cast<double *>(p_);
-        }
-        if (!rc) {
+            // statistics, iteration counts and flags go straight into the block's page-locked landing area (the kernels
+            // store there: no small D2H copy that could queue on the DMA engine behind a bulk download)
             hipError_t e = hipEventRecord(sub->evS0, c->stream);
-            if (npair)
+            if (npair) {
                 hipLaunchKernelGGL(k_motion_stats, dim3((unsigned)npair), dim3(nw > 128 ? 256 : (nw > 64 ? 128 : 64)), 0, c->stream,
-                                   (int)npair, nHead, nw, 1.0 / dw, sub->rXi, dS, (double *)nullptr);
-            if (e == hipSuccess) e = hipEventRecord(sub->evS1, c->stream);
-            if (e == hipSuccess && npair) {
-                e = hipMemcpyAsync(sub->pinRes, dS, npair * 6 * sizeof(double), hipMemcpyDeviceToHost, c->stream);
-                if (e == hipSuccess)
-                    e = hipMemcpyAsync(sub->pinRes + npair * 6, sub->rNi, npair * sizeof(int), hipMemcpyDeviceToHost, c->stream);
-                if (e == hipSuccess)
-                    e = hipMemcpyAsync(reinterpret_cast<int *>(sub->pinRes + npair * 6) + npair, sub->rFl, npair * sizeof(int),
-                                       hipMemcpyDeviceToHost, c->stream);
+                                   (int)npair, nHead, nw, 1.0 / dw, sub->rXi, sub->pinRes, (double *)nullptr);
+                hipLaunchKernelGGL(k_ints_to_host, dim3((unsigned)((npair + 255) / 256)), dim3(256), 0, c->stream, (int)npair, sub->rNi,
+                                   sub->rFl, reinterpret_cast<int *>(sub->pinRes + npair * 6));
             }
+            if (e == hipSuccess) e = hipEventRecord(sub->evS1, c->stream);
             if (e == hipSuccess) e = hipEventRecord(sub->evDone, c->stream);
             if (e != hipSuccess) {
                 snprintf(sub->err, sizeof(sub->err), "statistics / download of the block: %s", hipGetErrorString(e));
