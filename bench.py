@@ -201,6 +201,12 @@ def main():
 
     from raft_amd import backend
     from raft_amd.metrics import rao_group_err
+    # the rank's host thread and page-locked buffers go onto the socket its GPU hangs off (raft_amd/locality.py);
+    # the original CPU set comes back for the oracle leg, which wants every core
+    from raft_amd import locality
+    cpus_at_start = os.sched_getaffinity(0)
+    placement = ({"bound": False, "why": "RAFTX_NO_BIND"} if os.environ.get("RAFTX_NO_BIND")
+                 else locality.bind_near_device(backend.hip_library(), local))
     ctx = backend.hip_library().context(local)
     sw, fx, geo = make_sweep(ctx, args.designs, rank, pinned=not args.pageable)
     nw, nD = sw.nw, sw.n_design
@@ -300,6 +306,7 @@ def main():
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        os.sched_setaffinity(0, cpus_at_start)
         cpu, ores = oracle_run(sw, ctx)
         e = [rao_group_err(Xi[d, 0, 0], ores["Xi"][d, 0, 0], sw.zeta[0, 0]) for d in range(nD)]
         parity["oracle_checked_designs"] = int(nD)
@@ -362,6 +369,7 @@ def main():
         "roofline_fp64_valu": {"achieved": flops / (k_sum_ms * 1e-3) / 1e12, "peak": FP64_VALU_PEAK_TF, "unit": "TFLOP/s",
                                "frac": flops / (k_sum_ms * 1e-3) / 1e12 / FP64_VALU_PEAK_TF,
                                "algorithmic_flops_per_step": flops},
+        "host_placement": placement,
         "geometry": dict(geo, strips=int(off[-1]), strip_table_bytes_not_uploaded=int(off[-1]) * 256),
     }
     if isolated is not None:

@@ -443,6 +443,12 @@ int raftx_comm_reduce_sum(raftx_ctx *ctx, double *buf, size_t n, int root);
 int raftx_host_alloc(raftx_ctx *ctx, size_t bytes, void **out);
 int raftx_host_free(raftx_ctx *ctx, void *ptr);
 
+/* Where device `device` sits on the host: its PCI address (into pci_bus_id, at most len bytes incl. the terminator)
+ * and the NUMA node sysfs reports for it (-1 when unknown).  One process per GPU feeds 16 GB/s of descriptors from
+ * page-locked memory: raft_amd/locality.py pins the process to that node's cores BEFORE the ctx and its buffers are
+ * created, so that on a two-socket host no rank's stream crosses the socket link.  The oracle reports ("", -1). */
+int raftx_device_locality(int device, char *pci_bus_id, int len, int *numa_node);
+
 /* Duration (ms) of the device work of the last raftx_excitation /
  * raftx_linearize / raftx_solve_dynamics / raftx_solve_system call on this
  * ctx, measured with HIP events on the ctx's own stream (excludes H2D/D2H).

@@ -25,7 +25,7 @@ EXPORTS = (
     "raftx_excitation", "raftx_linearize", "raftx_solve_dynamics",
     "raftx_solve_system", "raftx_last_kernel_ms",
     "raftx_solve_dynamics_device", "raftx_fetch_results", "raftx_debug_math", "raftx_motion_stats", "raftx_solve_system_resident", "raftx_qtf_slender", "raftx_channel_stats", "raftx_qtf_force", "raftx_set_linearisation_point", "raftx_fetch_linearisation_point",
-    "raftx_build_designs", "raftx_fetch_strips", "raftx_fetch_statics", "raftx_channel_stats_poly", "raftx_qtf_slender_rows", "raftx_bem_excitation", "raftx_qtf_kay", "raftx_host_alloc", "raftx_host_free",
+    "raftx_build_designs", "raftx_fetch_strips", "raftx_fetch_statics", "raftx_channel_stats_poly", "raftx_qtf_slender_rows", "raftx_bem_excitation", "raftx_qtf_kay", "raftx_host_alloc", "raftx_host_free", "raftx_device_locality",
     "raftx_sweep_stats",
     "raftx_sweep_submit",
     "raftx_sweep_wait",
@@ -111,6 +111,8 @@ class RaftxLib:
         L.raftx_qtf_force.restype = C.c_int
         L.raftx_channel_stats.argtypes = [_vp, C.c_int, _vp, _vp, C.c_double, _vp, _vp]
         L.raftx_channel_stats.restype = C.c_int
+        L.raftx_device_locality.argtypes = [C.c_int, C.c_char_p, C.c_int, C.POINTER(C.c_int)]
+        L.raftx_device_locality.restype = C.c_int
         L.raftx_host_alloc.argtypes = [_vp, C.c_size_t, C.POINTER(_vp)]
         L.raftx_host_alloc.restype = C.c_int
         L.raftx_host_free.argtypes = [_vp, _vp]
@@ -166,6 +168,15 @@ class RaftxLib:
 
     def context(self, device_id=0):
         return Context(self, device_id)
+
+    def device_locality(self, device_id=0):
+        """(PCI address, NUMA node or -1) of a device: raftx_device_locality."""
+        buf = C.create_string_buffer(64)
+        node = C.c_int(-1)
+        rc = self.lib.raftx_device_locality(int(device_id), buf, len(buf), C.byref(node))
+        if rc != 0:
+            raise RaftxError("raftx_device_locality(device=%d) failed (rc=%d)" % (device_id, rc))
+        return buf.value.decode(), node.value
 
 
 class Context:

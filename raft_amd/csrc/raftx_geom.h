@@ -492,6 +492,15 @@ __device__ inline int geom_member_inertia(const double *gm, const double *gs, in
 }
 
 // one thread per member: pose, wet-strip count, hydrostatics and inertia about the member's own node
+// clears what the pass accumulates into (one launch instead of five fills: every launch of the preparation stream has
+// to find a free wave slot beside the fused kernel of the batch before)
+__global__ void k_geom_zero(GeomArgs A) {
+    const int d = blockIdx.x * blockDim.x + threadIdx.x;
+    if (d < A.nDesign) A.drho[d] = 0.0;
+    if (d < 4) A.err[d] = 0;
+    if (d < 3) A.tot[d] = 0;
+    if (d == 0) { A.off[0] = 0; A.cmoff[0] = 0; }
+}
 // design of every member (thread per design); also rejects non-monotone member offsets (err[2] = design + 1)
 __global__ void k_geom_mdesign(GeomArgs A) {
     const int d = blockIdx.x * blockDim.x + threadIdx.x;
@@ -791,13 +800,21 @@ __global__ void k_geom_offsets(GeomArgs A) {
 }
 
 // one wavefront per member: lanes = the member's strips in order; wet strips are compacted with ballots
+#define GEOM_FILL_STAGE 24       // stations of a member staged in LDS (3 KB)
 __global__ __launch_bounds__(64) void k_geom_fill(GeomArgs A) {
     GEOM_NOFMA
     const int64_t m = blockIdx.x;
     const int lane = threadIdx.x;
     const double *gm = A.gm + (size_t)m * RAFTX_GM_N;
-    const double *gs = A.gs + (size_t)A.so(m) * RAFTX_GS_N;
+    const double *gsg = A.gs + (size_t)A.so(m) * RAFTX_GS_N;
     const int n = (int)(A.so(m + 1) - A.so(m));
+    // the member's station table is read many times per strip (interpolations): keep it in LDS when it is small
+    __shared__ double sgs[GEOM_FILL_STAGE * RAFTX_GS_N];
+    const bool staged = n <= GEOM_FILL_STAGE;
+    if (staged)
+        for (int t = lane; t < n * RAFTX_GS_N; t += 64) sgs[t] = gsg[t];
+    __syncthreads();
+    const double *gs = staged ? sgs : gsg;
     const int d = A.mdesign[m];
     const double *mp = A.mpose + (size_t)m * MP_N;
     const bool circ = gm[RAFTX_GM_SHAPE] != 0.0;

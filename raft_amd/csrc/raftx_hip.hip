@@ -671,6 +671,24 @@ extern "C" int raftx_host_free(raftx_ctx *c, void *ptr) {
     return 0;
 }
 
+// Where the GPU sits on the host: PCI address and NUMA node (sysfs), for placing the feeding thread and its page-locked
+// buffers on the socket the GPU hangs off.  No ctx: callers ask before they create one.
+extern "C" int raftx_device_locality(int device, char *pci_bus_id, int len, int *numa_node) {
+    if (numa_node) *numa_node = -1;
+    char id[64] = {0};
+    if (hipDeviceGetPCIBusId(id, (int)sizeof(id), device) != hipSuccess) return -2;
+    if (pci_bus_id && len > 0) snprintf(pci_bus_id, (size_t)len, "%s", id);
+    for (char *p = id; *p; p++) *p = (char)tolower(*p);
+    char path[160];
+    snprintf(path, sizeof(path), "/sys/bus/pci/devices/%s/numa_node", id);
+    if (FILE *f = fopen(path, "r")) {
+        int node = -1;
+        if (fscanf(f, "%d", &node) == 1 && numa_node) *numa_node = node;
+        fclose(f);
+    }
+    return 0;
+}
+
 extern "C" const char *raftx_last_error(raftx_ctx *c) { return c ? c->err : "null ctx"; }
 extern "C" double raftx_last_kernel_ms(raftx_ctx *c) { return c ? c->last_ms : 0.0; }
 
@@ -882,9 +900,7 @@ static int build_phase1(raftx_ctx *c, hipStream_t sCopy, hipStream_t sPrep, int 
         A.off = (int64_t *)p_[10]; A.cmoff = (int64_t *)p_[11];
         A.mdesign_w = (int *)p_[12]; A.mdesign = A.mdesign_w;
     }
-    HIPCHK(c, hipMemsetAsync(errd, 0, 4 * sizeof(int), sPrep));
-    HIPCHK(c, hipMemsetAsync(A.drho, 0, (size_t)(nDesign ? nDesign : 1) * sizeof(double), sPrep));
-    HIPCHK(c, hipMemsetAsync(A.tot, 0, 3 * sizeof(long long), sPrep));
+    hipLaunchKernelGGL(k_geom_zero, dim3((unsigned)(nDesign / 256 + 1)), dim3(256), 0, sPrep, A);
     HIPCHK(c, hipEventRecord(c->evG2, sPrep));
     if (nDesign > 0) hipLaunchKernelGGL(k_geom_mdesign, dim3((unsigned)(nDesign / 256 + 1)), dim3(256), 0, sPrep, A);
     if (nMember > 0) {
@@ -897,8 +913,6 @@ static int build_phase1(raftx_ctx *c, hipStream_t sCopy, hipStream_t sPrep, int 
         HIPCHK(c, hipMemsetAsync(A.soff, 0, sizeof(int64_t), sPrep));
         HIPCHK(c, hipMemsetAsync(A.cmsoff, 0, sizeof(int64_t), sPrep));
     }
-    HIPCHK(c, hipMemsetAsync(A.off, 0, sizeof(int64_t), sPrep));
-    HIPCHK(c, hipMemsetAsync(A.cmoff, 0, sizeof(int64_t), sPrep));
     if (nDesign > 0) {
         hipLaunchKernelGGL(k_geom_design_counts, dim3((unsigned)(nDesign / 256 + 1)), dim3(256), 0, sPrep, A);
         hipLaunchKernelGGL(k_geom_scan, dim3(1), dim3(1024), 0, sPrep, A);
