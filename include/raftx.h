@@ -210,6 +210,16 @@ int raftx_solve_system(raftx_ctx *ctx, int nSys, int nUnit, int nRhs, int nw,
                        const double *Mc, const double *Bc, const double *Cc,
                        const raftx_c128 *F, raftx_c128 *Xi);
 
+/* Impedance solve of ONE unit with n reduced DOFs (n > 6: flexible members, raft_model.py:1081-1088 with the
+ * nDOF x nDOF matrices of raft_fowt.py's T reduction -- 150 for the reference's VolturnUS-S-flexible deck): per bin
+ *   Z = -w^2 M + i w B + C,  Xi[r] = Z^-1 F[r].
+ * M, B [n,n], or [n,n,nw] where bit 0 (M) / bit 1 (B) of freq_mask is set; C [n,n]; F, Xi [nRhs,n,nw];
+ * Z [n,n,nw] out or NULL.  The drag linearisation of such a unit runs node by node through raftx_linearize (every
+ * structural node with wet strips is one "design" about its own position, raft_member.py:2046-2056); the projections
+ * with the unit's T matrix between the two calls are host glue (raft_amd/dropin.py Engine._solve_general). */
+int raftx_solve_dense(raftx_ctx *ctx, int n, int nRhs, int nw, const double *w, const double *M, const double *B,
+                      const double *C, int freq_mask, const raftx_c128 *F, raftx_c128 *Xi, raftx_c128 *Z);
+
 /* The same coupled solve fed from the RESIDENT results of raftx_solve_dynamics_device (which must have
  * kept Z and F_wave): consecutive groups of nUnit designs are the units of one array; for group g,
  * case c: Z_sys = blockdiag_u(Z[g*nUnit+u, c]) + (-w^2 Mc[g] + i w Bc[g] + Cc[g]),

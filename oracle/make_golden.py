@@ -676,7 +676,56 @@ def fixture_f4():
     standin.save_fixture(os.path.join(GOLD, "f4_oc4semi_qtf12d.npz"), fx)
 
 
-ALL = {"f4": fixture_f4, "c5full": fixture_c5_full, "refstatics": fixture_ref_statics, "refmembers": fixture_ref_members, "bem": fixture_bem, "geom": fixture_geom, "c5oc4": fixture_c5_oc4, "c5": fixture_c5, "qtf": fixture_qtf, "c1": fixture_c1, "c2": fixture_c2, "pose": fixture_pose,
+def fixture_flexible():
+    """The reference's flexible deck (tests/test_data/VolturnUS-S-flexible.yaml: beam pontoons and tower, 150 reduced /
+    360 full DOFs): (i) its OWN hydroLinearization golden (tests/test_fowt.py:150-175; the deck ships no
+    hydroExcitation pickle), set up exactly as that test does, plus live F_hydro_iner of a few of the excitation test's
+    cases in its place; (ii) live Model.solveDynamics for one- and two-heading sea states."""
+    raft = rh.import_raft()
+    name = "VolturnUS-S-flexible"
+    d = rh.prepare_design(rh.load_design(os.path.join(REF, "tests/test_data", name + ".yaml")))
+    model = raft.Model(d)
+    fowt = model.fowtList[0]
+    fowt.setPosition(np.zeros(fowt.nDOF))              # tests/test_fowt.py:46-48
+    fowt.calcStatics()
+    fowt.calcHydroConstants()
+    fowt.calcTurbineConstants(rh.make_case(), ptfm_pitch=0)
+    fowt.C_moor = np.zeros((fowt.nDOF, fowt.nDOF))
+    with open(os.path.join(REF, "tests/test_data", name + "_true_hydroLinearization.pkl"), "rb") as f:
+        lin = pickle.load(f)
+    exc_cases = [dict(wave_heading=h, wave_period=T, wave_height=H)
+                 for h, T, H in ((0, 10, 2), (45, 5, 1), (135, 15, 2), (270, 20, 1))]
+    exc_F, exc_full = [], []
+    for c in exc_cases:
+        fowt.calcHydroExcitation(dict(c, wave_spectrum="JONSWAP"), memberList=fowt.memberList)
+        exc_F.append(np.array(fowt.F_hydro_iner))
+        exc_full.append(np.array(fowt.F_hydro_iner_fullDOF))
+    fx = {"config": "reference goldens " + name, "model": standin.snapshot_model(model),
+          "exc_cases": [dict(c, wave_spectrum="JONSWAP") for c in exc_cases], "exc_F_hydro_iner": np.array(exc_F),
+          "exc_F_hydro_iner_fullDOF": np.array(exc_full),
+          "lin_B_hydro_drag": np.array(lin["B_hydro_drag"]), "lin_F_hydro_drag": np.array(lin["F_hydro_drag"])}
+    standin.save_fixture(os.path.join(GOLD, "refgold_%s.npz" % name), fx)
+
+    cm = np.zeros((fowt.nDOF, fowt.nDOF))
+    cm[:6, :6] = rh.DEFAULT_C_MOOR
+    m = rh.build_model(d, c_moor=cm)
+    cases = [rh.make_case(Hs=6.0, Tp=12.0, heading=15.0),
+             rh.make_case(Hs=[6.0, 3.0], Tp=[12.0, 9.0], heading=[0.0, 30.0], spectrum=["JONSWAP", "JONSWAP"], gamma=[0, 0])]
+    sols = []
+    for c in cases:
+        r = run_case(m, c, lean=True)
+        r["Xi_fullDOF"] = np.array(m.fowtList[0].Xi_fullDOF)[:-1]
+        sols.append(r)
+    m.nIter = 15                                        # the deck's own nIter = 4 stops unconverged: one run to convergence
+    r = run_case(m, rh.make_case(Hs=9.0, Tp=14.0, heading=200.0), lean=True)
+    r["Xi_fullDOF"] = np.array(m.fowtList[0].Xi_fullDOF)[:-1]
+    m.nIter = 4
+    fx = {"config": "VolturnUS-S-flexible (150 reduced DOFs), live reference solveDynamics", "model": standin.snapshot_model(m),
+          "cases": sols, "nIter_converged": 15, "case_converged": r}
+    standin.save_fixture(os.path.join(GOLD, "flex_volturnus.npz"), fx)
+
+
+ALL = {"flexible": fixture_flexible, "f4": fixture_f4, "c5full": fixture_c5_full, "refstatics": fixture_ref_statics, "refmembers": fixture_ref_members, "bem": fixture_bem, "geom": fixture_geom, "c5oc4": fixture_c5_oc4, "c5": fixture_c5, "qtf": fixture_qtf, "c1": fixture_c1, "c2": fixture_c2, "pose": fixture_pose,
        "refgold": fixture_ref_goldens, "c4": fixture_c4, "c3": fixture_c3}
 
 if __name__ == "__main__":

@@ -25,7 +25,7 @@ EXPORTS = (
     "raftx_excitation", "raftx_linearize", "raftx_solve_dynamics",
     "raftx_solve_system", "raftx_last_kernel_ms",
     "raftx_solve_dynamics_device", "raftx_fetch_results", "raftx_debug_math", "raftx_motion_stats", "raftx_solve_system_resident", "raftx_qtf_slender", "raftx_channel_stats", "raftx_qtf_force", "raftx_set_linearisation_point", "raftx_fetch_linearisation_point",
-    "raftx_build_designs", "raftx_fetch_strips", "raftx_fetch_statics", "raftx_channel_stats_poly", "raftx_qtf_slender_rows", "raftx_bem_excitation", "raftx_qtf_kay", "raftx_host_alloc", "raftx_host_free", "raftx_device_locality",
+    "raftx_build_designs", "raftx_fetch_strips", "raftx_fetch_statics", "raftx_channel_stats_poly", "raftx_qtf_slender_rows", "raftx_bem_excitation", "raftx_qtf_kay", "raftx_host_alloc", "raftx_host_free", "raftx_device_locality", "raftx_solve_dense",
     "raftx_sweep_stats",
     "raftx_sweep_submit",
     "raftx_sweep_wait",
@@ -111,6 +111,8 @@ class RaftxLib:
         L.raftx_qtf_force.restype = C.c_int
         L.raftx_channel_stats.argtypes = [_vp, C.c_int, _vp, _vp, C.c_double, _vp, _vp]
         L.raftx_channel_stats.restype = C.c_int
+        L.raftx_solve_dense.argtypes = [_vp, C.c_int, C.c_int, C.c_int, _vp, _vp, _vp, _vp, C.c_int, _vp, _vp, _vp]
+        L.raftx_solve_dense.restype = C.c_int
         L.raftx_device_locality.argtypes = [C.c_int, C.c_char_p, C.c_int, C.POINTER(C.c_int)]
         L.raftx_device_locality.restype = C.c_int
         L.raftx_host_alloc.argtypes = [_vp, C.c_size_t, C.POINTER(_vp)]
@@ -655,6 +657,29 @@ class Context:
                                               _ptr(Mc), _ptr(Bc), _ptr(Cc), _ptr(F), _ptr(Xi))
         self._check(rc, "raftx_solve_system")
         return Xi
+
+    def solve_dense(self, w, M, B, C_, F, want_Z=False):
+        """Xi [nRhs,n,nw] (and Z [n,n,nw]) of one n-DOF unit: raftx_solve_dense.  M, B: [n,n] or [n,n,nw]."""
+        w = _f64(w)
+        nw = len(w)
+        F = _c128(F)
+        nR, n = F.shape[0], F.shape[1]
+        if F.shape != (nR, n, nw):
+            raise ValueError("F must be [nRhs,n,nw]")
+        M, B = _f64(M), _f64(B)
+        mask = 0
+        for bit, A, name in ((1, M, "M"), (2, B, "B")):
+            if A.shape == (n, n, nw):
+                mask |= bit
+            elif A.shape != (n, n):
+                raise ValueError("%s must be [n,n] or [n,n,nw]" % name)
+        C_ = _f64(C_, (n, n), "C")
+        Xi = np.empty((nR, n, nw), dtype=np.complex128)
+        Z = np.empty((n, n, nw), dtype=np.complex128) if want_Z else None
+        rc = self.rlib.lib.raftx_solve_dense(self._h, n, nR, nw, _ptr(w), _ptr(M), _ptr(B), _ptr(C_), mask, _ptr(F),
+                                             _ptr(Xi), _ptr(Z))
+        self._check(rc, "raftx_solve_dense")
+        return (Xi, Z) if want_Z else Xi
 
     def debug_math(self, x):
         x = _f64(x).ravel()

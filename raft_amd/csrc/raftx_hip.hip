@@ -197,6 +197,109 @@ static int solve_system_shape(int n, int nRhs, size_t *lds) {
     return nbin;
 }
 
+// General dense impedance solve for units with more than 6 reduced DOFs (flexible members: raft_model.py:1081-1088 with
+// nDOF x nDOF matrices, 150 for the reference's flexible VolturnUS-S).  One workgroup per frequency bin; the augmented
+// matrix [Z | F] of the bin lives in a global workspace (n = 150: 360 KB, beyond LDS, resident in L2), the pivot row and
+// the multiplier column of every elimination step are staged in LDS.  Partial pivoting by |re| + |im|, first largest
+// (zgetrf's izamax).  M and B are [n,n] or, with the bit of freq_mask set, [n,n,nw].
+#define DENSE_MAX_LD 1536
+__global__ void __launch_bounds__(256) k_solve_dense(int n, int nRhs, int nw, const double *__restrict__ w,
+                                                     const double *__restrict__ M, const double *__restrict__ B,
+                                                     const double *__restrict__ C, int freq_mask,
+                                                     const cplx *__restrict__ F, cplx *__restrict__ work,
+                                                     cplx *__restrict__ Xi, cplx *__restrict__ Zout) {
+    __shared__ cplx rowk[DENSE_MAX_LD], colk[DENSE_MAX_LD];
+    __shared__ double rbest[4];
+    __shared__ int rrow[4];
+    const int iw = blockIdx.x, ld = n + nRhs, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    cplx *A = work + (size_t)iw * n * ld;
+    const double ww = w[iw];
+    const bool mw = freq_mask & 1, bw = freq_mask & 2;
+    for (int e = tid; e < n * ld; e += 256) {
+        const int r = e / ld, c = e % ld;
+        cplx v;
+        if (c < n) {
+            const size_t o = (size_t)r * n + c;
+            const double m = mw ? M[o * nw + iw] : M[o], b = bw ? B[o * nw + iw] : B[o];
+            v = cplx{-(ww * ww) * m + C[o], ww * b};
+            if (Zout) Zout[o * nw + iw] = v;
+        } else {
+            v = F[((size_t)(c - n) * n + r) * nw + iw];
+        }
+        A[e] = v;
+    }
+    __syncthreads();
+    for (int k = 0; k < n; k++) {
+        double best = -1.0;
+        int p = n;
+        for (int r = k + tid; r < n; r += 256) {
+            const cplx a = A[(size_t)r * ld + k];
+            const double v = fabs(a.re) + fabs(a.im);
+            if (v > best) {
+                best = v;
+                p = r;
+            }
+        }
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) argmax_step(best, p, off);
+        if (lane == 0) {
+            rbest[wv] = best;
+            rrow[wv] = p;
+        }
+        __syncthreads();
+        best = rbest[0];
+        p = rrow[0];
+        for (int i = 1; i < 4; i++)
+            if (rbest[i] > best || (rbest[i] == best && rrow[i] < p)) {
+                best = rbest[i];
+                p = rrow[i];
+            }
+        if (p >= n) p = k;                                    // a column of NaNs: no row compares larger
+        for (int c = k + tid; c < ld; c += 256) {            // swap rows k and p; the pivot row goes to LDS
+            const cplx t = A[(size_t)k * ld + c], u = A[(size_t)p * ld + c];
+            A[(size_t)p * ld + c] = t;
+            A[(size_t)k * ld + c] = u;
+            rowk[c] = u;
+        }
+        __syncthreads();
+        const cplx pv = rowk[k];
+        const double dd = pv.re * pv.re + pv.im * pv.im;
+        const cplx inv = {pv.re / dd, -pv.im / dd};
+        for (int r = k + 1 + tid; r < n; r += 256) {
+            const cplx l = cmul(A[(size_t)r * ld + k], inv);
+            A[(size_t)r * ld + k] = l;
+            colk[r] = l;
+        }
+        __syncthreads();
+        for (int r = k + 1 + wv; r < n; r += 4) {            // a wave per row, lanes along the row
+            const cplx l = colk[r];
+            cplx *row = A + (size_t)r * ld;
+            for (int c = k + 1 + lane; c < ld; c += 64) row[c] = csub(row[c], cmul(l, rowk[c]));
+        }
+        __syncthreads();
+    }
+    for (int k = n - 1; k >= 0; k--) {                        // back substitution on the right-hand columns
+        const cplx pv = A[(size_t)k * ld + k];
+        const double dd = pv.re * pv.re + pv.im * pv.im;
+        for (int j = tid; j < nRhs; j += 256) {
+            const cplx sum = A[(size_t)k * ld + n + j];
+            const cplx x = {(sum.re * pv.re + sum.im * pv.im) / dd, (sum.im * pv.re - sum.re * pv.im) / dd};
+            A[(size_t)k * ld + n + j] = x;
+            rowk[j] = x;
+        }
+        __syncthreads();
+        for (int e = tid; e < k * nRhs; e += 256) {
+            const int r = e / nRhs, j = e % nRhs;
+            A[(size_t)r * ld + n + j] = csub(A[(size_t)r * ld + n + j], cmul(A[(size_t)r * ld + k], rowk[j]));
+        }
+        __syncthreads();
+    }
+    for (int e = tid; e < n * nRhs; e += 256) {
+        const int r = e % n, j = e / n;
+        Xi[((size_t)j * n + r) * nw + iw] = A[(size_t)r * ld + n + j];
+    }
+}
+
 // iteration counts and flags of a block straight into page-locked host memory (out[0..n) = a, out[n..2n) = b)
 __global__ void k_ints_to_host(int n, const int *__restrict__ a, const int *__restrict__ b, int *__restrict__ out) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1716,6 +1819,34 @@ extern "C" int raftx_solve_system(raftx_ctx *c, int nSys, int nUnit, int nRhs, i
     }
     if (finish_timed(c)) return -2;
     if (nSys) D2H(c, Xi, dX, nf * sizeof(cplx));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+extern "C" int raftx_solve_dense(raftx_ctx *c, int n, int nRhs, int nw, const double *w, const double *M, const double *B,
+                                 const double *C, int freq_mask, const raftx_c128 *F, raftx_c128 *Xi, raftx_c128 *Z) {
+    if (!c) return -1;
+    if (n < 1 || nRhs < 1 || nw < 1 || !w || !M || !B || !C || !F || !Xi) FAIL(c, "solve_dense: bad arguments");
+    if (n + nRhs > DENSE_MAX_LD) FAIL(c, "solve_dense: %d DOFs + %d right-hand sides exceed %d", n, nRhs, DENSE_MAX_LD);
+    HIPCHK(c, hipSetDevice(c->device));
+    Scratch sc(c);
+    const size_t nn = (size_t)n * n, nf = (size_t)nRhs * n * nw;
+    const size_t nM = nn * ((freq_mask & 1) ? nw : 1), nB = nn * ((freq_mask & 2) ? nw : 1);
+    double *dw = sc.alloc<double>(nw), *dM = sc.alloc<double>(nM), *dB = sc.alloc<double>(nB), *dC = sc.alloc<double>(nn);
+    cplx *dF = sc.alloc<cplx>(nf), *dX = sc.alloc<cplx>(nf), *dA = sc.alloc<cplx>((size_t)nw * n * (n + nRhs));
+    cplx *dZ = Z ? sc.alloc<cplx>(nn * nw) : nullptr;
+    if (!dw || !dM || !dB || !dC || !dF || !dX || !dA || (Z && !dZ)) FAIL(c, "solve_dense: device allocation failed");
+    H2D(c, dw, w, nw * sizeof(double));
+    H2D(c, dM, M, nM * sizeof(double));
+    H2D(c, dB, B, nB * sizeof(double));
+    H2D(c, dC, C, nn * sizeof(double));
+    H2D(c, dF, F, nf * sizeof(cplx));
+    HIPCHK(c, hipEventRecord(c->ev0, c->stream));
+    hipLaunchKernelGGL(k_solve_dense, dim3((unsigned)nw), dim3(256), 0, c->stream, n, nRhs, nw, dw, dM, dB, dC, freq_mask,
+                       dF, dA, dX, dZ);
+    if (finish_timed(c)) return -2;
+    D2H(c, Xi, dX, nf * sizeof(cplx));
+    if (Z) D2H(c, Z, dZ, nn * nw * sizeof(cplx));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     return 0;
 }

@@ -27,7 +27,7 @@ import numpy as np
 
 from . import waves
 from .rigid import translate_matrix_6to6
-from .strips import pack_fowt, UnsupportedFOWT
+from .strips import pack_fowt, pack_fowt_nodes, UnsupportedFOWT
 from . import backend
 
 
@@ -52,11 +52,130 @@ class Engine:
         fowt.nWaves, fowt.beta, fowt.S, fowt.zeta = nWaves, beta, S, zeta
 
     def _check_supported(self, fowt):
-        if int(fowt.nDOF) != 6:
-            raise UnsupportedFOWT("device path covers rigid 6-DOF FOWTs (nDOF=%d)" % fowt.nDOF)
         for rot in getattr(fowt, "rotorList", []):
             if rot.r3[2] < 0:
                 raise UnsupportedFOWT("submerged rotors (raft_fowt.py:1861-1883) are not on the device path")
+        if _general(fowt):
+            # more than 6 reduced DOFs (flexible members): strip theory node by node + the dense impedance solve; the
+            # potential-flow and second-order branches of such units have no reference deck to pin them on
+            if getattr(fowt, "potMod", False) or int(getattr(fowt, "potModMaster", 0)) in (2, 3) \
+                    or np.any(np.asarray(getattr(fowt, "A_BEM", 0.0))) or np.any(np.asarray(getattr(fowt, "B_BEM", 0.0))):
+                raise UnsupportedFOWT("potential-flow coefficients on a unit with %d reduced DOFs" % fowt.nDOF)
+            if int(getattr(fowt, "potSecOrder", 0)) != 0:
+                raise UnsupportedFOWT("second-order loads on a unit with %d reduced DOFs" % fowt.nDOF)
+            if _dynamic_mooring(fowt):
+                raise UnsupportedFOWT("moorMod==2 on a unit with %d reduced DOFs" % fowt.nDOF)
+
+    # ------------------------------------------------------------------ units with more than 6 reduced DOFs
+    def _node_units(self, fowt, members):
+        """Strip tables per structural node + the rows of T that map the reduced DOFs onto each node."""
+        rows, tables = pack_fowt_nodes(fowt, members)
+        T = np.asarray(fowt.T, dtype=float)
+        Tn = np.array([T[r:r + 6, :] for r in rows]).reshape(len(rows), 6, T.shape[1])
+        fowt._raftx_nodes = (rows, tables, Tn)
+        return fowt._raftx_nodes
+
+    def _excitation_general(self, fowt, case, members):
+        """raft_fowt.py:1853-1857,1886-1888 for nDOF > 6: per-node 6-vectors -> full-DOF rows -> T^T."""
+        self._sea_state(fowt, case)
+        nw, nFull, nDOF = fowt.nw, int(fowt.nFullDOF), int(fowt.nDOF)
+        rows, tables, Tn = self._node_units(fowt, members)
+        fowt.F_hydro_iner_fullDOF = np.zeros([fowt.nWaves, nFull, nw], dtype=complex)
+        if tables:
+            self._upload([fowt], fowt.zeta, fowt.beta, tables=tables)
+            F = self.ctx.excitation()[:, 0]                  # [nNode, nWaves, 6, nw]
+            for i, r in enumerate(rows):
+                fowt.F_hydro_iner_fullDOF[:, r:r + 6, :] += F[i]
+        T = np.asarray(fowt.T, dtype=float)
+        fowt.F_hydro_iner = np.einsum('fd,hfw->hdw', T, fowt.F_hydro_iner_fullDOF)
+        fowt.F_BEM = np.zeros([fowt.nWaves, nDOF, nw], dtype=complex)
+        fowt.F_BEM_fullDOF = np.zeros([fowt.nWaves, nFull, nw], dtype=complex)
+        fowt._raftx_fresh = True
+        return None
+
+    def _linearization_general(self, fowt, Xi):
+        """raft_fowt.py:1891-1936 for nDOF > 6: node motions T_node Xi -> per-node 6 x 6 blocks and drag excitation ->
+        T^T B_full T, T^T F_full."""
+        rows, tables, Tn = fowt._raftx_nodes
+        nDOF, nw, nH = int(fowt.nDOF), fowt.nw, fowt.nWaves
+        B_red = np.zeros([nDOF, nDOF])
+        F_red = np.zeros([nH, nDOF, nw], dtype=complex)
+        if tables:
+            self._upload([fowt], fowt.zeta, fowt.beta, tables=tables)     # no-op while these tables are resident
+            XiN = np.einsum('ufd,dw->ufw', Tn, np.asarray(Xi, dtype=complex))
+            B, F = self.ctx.linearize(XiN[:, None, :, :])                  # [nNode,1,6,6], [nNode,1,nWaves,6,nw]
+            B_red = np.einsum('ufd,ufg,uge->de', Tn, B[:, 0], Tn)
+            F_red = np.einsum('ufd,uhfw->hdw', Tn, F[:, 0])
+        fowt.B_hydro_drag = B_red
+        fowt._raftx_Fdrag = F_red
+        fowt.F_hydro_drag = F_red[0].copy()
+        return fowt.B_hydro_drag
+
+    def _solve_general(self, model, case, tol, display):
+        """raft_model.py:966-1302 for ONE unit with more than 6 reduced DOFs: the same fixed point with the strip
+        sweeps node by node (raftx_excitation / raftx_linearize) and the nDOF x nDOF impedance solves of every bin on
+        the device (raftx_solve_dense); the T projections between them and the convergence test are host glue."""
+        fowts = model.fowtList
+        if len(fowts) != 1 or getattr(model, "ms", None):
+            raise UnsupportedFOWT("arrays of units with more than 6 reduced DOFs are not on the device path")
+        fowt = fowts[0]
+        self._check_supported(fowt)
+        nw, n = model.nw, int(fowt.nDOF)
+        ctx = self.ctx
+        self._excitation_general(fowt, case, fowt.memberList)                # :1002
+        if fowt.nrotors > 0:                                                 # :1005-1010
+            M_turb = np.sum(fowt.A_aero, axis=3)
+            B_turb = np.sum(fowt.B_aero, axis=3)
+        else:
+            M_turb = B_turb = np.zeros([n, n, nw])
+        fowt.Fhydro_2nd = np.zeros([fowt.nWaves, n, nw], dtype=complex)      # :1035-1036
+        fowt.Fhydro_2nd_mean = np.zeros([fowt.nWaves, n])
+        B_gyro = np.sum(fowt.B_gyro, axis=2)
+        M_lin = fowt.M_struc + fowt.A_hydro_morison                          # :1045-1047
+        B_lin = fowt.B_struc + B_gyro
+        C_lin = fowt.C_struc + fowt.C_hydro + fowt.C_moor + fowt.C_elast
+        if np.any(M_turb):
+            M_lin = M_turb + M_lin[:, :, None]
+        if np.any(B_turb):
+            B_lin = B_turb + B_lin[:, :, None]
+        F_lin = fowt.F_BEM[0] + fowt.F_hydro_iner[0] + fowt.Fhydro_2nd[0]    # :1048
+        XiLast = np.zeros([n, nw], dtype=complex) + model.XiStart            # :999
+        nIter = int(model.nIter) + 1                                         # :977
+        converged = False
+        niter = 0
+        B_tot = B_lin
+        for iiter in range(nIter):
+            B_drag = self._linearization_general(fowt, XiLast)               # :1063-1064
+            B_tot = B_lin + (B_drag[:, :, None] if B_lin.ndim == 3 else B_drag)
+            Xi, Z = ctx.solve_dense(model.w, M_lin, B_tot, C_lin, (F_lin + fowt._raftx_Fdrag[0])[None], want_Z=True)
+            Xi = Xi[0]
+            niter = iiter + 1
+            if np.isnan(Xi).any():
+                raise Exception("Nan detected in response vector Xi.")       # :1098-1099
+            tolCheck = np.abs(Xi - XiLast) / (np.abs(Xi) + tol)              # :1103
+            if (tolCheck < tol).all():
+                converged = True
+                if display > 1:
+                    print(f" Iteration {iiter}, converged (largest change is {np.max(tolCheck):.5f} < {tol})")
+                break
+            XiLast = 0.2 * XiLast + 0.8 * Xi                                 # :1133
+        if display > 0 and not converged:
+            print("WARNING - solveDynamics iteration did not converge to the tolerance.")
+        fowt.Z = Z                                                           # :1155
+        nH = fowt.nWaves
+        F_wave = fowt.F_BEM + fowt.F_hydro_iner + fowt._raftx_Fdrag + fowt.Fhydro_2nd       # :1212
+        model.Xi = np.zeros([nH + 1, model.nDOF, nw], dtype=complex)         # :1195
+        model.Xi[:nH] = ctx.solve_dense(model.w, M_lin, B_tot, C_lin, F_wave)                # :1191, :1216
+        fowt.F_hydro_drag = fowt._raftx_Fdrag[nH - 1].copy()
+        fowt.Xi = model.Xi[:, :n, :]                                         # :1251-1255
+        fowt.Xi_fullDOF = np.zeros([nH + 1, int(fowt.nFullDOF), nw], dtype=complex)
+        for ih in range(nH + 1):
+            fowt.Xi_fullDOF[ih, :, :] = fowt.T @ fowt.Xi[ih, :, :]
+        model.results['response'] = {}                                       # :1300
+        model._raftx_niter = np.array([niter], dtype=np.int32)
+        model._raftx_flags = np.array([1 if converged else 0], dtype=np.int32)
+        self._resident = None
+        return model.Xi
 
     def _bem_excitation(self, fowt):
         """Potential-flow excitation of the sea state just set on ``fowt`` (raft_fowt.py:1788-1849,1887): the blend of the
@@ -130,6 +249,8 @@ class Engine:
         (the default empty list gives none: Model.solveDynamics passes fowt.memberList, raft_model.py:1017).  Sets nWaves,
         beta, S, zeta, F_BEM(_fullDOF), F_hydro_iner(_fullDOF)."""
         self._check_supported(fowt)
+        if _general(fowt):
+            return self._excitation_general(fowt, case, list(memberList))
         self._sea_state(fowt, case)
         members = list(memberList)
         nw, nFull = fowt.nw, int(getattr(fowt, "nFullDOF", fowt.nDOF))
@@ -163,6 +284,10 @@ class Engine:
 
     def calcHydroLinearization(self, fowt, Xi):
         """raft_fowt.py:1891-1936 (heading 0 only, :1910)."""
+        if _general(fowt):
+            if not hasattr(fowt, "_raftx_nodes"):
+                raise RuntimeError("calcHydroExcitation must be called before calcHydroLinearization")
+            return self._linearization_general(fowt, Xi)
         if not hasattr(fowt, "_raftx_table"):
             raise RuntimeError("calcHydroExcitation must be called before calcHydroLinearization")
         self._upload([fowt], fowt.zeta, fowt.beta)          # no-op while this unit and sea state are resident
@@ -375,6 +500,8 @@ class Engine:
         """raft_model.py:966-1302."""
         iCase = case['iCase'] if 'iCase' in case else None
         fowts = model.fowtList
+        if any(_general(f) for f in fowts):
+            return self._solve_general(model, case, tol, display)
         nF = len(fowts)
         nw = model.nw
         mats, F_extras = [], []
@@ -516,6 +643,11 @@ class Engine:
         self._resident = fowts[0] if nF == 1 else None
         model._raftx_flags = out['flags'][:, 0].copy()
         return model.Xi
+
+
+def _general(fowt):
+    """More reduced DOFs than the rigid body's six (flexible members, raft_fowt.py's T reduction)."""
+    return int(getattr(fowt, "nDOF", 6)) != 6
 
 
 def _dynamic_mooring(fowt):

@@ -36,6 +36,10 @@ def snapshot_member(mem):
     d["rB"] = np.array(mem.rB, dtype=float)
     d["node_r"] = np.array(mem.nodeList[0].r, dtype=float)
     d["node_T"] = np.array(mem.nodeList[0].T, dtype=float)
+    # every structural node of the member (flexible members have one per strip): position and number in the unit's
+    # full-DOF vector -- what the node-by-node path of units with more than 6 reduced DOFs reads
+    d["nodes_r"] = np.array([np.asarray(n.r, dtype=float)[:3] for n in mem.nodeList])
+    d["nodes_id"] = np.array([int(n.id) for n in mem.nodeList], dtype=np.int64)
     # reference products kept for packer checks (not read by raft_amd)
     d["ref_Imat"] = np.array(mem.Imat, dtype=float)
     d["ref_a_i"] = np.array(mem.a_i, dtype=float)
@@ -136,6 +140,12 @@ def build_member(d):
     node.id = 0
     node.nDOF = 6
     m.nodeList = [node]
+    if "nodes_id" in d:                                   # fixtures written since the node-by-node path exists
+        node.id = int(d["nodes_id"][0])
+        for r, i in zip(d["nodes_r"][1:], d["nodes_id"][1:]):
+            nd = Obj()
+            nd.r, nd.id, nd.nDOF = r, int(i), 6
+            m.nodeList.append(nd)
     m.ref = {k[4:]: v for k, v in d.items() if k.startswith("ref_")}
     return m
 

@@ -51,9 +51,8 @@ MAX_RUN = 16
 
 
 class UnsupportedFOWT(Exception):
-    """Raised when a FOWT is outside what the device path covers (flexible
-    members / more than 6 reduced DOFs); callers fall back loudly, never
-    silently."""
+    """Raised when a FOWT is outside what the device path covers; callers fall
+    back loudly, never silently."""
 
 
 def node_arm(T):
@@ -115,16 +114,23 @@ def pack_member(mem, imem, rho, k_array=None, arm_node=None):
     """Records for the submerged strips of one rigid member (vectorised over the member's strips).
 
     Returns (records [n,32], cm rows list of complex [2,nw])."""
-    if getattr(mem, "type", "rigid") != "rigid":
-        raise UnsupportedFOWT("member '%s' is type '%s' (only rigid members are on the device path)"
-                              % (getattr(mem, "name", "?"), mem.type))
+    rigid = getattr(mem, "type", "rigid") == "rigid"
+    if not rigid and arm_node is None:
+        raise UnsupportedFOWT("member '%s' is type '%s': a flexible member has no single arm to the reduced-DOF point "
+                              "(pack_fowt_nodes gives its strips node by node)" % (getattr(mem, "name", "?"), mem.type))
     circ = (mem.shape == "circular")
     potMod = bool(getattr(mem, "potMod", False))
     MCF = bool(getattr(mem, "MCF", False)) and circ and (k_array is not None)
     node = mem.nodeList[0]
     if arm_node is None:
         arm_node = node_arm(node.T)
-    r_node = np.asarray(node.r, dtype=float)[:3]
+    if rigid:
+        r_node = np.asarray(node.r, dtype=float)[:3]
+    else:                                  # strip il hangs on structural node il (raft_member.py:1969-1976, 2051-2056)
+        if len(mem.nodeList) != int(mem.ns):
+            raise UnsupportedFOWT("flexible member '%s': %d structural nodes for %d strips"
+                                  % (getattr(mem, "name", "?"), len(mem.nodeList), mem.ns))
+        r_node = np.array([np.asarray(nd.r, dtype=float)[:3] for nd in mem.nodeList])
     q = np.asarray(mem.q, dtype=float)
     p1 = np.asarray(mem.p1, dtype=float)
     p2 = np.asarray(mem.p2, dtype=float)
@@ -159,7 +165,7 @@ def pack_member(mem, imem, rho, k_array=None, arm_node=None):
         rec[i, F_STEP] = step
     rec[:, F_UNIT] = unit
     rec[:, F_X:F_X + 3] = r
-    rec[:, F_AX:F_AX + 3] = (r - r_node) + arm_node
+    rec[:, F_AX:F_AX + 3] = (r - (r_node if rigid else r_node[wet])) + arm_node
     rec[:, F_Q:F_Q + 3] = q
     rec[:, F_P1:F_P1 + 3] = p1
     rec[:, F_P2:F_P2 + 3] = p2
@@ -248,6 +254,38 @@ def pack_fowt(fowt, memberList=None, own_node=False):
         recs.append(r)
     strips = np.concatenate(recs, axis=0) if recs else np.zeros((0, NFIELD))
     return StripTable(strips, np.array(cms) if cms else None)
+
+
+def pack_fowt_nodes(fowt, memberList=None):
+    """The strips of a unit grouped by the STRUCTURAL NODE that carries them: (rows, tables) with rows[i] the first
+    full-DOF row (node.id * 6) of table i, arms about that node's own position.  A rigid member is one table on its
+    single node; a flexible member gives one single-strip table per wet node (raft_member.py:1969-1976, 2046-2056).
+    These tables are the "designs" of raftx_excitation / raftx_linearize for a unit with more than 6 reduced DOFs:
+    their 6-vectors and 6 x 6 blocks are rows / diagonal blocks of the full-DOF arrays that the unit's T matrix reduces
+    (raft_fowt.py:1853-1857, 1912-1929)."""
+    members = fowt.memberList if memberList is None else memberList
+    rho = float(fowt.rho_water)
+    rows, tables = [], []
+    for imem, mem in enumerate(members):
+        mcf = bool(getattr(mem, "MCF", False))
+        k_array = np.asarray(fowt.k, dtype=float) if mcf else None
+        rec, cms = pack_member(mem, imem, rho, k_array=k_array, arm_node=np.zeros(3))
+        if len(rec) == 0:
+            continue
+        if getattr(mem, "type", "rigid") == "rigid":
+            node = mem.nodeList[0]
+            rows.append(int(node.id) * int(getattr(node, "nDOF", 6)))
+            tables.append(StripTable(rec, np.array(cms) if cms else None))
+            continue
+        if mcf:
+            raise UnsupportedFOWT("flexible member '%s' with the MacCamy-Fuchs correction" % getattr(mem, "name", "?"))
+        for one in rec:
+            node = mem.nodeList[int(one[F_IL])]
+            one = one.copy()
+            one[F_STEP] = one[F_UNIT] = 0.0                  # a table of one strip has no run
+            rows.append(int(node.id) * int(getattr(node, "nDOF", 6)))
+            tables.append(StripTable(one[None, :], None))
+    return rows, tables
 
 
 def added_mass_morison(strips):
