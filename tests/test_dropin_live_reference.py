@@ -227,3 +227,54 @@ def test_installed_calcHydroExcitation_full_dof_and_member_list(patch):
         fo.calcHydroExcitation(copy.deepcopy(case))
     assert not np.any(fo.F_hydro_iner) and not np.any(fn.F_hydro_iner)
     assert fn.F_hydro_iner.shape == fo.F_hydro_iner.shape and not np.any(fn.F_hydro_iner_fullDOF)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# every platform deck of the reference tree that the reference itself can build and solve here (MoorPy / CCBlade stubbed,
+# mooring replaced by the injected stiffness of SURVEY 8d): rigid units, farms, internal-QTF decks, the flexible decks
+def _platform_decks():
+    if not rh.reference_available():
+        return []
+    import glob
+    out = []
+    for sub in ("designs", "examples", "tests/test_data"):
+        for path in sorted(glob.glob(os.path.join(rh.REFERENCE_ROOT, sub, "*.yaml"))):
+            if isinstance(rh.load_design(path), dict) and "platform" in rh.load_design(path):
+                out.append(os.path.relpath(path, rh.REFERENCE_ROOT))
+    return out
+
+
+@pytest.mark.parametrize("deck", _platform_decks())
+def test_every_solvable_deck_of_the_reference_tree(deck, oracle_ctx):
+    import io
+    from raft_amd import dropin
+    d = rh.prepare_design(rh.load_design(os.path.join(rh.REFERENCE_ROOT, deck)), settings=dict(min_freq=0.01, max_freq=0.25))
+    d["platform"].pop("outFolderQTF", None)
+
+    def build():
+        m = rh.build_model(d)
+        for f in m.fowtList:
+            f.outFolderQTF = None
+            if f.nDOF != 6:
+                cm = np.zeros((f.nDOF, f.nDOF))
+                cm[:6, :6] = rh.DEFAULT_C_MOOR
+                f.C_moor = cm
+        return m
+
+    case = rh.make_case(Hs=5.0, Tp=11.0, heading=25.0)
+    try:
+        with contextlib.redirect_stdout(io.StringIO()):
+            m_old = build()
+            m_new = copy.deepcopy(m_old)
+            Xi_old = m_old.solveDynamics(copy.deepcopy(case)).copy()
+    except Exception as e:                                    # decks the reference itself cannot run in this container
+        pytest.skip("reference cannot build/solve %s here: %s: %s" % (deck, type(e).__name__, str(e)[:80]))
+    eng = dropin.Engine(oracle_ctx, qtf_backend=_numpy_qtf_backend)
+    with contextlib.redirect_stdout(io.StringIO()):
+        Xi_new = eng.solveDynamics(m_new, copy.deepcopy(case)).copy()
+    assert Xi_new.shape == Xi_old.shape
+    general = m_old.fowtList[0].nDOF != 6
+    assert rel_err(Xi_new, Xi_old) < (1e-8 if general else 1e-10), deck
+    for fn, fo in zip(m_new.fowtList, m_old.fowtList):
+        assert rel_err(fn.B_hydro_drag, fo.B_hydro_drag) < 1e-9
+        assert rel_err(fn.Xi_fullDOF, fo.Xi_fullDOF) < (1e-8 if general else 1e-10)
