@@ -87,7 +87,7 @@ class Engine:
             for i, r in enumerate(rows):
                 fowt.F_hydro_iner_fullDOF[:, r:r + 6, :] += F[i]
         T = np.asarray(fowt.T, dtype=float)
-        fowt.F_hydro_iner = np.einsum('fd,hfw->hdw', T, fowt.F_hydro_iner_fullDOF)
+        fowt.F_hydro_iner = np.array([T.T @ fowt.F_hydro_iner_fullDOF[ih] for ih in range(fowt.nWaves)])   # :1888
         fowt.F_BEM = np.zeros([fowt.nWaves, nDOF, nw], dtype=complex)
         fowt.F_BEM_fullDOF = np.zeros([fowt.nWaves, nFull, nw], dtype=complex)
         fowt._raftx_fresh = True
@@ -102,10 +102,12 @@ class Engine:
         F_red = np.zeros([nH, nDOF, nw], dtype=complex)
         if tables:
             self._upload([fowt], fowt.zeta, fowt.beta, tables=tables)     # no-op while these tables are resident
-            XiN = np.einsum('ufd,dw->ufw', Tn, np.asarray(Xi, dtype=complex))
+            nU = len(rows)
+            T2 = Tn.reshape(nU * 6, nDOF)                                  # the nodes' rows of T, stacked: plain GEMMs
+            XiN = (T2 @ np.asarray(Xi, dtype=complex)).reshape(nU, 6, nw)
             B, F = self.ctx.linearize(XiN[:, None, :, :])                  # [nNode,1,6,6], [nNode,1,nWaves,6,nw]
-            B_red = np.einsum('ufd,ufg,uge->de', Tn, B[:, 0], Tn)
-            F_red = np.einsum('ufd,uhfw->hdw', Tn, F[:, 0])
+            B_red = T2.T @ np.matmul(B[:, 0], Tn).reshape(nU * 6, nDOF)    # sum_u T_u^T B_u T_u
+            F_red = np.array([T2.T @ F[:, 0, ih].reshape(nU * 6, nw) for ih in range(nH)])
         fowt.B_hydro_drag = B_red
         fowt._raftx_Fdrag = F_red
         fowt.F_hydro_drag = F_red[0].copy()
@@ -147,8 +149,7 @@ class Engine:
         for iiter in range(nIter):
             B_drag = self._linearization_general(fowt, XiLast)               # :1063-1064
             B_tot = B_lin + (B_drag[:, :, None] if B_lin.ndim == 3 else B_drag)
-            Xi, Z = ctx.solve_dense(model.w, M_lin, B_tot, C_lin, (F_lin + fowt._raftx_Fdrag[0])[None], want_Z=True)
-            Xi = Xi[0]
+            Xi = ctx.solve_dense(model.w, M_lin, B_tot, C_lin, (F_lin + fowt._raftx_Fdrag[0])[None])[0]
             niter = iiter + 1
             if np.isnan(Xi).any():
                 raise Exception("Nan detected in response vector Xi.")       # :1098-1099
@@ -161,11 +162,12 @@ class Engine:
             XiLast = 0.2 * XiLast + 0.8 * Xi                                 # :1133
         if display > 0 and not converged:
             print("WARNING - solveDynamics iteration did not converge to the tolerance.")
-        fowt.Z = Z                                                           # :1155
         nH = fowt.nWaves
         F_wave = fowt.F_BEM + fowt.F_hydro_iner + fowt._raftx_Fdrag + fowt.Fhydro_2nd       # :1212
         model.Xi = np.zeros([nH + 1, model.nDOF, nw], dtype=complex)         # :1195
-        model.Xi[:nH] = ctx.solve_dense(model.w, M_lin, B_tot, C_lin, F_wave)                # :1191, :1216
+        # the impedance of the last iteration (:1155) is the one every heading is solved with (:1191, :1216): it comes
+        # back from this call only (14 MB for 150 DOFs x 40 bins)
+        model.Xi[:nH], fowt.Z = ctx.solve_dense(model.w, M_lin, B_tot, C_lin, F_wave, want_Z=True)
         fowt.F_hydro_drag = fowt._raftx_Fdrag[nH - 1].copy()
         fowt.Xi = model.Xi[:, :n, :]                                         # :1251-1255
         fowt.Xi_fullDOF = np.zeros([nH + 1, int(fowt.nFullDOF), nw], dtype=complex)
