@@ -4,16 +4,17 @@
 // (raft/raft_member.py:190-271), Member.setPosition (:312-377), Member.calcHydroConstants / calcImat / getCmSides
 // (:1261-1486), the drag areas of Member.calcHydroLinearization (:2061-2110), Member.getHydrostatics (:838-1010),
 // FOWT.calcHydroConstants (raft/raft_fowt.py:1589-1625) and the hydrostatic part of FOWT.calcStatics
-// (:811-1201) -- runs here as five small kernels over ALL designs of a sweep at once:
+// (:811-1201) -- runs here as a handful of small kernels over ALL designs of a sweep at once:
 //
 //   k_geom_member   one thread per member : pose (q, p1, p2, R, end A), wet-strip count, member hydrostatics
 //   k_geom_design_counts / k_geom_scan / k_geom_offsets : exclusive scans of the wet / MacCamy-Fuchs strip counts
 //                   (per-design totals, one-workgroup scan over designs, member offsets inside each design)
-//   k_geom_fill     one wavefront / member: lanes = strips; compacted with ballots into the design's strip table
-//   k_geom_mcf      (row, bin)            : MacCamy-Fuchs complex Cm table (Hankel functions)
 //   k_geom_reduce   thread per (design, role): member -> platform reduction of hydrostatics / weight stiffness / inertia
-//   k_geom_design   one wavefront / design: run detection for the rotor recurrences (the rules of the routine the host
-//                                           upload path uses), device strip records, Morison added mass
+//   k_geom_design   one wavefront / design: the design's strip records generated straight into LDS (lanes = candidate
+//                                           strips of all its members, wet ones compacted with ballots), run detection
+//                                           for the rotor recurrences (the rules of the routine the host upload path
+//                                           uses), device strip records, Morison added mass
+//   k_geom_mcf      (row, bin)            : MacCamy-Fuchs complex Cm table (Hankel functions)
 //
 // The work is tiny next to the solve (a 10k-design sweep has ~110k members / ~530k strips); it exists to remove
 // the host packing and the 256 B/strip upload from the sweep's critical path, not to reach a roofline.
@@ -181,6 +182,43 @@ __device__ inline double geom_interp(double x, const double *gs, int n, int f) {
     if (xj == x) return fj;
     const double slope = (gs[(size_t)(j + 1) * RAFTX_GS_N + f] - fj) / (gs[(size_t)(j + 1) * RAFTX_GS_N + RAFTX_GS_S] - xj);
     return slope * (x - xj) + fj;
+}
+
+// the same interpolation with the search done once for several fields of one abscissa (same operations per field)
+struct GLocate {
+    int idx;        // >= 0: the value is the field of station idx (clamped ends, exact hit, last station); -1: interpolate
+    int j;
+    double xj, dx;
+};
+__device__ inline GLocate geom_locate(double x, const double *gs, int n) {
+    GEOM_NOFMA
+    GLocate L{0, 0, 0.0, 0.0};
+    if (x < gs[RAFTX_GS_S]) return L;
+    if (x > gs[(size_t)(n - 1) * RAFTX_GS_N + RAFTX_GS_S]) { L.idx = n - 1; return L; }
+    int j = 0;
+    for (int i0 = 0; i0 < n; i0 += 8) {                   // eight independent loads in flight instead of one per step
+        double sv[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) sv[u] = gs[(size_t)min(i0 + u, n - 1) * RAFTX_GS_N + RAFTX_GS_S];
+#pragma unroll
+        for (int u = 0; u < 8; u++)
+            if (i0 + u < n && sv[u] <= x) j = i0 + u;
+    }
+    L.j = j;
+    L.idx = j;
+    if (j == n - 1) return L;
+    L.xj = gs[(size_t)j * RAFTX_GS_N + RAFTX_GS_S];
+    if (L.xj == x) return L;
+    L.dx = gs[(size_t)(j + 1) * RAFTX_GS_N + RAFTX_GS_S] - L.xj;
+    L.idx = -1;
+    return L;
+}
+__device__ inline double geom_interp_at(const GLocate &L, double x, const double *gs, int f) {
+    GEOM_NOFMA
+    if (L.idx >= 0) return gs[(size_t)L.idx * RAFTX_GS_N + f];
+    const double fj = gs[(size_t)L.j * RAFTX_GS_N + f];
+    const double slope = (gs[(size_t)(L.j + 1) * RAFTX_GS_N + f] - fj) / L.dx;
+    return slope * (x - L.xj) + fj;
 }
 
 // strips of a station interval: 0 for a decreasing one, 1 for a flat transition, ceil(l / dlsMax) otherwise
@@ -498,7 +536,7 @@ __global__ void k_geom_zero(GeomArgs A) {
     const int d = blockIdx.x * blockDim.x + threadIdx.x;
     if (d < A.nDesign) A.drho[d] = 0.0;
     if (d < 4) A.err[d] = 0;
-    if (d < 3) A.tot[d] = 0;
+    if (d < 5) A.tot[d] = 0;
     if (d == 0) { A.off[0] = 0; A.cmoff[0] = 0; }
 }
 // design of every member (thread per design); also rejects non-monotone member offsets (err[2] = design + 1)
@@ -746,6 +784,9 @@ __global__ void k_geom_design_counts(GeomArgs A) {
     A.off[d + 1] = a;                                    // totals parked one slot up; k_geom_scan turns them into offsets
     A.cmoff[d + 1] = b;
     atomicMax(reinterpret_cast<unsigned long long *>(A.tot + 2), (unsigned long long)a);
+    // stations and members of the largest design: they size the LDS of k_geom_design
+    atomicMax(reinterpret_cast<unsigned long long *>(A.tot + 3), (unsigned long long)(A.so(A.mo(d + 1)) - A.so(A.mo(d))));
+    atomicMax(reinterpret_cast<unsigned long long *>(A.tot + 4), (unsigned long long)(A.mo(d + 1) - A.mo(d)));
 }
 __global__ __launch_bounds__(1024) void k_geom_scan(GeomArgs A) {
     __shared__ long long part[2][1024];
@@ -771,6 +812,8 @@ __global__ __launch_bounds__(1024) void k_geom_scan(GeomArgs A) {
             A.hostOut[0] = sa;
             A.hostOut[1] = sb;
             A.hostOut[2] = A.tot[2];                     // final: k_geom_design_counts has completed
+            A.hostOut[5] = A.tot[3];
+            A.hostOut[6] = A.tot[4];
             A.hostOut[8] = 0;
         }
     }
@@ -797,138 +840,6 @@ __global__ void k_geom_offsets(GeomArgs A) {
         a += A.cnt[m]; b += A.cntm[m];
     }
     if (d == A.nDesign - 1) { A.soff[A.nMember] = a; A.cmsoff[A.nMember] = b; }
-}
-
-// one wavefront per member: lanes = the member's strips in order; wet strips are compacted with ballots
-#define GEOM_FILL_STAGE 24       // stations of a member staged in LDS (3 KB)
-__global__ __launch_bounds__(64) void k_geom_fill(GeomArgs A) {
-    GEOM_NOFMA
-    const int64_t m = blockIdx.x;
-    const int lane = threadIdx.x;
-    const double *gm = A.gm + (size_t)m * RAFTX_GM_N;
-    const double *gsg = A.gs + (size_t)A.so(m) * RAFTX_GS_N;
-    const int n = (int)(A.so(m + 1) - A.so(m));
-    // the member's station table is read many times per strip (interpolations): keep it in LDS when it is small
-    __shared__ double sgs[GEOM_FILL_STAGE * RAFTX_GS_N];
-    const bool staged = n <= GEOM_FILL_STAGE;
-    if (staged)
-        for (int t = lane; t < n * RAFTX_GS_N; t += 64) sgs[t] = gsg[t];
-    __syncthreads();
-    const double *gs = staged ? sgs : gsg;
-    const int d = A.mdesign[m];
-    const double *mp = A.mpose + (size_t)m * MP_N;
-    const bool circ = gm[RAFTX_GM_SHAPE] != 0.0;
-    const int flags = (int)gm[RAFTX_GM_FLAGS];
-    const bool potMod = flags & RAFTX_GM_FLAG_POTMOD;
-    const bool mcf = (flags & RAFTX_GM_FLAG_MCF) && circ && !potMod;
-    double rA[3], rB[3], q[3], p1[3], p2[3], rP[3] = {0, 0, 0};
-    const double L = mp[19];
-    if (A.pose)
-        for (int i = 0; i < 3; i++) rP[i] = A.pose[(size_t)d * 6 + i];
-    for (int i = 0; i < 3; i++) {
-        rA[i] = mp[3 + i]; q[i] = mp[6 + i]; p1[i] = mp[9 + i]; p2[i] = mp[12 + i];
-        rB[i] = rA[i] + L * q[i];
-    }
-    const double armN[3] = {rA[0] - rP[0], rA[1] - rP[1], rA[2] - rP[2]};
-    const int64_t out0 = A.soff[m];
-    const int64_t cmrow0 = A.cmsoff[m], cmbase = A.cmsoff[A.mo(d)];
-    const int64_t mlocal = m - A.mo(d);
-    const double rho = A.rho, cdrag = sqrt(8 / M_PI);
-    // strips of the member in order: group g = 0 and g = n are the end plates (one strip each), 0 < g < n the station
-    // intervals (geom_interval_strips sub-strips each).  Lanes take the flattened (group, sub-strip) list 64 at a time.
-    __shared__ int cum[GEOM_MAX_STATIONS + 2];
-    int nwet = 0;
-    for (int g = lane; g <= n; g += 64) {
-        int cntg = 1;
-        if (g > 0 && g < n)
-            cntg = geom_interval_strips(gs[(size_t)g * RAFTX_GS_N + RAFTX_GS_S] - gs[(size_t)(g - 1) * RAFTX_GS_N + RAFTX_GS_S],
-                                        gm[RAFTX_GM_DLSMAX]);
-        cum[g + 1] = cntg;
-    }
-    __syncthreads();
-    if (lane == 0) {
-        int a = 0;
-        cum[0] = 0;
-        for (int g = 0; g <= n; g++) { a += cum[g + 1]; cum[g + 1] = a; }
-    }
-    __syncthreads();
-    const int total = cum[n + 1];
-    for (int t0 = 0; t0 < total; t0 += 64) {
-        {                                               // (block kept: the strip code below is shared with the oracle's layout)
-            const int t = t0 + lane;
-            const bool act = t < total;
-            const int tt = act ? t : 0;
-            int g = 0;
-            while (g < n && cum[g + 1] <= tt) g++;
-            const int j = tt - cum[g];
-            const int nsub = (g > 0 && g < n) ? cum[g + 1] - cum[g] : 1;
-            GStrip s = geom_strip(gs, n, g, j, nsub, circ);
-            double r[3];
-            for (int c = 0; c < 3; c++) r[c] = geom_along(rA[c], rB[c], s.ls, L);
-            const bool wet = act && (r[2] < 0);
-            const unsigned long long mask = __ballot(wet);
-            const int pos = nwet + __popcll(mask & ((1ull << lane) - 1ull));
-            nwet += __popcll(mask);
-            if (!wet) continue;
-            double rec[NF];                                 // the record is built in registers and stored once
-            for (int c = 0; c < NF; c++) rec[c] = 0.0;
-            for (int c = 0; c < 3; c++) {
-                rec[RAFTX_F_X + c] = r[c];
-                rec[RAFTX_F_AX + c] = (r[c] - rA[c]) + armN[c];
-                rec[RAFTX_F_Q + c] = q[c];
-                rec[RAFTX_F_P1 + c] = p1[c];
-                rec[RAFTX_F_P2 + c] = p2[c];
-            }
-            rec[RAFTX_F_CIRC] = circ ? 1.0 : 0.0;
-            rec[RAFTX_F_MCF] = -1.0;
-            rec[26] = (double)mlocal;
-            rec[27] = (double)t;
-            const double ds0 = s.ds0, ds1 = s.ds1, dr0 = s.drs0, dr1 = s.drs1, dls = s.dls;
-            if (!potMod) {
-                double v_i, v_end, a_i;
-                if (circ) {
-                    v_i = 0.25 * M_PI * ds0 * ds0 * dls;
-                    const double a3 = ds0 + dr0, b3 = ds0 - dr0;
-                    v_end = M_PI / 12.0 * fabs(a3 * a3 * a3 - b3 * b3 * b3);
-                    a_i = M_PI * ds0 * dr0;
-                } else {
-                    v_i = ds0 * ds1 * dls;
-                    const double ma = 0.5 * ((ds0 + dr0) + (ds1 + dr1)), mb = 0.5 * ((ds0 - dr0) + (ds1 - dr1));
-                    v_end = M_PI / 12.0 * (ma * ma * ma - mb * mb * mb);
-                    a_i = (ds0 + dr0) * (ds1 + dr1) - (ds0 - dr0) * (ds1 - dr1);
-                }
-                if (r[2] + 0.5 * dls > 0) v_i = v_i * (0.5 * dls - r[2]) / dls;      // pierces the waterline, :1328-1330
-                const double Ca1 = geom_interp(s.ls, gs, n, RAFTX_GS_CA + 1), Ca2 = geom_interp(s.ls, gs, n, RAFTX_GS_CA + 2);
-                const double CaE = geom_interp(s.ls, gs, n, RAFTX_GS_CA + 3);
-                rec[RAFTX_F_IQ] = rho * v_end * CaE;
-                rec[RAFTX_F_AI] = a_i;
-                rec[RAFTX_F_RHOV] = rho * v_i;
-                rec[RAFTX_F_AP1] = rho * v_i * Ca1;
-                rec[RAFTX_F_AP2] = rho * v_i * Ca2;
-                if (mcf) {
-                    rec[RAFTX_F_MCF] = (double)((cmrow0 - cmbase) + pos);
-                    double *ax = A.mcfaux + (size_t)(cmrow0 + pos) * 3;
-                    ax[0] = ds0 / 2; ax[1] = Ca1; ax[2] = Ca2;
-                } else {
-                    rec[RAFTX_F_IP1] = rho * v_i * (1.0 + Ca1);
-                    rec[RAFTX_F_IP2] = rho * v_i * (1.0 + Ca2);
-                }
-            }
-            double a_q, a_p1, a_p2, a_end;                                             // :2066-2110
-            if (circ) {
-                a_q = M_PI * ds0 * dls; a_p1 = ds0 * dls; a_p2 = ds0 * dls; a_end = fabs(M_PI * ds0 * dr0);
-            } else {
-                a_q = 2 * (ds0 + ds0) * dls; a_p1 = ds0 * dls; a_p2 = ds1 * dls;      // (sic) :2070
-                a_end = fabs((ds0 + dr0) * (ds1 + dr1) - (ds0 - dr0) * (ds1 - dr1));
-            }
-            rec[RAFTX_F_DQ] = cdrag * 0.5 * rho * a_q * geom_interp(s.ls, gs, n, RAFTX_GS_CD + 0);
-            rec[RAFTX_F_DP1] = cdrag * 0.5 * rho * a_p1 * geom_interp(s.ls, gs, n, RAFTX_GS_CD + 1);
-            rec[RAFTX_F_DP2] = cdrag * 0.5 * rho * a_p2 * geom_interp(s.ls, gs, n, RAFTX_GS_CD + 2);
-            rec[RAFTX_F_DEND] = cdrag * 0.5 * rho * a_end * geom_interp(s.ls, gs, n, RAFTX_GS_CD + 3);
-            double *dst = A.abi + (size_t)(out0 + pos) * NF;
-            for (int c = 0; c < NF; c++) dst[c] = rec[c];
-        }
-    }
 }
 
 // MacCamy-Fuchs (Cm_p1, Cm_p2)(k) with its cosine ramp, raft_member.py:1459-1484:
@@ -1028,6 +939,20 @@ __device__ constexpr int DS_SRC[DS_N] = {
 static_assert(DS_MCF == 2 && DS_X == 4 && DS_U == 7 && DS_A == 10 && DS_Q == 13 && DS_P1 == 16 && DS_P2 == 19 &&
               DS_IQ == 22 && DS_DQ == 27 && DS_N == 32, "DS_SRC follows the device record layout");
 #define GD_ROW (NF + 1)      // LDS row stride of a staged record (odd: lane-per-strip column reads are conflict-free)
+#ifdef GEOM_PHASE_TIMING     // tuning builds: cycles per phase of k_geom_design, summed over its waves (printed at ctx destroy)
+__device__ unsigned long long geom_phase_cycles[10];
+#define GEOM_PHASE(i)                                                                                   \
+    do {                                                                                                \
+        __syncthreads();                                                                                \
+        const unsigned long long now_ = wall_clock64();                                                 \
+        if (threadIdx.x == 0) atomicAdd(&geom_phase_cycles[i], now_ - tphase_);                         \
+        tphase_ = now_;                                                                                 \
+    } while (0)
+#define GEOM_PHASE_BEGIN unsigned long long tphase_ = wall_clock64();
+#else
+#define GEOM_PHASE(i)
+#define GEOM_PHASE_BEGIN
+#endif
 __global__ __launch_bounds__(64) void k_geom_design(GeomArgs A) {
     GEOM_NOFMA
     extern __shared__ double gd_lds[];
@@ -1038,9 +963,161 @@ __global__ __launch_bounds__(64) void k_geom_design(GeomArgs A) {
     double *rec = gd_lds;                                 // [S][GD_ROW]
     double *pjv = rec + (size_t)S * GD_ROW, *unv = pjv + S;
     int *okv = reinterpret_cast<int *>(unv + S), *rsv = okv + S, *mfl = rsv + S;
-    const double *src = A.abi + (size_t)i0 * NF;
-    for (int t = lane; t < S * NF; t += 64) rec[(t / NF) * GD_ROW + (t % NF)] = src[t];
+    GEOM_PHASE_BEGIN
+    // ---- the strip records of the design (Member.__init__ strip discretisation + calcHydroConstants / drag areas,
+    // raft_member.py:190-271, 1261-1368, 2061-2110) are generated HERE, straight into the LDS rows the rest of the kernel
+    // works on: lanes take the design's candidate strips (member by member, end plates and interval sub-strips in
+    // order) 64 at a time, wet ones are compacted with ballots -- the order of the one-wave-per-member pass this
+    // replaces, whose 256-B records went through HBM once more.  The ABI copy (raftx_fetch_strips) is written from LDS.
+    {
+        const int64_t m0 = A.mo(d), m1 = A.mo(d + 1);
+        const int nMem = (int)(m1 - m0);
+        const int64_t s0 = A.so(m0);
+        const int nSta = (int)(A.so(m1) - s0);
+        int *mcum = mfl + S;                              // per member: n + 2 running strip counts of its groups
+        int *mbase = mcum + nSta + 2 * nMem;              // [nMem + 1] candidates before each member
+        // groups of all members flattened over the lanes: member mi owns the n + 1 groups [sta0(mi) + mi, sta0(mi + 1) + mi + 1)
+        // (mbase doubles as the members' first-station table until the counts are in)
+        for (int mi = lane; mi <= nMem; mi += 64) mbase[mi] = (int)(A.so(m0 + mi) - s0);
+        __syncthreads();
+        for (int u = lane; u < nSta + nMem; u += 64) {
+            int mi = 0;
+            while (mi + 1 < nMem && mbase[mi + 1] + mi + 1 <= u) mi++;
+            const int sta0 = mbase[mi], n = mbase[mi + 1] - sta0, g = u - (sta0 + mi);
+            int cntg = 1;
+            if (g > 0 && g < n) {
+                const double *gs = A.gs + (size_t)(s0 + sta0) * RAFTX_GS_N;
+                cntg = geom_interval_strips(gs[(size_t)g * RAFTX_GS_N + RAFTX_GS_S] - gs[(size_t)(g - 1) * RAFTX_GS_N + RAFTX_GS_S],
+                                            A.gm[(size_t)(m0 + mi) * RAFTX_GM_N + RAFTX_GM_DLSMAX]);
+            }
+            mcum[sta0 + 2 * mi + g + 1] = cntg;
+        }
+        __syncthreads();
+        for (int mi = lane; mi < nMem; mi += 64) {
+            const int64_t m = m0 + mi;
+            const int n = (int)(A.so(m + 1) - A.so(m));
+            int *cum = mcum + (A.so(m) - s0) + 2 * mi;
+            int a = 0;
+            cum[0] = 0;
+            for (int g = 0; g <= n; g++) { a += cum[g + 1]; cum[g + 1] = a; }
+            mbase[mi + 1] = a;
+        }
+        __syncthreads();
+        if (lane == 0) {
+            int a = 0;
+            mbase[0] = 0;
+            for (int mi = 0; mi < nMem; mi++) { a += mbase[mi + 1]; mbase[mi + 1] = a; }
+        }
+        __syncthreads();
+        const int total = mbase[nMem];
+        GEOM_PHASE(0);
+        const double rho = A.rho, cdrag = sqrt(8 / M_PI);
+        double rP[3] = {0, 0, 0};
+        if (A.pose)
+            for (int i = 0; i < 3; i++) rP[i] = A.pose[(size_t)d * 6 + i];
+        int nwet = 0;
+        for (int t0 = 0; t0 < total; t0 += 64) {
+            const int t = t0 + lane;
+            const bool act = t < total;
+            const int tq = act ? t : 0;
+            int mi = 0;
+            while (mi + 1 < nMem && mbase[mi + 1] <= tq) mi++;
+            const int64_t m = m0 + mi;
+            const int tt = tq - mbase[mi];
+            const int n = (int)(A.so(m + 1) - A.so(m));
+            const int *cum = mcum + (A.so(m) - s0) + 2 * mi;
+            const double *gm = A.gm + (size_t)m * RAFTX_GM_N;
+            const double *gs = A.gs + (size_t)A.so(m) * RAFTX_GS_N;
+            const double *mp = A.mpose + (size_t)m * MP_N;
+            const bool circ = gm[RAFTX_GM_SHAPE] != 0.0;
+            const int flags = (int)gm[RAFTX_GM_FLAGS];
+            const bool potMod = flags & RAFTX_GM_FLAG_POTMOD;
+            const bool mcf = (flags & RAFTX_GM_FLAG_MCF) && circ && !potMod;
+            const double L = mp[19];
+            double rA[3], rB[3], q[3], p1[3], p2[3], armN[3];
+            for (int i = 0; i < 3; i++) {
+                rA[i] = mp[3 + i]; q[i] = mp[6 + i]; p1[i] = mp[9 + i]; p2[i] = mp[12 + i];
+                rB[i] = rA[i] + L * q[i];
+                armN[i] = rA[i] - rP[i];
+            }
+            int g = 0;
+            while (g < n && cum[g + 1] <= tt) g++;
+            const int j = tt - cum[g];
+            const int nsub = (g > 0 && g < n) ? cum[g + 1] - cum[g] : 1;
+            GStrip st = geom_strip(gs, n, g, j, nsub, circ);
+            double r[3];
+            for (int c = 0; c < 3; c++) r[c] = geom_along(rA[c], rB[c], st.ls, L);
+            const bool wet = act && (r[2] < 0);
+            const GLocate at = geom_locate(st.ls, gs, n);     // one search for the seven coefficient interpolations
+            const unsigned long long mask = __ballot(wet);
+            const int pos = nwet + __popcll(mask & ((1ull << lane) - 1ull));
+            nwet += __popcll(mask);
+            if (!wet || pos >= S) continue;
+            double *row = rec + (size_t)pos * GD_ROW;
+            for (int c = 0; c < NF; c++) row[c] = 0.0;
+            for (int c = 0; c < 3; c++) {
+                row[RAFTX_F_X + c] = r[c];
+                row[RAFTX_F_AX + c] = (r[c] - rA[c]) + armN[c];
+                row[RAFTX_F_Q + c] = q[c];
+                row[RAFTX_F_P1 + c] = p1[c];
+                row[RAFTX_F_P2 + c] = p2[c];
+            }
+            row[RAFTX_F_CIRC] = circ ? 1.0 : 0.0;
+            row[RAFTX_F_MCF] = -1.0;
+            row[26] = (double)mi;
+            row[27] = (double)tt;
+            const double ds0 = st.ds0, ds1 = st.ds1, dr0 = st.drs0, dr1 = st.drs1, dls = st.dls;
+            if (!potMod) {
+                double v_i, v_end, a_i;
+                if (circ) {
+                    v_i = 0.25 * M_PI * ds0 * ds0 * dls;
+                    const double a3 = ds0 + dr0, b3 = ds0 - dr0;
+                    v_end = M_PI / 12.0 * fabs(a3 * a3 * a3 - b3 * b3 * b3);
+                    a_i = M_PI * ds0 * dr0;
+                } else {
+                    v_i = ds0 * ds1 * dls;
+                    const double ma = 0.5 * ((ds0 + dr0) + (ds1 + dr1)), mb = 0.5 * ((ds0 - dr0) + (ds1 - dr1));
+                    v_end = M_PI / 12.0 * (ma * ma * ma - mb * mb * mb);
+                    a_i = (ds0 + dr0) * (ds1 + dr1) - (ds0 - dr0) * (ds1 - dr1);
+                }
+                if (r[2] + 0.5 * dls > 0) v_i = v_i * (0.5 * dls - r[2]) / dls;      // pierces the waterline, :1328-1330
+                const double Ca1 = geom_interp_at(at, st.ls, gs, RAFTX_GS_CA + 1), Ca2 = geom_interp_at(at, st.ls, gs, RAFTX_GS_CA + 2);
+                const double CaE = geom_interp_at(at, st.ls, gs, RAFTX_GS_CA + 3);
+                row[RAFTX_F_IQ] = rho * v_end * CaE;
+                row[RAFTX_F_AI] = a_i;
+                row[RAFTX_F_RHOV] = rho * v_i;
+                row[RAFTX_F_AP1] = rho * v_i * Ca1;
+                row[RAFTX_F_AP2] = rho * v_i * Ca2;
+                if (mcf) {
+                    const int64_t cmrow0 = A.cmsoff[m], cmbase = A.cmsoff[m0];
+                    const int posm = pos - (int)(A.soff[m] - i0);
+                    row[RAFTX_F_MCF] = (double)((cmrow0 - cmbase) + posm);
+                    double *ax = A.mcfaux + (size_t)(cmrow0 + posm) * 3;
+                    ax[0] = ds0 / 2; ax[1] = Ca1; ax[2] = Ca2;
+                } else {
+                    row[RAFTX_F_IP1] = rho * v_i * (1.0 + Ca1);
+                    row[RAFTX_F_IP2] = rho * v_i * (1.0 + Ca2);
+                }
+            }
+            double a_q, a_p1, a_p2, a_end;                                             // :2066-2110
+            if (circ) {
+                a_q = M_PI * ds0 * dls; a_p1 = ds0 * dls; a_p2 = ds0 * dls; a_end = fabs(M_PI * ds0 * dr0);
+            } else {
+                a_q = 2 * (ds0 + ds0) * dls; a_p1 = ds0 * dls; a_p2 = ds1 * dls;      // (sic) :2070
+                a_end = fabs((ds0 + dr0) * (ds1 + dr1) - (ds0 - dr0) * (ds1 - dr1));
+            }
+            row[RAFTX_F_DQ] = cdrag * 0.5 * rho * a_q * geom_interp_at(at, st.ls, gs, RAFTX_GS_CD + 0);
+            row[RAFTX_F_DP1] = cdrag * 0.5 * rho * a_p1 * geom_interp_at(at, st.ls, gs, RAFTX_GS_CD + 1);
+            row[RAFTX_F_DP2] = cdrag * 0.5 * rho * a_p2 * geom_interp_at(at, st.ls, gs, RAFTX_GS_CD + 2);
+            row[RAFTX_F_DEND] = cdrag * 0.5 * rho * a_end * geom_interp_at(at, st.ls, gs, RAFTX_GS_CD + 3);
+        }
+        __syncthreads();
+        GEOM_PHASE(1);
+        double *abi = A.abi + (size_t)i0 * NF;
+        for (int t = lane; t < S * NF; t += 64) abi[t] = rec[(t / NF) * GD_ROW + (t % NF)];
+    }
     __syncthreads();
+    GEOM_PHASE(2);
     // ---- run detection (derive_design_tables, same expressions and order; see there for the rules)
     for (int t = lane; t < S; t += 64) {
         bool pass = false;
@@ -1117,6 +1194,7 @@ __global__ __launch_bounds__(64) void k_geom_design(GeomArgs A) {
         if (fabs(cr[RAFTX_F_P1]) < 1e-15 && fabs(cr[RAFTX_F_P1 + 1]) < 1e-15 && fabs(cr[RAFTX_F_P2 + 2]) < 1e-15) fl |= DSI_AXAL;
         A.dsi[(size_t)i0 + t] = fl;
     }
+    GEOM_PHASE(3);
     // ---- device strip records, one 256 B row per strip, written by consecutive lanes (a lane keeps its field)
     {
         double *dso = A.ds + (size_t)i0 * DS_N;
@@ -1130,6 +1208,7 @@ __global__ __launch_bounds__(64) void k_geom_design(GeomArgs A) {
             dso[t] = v;
         }
     }
+    GEOM_PHASE(4);
     // ---- A_hydro_morison (raft_member.py:1333-1361 + helpers.py:537-560, raft_fowt.py:1625): every strip adds
     // c_n g g^T with g = [n ; arm x n] for its three directions n = p1, p2, q.  The 3 x (c, g) of every strip are formed
     // once (lane per strip) and parked over the staged records; lane (i, j) then sums c g_i g_j over the strips in order.
@@ -1156,6 +1235,7 @@ __global__ __launch_bounds__(64) void k_geom_design(GeomArgs A) {
             for (int e = 0; e < GV; e++) rec[(size_t)t * GV + e] = gv[e];
     }
     __syncthreads();
+    GEOM_PHASE(5);
     if (lane < 36) {
         const int i = lane / 6, j = lane % 6;
         double am = 0.0;
@@ -1169,12 +1249,13 @@ __global__ __launch_bounds__(64) void k_geom_design(GeomArgs A) {
         if (A.add_mask & RAFTX_ADD_HYDROSTATIC) A.C0[o] += A.Ch[o];
         if (A.add_mask & RAFTX_ADD_INERTIA) { A.M0[o] += A.Ms[o]; A.C0[o] += A.Cs[o]; }
     }
+    GEOM_PHASE(6);
     (void)mfl;
 }
 // dynamic LDS of k_geom_design for designs of up to maxS strips
-static size_t geom_design_lds(int maxS) {
+static size_t geom_design_lds(int maxS, int maxSta, int maxMem) {
     const size_t S = (size_t)(maxS > 0 ? maxS : 1);
-    return sizeof(double) * (S * GD_ROW + 2 * S) + sizeof(int) * 3 * S + 16;
+    return sizeof(double) * (S * GD_ROW + 2 * S) + sizeof(int) * (3 * S + (size_t)maxSta + 3 * (size_t)maxMem + 1) + 16;
 }
 
 __global__ __launch_bounds__(64) void k_geom_reduce(GeomArgs A) {

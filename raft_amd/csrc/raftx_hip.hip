@@ -726,6 +726,19 @@ static void free_list(raftx_ctx *c, std::vector<void *> &v) {
 
 extern "C" void raftx_ctx_destroy(raftx_ctx *c) {
     if (!c) return;
+#ifdef GEOM_PHASE_TIMING
+    if (c->owns_stream && c->slots) {
+        unsigned long long ph[10] = {0};
+        (void)hipDeviceSynchronize();
+        if (hipMemcpyFromSymbol(ph, HIP_SYMBOL(geom_phase_cycles), sizeof(ph)) == hipSuccess && ph[0]) {
+            unsigned long long tot = 0;
+            for (int i = 0; i < 7; i++) tot += ph[i];
+            fprintf(stderr, "[k_geom_design phases, %% of wave time] counts %.1f | generate %.1f | abi out %.1f | runs %.1f | ds out %.1f | g-vectors %.1f | morison+matrices %.1f\n",
+                    100.0 * ph[0] / tot, 100.0 * ph[1] / tot, 100.0 * ph[2] / tot, 100.0 * ph[3] / tot, 100.0 * ph[4] / tot,
+                    100.0 * ph[5] / tot, 100.0 * ph[6] / tot);
+        }
+    }
+#endif
     (void)raftx_comm_destroy(c);
     for (int sl = 0; sl < 2; sl++) {
         for (raftx_ctx *w : c->workers[sl]) raftx_ctx_destroy(w);
@@ -990,7 +1003,7 @@ static int build_phase1(raftx_ctx *c, hipStream_t sCopy, hipStream_t sPrep, int 
             alloc((size_t)nMember * MP_N * sizeof(double), &p_[4], tb) || alloc((size_t)nMember * MH_N * sizeof(double), &p_[5], tb) ||
             alloc((size_t)nMember * MI_N * sizeof(double), &p_[6], tb) || alloc(4 * sizeof(int), &p_[7], tb) ||
             alloc((size_t)nMember * sizeof(int), &p_[12], tb) ||
-            alloc((size_t)nDesign * sizeof(double), &p_[8], tb) || alloc(3 * sizeof(long long), &p_[9], tb) ||
+            alloc((size_t)nDesign * sizeof(double), &p_[8], tb) || alloc(5 * sizeof(long long), &p_[9], tb) ||
             alloc(((size_t)nDesign + 1) * sizeof(int64_t), &p_[10], c->design_allocs) ||
             alloc(((size_t)nDesign + 1) * sizeof(int64_t), &p_[11], c->design_allocs))
             return -2;
@@ -1067,7 +1080,7 @@ static int build_phase2(raftx_ctx *c, int64_t *stripOffsets, hipStream_t sGen = 
         dev_alloc(c, c->design_allocs, (size_t)nDesign * RAFTX_SP_N, &A.props))
         return -2;
     (void)tmp;
-    const size_t gd_lds = geom_design_lds(maxS);
+    const size_t gd_lds = geom_design_lds(maxS, (int)c->pin[5], (int)c->pin[6]);
     if (gd_lds > 160 * 1024)
         FAIL(c, "build_designs: a design has %d submerged strips (at most %d supported)", maxS, (int)((160 * 1024 - 16) / (8 * (GD_ROW + 2) + 12)));
     if (gd_lds > 64 * 1024)
@@ -1075,13 +1088,12 @@ static int build_phase2(raftx_ctx *c, int64_t *stripOffsets, hipStream_t sGen = 
     if (!sGen) sGen = c->stream;
     HIPCHK(c, hipStreamWaitEvent(sGen, c->evTot, 0));
     HIPCHK(c, hipEventRecord(c->evG0, sGen));
-    if (J.nMember > 0) hipLaunchKernelGGL(k_geom_fill, dim3((unsigned)J.nMember), dim3(64), 0, sGen, A);
-    if (nRows > 0)
-        hipLaunchKernelGGL(k_geom_mcf, dim3((unsigned)nRows, (unsigned)((nw + 63) / 64)), dim3(64), 0, sGen, A, (int64_t)nRows);
     if (nDesign > 0) {
         hipLaunchKernelGGL(k_geom_reduce, dim3((unsigned)(((size_t)nDesign * 3 + 63) / 64)), dim3(64), 0, sGen, A);
         hipLaunchKernelGGL(k_geom_design, dim3((unsigned)nDesign), dim3(64), gd_lds, sGen, A);
     }
+    if (nRows > 0)                                        // after k_geom_design: it leaves (R, Ca) of the MacCamy-Fuchs strips
+        hipLaunchKernelGGL(k_geom_mcf, dim3((unsigned)nRows, (unsigned)((nw + 63) / 64)), dim3(64), 0, sGen, A, (int64_t)nRows);
     HIPCHK(c, hipEventRecord(c->evG1, sGen));
     if (sGen != c->stream) HIPCHK(c, hipStreamWaitEvent(c->stream, c->evG1, 0));
     DevTables &T = c->T;
@@ -2168,8 +2180,15 @@ extern "C" int raftx_sweep_submit(raftx_ctx *c, int slot, int nDesign, const int
     S.t0 = std::chrono::steady_clock::now();
     auto since = [&]() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - S.t0).count(); };
     if (!c->sCopy) {
+        // the preparation stream outranks the ctx stream: the small kernels of the NEXT batch's member pass must get wave
+        // slots while the fused kernel of the current batch saturates the chip -- at equal priority they are not
+        // dispatched before the fused kernel's grid has been handed out completely (measured: a 40-workgroup kernel
+        // "ran" 2.4 ms), and the next batch's generation then starts late by the whole member pass
+        int prioLeast = 0, prioGreatest = 0;
+        HIPCHK(c, hipDeviceGetStreamPriorityRange(&prioLeast, &prioGreatest));
+        static const bool flat = getenv("RAFTX_SWEEP_FLAT_PRIORITY") != nullptr;
         HIPCHK(c, hipStreamCreateWithFlags(&c->sCopy, hipStreamNonBlocking));
-        HIPCHK(c, hipStreamCreateWithFlags(&c->sPrep, hipStreamNonBlocking));
+        HIPCHK(c, hipStreamCreateWithPriority(&c->sPrep, hipStreamNonBlocking, flat ? 0 : prioGreatest));
         HIPCHK(c, hipStreamCreateWithFlags(&c->sD2H, hipStreamNonBlocking));
     }
     if (!S.evXi) HIPCHK(c, hipEventCreate(&S.evXi));
