@@ -24,9 +24,11 @@ def build(force=False, verbose=False, extra=()):
 
 
 def build_timing(verbose=False):
-    """Instrumented tuning build (per-phase cycle counters): libraftx_hip_timing.so.  Never loaded by the product."""
+    """Instrumented tuning build (per-phase cycle counters of the fused kernel, read by scripts/phase_timing.py, and of
+    k_geom_design, printed to stderr when the ctx is destroyed): libraftx_hip_timing.so.  Never loaded by the product;
+    select it with RAFTX_HIP_LIB=<path>."""
     out = os.path.join(HERE, "libraftx_hip_timing.so")
-    cmd = [os.environ.get("HIPCC", "hipcc")] + FLAGS + ["-DRAFTX_PHASE_TIMING", "-o", out, SRC]
+    cmd = [os.environ.get("HIPCC", "hipcc")] + FLAGS + ["-DRAFTX_PHASE_TIMING", "-DGEOM_PHASE_TIMING", "-o", out, SRC]
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)
