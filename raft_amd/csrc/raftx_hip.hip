@@ -2180,15 +2180,14 @@ extern "C" int raftx_sweep_submit(raftx_ctx *c, int slot, int nDesign, const int
     S.t0 = std::chrono::steady_clock::now();
     auto since = [&]() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - S.t0).count(); };
     if (!c->sCopy) {
-        // the preparation stream outranks the ctx stream: the small kernels of the NEXT batch's member pass must get wave
-        // slots while the fused kernel of the current batch saturates the chip -- at equal priority they are not
-        // dispatched before the fused kernel's grid has been handed out completely (measured: a 40-workgroup kernel
-        // "ran" 2.4 ms), and the next batch's generation then starts late by the whole member pass
-        int prioLeast = 0, prioGreatest = 0;
-        HIPCHK(c, hipDeviceGetStreamPriorityRange(&prioLeast, &prioGreatest));
-        static const bool flat = getenv("RAFTX_SWEEP_FLAT_PRIORITY") != nullptr;
+        // All four are ordinary streams.  Measured (scripts/ubench/queue_probe2.hip, scripts/gpu_prep.sh): a HIGH-priority
+        // preparation stream whose hardware queue happens to sit apart from the busy one does get the next batch's member
+        // pass onto the chip early -- and the step gets SLOWER (4.21 vs 4.02 ms): its 184-VGPR waves break up the
+        // 2 x 256-VGPR residency of the fused kernel's workgroups, and the earlier generation / fused kernel of the next
+        // batch then only share the chip with the current one.  As it is, the member pass runs beside the fused kernel's
+        // last residency round, which costs nothing.
         HIPCHK(c, hipStreamCreateWithFlags(&c->sCopy, hipStreamNonBlocking));
-        HIPCHK(c, hipStreamCreateWithPriority(&c->sPrep, hipStreamNonBlocking, flat ? 0 : prioGreatest));
+        HIPCHK(c, hipStreamCreateWithFlags(&c->sPrep, hipStreamNonBlocking));
         HIPCHK(c, hipStreamCreateWithFlags(&c->sD2H, hipStreamNonBlocking));
     }
     if (!S.evXi) HIPCHK(c, hipEventCreate(&S.evXi));
