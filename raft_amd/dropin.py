@@ -27,7 +27,7 @@ import numpy as np
 
 from . import waves
 from .rigid import translate_matrix_6to6
-from .strips import pack_fowt, pack_fowt_nodes, UnsupportedFOWT
+from .strips import pack_fowt, pack_fowt_nodes, pack_fingerprint, UnsupportedFOWT
 from . import backend
 
 
@@ -511,7 +511,10 @@ class Engine:
             self._check_supported(fowt)
             # sea state + excitation inputs (raft_model.py:1002)
             self._sea_state(fowt, case)
-            fowt._raftx_table = pack_fowt(fowt)
+            fp = pack_fingerprint(fowt)                     # analyzeCases: one packing per pose, not per load case
+            if getattr(fowt, "_raftx_table_fp", None) != fp or getattr(fowt, "_raftx_table_all", None) is None:
+                fowt._raftx_table_all, fowt._raftx_table_fp = pack_fowt(fowt), fp
+            fowt._raftx_table = fowt._raftx_table_all
 
             if fowt.nrotors > 0:                                            # :1005-1010
                 M_turb = np.sum(fowt.A_aero, axis=3)

@@ -233,6 +233,29 @@ class StripTable:
         return self.strips.shape[0]
 
 
+_PACK_INPUTS = ("r", "q", "p1", "p2", "ds", "drs", "dls", "ls", "stations", "Cd_q", "Cd_p1", "Cd_p2", "Cd_End",
+                "Ca_p1", "Ca_p2", "Ca_End")
+
+
+def pack_fingerprint(fowt, memberList=None):
+    """Bytes of everything ``pack_fowt`` reads: two calls with equal fingerprints pack identical tables.  A caller that
+    solves many load cases on one unit (Model.analyzeCases) re-packs only when a member moved or was edited -- the
+    fingerprint costs a tenth of the packing."""
+    members = fowt.memberList if memberList is None else memberList
+    parts = [np.float64(fowt.rho_water).tobytes()]
+    for mem in members:
+        node = mem.nodeList[0]
+        parts.append(("%s|%s|%d|%d" % (getattr(mem, "type", "rigid"), mem.shape, bool(getattr(mem, "potMod", False)),
+                                       bool(getattr(mem, "MCF", False)))).encode())
+        parts.append(np.asarray(node.r, dtype=float).tobytes())
+        parts.append(np.asarray(node.T, dtype=float).tobytes())
+        for a in _PACK_INPUTS:
+            parts.append(np.asarray(getattr(mem, a), dtype=float).tobytes())
+        if getattr(mem, "MCF", False):
+            parts.append(np.asarray(fowt.k, dtype=float).tobytes())
+    return b"".join(parts)
+
+
 def pack_fowt(fowt, memberList=None, own_node=False):
     """StripTable for a rigid 6-DOF FOWT (reference object or stand-in).  memberList None: every member of the unit;
     a list (possibly empty): exactly those.  own_node: arms about each member's own node instead of the unit's

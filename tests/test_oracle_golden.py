@@ -133,3 +133,27 @@ def test_channel_stats_reproduce_nacelle_acceleration_formulae(oracle_ctx):
     r2d = np.rad2deg(1.0)
     c_std, _ = oracle_ctx.channel_stats(np.diag([1, 1, 1, r2d, r2d, r2d]), [0] * 6, f.dw)
     assert np.allclose(m_std, c_std, rtol=1e-13)
+
+
+def test_packed_table_is_reused_until_a_member_changes(oracle_ctx):
+    """Model.analyzeCases solves many load cases on one unit: the strip table is packed once per pose / member state
+    (raft_amd.strips.pack_fingerprint), and re-packed as soon as anything the packer reads is edited."""
+    fx, model = load_model_fixture("c2_volturnus.npz")
+    eng = dropin.Engine(oracle_ctx)
+    fowt = model.fowtList[0]
+    cases = [case_from_fixture(c) for c in fx["cases"][:2]]
+    eng.solveDynamics(model, cases[0])
+    table = fowt._raftx_table
+    Xi1 = eng.solveDynamics(model, cases[1]).copy()
+    assert fowt._raftx_table is table                                   # second load case: no re-packing
+    assert group_rel_err(Xi1[:1], ref_headings(fx["cases"][1])[0][:1]) < 1e-10
+    fowt.memberList[0].Cd_q = np.asarray(fowt.memberList[0].Cd_q) * 1.5    # an edited coefficient ...
+    fowt.memberList[1].r = np.asarray(fowt.memberList[1].r) + [0.0, 0.0, -0.25]   # ... and a member that moved
+    Xi2 = eng.solveDynamics(model, cases[1]).copy()
+    assert fowt._raftx_table is not table
+    _, fresh = load_model_fixture("c2_volturnus.npz")
+    f2 = fresh.fowtList[0]
+    f2.memberList[0].Cd_q = np.asarray(f2.memberList[0].Cd_q) * 1.5
+    f2.memberList[1].r = np.asarray(f2.memberList[1].r) + [0.0, 0.0, -0.25]
+    Xi3 = dropin.Engine(oracle_ctx).solveDynamics(fresh, cases[1])
+    assert np.array_equal(Xi2, Xi3) and not np.array_equal(Xi2, Xi1)
