@@ -56,6 +56,7 @@ if ROOT not in sys.path:
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8 TB/s spec
 FP64_VALU_PEAK_TF = 78.6       # MI355X vector fp64 peak
+FP64_FMA_SUSTAINED_TF = 50.8      # measured: profiles/r02_valu_mfma_probe.jsonl (probe fma64)
 
 
 def make_sweep(ctx, n_design, rank=0, pinned=True):
@@ -368,7 +369,12 @@ def main():
                              "kernel is fp64-VALU-bound (SURVEY.md 8d): see roofline_fp64_valu"},
         "roofline_fp64_valu": {"achieved": flops / (k_sum_ms * 1e-3) / 1e12, "peak": FP64_VALU_PEAK_TF, "unit": "TFLOP/s",
                                "frac": flops / (k_sum_ms * 1e-3) / 1e12 / FP64_VALU_PEAK_TF,
-                               "algorithmic_flops_per_step": flops},
+                               "algorithmic_flops_per_step": flops,
+                               "sustained_fma_probe": {"tflops": FP64_FMA_SUSTAINED_TF,
+                                                       "frac": flops / (k_sum_ms * 1e-3) / 1e12 / FP64_FMA_SUSTAINED_TF,
+                                                       "note": "what a pure v_fma_f64 loop sustains on an MI355X at the kernel's "
+                                                               "occupancy (the clock drops to 1.7 GHz under fp64 load): "
+                                                               "scripts/ubench/valu_mfma_probe.hip, profiles/r02_valu_mfma_probe.jsonl"}},
         "host_placement": placement,
         "geometry": dict(geo, strips=int(off[-1]), strip_table_bytes_not_uploaded=int(off[-1]) * 256),
     }
