@@ -159,10 +159,10 @@ __global__ void __launch_bounds__(256) k_solve_system(int nSys, int nUnit, int n
         const cplx inv = {pv.re / dd, -pv.im / dd};
         for (int r = k + 1 + lane; r < n; r += 64) A[r * ld + k] = cmul(A[r * ld + k], inv);
         wave_lds_fence();
-        const int nc = ld - k - 1, nupd = (n - k - 1) * nc;
-        for (int e = lane; e < nupd; e += 64) {
-            const int r = k + 1 + e / nc, c = k + 1 + e % nc;
-            A[r * ld + c] = csub(A[r * ld + c], cmul(A[r * ld + k], A[k * ld + c]));
+        // rank-1 update: the lanes as an 8 x 8 grid over (row, column), strided by 8 -- no division in the loop
+        for (int r = k + 1 + (lane >> 3); r < n; r += 8) {
+            const cplx l = A[r * ld + k];
+            for (int c = k + 1 + (lane & 7); c < ld; c += 8) A[r * ld + c] = csub(A[r * ld + c], cmul(l, A[k * ld + c]));
         }
         wave_lds_fence();
     }
@@ -175,9 +175,14 @@ __global__ void __launch_bounds__(256) k_solve_system(int nSys, int nUnit, int n
             A[k * ld + n + j] = cplx{(sum.re * pv.re + sum.im * pv.im) / dd, (sum.im * pv.re - sum.re * pv.im) / dd};
         }
         wave_lds_fence();
-        for (int e = lane; e < k * nRhs; e += 64) {
-            const int r = e / nRhs, j = e % nRhs;
-            A[r * ld + n + j] = csub(A[r * ld + n + j], cmul(A[r * ld + k], A[k * ld + n + j]));
+        if (nRhs == 1) {
+            const cplx xk = A[k * ld + n];
+            for (int r = lane; r < k; r += 64) A[r * ld + n] = csub(A[r * ld + n], cmul(A[r * ld + k], xk));
+        } else {
+            for (int e = lane; e < k * nRhs; e += 64) {
+                const int r = e / nRhs, j = e % nRhs;
+                A[r * ld + n + j] = csub(A[r * ld + n + j], cmul(A[r * ld + k], A[k * ld + n + j]));
+            }
         }
         wave_lds_fence();
     }
