@@ -789,21 +789,33 @@ __global__ void k_geom_design_counts(GeomArgs A) {
     atomicMax(reinterpret_cast<unsigned long long *>(A.tot + 4), (unsigned long long)(A.mo(d + 1) - A.mo(d)));
 }
 __global__ __launch_bounds__(1024) void k_geom_scan(GeomArgs A) {
-    __shared__ long long part[2][1024];
+    __shared__ long long part[2][1025];
     const int t = threadIdx.x, T = blockDim.x;
     const int n = A.nDesign;
     const int per = (n + T - 1) / T, lo = t * per, hi = (lo + per < n) ? lo + per : n;
     long long a = 0, b = 0;
     for (int i = lo; i < hi; i++) { a += A.off[i + 1]; b += A.cmoff[i + 1]; }
-    part[0][t] = a; part[1][t] = b;
+    // exclusive scan of the 1024 partial sums: inside a wave by shuffles, across the 16 waves through LDS (a serial pass
+    // of thread 0 over the partials took 30 us of the member pass that the next batch's generation waits for)
+    {
+        const int lane = t & 63, wv = t >> 6;
+        long long ia = a, ib = b;
+        for (int o = 1; o < 64; o <<= 1) {
+            const long long ua = __shfl_up(ia, o, 64), ub = __shfl_up(ib, o, 64);
+            if (lane >= o) { ia += ua; ib += ub; }
+        }
+        if (lane == 63) { part[0][wv] = ia; part[1][wv] = ib; }
+        __syncthreads();
+        long long basea = 0, baseb = 0;
+        for (int i = 0; i < wv; i++) { basea += part[0][i]; baseb += part[1][i]; }
+        __syncthreads();
+        part[0][t] = basea + ia - a;                      // exclusive prefix of this thread
+        part[1][t] = baseb + ib - b;
+        if (t == T - 1) { part[0][T] = basea + ia; part[1][T] = baseb + ib; }
+    }
     __syncthreads();
     if (t == 0) {
-        long long sa = 0, sb = 0;
-        for (int i = 0; i < T; i++) {
-            const long long x = part[0][i], y = part[1][i];
-            part[0][i] = sa; part[1][i] = sb;
-            sa += x; sb += y;
-        }
+        const long long sa = part[0][T], sb = part[1][T];
         A.off[0] = 0;
         A.cmoff[0] = 0;
         A.tot[0] = sa;
