@@ -160,6 +160,7 @@ struct GeomArgs {
                                  // download): [0..2] = tot, [3..4] = err as 4 ints, [8 .. 8 + nDesign] = off
     int64_t mbase, sbase, cbase;
     int *mdesign_w;              // mdesign, writable (filled on the device by k_geom_mdesign)
+    int mgrid;                   // > 0: member kernels run on a (member position < mgrid, design) grid, designs fastest
     __device__ int64_t mo(int d) const { return memberOff[d] - mbase; }
     __device__ int64_t so(int64_t m) const { return stationOff[m] - sbase; }
     __device__ int64_t co(int64_t m) const { return capOff[m] - cbase; }
@@ -551,10 +552,24 @@ __global__ void k_geom_mdesign(GeomArgs A) {
     for (int64_t m = m0; m < m1; m++) A.mdesign_w[m] = d;
 }
 #define GEOM_MAX_STATIONS 1024
+// Member of this thread.  With A.mgrid > 0 the threads are laid out (member position, design) with the design running
+// fastest: a wavefront then holds the SAME member of 64 designs -- in a sweep the designs share a topology, so its lanes
+// take the same branches (the straight member order puts columns, pontoons and braces of a few designs side by side in
+// one wave, which then walks every path in turn).  -1: no member for this thread.
+__device__ inline int64_t geom_member_of_thread(const GeomArgs &A) {
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (A.mgrid <= 0) return t < A.nMember ? t : -1;
+    const int64_t k = t / A.nDesign;
+    if (k >= A.mgrid) return -1;
+    const int d = (int)(t % A.nDesign);
+    const int64_t m = A.mo(d) + k;
+    return m < A.mo(d + 1) ? m : -1;
+}
 __global__ __launch_bounds__(128) void k_geom_member(GeomArgs A) {
     GEOM_NOFMA
-    const int64_t m = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (m >= A.nMember) return;
+    if (A.mgrid > 0 && A.err[2]) return;                  // member offsets rejected: the grid cannot be walked
+    const int64_t m = geom_member_of_thread(A);
+    if (m < 0) return;
     const double *gm = A.gm + (size_t)m * RAFTX_GM_N;
     const double *gs = A.gs + (size_t)A.so(m) * RAFTX_GS_N;
     const int n = (int)(A.so(m + 1) - A.so(m));
@@ -758,8 +773,8 @@ __global__ void k_geom_trim(GeomArgs A) {
 __global__ __launch_bounds__(128) void k_geom_reinertia(GeomArgs A) {
     GEOM_NOFMA
     if (A.err[2] | A.err[3]) return;                      // rejected descriptors: phase 2 reports them
-    const int64_t m = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (m >= A.nMember) return;
+    const int64_t m = geom_member_of_thread(A);
+    if (m < 0) return;
     const double *gm = A.gm + (size_t)m * RAFTX_GM_N;
     if ((int)gm[RAFTX_GM_FLAGS] & RAFTX_GM_FLAG_NOSTATIC) return;
     const double *gs = A.gs + (size_t)A.so(m) * RAFTX_GS_N;

@@ -25,6 +25,7 @@
 #include <rccl/rccl.h>        // types only: the library is dlopen'ed on the first raftx_comm_* call
 #include <dlfcn.h>
 
+#include <algorithm>
 #include <cmath>
 #include <cstdint>
 #include <cstdio>
@@ -1024,11 +1025,18 @@ static int build_phase1(raftx_ctx *c, hipStream_t sCopy, hipStream_t sPrep, int 
     hipLaunchKernelGGL(k_geom_zero, dim3((unsigned)(nDesign / 256 + 1)), dim3(256), 0, sPrep, A);
     HIPCHK(c, hipEventRecord(c->evG2, sPrep));
     if (nDesign > 0) hipLaunchKernelGGL(k_geom_mdesign, dim3((unsigned)(nDesign / 256 + 1)), dim3(256), 0, sPrep, A);
+    A.mgrid = 0;
     if (nMember > 0) {
-        hipLaunchKernelGGL(k_geom_member, dim3((unsigned)((nMember + 127) / 128)), dim3(128), 0, sPrep, A);
+        // member kernels on a (member position, design) grid when that wastes few threads: wavefronts of like members
+        int64_t maxMem = 0;
+        for (int d = 0; d < nDesign; d++) maxMem = std::max(maxMem, memberOff[lo + d + 1] - memberOff[lo + d]);
+        static const bool flat_members = getenv("RAFTX_GEOM_FLAT_MEMBERS") != nullptr;
+        A.mgrid = (!flat_members && nDesign >= 64 && maxMem * nDesign <= nMember + nMember / 4) ? (int)maxMem : 0;
+        const int64_t nThread = A.mgrid > 0 ? (int64_t)A.mgrid * nDesign : nMember;
+        hipLaunchKernelGGL(k_geom_member, dim3((unsigned)((nThread + 127) / 128)), dim3(128), 0, sPrep, A);
         if (add_mask & RAFTX_TRIM_BALLAST) {              // heave trim: density correction, then the inertia again
             hipLaunchKernelGGL(k_geom_trim, dim3((unsigned)(nDesign / 128 + 1)), dim3(128), 0, sPrep, A);
-            hipLaunchKernelGGL(k_geom_reinertia, dim3((unsigned)((nMember + 127) / 128)), dim3(128), 0, sPrep, A);
+            hipLaunchKernelGGL(k_geom_reinertia, dim3((unsigned)((nThread + 127) / 128)), dim3(128), 0, sPrep, A);
         }
     } else {
         HIPCHK(c, hipMemsetAsync(A.soff, 0, sizeof(int64_t), sPrep));
