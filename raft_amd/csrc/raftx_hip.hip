@@ -570,6 +570,8 @@ struct BuildJob {
     double *M0d = nullptr, *C0d = nullptr;
     const double *B0d = nullptr, *MBwd = nullptr;
     bool active = false;
+    bool reduce_late = false;
+    hipStream_t reduce_stream = nullptr; // side stream the member -> platform reductions were launched on (evRed), or null
 };
 
 struct raftx_ctx {
@@ -578,6 +580,8 @@ struct raftx_ctx {
     bool owns_stream;                    // false for the block contexts of raftx_sweep_stats (they run on the parent's stream)
     hipEvent_t ev0, ev1;
     hipEvent_t evUp, evTot, evG0, evG1, evG2, evG3, evS0, evS1, evDone;   // build phases, statistics, block finished
+    hipEvent_t evMem, evRed;             // member pass done (preparation stream) / per-design reduction done (side stream)
+    hipStream_t sAux;                    // side stream of the parent ctx: the reductions of the member pass run beside its scans
     BuildJob job;
     long long *pin;                      // page-locked landing area of the build totals and offsets [8 + nDesign + 1]
     size_t pin_n;
@@ -713,8 +717,9 @@ extern "C" int raftx_ctx_create(int device_id, raftx_ctx **out) {
     c->pinRes_n = 0;
     c->sCopy = c->sPrep = c->sD2H = nullptr;
     bool ok = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) == hipSuccess;
+    c->sAux = nullptr;
     for (hipEvent_t *e : {&c->ev0, &c->ev1, &c->evUp, &c->evTot, &c->evG0, &c->evG1, &c->evG2, &c->evG3, &c->evS0,
-                          &c->evS1, &c->evDone})
+                          &c->evS1, &c->evDone, &c->evMem, &c->evRed})
         ok = ok && hipEventCreate(e) == hipSuccess;
     if (!ok) {
         delete[] c->slots;
@@ -772,8 +777,10 @@ extern "C" void raftx_ctx_destroy(raftx_ctx *c) {
     c->pool.trim();
     if (c->pin) (void)hipHostFree(c->pin);
     if (c->pinRes) (void)hipHostFree(c->pinRes);
-    for (hipEvent_t e : {c->ev0, c->ev1, c->evUp, c->evTot, c->evG0, c->evG1, c->evG2, c->evG3, c->evS0, c->evS1, c->evDone})
+    for (hipEvent_t e : {c->ev0, c->ev1, c->evUp, c->evTot, c->evG0, c->evG1, c->evG2, c->evG3, c->evS0, c->evS1, c->evDone,
+                         c->evMem, c->evRed})
         (void)hipEventDestroy(e);
+    if (c->sAux) (void)hipStreamDestroy(c->sAux);
     for (hipStream_t st : {c->sCopy, c->sPrep, c->sD2H})
         if (st) (void)hipStreamDestroy(st);
     if (c->owns_stream) (void)hipStreamDestroy(c->stream);
@@ -1042,6 +1049,29 @@ static int build_phase1(raftx_ctx *c, hipStream_t sCopy, hipStream_t sPrep, int 
         HIPCHK(c, hipMemsetAsync(A.soff, 0, sizeof(int64_t), sPrep));
         HIPCHK(c, hipMemsetAsync(A.cmsoff, 0, sizeof(int64_t), sPrep));
     }
+    // the member -> platform reductions need the member pass only: they run on a side stream beside the scans, off the
+    // stream the fused kernel waits on (phase 2 orders the design kernel behind them)
+    if (dev_alloc(c, c->design_allocs, (size_t)nDesign * 36, &A.Ch) || dev_alloc(c, c->design_allocs, (size_t)nDesign * 6, &A.Wh) ||
+        dev_alloc(c, c->design_allocs, (size_t)nDesign * 36, &A.Ms) || dev_alloc(c, c->design_allocs, (size_t)nDesign * 36, &A.Cs) ||
+        dev_alloc(c, c->design_allocs, (size_t)nDesign * 6, &A.Ws) || dev_alloc(c, c->design_allocs, (size_t)nDesign * RAFTX_SP_N, &A.props))
+        return -2;
+    J.reduce_stream = nullptr;
+    static const bool reduce_late = getenv("RAFTX_REDUCE_PHASE2") != nullptr;      // tuning: on the ctx stream, before the design kernel
+    J.reduce_late = reduce_late;
+    if (nDesign > 0 && !reduce_late) {
+        hipStream_t sRed = sPrep;
+        if (sPrep != c->stream) {                         // crossings: a stream of its own per block context
+            if (!c->sAux) HIPCHK(c, hipStreamCreateWithFlags(&c->sAux, hipStreamNonBlocking));
+            sRed = c->sAux;
+            HIPCHK(c, hipEventRecord(c->evMem, sPrep));
+            HIPCHK(c, hipStreamWaitEvent(sRed, c->evMem, 0));
+        }
+        hipLaunchKernelGGL(k_geom_reduce, dim3((unsigned)(((size_t)nDesign * 3 + 63) / 64)), dim3(64), 0, sRed, A);
+        if (sRed != sPrep) {
+            HIPCHK(c, hipEventRecord(c->evRed, sRed));
+            J.reduce_stream = sRed;
+        }
+    }
     if (nDesign > 0) {
         hipLaunchKernelGGL(k_geom_design_counts, dim3((unsigned)(nDesign / 256 + 1)), dim3(256), 0, sPrep, A);
         hipLaunchKernelGGL(k_geom_scan, dim3(1), dim3(1024), 0, sPrep, A);
@@ -1087,10 +1117,7 @@ static int build_phase2(raftx_ctx *c, int64_t *stripOffsets, hipStream_t sGen = 
     if (dev_alloc(c, c->design_allocs, nStrips * NF, &A.abi) || dev_alloc(c, c->design_allocs, nStrips * DS_N, &A.ds) ||
         dev_alloc(c, c->design_allocs, nStrips, &A.dsi) || dev_alloc(c, c->design_allocs, nRows * 3, &A.mcfaux) ||
         dev_alloc(c, c->design_allocs, nRows * 2 * (size_t)nw, &A.cm) ||
-        dev_alloc(c, c->design_allocs, (size_t)nDesign * 36, &A.A) || dev_alloc(c, c->design_allocs, (size_t)nDesign * 36, &A.Ch) ||
-        dev_alloc(c, c->design_allocs, (size_t)nDesign * 6, &A.Wh) || dev_alloc(c, c->design_allocs, (size_t)nDesign * 36, &A.Ms) ||
-        dev_alloc(c, c->design_allocs, (size_t)nDesign * 36, &A.Cs) || dev_alloc(c, c->design_allocs, (size_t)nDesign * 6, &A.Ws) ||
-        dev_alloc(c, c->design_allocs, (size_t)nDesign * RAFTX_SP_N, &A.props))
+        dev_alloc(c, c->design_allocs, (size_t)nDesign * 36, &A.A))
         return -2;
     (void)tmp;
     const size_t gd_lds = geom_design_lds(maxS, (int)c->pin[5], (int)c->pin[6]);
@@ -1102,7 +1129,8 @@ static int build_phase2(raftx_ctx *c, int64_t *stripOffsets, hipStream_t sGen = 
     HIPCHK(c, hipStreamWaitEvent(sGen, c->evTot, 0));
     HIPCHK(c, hipEventRecord(c->evG0, sGen));
     if (nDesign > 0) {
-        hipLaunchKernelGGL(k_geom_reduce, dim3((unsigned)(((size_t)nDesign * 3 + 63) / 64)), dim3(64), 0, sGen, A);
+        if (J.reduce_stream) HIPCHK(c, hipStreamWaitEvent(sGen, c->evRed, 0));     // the reductions of phase 1 (side stream)
+        if (J.reduce_late) hipLaunchKernelGGL(k_geom_reduce, dim3((unsigned)(((size_t)nDesign * 3 + 63) / 64)), dim3(64), 0, sGen, A);
         hipLaunchKernelGGL(k_geom_design, dim3((unsigned)nDesign), dim3(64), gd_lds, sGen, A);
     }
     if (nRows > 0)                                        // after k_geom_design: it leaves (R, Ca) of the MacCamy-Fuchs strips
