@@ -306,21 +306,14 @@ __global__ void __launch_bounds__(256) k_solve_dense(int n, int nRhs, int nw, co
     }
 }
 
-// iteration counts and flags of a block straight into page-locked host memory (out[0..n) = a, out[n..2n) = b)
-__global__ void k_ints_to_host(int n, const int *__restrict__ a, const int *__restrict__ b, int *__restrict__ out) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) {
-        out[i] = a[i];
-        out[n + i] = b[i];
-    }
-}
-
 // Motion statistics of the resident responses (raft_fowt.py:2310-2357; helpers.py:678-700): one
 // workgroup per (design, case), lanes stride the frequency axis (coalesced 16 B/lane reads of the
 // Xi slab: a pure HBM stream, 19.2 KB in -> 48 B out per pair at C3).
 __global__ void __launch_bounds__(256) k_motion_stats(int npair, int nHead, int nw, double inv_dw,
                                                       const cplx *__restrict__ Xi, double *__restrict__ sd,
-                                                      double *__restrict__ psd) {
+                                                      double *__restrict__ psd,
+                                                      const int *__restrict__ niter = nullptr, const int *__restrict__ flags = nullptr,
+                                                      int *__restrict__ ints_out = nullptr) {
     __shared__ double part[4][6];
     const int p = blockIdx.x;
     if (p >= npair) return;
@@ -352,6 +345,10 @@ __global__ void __launch_bounds__(256) k_motion_stats(int npair, int nHead, int 
         double a = 0.0;
         for (int q = 0; q < (int)(blockDim.x >> 6); q++) a += part[q][threadIdx.x];
         sd[(size_t)p * 6 + threadIdx.x] = sqrt(0.5 * a);
+    }
+    if (ints_out && threadIdx.x == 6) {                   // sweep crossings: iteration count and flags of the pair ride along
+        ints_out[p] = niter[p];                           // (out[0..n) = niter, out[n..2n) = flags, page-locked host memory)
+        ints_out[npair + p] = flags[p];
     }
 }
 
@@ -2331,9 +2328,8 @@ extern "C" int raftx_sweep_submit(raftx_ctx *c, int slot, int nDesign, const int
             hipError_t e = hipEventRecord(sub->evS0, c->stream);
             if (npair) {
                 hipLaunchKernelGGL(k_motion_stats, dim3((unsigned)npair), dim3(nw > 128 ? 256 : (nw > 64 ? 128 : 64)), 0, c->stream,
-                                   (int)npair, nHead, nw, 1.0 / dw, sub->rXi, sub->pinRes, (double *)nullptr);
-                hipLaunchKernelGGL(k_ints_to_host, dim3((unsigned)((npair + 255) / 256)), dim3(256), 0, c->stream, (int)npair, sub->rNi,
-                                   sub->rFl, reinterpret_cast<int *>(sub->pinRes + npair * 6));
+                                   (int)npair, nHead, nw, 1.0 / dw, sub->rXi, sub->pinRes, (double *)nullptr, (const int *)sub->rNi,
+                                   (const int *)sub->rFl, reinterpret_cast<int *>(sub->pinRes + npair * 6));
             }
             if (e == hipSuccess) e = hipEventRecord(sub->evS1, c->stream);
             if (e == hipSuccess) e = hipEventRecord(sub->evDone, c->stream);
