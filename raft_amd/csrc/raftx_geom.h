@@ -980,10 +980,15 @@ __device__ unsigned long long geom_phase_cycles[10];
 #define GEOM_PHASE(i)
 #define GEOM_PHASE_BEGIN
 #endif
-__global__ __launch_bounds__(64) void k_geom_design(GeomArgs A) {
+#ifndef GD_T
+#define GD_T 128            // threads per design: two wavefronts share the candidate strips and the output loops
+#endif
+static_assert(GD_T % 64 == 0 && GD_T % DS_N == 0 && GD_T <= 256, "k_geom_design: whole wavefronts, a lane keeps its record field");
+__global__ __launch_bounds__(GD_T) void k_geom_design(GeomArgs A) {
     GEOM_NOFMA
     extern __shared__ double gd_lds[];
-    const int d = blockIdx.x, lane = threadIdx.x;
+    __shared__ int wcnt[GD_T / 64];
+    const int d = blockIdx.x, lane = threadIdx.x;        // lane: thread of the design's workgroup (0 .. GD_T-1)
     if (d >= A.nDesign) return;
     const int64_t i0 = A.off[d], i1 = A.off[d + 1];
     const int S = (int)(i1 - i0);
@@ -1005,9 +1010,9 @@ __global__ __launch_bounds__(64) void k_geom_design(GeomArgs A) {
         int *mbase = mcum + nSta + 2 * nMem;              // [nMem + 1] candidates before each member
         // groups of all members flattened over the lanes: member mi owns the n + 1 groups [sta0(mi) + mi, sta0(mi + 1) + mi + 1)
         // (mbase doubles as the members' first-station table until the counts are in)
-        for (int mi = lane; mi <= nMem; mi += 64) mbase[mi] = (int)(A.so(m0 + mi) - s0);
+        for (int mi = lane; mi <= nMem; mi += GD_T) mbase[mi] = (int)(A.so(m0 + mi) - s0);
         __syncthreads();
-        for (int u = lane; u < nSta + nMem; u += 64) {
+        for (int u = lane; u < nSta + nMem; u += GD_T) {
             int mi = 0;
             while (mi + 1 < nMem && mbase[mi + 1] + mi + 1 <= u) mi++;
             const int sta0 = mbase[mi], n = mbase[mi + 1] - sta0, g = u - (sta0 + mi);
@@ -1020,7 +1025,7 @@ __global__ __launch_bounds__(64) void k_geom_design(GeomArgs A) {
             mcum[sta0 + 2 * mi + g + 1] = cntg;
         }
         __syncthreads();
-        for (int mi = lane; mi < nMem; mi += 64) {
+        for (int mi = lane; mi < nMem; mi += GD_T) {
             const int64_t m = m0 + mi;
             const int n = (int)(A.so(m + 1) - A.so(m));
             int *cum = mcum + (A.so(m) - s0) + 2 * mi;
@@ -1043,7 +1048,7 @@ __global__ __launch_bounds__(64) void k_geom_design(GeomArgs A) {
         if (A.pose)
             for (int i = 0; i < 3; i++) rP[i] = A.pose[(size_t)d * 6 + i];
         int nwet = 0;
-        for (int t0 = 0; t0 < total; t0 += 64) {
+        for (int t0 = 0; t0 < total; t0 += GD_T) {
             const int t = t0 + lane;
             const bool act = t < total;
             const int tq = act ? t : 0;
@@ -1076,9 +1081,19 @@ __global__ __launch_bounds__(64) void k_geom_design(GeomArgs A) {
             for (int c = 0; c < 3; c++) r[c] = geom_along(rA[c], rB[c], st.ls, L);
             const bool wet = act && (r[2] < 0);
             const GLocate at = geom_locate(st.ls, gs, n);     // one search for the seven coefficient interpolations
+            // compaction over the two wavefronts: ballots inside each, the first wave's count through LDS
             const unsigned long long mask = __ballot(wet);
-            const int pos = nwet + __popcll(mask & ((1ull << lane) - 1ull));
-            nwet += __popcll(mask);
+            const int wv = lane >> 6, ln = lane & 63;
+            if (ln == 0) wcnt[wv] = __popcll(mask);
+            __syncthreads();
+            int before = 0, all = 0;
+            for (int w = 0; w < GD_T / 64; w++) {
+                before += w < wv ? wcnt[w] : 0;
+                all += wcnt[w];
+            }
+            const int pos = nwet + before + __popcll(mask & ((1ull << ln) - 1ull));
+            nwet += all;
+            __syncthreads();
             if (!wet || pos >= S) continue;
             double *row = rec + (size_t)pos * GD_ROW;
             for (int c = 0; c < NF; c++) row[c] = 0.0;
@@ -1141,12 +1156,12 @@ __global__ __launch_bounds__(64) void k_geom_design(GeomArgs A) {
         __syncthreads();
         GEOM_PHASE(1);
         double *abi = A.abi + (size_t)i0 * NF;
-        for (int t = lane; t < S * NF; t += 64) abi[t] = rec[(t / NF) * GD_ROW + (t % NF)];
+        for (int t = lane; t < S * NF; t += GD_T) abi[t] = rec[(t / NF) * GD_ROW + (t % NF)];
     }
     __syncthreads();
     GEOM_PHASE(2);
     // ---- run detection (derive_design_tables, same expressions and order; see there for the rules)
-    for (int t = lane; t < S; t += 64) {
+    for (int t = lane; t < S; t += GD_T) {
         bool pass = false;
         double pj = 0.0;
         if (t > 0) {
@@ -1189,7 +1204,7 @@ __global__ __launch_bounds__(64) void k_geom_design(GeomArgs A) {
         if (S > 0) unv[s] = unit;
     }
     __syncthreads();
-    for (int t = lane; t < S; t += 64) {
+    for (int t = lane; t < S; t += GD_T) {
         const int s = rsv[t];
         const double unit = unv[s];
         const double *cr = rec + (size_t)t * GD_ROW;
@@ -1226,7 +1241,7 @@ __global__ __launch_bounds__(64) void k_geom_design(GeomArgs A) {
     {
         double *dso = A.ds + (size_t)i0 * DS_N;
         const int j = lane % DS_N, f = DS_SRC[j];
-        for (int t = lane; t < S * DS_N; t += 64) {
+        for (int t = lane; t < S * DS_N; t += GD_T) {
             const int i = t / DS_N;
             const double *cr = rec + (size_t)i * GD_ROW;
             double v = 0.0;
@@ -1240,7 +1255,7 @@ __global__ __launch_bounds__(64) void k_geom_design(GeomArgs A) {
     // c_n g g^T with g = [n ; arm x n] for its three directions n = p1, p2, q.  The 3 x (c, g) of every strip are formed
     // once (lane per strip) and parked over the staged records; lane (i, j) then sums c g_i g_j over the strips in order.
     constexpr int GV = 21;                                // doubles per strip: 3 x (c, g[6])
-    for (int t0 = 0; t0 < S; t0 += 64) {
+    for (int t0 = 0; t0 < S; t0 += GD_T) {
         const int t = t0 + lane;
         double gv[GV];
         if (t < S) {

@@ -1128,7 +1128,7 @@ static int build_phase2(raftx_ctx *c, int64_t *stripOffsets, hipStream_t sGen = 
     if (nDesign > 0) {
         if (J.reduce_stream) HIPCHK(c, hipStreamWaitEvent(sGen, c->evRed, 0));     // the reductions of phase 1 (side stream)
         if (J.reduce_late) hipLaunchKernelGGL(k_geom_reduce, dim3((unsigned)(((size_t)nDesign * 3 + 63) / 64)), dim3(64), 0, sGen, A);
-        hipLaunchKernelGGL(k_geom_design, dim3((unsigned)nDesign), dim3(64), gd_lds, sGen, A);
+        hipLaunchKernelGGL(k_geom_design, dim3((unsigned)nDesign), dim3(GD_T), gd_lds, sGen, A);
     }
     if (nRows > 0)                                        // after k_geom_design: it leaves (R, Ca) of the MacCamy-Fuchs strips
         hipLaunchKernelGGL(k_geom_mcf, dim3((unsigned)nRows, (unsigned)((nw + 63) / 64)), dim3(64), 0, sGen, A, (int64_t)nRows);
