@@ -1297,6 +1297,13 @@ static int shape_maxt(Shape sh) {
 #undef X
     return 0;
 }
+// waves per SIMD the kernel of a shape is compiled for
+static int shape_minb(Shape sh) {
+#define X(NB_, MT_, MB_) if (sh.nb == NB_ && sh.threads == MT_) return MB_;
+    SHAPES(X)
+#undef X
+    return 1;
+}
 static bool shape_ok(Shape sh, int nw) {
 #define X(NB_, MT_, MB_) if (sh.nb == NB_ && sh.threads == MT_) return (long)NB_ * MT_ >= nw;
     SHAPES(X)
@@ -1510,9 +1517,23 @@ static int solve_enqueue(raftx_ctx *c, int nIter, double tol, double XiStart, co
     int need = (T.MBw ? KF_FDEP : 0) | (A.Z ? KF_OUTZ : 0) | (A.F_wave ? KF_OUTF : 0) | (A.F_extra ? KF_EXTRA : 0) |
                      (T.cm ? KF_MCF : 0) | (T.nHead > 1 ? KF_MULTI : 0);
     const Shape sh = pick_shape(T.nw);
-    const bool xlg = sh.threads == 512 && sh.nb >= 3;        // XiLast in a global scratch slab (raftx_kernels.h XlStore)
+    const bool xlg = xl_global(sh.nb, shape_maxt(sh));       // XiLast in a global scratch slab (raftx_kernels.h XlStore)
+    // Workgroups a CU can hold by registers (the shape's waves per SIMD); LDS beyond what that residency needs goes to
+    // the run-start cache (raftx_kernels.h Kin): as many 16-byte-per-bin slots as fit without costing a resident pair.
+    const int wg_per_cu = std::max(1, shape_minb(sh) * 4 / (sh.threads / 64));
+    auto rc_slots = [&](int S_) {
+        if (!(shape_maxt(sh) == 128 && sh.nb == 2)) return 0;
+        static const char *env = getenv("RAFTX_RC_SLOTS");                 // tuning: cap (0 = no cache)
+        const int cap = env ? atoi(env) : 24;
+        const size_t base = lds_bytes(S_, xlg ? 0 : T.nw, sh.threads / 64, stage_policy(sh.nb, shape_maxt(sh)),
+                                      park_policy(sh.nb, shape_maxt(sh)));
+        const size_t budget = LDS_LIMIT / (size_t)wg_per_cu;
+        if (budget <= base) return 0;
+        return (int)std::min<size_t>((size_t)cap, (budget - base) / (16 * (size_t)xl_row(T.nw)));
+    };
+    A.rc_n = rc_slots(c->maxS);
     const size_t lds = lds_bytes(c->maxS, xlg ? 0 : T.nw, sh.threads / 64, stage_policy(sh.nb, shape_maxt(sh)),
-                                 park_policy(sh.nb, shape_maxt(sh)));
+                                 park_policy(sh.nb, shape_maxt(sh)), A.rc_n, T.nw);
     if (xlg && (!c->rXl || c->rXl_n < c->r_npair * 12 * (size_t)T.nw)) {
         HIPCHK(c, hipStreamSynchronize(c->stream));
         if (c->rXl) (void)hipFree(c->rXl);
@@ -1556,7 +1577,7 @@ static int solve_enqueue(raftx_ctx *c, int nIter, double tol, double XiStart, co
         auto lds_of = [&](int S_) {
             return lds_bytes(S_, xlg ? 0 : T.nw, sh.threads / 64, stage_policy(sh.nb, shape_maxt(sh)), park_policy(sh.nb, shape_maxt(sh)));
         };
-        auto fit = [&](int S_) { return (int)(LDS_LIMIT / lds_of(S_)); };
+        auto fit = [&](int S_) { return std::min(wg_per_cu, (int)(LDS_LIMIT / lds_of(S_))); };   // pairs a CU holds
         const int kmax = fit(0);
         bool mixed = false;
         if ((int)c->hS.size() == T.nDesign && T.nDesign > 0) {
@@ -1604,8 +1625,9 @@ static int solve_enqueue(raftx_ctx *c, int nIter, double tol, double XiStart, co
             A.pairs = c->pairList + at_;                                                                             \
             A.npairs = (int)n_;                                                                                      \
             at_ += n_;                                                                                               \
+            A.rc_n = rc_slots(clsS[(size_t)kk]);                                                                     \
             const size_t l_ = lds_bytes(clsS[(size_t)kk], xlg ? 0 : T.nw, sh.threads / 64, stage_policy(sh.nb, shape_maxt(sh)), \
-                                        park_policy(sh.nb, shape_maxt(sh)));                                         \
+                                        park_policy(sh.nb, shape_maxt(sh)), A.rc_n, T.nw);                           \
             hipLaunchKernelGGL((k_solve_dynamics<NB_, FL, MT_, MB_>), dim3(grid_for_pairs(n_)), dim3(sh.threads),    \
                                l_, c->stream, T, A);                                                                 \
         }                                                                                                            \

@@ -166,6 +166,8 @@ constexpr bool RUN_LOOPS = RAFTX_RUN_LOOPS && NB <= 2;
 // + 1.5 K  ~= 37 K  ->  four pairs per CU (160 KiB).  The one-wave-per-SIMD shapes additionally
 // stage the hot strip constants (ra, +7.6 K).
 struct Lds {
+    ldptr rc;      // [rc_n][nw_rc][2] run-start cache: rc_n slots of two doubles per bin (see Kin), rc_stride doubles apart
+    int rc_n, rc_stride;
     ldptr xl;      // [12][nxl]    XiLast (re/im rows), nxl = nw rounded up to even
     ldptr ra;      // [S][stage_n] hot strip constants: all RA_N, the first 6 (arm, q), or none -- see stage_policy
     ldptr uv;      // [S][12]      linearised drag vectors of the current heading
@@ -183,10 +185,17 @@ static __host__ __device__ inline int xl_row(int nw) { return (nw + 1) & ~1; }
 // park_n: doubles of the [uv | vsq | tile] span that the solve phase reuses as a per-lane parking column (0 = none);
 // the span is padded up to that size for designs with few strips
 static __host__ __device__ constexpr int park_policy(int nb, int maxt) { return (nb == 2 && maxt == 128) ? 12 * 128 : 0; }
-__device__ __forceinline__ Lds carve(double *base_, int S, int nw, int nwv, int stage_n, int park_n = 0) {
+// nw_xl: bins of the XiLast rows kept in LDS (0: XiLast lives in a global slab); rc_n slots of the run-start cache over
+// nw_rc bins
+__device__ __forceinline__ Lds carve(double *base_, int S, int nw_xl, int nwv, int stage_n, int park_n = 0, int rc_n = 0,
+                                     int nw_rc = 0) {
     Lds l;
     ldptr base = (ldptr)base_;
-    l.nxl = xl_row(nw);
+    l.rc = base;                                  // first: 16-byte aligned slots (ds_read_b128 / ds_write_b128)
+    l.rc_n = rc_n;
+    l.rc_stride = 2 * xl_row(nw_rc);
+    base += (size_t)rc_n * l.rc_stride;
+    l.nxl = xl_row(nw_xl);
     l.xl = base;
     l.ra = l.xl + (size_t)12 * l.nxl;
     l.vsq = l.ra + (size_t)S * stage_n;
@@ -200,12 +209,17 @@ __device__ __forceinline__ Lds carve(double *base_, int S, int nw, int nwv, int 
     l.fl = (liptr)(l.mat + 108);
     return l;
 }
-static size_t lds_bytes(int S, int nw, int nwv, int stage_n, int park_n = 0) {
+static size_t lds_bytes(int S, int nw, int nwv, int stage_n, int park_n = 0, int rc_n = 0, int nw_rc = 0) {
     size_t span = (size_t)S * (12 + 3 * nwv) + (size_t)nwv * TR_ROWS * TR_STRIDE;          // vsq | uv | tile
     if (park_n && span < (size_t)S * 3 + (size_t)park_n) span = (size_t)S * 3 + (size_t)park_n;
-    return sizeof(double) * ((size_t)12 * xl_row(nw) + (size_t)S * stage_n + span + (size_t)nwv * 24 + 36 + 108 + 2) +
+    return sizeof(double) * ((size_t)rc_n * 2 * xl_row(nw_rc) + (size_t)12 * xl_row(nw) + (size_t)S * stage_n + span +
+                             (size_t)nwv * 24 + 36 + 108 + 2) +
            sizeof(int) * (size_t)(stage_n == RA_N ? S + 2 : 2);
 }
+// shapes that keep XiLast in a per-pair global slab (SolveArgs::Xl) instead of LDS: the largest ones (no room), and the
+// two-waves-per-SIMD 200-bin shape, whose LDS goes to the run-start cache instead (XiLast is touched twice per
+// iteration, the run starts fourteen times)
+static __host__ __device__ constexpr bool xl_global(int nb, int maxt) { return (maxt == 512 && nb >= 3) || (maxt == 128 && nb == 2); }
 
 // LDS traffic between lanes of ONE wave needs no s_barrier (a wave's LDS instructions
 // execute in order); it only needs the compiler to keep the order.
@@ -296,6 +310,11 @@ __device__ __forceinline__ void set_heading_amp(const DevTables &T, Bins<NB> &b,
 // (helpers.py:211-218): 2 = k == 0, 1 = deep water (k h > 89.4), 0 = finite depth
 __device__ __forceinline__ int depth_mode(double k, double depth) { return k == 0.0 ? 2 : (k * depth > 89.4 ? 1 : 0); }
 
+// RAFTX_UNIT_ROTORS: keep the rotors of ONE unit step only and apply them twice for a two-unit step -- no more
+// instructions than choosing between two rotor sets per step with selects, and 16 VGPRs less at two bins per lane
+#ifndef RAFTX_UNIT_ROTORS
+#define RAFTX_UNIT_ROTORS 1
+#endif
 // ------------------------------------------------------------------ wave kinematics along a run
 // State per bin: a = amp * e^{-i k xi_s};  P = e^{k z_s};  Q = e^{-k (z_s + 2h)}  (Q = 0 in the
 // deep-water branch, helpers.py:215-218, unless KEEPQ);  rotors of one and of two unit steps.
@@ -303,14 +322,27 @@ template <int NB>
 struct Kin {
     double ar[NB], ai[NB], P[NB], Q[NB];
     double r1r[NB], r1i[NB], r1p[NB], r1q[NB];
+#if !RAFTX_UNIT_ROTORS
     double r2r[NB], r2i[NB], r2p[NB], r2q[NB];
+#endif
     // memo of the previous run start (wave-uniform keys, per-bin values): members that start at
     // the same depth share P, Q; members with the same step vector share the rotors
     double P0[NB], Q0[NB];
     double mz, mux, muy, muz;
     bool rot, dec;        // of the current step vector (wave-uniform): the phase rotor / the depth-decay rotors differ from 1
     bool vert;            // the step vector has no horizontal part (a vertical member, or a run of one strip)
+    // run-start cache cursor: every sweep of a pair meets the same run starts in the same order with the same memo
+    // hits, so the n-th transcendental evaluation of a sweep is the same quantity in every sweep -- the first sweep
+    // (the inertial excitation) stores the first cn of them per bin in LDS, the later sweeps read them back
+    ldptr rc;
+    int ce, cn, cstride, rot_slot, dec_slot;
 };
+struct RunCache {
+    ldptr p;
+    int n, stride;
+};
+__device__ __forceinline__ RunCache run_cache_of(const Lds &l) { return {l.rc, l.rc_n, l.rc_stride}; }
+__device__ __forceinline__ RunCache no_run_cache() { return {nullptr, 0, 0}; }
 
 // Run start: exact evaluation from the absolute position (helpers.py:201,211-222).
 //   amp[j] multiplies the phase factor (c1 for the velocity sweeps, 1 for the pressure sweep).
@@ -323,7 +355,40 @@ __device__ __forceinline__ RunStart run_start_of(cdptr rec) {
 __device__ __forceinline__ RunStart run_start_of(ldptr r) {              // staged LDS record
     return {r[12], r[13], r[14], r[15], r[16], r[17]};
 }
-template <int NB, bool KEEPQ>
+// One cacheable evaluation: two doubles per bin in slot `slot` of the run-start cache.  CM 1 (first sweep of a pair):
+// a fresh quantity is computed and stored while slots last; CM 2: read back what was stored, compute the rest.  A
+// quantity met again in the same sweep (fresh == false: a later run with the same step vector) is read back in both
+// modes.  Every lane reads only what it wrote itself.
+template <int CM, int NB, typename Fn>
+__device__ __forceinline__ void kin_cached(Kin<NB> &K, const Bins<NB> &b, int slot, bool fresh, double (&v0)[NB],
+                                           double (&v1)[NB], Fn compute) {
+    static_assert(CM == 1 || CM == 2, "cache mode");
+    const bool hit = slot < K.cn;                             // wave-uniform
+    ldptr sl = K.rc + slot * K.cstride;
+    if (hit && !(CM == 1 && fresh)) {
+#pragma unroll
+        for (int j = 0; j < NB; j++) {
+            ldptr e = sl + 2 * b.iw[j];
+            v0[j] = e[0];
+            v1[j] = e[1];
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < NB; j++) compute(j, v0[j], v1[j]);
+        if (CM == 1 && hit) {
+#pragma unroll
+            for (int j = 0; j < NB; j++)
+                if (b.act[j]) {
+                    ldptr e = sl + 2 * b.iw[j];
+                    e[0] = v0[j];
+                    e[1] = v1[j];
+                }
+        }
+    }
+}
+// CM 0: no cache.  The rotors and P, Q of the previous run start stay in registers for members with the same step
+// vector / start depth in every mode.
+template <int NB, bool KEEPQ, int CM = 0>
 __device__ __forceinline__ void kin_start(Kin<NB> &K, const RunStart rs, const Bins<NB> &b,
                                           const double (&amp)[NB], double cb, double sb) {
     const double x = rs.x, y = rs.y, z = rs.z, ux = rs.ux, uy = rs.uy, uz = rs.uz;
@@ -331,51 +396,90 @@ __device__ __forceinline__ void kin_start(Kin<NB> &K, const RunStart rs, const B
     const double du = cb * ux + sb * uy;
     const bool same_z = (z == K.mz);                      // wave-uniform
     const bool same_u = (ux == K.mux) && (uy == K.muy) && (uz == K.muz);
+    auto f_phasor = [&](int j, double &c_, double &s_) { fast_sincos(-(b.k[j] * xi), s_, c_); };
+    auto f_pq = [&](int j, double &P_, double &Q_) {
+        const double kz = b.k[j] * z;
+        const double Pe = fast_exp(kz);
+        const double Qe = fast_exp(-(b.k[j] * (z + 2.0 * b.depth)));       // e^{-k (z + 2h)}
+        // k == 0 (helpers.py:211-214): Sh = 1, Ch = Cc = 99999  <=>  P + Q = 99999, P - Q = 1 with csh = cch = 1
+        const bool k0 = b.k[j] == 0.0;
+        P_ = k0 ? 50000.0 : Pe;
+        Q_ = k0 ? 49999.0 : Qe;
+    };
+    auto f_rot = [&](int j, double &c_, double &s_) { fast_sincos(-(b.k[j] * du), s_, c_); };
+    auto f_dec = [&](int j, double &p_, double &q_) {
+        p_ = fast_exp(b.k[j] * uz);
+        q_ = fast_exp(-(b.k[j] * uz));
+    };
+    {
+        double c[NB], s[NB];
+        if constexpr (CM == 0) {
+#pragma unroll
+            for (int j = 0; j < NB; j++) f_phasor(j, c[j], s[j]);
+        } else {
+            kin_cached<CM>(K, b, K.ce++, true, c, s, f_phasor);
+        }
+#pragma unroll
+        for (int j = 0; j < NB; j++) {
+            K.ar[j] = amp[j] * c[j];
+            K.ai[j] = amp[j] * s[j];
+        }
+    }
+    if (!same_z) {
+        double P[NB], Q[NB];                              // cached in the KEEPQ form: the reader masks Q of the deep-water branch
+        if constexpr (CM == 0) {
+#pragma unroll
+            for (int j = 0; j < NB; j++) f_pq(j, P[j], Q[j]);
+        } else {
+            kin_cached<CM>(K, b, K.ce++, true, P, Q, f_pq);
+        }
+#pragma unroll
+        for (int j = 0; j < NB; j++) {
+            K.P0[j] = P[j];
+            K.Q0[j] = (!KEEPQ && depth_mode(b.k[j], b.depth) == 1) ? 0.0 : Q[j];
+        }
+    }
 #pragma unroll
     for (int j = 0; j < NB; j++) {
-        double s, c;
-        fast_sincos(-(b.k[j] * xi), s, c);
-        K.ar[j] = amp[j] * c;
-        K.ai[j] = amp[j] * s;
-        if (!same_z) {
-            const double kz = b.k[j] * z;
-            double P = fast_exp(kz);
-            double Q = fast_exp(-(b.k[j] * (z + 2.0 * b.depth)));       // e^{-k (z + 2h)}
-            const int mode = depth_mode(b.k[j], b.depth);
-            if (!KEEPQ) Q = (mode == 1) ? 0.0 : Q;
-            // k == 0 (helpers.py:211-214): Sh = 1, Ch = Cc = 99999  <=>  P + Q = 99999, P - Q = 1 with csh = cch = 1
-            K.P0[j] = (mode == 2) ? 50000.0 : P;
-            K.Q0[j] = (mode == 2) ? 49999.0 : Q;
-        }
         K.P[j] = K.P0[j];
         K.Q[j] = K.Q0[j];
     }
     K.mz = z;
     if (!same_u) {
-        const bool rot = du != 0.0, dec = uz != 0.0;  // wave-uniform: vertical members skip the phase rotor,
-        K.rot = rot;                                  // horizontal ones the depth-decay rotors
-        K.dec = dec;
+        K.rot = du != 0.0;                            // wave-uniform: vertical members skip the phase rotor,
+        K.dec = uz != 0.0;                            // horizontal ones the depth-decay rotors
         K.vert = (ux == 0.0) && (uy == 0.0);
-#pragma unroll
-        for (int j = 0; j < NB; j++) {
-            double s = 0.0, c = 1.0, p = 1.0, q = 1.0;
-            if (rot) fast_sincos(-(b.k[j] * du), s, c);
-            if (dec) {
-                p = fast_exp(b.k[j] * uz);
-                q = fast_exp(-(b.k[j] * uz));
-            }
-            K.r1r[j] = c;
-            K.r1i[j] = s;
-            K.r2r[j] = c * c - s * s;
-            K.r2i[j] = 2.0 * c * s;
-            K.r1p[j] = p;
-            K.r1q[j] = q;
-            K.r2p[j] = p * p;
-            K.r2q[j] = q * q;
-        }
         K.mux = ux;
         K.muy = uy;
         K.muz = uz;
+        double c[NB], s[NB], pp[NB], qq[NB];
+#pragma unroll
+        for (int j = 0; j < NB; j++) {
+            c[j] = 1.0; s[j] = 0.0; pp[j] = 1.0; qq[j] = 1.0;
+        }
+        if constexpr (CM == 0) {
+#pragma unroll
+            for (int j = 0; j < NB; j++) {
+                if (K.rot) f_rot(j, c[j], s[j]);
+                if (K.dec) f_dec(j, pp[j], qq[j]);
+            }
+        } else {
+            if (K.rot) kin_cached<CM>(K, b, K.ce++, true, c, s, f_rot);
+            if (K.dec) kin_cached<CM>(K, b, K.ce++, true, pp, qq, f_dec);
+        }
+#pragma unroll
+        for (int j = 0; j < NB; j++) {
+            K.r1r[j] = c[j];
+            K.r1i[j] = s[j];
+            K.r1p[j] = pp[j];
+            K.r1q[j] = qq[j];
+#if !RAFTX_UNIT_ROTORS
+            K.r2r[j] = c[j] * c[j] - s[j] * s[j];
+            K.r2i[j] = 2.0 * c[j] * s[j];
+            K.r2p[j] = pp[j] * pp[j];
+            K.r2q[j] = qq[j] * qq[j];
+#endif
+        }
     }
 }
 
@@ -392,6 +496,10 @@ __device__ __forceinline__ void kin_step1(Kin<NB> &K) {
 }
 template <int NB>
 __device__ __forceinline__ void kin_step2(Kin<NB> &K) {
+#if RAFTX_UNIT_ROTORS
+    kin_step1(K);
+    kin_step1(K);
+#else
 #pragma unroll
     for (int j = 0; j < NB; j++) {
         const double t = K.ar[j] * K.r2r[j] - K.ai[j] * K.r2i[j];
@@ -400,15 +508,16 @@ __device__ __forceinline__ void kin_step2(Kin<NB> &K) {
         K.P[j] *= K.r2p[j];
         K.Q[j] *= K.r2q[j];
     }
+#endif
 }
 // advance to the strip described by (fl, rec) -- wave-uniform control flow; rec is either the
 // global device record (scalar loads) or the staged LDS record
-template <int NB, bool KEEPQ, typename RecPtr>
+template <int NB, bool KEEPQ, int CM = 0, typename RecPtr>
 __device__ __forceinline__ void kin_advance(Kin<NB> &K, int fl, RecPtr rec, const Bins<NB> &b,
                                             const double (&amp)[NB], double cb, double sb) {
     const int m = fl & DSI_M;
     if (m == 0) {
-        kin_start<NB, KEEPQ>(K, run_start_of(rec), b, amp, cb, sb);
+        kin_start<NB, KEEPQ, CM>(K, run_start_of(rec), b, amp, cb, sb);
     } else if (m == 1) {
         kin_step1(K);
     } else {
@@ -420,14 +529,27 @@ __device__ __forceinline__ void kin_reset(Kin<NB> &K) {
 #pragma unroll
     for (int j = 0; j < NB; j++) {
         K.ar[j] = 0.0; K.ai[j] = 0.0; K.P[j] = 1.0; K.Q[j] = 0.0;
-        K.r1r[j] = K.r2r[j] = K.r1p[j] = K.r1q[j] = K.r2p[j] = K.r2q[j] = 1.0;
-        K.r1i[j] = K.r2i[j] = 0.0;
+        K.r1r[j] = K.r1p[j] = K.r1q[j] = 1.0;
+        K.r1i[j] = 0.0;
+#if !RAFTX_UNIT_ROTORS
+        K.r2r[j] = K.r2p[j] = K.r2q[j] = 1.0;
+        K.r2i[j] = 0.0;
+#endif
         K.P0[j] = 1.0;
         K.Q0[j] = 0.0;
     }
     K.mz = K.mux = K.muy = K.muz = __builtin_nan("");      // never equal: the first run start computes everything
     K.rot = K.dec = false;
     K.vert = true;
+    K.rc = nullptr;
+    K.ce = K.cn = K.cstride = K.rot_slot = K.dec_slot = 0;
+}
+template <int NB>
+__device__ __forceinline__ void kin_reset(Kin<NB> &K, const RunCache &rc) {
+    kin_reset(K);
+    K.rc = rc.p;
+    K.cn = rc.n;
+    K.cstride = rc.stride;
 }
 
 // ------------------------------------------------------------------ strip sweeps
@@ -458,11 +580,11 @@ __device__ __forceinline__ void kin_reset(Kin<NB> &K) {
 //   f3 = Imat ud + pDyn a_i q,  ud = i w u,  F += [f3 ; a x f3]     (helpers.py:468-483)
 // Imat = Iq qq^T + Ip1 p1p1^T + Ip2 p2p2^T (raft_member.py:1423-1448), or rhoV Cm(w) for
 // MacCamy-Fuchs strips (complex, per bin; raft_member.py:1415-1420).
-template <int NB, bool MCF>
+template <int NB, bool MCF, bool RC = false>
 __device__ __forceinline__ void inertial_excitation(const DevTables &T, cdptr ds,
                                                     ciptr dsi, int S, const cplx *__restrict__ cm,
                                                     const Bins<NB> &b, int ic, int ih, double cb, double sb,
-                                                    cplx (&F)[NB][6]) {
+                                                    cplx (&F)[NB][6], const RunCache rcache = {nullptr, 0, 0}) {
     double one[NB], w[NB], s1[NB], sp[NB], qm[NB];
 #pragma unroll
     for (int j = 0; j < NB; j++) {
@@ -475,7 +597,7 @@ __device__ __forceinline__ void inertial_excitation(const DevTables &T, cdptr ds
         qm[j] = (depth_mode(b.k[j], b.depth) == 1) ? 0.0 : 1.0;                              // deep water: Sh = Ch = e^{kz}
     }
     Kin<NB> K;
-    kin_reset(K);
+    kin_reset(K, rcache);                          // this sweep fills the run-start cache (if any)
     if (S <= 0) return;
     int fn = dsi[0];
 #pragma unroll 1
@@ -495,7 +617,7 @@ __device__ __forceinline__ void inertial_excitation(const DevTables &T, cdptr ds
         }
         const int fl = fn;
         fn = dsi[min(s + 1, S - 1)];
-        kin_advance<NB, true>(K, fl, rec, b, one, cb, sb);
+        kin_advance<NB, true, RC ? 1 : 0>(K, fl, rec, b, one, cb, sb);
 #pragma unroll
         for (int c = 0; c < 3; c++) {
             al[c] = n[c][0] * cb + n[c][1] * sb;
@@ -771,11 +893,11 @@ __device__ __forceinline__ void passA_core(const double (&ar)[NB], const double 
     }
 }
 // one strip of pass A: advances K, returns the three sums over this lane's bins
-template <int NB, typename RecPtr>
+template <int NB, int CM, typename RecPtr>
 __device__ __forceinline__ void passA_strip(Kin<NB> &K, const RecA &r, int fl, RecPtr rec, const Bins<NB> &b,
                                             double cb, double sb, const cplx (&X)[NB][6], double &v0, double &v1,
                                             double &v2) {
-    kin_advance<NB, false>(K, fl, rec, b, b.c1, cb, sb);
+    kin_advance<NB, false, CM>(K, fl, rec, b, b.c1, cb, sb);
     double ps[NB], pd[NB];
 #pragma unroll
     for (int j = 0; j < NB; j++) {
@@ -788,24 +910,82 @@ __device__ __forceinline__ void passA_strip(Kin<NB> &K, const RecA &r, int fl, R
 
 // Run-type-specialised step of the kinematic state (RT: 0 inclined, 1 vertical = no phase rotation, 2 horizontal = no
 // depth decay); m = 1 or 2 unit steps (wave-uniform)
+// The step count m (1 or 2 units) is wave-uniform: a BRANCH between the two rotor sets, not a select per value (the
+// compiler if-converts a plain `m == 1 ? r1 : r2` into 2 v_cndmask per double and computes the stepped state into
+// temporaries that are copied back -- 12 of 45 VALU instructions per strip of the vertical pass-B loop).  The state is
+// updated IN PLACE by tied-operand instructions, so that the two arms leave it in the same registers (a plain C++
+// update gives each arm its own result registers and a copy per value where the arms meet).
+__device__ __forceinline__ void mul_inplace(double &x, double r) { asm("v_mul_f64 %0, %0, %1" : "+v"(x) : "v"(r)); }
+// (ar, ai) <- (ar, ai) * (rr, ri)
+__device__ __forceinline__ void rot_inplace(double &ar, double &ai, double rr, double ri) {
+    const double t1 = ai * ri, t2 = ar * ri;
+    asm("v_fma_f64 %0, %0, %1, -%2" : "+v"(ar) : "v"(rr), "v"(t1));
+    asm("v_fma_f64 %0, %0, %1, %2" : "+v"(ai) : "v"(rr), "v"(t2));
+}
+template <int NB>
+__device__ __forceinline__ void kin_rotate1(Kin<NB> &K) {
+#pragma unroll
+    for (int j = 0; j < NB; j++) rot_inplace(K.ar[j], K.ai[j], K.r1r[j], K.r1i[j]);
+}
+template <int NB>
+__device__ __forceinline__ void kin_decay1(Kin<NB> &K) {
+#pragma unroll
+    for (int j = 0; j < NB; j++) {
+        mul_inplace(K.P[j], K.r1p[j]);
+        mul_inplace(K.Q[j], K.r1q[j]);
+    }
+}
+#if RAFTX_UNIT_ROTORS
+template <int NB>
+__device__ __forceinline__ void kin_rotate2(Kin<NB> &K) {
+    kin_rotate1(K);
+    kin_rotate1(K);
+}
+template <int NB>
+__device__ __forceinline__ void kin_decay2(Kin<NB> &K) {
+    kin_decay1(K);
+    kin_decay1(K);
+}
+// m = 1 or 2 (wave-uniform): the second application sits in a branch; the tied operands keep the state where it is
+template <int NB>
+__device__ __forceinline__ void kin_rotate(Kin<NB> &K, int m) {
+    kin_rotate1(K);
+    if (m == 2) kin_rotate1(K);
+}
+template <int NB>
+__device__ __forceinline__ void kin_decay(Kin<NB> &K, int m) {
+    kin_decay1(K);
+    if (m == 2) kin_decay1(K);
+}
+#else
+template <int NB>
+__device__ __forceinline__ void kin_rotate2(Kin<NB> &K) {
+#pragma unroll
+    for (int j = 0; j < NB; j++) rot_inplace(K.ar[j], K.ai[j], K.r2r[j], K.r2i[j]);
+}
+template <int NB>
+__device__ __forceinline__ void kin_decay2(Kin<NB> &K) {
+#pragma unroll
+    for (int j = 0; j < NB; j++) {
+        mul_inplace(K.P[j], K.r2p[j]);
+        mul_inplace(K.Q[j], K.r2q[j]);
+    }
+}
+template <int NB>
+__device__ __forceinline__ void kin_rotate(Kin<NB> &K, int m) {
+    if (m == 1) kin_rotate1(K);
+    else kin_rotate2(K);
+}
+template <int NB>
+__device__ __forceinline__ void kin_decay(Kin<NB> &K, int m) {
+    if (m == 1) kin_decay1(K);
+    else kin_decay2(K);
+}
+#endif
 template <int NB, int RT>
 __device__ __forceinline__ void kin_step_rt(Kin<NB> &K, int m) {      // RT 3 = RT 2 with an upright cross-section
-    if (RT != 1) {
-#pragma unroll
-        for (int j = 0; j < NB; j++) {
-            const double rr = (m == 1) ? K.r1r[j] : K.r2r[j], ri = (m == 1) ? K.r1i[j] : K.r2i[j];
-            const double t = K.ar[j] * rr - K.ai[j] * ri;
-            K.ai[j] = K.ar[j] * ri + K.ai[j] * rr;
-            K.ar[j] = t;
-        }
-    }
-    if (RT != 2 && RT != 3) {
-#pragma unroll
-        for (int j = 0; j < NB; j++) {
-            K.P[j] *= (m == 1) ? K.r1p[j] : K.r2p[j];
-            K.Q[j] *= (m == 1) ? K.r1q[j] : K.r2q[j];
-        }
-    }
+    if (RT != 1) kin_rotate(K, m);
+    if (RT != 2 && RT != 3) kin_decay(K, m);
 }
 
 // Pass A of one linearisation (raft_member.py:2039-2090, helpers.py:149-184,684): per strip,
@@ -814,17 +994,18 @@ __device__ __forceinline__ void kin_step_rt(Kin<NB> &K, int m) {      // RT 3 = 
 // Cross-lane sums go through
 // this wave's LDS transposition tile (no barrier, no shuffles); per-wave results land in
 // vsq[wave][s][3].
-template <int NB, int STAGE>
+template <int NB, int STAGE, bool RC = false>      // RC: the launch has a run-start cache (Kin), filled by the inertial sweep
 __device__ __forceinline__ void linearize_passA(cdptr ds, ciptr dsi, int S,
                                                 const Lds &l, const Bins<NB> &b, double cb, double sb,
                                                 const cplx (&X)[NB][6] PT_ARG) {
+    constexpr int CM = RC ? 2 : 0;
     const int tid = opaque((int)threadIdx.x);
     const int lane = tid & 63, wv = tid >> 6;
     ldptr tile = l.tile + wv * TR_ROWS * TR_STRIDE;
     ldptr wr = tile + tile_pos(lane);
     ldptr vout = l.vsq + wv * S * 3;
     Kin<NB> K;
-    kin_reset(K);
+    kin_reset(K, run_cache_of(l));
     if (S <= 0) return;
     StripSrc<STAGE> src(l, ds, dsi);
     // Two strips per batch (6 tile rows).  The cross-lane reduction of batch k is software-pipelined into batch
@@ -917,7 +1098,7 @@ __device__ __forceinline__ void linearize_passA(cdptr ds, ciptr dsi, int S,
     };
 #pragma unroll 1
     while (s < S) {
-        kin_start<NB, false>(K, run_start_of(src.rec(s)), b, b.c1, cb, sb);
+        kin_start<NB, false, CM>(K, run_start_of(src.rec(s)), b, b.c1, cb, sb);
         // a run of one strip has a zero step vector and says nothing about the member's axis: general form
         if (K.vert && K.dec && fabs(src_qz(src.rec(s))) == 1.0) run(std::integral_constant<int, 1>{});   // vertical (implies no phase rotation)
         else if (!K.vert && !K.dec) {                                        // horizontal
@@ -940,7 +1121,7 @@ __device__ __forceinline__ void linearize_passA(cdptr ds, ciptr dsi, int S,
             const auto rec = src.rec(s0);
             const RecA r = load_recA(rec);
             const int fl = src.flags(min(s0 + 1, S - 1));
-            passA_strip<NB>(K, r, fl, rec, b, cb, sb, X, va[0], va[1], va[2]);
+            passA_strip<NB, CM>(K, r, fl, rec, b, cb, sb, X, va[0], va[1], va[2]);
         }
         if (prev_s0 >= 0) {
             double a = ((pend[0] + pend[4]) + (pend[1] + pend[5])) + ((pend[2] + pend[6]) + (pend[3] + pend[7]));
@@ -953,7 +1134,7 @@ __device__ __forceinline__ void linearize_passA(cdptr ds, ciptr dsi, int S,
             const auto rec = src.rec(s0 + 1);
             const RecA r = load_recA(rec);
             const int fl = src.flags(min(s0 + 2, S - 1));
-            passA_strip<NB>(K, r, fl, rec, b, cb, sb, X, vb[0], vb[1], vb[2]);
+            passA_strip<NB, CM>(K, r, fl, rec, b, cb, sb, X, vb[0], vb[1], vb[2]);
         }
 #pragma unroll
         for (int c = 0; c < 3; c++) {
@@ -1091,11 +1272,11 @@ __device__ __forceinline__ void passB_core(const Kin<NB> &K, const double (&U)[6
         }
     }
 }
-template <int NB, typename RecPtr>
+template <int NB, int CM, typename RecPtr>
 __device__ __forceinline__ void passB_strip(Kin<NB> &K, int fl, RecPtr rec, const Bins<NB> &b,
                                             double cb, double sb, const double (&U)[6], const double (&V)[6],
                                             cplx (&F)[NB][6]) {
-    kin_advance<NB, false>(K, fl, rec, b, b.c1, cb, sb);
+    kin_advance<NB, false, CM>(K, fl, rec, b, b.c1, cb, sb);
     passB_core<NB>(K, U, V, F);
 }
 __device__ __forceinline__ void load_uv(ldptr uv, double (&U)[6], double (&V)[6]) {
@@ -1105,11 +1286,12 @@ __device__ __forceinline__ void load_uv(ldptr uv, double (&U)[6], double (&V)[6]
         V[q] = uv[6 + q];
     }
 }
-template <int NB, int STAGE>
+template <int NB, int STAGE, bool RC = false>
 __device__ __forceinline__ void drag_excitation(cdptr ds, ciptr dsi, int S, const Lds &l, const Bins<NB> &b, double cb,
                                                 double sb, cplx (&F)[NB][6]) {
+    constexpr int CM = RC ? 2 : 0;
     Kin<NB> K;
-    kin_reset(K);
+    kin_reset(K, run_cache_of(l));
     if (S <= 0) return;
     StripSrc<STAGE> src(l, ds, dsi);
     if constexpr (RUN_LOOPS<NB>) {
@@ -1120,19 +1302,61 @@ __device__ __forceinline__ void drag_excitation(cdptr ds, ciptr dsi, int S, cons
     //  * horizontal run (no depth decay: P, Q are the same for every strip): P+Q, P-Q leave the loop, the step is the
     //    phase rotation alone;
     //  * inclined run: the general form.
+    // Every strip loop has the shape  body(first strip); while (next strip continues the run) { step; body; }  -- the
+    // step feeds the body of the same trip, so the state is advanced in place (with the body ahead of the exit tests the
+    // compiler keeps the stepped state in temporaries beside the live one and copies it back on every trip).
     int s = 0;
     int fl = src.flags(min(1, S - 1));              // flags of strip 0; strip 1's are on their way
+    // The interior of a member steps by two units, its end strips by one: the two-unit steps get a loop of their own, so that
+    // no trip chooses between rotor sets (as selects, or as two arms whose results the compiler then copies together).
+#ifndef RAFTX_SPLIT_MASK
+#define RAFTX_SPLIT_MASK 0      // which pass-B run loops get the separate two-unit loop: 1 vertical, 2 upright pontoon, 4 horizontal, 8 inclined
+#endif
+#define RUN_LOOP(WHICH, STEP1, STEP2, STEPM, PRE)      \
+    do {                                               \
+        body();                                        \
+        int m_ = next_step();                          \
+        if constexpr ((RAFTX_SPLIT_MASK & (WHICH)) != 0) { \
+        _Pragma("unroll 1") while (m_ != 0) {          \
+            if (m_ == 2) {                             \
+                _Pragma("unroll 1") do {               \
+                    PRE;                               \
+                    STEP2;                             \
+                    body();                            \
+                    m_ = next_step();                  \
+                } while (m_ == 2);                     \
+            } else {                                   \
+                PRE;                                   \
+                STEP1;                                 \
+                body();                                \
+                m_ = next_step();                      \
+            }                                          \
+        }                                              \
+        } else {                                       \
+        _Pragma("unroll 1") while (m_ != 0) {          \
+            PRE;                                       \
+            STEPM;                                     \
+            body();                                    \
+            m_ = next_step();                          \
+        }                                              \
+        }                                              \
+    } while (0)
+    // does strip s + 1 continue the run of strip s?  Advances s; returns its step count (0: no, or the table has ended)
+    auto next_step = [&]() -> int {
+        if (++s >= S) return 0;
+        fl = src.flags(min(s + 1, S - 1));          // flags of the new strip s
+        return fl & DSI_M;
+    };
 #pragma unroll 1
     while (s < S) {
-        kin_start<NB, false>(K, run_start_of(src.rec(s)), b, b.c1, cb, sb);
+        kin_start<NB, false, CM>(K, run_start_of(src.rec(s)), b, b.c1, cb, sb);
         if (!K.rot) {
             double G1[NB][6], G2[NB][6];
 #pragma unroll
             for (int j = 0; j < NB; j++)
 #pragma unroll
                 for (int q = 0; q < 6; q++) G1[j][q] = G2[j][q] = 0.0;
-#pragma unroll 1
-            while (true) {
+            auto body = [&]() {
                 double U[6], V[6];
                 load_uv(l.uv + s * 12, U, V);
 #pragma unroll
@@ -1144,16 +1368,8 @@ __device__ __forceinline__ void drag_excitation(cdptr ds, ciptr dsi, int S, cons
                         G2[j][q] = fma(pd, V[q], G2[j][q]);
                     }
                 }
-                if (++s >= S) break;
-                fl = src.flags(min(s + 1, S - 1));  // flags of the new strip s
-                const int m = fl & DSI_M;
-                if (m == 0) break;                  // it starts the next run
-#pragma unroll
-                for (int j = 0; j < NB; j++) {
-                    K.P[j] *= (m == 1) ? K.r1p[j] : K.r2p[j];
-                    K.Q[j] *= (m == 1) ? K.r1q[j] : K.r2q[j];
-                }
-            }
+            };
+            RUN_LOOP(1, kin_decay1(K), kin_decay2(K), kin_decay(K, m_), );
 #pragma unroll
             for (int j = 0; j < NB; j++)
 #pragma unroll
@@ -1179,10 +1395,7 @@ __device__ __forceinline__ void drag_excitation(cdptr ds, ciptr dsi, int S, cons
                 Sq[j][0] = Sq[j][1] = S2[j][0] = S2[j][1] = S26[j][0] = S26[j][1] = 0.0;
                 S1[j][0] = S1[j][1] = S1y[j][0] = S1y[j][1] = S1x[j][0] = S1x[j][1] = 0.0;
             }
-            const int s_start = s;
-#pragma unroll 1
-            while (true) {
-                if (s != s_start) load_arm(src.rec(s), r);
+            auto body = [&]() {
                 ldptr bc = l.vsq + s * 3;
                 const double bq = bc[0] * alq, b1 = bc[1], b2 = bc[2] * al2;
                 const double b2w = b2 * (r.p2y * r.ax - r.p2x * r.ay), b1y = b1 * r.ay, b1x = b1 * r.ax;
@@ -1196,18 +1409,8 @@ __device__ __forceinline__ void drag_excitation(cdptr ds, ciptr dsi, int S, cons
                     S1y[j][0] = fma(b1y, t2r, S1y[j][0]); S1y[j][1] = fma(b1y, t2i, S1y[j][1]);
                     S1x[j][0] = fma(b1x, t2r, S1x[j][0]); S1x[j][1] = fma(b1x, t2i, S1x[j][1]);
                 }
-                if (++s >= S) break;
-                fl = src.flags(min(s + 1, S - 1));
-                const int m = fl & DSI_M;
-                if (m == 0) break;
-#pragma unroll
-                for (int j = 0; j < NB; j++) {
-                    const double rr = (m == 1) ? K.r1r[j] : K.r2r[j], ri = (m == 1) ? K.r1i[j] : K.r2i[j];
-                    const double t = K.ar[j] * rr - K.ai[j] * ri;
-                    K.ai[j] = K.ar[j] * ri + K.ai[j] * rr;
-                    K.ar[j] = t;
-                }
-            }
+            };
+            RUN_LOOP(2, kin_rotate1(K), kin_rotate2(K), kin_rotate(K, m_), load_arm(src.rec(s), r));
             const double c3q = -az * r.qy, c3p = -az * r.p2y, c4q = az * r.qx, c4p = az * r.p2x;
 #pragma unroll
             for (int j = 0; j < NB; j++) {
@@ -1231,8 +1434,7 @@ __device__ __forceinline__ void drag_excitation(cdptr ds, ciptr dsi, int S, cons
                 ps[j] = K.P[j] + K.Q[j];
                 pd[j] = K.P[j] - K.Q[j];
             }
-#pragma unroll 1
-            while (true) {
+            auto body = [&]() {
                 double U[6], V[6];
                 load_uv(l.uv + s * 12, U, V);
 #pragma unroll
@@ -1244,31 +1446,15 @@ __device__ __forceinline__ void drag_excitation(cdptr ds, ciptr dsi, int S, cons
                         F[j][q].im = fma(t1i, U[q], fma(t2i, V[q], F[j][q].im));
                     }
                 }
-                if (++s >= S) break;
-                fl = src.flags(min(s + 1, S - 1));
-                const int m = fl & DSI_M;
-                if (m == 0) break;
-#pragma unroll
-                for (int j = 0; j < NB; j++) {
-                    const double rr = (m == 1) ? K.r1r[j] : K.r2r[j], ri = (m == 1) ? K.r1i[j] : K.r2i[j];
-                    const double t = K.ar[j] * rr - K.ai[j] * ri;
-                    K.ai[j] = K.ar[j] * ri + K.ai[j] * rr;
-                    K.ar[j] = t;
-                }
-            }
+            };
+            RUN_LOOP(4, kin_rotate1(K), kin_rotate2(K), kin_rotate(K, m_), );
         } else {
-#pragma unroll 1
-            while (true) {
+            auto body = [&]() {
                 double U[6], V[6];
                 load_uv(l.uv + s * 12, U, V);
                 passB_core<NB>(K, U, V, F);
-                if (++s >= S) break;
-                fl = src.flags(min(s + 1, S - 1));
-                const int m = fl & DSI_M;
-                if (m == 0) break;
-                if (m == 1) kin_step1(K);
-                else kin_step2(K);
-            }
+            };
+            RUN_LOOP(8, (kin_rotate1(K), kin_decay1(K)), (kin_rotate2(K), kin_decay2(K)), (kin_rotate(K, m_), kin_decay(K, m_)), );
         }
     }
     } else {
@@ -1277,7 +1463,7 @@ __device__ __forceinline__ void drag_excitation(cdptr ds, ciptr dsi, int S, cons
         double U[6], V[6];
         load_uv(l.uv + s * 12, U, V);               // issued before the (branchy) kinematics update
         const int fl = src.flags(min(s + 1, S - 1));
-        passB_strip<NB>(K, fl, src.rec(s), b, cb, sb, U, V, F);
+        passB_strip<NB, CM>(K, fl, src.rec(s), b, cb, sb, U, V, F);
     }
     }
 }
@@ -1289,7 +1475,7 @@ __device__ __forceinline__ void drag_excitation(cdptr ds, ciptr dsi, int S, cons
 // U', V' are built once per strip by one lane each (into the uv rows, free before the first linearisation); the bin
 // sweep then costs 36 FMAs per strip and bin instead of the ~60 of the direct form.  MacCamy-Fuchs strips (complex
 // per-bin Cm) cannot be factored this way: kernels with KF_MCF keep inertial_excitation<.., true>.
-template <int NB>
+template <int NB, bool RC = false>
 __device__ __forceinline__ void inertial_excitation_uv(const DevTables &T, cdptr ds, ciptr dsi, int S, const Lds &l,
                                                        const Bins<NB> &b, int ic, int ih, double cb, double sb,
                                                        cplx (&F)[NB][6], bool multi) {
@@ -1335,7 +1521,7 @@ __device__ __forceinline__ void inertial_excitation_uv(const DevTables &T, cdptr
 #pragma unroll
     for (int j = 0; j < NB; j++) one[j] = 1.0;
     Kin<NB> K;
-    kin_reset(K);
+    kin_reset(K, run_cache_of(l));                 // this sweep fills the run-start cache
     if (S > 0) {
         int fn = dsi[0];
 #pragma unroll 1
@@ -1348,7 +1534,7 @@ __device__ __forceinline__ void inertial_excitation_uv(const DevTables &T, cdptr
             const double ai_ = rec[DS_IQ + 3];
             const int fl = fn;
             fn = dsi[min(s + 1, S - 1)];
-            kin_advance<NB, true>(K, fl, rec, b, one, cb, sb);
+            kin_advance<NB, true, RC ? 1 : 0>(K, fl, rec, b, one, cb, sb);
             double Aq[6];
             Aq[0] = ai_ * qx;
             Aq[1] = ai_ * qy;
@@ -1679,6 +1865,7 @@ struct SolveArgs {
     unsigned long long *dbg;             // RAFTX_PHASE_TIMING builds: [8] accumulated wave-0 cycles per phase
     const int *__restrict__ pairs;       // [npairs] the pairs of this launch, or null: all pairs 0 .. nDesign * nCase - 1
     int npairs;                          // (batches with very unequal strip counts are launched per LDS class)
+    int rc_n;                            // slots of the LDS run-start cache (0: none)
 };
 
 // The fused fixed point (raft_model.py:1052-1142) + per-heading response (:1189-1236).
@@ -1706,9 +1893,10 @@ __global__ void __launch_bounds__(MAXT, MINB) k_solve_dynamics(DevTables T, Solv
     const int pair = p.pair, S = p.S;
     const cplx *cm = (MCF && T.cm) ? p.cm : nullptr;
     constexpr int STAGE = stage_policy(NB, MAXT);
-    constexpr bool XLG = (MAXT == 512 && NB >= 3);
+    constexpr bool XLG = xl_global(NB, MAXT);
     constexpr int PARK = park_policy(NB, MAXT);
-    Lds l = carve(smem, S, XLG ? 0 : nw, blockDim.x >> 6, STAGE, PARK);
+    constexpr bool RC = PARK != 0 && XLG;            // the shape whose spare LDS is a run-start cache (A.rc_n slots)
+    Lds l = carve(smem, S, XLG ? 0 : nw, blockDim.x >> 6, STAGE, PARK, A.rc_n, nw);
     if (STAGE) stage_recA(p.ds, p.dsi, S, l, STAGE);
     XlStore<XLG> xl;
     if constexpr (XLG) {
@@ -1743,9 +1931,9 @@ __global__ void __launch_bounds__(MAXT, MINB) k_solve_dynamics(DevTables T, Solv
             }
         }
         if constexpr (MCF)
-            inertial_excitation<NB, true>(T, p.ds, p.dsi, S, cm, b, p.ic, 0, cb0, sb0, Flin);
+            inertial_excitation<NB, true, RC>(T, p.ds, p.dsi, S, cm, b, p.ic, 0, cb0, sb0, Flin, run_cache_of(l));
         else
-            inertial_excitation_uv<NB>(T, p.ds, p.dsi, S, l, b, p.ic, 0, cb0, sb0, Flin, multi);
+            inertial_excitation_uv<NB, RC>(T, p.ds, p.dsi, S, l, b, p.ic, 0, cb0, sb0, Flin, multi);
         store6(xio, nw, b, Flin);
     }
     // XiLast <- XiStart (:999), kept as xl[2q][bin] = re, xl[2q+1][bin] = im
@@ -1769,13 +1957,31 @@ __global__ void __launch_bounds__(MAXT, MINB) k_solve_dynamics(DevTables T, Solv
     PT_MARK(0);   // set-up + inertial excitation
 
     int iiter = 0, done = 0, converged = 0, nan = 0;
+    // DEFER (the parked two-bin shape with XiLast in its global slab): convergence test and relaxation of BOTH bins
+    // follow the second solve -- one round trip to the slab per iteration, its 24 loads in flight together while
+    // the registers of the 6x6 systems are dead -- and w * XiLast of the next linearisation stays in registers (Xc)
+    // instead of being fetched again at the top of the loop.
+    constexpr bool DEFER = PARK != 0 && XLG;
+    cplx Xc[DEFER ? NB : 1][6];
+    if constexpr (DEFER) {
+#pragma unroll
+        for (int j = 0; j < NB; j++)
+#pragma unroll
+            for (int q = 0; q < 6; q++) {
+                const double vr = xl.get(2 * q, b.iw[j]), vi = xl.get(2 * q + 1, b.iw[j]);      // what this lane just stored
+                Xc[j][q].re = b.act[j] ? b.w[j] * vr : 0.0;
+                Xc[j][q].im = b.act[j] ? b.w[j] * vi : 0.0;
+            }
+    }
 #pragma unroll 1
     while (true) {
         // The per-bin constants are re-read (L1/L2 hits) at the top of every iteration from an
         // opaque thread id, so that they do not stay live -- and get spilled -- across the solve.
         load_bins(T, b, opaque((int)threadIdx.x));
         set_heading_amp(T, b, p.ic, 0);
-        {
+        if constexpr (DEFER) {
+            linearize_passA<NB, STAGE, RC>(p.ds, p.dsi, S, l, b, cb0, sb0, Xc PT_PASS);         // :1063
+        } else {
             cplx X[NB][6];
 #pragma unroll
             for (int j = 0; j < NB; j++) {
@@ -1789,7 +1995,7 @@ __global__ void __launch_bounds__(MAXT, MINB) k_solve_dynamics(DevTables T, Solv
                 }
             }
             PT_MARK(7);   // XiLast fetch
-            linearize_passA<NB, STAGE>(p.ds, p.dsi, S, l, b, cb0, sb0, X PT_PASS);          // :1063
+            linearize_passA<NB, STAGE, RC>(p.ds, p.dsi, S, l, b, cb0, sb0, X PT_PASS);      // :1063
         }
         wg_sync(multi);
         PT_MARK(1);   // pass A
@@ -1802,7 +2008,7 @@ __global__ void __launch_bounds__(MAXT, MINB) k_solve_dynamics(DevTables T, Solv
 #pragma unroll
             for (int q = 0; q < 6; q++) x[j][q] = xio[(size_t)q * nw + iw];   // F_lin (clamped bin when inactive)
         }
-        drag_excitation<NB, STAGE>(p.ds, p.dsi, S, l, b, cb0, sb0, x);               // + F_drag (:1064,:1081)
+        drag_excitation<NB, STAGE, RC>(p.ds, p.dsi, S, l, b, cb0, sb0, x);           // + F_drag (:1064,:1081)
         PT_MARK(3);   // pass B
         int bad = 0, ok = 1;
         const bool last_chance = iiter + 1 >= A.nIter;
@@ -1822,6 +2028,7 @@ __global__ void __launch_bounds__(MAXT, MINB) k_solve_dynamics(DevTables T, Solv
                 }
             }
             assemble_and_solve<FLAGS>(l, Mw, Bw, nw, iw, w, xx, Zout, act);
+            if constexpr (DEFER) return;
             if (act) {
 #pragma unroll
                 for (int q = 0; q < 6; q++) {
@@ -1859,6 +2066,46 @@ __global__ void __launch_bounds__(MAXT, MINB) k_solve_dynamics(DevTables T, Solv
                 park2[(2 * q + 1) * nt] = x[0][q].im;
             }
             solve_bin(1, r1);
+            if constexpr (DEFER) {
+                // NaN check (:1098), convergence (:1103-1104) and relaxation (:1133) of both bins; bin 0's solution comes
+                // back from its parking column
+                ldptr pk = l.park + opaque(tid_s);
+                double lr[NB][6], li[NB][6];
+                int iwj[NB];
+                bool actj[NB];
+#pragma unroll
+                for (int j = 0; j < NB; j++) {
+                    const int ib = j * nt + tid_s;
+                    actj[j] = ib < nw;
+                    iwj[j] = actj[j] ? ib : 0;
+#pragma unroll
+                    for (int q = 0; q < 6; q++) {
+                        lr[j][q] = xl.get(2 * q, iwj[j]);
+                        li[j][q] = xl.get(2 * q + 1, iwj[j]);
+                    }
+                }
+#pragma unroll
+                for (int j = 0; j < NB; j++) {
+                    const double wl = T.w[iwj[j]];
+#pragma unroll
+                    for (int q = 0; q < 6; q++) {
+                        const cplx xx = j == 0 ? cplx{pk[(2 * q) * nt], pk[(2 * q + 1) * nt]} : r1[q];
+                        if constexpr (XLIO) {
+                            if (actj[j] && A.XlOut) A.XlOut[((size_t)pair * 6 + q) * nw + iwj[j]] = cplx{lr[j][q], li[j][q]};
+                        }
+                        if (actj[j] && (isnan(xx.re) || isnan(xx.im))) bad = 1;
+                        const double dr = xx.re - lr[j][q], di = xx.im - li[j][q];
+                        if (actj[j] && !conv_test(dr, di, xx.re, xx.im, A.tol)) ok = 0;
+                        const double nr = 0.2 * lr[j][q] + 0.8 * xx.re, ni = 0.2 * li[j][q] + 0.8 * xx.im;
+                        if (actj[j]) {
+                            xl.put(2 * q, iwj[j], nr);
+                            xl.put(2 * q + 1, iwj[j], ni);
+                        }
+                        Xc[j][q].re = actj[j] ? wl * nr : 0.0;
+                        Xc[j][q].im = actj[j] ? wl * ni : 0.0;
+                    }
+                }
+            }
             PT_MARK(4);   // assemble + solve + convergence
             done = iiter + 1;
             nan = wg_or(bad, multi);
@@ -1921,8 +2168,8 @@ __global__ void __launch_bounds__(MAXT, MINB) k_solve_dynamics(DevTables T, Solv
                             x[j][q] = A.F_extra[(((size_t)pair * nHs + ih) * 6 + q) * nw + b.iw[j]];
                 }
             }
-            inertial_excitation<NB, MCF>(T, p.ds, p.dsi, S, cm, b, p.ic, ih, cb, sb, x);
-            drag_excitation<NB, STAGE>(p.ds, p.dsi, S, l, b, cb, sb, x);               // :1209,:1212
+            inertial_excitation<NB, MCF, RC>(T, p.ds, p.dsi, S, cm, b, p.ic, ih, cb, sb, x, run_cache_of(l));   // refills the cache for this heading
+            drag_excitation<NB, STAGE, RC>(p.ds, p.dsi, S, l, b, cb, sb, x);           // :1209,:1212
             cplx *xo = A.Xi + ((size_t)pair * nHs + ih) * 6 * nw;
 #pragma unroll
             for (int j = 0; j < NB; j++) {
