@@ -468,6 +468,8 @@ double raftx_last_kernel_ms(raftx_ctx *ctx);
 /* Diagnostics: evaluates the device's own fp64 sincos/exp on n host values (the
  * oracle answers with libm), so the elementary functions are testable alone. */
 int raftx_debug_math(raftx_ctx *ctx, int n, const double *x, double *sin_out, double *cos_out, double *exp_out);
+/* The same with the table-driven sincos the fused fixed point uses at its run starts (64-entry table in LDS). */
+int raftx_debug_math_table(raftx_ctx *ctx, int n, const double *x, double *sin_out, double *cos_out, double *exp_out);
 
 #ifdef __cplusplus
 }

@@ -1522,18 +1522,19 @@ static int solve_enqueue(raftx_ctx *c, int nIter, double tol, double XiStart, co
     // the run-start cache (raftx_kernels.h Kin): as many 16-byte-per-bin slots as fit without costing a resident pair.
     const int wg_per_cu = std::max(1, shape_minb(sh) * 4 / (sh.threads / 64));
     auto rc_slots = [&](int S_) {
-        if (!(shape_maxt(sh) == 128 && sh.nb == 2)) return 0;
+        if (!(shape_maxt(sh) == 128 && sh.nb == 2)) return 0;                // (= rc_shape below)
         static const char *env = getenv("RAFTX_RC_SLOTS");                 // tuning: cap (0 = no cache)
         const int cap = env ? atoi(env) : 24;
         const size_t base = lds_bytes(S_, xlg ? 0 : T.nw, sh.threads / 64, stage_policy(sh.nb, shape_maxt(sh)),
-                                      park_policy(sh.nb, shape_maxt(sh)));
+                                      park_policy(sh.nb, shape_maxt(sh)), 0, T.nw);
         const size_t budget = LDS_LIMIT / (size_t)wg_per_cu;
         if (budget <= base) return 0;
         return (int)std::min<size_t>((size_t)cap, (budget - base) / (16 * (size_t)xl_row(T.nw)));
     };
+    const bool rc_shape = shape_maxt(sh) == 128 && sh.nb == 2;          // RC of k_solve_dynamics
     A.rc_n = rc_slots(c->maxS);
     const size_t lds = lds_bytes(c->maxS, xlg ? 0 : T.nw, sh.threads / 64, stage_policy(sh.nb, shape_maxt(sh)),
-                                 park_policy(sh.nb, shape_maxt(sh)), A.rc_n, T.nw);
+                                 park_policy(sh.nb, shape_maxt(sh)), A.rc_n, rc_shape ? T.nw : 0);
     if (xlg && (!c->rXl || c->rXl_n < c->r_npair * 12 * (size_t)T.nw)) {
         HIPCHK(c, hipStreamSynchronize(c->stream));
         if (c->rXl) (void)hipFree(c->rXl);
@@ -1575,7 +1576,8 @@ static int solve_enqueue(raftx_ctx *c, int nIter, double tol, double XiStart, co
     std::vector<int> clsS;
     {
         auto lds_of = [&](int S_) {
-            return lds_bytes(S_, xlg ? 0 : T.nw, sh.threads / 64, stage_policy(sh.nb, shape_maxt(sh)), park_policy(sh.nb, shape_maxt(sh)));
+            return lds_bytes(S_, xlg ? 0 : T.nw, sh.threads / 64, stage_policy(sh.nb, shape_maxt(sh)), park_policy(sh.nb, shape_maxt(sh)),
+                             0, rc_shape ? T.nw : 0);
         };
         auto fit = [&](int S_) { return std::min(wg_per_cu, (int)(LDS_LIMIT / lds_of(S_))); };   // pairs a CU holds
         const int kmax = fit(0);
@@ -1627,7 +1629,7 @@ static int solve_enqueue(raftx_ctx *c, int nIter, double tol, double XiStart, co
             at_ += n_;                                                                                               \
             A.rc_n = rc_slots(clsS[(size_t)kk]);                                                                     \
             const size_t l_ = lds_bytes(clsS[(size_t)kk], xlg ? 0 : T.nw, sh.threads / 64, stage_policy(sh.nb, shape_maxt(sh)), \
-                                        park_policy(sh.nb, shape_maxt(sh)), A.rc_n, T.nw);                           \
+                                        park_policy(sh.nb, shape_maxt(sh)), A.rc_n, rc_shape ? T.nw : 0);            \
             hipLaunchKernelGGL((k_solve_dynamics<NB_, FL, MT_, MB_>), dim3(grid_for_pairs(n_)), dim3(sh.threads),    \
                                l_, c->stream, T, A);                                                                 \
         }                                                                                                            \
@@ -2682,15 +2684,26 @@ extern "C" int raftx_debug_phase_cycles(raftx_ctx *c, unsigned long long *out8) 
 #endif
 
 __global__ void k_debug_math(int n, const double *__restrict__ x, double *__restrict__ s, double *__restrict__ c,
-                             double *__restrict__ e) {
+                             double *__restrict__ e, int table) {
+    __shared__ __attribute__((aligned(16))) double tab[2 * RAFTX_SC_N];
+    stage_sincos_table((ldptr)tab);
+    __syncthreads();
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) {
-        fast_sincos(x[i], s[i], c[i]);
+        if (table) tab_sincos(x[i], (ldptr)tab, s[i], c[i]);
+        else fast_sincos(x[i], s[i], c[i]);
         e[i] = fast_exp(x[i]);
     }
 }
 
+static int debug_math(raftx_ctx *c, int n, const double *x, double *sin_out, double *cos_out, double *exp_out, int table);
 extern "C" int raftx_debug_math(raftx_ctx *c, int n, const double *x, double *sin_out, double *cos_out, double *exp_out) {
+    return debug_math(c, n, x, sin_out, cos_out, exp_out, 0);
+}
+extern "C" int raftx_debug_math_table(raftx_ctx *c, int n, const double *x, double *sin_out, double *cos_out, double *exp_out) {
+    return debug_math(c, n, x, sin_out, cos_out, exp_out, 1);
+}
+static int debug_math(raftx_ctx *c, int n, const double *x, double *sin_out, double *cos_out, double *exp_out, int table) {
     if (!c || n < 0 || !x || !sin_out || !cos_out || !exp_out) return -1;
     HIPCHK(c, hipSetDevice(c->device));
     Scratch sc(c);
@@ -2698,7 +2711,7 @@ extern "C" int raftx_debug_math(raftx_ctx *c, int n, const double *x, double *si
     if (n && (!dx || !ds || !dc || !de)) FAIL(c, "debug_math: device allocation failed");
     if (n) {
         H2D(c, dx, x, n * sizeof(double));
-        hipLaunchKernelGGL(k_debug_math, dim3((n + 255) / 256), dim3(256), 0, c->stream, n, dx, ds, dc, de);
+        hipLaunchKernelGGL(k_debug_math, dim3((n + 255) / 256), dim3(256), 0, c->stream, n, dx, ds, dc, de, table);
         D2H(c, sin_out, ds, n * sizeof(double));
         D2H(c, cos_out, dc, n * sizeof(double));
         D2H(c, exp_out, de, n * sizeof(double));

@@ -20,6 +20,7 @@
 // Runs are detected by the library at upload from the absolute strip positions.
 #pragma once
 #include <type_traits>
+#include "raftx_tables.h"
 
 #define NF RAFTX_NFIELD
 
@@ -79,6 +80,34 @@ __device__ __forceinline__ void fast_sincos(double x, double &s, double &c) {
     double cc = (n & 1) ? sr : cr;
     s = (n & 2) ? -ss : ss;
     c = ((n + 1) & 2) ? -cc : cc;
+}
+
+// Table-driven variant for the kernels that have LDS to spare (the fused fixed point at the two-waves-per-SIMD shape):
+// x = n pi/32 + r, |r| <= pi/64, (cos, sin)(n pi/32) from a 64-entry table of correctly rounded values (raftx_tables.h,
+// staged in LDS), short polynomials for sin r and cos r - 1 (truncation < 2^-56), angle addition with the table value
+// as the addend.  23 VALU instructions instead of 45; same accuracy (tests/test_hip_parity.py).
+__device__ __forceinline__ void tab_sincos(double x, ldptr tab, double &s, double &c) {
+    const double fn = rint(x * RAFTX_32OPI);
+    double r = fma(-fn, RAFTX_PIO32_1, x);
+    r = fma(-fn, RAFTX_PIO32_2, r);
+    r = fma(-fn, RAFTX_PIO32_3, r);
+    const int n = (int)fn;
+    ldptr e = tab + ((n & (RAFTX_SC_N - 1)) << 1);
+    const double c0 = e[0], s0 = e[1];
+    const double z = r * r;
+    double ps = fma(z, 1.0 / 362880.0, -1.0 / 5040.0);
+    ps = fma(ps, z, 1.0 / 120.0);
+    ps = fma(ps, z, -1.0 / 6.0);
+    const double sr = fma(r * z, ps, r);                 // sin r
+    double pc = fma(z, 1.0 / 40320.0, -1.0 / 720.0);
+    pc = fma(pc, z, 1.0 / 24.0);
+    pc = fma(pc, z, -0.5);
+    const double cm = pc * z;                            // cos r - 1
+    c = fma(c0, cm, fma(-s0, sr, c0));
+    s = fma(s0, cm, fma(c0, sr, s0));
+}
+__device__ __forceinline__ void stage_sincos_table(ldptr tab) {
+    for (int i = threadIdx.x; i < 2 * RAFTX_SC_N; i += blockDim.x) tab[i] = RAFTX_SC_TAB[i];
 }
 
 __device__ __forceinline__ double fast_exp(double x) {
@@ -166,6 +195,7 @@ constexpr bool RUN_LOOPS = RAFTX_RUN_LOOPS && NB <= 2;
 // + 1.5 K  ~= 37 K  ->  four pairs per CU (160 KiB).  The one-wave-per-SIMD shapes additionally
 // stage the hot strip constants (ra, +7.6 K).
 struct Lds {
+    ldptr sct;     // [RAFTX_SC_N][2] (cos, sin) table of tab_sincos (shapes with a run-start cache)
     ldptr rc;      // [rc_n][nw_rc][2] run-start cache: rc_n slots of two doubles per bin (see Kin), rc_stride doubles apart
     int rc_n, rc_stride;
     ldptr xl;      // [12][nxl]    XiLast (re/im rows), nxl = nw rounded up to even
@@ -191,7 +221,9 @@ __device__ __forceinline__ Lds carve(double *base_, int S, int nw_xl, int nwv, i
                                      int nw_rc = 0) {
     Lds l;
     ldptr base = (ldptr)base_;
-    l.rc = base;                                  // first: 16-byte aligned slots (ds_read_b128 / ds_write_b128)
+    l.sct = base;                                 // first: 16-byte aligned entries (ds_read_b128 / ds_write_b128)
+    if (nw_rc) base += 2 * RAFTX_SC_N;
+    l.rc = base;
     l.rc_n = rc_n;
     l.rc_stride = 2 * xl_row(nw_rc);
     base += (size_t)rc_n * l.rc_stride;
@@ -212,7 +244,7 @@ __device__ __forceinline__ Lds carve(double *base_, int S, int nw_xl, int nwv, i
 static size_t lds_bytes(int S, int nw, int nwv, int stage_n, int park_n = 0, int rc_n = 0, int nw_rc = 0) {
     size_t span = (size_t)S * (12 + 3 * nwv) + (size_t)nwv * TR_ROWS * TR_STRIDE;          // vsq | uv | tile
     if (park_n && span < (size_t)S * 3 + (size_t)park_n) span = (size_t)S * 3 + (size_t)park_n;
-    return sizeof(double) * ((size_t)rc_n * 2 * xl_row(nw_rc) + (size_t)12 * xl_row(nw) + (size_t)S * stage_n + span +
+    return sizeof(double) * ((size_t)(nw_rc ? 2 * RAFTX_SC_N : 0) + (size_t)rc_n * 2 * xl_row(nw_rc) + (size_t)12 * xl_row(nw) + (size_t)S * stage_n + span +
                              (size_t)nwv * 24 + 36 + 108 + 2) +
            sizeof(int) * (size_t)(stage_n == RA_N ? S + 2 : 2);
 }
@@ -334,15 +366,15 @@ struct Kin {
     // run-start cache cursor: every sweep of a pair meets the same run starts in the same order with the same memo
     // hits, so the n-th transcendental evaluation of a sweep is the same quantity in every sweep -- the first sweep
     // (the inertial excitation) stores the first cn of them per bin in LDS, the later sweeps read them back
-    ldptr rc;
-    int ce, cn, cstride, rot_slot, dec_slot;
+    ldptr rc, sct;
+    int ce, cn, cstride;
 };
 struct RunCache {
     ldptr p;
     int n, stride;
+    ldptr sct;
 };
-__device__ __forceinline__ RunCache run_cache_of(const Lds &l) { return {l.rc, l.rc_n, l.rc_stride}; }
-__device__ __forceinline__ RunCache no_run_cache() { return {nullptr, 0, 0}; }
+__device__ __forceinline__ RunCache run_cache_of(const Lds &l) { return {l.rc, l.rc_n, l.rc_stride, l.sct}; }
 
 // Run start: exact evaluation from the absolute position (helpers.py:201,211-222).
 //   amp[j] multiplies the phase factor (c1 for the velocity sweeps, 1 for the pressure sweep).
@@ -396,7 +428,10 @@ __device__ __forceinline__ void kin_start(Kin<NB> &K, const RunStart rs, const B
     const double du = cb * ux + sb * uy;
     const bool same_z = (z == K.mz);                      // wave-uniform
     const bool same_u = (ux == K.mux) && (uy == K.muy) && (uz == K.muz);
-    auto f_phasor = [&](int j, double &c_, double &s_) { fast_sincos(-(b.k[j] * xi), s_, c_); };
+    auto f_phasor = [&](int j, double &c_, double &s_) {
+        if constexpr (CM != 0) tab_sincos(-(b.k[j] * xi), K.sct, s_, c_);
+        else fast_sincos(-(b.k[j] * xi), s_, c_);
+    };
     auto f_pq = [&](int j, double &P_, double &Q_) {
         const double kz = b.k[j] * z;
         const double Pe = fast_exp(kz);
@@ -406,7 +441,10 @@ __device__ __forceinline__ void kin_start(Kin<NB> &K, const RunStart rs, const B
         P_ = k0 ? 50000.0 : Pe;
         Q_ = k0 ? 49999.0 : Qe;
     };
-    auto f_rot = [&](int j, double &c_, double &s_) { fast_sincos(-(b.k[j] * du), s_, c_); };
+    auto f_rot = [&](int j, double &c_, double &s_) {
+        if constexpr (CM != 0) tab_sincos(-(b.k[j] * du), K.sct, s_, c_);
+        else fast_sincos(-(b.k[j] * du), s_, c_);
+    };
     auto f_dec = [&](int j, double &p_, double &q_) {
         p_ = fast_exp(b.k[j] * uz);
         q_ = fast_exp(-(b.k[j] * uz));
@@ -542,7 +580,8 @@ __device__ __forceinline__ void kin_reset(Kin<NB> &K) {
     K.rot = K.dec = false;
     K.vert = true;
     K.rc = nullptr;
-    K.ce = K.cn = K.cstride = K.rot_slot = K.dec_slot = 0;
+    K.sct = nullptr;
+    K.ce = K.cn = K.cstride = 0;
 }
 template <int NB>
 __device__ __forceinline__ void kin_reset(Kin<NB> &K, const RunCache &rc) {
@@ -550,6 +589,7 @@ __device__ __forceinline__ void kin_reset(Kin<NB> &K, const RunCache &rc) {
     K.rc = rc.p;
     K.cn = rc.n;
     K.cstride = rc.stride;
+    K.sct = rc.sct;
 }
 
 // ------------------------------------------------------------------ strip sweeps
@@ -584,7 +624,7 @@ template <int NB, bool MCF, bool RC = false>
 __device__ __forceinline__ void inertial_excitation(const DevTables &T, cdptr ds,
                                                     ciptr dsi, int S, const cplx *__restrict__ cm,
                                                     const Bins<NB> &b, int ic, int ih, double cb, double sb,
-                                                    cplx (&F)[NB][6], const RunCache rcache = {nullptr, 0, 0}) {
+                                                    cplx (&F)[NB][6], const RunCache rcache = {nullptr, 0, 0, nullptr}) {
     double one[NB], w[NB], s1[NB], sp[NB], qm[NB];
 #pragma unroll
     for (int j = 0; j < NB; j++) {
@@ -1896,8 +1936,9 @@ __global__ void __launch_bounds__(MAXT, MINB) k_solve_dynamics(DevTables T, Solv
     constexpr bool XLG = xl_global(NB, MAXT);
     constexpr int PARK = park_policy(NB, MAXT);
     constexpr bool RC = PARK != 0 && XLG;            // the shape whose spare LDS is a run-start cache (A.rc_n slots)
-    Lds l = carve(smem, S, XLG ? 0 : nw, blockDim.x >> 6, STAGE, PARK, A.rc_n, nw);
+    Lds l = carve(smem, S, XLG ? 0 : nw, blockDim.x >> 6, STAGE, PARK, RC ? A.rc_n : 0, RC ? nw : 0);
     if (STAGE) stage_recA(p.ds, p.dsi, S, l, STAGE);
+    if constexpr (RC) stage_sincos_table(l.sct);
     XlStore<XLG> xl;
     if constexpr (XLG) {
         xl.p = A.Xl + (size_t)pair * 12 * nw;

@@ -392,9 +392,10 @@ def test_device_sincos_exp_accuracy(hip_ctx):
     rng = np.random.default_rng(0)
     x = np.concatenate([rng.uniform(-50, 50, 20000), rng.uniform(-5000, 5000, 20000),
                         np.linspace(-1e-3, 1e-3, 101), [0.0, np.pi / 4, -np.pi / 4, np.pi / 2, 1e5, -1e5]])
-    s, c, _ = hip_ctx.debug_math(x)
-    assert np.max(np.abs(s - np.sin(x))) < 4e-16
-    assert np.max(np.abs(c - np.cos(x))) < 4e-16
+    for table in (False, True):          # straight-line polynomials; the table-driven form of the fused kernel's run starts
+        s, c, _ = hip_ctx.debug_math(x, table=table)
+        assert np.max(np.abs(s - np.sin(x))) < 4e-16
+        assert np.max(np.abs(c - np.cos(x))) < 4e-16
     xe = np.concatenate([rng.uniform(-700, 0, 20000), rng.uniform(0, 60, 20000), [0.0, -1e-300, 1e-9, -745.0]])
     _, _, e = hip_ctx.debug_math(xe)
     ref = np.exp(np.maximum(xe, -740.0))
