@@ -468,6 +468,11 @@ double raftx_last_kernel_ms(raftx_ctx *ctx);
 /* Diagnostics: evaluates the device's own fp64 sincos/exp on n host values (the
  * oracle answers with libm), so the elementary functions are testable alone. */
 int raftx_debug_math(raftx_ctx *ctx, int n, const double *x, double *sin_out, double *cos_out, double *exp_out);
+/* Diagnostics: which specialisation of the fused fixed point the last solve on this ctx launched -- the feature bits
+ * compiled in (1 frequency-dependent M/B, 2 Z out, 4 F_wave out, 8 extra excitation, 16 MacCamy-Fuchs, 32 several
+ * headings, 64 linearisation-point I/O; 127 = the full-featured kernel), the waves per SIMD it is compiled for and the
+ * slots of its LDS run-start cache.  The oracle answers 0, 0, 0.  Returns -1 before the first solve. */
+int raftx_last_solve_kernel(raftx_ctx *ctx, int *flags, int *waves_per_simd, int *cache_slots);
 /* The same with the table-driven sincos the fused fixed point uses at its run starts (64-entry table in LDS). */
 int raftx_debug_math_table(raftx_ctx *ctx, int n, const double *x, double *sin_out, double *cos_out, double *exp_out);
 

@@ -24,7 +24,7 @@ EXPORTS = (
     "raftx_last_error", "raftx_upload_designs", "raftx_upload_cases",
     "raftx_excitation", "raftx_linearize", "raftx_solve_dynamics",
     "raftx_solve_system", "raftx_last_kernel_ms",
-    "raftx_solve_dynamics_device", "raftx_fetch_results", "raftx_debug_math", "raftx_debug_math_table", "raftx_motion_stats", "raftx_solve_system_resident", "raftx_qtf_slender", "raftx_channel_stats", "raftx_qtf_force", "raftx_set_linearisation_point", "raftx_fetch_linearisation_point",
+    "raftx_solve_dynamics_device", "raftx_fetch_results", "raftx_debug_math", "raftx_debug_math_table", "raftx_last_solve_kernel", "raftx_motion_stats", "raftx_solve_system_resident", "raftx_qtf_slender", "raftx_channel_stats", "raftx_qtf_force", "raftx_set_linearisation_point", "raftx_fetch_linearisation_point",
     "raftx_build_designs", "raftx_fetch_strips", "raftx_fetch_statics", "raftx_channel_stats_poly", "raftx_qtf_slender_rows", "raftx_bem_excitation", "raftx_qtf_kay", "raftx_host_alloc", "raftx_host_free", "raftx_device_locality", "raftx_solve_dense",
     "raftx_sweep_stats",
     "raftx_sweep_submit",
@@ -129,6 +129,8 @@ class RaftxLib:
         L.raftx_motion_stats.restype = C.c_int
         L.raftx_debug_math.argtypes = [_vp, C.c_int, _vp, _vp, _vp, _vp]
         L.raftx_debug_math.restype = C.c_int
+        L.raftx_last_solve_kernel.argtypes = [_vp, _vp, _vp, _vp]
+        L.raftx_last_solve_kernel.restype = C.c_int
         L.raftx_debug_math_table.argtypes = [_vp, C.c_int, _vp, _vp, _vp, _vp]
         L.raftx_debug_math_table.restype = C.c_int
         L.raftx_build_designs.argtypes = [_vp, C.c_int, _vp, _vp, _vp, _vp, _vp, _vp, _vp, C.c_double, C.c_double, C.c_int,
@@ -682,6 +684,13 @@ class Context:
                                              _ptr(Xi), _ptr(Z))
         self._check(rc, "raftx_solve_dense")
         return (Xi, Z) if want_Z else Xi
+
+    def last_solve_kernel(self):
+        """(feature bits, waves per SIMD, run-start cache slots) of the fused kernel the last solve launched."""
+        f, w, n = C.c_int(0), C.c_int(0), C.c_int(0)
+        rc = self.rlib.lib.raftx_last_solve_kernel(self._h, C.byref(f), C.byref(w), C.byref(n))
+        self._check(rc, "raftx_last_solve_kernel")
+        return f.value, w.value, n.value
 
     def debug_math(self, x, table=False):
         """The device's own sincos / exp on x; table=True: the table-driven sincos of the fused kernel's run starts."""

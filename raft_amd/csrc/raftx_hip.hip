@@ -594,6 +594,7 @@ struct raftx_ctx {
     cplx *rXi, *rFw, *rZ, *rFe;
     double *rB, *rXl;
     size_t rXl_n;
+    int last_flags = -1, last_minb = 0, last_rc = 0;       // specialisation of the last fused-kernel launch (raftx_last_solve_kernel)
     cplx *rQtf;                          // QTFs of the last raftx_qtf_slender call, kept for raftx_qtf_force
     size_t rQtf_n;
     int rQtf_sets, rQtf_nw2;
@@ -1520,7 +1521,29 @@ static int solve_enqueue(raftx_ctx *c, int nIter, double tol, double XiStart, co
     const bool xlg = xl_global(sh.nb, shape_maxt(sh));       // XiLast in a global scratch slab (raftx_kernels.h XlStore)
     // Workgroups a CU can hold by registers (the shape's waves per SIMD); LDS beyond what that residency needs goes to
     // the run-start cache (raftx_kernels.h Kin): as many 16-byte-per-bin slots as fit without costing a resident pair.
-    const int wg_per_cu = std::max(1, shape_minb(sh) * 4 / (sh.threads / 64));
+    const bool rc_shape = shape_maxt(sh) == 128 && sh.nb == 2;          // RC of k_solve_dynamics
+    // Which specialisation runs.  The 200-bin shape has lean kernels (two waves per SIMD, no Z / F_wave / restart I/O)
+    // for the feature sets a sweep meets -- several headings, MacCamy-Fuchs columns, frequency-dependent M / B (turbine
+    // aerodynamics, potential-flow coefficients), a resident extra excitation (BEM, second-order) -- and takes the
+    // smallest one that covers what this call needs; everything else (the drop-in's optional outputs) is the
+    // full-featured kernel at one wave per SIMD.
+#define RAFTX_LEAN128(X) X(0) X(KF_FDEP) X(KF_MCF) X(KF_MULTI) X(KF_FDEP | KF_EXTRA) X(KF_FDEP | KF_MCF) X(KF_FDEP | KF_MULTI) \
+    X(KF_MCF | KF_MULTI) X(KF_FDEP | KF_EXTRA | KF_MULTI) X(KF_FDEP | KF_MCF | KF_MULTI)
+    if (c->have_xl0 || c->want_xlout) need |= KF_XLIO;
+    int lean = -1;
+    if (rc_shape) {
+#define X(F) if (lean < 0 && (need & ~(F)) == 0) lean = (F);
+        RAFTX_LEAN128(X)
+#undef X
+    } else if (need == 0) {
+        lean = 0;
+    }
+    static const char *force_all = getenv("RAFTX_FORCE_ALL");           // tuning / tests: always the full-featured kernel
+    if (force_all && atoi(force_all)) lean = -1;
+    const int minb_used = lean >= 0 ? shape_minb(sh) : 1;
+    c->last_flags = lean >= 0 ? lean : KF_ALL;
+    c->last_minb = minb_used;
+    const int wg_per_cu = std::max(1, minb_used * 4 / (sh.threads / 64));
     auto rc_slots = [&](int S_) {
         if (!(shape_maxt(sh) == 128 && sh.nb == 2)) return 0;                // (= rc_shape below)
         static const char *env = getenv("RAFTX_RC_SLOTS");                 // tuning: cap (0 = no cache)
@@ -1531,8 +1554,8 @@ static int solve_enqueue(raftx_ctx *c, int nIter, double tol, double XiStart, co
         if (budget <= base) return 0;
         return (int)std::min<size_t>((size_t)cap, (budget - base) / (16 * (size_t)xl_row(T.nw)));
     };
-    const bool rc_shape = shape_maxt(sh) == 128 && sh.nb == 2;          // RC of k_solve_dynamics
     A.rc_n = rc_slots(c->maxS);
+    c->last_rc = A.rc_n;
     const size_t lds = lds_bytes(c->maxS, xlg ? 0 : T.nw, sh.threads / 64, stage_policy(sh.nb, shape_maxt(sh)),
                                  park_policy(sh.nb, shape_maxt(sh)), A.rc_n, rc_shape ? T.nw : 0);
     if (xlg && (!c->rXl || c->rXl_n < c->r_npair * 12 * (size_t)T.nw)) {
@@ -1634,11 +1657,13 @@ static int solve_enqueue(raftx_ctx *c, int nIter, double tol, double XiStart, co
                                l_, c->stream, T, A);                                                                 \
         }                                                                                                            \
     } while (0)
+#define TRY_LEAN_(F) if (lean == (F)) LAUNCH_SOLVE(2, 128, RAFTX_MINB128, (F));
 #define DISPATCH_ONE_(NB_, MT_, MB_)                                                                                 \
     if (!hit_ && sh.nb == NB_ && sh.threads == MT_) {                                                                \
         hit_ = true;                                                                                                 \
-        if (need == 0) LAUNCH_SOLVE(NB_, MT_, MB_, 0);                                                               \
-        else LAUNCH_SOLVE(NB_, MT_, 1, KF_ALL);   /* full-featured variant: trade occupancy for registers (no spills) */                                                                    \
+        if (lean < 0) LAUNCH_SOLVE(NB_, MT_, 1, KF_ALL);   /* full-featured variant: trade occupancy for registers */ \
+        else if constexpr (NB_ == 2 && MT_ == 128) { RAFTX_LEAN128(TRY_LEAN_) }                                      \
+        else LAUNCH_SOLVE(NB_, MT_, MB_, 0);                                                                         \
     }
     DISPATCH_SHAPE(sh, _);
 #undef DISPATCH_ONE_
@@ -2696,6 +2721,13 @@ __global__ void k_debug_math(int n, const double *__restrict__ x, double *__rest
     }
 }
 
+extern "C" int raftx_last_solve_kernel(raftx_ctx *c, int *flags, int *waves_per_simd, int *cache_slots) {
+    if (!c || c->last_flags < 0) return -1;
+    if (flags) *flags = c->last_flags;
+    if (waves_per_simd) *waves_per_simd = c->last_minb;
+    if (cache_slots) *cache_slots = c->last_rc;
+    return 0;
+}
 static int debug_math(raftx_ctx *c, int n, const double *x, double *sin_out, double *cos_out, double *exp_out, int table);
 extern "C" int raftx_debug_math(raftx_ctx *c, int n, const double *x, double *sin_out, double *cos_out, double *exp_out) {
     return debug_math(c, n, x, sin_out, cos_out, exp_out, 0);

@@ -1691,13 +1691,24 @@ __device__ __forceinline__ void solve6(Lu6 &A, cplx x[6]) {
 __device__ constexpr int EQ_ORDER[6] = {RAFTX_EQ_ORDER};
 
 // Assemble and solve one bin's 6x6 system: x <- Z^-1 x  (raft_model.py:1086-1089)
+// Frequency-dependent added mass / damping of a design, [2][36][nw] doubles, as a raw buffer: entry e of bin iw is one
+// buffer_load_dwordx2 with the lane's byte offset in ONE VGPR and the entry's row offset in an SGPR (a 64-bit global
+// pointer per entry costs a VALU add and two VGPRs each, and the compiler keeps all 72 of them).  No table: a buffer of
+// zero records, whose loads return 0.
+typedef __amdgpu_buffer_rsrc_t MbRsrc;
+__device__ __forceinline__ MbRsrc mb_rsrc(const double *MBw_design, int nw) {
+    return __builtin_amdgcn_make_buffer_rsrc((void *)MBw_design, 0, MBw_design ? 72 * nw * (int)sizeof(double) : 0, 0x00020000);
+}
+__device__ __forceinline__ double mb_load(MbRsrc r, int lane_bytes, int row_bytes) {
+    return __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(r, lane_bytes, row_bytes, 0));
+}
 template <int FLAGS>
-__device__ __forceinline__ void assemble_and_solve(const Lds &l, const double *__restrict__ Mw, const double *__restrict__ Bw,
-                                                   int nw, int iw, double w, cplx x[6], cplx *__restrict__ Zout,
-                                                   bool active) {
+__device__ __forceinline__ void assemble_and_solve(const Lds &l, MbRsrc mb, int nw, int iw, double w, cplx x[6],
+                                                   cplx *__restrict__ Zout, bool active) {
     Lu6 lu;
     const double w2 = w * w;
     if constexpr ((FLAGS & (KF_FDEP | KF_OUTZ)) != 0) iw = opaque(iw);   // per-entry addresses are formed here, not hoisted
+    const int row = nw * (int)sizeof(double), lane_bytes = iw * (int)sizeof(double);
     // The equations enter the elimination in the order EQ_ORDER (register row i holds equation EQ_ORDER[i]): a
     // compile-time renaming, free.  Partial pivoting chooses rows by magnitude, so the same pivot rows, multipliers and
     // updates follow whatever the starting order (it only decides exact ties); what changes is how often a row
@@ -1712,10 +1723,8 @@ __device__ __forceinline__ void assemble_and_solve(const Lds &l, const double *_
             const int e = EQ_ORDER[r] * 6 + c;
             double M = l.mat[e], B = l.mat[36 + e];
             if constexpr ((FLAGS & KF_FDEP) != 0) {
-                if (Mw) {
-                    M += (Mw + (size_t)e * nw)[iw];          // uniform row base + lane offset: SGPR base + VGPR offset
-                    B += (Bw + (size_t)e * nw)[iw];
-                }
+                M += mb_load(mb, lane_bytes, e * row);
+                B += mb_load(mb, lane_bytes, (36 + e) * row);
             }
             B += l.Bd[e];
             lu.ar[r][c] = fma(-w2, M, l.mat[72 + e]);     // Z = -w^2 M + i w B + C  (:1086)
@@ -1991,8 +2000,7 @@ __global__ void __launch_bounds__(MAXT, MINB) k_solve_dynamics(DevTables T, Solv
                 xl.put(2 * q + 1, b.iw[j], x0.im);
             }
         }
-    const double *Mw = (FDEP && T.MBw) ? T.MBw + ((size_t)p.d * 2 + 0) * 36 * nw : nullptr;
-    const double *Bw = (FDEP && T.MBw) ? T.MBw + ((size_t)p.d * 2 + 1) * 36 * nw : nullptr;
+    const MbRsrc mb = mb_rsrc((FDEP && T.MBw) ? T.MBw + (size_t)p.d * 72 * nw : nullptr, nw);
     cplx *Zout = (OUTZ && A.Z) ? A.Z + (size_t)pair * 36 * nw : nullptr;
     wg_sync(multi);
     PT_MARK(0);   // set-up + inertial excitation
@@ -2068,7 +2076,7 @@ __global__ void __launch_bounds__(MAXT, MINB) k_solve_dynamics(DevTables T, Solv
                     for (int q = 0; q < 6; q++) A.F_wave[(((size_t)pair * nHs) * 6 + q) * nw + iw] = xx[q];
                 }
             }
-            assemble_and_solve<FLAGS>(l, Mw, Bw, nw, iw, w, xx, Zout, act);
+            assemble_and_solve<FLAGS>(l, mb, nw, iw, w, xx, Zout, act);
             if constexpr (DEFER) return;
             if (act) {
 #pragma unroll
@@ -2135,8 +2143,12 @@ __global__ void __launch_bounds__(MAXT, MINB) k_solve_dynamics(DevTables T, Solv
                             if (actj[j] && A.XlOut) A.XlOut[((size_t)pair * 6 + q) * nw + iwj[j]] = cplx{lr[j][q], li[j][q]};
                         }
                         if (actj[j] && (isnan(xx.re) || isnan(xx.im))) bad = 1;
-                        const double dr = xx.re - lr[j][q], di = xx.im - li[j][q];
-                        if (actj[j] && !conv_test(dr, di, xx.re, xx.im, A.tol)) ok = 0;
+                        // the vote is an AND over the workgroup: once a lane of this wave has failed, the remaining
+                        // tests of the wave cannot change it (every iteration but the last one of a pair ends here)
+                        if (__all(ok)) {
+                            const double dr = xx.re - lr[j][q], di = xx.im - li[j][q];
+                            if (actj[j] && !conv_test(dr, di, xx.re, xx.im, A.tol)) ok = 0;
+                        }
                         const double nr = 0.2 * lr[j][q] + 0.8 * xx.re, ni = 0.2 * li[j][q] + 0.8 * xx.im;
                         if (actj[j]) {
                             xl.put(2 * q, iwj[j], nr);
@@ -2195,9 +2207,8 @@ __global__ void __launch_bounds__(MAXT, MINB) k_solve_dynamics(DevTables T, Solv
         for (int ih = 1; ih < nH; ih++) {
             const double beta = T.beta[(size_t)p.ic * nHs + ih];
             const double cb = to_sgpr(cos(beta)), sb = to_sgpr(sin(beta));
+            load_bins(T, b, opaque((int)threadIdx.x));    // re-derived, as at the top of every iteration: nothing of b lives through the fixed point
             set_heading_amp(T, b, p.ic, ih);
-            wg_sync(multi);
-            strip_phase<false>(p.ds, p.dsi, S, l, cb, sb, multi);
             cplx x[NB][6];
             zero6(x);
             if constexpr (EXTRA) {
@@ -2209,22 +2220,45 @@ __global__ void __launch_bounds__(MAXT, MINB) k_solve_dynamics(DevTables T, Solv
                             x[j][q] = A.F_extra[(((size_t)pair * nHs + ih) * 6 + q) * nw + b.iw[j]];
                 }
             }
-            inertial_excitation<NB, MCF, RC>(T, p.ds, p.dsi, S, cm, b, p.ic, ih, cb, sb, x, run_cache_of(l));   // refills the cache for this heading
+            wg_sync(multi);                               // the uv rows are free (previous heading's pass B is over)
+            // the inertial sweep refills the run-start cache for this heading
+            if constexpr (MCF)
+                inertial_excitation<NB, true, RC>(T, p.ds, p.dsi, S, cm, b, p.ic, ih, cb, sb, x, run_cache_of(l));
+            else
+                inertial_excitation_uv<NB, RC>(T, p.ds, p.dsi, S, l, b, p.ic, ih, cb, sb, x, multi);      // U', V' through the uv rows
+            wg_sync(multi);
+            strip_phase<false>(p.ds, p.dsi, S, l, cb, sb, multi);
             drag_excitation<NB, STAGE, RC>(p.ds, p.dsi, S, l, b, cb, sb, x);           // :1209,:1212
             cplx *xo = A.Xi + ((size_t)pair * nHs + ih) * 6 * nw;
+            if constexpr (OUTF) {
 #pragma unroll
-            for (int j = 0; j < NB; j++) {
-                if constexpr (OUTF) {
+                for (int j = 0; j < NB; j++)
                     if (b.act[j] && A.F_wave) {
 #pragma unroll
                         for (int q = 0; q < 6; q++) A.F_wave[(((size_t)pair * nHs + ih) * 6 + q) * nw + b.iw[j]] = x[j][q];
                     }
-                }
-                const double w = b.w[j];
-                assemble_and_solve<(FLAGS & ~KF_OUTZ)>(l, Mw, Bw, nw, b.iw[j], w, x[j], nullptr, b.act[j]);   // Zinv @ F_wave (:1216)
+            }
+            // While one bin's system is being factorised the right-hand sides of the later bins wait in their own
+            // places of the output slab (written and read back by the same lane), not in registers.
+#pragma unroll
+            for (int j = 1; j < NB; j++)
                 if (b.act[j]) {
 #pragma unroll
-                    for (int q = 0; q < 6; q++) xo[(size_t)q * nw + b.iw[j]] = nan ? cplx{NAN, NAN} : x[j][q];
+                    for (int q = 0; q < 6; q++) xo[(size_t)q * nw + b.iw[j]] = x[j][q];
+                }
+#pragma unroll
+            for (int j = 0; j < NB; j++) {
+                const int ib = j * blockDim.x + opaque((int)threadIdx.x);
+                const bool act = ib < nw;
+                const int iw = act ? ib : 0;
+                const double wl = T.w[iw];
+                cplx y[6];
+#pragma unroll
+                for (int q = 0; q < 6; q++) y[q] = j == 0 ? x[0][q] : xo[(size_t)q * nw + iw];
+                assemble_and_solve<(FLAGS & ~KF_OUTZ)>(l, mb, nw, iw, act ? wl : 0.0, y, nullptr, act);   // Zinv @ F_wave (:1216)
+                if (act) {
+#pragma unroll
+                    for (int q = 0; q < 6; q++) xo[(size_t)q * nw + iw] = nan ? cplx{NAN, NAN} : y[q];
                 }
             }
         }

@@ -609,3 +609,59 @@ def test_ragged_batch_is_launched_per_lds_class(hip_ctx, oracle_ctx):
         assert group_rel_err(oh["Xi"][d], oo["Xi"][d]) < TOL
     again = hip_ctx.solve_dynamics(6, 0.01, 0.1)
     assert np.array_equal(oh["Xi"].view(np.uint8), again["Xi"].view(np.uint8))
+
+
+# feature bits of the fused kernel (raftx_last_solve_kernel): the lean specialisations of the 200-bin shape
+KF_FDEP, KF_EXTRA, KF_MCF, KF_MULTI, KF_ALL = 1, 8, 16, 32, 127
+
+
+@pytest.mark.parametrize("fdep,mcf,nH,extra,expect", [
+    (False, 0.0, 1, False, 0),
+    (True, 0.0, 1, False, KF_FDEP),                                   # turbine aerodynamics: M(w), B(w)
+    (False, 0.3, 1, False, KF_MCF),                                   # MacCamy-Fuchs columns
+    (False, 0.0, 3, False, KF_MULTI),                                 # several wave headings
+    (True, 0.0, 1, True, KF_FDEP | KF_EXTRA),                         # + a resident extra excitation (BEM, second-order)
+    (False, 0.0, 1, True, KF_FDEP | KF_EXTRA),                        # extra excitation alone: the same kernel, empty M/B buffer
+    (True, 0.3, 1, False, KF_FDEP | KF_MCF),
+    (True, 0.0, 2, False, KF_FDEP | KF_MULTI),
+    (False, 0.3, 2, False, KF_MCF | KF_MULTI),
+    (True, 0.0, 2, True, KF_FDEP | KF_EXTRA | KF_MULTI),
+    (True, 0.3, 2, False, KF_FDEP | KF_MCF | KF_MULTI),
+    (True, 0.3, 2, True, KF_ALL),                                     # no lean kernel covers this: full-featured
+])
+def test_featured_sweep_kernels_run_lean_and_match_the_oracle(hip_ctx, oracle_ctx, fdep, mcf, nH, extra, expect):
+    """Every lean specialisation of the C2/C3 shape (two waves per SIMD, results resident) against the oracle, and the
+    dispatch itself: the smallest kernel that covers the sweep's features, the full-featured one only as the last resort
+    (raft_model.py:1006-1007,1045-1048 frequency-dependent terms; :1200-1236 headings; raft_member.py:1415-1420 MCF)."""
+    rng = np.random.default_rng(4242 + expect)
+    nw, nC = 200, 2
+    S_list = [53, 47, 0, 60]
+    tables = [(_member_run_table(rng, max(1, S // 10), 10) if S else random_strips(rng, 0)) for S in S_list]
+    if mcf:
+        from raft_amd import strips as st
+        from raft_amd.strips import StripTable
+        for i, t in enumerate(tables):                                # member-run geometry, MacCamy-Fuchs rows on some strips
+            cms = []
+            for srow in range(t.n):
+                if rng.uniform() < mcf:
+                    t.strips[srow, st.F_MCF] = float(len(cms))
+                    t.strips[srow, st.F_IP1] = t.strips[srow, st.F_IP2] = 0.0
+                    cms.append(rng.uniform(1.2, 2.2, size=(2, nw)) + 1j * rng.uniform(-0.5, 0.5, size=(2, nw)))
+            tables[i] = StripTable(t.strips, np.array(cms) if cms else None)
+    mats = random_matrices(rng, len(S_list), nw, fdep)
+    cases = synthetic_cases(rng, nC, nH, nw)
+    _both(hip_ctx, oracle_ctx, tables, mats, cases)
+    Fe = None
+    if extra:
+        Fe = 2e4 * (rng.normal(size=(len(S_list), nC, nH, 6, nw)) + 1j * rng.normal(size=(len(S_list), nC, nH, 6, nw)))
+    res = []
+    for ctx in (hip_ctx, oracle_ctx):
+        ctx.solve_dynamics_device(7, 0.01, 0.1, F_extra=Fe)
+        res.append(ctx.fetch_results(want_Xi=True))
+    flags, waves, _ = hip_ctx.last_solve_kernel()
+    assert flags == expect, (flags, expect)
+    assert waves == (1 if expect == KF_ALL else 2)
+    assert np.array_equal(res[0]["niter"], res[1]["niter"])
+    assert np.array_equal(res[0]["flags"], res[1]["flags"])
+    for d in range(len(S_list)):
+        assert group_rel_err(res[0]["Xi"][d], res[1]["Xi"][d]) < TOL
