@@ -34,11 +34,19 @@ Also on the JSON line:
                     live reference's own solveDynamics (tests/golden/c3_variants.npz);
   cpu_baseline      the oracle (oracle/raftx_oracle.c, kind "port") on this host.
 
+  xi_out / isolated_call   the same step with the 192 MB of responses downloaded too
+                    (SURVEY.md 8d's literal "D2H of Xi"), streamed and as isolated blocking
+                    calls -- extra legs after the timed region, N = 1 only;
+  featured_sweeps   the lean featured specialisations of the fused kernel on the same
+                    designs (frequency-dependent M/B, three sea states, two headings,
+                    MacCamy-Fuchs columns): resident kernel time per pair-iteration
+                    against the plain sweep's, a sample checked against the oracle.
+
 Multi-GPU: one process per GPU; designs are block-partitioned over ranks, no
 collective while solving; the statistics are gathered onto rank 0 INSIDE the
-timed region (RCCL through the library's own communicator, raft_amd/comm.py;
-torch.distributed is plumbing for barrier + max-over-ranks only).  Weak scaling:
-nDesign per rank is fixed.
+timed region.  Barrier, max-over-ranks and gather all go through the library's
+own communicator (raft_amd/comm.py: RCCL via raftx_comm_*, rendezvous over TCP on
+MASTER_ADDR) -- no torch in this file.  Weak scaling: nDesign per rank is fixed.
 
 Prints ONE JSON line (rank 0).
 """
@@ -59,15 +67,19 @@ FP64_VALU_PEAK_TF = 78.6       # MI355X vector fp64 peak
 FP64_FMA_SUSTAINED_TF = 50.8      # measured: profiles/r02_valu_mfma_probe.jsonl (probe fma64)
 
 
-def make_sweep(ctx, n_design, rank=0, pinned=True):
+def make_sweep(ctx, n_design, rank=0, pinned=True, mcf=False, zeta=None, beta=None, MBw=None):
     """Descriptors of this rank's designs (host, vectorised): rank r takes rows [r*n, (r+1)*n) of one default_rng(0)
-    draw, so rank 0's first 64 designs are the committed reference-built variants."""
+    draw, so rank 0's first 64 designs are the committed reference-built variants.  mcf / zeta, beta / MBw: the featured
+    legs (MacCamy-Fuchs columns; other sea states / headings; frequency-dependent added mass and damping)."""
     from raft_amd import snapshot
     from raft_amd import geometry as G
     from raft_amd.sweep import GeometrySweep
     fx = snapshot.load_fixture("c3_variants.npz")
     fg = snapshot.load_fixture("geom_units.npz")
     base = json.loads(fg["c3_base_json"])
+    if mcf:                                             # MacCamy-Fuchs correction on the four columns (raft_member.py:1415-1420)
+        for m in base["platform"]["members"][:2]:
+            m["MCF"] = True
     u0 = [u for u in fg["units"] if u["name"] == "C3-variant-0"][0]
     # constants that are not geometry: rotor-nacelle assembly (live reference minus its massless-RNA twin), mooring
     M_rna = np.asarray(u0["M_struc"]) - np.asarray(u0["M_struc_bare"])
@@ -92,8 +104,10 @@ def make_sweep(ctx, n_design, rank=0, pinned=True):
             b[...] = a
             return b
         M0, B0, C0 = _pin(M0), _pin(B0), _pin(C0)
-    sw = GeometrySweep(D, M0, B0, C0, fx["w"], fx["k"], float(fx["depth"]), np.asarray(fx["zeta"])[None], np.asarray(fx["beta"])[None],
-                       int(fx["nIter"]), float(fx["XiStart"]), tol=0.01, add_mask=G.ADD_MORISON | G.ADD_HYDROSTATIC | G.ADD_INERTIA)
+    sw = GeometrySweep(D, M0, B0, C0, fx["w"], fx["k"], float(fx["depth"]),
+                       np.asarray(fx["zeta"])[None] if zeta is None else zeta, np.asarray(fx["beta"])[None] if beta is None else beta,
+                       int(fx["nIter"]), float(fx["XiStart"]), tol=0.01, add_mask=G.ADD_MORISON | G.ADD_HYDROSTATIC | G.ADD_INERTIA,
+                       MBw=MBw)
     geo = {"designs": int(n_design), "members": int(D.member_off[-1]), "host_descriptor_ms": 1e3 * t_desc,
            "descriptor_bytes": int(D.members.nbytes + D.stations.nbytes + D.caps.nbytes), "descriptors_page_locked": bool(pinned)}
     return sw, fx, geo
@@ -128,9 +142,10 @@ def algorithmic_flops(off, nw, niter):
 
 
 def oracle_run(sw, ctx):
-    """The CPU oracle (oracle/raftx_oracle.c) on this host, over EVERY design of the timed batch: its wall time is the
-    cpu_baseline, its responses are the checker of the batch.  The oracle gets the strip tables and statics the device
-    generated, fetched once."""
+    """The CPU oracle (oracle/raftx_oracle.c) on this host, over EVERY design of the timed batch.  Two checks and one
+    timing: (i) the oracle's own geometry chain (raftx_build_designs of oracle/raftx_geom_oracle.h) on the same member
+    descriptions, compared with the strip tables and statics the device generated -- all designs; (ii) the oracle's
+    fixed point on those tables: its responses check the batch, its wall time is the cpu_baseline."""
     import subprocess
     from raft_amd._abi import RaftxLib
     so = os.path.join(ROOT, "oracle", "libraftx_oracle_fast.so")          # same source as the checker, -O3 -march=x86-64-v3
@@ -148,6 +163,26 @@ def oracle_run(sw, ctx):
     C0 = S["C_struc"] + S["C_hydro"] + sw.C0
     n = sw.n_design
     o = lib.context(0)
+    # (i) generator check: the same descriptors through the oracle's serial member / strip walk
+    t0 = time.perf_counter()
+    sw.upload(o)
+    t_geom = time.perf_counter() - t0
+    o_strips, _ = o.fetch_strips(sw.off[-1])
+    oS = o.fetch_statics()
+    gen = {"designs": int(n), "strip_count_mismatches": int(np.count_nonzero(np.asarray(sw.off) != np.asarray(off))),
+           "oracle_geometry_s": t_geom}
+    if gen["strip_count_mismatches"] == 0:
+        # the 26 geometric / coefficient fields group-wise relative to the group's largest magnitude, the member / strip indices
+        # exactly (the run hints behind them are never read by the library: it detects runs itself)
+        groups = [(0, 3), (3, 6), (6, 15), (15, 18), (18, 19), (19, 23), (23, 26)]      # positions, arms, triads, scalars (tests/test_geometry.py)
+        gen["strips_max_err_rel_to_field_max"] = float(max(
+            np.max(np.abs(strips[:, a:b] - o_strips[:, a:b])) / max(np.max(np.abs(o_strips[:, a:b])), 1e-300) for a, b in groups))
+        gen["strip_index_mismatches"] = int(np.count_nonzero(strips[:, 26:28] != o_strips[:, 26:28]))
+        for key in ("A_morison", "C_hydro", "M_struc", "C_struc", "W_hydro", "W_struc"):
+            a, b = np.asarray(S[key]).reshape(n, -1), np.asarray(oS[key]).reshape(n, -1)
+            gen["%s_max_group_rel_err" % key] = float(np.max(np.max(np.abs(a - b), axis=1) / np.maximum(np.max(np.abs(b), axis=1), 1e-300)))
+    sw.off = off
+    # (ii) the fixed point on the device-generated tables
     o.upload_designs_raw(off, strips, M0, sw.B0, C0, nw)
     o.upload_cases(sw.w, sw.k, sw.depth, 1025.0, 9.81, sw.zeta, sw.beta)
     o.solve_dynamics_device(sw.nIter, sw.tol, sw.XiStart)      # warm-up (thread pool, page faults)
@@ -163,7 +198,93 @@ def oracle_run(sw, ctx):
             "algorithmic_gflops": flops / dt / 1e9,
             "note": "a scalar loop-by-loop restatement of the reference (materialised kinematics, libm cabs): the checker doing "
                     "double duty, not a tuned CPU implementation -- %.2f GFLOP/s per thread" % (flops / dt / 1e9 / max(threads, 1))}
-    return base, res
+    return base, res, gen
+
+
+def reference_on_this_host():
+    """The unmodified NumPy reference timed on THIS host (oracle/time_reference.py), when its tree is here
+    (RAFT_REFERENCE_ROOT or /root/reference: the build container; the GPU box of the pool has no copy)."""
+    import subprocess
+    root = os.environ.get("RAFT_REFERENCE_ROOT", "/root/reference")
+    if not os.path.isdir(os.path.join(root, "raft")):
+        return None
+    try:
+        env = dict(os.environ, RAFTX_REF_TIMING_NOWRITE="1", OMP_NUM_THREADS="1", OPENBLAS_NUM_THREADS="1")
+        out = subprocess.run([sys.executable, os.path.join(ROOT, "oracle", "time_reference.py"), "2"], env=env, timeout=300,
+                             capture_output=True, text=True, check=True).stdout.strip().splitlines()[-1]
+        r = json.loads(out)
+        return {"dcf_per_s_one_core": r["dcf_per_s_per_core"], "designs": r["designs"], "cores_on_host": os.cpu_count(),
+                "solveDynamics_s_per_design": r["solveDynamics_s_per_design"], "where": "this host, RAFT_REFERENCE_ROOT=%s" % root}
+    except Exception as e:                                  # noqa: BLE001 -- a reported absence, never a failed bench
+        return {"error": "%s: %s" % (type(e).__name__, str(e)[:200])}
+
+
+def featured_legs(ctx, n_design, base_sw, base_ms, base_pair_iters):
+    """The lean featured specialisations of the fused kernel (two waves per SIMD) on the C3 designs, resident in / resident
+    out: kernel time per (pair, iteration) against the plain sweep's, and a sample of each leg against the CPU oracle.
+    Legs: frequency-dependent M(w), B(w) (the turbine's aerodynamic matrices of raft_model.py:1006-1007: the kernel re-reads
+    2 x 36 x nw doubles per pair and iteration -- the leg where HBM traffic starts to matter); C2's three sea states as
+    cases; two wave headings (raft_model.py:1200-1236); MacCamy-Fuchs columns (raft_member.py:1415-1420)."""
+    from raft_amd import waves
+    from raft_amd._abi import RaftxLib
+    from raft_amd.metrics import group_rel_err
+    nw = base_sw.nw
+    w = base_sw.w
+    dw = float(w[1] - w[0])
+    rng = np.random.default_rng(5)
+    sea = lambda Hs, Tp: np.sqrt(2.0 * waves.jonswap(w, Hs, Tp) * dw)
+    legs = {}
+    specs = {
+        "freq_dependent_MB": dict(MBw="aero"),
+        "three_sea_states": dict(zeta=np.stack([sea(6.0, 12.0), sea(4.0, 10.0), sea(8.0, 14.0)])[:, None, :], beta=np.zeros((3, 1))),
+        "two_headings": dict(zeta=np.stack([sea(6.0, 12.0), sea(3.0, 9.0)])[None, :, :], beta=np.array([[0.0, np.deg2rad(30.0)]])),
+        "maccamy_fuchs_columns": dict(mcf=True),
+    }
+    oracle = RaftxLib(os.path.join(ROOT, "oracle", "libraftx_oracle.so"))
+    n_chk = 8
+    for name, kw in specs.items():
+        kw = dict(kw)
+        if kw.get("MBw") == "aero":                       # smooth in w, different per design: rotor added mass / damping shaped
+            amp = rng.uniform(0.5, 1.5, size=(n_design, 2, 6, 6, 1))
+            shape = np.stack([1.0 / (1.0 + (w / 0.6) ** 2), (w / 0.8) / (1.0 + (w / 0.8) ** 2)])[None, :, None, None, :]
+            kw["MBw"] = np.ascontiguousarray(amp * shape * np.array([2e5, 4e5])[None, :, None, None, None]
+                                             * np.eye(6)[None, None, :, :, None])
+        sw, _, _ = make_sweep(ctx, n_design, 0, pinned=False, **kw)
+        sw.upload(ctx)
+        ks = []
+        for i in range(6):
+            ctx.solve_dynamics_device(sw.nIter, sw.tol, sw.XiStart)
+            if i >= 2:
+                ks.append(ctx.last_kernel_ms())
+        flags, waves_per_simd, slots = ctx.last_solve_kernel()
+        r = ctx.fetch_results(want_Xi=True)
+        k_ms = float(np.mean(ks))
+        pairs = sw.n_design * sw.n_case
+        # an extra heading costs one inertial + one drag sweep + the solves of an iteration's worth: count it as one
+        pair_iters = float(np.sum(r["niter"])) + pairs * (sw.n_head - 1)
+        leg = {"kernel_ms": k_ms, "pairs": int(pairs), "headings": int(sw.n_head), "mean_iterations": float(np.mean(r["niter"])),
+               "kernel_flags": int(flags), "waves_per_simd": int(waves_per_simd), "run_start_cache_slots": int(slots),
+               "ns_per_pair_iteration": 1e6 * k_ms / pair_iters,
+               "vs_plain_sweep": (k_ms / pair_iters) / (base_ms / base_pair_iters),
+               "dcf_per_s": pairs * sw.n_head * nw / (k_ms * 1e-3)}
+        if sw.MBw is not None:
+            A_full = algorithmic_bytes(sw.off, nw) + float(np.sum(r["niter"])) * 2 * 36 * nw * 8.0
+            leg["hbm_frac_incl_MB_rereads"] = A_full / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS
+        # the first n_chk designs through the oracle's own chain (geometry, MacCamy-Fuchs tables, fixed point)
+        sub = sw.take(0, n_chk)
+        o = oracle.context(0)
+        sub.upload(o)
+        o.solve_dynamics_device(sw.nIter, sw.tol, sw.XiStart)
+        ro = o.fetch_results(want_Xi=True)
+        o.close()
+        err = max(group_rel_err(r["Xi"][d], ro["Xi"][d]) for d in range(n_chk))
+        leg["oracle_checked_designs"] = n_chk
+        leg["max_group_rel_err_vs_oracle"] = float(err)
+        leg["niter_mismatches_vs_oracle"] = int(np.count_nonzero(ro["niter"] != r["niter"][:n_chk]))
+        assert err < 1e-6 and leg["niter_mismatches_vs_oracle"] == 0, "featured leg %s fails parity: %r" % (name, leg)
+        legs[name] = leg
+        del sw, r
+    return legs
 
 
 def main():
@@ -180,25 +301,18 @@ def main():
     ap.add_argument("--no-stream", action="store_true", help="time isolated blocking calls (raftx_sweep_stats) instead of streaming the "
                                                              "steps through the library's two slots (raftx_sweep_submit / _wait)")
     ap.add_argument("--no-cpu-baseline", action="store_true", help="skip the oracle leg (cpu_baseline and the all-design check)")
+    ap.add_argument("--no-extra-legs", action="store_true", help="skip the legs outside the headline (xi-out, featured sweeps)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    dist = None
-    # RAFTX_BENCH_BACKEND=gloo + RAFTX_BENCH_DEVICE=0: rehearsal of the multi-rank path on a single-GPU box (all ranks
-    # share device 0, host transport for the gather); the driver's runs use RCCL with one GPU per rank
-    backend_name = os.environ.get("RAFTX_BENCH_BACKEND", "nccl")
-    if "RAFTX_BENCH_DEVICE" in os.environ:
+    # RAFTX_BENCH_DEVICE=0: rehearsal of the multi-rank path on a single-GPU box (all ranks share device 0; RCCL refuses
+    # that, so the exchange steps fall back to the host transport and the JSON line says so); the driver's runs have one
+    # GPU per rank and use RCCL or fail
+    rehearsal = "RAFTX_BENCH_DEVICE" in os.environ
+    if rehearsal:
         local = int(os.environ["RAFTX_BENCH_DEVICE"])
-    if world > 1:
-        import torch
-        import torch.distributed as dist
-        torch.cuda.set_device(local)
-        if backend_name == "nccl":
-            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local))
-        else:
-            dist.init_process_group(backend=backend_name)
 
     from raft_amd import backend
     from raft_amd.metrics import rao_group_err
@@ -220,7 +334,7 @@ def main():
         # the exchange step gets its own context (= its own stream): the gather of step i must not queue behind the
         # kernels of step i + 1, which are already on the solver context's stream when the steps are streamed
         ctx_comm = backend.hip_library().context(local)
-        comm, gather_kind = rcomm.from_env(ctx_comm, prefer="rccl" if backend_name == "nccl" else "host")
+        comm, gather_kind = rcomm.from_env(ctx_comm, prefer="rccl", fallback="host" if rehearsal else "error")
 
     stream_steps = not args.no_stream
     Xi_pinned = [ctx.pinned_empty((nD, 1, 1, 6, nw)) for _ in range(2 if stream_steps else 1)] if args.xi_out else [None, None]
@@ -248,12 +362,11 @@ def main():
             h = h_next
         return out
 
-    def barrier():
-        if dist is not None:
-            import torch
-            torch.cuda.synchronize()
-            dist.barrier()
-            torch.cuda.synchronize()
+    def barrier():                                        # device idle on every rank, then all ranks together, both sides
+        ctx.synchronize()
+        if comm is not None:
+            ctx_comm.synchronize()
+            comm.barrier()
 
     if stream_steps:
         # untimed priming, before the W warm-up steps: the first crossing of a stream is cut into two blocks, the following
@@ -274,11 +387,8 @@ def main():
         for _ in range(5):                                # (no gather here: only this rank runs it)
             sw.run_crossing(ctx, n_chunk=args.chunks, n_worker=args.workers, Xi_out=Xi_pinned[0])
         isolated = (time.perf_counter() - t1) / 5
-    if dist is not None:
-        import torch
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if backend_name == "nccl" else "cpu")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    if comm is not None:
+        elapsed = comm.all_max(elapsed)                   # the slowest rank's clock
     tims = np.array(tims)
     off = r["strip_off"]
     niter = r["niter"]
@@ -308,7 +418,12 @@ def main():
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         os.sched_setaffinity(0, cpus_at_start)
-        cpu, ores = oracle_run(sw, ctx)
+        cpu, ores, gen_chk = oracle_run(sw, ctx)
+        parity["generator_vs_oracle_all_designs"] = gen_chk
+        assert gen_chk["strip_count_mismatches"] == 0 and gen_chk.get("strips_max_err_rel_to_field_max", 1.0) < 1e-9 and \
+            gen_chk.get("strip_index_mismatches", 1) == 0 and \
+            all(v < 1e-7 for k_, v in gen_chk.items() if k_.endswith("_max_group_rel_err")), \
+            "device-generated tables / statics differ from the oracle's generator: %r" % gen_chk
         e = [rao_group_err(Xi[d, 0, 0], ores["Xi"][d, 0, 0], sw.zeta[0, 0]) for d in range(nD)]
         parity["oracle_checked_designs"] = int(nD)
         parity["rao_max_rel_err_vs_oracle"] = float(np.max(e))
@@ -329,6 +444,44 @@ def main():
         resident = {"kernel_ms": k, "dcf_per_s": nD * nw / (k * 1e-3),
                     "hbm_frac": algorithmic_bytes(off, nw) / (k * 1e-3) / 1e9 / HBM_PEAK_GBS,
                     "fp64_valu_frac": algorithmic_flops(off, nw, niter) / (k * 1e-3) / 1e12 / FP64_VALU_PEAK_TF}
+
+    # ---- legs outside the headline (N = 1): SURVEY 8d's literal step (responses downloaded), featured sweeps
+    xi_leg = featured = None
+    if rank == 0 and world == 1 and not args.no_extra_legs and not args.xi_out:
+        Xp = [ctx.pinned_empty((nD, 1, 1, 6, nw)) for _ in range(2)]
+
+        def xi_steps(n):
+            h = sw.submit_crossing(ctx, 0, n_chunk=args.chunks, Xi_out=Xp[0])
+            for i in range(n):
+                hn = sw.submit_crossing(ctx, (i + 1) % 2, n_chunk=args.chunks, Xi_out=Xp[(i + 1) % 2]) if i + 1 < n else None
+                sw.wait_crossing(ctx, h)
+                h = hn
+        xi_steps(3)
+        ctx.synchronize()
+        t1 = time.perf_counter()
+        xi_steps(args.steps)
+        ctx.synchronize()
+        t_xi = (time.perf_counter() - t1) / args.steps
+        t1 = time.perf_counter()
+        for _ in range(3):
+            sw.run_crossing(ctx, n_chunk=args.chunks, n_worker=args.workers, Xi_out=Xp[0])
+        t_xi_iso = (time.perf_counter() - t1) / 3
+        assert np.array_equal(Xp[0].view(np.uint64), Xi.reshape(Xp[0].shape).view(np.uint64)), "xi-out leg: responses differ from the checked batch"
+        xi_leg = {"state": "xi out: SURVEY 8d's literal step, H2D of the descriptors + kernels + D2H of Xi (%.0f MB per step, "
+                           "page-locked destination)" % (Xp[0].nbytes / 1e6),
+                  "streamed_ms_per_step": 1e3 * t_xi, "streamed_dcf_per_s": nD * nw / t_xi,
+                  "isolated_ms_per_step": 1e3 * t_xi_iso, "isolated_dcf_per_s": nD * nw / t_xi_iso}
+        for b_ in Xp:
+            ctx.free_pinned(b_)
+        sw.upload(ctx)                                    # the plain sweep, resident: the yardstick of the featured legs
+        ks = []
+        for i in range(6):
+            ctx.solve_dynamics_device(sw.nIter, sw.tol, sw.XiStart)
+            if i >= 2:
+                ks.append(ctx.last_kernel_ms())
+        featured = {"plain_sweep": {"kernel_ms": float(np.mean(ks)), "pairs": int(nD), "kernel_flags": ctx.last_solve_kernel()[0],
+                                    "ns_per_pair_iteration": 1e6 * float(np.mean(ks)) / float(np.sum(niter))}}
+        featured.update(featured_legs(ctx, nD, sw, float(np.mean(ks)), float(np.sum(niter))))
 
     n_dcf_rank = nD * 1 * nw
     value = n_dcf_rank * world * args.steps / elapsed
@@ -362,19 +515,21 @@ def main():
                               "solve_kernels_sum": k_sum_ms, "statistics_kernels_sum": float(np.mean(tims[:, 3]))},
         "parity": parity,
         "mean_iterations": float(np.mean(niter)),
-        "roofline": {"bound": "hbm", "achieved": A / (k_sum_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": A / (k_sum_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": measured_traffic(nD),
-                     "kernel": "k_solve_dynamics", "kernel_ms_per_step": k_sum_ms, "algorithmic_bytes_per_step": A,
-                     "note": "summed over the launches of one step (the library cuts a step into design blocks); the fused "
-                             "kernel is fp64-VALU-bound (SURVEY.md 8d): see roofline_fp64_valu"},
-        "roofline_fp64_valu": {"achieved": flops / (k_sum_ms * 1e-3) / 1e12, "peak": FP64_VALU_PEAK_TF, "unit": "TFLOP/s",
-                               "frac": flops / (k_sum_ms * 1e-3) / 1e12 / FP64_VALU_PEAK_TF,
-                               "algorithmic_flops_per_step": flops,
-                               "sustained_fma_probe": {"tflops": FP64_FMA_SUSTAINED_TF,
-                                                       "frac": flops / (k_sum_ms * 1e-3) / 1e12 / FP64_FMA_SUSTAINED_TF,
-                                                       "note": "what a pure v_fma_f64 loop sustains on an MI355X at the kernel's "
-                                                               "occupancy (the clock drops to 1.7 GHz under fp64 load): "
-                                                               "scripts/ubench/valu_mfma_probe.hip, profiles/r02_valu_mfma_probe.jsonl"}},
+        # the BINDING roof: the fused kernel is fp64-VALU-bound (370 FLOP per algorithmic byte against a machine balance of
+        # 10); the HBM view and the measured traffic sit beside it
+        "roofline": {"bound": "fp64_valu", "achieved": flops / (k_sum_ms * 1e-3) / 1e12, "peak": FP64_VALU_PEAK_TF, "unit": "TFLOP/s",
+                     "frac": flops / (k_sum_ms * 1e-3) / 1e12 / FP64_VALU_PEAK_TF,
+                     "traffic": measured_traffic(nD),
+                     "kernel": "k_solve_dynamics", "kernel_ms_per_step": k_sum_ms, "algorithmic_flops_per_step": flops,
+                     "hbm": {"achieved": A / (k_sum_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                             "frac": A / (k_sum_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "algorithmic_bytes_per_step": A},
+                     "sustained_fma_probe": {"tflops": FP64_FMA_SUSTAINED_TF,
+                                             "frac": flops / (k_sum_ms * 1e-3) / 1e12 / FP64_FMA_SUSTAINED_TF,
+                                             "note": "what a pure v_fma_f64 loop sustains on an MI355X at the kernel's occupancy "
+                                                     "(the clock drops to 1.7 GHz under fp64 load): scripts/ubench/valu_mfma_probe.hip, "
+                                                     "profiles/r02_valu_mfma_probe.jsonl"},
+                     "note": "kernel time = HIP events around every k_solve_dynamics launch of the timed steps, summed per step; "
+                             "traffic = 2 x FETCH_SIZE + WRITE_SIZE of separate rocprofv3 --pmc passes (profiles/traffic_latest.json)"},
         "host_placement": placement,
         "geometry": dict(geo, strips=int(off[-1]), strip_table_bytes_not_uploaded=int(off[-1]) * 256),
     }
@@ -384,6 +539,13 @@ def main():
                                         "(upload of all descriptors on the critical path)"}
     if resident is not None:
         out["kernel_resident"] = resident
+    if xi_leg is not None:
+        out["xi_out"] = xi_leg
+    if featured is not None:
+        out["featured_sweeps"] = featured
+    ref_here = reference_on_this_host() if (rank == 0 and world == 1 and not args.no_cpu_baseline) else None
+    if ref_here is not None:
+        out["reference_numpy_this_host"] = ref_here
     ref_path = os.path.join(ROOT, "profiles", "reference_cpu_timing.json")
     if os.path.exists(ref_path):      # the unmodified NumPy reference, timed in the BUILD container (it cannot travel to the GPU box)
         with open(ref_path) as f:
@@ -400,8 +562,6 @@ def main():
         comm.close()
     if ctx_comm is not None:
         ctx_comm.close()
-    if dist is not None:
-        dist.destroy_process_group()
 
 
 if __name__ == "__main__":

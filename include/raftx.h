@@ -468,6 +468,10 @@ double raftx_last_kernel_ms(raftx_ctx *ctx);
 /* Diagnostics: evaluates the device's own fp64 sincos/exp on n host values (the
  * oracle answers with libm), so the elementary functions are testable alone. */
 int raftx_debug_math(raftx_ctx *ctx, int n, const double *x, double *sin_out, double *cos_out, double *exp_out);
+/* Blocks until every stream of the context's DEVICE is idle (hipDeviceSynchronize): the device-side half of a timed
+ * region's barrier, for callers that bracket library calls themselves (bench.py).  The oracle returns at once. */
+int raftx_device_synchronize(raftx_ctx *ctx);
+
 /* Diagnostics: which specialisation of the fused fixed point the last solve on this ctx launched -- the feature bits
  * compiled in (1 frequency-dependent M/B, 2 Z out, 4 F_wave out, 8 extra excitation, 16 MacCamy-Fuchs, 32 several
  * headings, 64 linearisation-point I/O; 127 = the full-featured kernel), the waves per SIMD it is compiled for and the

@@ -20,7 +20,7 @@ ROOT = os.path.dirname(HERE)
 sys.path.insert(0, ROOT)
 
 from oracle import ref_harness as rh          # noqa: E402
-from tests import standin                     # noqa: E402
+from raft_amd import snapshot as standin
 
 REF = rh.REFERENCE_ROOT
 GOLD = standin.GOLDEN_DIR

@@ -75,12 +75,13 @@ def main():
         t_solve += t2 - t1
         nw = m.nw
     out = {"what": "raft.Model.solveDynamics (reference, NumPy), C3 sweep variants, 1 sea state, %d bins" % nw,
-           "designs": n, "cores": 1, "host": "build container (%d logical cores)" % (os.cpu_count() or 0),
+           "designs": n, "cores": 1, "host": "%d logical cores" % (os.cpu_count() or 0),
            "solveDynamics_s_per_design": t_solve / n, "model_build_s_per_design": t_build / n,
            "dcf_per_s_per_core": n * nw / t_solve}
-    os.makedirs(os.path.join(ROOT, "profiles"), exist_ok=True)
-    with open(os.path.join(ROOT, "profiles", "reference_cpu_timing.json"), "w") as f:
-        json.dump(out, f, indent=1)
+    if not os.environ.get("RAFTX_REF_TIMING_NOWRITE"):        # bench.py's on-host leg only wants the line below
+        os.makedirs(os.path.join(ROOT, "profiles"), exist_ok=True)
+        with open(os.path.join(ROOT, "profiles", "reference_cpu_timing.json"), "w") as f:
+            json.dump(out, f, indent=1)
     print(json.dumps(out))
 
 

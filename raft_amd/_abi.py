@@ -24,7 +24,7 @@ EXPORTS = (
     "raftx_last_error", "raftx_upload_designs", "raftx_upload_cases",
     "raftx_excitation", "raftx_linearize", "raftx_solve_dynamics",
     "raftx_solve_system", "raftx_last_kernel_ms",
-    "raftx_solve_dynamics_device", "raftx_fetch_results", "raftx_debug_math", "raftx_debug_math_table", "raftx_last_solve_kernel", "raftx_motion_stats", "raftx_solve_system_resident", "raftx_qtf_slender", "raftx_channel_stats", "raftx_qtf_force", "raftx_set_linearisation_point", "raftx_fetch_linearisation_point",
+    "raftx_solve_dynamics_device", "raftx_fetch_results", "raftx_debug_math", "raftx_debug_math_table", "raftx_last_solve_kernel", "raftx_device_synchronize", "raftx_motion_stats", "raftx_solve_system_resident", "raftx_qtf_slender", "raftx_channel_stats", "raftx_qtf_force", "raftx_set_linearisation_point", "raftx_fetch_linearisation_point",
     "raftx_build_designs", "raftx_fetch_strips", "raftx_fetch_statics", "raftx_channel_stats_poly", "raftx_qtf_slender_rows", "raftx_bem_excitation", "raftx_qtf_kay", "raftx_host_alloc", "raftx_host_free", "raftx_device_locality", "raftx_solve_dense",
     "raftx_sweep_stats",
     "raftx_sweep_submit",
@@ -129,6 +129,8 @@ class RaftxLib:
         L.raftx_motion_stats.restype = C.c_int
         L.raftx_debug_math.argtypes = [_vp, C.c_int, _vp, _vp, _vp, _vp]
         L.raftx_debug_math.restype = C.c_int
+        L.raftx_device_synchronize.argtypes = [_vp]
+        L.raftx_device_synchronize.restype = C.c_int
         L.raftx_last_solve_kernel.argtypes = [_vp, _vp, _vp, _vp]
         L.raftx_last_solve_kernel.restype = C.c_int
         L.raftx_debug_math_table.argtypes = [_vp, C.c_int, _vp, _vp, _vp, _vp]
@@ -196,6 +198,10 @@ class Context:
             raise RaftxError("raftx_ctx_create(device=%d) failed (rc=%d) in %s"
                              % (device_id, rc, rlib.path))
         self.nDesign = self.nCase = self.nHead = self.nw = 0
+        self._comm = None
+        # bumped by every call that replaces what is resident on the context (designs, cases, sweep crossings): callers
+        # that skip an upload because "their" tables are already there compare it (raft_amd/dropin.py Engine._upload)
+        self.resident_generation = 0
 
     def close(self):
         if self._h:
@@ -225,6 +231,7 @@ class Context:
     # ------------------------------------------------------------- uploads
     def upload_designs(self, strip_tables, M0, B0, C0, nw, MBw=None):
         """strip_tables: list of raft_amd.strips.StripTable (one per design)."""
+        self.resident_generation += 1
         nD = len(strip_tables)
         off = np.zeros(nD + 1, dtype=np.int64)
         cmoff = np.zeros(nD + 1, dtype=np.int64)
@@ -240,6 +247,7 @@ class Context:
         return self.upload_designs_raw(off, strips, M0, B0, C0, nw, MBw, cmoff if cm is not None else None, cm)
 
     def upload_designs_raw(self, off, strips, M0, B0, C0, nw, MBw=None, cmoff=None, cm=None):
+        self.resident_generation += 1
         off = np.ascontiguousarray(off, dtype=np.int64)
         nD = len(off) - 1
         strips = _f64(strips)
@@ -264,6 +272,7 @@ class Context:
                       g=9.81, k=None, add_mask=0, MBw=None, cap_off=None, caps=None, Fz_moor=None):
         """Geometry -> resident strip tables (+ statics) on the device: raftx_build_designs.  Member / station / cap
         records as raft_amd/geometry.py packs them.  Returns the strip offsets [nDesign+1]."""
+        self.resident_generation += 1
         member_off = np.ascontiguousarray(member_off, dtype=np.int64)
         station_off = np.ascontiguousarray(station_off, dtype=np.int64)
         nD = len(member_off) - 1
@@ -341,6 +350,7 @@ class Context:
         """Enqueue one sweep crossing on ``slot`` (0 or 1) and return a handle for ``sweep_wait`` (raftx_sweep_submit): the
         call returns once the kernels are queued, so the upload of the next batch can overlap them.  The handle keeps the
         input and output arrays alive; do not modify the inputs before ``sweep_wait``."""
+        self.resident_generation += 1
         nD, nC, nH, nw, inputs, out = self._sweep_prepare(tables, M0, B0, C0, w, k, depth, zeta, beta, pose, Fz_moor, want_Xi, Xi_out)
         (member_off, members, station_off, stations, cap_off, caps, pose, M0, B0, C0, Fz, w, k, zeta, beta) = inputs
         rc = self.rlib.lib.raftx_sweep_submit(self._h, int(slot), nD, _ptr(member_off), _ptr(members), _ptr(station_off), _ptr(stations),
@@ -369,6 +379,7 @@ class Context:
         pipelined over internal streams.  Returns dict(std [nD,nC,6], niter, flags [nD,nC], Xi or None, strip_off [nD+1],
         timing_ms [wall, generation kernels, solve kernels, statistics kernels]).  Unlike build_designs + solve, nothing
         stays resident on this context afterwards."""
+        self.resident_generation += 1
         nD, nC, nH, nw, inputs, out = self._sweep_prepare(tables, M0, B0, C0, w, k, depth, zeta, beta, pose, Fz_moor, want_Xi, Xi_out)
         (member_off, members, station_off, stations, cap_off, caps, pose, M0, B0, C0, Fz, w, k, zeta, beta) = inputs
         rc = self.rlib.lib.raftx_sweep_stats(self._h, nD, _ptr(member_off), _ptr(members), _ptr(station_off), _ptr(stations),
@@ -400,6 +411,7 @@ class Context:
         return out
 
     def upload_cases(self, w, k, depth, rho, g, zeta, beta):
+        self.resident_generation += 1
         w = _f64(w)
         nw = w.shape[0]
         k = _f64(k, (nw,), "k")
@@ -685,6 +697,10 @@ class Context:
         self._check(rc, "raftx_solve_dense")
         return (Xi, Z) if want_Z else Xi
 
+    def synchronize(self):
+        """hipDeviceSynchronize on the context's device"""
+        self._check(self.rlib.lib.raftx_device_synchronize(self._h), "raftx_device_synchronize")
+
     def last_solve_kernel(self):
         """(feature bits, waves per SIMD, run-start cache slots) of the fused kernel the last solve launched."""
         f, w, n = C.c_int(0), C.c_int(0), C.c_int(0)
@@ -713,6 +729,11 @@ class Context:
         self._check(self.rlib.lib.raftx_comm_init(self._h, int(rank), int(world), C.c_char_p(bytes(unique_id))), "raftx_comm_init")
         self._comm = (int(rank), int(world))
 
+    def _need_comm(self, what):
+        if self._comm is None:
+            raise RaftxError("%s: no communicator on this context (comm_init first)" % what)
+        return self._comm
+
     def comm_destroy(self):
         self._check(self.rlib.lib.raftx_comm_destroy(self._h), "raftx_comm_destroy")
         self._comm = None
@@ -728,7 +749,7 @@ class Context:
         """Row blocks of every rank (counts[r] rows each, same trailing shape and dtype) back to back on root."""
         local = np.ascontiguousarray(local)
         counts = np.ascontiguousarray(counts, dtype=np.int64)
-        rank, _ = self._comm
+        rank, _ = self._need_comm("comm_gather_rows")
         if local.shape[0] != counts[rank]:
             raise ValueError("this rank holds %d rows, counts says %d" % (local.shape[0], counts[rank]))
         row_bytes = int(np.prod(local.shape[1:], dtype=np.int64)) * local.dtype.itemsize
@@ -740,7 +761,7 @@ class Context:
     def comm_gather_xi(self, counts, root=0, out=None):
         """The resident responses of every rank's last solve -> [sum(counts), nHead, 6, nw] on root, HBM to HBM."""
         counts = np.ascontiguousarray(counts, dtype=np.int64)
-        rank, _ = self._comm
+        rank, _ = self._need_comm("comm_gather_xi")
         if rank == root:
             shape = (int(counts.sum()), self.nHead, 6, self.nw)
             if out is None:

@@ -15,8 +15,11 @@ Two transports behind one small interface (``rank``, ``world``, ``broadcast_arra
 ``python -m torch.distributed.run`` exports), listening on MASTER_PORT + 101 (RAFTX_COMM_PORT overrides) so that it
 does not collide with the launcher's own store.
 """
+import hashlib
+import hmac
+import io
+import json
 import os
-import pickle
 import socket
 import struct
 import time
@@ -46,30 +49,103 @@ def _recv_msg(sock):
     return _recv_exact(sock, n)
 
 
+# Wire format: arrays travel as .npy bytes (np.save / np.load with allow_pickle=False), dictionaries of arrays and
+# scalars as a JSON header followed by the arrays -- nothing on this channel is ever unpickled.
+def _pack_array(a):
+    f = io.BytesIO()
+    np.save(f, np.ascontiguousarray(a), allow_pickle=False)
+    return f.getvalue()
+
+
+def _unpack_array(b):
+    return np.load(io.BytesIO(b), allow_pickle=False)
+
+
+def _pack_dict(d):
+    head, blobs = {}, []
+    for k, v in d.items():
+        if isinstance(v, np.ndarray):
+            head[k] = ["array", len(blobs)]
+            blobs.append(_pack_array(v))
+        elif isinstance(v, (bool, int, float, str)) or v is None:
+            head[k] = ["scalar", v]
+        elif isinstance(v, (np.integer, np.floating)):
+            head[k] = ["scalar", v.item()]
+        else:
+            raise TypeError("broadcast_arrays carries arrays and plain scalars, not %s (%r)" % (type(v).__name__, k))
+    h = json.dumps(head).encode()
+    return b"".join([struct.pack("<QQ", len(h), len(blobs)), h] + [struct.pack("<Q", len(x)) + x for x in blobs])
+
+
+def _unpack_dict(b):
+    nh, nb = struct.unpack_from("<QQ", b, 0)
+    at = 16
+    head = json.loads(b[at:at + nh].decode())
+    at += nh
+    blobs = []
+    for _ in range(nb):
+        (n,) = struct.unpack_from("<Q", b, at)
+        blobs.append(b[at + 8:at + 8 + n])
+        at += 8 + n
+    return {k: (_unpack_array(blobs[v[1]]) if v[0] == "array" else v[1]) for k, v in head.items()}
+
+
+def _job_token(env, addr, port, world):
+    """Shared by the ranks of one job: RAFTX_COMM_TOKEN if the launcher exports one, else derived from what every rank of
+    the job (and nobody launched separately) sees -- the rendezvous endpoint, the world size and the elastic run id."""
+    tok = env.get("RAFTX_COMM_TOKEN")
+    if tok:
+        return tok.encode()
+    return ("raftx|%s|%s|%s|%s" % (addr, port, world, env.get("TORCHELASTIC_RUN_ID", ""))).encode()
+
+
 class HostComm:
-    """Star topology over TCP: rank 0 holds one socket per peer.  Collectives are rooted at rank 0."""
+    """Star topology over TCP: rank 0 holds one socket per peer.  Collectives are rooted at rank 0.
+
+    A peer proves it belongs to the job (HMAC of a nonce under the job token, ``_job_token``) and announces a rank in
+    1 .. world-1 that nobody else has taken before it is admitted.  ``timeout`` bounds the rendezvous only; collectives
+    block (ranks of a sweep may finish minutes apart -- a resumed rank only loads its shards) unless
+    ``collective_timeout`` / RAFTX_COMM_TIMEOUT sets a bound."""
 
     kind = "host-tcp"
 
-    def __init__(self, rank, world, addr="127.0.0.1", port=29601, timeout=120.0):
+    def __init__(self, rank, world, addr="127.0.0.1", port=29601, timeout=120.0, token=None, collective_timeout=None):
         self.rank, self.world = int(rank), int(world)
         self.peers = {}
         self.sock = None
         if self.world == 1:
             return
+        if not 0 <= self.rank < self.world:
+            raise ValueError("rank %d outside 0..%d" % (self.rank, self.world - 1))
+        token = token if token is not None else _job_token(os.environ, addr, port, self.world)
+        if collective_timeout is None and os.environ.get("RAFTX_COMM_TIMEOUT"):
+            collective_timeout = float(os.environ["RAFTX_COMM_TIMEOUT"])
         if self.rank == 0:
             srv = socket.socket(socket.AF_INET, socket.SOCK_STREAM)
             srv.setsockopt(socket.SOL_SOCKET, socket.SO_REUSEADDR, 1)
             srv.bind((addr, int(port)))
             srv.listen(self.world)
-            srv.settimeout(timeout)
+            t_end = time.time() + timeout
             try:
                 while len(self.peers) < self.world - 1:
+                    srv.settimeout(max(t_end - time.time(), 0.01))
                     conn, _ = srv.accept()
-                    conn.setsockopt(socket.IPPROTO_TCP, socket.TCP_NODELAY, 1)
-                    conn.settimeout(timeout)
-                    (r,) = struct.unpack("<i", _recv_exact(conn, 4))
-                    self.peers[r] = conn
+                    try:
+                        conn.setsockopt(socket.IPPROTO_TCP, socket.TCP_NODELAY, 1)
+                        conn.settimeout(10.0)
+                        nonce = os.urandom(16)
+                        conn.sendall(nonce)
+                        (r,) = struct.unpack("<i", _recv_exact(conn, 4))
+                        mac = _recv_exact(conn, 32)
+                        good = hmac.compare_digest(mac, hmac.new(token, nonce + struct.pack("<i", r), hashlib.sha256).digest())
+                        if not good or not 0 < r < self.world or r in self.peers:
+                            conn.close()                  # a stranger, an out-of-range or a duplicate rank: not admitted
+                            continue
+                        conn.sendall(b"OK")
+                        conn.settimeout(collective_timeout)
+                        self.peers[r] = conn
+                    except (OSError, ConnectionError, struct.error):
+                        conn.close()
             finally:
                 srv.close()
         else:
@@ -84,7 +160,11 @@ class HostComm:
                     time.sleep(0.05)
             s.setsockopt(socket.IPPROTO_TCP, socket.TCP_NODELAY, 1)
             s.settimeout(timeout)
-            s.sendall(struct.pack("<i", self.rank))
+            nonce = _recv_exact(s, 16)
+            s.sendall(struct.pack("<i", self.rank) + hmac.new(token, nonce + struct.pack("<i", self.rank), hashlib.sha256).digest())
+            if _recv_exact(s, 2) != b"OK":
+                raise ConnectionError("rank 0 did not admit rank %d" % self.rank)
+            s.settimeout(collective_timeout)
             self.sock = s
 
     # -------------------------------------------------------------- primitives (root = 0)
@@ -110,23 +190,28 @@ class HostComm:
         self.gather_bytes(b"")
         self.bcast_bytes(b"")
 
+    def all_max(self, x):
+        """max of a float over the ranks, on every rank (the elapsed time of a timed region)"""
+        parts = self.gather_bytes(struct.pack("<d", float(x)))
+        m = struct.pack("<d", max(struct.unpack("<d", p)[0] for p in parts)) if parts is not None else None
+        return struct.unpack("<d", self.bcast_bytes(m))[0]
+
     # -------------------------------------------------------------- the interface the sweep drivers use
     def broadcast_arrays(self, arrays=None):
         """dict of arrays / scalars from rank 0 to every rank"""
-        return pickle.loads(self.bcast_bytes(pickle.dumps(arrays, protocol=4) if self.rank == 0 else None))
+        return _unpack_dict(self.bcast_bytes(_pack_dict(arrays) if self.rank == 0 else None))
 
     def all_counts(self, n):
         c = self.gather_bytes(struct.pack("<q", int(n)))
-        c = pickle.loads(self.bcast_bytes(pickle.dumps([struct.unpack("<q", x)[0] for x in c]) if self.rank == 0 else None))
-        return np.asarray(c, dtype=np.int64)
+        b = self.bcast_bytes(b"".join(c) if self.rank == 0 else None)
+        return np.frombuffer(b, dtype="<i8").astype(np.int64)
 
     def gather_rows(self, local, counts=None):
         """Row blocks (first axis) of every rank concatenated in rank order on rank 0; None elsewhere."""
-        local = np.ascontiguousarray(local)
-        parts = self.gather_bytes(pickle.dumps(local, protocol=4))
+        parts = self.gather_bytes(_pack_array(local))
         if parts is None:
             return None
-        return np.concatenate([pickle.loads(p) for p in parts], axis=0)
+        return np.concatenate([_unpack_array(p) for p in parts], axis=0)
 
     def gather_xi(self, ctx, counts=None, out=None):
         """The resident responses of every rank's last solve, [sum pairs, nHead, 6, nw] on rank 0."""
@@ -139,12 +224,12 @@ class HostComm:
 
     def reduce_sum(self, arr):
         """element-wise sum over ranks on rank 0 (rank order: deterministic); None elsewhere"""
-        parts = self.gather_bytes(pickle.dumps(np.ascontiguousarray(arr), protocol=4))
+        parts = self.gather_bytes(_pack_array(arr))
         if parts is None:
             return None
-        total = pickle.loads(parts[0]).copy()
+        total = _unpack_array(parts[0]).copy()
         for p in parts[1:]:
-            total += pickle.loads(p)
+            total += _unpack_array(p)
         return total
 
     def close(self):
@@ -179,6 +264,9 @@ class RcclComm:
     def barrier(self):
         self.boot.barrier()
 
+    def all_max(self, x):
+        return self.boot.all_max(x)
+
     def all_counts(self, n):
         return self.boot.all_counts(n)
 
@@ -186,15 +274,15 @@ class RcclComm:
         """Structure (names, shapes, dtypes, scalars) over the rendezvous channel, array payloads over RCCL."""
         meta = None
         if self.rank == 0:
-            meta = {k: (np.asarray(v).shape, np.asarray(v).dtype.str) if isinstance(v, np.ndarray) else ("scalar", v)
-                    for k, v in arrays.items()}
-        meta = pickle.loads(self.boot.bcast_bytes(pickle.dumps(meta) if self.rank == 0 else None))
+            meta = {k: [list(np.asarray(v).shape), np.asarray(v).dtype.str] if isinstance(v, np.ndarray)
+                    else ["scalar", v.item() if isinstance(v, (np.integer, np.floating)) else v] for k, v in arrays.items()}
+        meta = json.loads(self.boot.bcast_bytes(json.dumps(meta).encode() if self.rank == 0 else None).decode())
         out = {}
         for k in meta:
             if meta[k][0] == "scalar":
                 out[k] = meta[k][1]
                 continue
-            shape, dt = meta[k]
+            shape, dt = tuple(meta[k][0]), meta[k][1]
             a = np.ascontiguousarray(arrays[k]) if self.rank == 0 else np.empty(shape, dtype=np.dtype(dt))
             self.ctx.comm_broadcast(a, 0)
             out[k] = a
@@ -228,19 +316,23 @@ class RcclComm:
             self.boot.close()
 
 
-def from_env(ctx=None, prefer="rccl", environ=None):
-    """(comm, kind) for this process from the launcher's environment.  prefer="rccl" needs a device context; if the
-    RCCL communicator cannot be created (e.g. a rehearsal with several ranks on ONE GPU, which RCCL refuses), the host
-    transport is used and ``kind`` says so -- the caller reports it, nothing is silent."""
+def from_env(ctx=None, prefer="rccl", environ=None, fallback="error"):
+    """(comm, kind) for this process from the launcher's environment.  prefer="rccl" needs a device context.  If the RCCL
+    communicator cannot be created the ranks fail together (ncclCommInitRank is collective) -- a sweep whose ranks own
+    distinct GPUs must not quietly move its exchange steps onto TCP.  fallback="host" is for rehearsals with several
+    ranks on ONE GPU (which RCCL refuses): the host transport is used and ``kind`` says so."""
     env = os.environ if environ is None else environ
     rank, world = int(env.get("RANK", "0")), int(env.get("WORLD_SIZE", "1"))
     addr = env.get("MASTER_ADDR", "127.0.0.1")
     port = int(env.get("RAFTX_COMM_PORT", int(env.get("MASTER_PORT", "29500")) + 101))
-    boot = HostComm(rank, world, addr, port)
+    boot = HostComm(rank, world, addr, port, token=_job_token(env, addr, port, world))
     if prefer == "rccl" and ctx is not None and ctx.rlib.is_device and world > 1:
         try:
             c = RcclComm(ctx, boot)
             return c, c.kind
-        except Exception as e:          # noqa: BLE001 -- ncclCommInitRank is collective: every rank lands here together
+        except Exception as e:          # noqa: BLE001 -- every rank lands here together
+            if fallback != "host":
+                boot.close()
+                raise RuntimeError("RCCL communicator of rank %d / %d could not be created: %s" % (rank, world, e)) from e
             return boot, "host-tcp (RCCL unavailable: %s)" % str(e)[:120]
     return boot, boot.kind

@@ -2721,6 +2721,12 @@ __global__ void k_debug_math(int n, const double *__restrict__ x, double *__rest
     }
 }
 
+extern "C" int raftx_device_synchronize(raftx_ctx *c) {
+    if (!c) return -1;
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipDeviceSynchronize());
+    return 0;
+}
 extern "C" int raftx_last_solve_kernel(raftx_ctx *c, int *flags, int *waves_per_simd, int *cache_slots) {
     if (!c || c->last_flags < 0) return -1;
     if (flags) *flags = c->last_flags;

@@ -1716,6 +1716,18 @@ __device__ __forceinline__ void assemble_and_solve(const Lds &l, MbRsrc mb, int 
     // inertia coupling m z_g w^2 exceeds m w^2, and LAPACK's first two interchanges are 0<->4 and 1<->3 in ~94 % of
     // the bins of the VolturnUS-S sweep; starting from that arrangement makes the predicated swap blocks of the two
     // largest steps wave-uniformly skippable.
+    if constexpr ((FLAGS & KF_FDEP) != 0) {
+        // All 72 loads of the bin's M(w), B(w) column are issued back to back and land in the registers of the system they
+        // become part of -- one exposed round trip per solve instead of one per row, and no staging registers.
+#pragma unroll
+        for (int r = 0; r < 6; r++)
+#pragma unroll
+            for (int c = 0; c < 6; c++) {
+                const int e = EQ_ORDER[r] * 6 + c;
+                lu.ar[r][c] = mb_load(mb, lane_bytes, e * row);
+                lu.ai[r][c] = mb_load(mb, lane_bytes, (36 + e) * row);
+            }
+    }
 #pragma unroll
     for (int r = 0; r < 6; r++) {
 #pragma unroll
@@ -1723,8 +1735,8 @@ __device__ __forceinline__ void assemble_and_solve(const Lds &l, MbRsrc mb, int 
             const int e = EQ_ORDER[r] * 6 + c;
             double M = l.mat[e], B = l.mat[36 + e];
             if constexpr ((FLAGS & KF_FDEP) != 0) {
-                M += mb_load(mb, lane_bytes, e * row);
-                B += mb_load(mb, lane_bytes, (36 + e) * row);
+                M += lu.ar[r][c];
+                B += lu.ai[r][c];
             }
             B += l.Bd[e];
             lu.ar[r][c] = fma(-w2, M, l.mat[72 + e]);     // Z = -w^2 M + i w B + C  (:1086)

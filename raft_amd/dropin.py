@@ -221,9 +221,12 @@ class Engine:
         nD = len(tables)
         zeta, beta = np.asarray(case_zeta, dtype=float), np.asarray(case_beta, dtype=float)
         key = getattr(self, "_up_key", None)
+        # skip only if nothing else has been uploaded to the (possibly shared) context since: its generation counter
+        # moves with every upload / build / crossing, whoever made it
         if (mats is None and key is not None and key[0] is self.ctx and len(key[1]) == nD
                 and all(a is b for a, b in zip(key[1], tables)) and key[2].shape == zeta.shape
-                and np.array_equal(key[2], zeta) and np.array_equal(key[3], beta)):
+                and np.array_equal(key[2], zeta) and np.array_equal(key[3], beta)
+                and key[4] == self.ctx.resident_generation):
             return
         self._up_key = None
         if mats is None:
@@ -243,7 +246,7 @@ class Engine:
         # (raft_member.py:1899; raft_fowt.py:1857 does not forward rho/g)
         ctx.upload_cases(f0.w, f0.k, f0.depth, 1025.0, 9.81, zeta[None, :, :], beta[None, :])
         if mats is None:
-            self._up_key = (ctx, list(tables), zeta.copy(), beta.copy())
+            self._up_key = (ctx, list(tables), zeta.copy(), beta.copy(), ctx.resident_generation)
 
     # ------------------------------------------------------------------
     def calcHydroExcitation(self, fowt, case, memberList=[]):

@@ -143,12 +143,16 @@ def kay_correction(kay_geom, w, k, beta, h, rho=1025.0, g=9.81, Nm=10):
     k1, k2 = k[:, None], k[None, :]
     up = w2 >= w1
 
-    def omega(k1R, k2R, n):
-        H_N_ii = 0.5 * (hankel1(n - 1, k1R) - hankel1(n + 1, k1R))
-        H_N_jj = 0.5 * np.conj(hankel1(n - 1, k2R) - hankel1(n + 1, k2R))
-        H_Nm1_ii = 0.5 * (hankel1(n, k1R) - hankel1(n + 2, k1R))
-        H_Nm1_jj = 0.5 * np.conj(hankel1(n, k2R) - hankel1(n + 2, k2R))
-        return 1 / (H_Nm1_ii * H_N_jj) - 1 / (H_N_ii * H_Nm1_jj)
+    def dhankel(n, x):
+        """H_n'(x) of the Hankel function of the first kind (recurrence H' = (H_{n-1} - H_{n+1}) / 2)"""
+        return 0.5 * (hankel1(n - 1, x) - hankel1(n + 1, x))
+
+    def omega(x1, x2, n):
+        # the n-th term of the Kim & Yue sum for the pair (k1 R, k2 R): 1/(H'_{n+1}(x1) conj H'_n(x2)) - 1/(H'_n(x1) conj H'_{n+1}(x2))
+        # (raft_member.py:1688-1695); one table of derivatives per argument
+        d1, d1p = dhankel(n, x1), dhankel(n + 1, x1)
+        d2, d2p = np.conj(dhankel(n, x2)), np.conj(dhankel(n + 1, x2))
+        return 1.0 / (d1p * d2) - 1.0 / (d1 * d2p)
 
     cosB, sinB = np.cos(beta), np.sin(beta)
     kd = k1 - k2                                           # k1_k2 = (k1-k2) (cosB, sinB, 0)

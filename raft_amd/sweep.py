@@ -147,7 +147,9 @@ class Sweep:
     # ------------------------------------------------------------------ solve
     def upload(self, ctx):
         ctx.upload_designs_raw(self.off, self.strips, self.M0, self.B0, self.C0, self.nw, self.MBw, self.cmoff, self.cm)
-        ctx.upload_cases(self.w, self.k, self.depth, self.rho, self.g, self.zeta, self.beta)
+        # the dynamic-pressure scale of the wave kinematics is Member.computeWaveKinematics' own default, not the site's
+        # density (see GeometrySweep.upload)
+        ctx.upload_cases(self.w, self.k, self.depth, WAVE_RHO, WAVE_G, self.zeta, self.beta)
         self._upload_bem(ctx)
 
     def solve(self, ctx, upload=True):
@@ -284,6 +286,7 @@ class GeometrySweep(Sweep):
         """The whole boundary crossing in ONE library call (raftx_sweep_stats): descriptors in, motion statistics +
         iteration counts (+ responses) out, with upload / generation / solve / download of consecutive design blocks
         overlapped on the library's internal streams.  Nothing stays resident on ``ctx``."""
+        self._crossing_supported()
         t = self.tables
         r = ctx.sweep_stats(t, self.M0, self.B0, self.C0, self.w, self.k, self.depth, self.zeta, self.beta, self.nIter,
                             self.tol, self.XiStart, pose=self.pose, rho=self.rho, g=self.g, add_mask=self.add_mask,
@@ -295,9 +298,16 @@ class GeometrySweep(Sweep):
         """Streamed form of ``run_crossing`` for back-to-back batches: enqueue this batch on ``slot`` (0 / 1) and return a
         handle; ``wait_crossing`` collects the results.  With two slots the descriptor upload of one batch overlaps the
         kernels of the other (raftx_sweep_submit / raftx_sweep_wait)."""
+        self._crossing_supported()
         return ctx.sweep_submit(slot, self.tables, self.M0, self.B0, self.C0, self.w, self.k, self.depth, self.zeta, self.beta,
                                 self.nIter, self.tol, self.XiStart, pose=self.pose, rho=self.rho, g=self.g, add_mask=self.add_mask,
                                 n_chunk=n_chunk, want_Xi=want_Xi, Xi_out=Xi_out)
+
+    def _crossing_supported(self):
+        """raftx_sweep_stats / raftx_sweep_submit carry neither frequency-dependent matrices nor potential-flow excitation
+        (include/raftx.h): a sweep that has them must go through upload() + solve(), never lose them silently."""
+        if self.MBw is not None or getattr(self, "bem", None) is not None:
+            raise ValueError("the one-call crossing does not carry MBw / BEM excitation: use upload() + solve() (+ run_stats)")
 
     def wait_crossing(self, ctx, handle):
         r = ctx.sweep_wait(handle)
@@ -355,6 +365,42 @@ def run_sharded(sweep, ctx, comm=None, gather=True):
     return {"Xi": Xi.reshape((sweep.n_design, sweep.n_case) + Xi.shape[1:]), "niter": ni, "flags": fl}
 
 
+def shard_fingerprint(sweep, lo, hi):
+    """sha256 over everything the statistics of designs [lo, hi) depend on: their tables (packed strips or member
+    descriptions), matrices, the sea states and the solver settings.  A checkpointed shard is reused only if it matches."""
+    import hashlib
+    h = hashlib.sha256()
+
+    def add(a):
+        if a is None:
+            h.update(b"<none>")
+            return
+        a = np.ascontiguousarray(a)
+        h.update(str(a.dtype).encode() + str(a.shape).encode())
+        h.update(a.tobytes())
+
+    sub = sweep.take(lo, hi)
+    t = getattr(sub, "tables", None)
+    if t is not None:                                            # GeometrySweep: member descriptions
+        for name in ("member_off", "members", "station_off", "stations", "cap_off", "caps"):
+            add(getattr(t, name, None))
+        add(np.array([sub.add_mask]))
+        add(sub.pose)
+    else:
+        add(sub.off)
+        add(sub.strips)
+        add(getattr(sub, "cmoff", None))
+        add(getattr(sub, "cm", None))
+    for a in (sub.M0, sub.B0, sub.C0, sub.MBw, sub.w, sub.k, sub.zeta, sub.beta):
+        add(a)
+    b = getattr(sub, "bem", None)
+    if b is not None:
+        for k_ in ("heads", "X", "hadj", "xy"):
+            add(b[k_])
+    add(np.array([sub.depth, sub.rho, sub.g, sub.tol, sub.XiStart, float(sub.nIter), float(sub.n_case), float(lo), float(hi)]))
+    return h.hexdigest()
+
+
 def run_stats_sharded(sweep, ctx, comm=None, checkpoint_dir=None, shards_per_rank=1):
     """The optimiser-style exchange: every rank solves its designs and only the motion statistics (48 B per design-case)
     and iteration counts are gathered onto rank 0.
@@ -383,9 +429,10 @@ def run_stats_sharded(sweep, ctx, comm=None, checkpoint_dir=None, shards_per_ran
             path = os.path.join(checkpoint_dir, "shard_%05d_of_%05d.npz" % (sid, n_shard))
             lo, hi = shard_bounds(sweep.n_design, sid, n_shard)
             got = None
+            fp = shard_fingerprint(sweep, lo, hi)
             if os.path.exists(path):
-                with np.load(path) as z:
-                    if int(z["lo"]) == lo and int(z["hi"]) == hi:
+                with np.load(path) as z:                         # a shard of another sweep in the same directory is recomputed
+                    if int(z["lo"]) == lo and int(z["hi"]) == hi and "fp" in z.files and str(z["fp"]) == fp:
                         got = {k_: z[k_] for k_ in keys}
             if got is None:
                 if hi > lo:
@@ -395,7 +442,7 @@ def run_stats_sharded(sweep, ctx, comm=None, checkpoint_dir=None, shards_per_ran
                            "flags": np.zeros((0, sweep.n_case), np.int32)}
                 tmp = path + ".tmp.%d" % os.getpid()
                 with open(tmp, "wb") as f:
-                    np.savez(f, lo=lo, hi=hi, **{k_: got[k_] for k_ in keys})
+                    np.savez(f, lo=lo, hi=hi, fp=np.array(fp), **{k_: got[k_] for k_ in keys})
                 os.replace(tmp, path)
             parts.append(got)
         local = {k_: np.concatenate([p[k_] for p in parts], axis=0) for k_ in keys}

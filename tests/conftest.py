@@ -42,6 +42,29 @@ def oracle_ctx(oracle_lib):
     ctx.close()
 
 
+def _gpu_present():
+    """Does raftx_ctx_create find a device?  (cached; the library itself loads anywhere)"""
+    if not hasattr(_gpu_present, "v"):
+        from raft_amd import backend
+        from raft_amd._abi import RaftxError
+        try:
+            backend.hip_library().context(0).close()
+            _gpu_present.v = True
+        except RaftxError as e:
+            if "rc=-3" not in str(e):
+                raise
+            _gpu_present.v = False
+    return _gpu_present.v
+
+
+@pytest.fixture(autouse=True)
+def _skip_device_tests_without_a_gpu(request):
+    """Every @pytest.mark.gpu test -- whatever fixtures it uses -- is skipped on a box without a GPU unless the device
+    tests were asked for (-m gpu / RAFTX_REQUIRE_GPU=1), in which case they run and FAIL."""
+    if request.node.get_closest_marker("gpu") is not None and not request.config._raftx_require_gpu and not _gpu_present():
+        pytest.skip("no GPU on this box (run the device tests with -m gpu on an MI355X)")
+
+
 @pytest.fixture(scope="session")
 def hip_lib():
     """The product library; GPU tests fail (not skip) if it is missing."""

@@ -13,7 +13,7 @@ import pytest
 from raft_amd import sweep as sw
 from raft_amd._abi import EXPORTS
 from tests.conftest import HIP_SO, ORACLE_SO, ROOT
-from tests import standin
+from raft_amd import snapshot as standin
 
 
 def _header_functions():

@@ -10,7 +10,7 @@ import numpy as np
 import pytest
 
 from raft_amd import bem, dropin
-from tests import standin
+from raft_amd import snapshot as standin
 from tests.util import group_rel_err, rel_err, case_from_fixture, load_model_fixture, random_strips, random_matrices, \
     synthetic_cases
 

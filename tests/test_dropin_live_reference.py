@@ -262,13 +262,25 @@ def test_every_solvable_deck_of_the_reference_tree(deck, oracle_ctx):
         return m
 
     case = rh.make_case(Hs=5.0, Tp=11.0, heading=25.0)
-    try:
-        with contextlib.redirect_stdout(io.StringIO()):
-            m_old = build()
-            m_new = copy.deepcopy(m_old)
-            Xi_old = m_old.solveDynamics(copy.deepcopy(case)).copy()
-    except Exception as e:                                    # decks the reference itself cannot run in this container
-        pytest.skip("reference cannot build/solve %s here: %s: %s" % (deck, type(e).__name__, str(e)[:80]))
+    # decks name their coefficient files relative to where upstream runs them from: the deck's own directory (its tests),
+    # the tree's root (its examples)
+    here = os.getcwd()
+    err = None
+    for cwd in (os.path.dirname(os.path.join(rh.REFERENCE_ROOT, deck)), rh.REFERENCE_ROOT):
+        try:
+            os.chdir(cwd)
+            with contextlib.redirect_stdout(io.StringIO()):
+                m_old = build()
+                m_new = copy.deepcopy(m_old)
+                Xi_old = m_old.solveDynamics(copy.deepcopy(case)).copy()
+            err = None
+            break
+        except Exception as e:                                # noqa: BLE001 -- decks the reference itself cannot run in this container
+            err = e
+        finally:
+            os.chdir(here)
+    if err is not None:
+        pytest.skip("reference cannot build/solve %s here: %s: %s" % (deck, type(err).__name__, str(err)[:80]))
     eng = dropin.Engine(oracle_ctx, qtf_backend=_numpy_qtf_backend)
     with contextlib.redirect_stdout(io.StringIO()):
         Xi_new = eng.solveDynamics(m_new, copy.deepcopy(case)).copy()

@@ -7,7 +7,7 @@ import numpy as np
 import pytest
 
 from raft_amd import dropin, geometry as G
-from tests import standin
+from raft_amd import snapshot as standin
 from tests.util import group_rel_err, rel_err, case_from_fixture, load_model_fixture, volturnus_sweep, rao_group_err, \
     psd_group_err
 

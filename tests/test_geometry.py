@@ -12,7 +12,7 @@ import pytest
 
 from raft_amd import geometry as G
 from raft_amd._abi import RaftxError
-from tests import standin
+from raft_amd import snapshot as standin
 from tests.util import rel_err, group_rel_err
 
 FX = standin.load_fixture("geom_units.npz")

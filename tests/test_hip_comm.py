@@ -9,7 +9,7 @@ import numpy as np
 import pytest
 
 from raft_amd import sweep as sw
-from tests import standin
+from raft_amd import snapshot as standin
 
 pytestmark = pytest.mark.gpu
 
@@ -83,18 +83,30 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _rank_main(rank, world, port, n, out_path):
+def _rank_main(rank, world, port, n, out_path, own_gpu=False):
     from raft_amd import backend
     from raft_amd.comm import from_env
-    ctx = backend.hip_library().context(0)                      # both ranks on the one GPU of the box
-    comm, how = from_env(ctx, prefer="rccl", environ={"RANK": str(rank), "WORLD_SIZE": str(world), "MASTER_ADDR": "127.0.0.1",
-                                                      "RAFTX_COMM_PORT": str(port)})
+    # own_gpu: one device per rank, RCCL or nothing; otherwise both ranks on the one GPU of the box (a rehearsal: RCCL
+    # refuses two ranks on one device, the host transport takes over and says so)
+    ctx = backend.hip_library().context(rank if own_gpu else 0)
+    comm, how = from_env(ctx, prefer="rccl", fallback="error" if own_gpu else "host",
+                         environ={"RANK": str(rank), "WORLD_SIZE": str(world), "MASTER_ADDR": "127.0.0.1", "RAFTX_COMM_PORT": str(port)})
     try:
         s, _ = _c3_sweep(n)
+        extra = {}
+        if own_gpu:                                             # every exchange step of raft_amd.comm over real 2-rank RCCL
+            cases = comm.broadcast_arrays({"w": s.w, "zeta": s.zeta, "depth": s.depth} if rank == 0 else None)
+            assert np.array_equal(cases["w"], s.w) and cases["depth"] == s.depth
+            rows = np.arange(12.0).reshape(4, 3) + 100.0 * rank
+            g = comm.gather_rows(rows[:3 + rank])
+            tot = comm.reduce_sum(np.full((5, 2), 1.0 + rank) * (1 + 1j))
+            assert abs(comm.all_max(10.0 + rank) - 11.0) == 0.0
+            if rank == 0:
+                extra = {"rows": g, "tot": tot}
         res = sw.run_sharded(s, ctx, comm)
         st = sw.run_stats_sharded(s, ctx, comm)
         if rank == 0:
-            np.savez(out_path, Xi=res["Xi"], niter=res["niter"], std=st["std"], how=np.array(how))
+            np.savez(out_path, Xi=res["Xi"], niter=res["niter"], std=st["std"], how=np.array(how), **extra)
     finally:
         comm.close()
         ctx.close()
@@ -118,6 +130,38 @@ def test_two_processes_on_one_gpu_shard_and_gather(tmp_path, hip_ctx):
     how = str(got["how"])
     assert how == "rccl" or how.startswith("host-tcp (RCCL unavailable"), how
     print("two ranks on one GPU used:", how)
+    s, _ = _c3_sweep(n)
+    one = s.run(hip_ctx)
+    std = s.run_stats(hip_ctx)["std"]
+    assert np.array_equal(got["Xi"].view(np.uint64), one["Xi"].view(np.uint64))
+    assert np.array_equal(got["niter"], one["niter"]) and np.array_equal(got["std"].view(np.uint64), std.view(np.uint64))
+
+
+def test_two_rank_rccl_over_two_gpus(tmp_path, hip_lib, hip_ctx):
+    """Where two GPUs are visible: two rank processes, one device each, the library's RCCL communicator for real --
+    broadcast, gather_rows, reduce_sum, gather_xi -- and the sharded C3 sweep bit-identical to the single-rank run.
+    Skipped on one-GPU boxes (the build pool's); no host fallback is allowed here."""
+    from raft_amd._abi import RaftxError
+    try:
+        hip_lib.context(1).close()
+    except RaftxError:
+        pytest.skip("one GPU visible")
+    import multiprocessing as mp
+    n = 9
+    out = str(tmp_path / "g2.npz")
+    port = _free_port()
+    mpc = mp.get_context("spawn")
+    procs = [mpc.Process(target=_rank_main, args=(r, 2, port, n, out, True)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(300)
+        assert p.exitcode == 0
+    got = np.load(out)
+    assert str(got["how"]) == "rccl"
+    rows = np.arange(12.0).reshape(4, 3)
+    assert np.array_equal(got["rows"], np.concatenate([rows[:3], rows + 100.0], axis=0))
+    assert np.array_equal(got["tot"], np.full((5, 2), 3.0) * (1 + 1j))
     s, _ = _c3_sweep(n)
     one = s.run(hip_ctx)
     std = s.run_stats(hip_ctx)["std"]

@@ -5,7 +5,7 @@ import pytest
 
 from oracle import qtf_oracle
 from raft_amd import qtf as rq
-from tests import standin
+from raft_amd import snapshot as standin
 from tests.util import rel_err
 
 pytestmark = pytest.mark.gpu

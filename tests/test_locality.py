@@ -60,8 +60,11 @@ def test_oracle_reports_no_locality(oracle_lib):
 
 @pytest.mark.gpu
 def test_device_reports_a_pci_address():
-    pci, node = backend.hip_library().device_locality(0)
-    assert len(pci.split(":")) == 3 and node >= -1
-    rec = locality.bind_near_device(backend.hip_library(), 0)
-    assert rec["pci"] == pci
-    os.sched_setaffinity(0, range(os.cpu_count()))
+    saved = os.sched_getaffinity(0)
+    try:
+        pci, node = backend.hip_library().device_locality(0)
+        assert len(pci.split(":")) == 3 and node >= -1
+        rec = locality.bind_near_device(backend.hip_library(), 0)
+        assert rec["pci"] == pci
+    finally:
+        os.sched_setaffinity(0, saved)

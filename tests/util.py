@@ -2,7 +2,7 @@ import copy
 
 import numpy as np
 
-from tests import standin
+from raft_amd import snapshot as standin
 
 
 from raft_amd.metrics import group_rel_err, rao_group_err, psd_group_err, rel_err     # noqa: F401,E402
@@ -115,7 +115,7 @@ class FakeLines:
 
 def attach_fake_lines(model):
     for f in model.fowtList:
-        if not hasattr(f, "nodeList"):                      # stand-in units (tests/standin.py): PRP-referred rigid body
+        if not hasattr(f, "nodeList"):                      # stand-in units (raft_amd/snapshot.py): PRP-referred rigid body
             node = standin.Obj()
             node.r = np.array([f.x_ref, f.y_ref, 0.0])
             f.nodeList, f.reducedDOF, f.r6 = [node], [[0, 0]], np.r_[node.r, 0.0, 0.0, 0.0]
