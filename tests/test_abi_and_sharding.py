@@ -368,3 +368,84 @@ def test_sharded_statistics_resume_from_shard_files(tmp_path, oracle_lib, monkey
     mp.spawn(_ckpt_rank_main, args=(2, _free_port(), n, ckpt, out, "host"), nprocs=2, join=True)
     got = np.load(out)
     assert np.array_equal(got["std"].view(np.uint64), ref["std"].view(np.uint64)) and np.array_equal(got["niter"], ref["niter"])
+
+
+def test_checkpoint_of_another_sweep_is_not_reused(tmp_path, oracle_lib, monkeypatch):
+    """Same directory, same shard bounds, different sea state / solver settings: the stored shards carry a fingerprint of
+    everything their statistics depend on and are recomputed, not silently returned."""
+    n = 5
+    s, _ = _c3_sweep(n)
+    ctx = oracle_lib.context(0)
+    ckpt = str(tmp_path / "ckpt")
+    first = sw.run_stats_sharded(s, ctx, None, checkpoint_dir=ckpt, shards_per_rank=2)
+    s2, _ = _c3_sweep(n)
+    s2.zeta = s2.zeta * 1.5                                        # another sea state, same shapes
+    ref2 = s2.run_stats(ctx)
+    solved = []
+    orig = sw.Sweep.run_stats
+    monkeypatch.setattr(sw.Sweep, "run_stats", lambda self, c, want_psd=False: (solved.append(self.n_design), orig(self, c, want_psd))[1])
+    second = sw.run_stats_sharded(s2, ctx, None, checkpoint_dir=ckpt, shards_per_rank=2)
+    assert len(solved) == 2                                        # both shards again
+    assert np.array_equal(second["std"].view(np.uint64), ref2["std"].view(np.uint64))
+    assert not np.array_equal(second["std"], first["std"])
+    solved.clear()
+    s3, _ = _c3_sweep(n)
+    s3.zeta = s3.zeta * 1.5
+    s3.nIter += 1                                                  # a solver setting
+    sw.run_stats_sharded(s3, ctx, None, checkpoint_dir=ckpt, shards_per_rank=2)
+    assert len(solved) == 2
+    ctx.close()
+
+
+def test_host_transport_admits_only_the_ranks_of_its_job(tmp_path):
+    """HostComm: a peer with the wrong job token, an out-of-range rank or a rank already taken is not admitted; payloads
+    are .npy / JSON, never pickles; all_max and the dictionary broadcast round-trip."""
+    import threading
+    from raft_amd import comm as rc
+    port = _free_port()
+    res = {}
+
+    def root():
+        c = rc.HostComm(0, 2, "127.0.0.1", port, timeout=20.0, token=b"job-A")
+        res["max"] = c.all_max(1.5)
+        res["d"] = c.broadcast_arrays({"a": np.arange(4.0), "n": 3, "name": "x", "f": 0.25, "none": None})
+        res["rows"] = c.gather_rows(np.zeros((1, 2)))
+        c.close()
+
+    t = threading.Thread(target=root)
+    t.start()
+    import time
+    time.sleep(0.2)
+    with pytest.raises((ConnectionError, OSError)):                # wrong token
+        rc.HostComm(1, 2, "127.0.0.1", port, timeout=2.0, token=b"job-B")
+    with pytest.raises((ConnectionError, OSError, ValueError)):   # out-of-range rank
+        rc.HostComm(5, 2, "127.0.0.1", port, timeout=2.0, token=b"job-A")
+    c1 = rc.HostComm(1, 2, "127.0.0.1", port, timeout=20.0, token=b"job-A")
+    assert c1.all_max(7.25) == 7.25
+    d = c1.broadcast_arrays(None)
+    c1.gather_rows(np.ones((2, 2)))
+    c1.close()
+    t.join(30)
+    assert res["max"] == 7.25 and res["rows"].shape == (3, 2)
+    assert np.array_equal(d["a"], np.arange(4.0)) and d["n"] == 3 and d["name"] == "x" and d["f"] == 0.25 and d["none"] is None
+    with pytest.raises(TypeError):
+        rc._pack_dict({"bad": object()})
+    import inspect
+    assert "pickle" not in inspect.getsource(rc).replace("allow_pickle", "").replace("unpickled", "").replace("pickles", "")
+
+
+def test_crossing_refuses_what_it_cannot_carry(oracle_ctx):
+    """GeometrySweep.run_crossing / submit_crossing with frequency-dependent matrices or BEM excitation raise instead of
+    returning statistics without those terms."""
+    from raft_amd.sweep import GeometrySweep
+
+    class T:                                                      # the check runs before the tables are touched
+        n_design = 2
+    nw = 4
+    z = np.zeros((2, 6, 6))
+    s = GeometrySweep(T(), z, z, z, np.linspace(0.1, 1, nw), np.linspace(0.01, 0.1, nw), 200.0, np.ones((1, 1, nw)), np.zeros((1, 1)),
+                      4, 0.1, MBw=np.zeros((2, 2, 6, 6, nw)))
+    with pytest.raises(ValueError, match="MBw"):
+        s.run_crossing(oracle_ctx)
+    with pytest.raises(ValueError, match="MBw"):
+        s.submit_crossing(oracle_ctx, 0)
