@@ -302,7 +302,11 @@ def main():
                                                              "steps through the library's two slots (raftx_sweep_submit / _wait)")
     ap.add_argument("--no-cpu-baseline", action="store_true", help="skip the oracle leg (cpu_baseline and the all-design check)")
     ap.add_argument("--no-extra-legs", action="store_true", help="skip the legs outside the headline (xi-out, featured sweeps)")
+    ap.add_argument("--profile", action="store_true", help="for runs under rocprofv3: whole-batch launches only (--chunks 1), no isolated / "
+                                                            "extra / oracle legs -- ONE population of k_solve_dynamics launches in the trace")
     args = ap.parse_args()
+    if args.profile:
+        args.chunks, args.no_extra_legs, args.no_cpu_baseline = 1, True, True
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -382,7 +386,7 @@ def main():
     r = res[-1]
     tims = [x["timing_ms"] for x in res]
     isolated = None
-    if stream_steps and rank == 0:                        # the same step as an isolated blocking call (outside the timed region)
+    if stream_steps and rank == 0 and not args.profile:   # the same step as an isolated blocking call (outside the timed region)
         t1 = time.perf_counter()
         for _ in range(5):                                # (no gather here: only this rank runs it)
             sw.run_crossing(ctx, n_chunk=args.chunks, n_worker=args.workers, Xi_out=Xi_pinned[0])

@@ -49,6 +49,11 @@ __device__ __forceinline__ ciptr as_const(const int *p) { return (ciptr)p; }
 // Straight-line sincos / exp for the moderate arguments of this problem
 // (|k xi| < 1e5, |k z| < 700): Cody-Waite reduction + Taylor polynomials whose
 // truncation error is < 2^-55 on the reduced interval.  No tables, no branches.
+// The run-start evaluations are compiled WITHOUT floating-point contraction (explicit fma calls only): a quantity read
+// back from the run-start cache was computed by the sweep that filled it, a quantity that found no slot by the sweep
+// that needs it -- the two must be the same bits, or a batch's results would depend on how many cache slots its
+// launch happened to get (tests/test_geometry.py: chunked crossings are bit-identical to the plain sequence).
+#pragma clang fp contract(off)
 __device__ __forceinline__ void fast_sincos(double x, double &s, double &c) {
     const double two_over_pi = 6.36619772367581382433e-01;
     const double pio2_1 = 1.57079632673412561417e+00;    // first 33 bits of pi/2
@@ -135,6 +140,7 @@ __device__ __forceinline__ double fast_exp(double x) {
     return ldexp(p, (int)fn);
 }
 
+#pragma clang fp contract(fast)
 // ------------------------------------------------------------------ device tables
 // Device strip record (doubles), built at upload from the 32-double ABI record.
 #define DS_N 32
@@ -387,6 +393,7 @@ __device__ __forceinline__ RunStart run_start_of(cdptr rec) {
 __device__ __forceinline__ RunStart run_start_of(ldptr r) {              // staged LDS record
     return {r[12], r[13], r[14], r[15], r[16], r[17]};
 }
+#pragma clang fp contract(off)          // (see fast_sincos)
 // One cacheable evaluation: two doubles per bin in slot `slot` of the run-start cache.  CM 1 (first sweep of a pair):
 // a fresh quantity is computed and stored while slots last; CM 2: read back what was stored, compute the rest.  A
 // quantity met again in the same sweep (fresh == false: a later run with the same step vector) is read back in both
@@ -521,6 +528,7 @@ __device__ __forceinline__ void kin_start(Kin<NB> &K, const RunStart rs, const B
     }
 }
 
+#pragma clang fp contract(fast)
 template <int NB>
 __device__ __forceinline__ void kin_step1(Kin<NB> &K) {
 #pragma unroll
@@ -714,8 +722,11 @@ __device__ __forceinline__ void inertial_excitation(const DevTables &T, cdptr ds
 #ifndef RAFTX_STAGE256
 #define RAFTX_STAGE256 0
 #endif
+#ifndef RAFTX_STAGE128
+#define RAFTX_STAGE128 6     // (0, all through scalar loads, measured at the round-3 kernel: 3.63 ms against 3.33)
+#endif
 static __host__ __device__ constexpr int stage_policy(int nb, int maxt) {
-    return maxt == 64 ? RA_N : (maxt == 128 ? 6 : ((RAFTX_STAGE256 && maxt == 256 && nb == 1) ? RA_N : 0));
+    return maxt == 64 ? RA_N : (maxt == 128 ? RAFTX_STAGE128 : ((RAFTX_STAGE256 && maxt == 256 && nb == 1) ? RA_N : 0));
 }
 
 // Hot per-strip constants of pass A.  Two sources (template STAGE):
