@@ -52,10 +52,9 @@ class Engine:
         fowt.nWaves, fowt.beta, fowt.S, fowt.zeta = nWaves, beta, S, zeta
 
     def _check_supported(self, fowt):
-        for rot in getattr(fowt, "rotorList", []):
-            if rot.r3[2] < 0:
-                raise UnsupportedFOWT("submerged rotors (raft_fowt.py:1861-1883) are not on the device path")
         if _general(fowt):
+            if any(rot.r3[2] < 0 for rot in getattr(fowt, "rotorList", [])):
+                raise UnsupportedFOWT("submerged rotors on a unit with %d reduced DOFs" % fowt.nDOF)
             # more than 6 reduced DOFs (flexible members): strip theory node by node + the dense impedance solve; the
             # potential-flow and second-order branches of such units have no reference deck to pin them on
             if getattr(fowt, "potMod", False) or int(getattr(fowt, "potModMaster", 0)) in (2, 3) \
@@ -187,7 +186,7 @@ class Engine:
         self._bem_excitation_units([fowt])
         return fowt.F_BEM, fowt.F_BEM_fullDOF
 
-    def _bem_excitation_units(self, fowts):
+    def _bem_excitation_units(self, fowts, n_pad=0):
         """F_BEM / F_BEM_fullDOF of the units resident on the context (Model.solveDynamics): one device launch for all
         units that carry potential-flow coefficients (they must share their BEM heading grid, as the units of a farm do)."""
         pot = [bool(getattr(f, "potMod", False) or getattr(f, "potModMaster", 1) in [2, 3]) for f in fowts]
@@ -197,12 +196,12 @@ class Engine:
             if any(h.shape != heads[0].shape or not np.array_equal(h, heads[0]) for h in heads):
                 raise UnsupportedFOWT("units with different BEM heading grids are not on the device path")
             nw = fowts[0].nw
-            X = np.zeros((len(fowts), len(heads[0]), 6, nw), dtype=complex)
+            X = np.zeros((len(fowts) + n_pad, len(heads[0]), 6, nw), dtype=complex)   # n_pad: further designs resident beside the units
             for i, (f, p) in enumerate(zip(fowts, pot)):
                 if p:
                     X[i] = np.asarray(f.X_BEM)[:, :6, :]
-            F6 = self.ctx.bem_excitation(heads[0], X, heading_adjust=[float(getattr(f, "heading_adjust", 0.0)) for f in fowts],
-                                         xy_ref=[[float(f.x_ref), float(f.y_ref)] for f in fowts], fetch=True)
+            F6 = self.ctx.bem_excitation(heads[0], X, heading_adjust=[float(getattr(f, "heading_adjust", 0.0)) for f in fowts] + [0.0] * n_pad,
+                                         xy_ref=[[float(f.x_ref), float(f.y_ref)] for f in fowts] + [[0.0, 0.0]] * n_pad, fetch=True)
         for i, f in enumerate(fowts):
             nFull = int(getattr(f, "nFullDOF", f.nDOF))
             F_full = np.zeros([f.nWaves, nFull, f.nw], dtype=complex)
@@ -248,6 +247,43 @@ class Engine:
         if mats is None:
             self._up_key = (ctx, list(tables), zeta.copy(), beta.copy(), ctx.resident_generation)
 
+    # ------------------------------------------------------------------ submerged rotors (raft_fowt.py:1780-1784,1861-1883)
+    @staticmethod
+    def _rotor_kinematics(fowt):
+        """rot.u / ud / pDyn of every rotor: zeros, and for a submerged rotor the wave kinematics at its hub for every
+        heading (host: one point)."""
+        for rot in getattr(fowt, "rotorList", []):
+            rot.u = np.zeros([fowt.nWaves, 3, fowt.nw], dtype=complex)
+            rot.ud = np.zeros([fowt.nWaves, 3, fowt.nw], dtype=complex)
+            rot.pDyn = np.zeros([fowt.nWaves, fowt.nw], dtype=complex)
+            if rot.r3[2] < 0:
+                for ih in range(fowt.nWaves):
+                    rot.u[ih], rot.ud[ih], rot.pDyn[ih] = waves.wave_kin(fowt.zeta[ih], fowt.beta[ih], fowt.w, fowt.k, fowt.depth, rot.r3)
+
+    @staticmethod
+    def _rotor_tables(fowt):
+        """[table about the PRP, table about the reduced-DOF point] of the submerged rotors' pseudo-strips, or []."""
+        from .strips import pack_rotors
+        t0 = pack_rotors(fowt, with_node_arm=False)
+        return [] if t0 is None else [t0, pack_rotors(fowt, with_node_arm=True)]
+
+    @staticmethod
+    def _add_rotor_excitation(fowt, F_prp, F_red, F_iner, F_full=None):
+        """Upstream adds the rotor force to ONE heading only -- the force loop sits behind the heading loop and uses its
+        last index (raft_fowt.py:1868-1883): reproduced.  F_prp / F_red [nWaves,6,nw]: device excitation of the two rotor
+        tables; F_full: the full-DOF array whose rotor-node slots take the PRP-referred vector."""
+        ih = fowt.nWaves - 1
+        F_iner[ih] += F_red[ih]
+        if F_full is not None:
+            for rot in fowt.rotorList:
+                if rot.r3[2] < 0:
+                    node = rot.nodeList[0]
+                    nd = int(getattr(node, "nDOF", 6))
+                    i0 = int(getattr(node, "id", 0)) * nd
+                    if F_full.shape[1] >= i0 + 6:
+                        # (with several submerged rotors every rotor's slots would need its own table: one is what exists)
+                        F_full[ih, i0:i0 + 6, :] += F_prp[ih]
+
     # ------------------------------------------------------------------
     def calcHydroExcitation(self, fowt, case, memberList=[]):
         """raft_fowt.py:1732-1888.  As upstream, only the members of ``memberList`` contribute strip-theory excitation
@@ -266,10 +302,14 @@ class Engine:
         per_member = []
         if members and all(i is not None for i in ids):
             per_member = [pack_fowt(fowt, [m], own_node=True) for m in members]
-        self._upload([fowt], fowt.zeta, fowt.beta, tables=[fowt._raftx_table] + per_member)
+        self._rotor_kinematics(fowt)
+        rotor_tables = self._rotor_tables(fowt)
+        if sum(1 for rot in getattr(fowt, "rotorList", []) if rot.r3[2] < 0) > 1:
+            raise UnsupportedFOWT("more than one submerged rotor on a unit")
+        self._upload([fowt], fowt.zeta, fowt.beta, tables=[fowt._raftx_table] + per_member + rotor_tables)
         self._up_key = None                                  # more designs than the unit's own table are resident
-        if members:
-            F = self.ctx.excitation()[:, 0]                  # [1 + nMembers, nWaves, 6, nw]
+        if members or rotor_tables:
+            F = self.ctx.excitation()[:, 0]                  # [1 + nMembers (+ 2), nWaves, 6, nw]
         else:
             F = np.zeros([1, fowt.nWaves, 6, nw], dtype=complex)
         fowt.F_hydro_iner = np.ascontiguousarray(F[0])
@@ -281,6 +321,9 @@ class Engine:
                 fowt.F_hydro_iner_fullDOF[:, i0:i0 + 6, :] += F[1 + i]
         elif nFull == 6:
             fowt.F_hydro_iner_fullDOF[:] = F[0]
+        if rotor_tables:                                     # :1861-1883 (device sweep over the rotor's pseudo-strips)
+            n0 = 1 + len(per_member)
+            self._add_rotor_excitation(fowt, F[n0], F[n0 + 1], fowt.F_hydro_iner, fowt.F_hydro_iner_fullDOF)
         # potential-flow part: needs the unit's own table + sea state resident (one design)
         self._upload([fowt], fowt.zeta, fowt.beta)
         fowt.F_BEM, fowt.F_BEM_fullDOF = self._bem_excitation(fowt)
@@ -558,12 +601,32 @@ class Engine:
                              fowt.B_struc + B_gyro, C_lin, None])
 
         f0 = fowts[0]
-        self._upload(fowts, f0.zeta, f0.beta, mats)
+        # submerged rotors (:1861-1883): their pseudo-strip tables ride along as two more designs (benign matrices), the
+        # device evaluates their excitation with everything else and it joins the unit's excitation as part of F_extra
+        rotor_tables = []
+        if any(rot.r3[2] < 0 for f in fowts for rot in getattr(f, "rotorList", [])):
+            if nF > 1:
+                raise UnsupportedFOWT("submerged rotors in an array of units are not on the device path")
+            if sum(1 for rot in f0.rotorList if rot.r3[2] < 0) > 1:
+                raise UnsupportedFOWT("more than one submerged rotor on a unit")
+            self._rotor_kinematics(f0)
+            rotor_tables = self._rotor_tables(f0)
+        if rotor_tables:
+            benign = [np.zeros((6, 6)), np.zeros((6, 6)), np.eye(6), None]
+            self._upload(fowts, f0.zeta, f0.beta, mats + [benign, benign], tables=[f._raftx_table for f in fowts] + rotor_tables)
+        else:
+            self._upload(fowts, f0.zeta, f0.beta, mats)
         ctx = self.ctx
-        self._bem_excitation_units(fowts)                                   # F_BEM(_fullDOF) of every unit (:1788-1849,1887)
+        self._bem_excitation_units(fowts, n_pad=len(rotor_tables))          # F_BEM(_fullDOF) of every unit (:1788-1849,1887)
         F_extras = [fowt.F_BEM + fowt.Fhydro_2nd for fowt in fowts]
-        F_extra = np.array(F_extras)[:, None]                               # [nF,1,nH,6,nw]
         F_iner = ctx.excitation()                                            # side effect of :1002
+        F_rotor = None
+        if rotor_tables:
+            F_rotor = np.zeros_like(F_iner[0, 0])
+            self._add_rotor_excitation(f0, F_iner[nF, 0], F_iner[nF + 1, 0], F_rotor)
+            F_extras[0] = F_extras[0] + F_rotor
+            F_extras += [np.zeros_like(F_rotor), np.zeros_like(F_rotor)]
+        F_extra = np.array(F_extras)[:, None]                               # [nF (+2),1,nH,6,nw]
         internal_qtf = [getattr(f, "potSecOrder", 0) == 1 for f in fowts]
         if any(internal_qtf) and f0.nWaves > 1:
             # upstream's own branch for further headings is broken (fowt.qtf has a single heading slot, raft_fowt.py:2014,
@@ -611,7 +674,7 @@ class Engine:
             raise Exception("Nan detected in response vector Xi.")          # :1098-1099
         nH = f0.nWaves
         for i, fowt in enumerate(fowts):
-            fowt.F_hydro_iner = F_iner[i, 0]
+            fowt.F_hydro_iner = F_iner[i, 0] if F_rotor is None else F_iner[i, 0] + F_rotor
             fowt.Z = out['Z'][i, 0]                                         # :1155
             fowt.B_hydro_drag = out['B_drag'][i, 0]
             fowt._raftx_Fdrag = out['F_wave'][i, 0] - F_iner[i, 0] - F_extras[i]

@@ -311,6 +311,82 @@ def pack_fowt_nodes(fowt, memberList=None):
     return rows, tables
 
 
+# ---------------------------------------------------------------------------- submerged rotors (raft_fowt.py:1861-1883)
+def _sym_couple_basis():
+    """Least-norm map from a general 3x3 matrix M to three symmetric matrices S_x, S_y, S_z with
+    M = [e_x]x S_x + [e_y]x S_y + [e_z]x S_z  ([d]x = cross-product matrix): 9 equations, 18 unknowns."""
+    idx = [(0, 0), (0, 1), (0, 2), (1, 1), (1, 2), (2, 2)]
+    A = np.zeros((9, 18))
+    for kk in range(3):
+        e = np.zeros(3)
+        e[kk] = 1.0
+        X = np.array([[0, -e[2], e[1]], [e[2], 0, -e[0]], [-e[1], e[0], 0]])
+        for j, (a, b) in enumerate(idx):
+            S = np.zeros((3, 3))
+            S[a, b] = S[b, a] = 1.0
+            A[:, kk * 6 + j] = (X @ S).reshape(9)
+    return np.linalg.pinv(A), idx
+
+
+_COUPLE_PINV, _SYM_IDX = _sym_couple_basis()
+
+
+def pack_rotors(fowt, with_node_arm):
+    """Pseudo-strips that make the device's inertial-excitation sweep produce the force of every SUBMERGED rotor
+    (raft_fowt.py:1861-1883):  f3 = I3 ud,  f6 = [f3 ; a x f3 + M3 ud]  with I_hydro = rotateMatrix6(rot.I_hydro, rot.R_q),
+    I3 = I_hydro[:3,:3], M3 = I_hydro[3:,:3], ud the wave acceleration at the hub and a = rot.r3 - r6[:3].
+    The strip form is  f3 = sum_c I_c n_c (n_c . ud)  at an arm: the symmetric I3 is one strip (eigenvectors as its triad,
+    eigenvalues as its inertia scalars); the moment block M3 is written as  sum_k [e_k]x S_k  with symmetric S_k (least
+    norm) and every term is a couple -- two strips at the hub (same kinematics) with arms a +- e_k / 2 and inertia
+    +-S_k: no net force, moment e_k x (S_k ud).  with_node_arm: add the arm of the rotor's node to the reduced-DOF point
+    (what T^T applied to the rotor node's slots of the full-DOF vector adds, :1886-1888); without it the table gives the
+    vector about the PRP that goes into those slots.  Returns a StripTable, or None if no rotor is submerged."""
+    rows = []
+    for rot in getattr(fowt, "rotorList", []):
+        r3 = np.asarray(rot.r3, dtype=float)
+        if not r3[2] < 0:
+            continue
+        R = np.asarray(rot.R_q, dtype=float)
+        I6 = np.asarray(rot.I_hydro, dtype=float)
+        I3 = R @ I6[:3, :3] @ R.T                               # rotateMatrix6 (helpers.py:604-629): mass block ...
+        M3 = (R @ I6[:3, 3:] @ R.T).T                           # ... and the transposed product-of-inertia block
+        if not np.allclose(I3, I3.T, rtol=1e-9, atol=1e-9 * max(np.abs(I3).max(), 1e-300)):
+            raise UnsupportedFOWT("rotor inertial-excitation matrix I_hydro[:3,:3] is not symmetric")
+        arm = r3 - np.asarray(fowt.r6, dtype=float)[:3]
+        if with_node_arm:
+            arm = arm + node_arm(rot.nodeList[0].T)
+
+        def strip(S, a):
+            lam, vec = np.linalg.eigh(0.5 * (S + S.T))
+            rec = np.zeros(NFIELD)
+            rec[F_X:F_X + 3] = r3
+            rec[F_AX:F_AX + 3] = a
+            rec[F_Q:F_Q + 3], rec[F_P1:F_P1 + 3], rec[F_P2:F_P2 + 3] = vec[:, 0], vec[:, 1], vec[:, 2]
+            rec[F_IQ], rec[F_IP1], rec[F_IP2] = lam
+            rec[F_MCF] = -1.0
+            rec[F_MEM], rec[F_IL] = -1.0, len(rows)
+            rows.append(rec)
+
+        strip(I3, arm)
+        # [d]x S has no trace for symmetric S, and neither has the block itself: it is a sum of [r]x I terms of the blade
+        # members (translateMatrix3to6DOF) rotated as a whole
+        if abs(np.trace(M3)) > 1e-9 * max(np.abs(M3).max(), 1e-300):
+            raise UnsupportedFOWT("rotor I_hydro[3:,:3] has a trace: not a sum of translated symmetric inertia matrices")
+        if np.any(M3):
+            coef = _COUPLE_PINV @ M3.reshape(9)
+            for kk in range(3):
+                S = np.zeros((3, 3))
+                for j, (a_, b_) in enumerate(_SYM_IDX):
+                    S[a_, b_] = S[b_, a_] = coef[kk * 6 + j]
+                if not np.any(S):
+                    continue
+                e = np.zeros(3)
+                e[kk] = 0.5
+                strip(S, arm + e)
+                strip(-S, arm - e)
+    return StripTable(np.array(rows)) if rows else None
+
+
 def added_mass_morison(strips):
     """A_hydro_morison [6,6] from a strip table -- raft_member.py:1333-1361 and
     raft/helpers.py:537-560 (translateMatrix3to6DOF), in the folded frame.

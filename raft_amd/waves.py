@@ -123,3 +123,36 @@ def get_psd(xi, dw):
     if xi.ndim == 2:
         return np.sum(0.5 * np.abs(xi) ** 2 / dw, axis=0)
     raise Exception("getPSD must be passed an array with 1 or 2 dimensions.")
+
+
+def wave_kin(zeta0, beta, w, k, h, r, rho=1025.0, g=9.81):
+    """Wave velocity, acceleration and dynamic pressure amplitudes at one point r for one wave train -- helpers.getWaveKin
+    (raft/helpers.py:187-236) over all frequencies at once, with its three depth regimes (k == 0: the "ill-conditioned"
+    constants; k h > 89.4: deep-water exponentials; otherwise the hyperbolic ratios).  u, ud [3,nw], pDyn [nw]."""
+    zeta0 = np.asarray(zeta0)
+    w = np.asarray(w, dtype=float)
+    k = np.asarray(k, dtype=float)
+    nw = len(w)
+    u = np.zeros((3, nw), dtype=complex)
+    ud = np.zeros((3, nw), dtype=complex)
+    pDyn = np.zeros(nw, dtype=complex)
+    z = float(r[2])
+    if z > 0:
+        return u, ud, pDyn
+    zeta = zeta0 * np.exp(-1j * (k * (np.cos(beta) * r[0] + np.sin(beta) * r[1])))
+    zero, deep = k == 0.0, k * h > 89.4
+    mid = ~(zero | deep)
+    sh = np.ones(nw)
+    ch = np.full(nw, 99999.0)
+    cc = np.full(nw, 99999.0)
+    sh[deep] = ch[deep] = np.exp(k[deep] * z)
+    cc[deep] = np.exp(k[deep] * z) + np.exp(-k[deep] * (z + 2.0 * h))
+    sh[mid] = np.sinh(k[mid] * (z + h)) / np.sinh(k[mid] * h)
+    ch[mid] = np.cosh(k[mid] * (z + h)) / np.sinh(k[mid] * h)
+    cc[mid] = np.cosh(k[mid] * (z + h)) / np.cosh(k[mid] * h)
+    u[0] = w * zeta * ch * np.cos(beta)
+    u[1] = w * zeta * ch * np.sin(beta)
+    u[2] = 1j * w * zeta * sh
+    ud[:] = 1j * w * u
+    pDyn[:] = rho * g * zeta * cc
+    return u, ud, pDyn

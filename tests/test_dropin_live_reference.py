@@ -290,3 +290,63 @@ def test_every_solvable_deck_of_the_reference_tree(deck, oracle_ctx):
     for fn, fo in zip(m_new.fowtList, m_old.fowtList):
         assert rel_err(fn.B_hydro_drag, fo.B_hydro_drag) < 1e-9
         assert rel_err(fn.Xi_fullDOF, fo.Xi_fullDOF) < (1e-8 if general else 1e-10)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# submerged rotors (raft_fowt.py:1861-1883).  The reference tree's one deck with an underwater turbine
+# (designs/RM1_Floating.yaml) cannot be built here, so a live VolturnUS-S unit gets its rotor moved below the surface:
+# hub position, rotated 6 x 6 inertial-excitation matrix with a force block and a (traceless) moment block.
+def _sink_rotor(m):
+    from raft.helpers import getH
+    rng = np.random.default_rng(3)
+    for f in m.fowtList:
+        rot = f.rotorList[0]
+        rot.r3 = np.array([f.x_ref + 4.0, f.y_ref - 3.0, -18.0])
+        th = 0.3
+        rot.R_q = np.array([[np.cos(th), -np.sin(th), 0], [np.sin(th), np.cos(th), 0], [0, 0, 1.0]]) @ \
+            np.array([[1, 0, 0], [0, np.cos(0.2), -np.sin(0.2)], [0, np.sin(0.2), np.cos(0.2)]])
+        I3 = np.zeros((3, 3))
+        off = np.zeros((3, 3))
+        for _ in range(3):                                   # three "blades": symmetric inertia translated from their offsets
+            A = rng.normal(size=(3, 3))
+            Ii = 2e5 * (A @ A.T)
+            r = rng.uniform(-20, 20, size=3)
+            I3 += Ii
+            off += Ii @ getH(r)                              # translateMatrix3to6DOF's off-diagonal block (helpers.py:537-560)
+        I6 = np.zeros((6, 6))
+        I6[:3, :3], I6[:3, 3:], I6[3:, :3] = I3, off, off.T
+        rot.I_hydro = I6
+
+
+@pytest.mark.parametrize("headings", [[15.0], [0.0, 40.0]])
+def test_submerged_rotor_excitation_and_solve_match_the_reference(patch, headings):
+    """FOWT.calcHydroExcitation and Model.solveDynamics with a submerged rotor: the device path evaluates the rotor's
+    inertial excitation with pseudo-strips (one for the force block, couples for the moment block) and reproduces
+    upstream's behaviour of adding it to the LAST heading only (:1868-1883), the full-DOF slots of the rotor node and the
+    rotor's own kinematics arrays included."""
+    settings = dict(min_freq=0.01, max_freq=0.3, nIter=8, XiStart=0.1)
+    case = rh.make_case(Hs=5.0, Tp=11.0, heading=headings[0])
+    if len(headings) > 1:
+        case.update(wave_heading=headings, wave_spectrum=["JONSWAP"] * 2, wave_period=[11.0, 9.0], wave_height=[5.0, 2.0],
+                    wave_gamma=[0, 0])
+    m_new, m_old = _model("designs/VolturnUS-S.yaml", settings), _model("designs/VolturnUS-S.yaml", settings)
+    _sink_rotor(m_new)
+    _sink_rotor(m_old)
+    fn, fo = m_new.fowtList[0], m_old.fowtList[0]
+    fn.calcHydroExcitation(copy.deepcopy(case), memberList=fn.memberList)
+    with patch.unpatched():
+        fo.calcHydroExcitation(copy.deepcopy(case), memberList=fo.memberList)
+        base = copy.deepcopy(fo)
+        base.rotorList[0].r3 = np.array([0.0, 0.0, 150.0])   # the same unit with its rotor in the air
+        base.calcHydroExcitation(copy.deepcopy(case), memberList=base.memberList)
+    assert rel_err(fo.F_hydro_iner[-1], base.F_hydro_iner[-1]) > 1e-3          # the rotor term is not small in this set-up
+    assert rel_err(fn.F_hydro_iner, fo.F_hydro_iner) < 1e-10
+    assert rel_err(fn.F_hydro_iner_fullDOF, fo.F_hydro_iner_fullDOF) < 1e-10
+    rn, ro = fn.rotorList[0], fo.rotorList[0]
+    assert rel_err(rn.u, ro.u) < 1e-12 and rel_err(rn.ud, ro.ud) < 1e-12 and rel_err(rn.pDyn, ro.pDyn) < 1e-12
+    Xi_new = m_new.solveDynamics(copy.deepcopy(case)).copy()
+    with patch.unpatched():
+        Xi_old = m_old.solveDynamics(copy.deepcopy(case)).copy()
+    assert Xi_new.shape == Xi_old.shape
+    assert group_rel_err(Xi_new[:len(headings)], Xi_old[:len(headings)]) < 1e-10
+    assert rel_err(fn.F_hydro_iner, fo.F_hydro_iner) < 1e-10 and rel_err(fn.B_hydro_drag, fo.B_hydro_drag) < 1e-9

@@ -665,3 +665,47 @@ def test_featured_sweep_kernels_run_lean_and_match_the_oracle(hip_ctx, oracle_ct
     assert np.array_equal(res[0]["flags"], res[1]["flags"])
     for d in range(len(S_list)):
         assert group_rel_err(res[0]["Xi"][d], res[1]["Xi"][d]) < TOL
+
+
+def test_submerged_rotor_on_the_device(hip_ctx, oracle_ctx):
+    """Submerged rotors (raft_fowt.py:1861-1883) through the drop-in on the GPU: the rotor's pseudo-strips (force block +
+    moment couples) ride along as further designs of the excitation launch and the fused solve takes their excitation
+    as part of F_extra.  Device against the oracle on a stand-in unit whose rotor sits below the surface (the same
+    scenario is pinned on the live reference in tests/test_dropin_live_reference.py); the rotor term must matter."""
+    from raft_amd.snapshot import Obj
+    from raft_amd.rigid import alternator
+    out = {}
+    for name, ctx in (("hip", hip_ctx), ("oracle", oracle_ctx)):
+        fx, model = load_model_fixture("c2_volturnus.npz")
+        f = model.fowtList[0]
+        rng = np.random.default_rng(11)
+        rot = Obj()
+        rot.r3 = np.array([f.x_ref + 6.0, f.y_ref + 2.0, -14.0])
+        th = 0.4
+        rot.R_q = np.array([[np.cos(th), 0, np.sin(th)], [0, 1, 0], [-np.sin(th), 0, np.cos(th)]])
+        I3, off = np.zeros((3, 3)), np.zeros((3, 3))
+        for _ in range(3):
+            A = rng.normal(size=(3, 3))
+            Ii = 3e5 * (A @ A.T)
+            I3 += Ii
+            off += Ii @ alternator(rng.uniform(-15, 15, size=3))
+        rot.I_hydro = np.zeros((6, 6))
+        rot.I_hydro[:3, :3], rot.I_hydro[:3, 3:], rot.I_hydro[3:, :3] = I3, off, off.T
+        node = Obj()
+        node.id, node.nDOF, node.T = 0, 6, np.eye(6)
+        rot.nodeList = [node]
+        f.rotorList = [rot]
+        if not hasattr(f, "r6"):
+            f.r6 = np.r_[f.x_ref, f.y_ref, 0.0, 0.0, 0.0, 0.0]
+        eng = dropin.Engine(ctx)
+        case = case_from_fixture(fx["cases"][0])
+        eng.calcHydroExcitation(f, dict(case), memberList=f.memberList)
+        F1 = f.F_hydro_iner.copy()
+        Xi = eng.solveDynamics(model, dict(case)).copy()
+        out[name] = (F1, Xi, f.F_hydro_iner.copy(), rot.ud.copy())
+        if name == "hip":
+            f.rotorList = []
+            eng.calcHydroExcitation(f, dict(case), memberList=f.memberList)
+            assert rel_err(f.F_hydro_iner[-1], F1[-1]) > 1e-3
+    for a, b in zip(out["hip"], out["oracle"]):
+        assert rel_err(a, b) < TOL
