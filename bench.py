@@ -299,8 +299,13 @@ def main():
     ap.add_argument("--pageable", action="store_true", help="descriptors in ordinary NumPy memory instead of page-locked")
     ap.add_argument("--resident", action="store_true", help="also time the fused kernel alone, whole batch resident in HBM")
     ap.add_argument("--no-stream", action="store_true", help="time isolated blocking calls (raftx_sweep_stats) instead of streaming the "
-                                                             "steps through the library's two slots (raftx_sweep_submit / _wait)")
+                                                             "steps through the library's three slots (raftx_sweep_prepare / _launch / _wait)")
     ap.add_argument("--no-cpu-baseline", action="store_true", help="skip the oracle leg (cpu_baseline and the all-design check)")
+    ap.add_argument("--depth", type=int, default=2, help="batches in flight when the steps are streamed: 2 = submit(i+1), wait(i) (default); "
+                                                      "3 = prepare(i+2), launch(i+1), wait(i): the next batch's tables are generated in the drain "
+                                                      "of the running fused kernel -- measured on one box over 300 steps: 3.73 against 3.71 ms per step "
+                                                      "(the gap between fused kernels shrinks 0.35 -> 0.2 ms, the kernels sharing the drain slow each "
+                                                      "other by as much), so it is not the default")
     ap.add_argument("--no-extra-legs", action="store_true", help="skip the legs outside the headline (xi-out, featured sweeps)")
     ap.add_argument("--profile", action="store_true", help="for runs under rocprofv3: whole-batch launches only (--chunks 1), no isolated / "
                                                             "extra / oracle legs -- ONE population of k_solve_dynamics launches in the trace")
@@ -341,7 +346,7 @@ def main():
         comm, gather_kind = rcomm.from_env(ctx_comm, prefer="rccl", fallback="host" if rehearsal else "error")
 
     stream_steps = not args.no_stream
-    Xi_pinned = [ctx.pinned_empty((nD, 1, 1, 6, nw)) for _ in range(2 if stream_steps else 1)] if args.xi_out else [None, None]
+    Xi_pinned = [ctx.pinned_empty((nD, 1, 1, 6, nw)) for _ in range(3 if stream_steps else 1)] if args.xi_out else [None, None, None]
 
     def gather(r):
         if comm is not None:                              # statistics of every rank onto rank 0 (48 B + 8 B per design-case)
@@ -359,11 +364,25 @@ def main():
         if not stream_steps:
             return [step() for _ in range(n)]
         out = []
-        h = sw.submit_crossing(ctx, 0, n_chunk=args.chunks, Xi_out=Xi_pinned[0]) if n > 0 else None
-        for i in range(n):
-            h_next = sw.submit_crossing(ctx, (i + 1) % 2, n_chunk=args.chunks, Xi_out=Xi_pinned[(i + 1) % 2]) if i + 1 < n else None
-            out.append(gather(sw.wait_crossing(ctx, h)))
-            h = h_next
+        if args.depth == 2:
+            h = sw.submit_crossing(ctx, 0, n_chunk=args.chunks, Xi_out=Xi_pinned[0]) if n > 0 else None
+            for i in range(n):
+                h_next = sw.submit_crossing(ctx, (i + 1) % 2, n_chunk=args.chunks, Xi_out=Xi_pinned[(i + 1) % 2]) if i + 1 < n else None
+                out.append(gather(sw.wait_crossing(ctx, h)))
+                h = h_next
+            return out
+        sub = lambda i: sw.prepare_crossing(ctx, i % 3, n_chunk=args.chunks, Xi_out=Xi_pinned[i % 3])
+        hs = {i: sub(i) for i in range(min(n, 2))}        # batches 0 and 1 uploading, their member passes queued
+        if n > 0:
+            sw.launch_crossing(ctx, hs[0])
+        for i in range(n):                                # batch i solving | i+1 generated in its drain | i+2 uploading
+            if i + 2 < n:
+                hs[i + 2] = sub(i + 2)
+            if i + 1 < n:
+                sw.launch_crossing(ctx, hs[i + 1])
+            out.append(gather(sw.wait_crossing(ctx, hs.pop(i))))
+            if os.environ.get("RAFTX_BENCH_DEBUG"):
+                print("  step %d collected at %.3f ms" % (i, 1e3 * time.perf_counter()), file=sys.stderr)
         return out
 
     def barrier():                                        # device idle on every rank, then all ranks together, both sides
@@ -452,12 +471,12 @@ def main():
     # ---- legs outside the headline (N = 1): SURVEY 8d's literal step (responses downloaded), featured sweeps
     xi_leg = featured = None
     if rank == 0 and world == 1 and not args.no_extra_legs and not args.xi_out:
-        Xp = [ctx.pinned_empty((nD, 1, 1, 6, nw)) for _ in range(2)]
+        Xp = [ctx.pinned_empty((nD, 1, 1, 6, nw)) for _ in range(3)]
 
         def xi_steps(n):
             h = sw.submit_crossing(ctx, 0, n_chunk=args.chunks, Xi_out=Xp[0])
             for i in range(n):
-                hn = sw.submit_crossing(ctx, (i + 1) % 2, n_chunk=args.chunks, Xi_out=Xp[(i + 1) % 2]) if i + 1 < n else None
+                hn = sw.submit_crossing(ctx, (i + 1) % 3, n_chunk=args.chunks, Xi_out=Xp[(i + 1) % 3]) if i + 1 < n else None
                 sw.wait_crossing(ctx, h)
                 h = hn
         xi_steps(3)
@@ -470,7 +489,8 @@ def main():
         for _ in range(3):
             sw.run_crossing(ctx, n_chunk=args.chunks, n_worker=args.workers, Xi_out=Xp[0])
         t_xi_iso = (time.perf_counter() - t1) / 3
-        assert np.array_equal(Xp[0].view(np.uint64), Xi.reshape(Xp[0].shape).view(np.uint64)), "xi-out leg: responses differ from the checked batch"
+        for b_ in Xp:
+            assert np.array_equal(b_.view(np.uint64), Xi.reshape(b_.shape).view(np.uint64)), "xi-out leg: responses differ from the checked batch"
         xi_leg = {"state": "xi out: SURVEY 8d's literal step, H2D of the descriptors + kernels + D2H of Xi (%.0f MB per step, "
                            "page-locked destination)" % (Xp[0].nbytes / 1e6),
                   "streamed_ms_per_step": 1e3 * t_xi, "streamed_dcf_per_s": nD * nw / t_xi,
@@ -505,9 +525,9 @@ def main():
                    "step": "whole solver stage (SURVEY 8d): descriptor H2D + table/statics generation + fused fixed point + "
                            "statistics + D2H of %s; %s"
                            % ("statistics and full responses" if args.xi_out else "statistics (\"stats out\")",
-                              "steps streamed through the library's two slots (raftx_sweep_submit / raftx_sweep_wait): the descriptor "
-                              "upload and member pass of step i+1 run beside the kernels of step i, as consecutive batches of a long "
-                              "sweep do; every step moves its own 66 MB in and its own statistics out" if stream_steps
+                              "steps streamed through the library's slots (raftx_sweep_submit / raftx_sweep_wait): the descriptor upload and "
+                              "member pass of step i+1 run beside the kernels of step i, as consecutive batches of a long sweep do; every "
+                              "step moves its own 66 MB in and its own statistics out" if stream_steps
                               else "isolated blocking calls (raftx_sweep_stats)"),
                    "streamed": bool(stream_steps),
                    "state": "xi out" if args.xi_out else "stats out",

@@ -398,13 +398,28 @@ int raftx_sweep_stats(raftx_ctx *ctx, int nDesign, const int64_t *memberOff, con
                       double *std, int32_t *niter, int32_t *flags, raftx_c128 *Xi, int64_t *stripOffsets,
                       double *timing_ms);
 
-/* The same crossing in two calls, for back-to-back batches of a long sweep (a 10^6-candidate sweep is a stream of 10^4-design
- * batches): raftx_sweep_submit enqueues a whole crossing on slot 0 or 1 and returns as soon as its kernels are queued (the host
- * waits only for the few bytes that size each block's strip table); raftx_sweep_wait blocks until that crossing has finished
- * and fills the output arrays given at submit time (they and the input arrays must stay alive and untouched until then;
- * timing_ms as raftx_sweep_stats, [0] = host time from submit to the end of wait).  With two slots the descriptor upload and
- * member pass of batch i+1 run beside the kernels of batch i -- the upload that bounds an isolated call is
- * hidden.  raftx_sweep_stats is submit + wait on a free slot.  Results are bit-identical either way. */
+/* The same crossing in stages, for back-to-back batches of a long sweep (a 10^6-candidate sweep is a stream of 10^4-design
+ * batches), on slots 0 .. 2:
+ *   raftx_sweep_prepare  enqueues the descriptor upload and the member pass of a batch (returns at once; arguments as
+ *                        raftx_sweep_stats, all arrays must stay alive and untouched until the batch has been waited for);
+ *   raftx_sweep_launch   enqueues table generation, the fused fixed point and the statistics of a prepared batch (the host
+ *                        waits only for the few bytes of the member pass that size the strip tables -- long there when
+ *                        the batch was prepared a step ahead);
+ *   raftx_sweep_wait     blocks until that batch has finished and fills the output arrays given at prepare time
+ *                        (timing_ms as raftx_sweep_stats, [0] = host time from prepare to the end of wait).
+ * raftx_sweep_submit = prepare + launch.  With launch(i+1), prepare(i+2), wait(i) per step, three batches are in flight:
+ * batch i solving; batch i+1 with its member pass done a step earlier, so that its tables are generated in the drain of
+ * batch i's fused kernel and its own fused kernel follows without a gap; batch i+2 uploading.
+ * raftx_sweep_stats is submit + wait on a free slot.  Results are bit-identical whatever the staging. */
+int raftx_sweep_prepare(raftx_ctx *ctx, int slot, int nDesign, const int64_t *memberOff, const double *members,
+                        const int64_t *stationOff, const double *stations, const int64_t *capOff, const double *caps,
+                        const double *pose, double rho, double g, int add_mask,
+                        const double *M0, const double *B0, const double *C0, const double *Fz_moor,
+                        int nCase, int nHead, int nw, const double *w, const double *k, double depth,
+                        double rho_wave, double g_wave, const double *zeta, const double *beta,
+                        int nIter, double tol, double XiStart, int nChunk,
+                        double *std, int32_t *niter, int32_t *flags, raftx_c128 *Xi, int64_t *stripOffsets);
+int raftx_sweep_launch(raftx_ctx *ctx, int slot);
 int raftx_sweep_submit(raftx_ctx *ctx, int slot, int nDesign, const int64_t *memberOff, const double *members,
                        const int64_t *stationOff, const double *stations, const int64_t *capOff, const double *caps,
                        const double *pose, double rho, double g, int add_mask,

@@ -28,6 +28,8 @@ EXPORTS = (
     "raftx_build_designs", "raftx_fetch_strips", "raftx_fetch_statics", "raftx_channel_stats_poly", "raftx_qtf_slender_rows", "raftx_bem_excitation", "raftx_qtf_kay", "raftx_host_alloc", "raftx_host_free", "raftx_device_locality", "raftx_solve_dense",
     "raftx_sweep_stats",
     "raftx_sweep_submit",
+    "raftx_sweep_prepare",
+    "raftx_sweep_launch",
     "raftx_sweep_wait",
     "raftx_comm_unique_id", "raftx_comm_init", "raftx_comm_destroy", "raftx_comm_broadcast", "raftx_comm_gather_rows",
     "raftx_comm_gather_xi", "raftx_comm_reduce_sum",
@@ -129,6 +131,8 @@ class RaftxLib:
         L.raftx_motion_stats.restype = C.c_int
         L.raftx_debug_math.argtypes = [_vp, C.c_int, _vp, _vp, _vp, _vp]
         L.raftx_debug_math.restype = C.c_int
+        L.raftx_sweep_launch.argtypes = [_vp, C.c_int]
+        L.raftx_sweep_launch.restype = C.c_int
         L.raftx_device_synchronize.argtypes = [_vp]
         L.raftx_device_synchronize.restype = C.c_int
         L.raftx_last_solve_kernel.argtypes = [_vp, _vp, _vp, _vp]
@@ -153,6 +157,8 @@ class RaftxLib:
                                          _vp, _vp, _vp, _vp, C.c_int, C.c_int, C.c_int, _vp, _vp, C.c_double, C.c_double, C.c_double,
                                          _vp, _vp, C.c_int, C.c_double, C.c_double, C.c_int, _vp, _vp, _vp, _vp, _vp]
         L.raftx_sweep_submit.restype = C.c_int
+        L.raftx_sweep_prepare.argtypes = L.raftx_sweep_submit.argtypes
+        L.raftx_sweep_prepare.restype = C.c_int
         L.raftx_sweep_wait.argtypes = [_vp, C.c_int, _vp]
         L.raftx_sweep_wait.restype = C.c_int
         L.raftx_comm_unique_id.argtypes = [_vp, _vp]
@@ -344,23 +350,32 @@ class Context:
         inputs = (member_off, members, station_off, stations, cap_off, caps, pose, M0, B0, C0, Fz, w, k, zeta, beta)
         return nD, nC, nH, nw, inputs, out
 
-    def sweep_submit(self, slot, tables, M0, B0, C0, w, k, depth, zeta, beta, nIter, tol=0.01, XiStart=0.1, pose=None,
-                     rho=1025.0, g=9.81, rho_wave=1025.0, g_wave=9.81, add_mask=7, Fz_moor=None, n_chunk=0, want_Xi=False,
-                     Xi_out=None):
-        """Enqueue one sweep crossing on ``slot`` (0 or 1) and return a handle for ``sweep_wait`` (raftx_sweep_submit): the
-        call returns once the kernels are queued, so the upload of the next batch can overlap them.  The handle keeps the
-        input and output arrays alive; do not modify the inputs before ``sweep_wait``."""
+    def sweep_prepare(self, slot, tables, M0, B0, C0, w, k, depth, zeta, beta, nIter, tol=0.01, XiStart=0.1, pose=None,
+                      rho=1025.0, g=9.81, rho_wave=1025.0, g_wave=9.81, add_mask=7, Fz_moor=None, n_chunk=0, want_Xi=False,
+                      Xi_out=None):
+        """First stage of a sweep crossing on ``slot`` (0 .. 2): descriptor upload + member pass are enqueued
+        (raftx_sweep_prepare); returns a handle for ``sweep_launch`` / ``sweep_wait``.  The handle keeps the input and
+        output arrays alive; do not modify the inputs before ``sweep_wait``."""
         self.resident_generation += 1
         nD, nC, nH, nw, inputs, out = self._sweep_prepare(tables, M0, B0, C0, w, k, depth, zeta, beta, pose, Fz_moor, want_Xi, Xi_out)
         (member_off, members, station_off, stations, cap_off, caps, pose, M0, B0, C0, Fz, w, k, zeta, beta) = inputs
-        rc = self.rlib.lib.raftx_sweep_submit(self._h, int(slot), nD, _ptr(member_off), _ptr(members), _ptr(station_off), _ptr(stations),
-                                              _ptr(cap_off), _ptr(caps), _ptr(pose), float(rho), float(g), int(add_mask),
-                                              _ptr(M0), _ptr(B0), _ptr(C0), _ptr(Fz), nC, nH, nw, _ptr(w), _ptr(k), float(depth),
-                                              float(rho_wave), float(g_wave), _ptr(zeta), _ptr(beta), int(nIter), float(tol),
-                                              float(XiStart), int(n_chunk), _ptr(out["std"]), _ptr(out["niter"]), _ptr(out["flags"]),
-                                              _ptr(out["Xi"]), _ptr(out["strip_off"]))
-        self._check(rc, "raftx_sweep_submit")
+        rc = self.rlib.lib.raftx_sweep_prepare(self._h, int(slot), nD, _ptr(member_off), _ptr(members), _ptr(station_off), _ptr(stations),
+                                               _ptr(cap_off), _ptr(caps), _ptr(pose), float(rho), float(g), int(add_mask),
+                                               _ptr(M0), _ptr(B0), _ptr(C0), _ptr(Fz), nC, nH, nw, _ptr(w), _ptr(k), float(depth),
+                                               float(rho_wave), float(g_wave), _ptr(zeta), _ptr(beta), int(nIter), float(tol),
+                                               float(XiStart), int(n_chunk), _ptr(out["std"]), _ptr(out["niter"]), _ptr(out["flags"]),
+                                               _ptr(out["Xi"]), _ptr(out["strip_off"]))
+        self._check(rc, "raftx_sweep_prepare")
         return dict(slot=int(slot), inputs=inputs, out=out)
+
+    def sweep_launch(self, handle):
+        """Second stage: generation, fused fixed point and statistics of a prepared crossing are enqueued (raftx_sweep_launch)."""
+        self._check(self.rlib.lib.raftx_sweep_launch(self._h, int(handle["slot"])), "raftx_sweep_launch")
+        return handle
+
+    def sweep_submit(self, slot, *args, **kw):
+        """prepare + launch in one call (raftx_sweep_submit's two-stage form): returns the handle for ``sweep_wait``."""
+        return self.sweep_launch(self.sweep_prepare(slot, *args, **kw))
 
     def sweep_wait(self, handle):
         """Block until the crossing of ``handle`` (from ``sweep_submit``) has finished; returns its results

@@ -505,6 +505,7 @@ __global__ void __launch_bounds__(256) k_channel_stats_poly(int nCase, int nHead
 }
 
 // ------------------------------------------------------------------ host side
+#define RAFTX_NSLOT 3          // crossings in flight per context: one solving, one generated / generating, one uploading
 // Per-context device-memory pool: every call of the C-ABI needs a handful of device buffers (tables, results, scratch);
 // hipMalloc / hipFree cost 0.1-1 ms each and hipFree synchronises the whole device, which serialises contexts that
 // otherwise overlap copies and kernels on their own streams.  Blocks are rounded up (powers of two below 1 MiB, 1 MiB
@@ -577,6 +578,7 @@ struct raftx_ctx {
     bool owns_stream;                    // false for the block contexts of raftx_sweep_stats (they run on the parent's stream)
     hipEvent_t ev0, ev1;
     hipEvent_t evUp, evTot, evG0, evG1, evG2, evG3, evS0, evS1, evDone;   // build phases, statistics, block finished
+    hipEvent_t evZ;                      // the first kernel of the member pass has run (phase 1)
     hipEvent_t evMem, evRed;             // member pass done (preparation stream) / per-design reduction done (side stream)
     hipStream_t sAux;                    // side stream of the parent ctx: the reductions of the member pass run beside its scans
     BuildJob job;
@@ -584,7 +586,7 @@ struct raftx_ctx {
     size_t pin_n;
     double *pinRes;                      // page-locked landing area of a block's statistics (sweep crossing)
     size_t pinRes_n;
-    hipStream_t sCopy, sPrep, sD2H;      // internal streams of raftx_sweep_stats (created on first use)
+    hipStream_t sCopy, sPrep, sD2H, sGen; // internal streams of raftx_sweep_stats (created on first use)
     std::vector<double> case_key;        // the sea-state tables resident for the sweep crossing (skip identical re-uploads)
     char err[512];
     DevTables T;
@@ -627,12 +629,15 @@ struct raftx_ctx {
     cplx *g_cm;
     void *comm;                          // ncclComm_t of raftx_comm_init (RCCL), or null
     int comm_rank, comm_world;
-    std::vector<raftx_ctx *> workers[2]; // block contexts of the sweep crossings (device buffers, pool, events), per slot, kept for reuse
-    struct SweepSlot *slots;             // [2] crossings in flight (raftx_sweep_submit / raftx_sweep_wait)
+    std::vector<raftx_ctx *> workers[RAFTX_NSLOT]; // block contexts of the sweep crossings (device buffers, pool, events), per slot, kept for reuse
+    struct SweepSlot *slots;             // [RAFTX_NSLOT] crossings in flight (raftx_sweep_prepare / _launch / _wait)
 };
 // One sweep crossing in flight: everything raftx_sweep_wait needs to finish it.
 struct SweepSlot {
-    bool busy = false;
+    bool busy = false;                   // launched (phase 2 enqueued), not yet waited for
+    bool prepared = false;               // phase 1 enqueued (descriptor upload, member pass), not yet launched
+    int nIter = 0;
+    double tol = 0, XiStart = 0, dw = 0;
     std::vector<raftx_ctx *> blk;
     std::vector<int> bnd;
     int nCase = 0, nHead = 0, nw = 0;
@@ -708,7 +713,7 @@ extern "C" int raftx_ctx_create(int device_id, raftx_ctx **out) {
     c->comm_rank = 0;
     c->comm_world = 1;
     c->owns_stream = true;
-    c->slots = new SweepSlot[2];
+    c->slots = new SweepSlot[RAFTX_NSLOT];
     c->pin = nullptr;
     c->pin_n = 0;
     c->pinRes = nullptr;
@@ -716,7 +721,7 @@ extern "C" int raftx_ctx_create(int device_id, raftx_ctx **out) {
     c->sCopy = c->sPrep = c->sD2H = nullptr;
     bool ok = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) == hipSuccess;
     c->sAux = nullptr;
-    for (hipEvent_t *e : {&c->ev0, &c->ev1, &c->evUp, &c->evTot, &c->evG0, &c->evG1, &c->evG2, &c->evG3, &c->evS0,
+    for (hipEvent_t *e : {&c->evZ, &c->ev0, &c->ev1, &c->evUp, &c->evTot, &c->evG0, &c->evG1, &c->evG2, &c->evG3, &c->evS0,
                           &c->evS1, &c->evDone, &c->evMem, &c->evRed})
         ok = ok && hipEventCreate(e) == hipSuccess;
     if (!ok) {
@@ -749,7 +754,7 @@ extern "C" void raftx_ctx_destroy(raftx_ctx *c) {
     }
 #endif
     (void)raftx_comm_destroy(c);
-    for (int sl = 0; sl < 2; sl++) {
+    for (int sl = 0; sl < RAFTX_NSLOT; sl++) {
         for (raftx_ctx *w : c->workers[sl]) raftx_ctx_destroy(w);
         c->workers[sl].clear();
     }
@@ -767,7 +772,7 @@ extern "C" void raftx_ctx_destroy(raftx_ctx *c) {
     if (c->rKay) (void)hipFree(c->rKay);
     if (c->pairList) (void)hipFree(c->pairList);
     free_list(c, c->job.tmp);
-    for (int sl = 0; sl < 2; sl++) {
+    for (int sl = 0; sl < RAFTX_NSLOT; sl++) {
         free_list(c, c->slots[sl].allocs);
         if (c->slots[sl].evXi) (void)hipEventDestroy(c->slots[sl].evXi);
     }
@@ -775,7 +780,7 @@ extern "C" void raftx_ctx_destroy(raftx_ctx *c) {
     c->pool.trim();
     if (c->pin) (void)hipHostFree(c->pin);
     if (c->pinRes) (void)hipHostFree(c->pinRes);
-    for (hipEvent_t e : {c->ev0, c->ev1, c->evUp, c->evTot, c->evG0, c->evG1, c->evG2, c->evG3, c->evS0, c->evS1, c->evDone,
+    for (hipEvent_t e : {c->evZ, c->ev0, c->ev1, c->evUp, c->evTot, c->evG0, c->evG1, c->evG2, c->evG3, c->evS0, c->evS1, c->evDone,
                          c->evMem, c->evRed})
         (void)hipEventDestroy(e);
     if (c->sAux) (void)hipStreamDestroy(c->sAux);
@@ -1028,6 +1033,7 @@ static int build_phase1(raftx_ctx *c, hipStream_t sCopy, hipStream_t sPrep, int 
         A.mdesign_w = (int *)p_[12]; A.mdesign = A.mdesign_w;
     }
     hipLaunchKernelGGL(k_geom_zero, dim3((unsigned)(nDesign / 256 + 1)), dim3(256), 0, sPrep, A);
+    HIPCHK(c, hipEventRecord(c->evZ, sPrep));
     HIPCHK(c, hipEventRecord(c->evG2, sPrep));
     if (nDesign > 0) hipLaunchKernelGGL(k_geom_mdesign, dim3((unsigned)(nDesign / 256 + 1)), dim3(256), 0, sPrep, A);
     A.mgrid = 0;
@@ -2243,7 +2249,14 @@ static std::vector<int> sweep_bounds(int nDesign, long pairs, int nChunk, bool p
     return b;
 }
 
-extern "C" int raftx_sweep_submit(raftx_ctx *c, int slot, int nDesign, const int64_t *memberOff, const double *members,
+// is a crossing of another slot prepared or solving?
+static bool others_in_flight(raftx_ctx *c, int slot) {
+    for (int sl = 0; sl < RAFTX_NSLOT; sl++)
+        if (sl != slot && (c->slots[sl].busy || c->slots[sl].prepared)) return true;
+    return false;
+}
+
+extern "C" int raftx_sweep_prepare(raftx_ctx *c, int slot, int nDesign, const int64_t *memberOff, const double *members,
                                   const int64_t *stationOff, const double *stations, const int64_t *capOff,
                                   const double *caps, const double *pose, double rho, double g, int add_mask,
                                   const double *M0, const double *B0, const double *C0, const double *Fz_moor, int nCase,
@@ -2251,11 +2264,11 @@ extern "C" int raftx_sweep_submit(raftx_ctx *c, int slot, int nDesign, const int
                                   double g_wave, const double *zeta, const double *beta, int nIter, double tol,
                                   double XiStart, int nChunk, double *sd, int32_t *niter, int32_t *flags,
                                   raftx_c128 *Xi, int64_t *stripOffsets) {
-    RangeScope range_("raftx_sweep_submit: H2D + member pass + generation + fused fixed point + statistics (enqueue)");
+    RangeScope range_("raftx_sweep_prepare: descriptor H2D + member pass (enqueue)");
     if (!c) return -1;
-    if (slot < 0 || slot > 1) FAIL(c, "sweep_submit: slot must be 0 or 1");
+    if (slot < 0 || slot >= RAFTX_NSLOT) FAIL(c, "sweep_prepare: slot must be 0 .. %d", RAFTX_NSLOT - 1);
     SweepSlot &S = c->slots[slot];
-    if (S.busy) FAIL(c, "sweep_submit: slot %d is still in flight (call raftx_sweep_wait first)", slot);
+    if (S.busy || S.prepared) FAIL(c, "sweep_prepare: slot %d is still in flight (call raftx_sweep_wait first)", slot);
     if (nDesign < 0 || !memberOff || !members || !stationOff || !stations || !M0 || !B0 || !C0)
         FAIL(c, "sweep_stats: bad design arguments");
     if (nCase < 1 || nHead < 1 || nw < 1 || !w || !k || !zeta || !beta) FAIL(c, "sweep_stats: bad sea-state arguments");
@@ -2276,6 +2289,7 @@ extern "C" int raftx_sweep_submit(raftx_ctx *c, int slot, int nDesign, const int
         HIPCHK(c, hipStreamCreateWithFlags(&c->sCopy, hipStreamNonBlocking));
         HIPCHK(c, hipStreamCreateWithFlags(&c->sPrep, hipStreamNonBlocking));
         HIPCHK(c, hipStreamCreateWithFlags(&c->sD2H, hipStreamNonBlocking));
+        HIPCHK(c, hipStreamCreateWithFlags(&c->sGen, hipStreamNonBlocking));
     }
     if (!S.evXi) HIPCHK(c, hipEventCreate(&S.evXi));
     // sea-state tables: resident on the parent, shared by the blocks of both slots; identical tables are not uploaded
@@ -2296,10 +2310,11 @@ extern "C" int raftx_sweep_submit(raftx_ctx *c, int slot, int nDesign, const int
             c->case_key.swap(key);
         }
     }
-    S.bnd = sweep_bounds(nDesign, (long)nDesign * nCase, nChunk, c->slots[1 - slot].busy);
+    S.bnd = sweep_bounds(nDesign, (long)nDesign * nCase, nChunk, others_in_flight(c, slot));
     const std::vector<int> &bnd = S.bnd;
     const size_t nB = bnd.size() - 1;
-    const double dw = nw > 1 ? w[1] - w[0] : w[0];
+    S.dw = nw > 1 ? w[1] - w[0] : w[0];
+    S.nIter = nIter; S.tol = tol; S.XiStart = XiStart;
     S.blk.assign(nB, nullptr);
     std::vector<raftx_ctx *> &blk = S.blk;
     S.nCase = nCase; S.nHead = nHead; S.nw = nw;
@@ -2339,6 +2354,34 @@ extern "C" int raftx_sweep_submit(raftx_ctx *c, int slot, int nDesign, const int
         }
     }
     S.tl[1] = since();
+    S.prepared = true;
+    return 0;
+}
+
+extern "C" int raftx_sweep_launch(raftx_ctx *c, int slot) {
+    RangeScope range_("raftx_sweep_launch: generation + fused fixed point + statistics (enqueue)");
+    if (!c) return -1;
+    if (slot < 0 || slot >= RAFTX_NSLOT) FAIL(c, "sweep_launch: slot must be 0 .. %d", RAFTX_NSLOT - 1);
+    SweepSlot &S = c->slots[slot];
+    if (!S.prepared) FAIL(c, "sweep_launch: nothing prepared on slot %d (raftx_sweep_prepare first)", slot);
+    HIPCHK(c, hipSetDevice(c->device));
+    auto since = [&]() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - S.t0).count(); };
+    const std::vector<int> &bnd = S.bnd;
+    const size_t nB = bnd.size() - 1;
+    std::vector<raftx_ctx *> &blk = S.blk;
+    const int nCase = S.nCase, nHead = S.nHead, nw = S.nw, nIter = S.nIter;
+    const double tol = S.tol, XiStart = S.XiStart, dw = S.dw;
+    raftx_c128 *Xi = S.Xi;
+    S.prepared = false;
+    auto fail_drain = [&](int rc) {
+        (void)hipDeviceSynchronize();
+        for (raftx_ctx *sub : blk)
+            if (sub) {
+                free_list(sub, sub->job.tmp);
+                sub->job.active = false;
+            }
+        return rc;
+    };
     // ---- phase 2 + fixed point + statistics of every block, in order, on the ctx stream
     int rc_all = 0;
     for (size_t b = 0; b < nB && !rc_all; b++) {
@@ -2348,9 +2391,35 @@ extern "C" int raftx_sweep_submit(raftx_ctx *c, int slot, int nDesign, const int
         // measured (profiles/r02_crossing_splits.txt): generating a block's tables beside the fused kernel of the block
         // before it gains nothing (the block's descriptor upload is what it waits for) and inflates the kernel's timed
         // duration, so the default keeps everything on the ctx stream; RAFTX_SWEEP_GEN_OVERLAP=1 turns the overlap on
-        static const bool gen_overlap = getenv("RAFTX_SWEEP_GEN_OVERLAP") && atoi(getenv("RAFTX_SWEEP_GEN_OVERLAP"));
-        const bool pipelined = c->slots[1 - slot].busy;
-        int rc = build_phase2(sub, nullptr, ((b > 0 || pipelined) && gen_overlap) ? c->sPrep : nullptr);
+        // A crossing launched while another one is solving generates its tables on a stream of its own: its member pass
+        // ran a step earlier (raftx_sweep_prepare), so the tables can be built in the drain of the running fused kernel
+        // and this crossing's fused kernel follows it without a gap.  RAFTX_SWEEP_GEN_OVERLAP=0 keeps the generation on
+        // the ctx stream.
+        static const bool gen_overlap = !(getenv("RAFTX_SWEEP_GEN_OVERLAP") && !atoi(getenv("RAFTX_SWEEP_GEN_OVERLAP")));
+        const bool pipelined = others_in_flight(c, slot);
+        int rc = 0;
+        if (b == 0 && pipelined && gen_overlap) {
+            // When does the generation run?  Enqueued now, beside a fused kernel that has only just started, it would be
+            // dispatched at once and take LDS from that kernel for its whole run (measured: +0.25 ms on the kernel).  A
+            // small kernel queued BEHIND a running big grid is dispatched when that grid has been handed out -- which is
+            // when the member pass of the batch prepared last gets onto the chip: the generation waits for that batch's
+            // first kernel and so runs in the drain, beside that member pass.
+            for (int sl = 0; sl < RAFTX_NSLOT && !rc; sl++)
+                if (sl != slot && c->slots[sl].prepared && !c->slots[sl].blk.empty() && c->slots[sl].blk[0])
+                    if (hipStreamWaitEvent(c->sGen, c->slots[sl].blk[0]->evZ, 0) != hipSuccess) rc = -2;
+        }
+        if (!rc) rc = build_phase2(sub, nullptr, (pipelined && gen_overlap) ? c->sGen : nullptr);
+        if (!rc && b == 0 && pipelined && gen_overlap) {
+            // Small kernels are not dispatched while a big grid is being handed out: whatever of the NEXT batch's member pass
+            // has not finished when this batch's fused kernel starts would wait for the whole kernel and stall that batch's
+            // launch a step later.  So this fused kernel starts only when the member passes already queued (the batches
+            // prepared but not yet launched) are done as well -- they run beside this batch's table generation, in the
+            // drain of the fused kernel before.
+            for (int sl = 0; sl < RAFTX_NSLOT && !rc; sl++)
+                if (sl != slot && c->slots[sl].prepared)
+                    for (raftx_ctx *o : c->slots[sl].blk)
+                        if (o && hipStreamWaitEvent(c->stream, o->evTot, 0) != hipSuccess) rc = -2;
+        }
         if (!rc) {                                                      // the sea states of the parent
             DevTables &T = sub->T;
             const DevTables &P = c->T;
@@ -2414,10 +2483,26 @@ extern "C" int raftx_sweep_submit(raftx_ctx *c, int slot, int nDesign, const int
     return 0;
 }
 
+// raftx_sweep_submit = prepare + launch (the two-call form the earlier rounds had)
+extern "C" int raftx_sweep_submit(raftx_ctx *c, int slot, int nDesign, const int64_t *memberOff, const double *members,
+                                  const int64_t *stationOff, const double *stations, const int64_t *capOff,
+                                  const double *caps, const double *pose, double rho, double g, int add_mask,
+                                  const double *M0, const double *B0, const double *C0, const double *Fz_moor, int nCase,
+                                  int nHead, int nw, const double *w, const double *k, double depth, double rho_wave,
+                                  double g_wave, const double *zeta, const double *beta, int nIter, double tol,
+                                  double XiStart, int nChunk, double *sd, int32_t *niter, int32_t *flags,
+                                  raftx_c128 *Xi, int64_t *stripOffsets) {
+    const int rc = raftx_sweep_prepare(c, slot, nDesign, memberOff, members, stationOff, stations, capOff, caps, pose, rho, g, add_mask,
+                                       M0, B0, C0, Fz_moor, nCase, nHead, nw, w, k, depth, rho_wave, g_wave, zeta, beta, nIter, tol,
+                                       XiStart, nChunk, sd, niter, flags, Xi, stripOffsets);
+    if (rc) return rc;
+    return raftx_sweep_launch(c, slot);
+}
+
 extern "C" int raftx_sweep_wait(raftx_ctx *c, int slot, double *timing_ms) {
     RangeScope range_("raftx_sweep_wait: drain + outputs");
     if (!c) return -1;
-    if (slot < 0 || slot > 1) FAIL(c, "sweep_wait: slot must be 0 or 1");
+    if (slot < 0 || slot >= RAFTX_NSLOT) FAIL(c, "sweep_wait: slot must be 0 .. %d", RAFTX_NSLOT - 1);
     SweepSlot &S = c->slots[slot];
     if (!S.busy) FAIL(c, "sweep_wait: nothing submitted on slot %d", slot);
     HIPCHK(c, hipSetDevice(c->device));
@@ -2476,7 +2561,8 @@ extern "C" int raftx_sweep_stats(raftx_ctx *c, int nDesign, const int64_t *membe
                                  raftx_c128 *Xi, int64_t *stripOffsets, double *timing_ms) {
     if (!c) return -1;
     (void)nWorker;                                     // reserved (earlier versions drove the blocks from several host threads)
-    const int slot = c->slots[0].busy ? 1 : 0;         // a blocking crossing beside a streamed one takes the free slot
+    int slot = 0;                                      // a blocking crossing beside streamed ones takes a free slot
+    while (slot < RAFTX_NSLOT - 1 && (c->slots[slot].busy || c->slots[slot].prepared)) slot++;
     const int rc = raftx_sweep_submit(c, slot, nDesign, memberOff, members, stationOff, stations, capOff, caps, pose, rho, g, add_mask,
                                       M0, B0, C0, Fz_moor, nCase, nHead, nw, w, k, depth, rho_wave, g_wave, zeta, beta, nIter, tol,
                                       XiStart, nChunk, sd, niter, flags, Xi, stripOffsets);

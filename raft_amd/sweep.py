@@ -294,14 +294,23 @@ class GeometrySweep(Sweep):
         self.off = r["strip_off"]
         return r
 
-    def submit_crossing(self, ctx, slot, n_chunk=0, want_Xi=False, Xi_out=None):
-        """Streamed form of ``run_crossing`` for back-to-back batches: enqueue this batch on ``slot`` (0 / 1) and return a
-        handle; ``wait_crossing`` collects the results.  With two slots the descriptor upload of one batch overlaps the
-        kernels of the other (raftx_sweep_submit / raftx_sweep_wait)."""
+    def prepare_crossing(self, ctx, slot, n_chunk=0, want_Xi=False, Xi_out=None):
+        """First stage of the streamed form of ``run_crossing`` for back-to-back batches: enqueue this batch's descriptor
+        upload and member pass on ``slot`` (0 .. 2) and return a handle (raftx_sweep_prepare)."""
         self._crossing_supported()
-        return ctx.sweep_submit(slot, self.tables, self.M0, self.B0, self.C0, self.w, self.k, self.depth, self.zeta, self.beta,
-                                self.nIter, self.tol, self.XiStart, pose=self.pose, rho=self.rho, g=self.g, add_mask=self.add_mask,
-                                n_chunk=n_chunk, want_Xi=want_Xi, Xi_out=Xi_out)
+        return ctx.sweep_prepare(slot, self.tables, self.M0, self.B0, self.C0, self.w, self.k, self.depth, self.zeta, self.beta,
+                                 self.nIter, self.tol, self.XiStart, pose=self.pose, rho=self.rho, g=self.g, add_mask=self.add_mask,
+                                 n_chunk=n_chunk, want_Xi=want_Xi, Xi_out=Xi_out)
+
+    def launch_crossing(self, ctx, handle):
+        """Second stage: table generation, fused fixed point and statistics of a prepared batch (raftx_sweep_launch).  With
+        launch(i+1), prepare(i+2), wait(i) per step a long sweep keeps three batches in flight and the fused kernels of
+        consecutive batches follow each other without a gap."""
+        return ctx.sweep_launch(handle)
+
+    def submit_crossing(self, ctx, slot, n_chunk=0, want_Xi=False, Xi_out=None):
+        """prepare + launch in one call (raftx_sweep_submit); ``wait_crossing`` collects the results."""
+        return self.launch_crossing(ctx, self.prepare_crossing(ctx, slot, n_chunk=n_chunk, want_Xi=want_Xi, Xi_out=Xi_out))
 
     def _crossing_supported(self):
         """raftx_sweep_stats / raftx_sweep_submit carry neither frequency-dependent matrices nor potential-flow excitation

@@ -355,13 +355,47 @@ def check_streamed_crossings(ctx):
     assert nw == got[0]["Xi"].shape[-1]
 
 
+def check_staged_crossings(ctx):
+    """Three crossings in flight through the staged form (raftx_sweep_prepare / _launch / _wait on slots 0 .. 2, in the
+    order prepare(i+2), launch(i+1), wait(i) of a long sweep): every batch equals its blocking raftx_sweep_stats bit for
+    bit.  Misuse is reported: launching a slot that was not prepared, preparing one that is still in flight."""
+    from raft_amd._abi import RaftxError
+    args = (C3["w"], C3["k"], float(C3["depth"]), np.asarray(C3["zeta"])[None], np.asarray(C3["beta"])[None], int(C3["nIter"]), 0.01,
+            float(C3["XiStart"]))
+    sizes = (23, 41, 9, 30, 17)
+    batches = [_c3_crossing_inputs(n) for n in sizes]
+    want = [ctx.sweep_stats(D, M0, B0, C0, *args, want_Xi=True) for D, M0, B0, C0 in batches]
+    with pytest.raises(RaftxError, match="nothing prepared"):
+        ctx.sweep_launch(dict(slot=2))
+    n = len(batches)
+    sub = lambda i: ctx.sweep_prepare(i % 3, *batches[i], *args, want_Xi=True)
+    hs = {0: sub(0), 1: sub(1)}
+    with pytest.raises(RaftxError, match="still in flight"):
+        ctx.sweep_prepare(1, *batches[1], *args)
+    ctx.sweep_launch(hs[0])
+    got = []
+    for i in range(n):
+        if i + 2 < n:
+            hs[i + 2] = sub(i + 2)
+        if i + 1 < n:
+            ctx.sweep_launch(hs[i + 1])
+        got.append(ctx.sweep_wait(hs.pop(i)))
+    for g_, w_ in zip(got, want):
+        for key in ("Xi", "std"):
+            assert np.array_equal(g_[key].view(np.uint64), w_[key].view(np.uint64)), key
+        assert np.array_equal(g_["niter"], w_["niter"]) and np.array_equal(g_["flags"], w_["flags"])
+        assert np.array_equal(g_["strip_off"], w_["strip_off"])
+
+
 def test_oracle_streamed_crossings(oracle_ctx):
     check_streamed_crossings(oracle_ctx)
+    check_staged_crossings(oracle_ctx)
 
 
 @pytest.mark.gpu
 def test_hip_streamed_crossings(hip_ctx):
     check_streamed_crossings(hip_ctx)
+    check_staged_crossings(hip_ctx)
     check_crossing(hip_ctx, 20, 0, 0)                     # the blocking call still works on the same context afterwards
 
 
