@@ -195,6 +195,157 @@ __global__ void __launch_bounds__(256) k_solve_system(int nSys, int nUnit, int n
         if (iw0 + b < nw) Xi[(((size_t)s * nRhs + j) * n + k) * nw + iw0 + b] = Aall[(size_t)b * nel + k * ld + n + j];
     }
 }
+// Register-resident variant for arrays of 2 .. 5 units (n = 12 .. 30 rows): a LANE PER ROW, two systems per wavefront (lanes
+// 0-31 and 32-63), the whole row -- n complex entries plus up to four right-hand sides -- in the lane's registers.  The
+// elimination is unrolled over the column k, so every register index is static; partial pivoting is implicit (the pivot
+// row stays where it is and is marked done: the same pivot rows, multipliers and updates as zgetrf's interchanges,
+// raft_model.py:1191), the pivot search is a five-step argmax within the half-wave, the pivot row reaches the other rows
+// by ds_bpermute.  ~3.5 k instructions per PAIR of systems against ~10 k per system of the LDS-resident kernel above
+// (whose update loop spends its time on index arithmetic).  The augmented systems of a workgroup's four bins are staged
+// through LDS first so that the loads of Z / F stay coalesced along the frequency axis.
+template <typename T>
+__device__ __forceinline__ T half_bcast(T v, int src_lane) {          // value of lane src_lane (per-lane choice)
+    return __shfl(v, src_lane, 64);
+}
+__device__ __forceinline__ cplx half_bcast(cplx v, int src_lane) { return {__shfl(v.re, src_lane, 64), __shfl(v.im, src_lane, 64)}; }
+#define SYSROWS_MAXRHS 4
+template <int NU, bool RESIDENT>
+__global__ void __launch_bounds__(128) k_solve_system_rows(int nSys, int nRhs, int nw, int nCase, const double *__restrict__ w,
+                                                           const cplx *__restrict__ Zblk, const double *__restrict__ Mc,
+                                                           const double *__restrict__ Bc, const double *__restrict__ Cc,
+                                                           const cplx *__restrict__ F, cplx *__restrict__ Xi) {
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    constexpr int N = 6 * NU, NBIN = 4;
+    const int ld = N + nRhs, nel = N * ld;
+    const int ngrp = (nw + NBIN - 1) / NBIN;
+    const int s = blockIdx.x / ngrp, iw0 = (blockIdx.x % ngrp) * NBIN;
+    cplx *Aall = reinterpret_cast<cplx *>(smem);           // [NBIN][N][ld]
+    const int g = RESIDENT ? s / nCase : s, ic = RESIDENT ? s % nCase : 0;
+    for (int t = threadIdx.x; t < nel * NBIN; t += blockDim.x) {          // same assembly as k_solve_system
+        const int e = t / NBIN, b = t % NBIN;
+        const int iw = min(iw0 + b, nw - 1);
+        const double ww = w[iw];
+        const int r = e / ld, c = e % ld;
+        cplx v = {0.0, 0.0};
+        if (c < N) {
+            if (r / 6 == c / 6) {
+                const size_t pair = RESIDENT ? ((size_t)g * NU + r / 6) * nCase + ic : (size_t)s * NU + r / 6;
+                v = Zblk[((pair * 6 + r % 6) * 6 + c % 6) * nw + iw];
+            }
+            const size_t o = (size_t)g * N * N + (size_t)r * N + c;
+            const double m = Mc ? Mc[o] : 0.0, bb = Bc ? Bc[o] : 0.0, kk = Cc ? Cc[o] : 0.0;
+            if (Mc || Bc || Cc) {
+                v.re += -(ww * ww) * m + kk;
+                v.im += ww * bb;
+            }
+        } else if (RESIDENT) {
+            const size_t pair = ((size_t)g * NU + r / 6) * nCase + ic;
+            v = F[((pair * nRhs + (c - N)) * 6 + r % 6) * nw + iw];
+        } else {
+            v = F[(((size_t)s * nRhs + (c - N)) * N + r) * nw + iw];
+        }
+        Aall[(size_t)b * nel + e] = v;
+    }
+    __syncthreads();
+    const int lane = threadIdx.x & 63, half = lane >> 5, r = lane & 31, hbase = lane & 32;
+    const int bin = (threadIdx.x >> 6) * 2 + half;                          // two systems per wave
+    const bool row = r < N;
+    cplx a[N], bR[SYSROWS_MAXRHS];
+    {
+        const cplx *A = Aall + (size_t)bin * nel + (size_t)(row ? r : 0) * ld;
+#pragma unroll
+        for (int c = 0; c < N; c++) a[c] = A[c];
+#pragma unroll
+        for (int j = 0; j < SYSROWS_MAXRHS; j++) bR[j] = j < nRhs ? A[N + j] : cplx{0.0, 0.0};
+    }
+    bool todo = row;                                     // this row has not been a pivot row yet
+    int mystep = N;                                      // elimination step at which it was
+    int prow[N];                                         // pivot row of every step (the same in all lanes of the half)
+#pragma unroll
+    for (int k = 0; k < N; k++) {
+        // pivot: first row of the largest |re| + |im| in column k among the rows still to do (izamax)
+        double best = todo ? fabs(a[k].re) + fabs(a[k].im) : -1.0;
+        if (todo && !(best >= 0.0)) best = 0.0;          // NaN: comparable, so that a pivot is always found
+        int p = todo ? r : N;
+#pragma unroll
+        for (int off = 16; off >= 1; off >>= 1) {
+            const double ov = __shfl_xor(best, off, 64);
+            const int op = __shfl_xor(p, off, 64);
+            if (ov > best || (ov == best && op < p)) {
+                best = ov;
+                p = op;
+            }
+        }
+        prow[k] = p;
+        const int src = hbase + p;
+        const cplx pv = half_bcast(a[k], src);
+        const double dd = pv.re * pv.re + pv.im * pv.im;
+        const cplx inv = {pv.re / dd, -pv.im / dd};
+        const bool mine = todo && r == p;
+        const bool upd = todo && r != p;
+        const cplx l = cmul(a[k], inv);
+#pragma unroll
+        for (int c = k + 1; c < N; c++) {
+            const cplx u = half_bcast(a[c], src);
+            if (upd) a[c] = csub(a[c], cmul(l, u));
+        }
+#pragma unroll
+        for (int j = 0; j < SYSROWS_MAXRHS; j++)
+            if (j < nRhs) {                              // (uniform)
+                const cplx u = half_bcast(bR[j], src);
+                if (upd) bR[j] = csub(bR[j], cmul(l, u));
+            }
+        if (mine) {
+            todo = false;
+            mystep = k;
+            a[k] = inv;                                  // the reciprocal pivot, for the back substitution
+        }
+    }
+    // back substitution in pivot order: x_k from the row that was the pivot of step k, then out of the rows of earlier steps
+#pragma unroll
+    for (int k = N - 1; k >= 0; k--) {
+        const int src = hbase + prow[k];
+#pragma unroll
+        for (int j = 0; j < SYSROWS_MAXRHS; j++)
+            if (j < nRhs) {
+                if (mystep == k) bR[j] = cmul(bR[j], a[k]);
+                const cplx xk = half_bcast(bR[j], src);
+                if (mystep < k) bR[j] = csub(bR[j], cmul(a[k], xk));
+            }
+    }
+    // responses out: unknown k sits in the row that was the pivot of step k
+    if (row && iw0 + bin < nw && mystep < N) {
+#pragma unroll
+        for (int j = 0; j < SYSROWS_MAXRHS; j++)
+            if (j < nRhs) Xi[(((size_t)s * nRhs + j) * N + mystep) * nw + iw0 + bin] = bR[j];
+    }
+}
+static size_t solve_system_rows_lds(int n, int nRhs) { return sizeof(cplx) * (size_t)n * (n + nRhs) * 4; }
+static bool solve_system_rows_ok(int nUnit, int nRhs) {
+    static const char *off = getenv("RAFTX_SYSTEM_LDS");                 // tuning / tests: keep the LDS-resident kernel
+    return !(off && atoi(off)) && nUnit >= 2 && nUnit <= 5 && nRhs >= 1 && nRhs <= SYSROWS_MAXRHS;
+}
+// launches the register-resident kernel; returns false if this shape has none
+template <bool RESIDENT>
+static bool launch_solve_system_rows(hipStream_t st, int nSys, int nUnit, int nRhs, int nw, int nCase, const double *w, const cplx *Z,
+                                     const double *Mc, const double *Bc, const double *Cc, const cplx *F, cplx *X) {
+    if (!solve_system_rows_ok(nUnit, nRhs)) return false;
+    const size_t lds = solve_system_rows_lds(6 * nUnit, nRhs);
+    const dim3 grid((unsigned)((size_t)nSys * ((nw + 3) / 4)));
+#define ROWS_CASE(NU_)                                                                                                  \
+    case NU_:                                                                                                           \
+        if (lds > 64 * 1024)                                                                                            \
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_solve_system_rows<NU_, RESIDENT>),               \
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                            \
+        hipLaunchKernelGGL((k_solve_system_rows<NU_, RESIDENT>), grid, dim3(128), lds, st, nSys, nRhs, nw, nCase, w, Z, Mc, Bc, Cc, F, X); \
+        return true;
+    switch (nUnit) {
+        ROWS_CASE(2) ROWS_CASE(3) ROWS_CASE(4) ROWS_CASE(5)
+    }
+#undef ROWS_CASE
+    return false;
+}
+
 // bins per workgroup and dynamic LDS of k_solve_system
 static int solve_system_shape(int n, int nRhs, size_t *lds) {
     const size_t per = sizeof(cplx) * (size_t)n * (n + nRhs);
@@ -1915,7 +2066,7 @@ extern "C" int raftx_solve_system(raftx_ctx *c, int nSys, int nUnit, int nRhs, i
         if (dC) H2D(c, dC, Cc, nc * sizeof(double));
     }
     HIPCHK(c, hipEventRecord(c->ev0, c->stream));
-    if (nSys) {
+    if (nSys && !launch_solve_system_rows<false>(c->stream, nSys, nUnit, nRhs, nw, 1, dw, dZ, dM, dB, dC, dF, dX)) {
         if (lds > 64 * 1024)
             HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void *>(k_solve_system<false>),
                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -1978,7 +2129,7 @@ extern "C" int raftx_solve_system_resident(raftx_ctx *c, int nUnit, const double
     if (dB) H2D(c, dB, Bc, nc * sizeof(double));
     if (dC) H2D(c, dC, Cc, nc * sizeof(double));
     HIPCHK(c, hipEventRecord(c->ev0, c->stream));
-    if (nSys) {
+    if (nSys && !launch_solve_system_rows<true>(c->stream, nSys, nUnit, nRhs, nw, T.nCase, T.w, c->rZ, dM, dB, dC, c->rFw, dX)) {
         if (lds > 64 * 1024)
             HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void *>(k_solve_system<true>),
                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
