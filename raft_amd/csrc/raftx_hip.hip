@@ -201,126 +201,142 @@ __global__ void __launch_bounds__(256) k_solve_system(int nSys, int nUnit, int n
 // row stays where it is and is marked done: the same pivot rows, multipliers and updates as zgetrf's interchanges,
 // raft_model.py:1191), the pivot search is a five-step argmax within the half-wave, the pivot row reaches the other rows
 // by ds_bpermute.  ~3.5 k instructions per PAIR of systems against ~10 k per system of the LDS-resident kernel above
-// (whose update loop spends its time on index arithmetic).  The augmented systems of a workgroup's four bins are staged
-// through LDS first so that the loads of Z / F stay coalesced along the frequency axis.
+// (whose update loop spends its time on index arithmetic, and whose assembly through LDS is a chain of dependent loads).
 template <typename T>
 __device__ __forceinline__ T half_bcast(T v, int src_lane) {          // value of lane src_lane (per-lane choice)
     return __shfl(v, src_lane, 64);
 }
 __device__ __forceinline__ cplx half_bcast(cplx v, int src_lane) { return {__shfl(v.re, src_lane, 64), __shfl(v.im, src_lane, 64)}; }
 #define SYSROWS_MAXRHS 4
-template <int NU, bool RESIDENT>
-__global__ void __launch_bounds__(128) k_solve_system_rows(int nSys, int nRhs, int nw, int nCase, const double *__restrict__ w,
-                                                           const cplx *__restrict__ Zblk, const double *__restrict__ Mc,
-                                                           const double *__restrict__ Bc, const double *__restrict__ Cc,
-                                                           const cplx *__restrict__ F, cplx *__restrict__ Xi) {
-    extern __shared__ __attribute__((aligned(16))) double smem[];
-    constexpr int N = 6 * NU, NBIN = 4;
-    const int ld = N + nRhs, nel = N * ld;
-    const int ngrp = (nw + NBIN - 1) / NBIN;
-    const int s = blockIdx.x / ngrp, iw0 = (blockIdx.x % ngrp) * NBIN;
-    cplx *Aall = reinterpret_cast<cplx *>(smem);           // [NBIN][N][ld]
-    const int g = RESIDENT ? s / nCase : s, ic = RESIDENT ? s % nCase : 0;
-    for (int t = threadIdx.x; t < nel * NBIN; t += blockDim.x) {          // same assembly as k_solve_system
-        const int e = t / NBIN, b = t % NBIN;
-        const int iw = min(iw0 + b, nw - 1);
-        const double ww = w[iw];
-        const int r = e / ld, c = e % ld;
-        cplx v = {0.0, 0.0};
-        if (c < N) {
-            if (r / 6 == c / 6) {
-                const size_t pair = RESIDENT ? ((size_t)g * NU + r / 6) * nCase + ic : (size_t)s * NU + r / 6;
-                v = Zblk[((pair * 6 + r % 6) * 6 + c % 6) * nw + iw];
-            }
-            const size_t o = (size_t)g * N * N + (size_t)r * N + c;
-            const double m = Mc ? Mc[o] : 0.0, bb = Bc ? Bc[o] : 0.0, kk = Cc ? Cc[o] : 0.0;
-            if (Mc || Bc || Cc) {
-                v.re += -(ww * ww) * m + kk;
-                v.im += ww * bb;
-            }
-        } else if (RESIDENT) {
-            const size_t pair = ((size_t)g * NU + r / 6) * nCase + ic;
-            v = F[((pair * nRhs + (c - N)) * 6 + r % 6) * nw + iw];
-        } else {
-            v = F[(((size_t)s * nRhs + (c - N)) * N + r) * nw + iw];
-        }
-        Aall[(size_t)b * nel + e] = v;
-    }
-    __syncthreads();
-    const int lane = threadIdx.x & 63, half = lane >> 5, r = lane & 31, hbase = lane & 32;
-    const int bin = (threadIdx.x >> 6) * 2 + half;                          // two systems per wave
+template <int NU, int NR, bool RESIDENT>          // NR: right-hand sides compiled in (nRhs <= NR; the rest are zero columns)
+__global__ void __launch_bounds__(64) k_solve_system_rows(int nSys, int nRhs, int nw, int nCase, const double *__restrict__ w,
+                                                          const cplx *__restrict__ Zblk, const double *__restrict__ Mc,
+                                                          const double *__restrict__ Bc, const double *__restrict__ Cc,
+                                                          const cplx *__restrict__ F, cplx *__restrict__ Xi) {
+    constexpr int N = 6 * NU;
+    const int ngrp = (nw + 1) / 2;                       // two bins (systems) per wavefront: lanes 0-31 and 32-63
+    const int s = blockIdx.x / ngrp, lane = threadIdx.x, half = lane >> 5, r = lane & 31, hbase = lane & 32;
+    const int iwr = (blockIdx.x % ngrp) * 2 + half;
+    const bool live = iwr < nw;
+    const int iw = live ? iwr : nw - 1;
     const bool row = r < N;
-    cplx a[N], bR[SYSROWS_MAXRHS];
-    {
-        const cplx *A = Aall + (size_t)bin * nel + (size_t)(row ? r : 0) * ld;
+    const int rr = row ? r : 0;
+    const int g = RESIDENT ? s / nCase : s, ic = RESIDENT ? s % nCase : 0;
+    // The lane's row of [Z_sys | F] (raft_model.py:1164-1191), straight into registers: the unit's own 6 x 6 block from the
+    // per-unit impedances, the coupling terms from the group's matrices (rows are contiguous), everything else zero.  All
+    // loads are independent: one exposed round trip.
+    cplx a[N], bR[NR];
+    const double ww = w[iw];
+    const int u = rr / 6, q = rr % 6;
+    const size_t pair = RESIDENT ? ((size_t)g * NU + u) * nCase + ic : (size_t)s * NU + u;
+    cplx zb[6];
 #pragma unroll
-        for (int c = 0; c < N; c++) a[c] = A[c];
+    for (int c = 0; c < 6; c++) zb[c] = Zblk[((pair * 6 + q) * 6 + c) * nw + iw];
 #pragma unroll
-        for (int j = 0; j < SYSROWS_MAXRHS; j++) bR[j] = j < nRhs ? A[N + j] : cplx{0.0, 0.0};
+    for (int j = 0; j < NR; j++)
+        bR[j] = j < nRhs ? (RESIDENT ? F[((pair * nRhs + j) * 6 + q) * nw + iw] : F[(((size_t)s * nRhs + j) * N + rr) * nw + iw])
+                         : cplx{0.0, 0.0};
+    const size_t o = (size_t)g * N * N + (size_t)rr * N;
+#pragma unroll
+    for (int c = 0; c < N; c++) {
+        const double m = Mc ? Mc[o + c] : 0.0, bb = Bc ? Bc[o + c] : 0.0, kk = Cc ? Cc[o + c] : 0.0;
+        a[c] = {fma(-(ww * ww), m, kk), ww * bb};
     }
+#pragma unroll
+    for (int c = 0; c < N; c++) {                        // the diagonal block of the lane's unit (u is per lane: selects)
+        const int cu = c / 6;
+        const cplx z = zb[c % 6];
+        a[c].re += cu == u ? z.re : 0.0;
+        a[c].im += cu == u ? z.im : 0.0;
+    }
+    // the pivot row of a step travels through a row buffer in LDS: written by the one lane of each half that owns it, read
+    // back by all (same address within a half: a broadcast read)
+    __shared__ __attribute__((aligned(16))) double rowbuf_[2 * 2 * (N + NR)];
+    cplx *rowbuf = reinterpret_cast<cplx *>(rowbuf_) + half * (N + NR);
     bool todo = row;                                     // this row has not been a pivot row yet
     int mystep = N;                                      // elimination step at which it was
-    int prow[N];                                         // pivot row of every step (the same in all lanes of the half)
+    const unsigned rkey = 31u - (unsigned)r;             // ties go to the lower row (izamax takes the first largest)
 #pragma unroll
     for (int k = 0; k < N; k++) {
-        // pivot: first row of the largest |re| + |im| in column k among the rows still to do (izamax)
+        // pivot: the row of the largest |re| + |im| in column k among the rows still to do.  Magnitude and row travel as ONE
+        // key -- the row index replaces the five lowest mantissa bits (a choice between candidates equal to 7e-15 is
+        // arbitrary anyway) -- so that the argmax is a max: four row_shr steps inside the 16-lane rows, one row_bcast
+        // across the two rows of a half, all DPP (no LDS round trips).
         double best = todo ? fabs(a[k].re) + fabs(a[k].im) : -1.0;
         if (todo && !(best >= 0.0)) best = 0.0;          // NaN: comparable, so that a pivot is always found
-        int p = todo ? r : N;
-#pragma unroll
-        for (int off = 16; off >= 1; off >>= 1) {
-            const double ov = __shfl_xor(best, off, 64);
-            const int op = __shfl_xor(p, off, 64);
-            if (ov > best || (ov == best && op < p)) {
-                best = ov;
-                p = op;
-            }
+        double key = todo ? __hiloint2double(__double2hiint(best), (int)(((unsigned)__double2loint(best) & ~31u) | rkey)) : -1.0;
+#define DPP_MAX_(CTRL, ROWMASK)                                                                                          \
+        {                                                                                                               \
+            const int lo_ = __builtin_amdgcn_update_dpp(__double2loint(key), __double2loint(key), CTRL, ROWMASK, 0xf, false); \
+            const int hi_ = __builtin_amdgcn_update_dpp(__double2hiint(key), __double2hiint(key), CTRL, ROWMASK, 0xf, false); \
+            key = fmax(key, __hiloint2double(hi_, lo_));                                                                \
         }
-        prow[k] = p;
-        const int src = hbase + p;
-        const cplx pv = half_bcast(a[k], src);
-        const double dd = pv.re * pv.re + pv.im * pv.im;
-        const cplx inv = {pv.re / dd, -pv.im / dd};
+        DPP_MAX_(0x111, 0xf) DPP_MAX_(0x112, 0xf) DPP_MAX_(0x114, 0xf) DPP_MAX_(0x118, 0xf)     // row_shr:1,2,4,8 -> lane 15 of each row
+        DPP_MAX_(0x142, 0xa)                                                                    // row_bcast:15 into rows 1 and 3 -> lanes 31, 63
+#undef DPP_MAX_
+        const int klo0 = __builtin_amdgcn_readlane(__double2loint(key), 31), klo1 = __builtin_amdgcn_readlane(__double2loint(key), 63);
+        const int p = 31 - ((half ? klo1 : klo0) & 31);
         const bool mine = todo && r == p;
         const bool upd = todo && r != p;
-        const cplx l = cmul(a[k], inv);
+        if (mine) {
+#pragma unroll
+            for (int c = k; c < N; c++) rowbuf[c] = a[c];
+#pragma unroll
+            for (int j = 0; j < NR; j++)
+                rowbuf[N + j] = bR[j];
+        }
+        wave_lds_fence();
+        const cplx pv = rowbuf[k];
+        const double dinv = 1.0 / (pv.re * pv.re + pv.im * pv.im);
+        const cplx inv = {pv.re * dinv, -pv.im * dinv};
+        // rows that are done (or beyond the system) take a zero multiplier: the update itself stays straight-line code
+        const cplx lk = cmul(a[k], inv);
+        const cplx l = {upd ? lk.re : 0.0, upd ? lk.im : 0.0};
 #pragma unroll
         for (int c = k + 1; c < N; c++) {
-            const cplx u = half_bcast(a[c], src);
-            if (upd) a[c] = csub(a[c], cmul(l, u));
+            const cplx u = rowbuf[c];
+            a[c] = csub(a[c], cmul(l, u));
         }
 #pragma unroll
-        for (int j = 0; j < SYSROWS_MAXRHS; j++)
-            if (j < nRhs) {                              // (uniform)
-                const cplx u = half_bcast(bR[j], src);
-                if (upd) bR[j] = csub(bR[j], cmul(l, u));
-            }
+        for (int j = 0; j < NR; j++)
+        {
+            const cplx u = rowbuf[N + j];
+            bR[j] = csub(bR[j], cmul(l, u));
+        }
         if (mine) {
             todo = false;
             mystep = k;
             a[k] = inv;                                  // the reciprocal pivot, for the back substitution
         }
+        wave_lds_fence();                                // the buffer is rewritten in the next step
     }
     // back substitution in pivot order: x_k from the row that was the pivot of step k, then out of the rows of earlier steps
 #pragma unroll
     for (int k = N - 1; k >= 0; k--) {
-        const int src = hbase + prow[k];
+        if (mystep == k) {
 #pragma unroll
-        for (int j = 0; j < SYSROWS_MAXRHS; j++)
-            if (j < nRhs) {
-                if (mystep == k) bR[j] = cmul(bR[j], a[k]);
-                const cplx xk = half_bcast(bR[j], src);
-                if (mystep < k) bR[j] = csub(bR[j], cmul(a[k], xk));
+            for (int j = 0; j < NR; j++) {
+                bR[j] = cmul(bR[j], a[k]);
+                rowbuf[N + j] = bR[j];
             }
+        }
+        wave_lds_fence();
+        const cplx f = {mystep < k ? a[k].re : 0.0, mystep < k ? a[k].im : 0.0};
+#pragma unroll
+        for (int j = 0; j < NR; j++)
+        {
+            const cplx xk = rowbuf[N + j];
+            bR[j] = csub(bR[j], cmul(f, xk));
+        }
+        wave_lds_fence();
     }
     // responses out: unknown k sits in the row that was the pivot of step k
-    if (row && iw0 + bin < nw && mystep < N) {
+    if (row && live && mystep < N) {
 #pragma unroll
-        for (int j = 0; j < SYSROWS_MAXRHS; j++)
-            if (j < nRhs) Xi[(((size_t)s * nRhs + j) * N + mystep) * nw + iw0 + bin] = bR[j];
+        for (int j = 0; j < NR; j++)
+            if (j < nRhs) Xi[(((size_t)s * nRhs + j) * N + mystep) * nw + iw] = bR[j];
     }
 }
-static size_t solve_system_rows_lds(int n, int nRhs) { return sizeof(cplx) * (size_t)n * (n + nRhs) * 4; }
 static bool solve_system_rows_ok(int nUnit, int nRhs) {
     static const char *off = getenv("RAFTX_SYSTEM_LDS");                 // tuning / tests: keep the LDS-resident kernel
     return !(off && atoi(off)) && nUnit >= 2 && nUnit <= 5 && nRhs >= 1 && nRhs <= SYSROWS_MAXRHS;
@@ -330,18 +346,15 @@ template <bool RESIDENT>
 static bool launch_solve_system_rows(hipStream_t st, int nSys, int nUnit, int nRhs, int nw, int nCase, const double *w, const cplx *Z,
                                      const double *Mc, const double *Bc, const double *Cc, const cplx *F, cplx *X) {
     if (!solve_system_rows_ok(nUnit, nRhs)) return false;
-    const size_t lds = solve_system_rows_lds(6 * nUnit, nRhs);
-    const dim3 grid((unsigned)((size_t)nSys * ((nw + 3) / 4)));
-#define ROWS_CASE(NU_)                                                                                                  \
-    case NU_:                                                                                                           \
-        if (lds > 64 * 1024)                                                                                            \
-            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_solve_system_rows<NU_, RESIDENT>),               \
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                            \
-        hipLaunchKernelGGL((k_solve_system_rows<NU_, RESIDENT>), grid, dim3(128), lds, st, nSys, nRhs, nw, nCase, w, Z, Mc, Bc, Cc, F, X); \
-        return true;
-    switch (nUnit) {
-        ROWS_CASE(2) ROWS_CASE(3) ROWS_CASE(4) ROWS_CASE(5)
+    const dim3 grid((unsigned)((size_t)nSys * ((nw + 1) / 2)));
+    const int nr = nRhs == 1 ? 1 : (nRhs == 2 ? 2 : 4);
+#define ROWS_CASE(NU_, NR_)                                                                                             \
+    if (nUnit == NU_ && nr == NR_) {                                                                                    \
+        hipLaunchKernelGGL((k_solve_system_rows<NU_, NR_, RESIDENT>), grid, dim3(64), 0, st, nSys, nRhs, nw, nCase, w, Z, Mc, Bc, Cc, F, X); \
+        return true;                                                                                                    \
     }
+    ROWS_CASE(2, 1) ROWS_CASE(2, 2) ROWS_CASE(2, 4) ROWS_CASE(3, 1) ROWS_CASE(3, 2) ROWS_CASE(3, 4)
+    ROWS_CASE(4, 1) ROWS_CASE(4, 2) ROWS_CASE(4, 4) ROWS_CASE(5, 1) ROWS_CASE(5, 2) ROWS_CASE(5, 4)
 #undef ROWS_CASE
     return false;
 }
