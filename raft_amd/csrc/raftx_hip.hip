@@ -2178,8 +2178,9 @@ extern "C" int raftx_qtf_kay(raftx_ctx *c, int nSet, int nw2, const double *w2, 
     double *dw = sc.alloc<double>(nw2), *dk = sc.alloc<double>(nw2), *dI = sc.alloc<double>(nItem * QK_N),
            *dB = sc.alloc<double>(nSet);
     int64_t *dio = sc.alloc<int64_t>(nSet + 1);
-    cplx *dH = sc.alloc<cplx>(nItem * KAY_MAXN * nw2);
-    if (nSet && (!dw || !dk || !dB || !dio || (nItem && (!dI || !dH)))) FAIL(c, "qtf_kay: device allocation failed");
+    cplx *dH = sc.alloc<cplx>(nItem * KAY_ROWS * nw2);
+    double *dq = sc.alloc<double>(nw2);
+    if (nSet && (!dw || !dk || !dB || !dio || !dq || (nItem && (!dI || !dH)))) FAIL(c, "qtf_kay: device allocation failed");
     if (nSet) {
         H2D(c, dw, w2, nw2 * sizeof(double));
         H2D(c, dk, k2, nw2 * sizeof(double));
@@ -2190,9 +2191,9 @@ extern "C" int raftx_qtf_kay(raftx_ctx *c, int nSet, int nw2, const double *w2, 
     }
     HIPCHK(c, hipEventRecord(c->ev0, c->stream));
     if (nSet) {
-        if (nItem) hipLaunchKernelGGL(k_kay_tables, dim3((unsigned)nItem), dim3(128), 0, c->stream, nw2, Nm + 2, dk, dI, dH);
-        hipLaunchKernelGGL(k_kay_pairs, dim3((unsigned)((size_t)nSet * nw2)), dim3(nw2 > 64 ? 128 : 64), 0, c->stream, nw2, Nm,
-                           depth, rho, g, dw, dk, dio, dI, dB, dH, c->rKay);
+        if (nItem) hipLaunchKernelGGL(k_kay_tables, dim3((unsigned)nItem), dim3(128), 0, c->stream, nw2, Nm + 2, nSet, depth, dk, dio, dI, dB, dH, dq);
+        if (nItem) hipLaunchKernelGGL(k_kay_pairs, dim3((unsigned)((size_t)nSet * nw2)), dim3(nw2 > 64 ? 128 : 64), 0, c->stream, nw2, Nm,
+                                      depth, rho, g, dw, dk, dio, dI, dH, dq, c->rKay);
     }
     if (finish_timed(c)) return -2;
     if (nSet && kay_out) D2H(c, kay_out, c->rKay, nq * sizeof(cplx));

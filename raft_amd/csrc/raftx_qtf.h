@@ -461,11 +461,26 @@ __global__ void __launch_bounds__(256) k_qtf_force(int nSet, int nw2, const doub
 //   k_kay_pairs  : per (set, w1 row) threads over w2 >= w1: the n-sums for every item of the set
 #define QK_N 12
 #define KAY_MAXN 12          // Nm + 2 <= 12 stored orders (Nm = 10 upstream)
-
-__global__ void __launch_bounds__(128) k_kay_tables(int nw, int nOrd, const double *__restrict__ k,
-                                                    const double *__restrict__ items, cplx *__restrict__ HK) {
+#define KAY_ROWS (KAY_MAXN + 3)
+// Everything of the correction that depends on ONE frequency is tabulated per (item, frequency), so that the pair loop has
+// no transcendental function and no division (it used to evaluate four sinh, two cosh, two tanh, two sqrt, a sincos and 22
+// IEEE divisions per item and pair -- on the C5 deck the correction cost more than the QTF it corrects):
+//   rows 0 .. Nm+1   1 / H'_n(k R)                                  (the pair needs Im of products of these)
+//   row KAY_MAXN     (e^{k (z1 + h)}, e^{-k (z1 + h)})              sinh((k1 +- k2)(z + h)) = (E1 E2^{+-1} - 1 / ...) / 2 as
+//   row KAY_MAXN+1   (e^{k (z2 + h)}, e^{-k (z2 + h)})              products of these: no cancellation between large terms
+//   row KAY_MAXN+2   e^{-i k xi},  xi = cos(beta) x + sin(beta) y   (phase factor of the pair = product with a conjugate)
+// and per frequency alone  kq = k h / (sqrt(k h tanh k h) cosh k h)  (raft_member.py:1757-1760: "pre / cosh / cosh").
+__global__ void __launch_bounds__(128) k_kay_tables(int nw, int nOrd, int nSet, double h, const double *__restrict__ k,
+                                                    const int64_t *__restrict__ ioff, const double *__restrict__ items,
+                                                    const double *__restrict__ beta, cplx *__restrict__ HK,
+                                                    double *__restrict__ kq) {
     const int item = blockIdx.x;
-    const double R = items[(size_t)item * QK_N];
+    const double *rec = items + (size_t)item * QK_N;
+    const double R = rec[0];
+    int set = 0;
+    while (set + 1 < nSet && ioff[set + 1] <= item) set++;
+    const double xi = cos(beta[set]) * rec[10] + sin(beta[set]) * rec[11];
+    cplx *H = HK + (size_t)item * KAY_ROWS * nw;
     for (int i = threadIdx.x; i < nw; i += blockDim.x) {
         const double x = k[i] * R;
         // H_n = J_n + i Y_n for n = -1 .. nOrd; H_{-1} = -H_1
@@ -473,9 +488,20 @@ __global__ void __launch_bounds__(128) k_kay_tables(int nw, int nOrd, const doub
         double jc = j0(x), yc = y0(x);                // n
         for (int n = 0; n < nOrd; n++) {
             const double jp = jn(n + 1, x), yp = yn(n + 1, x);
-            HK[((size_t)item * KAY_MAXN + n) * nw + i] = cplx{0.5 * (jm - jp), 0.5 * (ym - yp)};   // H'_n
+            const double hr = 0.5 * (jm - jp), hi = 0.5 * (ym - yp), d = hr * hr + hi * hi;     // H'_n
+            H[(size_t)n * nw + i] = cplx{hr / d, -hi / d};
             jm = jc; ym = yc;
             jc = jp; yc = yp;
+        }
+        const double a1 = k[i] * (rec[2] + h), a2 = k[i] * (rec[3] + h);
+        H[(size_t)KAY_MAXN * nw + i] = cplx{exp(a1), exp(-a1)};
+        H[(size_t)(KAY_MAXN + 1) * nw + i] = cplx{exp(a2), exp(-a2)};
+        double ps, pc;
+        sincos(-(k[i] * xi), &ps, &pc);
+        H[(size_t)(KAY_MAXN + 2) * nw + i] = cplx{pc, ps};
+        if (item == 0) {
+            const double kh = k[i] * h;
+            kq[i] = kh / (sqrt(kh * tanh(kh)) * cosh(kh));
         }
     }
 }
@@ -483,52 +509,48 @@ __global__ void __launch_bounds__(128) k_kay_tables(int nw, int nOrd, const doub
 __global__ void __launch_bounds__(128) k_kay_pairs(int nw, int Nm, double h, double rho, double g,
                                                    const double *__restrict__ w, const double *__restrict__ k,
                                                    const int64_t *__restrict__ ioff, const double *__restrict__ items,
-                                                   const double *__restrict__ beta, const cplx *__restrict__ HK,
+                                                   const cplx *__restrict__ HK, const double *__restrict__ kq,
                                                    cplx *__restrict__ kay) {
     const int set = blockIdx.x / nw, i1 = blockIdx.x % nw;
-    const double w1 = w[i1], k1 = k[i1];
-    const double cB = cos(beta[set]), sB = sin(beta[set]);
+    const double w1 = w[i1], k1 = k[i1], q1 = kq[i1];
     for (int i2 = i1 + threadIdx.x; i2 < nw; i2 += blockDim.x) {
         const double w2 = w[i2], k2 = k[i2];
+        const double k1h = k1 * h, k2h = k2 * h, rsum = 1.0 / (k1h + k2h), rdif = (w1 == w2) ? 0.0 : 1.0 / (k1h - k2h);
+        const double qq = q1 * kq[i2], rk = 1.0 / (k1 * k2);
         double Fr[6] = {0, 0, 0, 0, 0, 0}, Fi[6] = {0, 0, 0, 0, 0, 0};
         for (int64_t it = ioff[set]; it < ioff[set + 1]; it++) {
             const double *rec = items + (size_t)it * QK_N;
             const double R = rec[0];
             const bool seg = rec[1] != 0.0;
-            const double k1R = k1 * R, k2R = k2 * R;
-            const cplx *H1 = HK + (size_t)it * KAY_MAXN * nw + i1, *H2 = HK + (size_t)it * KAY_MAXN * nw + i2;
+            const cplx *H1 = HK + (size_t)it * KAY_ROWS * nw + i1, *H2 = HK + (size_t)it * KAY_ROWS * nw + i2;
             double wgtA = 1.0, wgtB = 0.0;             // term_n = omega_n * (wgtA + wgtB n(n+1))
             if (seg) {
-                const double z1 = rec[2], z2 = rec[3];
-                const double Hh = h / R, k1h = k1R * Hh, k2h = k2R * Hh, ks = k1 + k2, kdh = k1h - k2h;
-                const double sp2 = sinh(ks * (z2 + h)) / (k1h + k2h), sp1 = sinh(ks * (z1 + h)) / (k1h + k2h);
-                const double sm2 = (w1 == w2) ? (z2 + h) / h : sinh((k1 - k2) * (z2 + h)) / kdh;
-                const double sm1 = (w1 == w2) ? (z1 + h) / h : sinh((k1 - k2) * (z1 + h)) / kdh;
+                // sinh((k1 + k2)(z + h)) / (k1h + k2h) and sinh((k1 - k2)(z + h)) / (k1h - k2h) at z1, z2 (:1752-1756)
+                const cplx e1a = H1[(size_t)KAY_MAXN * nw], e2a = H2[(size_t)KAY_MAXN * nw];
+                const cplx e1b = H1[(size_t)(KAY_MAXN + 1) * nw], e2b = H2[(size_t)(KAY_MAXN + 1) * nw];
+                const double sp1 = 0.5 * (e1a.re * e2a.re - e1a.im * e2a.im) * rsum, sp2 = 0.5 * (e1b.re * e2b.re - e1b.im * e2b.im) * rsum;
+                const double sm1 = (w1 == w2) ? (rec[2] + h) / h : 0.5 * (e1a.re * e2a.im - e1a.im * e2a.re) * rdif;
+                const double sm2 = (w1 == w2) ? (rec[3] + h) / h : 0.5 * (e1b.re * e2b.im - e1b.im * e2b.re) * rdif;
                 const double Im = 0.5 * (sp2 - sm2 - sp1 + sm1), Ip = 0.5 * (sp2 + sm2 - sp1 - sm1);
-                const double pre = k1h * k2h / sqrt(k1h * tanh(k1h)) / sqrt(k2h * tanh(k2h));
-                const double c1 = cosh(k1h), c2 = cosh(k2h);
-                wgtA = pre * Im / c1 / c2;
-                wgtB = pre * Ip / k1R / k2R / c1 / c2;
+                wgtA = qq * Im;
+                wgtB = qq * Ip * rk / (R * R);
             }
-            // sum_n (+-) rho g R 2i/pi/(k1R k2R) omega_n weight_n ; only the real part is kept (:1747,1783)
-            double acc = 0.0;                           // Re( 2i * sum omega_n weight_n ) = -2 * Im( sum )
-            double sr = 0.0, si = 0.0;
+            // sum_n (+-) rho g R 2i/pi/(k1R k2R) omega_n weight_n ; only the real part is kept (:1747,1783):
+            // Re(2i sum) = -2 Im(sum),  omega_n = 1 / (H'_{n+1}(k1R) conj H'_n(k2R)) - 1 / (H'_n(k1R) conj H'_{n+1}(k2R))
+            double si = 0.0;
+            cplx a0 = H1[0], b0 = H2[0];                                                  // reciprocals of H'_n
             for (int n = 0; n <= Nm; n++) {
-                const cplx a0 = H1[(size_t)n * nw], a1 = H1[(size_t)(n + 1) * nw];        // H'_n(k1R), H'_{n+1}(k1R)
-                const cplx b0 = cconj(H2[(size_t)n * nw]), b1 = cconj(H2[(size_t)(n + 1) * nw]);
-                const cplx d1 = cmul(a1, b0), d2 = cmul(a0, b1);
-                const double n1 = d1.re * d1.re + d1.im * d1.im, n2 = d2.re * d2.re + d2.im * d2.im;
-                const double orr = d1.re / n1 - d2.re / n2, oii = -d1.im / n1 + d2.im / n2;   // 1/d1 - 1/d2
-                const double wn = wgtA + wgtB * (double)(n * (n + 1));
-                sr += orr * wn;
-                si += oii * wn;
+                const cplx a1 = H1[(size_t)(n + 1) * nw], b1 = H2[(size_t)(n + 1) * nw];
+                // Im(a1 conj b0) - Im(a0 conj b1)
+                const double oii = (a1.im * b0.re - a1.re * b0.im) - (a0.im * b1.re - a0.re * b1.im);
+                si = fma(oii, wgtA + wgtB * (double)(n * (n + 1)), si);
+                a0 = a1;
+                b0 = b1;
             }
-            (void)sr;
-            acc = -2.0 * si;
-            double Fs = rho * g * R / M_PI / (k1R * k2R) * acc;
+            double Fs = rho * g / M_PI * rk / R * (-2.0 * si);
             if (!seg) Fs = -Fs;                                                          // waterline term carries the minus sign (:1745)
-            double ps, pc;
-            sincos(-((k1 - k2) * (cB * rec[10] + sB * rec[11])), &ps, &pc);
+            const cplx p1 = H1[(size_t)(KAY_MAXN + 2) * nw], p2 = H2[(size_t)(KAY_MAXN + 2) * nw];
+            const double pc = p1.re * p2.re + p1.im * p2.im, ps = p1.im * p2.re - p1.re * p2.im;     // e^{-i (k1 - k2) xi}
             const double fr = Fs * pc, fi = Fs * ps;
             const double px = rec[7], py = rec[8], pz = rec[9], ax = rec[4], ay = rec[5], az = rec[6];
             const double g6[6] = {px, py, pz, ay * pz - az * py, az * px - ax * pz, ax * py - ay * px};
