@@ -207,8 +207,10 @@ struct Lds {
     ldptr xl;      // [12][nxl]    XiLast (re/im rows), nxl = nw rounded up to even
     ldptr ra;      // [S][stage_n] hot strip constants: all RA_N, the first 6 (arm, q), or none -- see stage_policy
     ldptr uv;      // [S][12]      linearised drag vectors of the current heading
-    ldptr vsq;     // [NWV][S][3]  per-wave sums over bins of |v_q|^2, |v_p1|^2 (|v_perp|^2), |v_p2|^2;
-                     //              row 0 is overwritten by the live coefficients b_c (strip_phase)
+    ldptr vsq;     // [S][3] (+ [NWV-1][S][3] when NWV > 5)  sums over wave 0's bins of |v_q|^2, |v_p1|^2 (|v_perp|^2),
+                     //              |v_p2|^2; overwritten by the live coefficients b_c (strip_phase).  The other waves' sums
+                     //              lie in uv (dead between pass B and the strip phase): wave i at uv[s][3 (i-1) ..], read
+                     //              by the lane of strip s before it writes that record -- see vsq_of
     ldptr tile;    // [NWV][TR_ROWS][TR_STRIDE]
     ldptr park;    // start of the span (vsq rows >= 1 | uv | tile) the solve phase may reuse, see park_policy
     ldptr bdw;     // [NWV][24]    per-wave partials of the 21 unique B_drag entries
@@ -218,6 +220,8 @@ struct Lds {
     int nxl;
 };
 static __host__ __device__ inline int xl_row(int nw) { return (nw + 1) & ~1; }
+// rows of dedicated storage for the per-wave velocity sums: up to five waves, only wave 0's (the others lie in uv)
+static __host__ __device__ inline int vsq_rows(int nwv) { return nwv <= 5 ? 1 : nwv; }
 // park_n: doubles of the [uv | vsq | tile] span that the solve phase reuses as a per-lane parking column (0 = none);
 // the span is padded up to that size for designs with few strips
 static __host__ __device__ constexpr int park_policy(int nb, int maxt) { return (nb == 2 && maxt == 128) ? 12 * 128 : 0; }
@@ -237,7 +241,7 @@ __device__ __forceinline__ Lds carve(double *base_, int S, int nw_xl, int nwv, i
     l.xl = base;
     l.ra = l.xl + (size_t)12 * l.nxl;
     l.vsq = l.ra + (size_t)S * stage_n;
-    l.uv = l.vsq + (size_t)nwv * S * 3;
+    l.uv = l.vsq + (size_t)vsq_rows(nwv) * S * 3;
     l.tile = l.uv + (size_t)S * 12;
     l.bdw = l.tile + (size_t)nwv * TR_ROWS * TR_STRIDE;
     l.park = l.vsq + (size_t)S * 3;        // row 0 of vsq keeps the drag coefficients b_c for the other headings
@@ -248,11 +252,20 @@ __device__ __forceinline__ Lds carve(double *base_, int S, int nw_xl, int nwv, i
     return l;
 }
 static size_t lds_bytes(int S, int nw, int nwv, int stage_n, int park_n = 0, int rc_n = 0, int nw_rc = 0) {
-    size_t span = (size_t)S * (12 + 3 * nwv) + (size_t)nwv * TR_ROWS * TR_STRIDE;          // vsq | uv | tile
+    size_t span = (size_t)S * (12 + 3 * vsq_rows(nwv)) + (size_t)nwv * TR_ROWS * TR_STRIDE;          // vsq | uv | tile
     if (park_n && span < (size_t)S * 3 + (size_t)park_n) span = (size_t)S * 3 + (size_t)park_n;
     return sizeof(double) * ((size_t)(nw_rc ? 2 * RAFTX_SC_N : 0) + (size_t)rc_n * 2 * xl_row(nw_rc) + (size_t)12 * xl_row(nw) + (size_t)S * stage_n + span +
                              (size_t)nwv * 24 + 36 + 108 + 2) +
            sizeof(int) * (size_t)(stage_n == RA_N ? S + 2 : 2);
+}
+// where wave wv's velocity sums of strip s start, as base + s * stride
+__device__ __forceinline__ ldptr vsq_of(const Lds &l, int wv, int nwv, int S, int &stride) {
+    if (wv == 0 || nwv > 5) {
+        stride = 3;
+        return l.vsq + wv * S * 3;
+    }
+    stride = 12;
+    return l.uv + (wv - 1) * 3;
 }
 // shapes that keep XiLast in a per-pair global slab (SolveArgs::Xl) instead of LDS: the largest ones (no room), and the
 // two-waves-per-SIMD 200-bin shape, whose LDS goes to the run-start cache instead (XiLast is touched twice per
@@ -1054,7 +1067,9 @@ __device__ __forceinline__ void linearize_passA(cdptr ds, ciptr dsi, int S,
     const int lane = tid & 63, wv = tid >> 6;
     ldptr tile = l.tile + wv * TR_ROWS * TR_STRIDE;
     ldptr wr = tile + tile_pos(lane);
-    ldptr vout = l.vsq + wv * S * 3;
+    int vstride;
+    ldptr vout = vsq_of(l, wv, blockDim.x >> 6, S, vstride);
+    vout += ((lane >> 3) >= 3 ? vstride - 3 : 0) + (lane >> 3);          // this reader lane's row: strip s0 or s0 + 1, component row % 3
     Kin<NB> K;
     kin_reset(K, run_cache_of(l));
     if (S <= 0) return;
@@ -1113,7 +1128,7 @@ __device__ __forceinline__ void linearize_passA(cdptr ds, ciptr dsi, int S,
                 a += dpp_mov<0xB1>(a);
                 a += dpp_mov<0x4E>(a);
                 a += dpp_mov<0x104>(a);
-                if (writer && row < prev_nb * 3) vout[prev_s0 * 3 + row] = a;
+                if (writer && row < prev_nb * 3) vout[prev_s0 * vstride] = a;
             }
             int nb = 1;
             bool more = false;                      // does the run go on after this batch?
@@ -1179,7 +1194,7 @@ __device__ __forceinline__ void linearize_passA(cdptr ds, ciptr dsi, int S,
             a += dpp_mov<0xB1>(a);
             a += dpp_mov<0x4E>(a);
             a += dpp_mov<0x104>(a);
-            if (writer && row < prev_nb * 3) vout[prev_s0 * 3 + row] = a;
+            if (writer && row < prev_nb * 3) vout[prev_s0 * vstride] = a;
         }
         if (nb > 1) {
             const auto rec = src.rec(s0 + 1);
@@ -1200,7 +1215,7 @@ __device__ __forceinline__ void linearize_passA(cdptr ds, ciptr dsi, int S,
     }
     {   // drain: the last batch
         const double a = tile_reduce(tile, lane);
-        if (writer && row < prev_nb * 3) vout[prev_s0 * 3 + row] = a;
+        if (writer && row < prev_nb * 3) vout[prev_s0 * vstride] = a;
     }
     wave_lds_fence();
 }
@@ -1225,7 +1240,8 @@ __device__ __forceinline__ void strip_phase(cdptr ds, ciptr dsi, int S,
         if (FRESH) {
             double a = 0, c1 = 0, c2 = 0;
             for (int i = 0; i < nwv; i++) {
-                ldptr r = l.vsq + (i * S + s) * 3;
+                int st;
+                ldptr r = vsq_of(l, i, nwv, S, st) + s * st;
                 a += r[0];
                 c1 += r[1];
                 c2 += r[2];
