@@ -106,6 +106,9 @@ __host__ __device__ inline void derive_design_tables(const double *strips, int64
             // matrix (cos(pi/2) = 6e-17 and the like, raft_member.py:355-372).  Pass A may then leave the dust products
             // out of its velocity SQUARES (1e-17 of a positive sum); the records themselves keep the reference's values.
             if (fabs(o[DS_P1]) < 1e-15 && fabs(o[DS_P1 + 1]) < 1e-15 && fabs(o[DS_P2 + 2]) < 1e-15) dsf[(size_t)i] |= DSI_AXAL;
+            // Vertical axis: q = (0, 0, +-1) and p1, p2 horizontal up to the same dust; pass B leaves the dust components out
+            if (fabs(o[DS_Q]) < 1e-15 && fabs(o[DS_Q + 1]) < 1e-15 && fabs(o[DS_P1 + 2]) < 1e-15 && fabs(o[DS_P2 + 2]) < 1e-15)
+                dsf[(size_t)i] |= DSI_VAX;
             o[DS_IQ] = rec[RAFTX_F_IQ];
             o[DS_IQ + 1] = rec[RAFTX_F_IP1];
             o[DS_IQ + 2] = rec[RAFTX_F_IP2];
@@ -1234,6 +1237,8 @@ __global__ __launch_bounds__(GD_T) void k_geom_design(GeomArgs A) {
         }
         int fl = m | (cr[RAFTX_F_CIRC] != 0.0 ? DSI_CIRC : 0);
         if (fabs(cr[RAFTX_F_P1]) < 1e-15 && fabs(cr[RAFTX_F_P1 + 1]) < 1e-15 && fabs(cr[RAFTX_F_P2 + 2]) < 1e-15) fl |= DSI_AXAL;
+        if (fabs(cr[RAFTX_F_Q]) < 1e-15 && fabs(cr[RAFTX_F_Q + 1]) < 1e-15 && fabs(cr[RAFTX_F_P1 + 2]) < 1e-15 && fabs(cr[RAFTX_F_P2 + 2]) < 1e-15)
+            fl |= DSI_VAX;
         A.dsi[(size_t)i0 + t] = fl;
     }
     GEOM_PHASE(3);

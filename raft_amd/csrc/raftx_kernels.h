@@ -156,6 +156,7 @@ __device__ __forceinline__ double fast_exp(double x) {
 #define DSI_M 3
 #define DSI_CIRC 4
 #define DSI_AXAL 8       // upright cross-section: p1 = (0, 0, +-1), p2 horizontal, up to rounding dust (< 1e-15)
+#define DSI_VAX 16       // vertical axis: q = (0, 0, +-1), p1 and p2 horizontal, up to rounding dust (< 1e-15)
 
 struct DevTables {
     int nDesign;
@@ -1363,9 +1364,10 @@ __device__ __forceinline__ void drag_excitation(cdptr ds, ciptr dsi, int S, cons
     StripSrc<STAGE> src(l, ds, dsi);
     if constexpr (RUN_LOOPS<NB>) {
     // Loop over RUNS; the strips of a run form the inner loop, specialised by what changes along the run:
-    //  * vertical run (no phase rotation: a = e^{-i k xi} is the same for every strip): the sums G1 = sum (P+Q) U_s,
-    //    G2 = sum (P-Q) V_s are REAL (12 FMAs per strip and bin instead of 24 + 4) and meet the phasor once per run,
-    //    F += a G1 + i a G2; the step is two multiplies;
+    //  * vertical member (no phase rotation: a = e^{-i k xi} is the same for every strip): the sums G = sum (P+Q) U_s,
+    //    H = sum (P-Q) V_s are REAL and, of their twelve components, five are independent (5 FMAs per strip and bin instead
+    //    of 24 + 4); they meet the phasor once per run, F += a G + i a H; the step is two multiplies.  Other runs
+    //    without phase rotation (a member across the wave direction) take the loops below with the identity rotor;
     //  * horizontal run (no depth decay: P, Q are the same for every strip): P+Q, P-Q leave the loop, the step is the
     //    phase rotation alone;
     //  * inclined run: the general form.
@@ -1417,33 +1419,46 @@ __device__ __forceinline__ void drag_excitation(cdptr ds, ciptr dsi, int S, cons
 #pragma unroll 1
     while (s < S) {
         kin_start<NB, false, CM>(K, run_start_of(src.rec(s)), b, b.c1, cb, sb);
-        if (!K.rot) {
-            double G1[NB][6], G2[NB][6];
+        if (!K.rot && (fl & DSI_VAX)) {
+            // Vertical member (q = +-z, p1 and p2 horizontal; arm x, y fixed along the run): with h_s = sum_c b_c al_c n_c (horizontal)
+            //   U_s = [h_x, h_y, 0, -a_z h_y, a_z h_x, a_x h_y - a_y h_x],   V_s = b_q [0, 0, 1, a_y, -a_x, 0]
+            // so FIVE real sums per bin carry the run (U_0, U_1, U_3, U_4 and V_2 of the rows the strip phase wrote):
+            // 5 FMAs per strip and bin instead of 12, and the rest follows from the run's arm when the sums meet the phasor.
+            double G0[NB], G1[NB], G3[NB], G4[NB], H2[NB];
 #pragma unroll
-            for (int j = 0; j < NB; j++)
-#pragma unroll
-                for (int q = 0; q < 6; q++) G1[j][q] = G2[j][q] = 0.0;
+            for (int j = 0; j < NB; j++) G0[j] = G1[j] = G3[j] = G4[j] = H2[j] = 0.0;
+            RecA r;
+            load_arm(src.rec(s), r);
             auto body = [&]() {
-                double U[6], V[6];
-                load_uv(l.uv + s * 12, U, V);
+                ldptr uv = l.uv + s * 12;
+                const double u0 = uv[0], u1 = uv[1], u3 = uv[3], u4 = uv[4], v2 = uv[8];
 #pragma unroll
                 for (int j = 0; j < NB; j++) {
                     const double ps = K.P[j] + K.Q[j], pd = K.P[j] - K.Q[j];
-#pragma unroll
-                    for (int q = 0; q < 6; q++) {
-                        G1[j][q] = fma(ps, U[q], G1[j][q]);
-                        G2[j][q] = fma(pd, V[q], G2[j][q]);
-                    }
+                    G0[j] = fma(ps, u0, G0[j]);
+                    G1[j] = fma(ps, u1, G1[j]);
+                    G3[j] = fma(ps, u3, G3[j]);
+                    G4[j] = fma(ps, u4, G4[j]);
+                    H2[j] = fma(pd, v2, H2[j]);
                 }
             };
             RUN_LOOP(1, kin_decay1(K), kin_decay2(K), kin_decay(K, m_), );
 #pragma unroll
-            for (int j = 0; j < NB; j++)
-#pragma unroll
-                for (int q = 0; q < 6; q++) {
-                    F[j][q].re = fma(K.ar[j], G1[j][q], fma(-K.ai[j], G2[j][q], F[j][q].re));
-                    F[j][q].im = fma(K.ai[j], G1[j][q], fma(K.ar[j], G2[j][q], F[j][q].im));
-                }
+            for (int j = 0; j < NB; j++) {
+                const double g5 = r.ax * G1[j] - r.ay * G0[j], h3 = r.ay * H2[j], h4 = -r.ax * H2[j];
+                F[j][0].re = fma(K.ar[j], G0[j], F[j][0].re);
+                F[j][0].im = fma(K.ai[j], G0[j], F[j][0].im);
+                F[j][1].re = fma(K.ar[j], G1[j], F[j][1].re);
+                F[j][1].im = fma(K.ai[j], G1[j], F[j][1].im);
+                F[j][2].re = fma(-K.ai[j], H2[j], F[j][2].re);
+                F[j][2].im = fma(K.ar[j], H2[j], F[j][2].im);
+                F[j][3].re = fma(K.ar[j], G3[j], fma(-K.ai[j], h3, F[j][3].re));
+                F[j][3].im = fma(K.ai[j], G3[j], fma(K.ar[j], h3, F[j][3].im));
+                F[j][4].re = fma(K.ar[j], G4[j], fma(-K.ai[j], h4, F[j][4].re));
+                F[j][4].im = fma(K.ai[j], G4[j], fma(K.ar[j], h4, F[j][4].im));
+                F[j][5].re = fma(K.ar[j], g5, F[j][5].re);
+                F[j][5].im = fma(K.ai[j], g5, F[j][5].im);
+            }
         } else if (!K.dec && !K.vert && (fl & (DSI_AXAL | DSI_CIRC)) == DSI_AXAL) {
             // Upright pontoon (see linearize_passA): q, p2 horizontal, p1 = +-z.  With W_c = [n_c ; arm x n_c] and the arm moving
             // along q, W_q is the same for every strip of the run, W_p2 changes in its last component only
