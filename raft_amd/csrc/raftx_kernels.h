@@ -1049,7 +1049,7 @@ __device__ __forceinline__ void kin_decay(Kin<NB> &K, int m) {
 #endif
 template <int NB, int RT>
 __device__ __forceinline__ void kin_step_rt(Kin<NB> &K, int m) {      // RT 3 = RT 2 with an upright cross-section
-    if (RT != 1) kin_rotate(K, m);
+    if (RT != 1 && RT != 4) kin_rotate(K, m);
     if (RT != 2 && RT != 3) kin_decay(K, m);
 }
 
@@ -1098,11 +1098,49 @@ __device__ __forceinline__ void linearize_passA(cdptr ds, ciptr dsi, int S,
         }
         BodyHoist<NB> H;
         RecA r = load_recA(src.rec(s));             // a run has one unit triad (derive_design_tables); the arm is per strip
-        body_hoist<NB, RT>(H, X, r);
+        body_hoist<NB, RT == 4 ? 1 : RT>(H, X, r);
+        // RT 4, a vertical run of circular strips: the phasor a is the same for every strip, so with t1 = a (P+Q), t2 = i a (P-Q)
+        //   |v_z|^2               = |a|^2 pd^2 + 2 pd Re(conj(i a) Hz) + |Hz|^2
+        //   |v_x|^2 + |v_y|^2     = (cb^2 + sb^2) |a|^2 ps^2 + 2 ps Re(conj(a) (Mh + az Mg)) + |Hx + az Gx|^2 + |Hy + az Gy|^2
+        // (H: body terms fixed along the run, G = R(X4), R(-X3): the part that grows with the arm's z; Mh = cb Hx + sb Hy, Mg
+        // likewise).  Everything but ps, pd and az is a per-bin constant of the run: 5 FMAs per strip and bin instead of
+        // 4 multiplies + 16 FMAs, and the last two terms are a polynomial in az summed over this lane's bins once.
+        double A2[NB], A2p[NB], Cz2[NB], C1p[NB], C2p[NB], hz2s = 0.0, D0s = 0.0, D1s = 0.0, D2s = 0.0;
+        if constexpr (RT == 4) {
+            const double hh = cb * cb + sb * sb;
+#pragma unroll
+            for (int j = 0; j < NB; j++) {
+                const double ar = K.ar[j], ai = K.ai[j];
+                const double gxr = X[j][4].im, gxi = -X[j][4].re, gyr = -X[j][3].im, gyi = X[j][3].re;
+                A2[j] = fma(ar, ar, ai * ai);
+                A2p[j] = hh * A2[j];
+                Cz2[j] = 2.0 * fma(ar, H.zi[j], -(ai * H.zr[j]));
+                const double mhr = fma(cb, H.xr[j], sb * H.yr[j]), mhi = fma(cb, H.xi[j], sb * H.yi[j]);
+                const double mgr = fma(cb, gxr, sb * gyr), mgi = fma(cb, gxi, sb * gyi);
+                C1p[j] = 2.0 * fma(ar, mhr, ai * mhi);
+                C2p[j] = 2.0 * fma(ar, mgr, ai * mgi);
+                hz2s += fma(H.zr[j], H.zr[j], H.zi[j] * H.zi[j]);
+                D0s += fma(H.xr[j], H.xr[j], fma(H.xi[j], H.xi[j], fma(H.yr[j], H.yr[j], H.yi[j] * H.yi[j])));
+                D1s += 2.0 * fma(H.xr[j], gxr, fma(H.xi[j], gxi, fma(H.yr[j], gyr, H.yi[j] * gyi)));
+                D2s += fma(gxr, gxr, fma(gxi, gxi, fma(gyr, gyr, gyi * gyi)));
+            }
+        }
         const int s_start = s;
         auto strip = [&](int si, int fls, double (&v)[3]) {
             if (si != s_start) load_arm(src.rec(si), r);
-            if (RT == 2 || RT == 3) {
+            if constexpr (RT == 4) {
+                const double az = r.az;
+                double v0 = hz2s, v1 = fma(az, fma(az, D2s, D1s), D0s);
+#pragma unroll
+                for (int j = 0; j < NB; j++) {
+                    const double ps = K.P[j] + K.Q[j], pd = K.P[j] - K.Q[j];
+                    v0 = fma(pd, fma(A2[j], pd, Cz2[j]), v0);
+                    v1 = fma(ps, fma(A2p[j], ps, fma(az, C2p[j], C1p[j])), v1);
+                }
+                v[0] = v0;
+                v[1] = v1;
+                v[2] = 0.0;
+            } else if (RT == 2 || RT == 3) {
                 passA_core<NB, RT>(K.ar, K.ai, psh, pdh, r, (fls & DSI_CIRC) != 0, cb, sb, X, H, v[0], v[1], v[2]);
             } else {
                 double ps[NB], pd[NB];
@@ -1167,7 +1205,10 @@ __device__ __forceinline__ void linearize_passA(cdptr ds, ciptr dsi, int S,
     while (s < S) {
         kin_start<NB, false, CM>(K, run_start_of(src.rec(s)), b, b.c1, cb, sb);
         // a run of one strip has a zero step vector and says nothing about the member's axis: general form
-        if (K.vert && K.dec && fabs(src_qz(src.rec(s))) == 1.0) run(std::integral_constant<int, 1>{});   // vertical (implies no phase rotation)
+        if (K.vert && K.dec && fabs(src_qz(src.rec(s))) == 1.0) {                // vertical (implies no phase rotation)
+            if (fl & DSI_CIRC) run(std::integral_constant<int, 4>{});
+            else run(std::integral_constant<int, 1>{});
+        }
         else if (!K.vert && !K.dec) {                                        // horizontal
             if ((fl & (DSI_AXAL | DSI_CIRC)) == DSI_AXAL) run(std::integral_constant<int, 3>{});   // ... rectangular with an upright cross-section (a run has one triad and shape)
             else run(std::integral_constant<int, 2>{});
