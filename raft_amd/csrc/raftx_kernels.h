@@ -1088,8 +1088,9 @@ __device__ __forceinline__ void linearize_passA(cdptr ds, ciptr dsi, int S,
     // the loop.  The run-start evaluation (sincos / exp) is outside the batch loop's body.
     int s = 0;
     int fl = src.flags(min(1, S - 1));              // flags of strip 0; strip 1's are on their way
-    auto run = [&](auto rt_tag) {
+    auto run = [&](auto rt_tag, const int n, const int m0) {
         constexpr int RT = decltype(rt_tag)::value;
+        if (m0) kin_step_rt<NB, RT>(K, m0);         // continuation of a run longer than 64 strips
         double psh[NB], pdh[NB];                    // RT == 2: P + Q, P - Q of the whole run
 #pragma unroll
         for (int j = 0; j < NB; j++) {
@@ -1125,9 +1126,7 @@ __device__ __forceinline__ void linearize_passA(cdptr ds, ciptr dsi, int S,
                 D2s += fma(gxr, gxr, fma(gxi, gxi, fma(gyr, gyr, gyi * gyi)));
             }
         }
-        const int s_start = s;
-        auto strip = [&](int si, int fls, double (&v)[3]) {
-            if (si != s_start) load_arm(src.rec(si), r);
+        auto strip = [&](double (&v)[3]) {          // strip s at the state K
             if constexpr (RT == 4) {
                 const double az = r.az;
                 double v0 = hz2s, v1 = fma(az, fma(az, D2s, D1s), D0s);
@@ -1141,7 +1140,7 @@ __device__ __forceinline__ void linearize_passA(cdptr ds, ciptr dsi, int S,
                 v[1] = v1;
                 v[2] = 0.0;
             } else if (RT == 2 || RT == 3) {
-                passA_core<NB, RT>(K.ar, K.ai, psh, pdh, r, (fls & DSI_CIRC) != 0, cb, sb, X, H, v[0], v[1], v[2]);
+                passA_core<NB, RT>(K.ar, K.ai, psh, pdh, r, (fl & DSI_CIRC) != 0, cb, sb, X, H, v[0], v[1], v[2]);
             } else {
                 double ps[NB], pd[NB];
 #pragma unroll
@@ -1149,71 +1148,91 @@ __device__ __forceinline__ void linearize_passA(cdptr ds, ciptr dsi, int S,
                     ps[j] = K.P[j] + K.Q[j];
                     pd[j] = K.P[j] - K.Q[j];
                 }
-                passA_core<NB, RT>(K.ar, K.ai, ps, pd, r, (fls & DSI_CIRC) != 0, cb, sb, X, H, v[0], v[1], v[2]);
+                passA_core<NB, RT>(K.ar, K.ai, ps, pd, r, (fl & DSI_CIRC) != 0, cb, sb, X, H, v[0], v[1], v[2]);
             }
         };
-#pragma unroll 1
-        while (true) {
-            const int s0 = s;
+        // Batches of two strips (tile rows 0-2: strip A, rows 3-5: strip B).  The cross-lane reduction of a batch is software-
+        // pipelined into strip A of the next one: its 8 tile reads are issued before that strip and consumed after it.
+        // The run's length n is known, so the strips are a peeled A followed by a COUNTED loop of (step, B, step, A) with the
+        // steps unconditional and in place -- exits from the middle of a batch made the compiler carry the stepped state in
+        // temporaries and copy it back (22 v_mov_b64 per strip).
+        auto stripA = [&]() {
             double pend[8];
-            if (prev_s0 >= 0) {
+            const bool red = prev_s0 >= 0;              // false on the very first strip of the pass only
+            if (red) {
 #pragma unroll
                 for (int e = 0; e < 8; e++) pend[e] = rp[e];
             }
-            double va[3], vb[3] = {0.0, 0.0, 0.0};
-            strip(s0, fl, va);
-            if (prev_s0 >= 0) {
+            double va[3];
+            strip(va);
+            if (red) {
                 double a = ((pend[0] + pend[4]) + (pend[1] + pend[5])) + ((pend[2] + pend[6]) + (pend[3] + pend[7]));
                 a += dpp_mov<0xB1>(a);
                 a += dpp_mov<0x4E>(a);
                 a += dpp_mov<0x104>(a);
                 if (writer && row < prev_nb * 3) vout[prev_s0 * vstride] = a;
             }
-            int nb = 1;
-            bool more = false;                      // does the run go on after this batch?
-            if (s0 + 1 < S) {
-                fl = src.flags(min(s0 + 2, S - 1)); // flags of strip s0 + 1
-                const int m1 = fl & DSI_M;
-                if (m1 != 0) {
-                    kin_step_rt<NB, RT>(K, m1);
-                    strip(s0 + 1, fl, vb);
-                    nb = 2;
-                    if (s0 + 2 < S) {
-                        fl = src.flags(min(s0 + 3, S - 1));     // flags of strip s0 + 2
-                        const int m2 = fl & DSI_M;
-                        if (m2 != 0) {
-                            kin_step_rt<NB, RT>(K, m2);
-                            more = true;
-                        }
-                    }
-                }
-            }
 #pragma unroll
-            for (int c = 0; c < 3; c++) {
-                wr[c * TR_STRIDE] = va[c];
-                wr[(3 + c) * TR_STRIDE] = vb[c];
-            }
-            wave_lds_fence();
-            prev_s0 = s0;
-            prev_nb = nb;
-            s = s0 + nb;
+            for (int c = 0; c < 3; c++) wr[c * TR_STRIDE] = va[c];
             PT_MARK(6);   // strips of pass A
-            if (!more) break;
+        };
+        auto stripB = [&]() {
+            double vb[3];
+            strip(vb);
+#pragma unroll
+            for (int c = 0; c < 3; c++) wr[(3 + c) * TR_STRIDE] = vb[c];
+            wave_lds_fence();
+            prev_s0 = s - 1;
+            prev_nb = 2;
+            PT_MARK(6);
+        };
+        auto advance = [&]() {                      // to the next strip of this run: flags, arm, state
+            ++s;
+            fl = src.flags(min(s + 1, S - 1));
+            load_arm(src.rec(s), r);
+            kin_step_rt<NB, RT>(K, fl & DSI_M);
+        };
+        stripA();
+        int rem = n - 1;
+#pragma unroll 1
+        for (; rem >= 2; rem -= 2) {
+            advance();
+            stripB();
+            advance();
+            stripA();
         }
+        if (rem) {
+            advance();
+            stripB();
+        } else {                                    // an odd strip count: the last batch has one strip
+            wave_lds_fence();
+            prev_s0 = s;
+            prev_nb = 1;
+        }
+        if (++s < S) fl = src.flags(min(s + 1, S - 1));          // flags of the strip after the run
     };
+    int rt = 0;
 #pragma unroll 1
     while (s < S) {
-        kin_start<NB, false, CM>(K, run_start_of(src.rec(s)), b, b.c1, cb, sb);
-        // a run of one strip has a zero step vector and says nothing about the member's axis: general form
-        if (K.vert && K.dec && fabs(src_qz(src.rec(s))) == 1.0) {                // vertical (implies no phase rotation)
-            if (fl & DSI_CIRC) run(std::integral_constant<int, 4>{});
-            else run(std::integral_constant<int, 1>{});
+        // strips of this run (2..64; a longer one continues through another pass of this loop, without a start): lane i looks
+        // at strip s + 1 + i, the first one that does not continue ends the run.  The load is covered by the run start.
+        const int ahead = s + 1 + lane;
+        const int fa = dsi[min(ahead, S - 1)];
+        const int m0 = fl & DSI_M;
+        if (m0 == 0) {
+            kin_start<NB, false, CM>(K, run_start_of(src.rec(s)), b, b.c1, cb, sb);
+            // a run of one strip has a zero step vector and says nothing about the member's axis: general form
+            if (K.vert && K.dec && fabs(src_qz(src.rec(s))) == 1.0) rt = (fl & DSI_CIRC) ? 4 : 1;     // vertical (implies no phase rotation)
+            else if (!K.vert && !K.dec) rt = (fl & (DSI_AXAL | DSI_CIRC)) == DSI_AXAL ? 3 : 2;       // horizontal; 3: rectangular with an upright cross-section (a run has one triad and shape)
+            else rt = 0;
         }
-        else if (!K.vert && !K.dec) {                                        // horizontal
-            if ((fl & (DSI_AXAL | DSI_CIRC)) == DSI_AXAL) run(std::integral_constant<int, 3>{});   // ... rectangular with an upright cross-section (a run has one triad and shape)
-            else run(std::integral_constant<int, 2>{});
-        }
-        else run(std::integral_constant<int, 0>{});
+        const unsigned long long stop = __ballot(ahead >= S || (fa & DSI_M) == 0);
+        const int n = stop ? 1 + (int)__builtin_ctzll(stop) : 64;
+        if (rt == 4) run(std::integral_constant<int, 4>{}, n, m0);
+        else if (rt == 1) run(std::integral_constant<int, 1>{}, n, m0);
+        else if (rt == 3) run(std::integral_constant<int, 3>{}, n, m0);
+        else if (rt == 2) run(std::integral_constant<int, 2>{}, n, m0);
+        else run(std::integral_constant<int, 0>{}, n, m0);
     }
     } else {
 #pragma unroll 1
