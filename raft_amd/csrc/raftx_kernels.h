@@ -1541,18 +1541,29 @@ __device__ __forceinline__ void drag_excitation(cdptr ds, ciptr dsi, int S, cons
                 ldptr bc = l.vsq + s * 3;
                 const double bq = bc[0] * alq, b1 = bc[1], b2 = bc[2] * al2;
                 const double b2w = b2 * (r.p2y * r.ax - r.p2x * r.ay), b1y = b1 * r.ay, b1x = b1 * r.ax;
+                // no depth decay along the run: P + Q and P - Q leave the sums (t1 = a ps, t2 = i a pd) and meet them after the loop
 #pragma unroll
                 for (int j = 0; j < NB; j++) {
-                    const double t1r = K.ar[j] * ps[j], t1i = K.ai[j] * ps[j], t2r = -K.ai[j] * pd[j], t2i = K.ar[j] * pd[j];
-                    Sq[j][0] = fma(bq, t1r, Sq[j][0]);    Sq[j][1] = fma(bq, t1i, Sq[j][1]);
-                    S2[j][0] = fma(b2, t1r, S2[j][0]);    S2[j][1] = fma(b2, t1i, S2[j][1]);
-                    S26[j][0] = fma(b2w, t1r, S26[j][0]); S26[j][1] = fma(b2w, t1i, S26[j][1]);
-                    S1[j][0] = fma(b1, t2r, S1[j][0]);    S1[j][1] = fma(b1, t2i, S1[j][1]);
-                    S1y[j][0] = fma(b1y, t2r, S1y[j][0]); S1y[j][1] = fma(b1y, t2i, S1y[j][1]);
-                    S1x[j][0] = fma(b1x, t2r, S1x[j][0]); S1x[j][1] = fma(b1x, t2i, S1x[j][1]);
+                    const double ar = K.ar[j], ai = K.ai[j];
+                    Sq[j][0] = fma(bq, ar, Sq[j][0]);    Sq[j][1] = fma(bq, ai, Sq[j][1]);
+                    S2[j][0] = fma(b2, ar, S2[j][0]);    S2[j][1] = fma(b2, ai, S2[j][1]);
+                    S26[j][0] = fma(b2w, ar, S26[j][0]); S26[j][1] = fma(b2w, ai, S26[j][1]);
+                    S1[j][0] = fma(b1, ar, S1[j][0]);    S1[j][1] = fma(b1, ai, S1[j][1]);
+                    S1y[j][0] = fma(b1y, ar, S1y[j][0]); S1y[j][1] = fma(b1y, ai, S1y[j][1]);
+                    S1x[j][0] = fma(b1x, ar, S1x[j][0]); S1x[j][1] = fma(b1x, ai, S1x[j][1]);
                 }
             };
             RUN_LOOP(2, kin_rotate1(K), kin_rotate2(K), kin_rotate(K, m_), load_arm(src.rec(s), r));
+#pragma unroll
+            for (int j = 0; j < NB; j++) {
+                Sq[j][0] *= ps[j];  Sq[j][1] *= ps[j];
+                S2[j][0] *= ps[j];  S2[j][1] *= ps[j];
+                S26[j][0] *= ps[j]; S26[j][1] *= ps[j];
+                double t;                                             // times i pd
+                t = S1[j][0];  S1[j][0] = -S1[j][1] * pd[j];   S1[j][1] = t * pd[j];
+                t = S1y[j][0]; S1y[j][0] = -S1y[j][1] * pd[j]; S1y[j][1] = t * pd[j];
+                t = S1x[j][0]; S1x[j][0] = -S1x[j][1] * pd[j]; S1x[j][1] = t * pd[j];
+            }
             const double c3q = -az * r.qy, c3p = -az * r.p2y, c4q = az * r.qx, c4p = az * r.p2x;
 #pragma unroll
             for (int j = 0; j < NB; j++) {
