@@ -1675,41 +1675,168 @@ __device__ __forceinline__ void inertial_excitation_uv(const DevTables &T, cdptr
     for (int j = 0; j < NB; j++) one[j] = 1.0;
     Kin<NB> K;
     kin_reset(K, run_cache_of(l));                 // this sweep fills the run-start cache
+    // one strip in the general form: F += i w (t1 U' + t2 V') + pDyn A'
+    auto general_strip = [&](int s) {
+        cdptr rec = ds + (size_t)s * DS_N;
+        double U[6], V[6];
+        load_uv(l.uv + s * 12, U, V);
+        const double ax = rec[DS_A], ay = rec[DS_A + 1], az = rec[DS_A + 2];
+        const double qx = rec[DS_Q], qy = rec[DS_Q + 1], qz = rec[DS_Q + 2];
+        const double ai_ = rec[DS_IQ + 3];
+        double Aq[6];
+        Aq[0] = ai_ * qx;
+        Aq[1] = ai_ * qy;
+        Aq[2] = ai_ * qz;
+        Aq[3] = ai_ * (ay * qz - az * qy);
+        Aq[4] = ai_ * (az * qx - ax * qz);
+        Aq[5] = ai_ * (ax * qy - ay * qx);
+#pragma unroll
+        for (int j = 0; j < NB; j++) {
+            // i w t1 = i w s1 (P + Qk) a,  i w t2 = -w s1 (P - Qk) a   (a = e^{-i k xi}; Qk = 0 in deep water)
+            const double hs = fma(wd[j], K.Q[j], ws[j] * K.P[j]), hd = fma(-wd[j], K.Q[j], ws[j] * K.P[j]);
+            const double pp = sp[j] * (K.P[j] + K.Q[j]);                  // rho g zeta_s Cc
+            const double t1r = -hs * K.ai[j], t1i = hs * K.ar[j];
+            const double t2r = -hd * K.ar[j], t2i = -hd * K.ai[j];
+            const double pr = pp * K.ar[j], pi = pp * K.ai[j];
+#pragma unroll
+            for (int q = 0; q < 6; q++) {
+                F[j][q].re = fma(t1r, U[q], fma(t2r, V[q], fma(pr, Aq[q], F[j][q].re)));
+                F[j][q].im = fma(t1i, U[q], fma(t2i, V[q], fma(pi, Aq[q], F[j][q].im)));
+            }
+        }
+    };
+    if constexpr (RUN_LOOPS<NB>) {
+    // Loop over runs, specialised as in drag_excitation: with c1 = i hs a, c2 = -hd a, c3 = pp a the three terms are real
+    // multiples of the phasor (times i for the first), so
+    //  * vertical member (no phase rotation): REAL sums over the run's strips of hs U'_{0,1,3,4} and of pp a_i q_z - hd V'_2
+    //    (6 FMAs per strip and bin instead of 36 + 12), which meet the phasor once per run;
+    //  * upright pontoon (no depth decay; W_q the same for every strip, V'_s = I_1 [0, 0, 1, a_y, -a_x, 0]): seven complex sums
+    //    of the rotating phasor with real per-strip weights, which meet hs, hd, pp and the constant vectors once per run;
+    //  * anything else: the general strip.
+    if (S > 0) {
+        int s = 0;
+        int fl = dsi[0], fn = dsi[min(1, S - 1)];
+        auto next_step = [&]() -> int {
+            if (++s >= S) return 0;
+            fl = fn;
+            fn = dsi[min(s + 1, S - 1)];
+            return fl & DSI_M;
+        };
+#pragma unroll 1
+        while (s < S) {
+            cdptr rec0 = ds + (size_t)s * DS_N;
+            kin_start<NB, true, RC ? 1 : 0>(K, run_start_of(rec0), b, one, cb, sb);
+            if (!K.rot && (fl & DSI_VAX)) {
+                double G0[NB], G1[NB], G3[NB], G4[NB], Z2[NB];
+#pragma unroll
+                for (int j = 0; j < NB; j++) G0[j] = G1[j] = G3[j] = G4[j] = Z2[j] = 0.0;
+                const double ax = rec0[DS_A], ay = rec0[DS_A + 1];
+                auto body = [&]() {
+                    ldptr uv = l.uv + s * 12;
+                    const double u0 = uv[0], u1 = uv[1], u3 = uv[3], u4 = uv[4], v2 = uv[8];
+                    cdptr rec = ds + (size_t)s * DS_N;
+                    const double aq = rec[DS_IQ + 3] * rec[DS_Q + 2];
+#pragma unroll
+                    for (int j = 0; j < NB; j++) {
+                        const double wp = ws[j] * K.P[j];
+                        const double hs = fma(wd[j], K.Q[j], wp), hd = fma(-wd[j], K.Q[j], wp);
+                        const double pp = sp[j] * (K.P[j] + K.Q[j]);
+                        G0[j] = fma(hs, u0, G0[j]);
+                        G1[j] = fma(hs, u1, G1[j]);
+                        G3[j] = fma(hs, u3, G3[j]);
+                        G4[j] = fma(hs, u4, G4[j]);
+                        Z2[j] = fma(pp, aq, fma(-hd, v2, Z2[j]));
+                    }
+                };
+                RUN_LOOP(1, kin_decay1(K), kin_decay2(K), kin_decay(K, m_), );
+#pragma unroll
+                for (int j = 0; j < NB; j++) {
+                    const double ar = K.ar[j], ai = K.ai[j];
+                    const double g5 = ax * G1[j] - ay * G0[j], z3 = ay * Z2[j], z4 = -ax * Z2[j];
+                    F[j][0].re = fma(-ai, G0[j], F[j][0].re);
+                    F[j][0].im = fma(ar, G0[j], F[j][0].im);
+                    F[j][1].re = fma(-ai, G1[j], F[j][1].re);
+                    F[j][1].im = fma(ar, G1[j], F[j][1].im);
+                    F[j][2].re = fma(ar, Z2[j], F[j][2].re);
+                    F[j][2].im = fma(ai, Z2[j], F[j][2].im);
+                    F[j][3].re = fma(-ai, G3[j], fma(ar, z3, F[j][3].re));
+                    F[j][3].im = fma(ar, G3[j], fma(ai, z3, F[j][3].im));
+                    F[j][4].re = fma(-ai, G4[j], fma(ar, z4, F[j][4].re));
+                    F[j][4].im = fma(ar, G4[j], fma(ai, z4, F[j][4].im));
+                    F[j][5].re = fma(-ai, g5, F[j][5].re);
+                    F[j][5].im = fma(ar, g5, F[j][5].im);
+                }
+            } else if (!K.dec && !K.vert && (fl & (DSI_AXAL | DSI_CIRC)) == DSI_AXAL) {
+                const double qx = rec0[DS_Q], qy = rec0[DS_Q + 1], p2x = rec0[DS_P2], p2y = rec0[DS_P2 + 1];
+                const double alq = qx * cb + qy * sb, al2 = p2x * cb + p2y * sb;
+                const double wq = rec0[DS_A] * qy - rec0[DS_A + 1] * qx, az = rec0[DS_A + 2];
+                double Sq[NB][2], S2[NB][2], S26[NB][2], S1[NB][2], S1y[NB][2], S1x[NB][2], SA[NB][2];
+#pragma unroll
+                for (int j = 0; j < NB; j++) {
+                    Sq[j][0] = Sq[j][1] = S2[j][0] = S2[j][1] = S26[j][0] = S26[j][1] = SA[j][0] = SA[j][1] = 0.0;
+                    S1[j][0] = S1[j][1] = S1y[j][0] = S1y[j][1] = S1x[j][0] = S1x[j][1] = 0.0;
+                }
+                auto body = [&]() {
+                    cdptr rec = ds + (size_t)s * DS_N;
+                    const double ax = rec[DS_A], ay = rec[DS_A + 1];
+                    const double bq = rec[DS_IQ] * alq, b1 = rec[DS_IQ + 1], b2 = rec[DS_IQ + 2] * al2, ba = rec[DS_IQ + 3];
+                    const double b2w = b2 * (p2y * ax - p2x * ay), b1y = b1 * ay, b1x = b1 * ax;
+#pragma unroll
+                    for (int j = 0; j < NB; j++) {
+                        const double ar = K.ar[j], ai = K.ai[j];
+                        Sq[j][0] = fma(bq, ar, Sq[j][0]);    Sq[j][1] = fma(bq, ai, Sq[j][1]);
+                        S2[j][0] = fma(b2, ar, S2[j][0]);    S2[j][1] = fma(b2, ai, S2[j][1]);
+                        S26[j][0] = fma(b2w, ar, S26[j][0]); S26[j][1] = fma(b2w, ai, S26[j][1]);
+                        S1[j][0] = fma(b1, ar, S1[j][0]);    S1[j][1] = fma(b1, ai, S1[j][1]);
+                        S1y[j][0] = fma(b1y, ar, S1y[j][0]); S1y[j][1] = fma(b1y, ai, S1y[j][1]);
+                        S1x[j][0] = fma(b1x, ar, S1x[j][0]); S1x[j][1] = fma(b1x, ai, S1x[j][1]);
+                        SA[j][0] = fma(ba, ar, SA[j][0]);    SA[j][1] = fma(ba, ai, SA[j][1]);
+                    }
+                };
+                RUN_LOOP(2, kin_rotate1(K), kin_rotate2(K), kin_rotate(K, m_), );
+                const double c3q = -az * qy, c3p = -az * p2y, c4q = az * qx, c4p = az * p2x;
+#pragma unroll
+                for (int j = 0; j < NB; j++) {
+                    const double wp = ws[j] * K.P[j];
+                    const double hs = fma(wd[j], K.Q[j], wp), hd = fma(-wd[j], K.Q[j], wp);
+                    const double pp = sp[j] * (K.P[j] + K.Q[j]);
+                    // c1 = i hs a:  (re, im) -> (-hs im, hs re);  c2 = -hd a;  c3 = pp a (shares W_q with the axial term)
+                    const double qr = fma(pp, SA[j][0], -hs * Sq[j][1]), qi = fma(pp, SA[j][1], hs * Sq[j][0]);
+                    const double s2r = -hs * S2[j][1], s2i = hs * S2[j][0];
+                    const double s26r = -hs * S26[j][1], s26i = hs * S26[j][0];
+                    const double s1r = -hd * S1[j][0], s1i = -hd * S1[j][1];
+                    const double s1yr = -hd * S1y[j][0], s1yi = -hd * S1y[j][1];
+                    const double s1xr = -hd * S1x[j][0], s1xi = -hd * S1x[j][1];
+                    F[j][0].re = fma(qx, qr, fma(p2x, s2r, F[j][0].re));
+                    F[j][0].im = fma(qx, qi, fma(p2x, s2i, F[j][0].im));
+                    F[j][1].re = fma(qy, qr, fma(p2y, s2r, F[j][1].re));
+                    F[j][1].im = fma(qy, qi, fma(p2y, s2i, F[j][1].im));
+                    F[j][2].re += s1r;
+                    F[j][2].im += s1i;
+                    F[j][3].re = fma(c3q, qr, fma(c3p, s2r, F[j][3].re + s1yr));
+                    F[j][3].im = fma(c3q, qi, fma(c3p, s2i, F[j][3].im + s1yi));
+                    F[j][4].re = fma(c4q, qr, fma(c4p, s2r, F[j][4].re - s1xr));
+                    F[j][4].im = fma(c4q, qi, fma(c4p, s2i, F[j][4].im - s1xi));
+                    F[j][5].re = fma(wq, qr, F[j][5].re + s26r);
+                    F[j][5].im = fma(wq, qi, F[j][5].im + s26i);
+                }
+            } else {
+                auto body = [&]() { general_strip(s); };
+                RUN_LOOP(8, (kin_rotate1(K), kin_decay1(K)), (kin_rotate2(K), kin_decay2(K)), (kin_rotate(K, m_), kin_decay(K, m_)), );
+            }
+        }
+    }
+    } else {
     if (S > 0) {
         int fn = dsi[0];
 #pragma unroll 1
         for (int s = 0; s < S; s++) {
-            cdptr rec = ds + (size_t)s * DS_N;
-            double U[6], V[6];
-            load_uv(l.uv + s * 12, U, V);
-            const double ax = rec[DS_A], ay = rec[DS_A + 1], az = rec[DS_A + 2];
-            const double qx = rec[DS_Q], qy = rec[DS_Q + 1], qz = rec[DS_Q + 2];
-            const double ai_ = rec[DS_IQ + 3];
             const int fl = fn;
             fn = dsi[min(s + 1, S - 1)];
-            kin_advance<NB, true, RC ? 1 : 0>(K, fl, rec, b, one, cb, sb);
-            double Aq[6];
-            Aq[0] = ai_ * qx;
-            Aq[1] = ai_ * qy;
-            Aq[2] = ai_ * qz;
-            Aq[3] = ai_ * (ay * qz - az * qy);
-            Aq[4] = ai_ * (az * qx - ax * qz);
-            Aq[5] = ai_ * (ax * qy - ay * qx);
-#pragma unroll
-            for (int j = 0; j < NB; j++) {
-                // i w t1 = i w s1 (P + Qk) a,  i w t2 = -w s1 (P - Qk) a   (a = e^{-i k xi}; Qk = 0 in deep water)
-                const double hs = fma(wd[j], K.Q[j], ws[j] * K.P[j]), hd = fma(-wd[j], K.Q[j], ws[j] * K.P[j]);
-                const double pp = sp[j] * (K.P[j] + K.Q[j]);                  // rho g zeta_s Cc
-                const double t1r = -hs * K.ai[j], t1i = hs * K.ar[j];
-                const double t2r = -hd * K.ar[j], t2i = -hd * K.ai[j];
-                const double pr = pp * K.ar[j], pi = pp * K.ai[j];
-#pragma unroll
-                for (int q = 0; q < 6; q++) {
-                    F[j][q].re = fma(t1r, U[q], fma(t2r, V[q], fma(pr, Aq[q], F[j][q].re)));
-                    F[j][q].im = fma(t1i, U[q], fma(t2i, V[q], fma(pi, Aq[q], F[j][q].im)));
-                }
-            }
+            kin_advance<NB, true, RC ? 1 : 0>(K, fl, ds + (size_t)s * DS_N, b, one, cb, sb);
+            general_strip(s);
         }
+    }
     }
     // (the caller's barrier before the first linearisation also orders these uv reads before the strip phase's writes)
 }
