@@ -1358,9 +1358,12 @@ __device__ __forceinline__ void strip_phase(cdptr ds, ciptr dsi, int S,
         }
     }
     if (FRESH) {
-        // B_drag: reduce the 21 unique entries over the lanes of each wave (three tile rounds), then over waves
+        // B_drag: reduce the 21 unique entries over the lanes of each wave (four tile rounds), then over waves; only the
+        // waves that own strips (S <= 64: the first alone) take part
+        const int nwv_s = min(nwv, (S + 63) >> 6);
         ldptr tile = l.tile + wv * TR_ROWS * TR_STRIDE;
         ldptr wr = tile + tile_pos(lane);
+        if (wv < nwv_s)
 #pragma unroll
         for (int r0 = 0; r0 < 21; r0 += TR_ROWS) {
             wave_lds_fence();
@@ -1377,7 +1380,7 @@ __device__ __forceinline__ void strip_phase(cdptr ds, ciptr dsi, int S,
             const int lo = i < j ? i : j, hi = i < j ? j : i;
             const int e = lo * 6 - (lo * (lo - 1)) / 2 + (hi - lo);
             double acc = 0.0;
-            for (int q = 0; q < nwv; q++) acc += l.bdw[q * 24 + e];
+            for (int q = 0; q < nwv_s; q++) acc += l.bdw[q * 24 + e];
             l.Bd[tid] = acc;
         }
     }
