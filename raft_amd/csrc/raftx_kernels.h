@@ -1126,8 +1126,60 @@ __device__ __forceinline__ void linearize_passA(cdptr ds, ciptr dsi, int S,
                 D2s += fma(gxr, gxr, fma(gxi, gxi, fma(gyr, gyr, gyi * gyi)));
             }
         }
+        // RT 3, an upright pontoon: P + Q, P - Q do not change along the run and the rotation keeps |a|; the arm moves along q,
+        // (ax, ay) = (ax0, ay0) + lam (qx, qy).  With R(X) = -i X and
+        //   Zc = R(X2) + ay0 R(X3) - ax0 R(X4),  Zl = qy R(X3) - qx R(X4);   Yc = Hy + w2_0 R(X5),  Yl = (p2y qx - p2x qy) R(X5)
+        //   |v_q|^2  = alq^2 |a|^2 ps^2 + |Hx|^2                     + 2 alq ps Re(conj(a) Hx)
+        //   |v_z|^2  = |a|^2 pd^2 + |Zc + lam Zl|^2                  + 2 pd Re(conj(i a) (Zc + lam Zl))
+        //   |v_p2|^2 = al2^2 |a|^2 ps^2 + |Yc + lam Yl|^2            + 2 al2 ps Re(conj(a) (Yc + lam Yl))
+        // the first two columns are polynomials in lam summed over this lane's bins once per run; the cross terms cost
+        // 10 FMAs per strip and bin (22 in the direct form).
+        double hxr[NB], hxi[NB], zcr[NB], zci[NB], zlr[NB], zli[NB], ycr[NB], yci[NB], ylr[NB], yli[NB];
+        double E0 = 0.0, e10 = 0.0, e11 = 0.0, e12 = 0.0, e20 = 0.0, e21 = 0.0, e22 = 0.0, ax0 = 0.0, ay0 = 0.0;
+        if constexpr (RT == 3) {
+            const double alq = r.qx * cb + r.qy * sb, al2 = r.p2x * cb + r.p2y * sb;
+            ax0 = r.ax;
+            ay0 = r.ay;
+            const double w20 = r.p2y * ax0 - r.p2x * ay0, kap2 = r.p2y * r.qx - r.p2x * r.qy;
+#pragma unroll
+            for (int j = 0; j < NB; j++) {
+                const double A2 = fma(K.ar[j], K.ar[j], K.ai[j] * K.ai[j]), ps = psh[j], pd = pdh[j];
+                const double zr = fma(-ax0, X[j][4].im, fma(ay0, X[j][3].im, X[j][2].im));
+                const double zi = fma(ax0, X[j][4].re, fma(-ay0, X[j][3].re, -X[j][2].re));
+                const double lr = fma(-r.qx, X[j][4].im, r.qy * X[j][3].im), li = fma(r.qx, X[j][4].re, -(r.qy * X[j][3].re));
+                const double yr = fma(w20, X[j][5].im, H.yr[j]), yi = fma(-w20, X[j][5].re, H.yi[j]);
+                const double mr = kap2 * X[j][5].im, mi = -(kap2 * X[j][5].re);
+                const double sx = 2.0 * alq * ps, sz = 2.0 * pd, sy = 2.0 * al2 * ps;
+                hxr[j] = sx * H.xr[j]; hxi[j] = sx * H.xi[j];
+                zcr[j] = sz * zr; zci[j] = sz * zi; zlr[j] = sz * lr; zli[j] = sz * li;
+                ycr[j] = sy * yr; yci[j] = sy * yi; ylr[j] = sy * mr; yli[j] = sy * mi;
+                const double aps = A2 * ps * ps;
+                E0 += fma(alq * alq, aps, fma(H.xr[j], H.xr[j], H.xi[j] * H.xi[j]));
+                e10 += fma(A2 * pd, pd, fma(zr, zr, zi * zi));
+                e11 += 2.0 * fma(zr, lr, zi * li);
+                e12 += fma(lr, lr, li * li);
+                e20 += fma(al2 * al2, aps, fma(yr, yr, yi * yi));
+                e21 += 2.0 * fma(yr, mr, yi * mi);
+                e22 += fma(mr, mr, mi * mi);
+            }
+        }
         auto strip = [&](double (&v)[3]) {          // strip s at the state K
-            if constexpr (RT == 4) {
+            if constexpr (RT == 3) {
+                const double lam = fma(r.ax - ax0, r.qx, (r.ay - ay0) * r.qy);
+                double v0 = E0, v1 = fma(lam, fma(lam, e12, e11), e10), v2 = fma(lam, fma(lam, e22, e21), e20);
+#pragma unroll
+                for (int j = 0; j < NB; j++) {
+                    const double ar = K.ar[j], ai = K.ai[j];
+                    v0 = fma(ar, hxr[j], fma(ai, hxi[j], v0));
+                    const double wr = fma(lam, zlr[j], zcr[j]), wi = fma(lam, zli[j], zci[j]);
+                    v1 = fma(ar, wi, fma(-ai, wr, v1));
+                    const double yr = fma(lam, ylr[j], ycr[j]), yi = fma(lam, yli[j], yci[j]);
+                    v2 = fma(ar, yr, fma(ai, yi, v2));
+                }
+                v[0] = v0;
+                v[1] = v1;
+                v[2] = v2;
+            } else if constexpr (RT == 4) {
                 const double az = r.az;
                 double v0 = hz2s, v1 = fma(az, fma(az, D2s, D1s), D0s);
 #pragma unroll
@@ -1139,7 +1191,7 @@ __device__ __forceinline__ void linearize_passA(cdptr ds, ciptr dsi, int S,
                 v[0] = v0;
                 v[1] = v1;
                 v[2] = 0.0;
-            } else if (RT == 2 || RT == 3) {
+            } else if (RT == 2) {
                 passA_core<NB, RT>(K.ar, K.ai, psh, pdh, r, (fl & DSI_CIRC) != 0, cb, sb, X, H, v[0], v[1], v[2]);
             } else {
                 double ps[NB], pd[NB];
