@@ -7,7 +7,7 @@
 // (:811-1201) -- runs here as a handful of small kernels over ALL designs of a sweep at once:
 //
 //   k_geom_member   one thread per member : pose (q, p1, p2, R, end A), wet-strip count, member hydrostatics
-//   k_geom_design_counts / k_geom_scan / k_geom_offsets : exclusive scans of the wet / MacCamy-Fuchs strip counts
+//   k_geom_scan          : exclusive scan over the designs of the wet / MacCamy-Fuchs strip totals (added up by the member pass)
 //                   (per-design totals, one-workgroup scan over designs, member offsets inside each design)
 //   k_geom_reduce   thread per (design, role): member -> platform reduction of hydrostatics / weight stiffness / inertia
 //   k_geom_design   one wavefront / design: the design's strip records generated straight into LDS (lanes = candidate
@@ -145,7 +145,6 @@ struct GeomArgs {
     int nw;
     const double *k;             // [nw] or null
     int *cnt, *cntm;             // [nMember] wet strips / MacCamy-Fuchs rows per member
-    int64_t *soff, *cmsoff;      // [nMember+1] exclusive scans of the above
     double *mpose, *mhyd;        // [nMember,MP_N], [nMember,MH_N]
     double *abi;                 // [nStrips,NF] generated ABI records
     double *mcfaux;              // [nRows,3] R, Ca_p1, Ca_p2 of every MacCamy-Fuchs strip
@@ -538,7 +537,11 @@ __device__ inline int geom_member_inertia(const double *gm, const double *gs, in
 // to find a free wave slot beside the fused kernel of the batch before)
 __global__ void k_geom_zero(GeomArgs A) {
     const int d = blockIdx.x * blockDim.x + threadIdx.x;
-    if (d < A.nDesign) A.drho[d] = 0.0;
+    if (d < A.nDesign) {
+        A.drho[d] = 0.0;
+        A.off[d + 1] = 0;                                 // per-design totals: the member pass adds into them (k_geom_scan
+        A.cmoff[d + 1] = 0;                               // turns them into offsets)
+    }
     if (d < 4) A.err[d] = 0;
     if (d < 5) A.tot[d] = 0;
     if (d == 0) { A.off[0] = 0; A.cmoff[0] = 0; }
@@ -553,6 +556,9 @@ __global__ void k_geom_mdesign(GeomArgs A) {
         return;
     }
     for (int64_t m = m0; m < m1; m++) A.mdesign_w[m] = d;
+    // stations and members of the largest design: they size the LDS of k_geom_design
+    atomicMax(reinterpret_cast<unsigned long long *>(A.tot + 3), (unsigned long long)(A.so(m1) - A.so(m0)));
+    atomicMax(reinterpret_cast<unsigned long long *>(A.tot + 4), (unsigned long long)(m1 - m0));
 }
 #define GEOM_MAX_STATIONS 1024
 // Member of this thread.  With A.mgrid > 0 the threads are laid out (member position, design) with the design running
@@ -649,8 +655,12 @@ __global__ __launch_bounds__(128) void k_geom_member(GeomArgs A) {
             if (geom_along(rA[2], rB[2], s.ls, L) < 0) wet++;
         }
     }
+    const int wetm = ((flags & RAFTX_GM_FLAG_MCF) && circ && !(flags & RAFTX_GM_FLAG_POTMOD)) ? wet : 0;
     A.cnt[m] = wet;
-    A.cntm[m] = ((flags & RAFTX_GM_FLAG_MCF) && circ && !(flags & RAFTX_GM_FLAG_POTMOD)) ? wet : 0;
+    A.cntm[m] = wetm;
+    // per-design totals (integer sums: the order of the additions does not matter)
+    if (wet) atomicAdd(reinterpret_cast<unsigned long long *>(A.off + d + 1), (unsigned long long)wet);
+    if (wetm) atomicAdd(reinterpret_cast<unsigned long long *>(A.cmoff + d + 1), (unsigned long long)wetm);
     // ---- Member.getHydrostatics, rigid branch, about the member's node (raft_member.py:838-1010)
     double C[36], F[6], Vt = 0.0, rcV[3] = {0, 0, 0}, AWPm = 0.0;
     for (int i = 0; i < 36; i++) C[i] = 0.0;
@@ -790,32 +800,34 @@ __global__ __launch_bounds__(128) void k_geom_reinertia(GeomArgs A) {
         for (int i = 0; i < MI_N; i++) mi[i] = 0.0;
 }
 
-// Exclusive scans of the per-member wet-strip / MacCamy-Fuchs-row counts, in three steps that all run wide: per-design
-// totals (thread per design), a scan over the DESIGNS (one workgroup; 10^4 entries instead of 10^5 members), and the
-// member offsets inside every design (thread per design).
-__global__ void k_geom_design_counts(GeomArgs A) {
-    if (A.err[2] | A.err[3]) return;                      // rejected descriptors: phase 2 reports them
-    const int d = blockIdx.x * blockDim.x + threadIdx.x;
-    if (d >= A.nDesign) return;
-    long long a = 0, b = 0;
-    for (int64_t m = A.mo(d); m < A.mo(d + 1); m++) { a += A.cnt[m]; b += A.cntm[m]; }
-    A.off[d + 1] = a;                                    // totals parked one slot up; k_geom_scan turns them into offsets
-    A.cmoff[d + 1] = b;
-    atomicMax(reinterpret_cast<unsigned long long *>(A.tot + 2), (unsigned long long)a);
-    // stations and members of the largest design: they size the LDS of k_geom_design
-    atomicMax(reinterpret_cast<unsigned long long *>(A.tot + 3), (unsigned long long)(A.so(A.mo(d + 1)) - A.so(A.mo(d))));
-    atomicMax(reinterpret_cast<unsigned long long *>(A.tot + 4), (unsigned long long)(A.mo(d + 1) - A.mo(d)));
-}
+// Exclusive scan over the DESIGNS of the wet-strip / MacCamy-Fuchs-row totals the member pass left in off[d + 1] /
+// cmoff[d + 1] (one workgroup; 10^4 entries); the member offsets inside a design are formed where they are used
+// (k_geom_design).  Also the largest design (LDS of k_geom_design), and the error flags: this is the last kernel of
+// phase 1.
+#define GSCAN_CH 4096        // designs per pass of k_geom_scan (two 32-bit LDS rows)
 __global__ __launch_bounds__(1024) void k_geom_scan(GeomArgs A) {
-    __shared__ long long part[2][1025];
-    const int t = threadIdx.x, T = blockDim.x;
+    __shared__ long long part[2][17];
+    __shared__ unsigned buf[2][GSCAN_CH];
+    const int t = threadIdx.x, T = 1024;
     const int n = A.nDesign;
-    const int per = (n + T - 1) / T, lo = t * per, hi = (lo + per < n) ? lo + per : n;
-    long long a = 0, b = 0;
-    for (int i = lo; i < hi; i++) { a += A.off[i + 1]; b += A.cmoff[i + 1]; }
-    // exclusive scan of the 1024 partial sums: inside a wave by shuffles, across the 16 waves through LDS (a serial pass
-    // of thread 0 over the partials took 30 us of the member pass that the next batch's generation waits for)
-    {
+    constexpr int PER = GSCAN_CH / 1024;
+    // Chunks of GSCAN_CH designs go through LDS, so that global memory (and the page-locked copy of the offsets for the
+    // host) is read and written by consecutive lanes; a thread then scans PER consecutive entries of the chunk.  (A
+    // thread walking its own stretch of the global arrays took 50 us for 10^4 designs, on the path between two batches.)
+    long long carrya = 0, carryb = 0, mx = 0;
+    for (int c0 = 0; c0 < n; c0 += GSCAN_CH) {
+        const int cn = (n - c0 < GSCAN_CH) ? n - c0 : GSCAN_CH;
+        for (int i = t; i < GSCAN_CH; i += T) {
+            long long va = 0, vb = 0;
+            if (i < cn) { va = A.off[c0 + i + 1]; vb = A.cmoff[c0 + i + 1]; }
+            buf[0][i] = (unsigned)va;
+            buf[1][i] = (unsigned)vb;
+            mx = va > mx ? va : mx;
+        }
+        __syncthreads();
+        long long a = 0, b = 0;
+        for (int i = 0; i < PER; i++) { a += buf[0][t * PER + i]; b += buf[1][t * PER + i]; }
+        // exclusive scan of the 1024 partial sums: inside a wave by shuffles, across the 16 waves through LDS
         const int lane = t & 63, wv = t >> 6;
         long long ia = a, ib = b;
         for (int o = 1; o < 64; o <<= 1) {
@@ -824,54 +836,49 @@ __global__ __launch_bounds__(1024) void k_geom_scan(GeomArgs A) {
         }
         if (lane == 63) { part[0][wv] = ia; part[1][wv] = ib; }
         __syncthreads();
-        long long basea = 0, baseb = 0;
-        for (int i = 0; i < wv; i++) { basea += part[0][i]; baseb += part[1][i]; }
+        long long ra = carrya, rb = carryb, sa = 0, sb = 0;
+        for (int i = 0; i < 16; i++) {
+            if (i < wv) { ra += part[0][i]; rb += part[1][i]; }
+            sa += part[0][i]; sb += part[1][i];
+        }
+        ra += ia - a;                                     // offset of this thread's first design
+        rb += ib - b;
+        for (int i = 0; i < PER; i++) {                   // inclusive running totals -> offsets of design i + 1 (below 2^32: the
+            ra += buf[0][t * PER + i];                    // strip tables of that many strips would not fit any memory)
+            rb += buf[1][t * PER + i];
+            buf[0][t * PER + i] = (unsigned)ra;
+            buf[1][t * PER + i] = (unsigned)rb;
+        }
         __syncthreads();
-        part[0][t] = basea + ia - a;                      // exclusive prefix of this thread
-        part[1][t] = baseb + ib - b;
-        if (t == T - 1) { part[0][T] = basea + ia; part[1][T] = baseb + ib; }
+        for (int i = t; i < cn; i += T) {
+            const long long va = buf[0][i], vb = buf[1][i];
+            A.off[c0 + i + 1] = va;
+            A.cmoff[c0 + i + 1] = vb;
+            if (A.hostOut) A.hostOut[8 + c0 + i + 1] = va;
+        }
+        carrya += sa;
+        carryb += sb;
+        __syncthreads();
     }
+    if (mx) atomicMax(reinterpret_cast<unsigned long long *>(A.tot + 2), (unsigned long long)mx);
     __syncthreads();
     if (t == 0) {
-        const long long sa = part[0][T], sb = part[1][T];
         A.off[0] = 0;
         A.cmoff[0] = 0;
-        A.tot[0] = sa;
-        A.tot[1] = sb;
+        A.tot[0] = carrya;
+        A.tot[1] = carryb;
         if (A.hostOut) {
-            A.hostOut[0] = sa;
-            A.hostOut[1] = sb;
-            A.hostOut[2] = A.tot[2];                     // final: k_geom_design_counts has completed
+            A.hostOut[0] = carrya;
+            A.hostOut[1] = carryb;
+            A.hostOut[2] = A.tot[2];                     // final: every thread's maximum is in (a barrier ago)
+            int *e = reinterpret_cast<int *>(A.hostOut + 3);        // every error flag is final: phase 1 ends here
+            e[0] = A.err[0]; e[1] = A.err[1]; e[2] = A.err[2]; e[3] = A.err[3];
             A.hostOut[5] = A.tot[3];
             A.hostOut[6] = A.tot[4];
             A.hostOut[8] = 0;
         }
     }
-    __syncthreads();
-    a = part[0][t]; b = part[1][t];
-    for (int i = lo; i < hi; i++) {                      // inclusive running totals -> offsets of design i+1
-        a += A.off[i + 1]; b += A.cmoff[i + 1];
-        A.off[i + 1] = a; A.cmoff[i + 1] = b;
-        if (A.hostOut) A.hostOut[8 + i + 1] = a;
-    }
 }
-// member offsets from the design offsets
-__global__ void k_geom_offsets(GeomArgs A) {
-    const int d = blockIdx.x * blockDim.x + threadIdx.x;
-    if (d == 0 && A.hostOut) {                            // the last kernel of phase 1: every error flag is final
-        int *e = reinterpret_cast<int *>(A.hostOut + 3);
-        e[0] = A.err[0]; e[1] = A.err[1]; e[2] = A.err[2]; e[3] = A.err[3];
-    }
-    if (A.err[2] | A.err[3]) return;                      // rejected descriptors: phase 2 reports them
-    if (d >= A.nDesign) return;
-    int64_t a = A.off[d], b = A.cmoff[d];
-    for (int64_t m = A.mo(d); m < A.mo(d + 1); m++) {
-        A.soff[m] = a; A.cmsoff[m] = b;
-        a += A.cnt[m]; b += A.cntm[m];
-    }
-    if (d == A.nDesign - 1) { A.soff[A.nMember] = a; A.cmsoff[A.nMember] = b; }
-}
-
 // MacCamy-Fuchs (Cm_p1, Cm_p2)(k) with its cosine ramp, raft_member.py:1459-1484:
 //   Cm = 4i / (pi (kR)^2 H1'(kR)),  H1' = (H0 - H2)/2  (Hankel functions of the first kind)
 __global__ __launch_bounds__(64) void k_geom_mcf(GeomArgs A, int64_t nRows) {
@@ -1134,8 +1141,12 @@ __global__ __launch_bounds__(GD_T) void k_geom_design(GeomArgs A) {
                 row[RAFTX_F_AP1] = rho * v_i * Ca1;
                 row[RAFTX_F_AP2] = rho * v_i * Ca2;
                 if (mcf) {
-                    const int64_t cmrow0 = A.cmsoff[m], cmbase = A.cmsoff[m0];
-                    const int posm = pos - (int)(A.soff[m] - i0);
+                    // rows of this member in the MacCamy-Fuchs table / its first wet strip in the design: sums of the
+                    // member pass's counts over the members before it (a design has about ten)
+                    int64_t cmbase = A.cmoff[d], cmrow0 = cmbase;
+                    int wet0 = 0;
+                    for (int64_t mm = m0; mm < m; mm++) { cmrow0 += A.cntm[mm]; wet0 += A.cnt[mm]; }
+                    const int posm = pos - wet0;
                     row[RAFTX_F_MCF] = (double)((cmrow0 - cmbase) + posm);
                     double *ax = A.mcfaux + (size_t)(cmrow0 + posm) * 3;
                     ax[0] = ds0 / 2; ax[1] = Ca1; ax[2] = Ca2;
@@ -1190,7 +1201,29 @@ __global__ __launch_bounds__(GD_T) void k_geom_design(GeomArgs A) {
         pjv[t] = pj;
     }
     __syncthreads();
-    if (lane == 0) {                                      // pair tests -> runs: 64-strip cap, smallest step of the run
+    // pair tests -> runs (run start of every strip, smallest step of the run; a run is cut after 64 strips).  With one strip
+    // per lane: the start of strip t is the last strip <= t that failed its pair test (ballots, the first wave's last start
+    // through LDS), the smallest step an integer minimum over the run's strips (positive doubles order like their bit
+    // patterns).  Designs with more strips than lanes, or with a run that hits the cap, take the serial pass.
+    bool serial = S > GD_T;
+    if (!serial) {
+        const int wv = lane >> 6, ln = lane & 63;
+        const bool st = lane < S && (lane == 0 || !okv[lane]);
+        const unsigned long long mask = __ballot(st);
+        if (ln == 0) wcnt[wv] = mask ? wv * 64 + 63 - __builtin_clzll(mask) : -1;
+        if (st) reinterpret_cast<unsigned long long *>(unv)[lane] = 0x7ff0000000000000ull;
+        __syncthreads();
+        const unsigned long long below = mask & (ln == 63 ? ~0ull : ((2ull << ln) - 1ull));
+        int s = below ? wv * 64 + 63 - __builtin_clzll(below) : -1;
+        for (int w = wv - 1; w >= 0 && s < 0; w--) s = wcnt[w];
+        if (lane < S) {
+            rsv[lane] = s;
+            if (!st) atomicMin(reinterpret_cast<unsigned long long *>(unv) + s, (unsigned long long)__double_as_longlong(pjv[lane]));
+        }
+        serial = __syncthreads_or(lane < S && lane - s >= 64) != 0;
+        if (!serial && st && reinterpret_cast<unsigned long long *>(unv)[lane] == 0x7ff0000000000000ull) unv[lane] = 0.0;
+    }
+    if (serial && lane == 0) {
         int s = 0;
         double unit = 0.0;
         for (int t = 0; t < S; t++) {
@@ -1283,21 +1316,36 @@ __global__ __launch_bounds__(GD_T) void k_geom_design(GeomArgs A) {
     }
     __syncthreads();
     GEOM_PHASE(5);
-    if (lane < 36) {
-        const int i = lane / 6, j = lane % 6;
+    // lane (k, i, j): the sum over the k-th third of the strips; the three partial sums meet in lane (0, i, j)
+    {
+        const int k3 = lane / 36, e = lane % 36, i = e / 6, j = e % 6;
         double am = 0.0;
-        for (int s = 0; s < S; s++) {
-            const double *g = rec + (size_t)s * GV;
-            for (int tt = 0; tt < 3; tt++) am += g[tt * 7] * g[tt * 7 + 1 + i] * g[tt * 7 + 1 + j];
+        if (k3 < 3) {
+            const int lo = (int)(((long long)S * k3) / 3), hi = (int)(((long long)S * (k3 + 1)) / 3);
+            for (int s = lo; s < hi; s++) {
+                const double *g = rec + (size_t)s * GV;
+                for (int tt = 0; tt < 3; tt++) am += g[tt * 7] * g[tt * 7 + 1 + i] * g[tt * 7 + 1 + j];
+            }
         }
-        const size_t o = (size_t)d * 36 + lane;
-        A.A[o] = am;
-        if (A.add_mask & RAFTX_ADD_MORISON) A.M0[o] += am;
-        if (A.add_mask & RAFTX_ADD_HYDROSTATIC) A.C0[o] += A.Ch[o];
-        if (A.add_mask & RAFTX_ADD_INERTIA) { A.M0[o] += A.Ms[o]; A.C0[o] += A.Cs[o]; }
+        __syncthreads();                                  // the partial sums go where the g-vectors were
+        if (k3 < 3) rec[lane] = am;
+        __syncthreads();
+        if (lane < 36) {
+            am = (rec[lane] + rec[36 + lane]) + rec[72 + lane];
+            A.A[(size_t)d * 36 + lane] = am;              // k_geom_addup adds it (and the platform reductions) to M0 / C0
+        }
     }
     GEOM_PHASE(6);
     (void)mfl;
+}
+// What the device adds to the caller's matrices (add_mask), in a fixed order: Morison added mass (k_geom_design), then the
+// member -> platform reductions (k_geom_reduce, which runs beside the generation on its own stream).
+__global__ void k_geom_addup(GeomArgs A) {
+    const size_t o = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (o >= (size_t)A.nDesign * 36) return;
+    if (A.add_mask & RAFTX_ADD_MORISON) A.M0[o] += A.A[o];
+    if (A.add_mask & RAFTX_ADD_HYDROSTATIC) A.C0[o] += A.Ch[o];
+    if (A.add_mask & RAFTX_ADD_INERTIA) { A.M0[o] += A.Ms[o]; A.C0[o] += A.Cs[o]; }
 }
 // dynamic LDS of k_geom_design for designs of up to maxS strips
 static size_t geom_design_lds(int maxS, int maxSta, int maxMem) {

@@ -1179,7 +1179,6 @@ static int build_phase1(raftx_ctx *c, hipStream_t sCopy, hipStream_t sPrep, int 
         };
         void *p_[13] = {nullptr};
         if (alloc((size_t)nMember * sizeof(int), &p_[0], tb) || alloc((size_t)nMember * sizeof(int), &p_[1], tb) ||
-            alloc(((size_t)nMember + 1) * sizeof(int64_t), &p_[2], tb) || alloc(((size_t)nMember + 1) * sizeof(int64_t), &p_[3], tb) ||
             alloc((size_t)nMember * MP_N * sizeof(double), &p_[4], tb) || alloc((size_t)nMember * MH_N * sizeof(double), &p_[5], tb) ||
             alloc((size_t)nMember * MI_N * sizeof(double), &p_[6], tb) || alloc(4 * sizeof(int), &p_[7], tb) ||
             alloc((size_t)nMember * sizeof(int), &p_[12], tb) ||
@@ -1188,7 +1187,6 @@ static int build_phase1(raftx_ctx *c, hipStream_t sCopy, hipStream_t sPrep, int 
             alloc(((size_t)nDesign + 1) * sizeof(int64_t), &p_[11], c->design_allocs))
             return -2;
         A.cnt = (int *)p_[0]; A.cntm = (int *)p_[1];
-        A.soff = (int64_t *)p_[2]; A.cmsoff = (int64_t *)p_[3];
         A.mpose = (double *)p_[4]; A.mhyd = (double *)p_[5]; A.minert = (double *)p_[6];
         errd = (int *)p_[7]; A.err = errd;
         A.drho = (double *)p_[8];
@@ -1213,9 +1211,6 @@ static int build_phase1(raftx_ctx *c, hipStream_t sCopy, hipStream_t sPrep, int 
             hipLaunchKernelGGL(k_geom_trim, dim3((unsigned)(nDesign / 128 + 1)), dim3(128), 0, sPrep, A);
             hipLaunchKernelGGL(k_geom_reinertia, dim3((unsigned)((nThread + 127) / 128)), dim3(128), 0, sPrep, A);
         }
-    } else {
-        HIPCHK(c, hipMemsetAsync(A.soff, 0, sizeof(int64_t), sPrep));
-        HIPCHK(c, hipMemsetAsync(A.cmsoff, 0, sizeof(int64_t), sPrep));
     }
     // the member -> platform reductions need the member pass only: they run on a side stream beside the scans, off the
     // stream the fused kernel waits on (phase 2 orders the design kernel behind them)
@@ -1226,12 +1221,20 @@ static int build_phase1(raftx_ctx *c, hipStream_t sCopy, hipStream_t sPrep, int 
     J.reduce_stream = nullptr;
     static const bool reduce_late = getenv("RAFTX_REDUCE_PHASE2") != nullptr;      // tuning: on the ctx stream, before the design kernel
     J.reduce_late = reduce_late;
+    const bool side = nDesign > 0 && !reduce_late && sPrep != c->stream;          // crossings: a stream of its own per block context
+    if (side) HIPCHK(c, hipEventRecord(c->evMem, sPrep));
+    // the scan first: streams share hardware queues, and a reduction submitted ahead of it on the same queue would sit on
+    // the path to the totals (the host waits for them before it can size and launch the generation)
+    if (nDesign > 0 && side) hipLaunchKernelGGL(k_geom_scan, dim3(1), dim3(1024), 0, sPrep, A);
+    if (side) {                                           // ... and its markers, for the same reason
+        HIPCHK(c, hipEventRecord(c->evG3, sPrep));
+        HIPCHK(c, hipEventRecord(c->evTot, sPrep));
+    }
     if (nDesign > 0 && !reduce_late) {
         hipStream_t sRed = sPrep;
-        if (sPrep != c->stream) {                         // crossings: a stream of its own per block context
+        if (side) {
             if (!c->sAux) HIPCHK(c, hipStreamCreateWithFlags(&c->sAux, hipStreamNonBlocking));
             sRed = c->sAux;
-            HIPCHK(c, hipEventRecord(c->evMem, sPrep));
             HIPCHK(c, hipStreamWaitEvent(sRed, c->evMem, 0));
         }
         hipLaunchKernelGGL(k_geom_reduce, dim3((unsigned)(((size_t)nDesign * 3 + 63) / 64)), dim3(64), 0, sRed, A);
@@ -1240,15 +1243,13 @@ static int build_phase1(raftx_ctx *c, hipStream_t sCopy, hipStream_t sPrep, int 
             J.reduce_stream = sRed;
         }
     }
-    if (nDesign > 0) {
-        hipLaunchKernelGGL(k_geom_design_counts, dim3((unsigned)(nDesign / 256 + 1)), dim3(256), 0, sPrep, A);
-        hipLaunchKernelGGL(k_geom_scan, dim3(1), dim3(1024), 0, sPrep, A);
-        hipLaunchKernelGGL(k_geom_offsets, dim3((unsigned)(nDesign / 256 + 1)), dim3(256), 0, sPrep, A);
-    }
-    HIPCHK(c, hipEventRecord(c->evG3, sPrep));
     // totals, error flags and design offsets reach the host through the kernels' own stores into page-locked memory
     // (A.hostOut): a D2H copy of them would queue on the DMA engine behind a bulk download of the previous batch
-    HIPCHK(c, hipEventRecord(c->evTot, sPrep));
+    if (!side) {
+        if (nDesign > 0) hipLaunchKernelGGL(k_geom_scan, dim3(1), dim3(1024), 0, sPrep, A);
+        HIPCHK(c, hipEventRecord(c->evG3, sPrep));
+        HIPCHK(c, hipEventRecord(c->evTot, sPrep));
+    }
     J.active = true;
     return 0;
 }
@@ -1297,9 +1298,12 @@ static int build_phase2(raftx_ctx *c, int64_t *stripOffsets, hipStream_t sGen = 
     HIPCHK(c, hipStreamWaitEvent(sGen, c->evTot, 0));
     HIPCHK(c, hipEventRecord(c->evG0, sGen));
     if (nDesign > 0) {
-        if (J.reduce_stream) HIPCHK(c, hipStreamWaitEvent(sGen, c->evRed, 0));     // the reductions of phase 1 (side stream)
         if (J.reduce_late) hipLaunchKernelGGL(k_geom_reduce, dim3((unsigned)(((size_t)nDesign * 3 + 63) / 64)), dim3(64), 0, sGen, A);
         hipLaunchKernelGGL(k_geom_design, dim3((unsigned)nDesign), dim3(GD_T), gd_lds, sGen, A);
+        // the reductions of phase 1 (side stream) are not waited for until their results are added up: streams share
+        // hardware queues, and a reduction that ended up behind the scan would otherwise hold the generation back
+        if (J.reduce_stream) HIPCHK(c, hipStreamWaitEvent(sGen, c->evRed, 0));
+        hipLaunchKernelGGL(k_geom_addup, dim3((unsigned)(((size_t)nDesign * 36 + 255) / 256)), dim3(256), 0, sGen, A);
     }
     if (nRows > 0)                                        // after k_geom_design: it leaves (R, Ca) of the MacCamy-Fuchs strips
         hipLaunchKernelGGL(k_geom_mcf, dim3((unsigned)nRows, (unsigned)((nw + 63) / 64)), dim3(64), 0, sGen, A, (int64_t)nRows);
