@@ -1088,6 +1088,9 @@ __device__ __forceinline__ void linearize_passA(cdptr ds, ciptr dsi, int S,
     // the loop.  The run-start evaluation (sincos / exp) is outside the batch loop's body.
     int s = 0;
     int fl = src.flags(min(1, S - 1));              // flags of strip 0; strip 1's are on their way
+    // The strip flags come as one vector load per run -- lane i holds those of strip s + 1 + i, fetched beside the run-start
+    // evaluation -- and reach the scalar side by v_readlane: no scalar load (and no wait for one) per strip.
+    int fa = 0;
     auto run = [&](auto rt_tag, const int n, const int m0) {
         constexpr int RT = decltype(rt_tag)::value;
         if (m0) kin_step_rt<NB, RT>(K, m0);         // continuation of a run longer than 64 strips
@@ -1238,9 +1241,10 @@ __device__ __forceinline__ void linearize_passA(cdptr ds, ciptr dsi, int S,
             prev_nb = 2;
             PT_MARK(6);
         };
-        auto advance = [&]() {                      // to the next strip of this run: flags, arm, state
+        const int s_run = s;
+        auto advance = [&]() {                      // to the next strip of this run: flags (lane i of fa: strip s_run + 1 + i), arm, state
             ++s;
-            fl = src.flags(min(s + 1, S - 1));
+            fl = __builtin_amdgcn_readlane(fa, s - s_run - 1);
             load_arm(src.rec(s), r);
             kin_step_rt<NB, RT>(K, fl & DSI_M);
         };
@@ -1261,15 +1265,16 @@ __device__ __forceinline__ void linearize_passA(cdptr ds, ciptr dsi, int S,
             prev_s0 = s;
             prev_nb = 1;
         }
-        if (++s < S) fl = src.flags(min(s + 1, S - 1));          // flags of the strip after the run
+        ++s;
+        fl = __builtin_amdgcn_readlane(fa, s - s_run - 1);         // flags of the strip after the run (the last strip's again at the end of the table)
     };
     int rt = 0;
 #pragma unroll 1
     while (s < S) {
-        // strips of this run (2..64; a longer one continues through another pass of this loop, without a start): lane i looks
-        // at strip s + 1 + i, the first one that does not continue ends the run.  The load is covered by the run start.
+        // strips of this run (1..64; a longer one continues through another pass of this loop, without a start): the first
+        // strip that does not continue it ends the run
         const int ahead = s + 1 + lane;
-        const int fa = dsi[min(ahead, S - 1)];
+        fa = dsi[min(ahead, S - 1)];                                // covered by the run start
         const int m0 = fl & DSI_M;
         if (m0 == 0) {
             kin_start<NB, false, CM>(K, run_start_of(src.rec(s)), b, b.c1, cb, sb);
@@ -1525,15 +1530,36 @@ __device__ __forceinline__ void drag_excitation(cdptr ds, ciptr dsi, int S, cons
         }                                              \
         }                                              \
     } while (0)
-    // does strip s + 1 continue the run of strip s?  Advances s; returns its step count (0: no, or the table has ended)
-    auto next_step = [&]() -> int {
-        if (++s >= S) return 0;
-        fl = src.flags(min(s + 1, S - 1));          // flags of the new strip s
-        return fl & DSI_M;
-    };
+    // As in pass A: the flags of the strips after s come as one vector load per run (lane i: strip s + 1 + i), a ballot gives
+    // the run's length, and the strips are a COUNTED loop whose flags arrive by v_readlane -- no scalar load per strip.
+#define RUN_COUNTED(STEPM, PRE)                                    \
+    do {                                                           \
+        const int s_run_ = s;                                      \
+        body();                                                    \
+        _Pragma("unroll 1") for (int i_ = 1; i_ < n; i_++) {      \
+            ++s;                                                   \
+            fl = __builtin_amdgcn_readlane(fa, s - s_run_ - 1);    \
+            const int m_ = fl & DSI_M;                             \
+            PRE;                                                   \
+            STEPM;                                                 \
+            body();                                                \
+        }                                                          \
+        ++s;                                                       \
+        fl = __builtin_amdgcn_readlane(fa, s - s_run_ - 1);        \
+    } while (0)
 #pragma unroll 1
     while (s < S) {
-        kin_start<NB, false, CM>(K, run_start_of(src.rec(s)), b, b.c1, cb, sb);
+        const int ahead = s + 1 + ((int)threadIdx.x & 63);
+        const int fa = dsi[min(ahead, S - 1)];                      // covered by the run start
+        const int m0 = fl & DSI_M;
+        if (m0 == 0) {
+            kin_start<NB, false, CM>(K, run_start_of(src.rec(s)), b, b.c1, cb, sb);
+        } else {                                                    // continuation of a run longer than 64 strips
+            kin_rotate(K, m0);
+            kin_decay(K, m0);
+        }
+        const unsigned long long stop = __ballot(ahead >= S || (fa & DSI_M) == 0);
+        const int n = stop ? 1 + (int)__builtin_ctzll(stop) : 64;
         if (!K.rot && (fl & DSI_VAX)) {
             // Vertical member (q = +-z, p1 and p2 horizontal; arm x, y fixed along the run): with h_s = sum_c b_c al_c n_c (horizontal)
             //   U_s = [h_x, h_y, 0, -a_z h_y, a_z h_x, a_x h_y - a_y h_x],   V_s = b_q [0, 0, 1, a_y, -a_x, 0]
@@ -1557,7 +1583,7 @@ __device__ __forceinline__ void drag_excitation(cdptr ds, ciptr dsi, int S, cons
                     H2[j] = fma(pd, v2, H2[j]);
                 }
             };
-            RUN_LOOP(1, kin_decay1(K), kin_decay2(K), kin_decay(K, m_), );
+            RUN_COUNTED(kin_decay(K, m_), );
 #pragma unroll
             for (int j = 0; j < NB; j++) {
                 const double g5 = r.ax * G1[j] - r.ay * G0[j], h3 = r.ay * H2[j], h4 = -r.ax * H2[j];
@@ -1608,7 +1634,7 @@ __device__ __forceinline__ void drag_excitation(cdptr ds, ciptr dsi, int S, cons
                     S1x[j][0] = fma(b1x, ar, S1x[j][0]); S1x[j][1] = fma(b1x, ai, S1x[j][1]);
                 }
             };
-            RUN_LOOP(2, kin_rotate1(K), kin_rotate2(K), kin_rotate(K, m_), load_arm(src.rec(s), r));
+            RUN_COUNTED(kin_rotate(K, m_), load_arm(src.rec(s), r));
 #pragma unroll
             for (int j = 0; j < NB; j++) {
                 Sq[j][0] *= ps[j];  Sq[j][1] *= ps[j];
@@ -1655,14 +1681,14 @@ __device__ __forceinline__ void drag_excitation(cdptr ds, ciptr dsi, int S, cons
                     }
                 }
             };
-            RUN_LOOP(4, kin_rotate1(K), kin_rotate2(K), kin_rotate(K, m_), );
+            RUN_COUNTED(kin_rotate(K, m_), );
         } else {
             auto body = [&]() {
                 double U[6], V[6];
                 load_uv(l.uv + s * 12, U, V);
                 passB_core<NB>(K, U, V, F);
             };
-            RUN_LOOP(8, (kin_rotate1(K), kin_decay1(K)), (kin_rotate2(K), kin_decay2(K)), (kin_rotate(K, m_), kin_decay(K, m_)), );
+            RUN_COUNTED((kin_rotate(K, m_), kin_decay(K, m_)), );
         }
     }
     } else {

@@ -479,12 +479,16 @@ def _oriented_run_table(rng, axes, n_per=9):
         if a is None:                       # three unrelated strips: runs of one
             i += 3
             continue
-        q = np.asarray(a, dtype=float)
+        upright = len(a) == 4                # (x, y, 0, "up"): a pontoon -- rectangular, p1 = +-z (DSI_AXAL)
+        q = np.asarray(a[:3], dtype=float)
         q = q / np.linalg.norm(q)
         h = np.array([0.0, 0.0, 1.0]) if abs(q[2]) < 0.9 else np.array([1.0, 0.0, 0.0])
         p1 = np.cross(h, q)
         p1 /= np.linalg.norm(p1)
         p2 = np.cross(q, p1)
+        if upright:
+            p1 = np.array([0.0, 0.0, -1.0 if i % 2 else 1.0])
+            p2 = np.cross(q, p1)
         A = np.array([rng.uniform(-30, 30), rng.uniform(-30, 30), rng.uniform(-28, -22)])
         unit, pos = rng.uniform(0.3, 0.7), 0.0
         for j in range(n_per):
@@ -493,7 +497,7 @@ def _oriented_run_table(rng, axes, n_per=9):
             rec[i, st.F_AX:st.F_AX + 3] += r - rec[i, st.F_X:st.F_X + 3]
             rec[i, st.F_X:st.F_X + 3] = r
             rec[i, st.F_Q:st.F_Q + 3], rec[i, st.F_P1:st.F_P1 + 3], rec[i, st.F_P2:st.F_P2 + 3] = q, p1, p2
-            rec[i, st.F_CIRC] = float(j % 3 != 0)
+            rec[i, st.F_CIRC] = 0.0 if upright else float(j % 3 != 0)
             i += 1
     return base
 
@@ -506,8 +510,11 @@ def test_run_type_loops_of_the_lean_kernel(hip_ctx, oracle_ctx, nw, nH):
     rng = np.random.default_rng(77 + nw)
     axes_a = [(0, 0, 1), (1, 0, 0), (0, 1, 0), None, (0.3, -0.5, 0.4), (0, 0, -1), (-1, 0, 0), (0.6, 0.8, 0), (0, 0, 1)]
     axes_b = [None, (0, -1, 0), (0, 0, 1), (0.2, 0.1, -0.9), None]
-    tables = [_oriented_run_table(rng, axes_a), _oriented_run_table(rng, axes_b)]
-    mats = random_matrices(rng, 2)
+    # upright pontoons in several directions -- one of them square to the waves of the first sea state: no phase rotation
+    # without being vertical, it takes the pontoon loops with the identity rotor -- beside vertical columns (the shape of C3)
+    axes_c = [(1, 0, 0, "up"), (0, 0, 1), (0.6, 0.8, 0, "up"), (0, 1, 0, "up"), (0, 0, 1), (-0.5, 0.866, 0, "up")]
+    tables = [_oriented_run_table(rng, axes_a), _oriented_run_table(rng, axes_b), _oriented_run_table(rng, axes_c, n_per=12)]
+    mats = random_matrices(rng, 3)
     w, k, zeta, beta = synthetic_cases(rng, 2, nH, nw)
     beta = np.array([[0.0, 1.1], [0.4, -2.0]])[:, :nH]    # sin(0) = 0 exactly: the y-aligned member gets no phase rotation
     _both(hip_ctx, oracle_ctx, tables, mats, (w, k, zeta, beta))
@@ -515,7 +522,7 @@ def test_run_type_loops_of_the_lean_kernel(hip_ctx, oracle_ctx, nw, nH):
     oo = oracle_ctx.solve_dynamics(6)
     assert np.array_equal(oh["niter"], oo["niter"])
     assert np.array_equal(oh["flags"], oo["flags"])
-    for d in range(2):
+    for d in range(3):
         assert group_rel_err(oh["Xi"][d], oo["Xi"][d]) < TOL
     B, F = hip_ctx.linearize(oo["Xi"][:, :, 0])             # k_linearize shares the pass-A / pass-B loops
     Bo, Fo = oracle_ctx.linearize(oo["Xi"][:, :, 0])
