@@ -613,3 +613,37 @@ def test_oracle_member_descriptions_to_reference_response_mcf_pose(oracle_ctx):
 @pytest.mark.gpu
 def test_hip_member_descriptions_to_reference_response_mcf_pose(hip_ctx):
     check_pose_mcf_end_to_end(hip_ctx, 1e-9)
+
+
+def check_long_runs(ctx_a, ctx_b, dls):
+    """A spar discretised finely: runs of more than 64 strips are cut at the cap (and continue as a new run), designs with
+    more strips than the generation kernel has lanes take its serial run detection; generated tables and responses of
+    the two libraries agree."""
+    u = UNITS["OC3spar"]
+    t = G.concat_units([tables_of(u)])
+    mem = t.members.copy()
+    mem[:, G.GM_DLSMAX] = dls
+    nw = len(u["w"])
+    M0 = (np.eye(6) * [8e6, 8e6, 8e6, 7e9, 7e9, 2e8])[None]
+    C0 = np.diag([4e4, 4e4, 3e5, 1e9, 1e9, 1e8])[None]
+    rng = np.random.default_rng(5)
+    zeta = rng.uniform(0.1, 0.5, size=(1, 1, nw))
+    outs, strips = [], []
+    for ctx in (ctx_a, ctx_b):
+        off = ctx.build_designs(t.member_off, mem, t.station_off, t.stations, M0, np.zeros((1, 6, 6)), C0, nw,
+                                rho=u["rho"], g=u["g"], cap_off=t.cap_off, caps=t.caps, add_mask=G.ADD_MORISON)
+        strips.append(ctx.fetch_strips(off[-1])[0])
+        ctx.upload_cases(u["w"], u["k"], 320.0, u["rho"], u["g"], zeta, np.array([[0.3]]))
+        outs.append(ctx.solve_dynamics(6, 0.01, 0.1))
+    assert len(strips[0]) == len(strips[1]) > 64
+    assert rel_err(strips[0][:, :26], strips[1][:, :26]) < TOL
+    assert np.array_equal(strips[0][:, 26:28], strips[1][:, 26:28])
+    assert np.array_equal(outs[0]["niter"], outs[1]["niter"])
+    assert rel_err(outs[0]["Xi"], outs[1]["Xi"]) < 1e-9 and np.any(outs[0]["Xi"])
+    return len(strips[0])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dls,more_than", [(1.6, 64), (0.8, 128)])
+def test_hip_runs_longer_than_the_cap(hip_ctx, oracle_ctx, dls, more_than):
+    assert check_long_runs(hip_ctx, oracle_ctx, dls) > more_than
