@@ -1965,7 +1965,12 @@ __device__ __forceinline__ void solve6(Lu6 &A, cplx x[6]) {
             }
         }
         double pr = A.ar[k][k], pi = A.ai[k][k];
-        double d = 1.0 / (pr * pr + pi * pi);
+        // 1 / |pivot|^2: v_rcp_f64 + two Newton steps (5 instructions; the IEEE division sequence is 12).  A zero pivot
+        // still gives inf -> NaN and is flagged; |pivot|^2 of any physical system is far from the exponent range's ends.
+        const double y = pr * pr + pi * pi;
+        double d = __builtin_amdgcn_rcp(y);
+        d = fma(fma(-y, d, 1.0), d, d);
+        d = fma(fma(-y, d, 1.0), d, d);
         double ir = pr * d, ii = -pi * d;
         A.ar[k][k] = ir;            // keep the reciprocal pivot for the back substitution
         A.ai[k][k] = ii;
