@@ -1285,6 +1285,19 @@ __global__ __launch_bounds__(GD_T) void k_geom_design(GeomArgs A) {
             double v = 0.0;
             if (f >= 0) v = cr[f];
             else if (f <= -2) v = unv[rsv[i]] * cr[RAFTX_F_Q + (-2 - f)];
+            if (j == DS_MCF && v >= 0.0) {
+                // MacCamy-Fuchs row of the DEVICE record: the first row of this design with the same (R, Ca_p1, Ca_p2) --
+                // the strips of a column share them, so the solver's reads of the Cm table fall on a few rows per design
+                // (lines it has just touched) instead of one row per strip, 32 B per strip and bin out of HBM.  The ABI
+                // record (raftx_fetch_strips) keeps its own row, as the reference's table has one.
+                const double *ax0 = A.mcfaux + (size_t)A.cmoff[d] * 3, *axm = ax0 + (size_t)v * 3;
+                const int mrow = (int)v;
+                for (int r = 0; r < mrow; r++)
+                    if (ax0[r * 3] == axm[0] && ax0[r * 3 + 1] == axm[1] && ax0[r * 3 + 2] == axm[2]) {
+                        v = (double)r;
+                        break;
+                    }
+            }
             dso[t] = v;
         }
     }
