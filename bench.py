@@ -394,8 +394,8 @@ def main():
     if stream_steps:
         # untimed priming, before the W warm-up steps: the first crossing of a stream is cut into two blocks, the following
         # ones are single blocks, and each slot's block contexts allocate their device buffers the first time they meet a
-        # configuration -- three streamed steps bring both slots to the steady-state one
-        run_steps(3)
+        # configuration -- three streamed steps bring both slots to the steady-state one (seven the three of --depth 3)
+        run_steps(3 if args.depth == 2 else 7)
     run_steps(args.warmup)
     barrier()
     t0 = time.perf_counter()
