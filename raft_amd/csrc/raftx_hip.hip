@@ -751,6 +751,7 @@ struct raftx_ctx {
     double *pinRes;                      // page-locked landing area of a block's statistics (sweep crossing)
     size_t pinRes_n;
     hipStream_t sCopy, sPrep, sD2H, sGen; // internal streams of raftx_sweep_stats (created on first use)
+    hipStream_t sD2Hlow = nullptr;        // bulk download of the responses: a LOW-priority stream, created when first needed
     std::vector<double> case_key;        // the sea-state tables resident for the sweep crossing (skip identical re-uploads)
     char err[512];
     DevTables T;
@@ -948,7 +949,7 @@ extern "C" void raftx_ctx_destroy(raftx_ctx *c) {
                          c->evMem, c->evRed})
         (void)hipEventDestroy(e);
     if (c->sAux) (void)hipStreamDestroy(c->sAux);
-    for (hipStream_t st : {c->sCopy, c->sPrep, c->sD2H})
+    for (hipStream_t st : {c->sCopy, c->sPrep, c->sD2H, c->sD2Hlow})
         if (st) (void)hipStreamDestroy(st);
     if (c->owns_stream) (void)hipStreamDestroy(c->stream);
     delete c;
@@ -2632,19 +2633,32 @@ extern "C" int raftx_sweep_launch(raftx_ctx *c, int slot) {
     }
     // ---- full responses, if asked for: block by block behind the block's kernels, on their own stream
     if (!rc_all && Xi) {
+        // The bulk download goes to a LOW-priority stream, created when first needed: priority classes have hardware
+        // queues of their own, whereas the ordinary streams of this library share four, and a hardware queue is in order --
+        // the generation and the fused kernel of batch i+1 used to queue behind the 3.4 ms copy of batch i whenever the
+        // two streams landed on one queue (streamed steps with the responses downloaded: 7.0 ms per step instead of
+        // 4.6-5.0).  Created late, it does not move the other streams' queues (the plain step is sensitive to those:
+        // +5 % with the generation stream one queue further).  RAFTX_D2H_PRIORITY=0: the ordinary download stream.
+        static const bool d2h_low = !(getenv("RAFTX_D2H_PRIORITY") && !atoi(getenv("RAFTX_D2H_PRIORITY")));
+        if (d2h_low && !c->sD2Hlow) {
+            int least = 0, greatest = 0;
+            if (hipDeviceGetStreamPriorityRange(&least, &greatest) == hipSuccess && least != greatest)
+                (void)hipStreamCreateWithPriority(&c->sD2Hlow, hipStreamNonBlocking, least);
+        }
+        hipStream_t sDown = (d2h_low && c->sD2Hlow) ? c->sD2Hlow : c->sD2H;
         for (size_t b = 0; b < nB; b++) {
             raftx_ctx *sub = blk[b];
             const size_t p0 = (size_t)bnd[b] * nCase;
-            hipError_t e = hipStreamWaitEvent(c->sD2H, sub->evDone, 0);
+            hipError_t e = hipStreamWaitEvent(sDown, sub->evDone, 0);
             if (e == hipSuccess && sub->r_nx)
-                e = hipMemcpyAsync(Xi + p0 * nHead * 6 * nw, sub->rXi, sub->r_nx * sizeof(cplx), hipMemcpyDeviceToHost, c->sD2H);
+                e = hipMemcpyAsync(Xi + p0 * nHead * 6 * nw, sub->rXi, sub->r_nx * sizeof(cplx), hipMemcpyDeviceToHost, sDown);
             if (e != hipSuccess) {
                 snprintf(c->err, sizeof(c->err), "sweep_stats: download of the responses: %s", hipGetErrorString(e));
                 rc_all = -2;
                 break;
             }
         }
-        if (!rc_all && hipEventRecord(S.evXi, c->sD2H) != hipSuccess) rc_all = -2;
+        if (!rc_all && hipEventRecord(S.evXi, sDown) != hipSuccess) rc_all = -2;
     }
     if (rc_all) return fail_drain(rc_all);
     S.tl[2] = since();
