@@ -1603,47 +1603,51 @@ __device__ __forceinline__ void drag_excitation(cdptr ds, ciptr dsi, int S, cons
         } else if (!K.dec && !K.vert && (fl & (DSI_AXAL | DSI_CIRC)) == DSI_AXAL) {
             // Upright pontoon (see linearize_passA): q, p2 horizontal, p1 = +-z.  With W_c = [n_c ; arm x n_c] and the arm moving
             // along q, W_q is the same for every strip of the run, W_p2 changes in its last component only
-            // (w2 = (arm x p2)_z) and V_s = b_1 [0, 0, 1, a_y, -a_x, 0]: the strips add to SIX complex scalars per bin
-            //   Sq = sum b_q al_q t1,  S2 = sum b_2 al_2 t1,  S26 = sum b_2 al_2 w2 t1,  S1 = sum b_1 t2,  S1y, S1x = sum b_1 a_y|a_x t2
-            // (12 FMAs per strip and bin instead of 24, from the drag coefficients b_c the strip phase left in vsq row 0 --
-            // the U, V rows are not read) and meet the constant vectors once per run.
+            // (w2 = (arm x p2)_z) and V_s = b_1 [0, 0, 1, a_y, -a_x, 0].  The arm moves along q, (a_x, a_y) = (a_x0, a_y0) + lam (q_x, q_y),
+            // so w2, a_x, a_y are linear in lam and the strips add to FIVE complex scalars per bin
+            //   Sq = sum b_q al_q a,  S2 = sum b_2 al_2 a,  S2l = sum lam b_2 al_2 a,  S1 = sum b_1 a,  S1l = sum lam b_1 a
+            // (10 FMAs per strip and bin instead of 24, from the drag coefficients b_c the strip phase left in vsq row 0 --
+            // the U, V rows are not read); they meet P+Q, P-Q (no depth decay along the run) and the constant vectors once per run.
             RecA r = load_recA(src.rec(s));
             const double alq = r.qx * cb + r.qy * sb, al2 = r.p2x * cb + r.p2y * sb;
-            const double wq = r.ax * r.qy - r.ay * r.qx, az = r.az;
-            double ps[NB], pd[NB], Sq[NB][2], S2[NB][2], S26[NB][2], S1[NB][2], S1y[NB][2], S1x[NB][2];
+            const double ax0 = r.ax, ay0 = r.ay, az = r.az;
+            const double wq = ax0 * r.qy - ay0 * r.qx, w20 = r.p2y * ax0 - r.p2x * ay0, kap2 = r.p2y * r.qx - r.p2x * r.qy;
+            double Sq[NB][2], S2[NB][2], S2l[NB][2], S1[NB][2], S1l[NB][2];
 #pragma unroll
-            for (int j = 0; j < NB; j++) {
-                ps[j] = K.P[j] + K.Q[j];
-                pd[j] = K.P[j] - K.Q[j];
-                Sq[j][0] = Sq[j][1] = S2[j][0] = S2[j][1] = S26[j][0] = S26[j][1] = 0.0;
-                S1[j][0] = S1[j][1] = S1y[j][0] = S1y[j][1] = S1x[j][0] = S1x[j][1] = 0.0;
-            }
+            for (int j = 0; j < NB; j++)
+                Sq[j][0] = Sq[j][1] = S2[j][0] = S2[j][1] = S2l[j][0] = S2l[j][1] = S1[j][0] = S1[j][1] = S1l[j][0] = S1l[j][1] = 0.0;
             auto body = [&]() {
                 ldptr bc = l.vsq + s * 3;
+                const double lam = fma(r.ax - ax0, r.qx, (r.ay - ay0) * r.qy);
                 const double bq = bc[0] * alq, b1 = bc[1], b2 = bc[2] * al2;
-                const double b2w = b2 * (r.p2y * r.ax - r.p2x * r.ay), b1y = b1 * r.ay, b1x = b1 * r.ax;
-                // no depth decay along the run: P + Q and P - Q leave the sums (t1 = a ps, t2 = i a pd) and meet them after the loop
+                const double b2l = b2 * lam, b1l = b1 * lam;
 #pragma unroll
                 for (int j = 0; j < NB; j++) {
                     const double ar = K.ar[j], ai = K.ai[j];
                     Sq[j][0] = fma(bq, ar, Sq[j][0]);    Sq[j][1] = fma(bq, ai, Sq[j][1]);
                     S2[j][0] = fma(b2, ar, S2[j][0]);    S2[j][1] = fma(b2, ai, S2[j][1]);
-                    S26[j][0] = fma(b2w, ar, S26[j][0]); S26[j][1] = fma(b2w, ai, S26[j][1]);
+                    S2l[j][0] = fma(b2l, ar, S2l[j][0]); S2l[j][1] = fma(b2l, ai, S2l[j][1]);
                     S1[j][0] = fma(b1, ar, S1[j][0]);    S1[j][1] = fma(b1, ai, S1[j][1]);
-                    S1y[j][0] = fma(b1y, ar, S1y[j][0]); S1y[j][1] = fma(b1y, ai, S1y[j][1]);
-                    S1x[j][0] = fma(b1x, ar, S1x[j][0]); S1x[j][1] = fma(b1x, ai, S1x[j][1]);
+                    S1l[j][0] = fma(b1l, ar, S1l[j][0]); S1l[j][1] = fma(b1l, ai, S1l[j][1]);
                 }
             };
             RUN_COUNTED(kin_rotate(K, m_), load_arm(src.rec(s), r));
+            double S26[NB][2], S1y[NB][2], S1x[NB][2];
 #pragma unroll
             for (int j = 0; j < NB; j++) {
-                Sq[j][0] *= ps[j];  Sq[j][1] *= ps[j];
-                S2[j][0] *= ps[j];  S2[j][1] *= ps[j];
-                S26[j][0] *= ps[j]; S26[j][1] *= ps[j];
+                const double ps = K.P[j] + K.Q[j], pd = K.P[j] - K.Q[j];
+                Sq[j][0] *= ps;  Sq[j][1] *= ps;
+                S2[j][0] *= ps;  S2[j][1] *= ps;
+                S2l[j][0] *= ps; S2l[j][1] *= ps;
                 double t;                                             // times i pd
-                t = S1[j][0];  S1[j][0] = -S1[j][1] * pd[j];   S1[j][1] = t * pd[j];
-                t = S1y[j][0]; S1y[j][0] = -S1y[j][1] * pd[j]; S1y[j][1] = t * pd[j];
-                t = S1x[j][0]; S1x[j][0] = -S1x[j][1] * pd[j]; S1x[j][1] = t * pd[j];
+                t = S1[j][0];  S1[j][0] = -S1[j][1] * pd;   S1[j][1] = t * pd;
+                t = S1l[j][0]; S1l[j][0] = -S1l[j][1] * pd; S1l[j][1] = t * pd;
+#pragma unroll
+                for (int e = 0; e < 2; e++) {
+                    S26[j][e] = fma(kap2, S2l[j][e], w20 * S2[j][e]);
+                    S1y[j][e] = fma(r.qy, S1l[j][e], ay0 * S1[j][e]);
+                    S1x[j][e] = fma(r.qx, S1l[j][e], ax0 * S1[j][e]);
+                }
             }
             const double c3q = -az * r.qy, c3p = -az * r.p2y, c4q = az * r.qx, c4p = az * r.p2x;
 #pragma unroll
