@@ -1081,7 +1081,9 @@ __device__ __forceinline__ void linearize_passA(cdptr ds, ciptr dsi, int S,
     ldptr rp = tile + min(lane >> 3, TR_ROWS - 1) * TR_STRIDE + (lane & 7) * 9;
     const int row = lane >> 3;
     const bool writer = (lane & 7) == 0;
-    int prev_s0 = -1, prev_nb = 0;
+    int prev_s0 = -1, prev_rows = 0;                // the batch waiting in the tile: its first strip, its valid rows ...
+    bool prev_two = false;                          // ... and whether a strip owns two rows (circular strips: v_q, v_perp) or three
+    ldptr vout2 = vsq_of(l, wv, blockDim.x >> 6, S, vstride) + (lane >> 4) * vstride + ((lane >> 3) & 1);
     if constexpr (RUN_LOOPS<NB>) {
     // Loop over RUNS; batches of up to two strips of the same run form the inner loop, specialised by run type (see
     // drag_excitation): a vertical run steps P, Q only, a horizontal run the phasor only and keeps P + Q, P - Q out of
@@ -1225,10 +1227,10 @@ __device__ __forceinline__ void linearize_passA(cdptr ds, ciptr dsi, int S,
                 a += dpp_mov<0xB1>(a);
                 a += dpp_mov<0x4E>(a);
                 a += dpp_mov<0x104>(a);
-                if (writer && row < prev_nb * 3) vout[prev_s0 * vstride] = a;
+                if (writer && row < prev_rows) (prev_two ? vout2 : vout)[prev_s0 * vstride] = a;
             }
 #pragma unroll
-            for (int c = 0; c < 3; c++) wr[c * TR_STRIDE] = va[c];
+            for (int c = 0; c < (RT == 4 ? 2 : 3); c++) wr[c * TR_STRIDE] = va[c];
             PT_MARK(6);   // strips of pass A
         };
         auto stripB = [&]() {
@@ -1238,8 +1240,30 @@ __device__ __forceinline__ void linearize_passA(cdptr ds, ciptr dsi, int S,
             for (int c = 0; c < 3; c++) wr[(3 + c) * TR_STRIDE] = vb[c];
             wave_lds_fence();
             prev_s0 = s - 1;
-            prev_nb = 2;
+            prev_rows = 6;
+            prev_two = false;
             PT_MARK(6);
+        };
+        // RT 4: circular strips have two sums each (v_q, v_perp), so THREE strips share the six tile rows and one reduction
+        auto stripB4 = [&]() {
+            double vb[3];
+            strip(vb);
+            wr[2 * TR_STRIDE] = vb[0];
+            wr[3 * TR_STRIDE] = vb[1];
+            PT_MARK(6);
+        };
+        auto stripC4 = [&]() {
+            double vc[3];
+            strip(vc);
+            wr[4 * TR_STRIDE] = vc[0];
+            wr[5 * TR_STRIDE] = vc[1];
+            PT_MARK(6);
+        };
+        auto close4 = [&](int nstrip) {            // the batch of the last nstrip strips (ending at s) is complete
+            wave_lds_fence();
+            prev_s0 = s - (nstrip - 1);
+            prev_rows = 2 * nstrip;
+            prev_two = true;
         };
         const int s_run = s;
         auto advance = [&]() {                      // to the next strip of this run: flags (lane i of fa: strip s_run + 1 + i), arm, state
@@ -1250,6 +1274,31 @@ __device__ __forceinline__ void linearize_passA(cdptr ds, ciptr dsi, int S,
         };
         stripA();
         int rem = n - 1;
+        if constexpr (RT == 4) {
+#pragma unroll 1
+            for (; rem >= 3; rem -= 3) {
+                advance();
+                stripB4();
+                advance();
+                stripC4();
+                close4(3);
+                advance();
+                stripA();
+            }
+            if (rem == 2) {
+                advance();
+                stripB4();
+                advance();
+                stripC4();
+                close4(3);
+            } else if (rem == 1) {
+                advance();
+                stripB4();
+                close4(2);
+            } else {
+                close4(1);
+            }
+        } else {
 #pragma unroll 1
         for (; rem >= 2; rem -= 2) {
             advance();
@@ -1263,7 +1312,9 @@ __device__ __forceinline__ void linearize_passA(cdptr ds, ciptr dsi, int S,
         } else {                                    // an odd strip count: the last batch has one strip
             wave_lds_fence();
             prev_s0 = s;
-            prev_nb = 1;
+            prev_rows = 3;
+            prev_two = false;
+        }
         }
         ++s;
         fl = __builtin_amdgcn_readlane(fa, s - s_run - 1);         // flags of the strip after the run (the last strip's again at the end of the table)
@@ -1312,7 +1363,7 @@ __device__ __forceinline__ void linearize_passA(cdptr ds, ciptr dsi, int S,
             a += dpp_mov<0xB1>(a);
             a += dpp_mov<0x4E>(a);
             a += dpp_mov<0x104>(a);
-            if (writer && row < prev_nb * 3) vout[prev_s0 * vstride] = a;
+            if (writer && row < prev_rows) vout[prev_s0 * vstride] = a;
         }
         if (nb > 1) {
             const auto rec = src.rec(s0 + 1);
@@ -1327,13 +1378,13 @@ __device__ __forceinline__ void linearize_passA(cdptr ds, ciptr dsi, int S,
         }
         wave_lds_fence();
         prev_s0 = s0;
-        prev_nb = nb;
+        prev_rows = 3 * nb;
         PT_MARK(6);   // strips of pass A
     }
     }
     {   // drain: the last batch
         const double a = tile_reduce(tile, lane);
-        if (writer && row < prev_nb * 3) vout[prev_s0 * vstride] = a;
+        if (writer && row < prev_rows) (prev_two ? vout2 : vout)[prev_s0 * vstride] = a;
     }
     wave_lds_fence();
 }
