@@ -1053,6 +1053,63 @@ __device__ __forceinline__ void kin_step_rt(Kin<NB> &K, int m) {      // RT 3 = 
     if (RT != 2 && RT != 3) kin_decay(K, m);
 }
 
+// Two-unit rotors of ONE run type, held by the loop that uses them (the interior strips of a member step by two units; Kin keeps
+// the one-unit rotors only): squares of the one-unit rotors, formed at the run start.
+template <int NB>
+struct Rot2 {
+    double r[NB], i[NB];
+};
+template <int NB>
+__device__ __forceinline__ Rot2<NB> rot2_of(const Kin<NB> &K) {
+    Rot2<NB> R;
+#pragma unroll
+    for (int j = 0; j < NB; j++) {
+        R.r[j] = fma(K.r1r[j], K.r1r[j], -(K.r1i[j] * K.r1i[j]));
+        R.i[j] = 2.0 * (K.r1r[j] * K.r1i[j]);
+    }
+    return R;
+}
+template <int NB>
+__device__ __forceinline__ void kin_rotate_m(Kin<NB> &K, const Rot2<NB> &R, int m) {
+    // the two-unit rotor always, the one-unit rotor's inverse (its conjugate) on top for a one-unit step: ONE conditional arm --
+    // with a branch between two updates the compiler merges the arms' results through register copies
+#pragma unroll
+    for (int j = 0; j < NB; j++) rot_inplace(K.ar[j], K.ai[j], R.r[j], R.i[j]);
+    if (m != 2) {
+#pragma unroll
+        for (int j = 0; j < NB; j++) rot_inplace(K.ar[j], K.ai[j], K.r1r[j], -K.r1i[j]);
+    }
+}
+template <int NB>
+struct Dec2 {
+    double p[NB], q[NB];
+};
+template <int NB>
+__device__ __forceinline__ Dec2<NB> dec2_of(const Kin<NB> &K) {
+    Dec2<NB> D;
+#pragma unroll
+    for (int j = 0; j < NB; j++) {
+        D.p[j] = K.r1p[j] * K.r1p[j];
+        D.q[j] = K.r1q[j] * K.r1q[j];
+    }
+    return D;
+}
+template <int NB>
+__device__ __forceinline__ void kin_decay_m(Kin<NB> &K, const Dec2<NB> &D, int m) {
+#pragma unroll
+    for (int j = 0; j < NB; j++) {
+        mul_inplace(K.P[j], D.p[j]);
+        mul_inplace(K.Q[j], D.q[j]);
+    }
+    if (m != 2) {                                   // one-unit step: back by one unit (the rotors of P and Q are each other's inverses)
+#pragma unroll
+        for (int j = 0; j < NB; j++) {
+            mul_inplace(K.P[j], K.r1q[j]);
+            mul_inplace(K.Q[j], K.r1p[j]);
+        }
+    }
+}
+
 // Pass A of one linearisation (raft_member.py:2039-2090, helpers.py:149-184,684): per strip,
 // the sums over ALL bins of |v_rel . q|^2 and of the transverse squares, v_rel = u - i w (Xi_t + theta x a).
 // X[j][.] = w * XiLast (re/im), so that i w V = i (X_t + X_theta x a).
@@ -1265,12 +1322,19 @@ __device__ __forceinline__ void linearize_passA(cdptr ds, ciptr dsi, int S,
             prev_rows = 2 * nstrip;
             prev_two = true;
         };
+        // two-unit rotors of this run type (the general run keeps applying the one-unit ones twice)
+        Rot2<NB> R2;
+        Dec2<NB> D2;
+        if constexpr (RT == 2 || RT == 3) R2 = rot2_of(K);
+        if constexpr (RT == 1 || RT == 4) D2 = dec2_of(K);
         const int s_run = s;
         auto advance = [&]() {                      // to the next strip of this run: flags (lane i of fa: strip s_run + 1 + i), arm, state
             ++s;
             fl = __builtin_amdgcn_readlane(fa, s - s_run - 1);
             load_arm(src.rec(s), r);
-            kin_step_rt<NB, RT>(K, fl & DSI_M);
+            if constexpr (RT == 2 || RT == 3) kin_rotate_m(K, R2, fl & DSI_M);
+            else if constexpr (RT == 1 || RT == 4) kin_decay_m(K, D2, fl & DSI_M);
+            else kin_step_rt<NB, RT>(K, fl & DSI_M);
         };
         stripA();
         int rem = n - 1;
@@ -1634,7 +1698,8 @@ __device__ __forceinline__ void drag_excitation(cdptr ds, ciptr dsi, int S, cons
                     H2[j] = fma(pd, v2, H2[j]);
                 }
             };
-            RUN_COUNTED(kin_decay(K, m_), );
+            const Dec2<NB> D2 = dec2_of(K);
+            RUN_COUNTED(kin_decay_m(K, D2, m_), );
 #pragma unroll
             for (int j = 0; j < NB; j++) {
                 const double g5 = r.ax * G1[j] - r.ay * G0[j], h3 = r.ay * H2[j], h4 = -r.ax * H2[j];
@@ -1682,7 +1747,8 @@ __device__ __forceinline__ void drag_excitation(cdptr ds, ciptr dsi, int S, cons
                     S1l[j][0] = fma(b1l, ar, S1l[j][0]); S1l[j][1] = fma(b1l, ai, S1l[j][1]);
                 }
             };
-            RUN_COUNTED(kin_rotate(K, m_), load_arm(src.rec(s), r));
+            const Rot2<NB> R2 = rot2_of(K);
+            RUN_COUNTED(kin_rotate_m(K, R2, m_), load_arm(src.rec(s), r));
             double S26[NB][2], S1y[NB][2], S1x[NB][2];
 #pragma unroll
             for (int j = 0; j < NB; j++) {
