@@ -1950,7 +1950,8 @@ __device__ __forceinline__ void inertial_excitation_uv(const DevTables &T, cdptr
                         Z2[j] = fma(pp, aq, fma(-hd, v2, Z2[j]));
                     }
                 };
-                RUN_LOOP(1, kin_decay1(K), kin_decay2(K), kin_decay(K, m_), );
+                const Dec2<NB> D2 = dec2_of(K);
+                RUN_LOOP(1, kin_decay1(K), kin_decay2(K), kin_decay_m(K, D2, m_), );
 #pragma unroll
                 for (int j = 0; j < NB; j++) {
                     const double ar = K.ar[j], ai = K.ai[j];
@@ -1995,7 +1996,8 @@ __device__ __forceinline__ void inertial_excitation_uv(const DevTables &T, cdptr
                         SA[j][0] = fma(ba, ar, SA[j][0]);    SA[j][1] = fma(ba, ai, SA[j][1]);
                     }
                 };
-                RUN_LOOP(2, kin_rotate1(K), kin_rotate2(K), kin_rotate(K, m_), );
+                const Rot2<NB> R2 = rot2_of(K);
+                RUN_LOOP(2, kin_rotate1(K), kin_rotate2(K), kin_rotate_m(K, R2, m_), );
                 const double c3q = -az * qy, c3p = -az * p2y, c4q = az * qx, c4p = az * p2x;
 #pragma unroll
                 for (int j = 0; j < NB; j++) {
