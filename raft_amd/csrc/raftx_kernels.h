@@ -217,6 +217,7 @@ struct Lds {
     ldptr bdw;     // [NWV][24]    per-wave partials of the 21 unique B_drag entries
     ldptr Bd;      // [36]
     ldptr mat;     // [108]        M0, B0, C0
+    ldptr Bb;      // [36]         B0 + B_drag of the live linearisation (what the assembly of Z adds)
     liptr fl;         // [S]          strip flags (STAGE shapes only)
     int nxl;
 };
@@ -249,14 +250,15 @@ __device__ __forceinline__ Lds carve(double *base_, int S, int nw_xl, int nwv, i
     if (park_n && l.bdw < l.park + park_n) l.bdw = l.park + park_n;
     l.Bd = l.bdw + (size_t)nwv * 24;
     l.mat = l.Bd + 36;
-    l.fl = (liptr)(l.mat + 108);
+    l.Bb = l.mat + 108;
+    l.fl = (liptr)(l.Bb + 36);
     return l;
 }
 static size_t lds_bytes(int S, int nw, int nwv, int stage_n, int park_n = 0, int rc_n = 0, int nw_rc = 0) {
     size_t span = (size_t)S * (12 + 3 * vsq_rows(nwv)) + (size_t)nwv * TR_ROWS * TR_STRIDE;          // vsq | uv | tile
     if (park_n && span < (size_t)S * 3 + (size_t)park_n) span = (size_t)S * 3 + (size_t)park_n;
     return sizeof(double) * ((size_t)(nw_rc ? 2 * RAFTX_SC_N : 0) + (size_t)rc_n * 2 * xl_row(nw_rc) + (size_t)12 * xl_row(nw) + (size_t)S * stage_n + span +
-                             (size_t)nwv * 24 + 36 + 108 + 2) +
+                             (size_t)nwv * 24 + 36 + 108 + 36 + 2) +
            sizeof(int) * (size_t)(stage_n == RA_N ? S + 2 : 2);
 }
 // where wave wv's velocity sums of strip s start, as base + s * stride
@@ -1554,6 +1556,7 @@ __device__ __forceinline__ void strip_phase(cdptr ds, ciptr dsi, int S,
             double acc = 0.0;
             for (int q = 0; q < nwv_s; q++) acc += l.bdw[q * 24 + e];
             l.Bd[tid] = acc;
+            l.Bb[tid] = l.mat[36 + tid] + acc;
         }
     }
     wg_sync(multi);
@@ -2182,12 +2185,11 @@ __device__ __forceinline__ void assemble_and_solve(const Lds &l, MbRsrc mb, int 
 #pragma unroll
         for (int c = 0; c < 6; c++) {
             const int e = EQ_ORDER[r] * 6 + c;
-            double M = l.mat[e], B = l.mat[36 + e];
+            double M = l.mat[e], B = l.Bb[e];
             if constexpr ((FLAGS & KF_FDEP) != 0) {
                 M += lu.ar[r][c];
                 B += lu.ai[r][c];
             }
-            B += l.Bd[e];
             lu.ar[r][c] = fma(-w2, M, l.mat[72 + e]);     // Z = -w^2 M + i w B + C  (:1086)
             lu.ai[r][c] = w * B;
         }
