@@ -161,7 +161,7 @@ struct GeomArgs {
     long long *hostOut;          // page-locked host memory the device writes directly (no DMA copy to queue behind a bulk
                                  // download): [0..2] = tot, [3..4] = err as 4 ints, [8 .. 8 + nDesign] = off
     int64_t mbase, sbase, cbase;
-    int *mdesign_w;              // mdesign, writable (filled on the device by k_geom_mdesign)
+    int *mdesign_w;              // mdesign, writable (filled on the device by k_geom_zero)
     int mgrid;                   // > 0: member kernels run on a (member position < mgrid, design) grid, designs fastest
     __device__ int64_t mo(int d) const { return memberOff[d] - mbase; }
     __device__ int64_t so(int64_t m) const { return stationOff[m] - sbase; }
@@ -545,20 +545,10 @@ __global__ void k_geom_zero(GeomArgs A) {
     if (d < 4) A.err[d] = 0;
     if (d < 5) A.tot[d] = 0;
     if (d == 0) { A.off[0] = 0; A.cmoff[0] = 0; }
-}
-// design of every member (thread per design); also rejects non-monotone member offsets (err[2] = design + 1)
-__global__ void k_geom_mdesign(GeomArgs A) {
-    const int d = blockIdx.x * blockDim.x + threadIdx.x;
-    if (d >= A.nDesign) return;
-    const int64_t m0 = A.mo(d), m1 = A.mo(d + 1);
-    if (m1 < m0 || m0 < 0 || m1 > A.nMember) {
-        atomicCAS(A.err + 2, 0, d + 1);
-        return;
-    }
-    for (int64_t m = m0; m < m1; m++) A.mdesign_w[m] = d;
-    // stations and members of the largest design: they size the LDS of k_geom_design
-    atomicMax(reinterpret_cast<unsigned long long *>(A.tot + 3), (unsigned long long)(A.so(m1) - A.so(m0)));
-    atomicMax(reinterpret_cast<unsigned long long *>(A.tot + 4), (unsigned long long)(m1 - m0));
+    // design index of every member (the host has checked that the member offsets are monotone and in range): this used
+    // to be a kernel of its own between this one and the member pass, i.e. on the path between two batches
+    if (d < A.nDesign)
+        for (int64_t m = A.mo(d); m < A.mo(d + 1); m++) A.mdesign_w[m] = d;
 }
 #define GEOM_MAX_STATIONS 1024
 // Member of this thread.  With A.mgrid > 0 the threads are laid out (member position, design) with the design running
@@ -873,8 +863,6 @@ __global__ __launch_bounds__(1024) void k_geom_scan(GeomArgs A) {
             A.hostOut[2] = A.tot[2];                     // final: every thread's maximum is in (a barrier ago)
             int *e = reinterpret_cast<int *>(A.hostOut + 3);        // every error flag is final: phase 1 ends here
             e[0] = A.err[0]; e[1] = A.err[1]; e[2] = A.err[2]; e[3] = A.err[3];
-            A.hostOut[5] = A.tot[3];
-            A.hostOut[6] = A.tot[4];
             A.hostOut[8] = 0;
         }
     }

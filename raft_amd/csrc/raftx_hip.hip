@@ -729,6 +729,7 @@ struct BuildJob {
     std::vector<void *> tmp;            // descriptor uploads and per-member scratch: back to the pool when the job retires
     int nDesign = 0, nw = 0, add_mask = 0;
     int64_t nMember = 0;
+    int64_t maxMem = 0, maxSta = 0;     // members / stations of the largest design (host loop of phase 1)
     double *M0d = nullptr, *C0d = nullptr;
     const double *B0d = nullptr, *MBwd = nullptr;
     bool active = false;
@@ -1195,15 +1196,23 @@ static int build_phase1(raftx_ctx *c, hipStream_t sCopy, hipStream_t sPrep, int 
         A.off = (int64_t *)p_[10]; A.cmoff = (int64_t *)p_[11];
         A.mdesign_w = (int *)p_[12]; A.mdesign = A.mdesign_w;
     }
+    // the member offsets of every design, checked here (the kernels walk them): monotone, inside the slice; and the
+    // largest design's members / stations (they size the LDS of k_geom_design)
+    J.maxMem = J.maxSta = 0;
+    for (int d = 0; d < nDesign; d++) {
+        const int64_t a = memberOff[lo + d], b = memberOff[lo + d + 1];
+        if (b < a || a < m0 || b > m1) FAIL(c, "member offsets not monotone at design %d", lo + d);
+        if (stationOff[b] < stationOff[a]) FAIL(c, "build_designs: station offsets not monotone");
+        J.maxMem = std::max(J.maxMem, b - a);
+        J.maxSta = std::max(J.maxSta, stationOff[b] - stationOff[a]);
+    }
     hipLaunchKernelGGL(k_geom_zero, dim3((unsigned)(nDesign / 256 + 1)), dim3(256), 0, sPrep, A);
     HIPCHK(c, hipEventRecord(c->evZ, sPrep));
     HIPCHK(c, hipEventRecord(c->evG2, sPrep));
-    if (nDesign > 0) hipLaunchKernelGGL(k_geom_mdesign, dim3((unsigned)(nDesign / 256 + 1)), dim3(256), 0, sPrep, A);
     A.mgrid = 0;
     if (nMember > 0) {
         // member kernels on a (member position, design) grid when that wastes few threads: wavefronts of like members
-        int64_t maxMem = 0;
-        for (int d = 0; d < nDesign; d++) maxMem = std::max(maxMem, memberOff[lo + d + 1] - memberOff[lo + d]);
+        const int64_t maxMem = J.maxMem;
         static const bool flat_members = getenv("RAFTX_GEOM_FLAT_MEMBERS") != nullptr;
         A.mgrid = (!flat_members && nDesign >= 64 && maxMem * nDesign <= nMember + nMember / 4) ? (int)maxMem : 0;
         const int64_t nThread = A.mgrid > 0 ? (int64_t)A.mgrid * nDesign : nMember;
@@ -1273,7 +1282,6 @@ static int build_phase2(raftx_ctx *c, int64_t *stripOffsets, hipStream_t sGen = 
     }
     HIPCHK(c, hipGetLastError());
     const int *bad = reinterpret_cast<const int *>(c->pin + 3);
-    if (bad[2]) FAIL(c, "member offsets not monotone at design %d", bad[2] - 1);
     if (bad[3] > 0) FAIL(c, "member %d: needs 2..%d stations, dlsMax > 0 and length > 0", bad[3] - 1, GEOM_MAX_STATIONS);
     if (bad[3] < 0) FAIL(c, "build_designs: member %d is MacCamy-Fuchs but no wave numbers were given", -bad[3] - 1);
     if (bad[0]) FAIL(c, "member %d: cap/bulkhead layout not supported (the reference raises here too)", bad[0] - 1);
@@ -1290,7 +1298,7 @@ static int build_phase2(raftx_ctx *c, int64_t *stripOffsets, hipStream_t sGen = 
         dev_alloc(c, c->design_allocs, (size_t)nDesign * 36, &A.A))
         return -2;
     (void)tmp;
-    const size_t gd_lds = geom_design_lds(maxS, (int)c->pin[5], (int)c->pin[6]);
+    const size_t gd_lds = geom_design_lds(maxS, (int)J.maxSta, (int)J.maxMem);
     if (gd_lds > 160 * 1024)
         FAIL(c, "build_designs: a design has %d submerged strips (at most %d supported)", maxS, (int)((160 * 1024 - 16) / (8 * (GD_ROW + 2) + 12)));
     if (gd_lds > 64 * 1024)
