@@ -84,6 +84,7 @@ __host__ __device__ inline void derive_design_tables(const double *strips, int64
                 for (int j = 0; j < 3; j++)
                     if (pr[RAFTX_F_P1 + j] != rec[RAFTX_F_P1 + j] || pr[RAFTX_F_P2 + j] != rec[RAFTX_F_P2 + j]) m = 0;
                 if ((pr[RAFTX_F_CIRC] != 0.0) != (rec[RAFTX_F_CIRC] != 0.0)) m = 0;      // ... and one kind of cross-section
+                if ((pr[RAFTX_F_MCF] >= 0.0) != (rec[RAFTX_F_MCF] >= 0.0)) m = 0;        // ... MacCamy-Fuchs or not as a whole (the inertial sweep picks its loop per run)
                 // ... and the arm moves with the strip (the run-type loops keep arm components that cannot change along the
                 // run's axis out of the strip loop): a table whose arms do not follow the positions gets no runs
                 for (int j = 0; j < 3; j++) {
@@ -1251,6 +1252,7 @@ __global__ __launch_bounds__(GD_T) void k_geom_design(GeomArgs A) {
             for (int j = 0; j < 3; j++)
                 if (pr[RAFTX_F_P1 + j] != cr[RAFTX_F_P1 + j] || pr[RAFTX_F_P2 + j] != cr[RAFTX_F_P2 + j]) m = 0;
             if ((pr[RAFTX_F_CIRC] != 0.0) != (cr[RAFTX_F_CIRC] != 0.0)) m = 0;
+            if ((pr[RAFTX_F_MCF] >= 0.0) != (cr[RAFTX_F_MCF] >= 0.0)) m = 0;
             for (int j = 0; j < 3; j++) {
                 const double da = cr[RAFTX_F_AX + j] - pr[RAFTX_F_AX + j], dx = cr[RAFTX_F_X + j] - pr[RAFTX_F_X + j];
                 if (!(fabs(da - dx) <= 1e-9 * (1.0 + fabs(cr[RAFTX_F_X + j]) + fabs(cr[RAFTX_F_AX + j])))) m = 0;

@@ -1832,11 +1832,12 @@ __device__ __forceinline__ void drag_excitation(cdptr ds, ciptr dsi, int S, cons
 //   W_c = [n_c ; a x n_c]   (raft_member.py:1984-1991, helpers.py:468-483).
 // U', V' are built once per strip by one lane each (into the uv rows, free before the first linearisation); the bin
 // sweep then costs 36 FMAs per strip and bin instead of the ~60 of the direct form.  MacCamy-Fuchs strips (complex
-// per-bin Cm) cannot be factored this way: kernels with KF_MCF keep inertial_excitation<.., true>.
-template <int NB, bool RC = false>
+// per-bin Cm) cannot be factored this way: in kernels with KF_MCF their runs take the direct form (mcf_strip), the other
+// runs of the design the factored loops.
+template <int NB, bool RC = false, bool MCF = false>
 __device__ __forceinline__ void inertial_excitation_uv(const DevTables &T, cdptr ds, ciptr dsi, int S, const Lds &l,
                                                        const Bins<NB> &b, int ic, int ih, double cb, double sb,
-                                                       cplx (&F)[NB][6], bool multi) {
+                                                       cplx (&F)[NB][6], bool multi, const cplx *__restrict__ cm = nullptr) {
     for (int s = threadIdx.x; s < S; s += blockDim.x) {
         cdptr rec = ds + (size_t)s * DS_N;
         const double ax = rec[DS_A], ay = rec[DS_A + 1], az = rec[DS_A + 2];
@@ -1910,6 +1911,57 @@ __device__ __forceinline__ void inertial_excitation_uv(const DevTables &T, cdptr
             }
         }
     };
+    // one MacCamy-Fuchs strip (KF_MCF kernels): the transverse inertia coefficients are rhoV Cm(w), complex and per bin
+    // (raft_member.py:1415-1420), which no sum over a run factors -- the direct form of inertial_excitation<.., true>
+    auto mcf_strip = [&](int s) {
+        cdptr rec = ds + (size_t)s * DS_N;
+        const double ax = rec[DS_A], ay = rec[DS_A + 1], az = rec[DS_A + 2];
+        const double ai_ = rec[DS_IQ + 3], rhoV = rec[DS_IQ + 4], I0 = rec[DS_IQ];
+        const int mcf = (int)rec[DS_MCF];
+        double al[3], ga[3], n[3][3];
+#pragma unroll
+        for (int c = 0; c < 3; c++) {
+            n[c][0] = rec[DS_Q + 3 * c];
+            n[c][1] = rec[DS_Q + 3 * c + 1];
+            n[c][2] = rec[DS_Q + 3 * c + 2];
+            al[c] = n[c][0] * cb + n[c][1] * sb;
+            ga[c] = n[c][2];
+        }
+#pragma unroll
+        for (int j = 0; j < NB; j++) {
+            const double hs = fma(wd[j], K.Q[j], ws[j] * K.P[j]), hd = fma(-wd[j], K.Q[j], ws[j] * K.P[j]);
+            const double pp = sp[j] * (K.P[j] + K.Q[j]);
+            // n_c . ud = i w (al_c t1 + ga_c t2) with i w t1 = i hs a, i w t2 = -hd a
+            const cplx it1 = {-hs * K.ai[j], hs * K.ar[j]}, it2 = {-hd * K.ar[j], -hd * K.ai[j]};
+            const cplx pd = {pp * K.ar[j], pp * K.ai[j]};
+            cplx f3[3] = {{0, 0}, {0, 0}, {0, 0}};
+#pragma unroll
+            for (int c = 0; c < 3; c++) {
+                const cplx a = {al[c] * it1.re + ga[c] * it2.re, al[c] * it1.im + ga[c] * it2.im};
+                cplx g;
+                if (c == 0) {
+                    g = {I0 * a.re + pd.re * ai_, I0 * a.im + pd.im * ai_};
+                } else {
+                    const cplx m = cm[((size_t)mcf * 2 + (c - 1)) * T.nw + b.iw[j]];
+                    g = cmul(cscale(m, rhoV), a);
+                }
+#pragma unroll
+                for (int q = 0; q < 3; q++) {
+                    f3[q].re = fma(g.re, n[c][q], f3[q].re);
+                    f3[q].im = fma(g.im, n[c][q], f3[q].im);
+                }
+            }
+            F[j][0] = cadd(F[j][0], f3[0]);
+            F[j][1] = cadd(F[j][1], f3[1]);
+            F[j][2] = cadd(F[j][2], f3[2]);
+            F[j][3].re += ay * f3[2].re - az * f3[1].re;
+            F[j][3].im += ay * f3[2].im - az * f3[1].im;
+            F[j][4].re += az * f3[0].re - ax * f3[2].re;
+            F[j][4].im += az * f3[0].im - ax * f3[2].im;
+            F[j][5].re += ax * f3[1].re - ay * f3[0].re;
+            F[j][5].im += ax * f3[1].im - ay * f3[0].im;
+        }
+    };
     if constexpr (RUN_LOOPS<NB>) {
     // Loop over runs, specialised as in drag_excitation: with c1 = i hs a, c2 = -hd a, c3 = pp a the three terms are real
     // multiples of the phasor (times i for the first), so
@@ -1931,7 +1983,10 @@ __device__ __forceinline__ void inertial_excitation_uv(const DevTables &T, cdptr
         while (s < S) {
             cdptr rec0 = ds + (size_t)s * DS_N;
             kin_start<NB, true, RC ? 1 : 0>(K, run_start_of(rec0), b, one, cb, sb);
-            if (!K.rot && (fl & DSI_VAX)) {
+            if (MCF && rec0[DS_MCF] >= 0.0) {                       // a run is one member: MacCamy-Fuchs or not as a whole
+                auto body = [&]() { mcf_strip(s); };
+                RUN_LOOP(8, (kin_rotate1(K), kin_decay1(K)), (kin_rotate2(K), kin_decay2(K)), (kin_rotate(K, m_), kin_decay(K, m_)), );
+            } else if (!K.rot && (fl & DSI_VAX)) {
                 double G0[NB], G1[NB], G3[NB], G4[NB], Z2[NB];
 #pragma unroll
                 for (int j = 0; j < NB; j++) G0[j] = G1[j] = G3[j] = G4[j] = Z2[j] = 0.0;
@@ -2041,7 +2096,8 @@ __device__ __forceinline__ void inertial_excitation_uv(const DevTables &T, cdptr
             const int fl = fn;
             fn = dsi[min(s + 1, S - 1)];
             kin_advance<NB, true, RC ? 1 : 0>(K, fl, ds + (size_t)s * DS_N, b, one, cb, sb);
-            general_strip(s);
+            if (MCF && ds[(size_t)s * DS_N + DS_MCF] >= 0.0) mcf_strip(s);
+            else general_strip(s);
         }
     }
     }
@@ -2444,7 +2500,7 @@ __global__ void __launch_bounds__(MAXT, MINB) k_solve_dynamics(DevTables T, Solv
             }
         }
         if constexpr (MCF)
-            inertial_excitation<NB, true, RC>(T, p.ds, p.dsi, S, cm, b, p.ic, 0, cb0, sb0, Flin, run_cache_of(l));
+            inertial_excitation_uv<NB, RC, true>(T, p.ds, p.dsi, S, l, b, p.ic, 0, cb0, sb0, Flin, multi, cm);
         else
             inertial_excitation_uv<NB, RC>(T, p.ds, p.dsi, S, l, b, p.ic, 0, cb0, sb0, Flin, multi);
         store6(xio, nw, b, Flin);
@@ -2686,7 +2742,7 @@ __global__ void __launch_bounds__(MAXT, MINB) k_solve_dynamics(DevTables T, Solv
             wg_sync(multi);                               // the uv rows are free (previous heading's pass B is over)
             // the inertial sweep refills the run-start cache for this heading
             if constexpr (MCF)
-                inertial_excitation<NB, true, RC>(T, p.ds, p.dsi, S, cm, b, p.ic, ih, cb, sb, x, run_cache_of(l));
+                inertial_excitation_uv<NB, RC, true>(T, p.ds, p.dsi, S, l, b, p.ic, ih, cb, sb, x, multi, cm);
             else
                 inertial_excitation_uv<NB, RC>(T, p.ds, p.dsi, S, l, b, p.ic, ih, cb, sb, x, multi);      // U', V' through the uv rows
             wg_sync(multi);
