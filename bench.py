@@ -42,11 +42,21 @@ Also on the JSON line:
                     MacCamy-Fuchs columns): resident kernel time per pair-iteration
                     against the plain sweep's, a sample checked against the oracle.
 
+  c2_dropin / c4_farm / c5_qtf   BASELINE.json's configs[1], [3], [4] at their specified sizes (bench_legs.py),
+                    each against its committed live-reference golden and with the roofline of its own kernel.
+
 Multi-GPU: one process per GPU; designs are block-partitioned over ranks, no
 collective while solving; the statistics are gathered onto rank 0 INSIDE the
 timed region.  Barrier, max-over-ranks and gather all go through the library's
 own communicator (raft_amd/comm.py: RCCL via raftx_comm_*, rendezvous over TCP on
 MASTER_ADDR) -- no torch in this file.  Weak scaling: nDesign per rank is fixed.
+`python bench.py --gpus N` with no WORLD_SIZE in the environment starts the N
+ranks itself (launch_ranks: RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR /
+MASTER_PORT + a random RAFTX_COMM_TOKEN per job); under an external launcher
+(`python -m torch.distributed.run ... bench.py --gpus N`) the ranks are already
+there and --gpus must equal WORLD_SIZE.  `--workload c4 | c5` run the sharded
+forms of configs[3] (sea states over ranks, gather) and configs[4] (QTF rows
+interleaved over ranks, one SUM-reduce) instead of the C3 sweep.
 
 Prints ONE JSON line (rank 0).
 """
@@ -241,7 +251,7 @@ def featured_legs(ctx, n_design, base_sw, base_ms, base_pair_iters):
         "maccamy_fuchs_columns": dict(mcf=True),
     }
     oracle = RaftxLib(os.path.join(ROOT, "oracle", "libraftx_oracle.so"))
-    n_chk = 8
+    n_chk = min(256, n_design)                            # designs of every leg re-solved by the oracle's own chain
     for name, kw in specs.items():
         kw = dict(kw)
         if kw.get("MBw") == "aero":                       # smooth in w, different per design: rotor added mass / damping shaped
@@ -287,9 +297,112 @@ def featured_legs(ctx, n_design, base_sw, base_ms, base_pair_iters):
     return legs
 
 
+def launch_ranks(n, argv):
+    """`python bench.py --gpus N` without a launcher: start the N ranks (one process per GPU) and wait for them.  Rank r gets
+    RANK = LOCAL_RANK = r, WORLD_SIZE = N, a loopback rendezvous on two free ports and a random job token; rank 0 inherits
+    stdout (it prints the JSON line), every rank inherits stderr.  A rank that fails takes the others down (by PID) and
+    its exit code becomes ours.  RAFTX_BENCH_RANK_CMD (tests): the command to run instead of this file."""
+    import secrets
+    import shlex
+    import socket
+    import subprocess
+    from raft_amd import backend
+    rehearsal = "RAFTX_BENCH_DEVICE" in os.environ
+    if "RAFTX_BENCH_RANK_CMD" not in os.environ:
+        have = backend.hip_library().device_count()
+        if have < n and not rehearsal:
+            sys.stderr.write("bench.py: --gpus %d but this host has %d GPU(s) visible (RAFTX_BENCH_DEVICE=<id> rehearses the "
+                             "multi-rank path with every rank on one device)\n" % (n, have))
+            return 2
+    ports = []
+    for _ in range(2):                                    # MASTER_PORT (kept for launcher compatibility) and the comm's own port
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            ports.append(sk.getsockname()[1])
+    base = dict(os.environ, WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(ports[0]), RAFTX_COMM_PORT=str(ports[1]),
+                RAFTX_COMM_TOKEN=os.environ.get("RAFTX_COMM_TOKEN") or secrets.token_hex(16))
+    cmd = shlex.split(os.environ["RAFTX_BENCH_RANK_CMD"]) if "RAFTX_BENCH_RANK_CMD" in os.environ else [sys.executable, os.path.abspath(__file__)]
+    procs = []
+    for r in range(n):
+        env = dict(base, RANK=str(r), LOCAL_RANK=str(r))
+        procs.append(subprocess.Popen(cmd + list(argv), env=env, stdout=None if r == 0 else subprocess.DEVNULL))
+    rc = 0
+    live = set(range(n))
+    while live:
+        for r in sorted(live):
+            code = procs[r].poll()
+            if code is None:
+                continue
+            live.discard(r)
+            if code != 0 and rc == 0:
+                rc = code
+                sys.stderr.write("bench.py: rank %d exited with code %d; stopping the other ranks\n" % (r, code))
+                for o in live:
+                    procs[o].terminate()
+        if live:
+            time.sleep(0.02)
+    return rc
+
+
+def main_sharded_leg(args, world, rank, local, rehearsal):
+    """--workload c4 | c5: the sharded forms of configs[3] / configs[4] as the timed workload (bench_legs.py)."""
+    import bench_legs
+    from raft_amd import backend, comm as rcomm
+    ctx = backend.hip_library().context(local)
+    comm = gather_kind = None
+    if world > 1:
+        comm, gather_kind = rcomm.from_env(ctx, prefer="rccl", fallback="host" if rehearsal else "error")
+    ctx.synchronize()
+    if comm is not None:
+        comm.barrier()
+    if args.workload == "c4":
+        leg = bench_legs.c4_farm(ctx, farms=args.farms, repeat=max(args.steps, 2), comm=comm)
+        out = None
+        if rank == 0:
+            fs = leg["farm_sweep"]
+            out = {"metric": "design-case-frequency solves/sec (whole node)", "unit": "dcf solves/s",
+                   "value": world * fs["dcf_per_s_kernels"], "n_gpus": world, "steps": args.steps, "warmup": 1,
+                   "ms_per_step": fs["unit_fixed_points_kernel_ms"] + fs["coupled_solves_kernel_ms"], "higher_is_better": True,
+                   "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+                   "config": {"workload": "C4 farm sweep: %d farms/GPU x 4 units x 50 sea states x 200 bins (unit fixed points + coupled 24 x 24 "
+                                          "solves, kernels of rank 0); the farm as specified sharded by sea state" % args.farms, "gather": gather_kind},
+                   "roofline": fs["roofline"], "c4_farm": leg}
+    else:
+        t0 = time.perf_counter()
+        b = bench_legs.c5_qtf_batch(ctx, n_set=args.sets, repeat=max(args.steps, 2), deck="c5_oc4semi_qtf.npz", comm=comm, kay=True)
+        dt = b["wall_ms"] * 1e-3
+        times = [b["qtf_kernels_ms"], b["wall_ms"]]
+        allt = comm.gather_floats(times) if comm is not None else np.array([times])
+        out = None
+        if rank == 0:
+            q = b["q"]
+            herm = bool(np.allclose(q[0], np.conj(np.transpose(q[0], (1, 0, 2))), atol=1e-6 * np.abs(q[0]).max()))
+            assert herm and np.all(np.isfinite(q.view(float))), "reduced QTF is not Hermitian / finite"
+            k_max = float(np.max(allt[:, 0]))
+            out = {"metric": "QTF difference-frequency pairs/sec (whole node)", "unit": "pairs/s", "value": b["pairs"] / dt,
+                   "n_gpus": world, "steps": max(args.steps, 2), "warmup": 1, "ms_per_step": b["wall_ms"], "higher_is_better": True,
+                   "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+                   "config": {"workload": "C5 OC4semi-RAFT_QTF: %d sets x 200 x 200 grid (20 100 pairs each), rows interleaved over ranks, one "
+                                          "SUM-reduce onto rank 0; step = Kim & Yue tables + QTF kernels + download + reduce (wall of rank 0)" % args.sets,
+                              "gather": gather_kind},
+                   "roofline": bench_legs._roof(b["pairs"] * b["strips"] * bench_legs.QTF_FLOP_PER_STRIP_PAIR / world, k_max,
+                                                "k_qtf_pairs (+ k_qtf_tables), slowest rank"),
+                   "per_rank_ms": {"qtf_kernels": [float(x) for x in allt[:, 0]], "wall": [float(x) for x in allt[:, 1]]},
+                   "hermitian": herm}
+    if rank == 0:
+        print(json.dumps(out))
+    if comm is not None:
+        comm.close()
+    ctx.close()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--workload", choices=("c3", "c4", "c5"), default="c3", help="c3: the headline design sweep (default); c4 / c5: the sharded "
+                                                                                "farm / QTF workloads of BASELINE configs[3] / [4]")
+    ap.add_argument("--farms", type=int, default=200, help="--workload c4: farms per GPU of the farm sweep")
+    ap.add_argument("--sets", type=int, default=16, help="--workload c5: QTF sets per batch")
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--designs", type=int, default=10000, help="designs per GPU (weak scaling)")
@@ -313,15 +426,26 @@ def main():
     if args.profile:
         args.chunks, args.no_extra_legs, args.no_cpu_baseline = 1, True, True
 
+    if args.gpus < 1:
+        ap.error("--gpus must be >= 1")
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:  # no launcher around us: be the launcher
+        sys.exit(launch_ranks(args.gpus, sys.argv[1:]))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:                                # a line that says n_gpus = N must have been produced by N ranks
+        sys.stderr.write("bench.py: --gpus %d but WORLD_SIZE=%d: start the ranks with --nproc-per-node %d (or drop the launcher: "
+                         "`python bench.py --gpus %d` starts them itself)\n" % (args.gpus, world, args.gpus, args.gpus))
+        sys.exit(2)
     # RAFTX_BENCH_DEVICE=0: rehearsal of the multi-rank path on a single-GPU box (all ranks share device 0; RCCL refuses
     # that, so the exchange steps fall back to the host transport and the JSON line says so); the driver's runs have one
     # GPU per rank and use RCCL or fail
     rehearsal = "RAFTX_BENCH_DEVICE" in os.environ
     if rehearsal:
         local = int(os.environ["RAFTX_BENCH_DEVICE"])
+
+    if args.workload != "c3":
+        return main_sharded_leg(args, world, rank, local, rehearsal)
 
     from raft_amd import backend
     from raft_amd.metrics import rao_group_err
@@ -348,10 +472,15 @@ def main():
     stream_steps = not args.no_stream
     Xi_pinned = [ctx.pinned_empty((nD, 1, 1, 6, nw)) for _ in range(3 if stream_steps else 1)] if args.xi_out else [None, None, None]
 
+    gather_s = []                                         # host time of every gather (this rank's share of the exchange step)
+    solo = {"on": False}                                  # rank 0's single-rank leg runs the same steps without the exchange
+
     def gather(r):
-        if comm is not None:                              # statistics of every rank onto rank 0 (48 B + 8 B per design-case)
+        if comm is not None and not solo["on"]:           # statistics of every rank onto rank 0 (48 B + 8 B per design-case)
+            tg = time.perf_counter()
             r["std_all"] = comm.gather_rows(np.concatenate([r["std"].reshape(nD, -1), r["niter"].reshape(nD, -1).astype(np.float64)], axis=1),
                                             counts=np.full(world, nD, dtype=np.int64))       # weak scaling: every rank holds nD designs
+            gather_s.append(time.perf_counter() - tg)
         return r
 
     def step():                                           # one isolated, blocking crossing
@@ -397,9 +526,24 @@ def main():
         # configuration -- three streamed steps bring both slots to the steady-state one (seven the three of --depth 3)
         run_steps(3 if args.depth == 2 else 7)
     run_steps(args.warmup)
+    # N > 1: the single-rank yardstick of THIS invocation -- rank 0 alone runs the same K steps (no exchange step) while the
+    # other ranks wait at the barrier, so that the N-rank value can be set against N x one rank on the same box and build
+    single_rank = None
+    if comm is not None:
+        barrier()
+        if rank == 0:
+            solo["on"] = True
+            ctx.synchronize()
+            ts = time.perf_counter()
+            run_steps(args.steps)
+            ctx.synchronize()
+            single_rank = (time.perf_counter() - ts) / args.steps
+            solo["on"] = False
     barrier()
+    del gather_s[:]
     t0 = time.perf_counter()
     res = run_steps(args.steps)                           # returns after the last step's streams have drained
+    t_own = time.perf_counter() - t0                      # this rank's own K steps, before it waits for the others
     barrier()
     elapsed = time.perf_counter() - t0
     r = res[-1]
@@ -410,8 +554,10 @@ def main():
         for _ in range(5):                                # (no gather here: only this rank runs it)
             sw.run_crossing(ctx, n_chunk=args.chunks, n_worker=args.workers, Xi_out=Xi_pinned[0])
         isolated = (time.perf_counter() - t1) / 5
+    per_rank = None
     if comm is not None:
         elapsed = comm.all_max(elapsed)                   # the slowest rank's clock
+        per_rank = comm.gather_floats([1e3 * t_own / args.steps, 1e3 * float(np.mean(gather_s)) if gather_s else 0.0])
     tims = np.array(tims)
     off = r["strip_off"]
     niter = r["niter"]
@@ -506,6 +652,13 @@ def main():
         featured = {"plain_sweep": {"kernel_ms": float(np.mean(ks)), "pairs": int(nD), "kernel_flags": ctx.last_solve_kernel()[0],
                                     "ns_per_pair_iteration": 1e6 * float(np.mean(ks)) / float(np.sum(niter))}}
         featured.update(featured_legs(ctx, nD, sw, float(np.mean(ks)), float(np.sum(niter))))
+    # ---- BASELINE configs[1], [3], [4] at their specified sizes, each against its live-reference golden (N = 1)
+    cfg_legs = {}
+    if rank == 0 and world == 1 and not args.no_extra_legs:
+        import bench_legs
+        cfg_legs["c2_dropin"] = bench_legs.c2_dropin(ctx)
+        cfg_legs["c4_farm"] = bench_legs.c4_farm(ctx, farms=1000)
+        cfg_legs["c5_qtf"] = bench_legs.c5_qtf(ctx)
 
     n_dcf_rank = nD * 1 * nw
     value = n_dcf_rank * world * args.steps / elapsed
@@ -557,6 +710,16 @@ def main():
         "host_placement": placement,
         "geometry": dict(geo, strips=int(off[-1]), strip_table_bytes_not_uploaded=int(off[-1]) * 256),
     }
+    if per_rank is not None and rank == 0:
+        out["per_rank_ms"] = {"min": float(per_rank[:, 0].min()), "max": float(per_rank[:, 0].max()), "all": [float(x) for x in per_rank[:, 0]],
+                              "note": "every rank's own K steps / K, before the closing barrier"}
+        out["gather_ms"] = {"rank0": float(per_rank[0, 1]), "max": float(per_rank[:, 1].max()),
+                            "note": "host time inside the per-step exchange (%s); on rank 0 it includes waiting for the slowest rank's rows" % gather_kind}
+        if single_rank is not None:
+            v1 = n_dcf_rank / single_rank
+            out["single_rank_same_invocation"] = {"ms_per_step": 1e3 * single_rank, "value": v1,
+                                                  "note": "rank 0 alone, same K steps, the other ranks idle at the barrier"}
+            out["scaling_efficiency"] = value / (world * v1)
     if isolated is not None:
         out["isolated_call"] = {"ms_per_step": 1e3 * isolated, "dcf_per_s_per_gpu": n_dcf_rank / isolated,
                                 "note": "the same step as one blocking raftx_sweep_stats call with nothing else in flight "
@@ -567,6 +730,7 @@ def main():
         out["xi_out"] = xi_leg
     if featured is not None:
         out["featured_sweeps"] = featured
+    out.update(cfg_legs)
     ref_here = reference_on_this_host() if (rank == 0 and world == 1 and not args.no_cpu_baseline) else None
     if ref_here is not None:
         out["reference_numpy_this_host"] = ref_here

@@ -75,6 +75,9 @@ typedef struct { double re, im; } raftx_c128;
 int         raftx_version(void);
 /* 1 if this library computes on a GPU (libraftx_hip), 0 for the CPU oracle */
 int         raftx_is_device(void);
+/* GPUs this process can open (hipGetDeviceCount; 0 when there is none or the runtime cannot start).  bench.py's
+ * rank launcher checks it against --gpus before it starts one process per GPU.  The oracle answers 0. */
+int         raftx_device_count(void);
 int         raftx_ctx_create(int device_id, raftx_ctx **out);
 void        raftx_ctx_destroy(raftx_ctx *ctx);
 const char *raftx_last_error(raftx_ctx *ctx);
@@ -429,13 +432,23 @@ int raftx_sweep_submit(raftx_ctx *ctx, int slot, int nDesign, const int64_t *mem
                        int nIter, double tol, double XiStart, int nChunk,
                        double *std, int32_t *niter, int32_t *flags, raftx_c128 *Xi, int64_t *stripOffsets);
 int raftx_sweep_wait(raftx_ctx *ctx, int slot, double *timing_ms);
+/* Retires a batch that was prepared and will not be launched (its uploads and member pass are drained, its scratch is
+ * released, its outputs are left untouched).  No-op on an idle slot; an error on a launched one (raftx_sweep_wait
+ * collects that).  raftx_ctx_destroy retires whatever is still prepared.
+ * Sea states and slots: a batch is solved with the sea-state tables it was PREPARED with.  The library keeps one resident
+ * set of tables per distinct (w, k, zeta, beta, depth, rho_wave, g_wave) among the batches in flight (identical tables are
+ * uploaded once and shared), and a set is released only when the last batch prepared with it has been waited for or
+ * cancelled -- so consecutive batches of a stream may change sea states freely, at the cost of one small upload. */
+int raftx_sweep_cancel(raftx_ctx *ctx, int slot);
 
 /* ------------------------------------------------------------------------------------------------
  * Multi-GPU exchange steps: one process per GPU, one RCCL communicator per ctx, xGMI underneath.
  * The path shards with NO collective while kernels run; these calls are the once-per-batch exchanges around it:
  * the shared sea-state tables out (broadcast), the responses / statistics / QTF partials back (gather, reduce).
  * Every rank of the communicator must make the same call.  All calls are enqueued on the ctx's stream and return
- * after it has drained.  (The CPU oracle does not implement them: its tests use the host transport of
+ * after it has drained.  Each exchange step first validates its arguments and allocates its buffers locally, then the
+ * ranks MAX-reduce one status word: if any rank cannot take part (bad argument, allocation failure) the call fails on
+ * every rank with an error instead of leaving the others blocked in a send / receive that is never posted.  (The CPU oracle does not implement them: its tests use the host transport of
  * raft_amd/comm.py.)
  *
  * raftx_comm_unique_id: rank 0 creates the 128-byte RCCL unique id and hands it to the other ranks by any host

@@ -31,6 +31,7 @@ EXPORTS = (
     "raftx_sweep_prepare",
     "raftx_sweep_launch",
     "raftx_sweep_wait",
+    "raftx_sweep_cancel", "raftx_device_count",
     "raftx_comm_unique_id", "raftx_comm_init", "raftx_comm_destroy", "raftx_comm_broadcast", "raftx_comm_gather_rows",
     "raftx_comm_gather_xi", "raftx_comm_reduce_sum",
 )
@@ -161,6 +162,10 @@ class RaftxLib:
         L.raftx_sweep_prepare.restype = C.c_int
         L.raftx_sweep_wait.argtypes = [_vp, C.c_int, _vp]
         L.raftx_sweep_wait.restype = C.c_int
+        L.raftx_sweep_cancel.argtypes = [_vp, C.c_int]
+        L.raftx_sweep_cancel.restype = C.c_int
+        L.raftx_device_count.argtypes = []
+        L.raftx_device_count.restype = C.c_int
         L.raftx_comm_unique_id.argtypes = [_vp, _vp]
         L.raftx_comm_init.argtypes = [_vp, C.c_int, C.c_int, _vp]
         L.raftx_comm_destroy.argtypes = [_vp]
@@ -182,6 +187,10 @@ class RaftxLib:
 
     def context(self, device_id=0):
         return Context(self, device_id)
+
+    def device_count(self):
+        """GPUs this process can open (raftx_device_count; 0 for the oracle or a host without a GPU)."""
+        return int(self.lib.raftx_device_count())
 
     def device_locality(self, device_id=0):
         """(PCI address, NUMA node or -1) of a device: raftx_device_locality."""
@@ -384,6 +393,11 @@ class Context:
         self._check(self.rlib.lib.raftx_sweep_wait(self._h, int(handle["slot"]), _ptr(out["timing_ms"])), "raftx_sweep_wait")
         handle["inputs"] = None
         return out
+
+    def sweep_cancel(self, handle):
+        """Retire a crossing that was prepared and will not be launched (raftx_sweep_cancel)."""
+        self._check(self.rlib.lib.raftx_sweep_cancel(self._h, int(handle["slot"])), "raftx_sweep_cancel")
+        handle["inputs"] = None
 
     def sweep_stats(self, tables, M0, B0, C0, w, k, depth, zeta, beta, nIter, tol=0.01, XiStart=0.1, pose=None,
                     rho=1025.0, g=9.81, rho_wave=1025.0, g_wave=9.81, add_mask=7, Fz_moor=None, n_chunk=0, n_worker=0,

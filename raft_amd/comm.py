@@ -90,20 +90,32 @@ def _unpack_dict(b):
     return {k: (_unpack_array(blobs[v[1]]) if v[0] == "array" else v[1]) for k, v in head.items()}
 
 
+def _is_loopback(addr):
+    return addr in ("localhost", "::1") or addr.startswith("127.")
+
+
 def _job_token(env, addr, port, world):
-    """Shared by the ranks of one job: RAFTX_COMM_TOKEN if the launcher exports one, else derived from what every rank of
-    the job (and nobody launched separately) sees -- the rendezvous endpoint, the world size and the elastic run id."""
+    """Key of the admission handshake.  RAFTX_COMM_TOKEN, if the launcher exports one (bench.py's own rank launcher
+    draws 128 random bits per job), is a secret and the handshake then authenticates the peers.  Without it the key is
+    derived from what every rank of the job sees -- the rendezvous endpoint, the world size and the elastic run id: all
+    guessable, so the handshake is then only a guard against ACCIDENTAL cross-job connections (two jobs on one port),
+    which is all a loopback rendezvous on a single node needs.  A rendezvous on a routable address must bring a
+    secret: ``HostComm`` refuses to listen there without one."""
     tok = env.get("RAFTX_COMM_TOKEN")
     if tok:
         return tok.encode()
+    if world > 1 and not _is_loopback(str(addr)):
+        raise RuntimeError("rendezvous on %s:%s is reachable from other hosts: export RAFTX_COMM_TOKEN (a shared secret) "
+                           "for the ranks of the job" % (addr, port))
     return ("raftx|%s|%s|%s|%s" % (addr, port, world, env.get("TORCHELASTIC_RUN_ID", ""))).encode()
 
 
 class HostComm:
     """Star topology over TCP: rank 0 holds one socket per peer.  Collectives are rooted at rank 0.
 
-    A peer proves it belongs to the job (HMAC of a nonce under the job token, ``_job_token``) and announces a rank in
-    1 .. world-1 that nobody else has taken before it is admitted.  ``timeout`` bounds the rendezvous only; collectives
+    A peer answers a nonce with its HMAC under the job token (``_job_token``: an authentication when the launcher
+    supplied a secret, a cross-job collision guard otherwise) and announces a rank in 1 .. world-1 that nobody else has
+    taken before it is admitted; a connection gets 2 s for that exchange, so a stranger cannot hold up the rendezvous.  ``timeout`` bounds the rendezvous only; collectives
     block (ranks of a sweep may finish minutes apart -- a resumed rank only loads its shards) unless
     ``collective_timeout`` / RAFTX_COMM_TIMEOUT sets a bound."""
 
@@ -132,7 +144,7 @@ class HostComm:
                     conn, _ = srv.accept()
                     try:
                         conn.setsockopt(socket.IPPROTO_TCP, socket.TCP_NODELAY, 1)
-                        conn.settimeout(10.0)
+                        conn.settimeout(2.0)
                         nonce = os.urandom(16)
                         conn.sendall(nonce)
                         (r,) = struct.unpack("<i", _recv_exact(conn, 4))
@@ -195,6 +207,14 @@ class HostComm:
         parts = self.gather_bytes(struct.pack("<d", float(x)))
         m = struct.pack("<d", max(struct.unpack("<d", p)[0] for p in parts)) if parts is not None else None
         return struct.unpack("<d", self.bcast_bytes(m))[0]
+
+    def gather_floats(self, xs):
+        """[world, len(xs)] array of every rank's floats on rank 0 (per-rank timings of a bench), None elsewhere"""
+        xs = [float(x) for x in np.atleast_1d(xs)]
+        parts = self.gather_bytes(struct.pack("<%dd" % len(xs), *xs))
+        if parts is None:
+            return None
+        return np.array([struct.unpack("<%dd" % len(xs), p) for p in parts])
 
     # -------------------------------------------------------------- the interface the sweep drivers use
     def broadcast_arrays(self, arrays=None):
@@ -269,6 +289,9 @@ class RcclComm:
 
     def all_counts(self, n):
         return self.boot.all_counts(n)
+
+    def gather_floats(self, xs):
+        return self.boot.gather_floats(xs)
 
     def broadcast_arrays(self, arrays=None):
         """Structure (names, shapes, dtypes, scalars) over the rendezvous channel, array payloads over RCCL."""

@@ -737,6 +737,17 @@ struct BuildJob {
     hipStream_t reduce_stream = nullptr; // side stream the member -> platform reductions were launched on (evRed), or null
 };
 
+// One set of sea-state tables resident for the sweep crossings.  A crossing pins the set it was PREPARED with until it has
+// been waited for (or cancelled), so that a later prepare with other sea states on another slot can neither free nor
+// replace what an earlier batch still reads (its member pass reads k; its fused kernel everything).
+struct CaseSet {
+    std::vector<double> key;             // nCase, nHead, nw, depth, rho, g, w, k, zeta, beta as given by the caller
+    DevTables T;                         // only the sea-state fields are used
+    std::vector<void *> allocs;
+    int users = 0;                       // crossings prepared or in flight on this set
+    unsigned long long stamp = 0;        // last use (the idle set used longest ago is replaced)
+};
+
 struct raftx_ctx {
     int device;
     hipStream_t stream;
@@ -753,7 +764,8 @@ struct raftx_ctx {
     size_t pinRes_n;
     hipStream_t sCopy, sPrep, sD2H, sGen; // internal streams of raftx_sweep_stats (created on first use)
     hipStream_t sD2Hlow = nullptr;        // bulk download of the responses: a LOW-priority stream, created when first needed
-    std::vector<double> case_key;        // the sea-state tables resident for the sweep crossing (skip identical re-uploads)
+    CaseSet csets[RAFTX_NSLOT + 1];      // sea-state tables of the sweep crossings: one per crossing in flight + one being replaced
+    unsigned long long cset_clock = 0;
     char err[512];
     DevTables T;
     DevPool pool;
@@ -795,12 +807,14 @@ struct raftx_ctx {
     cplx *g_cm;
     void *comm;                          // ncclComm_t of raftx_comm_init (RCCL), or null
     int comm_rank, comm_world;
+    int *commFlag = nullptr;             // one int in HBM: the status word the ranks agree on before an exchange step (comm_agree)
     std::vector<raftx_ctx *> workers[RAFTX_NSLOT]; // block contexts of the sweep crossings (device buffers, pool, events), per slot, kept for reuse
     struct SweepSlot *slots;             // [RAFTX_NSLOT] crossings in flight (raftx_sweep_prepare / _launch / _wait)
 };
 // One sweep crossing in flight: everything raftx_sweep_wait needs to finish it.
 struct SweepSlot {
     bool busy = false;                   // launched (phase 2 enqueued), not yet waited for
+    int cset = -1;                       // the CaseSet of the parent this crossing was prepared with (pinned until retired)
     bool prepared = false;               // phase 1 enqueued (descriptor upload, member pass), not yet launched
     int nIter = 0;
     double tol = 0, XiStart = 0, dw = 0;
@@ -835,6 +849,14 @@ struct SweepSlot {
 
 extern "C" int raftx_version(void) { return RAFTX_VERSION; }
 extern "C" int raftx_is_device(void) { return 1; }
+extern "C" int raftx_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) {
+        (void)hipGetLastError();
+        return 0;
+    }
+    return n;
+}
 
 extern "C" int raftx_ctx_create(int device_id, raftx_ctx **out) {
     if (!out) return -1;
@@ -884,7 +906,7 @@ extern "C" int raftx_ctx_create(int device_id, raftx_ctx **out) {
     c->pin_n = 0;
     c->pinRes = nullptr;
     c->pinRes_n = 0;
-    c->sCopy = c->sPrep = c->sD2H = nullptr;
+    c->sCopy = c->sPrep = c->sD2H = c->sGen = nullptr;
     bool ok = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) == hipSuccess;
     c->sAux = nullptr;
     for (hipEvent_t *e : {&c->evZ, &c->ev0, &c->ev1, &c->evUp, &c->evTot, &c->evG0, &c->evG1, &c->evG2, &c->evG3, &c->evS0,
@@ -920,6 +942,10 @@ extern "C" void raftx_ctx_destroy(raftx_ctx *c) {
     }
 #endif
     (void)raftx_comm_destroy(c);
+    if (c->owns_stream) {                             // a crossing prepared and never launched still has work on sCopy / sPrep
+        (void)hipSetDevice(c->device);
+        (void)hipDeviceSynchronize();
+    }
     for (int sl = 0; sl < RAFTX_NSLOT; sl++) {
         for (raftx_ctx *w : c->workers[sl]) raftx_ctx_destroy(w);
         c->workers[sl].clear();
@@ -929,6 +955,7 @@ extern "C" void raftx_ctx_destroy(raftx_ctx *c) {
     free_list(c, c->design_allocs);
     free_list(c, c->case_allocs);
     free_list(c, c->result_allocs);
+    for (CaseSet &cs : c->csets) free_list(c, cs.allocs);
     c->pool.trim();
     if (c->rXl) (void)hipFree(c->rXl);
     if (c->rXl0) (void)hipFree(c->rXl0);
@@ -950,7 +977,7 @@ extern "C" void raftx_ctx_destroy(raftx_ctx *c) {
                          c->evMem, c->evRed})
         (void)hipEventDestroy(e);
     if (c->sAux) (void)hipStreamDestroy(c->sAux);
-    for (hipStream_t st : {c->sCopy, c->sPrep, c->sD2H, c->sD2Hlow})
+    for (hipStream_t st : {c->sCopy, c->sPrep, c->sD2H, c->sGen, c->sD2Hlow})
         if (st) (void)hipStreamDestroy(st);
     if (c->owns_stream) (void)hipStreamDestroy(c->stream);
     delete c;
@@ -1411,18 +1438,11 @@ extern "C" int raftx_fetch_statics(raftx_ctx *c, double *A_morison, double *C_hy
     return 0;
 }
 
-extern "C" int raftx_upload_cases(raftx_ctx *c, int nCase, int nHead, int nw, const double *w, const double *k,
-                                  double depth, double rho, double g, const double *zeta, const double *beta) {
-    RangeScope range_("raftx_upload_cases: H2D");
-    if (!c) return -1;
-    if (nCase < 0 || nHead < 1 || nw < 1 || !w || !k || !zeta || !beta) FAIL(c, "upload_cases: bad arguments");
-    if (nw > MAX_NW) FAIL(c, "nw=%d exceeds the %d bins per workgroup supported by this build", nw, MAX_NW);
-    HIPCHK(c, hipSetDevice(c->device));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
-    free_list(c, c->case_allocs);
-    c->have_cases = false;
-    c->bem_ready = false;
-    c->case_key.clear();
+// The sea-state tables of one set of cases into device memory of ctx `c` (allocations into `bag`, fields into `T`), copied
+// on `st`, which has drained when this returns (the depth constants are host temporaries).
+static int upload_case_tables(raftx_ctx *c, hipStream_t st, std::vector<void *> &bag, DevTables &T, int nCase, int nHead, int nw,
+                              const double *w, const double *k, double depth, double rho, double g, const double *zeta,
+                              const double *beta) {
     // per-bin depth constants, computed once on the host in full libm precision.  The kernels derive
     // the depth regime (k == 0 / deep / finite) from k themselves, with the same rule.
     std::vector<double> csh(nw), cch(nw);
@@ -1436,7 +1456,6 @@ extern "C" int raftx_upload_cases(raftx_ctx *c, int nCase, int nHead, int nw, co
             cch[i] = 1.0 / (1.0 + e2kh);
         }
     }
-    DevTables &T = c->T;
     T.nCase = nCase;
     T.nHead = nHead;
     T.nw = nw;
@@ -1444,14 +1463,30 @@ extern "C" int raftx_upload_cases(raftx_ctx *c, int nCase, int nHead, int nw, co
     T.rho = rho;
     T.g = g;
     int rc = 0;
-    rc |= upload(c, c->case_allocs, w, (size_t)nw, &T.w);
-    rc |= upload(c, c->case_allocs, k, (size_t)nw, &T.k);
-    rc |= upload(c, c->case_allocs, csh.data(), (size_t)nw, &T.csh);
-    rc |= upload(c, c->case_allocs, cch.data(), (size_t)nw, &T.cch);
-    rc |= upload(c, c->case_allocs, zeta, (size_t)nCase * nHead * nw, &T.zeta);
-    rc |= upload(c, c->case_allocs, beta, (size_t)nCase * nHead, &T.beta);
+    rc |= upload_on(c, st, bag, w, (size_t)nw, &T.w);
+    rc |= upload_on(c, st, bag, k, (size_t)nw, &T.k);
+    rc |= upload_on(c, st, bag, csh.data(), (size_t)nw, &T.csh);
+    rc |= upload_on(c, st, bag, cch.data(), (size_t)nw, &T.cch);
+    rc |= upload_on(c, st, bag, zeta, (size_t)nCase * nHead * nw, &T.zeta);
+    rc |= upload_on(c, st, bag, beta, (size_t)nCase * nHead, &T.beta);
+    const hipError_t e = hipStreamSynchronize(st);        // also on failure: csh / cch go out of scope
     if (rc) return -2;
+    HIPCHK(c, e);
+    return 0;
+}
+
+extern "C" int raftx_upload_cases(raftx_ctx *c, int nCase, int nHead, int nw, const double *w, const double *k,
+                                  double depth, double rho, double g, const double *zeta, const double *beta) {
+    RangeScope range_("raftx_upload_cases: H2D");
+    if (!c) return -1;
+    if (nCase < 0 || nHead < 1 || nw < 1 || !w || !k || !zeta || !beta) FAIL(c, "upload_cases: bad arguments");
+    if (nw > MAX_NW) FAIL(c, "nw=%d exceeds the %d bins per workgroup supported by this build", nw, MAX_NW);
+    HIPCHK(c, hipSetDevice(c->device));
     HIPCHK(c, hipStreamSynchronize(c->stream));
+    free_list(c, c->case_allocs);
+    c->have_cases = false;
+    c->bem_ready = false;
+    if (int rc = upload_case_tables(c, c->stream, c->case_allocs, c->T, nCase, nHead, nw, w, k, depth, rho, g, zeta, beta)) return rc;
     c->have_cases = true;
     return 0;
 }
@@ -2434,6 +2469,12 @@ static bool others_in_flight(raftx_ctx *c, int slot) {
     return false;
 }
 
+// the crossing of slot S no longer reads its sea-state set
+static void slot_release_cases(raftx_ctx *c, SweepSlot &S) {
+    if (S.cset >= 0 && c->csets[S.cset].users > 0) c->csets[S.cset].users--;
+    S.cset = -1;
+}
+
 extern "C" int raftx_sweep_prepare(raftx_ctx *c, int slot, int nDesign, const int64_t *memberOff, const double *members,
                                   const int64_t *stationOff, const double *stations, const int64_t *capOff,
                                   const double *caps, const double *pose, double rho, double g, int add_mask,
@@ -2470,8 +2511,10 @@ extern "C" int raftx_sweep_prepare(raftx_ctx *c, int slot, int nDesign, const in
         HIPCHK(c, hipStreamCreateWithFlags(&c->sGen, hipStreamNonBlocking));
     }
     if (!S.evXi) HIPCHK(c, hipEventCreate(&S.evXi));
-    // sea-state tables: resident on the parent, shared by the blocks of both slots; identical tables are not uploaded
-    // again (a change drains the ctx stream first: the other slot may still read the old ones)
+    // sea-state tables: sets resident on the parent, shared by the blocks of every slot that was prepared with the same
+    // tables; identical tables are not uploaded again.  The slot pins its set until it is retired (wait / cancel / failure),
+    // so other sea states prepared on another slot meanwhile get a set of their own and leave this one alone.
+    if (nw > MAX_NW) FAIL(c, "nw=%d exceeds the %d bins per workgroup supported by this build", nw, MAX_NW);
     {
         std::vector<double> key;
         key.reserve((size_t)nw * 2 + (size_t)nCase * nHead * (nw + 1) + 6);
@@ -2480,14 +2523,29 @@ extern "C" int raftx_sweep_prepare(raftx_ctx *c, int slot, int nDesign, const in
         key.insert(key.end(), k, k + nw);
         key.insert(key.end(), zeta, zeta + (size_t)nCase * nHead * nw);
         key.insert(key.end(), beta, beta + (size_t)nCase * nHead);
-        if (!c->have_cases || key.size() != c->case_key.size() ||
-            memcmp(key.data(), c->case_key.data(), key.size() * sizeof(double)) != 0) {
-            c->case_key.clear();
-            const int rc = raftx_upload_cases(c, nCase, nHead, nw, w, k, depth, rho_wave, g_wave, zeta, beta);
-            if (rc) return rc;
-            c->case_key.swap(key);
+        int hit = -1, idle = -1;
+        for (int i = 0; i <= RAFTX_NSLOT; i++) {
+            CaseSet &cs = c->csets[i];
+            if (!cs.key.empty() && cs.key.size() == key.size() && memcmp(key.data(), cs.key.data(), key.size() * sizeof(double)) == 0) hit = i;
+            else if (cs.users == 0 && (idle < 0 || cs.stamp < c->csets[idle].stamp)) idle = i;
         }
+        if (hit < 0) {
+            if (idle < 0) FAIL(c, "sweep_prepare: no free sea-state set (every set is pinned by a crossing in flight)");   // cannot happen: NSLOT + 1 sets
+            CaseSet &cs = c->csets[idle];
+            cs.key.clear();
+            free_list(c, cs.allocs);                      // users == 0: every crossing that read it has been waited for
+            if (int rc = upload_case_tables(c, c->sCopy, cs.allocs, cs.T, nCase, nHead, nw, w, k, depth, rho_wave, g_wave, zeta, beta)) {
+                free_list(c, cs.allocs);
+                return rc;
+            }
+            cs.key.swap(key);
+            hit = idle;
+        }
+        c->csets[hit].users++;
+        c->csets[hit].stamp = ++c->cset_clock;
+        S.cset = hit;
     }
+    const DevTables &CT = c->csets[S.cset].T;
     S.bnd = sweep_bounds(nDesign, (long)nDesign * nCase, nChunk, others_in_flight(c, slot));
     const std::vector<int> &bnd = S.bnd;
     const size_t nB = bnd.size() - 1;
@@ -2507,13 +2565,17 @@ extern "C" int raftx_sweep_prepare(raftx_ctx *c, int slot, int nDesign, const in
                 free_list(sub, sub->job.tmp);
                 sub->job.active = false;
             }
+        slot_release_cases(c, S);
         return rc;
     };
     // ---- the batch's offset arrays: one upload, shared by the blocks
     DevOffsets dOff{nullptr, nullptr, nullptr};
     {
         const int64_t nMemberAll = memberOff[nDesign];
-        if (nMemberAll < 0) FAIL(c, "sweep_stats: member offsets not monotone");
+        if (nMemberAll < 0) {
+            slot_release_cases(c, S);
+            FAIL(c, "sweep_stats: member offsets not monotone");
+        }
         int rc = upload_on(c, c->sCopy, S.allocs, memberOff, (size_t)nDesign + 1, &dOff.memberOff);
         rc |= upload_on(c, c->sCopy, S.allocs, stationOff, (size_t)nMemberAll + 1, &dOff.stationOff);
         if (capOff) rc |= upload_on(c, c->sCopy, S.allocs, capOff, (size_t)nMemberAll + 1, &dOff.capOff);
@@ -2525,7 +2587,7 @@ extern "C" int raftx_sweep_prepare(raftx_ctx *c, int slot, int nDesign, const in
         raftx_ctx *sub = blk[b];
         const int lo = bnd[b], n = bnd[b + 1] - lo;
         const int rc = build_phase1(sub, c->sCopy, c->sPrep, lo, n, memberOff, members, stationOff, stations, capOff, caps, pose,
-                                    rho, g, nw, k, add_mask, M0, B0, C0, nullptr, Fz_moor, &dOff, c->T.k);
+                                    rho, g, nw, k, add_mask, M0, B0, C0, nullptr, Fz_moor, &dOff, CT.k);
         if (rc) {
             snprintf(c->err, sizeof(c->err), "sweep_stats (block %zu): %s", b, sub->err);
             return fail_drain(rc);
@@ -2542,6 +2604,8 @@ extern "C" int raftx_sweep_launch(raftx_ctx *c, int slot) {
     if (slot < 0 || slot >= RAFTX_NSLOT) FAIL(c, "sweep_launch: slot must be 0 .. %d", RAFTX_NSLOT - 1);
     SweepSlot &S = c->slots[slot];
     if (!S.prepared) FAIL(c, "sweep_launch: nothing prepared on slot %d (raftx_sweep_prepare first)", slot);
+    if (S.cset < 0 || c->csets[S.cset].T.nCase != S.nCase || c->csets[S.cset].T.nHead != S.nHead || c->csets[S.cset].T.nw != S.nw)
+        FAIL(c, "sweep_launch: slot %d has lost its sea-state tables (internal error)", slot);
     HIPCHK(c, hipSetDevice(c->device));
     auto since = [&]() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - S.t0).count(); };
     const std::vector<int> &bnd = S.bnd;
@@ -2558,6 +2622,7 @@ extern "C" int raftx_sweep_launch(raftx_ctx *c, int slot) {
                 free_list(sub, sub->job.tmp);
                 sub->job.active = false;
             }
+        slot_release_cases(c, S);
         return rc;
     };
     // ---- phase 2 + fixed point + statistics of every block, in order, on the ctx stream
@@ -2598,9 +2663,9 @@ extern "C" int raftx_sweep_launch(raftx_ctx *c, int slot) {
                     for (raftx_ctx *o : c->slots[sl].blk)
                         if (o && hipStreamWaitEvent(c->stream, o->evTot, 0) != hipSuccess) rc = -2;
         }
-        if (!rc) {                                                      // the sea states of the parent
+        if (!rc) {                                                      // the sea states this crossing was prepared with
             DevTables &T = sub->T;
-            const DevTables &P = c->T;
+            const DevTables &P = c->csets[S.cset].T;
             T.nCase = P.nCase; T.nHead = P.nHead; T.nw = P.nw;
             T.w = P.w; T.k = P.k; T.csh = P.csh; T.cch = P.cch; T.zeta = P.zeta; T.beta = P.beta;
             T.depth = P.depth; T.rho = P.rho; T.g = P.g;
@@ -2690,6 +2755,30 @@ extern "C" int raftx_sweep_submit(raftx_ctx *c, int slot, int nDesign, const int
     return raftx_sweep_launch(c, slot);
 }
 
+// Retires a crossing that was prepared and will not be launched: its uploads and member pass are drained, its scratch and
+// sea-state set released; the output arrays given at prepare time are not touched.
+extern "C" int raftx_sweep_cancel(raftx_ctx *c, int slot) {
+    if (!c) return -1;
+    if (slot < 0 || slot >= RAFTX_NSLOT) FAIL(c, "sweep_cancel: slot must be 0 .. %d", RAFTX_NSLOT - 1);
+    SweepSlot &S = c->slots[slot];
+    if (S.busy) FAIL(c, "sweep_cancel: slot %d has been launched (raftx_sweep_wait collects it)", slot);
+    if (!S.prepared) return 0;
+    HIPCHK(c, hipSetDevice(c->device));
+    hipError_t e = hipSuccess;
+    for (hipStream_t st : {c->sCopy, c->sPrep})
+        if (st && e == hipSuccess) e = hipStreamSynchronize(st);
+    for (raftx_ctx *sub : S.blk)
+        if (sub) {
+            if (sub->sAux && e == hipSuccess) e = hipStreamSynchronize(sub->sAux);
+            free_list(sub, sub->job.tmp);
+            sub->job.active = false;
+        }
+    S.prepared = false;
+    slot_release_cases(c, S);
+    HIPCHK(c, e);
+    return 0;
+}
+
 extern "C" int raftx_sweep_wait(raftx_ctx *c, int slot, double *timing_ms) {
     RangeScope range_("raftx_sweep_wait: drain + outputs");
     if (!c) return -1;
@@ -2705,8 +2794,10 @@ extern "C" int raftx_sweep_wait(raftx_ctx *c, int slot, double *timing_ms) {
     S.tl[3] = since();
     if (es == hipSuccess && S.Xi) es = hipEventSynchronize(S.evXi);
     if (es == hipSuccess) es = hipGetLastError();
+    if (es == hipSuccess) slot_release_cases(c, S);
     if (es != hipSuccess) {
         (void)hipDeviceSynchronize();
+        slot_release_cases(c, S);
         for (raftx_ctx *sub : S.blk) {
             free_list(sub, sub->job.tmp);
             sub->job.active = false;
@@ -2771,6 +2862,7 @@ struct RcclApi {
     const char *(*GetErrorString)(ncclResult_t) = nullptr;
     ncclResult_t (*Broadcast)(const void *, void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
     ncclResult_t (*Reduce)(const void *, void *, size_t, ncclDataType_t, ncclRedOp_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*AllReduce)(const void *, void *, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
     ncclResult_t (*Send)(const void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
     ncclResult_t (*Recv)(void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
     ncclResult_t (*GroupStart)() = nullptr;
@@ -2801,6 +2893,7 @@ static RcclApi *rccl_api(raftx_ctx *c) {
     RCCL_SYM(GetErrorString, "ncclGetErrorString")
     RCCL_SYM(Broadcast, "ncclBroadcast")
     RCCL_SYM(Reduce, "ncclReduce")
+    RCCL_SYM(AllReduce, "ncclAllReduce")
     RCCL_SYM(Send, "ncclSend")
     RCCL_SYM(Recv, "ncclRecv")
     RCCL_SYM(GroupStart, "ncclGroupStart")
@@ -2842,6 +2935,10 @@ extern "C" int raftx_comm_destroy(raftx_ctx *c) {
         }
         c->comm = nullptr;
     }
+    if (c->commFlag) {
+        (void)hipFree(c->commFlag);
+        c->commFlag = nullptr;
+    }
     c->comm_rank = 0;
     c->comm_world = 1;
     return 0;
@@ -2872,15 +2969,49 @@ static int comm_ready(raftx_ctx *c, RcclApi **R, int root) {
     return *R ? 0 : -7;
 }
 
+// Every exchange step starts with the ranks agreeing that all of them can go through with it: each rank validates its
+// arguments and allocates its buffers FIRST, then the worst local status is MAX-reduced over the communicator (one int).
+// A rank that failed locally (bad argument, allocation) therefore fails the call on EVERY rank, with an error, instead of
+// leaving its peers blocked inside a send / receive it never posts.  `local_rc` 0 = ready.
+static int comm_agree(raftx_ctx *c, RcclApi *R, int local_rc) {
+    if (!c->commFlag) {
+        void *p = nullptr;
+        if (hipMalloc(&p, sizeof(int)) != hipSuccess) p = nullptr;     // no flag buffer: the peers time out in the collective below;
+        c->commFlag = reinterpret_cast<int *>(p);                      // nothing smaller than an int can fail here in practice
+        if (!p) FAIL(c, "comm: cannot allocate the status word");
+    }
+    int mine = local_rc ? 1 : 0, worst = 0;
+    HIPCHK(c, hipMemcpyAsync(c->commFlag, &mine, sizeof(int), hipMemcpyHostToDevice, c->stream));
+    NCCLCHK(c, R, R->AllReduce(c->commFlag, c->commFlag, 1, ncclInt, ncclMax, reinterpret_cast<ncclComm_t>(c->comm), c->stream));
+    HIPCHK(c, hipMemcpyAsync(&worst, c->commFlag, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (local_rc) return local_rc;                    // c->err already says why
+    if (worst) FAIL(c, "comm: another rank could not take part in this exchange step (see its error)");
+    return 0;
+}
+// local preparation of an exchange step: returns its status instead of leaving the function (see comm_agree)
+#define COMM_LOCAL(rc, cond, ...)                                  \
+    do {                                                           \
+        if (!(rc) && (cond)) {                                     \
+            snprintf(c->err, sizeof(c->err), __VA_ARGS__);         \
+            (rc) = -1;                                             \
+        }                                                          \
+    } while (0)
+
 extern "C" int raftx_comm_broadcast(raftx_ctx *c, void *buf, size_t bytes, int root) {
     RcclApi *R = nullptr;
     if (int rc = comm_ready(c, &R, root)) return rc;
-    if (!buf && bytes) FAIL(c, "comm_broadcast: buf is NULL");
-    if (!bytes) return 0;
     HIPCHK(c, hipSetDevice(c->device));
     Scratch sc(c);
-    char *d = sc.alloc<char>(bytes);
-    if (!d) FAIL(c, "comm_broadcast: device allocation failed");
+    int rc = 0;
+    char *d = nullptr;
+    COMM_LOCAL(rc, !buf && bytes, "comm_broadcast: buf is NULL");
+    if (!rc && bytes) {
+        d = sc.alloc<char>(bytes);
+        COMM_LOCAL(rc, !d, "comm_broadcast: device allocation failed");
+    }
+    if (int a = comm_agree(c, R, rc)) return a;
+    if (!bytes) return 0;
     if (c->comm_rank == root) H2D(c, d, buf, bytes);
     NCCLCHK(c, R, R->Broadcast(d, d, bytes, ncclChar, root, reinterpret_cast<ncclComm_t>(c->comm), c->stream));
     if (c->comm_rank != root) D2H(c, buf, d, bytes);
@@ -2888,38 +3019,52 @@ extern "C" int raftx_comm_broadcast(raftx_ctx *c, void *buf, size_t bytes, int r
     return 0;
 }
 
-// rows of every rank onto root, point to point; dsend: this rank's rows already in HBM
+// rows of every rank onto root, point to point; dsend: this rank's rows already in HBM.  `rc`: status of the caller's own
+// preparation.  Everything that can fail locally (counts, root's receive buffer) is done BEFORE the ranks agree to go on;
+// inside the ncclGroupStart / ncclGroupEnd pair nothing returns early.
 static int gather_rows_dev(raftx_ctx *c, RcclApi *R, const void *dsend, const int64_t *counts, size_t row_bytes, void *recv_host,
-                           int root, Scratch &sc) {
+                           int root, Scratch &sc, int rc) {
     const int me = c->comm_rank, world = c->comm_world;
     ncclComm_t comm = reinterpret_cast<ncclComm_t>(c->comm);
     size_t total = 0;
-    for (int r = 0; r < world; r++) {
-        if (counts[r] < 0) FAIL(c, "comm_gather: negative count for rank %d", r);
-        total += (size_t)counts[r];
+    for (int r = 0; r < world && !rc; r++) {
+        COMM_LOCAL(rc, counts[r] < 0, "comm_gather: negative count for rank %d", r);
+        if (!rc) total += (size_t)counts[r];
     }
     char *dall = nullptr;
-    if (me == root) {
-        if (!recv_host && total) FAIL(c, "comm_gather: recv is NULL on root");
-        dall = sc.alloc<char>(total * row_bytes);
-        if (total && !dall) FAIL(c, "comm_gather: device allocation failed");
-    }
-    NCCLCHK(c, R, R->GroupStart());
-    if (me == root) {
-        size_t o = 0;
-        for (int r = 0; r < world; r++) {
-            const size_t nb = (size_t)counts[r] * row_bytes;
-            if (nb) {
-                if (r == me) HIPCHK(c, hipMemcpyAsync(dall + o, dsend, nb, hipMemcpyDeviceToDevice, c->stream));
-                else NCCLCHK(c, R, R->Recv(dall + o, nb, ncclChar, r, comm, c->stream));
-            }
-            o += nb;
+    if (!rc && me == root) {
+        COMM_LOCAL(rc, !recv_host && total, "comm_gather: recv is NULL on root");
+        if (!rc && total) {
+            dall = sc.alloc<char>(total * row_bytes);
+            COMM_LOCAL(rc, !dall, "comm_gather: device allocation failed");
         }
-    } else {
-        const size_t nb = (size_t)counts[me] * row_bytes;
-        if (nb) NCCLCHK(c, R, R->Send(dsend, nb, ncclChar, root, comm, c->stream));
     }
-    NCCLCHK(c, R, R->GroupEnd());
+    if (int a = comm_agree(c, R, rc)) return a;
+    ncclResult_t nr = R->GroupStart();
+    hipError_t he = hipSuccess;
+    if (nr == ncclSuccess) {
+        if (me == root) {
+            size_t o = 0;
+            for (int r = 0; r < world; r++) {
+                const size_t nb = (size_t)counts[r] * row_bytes;
+                if (nb && nr == ncclSuccess && he == hipSuccess) {
+                    if (r == me) he = hipMemcpyAsync(dall + o, dsend, nb, hipMemcpyDeviceToDevice, c->stream);
+                    else nr = R->Recv(dall + o, nb, ncclChar, r, comm, c->stream);
+                }
+                o += nb;
+            }
+        } else {
+            const size_t nb = (size_t)counts[me] * row_bytes;
+            if (nb) nr = R->Send(dsend, nb, ncclChar, root, comm, c->stream);
+        }
+        const ncclResult_t ne = R->GroupEnd();        // always closed, whatever happened inside
+        if (nr == ncclSuccess) nr = ne;
+    }
+    if (nr != ncclSuccess) {
+        (void)hipStreamSynchronize(c->stream);
+        FAIL(c, "comm_gather: RCCL send / receive failed: %s", R->GetErrorString(nr));
+    }
+    HIPCHK(c, he);
     if (me == root && total) D2H(c, recv_host, dall, total * row_bytes);
     HIPCHK(c, hipStreamSynchronize(c->stream));
     return 0;
@@ -2929,43 +3074,54 @@ extern "C" int raftx_comm_gather_rows(raftx_ctx *c, const void *send, const int6
                                       int root) {
     RcclApi *R = nullptr;
     if (int rc = comm_ready(c, &R, root)) return rc;
-    if (!counts || !row_bytes) FAIL(c, "comm_gather_rows: bad arguments");
     HIPCHK(c, hipSetDevice(c->device));
     Scratch sc(c);
-    const size_t nb = (size_t)counts[c->comm_rank] * row_bytes;
+    int rc = 0;
+    COMM_LOCAL(rc, !counts || !row_bytes, "comm_gather_rows: bad arguments");
+    const size_t nb = rc ? 0 : (size_t)(counts[c->comm_rank] > 0 ? counts[c->comm_rank] : 0) * row_bytes;
     char *d = nullptr;
-    if (nb) {
-        if (!send) FAIL(c, "comm_gather_rows: send is NULL");
-        d = sc.alloc<char>(nb);
-        if (!d) FAIL(c, "comm_gather_rows: device allocation failed");
-        H2D(c, d, send, nb);
+    if (!rc && nb) {
+        COMM_LOCAL(rc, !send, "comm_gather_rows: send is NULL");
+        if (!rc) {
+            d = sc.alloc<char>(nb);
+            COMM_LOCAL(rc, !d, "comm_gather_rows: device allocation failed");
+        }
+        if (!rc && hipMemcpyAsync(d, send, nb, hipMemcpyHostToDevice, c->stream) != hipSuccess)
+            COMM_LOCAL(rc, true, "comm_gather_rows: H2D of this rank's rows failed");
     }
-    return gather_rows_dev(c, R, d, counts, row_bytes, recv, root, sc);
+    if (rc && !counts) return comm_agree(c, R, rc);   // nothing to walk: only tell the peers
+    return gather_rows_dev(c, R, d, counts, row_bytes, recv, root, sc, rc);
 }
 
 extern "C" int raftx_comm_gather_xi(raftx_ctx *c, const int64_t *counts, raftx_c128 *Xi_all, int root) {
     RcclApi *R = nullptr;
     if (int rc = comm_ready(c, &R, root)) return rc;
-    if (!counts) FAIL(c, "comm_gather_xi: counts is NULL");
-    if (!c->rXi) FAIL(c, "comm_gather_xi: no resident results");
-    if ((size_t)counts[c->comm_rank] != c->r_npair)
-        FAIL(c, "comm_gather_xi: counts[%d] = %lld but %zu (design, case) pairs are resident", c->comm_rank,
-             (long long)counts[c->comm_rank], c->r_npair);
     HIPCHK(c, hipSetDevice(c->device));
     Scratch sc(c);
+    int rc = 0;
+    COMM_LOCAL(rc, !counts, "comm_gather_xi: counts is NULL");
+    COMM_LOCAL(rc, !c->rXi, "comm_gather_xi: no resident results");
+    COMM_LOCAL(rc, (size_t)counts[c->comm_rank] != c->r_npair, "comm_gather_xi: counts[%d] = %lld but %zu (design, case) pairs are resident",
+               c->comm_rank, (long long)counts[c->comm_rank], c->r_npair);
+    if (rc && !counts) return comm_agree(c, R, rc);
     const size_t row_bytes = (size_t)c->T.nHead * 6 * c->T.nw * sizeof(cplx);
-    return gather_rows_dev(c, R, c->rXi, counts, row_bytes, Xi_all, root, sc);
+    return gather_rows_dev(c, R, c->rXi, counts, row_bytes, Xi_all, root, sc, rc);
 }
 
 extern "C" int raftx_comm_reduce_sum(raftx_ctx *c, double *buf, size_t n, int root) {
     RcclApi *R = nullptr;
     if (int rc = comm_ready(c, &R, root)) return rc;
-    if (!buf && n) FAIL(c, "comm_reduce_sum: buf is NULL");
-    if (!n) return 0;
     HIPCHK(c, hipSetDevice(c->device));
     Scratch sc(c);
-    double *d = sc.alloc<double>(n);
-    if (!d) FAIL(c, "comm_reduce_sum: device allocation failed");
+    int rc = 0;
+    double *d = nullptr;
+    COMM_LOCAL(rc, !buf && n, "comm_reduce_sum: buf is NULL");
+    if (!rc && n) {
+        d = sc.alloc<double>(n);
+        COMM_LOCAL(rc, !d, "comm_reduce_sum: device allocation failed");
+    }
+    if (int a = comm_agree(c, R, rc)) return a;
+    if (!n) return 0;
     H2D(c, d, buf, n * sizeof(double));
     NCCLCHK(c, R, R->Reduce(d, d, n, ncclDouble, ncclSum, root, reinterpret_cast<ncclComm_t>(c->comm), c->stream));
     if (c->comm_rank == root) D2H(c, buf, d, n * sizeof(double));

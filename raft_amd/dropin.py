@@ -280,9 +280,11 @@ class Engine:
                     node = rot.nodeList[0]
                     nd = int(getattr(node, "nDOF", 6))
                     i0 = int(getattr(node, "id", 0)) * nd
-                    if F_full.shape[1] >= i0 + 6:
-                        # (with several submerged rotors every rotor's slots would need its own table: one is what exists)
-                        F_full[ih, i0:i0 + 6, :] += F_prp[ih]
+                    if F_full.shape[1] < i0 + 6:          # T^T F_full must stay equal to the reduced vector: never skip silently
+                        raise UnsupportedFOWT("submerged rotor on node %d: its slots %d..%d lie outside the %d full DOFs of the unit"
+                                              % (int(getattr(node, "id", 0)), i0, i0 + 5, F_full.shape[1]))
+                    # (with several submerged rotors every rotor's slots would need its own table: one is what exists)
+                    F_full[ih, i0:i0 + 6, :] += F_prp[ih]
 
     # ------------------------------------------------------------------
     def calcHydroExcitation(self, fowt, case, memberList=[]):
@@ -302,10 +304,10 @@ class Engine:
         per_member = []
         if members and all(i is not None for i in ids):
             per_member = [pack_fowt(fowt, [m], own_node=True) for m in members]
-        self._rotor_kinematics(fowt)
-        rotor_tables = self._rotor_tables(fowt)
         if sum(1 for rot in getattr(fowt, "rotorList", []) if rot.r3[2] < 0) > 1:
             raise UnsupportedFOWT("more than one submerged rotor on a unit")
+        self._rotor_kinematics(fowt)
+        rotor_tables = self._rotor_tables(fowt)
         self._upload([fowt], fowt.zeta, fowt.beta, tables=[fowt._raftx_table] + per_member + rotor_tables)
         self._up_key = None                                  # more designs than the unit's own table are resident
         if members or rotor_tables:

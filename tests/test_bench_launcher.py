@@ -1,0 +1,44 @@
+"""CPU suite: `python bench.py --gpus N` starts its own N ranks (bench.py launch_ranks) -- against a stub rank
+(tests/helpers/stub_rank.py) that checks the environment it is given and meets the other ranks over the host transport."""
+import json
+import os
+import subprocess
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+STUB = "%s %s" % (sys.executable, os.path.join(ROOT, "tests", "helpers", "stub_rank.py"))
+
+
+def _bench(args, **env):
+    e = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "RAFTX_COMM_TOKEN")}
+    e.update(env)
+    return subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, env=e, capture_output=True, text=True, timeout=120)
+
+
+def test_gpus_n_starts_n_ranks_without_a_launcher():
+    r = _bench(["--gpus", "3", "--steps", "2"], RAFTX_BENCH_RANK_CMD=STUB)
+    assert r.returncode == 0, r.stderr
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, r.stdout                       # rank 0 alone owns stdout
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 3 and out["sum"] == 6.0 and out["argv"] == ["--gpus", "3", "--steps", "2"]
+
+
+def test_a_failing_rank_stops_the_job_with_its_exit_code():
+    t0 = time.time()
+    r = _bench(["--gpus", "2"], RAFTX_BENCH_RANK_CMD=STUB, STUB_MODE="fail")
+    assert r.returncode == 3 and "rank 1 exited with code 3" in r.stderr
+    assert time.time() - t0 < 30                           # rank 0 (sleeping) was terminated, not waited for
+
+
+def test_gpus_must_match_the_world_an_external_launcher_made():
+    r = _bench(["--gpus", "8"], WORLD_SIZE="2", RANK="0", LOCAL_RANK="0")
+    assert r.returncode == 2 and "--gpus 8 but WORLD_SIZE=2" in r.stderr
+    r = _bench(["--gpus", "1"], WORLD_SIZE="2", RANK="0", LOCAL_RANK="0")
+    assert r.returncode == 2
+
+
+def test_more_gpus_than_the_host_has_fails_loudly():
+    r = _bench(["--gpus", "2"])                            # this container has no GPU at all
+    assert r.returncode == 2 and "GPU(s) visible" in r.stderr

@@ -387,15 +387,56 @@ def check_staged_crossings(ctx):
         assert np.array_equal(g_["strip_off"], w_["strip_off"])
 
 
+def check_staged_crossings_with_changing_sea_states(ctx):
+    """A batch is solved with the sea states it was PREPARED with: three batches in flight, each with its own sea states
+    (other amplitudes, headings, number of cases), prepared before the batch ahead of them is launched -- every batch
+    equals its blocking call.  A prepared batch can be cancelled (its outputs untouched) and its slot used again."""
+    from raft_amd._abi import RaftxError
+    z0, b0 = np.asarray(C3["zeta"]), np.asarray(C3["beta"])
+    seas = [(z0[None], b0[None]),
+            (np.stack([0.5 * z0, 1.5 * z0]), np.stack([b0 + 0.3, b0 - 0.7])),
+            (0.8 * z0[None], b0[None] + 1.1),
+            (z0[None], b0[None])]
+    fixed = lambda z, b: (C3["w"], C3["k"], float(C3["depth"]), z, b, int(C3["nIter"]), 0.01, float(C3["XiStart"]))
+    batches = [_c3_crossing_inputs(n) for n in (19, 33, 8, 27)]
+    want = [ctx.sweep_stats(*bt, *fixed(*sea), want_Xi=True) for bt, sea in zip(batches, seas)]
+    sub = lambda i: ctx.sweep_prepare(i % 3, *batches[i], *fixed(*seas[i]), want_Xi=True)
+    hs = {0: sub(0), 1: sub(1)}
+    ctx.sweep_launch(hs[0])
+    got = []
+    for i in range(4):
+        if i + 2 < 4:
+            hs[i + 2] = sub(i + 2)
+        if i + 1 < 4:
+            ctx.sweep_launch(hs[i + 1])
+        got.append(ctx.sweep_wait(hs.pop(i)))
+    for g_, w_ in zip(got, want):
+        for key in ("Xi", "std"):
+            assert g_[key].shape == w_[key].shape and np.array_equal(g_[key].view(np.uint64), w_[key].view(np.uint64)), key
+        assert np.array_equal(g_["niter"], w_["niter"]) and np.array_equal(g_["flags"], w_["flags"])
+    # cancel: slot 1 prepared with yet other sea states, never launched
+    h = ctx.sweep_prepare(1, *batches[1], *fixed(0.3 * z0[None], b0[None] + 2.0), want_Xi=True)
+    h["out"]["std"][...] = -7.0
+    ctx.sweep_cancel(h)
+    assert np.all(h["out"]["std"] == -7.0)
+    with pytest.raises(RaftxError, match="nothing prepared"):
+        ctx.sweep_launch(h)
+    again = ctx.sweep_wait(ctx.sweep_submit(1, *batches[1], *fixed(*seas[1]), want_Xi=True))
+    assert np.array_equal(again["Xi"].view(np.uint64), want[1]["Xi"].view(np.uint64))
+    ctx.sweep_cancel(dict(slot=2))                        # idle slot: no-op
+
+
 def test_oracle_streamed_crossings(oracle_ctx):
     check_streamed_crossings(oracle_ctx)
     check_staged_crossings(oracle_ctx)
+    check_staged_crossings_with_changing_sea_states(oracle_ctx)
 
 
 @pytest.mark.gpu
 def test_hip_streamed_crossings(hip_ctx):
     check_streamed_crossings(hip_ctx)
     check_staged_crossings(hip_ctx)
+    check_staged_crossings_with_changing_sea_states(hip_ctx)
     check_crossing(hip_ctx, 20, 0, 0)                     # the blocking call still works on the same context afterwards
 
 
