@@ -297,6 +297,18 @@ def featured_legs(ctx, n_design, base_sw, base_ms, base_pair_iters):
     return legs
 
 
+def emit(out):
+    """The ONE JSON line, as the LAST line of stdout: whatever native libraries left in C's stdio buffer (RCCL prints a
+    version banner at communicator creation, which a pipe keeps buffered until exit) goes out first."""
+    import ctypes
+    try:
+        ctypes.CDLL(None).fflush(None)
+    except OSError:
+        pass
+    sys.stdout.write(json.dumps(out) + "\n")
+    sys.stdout.flush()
+
+
 def launch_ranks(n, argv):
     """`python bench.py --gpus N` without a launcher: start the N ranks (one process per GPU) and wait for them.  Rank r gets
     RANK = LOCAL_RANK = r, WORLD_SIZE = N, a loopback rendezvous on two free ports and a random job token; rank 0 inherits
@@ -389,11 +401,11 @@ def main_sharded_leg(args, world, rank, local, rehearsal):
                                                 "k_qtf_pairs (+ k_qtf_tables), slowest rank"),
                    "per_rank_ms": {"qtf_kernels": [float(x) for x in allt[:, 0]], "wall": [float(x) for x in allt[:, 1]]},
                    "hermitian": herm}
-    if rank == 0:
-        print(json.dumps(out))
     if comm is not None:
         comm.close()
     ctx.close()
+    if rank == 0:
+        emit(out)
 
 
 def main():
@@ -414,7 +426,8 @@ def main():
     ap.add_argument("--no-stream", action="store_true", help="time isolated blocking calls (raftx_sweep_stats) instead of streaming the "
                                                              "steps through the library's three slots (raftx_sweep_prepare / _launch / _wait)")
     ap.add_argument("--no-cpu-baseline", action="store_true", help="skip the oracle leg (cpu_baseline and the all-design check)")
-    ap.add_argument("--depth", type=int, default=2, help="batches in flight when the steps are streamed: 2 = submit(i+1), wait(i) (default); "
+    ap.add_argument("--depth", type=int, default=0, help="batches in flight when the steps are streamed: 2 = submit(i+1), wait(i) (default); 4 = prepare(i+3), launch(i+2), wait(i) "
+                                                      "(default with --xi-out: the download of a batch takes longer than its kernels); "
                                                       "3 = prepare(i+2), launch(i+1), wait(i): the next batch's tables are generated in the drain "
                                                       "of the running fused kernel -- measured on one box over 300 steps: 3.73 against 3.71 ms per step "
                                                       "(the gap between fused kernels shrinks 0.35 -> 0.2 ms, the kernels sharing the drain slow each "
@@ -425,6 +438,8 @@ def main():
     args = ap.parse_args()
     if args.profile:
         args.chunks, args.no_extra_legs, args.no_cpu_baseline = 1, True, True
+    if args.depth == 0:                                   # default: two batches in flight; three (staged) when the responses are downloaded
+        args.depth = 4 if args.xi_out else 2
 
     if args.gpus < 1:
         ap.error("--gpus must be >= 1")
@@ -470,7 +485,7 @@ def main():
         comm, gather_kind = rcomm.from_env(ctx_comm, prefer="rccl", fallback="host" if rehearsal else "error")
 
     stream_steps = not args.no_stream
-    Xi_pinned = [ctx.pinned_empty((nD, 1, 1, 6, nw)) for _ in range(3 if stream_steps else 1)] if args.xi_out else [None, None, None]
+    Xi_pinned = [ctx.pinned_empty((nD, 1, 1, 6, nw)) for _ in range(4 if stream_steps else 1)] if args.xi_out else [None, None, None, None]
 
     gather_s = []                                         # host time of every gather (this rank's share of the exchange step)
     solo = {"on": False}                                  # rank 0's single-rank leg runs the same steps without the exchange
@@ -500,15 +515,16 @@ def main():
                 out.append(gather(sw.wait_crossing(ctx, h)))
                 h = h_next
             return out
-        sub = lambda i: sw.prepare_crossing(ctx, i % 3, n_chunk=args.chunks, Xi_out=Xi_pinned[i % 3])
-        hs = {i: sub(i) for i in range(min(n, 2))}        # batches 0 and 1 uploading, their member passes queued
-        if n > 0:
-            sw.launch_crossing(ctx, hs[0])
-        for i in range(n):                                # batch i solving | i+1 generated in its drain | i+2 uploading
-            if i + 2 < n:
-                hs[i + 2] = sub(i + 2)
-            if i + 1 < n:
-                sw.launch_crossing(ctx, hs[i + 1])
+        d = args.depth                                    # staged: prepare(i+d-1), launch(i+d-2), wait(i)
+        sub = lambda i: sw.prepare_crossing(ctx, i % d, n_chunk=args.chunks, Xi_out=Xi_pinned[i % d])
+        hs = {i: sub(i) for i in range(min(n, d - 1))}
+        for i in range(min(n, d - 2)):
+            sw.launch_crossing(ctx, hs[i])
+        for i in range(n):
+            if i + d - 1 < n:
+                hs[i + d - 1] = sub(i + d - 1)
+            if i + d - 2 < n:
+                sw.launch_crossing(ctx, hs[i + d - 2])
             out.append(gather(sw.wait_crossing(ctx, hs.pop(i))))
             if os.environ.get("RAFTX_BENCH_DEBUG"):
                 print("  step %d collected at %.3f ms" % (i, 1e3 * time.perf_counter()), file=sys.stderr)
@@ -524,7 +540,7 @@ def main():
         # untimed priming, before the W warm-up steps: the first crossing of a stream is cut into two blocks, the following
         # ones are single blocks, and each slot's block contexts allocate their device buffers the first time they meet a
         # configuration -- three streamed steps bring both slots to the steady-state one (seven the three of --depth 3)
-        run_steps(3 if args.depth == 2 else 7)
+        run_steps(3 if args.depth == 2 else 2 * args.depth + 1)
     run_steps(args.warmup)
     # N > 1: the single-rank yardstick of THIS invocation -- rank 0 alone runs the same K steps (no exchange step) while the
     # other ranks wait at the barrier, so that the N-rank value can be set against N x one rank on the same box and build
@@ -617,15 +633,25 @@ def main():
     # ---- legs outside the headline (N = 1): SURVEY 8d's literal step (responses downloaded), featured sweeps
     xi_leg = featured = None
     if rank == 0 and world == 1 and not args.no_extra_legs and not args.xi_out:
-        Xp = [ctx.pinned_empty((nD, 1, 1, 6, nw)) for _ in range(3)]
+        Xp = [ctx.pinned_empty((nD, 1, 1, 6, nw)) for _ in range(4)]
 
         def xi_steps(n):
-            h = sw.submit_crossing(ctx, 0, n_chunk=args.chunks, Xi_out=Xp[0])
+            # four batches in flight, staged: batch i downloads (3.4-3.6 ms of PCIe: longer than a batch's kernels), batch
+            # i+1 solves, batch i+2 is queued behind it, batch i+3 uploads its descriptors and runs its member pass.
+            # prepare() never waits; launch(i+2) waits for a member pass that ran a step earlier; wait(i) for the download.
+            # (With three in flight -- prepare(i+2) only after wait(i) -- the chain download -> upload -> member pass ->
+            # fused kernel was serial: 5.0-5.1 ms per step, profiles/r04_xi_timeline.txt.)
+            sub = lambda i: sw.prepare_crossing(ctx, i % 4, n_chunk=args.chunks, Xi_out=Xp[i % 4])
+            hs = {i: sub(i) for i in range(min(n, 3))}
+            for i in range(min(n, 2)):
+                sw.launch_crossing(ctx, hs[i])
             for i in range(n):
-                hn = sw.submit_crossing(ctx, (i + 1) % 3, n_chunk=args.chunks, Xi_out=Xp[(i + 1) % 3]) if i + 1 < n else None
-                sw.wait_crossing(ctx, h)
-                h = hn
-        xi_steps(7)                                       # untimed: every one of the three slots reaches its steady-state configuration
+                if i + 3 < n:
+                    hs[i + 3] = sub(i + 3)
+                if i + 2 < n:
+                    sw.launch_crossing(ctx, hs[i + 2])
+                sw.wait_crossing(ctx, hs.pop(i))
+        xi_steps(9)                                       # untimed: every one of the four slots reaches its steady-state configuration
         ctx.synchronize()
         t1 = time.perf_counter()
         xi_steps(args.steps)
@@ -744,12 +770,12 @@ def main():
                                                   "where": "BUILD CONTAINER (8 cores), second-hand here: the reference tree does not travel to the GPU box"}
     if cpu is not None:
         out["cpu_baseline"] = cpu
-    if rank == 0:
-        print(json.dumps(out))
     if comm is not None:
         comm.close()
     if ctx_comm is not None:
         ctx_comm.close()
+    if rank == 0:
+        emit(out)
 
 
 if __name__ == "__main__":

@@ -402,7 +402,7 @@ int raftx_sweep_stats(raftx_ctx *ctx, int nDesign, const int64_t *memberOff, con
                       double *timing_ms);
 
 /* The same crossing in stages, for back-to-back batches of a long sweep (a 10^6-candidate sweep is a stream of 10^4-design
- * batches), on slots 0 .. 2:
+ * batches), on slots 0 .. RAFTX_SWEEP_SLOTS - 1:
  *   raftx_sweep_prepare  enqueues the descriptor upload and the member pass of a batch (returns at once; arguments as
  *                        raftx_sweep_stats, all arrays must stay alive and untouched until the batch has been waited for);
  *   raftx_sweep_launch   enqueues table generation, the fused fixed point and the statistics of a prepared batch (the host
@@ -412,8 +412,12 @@ int raftx_sweep_stats(raftx_ctx *ctx, int nDesign, const int64_t *memberOff, con
  *                        (timing_ms as raftx_sweep_stats, [0] = host time from prepare to the end of wait).
  * raftx_sweep_submit = prepare + launch.  With launch(i+1), prepare(i+2), wait(i) per step, three batches are in flight:
  * batch i solving; batch i+1 with its member pass done a step earlier, so that its tables are generated in the drain of
- * batch i's fused kernel and its own fused kernel follows without a gap; batch i+2 uploading.
+ * batch i's fused kernel and its own fused kernel follows without a gap; batch i+2 uploading.  When the
+ * responses are downloaded (192 MB per 10 k-design batch: 3.5 ms of PCIe, longer than the batch's kernels) a fourth slot
+ * keeps the download off the critical path: prepare(i+3), launch(i+2), wait(i) -- batch i downloading, i+1 solving, i+2
+ * queued behind it, i+3 uploading.
  * raftx_sweep_stats is submit + wait on a free slot.  Results are bit-identical whatever the staging. */
+#define RAFTX_SWEEP_SLOTS 4
 int raftx_sweep_prepare(raftx_ctx *ctx, int slot, int nDesign, const int64_t *memberOff, const double *members,
                         const int64_t *stationOff, const double *stations, const int64_t *capOff, const double *caps,
                         const double *pose, double rho, double g, int add_mask,

@@ -362,7 +362,7 @@ class Context:
     def sweep_prepare(self, slot, tables, M0, B0, C0, w, k, depth, zeta, beta, nIter, tol=0.01, XiStart=0.1, pose=None,
                       rho=1025.0, g=9.81, rho_wave=1025.0, g_wave=9.81, add_mask=7, Fz_moor=None, n_chunk=0, want_Xi=False,
                       Xi_out=None):
-        """First stage of a sweep crossing on ``slot`` (0 .. 2): descriptor upload + member pass are enqueued
+        """First stage of a sweep crossing on ``slot`` (0 .. 3): descriptor upload + member pass are enqueued
         (raftx_sweep_prepare); returns a handle for ``sweep_launch`` / ``sweep_wait``.  The handle keeps the input and
         output arrays alive; do not modify the inputs before ``sweep_wait``."""
         self.resident_generation += 1

@@ -669,7 +669,7 @@ __global__ void __launch_bounds__(256) k_channel_stats_poly(int nCase, int nHead
 }
 
 // ------------------------------------------------------------------ host side
-#define RAFTX_NSLOT 3          // crossings in flight per context: one solving, one generated / generating, one uploading
+#define RAFTX_NSLOT RAFTX_SWEEP_SLOTS   // crossings in flight per context: one downloading its responses, one solving, one generated / queued, one uploading
 // Per-context device-memory pool: every call of the C-ABI needs a handful of device buffers (tables, results, scratch);
 // hipMalloc / hipFree cost 0.1-1 ms each and hipFree synchronises the whole device, which serialises contexts that
 // otherwise overlap copies and kernels on their own streams.  Blocks are rounded up (powers of two below 1 MiB, 1 MiB
@@ -763,7 +763,7 @@ struct raftx_ctx {
     double *pinRes;                      // page-locked landing area of a block's statistics (sweep crossing)
     size_t pinRes_n;
     hipStream_t sCopy, sPrep, sD2H, sGen; // internal streams of raftx_sweep_stats (created on first use)
-    hipStream_t sD2Hlow = nullptr;        // bulk download of the responses: a LOW-priority stream, created when first needed
+    hipStream_t sD2Hlow = nullptr;        // bulk download of the responses: a stream of its own priority class, created when first needed
     CaseSet csets[RAFTX_NSLOT + 1];      // sea-state tables of the sweep crossings: one per crossing in flight + one being replaced
     unsigned long long cset_clock = 0;
     char err[512];
@@ -2290,6 +2290,8 @@ static int qtf_slender_impl(raftx_ctx *c, int nSet, int nw2, const double *w2, c
     cplx *dXi = sc.alloc<cplx>((size_t)nSet * 6 * nw2), *dK = kay ? sc.alloc<cplx>(nq) : (use_resident_kay ? c->rKay : nullptr);
     cplx *dT = sc.alloc<cplx>(nStrip * QT_N * nw2), *dTM = sc.alloc<cplx>(nMem * QTM_N * nw2),
          *dTS = sc.alloc<cplx>((size_t)nSet * QTS_N * nw2);
+    double *dD = sc.alloc<double>(nStrip * QD_N);
+    cplx *dTA = sc.alloc<cplx>(nStrip * QT_N * nw2);
     if (c->rQtf_n < nq || !c->rQtf) {                    // the result stays resident (raftx_qtf_force can reuse it)
         HIPCHK(c, hipStreamSynchronize(c->stream));
         if (c->rQtf) (void)hipFree(c->rQtf);
@@ -2302,7 +2304,7 @@ static int qtf_slender_impl(raftx_ctx *c, int nSet, int nw2, const double *w2, c
     c->rQtf_sets = nSet;
     c->rQtf_nw2 = nw2;
     cplx *dQ = c->rQtf;
-    if (nSet && (!dw || !dk || (nStrip && (!dS || !dss || !dT)) || (nMem && (!dM || !dms || !dTM)) || !dB || !dMs || !dso ||
+    if (nSet && (!dw || !dk || (nStrip && (!dS || !dss || !dT || !dD || !dTA)) || (nMem && (!dM || !dms || !dTM)) || !dB || !dMs || !dso ||
                  !dmo || !dXi || (kay && !dK) || !dTS || !dQ))
         FAIL(c, "qtf_slender: device allocation failed");
     if (nSet) {
@@ -2320,7 +2322,7 @@ static int qtf_slender_impl(raftx_ctx *c, int nSet, int nw2, const double *w2, c
         if (kay) H2D(c, dK, kay, nq * sizeof(cplx));
     }
     A.w = dw; A.k = dk; A.soff = dso; A.strips = dS; A.moff = dmo; A.members = dM; A.sset = dss; A.mset = dms;
-    A.Xi = dXi; A.beta = dB; A.Ms = dMs; A.kay = dK; A.T = dT; A.TM = dTM; A.TS = dTS; A.qtf = dQ;
+    A.Xi = dXi; A.beta = dB; A.Ms = dMs; A.kay = dK; A.T = dT; A.TA = dTA; A.D = dD; A.TM = dTM; A.TS = dTS; A.qtf = dQ;
     A.row_off = row_off;
     A.row_stride = row_stride;
     A.nrow = (nw2 - row_off + row_stride - 1) / row_stride;           // rows w1 = row_off + m*row_stride of this call
@@ -2333,8 +2335,12 @@ static int qtf_slender_impl(raftx_ctx *c, int nSet, int nw2, const double *w2, c
     if (nSet) {
         hipLaunchKernelGGL(k_qtf_tables, dim3((unsigned)(nStrip + nMem + nSet)), dim3(nw2 > 128 ? 256 : 128), 0, c->stream, A,
                            (int)nStrip, (int)nMem);
-        if (A.nrow)
-            hipLaunchKernelGGL(k_qtf_pairs, dim3((unsigned)((size_t)nSet * A.nrow)), dim3(nw2 > 64 ? 128 : 64), 0, c->stream, A);
+        if (A.nrow) {
+            static const int blk_env = getenv("RAFTX_QTF_BLOCK") ? atoi(getenv("RAFTX_QTF_BLOCK")) : 0;      // tuning: 64 | 128
+            const int blk = (blk_env == 64 || blk_env == 128) ? blk_env : (nw2 > 64 ? 128 : 64);
+            const size_t per_xcd = ((size_t)nSet * A.nrow + 7) / 8;                 // see k_qtf_pairs: a slab of the (set, row) list per XCD
+            hipLaunchKernelGGL(k_qtf_pairs, dim3((unsigned)(per_xcd * 8)), dim3(blk), 0, c->stream, A);
+        }
     }
     if (finish_timed(c)) return -2;
     if (nSet && qtf) D2H(c, qtf, dQ, nq * sizeof(cplx));
@@ -2428,7 +2434,23 @@ static int block_ctx(raftx_ctx *c, int slot, size_t i, raftx_ctx **out) {
 // has a crossing in flight (streamed batches: that crossing's kernels hide this one's upload), otherwise a small first block
 // whose kernels hide the descriptor upload of the rest (every further block costs a partial last residency round of the
 // fused kernel plus the fixed latencies of the generation kernels: two blocks measured best)
-static std::vector<int> sweep_bounds(int nDesign, long pairs, int nChunk, bool pipelined) {
+static std::vector<int> sweep_bounds(int nDesign, long pairs, int nChunk, bool pipelined, bool with_xi = false, int nCase = 1) {
+    // The responses are wanted and nothing else is in flight to hide their download behind: slabs of whole residency rounds
+    // (2 048 pairs = two rounds of 256 CUs x 4 resident pairs of the 200-bin shape), each slab's download running under the
+    // next slab's kernels -- at most RAFTX_XI_SLABS (default 6) of them, every slab but the last a multiple of 2 048 pairs.
+    if (with_xi && !pipelined && nChunk <= 0 && !getenv("RAFTX_SWEEP_SPLIT") && pairs >= 4096) {
+        static const int max_slabs = getenv("RAFTX_XI_SLABS") ? atoi(getenv("RAFTX_XI_SLABS")) : 6;
+        if (max_slabs > 1) {
+            const long round_pairs = 2048;
+            long per = round_pairs;
+            while ((pairs + per - 1) / per > max_slabs) per += round_pairs;
+            const int dper = (int)std::max<long>(1, per / std::max(nCase, 1));
+            std::vector<int> b{0};
+            while (b.back() + dper < nDesign) b.push_back(b.back() + dper);
+            b.push_back(nDesign);
+            return b;
+        }
+    }
     std::vector<double> fr;
     static const char *env = getenv("RAFTX_SWEEP_SPLIT");
     if (env && nChunk <= 0) {
@@ -2546,7 +2568,7 @@ extern "C" int raftx_sweep_prepare(raftx_ctx *c, int slot, int nDesign, const in
         S.cset = hit;
     }
     const DevTables &CT = c->csets[S.cset].T;
-    S.bnd = sweep_bounds(nDesign, (long)nDesign * nCase, nChunk, others_in_flight(c, slot));
+    S.bnd = sweep_bounds(nDesign, (long)nDesign * nCase, nChunk, others_in_flight(c, slot), Xi != nullptr, nCase);
     const std::vector<int> &bnd = S.bnd;
     const size_t nB = bnd.size() - 1;
     S.dw = nw > 1 ? w[1] - w[0] : w[0];
@@ -2706,19 +2728,26 @@ extern "C" int raftx_sweep_launch(raftx_ctx *c, int slot) {
     }
     // ---- full responses, if asked for: block by block behind the block's kernels, on their own stream
     if (!rc_all && Xi) {
-        // The bulk download goes to a LOW-priority stream, created when first needed: priority classes have hardware
-        // queues of their own, whereas the ordinary streams of this library share four, and a hardware queue is in order --
-        // the generation and the fused kernel of batch i+1 used to queue behind the 3.4 ms copy of batch i whenever the
-        // two streams landed on one queue (streamed steps with the responses downloaded: 7.0 ms per step instead of
-        // 4.6-5.0).  Created late, it does not move the other streams' queues (the plain step is sensitive to those:
-        // +5 % with the generation stream one queue further).  RAFTX_D2H_PRIORITY=0: the ordinary download stream.
-        static const bool d2h_low = !(getenv("RAFTX_D2H_PRIORITY") && !atoi(getenv("RAFTX_D2H_PRIORITY")));
-        if (d2h_low && !c->sD2Hlow) {
+        // The bulk download goes to a stream of its own PRIORITY CLASS, created when first needed: priority classes have
+        // hardware queues of their own, whereas the ordinary streams of this library share four, and a hardware queue is in
+        // order -- the generation and the fused kernel of batch i+1 used to queue behind the 3.4 ms copy of batch i whenever
+        // the two streams landed on one queue (round 3: 7.0 ms per step instead of 4.6-5.0).  Created late, it does not move the
+        // other streams' queues (the plain step is sensitive to those: +5 % with the generation stream one queue further).
+        // Which class: round 3 took the LOWEST, and the copy / kernel timeline of round 4 (profiles/r04_xi_timeline.txt)
+        // shows what that costs -- the command processor does not look at a low-priority queue while a 10 000-workgroup grid
+        // of the ordinary class is being handed out, so the download of batch i only STARTED 0.26 ms before the end of batch
+        // i+1's fused kernel, a whole step late, and then ran beside nothing.  The HIGHEST class is served at once: the copy
+        // is a barrier packet and an SDMA transfer, no compute, and starts when the batch's statistics kernel has finished.
+        // RAFTX_D2H_PRIORITY = high (default) | low | 0 (the ordinary download stream).
+        static const char *d2h_env = getenv("RAFTX_D2H_PRIORITY");
+        static const bool d2h_own = !(d2h_env && !strcmp(d2h_env, "0"));
+        static const bool d2h_low = d2h_own && d2h_env && !strcmp(d2h_env, "low");
+        if (d2h_own && !c->sD2Hlow) {
             int least = 0, greatest = 0;
             if (hipDeviceGetStreamPriorityRange(&least, &greatest) == hipSuccess && least != greatest)
-                (void)hipStreamCreateWithPriority(&c->sD2Hlow, hipStreamNonBlocking, least);
+                (void)hipStreamCreateWithPriority(&c->sD2Hlow, hipStreamNonBlocking, d2h_low ? least : greatest);
         }
-        hipStream_t sDown = (d2h_low && c->sD2Hlow) ? c->sD2Hlow : c->sD2H;
+        hipStream_t sDown = (d2h_own && c->sD2Hlow) ? c->sD2Hlow : c->sD2H;
         for (size_t b = 0; b < nB; b++) {
             raftx_ctx *sub = blk[b];
             const size_t p0 = (size_t)bnd[b] * nCase;

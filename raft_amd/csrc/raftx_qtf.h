@@ -17,20 +17,36 @@
 
 #define QS_N 24        // doubles per QTF strip record (raft_amd/qtf.py)
 #define QM_N 16        // doubles per QTF member record
-#define QT_N 24        // complex table entries per (strip, frequency)
+#define QT_N 26        // complex table entries per (strip, frequency)
 #define QTM_N 12       // complex table entries per (member, frequency)
 #define QTS_N 12       // complex table entries per (set, frequency)
+#define QD_N 32        // real per-strip constants derived by the table kernel
 
-// strip table fields
+// Strip table fields.  Every vector / matrix is stored in the STRIP'S OWN FRAME E = [p1 p2 q] (v' = E^T v,
+// M' = E^T M E): the projections of the Rainey terms are then component selections -- P_Ca v = (Ca1 v_1, Ca2 v_2, 0),
+// "remove the axial part" = drop component 3, q . v = v_3 -- and the pair kernel is left with the bilinear products
+// alone (tests/qtf_device_model.py is the numpy statement of the formulation, checked against the term-by-term
+// restatement of the reference in oracle/qtf_oracle.py).
 #define QT_U 0         // u[3]
-#define QT_G 3         // grad_u distinct entries: g00 g01 g02 g11 g12 g22
-#define QT_DR 9        // dr[3]
-#define QT_VT 12       // u - nodeV_t [3]  (nodeV_t = node velocity with its axial part removed)
-#define QT_GP 15       // grad_pres1st[3]
-#define QT_NAR 18      // nodeV_axial_rel
-#define QT_DWDZ 19     // q . grad_u q
-#define QT_E2 20       // exp(-i k (cos(deg2rad b) x + sin(deg2rad b) y)): phase of the 2nd-order potential
-#define QT_UT 21       // (u - (q.u) q) - nodeV_t  [3]: the transverse relative velocity of axdivAcc
+#define QT_DR 3        // dr[3]
+#define QT_X 6         // (u - nodeV_t)[1..2]  (nodeV_t = node velocity with its axial part removed; component 3 of the
+                       // difference never enters: every use is behind a transverse projection.  The transverse relative
+                       // velocity of axdivAcc, (u - (q.u) q) - nodeV_t, has the same two components and a zero third)
+#define QT_GP 8        // grad_pres1st[3]
+#define QT_NAR 11      // nodeV_axial_rel
+#define QT_DWDZ 12     // q . grad_u q
+#define QT_E2 13       // exp(-i k (cos(deg2rad b) x + sin(deg2rad b) y)): phase of the 2nd-order potential
+#define QT_G 14        // E^T grad_u E, row-major 3 x 3 (grad_u with the reference's twisted third row, helpers.py:274)
+#define QT_S 23        // E^T [i w theta]x E: entries 01, 02, 12 of the antisymmetric matrix
+// per-strip constants (k_qtf_tables, thread of frequency 0)
+#define QD_CA 0        // Ca_p1, Ca_p2
+#define QD_RV 2        // rho * v_side
+#define QD_RE 3        // rho * v_end * Ca_End
+#define QD_AI 4        // a_i
+#define QD_Z 5
+#define QD_HX 6        // cos(deg2rad b) E[0][i] + sin(deg2rad b) E[1][i], i = 0..2: horizontal direction of the 2nd-order potential
+#define QD_HZ 9        // E[2][i]
+#define QD_W 12        // [3][6]: [e_i ; r x e_i], the strip-frame force components as 6-DOF loads about the origin
 // member table fields
 #define QTM_UD 0       // ud_wl[3]
 #define QTM_ETAR 3     // eta_r
@@ -92,7 +108,10 @@ struct QtfArgs {
     const double *__restrict__ beta;       // [nSet]
     const double *__restrict__ Ms;         // [nSet,36]
     const cplx *__restrict__ kay;          // [nSet,nw,nw,6] or null
-    cplx *T;                               // [nStrip,QT_N,nw]
+    cplx *T;                               // [nStrip,QT_N,nw]   field-major: the w2 column of a field is one coalesced load
+    cplx *TA;                              // [nStrip,nw,QT_N]   the same values frequency-major: the w1 row of a strip is 416
+                                           //                    contiguous bytes for the scalar loads of the pair kernel
+    double *D;                             // [nStrip,QD_N]
     cplx *TM;                              // [nMem,QTM_N,nw]
     cplx *TS;                              // [nSet,QTS_N,nw]
     cplx *qtf;                             // [nSet,nw,nw,6]
@@ -194,19 +213,48 @@ __global__ void __launch_bounds__(256) k_qtf_tables(QtfArgs A, int nStrip, int n
             }
             const cplx nar = rdot(q, c3sub(u, nodeV));
             const c3 nodeVt = c3sub(nodeV, rvec(q, rdot(q, nodeV)));
-            const c3 ut = c3sub(u, rvec(q, rdot(q, u)));
             const cplx dwdz = rdot(q, gmul(G, c3{{q[0], 0}, {q[1], 0}, {q[2], 0}}));
+            const c3 ua = c3sub(u, nodeVt);
+            // into the strip's frame
+            const double *e[3] = {rec + 6, rec + 9, q};                       // p1, p2, q
             cplx *T = A.T + (size_t)b * QT_N * nw;
-            store3(T, QT_U, nw, i, u);
-            T[(size_t)(QT_G + 0) * nw + i] = G.g00; T[(size_t)(QT_G + 1) * nw + i] = G.g01; T[(size_t)(QT_G + 2) * nw + i] = G.g02;
-            T[(size_t)(QT_G + 3) * nw + i] = G.g11; T[(size_t)(QT_G + 4) * nw + i] = G.g12; T[(size_t)(QT_G + 5) * nw + i] = G.g22;
-            store3(T, QT_DR, nw, i, dr);
-            store3(T, QT_VT, nw, i, c3sub(u, nodeVt));
-            store3(T, QT_GP, nw, i, gp);
-            T[(size_t)QT_NAR * nw + i] = nar;
-            T[(size_t)QT_DWDZ * nw + i] = dwdz;
-            T[(size_t)QT_E2 * nw + i] = e2;
-            store3(T, QT_UT, nw, i, c3sub(ut, nodeVt));
+            cplx *TA = A.TA + ((size_t)b * nw + i) * QT_N;
+            auto put = [&](int f, cplx v) {
+                T[(size_t)f * nw + i] = v;
+                TA[f] = v;
+            };
+            const c3 Om = c3cmul(th, cplx{0.0, w});                           // i w theta: OMEGA v = Om x v (:1588-1589)
+            for (int a = 0; a < 3; a++) {
+                put(QT_U + a, rdot(e[a], u));
+                put(QT_DR + a, rdot(e[a], dr));
+                put(QT_GP + a, rdot(e[a], gp));
+                if (a < 2) put(QT_X + a, rdot(e[a], ua));
+                for (int c = 0; c < 3; c++) {
+                    const c3 ec = {{e[c][0], 0}, {e[c][1], 0}, {e[c][2], 0}};
+                    put(QT_G + 3 * a + c, rdot(e[a], gmul(G, ec)));
+                    if (c > a) put(QT_S + (a == 0 ? c - 1 : 2), rdot(e[a], ccross(Om, ec)));
+                }
+            }
+            put(QT_NAR, nar);
+            put(QT_DWDZ, dwdz);
+            put(QT_E2, e2);
+            if (i == 0) {
+                double *D = A.D + (size_t)b * QD_N;
+                D[QD_CA] = rec[12]; D[QD_CA + 1] = rec[13];
+                D[QD_RV] = A.rho * rec[15];
+                D[QD_RE] = A.rho * rec[16] * rec[14];
+                D[QD_AI] = rec[17];
+                D[QD_Z] = r[2];
+                for (int a = 0; a < 3; a++) {
+                    D[QD_HX + a] = cB * e[a][0] + sB * e[a][1];
+                    D[QD_HZ + a] = e[a][2];
+                    double *W = D + QD_W + 6 * a;
+                    W[0] = e[a][0]; W[1] = e[a][1]; W[2] = e[a][2];
+                    W[3] = r[1] * e[a][2] - r[2] * e[a][1];
+                    W[4] = r[2] * e[a][0] - r[0] * e[a][2];
+                    W[5] = r[0] * e[a][1] - r[1] * e[a][0];
+                }
+            }
         } else if (b < nStrip + nMem) {
             const int m = b - nStrip;
             const double *rec = A.members + (size_t)m * QM_N;
@@ -253,18 +301,25 @@ __global__ void __launch_bounds__(256) k_qtf_tables(QtfArgs A, int nStrip, int n
 // ---- pair kernel: grid (nSet * nw) rows of w1; threads stride w2 >= w1
 __global__ void __launch_bounds__(128) k_qtf_pairs(QtfArgs A) {
     const int nw = A.nw;
-    const int set = blockIdx.x / A.nrow, i1 = A.row_off + (blockIdx.x % A.nrow) * A.row_stride;
+    // Workgroups are dealt round-robin to the 8 XCDs, each with its own 4 MiB L2; a set's table is 4.4 MB at C5.  Every XCD
+    // therefore gets a CONTIGUOUS slab of the (set, row) list -- whole sets when there are at least 8 of them -- instead of
+    // rows of every set: the w2 columns it streams then stay in its L2 (measured: the set-interleaved order ran at the
+    // fabric's bandwidth, not the VALU's).  Inside a set the rows alternate between the long and the short end of the
+    // triangle, so that any part of a slab carries the same work.
+    const int total = A.nSet * A.nrow, per = (total + 7) >> 3;
+    const int item = (int)(blockIdx.x & 7) * per + (int)(blockIdx.x >> 3);
+    if (item >= total || (int)(blockIdx.x >> 3) >= per) return;
+    const int set = item / A.nrow, m_ = item % A.nrow;
+    const int i1 = A.row_off + ((m_ & 1) ? A.nrow - 1 - (m_ >> 1) : (m_ >> 1)) * A.row_stride;
     const double h = A.depth, rho = A.rho, g = A.g;
     const double w1 = A.w[i1], k1 = A.k[i1];
     const double beta = A.beta[set];
     const double cB = cos(beta * (M_PI / 180.0)), sB = sin(beta * (M_PI / 180.0));
     const cplx *TS = A.TS + (size_t)set * QTS_N * nw;
     const c3 th1 = load3(TS, QTS_TH, nw, i1);
-    const c3 Om1 = c3cmul(th1, cplx{0.0, w1});                             // i w1 theta1: OMEGA1 v = Om1 x v
     for (int i2 = i1 + threadIdx.x; i2 < nw; i2 += blockDim.x) {
         const double w2 = A.w[i2], k2 = A.k[i2];
         const c3 th2 = load3(TS, QTS_TH, nw, i2);
-        const c3 Om2c = c3conj(c3cmul(th2, cplx{0.0, w2}));
         cplx F[6] = {{0, 0}, {0, 0}, {0, 0}, {0, 0}, {0, 0}, {0, 0}};
         // Pinkster IV (raft_fowt.py:2053-2062)
         {
@@ -289,78 +344,112 @@ __global__ void __launch_bounds__(128) k_qtf_pairs(QtfArgs A) {
             const double g21 = (-g / (2 * w2)) * ((k2 * k2) * (1 - t2 * t2) - 2 * k2 * k1 * (1 + t2 * t1)) / den;
             paux = {0.0, 0.5 * (g21 - g12)};                               // 0.5 (gamma_21 + conj(gamma_12))
         }
+        // ---- strip terms (raft_member.py:1541-1633) in each strip's own frame, see the field list above and
+        // tests/qtf_device_model.py.  The row frequency's fields (index 1) are wave-uniform: scalar loads, scalar operands.
+        double zprev = __builtin_nan(""), xdk = 0.0, znr = 0.0, xr = 0.0;     // depth-dependent factors of the 2nd-order potential
+        const double dwp = w1 - w2, dk = k1 - k2;
+        double rden = 0.0;
+        if (pot) rden = 1.0 / (1.0 + exp(-2.0 * (nrm * h)));
         for (int64_t s = A.soff[set]; s < A.soff[set + 1]; s++) {
-            const double *rec = A.strips + (size_t)s * QS_N;
-            const double r[3] = {rec[0], rec[1], rec[2]};
-            const double *q = rec + 3, *p1 = rec + 6, *p2 = rec + 9;
-            const double Ca1 = rec[12], Ca2 = rec[13], CaE = rec[14], v_i = rec[15], v_e = rec[16], a_i = rec[17];
-            const cplx *T = A.T + (size_t)s * QT_N * nw;
-            const c3 u1 = load3(T, QT_U, nw, i1), u2 = load3(T, QT_U, nw, i2);
-            const g6 G1 = {T[(size_t)(QT_G + 0) * nw + i1], T[(size_t)(QT_G + 1) * nw + i1], T[(size_t)(QT_G + 2) * nw + i1],
-                           T[(size_t)(QT_G + 3) * nw + i1], T[(size_t)(QT_G + 4) * nw + i1], T[(size_t)(QT_G + 5) * nw + i1]};
-            const g6 G2 = {T[(size_t)(QT_G + 0) * nw + i2], T[(size_t)(QT_G + 1) * nw + i2], T[(size_t)(QT_G + 2) * nw + i2],
-                           T[(size_t)(QT_G + 3) * nw + i2], T[(size_t)(QT_G + 4) * nw + i2], T[(size_t)(QT_G + 5) * nw + i2]};
-            const g6 G2c = gconj(G2);
-            const c3 dr1 = load3(T, QT_DR, nw, i1), dr2 = load3(T, QT_DR, nw, i2);
-            const c3 ua1 = load3(T, QT_VT, nw, i1), ua2 = load3(T, QT_VT, nw, i2);     // u - nodeV_t
-            const c3 gp1 = load3(T, QT_GP, nw, i1), gp2 = load3(T, QT_GP, nw, i2);
-            const cplx nar1 = T[(size_t)QT_NAR * nw + i1], nar2 = T[(size_t)QT_NAR * nw + i2];
-            const cplx dz1 = T[(size_t)QT_DWDZ * nw + i1], dz2 = T[(size_t)QT_DWDZ * nw + i2];
-            const c3 ut1 = load3(T, QT_UT, nw, i1), ut2 = load3(T, QT_UT, nw, i2);
-
-            // second-order potential: acceleration and pressure (helpers.py:360-372)
-            c3 acc2 = {{0, 0}, {0, 0}, {0, 0}};
-            cplx p2nd = {0, 0};
-            if (pot && r[2] <= 0) {
-                const double den = cosh(nrm * h);
-                const double xy = cosh(nrm * (r[2] + h)) / den, zz = sinh(nrm * (r[2] + h)) / den;
-                const cplx ph = cmul(T[(size_t)QT_E2 * nw + i1], cconj(T[(size_t)QT_E2 * nw + i2]));   // e^{-i (k1-k2)(cB x + sB y)}
-                const cplx base = cmul(paux, ph);
-                acc2.x = cscale(base, xy * (w1 - w2) * kx);
-                acc2.y = cscale(base, xy * (w1 - w2) * ky);
-                acc2.z = cmuli(cscale(base, zz * (w1 - w2) * nrm));
-                p2nd = cscale(cmuli(base), -xy * rho * (w1 - w2));
+            cdptr D = as_const(A.D + (size_t)s * QD_N);
+            const cplx *T2 = A.T + (size_t)s * QT_N * nw + i2;
+            cdptr T1 = as_const(reinterpret_cast<const double *>(A.TA + ((size_t)s * nw + i1) * QT_N));
+#define U1(f) (cplx{T1[2 * (f)], T1[2 * (f) + 1]})
+#define L2(f) (T2[(size_t)(f) * nw])
+            const double Ca0 = D[QD_CA], Ca1 = D[QD_CA + 1], rv = D[QD_RV], a_i = D[QD_AI], z = D[QD_Z];
+            // second-order potential: acceleration and pressure (helpers.py:360-372); cosh / sinh of nrm (z + h) over
+            // cosh(nrm h) in decaying exponentials, re-evaluated only when the depth changes (wave-uniform branch)
+            if (z != zprev) {
+                zprev = z;
+                xdk = znr = xr = 0.0;
+                if (pot && z <= 0) {
+                    const double P = exp(nrm * z), Q = exp(-(nrm * (z + 2.0 * h)));
+                    const double xy = (P + Q) * rden, zz = (P - Q) * rden;
+                    xdk = xy * dk;
+                    znr = zz * nrm;
+                    xr = xy * rho;
+                }
             }
-            // convective acceleration (:1575) and the body-motion-in-the-wave-field term (:1582)
-            const c3 conv = c3scale(c3add(gmul(G1, c3conj(u2)), gmul(G2c, u1)), 0.25);
-            const g6 Gd1 = gscale(G1, cplx{0.0, w1}), Gd2c = gconj(gscale(G2, cplx{0.0, w2}));
-            const c3 nab = c3scale(c3add(gmul(Gd1, c3conj(dr2)), gmul(Gd2c, dr1)), 0.25);
-            // axial-divergence acceleration (helpers.py:311-335)
-            c3 ax = c3scale(c3add(c3cmul(c3conj(ut2), dz1), c3cmul(ut1, cconj(dz2))), 0.25);
-            ax = c3sub(ax, rvec(q, rdot(q, ax)));
-            // Rainey body-rotation terms (:1587-1609)
-            const c3 qn2c = rvec(q, cconj(nar2)), qn1 = rvec(q, nar1);
-            const c3 rs = c3add(ccross(Om1, qn2c), ccross(Om2c, qn1));
-            c3 f_rslb = c3scale(proj2(p1, p2, Ca1, Ca2, rs), -0.5);
-            const c3 Pu1 = proj2(p1, p2, Ca1, Ca2, ua1), Pu2c = c3conj(proj2(p1, p2, Ca1, Ca2, ua2));
-            c3 aux = c3add(c3add(gmul(G1, Pu2c), ccross(Om1, Pu2c)), c3add(gmul(G2c, Pu1), ccross(Om2c, Pu1)));
-            aux = c3scale(aux, 0.25);
-            aux = c3sub(aux, rvec(q, rdot(q, aux)));
-            f_rslb = c3add(f_rslb, aux);
-            const c3 u1t = c3sub(ua1, rvec(q, rdot(q, ua1))), u2t = c3sub(ua2, rvec(q, rdot(q, ua2)));
-            const c3 u2tc = c3conj(u2t);
-            c3 aux2 = c3add(c3add(gmul(G1, u2tc), ccross(Om1, u2tc)), c3add(gmul(G2c, u1t), ccross(Om2c, u1t)));
-            aux2 = c3scale(proj2(p1, p2, Ca1, Ca2, aux2), 0.25);
-            f_rslb = c3sub(f_rslb, aux2);
-            // assemble the strip force
-            c3 f = c3scale(proj2(p1, p2, 1.0 + Ca1, 1.0 + Ca2, c3add(c3add(acc2, conv), nab)), rho * v_i);
-            f = c3add(f, c3scale(proj2(p1, p2, Ca1, Ca2, ax), rho * v_i));
-            f = c3add(f, c3scale(f_rslb, rho * v_i));
-            // end effects (:1611-1627)
-            const cplx qsum = rdot(q, c3add(c3add(acc2, conv), nab));
-            cplx qs = cscale(qsum, rho * v_e * CaE);
-            const cplx p_nab = cscale(cadd(cdot(gp1, c3conj(dr2)), cdot(c3conj(gp2), dr1)), 0.25);
-            const c3 pp1 = proj2(p1, p2, 1.0, 1.0, ua1);
-            const cplx p_drop = cscale(cdot(pp1, Pu2c), -0.25 * rho);
-            qs = cadd(qs, cscale(cadd(cadd(p2nd, p_nab), p_drop), a_i));
-            f = c3add(f, rvec(q, qs));
-            const c3 Pu1t = proj2(p1, p2, Ca1, Ca2, u1t), Pu2t = proj2(p1, p2, Ca1, Ca2, u2t);
-            f = c3add(f, c3scale(c3add(c3cmul(c3conj(Pu1t), nar2), c3cmul(Pu2t, cconj(nar1))), 0.25 * a_i * rho));
-            // translateForce3to6DOF about the global origin (helpers.py:468-483)
-            F[0] = cadd(F[0], f.x); F[1] = cadd(F[1], f.y); F[2] = cadd(F[2], f.z);
-            F[3] = cadd(F[3], csub(cscale(f.z, r[1]), cscale(f.y, r[2])));
-            F[4] = cadd(F[4], csub(cscale(f.x, r[2]), cscale(f.z, r[0])));
-            F[5] = cadd(F[5], csub(cscale(f.y, r[0]), cscale(f.x, r[1])));
+            cplx A3[3], p2nd;
+            {
+                const cplx e1 = U1(QT_E2), e2c = cconj(L2(QT_E2));
+                const cplx ph = cmul(e1, e2c);                                            // e^{-i (k1-k2)(cB x + sB y)}
+                const cplx bw = {-(paux.im * ph.im) * dwp, (paux.im * ph.re) * dwp};      // paux (purely imaginary) * ph * (w1 - w2)
+#pragma unroll
+                for (int a_ = 0; a_ < 3; a_++) {
+                    const double cr = xdk * D[QD_HX + a_], ci = znr * D[QD_HZ + a_];
+                    A3[a_] = {bw.re * cr - bw.im * ci, bw.re * ci + bw.im * cr};
+                }
+                p2nd = {bw.im * xr, -(bw.re * xr)};                                       // -i * base * xy * rho * (w1 - w2)
+            }
+            // convective acceleration (:1575) + body motion in the wave field (:1582) through one product per side:
+            // G1 conj(u2 - i w1 dr2) + conj(G2) (u1 - i w2 dr1)
+            {
+                cplx av[3], bv[3];
+#pragma unroll
+                for (int j = 0; j < 3; j++) {
+                    const cplx u2 = L2(QT_U + j), d2 = L2(QT_DR + j), u1 = U1(QT_U + j), d1 = U1(QT_DR + j);
+                    av[j] = {fma(w1, d2.im, u2.re), fma(w1, d2.re, -u2.im)};
+                    bv[j] = {fma(w2, d1.im, u1.re), fma(-w2, d1.re, u1.im)};
+                }
+#pragma unroll
+                for (int a_ = 0; a_ < 3; a_++) {
+                    cplx acc = {0, 0};
+#pragma unroll
+                    for (int j = 0; j < 3; j++) {
+                        acc = cfma(U1(QT_G + 3 * a_ + j), av[j], acc);
+                        acc = cfma(cconj(L2(QT_G + 3 * a_ + j)), bv[j], acc);
+                    }
+                    A3[a_] = {fma(0.25, acc.re, A3[a_].re), fma(0.25, acc.im, A3[a_].im)};
+                }
+            }
+            const cplx nar1 = U1(QT_NAR), nar2 = L2(QT_NAR), dz1 = U1(QT_DWDZ), dz2c = cconj(L2(QT_DWDZ));
+            const cplx x1[2] = {U1(QT_X), U1(QT_X + 1)}, x2[2] = {L2(QT_X), L2(QT_X + 1)};
+            const cplx s01_1 = U1(QT_S), s01_2 = L2(QT_S);
+            // off-diagonal entries of M = G + S (the Rainey terms aux - aux2 leave only (Ca_other - Ca_i) M_i,other x_other)
+            const cplx m1[2] = {cadd(U1(QT_G + 1), s01_1), csub(U1(QT_G + 3), s01_1)};                 // M1_01, M1_10
+            const cplx m2c[2] = {cconj(cadd(L2(QT_G + 1), s01_2)), cconj(csub(L2(QT_G + 3), s01_2))};  // conj(M2_01), conj(M2_10)
+            const double Ca[2] = {Ca0, Ca1};
+            cplx f[3];
+#pragma unroll
+            for (int a_ = 0; a_ < 2; a_++) {
+                const int o = 1 - a_;
+                const cplx x2c = cconj(x2[a_]), x2oc = cconj(x2[o]);
+                const cplx t = cfma(m1[a_], x2oc, cmul(m2c[a_], x1[o]));                              // M1_io conj(x2_o) + conj(M2_io) x1_o
+                const cplx ax0 = cfma(x2c, dz1, cmul(x1[a_], dz2c));                                  // axial-divergence (helpers.py:311-335)
+                const cplx rs = cfma(U1(QT_S + 1 + a_), cconj(nar2), cmul(cconj(L2(QT_S + 1 + a_)), nar1));   // Rainey rotation (:1587-1590)
+                const cplx en = cfma(cconj(x1[a_]), nar2, cmul(x2[a_], cconj(nar1)));                 // end term of :1626
+                const double c_t = 0.25 * (Ca[o] - Ca[a_]), c_ax = 0.25 * Ca[a_], c_rs = -0.5 * Ca[a_], c_A = 1.0 + Ca[a_];
+                cplx g = {c_A * A3[a_].re, c_A * A3[a_].im};
+                g = {fma(c_ax, ax0.re, g.re), fma(c_ax, ax0.im, g.im)};
+                g = {fma(c_rs, rs.re, g.re), fma(c_rs, rs.im, g.im)};
+                g = {fma(c_t, t.re, g.re), fma(c_t, t.im, g.im)};
+                const double c_en = 0.25 * a_i * rho * Ca[a_];
+                f[a_] = {fma(c_en, en.re, rv * g.re), fma(c_en, en.im, rv * g.im)};
+            }
+            {
+                // end effects (:1611-1627): axial component
+                cplx pn = {0, 0};
+#pragma unroll
+                for (int j = 0; j < 3; j++) {
+                    pn = cfma(U1(QT_GP + j), cconj(L2(QT_DR + j)), pn);
+                    pn = cfma(cconj(L2(QT_GP + j)), U1(QT_DR + j), pn);
+                }
+                cplx pd = cscale(cmul(x1[0], cconj(x2[0])), Ca0);
+                pd = cadd(pd, cscale(cmul(x1[1], cconj(x2[1])), Ca1));
+                const double re_ = D[QD_RE], c_pd = -0.25 * rho;
+                cplx qs = {p2nd.re + 0.25 * pn.re + c_pd * pd.re, p2nd.im + 0.25 * pn.im + c_pd * pd.im};
+                f[2] = {fma(re_, A3[2].re, a_i * qs.re), fma(re_, A3[2].im, a_i * qs.im)};
+            }
+#pragma unroll
+            for (int a_ = 0; a_ < 3; a_++)
+#pragma unroll
+                for (int j = 0; j < 6; j++) {
+                    const double wj = D[QD_W + 6 * a_ + j];
+                    F[j] = {fma(wj, f[a_].re, F[j].re), fma(wj, f[a_].im, F[j].im)};
+                }
+#undef U1
+#undef L2
         }
         // waterline term (:1635-1668)
         for (int64_t m = A.moff[set]; m < A.moff[set + 1]; m++) {

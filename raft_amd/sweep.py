@@ -296,7 +296,7 @@ class GeometrySweep(Sweep):
 
     def prepare_crossing(self, ctx, slot, n_chunk=0, want_Xi=False, Xi_out=None):
         """First stage of the streamed form of ``run_crossing`` for back-to-back batches: enqueue this batch's descriptor
-        upload and member pass on ``slot`` (0 .. 2) and return a handle (raftx_sweep_prepare)."""
+        upload and member pass on ``slot`` (0 .. 3) and return a handle (raftx_sweep_prepare)."""
         self._crossing_supported()
         return ctx.sweep_prepare(slot, self.tables, self.M0, self.B0, self.C0, self.w, self.k, self.depth, self.zeta, self.beta,
                                  self.nIter, self.tol, self.XiStart, pose=self.pose, rho=self.rho, g=self.g, add_mask=self.add_mask,

@@ -98,3 +98,30 @@ def test_qtf_12d_file_round_trip(tmp_path):
     heads, w, q = rq.read_qtf12d(path, f.rho_water, f.g)
     assert len(w) == len(f.w1_2nd) and np.allclose(w, f.w1_2nd, rtol=1e-4)
     assert rel_err(q[:, :, 0, :], fx["motion_qtf"]) < 2e-4          # the file carries 5 significant digits
+
+
+@pytest.mark.parametrize("deck", ["refgold_qtf_VolturnUS-S.npz", "c5_oc4semi_qtf.npz"])
+def test_strip_frame_formulation_of_the_device_kernel(deck):
+    """k_qtf_pairs evaluates the strip terms in each strip's own frame (tests/qtf_device_model.py states the formulation
+    in numpy): it must equal the term-by-term restatement of the reference -- here on a 24-point grid with body motions,
+    vertical columns, pontoons, inclined braces and heave plates (Ca_p1 != Ca_p2 members included)."""
+    from raft_amd import waves
+    from tests import qtf_device_model as dm
+    fx = standin.load_fixture(deck)
+    f = standin.build_model(fx["model"]).fowtList[0]
+    tab = rq.pack_qtf(f)
+    nw2 = 24
+    w2 = np.arange(1, nw2 + 1) * 0.02 * 2 * np.pi
+    k2 = np.array([waves.wave_number(x, f.depth) for x in w2])
+    rng = np.random.default_rng(1)
+    amp = np.array([1.0, 0.3, 0.7, 0.01, 0.02, 0.004])[:, None] / (1.0 + (w2[None, :] / 0.6) ** 2)
+    Xi = amp * np.exp(1j * (rng.uniform(0, 6, 6)[:, None] + 1.5 * w2[None, :]))
+    beta = 0.6
+    full = qtf_oracle.qtf_slender_body(tab, Xi, beta, w2, k2, f.depth, f.rho_water, f.g, f.M_struc)
+    rest = qtf_oracle.qtf_slender_body(rq.QtfTable(np.zeros((0, rq.QS_N)), tab.members, tab.kay_geom), Xi, beta, w2, k2, f.depth,
+                                       f.rho_water, f.g, f.M_struc)
+    want = np.transpose(full - rest, (2, 0, 1))                     # the strip terms alone
+    with np.errstate(invalid="ignore"):
+        got = dm.qtf_strips(tab, Xi, beta, w2, k2, f.depth, f.rho_water, f.g)
+    iu = np.triu_indices(nw2)
+    assert rel_err(got[:, iu[0], iu[1]], want[:, iu[0], iu[1]]) < 1e-12
