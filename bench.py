@@ -433,6 +433,7 @@ def main():
                                                       "(the gap between fused kernels shrinks 0.35 -> 0.2 ms, the kernels sharing the drain slow each "
                                                       "other by as much), so it is not the default")
     ap.add_argument("--no-extra-legs", action="store_true", help="skip the legs outside the headline (xi-out, featured sweeps)")
+    ap.add_argument("--legs", default="xi,featured,configs", help="which legs outside the headline run (comma list of xi, featured, configs)")
     ap.add_argument("--profile", action="store_true", help="for runs under rocprofv3: whole-batch launches only (--chunks 1), no isolated / "
                                                             "extra / oracle legs -- ONE population of k_solve_dynamics launches in the trace")
     args = ap.parse_args()
@@ -632,7 +633,7 @@ def main():
 
     # ---- legs outside the headline (N = 1): SURVEY 8d's literal step (responses downloaded), featured sweeps
     xi_leg = featured = None
-    if rank == 0 and world == 1 and not args.no_extra_legs and not args.xi_out:
+    if rank == 0 and world == 1 and not args.no_extra_legs and not args.xi_out and "xi" in args.legs:
         Xp = [ctx.pinned_empty((nD, 1, 1, 6, nw)) for _ in range(4)]
 
         def xi_steps(n):
@@ -651,12 +652,17 @@ def main():
                 if i + 2 < n:
                     sw.launch_crossing(ctx, hs[i + 2])
                 sw.wait_crossing(ctx, hs.pop(i))
+                if os.environ.get("RAFTX_BENCH_DEBUG"):
+                    print("  xi step %d collected at %.3f ms" % (i, 1e3 * time.perf_counter()), file=sys.stderr)
         xi_steps(9)                                       # untimed: every one of the four slots reaches its steady-state configuration
+        # a streak of 30 batches (or K if larger): with four batches in flight the fill and the drain of the pipeline are
+        # worth two steps (the first batch's upload and kernels, the last batch's download), which a long sweep does not see
+        n_xi = max(args.steps, int(os.environ.get("RAFTX_BENCH_XI_STEPS", "30")))
         ctx.synchronize()
         t1 = time.perf_counter()
-        xi_steps(args.steps)
+        xi_steps(n_xi)
         ctx.synchronize()
-        t_xi = (time.perf_counter() - t1) / args.steps
+        t_xi = (time.perf_counter() - t1) / n_xi
         t1 = time.perf_counter()
         for _ in range(3):
             sw.run_crossing(ctx, n_chunk=args.chunks, n_worker=args.workers, Xi_out=Xp[0])
@@ -665,10 +671,11 @@ def main():
             assert np.array_equal(b_.view(np.uint64), Xi.reshape(b_.shape).view(np.uint64)), "xi-out leg: responses differ from the checked batch"
         xi_leg = {"state": "xi out: SURVEY 8d's literal step, H2D of the descriptors + kernels + D2H of Xi (%.0f MB per step, "
                            "page-locked destination)" % (Xp[0].nbytes / 1e6),
-                  "streamed_ms_per_step": 1e3 * t_xi, "streamed_dcf_per_s": nD * nw / t_xi,
+                  "streamed_ms_per_step": 1e3 * t_xi, "streamed_dcf_per_s": nD * nw / t_xi, "streamed_steps": n_xi, "batches_in_flight": 4,
                   "isolated_ms_per_step": 1e3 * t_xi_iso, "isolated_dcf_per_s": nD * nw / t_xi_iso}
         for b_ in Xp:
             ctx.free_pinned(b_)
+    if rank == 0 and world == 1 and not args.no_extra_legs and not args.xi_out and "featured" in args.legs:
         sw.upload(ctx)                                    # the plain sweep, resident: the yardstick of the featured legs
         ks = []
         for i in range(6):
@@ -680,7 +687,7 @@ def main():
         featured.update(featured_legs(ctx, nD, sw, float(np.mean(ks)), float(np.sum(niter))))
     # ---- BASELINE configs[1], [3], [4] at their specified sizes, each against its live-reference golden (N = 1)
     cfg_legs = {}
-    if rank == 0 and world == 1 and not args.no_extra_legs:
+    if rank == 0 and world == 1 and not args.no_extra_legs and "configs" in args.legs:
         import bench_legs
         cfg_legs["c2_dropin"] = bench_legs.c2_dropin(ctx)
         cfg_legs["c4_farm"] = bench_legs.c4_farm(ctx, farms=1000)

@@ -6,7 +6,7 @@ R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$R/gpurun_out/$TAG
 mkdir -p $OUT
 cd $R
-for P in low high 0; do
+for P in low high; do
   ( RAFTX_D2H_PRIORITY=$P timeout 300 python bench.py --no-cpu-baseline 2>$OUT/bench_$P.err | tail -1 ) > $OUT/bench_$P.json
   python - <<PY
 import json
@@ -14,7 +14,7 @@ d = json.load(open("$OUT/bench_$P.json"))
 print("$P: value %.1f M ms/step %.3f kernel %.3f | xi_out %s" % (d["value"]/1e6, d["ms_per_step"], d["roofline"]["kernel_ms_per_step"], {k: round(v, 3) for k, v in d["xi_out"].items() if k.endswith("ms_per_step")}))
 PY
 done
-for B in 64 128; do ( RAFTX_QTF_BLOCK=$B timeout 300 python scripts/bench_qtf.py 16 2>&1 | head -2 | cut -c1-330 ); done
+
 bash scripts/gpu_xi_trace.sh $TAG/trace 2>&1 | tail -5
 python - <<PY
 import csv

@@ -426,10 +426,36 @@ def check_staged_crossings_with_changing_sea_states(ctx):
     ctx.sweep_cancel(dict(slot=2))                        # idle slot: no-op
 
 
+def check_soak(ctx, n_step):
+    """A long streak through the four slots (prepare(i+3), launch(i+2), wait(i)): three batch sizes x two sets of sea states
+    in rotation, responses downloaded -- every collected batch equals its blocking call bit for bit, pools and slots are
+    recycled hundreds of times (the soak the sanitised build runs too, scripts/gpu_asan.sh)."""
+    z0, b0 = np.asarray(C3["zeta"]), np.asarray(C3["beta"])
+    seas = [(z0[None], b0[None]), (np.stack([0.5 * z0, 1.5 * z0]), np.stack([b0 + 0.3, b0 - 0.7]))]
+    fixed = lambda z, b: (C3["w"], C3["k"], float(C3["depth"]), z, b, int(C3["nIter"]), 0.01, float(C3["XiStart"]))
+    batches = [_c3_crossing_inputs(n) for n in (21, 8, 34)]
+    combos = [(bi, si) for bi in range(3) for si in range(2)]
+    want = {c: ctx.sweep_stats(*batches[c[0]], *fixed(*seas[c[1]]), want_Xi=True) for c in combos}
+    pick = lambda i: combos[(i * 5 + i // 7) % len(combos)]
+    sub = lambda i: ctx.sweep_prepare(i % 4, *batches[pick(i)[0]], *fixed(*seas[pick(i)[1]]), want_Xi=True)
+    hs = {i: sub(i) for i in range(min(n_step, 3))}
+    for i in range(min(n_step, 2)):
+        ctx.sweep_launch(hs[i])
+    for i in range(n_step):
+        if i + 3 < n_step:
+            hs[i + 3] = sub(i + 3)
+        if i + 2 < n_step:
+            ctx.sweep_launch(hs[i + 2])
+        g_, w_ = ctx.sweep_wait(hs.pop(i)), want[pick(i)]
+        assert np.array_equal(g_["Xi"].view(np.uint64), w_["Xi"].view(np.uint64)), i
+        assert np.array_equal(g_["std"].view(np.uint64), w_["std"].view(np.uint64)) and np.array_equal(g_["niter"], w_["niter"]), i
+
+
 def test_oracle_streamed_crossings(oracle_ctx):
     check_streamed_crossings(oracle_ctx)
     check_staged_crossings(oracle_ctx)
     check_staged_crossings_with_changing_sea_states(oracle_ctx)
+    check_soak(oracle_ctx, 9)
 
 
 @pytest.mark.gpu
@@ -438,6 +464,11 @@ def test_hip_streamed_crossings(hip_ctx):
     check_staged_crossings(hip_ctx)
     check_staged_crossings_with_changing_sea_states(hip_ctx)
     check_crossing(hip_ctx, 20, 0, 0)                     # the blocking call still works on the same context afterwards
+
+
+@pytest.mark.gpu
+def test_hip_soak_of_300_staged_crossings(hip_ctx):
+    check_soak(hip_ctx, 300)
 
 
 # ------------------------------------------------------------------ ballast trim (Model.adjustBallastDensity)
