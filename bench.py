@@ -200,14 +200,37 @@ def oracle_run(sw, ctx):
     o.solve_dynamics_device(sw.nIter, sw.tol, sw.XiStart)
     dt = time.perf_counter() - t0
     res = o.fetch_results(want_Xi=True)
-    o.close()
     flops = algorithmic_flops(off, nw, res["niter"])
-    base = {"value": n * nw / dt, "unit": "dcf solves/s", "cores": threads, "kind": "port",
-            "sample": "all %d designs of the timed batch x 1 sea state x %d bins, oracle/raftx_oracle.c (gcc -O3 -march=x86-64-v3, "
-                      "IEEE semantics, OpenMP over (design, case), %d threads), %.1f s" % (n, nw, threads, dt),
-            "algorithmic_gflops": flops / dt / 1e9,
-            "note": "a scalar loop-by-loop restatement of the reference (materialised kinematics, libm cabs): the checker doing "
-                    "double duty, not a tuned CPU implementation -- %.2f GFLOP/s per thread" % (flops / dt / 1e9 / max(threads, 1))}
+    plain = {"value": n * nw / dt, "unit": "dcf solves/s", "cores": threads, "kind": "port",
+             "sample": "all %d designs of the timed batch x 1 sea state x %d bins, oracle/raftx_oracle.c solve_core (gcc -O3 -march=x86-64-v3, "
+                       "IEEE semantics, OpenMP over (design, case), %d threads), %.1f s" % (n, nw, threads, dt),
+             "algorithmic_gflops": flops / dt / 1e9, "gflops_per_thread": flops / dt / 1e9 / max(threads, 1),
+             "note": "the CHECKER timed: a scalar loop-by-loop restatement of the reference (materialised complex kinematics, libm "
+                     "cabs, one malloc'ed work set per pair) -- not a tuned CPU implementation"}
+    # the honest CPU datapoint: the same fixed point restated for the vector units (oracle/raftx_port_simd.h), checked against
+    # the plain oracle's results of this very batch before its time counts
+    import ctypes as C
+    fn = lib.lib.raftx_oracle_solve_simd
+    fn.argtypes = [C.c_void_p, C.c_int, C.c_double, C.c_double]
+    fn.restype = C.c_int
+    assert fn(o._h, int(sw.nIter), float(sw.tol), float(sw.XiStart)) == 0          # warm-up
+    t0 = time.perf_counter()
+    assert fn(o._h, int(sw.nIter), float(sw.tol), float(sw.XiStart)) == 0
+    dts = time.perf_counter() - t0
+    rs = o.fetch_results(want_Xi=True)
+    o.close()
+    num = np.max(np.abs(rs["Xi"] - res["Xi"]).reshape(n, -1), axis=1)
+    den = np.max(np.abs(res["Xi"]).reshape(n, -1), axis=1)
+    simd_err = float(np.max(num / den))
+    simd_mis = int(np.count_nonzero(rs["niter"] != res["niter"]))
+    assert simd_err < 1e-10 and simd_mis == 0, "the vectorised CPU port differs from the oracle: %g, %d" % (simd_err, simd_mis)
+    base = {"value": n * nw / dts, "unit": "dcf solves/s", "cores": threads, "kind": "port-simd",
+            "sample": "all %d designs of the timed batch x 1 sea state x %d bins, oracle/raftx_port_simd.h (the oracle's fixed point with "
+                      "frequency as the unit-stride inner loop, split re / im arrays, #pragma omp simd, AVX2 + FMA; OpenMP over (design, case), "
+                      "%d threads), %.2f s" % (n, nw, threads, dts),
+            "algorithmic_gflops": flops / dts / 1e9, "gflops_per_thread": flops / dts / 1e9 / max(threads, 1),
+            "max_rel_err_vs_plain_oracle": simd_err, "niter_mismatches_vs_plain_oracle": simd_mis,
+            "plain_oracle": plain}
     return base, res, gen
 
 

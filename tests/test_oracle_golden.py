@@ -157,3 +157,33 @@ def test_packed_table_is_reused_until_a_member_changes(oracle_ctx):
     f2.memberList[1].r = np.asarray(f2.memberList[1].r) + [0.0, 0.0, -0.25]
     Xi3 = dropin.Engine(oracle_ctx).solveDynamics(fresh, cases[1])
     assert np.array_equal(Xi2, Xi3) and not np.array_equal(Xi2, Xi1)
+
+
+def test_vectorised_cpu_port_equals_the_checker(oracle_lib):
+    """bench.py's honest CPU datapoint (oracle/raftx_port_simd.h, kind "port-simd") is the plain oracle's fixed point
+    restated for the vector units: same responses to 1e-12, same iteration counts and flags, on the reference-built C3
+    variants with two sea states (it is never the checker itself)."""
+    import ctypes as C
+    from raft_amd import snapshot
+    fx = snapshot.load_fixture("c3_variants.npz")
+    nD = 12
+    off = np.asarray(fx["strip_offsets"], dtype=np.int64)[:nD + 1]
+    strips = np.asarray(fx["strips"], dtype=np.float64)[:off[-1]]
+    z0 = np.asarray(fx["zeta"], dtype=np.float64).reshape(1, -1)[0]
+    zeta = np.stack([z0, 0.4 * z0])[:, None, :]
+    beta = np.array([[0.0], [0.7]])
+    ctx = oracle_lib.context(0)
+    ctx.upload_designs_raw(off, strips, np.asarray(fx["M0"])[:nD], np.asarray(fx["B0"])[:nD], np.asarray(fx["C0"])[:nD], len(fx["w"]))
+    ctx.upload_cases(fx["w"], fx["k"], float(fx["depth"]), 1025.0, 9.81, zeta, beta)
+    ctx.solve_dynamics_device(int(fx["nIter"]), 0.01, float(fx["XiStart"]))
+    want = ctx.fetch_results(want_Xi=True)
+    fn = oracle_lib.lib.raftx_oracle_solve_simd
+    fn.argtypes = [C.c_void_p, C.c_int, C.c_double, C.c_double]
+    fn.restype = C.c_int
+    assert fn(ctx._h, int(fx["nIter"]), 0.01, float(fx["XiStart"])) == 0
+    got = ctx.fetch_results(want_Xi=True)
+    assert np.array_equal(got["niter"], want["niter"]) and np.array_equal(got["flags"], want["flags"])
+    for d in range(nD):
+        for ic in range(2):
+            assert group_rel_err(got["Xi"][d, ic], want["Xi"][d, ic]) < 1e-12
+    ctx.close()
