@@ -811,6 +811,10 @@ struct raftx_ctx {
     std::vector<raftx_ctx *> workers[RAFTX_NSLOT]; // block contexts of the sweep crossings (device buffers, pool, events), per slot, kept for reuse
     struct SweepSlot *slots;             // [RAFTX_NSLOT] crossings in flight (raftx_sweep_prepare / _launch / _wait)
 };
+// Offset arrays of a whole batch, resident on the device (uploaded once by the sweep crossing, shared by its blocks).
+struct DevOffsets {
+    const int64_t *memberOff, *stationOff, *capOff;      // device copies of the caller's arrays, absolute values
+};
 // One sweep crossing in flight: everything raftx_sweep_wait needs to finish it.
 struct SweepSlot {
     bool busy = false;                   // launched (phase 2 enqueued), not yet waited for
@@ -827,6 +831,17 @@ struct SweepSlot {
     int64_t *stripOffsets = nullptr;
     std::vector<void *> allocs;          // the batch's offset arrays on the device, shared by its blocks
     hipEvent_t evXi = nullptr;           // download of the responses finished (sD2H)
+    // phase 1 (descriptor upload + member pass) of the blocks behind the second one is enqueued by raftx_sweep_launch, one
+    // block ahead of the block being launched: the caller's arrays (alive until the batch has been waited for) and the
+    // batch's device offsets are kept for that
+    struct {
+        const int64_t *memberOff, *stationOff, *capOff;
+        const double *members, *stations, *caps, *pose, *M0, *B0, *C0, *Fz_moor, *k;
+        double rho, g;
+        int add_mask;
+        DevOffsets dOff;
+    } p1;
+    size_t next_p1 = 0;                  // first block whose phase 1 has not been enqueued yet
     std::chrono::steady_clock::time_point t0;
     double tl[4] = {0, 0, 0, 0};
 };
@@ -1120,10 +1135,6 @@ static int upload_on(raftx_ctx *c, hipStream_t st, std::vector<void *> &bag, con
     *dev = reinterpret_cast<const Tp *>(p);
     return 0;
 }
-// Offset arrays of a whole batch, resident on the device (uploaded once by the sweep crossing, shared by its blocks).
-struct DevOffsets {
-    const int64_t *memberOff, *stationOff, *capOff;      // device copies of the caller's arrays, absolute values
-};
 // Designs [lo, lo + nDesign) of the caller's batch: memberOff / stationOff / capOff are the batch's own (absolute) host
 // arrays, the descriptor arrays are sliced here.  shared == NULL: the offsets of the slice are uploaded by this call.
 static int build_phase1(raftx_ctx *c, hipStream_t sCopy, hipStream_t sPrep, int lo, int nDesign, const int64_t *memberOff,
@@ -2603,18 +2614,25 @@ extern "C" int raftx_sweep_prepare(raftx_ctx *c, int slot, int nDesign, const in
         if (capOff) rc |= upload_on(c, c->sCopy, S.allocs, capOff, (size_t)nMemberAll + 1, &dOff.capOff);
         if (rc) return fail_drain(-2);
     }
-    // ---- phase 1 of every block: H2D on sCopy, member pass + scans on sPrep
-    for (size_t b = 0; b < nB; b++) {
+    // ---- phase 1: H2D on sCopy, member pass + scans on sPrep.  Every block here -- except for an isolated crossing cut into
+    // slabs (responses wanted, nothing else in flight): there only the first two; raftx_sweep_launch enqueues the others one
+    // block ahead of the block it launches.  (The ordinary streams share hardware queues: with every block's copies queued
+    // first, the first slab's generation sat behind 1.7 ms of uploads -- profiles/r04_iso_timeline.txt.)
+    S.p1 = {memberOff, stationOff, capOff, members, stations, caps, pose, M0, B0, C0, Fz_moor, k, rho, g, add_mask, dOff};
+    const size_t nFirst = (Xi && nB > 2 && !others_in_flight(c, slot)) ? 2 : nB;
+    for (size_t b = 0; b < nB; b++)
         if (block_ctx(c, slot, b, &blk[b])) return fail_drain(-1);
+    for (size_t b = 0; b < nFirst; b++) {
         raftx_ctx *sub = blk[b];
         const int lo = bnd[b], n = bnd[b + 1] - lo;
         const int rc = build_phase1(sub, c->sCopy, c->sPrep, lo, n, memberOff, members, stationOff, stations, capOff, caps, pose,
-                                    rho, g, nw, k, add_mask, M0, B0, C0, nullptr, Fz_moor, &dOff, CT.k);
+                                    rho, g, nw, k, add_mask, M0, B0, C0, nullptr, Fz_moor, &S.p1.dOff, CT.k);
         if (rc) {
             snprintf(c->err, sizeof(c->err), "sweep_stats (block %zu): %s", b, sub->err);
             return fail_drain(rc);
         }
     }
+    S.next_p1 = nFirst;
     S.tl[1] = since();
     S.prepared = true;
     return 0;
@@ -2647,6 +2665,32 @@ extern "C" int raftx_sweep_launch(raftx_ctx *c, int slot) {
         slot_release_cases(c, S);
         return rc;
     };
+    // ---- full responses, if asked for: every block's download is enqueued right behind the block's kernels, on a stream of
+    // its own (enqueued after ALL blocks -- as until round 4 -- the first download of an isolated call could not start before
+    // the host had seen the member pass of the LAST block, i.e. before every descriptor had been uploaded: 1.6 ms late)
+    hipStream_t sDown = nullptr;
+    if (Xi) {
+        // The bulk download goes to a stream of its own PRIORITY CLASS, created when first needed: priority classes have
+        // hardware queues of their own, whereas the ordinary streams of this library share four, and a hardware queue is in
+        // order -- the generation and the fused kernel of batch i+1 used to queue behind the 3.4 ms copy of batch i whenever
+        // the two streams landed on one queue (round 3: 7.0 ms per step instead of 4.6-5.0).  Created late, it does not move the
+        // other streams' queues (the plain step is sensitive to those: +5 % with the generation stream one queue further).
+        // Which class: round 3 took the LOWEST, and the copy / kernel timeline of round 4 (profiles/r04_xi_timeline.txt)
+        // shows what that costs -- the command processor does not look at a low-priority queue while a 10 000-workgroup grid
+        // of the ordinary class is being handed out, so the download of batch i only STARTED 0.26 ms before the end of batch
+        // i+1's fused kernel, a whole step late, and then ran beside nothing.  The HIGHEST class is served at once: the copy
+        // is a barrier packet and an SDMA transfer, no compute, and starts when the batch's statistics kernel has finished.
+        // RAFTX_D2H_PRIORITY = high (default) | low | 0 (the ordinary download stream).
+        static const char *d2h_env = getenv("RAFTX_D2H_PRIORITY");
+        static const bool d2h_own = !(d2h_env && !strcmp(d2h_env, "0"));
+        static const bool d2h_low = d2h_own && d2h_env && !strcmp(d2h_env, "low");
+        if (d2h_own && !c->sD2Hlow) {
+            int least = 0, greatest = 0;
+            if (hipDeviceGetStreamPriorityRange(&least, &greatest) == hipSuccess && least != greatest)
+                (void)hipStreamCreateWithPriority(&c->sD2Hlow, hipStreamNonBlocking, d2h_low ? least : greatest);
+        }
+        sDown = (d2h_own && c->sD2Hlow) ? c->sD2Hlow : c->sD2H;
+    }
     // ---- phase 2 + fixed point + statistics of every block, in order, on the ctx stream
     int rc_all = 0;
     for (size_t b = 0; b < nB && !rc_all; b++) {
@@ -2663,6 +2707,17 @@ extern "C" int raftx_sweep_launch(raftx_ctx *c, int slot) {
         static const bool gen_overlap = !(getenv("RAFTX_SWEEP_GEN_OVERLAP") && !atoi(getenv("RAFTX_SWEEP_GEN_OVERLAP")));
         const bool pipelined = others_in_flight(c, slot);
         int rc = 0;
+        if (S.next_p1 < nB && S.next_p1 <= b + 1) {                     // deferred phase 1: keep one block's upload ahead
+            const size_t bn = S.next_p1++;
+            const int rc1 = build_phase1(blk[bn], c->sCopy, c->sPrep, bnd[bn], bnd[bn + 1] - bnd[bn], S.p1.memberOff, S.p1.members,
+                                         S.p1.stationOff, S.p1.stations, S.p1.capOff, S.p1.caps, S.p1.pose, S.p1.rho, S.p1.g, nw, S.p1.k,
+                                         S.p1.add_mask, S.p1.M0, S.p1.B0, S.p1.C0, nullptr, S.p1.Fz_moor, &S.p1.dOff,
+                                         c->csets[S.cset].T.k);
+            if (rc1) {
+                snprintf(sub->err, sizeof(sub->err), "%s", blk[bn]->err);
+                rc = rc1;
+            }
+        }
         if (b == 0 && pipelined && gen_overlap) {
             // When does the generation run?  Enqueued now, beside a fused kernel that has only just started, it would be
             // dispatched at once and take LDS from that kernel for its whole run (measured: +0.25 ms on the kernel).  A
@@ -2673,7 +2728,11 @@ extern "C" int raftx_sweep_launch(raftx_ctx *c, int slot) {
                 if (sl != slot && c->slots[sl].prepared && !c->slots[sl].blk.empty() && c->slots[sl].blk[0])
                     if (hipStreamWaitEvent(c->sGen, c->slots[sl].blk[0]->evZ, 0) != hipSuccess) rc = -2;
         }
-        if (!rc) rc = build_phase2(sub, nullptr, (pipelined && gen_overlap) ? c->sGen : nullptr);
+        // slabs of a crossing that downloads its responses (sweep_bounds): the tables of slab b + 1 are generated on the side
+        // stream while slab b solves -- with five slabs the serial generation was 0.4 ms per slab (RAFTX_XI_GEN_OVERLAP=0)
+        static const bool xi_gen_overlap = !(getenv("RAFTX_XI_GEN_OVERLAP") && !atoi(getenv("RAFTX_XI_GEN_OVERLAP")));
+        const bool gen_side = (pipelined && gen_overlap) || (b > 0 && Xi != nullptr && nB > 2 && xi_gen_overlap);
+        if (!rc) rc = build_phase2(sub, nullptr, gen_side ? c->sGen : nullptr);
         if (!rc && b == 0 && pipelined && gen_overlap) {
             // Small kernels are not dispatched while a big grid is being handed out: whatever of the NEXT batch's member pass
             // has not finished when this batch's fused kernel starts would wait for the whole kernel and stall that batch's
@@ -2716,6 +2775,12 @@ extern "C" int raftx_sweep_launch(raftx_ctx *c, int slot) {
             }
             if (e == hipSuccess) e = hipEventRecord(sub->evS1, c->stream);
             if (e == hipSuccess) e = hipEventRecord(sub->evDone, c->stream);
+            if (e == hipSuccess && Xi) {                                 // this block's responses: behind its kernels, on the download stream
+                const size_t p0 = (size_t)lo * nCase;
+                e = hipStreamWaitEvent(sDown, sub->evDone, 0);
+                if (e == hipSuccess && sub->r_nx)
+                    e = hipMemcpyAsync(Xi + p0 * nHead * 6 * nw, sub->rXi, sub->r_nx * sizeof(cplx), hipMemcpyDeviceToHost, sDown);
+            }
             if (e != hipSuccess) {
                 snprintf(sub->err, sizeof(sub->err), "statistics / download of the block: %s", hipGetErrorString(e));
                 rc = -2;
@@ -2726,42 +2791,7 @@ extern "C" int raftx_sweep_launch(raftx_ctx *c, int slot) {
             rc_all = rc;
         }
     }
-    // ---- full responses, if asked for: block by block behind the block's kernels, on their own stream
-    if (!rc_all && Xi) {
-        // The bulk download goes to a stream of its own PRIORITY CLASS, created when first needed: priority classes have
-        // hardware queues of their own, whereas the ordinary streams of this library share four, and a hardware queue is in
-        // order -- the generation and the fused kernel of batch i+1 used to queue behind the 3.4 ms copy of batch i whenever
-        // the two streams landed on one queue (round 3: 7.0 ms per step instead of 4.6-5.0).  Created late, it does not move the
-        // other streams' queues (the plain step is sensitive to those: +5 % with the generation stream one queue further).
-        // Which class: round 3 took the LOWEST, and the copy / kernel timeline of round 4 (profiles/r04_xi_timeline.txt)
-        // shows what that costs -- the command processor does not look at a low-priority queue while a 10 000-workgroup grid
-        // of the ordinary class is being handed out, so the download of batch i only STARTED 0.26 ms before the end of batch
-        // i+1's fused kernel, a whole step late, and then ran beside nothing.  The HIGHEST class is served at once: the copy
-        // is a barrier packet and an SDMA transfer, no compute, and starts when the batch's statistics kernel has finished.
-        // RAFTX_D2H_PRIORITY = high (default) | low | 0 (the ordinary download stream).
-        static const char *d2h_env = getenv("RAFTX_D2H_PRIORITY");
-        static const bool d2h_own = !(d2h_env && !strcmp(d2h_env, "0"));
-        static const bool d2h_low = d2h_own && d2h_env && !strcmp(d2h_env, "low");
-        if (d2h_own && !c->sD2Hlow) {
-            int least = 0, greatest = 0;
-            if (hipDeviceGetStreamPriorityRange(&least, &greatest) == hipSuccess && least != greatest)
-                (void)hipStreamCreateWithPriority(&c->sD2Hlow, hipStreamNonBlocking, d2h_low ? least : greatest);
-        }
-        hipStream_t sDown = (d2h_own && c->sD2Hlow) ? c->sD2Hlow : c->sD2H;
-        for (size_t b = 0; b < nB; b++) {
-            raftx_ctx *sub = blk[b];
-            const size_t p0 = (size_t)bnd[b] * nCase;
-            hipError_t e = hipStreamWaitEvent(sDown, sub->evDone, 0);
-            if (e == hipSuccess && sub->r_nx)
-                e = hipMemcpyAsync(Xi + p0 * nHead * 6 * nw, sub->rXi, sub->r_nx * sizeof(cplx), hipMemcpyDeviceToHost, sDown);
-            if (e != hipSuccess) {
-                snprintf(c->err, sizeof(c->err), "sweep_stats: download of the responses: %s", hipGetErrorString(e));
-                rc_all = -2;
-                break;
-            }
-        }
-        if (!rc_all && hipEventRecord(S.evXi, sDown) != hipSuccess) rc_all = -2;
-    }
+    if (!rc_all && Xi && hipEventRecord(S.evXi, sDown) != hipSuccess) rc_all = -2;
     if (rc_all) return fail_drain(rc_all);
     S.tl[2] = since();
     S.busy = true;
