@@ -470,6 +470,134 @@ __global__ void __launch_bounds__(256) k_solve_dense(int n, int nRhs, int nw, co
     }
 }
 
+// The same solve for systems of up to 32 RB x 32 CB - nRhs unknowns (the reference's flexible deck: 150) with the whole
+// augmented matrix in REGISTERS: 1024 threads as a 32 x 32 grid, thread (ti, tj) owns the entries (ti + 32 a, tj + 32 b) --
+// 25 complex numbers at RB = CB = 5 -- so that a step of the elimination touches LDS for the pivot row and the column of
+// multipliers only.  k_solve_dense above keeps the matrix in an L2-resident workspace and pays three round trips through L2
+// per step: 150 steps, 1.8 ms per call, nine calls per drop-in solveDynamics of the flexible deck.  Here a step is three
+// workgroup barriers.  Gauss-Jordan with partial pivoting (izamax order: first largest |re| + |im| among the rows that have
+// not been pivots yet) and IMPLICIT row interchanges -- a pivot row stays where it is: every register index is static (the
+// step loop is unrolled over the 32-column blocks), the one dynamic choice, which of a thread's RB rows is the pivot row,
+// goes through an LDS staging area.  Rows above the pivot are eliminated too (the lanes that own them would idle
+// otherwise), so there is no back substitution: unknown k is the pivot row's right-hand side over its pivot.
+template <int RB, int CB>
+__global__ void __launch_bounds__(1024) k_solve_dense_reg(int n, int nRhs, int nw, const double *__restrict__ w,
+                                                          const double *__restrict__ M, const double *__restrict__ B,
+                                                          const double *__restrict__ C, int freq_mask,
+                                                          const cplx *__restrict__ F, cplx *__restrict__ Xi,
+                                                          cplx *__restrict__ Zout) {
+    __shared__ cplx stage[RB][CB * 32];                   // the RB rows of the thread row that holds the pivot row
+    __shared__ cplx colk[RB * 32];                        // multipliers of the step, by row (0 for the pivot row)
+    __shared__ cplx invp[RB * 32];                        // 1 / pivot of the step in which the row was the pivot row
+    __shared__ int ord[RB * 32];                          // ... and that step
+    __shared__ int psel;
+    const int iw = blockIdx.x, ld = n + nRhs, tid = threadIdx.x, ti = tid & 31, tj = tid >> 5;
+    const double ww = w[iw];
+    const bool mw = freq_mask & 1, bw = freq_mask & 2;
+    // entries of the thread: block rows 0 .. RB-2 in registers (80 at RB = CB = 5: 1024 threads leave 128 per lane), the last
+    // block row in LDS, one column of 16 bytes per thread and block column
+    extern __shared__ __attribute__((aligned(16))) unsigned char dense_tail_[];
+    cplx *tail = reinterpret_cast<cplx *>(dense_tail_);   // [CB][1024]
+    cplx Areg[RB - 1][CB];
+    auto LD = [&](int a_, int b_) -> cplx { return a_ < RB - 1 ? Areg[a_ < RB - 1 ? a_ : 0][b_] : tail[b_ * 1024 + tid]; };
+    auto ST = [&](int a_, int b_, cplx v_) {
+        if (a_ < RB - 1) Areg[a_ < RB - 1 ? a_ : 0][b_] = v_;
+        else tail[b_ * 1024 + tid] = v_;
+    };
+    unsigned done = 0;                                    // bit a: row ti + 32 a has been a pivot row (or does not exist)
+#pragma unroll
+    for (int a = 0; a < RB; a++) {
+        const int r = ti + 32 * a;
+        if (r >= n) done |= 1u << a;
+#pragma unroll
+        for (int b = 0; b < CB; b++) {
+            const int c = tj + 32 * b;
+            cplx v = {0.0, 0.0};
+            if (r < n && c < n) {
+                const size_t o = (size_t)r * n + c;
+                const double m = mw ? M[o * nw + iw] : M[o], bb = bw ? B[o * nw + iw] : B[o];
+                v = cplx{-(ww * ww) * m + C[o], ww * bb};
+                if (Zout) Zout[o * nw + iw] = v;
+            } else if (r < n && c < ld) {
+                v = F[((size_t)(c - n) * n + r) * nw + iw];
+            }
+            ST(a, b, v);
+        }
+    }
+#pragma unroll
+    for (int kb = 0; kb < CB; kb++) {
+        for (int kk = 0; kk < 32; kk++) {
+            const int k = kb * 32 + kk;
+            if (k >= n) break;                            // (uniform)
+            // ---- pivot search down column k: its owners are the 32 threads with tj == kk, one half-wave
+            double best = -1.0;
+            int p = RB * 32;
+            if (tj == kk) {
+#pragma unroll
+                for (int a = 0; a < RB; a++)
+                    if (!(done >> a & 1u)) {
+                        const cplx e_ = LD(a, kb);
+                        double v = fabs(e_.re) + fabs(e_.im);
+                        if (!(v <= 1.7e308)) v = 1.7e308;        // NaN / inf: take the row, the result is flagged not finite
+                        if (v > best) {
+                            best = v;
+                            p = ti + 32 * a;
+                        }
+                    }
+            }
+#pragma unroll
+            for (int off = 16; off >= 1; off >>= 1) argmax_step(best, p, off);       // stays inside the half-wave
+            if (tj == kk && ti == 0) psel = p;
+            __syncthreads();
+            p = psel;
+            const int ap = p >> 5;
+            if (ti == (p & 31)) {                         // the thread row of the pivot row publishes its rows; the row is done
+#pragma unroll
+                for (int a = 0; a < RB; a++)
+#pragma unroll
+                    for (int b = 0; b < CB; b++)
+                        if (b >= kb) stage[a][tj + 32 * b] = LD(a, b);
+                done |= 1u << ap;
+            }
+            __syncthreads();
+            const cplx pv = stage[ap][k];
+            const double dd = pv.re * pv.re + pv.im * pv.im;
+            const cplx inv = {pv.re / dd, -pv.im / dd};
+            if (tj == kk) {
+#pragma unroll
+                for (int a = 0; a < RB; a++) {
+                    const int r = ti + 32 * a;
+                    colk[r] = (r == p) ? cplx{0.0, 0.0} : cmul(LD(a, kb), inv);
+                }
+                if (ti == 0) {
+                    invp[p] = inv;
+                    ord[p] = k;
+                }
+            }
+            __syncthreads();
+            // (the pivot-row entry and the multipliers come from LDS where they are used: 128 registers per lane at 1024
+            // threads hold the 25 entries and little else)
+#pragma unroll
+            for (int b = 0; b < CB; b++)
+                if (b > kb || (b == kb && tj > kk)) {
+                    const cplx rkb = stage[ap][tj + 32 * b];
+#pragma unroll
+                    for (int a = 0; a < RB; a++) ST(a, b, csub(LD(a, b), cmul(colk[ti + 32 * a], rkb)));
+                }
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int a = 0; a < RB; a++) {
+        const int r = ti + 32 * a;
+#pragma unroll
+        for (int b = 0; b < CB; b++) {
+            const int c = tj + 32 * b;
+            if (r < n && c >= n && c < ld) Xi[((size_t)(c - n) * n + ord[r]) * nw + iw] = cmul(LD(a, b), invp[r]);
+        }
+    }
+}
+
 // Motion statistics of the resident responses (raft_fowt.py:2310-2357; helpers.py:678-700): one
 // workgroup per (design, case), lanes stride the frequency axis (coalesced 16 B/lane reads of the
 // Xi slab: a pure HBM stream, 19.2 KB in -> 48 B out per pair at C3).
@@ -2170,8 +2298,18 @@ extern "C" int raftx_solve_dense(raftx_ctx *c, int n, int nRhs, int nw, const do
     H2D(c, dC, C, nn * sizeof(double));
     H2D(c, dF, F, nf * sizeof(cplx));
     HIPCHK(c, hipEventRecord(c->ev0, c->stream));
-    hipLaunchKernelGGL(k_solve_dense, dim3((unsigned)nw), dim3(256), 0, c->stream, n, nRhs, nw, dw, dM, dB, dC, freq_mask,
-                       dF, dA, dX, dZ);
+    static const bool dense_l2 = getenv("RAFTX_DENSE_L2") && atoi(getenv("RAFTX_DENSE_L2"));     // tuning / tests: the L2-workspace kernel
+    if (!dense_l2 && n + nRhs <= 160 && n > 96)          // the register-resident kernel (the flexible deck: 150 + 1; measured:
+                                                          // 0.59 against 1.34 ms at 150 x 40 bins, 0.30 against 0.22 at 60 DOFs)
+    {
+        const size_t tail_lds = (size_t)5 * 1024 * sizeof(cplx);         // the last block row of every thread (see the kernel)
+        if (prep_lds(c, k_solve_dense_reg<5, 5>, tail_lds)) return -1;
+        hipLaunchKernelGGL((k_solve_dense_reg<5, 5>), dim3((unsigned)nw), dim3(1024), tail_lds, c->stream, n, nRhs, nw, dw, dM, dB,
+                           dC, freq_mask, dF, dX, dZ);
+    }
+    else
+        hipLaunchKernelGGL(k_solve_dense, dim3((unsigned)nw), dim3(256), 0, c->stream, n, nRhs, nw, dw, dM, dB, dC, freq_mask,
+                           dF, dA, dX, dZ);
     if (finish_timed(c)) return -2;
     D2H(c, Xi, dX, nf * sizeof(cplx));
     if (Z) D2H(c, Z, dZ, nn * nw * sizeof(cplx));
