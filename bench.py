@@ -489,6 +489,10 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if rank != 0:                                         # stdout carries ONE line, rank 0's: whatever native libraries of the other
+        dn = os.open(os.devnull, os.O_WRONLY)             # ranks print there (RCCL's version banner at exit) must not follow it
+        os.dup2(dn, 1)
+        os.close(dn)
     if world != args.gpus:                                # a line that says n_gpus = N must have been produced by N ranks
         sys.stderr.write("bench.py: --gpus %d but WORLD_SIZE=%d: start the ranks with --nproc-per-node %d (or drop the launcher: "
                          "`python bench.py --gpus %d` starts them itself)\n" % (args.gpus, world, args.gpus, args.gpus))

@@ -19,6 +19,9 @@ for d in sorted(os.listdir(src)):
             out["_wg"], out["_grid"] = r["Workgroup_Size"], r["Grid_Size"]
     for k, v in acc.items():
         out[k] = {"launches": len(v), "mean_per_launch": sum(v) / len(v)}
+out["_note"] = ("_vgpr / _agpr are rocprofv3's VGPR_Count / Accum_VGPR_Count columns: on gfx950 (unified 512-entry file) the tool reports "
+                "the ARCH-VGPR allocation in its own granule (128 for every kernel compiled to two waves per SIMD), not the compiler's "
+                "count -- k_solve_dynamics<2,0,128,2> is 254 VGPRs + 0 AGPRs, 0 B scratch by -Rpass-analysis=kernel-resource-usage (DESIGN.md 3.1)")
 json.dump(out, open(os.path.join(dst, "pmc_summary.json"), "w"), indent=1)
 if "FETCH_SIZE" in out and "WRITE_SIZE" in out:      # rocprofv3 reports KB; FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950
     f, w_ = out["FETCH_SIZE"]["mean_per_launch"] * 1e3, out["WRITE_SIZE"]["mean_per_launch"] * 1e3
