@@ -2584,22 +2584,13 @@ static int block_ctx(raftx_ctx *c, int slot, size_t i, raftx_ctx **out) {
 // whose kernels hide the descriptor upload of the rest (every further block costs a partial last residency round of the
 // fused kernel plus the fixed latencies of the generation kernels: two blocks measured best)
 static std::vector<int> sweep_bounds(int nDesign, long pairs, int nChunk, bool pipelined, bool with_xi = false, int nCase = 1) {
-    // The responses are wanted and nothing else is in flight to hide their download behind: slabs of whole residency rounds
-    // (2 048 pairs = two rounds of 256 CUs x 4 resident pairs of the 200-bin shape), each slab's download running under the
-    // next slab's kernels -- at most RAFTX_XI_SLABS (default 6) of them, every slab but the last a multiple of 2 048 pairs.
-    if (with_xi && !pipelined && nChunk <= 0 && !getenv("RAFTX_SWEEP_SPLIT") && pairs >= 4096) {
-        static const int max_slabs = getenv("RAFTX_XI_SLABS") ? atoi(getenv("RAFTX_XI_SLABS")) : 6;
-        if (max_slabs > 1) {
-            const long round_pairs = 2048;
-            long per = round_pairs;
-            while ((pairs + per - 1) / per > max_slabs) per += round_pairs;
-            const int dper = (int)std::max<long>(1, per / std::max(nCase, 1));
-            std::vector<int> b{0};
-            while (b.back() + dper < nDesign) b.push_back(b.back() + dper);
-            b.push_back(nDesign);
-            return b;
-        }
-    }
+    // The responses are wanted and nothing else is in flight to hide their download behind: four slabs, 20 / 30 / 30 / 20 % --
+    // a small first one (its upload is what everything waits for), a small last one (its download is what is left when the
+    // kernels have finished), each slab's download running under the next slab's kernels.  Measured on one box
+    // (scripts/gpu_r4_iso3.sh): 6.2-6.4 ms against 6.8-7.0 for five equal slabs of 2 048 pairs and 6.6 for three; RAFTX_XI_SLABS=0
+    // keeps the two-block form.
+    static const bool xi_slabs = !(getenv("RAFTX_XI_SLABS") && !atoi(getenv("RAFTX_XI_SLABS")));
+    (void)nCase;
     std::vector<double> fr;
     static const char *env = getenv("RAFTX_SWEEP_SPLIT");
     if (env && nChunk <= 0) {
@@ -2616,6 +2607,7 @@ static std::vector<int> sweep_bounds(int nDesign, long pairs, int nChunk, bool p
     if (fr.empty()) {
         if (nChunk > 0) fr.assign((size_t)nChunk, 1.0);
         else if (pipelined) fr = {1.0};              // the crossing in the other slot hides this one's upload: one launch, no extra tail
+        else if (with_xi && xi_slabs && pairs >= 4096) fr = {0.2, 0.3, 0.3, 0.2};
         else if (pairs >= 3072) fr = {0.2, 0.8};     // measured on MI355X at 10 k pairs (profiles/r02_crossing_splits.txt)
         else fr = {1.0};
     }
@@ -2866,9 +2858,10 @@ extern "C" int raftx_sweep_launch(raftx_ctx *c, int slot) {
                 if (sl != slot && c->slots[sl].prepared && !c->slots[sl].blk.empty() && c->slots[sl].blk[0])
                     if (hipStreamWaitEvent(c->sGen, c->slots[sl].blk[0]->evZ, 0) != hipSuccess) rc = -2;
         }
-        // slabs of a crossing that downloads its responses (sweep_bounds): the tables of slab b + 1 are generated on the side
-        // stream while slab b solves -- with five slabs the serial generation was 0.4 ms per slab (RAFTX_XI_GEN_OVERLAP=0)
-        static const bool xi_gen_overlap = !(getenv("RAFTX_XI_GEN_OVERLAP") && !atoi(getenv("RAFTX_XI_GEN_OVERLAP")));
+        // slabs of a crossing that downloads its responses (sweep_bounds): RAFTX_XI_GEN_OVERLAP=1 generates the tables of slab
+        // b + 1 on the side stream while slab b solves -- measured with five slabs: 6.71 against 6.74 ms, so it stays off (the
+        // fused kernel's HIP-event time then is that launch alone)
+        static const bool xi_gen_overlap = getenv("RAFTX_XI_GEN_OVERLAP") && atoi(getenv("RAFTX_XI_GEN_OVERLAP"));
         const bool gen_side = (pipelined && gen_overlap) || (b > 0 && Xi != nullptr && nB > 2 && xi_gen_overlap);
         if (!rc) rc = build_phase2(sub, nullptr, gen_side ? c->sGen : nullptr);
         if (!rc && b == 0 && pipelined && gen_overlap) {
