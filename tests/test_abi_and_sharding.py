@@ -60,6 +60,7 @@ def test_product_fails_loudly_without_a_gpu():
     from raft_amd._abi import RaftxError
     with pytest.raises(RaftxError):
         backend.hip_library().context(0)
+    assert backend.hip_library().device_count() == 0          # what bench.py's rank launcher checks --gpus against
 
 
 def test_shard_bounds_cover_and_balance():

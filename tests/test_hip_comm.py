@@ -167,3 +167,11 @@ def test_two_rank_rccl_over_two_gpus(tmp_path, hip_lib, hip_ctx):
     std = s.run_stats(hip_ctx)["std"]
     assert np.array_equal(got["Xi"].view(np.uint64), one["Xi"].view(np.uint64))
     assert np.array_equal(got["niter"], one["niter"]) and np.array_equal(got["std"].view(np.uint64), std.view(np.uint64))
+
+
+@pytest.mark.gpu
+def test_device_count_is_what_the_rank_launcher_sees(oracle_lib):
+    """raftx_device_count: bench.py --gpus N refuses to start more ranks than this (the oracle has no devices)."""
+    from raft_amd import backend
+    assert backend.hip_library().device_count() >= 1
+    assert oracle_lib.device_count() == 0
