@@ -42,3 +42,35 @@ def test_gpus_must_match_the_world_an_external_launcher_made():
 def test_more_gpus_than_the_host_has_fails_loudly():
     r = _bench(["--gpus", "2"])                            # this container has no GPU at all
     assert r.returncode == 2 and "GPU(s) visible" in r.stderr
+
+
+import pytest  # noqa: E402
+
+
+@pytest.mark.gpu
+def test_two_ranks_on_one_gpu_through_bench_itself():
+    """`python bench.py --gpus 2` with no launcher around it, both ranks on device 0 (RAFTX_BENCH_DEVICE=0: RCCL refuses two
+    ranks on one device, the exchange steps take the host transport and the line says so): two ranks are started, the
+    statistics of both are gathered inside the timed steps, rank 0 prints ONE line that says n_gpus = 2 and carries the
+    per-rank / gather / single-rank keys."""
+    r = _bench(["--gpus", "2", "--steps", "3", "--warmup", "1", "--designs", "512", "--no-cpu-baseline"], RAFTX_BENCH_DEVICE="0")
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1 and r.stdout.strip().splitlines()[-1] == lines[0], r.stdout[-500:]     # the JSON line is the LAST line
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["config"]["designs_per_gpu"] == 512
+    assert "host-tcp" in out["config"]["gather"]
+    assert len(out["per_rank_ms"]["all"]) == 2 and out["gather_ms"]["rank0"] >= 0.0
+    assert 0.2 < out["scaling_efficiency"] < 1.2 and out["single_rank_same_invocation"]["value"] > 0
+    assert out["parity"]["niter_mismatches_vs_reference"] == 0
+
+
+@pytest.mark.gpu
+def test_sharded_qtf_workload_through_bench_itself():
+    """--workload c5 with two ranks on one GPU: rows of every QTF interleaved over the ranks, one SUM-reduce onto rank 0; the
+    reduced matrices are Hermitian and finite (asserted inside), the line carries both ranks' kernel times."""
+    r = _bench(["--gpus", "2", "--workload", "c5", "--steps", "2", "--sets", "2"], RAFTX_BENCH_DEVICE="0")
+    assert r.returncode == 0, r.stderr[-2000:]
+    out = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert out["n_gpus"] == 2 and out["scaling"] == "strong" and out["hermitian"] is True
+    assert len(out["per_rank_ms"]["qtf_kernels"]) == 2
