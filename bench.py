@@ -699,9 +699,9 @@ def main():
                 if os.environ.get("RAFTX_BENCH_DEBUG"):
                     print("  xi step %d collected at %.3f ms" % (i, 1e3 * time.perf_counter()), file=sys.stderr)
         xi_steps(9)                                       # untimed: every one of the four slots reaches its steady-state configuration
-        # a streak of 30 batches (or K if larger): with four batches in flight the fill and the drain of the pipeline are
+        # a streak of 60 batches (or K if larger): with four batches in flight the fill and the drain of the pipeline are
         # worth two steps (the first batch's upload and kernels, the last batch's download), which a long sweep does not see
-        n_xi = max(args.steps, int(os.environ.get("RAFTX_BENCH_XI_STEPS", "30")))
+        n_xi = max(args.steps, int(os.environ.get("RAFTX_BENCH_XI_STEPS", "60")))
         ctx.synchronize()
         t1 = time.perf_counter()
         xi_steps(n_xi)
