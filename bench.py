@@ -464,7 +464,7 @@ def main():
     ap.add_argument("--pageable", action="store_true", help="descriptors in ordinary NumPy memory instead of page-locked")
     ap.add_argument("--resident", action="store_true", help="also time the fused kernel alone, whole batch resident in HBM")
     ap.add_argument("--no-stream", action="store_true", help="time isolated blocking calls (raftx_sweep_stats) instead of streaming the "
-                                                             "steps through the library's three slots (raftx_sweep_prepare / _launch / _wait)")
+                                                             "steps through the library's slots (raftx_sweep_prepare / _launch / _wait)")
     ap.add_argument("--no-cpu-baseline", action="store_true", help="skip the oracle leg (cpu_baseline and the all-design check)")
     ap.add_argument("--depth", type=int, default=0, help="batches in flight when the steps are streamed: 2 = submit(i+1), wait(i) (default); 4 = prepare(i+3), launch(i+2), wait(i) "
                                                       "(default with --xi-out: the download of a batch takes longer than its kernels); "
