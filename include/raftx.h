@@ -222,6 +222,12 @@ int raftx_solve_system(raftx_ctx *ctx, int nSys, int nUnit, int nRhs, int nw,
  * with the unit's T matrix between the two calls are host glue (raft_amd/dropin.py Engine._solve_general). */
 int raftx_solve_dense(raftx_ctx *ctx, int n, int nRhs, int nw, const double *w, const double *M, const double *B,
                       const double *C, int freq_mask, const raftx_c128 *F, raftx_c128 *Xi, raftx_c128 *Z);
+/* The same for nSys systems of one size in ONE launch (a sweep of flexible units x sea states, raft_amd/flex.py): every
+ * array gains a leading system axis -- M, B [nSys,n,n(,nw)], C [nSys,n,n], F, Xi [nSys,nRhs,n,nw], Z [nSys,n,n,nw] or
+ * NULL; w [nw] and freq_mask are shared. */
+int raftx_solve_dense_batch(raftx_ctx *ctx, int nSys, int n, int nRhs, int nw, const double *w, const double *M,
+                            const double *B, const double *C, int freq_mask, const raftx_c128 *F, raftx_c128 *Xi,
+                            raftx_c128 *Z);
 
 /* The same coupled solve fed from the RESIDENT results of raftx_solve_dynamics_device (which must have
  * kept Z and F_wave): consecutive groups of nUnit designs are the units of one array; for group g,

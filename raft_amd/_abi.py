@@ -31,7 +31,7 @@ EXPORTS = (
     "raftx_sweep_prepare",
     "raftx_sweep_launch",
     "raftx_sweep_wait",
-    "raftx_sweep_cancel", "raftx_device_count",
+    "raftx_sweep_cancel", "raftx_device_count", "raftx_solve_dense_batch",
     "raftx_comm_unique_id", "raftx_comm_init", "raftx_comm_destroy", "raftx_comm_broadcast", "raftx_comm_gather_rows",
     "raftx_comm_gather_xi", "raftx_comm_reduce_sum",
 )
@@ -116,6 +116,8 @@ class RaftxLib:
         L.raftx_channel_stats.restype = C.c_int
         L.raftx_solve_dense.argtypes = [_vp, C.c_int, C.c_int, C.c_int, _vp, _vp, _vp, _vp, C.c_int, _vp, _vp, _vp]
         L.raftx_solve_dense.restype = C.c_int
+        L.raftx_solve_dense_batch.argtypes = [_vp, C.c_int, C.c_int, C.c_int, C.c_int, _vp, _vp, _vp, _vp, C.c_int, _vp, _vp, _vp]
+        L.raftx_solve_dense_batch.restype = C.c_int
         L.raftx_device_locality.argtypes = [C.c_int, C.c_char_p, C.c_int, C.POINTER(C.c_int)]
         L.raftx_device_locality.restype = C.c_int
         L.raftx_host_alloc.argtypes = [_vp, C.c_size_t, C.POINTER(_vp)]
@@ -724,6 +726,30 @@ class Context:
         rc = self.rlib.lib.raftx_solve_dense(self._h, n, nR, nw, _ptr(w), _ptr(M), _ptr(B), _ptr(C_), mask, _ptr(F),
                                              _ptr(Xi), _ptr(Z))
         self._check(rc, "raftx_solve_dense")
+        return (Xi, Z) if want_Z else Xi
+
+    def solve_dense_batch(self, w, M, B, C_, F, want_Z=False):
+        """Xi [nSys,nRhs,n,nw] (and Z [nSys,n,n,nw]) of nSys n-DOF systems in one launch: raftx_solve_dense_batch.
+        M, B: [nSys,n,n] or [nSys,n,n,nw]; C_ [nSys,n,n]; F [nSys,nRhs,n,nw]."""
+        w = _f64(w)
+        nw = len(w)
+        F = _c128(F)
+        nS, nR, n = F.shape[0], F.shape[1], F.shape[2]
+        if F.shape != (nS, nR, n, nw):
+            raise ValueError("F must be [nSys,nRhs,n,nw]")
+        M, B = _f64(M), _f64(B)
+        mask = 0
+        for bit, A, name in ((1, M, "M"), (2, B, "B")):
+            if A.shape == (nS, n, n, nw):
+                mask |= bit
+            elif A.shape != (nS, n, n):
+                raise ValueError("%s must be [nSys,n,n] or [nSys,n,n,nw]" % name)
+        C_ = _f64(C_, (nS, n, n), "C")
+        Xi = np.empty((nS, nR, n, nw), dtype=np.complex128)
+        Z = np.empty((nS, n, n, nw), dtype=np.complex128) if want_Z else None
+        rc = self.rlib.lib.raftx_solve_dense_batch(self._h, nS, n, nR, nw, _ptr(w), _ptr(M), _ptr(B), _ptr(C_), mask, _ptr(F),
+                                                   _ptr(Xi), _ptr(Z))
+        self._check(rc, "raftx_solve_dense_batch")
         return (Xi, Z) if want_Z else Xi
 
     def synchronize(self):

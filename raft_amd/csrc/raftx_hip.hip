@@ -382,9 +382,19 @@ __global__ void __launch_bounds__(256) k_solve_dense(int n, int nRhs, int nw, co
     __shared__ double rbest[4];
     __shared__ int rrow[4];
     const int iw = blockIdx.x, ld = n + nRhs, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const bool mw = freq_mask & 1, bw = freq_mask & 2;
+    {                                                     // blockIdx.y: the system of a batch (raftx_solve_dense_batch)
+        const size_t sy = blockIdx.y, nn = (size_t)n * n;
+        M += sy * nn * (mw ? nw : 1);
+        B += sy * nn * (bw ? nw : 1);
+        C += sy * nn;
+        F += sy * nRhs * n * nw;
+        Xi += sy * nRhs * n * nw;
+        if (Zout) Zout += sy * nn * nw;
+        work += sy * nw * n * ld;
+    }
     cplx *A = work + (size_t)iw * n * ld;
     const double ww = w[iw];
-    const bool mw = freq_mask & 1, bw = freq_mask & 2;
     for (int e = tid; e < n * ld; e += 256) {
         const int r = e / ld, c = e % ld;
         cplx v;
@@ -494,6 +504,15 @@ __global__ void __launch_bounds__(1024) k_solve_dense_reg(int n, int nRhs, int n
     const int iw = blockIdx.x, ld = n + nRhs, tid = threadIdx.x, ti = tid & 31, tj = tid >> 5;
     const double ww = w[iw];
     const bool mw = freq_mask & 1, bw = freq_mask & 2;
+    {                                                     // blockIdx.y: the system of a batch (raftx_solve_dense_batch)
+        const size_t sy = blockIdx.y, nn = (size_t)n * n;
+        M += sy * nn * (mw ? nw : 1);
+        B += sy * nn * (bw ? nw : 1);
+        C += sy * nn;
+        F += sy * nRhs * n * nw;
+        Xi += sy * nRhs * n * nw;
+        if (Zout) Zout += sy * nn * nw;
+    }
     // entries of the thread: block rows 0 .. RB-2 in registers (80 at RB = CB = 5: 1024 threads leave 128 per lane), the last
     // block row in LDS, one column of 16 bytes per thread and block column
     extern __shared__ __attribute__((aligned(16))) unsigned char dense_tail_[];
@@ -2279,42 +2298,55 @@ extern "C" int raftx_solve_system(raftx_ctx *c, int nSys, int nUnit, int nRhs, i
     return 0;
 }
 
-extern "C" int raftx_solve_dense(raftx_ctx *c, int n, int nRhs, int nw, const double *w, const double *M, const double *B,
-                                 const double *C, int freq_mask, const raftx_c128 *F, raftx_c128 *Xi, raftx_c128 *Z) {
+static int solve_dense_impl(raftx_ctx *c, int nSys, int n, int nRhs, int nw, const double *w, const double *M, const double *B,
+                            const double *C, int freq_mask, const raftx_c128 *F, raftx_c128 *Xi, raftx_c128 *Z) {
     if (!c) return -1;
-    if (n < 1 || nRhs < 1 || nw < 1 || !w || !M || !B || !C || !F || !Xi) FAIL(c, "solve_dense: bad arguments");
+    if (nSys < 0 || n < 1 || nRhs < 1 || nw < 1 || !w || !M || !B || !C || !F || !Xi) FAIL(c, "solve_dense: bad arguments");
     if (n + nRhs > DENSE_MAX_LD) FAIL(c, "solve_dense: %d DOFs + %d right-hand sides exceed %d", n, nRhs, DENSE_MAX_LD);
+    if (nSys > 65535) FAIL(c, "solve_dense_batch: at most 65 535 systems per call");
+    if (nSys == 0) return 0;
     HIPCHK(c, hipSetDevice(c->device));
     Scratch sc(c);
-    const size_t nn = (size_t)n * n, nf = (size_t)nRhs * n * nw;
-    const size_t nM = nn * ((freq_mask & 1) ? nw : 1), nB = nn * ((freq_mask & 2) ? nw : 1);
-    double *dw = sc.alloc<double>(nw), *dM = sc.alloc<double>(nM), *dB = sc.alloc<double>(nB), *dC = sc.alloc<double>(nn);
-    cplx *dF = sc.alloc<cplx>(nf), *dX = sc.alloc<cplx>(nf), *dA = sc.alloc<cplx>((size_t)nw * n * (n + nRhs));
-    cplx *dZ = Z ? sc.alloc<cplx>(nn * nw) : nullptr;
-    if (!dw || !dM || !dB || !dC || !dF || !dX || !dA || (Z && !dZ)) FAIL(c, "solve_dense: device allocation failed");
+    static const bool dense_l2 = getenv("RAFTX_DENSE_L2") && atoi(getenv("RAFTX_DENSE_L2"));     // tuning / tests: the L2-workspace kernel
+    // the register-resident kernel (the flexible deck: 150 + 1; measured: 0.59 against 1.34 ms at 150 x 40 bins, 0.30 against
+    // 0.22 at 60 DOFs)
+    const bool reg = !dense_l2 && n + nRhs <= 160 && n > 96;
+    const size_t nn = (size_t)n * n, nf = (size_t)nSys * nRhs * n * nw;
+    const size_t nM = (size_t)nSys * nn * ((freq_mask & 1) ? nw : 1), nB = (size_t)nSys * nn * ((freq_mask & 2) ? nw : 1);
+    double *dw = sc.alloc<double>(nw), *dM = sc.alloc<double>(nM), *dB = sc.alloc<double>(nB), *dC = sc.alloc<double>((size_t)nSys * nn);
+    cplx *dF = sc.alloc<cplx>(nf), *dX = sc.alloc<cplx>(nf);
+    cplx *dA = reg ? nullptr : sc.alloc<cplx>((size_t)nSys * nw * n * (n + nRhs));
+    cplx *dZ = Z ? sc.alloc<cplx>((size_t)nSys * nn * nw) : nullptr;
+    if (!dw || !dM || !dB || !dC || !dF || !dX || (!reg && !dA) || (Z && !dZ)) FAIL(c, "solve_dense: device allocation failed");
     H2D(c, dw, w, nw * sizeof(double));
     H2D(c, dM, M, nM * sizeof(double));
     H2D(c, dB, B, nB * sizeof(double));
-    H2D(c, dC, C, nn * sizeof(double));
+    H2D(c, dC, C, (size_t)nSys * nn * sizeof(double));
     H2D(c, dF, F, nf * sizeof(cplx));
     HIPCHK(c, hipEventRecord(c->ev0, c->stream));
-    static const bool dense_l2 = getenv("RAFTX_DENSE_L2") && atoi(getenv("RAFTX_DENSE_L2"));     // tuning / tests: the L2-workspace kernel
-    if (!dense_l2 && n + nRhs <= 160 && n > 96)          // the register-resident kernel (the flexible deck: 150 + 1; measured:
-                                                          // 0.59 against 1.34 ms at 150 x 40 bins, 0.30 against 0.22 at 60 DOFs)
-    {
+    const dim3 grid((unsigned)nw, (unsigned)nSys);
+    if (reg) {
         const size_t tail_lds = (size_t)5 * 1024 * sizeof(cplx);         // the last block row of every thread (see the kernel)
         if (prep_lds(c, k_solve_dense_reg<5, 5>, tail_lds)) return -1;
-        hipLaunchKernelGGL((k_solve_dense_reg<5, 5>), dim3((unsigned)nw), dim3(1024), tail_lds, c->stream, n, nRhs, nw, dw, dM, dB,
-                           dC, freq_mask, dF, dX, dZ);
+        hipLaunchKernelGGL((k_solve_dense_reg<5, 5>), grid, dim3(1024), tail_lds, c->stream, n, nRhs, nw, dw, dM, dB, dC, freq_mask,
+                           dF, dX, dZ);
+    } else {
+        hipLaunchKernelGGL(k_solve_dense, grid, dim3(256), 0, c->stream, n, nRhs, nw, dw, dM, dB, dC, freq_mask, dF, dA, dX, dZ);
     }
-    else
-        hipLaunchKernelGGL(k_solve_dense, dim3((unsigned)nw), dim3(256), 0, c->stream, n, nRhs, nw, dw, dM, dB, dC, freq_mask,
-                           dF, dA, dX, dZ);
     if (finish_timed(c)) return -2;
     D2H(c, Xi, dX, nf * sizeof(cplx));
-    if (Z) D2H(c, Z, dZ, nn * nw * sizeof(cplx));
+    if (Z) D2H(c, Z, dZ, (size_t)nSys * nn * nw * sizeof(cplx));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     return 0;
+}
+extern "C" int raftx_solve_dense(raftx_ctx *c, int n, int nRhs, int nw, const double *w, const double *M, const double *B,
+                                 const double *C, int freq_mask, const raftx_c128 *F, raftx_c128 *Xi, raftx_c128 *Z) {
+    return solve_dense_impl(c, 1, n, nRhs, nw, w, M, B, C, freq_mask, F, Xi, Z);
+}
+extern "C" int raftx_solve_dense_batch(raftx_ctx *c, int nSys, int n, int nRhs, int nw, const double *w, const double *M,
+                                       const double *B, const double *C, int freq_mask, const raftx_c128 *F, raftx_c128 *Xi,
+                                       raftx_c128 *Z) {
+    return solve_dense_impl(c, nSys, n, nRhs, nw, w, M, B, C, freq_mask, F, Xi, Z);
 }
 
 extern "C" int raftx_solve_system_resident(raftx_ctx *c, int nUnit, const double *Mc, const double *Bc, const double *Cc,

@@ -856,6 +856,36 @@ def sweep_from_member_tables(model, base_table, tables, cases, ctx, tol=0.01, po
                          XiStart=model.XiStart, tol=tol, pose=poses, rho=float(f0.rho_water), g=float(f0.g))
 
 
+def flex_sweep_from_models(models, cases, tol=0.01):
+    """A ``raft_amd.flex.FlexSweep``: units with MORE than 6 reduced DOFs (flexible members; one per Model, positioned and
+    with their statics computed) x load cases in one batch -- the fixed point of raft_model.py:966-1302 for every (unit,
+    case) at once: node-by-node strip sweeps of the whole batch in one launch per iteration, every impedance solve of an
+    iteration in one launch (raftx_solve_dense_batch).  What Engine._solve_general does one case at a time.
+    Single strip-theory units only, as there (no potential-flow coefficients, second-order loads, moorMod == 2)."""
+    from .flex import FlexSweep, FlexUnit
+    eng = Engine(ctx=False)
+    units = []
+    f0 = models[0].fowtList[0]
+    for m in models:
+        if len(m.fowtList) != 1 or getattr(m, "ms", None):
+            raise UnsupportedFOWT("arrays of units with more than 6 reduced DOFs are not on the device path")
+        f = m.fowtList[0]
+        if not _general(f):
+            raise UnsupportedFOWT("flex_sweep_from_models is for units with more than 6 reduced DOFs (rigid units: sweep_from_units / "
+                                  "sweep_from_member_tables)")
+        eng._check_supported(f)
+        if len(f.w) != len(f0.w) or not np.array_equal(f.w, f0.w):
+            raise UnsupportedFOWT("the units of a flexible sweep must share their frequency grid")
+        units.append(FlexUnit.from_fowt(f))
+    zeta, beta = [], []
+    for case in cases:
+        _, b, _, z = waves.sea_state(dict(case), f0.w, f0.dw)
+        zeta.append(z)
+        beta.append(b)
+    return FlexSweep(units, f0.w, f0.k, f0.depth, np.array(zeta), np.array(beta), nIter=int(models[0].nIter),
+                     XiStart=models[0].XiStart, tol=tol)
+
+
 _default_engine = Engine()
 
 

@@ -99,6 +99,62 @@ def _check_solve(ctx):
         eng.saveTurbineOutputs(fowt, {}, case_from_fixture(fx["cases"][0]))
 
 
+def _check_flex_sweep(ctx, n_unit):
+    """raft_amd.flex.FlexSweep: n_unit copies of the flexible deck x three sea states in one batch (node sweeps of the whole
+    batch in one launch per iteration, every impedance solve of an iteration in one launch) equal the drop-in's one-case-
+    at-a-time solveDynamics -- responses, iteration counts, convergence flags, B_hydro_drag -- and the live reference."""
+    fx, model = load_model_fixture("flex_volturnus.npz")
+    eng = dropin.Engine(ctx)
+    base = case_from_fixture(fx["cases"][0])
+    cases = [base, dict(base, wave_height=4.0, wave_period=9.0, wave_heading=-20.0), dict(base, wave_height=1.0, wave_period=6.0)]
+    single, nit, flg, Bd = [], [], [], []
+    for c in cases:
+        single.append(eng.solveDynamics(model, dict(c)).copy())
+        nit.append(int(model._raftx_niter[0]))
+        flg.append(int(model._raftx_flags[0]))
+        Bd.append(np.array(model.fowtList[0].B_hydro_drag))
+    sw = dropin.flex_sweep_from_models([model] * n_unit, cases)
+    out = sw.run(ctx, want_Z=(n_unit == 1))
+    assert out["Xi"].shape == (n_unit, 3, 1, 150, model.nw)
+    for d in range(n_unit):
+        assert list(out["niter"][d]) == nit and list(out["flags"][d] & 1) == flg
+        for ic in range(3):
+            assert rel_err(out["Xi"][d, ic, 0], single[ic][0]) < 1e-10
+            assert rel_err(out["B_drag"][d, ic], Bd[ic]) < 1e-12
+    assert rel_err(out["Xi"][0, 0, :1], ref_headings(fx["cases"][0])[0][:1]) < 1e-8
+    if n_unit == 1:
+        eng.solveDynamics(model, dict(cases[2]))
+        assert rel_err(out["Z"][0, 2], model.fowtList[0].Z) < 1e-12
+    with pytest.raises(dropin.UnsupportedFOWT):             # rigid units go through the 6-DOF sweeps
+        dropin.flex_sweep_from_models([load_model_fixture("c1_oc3spar.npz")[1]], cases)
+
+
+def test_oracle_flexible_sweep(oracle_ctx):
+    _check_flex_sweep(oracle_ctx, 1)
+
+
+@pytest.mark.gpu
+def test_hip_flexible_sweep(hip_ctx):
+    _check_flex_sweep(hip_ctx, 3)
+
+
+@pytest.mark.gpu
+def test_hip_solve_dense_batch_equals_single_calls(hip_ctx, oracle_ctx):
+    """raftx_solve_dense_batch: five 150-DOF systems (register-resident kernel) and five 40-DOF ones (L2-workspace kernel)
+    in one launch each equal the single-system calls bit for bit, and the oracle to rounding."""
+    rng = np.random.default_rng(5)
+    for n in (150, 40):
+        probs = [_dense_problem(rng, n, 2, 6, 0) for _ in range(5)]
+        w = probs[0][0]
+        M, B, C, F = (np.array([p[i] for p in probs]) for i in (1, 2, 3, 4))
+        Xb, Zb = hip_ctx.solve_dense_batch(w, M, B, C, F, want_Z=True)
+        for i in range(5):
+            Xs, Zs = hip_ctx.solve_dense(w, M[i], B[i], C[i], F[i], want_Z=True)
+            assert np.array_equal(Xb[i].view(np.uint64), Xs.view(np.uint64)) and np.array_equal(Zb[i].view(np.uint64), Zs.view(np.uint64))
+        Xo = oracle_ctx.solve_dense_batch(w, M, B, C, F)
+        assert rel_err(Xb, Xo) < 1e-10
+
+
 def test_oracle_solve_dense(oracle_ctx):
     _check_dense(oracle_ctx)
 
