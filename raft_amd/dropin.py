@@ -798,7 +798,7 @@ def sweep_from_models(models, cases, tol=0.01):
     for m in models:
         f = m.fowtList[0]
         if int(f.nDOF) != 6:
-            raise UnsupportedFOWT("device path covers rigid 6-DOF FOWTs (nDOF=%d)" % f.nDOF)
+            raise UnsupportedFOWT("this sweep covers rigid 6-DOF FOWTs (nDOF=%d): units with flexible members go through flex_sweep_from_models" % f.nDOF)
         rows.append((pack_fowt(f),) + unit_matrices(f, m.nw))
     return Sweep.from_fowts(rows, f0.w, f0.k, f0.depth, np.array(zeta), np.array(beta),
                             nIter=int(models[0].nIter), XiStart=models[0].XiStart, tol=tol)
@@ -832,7 +832,7 @@ def sweep_from_member_tables(model, base_table, tables, cases, ctx, tol=0.01, po
     from . import geometry as G
     f0 = model.fowtList[0]
     if int(f0.nDOF) != 6:
-        raise UnsupportedFOWT("device path covers rigid 6-DOF FOWTs (nDOF=%d)" % f0.nDOF)
+        raise UnsupportedFOWT("the geometry generator covers rigid 6-DOF FOWTs (nDOF=%d): units with flexible members are built upstream and swept with flex_sweep_from_models" % f0.nDOF)
     M0, B0, C0, MBw = unit_matrices(f0, model.nw)
     if MBw is not None:
         raise UnsupportedFOWT("frequency-dependent base matrices: pass them per design through GeometrySweep(MBw=...)")
