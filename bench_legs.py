@@ -223,3 +223,42 @@ def c5_qtf(ctx, n_set=16):
                               "one_200x200_qtf_ms": (o["qtf_kernels_ms"] + o["kim_yue_kernels_ms"]) / o["sets"],
                               "strip_pairs_per_s": o["pairs"] * o["strips"] / (o["qtf_kernels_ms"] * 1e-3),
                               "roofline": _roof(flops_o, o["qtf_kernels_ms"], "k_qtf_pairs (+ k_qtf_tables, same HIP-event bracket)")}}
+
+
+def flex_sweep(ctx, n_unit=16):
+    """The first widening beyond the rigid 6-DOF scope: the reference's flexible deck (tests/test_data/VolturnUS-S-flexible.yaml,
+    150 reduced DOFs, 40 bins) -- ``n_unit`` units x 3 sea states as ONE batch (raft_amd/flex.py: node-by-node strip sweeps of
+    the whole batch in one launch per iteration, every impedance solve of an iteration in one raftx_solve_dense_batch launch)
+    against the drop-in's one-case-at-a-time Model.solveDynamics and the live-reference golden."""
+    from raft_amd import dropin, snapshot
+    from raft_amd.metrics import rel_err
+    fx, model = snapshot.load_model_fixture("flex_volturnus.npz")
+    eng = dropin.Engine(ctx)
+    base = snapshot.case_from_fixture(fx["cases"][0])
+    cases = [base, dict(base, wave_height=4.0, wave_period=9.0, wave_heading=-20.0), dict(base, wave_height=1.0, wave_period=6.0)]
+    single, nit = [], []
+    t_single = 0.0
+    for rep in range(2):
+        single, nit = [], []
+        t0 = time.perf_counter()
+        for c in cases:
+            single.append(eng.solveDynamics(model, dict(c)).copy())
+            nit.append(int(model._raftx_niter[0]))
+        t_single = (time.perf_counter() - t0) / len(cases)
+    sw = dropin.flex_sweep_from_models([model] * n_unit, cases)
+    out, t_batch = None, 0.0
+    for rep in range(2):
+        t0 = time.perf_counter()
+        out = sw.run(ctx)
+        t_batch = time.perf_counter() - t0
+    err = max(rel_err(out["Xi"][d, ic, 0], single[ic][0]) for d in range(n_unit) for ic in range(3))
+    Xr = np.asarray(fx["cases"][0]["Xi"])[:1]
+    err_ref = float(rel_err(out["Xi"][0, 0, :1], Xr))
+    assert err < 1e-9 and err_ref < 1e-7 and all(list(out["niter"][d]) == nit for d in range(n_unit)), (err, err_ref)
+    pairs = n_unit * 3
+    return {"config": "VolturnUS-S-flexible (150 reduced DOFs, %d bins): %d units x 3 sea states in one batch" % (model.nw, n_unit),
+            "golden": "tests/golden/flex_volturnus.npz (live reference)", "dropin_ms_per_unit_case": 1e3 * t_single,
+            "batch_ms": 1e3 * t_batch, "batch_ms_per_unit_case": 1e3 * t_batch / pairs, "speedup_vs_dropin": t_single * pairs / t_batch,
+            "kernel_ms_strip_sweeps": float(out["kernel_ms"][0]), "kernel_ms_dense_solves": float(out["kernel_ms"][1]),
+            "max_rel_err_vs_dropin": float(err), "rel_err_vs_reference": err_ref, "iterations": [int(x) for x in out["niter"][0]],
+            "reference_numpy_s_per_case_build_container": float(fx["cases"][0].get("ref_seconds", float("nan")))}
