@@ -32,7 +32,8 @@ def _dense_problem(rng, n, nR, nw, mask):
 
 def _check_dense(ctx, tol=1e-10):
     rng = np.random.default_rng(5)
-    for n, nR, nw, mask in ((1, 1, 3, 0), (7, 2, 5, 1), (37, 3, 4, 2), (150, 2, 6, 3), (257, 1, 2, 0)):
+    for n, nR, nw, mask in ((1, 1, 3, 0), (7, 2, 5, 1), (37, 3, 4, 2), (97, 1, 3, 0), (128, 2, 2, 1), (150, 2, 6, 3), (158, 2, 2, 0),
+                            (159, 2, 2, 0), (257, 1, 2, 0)):
         w, M, B, C, F = _dense_problem(rng, n, nR, nw, mask)
         Xi, Z = ctx.solve_dense(w, M, B, C, F, want_Z=True)
         assert Xi.shape == (nR, n, nw) and Z.shape == (n, n, nw)
