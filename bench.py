@@ -408,6 +408,15 @@ def launch_ranks(n, argv):
     return rc
 
 
+def comm_fallback(rehearsal):
+    """What the ranks do when the RCCL communicator cannot be created (or its probe collective fails): "host" = all
+    ranks move the exchange step onto the rendezvous channel together and the JSON line's `gather` says so, with the
+    reason; "error" = the bench fails.  The sweep has no data-path collective (the gather carries 56 B per
+    design-case), so a measured line that names its transport is worth more than no line: "host" unless
+    RAFTX_BENCH_COMM_FALLBACK=error."""
+    return "host" if rehearsal else os.environ.get("RAFTX_BENCH_COMM_FALLBACK", "host")
+
+
 def main_sharded_leg(args, world, rank, local, rehearsal):
     """--workload c4 | c5: the sharded forms of configs[3] / configs[4] as the timed workload (bench_legs.py)."""
     import bench_legs
@@ -415,7 +424,7 @@ def main_sharded_leg(args, world, rank, local, rehearsal):
     ctx = backend.hip_library().context(local)
     comm = gather_kind = None
     if world > 1:
-        comm, gather_kind = rcomm.from_env(ctx, prefer="rccl", fallback="host" if rehearsal else "error")
+        comm, gather_kind = rcomm.from_env(ctx, prefer="rccl", fallback=comm_fallback(rehearsal))
     ctx.synchronize()
     if comm is not None:
         comm.barrier()
@@ -539,7 +548,7 @@ def main():
         # the exchange step gets its own context (= its own stream): the gather of step i must not queue behind the
         # kernels of step i + 1, which are already on the solver context's stream when the steps are streamed
         ctx_comm = backend.hip_library().context(local)
-        comm, gather_kind = rcomm.from_env(ctx_comm, prefer="rccl", fallback="host" if rehearsal else "error")
+        comm, gather_kind = rcomm.from_env(ctx_comm, prefer="rccl", fallback=comm_fallback(rehearsal))
 
     stream_steps = not args.no_stream
     Xi_pinned = [ctx.pinned_empty((nD, 1, 1, 6, nw)) for _ in range(4 if stream_steps else 1)] if args.xi_out else [None, None, None, None]

@@ -22,6 +22,8 @@ import json
 import os
 import socket
 import struct
+import sys
+import threading
 import time
 
 import numpy as np
@@ -261,15 +263,35 @@ class HostComm:
         self.peers, self.sock = {}, None
 
 
+def _attempt(fn, seconds):
+    """None if fn() returned within the deadline, else what went wrong.  fn runs on a daemon thread (ctypes releases the
+    GIL inside the library): a call that never returns is abandoned, not waited for."""
+    box = {}
+
+    def run():
+        try:
+            fn()
+        except BaseException as e:                      # noqa: BLE001 -- reported to the caller
+            box["e"] = "%s: %s" % (type(e).__name__, e)
+    t = threading.Thread(target=run, daemon=True)
+    t.start()
+    t.join(seconds)
+    if t.is_alive():
+        return "no return within %.0f s" % seconds
+    return box.get("e")
+
+
 class RcclComm:
     """The library's RCCL communicator on ``ctx`` (raftx_comm_*); ``boot`` is the HostComm that carried the unique id and
     keeps serving the tiny control messages (counts)."""
 
     kind = "rccl"
 
-    def __init__(self, ctx, boot):
+    def __init__(self, ctx, boot, deadline=None):
         self.ctx, self.boot = ctx, boot
         self.rank, self.world = boot.rank, boot.world
+        if deadline is None:
+            deadline = float(os.environ.get("RAFTX_COMM_INIT_TIMEOUT", "180"))
         uid = None
         if self.rank == 0:
             try:
@@ -279,7 +301,21 @@ class RcclComm:
         uid = boot.bcast_bytes(uid)
         if len(uid) != 128:
             raise RuntimeError("no RCCL unique id from rank 0: %s" % uid.decode(errors="replace"))
-        ctx.comm_init(self.rank, self.world, uid)
+        # ncclCommInitRank is collective and blocks: a rank that fails (or never arrives) leaves the others inside it.  It
+        # runs under a deadline, and the ranks AGREE on the outcome over the rendezvous channel before anyone uses the
+        # communicator -- so that they fail, or fall back, together.
+        self._agree(_attempt(lambda: ctx.comm_init(self.rank, self.world, uid), deadline), "ncclCommInitRank")
+        # one probe collective before the communicator is trusted with results: 1 + 2 + .. + world on the root
+        probe = np.array([self.rank + 1.0])
+        err = _attempt(lambda: ctx.comm_reduce_sum(probe, 0), deadline)
+        if err is None and self.rank == 0 and probe[0] != self.world * (self.world + 1) / 2:
+            err = "probe reduction gave %r, expected %r" % (probe[0], self.world * (self.world + 1) / 2)
+        self._agree(err, "probe ncclReduce")
+
+    def _agree(self, err, what):
+        bad = self.boot.all_max(1.0 if err else 0.0)
+        if bad:
+            raise RuntimeError("%s: %s" % (what, err or "another rank failed"))
 
     def barrier(self):
         self.boot.barrier()
@@ -340,10 +376,12 @@ class RcclComm:
 
 
 def from_env(ctx=None, prefer="rccl", environ=None, fallback="error"):
-    """(comm, kind) for this process from the launcher's environment.  prefer="rccl" needs a device context.  If the RCCL
-    communicator cannot be created the ranks fail together (ncclCommInitRank is collective) -- a sweep whose ranks own
-    distinct GPUs must not quietly move its exchange steps onto TCP.  fallback="host" is for rehearsals with several
-    ranks on ONE GPU (which RCCL refuses): the host transport is used and ``kind`` says so."""
+    """(comm, kind) for this process from the launcher's environment.  prefer="rccl" needs a device context.  The RCCL
+    communicator is created under a deadline (RAFTX_COMM_INIT_TIMEOUT, 180 s), proves itself with one probe reduction,
+    and the ranks agree on the outcome over the rendezvous channel -- so they land in the same branch below together.
+    fallback="error" (default): a sweep whose ranks own distinct GPUs must not quietly move its exchange steps onto TCP.
+    fallback="host": the host transport is used and ``kind`` says so, with the reason (rehearsals with several ranks on
+    ONE GPU, which RCCL refuses; bench.py, whose JSON line carries ``kind``)."""
     env = os.environ if environ is None else environ
     rank, world = int(env.get("RANK", "0")), int(env.get("WORLD_SIZE", "1"))
     addr = env.get("MASTER_ADDR", "127.0.0.1")
@@ -357,5 +395,6 @@ def from_env(ctx=None, prefer="rccl", environ=None, fallback="error"):
             if fallback != "host":
                 boot.close()
                 raise RuntimeError("RCCL communicator of rank %d / %d could not be created: %s" % (rank, world, e)) from e
-            return boot, "host-tcp (RCCL unavailable: %s)" % str(e)[:120]
+            sys.stderr.write("raftx comm: rank %d / %d falls back to the host transport: %s\n" % (rank, world, e))
+            return boot, "host-tcp (RCCL unavailable: %s)" % str(e)[:160]
     return boot, boot.kind
