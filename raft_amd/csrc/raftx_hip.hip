@@ -33,6 +33,7 @@
 #include <cstring>
 #include <chrono>
 #include <map>
+#include <functional>
 #include <mutex>
 #include <thread>
 #include <unordered_map>
@@ -910,6 +911,7 @@ struct raftx_ctx {
     double *pinRes;                      // page-locked landing area of a block's statistics (sweep crossing)
     size_t pinRes_n;
     hipStream_t sCopy, sPrep, sD2H, sGen; // internal streams of raftx_sweep_stats (created on first use)
+    hipStream_t sSlab[2] = {nullptr, nullptr}; // with sGen: the streams the slabs of a crossing with responses out go to (SlabPlan)
     hipStream_t sD2Hlow = nullptr;        // bulk download of the responses: a stream of its own priority class, created when first needed
     CaseSet csets[RAFTX_NSLOT + 1];      // sea-state tables of the sweep crossings: one per crossing in flight + one being replaced
     unsigned long long cset_clock = 0;
@@ -936,6 +938,10 @@ struct raftx_ctx {
     std::vector<int> hS;                 // submerged strips of every design (host copy: LDS classes of the fused kernel)
     int *pairList;                       // device pair lists of a launch split into LDS classes
     size_t pairList_n;
+    int *identList = nullptr;            // 0, 1, 2, ..: the pair list of a launch cut into slabs (SlabPlan)
+    size_t identList_n = 0;
+    std::vector<hipEvent_t> evSlab;      // completion markers of the slabs (no timing), created as needed, kept
+    hipEvent_t evFork = nullptr, evJoin = nullptr;
     unsigned long long *dbg;
     double last_ms;
     bool have_designs, have_cases;
@@ -991,6 +997,9 @@ struct SweepSlot {
     size_t next_p1 = 0;                  // first block whose phase 1 has not been enqueued yet
     std::chrono::steady_clock::time_point t0;
     double tl[4] = {0, 0, 0, 0};
+    size_t nSlabEv = 0;
+    bool slab = false;                   // this crossing's fused launches were cut into slabs (SlabPlan)
+    std::vector<double> tlb;             // RAFTX_SWEEP_DEBUG: host time per block of raftx_sweep_launch (upload enqueued | totals seen | enqueued)
 };
 
 #define MAX_NW 2048
@@ -1126,6 +1135,10 @@ extern "C" void raftx_ctx_destroy(raftx_ctx *c) {
     if (c->bemF) (void)hipFree(c->bemF);
     if (c->rKay) (void)hipFree(c->rKay);
     if (c->pairList) (void)hipFree(c->pairList);
+    if (c->identList) (void)hipFree(c->identList);
+    for (hipEvent_t e : c->evSlab) (void)hipEventDestroy(e);
+    if (c->evFork) (void)hipEventDestroy(c->evFork);
+    if (c->evJoin) (void)hipEventDestroy(c->evJoin);
     free_list(c, c->job.tmp);
     for (int sl = 0; sl < RAFTX_NSLOT; sl++) {
         free_list(c, c->slots[sl].allocs);
@@ -1139,7 +1152,7 @@ extern "C" void raftx_ctx_destroy(raftx_ctx *c) {
                          c->evMem, c->evRed})
         (void)hipEventDestroy(e);
     if (c->sAux) (void)hipStreamDestroy(c->sAux);
-    for (hipStream_t st : {c->sCopy, c->sPrep, c->sD2H, c->sGen, c->sD2Hlow})
+    for (hipStream_t st : {c->sCopy, c->sPrep, c->sD2H, c->sGen, c->sD2Hlow, c->sSlab[0], c->sSlab[1]})
         if (st) (void)hipStreamDestroy(st);
     if (c->owns_stream) (void)hipStreamDestroy(c->stream);
     delete c;
@@ -1862,7 +1875,35 @@ static int ensure_results(raftx_ctx *c, int want_mask, bool need_fe) {
 }
 
 // enqueues the fused fixed point on the ctx stream between ev0 and ev1; does not wait for it
-static int solve_enqueue(raftx_ctx *c, int nIter, double tol, double XiStart, const raftx_c128 *F_extra, int want_mask) {
+// A fused-kernel launch cut into SLABS of the pair list (a crossing that downloads its responses: slab k's download runs
+// while the slabs behind it solve).  The slabs go round-robin to the streams `alts`, none to the ctx stream: pairs are
+// independent, and a grid queued on another stream is handed out as soon as the grids before it are exhausted -- the
+// workgroups of the next slabs fill the CUs a slab's last residency round leaves idle, so a cut costs no tail (slabs as
+// consecutive launches of ONE stream each wait for the slowest pair of the slab before: +0.1-0.15 ms per cut,
+// profiles/r02_crossing_splits.txt), and the ctx stream stays free for what the NEXT block needs (its table generation
+// runs beside these slabs instead of behind them).  `after(p0, p1, s)` enqueues what follows the pairs [p0, p1) on the
+// stream s they were launched on.  The caller joins: `slab_join` orders the ctx stream behind every stream in `alts`.
+// A launch that is already split into LDS classes is not cut again: it runs on the ctx stream, one call of `after`.
+struct SlabPlan {
+    std::vector<size_t> bnd;                                             // 0 = bnd[0] < .. < bnd.back() = pairs of the ctx
+    std::vector<hipStream_t> alts;
+    size_t next = 0;                                                     // round-robin position, carried from block to block
+    std::function<int(size_t, size_t, hipStream_t)> after;
+};
+static int slab_join(raftx_ctx *c, hipStream_t into, const std::vector<hipStream_t> &alts) {
+    for (hipStream_t s : alts) {
+        HIPCHK(c, hipEventRecord(c->evJoin, s));                         // a wait captures the record that precedes it: one event serves
+        HIPCHK(c, hipStreamWaitEvent(into, c->evJoin, 0));
+    }
+    return 0;
+}
+__global__ void k_iota(int n, int *__restrict__ out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = i;
+}
+
+static int solve_enqueue(raftx_ctx *c, int nIter, double tol, double XiStart, const raftx_c128 *F_extra, int want_mask,
+                         SlabPlan *plan = nullptr) {
     if (check_ready(c)) return -1;
     if (nIter < 0) FAIL(c, "solve_dynamics: nIter < 0");
     HIPCHK(c, hipSetDevice(c->device));
@@ -2010,15 +2051,44 @@ static int solve_enqueue(raftx_ctx *c, int nIter, double tol, double XiStart, co
                 }
         }
     }
+    const bool slabbed = plan && cls.empty() && !plan->alts.empty() && plan->bnd.size() >= 2 && plan->bnd.back() == c->r_npair;
+    if (slabbed) {
+        if (c->identList_n < c->r_npair) {
+            HIPCHK(c, hipStreamSynchronize(c->stream));
+            if (c->identList) (void)hipFree(c->identList);
+            c->identList = nullptr;
+            void *p_ = nullptr;
+            HIPCHK(c, hipMalloc(&p_, c->r_npair * sizeof(int)));
+            c->identList = reinterpret_cast<int *>(p_);
+            c->identList_n = c->r_npair;
+            hipLaunchKernelGGL(k_iota, dim3((unsigned)((c->r_npair + 255) / 256)), dim3(256), 0, c->stream, (int)c->r_npair, c->identList);
+        }
+        if (!c->evFork) HIPCHK(c, hipEventCreateWithFlags(&c->evFork, hipEventDisableTiming));
+        if (!c->evJoin) HIPCHK(c, hipEventCreateWithFlags(&c->evJoin, hipEventDisableTiming));
+    }
+    int rc_after = 0;
 #define LAUNCH_SOLVE(NB_, MT_, MB_, FL)                                                                              \
     do {                                                                                                             \
         if (prep_lds(c, k_solve_dynamics<NB_, FL, MT_, MB_>, lds)) return -1;                                        \
         HIPCHK(c, hipEventRecord(c->ev0, c->stream));                                                                \
         A.pairs = nullptr;                                                                                           \
         A.npairs = 0;                                                                                                \
-        if (c->r_npair && cls.empty())                                                                               \
+        if (c->r_npair && cls.empty() && !slabbed)                                                                   \
             hipLaunchKernelGGL((k_solve_dynamics<NB_, FL, MT_, MB_>), dim3(grid_for_pairs(c->r_npair)),              \
                                dim3(sh.threads), lds, c->stream, T, A);                                              \
+        if (slabbed) {                                            /* the tables and the iota list are on the ctx stream */ \
+            HIPCHK(c, hipEventRecord(c->evFork, c->stream));                                                         \
+            for (size_t k_ = 0; k_ < plan->alts.size() && k_ + 1 < plan->bnd.size(); k_++)                           \
+                HIPCHK(c, hipStreamWaitEvent(plan->alts[(plan->next + k_) % plan->alts.size()], c->evFork, 0));      \
+            for (size_t k_ = 0; k_ + 1 < plan->bnd.size() && !rc_after; k_++) {                                      \
+                hipStream_t s_ = plan->alts[plan->next++ % plan->alts.size()];                                       \
+                A.pairs = c->identList + plan->bnd[k_];                                                              \
+                A.npairs = (int)(plan->bnd[k_ + 1] - plan->bnd[k_]);                                                 \
+                hipLaunchKernelGGL((k_solve_dynamics<NB_, FL, MT_, MB_>), dim3(grid_for_pairs((size_t)A.npairs)),    \
+                                   dim3(sh.threads), lds, s_, T, A);                                                 \
+                if (plan->after) rc_after = plan->after(plan->bnd[k_], plan->bnd[k_ + 1], s_);                       \
+            }                                                                                                        \
+        }                                                                                                            \
         size_t at_ = 0;                                                                                              \
         for (int kk = (int)cls.size() - 1; kk >= 0; kk--) {                                                          \
             const size_t n_ = cls[(size_t)kk].size();                                                                \
@@ -2032,6 +2102,7 @@ static int solve_enqueue(raftx_ctx *c, int nIter, double tol, double XiStart, co
             hipLaunchKernelGGL((k_solve_dynamics<NB_, FL, MT_, MB_>), dim3(grid_for_pairs(n_)), dim3(sh.threads),    \
                                l_, c->stream, T, A);                                                                 \
         }                                                                                                            \
+        if (plan && plan->after && !slabbed) rc_after = plan->after(0, c->r_npair, c->stream);                       \
     } while (0)
 #define TRY_LEAN_(F) if (lean == (F)) LAUNCH_SOLVE(2, 128, RAFTX_MINB128, (F));
 #define DISPATCH_ONE_(NB_, MT_, MB_)                                                                                 \
@@ -2046,6 +2117,7 @@ static int solve_enqueue(raftx_ctx *c, int nIter, double tol, double XiStart, co
 #undef LAUNCH_SOLVE
     HIPCHK(c, hipEventRecord(c->ev1, c->stream));
     HIPCHK(c, hipGetLastError());
+    if (rc_after) FAIL(c, "solve_dynamics: what follows a slab of the launch could not be enqueued");
     return 0;
 }
 static int finish_enqueued(raftx_ctx *c) {
@@ -2616,12 +2688,11 @@ static int block_ctx(raftx_ctx *c, int slot, size_t i, raftx_ctx **out) {
 // whose kernels hide the descriptor upload of the rest (every further block costs a partial last residency round of the
 // fused kernel plus the fixed latencies of the generation kernels: two blocks measured best)
 static std::vector<int> sweep_bounds(int nDesign, long pairs, int nChunk, bool pipelined, bool with_xi = false, int nCase = 1) {
-    // The responses are wanted and nothing else is in flight to hide their download behind: four slabs, 20 / 30 / 30 / 20 % --
-    // a small first one (its upload is what everything waits for), a small last one (its download is what is left when the
-    // kernels have finished), each slab's download running under the next slab's kernels.  Measured on one box
-    // (scripts/gpu_r4_iso3.sh): 6.2-6.4 ms against 6.8-7.0 for five equal slabs of 2 048 pairs and 6.6 for three; RAFTX_XI_SLABS=0
-    // keeps the two-block form.
-    static const bool xi_slabs = !(getenv("RAFTX_XI_SLABS") && !atoi(getenv("RAFTX_XI_SLABS")));
+    // RAFTX_XI_SLABS=1: round 4's first form for a crossing that downloads its responses with nothing else in flight -- four
+    // BLOCKS, 20 / 30 / 30 / 20 %, each block's download under the next block's kernels (6.2-6.4 ms against 7.5 for two
+    // blocks downloaded whole).  Superseded by slabs of the fused launch inside the two blocks (SlabPlan, raftx_sweep_launch:
+    // 5.7 ms on the box where this form took 6.95); kept for A/B runs.
+    static const bool xi_slabs = getenv("RAFTX_XI_SLABS") && atoi(getenv("RAFTX_XI_SLABS"));     // round 4's first form: blocks as slabs
     (void)nCase;
     std::vector<double> fr;
     static const char *env = getenv("RAFTX_SWEEP_SPLIT");
@@ -2855,6 +2926,45 @@ extern "C" int raftx_sweep_launch(raftx_ctx *c, int slot) {
     }
     // ---- phase 2 + fixed point + statistics of every block, in order, on the ctx stream
     int rc_all = 0;
+    static const long slab_pairs = getenv("RAFTX_XI_SLAB_PAIRS") ? atol(getenv("RAFTX_XI_SLAB_PAIRS")) : 1024;
+    static const int slab_streams = getenv("RAFTX_XI_SLAB_STREAMS") ? std::min(3, std::max(1, atoi(getenv("RAFTX_XI_SLAB_STREAMS")))) : 1;
+    const bool slab_mode = Xi && sDown && slab_pairs > 0 && !others_in_flight(c, slot);
+    SlabPlan plan;
+    S.slab = slab_mode;
+    if (slab_mode) {
+        hipStream_t *ss[3] = {&c->sGen, &c->sSlab[0], &c->sSlab[1]};
+        for (int i = 0; i < slab_streams; i++) {
+            if (!*ss[i]) HIPCHK(c, hipStreamCreateWithFlags(ss[i], hipStreamNonBlocking));
+            plan.alts.push_back(*ss[i]);
+        }
+    }
+    // statistics, iteration counts and flags of a block go straight into its page-locked landing area (the kernels store
+    // there: no small D2H copy that could queue on the DMA engine behind a bulk download); behind them, on the download
+    // stream, the block's responses unless they leave slab by slab
+    auto enqueue_stats = [&](size_t b) -> int {
+        raftx_ctx *sub = blk[b];
+        const int lo = bnd[b];
+        const size_t npair = (size_t)(bnd[b + 1] - lo) * nCase;
+        hipError_t e = hipEventRecord(sub->evS0, c->stream);
+        if (npair) {
+            hipLaunchKernelGGL(k_motion_stats, dim3((unsigned)npair), dim3(nw > 128 ? 256 : (nw > 64 ? 128 : 64)), 0, c->stream,
+                               (int)npair, nHead, nw, 1.0 / dw, sub->rXi, sub->pinRes, (double *)nullptr, (const int *)sub->rNi,
+                               (const int *)sub->rFl, reinterpret_cast<int *>(sub->pinRes + npair * 6));
+        }
+        if (e == hipSuccess) e = hipEventRecord(sub->evS1, c->stream);
+        if (e == hipSuccess) e = hipEventRecord(sub->evDone, c->stream);
+        if (e == hipSuccess && Xi && !slab_mode) {
+            const size_t p0 = (size_t)lo * nCase;
+            e = hipStreamWaitEvent(sDown, sub->evDone, 0);
+            if (e == hipSuccess && sub->r_nx)
+                e = hipMemcpyAsync(Xi + p0 * nHead * 6 * nw, sub->rXi, sub->r_nx * sizeof(cplx), hipMemcpyDeviceToHost, sDown);
+        }
+        if (e != hipSuccess) {
+            snprintf(sub->err, sizeof(sub->err), "statistics / download of the block: %s", hipGetErrorString(e));
+            return -2;
+        }
+        return 0;
+    };
     for (size_t b = 0; b < nB && !rc_all; b++) {
         raftx_ctx *sub = blk[b];
         const int lo = bnd[b], n = bnd[b + 1] - lo;
@@ -2869,6 +2979,7 @@ extern "C" int raftx_sweep_launch(raftx_ctx *c, int slot) {
         static const bool gen_overlap = !(getenv("RAFTX_SWEEP_GEN_OVERLAP") && !atoi(getenv("RAFTX_SWEEP_GEN_OVERLAP")));
         const bool pipelined = others_in_flight(c, slot);
         int rc = 0;
+        if (b == 0) S.tlb.clear();
         if (S.next_p1 < nB && S.next_p1 <= b + 1) {                     // deferred phase 1: keep one block's upload ahead
             const size_t bn = S.next_p1++;
             const int rc1 = build_phase1(blk[bn], c->sCopy, c->sPrep, bnd[bn], bnd[bn + 1] - bnd[bn], S.p1.memberOff, S.p1.members,
@@ -2895,7 +3006,9 @@ extern "C" int raftx_sweep_launch(raftx_ctx *c, int slot) {
         // fused kernel's HIP-event time then is that launch alone)
         static const bool xi_gen_overlap = getenv("RAFTX_XI_GEN_OVERLAP") && atoi(getenv("RAFTX_XI_GEN_OVERLAP"));
         const bool gen_side = (pipelined && gen_overlap) || (b > 0 && Xi != nullptr && nB > 2 && xi_gen_overlap);
+        S.tlb.push_back(since());
         if (!rc) rc = build_phase2(sub, nullptr, gen_side ? c->sGen : nullptr);
+        S.tlb.push_back(since());
         if (!rc && b == 0 && pipelined && gen_overlap) {
             // Small kernels are not dispatched while a big grid is being handed out: whatever of the NEXT batch's member pass
             // has not finished when this batch's fused kernel starts would wait for the whole kernel and stall that batch's
@@ -2914,7 +3027,36 @@ extern "C" int raftx_sweep_launch(raftx_ctx *c, int slot) {
             T.w = P.w; T.k = P.k; T.csh = P.csh; T.cch = P.cch; T.zeta = P.zeta; T.beta = P.beta;
             T.depth = P.depth; T.rho = P.rho; T.g = P.g;
             sub->have_cases = true;
-            rc = solve_enqueue(sub, nIter, tol, XiStart, nullptr, 0);
+            // Responses wanted and nothing else in flight: the block's launch is cut into slabs of the pair list on the slab
+            // stream(s), each followed by its own download (SlabPlan).  The download (3.5 ms for 192 MB) is longer than the
+            // solve, so the call ends one slab's download after the last slab when the first download starts early and the
+            // copy engine is then never left waiting.  Measured (scripts/gpu_r4_slab.sh, 10 000 pairs, one box, median of six
+            // calls): whole blocks 7.7 ms; four blocks as slabs (round 4's first form) 6.95; slabs of 512 / 768 / 1024 / 1536
+            // pairs on one slab stream 7.9 / 6.2 / 5.7 / 6.1 -- one residency round per slab (256 CUs x 4 pairs) -- and no
+            // better on two or three streams (6.0-6.3).  RAFTX_XI_SLAB_PAIRS: pairs per slab (0: whole blocks);
+            // RAFTX_XI_SLAB_STREAMS: 1 .. 3.
+            if (slab_mode) {
+                plan.bnd.clear();
+                for (size_t p = 0; p < npair; p += (size_t)slab_pairs) plan.bnd.push_back(p);
+                if (plan.bnd.size() > 1 && npair - plan.bnd.back() < (size_t)slab_pairs / 2) plan.bnd.pop_back();   // no sliver at the end
+                plan.bnd.push_back(npair);
+                size_t *kslab = &S.nSlabEv;
+                S.nSlabEv = 0;
+                plan.after = [=](size_t q0, size_t q1, hipStream_t s) -> int {
+                    if (q1 <= q0) return 0;
+                    while (sub->evSlab.size() <= *kslab) {
+                        hipEvent_t e = nullptr;
+                        if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return -2;
+                        sub->evSlab.push_back(e);
+                    }
+                    hipEvent_t e = sub->evSlab[(*kslab)++];
+                    const size_t per = (size_t)nHead * 6 * nw;
+                    if (hipEventRecord(e, s) != hipSuccess || hipStreamWaitEvent(sDown, e, 0) != hipSuccess) return -2;
+                    return hipMemcpyAsync(Xi + ((size_t)lo * nCase + q0) * per, sub->rXi + q0 * per, (q1 - q0) * per * sizeof(cplx),
+                                          hipMemcpyDeviceToHost, sDown) == hipSuccess ? 0 : -2;
+                };
+            }
+            if (!rc) rc = solve_enqueue(sub, nIter, tol, XiStart, nullptr, 0, slab_mode ? &plan : nullptr);
         }
         if (!rc) {
             const size_t need = npair * 7 + 2;                          // std [npair,6] | niter, flags [npair] int32 each
@@ -2927,31 +3069,20 @@ extern "C" int raftx_sweep_launch(raftx_ctx *c, int slot) {
                 sub->pinRes_n = need;
             }
         }
-        if (!rc) {
-            // statistics, iteration counts and flags go straight into the block's page-locked landing area (the kernels
-            // store there: no small D2H copy that could queue on the DMA engine behind a bulk download)
-            hipError_t e = hipEventRecord(sub->evS0, c->stream);
-            if (npair) {
-                hipLaunchKernelGGL(k_motion_stats, dim3((unsigned)npair), dim3(nw > 128 ? 256 : (nw > 64 ? 128 : 64)), 0, c->stream,
-                                   (int)npair, nHead, nw, 1.0 / dw, sub->rXi, sub->pinRes, (double *)nullptr, (const int *)sub->rNi,
-                                   (const int *)sub->rFl, reinterpret_cast<int *>(sub->pinRes + npair * 6));
-            }
-            if (e == hipSuccess) e = hipEventRecord(sub->evS1, c->stream);
-            if (e == hipSuccess) e = hipEventRecord(sub->evDone, c->stream);
-            if (e == hipSuccess && Xi) {                                 // this block's responses: behind its kernels, on the download stream
-                const size_t p0 = (size_t)lo * nCase;
-                e = hipStreamWaitEvent(sDown, sub->evDone, 0);
-                if (e == hipSuccess && sub->r_nx)
-                    e = hipMemcpyAsync(Xi + p0 * nHead * 6 * nw, sub->rXi, sub->r_nx * sizeof(cplx), hipMemcpyDeviceToHost, sDown);
-            }
-            if (e != hipSuccess) {
-                snprintf(sub->err, sizeof(sub->err), "statistics / download of the block: %s", hipGetErrorString(e));
-                rc = -2;
-            }
-        }
+        if (!rc && !slab_mode) rc = enqueue_stats(b);                   // (slab mode: after the join, below)
+        S.tlb.push_back(since());
         if (rc) {
             snprintf(c->err, sizeof(c->err), "sweep_stats (block %zu): %s", b, sub->err);
             rc_all = rc;
+        }
+    }
+    if (!rc_all && slab_mode) {                                         // the statistics read what the slabs wrote: behind all of them
+        if (!blk[0]->evJoin && hipEventCreateWithFlags(&blk[0]->evJoin, hipEventDisableTiming) != hipSuccess) rc_all = -2;
+        if (!rc_all) rc_all = slab_join(blk[0], c->stream, plan.alts);
+        if (!rc_all && hipEventRecord(blk[nB - 1]->ev1, c->stream) != hipSuccess) rc_all = -2;
+        for (size_t b = 0; b < nB && !rc_all; b++) {
+            rc_all = enqueue_stats(b);
+            if (rc_all) snprintf(c->err, sizeof(c->err), "sweep_stats (block %zu): %s", b, blk[b]->err);
         }
     }
     if (!rc_all && Xi && hipEventRecord(S.evXi, sDown) != hipSuccess) rc_all = -2;
@@ -3033,7 +3164,10 @@ extern "C" int raftx_sweep_wait(raftx_ctx *c, int slot, double *timing_ms) {
         const int lo = S.bnd[b], n = S.bnd[b + 1] - lo;
         const size_t npair = (size_t)n * S.nCase, p0 = (size_t)lo * S.nCase;
         float ms = 0.f;
-        HIPCHK(c, hipEventElapsedTime(&ms, sub->ev0, sub->ev1));
+        // slabs on their own streams: the span from the first block's first launch to the last slab's end (the generation
+        // of the later blocks runs inside it)
+        if (!S.slab) HIPCHK(c, hipEventElapsedTime(&ms, sub->ev0, sub->ev1));
+        else if (b + 1 == nB) HIPCHK(c, hipEventElapsedTime(&ms, S.blk[0]->ev0, sub->ev1));
         ts += ms;
         HIPCHK(c, hipEventElapsedTime(&ms, sub->evS0, sub->evS1));
         tst += ms;
@@ -3050,6 +3184,11 @@ extern "C" int raftx_sweep_wait(raftx_ctx *c, int slot, double *timing_ms) {
     if (dbg_host)
         fprintf(stderr, "[raftx_sweep slot %d] host ms since submit: pre %.3f | phase-1 enqueued %.3f | phase-2 enqueued %.3f | ctx stream "
                 "reached the end %.3f | done %.3f\n", slot, S.tl[0], S.tl[1], S.tl[2], S.tl[3], wall);
+    if (dbg_host && S.tlb.size() > 3) {
+        fprintf(stderr, "[raftx_sweep slot %d] launch loop, host ms per block (next upload enqueued | totals seen | block enqueued):", slot);
+        for (size_t i = 0; i + 2 < S.tlb.size(); i += 3) fprintf(stderr, "  %.3f %.3f %.3f", S.tlb[i], S.tlb[i + 1], S.tlb[i + 2]);
+        fprintf(stderr, "\n");
+    }
     if (timing_ms) { timing_ms[0] = wall; timing_ms[1] = tb; timing_ms[2] = ts; timing_ms[3] = tst; }
     c->last_ms = ts;
     return 0;

@@ -310,6 +310,25 @@ def test_hip_sweep_crossing_chunked_equals_the_plain_sequence(hip_ctx, n, n_chun
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("slab_pairs,streams", [(100, 1), (64, 3), (1, 2)])
+def test_hip_sweep_crossing_with_responses_in_slabs(slab_pairs, streams):
+    """A crossing that downloads its responses cuts its fused launch into slabs of the pair list, each with its own
+    download (raftx_hip.hip SlabPlan; one residency round per slab by default -- more pairs than these batches have).
+    Forced down to 100 / 64 / 1 pairs per slab, on one to three slab streams, in a process of its own (the setting is read
+    once): still the plain sequence bit for bit, whole batch and chunked."""
+    import os
+    import subprocess
+    import sys
+    env = dict(os.environ, RAFTX_XI_SLAB_PAIRS=str(slab_pairs), RAFTX_XI_SLAB_STREAMS=str(streams))
+    code = ("import tests.test_geometry as t; from raft_amd import backend; ctx = backend.hip_library().context(0); "
+            "t.check_crossing(ctx, %d, 0, 0); t.check_crossing(ctx, %d, 3, 2); t.check_crossing(ctx, 7, 0, 0); print('slabs ok')"
+            % ((333, 200) if slab_pairs > 1 else (40, 25)))
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600,
+                       cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    assert r.returncode == 0 and "slabs ok" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
+
+
+@pytest.mark.gpu
 def test_hip_sweep_crossing_reuses_its_worker_streams_and_reports_errors(hip_ctx):
     """Several crossings on one context (worker contexts and their memory pools are kept), then a bad batch: the error of
     the failing worker comes back through raftx_last_error, and the context still works afterwards."""
