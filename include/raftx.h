@@ -384,7 +384,10 @@ int raftx_fetch_statics(raftx_ctx *ctx, double *A_morison, double *C_hydro, doub
  * drives over internal streams: the descriptor H2D of every block back to back on a copy stream, the member pass and
  * the scans of a block on a preparation stream as soon as its descriptors have landed, and strip generation, the fused
  * fixed point and the statistics of block 0, 1, 2, ... one after the other on the ctx stream (so the HIP events around
- * each fixed-point launch time that launch alone); the responses, if asked for, follow on a download stream.  What the
+ * each fixed-point launch time that launch alone); the responses, if asked for, follow on a download stream -- block by
+ * block, or, when no other crossing is in flight, in slabs of one residency round of the fused kernel (each block's launch
+ * is then cut into slabs of the pair list on a slab stream, every slab followed by its own download; timing_ms[2] is then
+ * the span from the first slab's launch to the last slab's end).  What the
  * reference does per candidate in raft/parametersweep.py:39-100 / raft/omdao_raft.py:746-792 (build a Model,
  * analyzeCases, read the statistics).
  * Descriptor arguments as raftx_build_designs (MBw not supported here; k doubles as the wave numbers of the
