@@ -228,6 +228,17 @@ int raftx_solve_dense(raftx_ctx *ctx, int n, int nRhs, int nw, const double *w, 
 int raftx_solve_dense_batch(raftx_ctx *ctx, int nSys, int n, int nRhs, int nw, const double *w, const double *M,
                             const double *B, const double *C, int freq_mask, const raftx_c128 *F, raftx_c128 *Xi,
                             raftx_c128 *Z);
+/* The fixed point of such units re-solves with the SAME M, C and frequency-dependent part of B in every iteration
+ * (raft_model.py:1045-1047, 1081-1088): only the drag linearisation B_drag and the drag excitation change (:1063-1064).
+ * raftx_dense_resident keeps the matrices of nSet units on the device (shapes as raftx_solve_dense_batch; nSet = 0 releases
+ * them); raftx_solve_dense_resident then solves nSet * nPer systems -- system s with the matrices of unit s / nPer (the
+ * sea states of one unit share them) and B + Badd[s], Badd [nSet*nPer,n,n] or NULL -- F, Xi [nSet*nPer,nRhs,n,nw],
+ * Z [nSet*nPer,n,n,nw] or NULL.  With the rotor's frequency-dependent matrices the flexible deck's M and B are 7.2 MB
+ * each: an iteration then uploads 0.2 MB instead of 14.6. */
+int raftx_dense_resident(raftx_ctx *ctx, int nSet, int n, int nw, const double *w, const double *M, const double *B,
+                         const double *C, int freq_mask);
+int raftx_solve_dense_resident(raftx_ctx *ctx, int nPer, const double *Badd, int nRhs, const raftx_c128 *F, raftx_c128 *Xi,
+                               raftx_c128 *Z);
 
 /* The same coupled solve fed from the RESIDENT results of raftx_solve_dynamics_device (which must have
  * kept Z and F_wave): consecutive groups of nUnit designs are the units of one array; for group g,

@@ -31,7 +31,7 @@ EXPORTS = (
     "raftx_sweep_prepare",
     "raftx_sweep_launch",
     "raftx_sweep_wait",
-    "raftx_sweep_cancel", "raftx_device_count", "raftx_solve_dense_batch",
+    "raftx_sweep_cancel", "raftx_device_count", "raftx_solve_dense_batch", "raftx_dense_resident", "raftx_solve_dense_resident",
     "raftx_comm_unique_id", "raftx_comm_init", "raftx_comm_destroy", "raftx_comm_broadcast", "raftx_comm_gather_rows",
     "raftx_comm_gather_xi", "raftx_comm_reduce_sum",
 )
@@ -118,6 +118,10 @@ class RaftxLib:
         L.raftx_solve_dense.restype = C.c_int
         L.raftx_solve_dense_batch.argtypes = [_vp, C.c_int, C.c_int, C.c_int, C.c_int, _vp, _vp, _vp, _vp, C.c_int, _vp, _vp, _vp]
         L.raftx_solve_dense_batch.restype = C.c_int
+        L.raftx_dense_resident.argtypes = [_vp, C.c_int, C.c_int, C.c_int, _vp, _vp, _vp, _vp, C.c_int]
+        L.raftx_dense_resident.restype = C.c_int
+        L.raftx_solve_dense_resident.argtypes = [_vp, C.c_int, _vp, C.c_int, _vp, _vp, _vp]
+        L.raftx_solve_dense_resident.restype = C.c_int
         L.raftx_device_locality.argtypes = [C.c_int, C.c_char_p, C.c_int, C.POINTER(C.c_int)]
         L.raftx_device_locality.restype = C.c_int
         L.raftx_host_alloc.argtypes = [_vp, C.c_size_t, C.POINTER(_vp)]
@@ -750,6 +754,45 @@ class Context:
         rc = self.rlib.lib.raftx_solve_dense_batch(self._h, nS, n, nR, nw, _ptr(w), _ptr(M), _ptr(B), _ptr(C_), mask, _ptr(F),
                                                    _ptr(Xi), _ptr(Z))
         self._check(rc, "raftx_solve_dense_batch")
+        return (Xi, Z) if want_Z else Xi
+
+    def dense_resident(self, w, M, B, C_):
+        """Keeps M, B [nSet,n,n] or [nSet,n,n,nw] and C_ [nSet,n,n] of nSet units on the device for solve_dense_resident
+        (raftx_dense_resident); dense_resident(None, None, None, None) releases them."""
+        if w is None:
+            self._check(self.rlib.lib.raftx_dense_resident(self._h, 0, 0, 0, None, None, None, None, 0), "raftx_dense_resident")
+            self._dense = None
+            return
+        w = _f64(w)
+        nw = len(w)
+        M, B = _f64(M), _f64(B)
+        nS, n = M.shape[0], M.shape[1]
+        mask = 0
+        for bit, A, name in ((1, M, "M"), (2, B, "B")):
+            if A.shape == (nS, n, n, nw):
+                mask |= bit
+            elif A.shape != (nS, n, n):
+                raise ValueError("%s must be [nSet,n,n] or [nSet,n,n,nw]" % name)
+        C_ = _f64(C_, (nS, n, n), "C")
+        rc = self.rlib.lib.raftx_dense_resident(self._h, nS, n, nw, _ptr(w), _ptr(M), _ptr(B), _ptr(C_), mask)
+        self._check(rc, "raftx_dense_resident")
+        self._dense = (nS, n, nw)
+
+    def solve_dense_resident(self, F, Badd=None, want_Z=False):
+        """Xi [nSys,nRhs,n,nw] (and Z [nSys,n,n,nw]) with the resident matrices: nSys = nSet * nPer systems, system s with
+        the matrices of unit s // nPer and B + Badd[s] (Badd [nSys,n,n] or None): raftx_solve_dense_resident."""
+        if getattr(self, "_dense", None) is None:
+            raise ValueError("solve_dense_resident: dense_resident first")
+        nSet, n, nw = self._dense
+        F = _c128(F)
+        nS, nR = F.shape[0], F.shape[1]
+        if F.shape != (nS, nR, n, nw) or nS % nSet:
+            raise ValueError("F must be [nSet*nPer,nRhs,n,nw]")
+        Badd = None if Badd is None else _f64(Badd, (nS, n, n), "Badd")
+        Xi = np.empty((nS, nR, n, nw), dtype=np.complex128)
+        Z = np.empty((nS, n, n, nw), dtype=np.complex128) if want_Z else None
+        rc = self.rlib.lib.raftx_solve_dense_resident(self._h, nS // nSet, _ptr(Badd), nR, _ptr(F), _ptr(Xi), _ptr(Z))
+        self._check(rc, "raftx_solve_dense_resident")
         return (Xi, Z) if want_Z else Xi
 
     def synchronize(self):

@@ -35,6 +35,7 @@
 #include <map>
 #include <functional>
 #include <mutex>
+#include <type_traits>
 #include <thread>
 #include <unordered_map>
 #include <vector>
@@ -76,6 +77,7 @@ struct RangeScope {
 #include "raftx_kernels.h"
 #include "raftx_qtf.h"
 #include "raftx_geom.h"
+#include "raftx_dense.h"
 
 // Coupled array solve (raft_model.py:1164-1236): Xi = Z_sys^-1 F for every (system, bin).  One wavefront per
 // (system, bin), NBIN (1, 2 or 4: what fits LDS) consecutive bins per workgroup so that the loads of one matrix entry
@@ -84,14 +86,6 @@ struct RangeScope {
 // pivot search as a wave reduction, multipliers with a lane per row, the rank-1 update with the lanes over the
 // (row, column) entries, back substitution column by column with a lane per (row, right-hand side).  A wave's LDS
 // traffic needs no s_barrier (wave_lds_fence).
-__device__ __forceinline__ void argmax_step(double &v, int &r, int off) {
-    const double ov = __shfl_xor(v, off, 64);
-    const int orr = __shfl_xor(r, off, 64);
-    if (ov > v || (ov == v && orr < r)) {
-        v = ov;
-        r = orr;
-    }
-}
 template <bool RESIDENT>
 __global__ void __launch_bounds__(256) k_solve_system(int nSys, int nUnit, int nRhs, int nw, int nCase,
                                                       const double *__restrict__ w, const cplx *__restrict__ Zblk,
@@ -366,256 +360,6 @@ static int solve_system_shape(int n, int nRhs, size_t *lds) {
     const int nbin = per * 4 <= 64 * 1024 ? 4 : (per * 2 <= 64 * 1024 ? 2 : 1);
     *lds = per * nbin;
     return nbin;
-}
-
-// General dense impedance solve for units with more than 6 reduced DOFs (flexible members: raft_model.py:1081-1088 with
-// nDOF x nDOF matrices, 150 for the reference's flexible VolturnUS-S).  One workgroup per frequency bin; the augmented
-// matrix [Z | F] of the bin lives in a global workspace (n = 150: 360 KB, beyond LDS, resident in L2), the pivot row and
-// the multiplier column of every elimination step are staged in LDS.  Partial pivoting by |re| + |im|, first largest
-// (zgetrf's izamax).  M and B are [n,n] or, with the bit of freq_mask set, [n,n,nw].
-#define DENSE_MAX_LD 1536
-__global__ void __launch_bounds__(256) k_solve_dense(int n, int nRhs, int nw, const double *__restrict__ w,
-                                                     const double *__restrict__ M, const double *__restrict__ B,
-                                                     const double *__restrict__ C, int freq_mask,
-                                                     const cplx *__restrict__ F, cplx *__restrict__ work,
-                                                     cplx *__restrict__ Xi, cplx *__restrict__ Zout) {
-    __shared__ cplx rowk[DENSE_MAX_LD], colk[DENSE_MAX_LD];
-    __shared__ double rbest[4];
-    __shared__ int rrow[4];
-    const int iw = blockIdx.x, ld = n + nRhs, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    const bool mw = freq_mask & 1, bw = freq_mask & 2;
-    {                                                     // blockIdx.y: the system of a batch (raftx_solve_dense_batch)
-        const size_t sy = blockIdx.y, nn = (size_t)n * n;
-        M += sy * nn * (mw ? nw : 1);
-        B += sy * nn * (bw ? nw : 1);
-        C += sy * nn;
-        F += sy * nRhs * n * nw;
-        Xi += sy * nRhs * n * nw;
-        if (Zout) Zout += sy * nn * nw;
-        work += sy * nw * n * ld;
-    }
-    cplx *A = work + (size_t)iw * n * ld;
-    const double ww = w[iw];
-    for (int e = tid; e < n * ld; e += 256) {
-        const int r = e / ld, c = e % ld;
-        cplx v;
-        if (c < n) {
-            const size_t o = (size_t)r * n + c;
-            const double m = mw ? M[o * nw + iw] : M[o], b = bw ? B[o * nw + iw] : B[o];
-            v = cplx{-(ww * ww) * m + C[o], ww * b};
-            if (Zout) Zout[o * nw + iw] = v;
-        } else {
-            v = F[((size_t)(c - n) * n + r) * nw + iw];
-        }
-        A[e] = v;
-    }
-    __syncthreads();
-    for (int k = 0; k < n; k++) {
-        double best = -1.0;
-        int p = n;
-        for (int r = k + tid; r < n; r += 256) {
-            const cplx a = A[(size_t)r * ld + k];
-            const double v = fabs(a.re) + fabs(a.im);
-            if (v > best) {
-                best = v;
-                p = r;
-            }
-        }
-#pragma unroll
-        for (int off = 32; off >= 1; off >>= 1) argmax_step(best, p, off);
-        if (lane == 0) {
-            rbest[wv] = best;
-            rrow[wv] = p;
-        }
-        __syncthreads();
-        best = rbest[0];
-        p = rrow[0];
-        for (int i = 1; i < 4; i++)
-            if (rbest[i] > best || (rbest[i] == best && rrow[i] < p)) {
-                best = rbest[i];
-                p = rrow[i];
-            }
-        if (p >= n) p = k;                                    // a column of NaNs: no row compares larger
-        for (int c = k + tid; c < ld; c += 256) {            // swap rows k and p; the pivot row goes to LDS
-            const cplx t = A[(size_t)k * ld + c], u = A[(size_t)p * ld + c];
-            A[(size_t)p * ld + c] = t;
-            A[(size_t)k * ld + c] = u;
-            rowk[c] = u;
-        }
-        __syncthreads();
-        const cplx pv = rowk[k];
-        const double dd = pv.re * pv.re + pv.im * pv.im;
-        const cplx inv = {pv.re / dd, -pv.im / dd};
-        for (int r = k + 1 + tid; r < n; r += 256) {
-            const cplx l = cmul(A[(size_t)r * ld + k], inv);
-            A[(size_t)r * ld + k] = l;
-            colk[r] = l;
-        }
-        __syncthreads();
-        for (int r = k + 1 + wv; r < n; r += 4) {            // a wave per row, lanes along the row
-            const cplx l = colk[r];
-            cplx *row = A + (size_t)r * ld;
-            for (int c = k + 1 + lane; c < ld; c += 64) row[c] = csub(row[c], cmul(l, rowk[c]));
-        }
-        __syncthreads();
-    }
-    for (int k = n - 1; k >= 0; k--) {                        // back substitution on the right-hand columns
-        const cplx pv = A[(size_t)k * ld + k];
-        const double dd = pv.re * pv.re + pv.im * pv.im;
-        for (int j = tid; j < nRhs; j += 256) {
-            const cplx sum = A[(size_t)k * ld + n + j];
-            const cplx x = {(sum.re * pv.re + sum.im * pv.im) / dd, (sum.im * pv.re - sum.re * pv.im) / dd};
-            A[(size_t)k * ld + n + j] = x;
-            rowk[j] = x;
-        }
-        __syncthreads();
-        for (int e = tid; e < k * nRhs; e += 256) {
-            const int r = e / nRhs, j = e % nRhs;
-            A[(size_t)r * ld + n + j] = csub(A[(size_t)r * ld + n + j], cmul(A[(size_t)r * ld + k], rowk[j]));
-        }
-        __syncthreads();
-    }
-    for (int e = tid; e < n * nRhs; e += 256) {
-        const int r = e % n, j = e / n;
-        Xi[((size_t)j * n + r) * nw + iw] = A[(size_t)r * ld + n + j];
-    }
-}
-
-// The same solve for systems of up to 32 RB x 32 CB - nRhs unknowns (the reference's flexible deck: 150) with the whole
-// augmented matrix in REGISTERS: 1024 threads as a 32 x 32 grid, thread (ti, tj) owns the entries (ti + 32 a, tj + 32 b) --
-// 25 complex numbers at RB = CB = 5 -- so that a step of the elimination touches LDS for the pivot row and the column of
-// multipliers only.  k_solve_dense above keeps the matrix in an L2-resident workspace and pays three round trips through L2
-// per step: 150 steps, 1.8 ms per call, nine calls per drop-in solveDynamics of the flexible deck.  Here a step is three
-// workgroup barriers.  Gauss-Jordan with partial pivoting (izamax order: first largest |re| + |im| among the rows that have
-// not been pivots yet) and IMPLICIT row interchanges -- a pivot row stays where it is: every register index is static (the
-// step loop is unrolled over the 32-column blocks), the one dynamic choice, which of a thread's RB rows is the pivot row,
-// goes through an LDS staging area.  Rows above the pivot are eliminated too (the lanes that own them would idle
-// otherwise), so there is no back substitution: unknown k is the pivot row's right-hand side over its pivot.
-template <int RB, int CB>
-__global__ void __launch_bounds__(1024) k_solve_dense_reg(int n, int nRhs, int nw, const double *__restrict__ w,
-                                                          const double *__restrict__ M, const double *__restrict__ B,
-                                                          const double *__restrict__ C, int freq_mask,
-                                                          const cplx *__restrict__ F, cplx *__restrict__ Xi,
-                                                          cplx *__restrict__ Zout) {
-    __shared__ cplx stage[RB][CB * 32];                   // the RB rows of the thread row that holds the pivot row
-    __shared__ cplx colk[RB * 32];                        // multipliers of the step, by row (0 for the pivot row)
-    __shared__ cplx invp[RB * 32];                        // 1 / pivot of the step in which the row was the pivot row
-    __shared__ int ord[RB * 32];                          // ... and that step
-    __shared__ int psel;
-    const int iw = blockIdx.x, ld = n + nRhs, tid = threadIdx.x, ti = tid & 31, tj = tid >> 5;
-    const double ww = w[iw];
-    const bool mw = freq_mask & 1, bw = freq_mask & 2;
-    {                                                     // blockIdx.y: the system of a batch (raftx_solve_dense_batch)
-        const size_t sy = blockIdx.y, nn = (size_t)n * n;
-        M += sy * nn * (mw ? nw : 1);
-        B += sy * nn * (bw ? nw : 1);
-        C += sy * nn;
-        F += sy * nRhs * n * nw;
-        Xi += sy * nRhs * n * nw;
-        if (Zout) Zout += sy * nn * nw;
-    }
-    // entries of the thread: block rows 0 .. RB-2 in registers (80 at RB = CB = 5: 1024 threads leave 128 per lane), the last
-    // block row in LDS, one column of 16 bytes per thread and block column
-    extern __shared__ __attribute__((aligned(16))) unsigned char dense_tail_[];
-    cplx *tail = reinterpret_cast<cplx *>(dense_tail_);   // [CB][1024]
-    cplx Areg[RB - 1][CB];
-    auto LD = [&](int a_, int b_) -> cplx { return a_ < RB - 1 ? Areg[a_ < RB - 1 ? a_ : 0][b_] : tail[b_ * 1024 + tid]; };
-    auto ST = [&](int a_, int b_, cplx v_) {
-        if (a_ < RB - 1) Areg[a_ < RB - 1 ? a_ : 0][b_] = v_;
-        else tail[b_ * 1024 + tid] = v_;
-    };
-    unsigned done = 0;                                    // bit a: row ti + 32 a has been a pivot row (or does not exist)
-#pragma unroll
-    for (int a = 0; a < RB; a++) {
-        const int r = ti + 32 * a;
-        if (r >= n) done |= 1u << a;
-#pragma unroll
-        for (int b = 0; b < CB; b++) {
-            const int c = tj + 32 * b;
-            cplx v = {0.0, 0.0};
-            if (r < n && c < n) {
-                const size_t o = (size_t)r * n + c;
-                const double m = mw ? M[o * nw + iw] : M[o], bb = bw ? B[o * nw + iw] : B[o];
-                v = cplx{-(ww * ww) * m + C[o], ww * bb};
-                if (Zout) Zout[o * nw + iw] = v;
-            } else if (r < n && c < ld) {
-                v = F[((size_t)(c - n) * n + r) * nw + iw];
-            }
-            ST(a, b, v);
-        }
-    }
-#pragma unroll
-    for (int kb = 0; kb < CB; kb++) {
-        for (int kk = 0; kk < 32; kk++) {
-            const int k = kb * 32 + kk;
-            if (k >= n) break;                            // (uniform)
-            // ---- pivot search down column k: its owners are the 32 threads with tj == kk, one half-wave
-            double best = -1.0;
-            int p = RB * 32;
-            if (tj == kk) {
-#pragma unroll
-                for (int a = 0; a < RB; a++)
-                    if (!(done >> a & 1u)) {
-                        const cplx e_ = LD(a, kb);
-                        double v = fabs(e_.re) + fabs(e_.im);
-                        if (!(v <= 1.7e308)) v = 1.7e308;        // NaN / inf: take the row, the result is flagged not finite
-                        if (v > best) {
-                            best = v;
-                            p = ti + 32 * a;
-                        }
-                    }
-            }
-#pragma unroll
-            for (int off = 16; off >= 1; off >>= 1) argmax_step(best, p, off);       // stays inside the half-wave
-            if (tj == kk && ti == 0) psel = p;
-            __syncthreads();
-            p = psel;
-            const int ap = p >> 5;
-            if (ti == (p & 31)) {                         // the thread row of the pivot row publishes its rows; the row is done
-#pragma unroll
-                for (int a = 0; a < RB; a++)
-#pragma unroll
-                    for (int b = 0; b < CB; b++)
-                        if (b >= kb) stage[a][tj + 32 * b] = LD(a, b);
-                done |= 1u << ap;
-            }
-            __syncthreads();
-            const cplx pv = stage[ap][k];
-            const double dd = pv.re * pv.re + pv.im * pv.im;
-            const cplx inv = {pv.re / dd, -pv.im / dd};
-            if (tj == kk) {
-#pragma unroll
-                for (int a = 0; a < RB; a++) {
-                    const int r = ti + 32 * a;
-                    colk[r] = (r == p) ? cplx{0.0, 0.0} : cmul(LD(a, kb), inv);
-                }
-                if (ti == 0) {
-                    invp[p] = inv;
-                    ord[p] = k;
-                }
-            }
-            __syncthreads();
-            // (the pivot-row entry and the multipliers come from LDS where they are used: 128 registers per lane at 1024
-            // threads hold the 25 entries and little else)
-#pragma unroll
-            for (int b = 0; b < CB; b++)
-                if (b > kb || (b == kb && tj > kk)) {
-                    const cplx rkb = stage[ap][tj + 32 * b];
-#pragma unroll
-                    for (int a = 0; a < RB; a++) ST(a, b, csub(LD(a, b), cmul(colk[ti + 32 * a], rkb)));
-                }
-        }
-    }
-    __syncthreads();
-#pragma unroll
-    for (int a = 0; a < RB; a++) {
-        const int r = ti + 32 * a;
-#pragma unroll
-        for (int b = 0; b < CB; b++) {
-            const int c = tj + 32 * b;
-            if (r < n && c >= n && c < ld) Xi[((size_t)(c - n) * n + ord[r]) * nw + iw] = cmul(LD(a, b), invp[r]);
-        }
-    }
 }
 
 // Motion statistics of the resident responses (raft_fowt.py:2310-2357; helpers.py:678-700): one
@@ -896,6 +640,12 @@ struct CaseSet {
     unsigned long long stamp = 0;        // last use (the idle set used longest ago is replaced)
 };
 
+// resident matrices of the dense solves (raftx_dense_resident): device pointers owned by `allocs`
+struct DenseResident {
+    int nSet = 0, n = 0, nw = 0, freq_mask = 0;
+    double *w = nullptr, *M = nullptr, *B = nullptr, *C = nullptr;
+    std::vector<void *> allocs;
+};
 struct raftx_ctx {
     int device;
     hipStream_t stream;
@@ -938,6 +688,7 @@ struct raftx_ctx {
     std::vector<int> hS;                 // submerged strips of every design (host copy: LDS classes of the fused kernel)
     int *pairList;                       // device pair lists of a launch split into LDS classes
     size_t pairList_n;
+    DenseResident dense;                 // matrices kept for raftx_solve_dense_resident
     int *identList = nullptr;            // 0, 1, 2, ..: the pair list of a launch cut into slabs (SlabPlan)
     size_t identList_n = 0;
     std::vector<hipEvent_t> evSlab;      // completion markers of the slabs (no timing), created as needed, kept
@@ -1135,6 +886,7 @@ extern "C" void raftx_ctx_destroy(raftx_ctx *c) {
     if (c->bemF) (void)hipFree(c->bemF);
     if (c->rKay) (void)hipFree(c->rKay);
     if (c->pairList) (void)hipFree(c->pairList);
+    free_list(c, c->dense.allocs);
     if (c->identList) (void)hipFree(c->identList);
     for (hipEvent_t e : c->evSlab) (void)hipEventDestroy(e);
     if (c->evFork) (void)hipEventDestroy(c->evFork);
@@ -2370,19 +2122,49 @@ extern "C" int raftx_solve_system(raftx_ctx *c, int nSys, int nUnit, int nRhs, i
     return 0;
 }
 
+// launch of the dense solves of nSys systems x nw bins on device arrays: the register-resident kernel where the augmented
+// matrix fits its grid (the flexible deck: 150 + 1), the L2-workspace kernel otherwise.  Matrix set of system s: s / mdiv.
+static bool dense_reg_shape(int n, int nRhs) {
+    static const bool dense_l2 = getenv("RAFTX_DENSE_L2") && atoi(getenv("RAFTX_DENSE_L2"));     // tuning / tests: the L2-workspace kernel
+    return !dense_l2 && n + nRhs <= 160;
+}
+static int dense_launch(raftx_ctx *c, int nSys, int mdiv, int n, int nRhs, int nw, const double *dw, const double *dM, const double *dB,
+                        const double *dC, int freq_mask, const double *dBadd, const cplx *dF, cplx *dX, cplx *dZ, cplx *dA) {
+    const dim3 grid((unsigned)nw, (unsigned)nSys);
+    if (dense_reg_shape(n, nRhs)) {
+#define DENSE_REG_(RB_, CB_)                                                                                            \
+        hipLaunchKernelGGL((k_solve_dense_reg2<RB_, CB_, 16>), grid, dim3(512), 0, c->stream, n, nRhs, nw, dw, dM, dB, dC, freq_mask, \
+                           mdiv, dBadd, dF, dX, dZ)
+        // entries per thread: the smallest 32 RB x 16 CB grid that holds [Z | F] (measured at 60 DOFs: 0.076 ms with 3 x 6
+        // against 0.136 with 5 x 10 and 0.23 for the L2-workspace kernel)
+        if (n + nRhs <= 32) DENSE_REG_(1, 2);
+        else if (n + nRhs <= 64) DENSE_REG_(2, 4);
+        else if (n + nRhs <= 96) DENSE_REG_(3, 6);
+        else if (n + nRhs <= 128) DENSE_REG_(4, 8);
+        else DENSE_REG_(5, 10);
+#undef DENSE_REG_
+    } else {
+        hipLaunchKernelGGL(k_solve_dense, grid, dim3(256), 0, c->stream, n, nRhs, nw, dw, dM, dB, dC, freq_mask, mdiv, dBadd, dF, dA, dX, dZ);
+    }
+    HIPCHK(c, hipGetLastError());
+    return 0;
+}
+static int dense_check(raftx_ctx *c, const char *who, int nSys, int n, int nRhs, int nw) {
+    if (nSys < 0 || n < 1 || nRhs < 1 || nw < 1) FAIL(c, "%s: bad arguments", who);
+    if (n + nRhs > DENSE_MAX_LD) FAIL(c, "%s: %d DOFs + %d right-hand sides exceed %d", who, n, nRhs, DENSE_MAX_LD);
+    if (nSys > 65535) FAIL(c, "%s: at most 65 535 systems per call", who);
+    return 0;
+}
+
 static int solve_dense_impl(raftx_ctx *c, int nSys, int n, int nRhs, int nw, const double *w, const double *M, const double *B,
                             const double *C, int freq_mask, const raftx_c128 *F, raftx_c128 *Xi, raftx_c128 *Z) {
     if (!c) return -1;
-    if (nSys < 0 || n < 1 || nRhs < 1 || nw < 1 || !w || !M || !B || !C || !F || !Xi) FAIL(c, "solve_dense: bad arguments");
-    if (n + nRhs > DENSE_MAX_LD) FAIL(c, "solve_dense: %d DOFs + %d right-hand sides exceed %d", n, nRhs, DENSE_MAX_LD);
-    if (nSys > 65535) FAIL(c, "solve_dense_batch: at most 65 535 systems per call");
+    if (!w || !M || !B || !C || !F || !Xi) FAIL(c, "solve_dense: bad arguments");
+    if (dense_check(c, "solve_dense", nSys, n, nRhs, nw)) return -1;
     if (nSys == 0) return 0;
     HIPCHK(c, hipSetDevice(c->device));
     Scratch sc(c);
-    static const bool dense_l2 = getenv("RAFTX_DENSE_L2") && atoi(getenv("RAFTX_DENSE_L2"));     // tuning / tests: the L2-workspace kernel
-    // the register-resident kernel (the flexible deck: 150 + 1; measured: 0.59 against 1.34 ms at 150 x 40 bins, 0.30 against
-    // 0.22 at 60 DOFs)
-    const bool reg = !dense_l2 && n + nRhs <= 160 && n > 96;
+    const bool reg = dense_reg_shape(n, nRhs);
     const size_t nn = (size_t)n * n, nf = (size_t)nSys * nRhs * n * nw;
     const size_t nM = (size_t)nSys * nn * ((freq_mask & 1) ? nw : 1), nB = (size_t)nSys * nn * ((freq_mask & 2) ? nw : 1);
     double *dw = sc.alloc<double>(nw), *dM = sc.alloc<double>(nM), *dB = sc.alloc<double>(nB), *dC = sc.alloc<double>((size_t)nSys * nn);
@@ -2396,15 +2178,7 @@ static int solve_dense_impl(raftx_ctx *c, int nSys, int n, int nRhs, int nw, con
     H2D(c, dC, C, (size_t)nSys * nn * sizeof(double));
     H2D(c, dF, F, nf * sizeof(cplx));
     HIPCHK(c, hipEventRecord(c->ev0, c->stream));
-    const dim3 grid((unsigned)nw, (unsigned)nSys);
-    if (reg) {
-        const size_t tail_lds = (size_t)5 * 1024 * sizeof(cplx);         // the last block row of every thread (see the kernel)
-        if (prep_lds(c, k_solve_dense_reg<5, 5>, tail_lds)) return -1;
-        hipLaunchKernelGGL((k_solve_dense_reg<5, 5>), grid, dim3(1024), tail_lds, c->stream, n, nRhs, nw, dw, dM, dB, dC, freq_mask,
-                           dF, dX, dZ);
-    } else {
-        hipLaunchKernelGGL(k_solve_dense, grid, dim3(256), 0, c->stream, n, nRhs, nw, dw, dM, dB, dC, freq_mask, dF, dA, dX, dZ);
-    }
+    if (dense_launch(c, nSys, 1, n, nRhs, nw, dw, dM, dB, dC, freq_mask, nullptr, dF, dX, dZ, dA)) return -1;
     if (finish_timed(c)) return -2;
     D2H(c, Xi, dX, nf * sizeof(cplx));
     if (Z) D2H(c, Z, dZ, (size_t)nSys * nn * nw * sizeof(cplx));
@@ -2419,6 +2193,61 @@ extern "C" int raftx_solve_dense_batch(raftx_ctx *c, int nSys, int n, int nRhs, 
                                        const double *B, const double *C, int freq_mask, const raftx_c128 *F, raftx_c128 *Xi,
                                        raftx_c128 *Z) {
     return solve_dense_impl(c, nSys, n, nRhs, nw, w, M, B, C, freq_mask, F, Xi, Z);
+}
+
+// The matrices of a fixed point stay on the device: M, B, C of nSet units are uploaded once (raftx_dense_resident); every
+// iteration then sends what CHANGES -- the drag linearisation Badd [n,n] of each (unit, sea state) and the right-hand sides --
+// and gets the responses back (raftx_solve_dense_resident).  With frequency-dependent rotor matrices the flexible deck's M and
+// B are 7.2 MB each: re-uploaded by every raftx_solve_dense call they were most of the call.
+extern "C" int raftx_dense_resident(raftx_ctx *c, int nSet, int n, int nw, const double *w, const double *M, const double *B,
+                                    const double *C, int freq_mask) {
+    if (!c) return -1;
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    DenseResident &R = c->dense;
+    free_list(c, R.allocs);
+    R = DenseResident();
+    if (nSet == 0) return 0;                                              // (release)
+    if (!w || !M || !B || !C) FAIL(c, "dense_resident: bad arguments");
+    if (dense_check(c, "dense_resident", nSet, n, 1, nw)) return -1;
+    const size_t nn = (size_t)n * n, nM = (size_t)nSet * nn * ((freq_mask & 1) ? nw : 1), nB = (size_t)nSet * nn * ((freq_mask & 2) ? nw : 1);
+    if (dev_alloc(c, R.allocs, (size_t)nw, &R.w) || dev_alloc(c, R.allocs, nM, &R.M) || dev_alloc(c, R.allocs, nB, &R.B) ||
+        dev_alloc(c, R.allocs, (size_t)nSet * nn, &R.C))
+        return -2;
+    H2D(c, R.w, w, nw * sizeof(double));
+    H2D(c, R.M, M, nM * sizeof(double));
+    H2D(c, R.B, B, nB * sizeof(double));
+    H2D(c, R.C, C, (size_t)nSet * nn * sizeof(double));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    R.nSet = nSet; R.n = n; R.nw = nw; R.freq_mask = freq_mask;
+    return 0;
+}
+extern "C" int raftx_solve_dense_resident(raftx_ctx *c, int nPer, const double *Badd, int nRhs, const raftx_c128 *F, raftx_c128 *Xi,
+                                          raftx_c128 *Z) {
+    if (!c) return -1;
+    const DenseResident &R = c->dense;
+    if (R.nSet < 1) FAIL(c, "solve_dense_resident: no resident matrices (raftx_dense_resident first)");
+    if (nPer < 1 || !F || !Xi) FAIL(c, "solve_dense_resident: bad arguments");
+    const int nSys = R.nSet * nPer, n = R.n, nw = R.nw;
+    if (dense_check(c, "solve_dense_resident", nSys, n, nRhs, nw)) return -1;
+    HIPCHK(c, hipSetDevice(c->device));
+    Scratch sc(c);
+    const bool reg = dense_reg_shape(n, nRhs);
+    const size_t nn = (size_t)n * n, nf = (size_t)nSys * nRhs * n * nw;
+    double *dBadd = Badd ? sc.alloc<double>((size_t)nSys * nn) : nullptr;
+    cplx *dF = sc.alloc<cplx>(nf), *dX = sc.alloc<cplx>(nf);
+    cplx *dA = reg ? nullptr : sc.alloc<cplx>((size_t)nSys * nw * n * (n + nRhs));
+    cplx *dZ = Z ? sc.alloc<cplx>((size_t)nSys * nn * nw) : nullptr;
+    if ((Badd && !dBadd) || !dF || !dX || (!reg && !dA) || (Z && !dZ)) FAIL(c, "solve_dense_resident: device allocation failed");
+    if (Badd) H2D(c, dBadd, Badd, (size_t)nSys * nn * sizeof(double));
+    H2D(c, dF, F, nf * sizeof(cplx));
+    HIPCHK(c, hipEventRecord(c->ev0, c->stream));
+    if (dense_launch(c, nSys, nPer, n, nRhs, nw, R.w, R.M, R.B, R.C, R.freq_mask, dBadd, dF, dX, dZ, dA)) return -1;
+    if (finish_timed(c)) return -2;
+    D2H(c, Xi, dX, nf * sizeof(cplx));
+    if (Z) D2H(c, Z, dZ, (size_t)nSys * nn * nw * sizeof(cplx));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return 0;
 }
 
 extern "C" int raftx_solve_system_resident(raftx_ctx *c, int nUnit, const double *Mc, const double *Bc, const double *Cc,

@@ -144,11 +144,13 @@ class Engine:
         nIter = int(model.nIter) + 1                                         # :977
         converged = False
         niter = 0
-        B_tot = B_lin
+        # M, C and the iterate-independent part of B stay on the device for the whole fixed point (with the rotor's
+        # frequency-dependent matrices they are [n,n,nw]: 7.2 MB each at 150 DOFs x 40 bins); an iteration sends B_drag
+        ctx.dense_resident(model.w, M_lin[None], B_lin[None], C_lin[None])
+        B_drag = np.zeros([n, n])
         for iiter in range(nIter):
             B_drag = self._linearization_general(fowt, XiLast)               # :1063-1064
-            B_tot = B_lin + (B_drag[:, :, None] if B_lin.ndim == 3 else B_drag)
-            Xi = ctx.solve_dense(model.w, M_lin, B_tot, C_lin, (F_lin + fowt._raftx_Fdrag[0])[None])[0]
+            Xi = ctx.solve_dense_resident((F_lin + fowt._raftx_Fdrag[0])[None, None], Badd=B_drag[None])[0, 0]
             niter = iiter + 1
             if np.isnan(Xi).any():
                 raise Exception("Nan detected in response vector Xi.")       # :1098-1099
@@ -166,7 +168,9 @@ class Engine:
         model.Xi = np.zeros([nH + 1, model.nDOF, nw], dtype=complex)         # :1195
         # the impedance of the last iteration (:1155) is the one every heading is solved with (:1191, :1216): it comes
         # back from this call only (14 MB for 150 DOFs x 40 bins)
-        model.Xi[:nH], fowt.Z = ctx.solve_dense(model.w, M_lin, B_tot, C_lin, F_wave, want_Z=True)
+        Xi_h, Z = ctx.solve_dense_resident(F_wave[None], Badd=B_drag[None], want_Z=True)
+        model.Xi[:nH], fowt.Z = Xi_h[0], Z[0]
+        ctx.dense_resident(None, None, None, None)
         fowt.F_hydro_drag = fowt._raftx_Fdrag[nH - 1].copy()
         fowt.Xi = model.Xi[:, :n, :]                                         # :1251-1255
         fowt.Xi_fullDOF = np.zeros([nH + 1, int(fowt.nFullDOF), nw], dtype=complex)

@@ -8,7 +8,8 @@ once:
   * every structural node with wet strips of every unit is one "design" of the strip kernels (raftx_excitation /
     raftx_linearize: arms about the node's own position, raft_member.py:1969-1976, 2046-2056) -- one launch per iteration
     for the whole batch instead of one per unit and case;
-  * the impedance solves of all units, cases and bins are ONE launch of raftx_solve_dense_batch (grid = bins x systems);
+  * the impedance solves of all units, cases and bins are ONE launch (raftx_solve_dense_resident, grid = bins x systems):
+    M, B, C of the units stay on the device for the whole fixed point, an iteration sends the drag linearisations only;
   * between the two, the projections with each unit's T (node motions T_node Xi, sum_u T_u^T B_u T_u, T^T F) are batched
     matrix products on the host, and the convergence test / relaxation of raft_model.py:1103,1133 runs per (unit, case):
     a pair that has converged keeps its response and drops out of the linearisation's effect (its rows are still swept --
@@ -98,8 +99,7 @@ class FlexSweep:
         M = np.array([u.M for u in self.units])
         B0 = np.array([u.B for u in self.units])
         C0 = np.array([u.C for u in self.units])
-        Msys = np.repeat(M, nC, axis=0)                              # systems = (unit, case) pairs, unit-major
-        Csys = np.repeat(C0, nC, axis=0)
+        ctx.dense_resident(self.w, M, B0, C0)                        # systems = (unit, case) pairs, unit-major: unit = system // nC
         XiLast = np.full((nD, nC, n, nw), self.XiStart, dtype=complex)           # :999
         Xi = np.zeros((nD, nC, n, nw), dtype=complex)
         B_drag = np.zeros((nD, nC, n, n))
@@ -125,9 +125,8 @@ class FlexSweep:
                 B_drag[d, act] = np.matmul(T2[d].T, BT)[act]                                      # sum_u T_u^T B_u T_u
                 Fs = Fdn[lo:hi].transpose(1, 2, 0, 3, 4).reshape(nC, nH, -1, nw)                  # [nC, nH, nNode * 6, nw]
                 F_drag[d, act] = np.matmul(T2[d].T, Fs)[act]                                      # T^T F_full
-            Bsys = (B0[:, None] + B_drag).reshape(nD * nC, n, n)
             rhs = (F_iner[:, :, 0] + F_drag[:, :, 0]).reshape(nD * nC, 1, n, nw)           # :1048, 1087
-            X = ctx.solve_dense_batch(self.w, Msys, Bsys, Csys, rhs)[:, 0].reshape(nD, nC, n, nw)
+            X = ctx.solve_dense_resident(rhs, Badd=B_drag.reshape(nD * nC, n, n))[:, 0].reshape(nD, nC, n, nw)
             t_dense += ctx.last_kernel_ms()
             for d in range(nD):
                 for c in range(nC):
@@ -145,10 +144,10 @@ class FlexSweep:
                     else:
                         XiLast[d, c] = 0.2 * XiLast[d, c] + 0.8 * X[d, c]                          # :1133
         # every heading with the impedance of the pair's last iteration (:1155, 1191, 1212-1216)
-        Bsys = (B0[:, None] + B_drag).reshape(nD * nC, n, n)
         F_wave = (F_iner + F_drag).reshape(nD * nC, nH, n, nw)
-        out = ctx.solve_dense_batch(self.w, Msys, Bsys, Csys, F_wave, want_Z=want_Z)
+        out = ctx.solve_dense_resident(F_wave, Badd=B_drag.reshape(nD * nC, n, n), want_Z=want_Z)
         t_dense += ctx.last_kernel_ms()
+        ctx.dense_resident(None, None, None, None)
         res = {"Xi": (out[0] if want_Z else out).reshape(nD, nC, nH, n, nw), "niter": niter,
                "flags": conv.astype(np.int32) | (2 * np.isnan(Xi).any(axis=(2, 3))).astype(np.int32),
                "B_drag": B_drag, "kernel_ms": (t_strip, t_dense)}
