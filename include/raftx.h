@@ -239,6 +239,24 @@ int raftx_dense_resident(raftx_ctx *ctx, int nSet, int n, int nw, const double *
                          const double *C, int freq_mask);
 int raftx_solve_dense_resident(raftx_ctx *ctx, int nPer, const double *Badd, int nRhs, const raftx_c128 *F, raftx_c128 *Xi,
                                raftx_c128 *Z);
+/* The whole fixed point of such units on the device, every (unit, sea state) of a batch at once: raft_model.py:1052-1155
+ * with the projections of raft_fowt.py:1886-1888, 1912-1936 --
+ *   XiLast <- XiStart; repeat <= nIter+1 times { node motions T_node XiLast; drag linearisation of every (node, sea state)
+ *   (the strip kernels of raftx_linearize); B_drag = sum_nodes T_node^T B_node T_node, F_drag = sum_nodes T_node^T F_node;
+ *   Xi = (-w^2 M + i w (B + B_drag) + C)^-1 (F_lin + F_drag)[heading 0]; converged (|Xi - XiLast| / (|Xi| + tol) < tol for all
+ *   entries)? else XiLast <- 0.2 XiLast + 0.8 Xi }, then every heading with the impedance of the last iteration.
+ * A pair that has converged keeps the results of ITS last iteration (as if it had been solved alone).
+ * The RESIDENT designs are the wet structural nodes, unit after unit (raftx_upload_designs with the strip tables of
+ * raft_amd/strips.py pack_fowt_nodes: node i of unit u is design nodeOff[u] + i, nodeOff [nUnit+1]); the resident sea
+ * states (raftx_upload_cases) are shared by the units.  Tn [nNode,6,n]: the six rows of each node in its unit's T;
+ * M, B [nUnit,n,n] or [nUnit,n,n,nw] (freq_mask bits 0, 1), C [nUnit,n,n]: raft_model.py:1045-1047; F_lin
+ * [nUnit,nCase,nHead,n,nw]: every excitation but the drag's (:1048).
+ * Out: Xi [nUnit,nCase,nHead,n,nw]; niter, flags [nUnit,nCase] (bit 0 converged, bit 1 NaN); B_drag [nUnit,nCase,n,n],
+ * F_drag [nUnit,nCase,nHead,n,nw], Z [nUnit,nCase,n,n,nw] or NULL each. */
+int raftx_flex_solve(raftx_ctx *ctx, int nUnit, const int64_t *nodeOff, int n, const double *Tn, const double *M,
+                     const double *B, const double *C, int freq_mask, const raftx_c128 *F_lin, int nIter, double tol,
+                     double XiStart, raftx_c128 *Xi, int32_t *niter, int32_t *flags, double *B_drag, raftx_c128 *F_drag,
+                     raftx_c128 *Z);
 
 /* The same coupled solve fed from the RESIDENT results of raftx_solve_dynamics_device (which must have
  * kept Z and F_wave): consecutive groups of nUnit designs are the units of one array; for group g,
@@ -531,6 +549,9 @@ int raftx_device_synchronize(raftx_ctx *ctx);
 int raftx_last_solve_kernel(raftx_ctx *ctx, int *flags, int *waves_per_simd, int *cache_slots);
 /* The same with the table-driven sincos the fused fixed point uses at its run starts (64-entry table in LDS). */
 int raftx_debug_math_table(raftx_ctx *ctx, int n, const double *x, double *sin_out, double *cos_out, double *exp_out);
+/* Test hook: out [n,n] = A^T W for A, W [K,n] through the projection kernel of raftx_flex_solve (MFMA tiles): checked
+ * against NumPy with an ASYMMETRIC product (the projections themselves are symmetric and would hide a transposed tile). */
+int raftx_debug_flex_gemm(raftx_ctx *ctx, int K, int n, const double *A, const double *W, double *out);
 
 #ifdef __cplusplus
 }

@@ -31,7 +31,7 @@ EXPORTS = (
     "raftx_sweep_prepare",
     "raftx_sweep_launch",
     "raftx_sweep_wait",
-    "raftx_sweep_cancel", "raftx_device_count", "raftx_solve_dense_batch", "raftx_dense_resident", "raftx_solve_dense_resident",
+    "raftx_sweep_cancel", "raftx_device_count", "raftx_solve_dense_batch", "raftx_dense_resident", "raftx_solve_dense_resident", "raftx_flex_solve", "raftx_debug_flex_gemm",
     "raftx_comm_unique_id", "raftx_comm_init", "raftx_comm_destroy", "raftx_comm_broadcast", "raftx_comm_gather_rows",
     "raftx_comm_gather_xi", "raftx_comm_reduce_sum",
 )
@@ -122,6 +122,11 @@ class RaftxLib:
         L.raftx_dense_resident.restype = C.c_int
         L.raftx_solve_dense_resident.argtypes = [_vp, C.c_int, _vp, C.c_int, _vp, _vp, _vp]
         L.raftx_solve_dense_resident.restype = C.c_int
+        L.raftx_flex_solve.argtypes = [_vp, C.c_int, _vp, C.c_int, _vp, _vp, _vp, _vp, C.c_int, _vp, C.c_int, C.c_double, C.c_double,
+                                       _vp, _vp, _vp, _vp, _vp, _vp]
+        L.raftx_flex_solve.restype = C.c_int
+        L.raftx_debug_flex_gemm.argtypes = [_vp, C.c_int, C.c_int, _vp, _vp, _vp]
+        L.raftx_debug_flex_gemm.restype = C.c_int
         L.raftx_device_locality.argtypes = [C.c_int, C.c_char_p, C.c_int, C.POINTER(C.c_int)]
         L.raftx_device_locality.restype = C.c_int
         L.raftx_host_alloc.argtypes = [_vp, C.c_size_t, C.POINTER(_vp)]
@@ -794,6 +799,46 @@ class Context:
         rc = self.rlib.lib.raftx_solve_dense_resident(self._h, nS // nSet, _ptr(Badd), nR, _ptr(F), _ptr(Xi), _ptr(Z))
         self._check(rc, "raftx_solve_dense_resident")
         return (Xi, Z) if want_Z else Xi
+
+    def flex_solve(self, node_off, Tn, M, B, C_, F_lin, nIter, tol, XiStart, want_B=True, want_F=True, want_Z=False):
+        """The fixed point of units with more than 6 reduced DOFs on the resident node tables and sea states
+        (raftx_flex_solve): node_off [nUnit+1], Tn [nNode,6,n], M, B [nUnit,n,n(,nw)], C_ [nUnit,n,n], F_lin
+        [nUnit,nCase,nHead,n,nw].  dict Xi [nUnit,nCase,nHead,n,nw], niter, flags [nUnit,nCase], B_drag, F_drag, Z."""
+        node_off = np.ascontiguousarray(node_off, dtype=np.int64)
+        nU = len(node_off) - 1
+        Tn = _f64(Tn)
+        n = Tn.shape[2]
+        F_lin = _c128(F_lin)
+        nC, nH, nw = F_lin.shape[1], F_lin.shape[2], F_lin.shape[4]
+        if Tn.shape != (int(node_off[-1]), 6, n) or F_lin.shape != (nU, nC, nH, n, nw):
+            raise ValueError("flex_solve: Tn must be [nNode,6,n] and F_lin [nUnit,nCase,nHead,n,nw]")
+        M, B = _f64(M), _f64(B)
+        mask = 0
+        for bit, A, name in ((1, M, "M"), (2, B, "B")):
+            if A.shape == (nU, n, n, nw):
+                mask |= bit
+            elif A.shape != (nU, n, n):
+                raise ValueError("%s must be [nUnit,n,n] or [nUnit,n,n,nw]" % name)
+        C_ = _f64(C_, (nU, n, n), "C")
+        Xi = np.empty((nU, nC, nH, n, nw), dtype=np.complex128)
+        niter = np.zeros((nU, nC), dtype=np.int32)
+        flags = np.zeros((nU, nC), dtype=np.int32)
+        Bd = np.empty((nU, nC, n, n)) if want_B else None
+        Fd = np.empty((nU, nC, nH, n, nw), dtype=np.complex128) if want_F else None
+        Z = np.empty((nU, nC, n, n, nw), dtype=np.complex128) if want_Z else None
+        rc = self.rlib.lib.raftx_flex_solve(self._h, nU, _ptr(node_off), n, _ptr(Tn), _ptr(M), _ptr(B), _ptr(C_), mask, _ptr(F_lin),
+                                            int(nIter), float(tol), float(XiStart), _ptr(Xi), _ptr(niter), _ptr(flags), _ptr(Bd),
+                                            _ptr(Fd), _ptr(Z))
+        self._check(rc, "raftx_flex_solve")
+        return {"Xi": Xi, "niter": niter, "flags": flags, "B_drag": Bd, "F_drag": Fd, "Z": Z}
+
+    def debug_flex_gemm(self, A, W):
+        """A^T W ([K,n] each, K a multiple of 6) through the projection kernel of raftx_flex_solve (test hook)."""
+        A, W = _f64(A), _f64(W)
+        K, n = A.shape
+        out = np.empty((n, n))
+        self._check(self.rlib.lib.raftx_debug_flex_gemm(self._h, K, n, _ptr(A), _ptr(W), _ptr(out)), "raftx_debug_flex_gemm")
+        return out
 
     def synchronize(self):
         """hipDeviceSynchronize on the context's device"""

@@ -23,8 +23,10 @@ __device__ __forceinline__ void argmax_step(double &v, int &r, int off) {
 __global__ void __launch_bounds__(256) k_solve_dense(int n, int nRhs, int nw, const double *__restrict__ w,
                                                      const double *__restrict__ M, const double *__restrict__ B,
                                                      const double *__restrict__ C, int freq_mask, int mdiv,
-                                                     const double *__restrict__ Badd, const cplx *__restrict__ F,
-                                                     cplx *__restrict__ work, cplx *__restrict__ Xi, cplx *__restrict__ Zout) {
+                                                     const double *__restrict__ Badd, const int *__restrict__ active,
+                                                     const cplx *__restrict__ F, cplx *__restrict__ work, cplx *__restrict__ Xi,
+                                                     cplx *__restrict__ Zout) {
+    if (active && !active[blockIdx.y]) return;            // a system whose fixed point has ended keeps its last response
     __shared__ cplx rowk[DENSE_MAX_LD], colk[DENSE_MAX_LD];
     __shared__ double rbest[4];
     __shared__ int rrow[4];
@@ -159,8 +161,10 @@ template <int RB, int CB, int TJ>
 __global__ void __launch_bounds__(32 * TJ) k_solve_dense_reg2(int n, int nRhs, int nw, const double *__restrict__ w,
                                                                const double *__restrict__ M, const double *__restrict__ B,
                                                                const double *__restrict__ C, int freq_mask, int mdiv,
-                                                               const double *__restrict__ Badd, const cplx *__restrict__ F,
-                                                               cplx *__restrict__ Xi, cplx *__restrict__ Zout) {
+                                                               const double *__restrict__ Badd, const int *__restrict__ active,
+                                                               const cplx *__restrict__ F, cplx *__restrict__ Xi,
+                                                               cplx *__restrict__ Zout) {
+    if (active && !active[blockIdx.y]) return;            // a system whose fixed point has ended keeps its last response
     static_assert(RB * 32 <= 256 && RB <= 8, "k_solve_dense_reg2: the pivot key carries the row in eight bits");
     constexpr int NC = CB * TJ;                           // columns of the augmented matrix the grid covers
     __shared__ cplx stage[NC];                            // the pivot row of the step

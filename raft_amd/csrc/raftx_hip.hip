@@ -78,6 +78,7 @@ struct RangeScope {
 #include "raftx_qtf.h"
 #include "raftx_geom.h"
 #include "raftx_dense.h"
+#include "raftx_flex.h"
 
 // Coupled array solve (raft_model.py:1164-1236): Xi = Z_sys^-1 F for every (system, bin).  One wavefront per
 // (system, bin), NBIN (1, 2 or 4: what fits LDS) consecutive bins per workgroup so that the loads of one matrix entry
@@ -1551,18 +1552,10 @@ extern "C" int raftx_excitation(raftx_ctx *c, raftx_c128 *F_iner) {
     return 0;
 }
 
-extern "C" int raftx_linearize(raftx_ctx *c, const raftx_c128 *Xi, double *B_drag, raftx_c128 *F_drag) {
-    if (check_ready(c)) return -1;
-    if (!Xi) FAIL(c, "linearize: Xi is NULL");
-    HIPCHK(c, hipSetDevice(c->device));
+// one drag linearisation on device arrays (enqueued on the ctx stream between ev0 and the caller's ev1)
+static int linearize_enqueue(raftx_ctx *c, const cplx *dXi, double *dB, cplx *dF) {
     const DevTables &T = c->T;
-    size_t npair = (size_t)T.nDesign * T.nCase;
-    Scratch sc(c);
-    cplx *dXi = sc.alloc<cplx>(npair * 6 * T.nw);
-    double *dB = B_drag ? sc.alloc<double>(npair * 36) : nullptr;
-    cplx *dF = F_drag ? sc.alloc<cplx>(npair * T.nHead * 6 * T.nw) : nullptr;
-    if (npair && (!dXi || (B_drag && !dB) || (F_drag && !dF))) FAIL(c, "linearize: device allocation failed");
-    if (npair) H2D(c, dXi, Xi, npair * 6 * T.nw * sizeof(cplx));
+    const size_t npair = (size_t)T.nDesign * T.nCase;
     const Shape sh = pick_shape(T.nw);
     const size_t lds = lds_bytes(c->maxS, 0, sh.threads / 64, stage_policy(sh.nb, shape_maxt(sh)));
 #define DISPATCH_ONE_(NB_, MT_, MB_)                                                                                  \
@@ -1576,6 +1569,21 @@ extern "C" int raftx_linearize(raftx_ctx *c, const raftx_c128 *Xi, double *B_dra
     }
     DISPATCH_SHAPE(sh, _);
 #undef DISPATCH_ONE_
+    return 0;
+}
+extern "C" int raftx_linearize(raftx_ctx *c, const raftx_c128 *Xi, double *B_drag, raftx_c128 *F_drag) {
+    if (check_ready(c)) return -1;
+    if (!Xi) FAIL(c, "linearize: Xi is NULL");
+    HIPCHK(c, hipSetDevice(c->device));
+    const DevTables &T = c->T;
+    size_t npair = (size_t)T.nDesign * T.nCase;
+    Scratch sc(c);
+    cplx *dXi = sc.alloc<cplx>(npair * 6 * T.nw);
+    double *dB = B_drag ? sc.alloc<double>(npair * 36) : nullptr;
+    cplx *dF = F_drag ? sc.alloc<cplx>(npair * T.nHead * 6 * T.nw) : nullptr;
+    if (npair && (!dXi || (B_drag && !dB) || (F_drag && !dF))) FAIL(c, "linearize: device allocation failed");
+    if (npair) H2D(c, dXi, Xi, npair * 6 * T.nw * sizeof(cplx));
+    if (linearize_enqueue(c, dXi, dB, dF)) return -1;
     if (finish_timed(c)) return -2;
     if (dB) D2H(c, B_drag, dB, npair * 36 * sizeof(double));
     if (dF) D2H(c, F_drag, dF, npair * T.nHead * 6 * T.nw * sizeof(cplx));
@@ -2129,12 +2137,13 @@ static bool dense_reg_shape(int n, int nRhs) {
     return !dense_l2 && n + nRhs <= 160;
 }
 static int dense_launch(raftx_ctx *c, int nSys, int mdiv, int n, int nRhs, int nw, const double *dw, const double *dM, const double *dB,
-                        const double *dC, int freq_mask, const double *dBadd, const cplx *dF, cplx *dX, cplx *dZ, cplx *dA) {
+                        const double *dC, int freq_mask, const double *dBadd, const cplx *dF, cplx *dX, cplx *dZ, cplx *dA,
+                        const int *dActive = nullptr) {
     const dim3 grid((unsigned)nw, (unsigned)nSys);
     if (dense_reg_shape(n, nRhs)) {
 #define DENSE_REG_(RB_, CB_)                                                                                            \
         hipLaunchKernelGGL((k_solve_dense_reg2<RB_, CB_, 16>), grid, dim3(512), 0, c->stream, n, nRhs, nw, dw, dM, dB, dC, freq_mask, \
-                           mdiv, dBadd, dF, dX, dZ)
+                           mdiv, dBadd, dActive, dF, dX, dZ)
         // entries per thread: the smallest 32 RB x 16 CB grid that holds [Z | F] (measured at 60 DOFs: 0.076 ms with 3 x 6
         // against 0.136 with 5 x 10 and 0.23 for the L2-workspace kernel)
         if (n + nRhs <= 32) DENSE_REG_(1, 2);
@@ -2144,7 +2153,7 @@ static int dense_launch(raftx_ctx *c, int nSys, int mdiv, int n, int nRhs, int n
         else DENSE_REG_(5, 10);
 #undef DENSE_REG_
     } else {
-        hipLaunchKernelGGL(k_solve_dense, grid, dim3(256), 0, c->stream, n, nRhs, nw, dw, dM, dB, dC, freq_mask, mdiv, dBadd, dF, dA, dX, dZ);
+        hipLaunchKernelGGL(k_solve_dense, grid, dim3(256), 0, c->stream, n, nRhs, nw, dw, dM, dB, dC, freq_mask, mdiv, dBadd, dActive, dF, dA, dX, dZ);
     }
     HIPCHK(c, hipGetLastError());
     return 0;
@@ -2247,6 +2256,103 @@ extern "C" int raftx_solve_dense_resident(raftx_ctx *c, int nPer, const double *
     D2H(c, Xi, dX, nf * sizeof(cplx));
     if (Z) D2H(c, Z, dZ, (size_t)nSys * nn * nw * sizeof(cplx));
     HIPCHK(c, hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+// The fixed point of flexible units on the device (raftx_flex.h; include/raftx.h raftx_flex_solve).
+extern "C" int raftx_flex_solve(raftx_ctx *c, int nUnit, const int64_t *nodeOff, int n, const double *Tn, const double *M,
+                                const double *B, const double *C, int freq_mask, const raftx_c128 *F_lin, int nIter, double tol,
+                                double XiStart, raftx_c128 *Xi, int32_t *niter, int32_t *flags, double *B_drag, raftx_c128 *F_drag,
+                                raftx_c128 *Z) {
+    RangeScope range_("raftx_flex_solve: fixed point of units with flexible members");
+    if (check_ready(c)) return -1;
+    if (nUnit < 1 || !nodeOff || !Tn || !M || !B || !C || !F_lin || !Xi || !niter || !flags || nIter < 0)
+        FAIL(c, "flex_solve: bad arguments");
+    HIPCHK(c, hipSetDevice(c->device));
+    const DevTables &T = c->T;
+    const int nCase = T.nCase, nHead = T.nHead, nw = T.nw, nNode = T.nDesign;
+    if (nodeOff[0] != 0 || nodeOff[nUnit] != nNode) FAIL(c, "flex_solve: nodeOff must run from 0 to the %d resident node tables", nNode);
+    for (int u = 0; u < nUnit; u++)
+        if (nodeOff[u + 1] < nodeOff[u]) FAIL(c, "flex_solve: node offsets not monotone");
+    const int nSys = nUnit * nCase;
+    if (dense_check(c, "flex_solve", nSys, n, nHead, nw)) return -1;
+    if (n < 6) FAIL(c, "flex_solve: n = %d reduced DOFs", n);
+    Scratch sc(c);
+    const size_t nn = (size_t)n * n, nxs = (size_t)n * nw, npn = (size_t)nNode * nCase;
+    const size_t nM = (size_t)nUnit * nn * ((freq_mask & 1) ? nw : 1), nB = (size_t)nUnit * nn * ((freq_mask & 2) ? nw : 1);
+    const bool reg1 = dense_reg_shape(n, 1), regH = dense_reg_shape(n, nHead);
+    std::vector<int> hNodeUnit((size_t)nNode);
+    for (int u = 0; u < nUnit; u++)
+        for (int64_t i = nodeOff[u]; i < nodeOff[u + 1]; i++) hNodeUnit[(size_t)i] = u;
+    double *dM = sc.alloc<double>(nM), *dB = sc.alloc<double>(nB), *dC = sc.alloc<double>((size_t)nUnit * nn);
+    double *dTn = sc.alloc<double>((size_t)nNode * 6 * n), *dW = sc.alloc<double>((size_t)nCase * nNode * 6 * n);
+    double *dBn = sc.alloc<double>(npn * 36), *dBd = sc.alloc<double>((size_t)nSys * nn);
+    int64_t *dOff = sc.alloc<int64_t>((size_t)nUnit + 1);
+    int *dNodeUnit = sc.alloc<int>((size_t)nNode), *dAct = sc.alloc<int>((size_t)nSys), *dNi = sc.alloc<int>((size_t)nSys),
+        *dFl = sc.alloc<int>((size_t)nSys), *dCount = sc.alloc<int>(1);
+    cplx *dXiN = sc.alloc<cplx>(npn * 6 * nw), *dFn = sc.alloc<cplx>(npn * nHead * 6 * nw);
+    cplx *dFlin = sc.alloc<cplx>((size_t)nSys * nHead * nxs), *dFw = sc.alloc<cplx>((size_t)nSys * nHead * nxs);
+    cplx *dFd = sc.alloc<cplx>((size_t)nSys * nHead * nxs), *dRhs = sc.alloc<cplx>((size_t)nSys * nxs);
+    cplx *dXnew = sc.alloc<cplx>((size_t)nSys * nxs), *dXi = sc.alloc<cplx>((size_t)nSys * nxs), *dXl = sc.alloc<cplx>((size_t)nSys * nxs);
+    cplx *dXh = sc.alloc<cplx>((size_t)nSys * nHead * nxs);
+    cplx *dA = (reg1 && regH) ? nullptr : sc.alloc<cplx>((size_t)nSys * nw * n * (n + nHead));
+    cplx *dZ = Z ? sc.alloc<cplx>((size_t)nSys * nn * nw) : nullptr;
+    if (!dM || !dB || !dC || !dTn || !dW || !dBn || !dBd || !dOff || !dNodeUnit || !dAct || !dNi || !dFl || !dCount || !dXiN || !dFn ||
+        !dFlin || !dFw || !dFd || !dRhs || !dXnew || !dXi || !dXl || !dXh || (!(reg1 && regH) && !dA) || (Z && !dZ))
+        FAIL(c, "flex_solve: device allocation failed");
+    if (pin_reserve(c, 16)) return -2;
+    H2D(c, dM, M, nM * sizeof(double));
+    H2D(c, dB, B, nB * sizeof(double));
+    H2D(c, dC, C, (size_t)nUnit * nn * sizeof(double));
+    H2D(c, dTn, Tn, (size_t)nNode * 6 * n * sizeof(double));
+    H2D(c, dOff, nodeOff, ((size_t)nUnit + 1) * sizeof(int64_t));
+    H2D(c, dNodeUnit, hNodeUnit.data(), (size_t)nNode * sizeof(int));
+    H2D(c, dFlin, F_lin, (size_t)nSys * nHead * nxs * sizeof(cplx));
+    HIPCHK(c, hipMemsetAsync(dNi, 0, (size_t)nSys * sizeof(int), c->stream));
+    HIPCHK(c, hipMemsetAsync(dFl, 0, (size_t)nSys * sizeof(int), c->stream));
+    HIPCHK(c, hipMemsetAsync(dBd, 0, (size_t)nSys * nn * sizeof(double), c->stream));
+    HIPCHK(c, hipMemsetAsync(dXi, 0, (size_t)nSys * nxs * sizeof(cplx), c->stream));
+    HIPCHK(c, hipMemsetAsync(dFd, 0, (size_t)nSys * nHead * nxs * sizeof(cplx), c->stream));
+    {
+        std::vector<int> ones((size_t)nSys, 1);
+        H2D(c, dAct, ones.data(), (size_t)nSys * sizeof(int));
+        HIPCHK(c, hipStreamSynchronize(c->stream));                       // (the host vectors above go out of scope)
+    }
+    const size_t nxl = (size_t)nSys * nxs;
+    hipLaunchKernelGGL(k_flex_fill, dim3((unsigned)((nxl + 255) / 256)), dim3(256), 0, c->stream, nxl, cplx{XiStart, 0.0}, dXl);   // :999
+    hipEvent_t e0 = c->evG2, e1 = c->evG3;                                // (free here: the span of the whole fixed point)
+    HIPCHK(c, hipEventRecord(e0, c->stream));
+    const int nt = (n + 15) / 16;
+    const dim3 gridB((unsigned)((nt * nt + 3) / 4), (unsigned)nSys), gridF((unsigned)((nxs + 255) / 256), (unsigned)(nSys * nHead));
+    volatile int *hCount = reinterpret_cast<volatile int *>(c->pin);
+    for (int it = 0; it <= nIter; it++) {                                 // :977, 1052
+        // node motions -> linearisation of every (node, sea state) -> projections with the units' T
+        hipLaunchKernelGGL(k_flex_node_motion, dim3((unsigned)npn), dim3(256), 0, c->stream, nCase, n, nw, dNodeUnit, dTn, dXl, dXiN);
+        if (linearize_enqueue(c, dXiN, dBn, dFn)) return -1;
+        hipLaunchKernelGGL(k_flex_w, dim3((unsigned)npn), dim3(256), 0, c->stream, nNode, nCase, n, dTn, dBn, dW);
+        hipLaunchKernelGGL(k_flex_gemm_B, gridB, dim3(256), 0, c->stream, nNode, nCase, n, dOff, dTn, dW, dAct, dBd);
+        hipLaunchKernelGGL(k_flex_project_F, gridF, dim3(256), 0, c->stream, nCase, nHead, n, nw, dOff, dTn, dFn, dFlin, dAct, dFw, dFd, dRhs);
+        if (dense_launch(c, nSys, nCase, n, 1, nw, T.w, dM, dB, dC, freq_mask, dBd, dRhs, dXnew, nullptr, dA, dAct)) return -1;
+        HIPCHK(c, hipMemsetAsync(dCount, 0, sizeof(int), c->stream));
+        hipLaunchKernelGGL(k_flex_converge, dim3((unsigned)nSys), dim3(256), 0, c->stream, n, nw, tol, it, dXnew, dXi, dXl, dAct, dNi, dFl,
+                           dCount);
+        HIPCHK(c, hipMemcpyAsync(const_cast<int *>(hCount), dCount, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        if (*hCount == 0) break;
+    }
+    // every heading with the impedance of the pair's last iteration (:1155, 1191, 1212-1216)
+    if (dense_launch(c, nSys, nCase, n, nHead, nw, T.w, dM, dB, dC, freq_mask, dBd, dFw, dXh, dZ, dA)) return -1;
+    HIPCHK(c, hipEventRecord(e1, c->stream));
+    D2H(c, Xi, dXh, (size_t)nSys * nHead * nxs * sizeof(cplx));
+    D2H(c, niter, dNi, (size_t)nSys * sizeof(int));
+    D2H(c, flags, dFl, (size_t)nSys * sizeof(int));
+    if (B_drag) D2H(c, B_drag, dBd, (size_t)nSys * nn * sizeof(double));
+    if (F_drag) D2H(c, F_drag, dFd, (size_t)nSys * nHead * nxs * sizeof(cplx));
+    if (Z) D2H(c, Z, dZ, (size_t)nSys * nn * nw * sizeof(cplx));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    float ms = 0.f;
+    HIPCHK(c, hipEventElapsedTime(&ms, e0, e1));
+    c->last_ms = ms;
     return 0;
 }
 
@@ -3360,6 +3466,25 @@ extern "C" int raftx_last_solve_kernel(raftx_ctx *c, int *flags, int *waves_per_
 static int debug_math(raftx_ctx *c, int n, const double *x, double *sin_out, double *cos_out, double *exp_out, int table);
 extern "C" int raftx_debug_math(raftx_ctx *c, int n, const double *x, double *sin_out, double *cos_out, double *exp_out) {
     return debug_math(c, n, x, sin_out, cos_out, exp_out, 0);
+}
+extern "C" int raftx_debug_flex_gemm(raftx_ctx *c, int K, int n, const double *A, const double *W, double *out) {
+    if (!c) return -1;
+    if (K < 1 || K % 6 || n < 1 || !A || !W || !out) FAIL(c, "debug_flex_gemm: K must be a multiple of 6");
+    HIPCHK(c, hipSetDevice(c->device));
+    Scratch sc(c);
+    double *dA = sc.alloc<double>((size_t)K * n), *dW = sc.alloc<double>((size_t)K * n), *dO = sc.alloc<double>((size_t)n * n);
+    int64_t *dOff = sc.alloc<int64_t>(2);
+    if (!dA || !dW || !dO || !dOff) FAIL(c, "debug_flex_gemm: device allocation failed");
+    const int64_t off[2] = {0, K / 6};
+    H2D(c, dA, A, (size_t)K * n * sizeof(double));
+    H2D(c, dW, W, (size_t)K * n * sizeof(double));
+    H2D(c, dOff, off, sizeof(off));
+    const int nt = (n + 15) / 16;
+    hipLaunchKernelGGL(k_flex_gemm_B, dim3((unsigned)((nt * nt + 3) / 4), 1), dim3(256), 0, c->stream, K / 6, 1, n, dOff, dA, dW,
+                       (const int *)nullptr, dO);
+    D2H(c, out, dO, (size_t)n * n * sizeof(double));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return 0;
 }
 extern "C" int raftx_debug_math_table(raftx_ctx *c, int n, const double *x, double *sin_out, double *cos_out, double *exp_out) {
     return debug_math(c, n, x, sin_out, cos_out, exp_out, 1);

@@ -140,37 +140,28 @@ class Engine:
         if np.any(B_turb):
             B_lin = B_turb + B_lin[:, :, None]
         F_lin = fowt.F_BEM[0] + fowt.F_hydro_iner[0] + fowt.Fhydro_2nd[0]    # :1048
-        XiLast = np.zeros([n, nw], dtype=complex) + model.XiStart            # :999
-        nIter = int(model.nIter) + 1                                         # :977
-        converged = False
-        niter = 0
-        # M, C and the iterate-independent part of B stay on the device for the whole fixed point (with the rotor's
-        # frequency-dependent matrices they are [n,n,nw]: 7.2 MB each at 150 DOFs x 40 bins); an iteration sends B_drag
-        ctx.dense_resident(model.w, M_lin[None], B_lin[None], C_lin[None])
-        B_drag = np.zeros([n, n])
-        for iiter in range(nIter):
-            B_drag = self._linearization_general(fowt, XiLast)               # :1063-1064
-            Xi = ctx.solve_dense_resident((F_lin + fowt._raftx_Fdrag[0])[None, None], Badd=B_drag[None])[0, 0]
-            niter = iiter + 1
-            if np.isnan(Xi).any():
-                raise Exception("Nan detected in response vector Xi.")       # :1098-1099
-            tolCheck = np.abs(Xi - XiLast) / (np.abs(Xi) + tol)              # :1103
-            if (tolCheck < tol).all():
-                converged = True
-                if display > 1:
-                    print(f" Iteration {iiter}, converged (largest change is {np.max(tolCheck):.5f} < {tol})")
-                break
-            XiLast = 0.2 * XiLast + 0.8 * Xi                                 # :1133
+        # the fixed point itself runs on the device (raftx_flex_solve): node motions, strip linearisation of every node,
+        # the projections with T, the dense solves and the convergence test; M, C and the iterate-independent part of B
+        # (with the rotor's frequency-dependent matrices [n,n,nw]: 7.2 MB each at 150 DOFs x 40 bins) go up once
+        rows, tables, Tn = fowt._raftx_nodes
+        nH = fowt.nWaves
+        F_lin = fowt.F_BEM + fowt.F_hydro_iner + fowt.Fhydro_2nd             # :1048, 1212 without the drag excitation
+        if tables:
+            self._upload([fowt], fowt.zeta, fowt.beta, tables=tables)         # no-op while these tables are resident
+        out = ctx.flex_solve([0, len(rows)], Tn, M_lin[None], B_lin[None], C_lin[None], F_lin[None, None], int(model.nIter), tol,
+                             model.XiStart, want_Z=True)
+        niter = int(out["niter"][0, 0])
+        if int(out["flags"][0, 0]) & 2:
+            raise Exception("Nan detected in response vector Xi.")           # :1098-1099
+        converged = bool(int(out["flags"][0, 0]) & 1)
+        if converged and display > 1:
+            print(f" Iteration {niter - 1}, converged (within {tol})")
         if display > 0 and not converged:
             print("WARNING - solveDynamics iteration did not converge to the tolerance.")
-        nH = fowt.nWaves
-        F_wave = fowt.F_BEM + fowt.F_hydro_iner + fowt._raftx_Fdrag + fowt.Fhydro_2nd       # :1212
+        fowt.B_hydro_drag = out["B_drag"][0, 0]
+        fowt._raftx_Fdrag = out["F_drag"][0, 0]
         model.Xi = np.zeros([nH + 1, model.nDOF, nw], dtype=complex)         # :1195
-        # the impedance of the last iteration (:1155) is the one every heading is solved with (:1191, :1216): it comes
-        # back from this call only (14 MB for 150 DOFs x 40 bins)
-        Xi_h, Z = ctx.solve_dense_resident(F_wave[None], Badd=B_drag[None], want_Z=True)
-        model.Xi[:nH], fowt.Z = Xi_h[0], Z[0]
-        ctx.dense_resident(None, None, None, None)
+        model.Xi[:nH], fowt.Z = out["Xi"][0, 0], out["Z"][0, 0]              # Z: the impedance of the last iteration (:1155)
         fowt.F_hydro_drag = fowt._raftx_Fdrag[nH - 1].copy()
         fowt.Xi = model.Xi[:, :n, :]                                         # :1251-1255
         fowt.Xi_fullDOF = np.zeros([nH + 1, int(fowt.nFullDOF), nw], dtype=complex)

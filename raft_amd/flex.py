@@ -5,15 +5,14 @@ raft/raft_fowt.py's T reduction; 150 DOFs for tests/test_data/VolturnUS-S-flexib
 (raft_amd/dropin.py Engine._solve_general).  Here the same fixed point runs for EVERY (unit, sea state) of a batch at
 once:
 
-  * every structural node with wet strips of every unit is one "design" of the strip kernels (raftx_excitation /
-    raftx_linearize: arms about the node's own position, raft_member.py:1969-1976, 2046-2056) -- one launch per iteration
-    for the whole batch instead of one per unit and case;
-  * the impedance solves of all units, cases and bins are ONE launch (raftx_solve_dense_resident, grid = bins x systems):
-    M, B, C of the units stay on the device for the whole fixed point, an iteration sends the drag linearisations only;
-  * between the two, the projections with each unit's T (node motions T_node Xi, sum_u T_u^T B_u T_u, T^T F) are batched
-    matrix products on the host, and the convergence test / relaxation of raft_model.py:1103,1133 runs per (unit, case):
-    a pair that has converged keeps its response and drops out of the linearisation's effect (its rows are still swept --
-    the launch is one -- but its result is frozen), exactly as if it had been solved alone.
+  * every structural node with wet strips of every unit is one "design" of the strip kernels (arms about the node's own
+    position, raft_member.py:1969-1976, 2046-2056) -- one launch per iteration for the whole batch;
+  * node motions T_node Xi, the projections sum_u T_u^T B_u T_u (a GEMM per pair: MFMA tiles) and T^T F, the impedance solves
+    of all units, cases and bins (one launch, grid = bins x systems) and the convergence test / relaxation of
+    raft_model.py:1103,1133 per (unit, case) all run on the device (raftx_flex_solve, raft_amd/csrc/raftx_flex.h): the host
+    only reduces the inertial excitation once, before the fixed point;
+  * a pair that has converged keeps its response and drops out of the linearisation's effect (its rows are still swept --
+    the launches cover the batch -- but its results are frozen), exactly as if it had been solved alone.
 
 Units come from live ``FOWT`` objects (``FlexUnit.from_fowt``: the reference's own T, M_struc, C_struc, C_elast ... -- the
 finite-element assembly stays upstream) or from arrays.  All units of a sweep share the frequency grid; they may differ
@@ -78,13 +77,13 @@ class FlexSweep:
 
     def run(self, ctx, want_Z=False):
         """{"Xi": [nUnit,nCase,nHead,nDOF,nw], "niter", "flags" [nUnit,nCase] (1 = converged), "B_drag" [nUnit,nCase,nDOF,nDOF],
-        "kernel_ms": (strip kernels, dense solves) summed over the iterations}."""
+        "kernel_ms": (inertial excitation sweep, the fixed point's span on the device)}."""
         nD, nC, nH, nw, n = len(self.units), self.zeta.shape[0], self.zeta.shape[1], len(self.w), self.n
         tables = [t for u in self.units for t in u.tables]
         first = np.concatenate([[0], np.cumsum([len(u.tables) for u in self.units])]).astype(int)
         nN = len(tables)
         Z6 = np.zeros((nN, 6, 6))
-        t_strip = t_dense = 0.0
+        t_strip = 0.0
         ctx.upload_designs(tables, Z6, Z6, Z6, nw)
         ctx.upload_cases(self.w, self.k, self.depth, WAVE_RHO, WAVE_G, self.zeta, self.beta)
         # stacked node rows of T per unit: T2[d] [nNode_d * 6, nDOF]
@@ -99,58 +98,10 @@ class FlexSweep:
         M = np.array([u.M for u in self.units])
         B0 = np.array([u.B for u in self.units])
         C0 = np.array([u.C for u in self.units])
-        ctx.dense_resident(self.w, M, B0, C0)                        # systems = (unit, case) pairs, unit-major: unit = system // nC
-        XiLast = np.full((nD, nC, n, nw), self.XiStart, dtype=complex)           # :999
-        Xi = np.zeros((nD, nC, n, nw), dtype=complex)
-        B_drag = np.zeros((nD, nC, n, n))
-        F_drag = np.zeros((nD, nC, nH, n, nw), dtype=complex)
-        active = np.ones((nD, nC), dtype=bool)
-        conv = np.zeros((nD, nC), dtype=bool)
-        niter = np.zeros((nD, nC), dtype=np.int32)
-        for iiter in range(self.nIter + 1):                           # :977, 1052
-            if not active.any():
-                break
-            # node motions T_node XiLast -> linearisation of every (node, case)  (raft_fowt.py:1912-1929)
-            XiN = np.empty((nN, nC, 6, nw), dtype=complex)
-            for d in range(nD):
-                XiN[first[d]:first[d + 1]] = (T2[d] @ XiLast[d]).reshape(nC, -1, 6, nw).transpose(1, 0, 2, 3)
-            Bn, Fdn = ctx.linearize(XiN)                             # [nN,nC,6,6], [nN,nC,nH,6,nw]
-            t_strip += ctx.last_kernel_ms()
-            for d in range(nD):                                       # BLAS products per unit, all its cases at once
-                act = active[d]
-                if not act.any():
-                    continue
-                Tn, lo, hi = self.units[d].Tn, first[d], first[d + 1]
-                BT = np.matmul(Bn[lo:hi].transpose(1, 0, 2, 3), Tn).reshape(nC, -1, n)           # [nC, nNode * 6, nDOF]
-                B_drag[d, act] = np.matmul(T2[d].T, BT)[act]                                      # sum_u T_u^T B_u T_u
-                Fs = Fdn[lo:hi].transpose(1, 2, 0, 3, 4).reshape(nC, nH, -1, nw)                  # [nC, nH, nNode * 6, nw]
-                F_drag[d, act] = np.matmul(T2[d].T, Fs)[act]                                      # T^T F_full
-            rhs = (F_iner[:, :, 0] + F_drag[:, :, 0]).reshape(nD * nC, 1, n, nw)           # :1048, 1087
-            X = ctx.solve_dense_resident(rhs, Badd=B_drag.reshape(nD * nC, n, n))[:, 0].reshape(nD, nC, n, nw)
-            t_dense += ctx.last_kernel_ms()
-            for d in range(nD):
-                for c in range(nC):
-                    if not active[d, c]:
-                        continue
-                    Xi[d, c] = X[d, c]
-                    niter[d, c] = iiter + 1
-                    if np.isnan(X[d, c]).any():                      # :1098: the reference raises; a batch flags and goes on
-                        active[d, c] = False
-                        continue
-                    tolCheck = np.abs(X[d, c] - XiLast[d, c]) / (np.abs(X[d, c]) + self.tol)       # :1103
-                    if (tolCheck < self.tol).all():
-                        conv[d, c] = True
-                        active[d, c] = False
-                    else:
-                        XiLast[d, c] = 0.2 * XiLast[d, c] + 0.8 * X[d, c]                          # :1133
-        # every heading with the impedance of the pair's last iteration (:1155, 1191, 1212-1216)
-        F_wave = (F_iner + F_drag).reshape(nD * nC, nH, n, nw)
-        out = ctx.solve_dense_resident(F_wave, Badd=B_drag.reshape(nD * nC, n, n), want_Z=want_Z)
-        t_dense += ctx.last_kernel_ms()
-        ctx.dense_resident(None, None, None, None)
-        res = {"Xi": (out[0] if want_Z else out).reshape(nD, nC, nH, n, nw), "niter": niter,
-               "flags": conv.astype(np.int32) | (2 * np.isnan(Xi).any(axis=(2, 3))).astype(np.int32),
-               "B_drag": B_drag, "kernel_ms": (t_strip, t_dense)}
+        out = ctx.flex_solve(first, np.concatenate([u.Tn for u in self.units]), M, B0, C0, F_iner, self.nIter, self.tol, self.XiStart,
+                             want_F=False, want_Z=want_Z)
+        t_fix = ctx.last_kernel_ms()
+        res = {"Xi": out["Xi"], "niter": out["niter"], "flags": out["flags"], "B_drag": out["B_drag"], "kernel_ms": (t_strip, t_fix)}
         if want_Z:
-            res["Z"] = out[1].reshape(nD, nC, n, n, nw)
+            res["Z"] = out["Z"]
         return res

@@ -45,12 +45,12 @@ int main(int argc, char **argv) {
     CK(hipMalloc(&dA, (size_t)nSys * nw * n * (n + nRhs) * 16));
     auto run = [&](int which) {
         if (which == 0)
-            hipLaunchKernelGGL(k_solve_dense, grid, dim3(256), 0, 0, n, nRhs, nw, dw, dM, dB, dC, 0, 1, (const double *)nullptr, dF, dA, dX, (cplx *)nullptr);
+            hipLaunchKernelGGL(k_solve_dense, grid, dim3(256), 0, 0, n, nRhs, nw, dw, dM, dB, dC, 0, 1, (const double *)nullptr, (const int *)nullptr, dF, dA, dX, (cplx *)nullptr);
         else if (which == 1)
-            hipLaunchKernelGGL((k_solve_dense_reg2<5, 10, 16>), grid, dim3(512), 0, 0, n, nRhs, nw, dw, dM, dB, dC, 0, 1, (const double *)nullptr, dF, dX,
+            hipLaunchKernelGGL((k_solve_dense_reg2<5, 10, 16>), grid, dim3(512), 0, 0, n, nRhs, nw, dw, dM, dB, dC, 0, 1, (const double *)nullptr, (const int *)nullptr, dF, dX,
                                (cplx *)nullptr);
         else
-            hipLaunchKernelGGL((k_solve_dense_reg2<3, 6, 16>), grid, dim3(512), 0, 0, n, nRhs, nw, dw, dM, dB, dC, 0, 1, (const double *)nullptr, dF, dX,
+            hipLaunchKernelGGL((k_solve_dense_reg2<3, 6, 16>), grid, dim3(512), 0, 0, n, nRhs, nw, dw, dM, dB, dC, 0, 1, (const double *)nullptr, (const int *)nullptr, dF, dX,
                                (cplx *)nullptr);
     };
     for (int which = 0; which < 3; which++) {

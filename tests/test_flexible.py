@@ -130,6 +130,110 @@ def _check_flex_sweep(ctx, n_unit):
         dropin.flex_sweep_from_models([load_model_fixture("c1_oc3spar.npz")[1]], cases)
 
 
+def _flex_problem(rng, n_unit, nodes_per_unit, n, n_case, n_head, freq_dep):
+    """A synthetic batch for raftx_flex_solve: node strip tables taken from the flexible deck (the first nodes of its
+    packing, re-used unit after unit), random T rows, well-conditioned M / B / C, random excitation."""
+    fx, model = load_model_fixture("flex_volturnus.npz")
+    fowt = model.fowtList[0]
+    from raft_amd.strips import pack_fowt_nodes
+    _, tables = pack_fowt_nodes(fowt, fowt.memberList)
+    node_off = np.concatenate([[0], np.cumsum(nodes_per_unit)]).astype(np.int64)
+    tabs = [tables[(3 * u + i) % len(tables)] for u in range(n_unit) for i in range(nodes_per_unit[u])]
+    Tn = rng.normal(size=(int(node_off[-1]), 6, n)) * 0.3
+    nw = int(model.nw)                                     # (the node tables carry the deck's MacCamy-Fuchs columns: its grid)
+    w = np.asarray(model.w)
+    k = np.asarray(fowt.k)
+    sh = (n_unit, n, n, nw) if freq_dep else (n_unit, n, n)
+    M = rng.normal(size=sh) * 1e5 + (np.eye(n) * 2e7)[(None, ..., None) if freq_dep else (None, ...)]
+    B = rng.normal(size=(n_unit, n, n)) * 1e4 + np.eye(n)[None] * 1e6
+    C = rng.normal(size=(n_unit, n, n)) * 1e5 + np.eye(n)[None] * 3e7
+    zeta = np.abs(rng.normal(size=(n_case, n_head, nw))) * np.array([0.05, 1.5, 0.4][:n_case])[:, None, None]
+    beta = rng.uniform(-0.5, 0.5, size=(n_case, n_head))
+    F_lin = (rng.normal(size=(n_unit, n_case, n_head, n, nw)) + 1j * rng.normal(size=(n_unit, n_case, n_head, n, nw))) * 1e6
+    return dict(node_off=node_off, tabs=tabs, Tn=Tn, w=w, k=k, depth=float(fowt.depth), M=M, B=B, C=C, zeta=zeta, beta=beta, F_lin=F_lin)
+
+
+def _run_flex(ctx, P, units=None, cases=None, nIter=12, tol=0.01):
+    """raftx_flex_solve on (a subset of) the problem's units and sea states"""
+    us = list(range(len(P["node_off"]) - 1)) if units is None else units
+    cs = list(range(P["zeta"].shape[0])) if cases is None else cases
+    nodes = [i for u in us for i in range(int(P["node_off"][u]), int(P["node_off"][u + 1]))]
+    off = np.concatenate([[0], np.cumsum([int(P["node_off"][u + 1] - P["node_off"][u]) for u in us])])
+    nw = len(P["w"])
+    Z6 = np.zeros((len(nodes), 6, 6))
+    ctx.upload_designs([P["tabs"][i] for i in nodes], Z6, Z6, Z6, nw)
+    ctx.upload_cases(P["w"], P["k"], P["depth"], 1025.0, 9.81, P["zeta"][cs], P["beta"][cs])
+    return ctx.flex_solve(off, P["Tn"][nodes], P["M"][us], P["B"][us], P["C"][us], P["F_lin"][us][:, cs], nIter, tol, 0.1, want_Z=True)
+
+
+def _check_flex_solve(ctx, other=None):
+    """raftx_flex_solve directly: ragged units (3, 1 and 5 wet nodes), two headings, three sea states that need different
+    numbers of iterations, frequency-dependent M.  A pair's result is that of solving it ALONE (converged pairs are frozen,
+    the others go on); `other`: a second backend that must agree (device against the checker)."""
+    rng = np.random.default_rng(11)
+    P = _flex_problem(rng, 3, [3, 1, 5], 20, 3, 2, True)
+    out = _run_flex(ctx, P)
+    assert out["Xi"].shape == (3, 3, 2, 20, len(P["w"])) and np.isfinite(out["Xi"]).all()
+    assert len(set(out["niter"].ravel().tolist())) > 1, out["niter"]          # the batch really has pairs of different length
+    assert (out["flags"] == 1).all()
+    for u, c in ((0, 0), (1, 2), (2, 1)):
+        alone = _run_flex(ctx, P, [u], [c])
+        assert int(alone["niter"][0, 0]) == int(out["niter"][u, c])
+        for key in ("Xi", "B_drag", "F_drag", "Z"):
+            assert rel_err(alone[key][0, 0], out[key][u, c]) < 1e-12, key
+    Zchk = -(P["w"] ** 2) * P["M"][2] + 1j * P["w"] * (P["B"][2] + out["B_drag"][2, 1])[:, :, None] + P["C"][2][:, :, None]
+    assert rel_err(out["Z"][2, 1], Zchk) < 1e-13
+    for h in range(2):                                                        # Z Xi = F_lin + F_drag, every heading
+        lhs = np.einsum("ijw,jw->iw", out["Z"][2, 1], out["Xi"][2, 1, h])
+        assert rel_err(lhs, P["F_lin"][2, 1, h] + out["F_drag"][2, 1, h]) < 1e-9
+    few = _run_flex(ctx, P, nIter=1)                                          # the iteration cap: not converged, flagged so
+    assert (few["niter"] == 2).all() and not (few["flags"] & 1).any()
+    if other is not None:
+        ref = _run_flex(other, P)
+        assert np.array_equal(ref["niter"], out["niter"]) and np.array_equal(ref["flags"], out["flags"])
+        for key in ("Xi", "B_drag", "F_drag", "Z"):
+            assert rel_err(out[key], ref[key]) < 1e-9, key
+    with pytest.raises(Exception, match="nodeOff"):
+        ctx.flex_solve([0, 2], P["Tn"][:2], P["M"][:1], P["B"][:1], P["C"][:1], P["F_lin"][:1], 3, 0.01, 0.1)
+
+
+def test_oracle_flex_solve_entry(oracle_ctx):
+    _check_flex_solve(oracle_ctx)
+
+
+@pytest.mark.gpu
+def test_hip_flex_solve_entry(hip_ctx, oracle_ctx):
+    _check_flex_solve(hip_ctx, oracle_ctx)
+
+
+@pytest.mark.gpu
+def test_hip_flex_solve_larger_systems(hip_ctx, oracle_ctx):
+    """150 reduced DOFs (the register-resident dense kernel's largest grid) and 170 (the L2-workspace kernel), one heading"""
+    for n in (150, 170):
+        P = _flex_problem(np.random.default_rng(n), 2, [4, 2], n, 2, 1, False)
+        a, b = _run_flex(hip_ctx, P), _run_flex(oracle_ctx, P)
+        assert np.array_equal(a["niter"], b["niter"]) and np.array_equal(a["flags"], b["flags"])
+        assert rel_err(a["Xi"], b["Xi"]) < 1e-9 and rel_err(a["B_drag"], b["B_drag"]) < 1e-11
+
+
+def _check_flex_gemm(ctx):
+    rng = np.random.default_rng(4)
+    for K, n in ((360, 150), (6, 7), (54, 33), (12, 16)):
+        A, W = rng.normal(size=(K, n)), rng.normal(size=(K, n))
+        got = ctx.debug_flex_gemm(A, W)
+        assert rel_err(got, A.T @ W) < 1e-13 and rel_err(got, (A.T @ W).T) > 0.1       # (an asymmetric product)
+
+
+def test_oracle_flex_gemm(oracle_ctx):
+    _check_flex_gemm(oracle_ctx)
+
+
+@pytest.mark.gpu
+def test_hip_flex_projection_gemm_tiles(hip_ctx):
+    """the MFMA tiles of sum_nodes T^T B T against NumPy, with an asymmetric product"""
+    _check_flex_gemm(hip_ctx)
+
+
 def test_oracle_flexible_sweep(oracle_ctx):
     _check_flex_sweep(oracle_ctx, 1)
 
