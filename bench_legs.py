@@ -227,9 +227,10 @@ def c5_qtf(ctx, n_set=16):
 
 def flex_sweep(ctx, n_unit=16):
     """The first widening beyond the rigid 6-DOF scope: the reference's flexible deck (tests/test_data/VolturnUS-S-flexible.yaml,
-    150 reduced DOFs, 40 bins) -- ``n_unit`` units x 3 sea states as ONE batch (raft_amd/flex.py: node-by-node strip sweeps of
-    the whole batch in one launch per iteration, every impedance solve of an iteration in one raftx_solve_dense_batch launch)
-    against the drop-in's one-case-at-a-time Model.solveDynamics and the live-reference golden."""
+    150 reduced DOFs, 40 bins) -- ``n_unit`` units x 3 sea states as ONE batch (raft_amd/flex.py: the whole fixed point on the
+    device, raftx_flex_solve -- node-by-node strip sweeps of the batch in one launch per iteration, the projections with the
+    units' T as MFMA GEMM tiles, every impedance solve of an iteration in one launch) against the drop-in's one-case-at-a-time
+    Model.solveDynamics and the live-reference golden."""
     from raft_amd import dropin, snapshot
     from raft_amd.metrics import rel_err
     fx, model = snapshot.load_model_fixture("flex_volturnus.npz")
@@ -256,9 +257,16 @@ def flex_sweep(ctx, n_unit=16):
     err_ref = float(rel_err(out["Xi"][0, 0, :1], Xr))
     assert err < 1e-9 and err_ref < 1e-7 and all(list(out["niter"][d]) == nit for d in range(n_unit)), (err, err_ref)
     pairs = n_unit * 3
+    n = int(out["Xi"].shape[3])
+    solves = (int(out["niter"].sum()) + pairs) * int(model.nw)          # one per (pair, iteration, bin) + the all-headings solve
+    flops = solves * 8.0 * (n ** 3 / 3.0 + n * n)
+    dev_ms = float(out["kernel_ms"][1])
     return {"config": "VolturnUS-S-flexible (150 reduced DOFs, %d bins): %d units x 3 sea states in one batch" % (model.nw, n_unit),
             "golden": "tests/golden/flex_volturnus.npz (live reference)", "dropin_ms_per_unit_case": 1e3 * t_single,
             "batch_ms": 1e3 * t_batch, "batch_ms_per_unit_case": 1e3 * t_batch / pairs, "speedup_vs_dropin": t_single * pairs / t_batch,
-            "kernel_ms_strip_sweeps": float(out["kernel_ms"][0]), "kernel_ms_dense_solves": float(out["kernel_ms"][1]),
+            "kernel_ms_excitation_sweep": float(out["kernel_ms"][0]), "device_ms_fixed_point": dev_ms,
+            "roofline": {"bound": "fp64_valu", "kernel": "k_solve_dense_reg2<5,10,16> (the span of the whole fixed point: + strip sweeps, projections, convergence tests)",
+                         "achieved": flops / (dev_ms * 1e-3) / 1e12, "peak": FP64_VALU_PEAK_TF, "unit": "TFLOP/s", "frac": flops / (dev_ms * 1e-3) / 1e12 / FP64_VALU_PEAK_TF,
+                         "algorithmic_flops": float(flops), "note": "n^3/3 + n^2 complex multiply-adds per solve (the pivoted LU's count; the kernel is a Gauss-Jordan sweep: n^3)"},
             "max_rel_err_vs_dropin": float(err), "rel_err_vs_reference": err_ref, "iterations": [int(x) for x in out["niter"][0]],
             "reference_numpy_s_per_case_build_container": float(fx["cases"][0].get("ref_seconds", float("nan")))}
