@@ -511,6 +511,35 @@ def run_farm_sharded(sweep, ctx, n_unit, Cc=None, Mc=None, Bc=None, comm=None):
     return out if rank == 0 else local
 
 
+def run_flex_sharded(flex_sweep, ctx, comm=None):
+    """A sweep of units with flexible members (raft_amd/flex.py FlexSweep): the UNITS are block-partitioned over the ranks, every
+    rank runs the whole fixed point of its units x all sea states on its GPU (raftx_flex_solve: no collective while solving),
+    and rank 0 gathers responses, iteration counts, flags and B_drag along the unit axis.  Rank 0 returns the assembled
+    dict, the others their local block."""
+    from .flex import FlexSweep
+    if comm is None or comm.world == 1:
+        return flex_sweep.run(ctx)
+    rank, world = comm.rank, comm.world
+    n = len(flex_sweep.units)
+    lo, hi = shard_bounds(n, rank, world)
+    counts = _counts(n, world)
+    local = None
+    if hi > lo:
+        sub = FlexSweep(flex_sweep.units[lo:hi], flex_sweep.w, flex_sweep.k, flex_sweep.depth, flex_sweep.zeta, flex_sweep.beta,
+                        flex_sweep.nIter, flex_sweep.XiStart, flex_sweep.tol)
+        local = sub.run(ctx)
+    nC, nH, nw, nd = flex_sweep.zeta.shape[0], flex_sweep.zeta.shape[1], len(flex_sweep.w), flex_sweep.n
+    empty = {"Xi": np.zeros((0, nC, nH, nd, nw), dtype=complex), "niter": np.zeros((0, nC), dtype=np.int32),
+             "flags": np.zeros((0, nC), dtype=np.int32), "B_drag": np.zeros((0, nC, nd, nd))}
+    out = {}
+    for key in ("Xi", "niter", "flags", "B_drag"):
+        out[key] = comm.gather_rows(np.ascontiguousarray((local or empty)[key]), counts)
+    if rank != 0:
+        return local
+    out["kernel_ms"] = local["kernel_ms"] if local else (0.0, 0.0)
+    return out
+
+
 class Pipeline:
     """Host-buffer boundary with copies overlapped with compute.  ``n_workers`` raftx contexts (= HIP streams with their
     own device buffers and memory pools) live as long as the Pipeline; ``run`` cuts the designs of a sweep into blocks

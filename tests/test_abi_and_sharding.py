@@ -311,6 +311,52 @@ def test_two_rank_farm_cases(tmp_path, kind):
         assert [int(got["niter"][u, i]) for u in range(4)] == [int(c["units"][u]["niter"]) for u in range(4)]
 
 
+def _flex_units(n_unit):
+    """n_unit variants of the reference's flexible deck (its own T, node tables and matrices; inertia scaled per unit so that
+    the units differ) x two sea states"""
+    from raft_amd import dropin
+    from raft_amd.flex import FlexSweep
+    from tests.util import load_model_fixture, case_from_fixture
+    fx, model = load_model_fixture("flex_volturnus.npz")
+    base = case_from_fixture(fx["cases"][0])
+    s = dropin.flex_sweep_from_models([model], [base, dict(base, wave_height=3.0, wave_period=8.0)])
+    u0 = s.units[0]
+    from raft_amd.flex import FlexUnit
+    units = [FlexUnit(u0.tables, u0.Tn, u0.M * (1.0 + 0.1 * i), u0.B, u0.C) for i in range(n_unit)]
+    return FlexSweep(units, s.w, s.k, s.depth, s.zeta, s.beta, s.nIter, s.XiStart, s.tol)
+
+
+def _flex_rank_main(rank, world, port, n_unit, out_path, kind):
+    from raft_amd._abi import RaftxLib
+    comm = _make_comm(kind, rank, world, port)
+    try:
+        ctx = RaftxLib(ORACLE_SO).context(0)
+        res = sw.run_flex_sharded(_flex_units(n_unit), ctx, comm)
+        ctx.close()
+        if rank == 0:
+            np.savez(out_path, Xi=res["Xi"], niter=res["niter"], flags=res["flags"], B_drag=res["B_drag"])
+    finally:
+        comm.close()
+
+
+@pytest.mark.parametrize("kind,n_unit", [("gloo", 3), ("host", 3), ("host", 1)])
+def test_two_rank_flexible_units(tmp_path, oracle_lib, kind, n_unit):
+    """Units with flexible members block-partitioned over two ranks (2 + 1; 1 + 0: a rank without units still takes part in
+    the gather), every rank running the whole fixed point of its units: identical to the single-process batch."""
+    import torch.multiprocessing as mp
+    out = str(tmp_path / "flex.npz")
+    mp.spawn(_flex_rank_main, args=(2, _free_port(), n_unit, out, kind), nprocs=2, join=True)
+    got = np.load(out)
+    ctx = oracle_lib.context(0)
+    ref = _flex_units(n_unit).run(ctx)
+    ctx.close()
+    assert got["Xi"].shape == ref["Xi"].shape == (n_unit, 2, 1, 150, ref["Xi"].shape[4])
+    for key in ("Xi", "B_drag"):
+        assert np.array_equal(got[key].view(np.float64), ref[key].view(np.float64)), key
+    assert np.array_equal(got["niter"], ref["niter"]) and np.array_equal(got["flags"], ref["flags"])
+    assert len(set(float(np.abs(got["Xi"][i]).sum()) for i in range(n_unit))) == n_unit          # the units really differ
+
+
 @pytest.mark.parametrize("kind", TRANSPORTS)
 def test_two_rank_qtf_sets(tmp_path, kind):
     """QTF sets sharded over two ranks (2 + 1) and gathered: identical to the single-process batch."""
