@@ -205,7 +205,10 @@ __device__ __forceinline__ T half_bcast(T v, int src_lane) {          // value o
 __device__ __forceinline__ cplx half_bcast(cplx v, int src_lane) { return {__shfl(v.re, src_lane, 64), __shfl(v.im, src_lane, 64)}; }
 #define SYSROWS_MAXRHS 4
 template <int NU, int NR, bool RESIDENT>          // NR: right-hand sides compiled in (nRhs <= NR; the rest are zero columns)
-__global__ void __launch_bounds__(64) k_solve_system_rows(int nSys, int nRhs, int nw, int nCase, const double *__restrict__ w,
+#ifndef RAFTX_SYSROWS_WAVES
+#define RAFTX_SYSROWS_WAVES 2     // waves per SIMD the register allocation aims at (tuning builds: 3, 4)
+#endif
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(RAFTX_SYSROWS_WAVES, RAFTX_SYSROWS_WAVES))) k_solve_system_rows(int nSys, int nRhs, int nw, int nCase, const double *__restrict__ w,
                                                           const cplx *__restrict__ Zblk, const double *__restrict__ Mc,
                                                           const double *__restrict__ Bc, const double *__restrict__ Cc,
                                                           const cplx *__restrict__ F, cplx *__restrict__ Xi) {
@@ -283,7 +286,12 @@ __global__ void __launch_bounds__(64) k_solve_system_rows(int nSys, int nRhs, in
         }
         wave_lds_fence();
         const cplx pv = rowbuf[k];
-        const double dinv = 1.0 / (pv.re * pv.re + pv.im * pv.im);
+        // 1 / |pivot|^2: v_rcp_f64 + two Newton steps (5 instructions; the IEEE division sequence is ~15).  A zero pivot still
+        // ends in NaN.
+        const double pp = pv.re * pv.re + pv.im * pv.im;
+        double dinv = __builtin_amdgcn_rcp(pp);
+        dinv = fma(fma(-pp, dinv, 1.0), dinv, dinv);
+        dinv = fma(fma(-pp, dinv, 1.0), dinv, dinv);
         const cplx inv = {pv.re * dinv, -pv.im * dinv};
         // rows that are done (or beyond the system) take a zero multiplier: the update itself stays straight-line code
         const cplx lk = cmul(a[k], inv);
@@ -291,13 +299,13 @@ __global__ void __launch_bounds__(64) k_solve_system_rows(int nSys, int nRhs, in
 #pragma unroll
         for (int c = k + 1; c < N; c++) {
             const cplx u = rowbuf[c];
-            a[c] = csub(a[c], cmul(l, u));
+            a[c] = cfnma(a[c], l, u);                     // four FMAs (as a difference of a product: six instructions)
         }
 #pragma unroll
         for (int j = 0; j < NR; j++)
         {
             const cplx u = rowbuf[N + j];
-            bR[j] = csub(bR[j], cmul(l, u));
+            bR[j] = cfnma(bR[j], l, u);
         }
         if (mine) {
             todo = false;
@@ -322,7 +330,7 @@ __global__ void __launch_bounds__(64) k_solve_system_rows(int nSys, int nRhs, in
         for (int j = 0; j < NR; j++)
         {
             const cplx xk = rowbuf[N + j];
-            bR[j] = csub(bR[j], cmul(f, xk));
+            bR[j] = cfnma(bR[j], f, xk);
         }
         wave_lds_fence();
     }

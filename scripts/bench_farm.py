@@ -23,7 +23,7 @@ for _ in range(3):
     wall = time.perf_counter() - t0
 nw = model.nw
 err = max(group_rel_err(out["Xi"][0, i, :1], ref_headings(c)[0]) for i, c in enumerate(fx["cases"]))
-FLOP_PER_SOLVE = 8.0 * (2.0 / 3.0 * 24 ** 3 + 2.0 * 24 ** 2)      # complex LU + two triangular solves, 8 flops per complex multiply-add
+FLOP_PER_SOLVE = 8.0 * (24 ** 3 / 3.0 + 24 ** 2)      # pivoted complex LU (n^3/3 multiply-adds) + the two triangular sweeps, 8 flops per complex multiply-add
 extra = {}
 if "--sweep" in sys.argv:
     from raft_amd.sweep import Sweep
