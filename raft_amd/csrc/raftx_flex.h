@@ -117,8 +117,9 @@ __global__ void __launch_bounds__(256) k_flex_project_F(int nCase, int nHead, in
 
 // Convergence test and relaxation of every (unit, sea state) still iterating (raft_model.py:1098-1133): its response of this
 // iteration is kept; NaN -> flagged 2 and dropped; all entries within tol -> flagged 1 (converged) and frozen; otherwise
-// XiLast <- 0.2 XiLast + 0.8 Xi.  The number of pairs still iterating goes to *nActive (page-locked host memory).
-__global__ void __launch_bounds__(256) k_flex_converge(int n, int nw, double tol, int iter, const cplx *__restrict__ Xnew,
+// XiLast <- 0.2 XiLast + 0.8 Xi.  The number of pairs still iterating is added up in *nActive; the iteration number comes from
+// device memory (*iterp, advanced by k_flex_tick) so that the launches of an iteration are the same every time: one hipGraph.
+__global__ void __launch_bounds__(256) k_flex_converge(int n, int nw, double tol, const int *__restrict__ iterp, const cplx *__restrict__ Xnew,
                                                        cplx *__restrict__ Xi, cplx *__restrict__ XiLast, int *__restrict__ active,
                                                        int *__restrict__ niter, int *__restrict__ flags, int *__restrict__ nActive) {
     const int s = blockIdx.x;
@@ -146,13 +147,15 @@ __global__ void __launch_bounds__(256) k_flex_converge(int n, int nw, double tol
             XiLast[o + e] = cplx{0.2 * xl.re + 0.8 * x.re, 0.2 * xl.im + 0.8 * x.im};                    // :1133
         }
     if (threadIdx.x == 0) {
-        niter[s] = iter + 1;
+        niter[s] = *iterp + 1;
         if (isnan_) flags[s] |= 2;
         if (conv) flags[s] |= 1;
         if (isnan_ || conv) active[s] = 0;
         else atomicAdd(nActive, 1);
     }
 }
+
+__global__ void k_flex_tick(int *iterp) { *iterp += 1; }
 
 __global__ void k_flex_fill(size_t n, cplx v, cplx *__restrict__ out) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;

@@ -1561,7 +1561,7 @@ extern "C" int raftx_excitation(raftx_ctx *c, raftx_c128 *F_iner) {
 }
 
 // one drag linearisation on device arrays (enqueued on the ctx stream between ev0 and the caller's ev1)
-static int linearize_enqueue(raftx_ctx *c, const cplx *dXi, double *dB, cplx *dF) {
+static int linearize_enqueue(raftx_ctx *c, const cplx *dXi, double *dB, cplx *dF, bool timed = true) {
     const DevTables &T = c->T;
     const size_t npair = (size_t)T.nDesign * T.nCase;
     const Shape sh = pick_shape(T.nw);
@@ -1570,7 +1570,7 @@ static int linearize_enqueue(raftx_ctx *c, const cplx *dXi, double *dB, cplx *dF
     if (!hit_ && sh.nb == NB_ && sh.threads == MT_) {                                                                 \
         hit_ = true;                                                                                                  \
         if (prep_lds(c, k_linearize<NB_, MT_, MB_>, lds)) return -1;                                                  \
-        HIPCHK(c, hipEventRecord(c->ev0, c->stream));                                                                 \
+        if (timed) HIPCHK(c, hipEventRecord(c->ev0, c->stream));                                                      \
         if (npair)                                                                                                    \
             hipLaunchKernelGGL((k_linearize<NB_, MT_, MB_>), dim3(grid_for_pairs(npair)), dim3(sh.threads), lds,      \
                                c->stream, T, dXi, dB, dF);                                                            \
@@ -2333,21 +2333,55 @@ extern "C" int raftx_flex_solve(raftx_ctx *c, int nUnit, const int64_t *nodeOff,
     const int nt = (n + 15) / 16;
     const dim3 gridB((unsigned)((nt * nt + 3) / 4), (unsigned)nSys), gridF((unsigned)((nxs + 255) / 256), (unsigned)(nSys * nHead));
     volatile int *hCount = reinterpret_cast<volatile int *>(c->pin);
-    for (int it = 0; it <= nIter; it++) {                                 // :977, 1052
-        // node motions -> linearisation of every (node, sea state) -> projections with the units' T
+    int *dIter = sc.alloc<int>(1);
+    if (!dIter) FAIL(c, "flex_solve: device allocation failed");
+    HIPCHK(c, hipMemsetAsync(dIter, 0, sizeof(int), c->stream));
+    // one iteration: node motions -> linearisation of every (node, sea state) -> projections with the units' T -> dense solves ->
+    // convergence test / relaxation -> the count of pairs still iterating to the host
+    auto enqueue_iteration = [&]() -> int {
         hipLaunchKernelGGL(k_flex_node_motion, dim3((unsigned)npn), dim3(256), 0, c->stream, nCase, n, nw, dNodeUnit, dTn, dXl, dXiN);
-        if (linearize_enqueue(c, dXiN, dBn, dFn)) return -1;
+        if (linearize_enqueue(c, dXiN, dBn, dFn, false)) return -1;
         hipLaunchKernelGGL(k_flex_w, dim3((unsigned)npn), dim3(256), 0, c->stream, nNode, nCase, n, dTn, dBn, dW);
         hipLaunchKernelGGL(k_flex_gemm_B, gridB, dim3(256), 0, c->stream, nNode, nCase, n, dOff, dTn, dW, dAct, dBd);
         hipLaunchKernelGGL(k_flex_project_F, gridF, dim3(256), 0, c->stream, nCase, nHead, n, nw, dOff, dTn, dFn, dFlin, dAct, dFw, dFd, dRhs);
         if (dense_launch(c, nSys, nCase, n, 1, nw, T.w, dM, dB, dC, freq_mask, dBd, dRhs, dXnew, nullptr, dA, dAct)) return -1;
         HIPCHK(c, hipMemsetAsync(dCount, 0, sizeof(int), c->stream));
-        hipLaunchKernelGGL(k_flex_converge, dim3((unsigned)nSys), dim3(256), 0, c->stream, n, nw, tol, it, dXnew, dXi, dXl, dAct, dNi, dFl,
+        hipLaunchKernelGGL(k_flex_converge, dim3((unsigned)nSys), dim3(256), 0, c->stream, n, nw, tol, dIter, dXnew, dXi, dXl, dAct, dNi, dFl,
                            dCount);
+        hipLaunchKernelGGL(k_flex_tick, dim3(1), dim3(1), 0, c->stream, dIter);
         HIPCHK(c, hipMemcpyAsync(const_cast<int *>(hCount), dCount, sizeof(int), hipMemcpyDeviceToHost, c->stream));
-        HIPCHK(c, hipStreamSynchronize(c->stream));
-        if (*hCount == 0) break;
+        return 0;
+    };
+    // The launches of an iteration are the same every time (the iteration number lives in device memory), so they can be
+    // captured ONCE into a hipGraph and replayed: RAFTX_FLEX_GRAPH=1.  Measured (scripts/bench_flex.py, prof_flex_dropin.py): the
+    // capture + instantiation of every call costs more than the four or five replays save -- 13.5 against 13.1 ms for a batch
+    // of 16 units x 3 sea states, 2.5-2.9 against 2.3 ms for a single unit -- so plain launches are the default (a graph kept
+    // across calls of one shape would pay; not built).  The first iteration always runs plainly (it sets the kernels' LDS
+    // attributes, which a capture must not contain).
+    static const bool use_graph = getenv("RAFTX_FLEX_GRAPH") && atoi(getenv("RAFTX_FLEX_GRAPH"));
+    hipGraph_t graph = nullptr;
+    hipGraphExec_t gexec = nullptr;
+    int rc_it = 0;
+    for (int it = 0; it <= nIter && !rc_it; it++) {                       // :977, 1052
+        if (it == 1 && use_graph && nIter > 1) {
+            if (hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal) == hipSuccess) {
+                const int rcq = enqueue_iteration();
+                const hipError_t ee = hipStreamEndCapture(c->stream, &graph);
+                if (rcq || ee != hipSuccess || !graph || hipGraphInstantiate(&gexec, graph, nullptr, nullptr, 0) != hipSuccess) gexec = nullptr;
+                (void)hipGetLastError();
+            }
+        }
+        if (gexec && it >= 1) {
+            if (hipGraphLaunch(gexec, c->stream) != hipSuccess) rc_it = -2;
+        } else {
+            rc_it = enqueue_iteration();
+        }
+        if (!rc_it && hipStreamSynchronize(c->stream) != hipSuccess) rc_it = -2;
+        if (!rc_it && *hCount == 0) break;
     }
+    if (gexec) (void)hipGraphExecDestroy(gexec);
+    if (graph) (void)hipGraphDestroy(graph);
+    if (rc_it) FAIL(c, "flex_solve: an iteration could not be enqueued (%s)", hipGetErrorString(hipGetLastError()));
     // every heading with the impedance of the pair's last iteration (:1155, 1191, 1212-1216)
     if (dense_launch(c, nSys, nCase, n, nHead, nw, T.w, dM, dB, dC, freq_mask, dBd, dFw, dXh, dZ, dA)) return -1;
     HIPCHK(c, hipEventRecord(e1, c->stream));

@@ -216,6 +216,27 @@ def test_hip_flex_solve_larger_systems(hip_ctx, oracle_ctx):
         assert rel_err(a["Xi"], b["Xi"]) < 1e-9 and rel_err(a["B_drag"], b["B_drag"]) < 1e-11
 
 
+@pytest.mark.gpu
+def test_hip_flex_solve_iterations_as_a_graph(hip_ctx, tmp_path):
+    """RAFTX_FLEX_GRAPH=1: the launches of an iteration captured once into a hipGraph and replayed (in a process of its own: the
+    setting is read once) -- the same bits as plain launches."""
+    import os
+    import subprocess
+    import sys
+    out = str(tmp_path / "graph.npz")
+    code = ("import numpy as np, tests.test_flexible as t; from raft_amd import backend; ctx = backend.hip_library().context(0); "
+            "P = t._flex_problem(np.random.default_rng(11), 3, [3, 1, 5], 20, 3, 2, True); r = t._run_flex(ctx, P); "
+            "np.savez(%r, Xi=r['Xi'], niter=r['niter'], B=r['B_drag'])" % out)
+    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, RAFTX_FLEX_GRAPH="1"), capture_output=True, text=True, timeout=600,
+                       cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    got = np.load(out)
+    ref = _run_flex(hip_ctx, _flex_problem(np.random.default_rng(11), 3, [3, 1, 5], 20, 3, 2, True))
+    assert int(got["niter"].max()) > 2                                       # (replays happened)
+    assert np.array_equal(got["niter"], ref["niter"])
+    assert np.array_equal(got["Xi"].view(np.float64), ref["Xi"].view(np.float64)) and np.array_equal(got["B"], ref["B_drag"])
+
+
 def _check_flex_gemm(ctx):
     rng = np.random.default_rng(4)
     for K, n in ((360, 150), (6, 7), (54, 33), (12, 16)):
