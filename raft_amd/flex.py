@@ -18,9 +18,30 @@ Units come from live ``FOWT`` objects (``FlexUnit.from_fowt``: the reference's o
 finite-element assembly stays upstream) or from arrays.  All units of a sweep share the frequency grid; they may differ
 in everything else, including their number of nodes, but not in nDOF.
 """
+import contextlib
+
 import numpy as np
 
 from .strips import pack_fowt_nodes
+
+try:
+    from threadpoolctl import ThreadpoolController
+except ImportError:                                  # optional: without it the products below run with BLAS's own thread count
+    ThreadpoolController = None
+_BLAS = None                                         # the controller, made once (it walks the loaded libraries)
+
+
+def _few_blas_threads():
+    """The host's share of a sweep is a handful of small products (the inertial excitation reduced with T, once).  On a
+    many-core host OpenBLAS starts all its threads for each of them and they keep spinning afterwards, beside the runtime
+    threads of the device library: measured on the 256-thread GPU box, calls of FlexSweep.run then take 40-70 ms every few
+    calls instead of 24 (scripts/prof_flex_batch.py).  Eight threads are plenty for 150 x 360 products."""
+    global _BLAS
+    if ThreadpoolController is None:
+        return contextlib.nullcontext()
+    if _BLAS is None:
+        _BLAS = ThreadpoolController()
+    return _BLAS.limit(limits=8, user_api="blas")
 
 WAVE_RHO, WAVE_G = 1025.0, 9.81        # hard-wired defaults of Member.calcHydroExcitation (raft_member.py:1940)
 
@@ -92,9 +113,10 @@ class FlexSweep:
         Fn = ctx.excitation()                                        # [nN, nC, nH, 6, nw]
         t_strip += ctx.last_kernel_ms()
         F_iner = np.zeros((nD, nC, nH, n, nw), dtype=complex)
-        for d in range(nD):
-            blk = Fn[first[d]:first[d + 1]]                          # [nNode, nC, nH, 6, nw]
-            F_iner[d] = np.matmul(T2[d].T, blk.transpose(1, 2, 0, 3, 4).reshape(nC, nH, -1, nw))
+        with _few_blas_threads():
+            for d in range(nD):
+                blk = Fn[first[d]:first[d + 1]]                      # [nNode, nC, nH, 6, nw]
+                F_iner[d] = np.matmul(T2[d].T, blk.transpose(1, 2, 0, 3, 4).reshape(nC, nH, -1, nw))
         M = np.array([u.M for u in self.units])
         B0 = np.array([u.B for u in self.units])
         C0 = np.array([u.C for u in self.units])
