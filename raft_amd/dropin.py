@@ -861,8 +861,9 @@ def sweep_from_member_tables(model, base_table, tables, cases, ctx, tol=0.01, po
 def flex_sweep_from_models(models, cases, tol=0.01):
     """A ``raft_amd.flex.FlexSweep``: units with MORE than 6 reduced DOFs (flexible members; one per Model, positioned and
     with their statics computed) x load cases in one batch -- the fixed point of raft_model.py:966-1302 for every (unit,
-    case) at once: node-by-node strip sweeps of the whole batch in one launch per iteration, every impedance solve of an
-    iteration in one launch (raftx_solve_dense_batch).  What Engine._solve_general does one case at a time.
+    case) at once, on the device (raftx_flex_solve): node-by-node strip sweeps of the whole batch in one launch per iteration,
+    the projections with the units' T, every impedance solve of an iteration in one launch, the convergence test per pair.
+    What Engine._solve_general does one case at a time.
     Single strip-theory units only, as there (no potential-flow coefficients, second-order loads, moorMod == 2)."""
     from .flex import FlexSweep, FlexUnit
     eng = Engine(ctx=False)
