@@ -152,7 +152,10 @@ __global__ void __launch_bounds__(256) k_solve_dense(int n, int nRhs, int nw, co
 // its own multipliers from the raw column (one barrier less: 0.37 against 0.36), the next column's pivot search by its owners
 // right after they have updated it (look-ahead: no gain), the owners taking the pivot by v_readlane inside their half-wave and
 // forming the multipliers while the pivot row is being published (two barriers per step: 0.269 against 0.273), 768 threads x 35
-// entries (three waves per SIMD, 196 B scratch: 0.40) and 1024 x 25 (0.53).
+// entries (three waves per SIMD, 196 B scratch: 0.40) and 1024 x 25 (0.53).  Where a step's 1.8 us go, by elimination on the probe
+// (variants that skip a part; wrong results, timing only): the update 0.10 of the 0.275 ms, the pivot search 0.04, the second
+// and third barrier 0.012 each; the remaining 0.13 ms is the chain publish -> read pivot -> reciprocal -> multipliers -> read
+// them back, with two dozen branches per step around the divergent parts.
 // Badd: [n,n] per system added to B (the drag linearisation of the iteration; B itself may stay resident); mdiv: systems
 // sy share the matrices of set sy / mdiv (the sea states of one unit).
 // a - l u in four FMAs (a - (l u) written as a difference costs six instructions)
