@@ -148,7 +148,8 @@ __global__ void __launch_bounds__(256) k_solve_dense(int n, int nRhs, int nw, co
 //   (only that row -- publishing all RB rows of the thread row costs 0.50 against 0.36 ms);  BARRIER;  the owners of column k
 //   form the multipliers (1 / pivot by v_rcp_f64 + two Newton steps);  BARRIER;  update, a - l u in four FMAs.
 // History of the form (scripts/ubench/dense_probe.hip, n = 150, 40 bins): 1024 threads with the last block row in LDS 0.59 ms;
-// 512 threads all in registers 0.36; DPP argmax 0.29; rcp + four-FMA update 0.27.  Measured and not kept: every thread forming
+// 512 threads all in registers 0.36; DPP argmax 0.29; rcp + four-FMA update 0.275; the owners' work (search, reciprocal,
+// multipliers) inside their branch so that the other seven waves skip it 0.267.  Measured and not kept: every thread forming
 // its own multipliers from the raw column (one barrier less: 0.37 against 0.36), the next column's pivot search by its owners
 // right after they have updated it (look-ahead: no gain), the owners taking the pivot by v_readlane inside their half-wave and
 // forming the multipliers while the pivot row is being published (two barriers per step: 0.269 against 0.273), 768 threads x 35
@@ -223,29 +224,30 @@ __global__ void __launch_bounds__(32 * TJ) k_solve_dense_reg2(int n, int nRhs, i
             // equal to 6e-14 is arbitrary anyway; ties go to the lower row as izamax takes the first largest) -- so that
             // the argmax is a max: four row_shr steps inside the 16-lane rows, one row_bcast across the two rows of the
             // half-wave, all DPP (the shuffle form is fifteen dependent ds_bpermute round trips)
-            double key = -1.0;
+            // (everything the owners alone need sits INSIDE their branch: the other seven waves skip it -- the chain of a step
+            // is issue-bound, two waves per SIMD each walking through whatever is not branched around)
             if (tj == kk) {
+                double key = -1.0;
 #pragma unroll
-                for (int a = 0; a < RB; a++)
-                    if (!(done >> a & 1u)) {
-                        double v = fabs(A[a][kb].re) + fabs(A[a][kb].im);
-                        if (!(v <= 1.7e308)) v = 1.7e308;
-                        const double kv = __hiloint2double(__double2hiint(v), (int)(((unsigned)__double2loint(v) & ~255u) | (unsigned)(255 - (ti + 32 * a))));
-                        key = fmax(key, kv);
-                    }
-            }
+                for (int a = 0; a < RB; a++) {
+                    double v = fabs(A[a][kb].re) + fabs(A[a][kb].im);
+                    if (!(v <= 1.7e308)) v = 1.7e308;
+                    const double kv = __hiloint2double(__double2hiint(v), (int)(((unsigned)__double2loint(v) & ~255u) | (unsigned)(255 - (ti + 32 * a))));
+                    key = fmax(key, (done >> a & 1u) ? -1.0 : kv);
+                }
 #define DPP_MAX_(CTRL, ROWMASK)                                                                                          \
-            {                                                                                                       \
-                const int lo_ = __builtin_amdgcn_update_dpp(__double2loint(key), __double2loint(key), CTRL, ROWMASK, 0xf, false); \
-                const int hi_ = __builtin_amdgcn_update_dpp(__double2hiint(key), __double2hiint(key), CTRL, ROWMASK, 0xf, false); \
-                key = fmax(key, __hiloint2double(hi_, lo_));                                                        \
-            }
-            DPP_MAX_(0x111, 0xf) DPP_MAX_(0x112, 0xf) DPP_MAX_(0x114, 0xf) DPP_MAX_(0x118, 0xf)     // row_shr:1,2,4,8 -> lane 15 of each row
-            DPP_MAX_(0x142, 0xa)                                                                    // row_bcast:15 into rows 1 and 3 -> lanes 31, 63
+                {                                                                                                       \
+                    const int lo_ = __builtin_amdgcn_update_dpp(__double2loint(key), __double2loint(key), CTRL, ROWMASK, 0xf, false); \
+                    const int hi_ = __builtin_amdgcn_update_dpp(__double2hiint(key), __double2hiint(key), CTRL, ROWMASK, 0xf, false); \
+                    key = fmax(key, __hiloint2double(hi_, lo_));                                                        \
+                }
+                DPP_MAX_(0x111, 0xf) DPP_MAX_(0x112, 0xf) DPP_MAX_(0x114, 0xf) DPP_MAX_(0x118, 0xf)     // row_shr:1,2,4,8 -> lane 15 of each row
+                DPP_MAX_(0x142, 0xa)                                                                    // row_bcast:15 into rows 1 and 3 -> lanes 31, 63
 #undef DPP_MAX_
-            if (tj == kk && ti == 31) psel = 255 - (__double2loint(key) & 255);
+                if (ti == 31) psel = 255 - (__double2loint(key) & 255);
+            }
             __syncthreads();
-            const int p = psel;
+            const int p = __builtin_amdgcn_readfirstlane(psel);   // (uniform: scalar compares below)
             const int ap = p >> 5;
             if (ti == (p & 31)) {                         // the thread row of the pivot row publishes it; the row is done
 #pragma unroll
@@ -258,13 +260,13 @@ __global__ void __launch_bounds__(32 * TJ) k_solve_dense_reg2(int n, int nRhs, i
                 done |= 1u << ap;
             }
             __syncthreads();
-            const cplx pv = stage[k];
-            const double dd = pv.re * pv.re + pv.im * pv.im;
-            double d = __builtin_amdgcn_rcp(dd);           // 1 / |pivot|^2: v_rcp_f64 + two Newton steps (a zero pivot still ends in NaN)
-            d = fma(fma(-dd, d, 1.0), d, d);
-            d = fma(fma(-dd, d, 1.0), d, d);
-            const cplx inv = {pv.re * d, -pv.im * d};
             if (tj == kk) {
+                const cplx pv = stage[k];
+                const double dd = pv.re * pv.re + pv.im * pv.im;
+                double d = __builtin_amdgcn_rcp(dd);       // 1 / |pivot|^2: v_rcp_f64 + two Newton steps (a zero pivot still ends in NaN)
+                d = fma(fma(-dd, d, 1.0), d, d);
+                d = fma(fma(-dd, d, 1.0), d, d);
+                const cplx inv = {pv.re * d, -pv.im * d};
 #pragma unroll
                 for (int a = 0; a < RB; a++) {
                     const int r = ti + 32 * a;
