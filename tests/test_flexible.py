@@ -281,6 +281,39 @@ def test_hip_solve_dense_batch_equals_single_calls(hip_ctx, oracle_ctx):
         assert rel_err(Xb, Xo) < 1e-10
 
 
+def _check_dense_resident(ctx):
+    """raftx_dense_resident / raftx_solve_dense_resident: the matrices of two units kept on the device, three systems per unit
+    (its sea states) that add their own Badd to B -- equal to the stateless batch call with B + Badd written out; for the
+    register-resident kernel's shapes and the L2-workspace one's, frequency-dependent M / B and not."""
+    rng = np.random.default_rng(8)
+    for n, nR, nw, mask in ((12, 1, 4, 0), (40, 2, 3, 2), (150, 1, 5, 3), (170, 2, 3, 1)):
+        probs = [_dense_problem(rng, n, nR, nw, mask) for _ in range(2)]
+        w = probs[0][0]
+        M, B, C = (np.array([p[i] for p in probs]) for i in (1, 2, 3))
+        F = rng.normal(size=(6, nR, n, nw)) + 1j * rng.normal(size=(6, nR, n, nw))
+        Badd = rng.normal(size=(6, n, n))
+        ctx.dense_resident(w, M, B, C)
+        X, Z = ctx.solve_dense_resident(F, Badd=Badd, want_Z=True)
+        X0 = ctx.solve_dense_resident(F)                                      # no Badd: B alone
+        Bfull = np.repeat(B, 3, axis=0) + (Badd[..., None] if mask & 2 else Badd)
+        Xb, Zb = ctx.solve_dense_batch(w, np.repeat(M, 3, axis=0), Bfull, np.repeat(C, 3, axis=0), F, want_Z=True)
+        assert np.array_equal(X.view(np.float64), Xb.view(np.float64)) and np.array_equal(Z.view(np.float64), Zb.view(np.float64))
+        assert np.array_equal(X0.view(np.float64), ctx.solve_dense_batch(w, np.repeat(M, 3, axis=0), np.repeat(B, 3, axis=0),
+                                                                         np.repeat(C, 3, axis=0), F).view(np.float64))
+        ctx.dense_resident(None, None, None, None)
+        with pytest.raises(Exception, match="resident"):
+            ctx.solve_dense_resident(F)
+
+
+def test_oracle_solve_dense_resident(oracle_ctx):
+    _check_dense_resident(oracle_ctx)
+
+
+@pytest.mark.gpu
+def test_hip_solve_dense_resident(hip_ctx):
+    _check_dense_resident(hip_ctx)
+
+
 def test_oracle_solve_dense(oracle_ctx):
     _check_dense(oracle_ctx)
 
