@@ -596,7 +596,12 @@ struct DevPool {
             free_.erase(it);
             return hipSuccess;
         }
+        static const bool dbg = getenv("RAFTX_POOL_DEBUG") != nullptr;   // tuning: pool misses (they cost a hipMalloc) on stderr
+        const auto t0 = std::chrono::steady_clock::now();
         hipError_t e = hipMalloc(out, cap);
+        if (dbg)
+            fprintf(stderr, "[raftx pool] miss: hipMalloc(%zu) %.3f ms (%zu blocks free)\n", cap,
+                    std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(), free_.size());
         if (e != hipSuccess) {                      // make room and retry once
             (void)hipGetLastError();
             trim();
