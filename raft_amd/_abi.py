@@ -466,8 +466,12 @@ class Context:
         self.nCase, self.nHead, self.nw = nC, nH, nw
 
     # ------------------------------------------------------------- compute
-    def excitation(self):
-        F = np.empty((self.nDesign, self.nCase, self.nHead, 6, self.nw), dtype=np.complex128)
+    def excitation(self, out=None):
+        """F_iner [nDesign,nCase,nHead,6,nw]; out: a preallocated C-contiguous complex128 array of that shape (e.g. page-locked)"""
+        shape = (self.nDesign, self.nCase, self.nHead, 6, self.nw)
+        F = np.empty(shape, dtype=np.complex128) if out is None else _c128(out, shape, "out")
+        if out is not None and F is not out:
+            raise ValueError("excitation: out must be a C-contiguous complex128 array")
         self._check(self.rlib.lib.raftx_excitation(self._h, _ptr(F)), "raftx_excitation")
         return F
 
@@ -800,10 +804,11 @@ class Context:
         self._check(rc, "raftx_solve_dense_resident")
         return (Xi, Z) if want_Z else Xi
 
-    def flex_solve(self, node_off, Tn, M, B, C_, F_lin, nIter, tol, XiStart, want_B=True, want_F=True, want_Z=False):
+    def flex_solve(self, node_off, Tn, M, B, C_, F_lin, nIter, tol, XiStart, want_B=True, want_F=True, want_Z=False, out=None):
         """The fixed point of units with more than 6 reduced DOFs on the resident node tables and sea states
         (raftx_flex_solve): node_off [nUnit+1], Tn [nNode,6,n], M, B [nUnit,n,n(,nw)], C_ [nUnit,n,n], F_lin
-        [nUnit,nCase,nHead,n,nw].  dict Xi [nUnit,nCase,nHead,n,nw], niter, flags [nUnit,nCase], B_drag, F_drag, Z."""
+        [nUnit,nCase,nHead,n,nw].  dict Xi [nUnit,nCase,nHead,n,nw], niter, flags [nUnit,nCase], B_drag, F_drag, Z.
+        out: optional dict of preallocated arrays for "Xi", "B_drag", "F_drag", "Z" (e.g. from pinned_empty)."""
         node_off = np.ascontiguousarray(node_off, dtype=np.int64)
         nU = len(node_off) - 1
         Tn = _f64(Tn)
@@ -820,12 +825,23 @@ class Context:
             elif A.shape != (nU, n, n):
                 raise ValueError("%s must be [nUnit,n,n] or [nUnit,n,n,nw]" % name)
         C_ = _f64(C_, (nU, n, n), "C")
-        Xi = np.empty((nU, nC, nH, n, nw), dtype=np.complex128)
+        out = out or {}
+
+        def buf(key, shape, dtype, want):                 # a caller's preallocated (e.g. page-locked) array, or a fresh one
+            if not want:
+                return None
+            a = out.get(key)
+            if a is None:
+                return np.empty(shape, dtype=dtype)
+            if a.shape != tuple(shape) or a.dtype != np.dtype(dtype) or not a.flags["C_CONTIGUOUS"]:
+                raise ValueError("flex_solve: out[%r] must be a C-contiguous %s array of shape %s" % (key, np.dtype(dtype), tuple(shape)))
+            return a
+        Xi = buf("Xi", (nU, nC, nH, n, nw), np.complex128, True)
         niter = np.zeros((nU, nC), dtype=np.int32)
         flags = np.zeros((nU, nC), dtype=np.int32)
-        Bd = np.empty((nU, nC, n, n)) if want_B else None
-        Fd = np.empty((nU, nC, nH, n, nw), dtype=np.complex128) if want_F else None
-        Z = np.empty((nU, nC, n, n, nw), dtype=np.complex128) if want_Z else None
+        Bd = buf("B_drag", (nU, nC, n, n), np.float64, want_B)
+        Fd = buf("F_drag", (nU, nC, nH, n, nw), np.complex128, want_F)
+        Z = buf("Z", (nU, nC, n, n, nw), np.complex128, want_Z)
         rc = self.rlib.lib.raftx_flex_solve(self._h, nU, _ptr(node_off), n, _ptr(Tn), _ptr(M), _ptr(B), _ptr(C_), mask, _ptr(F_lin),
                                             int(nIter), float(tol), float(XiStart), _ptr(Xi), _ptr(niter), _ptr(flags), _ptr(Bd),
                                             _ptr(Fd), _ptr(Z))

@@ -95,10 +95,50 @@ class FlexSweep:
             zeta, beta = zeta[None], beta[None]
         self.zeta, self.beta = np.ascontiguousarray(zeta), np.ascontiguousarray(beta)
         self.nIter, self.XiStart, self.tol = int(nIter), float(XiStart), float(tol)
+        self._token = object()                                       # key of this sweep's page-locked arrays in a context's store
 
-    def run(self, ctx, want_Z=False):
+    def _pinned(self, ctx, name, shape, dtype=np.float64, fill=None):
+        """A page-locked host array of this sweep on ``ctx``, kept across runs (raftx_host_alloc through ctx.pinned_empty; plain
+        NumPy memory where the backend has no such thing).  Blocking calls with pageable arrays of a few MB are what the runtime
+        pins and unpins behind the caller's back: on the GPU box every second or third run took 40-65 ms instead of 20 until
+        the arrays were page-locked (scripts/prof_flex_batch.py)."""
+        store = self._store(ctx).setdefault(self._token, {})
+        a = store.get(name)
+        if a is None or a.shape != tuple(shape) or a.dtype != np.dtype(dtype):
+            if a is not None and hasattr(ctx, "free_pinned"):
+                try:
+                    ctx.free_pinned(a)
+                except ValueError:
+                    pass
+            try:
+                a = ctx.pinned_empty(shape, dtype=dtype)
+            except Exception:                                        # noqa: BLE001 -- e.g. a backend without page-locked memory
+                a = np.empty(shape, dtype=dtype)
+            store[name] = a
+            if fill is not None:
+                a[...] = fill
+        return a
+
+    @staticmethod
+    def _store(ctx):
+        # the arrays live WITH the context (they die with it: ctx.close() frees page-locked memory), keyed by the sweep's token
+        try:
+            return ctx.__dict__.setdefault("_flex_bufs", {})
+        except AttributeError:
+            return {}
+
+    def release(self, ctx):
+        """Frees the page-locked arrays this sweep holds on ``ctx`` (ctx.close() does it too)."""
+        for a in self._store(ctx).pop(self._token, {}).values():
+            try:
+                ctx.free_pinned(a)
+            except (ValueError, AttributeError):
+                pass
+
+    def run(self, ctx, want_Z=False, copy=True):
         """{"Xi": [nUnit,nCase,nHead,nDOF,nw], "niter", "flags" [nUnit,nCase] (1 = converged), "B_drag" [nUnit,nCase,nDOF,nDOF],
-        "kernel_ms": (inertial excitation sweep, the fixed point's span on the device)}."""
+        "kernel_ms": (inertial excitation sweep, the fixed point's span on the device)}.  copy=False: Xi, B_drag (and Z) are
+        views of this sweep's page-locked arrays, valid until its next run on ``ctx`` / release(ctx) / ctx.close()."""
         nD, nC, nH, nw, n = len(self.units), self.zeta.shape[0], self.zeta.shape[1], len(self.w), self.n
         tables = [t for u in self.units for t in u.tables]
         first = np.concatenate([[0], np.cumsum([len(u.tables) for u in self.units])]).astype(int)
@@ -109,21 +149,31 @@ class FlexSweep:
         ctx.upload_cases(self.w, self.k, self.depth, WAVE_RHO, WAVE_G, self.zeta, self.beta)
         # stacked node rows of T per unit: T2[d] [nNode_d * 6, nDOF]
         T2 = [u.Tn.reshape(-1, n) for u in self.units]
+        # what does not change from run to run goes into page-locked arrays once
+        fresh = self._token not in self._store(ctx)
+        Tn = self._pinned(ctx, "Tn", (nN, 6, n))
+        M = self._pinned(ctx, "M", (nD, n, n))
+        B0 = self._pinned(ctx, "B", (nD, n, n))
+        C0 = self._pinned(ctx, "C", (nD, n, n))
+        if fresh:
+            Tn[...] = np.concatenate([u.Tn for u in self.units])
+            for d, u in enumerate(self.units):
+                M[d], B0[d], C0[d] = u.M, u.B, u.C
         # inertial excitation of every heading, reduced: F_iner[d,c,h] = sum_u T_u^T F_u  (raft_fowt.py:1886-1888)
-        Fn = ctx.excitation()                                        # [nN, nC, nH, 6, nw]
+        Fn = ctx.excitation(out=self._pinned(ctx, "Fn", (nN, nC, nH, 6, nw), np.complex128))
         t_strip += ctx.last_kernel_ms()
-        F_iner = np.zeros((nD, nC, nH, n, nw), dtype=complex)
+        F_iner = self._pinned(ctx, "F_iner", (nD, nC, nH, n, nw), np.complex128)
         with _few_blas_threads():
             for d in range(nD):
                 blk = Fn[first[d]:first[d + 1]]                      # [nNode, nC, nH, 6, nw]
                 F_iner[d] = np.matmul(T2[d].T, blk.transpose(1, 2, 0, 3, 4).reshape(nC, nH, -1, nw))
-        M = np.array([u.M for u in self.units])
-        B0 = np.array([u.B for u in self.units])
-        C0 = np.array([u.C for u in self.units])
-        out = ctx.flex_solve(first, np.concatenate([u.Tn for u in self.units]), M, B0, C0, F_iner, self.nIter, self.tol, self.XiStart,
-                             want_F=False, want_Z=want_Z)
-        t_fix = ctx.last_kernel_ms()
-        res = {"Xi": out["Xi"], "niter": out["niter"], "flags": out["flags"], "B_drag": out["B_drag"], "kernel_ms": (t_strip, t_fix)}
+        bufs = {"Xi": self._pinned(ctx, "Xi", (nD, nC, nH, n, nw), np.complex128), "B_drag": self._pinned(ctx, "B_drag", (nD, nC, n, n))}
         if want_Z:
-            res["Z"] = out["Z"]
+            bufs["Z"] = self._pinned(ctx, "Z", (nD, nC, n, n, nw), np.complex128)
+        out = ctx.flex_solve(first, Tn, M, B0, C0, F_iner, self.nIter, self.tol, self.XiStart, want_F=False, want_Z=want_Z, out=bufs)
+        t_fix = ctx.last_kernel_ms()
+        take = (lambda a: np.array(a)) if copy else (lambda a: a)
+        res = {"Xi": take(out["Xi"]), "niter": out["niter"], "flags": out["flags"], "B_drag": take(out["B_drag"]), "kernel_ms": (t_strip, t_fix)}
+        if want_Z:
+            res["Z"] = take(out["Z"])
         return res

@@ -14,6 +14,7 @@ tot, shown = [], 0
 for rep in range(14):
     if rep % 3 == 0:
         eng.solveDynamics(model, dict(cases[rep % 2]))
+    time.sleep(float(os.environ.get('IDLE_MS', '0')) * 1e-3)
     pr = cProfile.Profile()
     t0 = time.perf_counter(); pr.enable(); sw.run(ctx); pr.disable(); tot.append(1e3 * (time.perf_counter() - t0))
     if tot[-1] > 38 and rep > 1 and shown < 2:
