@@ -255,6 +255,30 @@ def test_hip_flex_projection_gemm_tiles(hip_ctx):
     _check_flex_gemm(hip_ctx)
 
 
+def test_flexible_sweep_keeps_its_host_arrays(oracle_lib):
+    """FlexSweep holds its host arrays (page-locked on the device backend) across runs, in the context's store: a second run
+    re-uses them and gives the same bits; copy=False hands out views of them; release() / a new context start afresh."""
+    fx, model = load_model_fixture("flex_volturnus.npz")
+    base = case_from_fixture(fx["cases"][0])
+    sw = dropin.flex_sweep_from_models([model], [base])
+    ctx = oracle_lib.context(0)
+    a = sw.run(ctx)
+    v1 = sw.run(ctx, copy=False)
+    v2 = sw.run(ctx, copy=False)
+    assert v1["Xi"] is not a["Xi"] and np.shares_memory(v1["Xi"], v2["Xi"]) and not np.shares_memory(a["Xi"], v1["Xi"])
+    assert np.array_equal(a["Xi"].view(np.float64), v2["Xi"].view(np.float64)) and np.array_equal(a["B_drag"], v2["B_drag"])
+    assert len(ctx._flex_bufs) == 1
+    sw.release(ctx)
+    assert len(ctx._flex_bufs) == 0
+    b = sw.run(ctx)                                                          # allocates again
+    assert np.array_equal(a["Xi"].view(np.float64), b["Xi"].view(np.float64))
+    ctx.close()
+    ctx2 = oracle_lib.context(0)                                             # another context: its own arrays
+    c = sw.run(ctx2)
+    assert np.array_equal(a["Xi"].view(np.float64), c["Xi"].view(np.float64))
+    ctx2.close()
+
+
 def test_oracle_flexible_sweep(oracle_ctx):
     _check_flex_sweep(oracle_ctx, 1)
 
