@@ -12,4 +12,4 @@ for _ in range(3):
 pr = cProfile.Profile(); pr.enable()
 eng.solveDynamics(model, dict(base))
 pr.disable()
-pstats.Stats(pr).sort_stats("tottime").print_stats(12)
+pstats.Stats(pr).sort_stats("tottime").print_stats(22)
