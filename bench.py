@@ -8,16 +8,20 @@ of the five parameters of raft/parametersweep.py:33-37, each x U[0.75,1.25]
 frequency bins, nIter=4 (up to 5 fixed-point iterations), all fp64.
 
 A STEP is one whole pass of the solver stage as SURVEY.md 8d defines it --
-"H2D of the tables + kernels + D2H": the member descriptions of every design
-of this rank (host arrays, page-locked) go in, the response statistics
-(std of the six motions + iteration counts + flags) come out, in ONE library
-call (raftx_sweep_stats): descriptor H2D, strip-table / statics generation
-(k_geom_*), the fused fixed point (k_solve_dynamics: strip sweeps +
-drag-linearisation iterations + per-bin 6x6 complex solves), the statistics
-kernel and the D2H, block-pipelined over internal streams.  `value` = dcf of all
-ranks / wall time of the K timed steps.  Host work outside the step (editing the
-descriptors of the variants: vectorised NumPy, reported as
-geometry.host_descriptor_ms) is not part of the solver stage.  ("state": "stats
+"H2D of the tables + kernels + D2H" -- over a batch of NEW candidates: the five
+sweep parameters of every design of this rank go in (raft/parametersweep.py:39-40
+draws exactly these), the library writes the member descriptions in HBM
+(raftx_sweep_prepare_variants -> k_geom_expand: the dependent-geometry edits of
+parametersweep.py:56-87), generates strip tables / statics (k_geom_*), runs the
+fused fixed point (k_solve_dynamics: strip sweeps + drag-linearisation iterations +
+per-bin 6x6 complex solves) and the statistics kernel, and the response statistics
+(std of the six motions + iteration counts + flags) come out; block-pipelined over
+internal streams, consecutive steps streamed through the library's slots.  Every
+timed step solves DIFFERENT candidates (rows of one default_rng(0) stream); the host
+work per step is drawing the parameter rows (geometry.host_params_ms_per_step, inside
+the timed loop).  `value` = dcf of all ranks / wall time of the K timed steps.
+--descriptors host is the form of rounds 1-4: ONE batch expanded by NumPy
+(geometry.host_descriptor_ms, outside the step) and its 66 MB re-uploaded every step.  ("state": "stats
 out"; --xi-out times the same step with the full responses downloaded too.)
 
 Also on the JSON line:
@@ -32,7 +36,10 @@ Also on the JSON line:
   parity            every design of the timed batch against the CPU oracle (RAO
                     group-relative error, iteration counts), the first 64 against the
                     live reference's own solveDynamics (tests/golden/c3_variants.npz);
-  cpu_baseline      the oracle (oracle/raftx_oracle.c, kind "port") on this host.
+  cpu_baseline      the UNMODIFIED reference (raft.Model.solveDynamics, NumPy/SciPy; kind "reference") timed on this
+                    host's cores -- one core, and a multiprocessing.Pool over as many CPUs as the container can run on --
+                    from the byte-compiled archive oracle/_ref/raft_reference.zip (oracle/stage_reference.py); beside it
+                    (`port_simd`) the vectorised C port of the oracle with OpenMP.
 
   xi_out / isolated_call   the same step with the 192 MB of responses downloaded too
                     (SURVEY.md 8d's literal "D2H of Xi"), streamed and as isolated blocking
@@ -78,9 +85,18 @@ FP64_VALU_PEAK_TF = 78.6       # MI355X vector fp64 peak
 FP64_FMA_SUSTAINED_TF = 50.8      # measured: profiles/r02_valu_mfma_probe.jsonl (probe fma64)
 
 
-def make_sweep(ctx, n_design, rank=0, pinned=True, mcf=False, zeta=None, beta=None, MBw=None):
+def scale_rows(lo, hi):
+    """Rows [lo, hi) of THE default_rng(0) stream of U[0.75,1.25]^5 scale factors, without drawing the rows
+    before them: PCG64 advanced by one step per double, the same numbers as default_rng(0).uniform(size=(hi, 5))[lo:]."""
+    bg = np.random.PCG64(0)
+    bg.advance(int(lo) * 5)
+    return np.random.Generator(bg).uniform(0.75, 1.25, size=(int(hi) - int(lo), 5))
+
+
+def make_sweep(ctx, n_design, rank=0, pinned=True, mcf=False, zeta=None, beta=None, MBw=None, rows=None, variants=False):
     """Descriptors of this rank's designs (host, vectorised): rank r takes rows [r*n, (r+1)*n) of one default_rng(0)
-    draw, so rank 0's first 64 designs are the committed reference-built variants.  mcf / zeta, beta / MBw: the featured
+    draw (weak scaling), or the rows [lo, hi) given as ``rows`` (strong scaling: contiguous shards of ONE sweep), so rank
+    0's first 64 designs are the committed reference-built variants.  mcf / zeta, beta / MBw: the featured
     legs (MacCamy-Fuchs columns; other sea states / headings; frequency-dependent added mass and damping)."""
     from raft_amd import snapshot
     from raft_amd import geometry as G
@@ -95,11 +111,23 @@ def make_sweep(ctx, n_design, rank=0, pinned=True, mcf=False, zeta=None, beta=No
     # constants that are not geometry: rotor-nacelle assembly (live reference minus its massless-RNA twin), mooring
     M_rna = np.asarray(u0["M_struc"]) - np.asarray(u0["M_struc_bare"])
     C_rest = np.asarray(u0["C_struc"]) - np.asarray(u0["C_struc_bare"]) + np.diag([7e4, 7e4, 0.0, 0.0, 0.0, 1e8])
-    scales = np.random.default_rng(0).uniform(0.75, 1.25, size=((rank + 1) * n_design, 5))[rank * n_design:]
-    t0 = time.perf_counter()
-    D = G.volturnus_sweep(base, scales).tables()
-    t_desc = time.perf_counter() - t0
-    if pinned:                                          # page-locked staging (raftx_host_alloc): full-rate, asynchronous H2D
+    lo, hi = (rank * n_design, (rank + 1) * n_design) if rows is None else (int(rows[0]), int(rows[1]))
+    n_design = hi - lo
+    scales = scale_rows(lo, hi)
+    prog = None
+    if variants:
+        # the candidates as PARAMETERS: the library writes their descriptors on the device (raftx_sweep_prepare_variants);
+        # what the host does per batch is draw / receive the parameter rows
+        prog = G.volturnus_program(base)
+        t0 = time.perf_counter()
+        params = G.volturnus_params(scales)
+        t_desc = time.perf_counter() - t0
+        D = None
+    else:
+        t0 = time.perf_counter()
+        D = G.volturnus_sweep(base, scales).tables()
+        t_desc = time.perf_counter() - t0
+    if pinned and D is not None:                        # page-locked staging (raftx_host_alloc): full-rate, asynchronous H2D
         for name in ("members", "stations", "caps", "member_off", "station_off", "cap_off"):
             a = getattr(D, name, None)
             if a is not None and a.size:
@@ -115,12 +143,27 @@ def make_sweep(ctx, n_design, rank=0, pinned=True, mcf=False, zeta=None, beta=No
             b[...] = a
             return b
         M0, B0, C0 = _pin(M0), _pin(B0), _pin(C0)
-    sw = GeometrySweep(D, M0, B0, C0, fx["w"], fx["k"], float(fx["depth"]),
-                       np.asarray(fx["zeta"])[None] if zeta is None else zeta, np.asarray(fx["beta"])[None] if beta is None else beta,
+    zeta_ = np.asarray(fx["zeta"])[None] if zeta is None else zeta
+    beta_ = np.asarray(fx["beta"])[None] if beta is None else beta
+    if variants:
+        from raft_amd.sweep import VariantSweep
+        assert MBw is None
+        sw = VariantSweep(prog, params, M0, B0, C0, fx["w"], fx["k"], float(fx["depth"]), zeta_, beta_, int(fx["nIter"]),
+                          float(fx["XiStart"]), tol=0.01, add_mask=G.ADD_MORISON | G.ADD_HYDROSTATIC | G.ADD_INERTIA)
+        b = prog.base
+        geo = {"designs": int(n_design), "members": int(b.n) * int(n_design), "host_descriptor_ms": 1e3 * t_desc,
+               "descriptors": "written on the device (k_geom_expand) from %d parameters per design; the host sends %d B per design "
+                              "instead of %d" % (prog.n_param, 8 * prog.n_param, b.members.nbytes + b.stations.nbytes + b.caps.nbytes),
+               "descriptor_bytes": int(params.nbytes),
+               "descriptor_bytes_written_on_device": int(n_design) * int(b.members.nbytes + b.stations.nbytes + b.caps.nbytes),
+               "descriptors_page_locked": False}
+        return sw, fx, geo
+    sw = GeometrySweep(D, M0, B0, C0, fx["w"], fx["k"], float(fx["depth"]), zeta_, beta_,
                        int(fx["nIter"]), float(fx["XiStart"]), tol=0.01, add_mask=G.ADD_MORISON | G.ADD_HYDROSTATIC | G.ADD_INERTIA,
                        MBw=MBw)
     geo = {"designs": int(n_design), "members": int(D.member_off[-1]), "host_descriptor_ms": 1e3 * t_desc,
-           "descriptor_bytes": int(D.members.nbytes + D.stations.nbytes + D.caps.nbytes), "descriptors_page_locked": bool(pinned)}
+           "descriptors": "expanded on the host (NumPy) and uploaded", "descriptor_bytes": int(D.members.nbytes + D.stations.nbytes + D.caps.nbytes),
+           "descriptors_page_locked": bool(pinned)}
     return sw, fx, geo
 
 
@@ -138,6 +181,19 @@ def measured_traffic(n_design):
     if n_prof <= 0:
         return None
     return float(t["hbm_bytes_per_launch"]) * float(n_design) / n_prof
+
+
+def traffic_provenance():
+    """Where `roofline.traffic` comes from: PMC counters need rocprofv3 around the process, so THIS run cannot measure them;
+    the figure is the committed profile's, scaled to the designs of one step."""
+    path = os.path.join(ROOT, "profiles", "traffic_latest.json")
+    if not os.path.exists(path):
+        return None
+    with open(path) as f:
+        t = json.load(f)
+    return {"measured_in_this_run": False, "file": "profiles/traffic_latest.json", "source": t.get("source"),
+            "measured_at": t.get("measured_at"), "kernel_source_head": t.get("kernel_source_head"),
+            "designs_per_launch_in_profile": t.get("designs_per_launch", t.get("designs_per_gpu"))}
 
 
 def algorithmic_bytes(off, nw):
@@ -164,6 +220,15 @@ def oracle_run(sw, ctx):
         subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle")], stdout=subprocess.DEVNULL)
     lib = RaftxLib(so)
     lib.lib.raftx_oracle_threads.restype = int
+    import ctypes as C
+    budget = cpu_budget()
+    try:                                                  # one OpenMP thread per CPU the container can actually run on
+        nthr = max(1, int(round(budget["effective_parallel_cpus"])))
+        if budget.get("cgroup_cpu_limit"):
+            nthr = max(1, min(nthr, int(budget["cgroup_cpu_limit"])))
+        C.CDLL("libgomp.so.1").omp_set_num_threads(nthr)
+    except OSError:
+        pass
     threads = int(lib.lib.raftx_oracle_threads())
     nw = sw.nw
     sw.upload(ctx)                                        # device generation (outside every timed region)
@@ -252,22 +317,77 @@ def oracle_run(sw, ctx):
     return base, res, gen
 
 
-def reference_on_this_host():
-    """The unmodified NumPy reference timed on THIS host (oracle/time_reference.py), when its tree is here
-    (RAFT_REFERENCE_ROOT or /root/reference: the build container; the GPU box of the pool has no copy)."""
+_CPU_BUDGET = {}
+
+
+def cpu_budget():
+    """oracle/time_reference.py --probe in a child process (never a fork of this process: it holds a HIP context): logical
+    CPUs, the CPUs' worth of run time the container actually gets, the cgroup quota if one is visible."""
     import subprocess
-    root = os.environ.get("RAFT_REFERENCE_ROOT", "/root/reference")
-    if not os.path.isdir(os.path.join(root, "raft")):
+    if not _CPU_BUDGET:
+        try:
+            r = subprocess.run([sys.executable, os.path.join(ROOT, "oracle", "time_reference.py"), "--probe"], timeout=120,
+                               capture_output=True, text=True, check=True).stdout.strip().splitlines()[-1]
+            _CPU_BUDGET.update(json.loads(r))
+        except Exception as e:                              # noqa: BLE001
+            n = len(os.sched_getaffinity(0))
+            _CPU_BUDGET.update({"logical_cpus": n, "effective_parallel_cpus": float(n), "cgroup_cpu_limit": None,
+                                "error": "%s: %s" % (type(e).__name__, str(e)[:120])})
+    return dict(_CPU_BUDGET)
+
+
+def reference_on_this_host():
+    """The UNMODIFIED NumPy/SciPy reference (raft.Model.solveDynamics, raft/raft_model.py:966) timed on THIS host by
+    oracle/time_reference.py in child processes: (i) one process, one core, 2 designs; (ii) multiprocessing.Pool over
+    every usable core with 2 x cores (design, case) items, BLAS/OpenMP threads = 1.  The
+    reference comes from /root/reference (build container) or from oracle/_ref/raft_reference.zip (GPU box: the
+    byte-compiled archive oracle/stage_reference.py builds, git-ignored, shipped with the snapshot).  Each timed solve is
+    compared with the committed live-reference fixture tests/golden/c3_variants.npz inside the child; a mismatch fails
+    the leg.  Returns None when neither form of the reference is on this host."""
+    import subprocess
+    sys.path.insert(0, ROOT)
+    from oracle import ref_harness as rh
+    if not rh.reference_available():
         return None
     try:
-        env = dict(os.environ, RAFTX_REF_TIMING_NOWRITE="1", OMP_NUM_THREADS="1", OPENBLAS_NUM_THREADS="1")
-        out = subprocess.run([sys.executable, os.path.join(ROOT, "oracle", "time_reference.py"), "2"], env=env, timeout=300,
-                             capture_output=True, text=True, check=True).stdout.strip().splitlines()[-1]
-        r = json.loads(out)
-        return {"dcf_per_s_one_core": r["dcf_per_s_per_core"], "designs": r["designs"], "cores_on_host": os.cpu_count(),
-                "solveDynamics_s_per_design": r["solveDynamics_s_per_design"], "where": "this host, RAFT_REFERENCE_ROOT=%s" % root}
+        cores = len(os.sched_getaffinity(0))
+    except AttributeError:
+        cores = os.cpu_count() or 1
+    script = os.path.join(ROOT, "oracle", "time_reference.py")
+    env = dict(os.environ, OMP_NUM_THREADS="1", OPENBLAS_NUM_THREADS="1", MKL_NUM_THREADS="1", MPLBACKEND="Agg")
+    out = {}
+    try:
+        t0 = time.perf_counter()
+        # how many CPUs this container can RUN on at once (the pool's boxes show 256 logical CPUs to a container with a much
+        # smaller CPU-time quota: Pool(256) measured there = 256 processes taking turns, 65 s per solve instead of 2.1)
+        probe = cpu_budget()
+        procs = max(1, min(cores, int(round(probe["effective_parallel_cpus"]))))
+        if probe.get("cgroup_cpu_limit"):                  # the CFS quota is the sustained figure (the one-second probe sees its burst)
+            procs = max(1, min(procs, int(probe["cgroup_cpu_limit"])))
+        try:                                                # ~0.4 GB per worker (numpy + scipy + matplotlib + a Model)
+            with open("/proc/meminfo") as f:
+                avail_kb = [int(l.split()[1]) for l in f if l.startswith("MemAvailable")][0]
+            procs = max(1, min(procs, int(avail_kb / 1024 / 400)))
+        except Exception:                                   # noqa: BLE001
+            pass
+        r1 = json.loads(subprocess.run([sys.executable, script, "--designs", "2"], env=env, timeout=300, capture_output=True,
+                                       text=True, check=True).stdout.strip().splitlines()[-1])
+        rp = json.loads(subprocess.run([sys.executable, script, "--pool", "--procs", str(procs), "--items", str(2 * procs)],
+                                       env=env, timeout=900, capture_output=True, text=True, check=True).stdout.strip().splitlines()[-1])
+        err = max(r1["max_rel_err_vs_committed_reference_fixture"], rp["max_rel_err_vs_committed_reference_fixture"])
+        assert err < 1e-9, "the timed reference does not reproduce tests/golden/c3_variants.npz: %g" % err
+        out = {"dcf_per_s_one_core": r1["dcf_per_s_one_core"], "solveDynamics_s_per_design": r1["solveDynamics_s_per_design"],
+               "model_build_s_per_design": r1["model_build_s_per_design"], "one_core_designs": r1["designs"],
+               "dcf_per_s_pool": rp["dcf_per_s_pool"], "dcf_per_s_pool_solve_only": rp["dcf_per_s_pool_solve_only"],
+               "pool_procs": rp["procs"], "pool_items": rp["items"], "pool_wall_s": rp["wall_s"],
+               "pool_mean_solveDynamics_s": rp["mean_solveDynamics_s"], "pool_worker_busy_fraction": rp["worker_busy_fraction"],
+               "cores_on_host": cores, "cpu_budget_probe": probe, "reference_from": rp["reference_from"],
+               "max_rel_err_vs_committed_reference_fixture": err, "leg_wall_s": time.perf_counter() - t0}
+        return out
+    except subprocess.CalledProcessError as e:
+        return {"error": "time_reference.py failed: %s" % (e.stderr or "")[-300:]}
     except Exception as e:                                  # noqa: BLE001 -- a reported absence, never a failed bench
-        return {"error": "%s: %s" % (type(e).__name__, str(e)[:200])}
+        return {"error": "%s: %s" % (type(e).__name__, str(e)[:300])}
 
 
 def featured_legs(ctx, n_design, base_sw, base_ms, base_pair_iters):
@@ -478,7 +598,14 @@ def main():
     ap.add_argument("--sets", type=int, default=16, help="--workload c5: QTF sets per batch")
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--designs", type=int, default=10000, help="designs per GPU (weak scaling)")
+    ap.add_argument("--designs", type=int, default=10000, help="designs per GPU (weak scaling) / designs of the whole sweep (strong scaling)")
+    ap.add_argument("--descriptors", choices=("device", "host"), default="device",
+                    help="device (default): every step solves NEW candidates -- their five parameters go in, the library writes the "
+                         "member descriptors in HBM (raftx_sweep_prepare_variants).  host: round 1-4's form -- the descriptors of ONE "
+                         "batch are expanded by NumPy once (geometry.host_descriptor_ms) and the same 66 MB are re-uploaded every step")
+    ap.add_argument("--scaling", choices=("weak", "strong"), default="weak",
+                    help="weak (default, what the driver's contract line reports): --designs per GPU.  strong: ONE sweep of --designs "
+                         "(BASELINE configs[2]: 10 000) cut into N contiguous shards, SURVEY 8e (1 250 per GPU at N = 8)")
     ap.add_argument("--chunks", type=int, default=0, help="design blocks per step (0 = library default)")
     ap.add_argument("--workers", type=int, default=0, help="internal streams (0 = library default)")
     ap.add_argument("--xi-out", action="store_true", help="download the full responses inside the step as well")
@@ -537,8 +664,31 @@ def main():
     placement = ({"bound": False, "why": "RAFTX_NO_BIND"} if os.environ.get("RAFTX_NO_BIND")
                  else locality.bind_near_device(backend.hip_library(), local))
     ctx = backend.hip_library().context(local)
-    sw, fx, geo = make_sweep(ctx, args.designs, rank, pinned=not args.pageable)
+    from raft_amd.sweep import shard_bounds
+    strong = args.scaling == "strong"
+    shard = [shard_bounds(args.designs, r_, world) for r_ in range(world)] if strong else [(r_ * args.designs, (r_ + 1) * args.designs) for r_ in range(world)]
+    counts_all = np.array([hi_ - lo_ for lo_, hi_ in shard], dtype=np.int64)
+    if strong and counts_all.min() < 1:
+        sys.stderr.write("bench.py: --scaling strong needs at least one design per rank\n")
+        sys.exit(2)
+    variants = args.descriptors == "device"
+    sw, fx, geo = make_sweep(ctx, args.designs, rank, pinned=not args.pageable, rows=shard[rank], variants=variants)
     nw, nD = sw.nw, sw.n_design
+    # distinct candidates per step: batch b >= 1 of this rank = rows shard + b * (all ranks' designs) of the same stream
+    # (batch 0 = the standard rows, whose first 64 designs are the reference-built variants: the parity batch)
+    from raft_amd import geometry as G_
+    n_all = int(counts_all.sum()) if strong else args.designs * world
+    batch_no = {"next": 1}
+    host_params_s = []
+
+    def fresh_candidates():
+        if not variants:
+            return
+        tq = time.perf_counter()
+        b = batch_no["next"]
+        batch_no["next"] += 1
+        sw.set_params(G_.volturnus_params(scale_rows(shard[rank][0] + b * n_all, shard[rank][1] + b * n_all)))
+        host_params_s.append(time.perf_counter() - tq)
 
     comm = None
     gather_kind = None
@@ -560,11 +710,12 @@ def main():
         if comm is not None and not solo["on"]:           # statistics of every rank onto rank 0 (48 B + 8 B per design-case)
             tg = time.perf_counter()
             r["std_all"] = comm.gather_rows(np.concatenate([r["std"].reshape(nD, -1), r["niter"].reshape(nD, -1).astype(np.float64)], axis=1),
-                                            counts=np.full(world, nD, dtype=np.int64))       # weak scaling: every rank holds nD designs
+                                            counts=counts_all)            # weak: nD on every rank; strong: the shards' sizes
             gather_s.append(time.perf_counter() - tg)
         return r
 
     def step():                                           # one isolated, blocking crossing
+        fresh_candidates()
         return gather(sw.run_crossing(ctx, n_chunk=args.chunks, n_worker=args.workers, Xi_out=Xi_pinned[0]))
 
     def run_steps(n):
@@ -574,15 +725,21 @@ def main():
         if not stream_steps:
             return [step() for _ in range(n)]
         out = []
+        def submit(slot):
+            fresh_candidates()                            # (the handle keeps its parameter rows alive until it is waited for)
+            return sw.submit_crossing(ctx, slot, n_chunk=args.chunks, Xi_out=Xi_pinned[slot])
         if args.depth == 2:
-            h = sw.submit_crossing(ctx, 0, n_chunk=args.chunks, Xi_out=Xi_pinned[0]) if n > 0 else None
+            h = submit(0) if n > 0 else None
             for i in range(n):
-                h_next = sw.submit_crossing(ctx, (i + 1) % 2, n_chunk=args.chunks, Xi_out=Xi_pinned[(i + 1) % 2]) if i + 1 < n else None
+                h_next = submit((i + 1) % 2) if i + 1 < n else None
                 out.append(gather(sw.wait_crossing(ctx, h)))
                 h = h_next
             return out
         d = args.depth                                    # staged: prepare(i+d-1), launch(i+d-2), wait(i)
-        sub = lambda i: sw.prepare_crossing(ctx, i % d, n_chunk=args.chunks, Xi_out=Xi_pinned[i % d])
+
+        def sub(i):
+            fresh_candidates()
+            return sw.prepare_crossing(ctx, i % d, n_chunk=args.chunks, Xi_out=Xi_pinned[i % d])
         hs = {i: sub(i) for i in range(min(n, d - 1))}
         for i in range(min(n, d - 2)):
             sw.launch_crossing(ctx, hs[i])
@@ -623,6 +780,8 @@ def main():
             solo["on"] = False
     barrier()
     del gather_s[:]
+    del host_params_s[:]
+    first_timed_batch = batch_no["next"]
     t0 = time.perf_counter()
     res = run_steps(args.steps)                           # returns after the last step's streams have drained
     t_own = time.perf_counter() - t0                      # this rank's own K steps, before it waits for the others
@@ -630,29 +789,48 @@ def main():
     elapsed = time.perf_counter() - t0
     r = res[-1]
     tims = [x["timing_ms"] for x in res]
+    host_params_ms = 1e3 * float(np.mean(host_params_s)) if host_params_s else None
     isolated = None
     if stream_steps and rank == 0 and not args.profile:   # the same step as an isolated blocking call (outside the timed region)
         t1 = time.perf_counter()
         for _ in range(5):                                # (no gather here: only this rank runs it)
+            fresh_candidates()
             sw.run_crossing(ctx, n_chunk=args.chunks, n_worker=args.workers, Xi_out=Xi_pinned[0])
         isolated = (time.perf_counter() - t1) / 5
     per_rank = None
     if comm is not None:
         elapsed = comm.all_max(elapsed)                   # the slowest rank's clock
-        per_rank = comm.gather_floats([1e3 * t_own / args.steps, 1e3 * float(np.mean(gather_s)) if gather_s else 0.0])
+        per_rank = comm.gather_floats([1e3 * t_own / args.steps, 1e3 * float(np.mean(gather_s)) if gather_s else 0.0,
+                                       float(geo["host_descriptor_ms"])])
     tims = np.array(tims)
-    off = r["strip_off"]
-    niter = r["niter"]
-    nan = int(np.count_nonzero(r["flags"] & 2))
+    nan = int(sum(np.count_nonzero(x["flags"] & 2) for x in res))
+    # algorithmic work of the TIMED steps (each step its own candidates when the descriptors are device-made): means per step
+    A_steps = float(np.mean([algorithmic_bytes(x["strip_off"], nw) for x in res]))
+    flops_steps = float(np.mean([algorithmic_flops(x["strip_off"], nw, x["niter"]) for x in res]))
+    mean_iter_timed = float(np.mean([np.mean(x["niter"]) for x in res]))
     if comm is not None and rank == 0:
-        assert r["std_all"].shape == (nD * world, 7) and np.array_equal(r["std_all"][:nD, :6], r["std"].reshape(nD, 6))
+        assert r["std_all"].shape == (int(counts_all.sum()), 7) and np.array_equal(r["std_all"][:nD, :6], r["std"].reshape(nD, 6))
 
-    # ---- parity of the timed batch (outside the timed region): one more crossing with the responses downloaded
+    # ---- outside the timed region: determinism of a timed batch, then parity on the STANDARD batch (rows whose first 64
+    # designs the live reference solved), one more crossing with the responses downloaded
+    if variants:
+        distinct = len({x["std"].tobytes() for x in res})
+        assert distinct == len(res), "timed steps were meant to solve distinct candidates (%d distinct of %d)" % (distinct, len(res))
+        b_last = first_timed_batch + len(res) - 1             # the last timed step's candidates, once more, alone
+        sw.set_params(G_.volturnus_params(scale_rows(shard[rank][0] + b_last * n_all, shard[rank][1] + b_last * n_all)))
+        again = sw.run_crossing(ctx, n_chunk=args.chunks, n_worker=args.workers)
+        assert np.array_equal(again["std"].view(np.uint64), r["std"].view(np.uint64)) and np.array_equal(again["niter"], r["niter"]), \
+            "the same candidates solved twice (streamed / alone) differ"
+        sw.set_params(G_.volturnus_params(scale_rows(*shard[rank])))
     chk = sw.run_crossing(ctx, n_chunk=args.chunks, n_worker=args.workers, want_Xi=True)
-    for x in res:                                         # every timed step produced the same bits
-        assert np.array_equal(x["std"].view(np.uint64), r["std"].view(np.uint64)) and np.array_equal(x["niter"], r["niter"])
-    assert np.array_equal(chk["std"].view(np.uint64), r["std"].view(np.uint64)) and np.array_equal(chk["niter"], niter), \
-        "two crossings of the same batch differ"
+    if not variants:
+        for x in res:                                     # every timed step re-solved the same batch: the same bits
+            assert np.array_equal(x["std"].view(np.uint64), r["std"].view(np.uint64)) and np.array_equal(x["niter"], r["niter"])
+        assert np.array_equal(chk["std"].view(np.uint64), r["std"].view(np.uint64)) and np.array_equal(chk["niter"], r["niter"]), \
+            "two crossings of the same batch differ"
+    off = chk["strip_off"]
+    niter = chk["niter"]
+    nan += int(np.count_nonzero(chk["flags"] & 2))
     Xi = chk["Xi"]
     parity = {"nan_flags": nan}
     if rank == 0:                                         # the first 64 designs are the live reference's own variants
@@ -771,27 +949,33 @@ def main():
         cfg_legs["flex_sweep"] = guarded("flex_sweep", lambda: bench_legs.flex_sweep(ctx))
 
     n_dcf_rank = nD * 1 * nw
-    value = n_dcf_rank * world * args.steps / elapsed
+    value = int(counts_all.sum()) * nw * args.steps / elapsed
     k_sum_ms = float(np.mean(tims[:, 2]))                 # k_solve_dynamics: summed HIP-event durations of one step's launches
-    A = algorithmic_bytes(off, nw)
-    flops = algorithmic_flops(off, nw, niter)
+    A = A_steps
+    flops = flops_steps
     out = {
         "metric": "design-case-frequency solves/sec (whole node)",
         "value": value, "unit": "dcf solves/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": 1e3 * elapsed / args.steps,
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
         "dtype": "f64", "data": "synthetic",
-        "config": {"workload": "C3 VolturnUS-S parameter sweep: %d designs/GPU x 1 sea state (JONSWAP Hs6 Tp12, 0 deg) x %d bins, "
-                               "nIter=4, tol=0.01; designs = distinct U[0.75,1.25]^5 variants (default_rng(0))" % (nD, nw),
-                   "designs_per_gpu": nD, "cases": 1, "nw": nw,
-                   "step": "whole solver stage (SURVEY 8d): descriptor H2D + table/statics generation + fused fixed point + "
+        "config": {"workload": "C3 VolturnUS-S parameter sweep: %s x 1 sea state (JONSWAP Hs6 Tp12, 0 deg) x %d bins, "
+                               "nIter=4, tol=0.01; designs = distinct U[0.75,1.25]^5 variants (default_rng(0))"
+                               % (("ONE sweep of %d designs in %d contiguous shards" % (int(counts_all.sum()), world)) if strong
+                                  else "%d designs/GPU" % nD, nw),
+                   "designs_per_gpu": nD, "shard_designs": [int(c) for c in counts_all], "total_designs": int(counts_all.sum()),
+                   "cases": 1, "nw": nw,
+                   "step": "whole solver stage (SURVEY 8d): %s + table/statics generation + fused fixed point + "
                            "statistics + D2H of %s; %s"
-                           % ("statistics and full responses" if args.xi_out else "statistics (\"stats out\")",
-                              "steps streamed through the library's slots (raftx_sweep_submit / raftx_sweep_wait): the descriptor upload and "
+                           % ("H2D of the candidates' PARAMETERS (5 per design; NEW candidates every step) + member descriptors written "
+                              "on the device (k_geom_expand)" if variants else "descriptor H2D (the same batch every step)",
+                              "statistics and full responses" if args.xi_out else "statistics (\"stats out\")",
+                              "steps streamed through the library's slots (raftx_sweep_submit / raftx_sweep_wait): the upload and "
                               "member pass of step i+1 run beside the kernels of step i, as consecutive batches of a long sweep do; every "
-                              "step moves its own 66 MB in and its own statistics out" if stream_steps
-                              else "isolated blocking calls (raftx_sweep_stats)"),
+                              "step moves its own inputs in and its own statistics out" if stream_steps
+                              else "isolated blocking calls"),
+                   "descriptors": args.descriptors,
                    "streamed": bool(stream_steps),
                    "state": "xi out" if args.xi_out else "stats out",
                    "sharding": "designs over ranks, no collective while solving; statistics gathered to rank 0 inside the step"
@@ -801,12 +985,12 @@ def main():
                               "generation_kernels_sum": float(np.mean(tims[:, 1])),
                               "solve_kernels_sum": k_sum_ms, "statistics_kernels_sum": float(np.mean(tims[:, 3]))},
         "parity": parity,
-        "mean_iterations": float(np.mean(niter)),
+        "mean_iterations": mean_iter_timed,
         # the BINDING roof: the fused kernel is fp64-VALU-bound (370 FLOP per algorithmic byte against a machine balance of
         # 10); the HBM view and the measured traffic sit beside it
         "roofline": {"bound": "fp64_valu", "achieved": flops / (k_sum_ms * 1e-3) / 1e12, "peak": FP64_VALU_PEAK_TF, "unit": "TFLOP/s",
                      "frac": flops / (k_sum_ms * 1e-3) / 1e12 / FP64_VALU_PEAK_TF,
-                     "traffic": measured_traffic(nD),
+                     "traffic": measured_traffic(nD), "traffic_from_profile": traffic_provenance(),
                      "kernel": "k_solve_dynamics", "kernel_ms_per_step": k_sum_ms, "algorithmic_flops_per_step": flops,
                      "hbm": {"achieved": A / (k_sum_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                              "frac": A / (k_sum_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "algorithmic_bytes_per_step": A},
@@ -818,17 +1002,23 @@ def main():
                      "note": "kernel time = HIP events around every k_solve_dynamics launch of the timed steps, summed per step; "
                              "traffic = 2 x FETCH_SIZE + WRITE_SIZE of separate rocprofv3 --pmc passes (profiles/traffic_latest.json)"},
         "host_placement": placement,
-        "geometry": dict(geo, strips=int(off[-1]), strip_table_bytes_not_uploaded=int(off[-1]) * 256),
+        "geometry": dict(geo, strips=int(off[-1]), strip_table_bytes_not_uploaded=int(off[-1]) * 256,
+                         host_params_ms_per_step=host_params_ms, distinct_candidates_per_step=bool(variants)),
     }
     if per_rank is not None and rank == 0:
         out["per_rank_ms"] = {"min": float(per_rank[:, 0].min()), "max": float(per_rank[:, 0].max()), "all": [float(x) for x in per_rank[:, 0]],
                               "note": "every rank's own K steps / K, before the closing barrier"}
+        out["host_descriptor_ms_per_rank"] = {"all": [float(x) for x in per_rank[:, 2]],
+                                              "note": "host NumPy time each rank spent expanding ITS designs' descriptors (outside the step): "
+                                                      "ranks of one socket contend for it when they all do it at once"}
         out["gather_ms"] = {"rank0": float(per_rank[0, 1]), "max": float(per_rank[:, 1].max()),
                             "note": "host time inside the per-step exchange (%s); on rank 0 it includes waiting for the slowest rank's rows" % gather_kind}
         if single_rank is not None:
             v1 = n_dcf_rank / single_rank
-            out["single_rank_same_invocation"] = {"ms_per_step": 1e3 * single_rank, "value": v1,
-                                                  "note": "rank 0 alone, same K steps, the other ranks idle at the barrier"}
+            out["single_rank_same_invocation"] = {"ms_per_step": 1e3 * single_rank, "value": v1, "designs": int(nD),
+                                                  "note": "rank 0 alone on ITS %d designs, same K steps, the other ranks idle at the barrier"
+                                                          "%s" % (nD, " (strong scaling: a shard, not the whole sweep -- the one-GPU time of the whole "
+                                                                      "sweep is the N = 1 run of the same command)" if strong else "")}
             out["scaling_efficiency"] = value / (world * v1)
     if isolated is not None:
         out["isolated_call"] = {"ms_per_step": 1e3 * isolated, "dcf_per_s_per_gpu": n_dcf_rank / isolated,
@@ -841,19 +1031,47 @@ def main():
     if featured is not None:
         out["featured_sweeps"] = featured
     out.update(cfg_legs)
+    # ---- the CPU baseline (rank 0, N = 1): the UNMODIFIED reference on this host's cores when this host has it (build
+    # container: /root/reference; GPU box: oracle/_ref/raft_reference.zip), the vectorised C port beside it
     ref_here = reference_on_this_host() if (rank == 0 and world == 1 and not args.no_cpu_baseline) else None
-    if ref_here is not None:
-        out["reference_numpy_this_host"] = ref_here
+    if ref_here is not None and "error" not in ref_here:
+        nw_ = nw
+        out["cpu_baseline"] = {
+            "value": ref_here["dcf_per_s_pool"], "unit": "dcf solves/s", "cores": ref_here["pool_procs"], "kind": "reference",
+            "implementation": "reference-numpy: the unmodified raft.Model.solveDynamics (raft/raft_model.py:966) under the stub "
+                              "recipe of SURVEY.md 8c, imported from %s" % ("oracle/_ref/raft_reference.zip (byte-compiled by "
+                              "oracle/stage_reference.py from the sources under /root/reference)" if ref_here["reference_from"] == "archive"
+                              else "/root/reference"),
+            "sample": "C3 sweep variants (the first 64 designs of the timed batch, cyclically) x 1 sea state x %d bins: "
+                      "multiprocessing.Pool(%d) over %d (design, case) items, BLAS/OpenMP threads = 1, %.1f s wall (each item = "
+                      "Model(design) + statics + hydro constants + solveDynamics); one core alone: %d designs, %.2f s per solveDynamics; "
+                      "every timed solve equals tests/golden/c3_variants.npz (max rel. diff %.1e)"
+                      % (nw_, ref_here["pool_procs"], ref_here["pool_items"], ref_here["pool_wall_s"], ref_here["one_core_designs"],
+                         ref_here["solveDynamics_s_per_design"], ref_here["max_rel_err_vs_committed_reference_fixture"]),
+            "dcf_per_s_one_core": ref_here["dcf_per_s_one_core"], "dcf_per_s_pool": ref_here["dcf_per_s_pool"],
+            "dcf_per_s_pool_solve_only": ref_here["dcf_per_s_pool_solve_only"], "cores_on_host": ref_here["cores_on_host"],
+            "details": ref_here,
+            "gpu_over_reference": {"one_core": value / ref_here["dcf_per_s_one_core"], "pool_all_cores": value / ref_here["dcf_per_s_pool"],
+                                   "note": "a reported ratio, not a quality claim: the roofline fraction is"},
+        }
+        if cpu is not None:
+            out["cpu_baseline"]["port_simd"] = cpu
+    else:
+        if ref_here is not None:
+            out["reference_numpy_this_host"] = ref_here     # the error, so that its absence is explained on the line
+        if cpu is not None:
+            out["cpu_baseline"] = cpu
+    if _CPU_BUDGET:
+        out["host_cpu_budget"] = dict(_CPU_BUDGET, note="logical CPUs this container sees vs the CPUs' worth of run time it gets (one busy "
+                                      "loop per logical CPU for 1 s, CPU time / wall time): the CPU legs use the latter as their worker / thread count")
     ref_path = os.path.join(ROOT, "profiles", "reference_cpu_timing.json")
-    if os.path.exists(ref_path):      # the unmodified NumPy reference, timed in the BUILD container (it cannot travel to the GPU box)
+    if os.path.exists(ref_path):      # the same measurement made in the BUILD container (8 cores), for comparison
         with open(ref_path) as f:
             rt = json.load(f)
-        out["reference_numpy_build_container"] = {"dcf_per_s_one_core": rt.get("dcf_per_s_per_core"),
-                                                  "dcf_per_s_pool": rt.get("pool", {}).get("dcf_per_s_all_cores_solve_only"),
-                                                  "pool_cores": rt.get("pool", {}).get("cores"),
-                                                  "where": "BUILD CONTAINER (8 cores), second-hand here: the reference tree does not travel to the GPU box"}
-    if cpu is not None:
-        out["cpu_baseline"] = cpu
+        out["reference_numpy_build_container"] = {"dcf_per_s_one_core": rt.get("single", rt).get("dcf_per_s_one_core", rt.get("dcf_per_s_per_core")),
+                                                  "dcf_per_s_pool": rt.get("pool", {}).get("dcf_per_s_pool", rt.get("pool", {}).get("dcf_per_s_all_cores_solve_only")),
+                                                  "pool_procs": rt.get("pool", {}).get("procs", rt.get("pool", {}).get("cores")),
+                                                  "where": "BUILD CONTAINER (8 cores), oracle/time_reference.py --write"}
     if comm is not None:
         comm.close()
     if ctx_comm is not None:

@@ -484,14 +484,55 @@ int raftx_sweep_wait(raftx_ctx *ctx, int slot, double *timing_ms);
 int raftx_sweep_cancel(raftx_ctx *ctx, int slot);
 
 /* ------------------------------------------------------------------------------------------------
+ * Parametric VARIANTS of one base unit, expanded on the device (raft/parametersweep.py:39-87: a sweep edits a handful of
+ * parameters per candidate -- column diameters, draft, column radius, pontoon height -- and the dependent geometry
+ * follows).  The host describes the base unit once and, per candidate, sends only its nParam parameter values; the
+ * library writes each candidate's member / station / cap descriptors in HBM (k_geom_expand) and goes on as
+ * raftx_sweep_prepare does.  Per batch of 10^4 candidates: 0.4 MB of parameters instead of 66 MB of descriptors, and no
+ * host work per candidate.
+ *
+ * raftx_variant_program: the base unit's descriptors (as raftx_build_designs takes them, ONE design: nMember members,
+ *   stationOff / capOff [nMember+1], capOff / caps may be NULL) and the edit program.  Edits are AFFINE in the parameters:
+ *     endEdit [nMember] != 0: the member's end points BEFORE its heading rotation are
+ *         (rA, rB)[i] = endCoef[m][i][0] + sum_p endCoef[m][i][1+p] * param[p]      endCoef [nMember,6,nParam+1]
+ *       evaluated left to right without fused multiply-adds; the length |rB - rA| follows (raft_member.py:72), the ends
+ *       are rotated by the member's heading, headCS [nMember,2] = (cos, sin) of it (raft_member.py:75-77,
+ *       helpers.py:587-602), and the positions of the member's stations, ballast fills and caps keep their FRACTION of
+ *       the length (raft_member.py:99,143,173: the deck's station units are arbitrary).
+ *     diaEdit [nStation] != 0: the station's diameter / side pair is (d, d2)[j] = diaCoef[s][j][0] + sum_p ... [nStation,2,nParam+1].
+ *   Everything else of a variant is the base unit's.  The program stays on ctx until replaced (nMember = 0 clears it).
+ * raftx_expand_variants: the descriptors of nDesign variants back on the host (members [nDesign*nMember,RAFTX_GM_N],
+ *   stations [nDesign*nStation,RAFTX_GS_N], caps [nDesign*nCap,RAFTX_GC_N] or NULL; offsets are uniform:
+ *   memberOff[d] = d*nMember, stationOff[d*nMember+m] = d*nStation + base stationOff[m]) -- for checking and for feeding
+ *   another library; the sweep path never downloads them.
+ * raftx_sweep_prepare_variants: raftx_sweep_prepare with params [nDesign,nParam] in place of the six descriptor
+ *   arguments; raftx_sweep_launch / _wait / _cancel as usual (params must stay alive until the batch has been waited for). */
+int raftx_variant_program(raftx_ctx *ctx, int nMember, const double *members, const int64_t *stationOff, const double *stations,
+                          const int64_t *capOff, const double *caps, int nParam,
+                          const double *endCoef, const int32_t *endEdit, const double *headCS,
+                          const double *diaCoef, const int32_t *diaEdit);
+int raftx_expand_variants(raftx_ctx *ctx, int nDesign, const double *params, double *members, double *stations, double *caps);
+int raftx_sweep_prepare_variants(raftx_ctx *ctx, int slot, int nDesign, const double *params,
+                                 const double *pose, double rho, double g, int add_mask,
+                                 const double *M0, const double *B0, const double *C0, const double *Fz_moor,
+                                 int nCase, int nHead, int nw, const double *w, const double *k, double depth,
+                                 double rho_wave, double g_wave, const double *zeta, const double *beta,
+                                 int nIter, double tol, double XiStart, int nChunk,
+                                 double *std, int32_t *niter, int32_t *flags, raftx_c128 *Xi, int64_t *stripOffsets);
+
+/* ------------------------------------------------------------------------------------------------
  * Multi-GPU exchange steps: one process per GPU, one RCCL communicator per ctx, xGMI underneath.
  * The path shards with NO collective while kernels run; these calls are the once-per-batch exchanges around it:
  * the shared sea-state tables out (broadcast), the responses / statistics / QTF partials back (gather, reduce).
  * Every rank of the communicator must make the same call.  All calls are enqueued on the ctx's stream and return
  * after it has drained.  Each exchange step first validates its arguments and allocates its buffers locally, then the
  * ranks MAX-reduce one status word: if any rank cannot take part (bad argument, allocation failure) the call fails on
- * every rank with an error instead of leaving the others blocked in a send / receive that is never posted.  (The CPU oracle does not implement them: its tests use the host transport of
- * raft_amd/comm.py.)
+ * every rank with an error instead of leaving the others blocked in a send / receive that is never posted.  The status
+ * word lives on the device since raftx_comm_init and a local HIP error on the way into the vote is folded into the vote,
+ * so the vote itself is always posted.  NOT recoverable (the peers stay in the collective until RCCL's own watchdog /
+ * the caller's deadline, raft_amd/comm.py `timeout`): a rank whose process dies, a rank whose status AllReduce itself
+ * fails, or a copy that fails on the root in the MIDDLE of the grouped sends / receives after a successful vote.
+ * (The CPU oracle does not implement these calls: its tests use the host transport of raft_amd/comm.py.)
  *
  * raftx_comm_unique_id: rank 0 creates the 128-byte RCCL unique id and hands it to the other ranks by any host
  *   channel (raft_amd/comm.py: a TCP rendezvous on MASTER_ADDR);  raftx_comm_init: collective, binds ctx to

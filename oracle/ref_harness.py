@@ -9,8 +9,11 @@ things only:
   * generating the golden vectors under ``tests/golden/`` (``make_golden.py``),
   * pinning ``oracle/`` (the C / numpy restatement) against the live reference.
 
-Nothing under ``raft_amd/`` may import this file, and nothing that runs on the
-GPU box may either: ``/root/reference`` does not exist there.
+Nothing under ``raft_amd/`` may import this file.  On the GPU box ``/root/reference``
+does not exist; there the only thing to import is the byte-compiled archive
+``oracle/_ref/raft_reference.zip`` that ``oracle/stage_reference.py`` builds in the
+build container (git-ignored, travels with the snapshot) -- used by ``bench.py``'s
+``cpu_baseline`` leg (kind "reference-numpy") and by tests, never by the product.
 """
 import os
 import sys
@@ -20,10 +23,27 @@ import copy
 import numpy as np
 
 REFERENCE_ROOT = os.environ.get("RAFT_REFERENCE_ROOT", "/root/reference")
+ARCHIVE = os.path.join(os.path.dirname(os.path.abspath(__file__)), "_ref", "raft_reference.zip")
+
+
+def tree_available():
+    return os.path.isdir(os.path.join(REFERENCE_ROOT, "raft"))
+
+
+def archive_available():
+    return os.path.isfile(ARCHIVE)
 
 
 def reference_available():
-    return os.path.isdir(os.path.join(REFERENCE_ROOT, "raft"))
+    return tree_available() or archive_available()
+
+
+def reference_kind():
+    """'tree' (sources under REFERENCE_ROOT: the build container), 'archive' (oracle/_ref/raft_reference.zip: the GPU
+    box) or None.  RAFTX_REF_FORCE_ARCHIVE=1 picks the archive even where the tree exists (to rehearse the GPU box)."""
+    if archive_available() and (os.environ.get("RAFTX_REF_FORCE_ARCHIVE") or not tree_available()):
+        return "archive"
+    return "tree" if tree_available() else None
 
 
 def _raise_stub(*a, **k):
@@ -62,13 +82,14 @@ def install_stubs():
         ph.pyhams = php
         sys.modules["pyhams"] = ph
         sys.modules["pyhams.pyhams"] = php
-    if REFERENCE_ROOT not in sys.path:
-        sys.path.insert(0, REFERENCE_ROOT)
+    root = ARCHIVE if reference_kind() == "archive" else REFERENCE_ROOT
+    if root not in sys.path:
+        sys.path.insert(0, root)
 
 
 def import_raft():
     if not reference_available():
-        raise RuntimeError("reference tree not present at %s" % REFERENCE_ROOT)
+        raise RuntimeError("reference not present: neither %s nor %s" % (REFERENCE_ROOT, ARCHIVE))
     install_stubs()
     import matplotlib
     matplotlib.use("Agg")
@@ -80,6 +101,17 @@ def load_design(path):
     import yaml
     with open(path) as f:
         return yaml.load(f, Loader=yaml.FullLoader)
+
+
+def load_deck(rel):
+    """A deck of the reference tree by its path relative to the tree ('examples/VolturnUS-S_example.yaml'); read from the
+    staged archive (decks/<basename>) when that is what this host has."""
+    if reference_kind() == "archive":
+        import yaml
+        import zipfile
+        with zipfile.ZipFile(ARCHIVE) as z:
+            return yaml.load(z.read("decks/" + os.path.basename(rel)), Loader=yaml.FullLoader)
+    return load_design(os.path.join(REFERENCE_ROOT, rel))
 
 
 DEFAULT_C_MOOR = np.diag([7e4, 7e4, 0.0, 0.0, 0.0, 1e8])   # SURVEY.md section 8d

@@ -34,6 +34,7 @@ EXPORTS = (
     "raftx_sweep_cancel", "raftx_device_count", "raftx_solve_dense_batch", "raftx_dense_resident", "raftx_solve_dense_resident", "raftx_flex_solve", "raftx_debug_flex_gemm",
     "raftx_comm_unique_id", "raftx_comm_init", "raftx_comm_destroy", "raftx_comm_broadcast", "raftx_comm_gather_rows",
     "raftx_comm_gather_xi", "raftx_comm_reduce_sum",
+    "raftx_variant_program", "raftx_expand_variants", "raftx_sweep_prepare_variants",
 )
 WANT_BDRAG, WANT_FWAVE, WANT_Z = 1, 2, 4
 
@@ -171,6 +172,14 @@ class RaftxLib:
         L.raftx_sweep_submit.restype = C.c_int
         L.raftx_sweep_prepare.argtypes = L.raftx_sweep_submit.argtypes
         L.raftx_sweep_prepare.restype = C.c_int
+        L.raftx_variant_program.argtypes = [_vp, C.c_int, _vp, _vp, _vp, _vp, _vp, C.c_int, _vp, _vp, _vp, _vp, _vp]
+        L.raftx_variant_program.restype = C.c_int
+        L.raftx_expand_variants.argtypes = [_vp, C.c_int, _vp, _vp, _vp, _vp]
+        L.raftx_expand_variants.restype = C.c_int
+        L.raftx_sweep_prepare_variants.argtypes = [_vp, C.c_int, C.c_int, _vp, _vp, C.c_double, C.c_double, C.c_int,
+                                                   _vp, _vp, _vp, _vp, C.c_int, C.c_int, C.c_int, _vp, _vp, C.c_double, C.c_double, C.c_double,
+                                                   _vp, _vp, C.c_int, C.c_double, C.c_double, C.c_int, _vp, _vp, _vp, _vp, _vp]
+        L.raftx_sweep_prepare_variants.restype = C.c_int
         L.raftx_sweep_wait.argtypes = [_vp, C.c_int, _vp]
         L.raftx_sweep_wait.restype = C.c_int
         L.raftx_sweep_cancel.argtypes = [_vp, C.c_int]
@@ -230,6 +239,9 @@ class Context:
         self.resident_generation = 0
 
     def close(self):
+        if self._h and self.poisoned:     # a thread may still be inside the library on this context: leak it, never destroy it
+            self._h = _vp()
+            return
         if self._h:
             for ptr in list(getattr(self, "_pinned", {}).values()):       # page-locked buffers still out: release them
                 self.rlib.lib.raftx_host_free(self._h, _vp(ptr))
@@ -249,7 +261,11 @@ class Context:
     def __exit__(self, *a):
         self.close()
 
+    poisoned = None                       # set by raft_amd/comm.py when a call on this context never returned
+
     def _check(self, rc, what):
+        if self.poisoned:
+            raise RaftxError("%s: this context must not be used any more: %s" % (what, self.poisoned))
         if rc != 0:
             msg = self.rlib.lib.raftx_last_error(self._h)
             raise RaftxError("%s failed (rc=%d): %s" % (what, rc, (msg or b"").decode()))
@@ -386,6 +402,81 @@ class Context:
                                                float(XiStart), int(n_chunk), _ptr(out["std"]), _ptr(out["niter"]), _ptr(out["flags"]),
                                                _ptr(out["Xi"]), _ptr(out["strip_off"]))
         self._check(rc, "raftx_sweep_prepare")
+        return dict(slot=int(slot), inputs=inputs, out=out)
+
+    # ------------------------------------------------------------- parametric variants of one base unit
+    def variant_program(self, prog):
+        """Installs a raft_amd.geometry.VariantProgram on the context (raftx_variant_program); None clears it."""
+        if prog is None:
+            self._check(self.rlib.lib.raftx_variant_program(self._h, 0, None, None, None, None, None, 0, None, None, None, None, None),
+                        "raftx_variant_program")
+            self._vprog = None
+            return
+        b = prog.base
+        nM, nSt, nCap, nP = b.n, len(b.stations), len(b.caps), prog.n_param
+        arrs = dict(members=_f64(b.members, (nM, 16), "members"), station_off=np.ascontiguousarray(b.station_off, dtype=np.int64),
+                    stations=_f64(b.stations, (nSt, 16), "stations"), cap_off=np.ascontiguousarray(b.cap_off, dtype=np.int64),
+                    caps=_f64(b.caps if nCap else np.zeros((1, 4)), (max(nCap, 1), 4), "caps"),
+                    end_coef=_f64(prog.end_coef, (nM, 6, nP + 1), "end_coef"), end_edit=np.ascontiguousarray(prog.end_edit, dtype=np.int32),
+                    head_cs=_f64(prog.head_cs, (nM, 2), "head_cs"), dia_coef=_f64(prog.dia_coef, (nSt, 2, nP + 1), "dia_coef"),
+                    dia_edit=np.ascontiguousarray(prog.dia_edit, dtype=np.int32))
+        rc = self.rlib.lib.raftx_variant_program(self._h, nM, _ptr(arrs["members"]), _ptr(arrs["station_off"]), _ptr(arrs["stations"]),
+                                                 _ptr(arrs["cap_off"]), _ptr(arrs["caps"]), nP, _ptr(arrs["end_coef"]),
+                                                 _ptr(arrs["end_edit"]), _ptr(arrs["head_cs"]), _ptr(arrs["dia_coef"]), _ptr(arrs["dia_edit"]))
+        self._check(rc, "raftx_variant_program")
+        self._vprog = (nM, nSt, nCap, nP)
+
+    def expand_variants(self, params):
+        """(members [nD*nM,16], stations [nD*nSt,16], caps [nD*nCap,4]) of the variants ``params`` [nD,nParam] of the installed
+        program, written by the library (raftx_expand_variants): for checks -- the sweep path never downloads them."""
+        if getattr(self, "_vprog", None) is None:
+            raise RaftxError("expand_variants: no program installed (variant_program first)")
+        nM, nSt, nCap, nP = self._vprog
+        params = _f64(params)
+        nD = params.shape[0]
+        params = _f64(params, (nD, nP), "params")
+        gm, gs, gc = np.empty((nD * nM, 16)), np.empty((nD * nSt, 16)), np.empty((nD * nCap, 4))
+        self._check(self.rlib.lib.raftx_expand_variants(self._h, nD, _ptr(params), _ptr(gm), _ptr(gs), _ptr(gc) if nCap else None),
+                    "raftx_expand_variants")
+        return gm, gs, gc
+
+    def sweep_prepare_variants(self, slot, params, M0, B0, C0, w, k, depth, zeta, beta, nIter, tol=0.01, XiStart=0.1, pose=None,
+                               rho=1025.0, g=9.81, rho_wave=1025.0, g_wave=9.81, add_mask=7, Fz_moor=None, n_chunk=0, want_Xi=False,
+                               Xi_out=None):
+        """``sweep_prepare`` for variants of the installed program: ``params`` [nD,nParam] cross the bus, the descriptors are
+        written on the device (raftx_sweep_prepare_variants).  sweep_launch / sweep_wait / sweep_cancel as usual."""
+        if getattr(self, "_vprog", None) is None:
+            raise RaftxError("sweep_prepare_variants: no program installed (variant_program first)")
+        self.resident_generation += 1
+        nP = self._vprog[3]
+        params = _f64(params)
+        nD = params.shape[0]
+        params = _f64(params, (nD, nP), "params")
+        M0, B0, C0 = _f64(M0, (nD, 6, 6), "M0"), _f64(B0, (nD, 6, 6), "B0"), _f64(C0, (nD, 6, 6), "C0")
+        pose = None if pose is None else _f64(pose, (nD, 6), "pose")
+        Fz = None if Fz_moor is None else _f64(Fz_moor, (nD,), "Fz_moor")
+        w = _f64(w)
+        nw = len(w)
+        k = _f64(k, (nw,), "k")
+        zeta = _f64(zeta)
+        if zeta.ndim == 2:
+            zeta, beta = zeta[None], np.asarray(beta, dtype=np.float64)[None]
+        nC, nH = zeta.shape[0], zeta.shape[1]
+        zeta, beta = _f64(zeta, (nC, nH, nw), "zeta"), _f64(beta, (nC, nH), "beta")
+        Xi = Xi_out
+        if Xi is None and want_Xi:
+            Xi = np.empty((nD, nC, nH, 6, nw), dtype=np.complex128)
+        if Xi is not None and (Xi.dtype != np.complex128 or Xi.shape != (nD, nC, nH, 6, nw) or not Xi.flags["C_CONTIGUOUS"]):
+            raise ValueError("Xi_out must be a C-contiguous complex128 array of shape %s" % ((nD, nC, nH, 6, nw),))
+        out = dict(std=np.empty((nD, nC, 6)), niter=np.zeros((nD, nC), dtype=np.int32), flags=np.zeros((nD, nC), dtype=np.int32),
+                   Xi=Xi, strip_off=np.zeros(nD + 1, dtype=np.int64), timing_ms=np.zeros(4))
+        inputs = (params, pose, M0, B0, C0, Fz, w, k, zeta, beta)
+        rc = self.rlib.lib.raftx_sweep_prepare_variants(self._h, int(slot), nD, _ptr(params), _ptr(pose), float(rho), float(g), int(add_mask),
+                                                        _ptr(M0), _ptr(B0), _ptr(C0), _ptr(Fz), nC, nH, nw, _ptr(w), _ptr(k), float(depth),
+                                                        float(rho_wave), float(g_wave), _ptr(zeta), _ptr(beta), int(nIter), float(tol),
+                                                        float(XiStart), int(n_chunk), _ptr(out["std"]), _ptr(out["niter"]),
+                                                        _ptr(out["flags"]), _ptr(out["Xi"]), _ptr(out["strip_off"]))
+        self._check(rc, "raftx_sweep_prepare_variants")
         return dict(slot=int(slot), inputs=inputs, out=out)
 
     def sweep_launch(self, handle):

@@ -277,8 +277,14 @@ def _attempt(fn, seconds):
     t.start()
     t.join(seconds)
     if t.is_alive():
-        return "no return within %.0f s" % seconds
+        return CommTimeout("no return within %.0f s" % seconds)
     return box.get("e")
+
+
+class CommTimeout(RuntimeError):
+    """A library call of the communicator's set-up did not return: its thread is still INSIDE the library on that context.
+    The library is not thread-safe per context, so the context is poisoned (``ctx.poisoned``) -- nothing may use it again,
+    neither for exchange steps nor for uploads / solves -- and there is no fallback to the host transport on it."""
 
 
 class RcclComm:
@@ -304,16 +310,24 @@ class RcclComm:
         # ncclCommInitRank is collective and blocks: a rank that fails (or never arrives) leaves the others inside it.  It
         # runs under a deadline, and the ranks AGREE on the outcome over the rendezvous channel before anyone uses the
         # communicator -- so that they fail, or fall back, together.
-        self._agree(_attempt(lambda: ctx.comm_init(self.rank, self.world, uid), deadline), "ncclCommInitRank")
+        self._agree(self._guard(_attempt(lambda: ctx.comm_init(self.rank, self.world, uid), deadline)), "ncclCommInitRank")
         # one probe collective before the communicator is trusted with results: 1 + 2 + .. + world on the root
         probe = np.array([self.rank + 1.0])
-        err = _attempt(lambda: ctx.comm_reduce_sum(probe, 0), deadline)
+        err = self._guard(_attempt(lambda: ctx.comm_reduce_sum(probe, 0), deadline))
         if err is None and self.rank == 0 and probe[0] != self.world * (self.world + 1) / 2:
             err = "probe reduction gave %r, expected %r" % (probe[0], self.world * (self.world + 1) / 2)
         self._agree(err, "probe ncclReduce")
 
+    def _guard(self, err):
+        if isinstance(err, CommTimeout):                 # the abandoned thread may still be running in the library on this ctx
+            self.ctx.poisoned = "a communicator set-up call never returned (%s)" % err
+        return err
+
     def _agree(self, err, what):
-        bad = self.boot.all_max(1.0 if err else 0.0)
+        # 2 = some rank timed out (its context is unusable: nobody falls back), 1 = some rank got an error back, 0 = fine
+        bad = self.boot.all_max(2.0 if isinstance(err, CommTimeout) else (1.0 if err else 0.0))
+        if bad >= 2:
+            raise CommTimeout("%s: %s" % (what, err or "another rank's call never returned"))
         if bad:
             raise RuntimeError("%s: %s" % (what, err or "another rank failed"))
 
@@ -381,7 +395,9 @@ def from_env(ctx=None, prefer="rccl", environ=None, fallback="error"):
     and the ranks agree on the outcome over the rendezvous channel -- so they land in the same branch below together.
     fallback="error" (default): a sweep whose ranks own distinct GPUs must not quietly move its exchange steps onto TCP.
     fallback="host": the host transport is used and ``kind`` says so, with the reason (rehearsals with several ranks on
-    ONE GPU, which RCCL refuses; bench.py, whose JSON line carries ``kind``)."""
+    ONE GPU, which RCCL refuses; bench.py, whose JSON line carries ``kind``) -- but only after an error that RETURNED:
+    after a timeout (CommTimeout) a thread is still inside the library on ``ctx``, the context is marked ``poisoned`` and
+    every rank raises."""
     env = os.environ if environ is None else environ
     rank, world = int(env.get("RANK", "0")), int(env.get("WORLD_SIZE", "1"))
     addr = env.get("MASTER_ADDR", "127.0.0.1")
@@ -392,7 +408,7 @@ def from_env(ctx=None, prefer="rccl", environ=None, fallback="error"):
             c = RcclComm(ctx, boot)
             return c, c.kind
         except Exception as e:          # noqa: BLE001 -- every rank lands here together
-            if fallback != "host":
+            if fallback != "host" or isinstance(e, CommTimeout):     # a timed-out context is never reused, not even over TCP
                 boot.close()
                 raise RuntimeError("RCCL communicator of rank %d / %d could not be created: %s" % (rank, world, e)) from e
             sys.stderr.write("raftx comm: rank %d / %d falls back to the host transport: %s\n" % (rank, world, e))

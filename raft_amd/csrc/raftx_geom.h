@@ -1418,3 +1418,84 @@ __global__ __launch_bounds__(64) void k_geom_reduce(GeomArgs A) {
         pr[11] = 0.0;
     }
 }
+
+// ------------------------------------------------------------------------------------------------------------------
+// Parametric variants of one base unit, written in HBM (raftx_variant_program / raftx_sweep_prepare_variants;
+// raft/parametersweep.py:39-87 edits a handful of parameters per candidate and the dependent geometry follows).
+// One thread per descriptor ROW of a variant -- member, station or cap -- copies the base row and applies the edits:
+// the member's end points as affine functions of the parameters, its length (raft_member.py:72), the heading rotation
+// (:75-77, helpers.py:587-602), station / ballast / cap positions as fractions of the length (:99,143,173), diameters
+// as affine functions.  Every expression is evaluated like the host's NumPy form -- left to right, no fused
+// multiply-add -- so that the rows are the bits raft_amd/geometry.py SweepTables produces (tests/test_geometry.py).
+// 6.6 KB per VolturnUS-S variant: a 10^4-design batch is 66 MB of stores (16-double rows, one full line per thread)
+// instead of 66 MB over PCIe.
+struct ExpandArgs {
+    int n, nM, nSt, nCap, nP;
+    const double *params;                                    // [n,nP]
+    const double *gm, *gs, *gc;                              // base rows
+    const int *stMember, *capMember;
+    const double *stFrac, *fillFrac, *capFrac;
+    const double *endCoef, *headCS, *diaCoef;                // [nM,6,nP+1] [nM,2] [nSt,2,nP+1]
+    const int *endEdit, *diaEdit;
+    double *gm_out, *gs_out, *gc_out;                        // [n*nM,GM_N] [n*nSt,GS_N] [n*nCap,GC_N]
+};
+__device__ inline double affine_eval(const double *coef, const double *p, int nP) {
+    GEOM_NOFMA
+    double v = coef[0];
+    for (int q = 0; q < nP; q++) v = v + coef[1 + q] * p[q];
+    return v;
+}
+__global__ void __launch_bounds__(256) k_geom_expand(ExpandArgs E) {
+    GEOM_NOFMA
+    const int per = E.nM + E.nSt + E.nCap;
+    const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= (size_t)E.n * per) return;
+    const int d = (int)(t / per), r = (int)(t % per);
+    const double *p = E.params + (size_t)d * E.nP;
+    const int m = r < E.nM ? r : (r < E.nM + E.nSt ? E.stMember[r - E.nM] : E.capMember[r - E.nM - E.nSt]);
+    const double *bm = E.gm + (size_t)m * RAFTX_GM_N;
+    const bool ed = E.endEdit[m] != 0;
+    double e[6] = {0, 0, 0, 0, 0, 0}, L = bm[RAFTX_GM_L];
+    if (ed) {
+        for (int i = 0; i < 6; i++) e[i] = affine_eval(E.endCoef + ((size_t)m * 6 + i) * (E.nP + 1), p, E.nP);
+        const double dx = e[3] - e[0], dy = e[4] - e[1], dz = e[5] - e[2];
+        L = sqrt((dx * dx + dy * dy) + dz * dz);             // |rB - rA| before the heading rotation (raft_member.py:72)
+    }
+    if (r < E.nM) {
+        double *o = E.gm_out + ((size_t)d * E.nM + m) * RAFTX_GM_N;
+        for (int i = 0; i < RAFTX_GM_N; i++) o[i] = bm[i];
+        if (ed) {
+            const double c = E.headCS[2 * m], s = E.headCS[2 * m + 1];
+            o[RAFTX_GM_RA + 0] = c * e[0] + (-s) * e[1];
+            o[RAFTX_GM_RA + 1] = s * e[0] + c * e[1];
+            o[RAFTX_GM_RA + 2] = e[2];
+            o[RAFTX_GM_RB + 0] = c * e[3] + (-s) * e[4];
+            o[RAFTX_GM_RB + 1] = s * e[3] + c * e[4];
+            o[RAFTX_GM_RB + 2] = e[5];
+            o[RAFTX_GM_L] = L;
+        }
+    } else if (r < E.nM + E.nSt) {
+        const int si = r - E.nM;
+        const double *b = E.gs + (size_t)si * RAFTX_GS_N;
+        double *o = E.gs_out + ((size_t)d * E.nSt + si) * RAFTX_GS_N;
+        for (int i = 0; i < RAFTX_GS_N; i++) o[i] = b[i];
+        if (ed) {
+            o[RAFTX_GS_S] = E.stFrac[si] * L;
+            o[RAFTX_GS_LFILL] = E.fillFrac[si] * L;
+        }
+        if (E.diaEdit[si]) {
+            o[RAFTX_GS_D] = affine_eval(E.diaCoef + ((size_t)si * 2 + 0) * (E.nP + 1), p, E.nP);
+            o[RAFTX_GS_D + 1] = affine_eval(E.diaCoef + ((size_t)si * 2 + 1) * (E.nP + 1), p, E.nP);
+        }
+    } else {
+        const int ci = r - E.nM - E.nSt;
+        const double *b = E.gc + (size_t)ci * RAFTX_GC_N;
+        double *o = E.gc_out + ((size_t)d * E.nCap + ci) * RAFTX_GC_N;
+        for (int i = 0; i < RAFTX_GC_N; i++) o[i] = b[i];
+        if (ed) o[RAFTX_GC_S] = E.capFrac[ci] * L;
+    }
+}
+static inline void launch_expand(const ExpandArgs &E, hipStream_t st) {
+    const size_t nT = (size_t)E.n * (E.nM + E.nSt + E.nCap);
+    if (nT) hipLaunchKernelGGL(k_geom_expand, dim3((unsigned)((nT + 255) / 256)), dim3(256), 0, st, E);
+}

@@ -204,14 +204,20 @@ __device__ __forceinline__ T half_bcast(T v, int src_lane) {          // value o
 }
 __device__ __forceinline__ cplx half_bcast(cplx v, int src_lane) { return {__shfl(v.re, src_lane, 64), __shfl(v.im, src_lane, 64)}; }
 #define SYSROWS_MAXRHS 4
-template <int NU, int NR, bool RESIDENT>          // NR: right-hand sides compiled in (nRhs <= NR; the rest are zero columns)
+// ASM (resident form only): the units' 6 x 6 impedance blocks are ASSEMBLED here, Z = -w^2 M0 + i w (B0 + B_drag) + C0 with the
+// unit kernel's own expression (assemble_and_solve: fma(-w^2, M, C), w * (B0 + Bd) -- the same bits), from 36 x 4 doubles
+// per unit instead of 36 x nw complex per pair: the fixed points then need not export Z at all (a farm sweep of 200 000
+// pairs writes and re-reads 23 GB of it) and run as the LEAN kernel with the excitation export (KF_OUTF).
+template <int NU, int NR, bool RESIDENT, bool ASM = false>          // NR: right-hand sides compiled in (nRhs <= NR; the rest are zero columns)
 #ifndef RAFTX_SYSROWS_WAVES
 #define RAFTX_SYSROWS_WAVES 2     // waves per SIMD the register allocation aims at (tuning builds: 3, 4)
 #endif
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(RAFTX_SYSROWS_WAVES, RAFTX_SYSROWS_WAVES))) k_solve_system_rows(int nSys, int nRhs, int nw, int nCase, const double *__restrict__ w,
                                                           const cplx *__restrict__ Zblk, const double *__restrict__ Mc,
                                                           const double *__restrict__ Bc, const double *__restrict__ Cc,
-                                                          const cplx *__restrict__ F, cplx *__restrict__ Xi) {
+                                                          const cplx *__restrict__ F, cplx *__restrict__ Xi,
+                                                          const double *__restrict__ uM = nullptr, const double *__restrict__ uB = nullptr,
+                                                          const double *__restrict__ uC = nullptr, const double *__restrict__ uBd = nullptr) {
     constexpr int N = 6 * NU;
     const int ngrp = (nw + 1) / 2;                       // two bins (systems) per wavefront: lanes 0-31 and 32-63
     const int s = blockIdx.x / ngrp, lane = threadIdx.x, half = lane >> 5, r = lane & 31, hbase = lane & 32;
@@ -229,8 +235,18 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(RAFTX_S
     const int u = rr / 6, q = rr % 6;
     const size_t pair = RESIDENT ? ((size_t)g * NU + u) * nCase + ic : (size_t)s * NU + u;
     cplx zb[6];
+    if constexpr (ASM) {
+        const size_t dsg = ((size_t)g * NU + u) * 36 + q * 6, pr = pair * 36 + q * 6;
+        const double w2 = ww * ww;
 #pragma unroll
-    for (int c = 0; c < 6; c++) zb[c] = Zblk[((pair * 6 + q) * 6 + c) * nw + iw];
+        for (int c = 0; c < 6; c++) {
+            const double Bq = uB[dsg + c] + uBd[pr + c];
+            zb[c] = {fma(-w2, uM[dsg + c], uC[dsg + c]), ww * Bq};
+        }
+    } else {
+#pragma unroll
+        for (int c = 0; c < 6; c++) zb[c] = Zblk[((pair * 6 + q) * 6 + c) * nw + iw];
+    }
 #pragma unroll
     for (int j = 0; j < NR; j++)
         bR[j] = j < nRhs ? (RESIDENT ? F[((pair * nRhs + j) * 6 + q) * nw + iw] : F[(((size_t)s * nRhs + j) * N + rr) * nw + iw])
@@ -346,21 +362,38 @@ static bool solve_system_rows_ok(int nUnit, int nRhs) {
     return !(off && atoi(off)) && nUnit >= 2 && nUnit <= 5 && nRhs >= 1 && nRhs <= SYSROWS_MAXRHS;
 }
 // launches the register-resident kernel; returns false if this shape has none
-template <bool RESIDENT>
+template <bool RESIDENT, bool ASM = false>
 static bool launch_solve_system_rows(hipStream_t st, int nSys, int nUnit, int nRhs, int nw, int nCase, const double *w, const cplx *Z,
-                                     const double *Mc, const double *Bc, const double *Cc, const cplx *F, cplx *X) {
+                                     const double *Mc, const double *Bc, const double *Cc, const cplx *F, cplx *X,
+                                     const double *uM = nullptr, const double *uB = nullptr, const double *uC = nullptr,
+                                     const double *uBd = nullptr) {
     if (!solve_system_rows_ok(nUnit, nRhs)) return false;
     const dim3 grid((unsigned)((size_t)nSys * ((nw + 1) / 2)));
     const int nr = nRhs == 1 ? 1 : (nRhs == 2 ? 2 : 4);
 #define ROWS_CASE(NU_, NR_)                                                                                             \
     if (nUnit == NU_ && nr == NR_) {                                                                                    \
-        hipLaunchKernelGGL((k_solve_system_rows<NU_, NR_, RESIDENT>), grid, dim3(64), 0, st, nSys, nRhs, nw, nCase, w, Z, Mc, Bc, Cc, F, X); \
+        hipLaunchKernelGGL((k_solve_system_rows<NU_, NR_, RESIDENT, ASM>), grid, dim3(64), 0, st, nSys, nRhs, nw, nCase, w, Z, Mc, Bc, Cc, F, X, \
+                           uM, uB, uC, uBd);                                                                           \
         return true;                                                                                                    \
     }
     ROWS_CASE(2, 1) ROWS_CASE(2, 2) ROWS_CASE(2, 4) ROWS_CASE(3, 1) ROWS_CASE(3, 2) ROWS_CASE(3, 4)
     ROWS_CASE(4, 1) ROWS_CASE(4, 2) ROWS_CASE(4, 4) ROWS_CASE(5, 1) ROWS_CASE(5, 2) ROWS_CASE(5, 4)
 #undef ROWS_CASE
     return false;
+}
+
+// The same assembly as a kernel of its own, for the shapes the register-resident solver does not take (more than five
+// units / four right-hand sides): Z [pair,36,nw] into a scratch slab, then the LDS-resident solver as before.
+__global__ void __launch_bounds__(256) k_assemble_unit_z(int npair, int nCase, int nw, const double *__restrict__ w,
+                                                         const double *__restrict__ uM, const double *__restrict__ uB,
+                                                         const double *__restrict__ uC, const double *__restrict__ uBd,
+                                                         cplx *__restrict__ Z) {
+    const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= (size_t)npair * 36 * nw) return;
+    const int iw = (int)(t % nw), e = (int)((t / nw) % 36);
+    const size_t pair = t / ((size_t)36 * nw), d = pair / nCase;
+    const double ww = w[iw], Bq = uB[d * 36 + e] + uBd[pair * 36 + e];
+    Z[t] = {fma(-(ww * ww), uM[d * 36 + e], uC[d * 36 + e]), ww * Bq};
 }
 
 // bins per workgroup and dynamic LDS of k_solve_system
@@ -654,6 +687,37 @@ struct CaseSet {
     unsigned long long stamp = 0;        // last use (the idle set used longest ago is replaced)
 };
 
+// Edit program of parametric variants (raftx_variant_program): the base unit's descriptors and the affine edits, resident
+// on the device; the uniform offset arrays of a batch of nDesign variants on the host (cached per batch size).
+struct VariantProg {
+    int nM = 0, nSt = 0, nCap = 0, nP = 0;
+    bool has_caps = false;
+    double *gm = nullptr, *gs = nullptr, *gc = nullptr;                  // base descriptors
+    int *stMember = nullptr, *capMember = nullptr;                       // member of every station / cap row
+    double *stFrac = nullptr, *fillFrac = nullptr, *capFrac = nullptr;   // positions as fractions of the member length
+    double *endCoef = nullptr, *headCS = nullptr, *diaCoef = nullptr;
+    int *endEdit = nullptr, *diaEdit = nullptr;
+    std::vector<int64_t> hS, hC;                                         // base stationOff / capOff (host)
+    std::vector<void *> allocs;
+    int cachedN = -1;
+    std::vector<int64_t> memberOff, stationOff, capOff;                  // uniform offsets of cachedN variants
+};
+// where a block's descriptors come from when they are not the caller's arrays
+struct VariantSrc {
+    const VariantProg *prog;
+    const double *params;                                                // host, [nDesign of the batch, nP]
+};
+
+static void expand_args(const VariantProg &P, int n, double *gm_out, double *gs_out, double *gc_out, ExpandArgs &E) {
+    E.n = n; E.nM = P.nM; E.nSt = P.nSt; E.nCap = P.nCap; E.nP = P.nP;
+    E.gm = P.gm; E.gs = P.gs; E.gc = P.gc;
+    E.stMember = P.stMember; E.capMember = P.capMember;
+    E.stFrac = P.stFrac; E.fillFrac = P.fillFrac; E.capFrac = P.capFrac;
+    E.endCoef = P.endCoef; E.headCS = P.headCS; E.diaCoef = P.diaCoef;
+    E.endEdit = P.endEdit; E.diaEdit = P.diaEdit;
+    E.gm_out = gm_out; E.gs_out = gs_out; E.gc_out = gc_out;
+}
+
 // resident matrices of the dense solves (raftx_dense_resident): device pointers owned by `allocs`
 struct DenseResident {
     int nSet = 0, n = 0, nw = 0, freq_mask = 0;
@@ -728,6 +792,7 @@ struct raftx_ctx {
     int *commFlag = nullptr;             // one int in HBM: the status word the ranks agree on before an exchange step (comm_agree)
     std::vector<raftx_ctx *> workers[RAFTX_NSLOT]; // block contexts of the sweep crossings (device buffers, pool, events), per slot, kept for reuse
     struct SweepSlot *slots;             // [RAFTX_NSLOT] crossings in flight (raftx_sweep_prepare / _launch / _wait)
+    VariantProg vprog;                   // raftx_variant_program
 };
 // Offset arrays of a whole batch, resident on the device (uploaded once by the sweep crossing, shared by its blocks).
 struct DevOffsets {
@@ -758,6 +823,7 @@ struct SweepSlot {
         double rho, g;
         int add_mask;
         DevOffsets dOff;
+        VariantSrc var;                  // prog == nullptr: the caller's descriptor arrays
     } p1;
     size_t next_p1 = 0;                  // first block whose phase 1 has not been enqueued yet
     std::chrono::steady_clock::time_point t0;
@@ -901,6 +967,7 @@ extern "C" void raftx_ctx_destroy(raftx_ctx *c) {
     if (c->rKay) (void)hipFree(c->rKay);
     if (c->pairList) (void)hipFree(c->pairList);
     free_list(c, c->dense.allocs);
+    free_list(c, c->vprog.allocs);
     if (c->identList) (void)hipFree(c->identList);
     for (hipEvent_t e : c->evSlab) (void)hipEventDestroy(e);
     if (c->evFork) (void)hipEventDestroy(c->evFork);
@@ -1067,12 +1134,13 @@ static int build_phase1(raftx_ctx *c, hipStream_t sCopy, hipStream_t sPrep, int 
                         const double *members, const int64_t *stationOff, const double *stations, const int64_t *capOff,
                         const double *caps, const double *pose, double rho, double g, int nw, const double *k, int add_mask,
                         const double *M0, const double *B0, const double *C0, const double *MBw, const double *Fz_moor,
-                        const DevOffsets *shared, const double *k_dev = nullptr) {
+                        const DevOffsets *shared, const double *k_dev = nullptr, const VariantSrc *var = nullptr) {
     RangeScope range_("build phase 1: descriptor H2D, member pass, scans (enqueue)");
     BuildJob &J = c->job;
-    if (nDesign < 0 || lo < 0 || !memberOff || !members || !stationOff || !stations || !M0 || !B0 || !C0)
+    if (var && !var->prog) var = nullptr;
+    if (nDesign < 0 || lo < 0 || !memberOff || (!members && !var) || !stationOff || (!stations && !var) || !M0 || !B0 || !C0)
         FAIL(c, "build_designs: bad arguments");
-    if ((capOff == nullptr) != (caps == nullptr)) FAIL(c, "build_designs: capOff and caps must be given together");
+    if (!var && (capOff == nullptr) != (caps == nullptr)) FAIL(c, "build_designs: capOff and caps must be given together");
     if (nw < 1 || nw > MAX_NW) FAIL(c, "build_designs: nw=%d outside 1..%d", nw, MAX_NW);
     const int64_t m0 = memberOff[lo], m1 = memberOff[lo + nDesign], nMember = m1 - m0;
     if (nMember < 0 || m0 < 0) FAIL(c, "build_designs: member offsets not monotone");
@@ -1107,10 +1175,32 @@ static int build_phase1(raftx_ctx *c, hipStream_t sCopy, hipStream_t sPrep, int 
         rc |= upload_on(c, sCopy, tmp, stationOff + m0, (size_t)nMember + 1, &A.stationOff);
         if (capOff) rc |= upload_on(c, sCopy, tmp, capOff + m0, (size_t)nMember + 1, &A.capOff);
     }
-    rc |= upload_on(c, sCopy, tmp, members + (size_t)m0 * RAFTX_GM_N, (size_t)nMember * RAFTX_GM_N, &A.gm);
-    rc |= upload_on(c, sCopy, tmp, stations + (size_t)s0 * RAFTX_GS_N, (size_t)(s1 - s0) * RAFTX_GS_N, &A.gs);
+    ExpandArgs E;
+    memset(&E, 0, sizeof(E));
+    if (var) {
+        // variants of one base unit: only their parameters cross the bus (nP doubles per design); the descriptors are
+        // written in HBM by k_geom_expand, enqueued below on sPrep ahead of the member pass
+        const VariantProg &P = *var->prog;
+        if (nMember != (int64_t)nDesign * P.nM || s1 - s0 != (int64_t)nDesign * P.nSt || c1 - c0 != (int64_t)nDesign * P.nCap)
+            FAIL(c, "build_designs: offsets do not describe %d variants of the program's base unit", nDesign);
+        void *pg = nullptr, *ps = nullptr, *pc = nullptr;
+        HIPCHK(c, c->pool.get(std::max<size_t>((size_t)nMember * RAFTX_GM_N, 1) * sizeof(double), &pg));
+        tmp.push_back(pg);
+        HIPCHK(c, c->pool.get(std::max<size_t>((size_t)(s1 - s0) * RAFTX_GS_N, 1) * sizeof(double), &ps));
+        tmp.push_back(ps);
+        HIPCHK(c, c->pool.get(std::max<size_t>((size_t)(c1 - c0) * RAFTX_GC_N, 1) * sizeof(double), &pc));
+        tmp.push_back(pc);
+        rc |= upload_on(c, sCopy, tmp, var->params + (size_t)lo * P.nP, (size_t)nDesign * P.nP, &E.params);
+        expand_args(P, nDesign, reinterpret_cast<double *>(pg), reinterpret_cast<double *>(ps), reinterpret_cast<double *>(pc), E);
+        A.gm = E.gm_out;
+        A.gs = E.gs_out;
+        if (capOff) A.caps = E.gc_out;
+    } else {
+        rc |= upload_on(c, sCopy, tmp, members + (size_t)m0 * RAFTX_GM_N, (size_t)nMember * RAFTX_GM_N, &A.gm);
+        rc |= upload_on(c, sCopy, tmp, stations + (size_t)s0 * RAFTX_GS_N, (size_t)(s1 - s0) * RAFTX_GS_N, &A.gs);
+    }
     rc |= upload_on(c, sCopy, tmp, pose ? pose + (size_t)lo * 6 : nullptr, pose ? (size_t)nDesign * 6 : 0, &A.pose);
-    if (capOff) {
+    if (capOff && !var) {
         if (c1 > c0) rc |= upload_on(c, sCopy, tmp, caps + (size_t)c0 * RAFTX_GC_N, (size_t)(c1 - c0) * RAFTX_GC_N, &A.caps);
         else {                                        // no caps in this slice: a valid, never-read address
             void *p_ = nullptr;
@@ -1134,6 +1224,7 @@ static int build_phase1(raftx_ctx *c, hipStream_t sCopy, hipStream_t sPrep, int 
     A.C0 = J.C0d;
     HIPCHK(c, hipEventRecord(c->evUp, sCopy));
     HIPCHK(c, hipStreamWaitEvent(sPrep, c->evUp, 0));
+    if (var && nDesign > 0) launch_expand(E, sPrep);
     // device-side scratch; on a pooled block a memset on sPrep is ordered before the kernels that use it
     int *errd = nullptr;
     {
@@ -1718,7 +1809,7 @@ static int solve_enqueue(raftx_ctx *c, int nIter, double tol, double XiStart, co
     // smallest one that covers what this call needs; everything else (the drop-in's optional outputs) is the
     // full-featured kernel at one wave per SIMD.
 #define RAFTX_LEAN128(X) X(0) X(KF_FDEP) X(KF_MCF) X(KF_MULTI) X(KF_FDEP | KF_EXTRA) X(KF_FDEP | KF_MCF) X(KF_FDEP | KF_MULTI) \
-    X(KF_MCF | KF_MULTI) X(KF_FDEP | KF_EXTRA | KF_MULTI) X(KF_FDEP | KF_MCF | KF_MULTI)
+    X(KF_MCF | KF_MULTI) X(KF_FDEP | KF_EXTRA | KF_MULTI) X(KF_FDEP | KF_MCF | KF_MULTI) X(KF_OUTF) X(KF_OUTF | KF_MULTI)
     if (c->have_xl0 || c->want_xlout) need |= KF_XLIO;
     int lean = -1;
     if (rc_shape) {
@@ -2406,9 +2497,13 @@ extern "C" int raftx_flex_solve(raftx_ctx *c, int nUnit, const int64_t *nodeOff,
 extern "C" int raftx_solve_system_resident(raftx_ctx *c, int nUnit, const double *Mc, const double *Bc, const double *Cc,
                                            raftx_c128 *Xi) {
     if (!c) return -1;
-    if (!c->rXi || !c->rZ || !c->rFw)
-        FAIL(c, "solve_system_resident: needs resident Z and F_wave (raftx_solve_dynamics_device with RAFTX_WANT_Z|RAFTX_WANT_FWAVE)");
     const DevTables &T = c->T;
+    // what the coupled solve is fed from: the exported impedances (RAFTX_WANT_Z), or -- no Z kept -- the units' constant
+    // matrices + the exported B_drag (RAFTX_WANT_BDRAG), assembled on the fly; frequency-dependent M(w), B(w) need the export
+    const bool assemble = c->rXi && !c->rZ && c->rB && c->rFw && !T.MBw;
+    if (!c->rXi || !c->rFw || (!c->rZ && !assemble))
+        FAIL(c, "solve_system_resident: needs resident F_wave and either Z or (constant matrices) B_drag "
+                "(raftx_solve_dynamics_device with RAFTX_WANT_FWAVE | RAFTX_WANT_Z, or RAFTX_WANT_FWAVE | RAFTX_WANT_BDRAG)");
     if (nUnit < 1 || T.nDesign % nUnit != 0 || !Xi) FAIL(c, "solve_system_resident: bad arguments (nDesign=%d, nUnit=%d)", T.nDesign, nUnit);
     HIPCHK(c, hipSetDevice(c->device));
     const int nGroup = T.nDesign / nUnit, nSys = nGroup * T.nCase, n = 6 * nUnit, nRhs = T.nHead, nw = T.nw;
@@ -2424,13 +2519,28 @@ extern "C" int raftx_solve_system_resident(raftx_ctx *c, int nUnit, const double
     if (dM) H2D(c, dM, Mc, nc * sizeof(double));
     if (dB) H2D(c, dB, Bc, nc * sizeof(double));
     if (dC) H2D(c, dC, Cc, nc * sizeof(double));
+    const cplx *Zsrc = c->rZ;
+    const bool rows = solve_system_rows_ok(nUnit, nRhs);
+    if (assemble && !rows && nSys) {                     // no register-resident solver for this shape: materialise Z once
+        const size_t nz = (size_t)T.nDesign * T.nCase * 36 * nw;
+        cplx *dZ = sc.alloc<cplx>(nz);
+        if (!dZ) FAIL(c, "solve_system_resident: device allocation failed");
+        hipLaunchKernelGGL(k_assemble_unit_z, dim3((unsigned)((nz + 255) / 256)), dim3(256), 0, c->stream, T.nDesign * T.nCase, T.nCase, nw,
+                           T.w, T.M0, T.B0, T.C0, c->rB, dZ);
+        Zsrc = dZ;
+    }
     HIPCHK(c, hipEventRecord(c->ev0, c->stream));
-    if (nSys && !launch_solve_system_rows<true>(c->stream, nSys, nUnit, nRhs, nw, T.nCase, T.w, c->rZ, dM, dB, dC, c->rFw, dX)) {
+    bool done = !nSys;
+    if (!done && rows)
+        done = assemble ? launch_solve_system_rows<true, true>(c->stream, nSys, nUnit, nRhs, nw, T.nCase, T.w, nullptr, dM, dB, dC, c->rFw, dX,
+                                                               T.M0, T.B0, T.C0, c->rB)
+                        : launch_solve_system_rows<true>(c->stream, nSys, nUnit, nRhs, nw, T.nCase, T.w, c->rZ, dM, dB, dC, c->rFw, dX);
+    if (!done) {
         if (lds > 64 * 1024)
             HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void *>(k_solve_system<true>),
                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         hipLaunchKernelGGL(k_solve_system<true>, dim3((unsigned)((size_t)nSys * ((nw + nbin - 1) / nbin))), dim3(64 * nbin), lds,
-                           c->stream, nSys, nUnit, nRhs, nw, T.nCase, T.w, c->rZ, dM, dB, dC, c->rFw, dX);
+                           c->stream, nSys, nUnit, nRhs, nw, T.nCase, T.w, Zsrc, dM, dB, dC, c->rFw, dX);
     }
     if (finish_timed(c)) return -2;
     if (nSys) D2H(c, Xi, dX, nf * sizeof(cplx));
@@ -2723,24 +2833,24 @@ static void slot_release_cases(raftx_ctx *c, SweepSlot &S) {
     S.cset = -1;
 }
 
-extern "C" int raftx_sweep_prepare(raftx_ctx *c, int slot, int nDesign, const int64_t *memberOff, const double *members,
-                                  const int64_t *stationOff, const double *stations, const int64_t *capOff,
-                                  const double *caps, const double *pose, double rho, double g, int add_mask,
-                                  const double *M0, const double *B0, const double *C0, const double *Fz_moor, int nCase,
-                                  int nHead, int nw, const double *w, const double *k, double depth, double rho_wave,
-                                  double g_wave, const double *zeta, const double *beta, int nIter, double tol,
-                                  double XiStart, int nChunk, double *sd, int32_t *niter, int32_t *flags,
-                                  raftx_c128 *Xi, int64_t *stripOffsets) {
+static int sweep_prepare_impl(raftx_ctx *c, int slot, int nDesign, const int64_t *memberOff, const double *members,
+                              const int64_t *stationOff, const double *stations, const int64_t *capOff,
+                              const double *caps, const double *pose, double rho, double g, int add_mask,
+                              const double *M0, const double *B0, const double *C0, const double *Fz_moor, int nCase,
+                              int nHead, int nw, const double *w, const double *k, double depth, double rho_wave,
+                              double g_wave, const double *zeta, const double *beta, int nIter, double tol,
+                              double XiStart, int nChunk, double *sd, int32_t *niter, int32_t *flags,
+                              raftx_c128 *Xi, int64_t *stripOffsets, const VariantSrc *var) {
     RangeScope range_("raftx_sweep_prepare: descriptor H2D + member pass (enqueue)");
     if (!c) return -1;
     if (slot < 0 || slot >= RAFTX_NSLOT) FAIL(c, "sweep_prepare: slot must be 0 .. %d", RAFTX_NSLOT - 1);
     SweepSlot &S = c->slots[slot];
     if (S.busy || S.prepared) FAIL(c, "sweep_prepare: slot %d is still in flight (call raftx_sweep_wait first)", slot);
-    if (nDesign < 0 || !memberOff || !members || !stationOff || !stations || !M0 || !B0 || !C0)
+    if (nDesign < 0 || !memberOff || (!members && !var) || !stationOff || (!stations && !var) || !M0 || !B0 || !C0)
         FAIL(c, "sweep_stats: bad design arguments");
     if (nCase < 1 || nHead < 1 || nw < 1 || !w || !k || !zeta || !beta) FAIL(c, "sweep_stats: bad sea-state arguments");
     if (!sd || !niter || !flags) FAIL(c, "sweep_stats: std, niter and flags are required");
-    if ((capOff == nullptr) != (caps == nullptr)) FAIL(c, "sweep_stats: capOff and caps must be given together");
+    if (!var && (capOff == nullptr) != (caps == nullptr)) FAIL(c, "sweep_stats: capOff and caps must be given together");
     if (nIter < 0) FAIL(c, "sweep_stats: nIter < 0");
     if (nChunk > 64) nChunk = 64;
     HIPCHK(c, hipSetDevice(c->device));
@@ -2833,7 +2943,8 @@ extern "C" int raftx_sweep_prepare(raftx_ctx *c, int slot, int nDesign, const in
     // slabs (responses wanted, nothing else in flight): there only the first two; raftx_sweep_launch enqueues the others one
     // block ahead of the block it launches.  (The ordinary streams share hardware queues: with every block's copies queued
     // first, the first slab's generation sat behind 1.7 ms of uploads -- profiles/r04_iso_timeline.txt.)
-    S.p1 = {memberOff, stationOff, capOff, members, stations, caps, pose, M0, B0, C0, Fz_moor, k, rho, g, add_mask, dOff};
+    S.p1 = {memberOff, stationOff, capOff, members, stations, caps, pose, M0, B0, C0, Fz_moor, k, rho, g, add_mask, dOff,
+            var ? *var : VariantSrc{nullptr, nullptr}};
     const size_t nFirst = (Xi && nB > 2 && !others_in_flight(c, slot)) ? 2 : nB;
     for (size_t b = 0; b < nB; b++)
         if (block_ctx(c, slot, b, &blk[b])) return fail_drain(-1);
@@ -2841,7 +2952,7 @@ extern "C" int raftx_sweep_prepare(raftx_ctx *c, int slot, int nDesign, const in
         raftx_ctx *sub = blk[b];
         const int lo = bnd[b], n = bnd[b + 1] - lo;
         const int rc = build_phase1(sub, c->sCopy, c->sPrep, lo, n, memberOff, members, stationOff, stations, capOff, caps, pose,
-                                    rho, g, nw, k, add_mask, M0, B0, C0, nullptr, Fz_moor, &S.p1.dOff, CT.k);
+                                    rho, g, nw, k, add_mask, M0, B0, C0, nullptr, Fz_moor, &S.p1.dOff, CT.k, var);
         if (rc) {
             snprintf(c->err, sizeof(c->err), "sweep_stats (block %zu): %s", b, sub->err);
             return fail_drain(rc);
@@ -2851,6 +2962,154 @@ extern "C" int raftx_sweep_prepare(raftx_ctx *c, int slot, int nDesign, const in
     S.tl[1] = since();
     S.prepared = true;
     return 0;
+}
+
+extern "C" int raftx_sweep_prepare(raftx_ctx *c, int slot, int nDesign, const int64_t *memberOff, const double *members,
+                                  const int64_t *stationOff, const double *stations, const int64_t *capOff,
+                                  const double *caps, const double *pose, double rho, double g, int add_mask,
+                                  const double *M0, const double *B0, const double *C0, const double *Fz_moor, int nCase,
+                                  int nHead, int nw, const double *w, const double *k, double depth, double rho_wave,
+                                  double g_wave, const double *zeta, const double *beta, int nIter, double tol,
+                                  double XiStart, int nChunk, double *sd, int32_t *niter, int32_t *flags,
+                                  raftx_c128 *Xi, int64_t *stripOffsets) {
+    return sweep_prepare_impl(c, slot, nDesign, memberOff, members, stationOff, stations, capOff, caps, pose, rho, g, add_mask, M0, B0,
+                              C0, Fz_moor, nCase, nHead, nw, w, k, depth, rho_wave, g_wave, zeta, beta, nIter, tol, XiStart, nChunk, sd,
+                              niter, flags, Xi, stripOffsets, nullptr);
+}
+
+// ---- parametric variants of one base unit (include/raftx.h; raft/parametersweep.py:39-87)
+extern "C" int raftx_variant_program(raftx_ctx *c, int nMember, const double *members, const int64_t *stationOff, const double *stations,
+                                     const int64_t *capOff, const double *caps, int nParam, const double *endCoef,
+                                     const int32_t *endEdit, const double *headCS, const double *diaCoef, const int32_t *diaEdit) {
+    if (!c) return -1;
+    for (int sl = 0; sl < RAFTX_NSLOT; sl++)
+        if (c->slots && (c->slots[sl].busy || c->slots[sl].prepared) && c->slots[sl].p1.var.prog)
+            FAIL(c, "variant_program: a batch of variants is still in flight (raftx_sweep_wait first)");
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    VariantProg &P = c->vprog;
+    free_list(c, P.allocs);
+    P = VariantProg();
+    if (nMember == 0) return 0;
+    if (nMember < 0 || nParam < 0 || nParam > 64 || !members || !stationOff || !stations || (capOff == nullptr) != (caps == nullptr))
+        FAIL(c, "variant_program: bad arguments");
+    if (!endEdit || !endCoef || !headCS || !diaEdit || !diaCoef) FAIL(c, "variant_program: the edit tables are required (all-zero flags = no edit)");
+    const int nM = nMember, nP = nParam;
+    if (stationOff[0] != 0 || (capOff && capOff[0] != 0)) FAIL(c, "variant_program: offsets must start at 0");
+    for (int m = 0; m < nM; m++)
+        if (stationOff[m + 1] < stationOff[m] || (capOff && capOff[m + 1] < capOff[m])) FAIL(c, "variant_program: offsets not monotone");
+    const int nSt = (int)stationOff[nM], nCap = capOff ? (int)capOff[nM] : 0;
+    std::vector<int> stM((size_t)nSt), cpM((size_t)nCap);
+    std::vector<double> stF((size_t)nSt), flF((size_t)nSt), cpF((size_t)nCap);
+    for (int m = 0; m < nM; m++) {
+        const double L = members[(size_t)m * RAFTX_GM_N + RAFTX_GM_L];
+        if (endEdit[m] && !(L > 0.0)) FAIL(c, "variant_program: member %d has no length", m);
+        for (int64_t i = stationOff[m]; i < stationOff[m + 1]; i++) {
+            stM[(size_t)i] = m;
+            stF[(size_t)i] = stations[(size_t)i * RAFTX_GS_N + RAFTX_GS_S] / L;          // fractions of the length: what the deck's
+            flF[(size_t)i] = stations[(size_t)i * RAFTX_GS_N + RAFTX_GS_LFILL] / L;      // arbitrary station units mean
+        }
+        if (capOff)
+            for (int64_t i = capOff[m]; i < capOff[m + 1]; i++) {
+                cpM[(size_t)i] = m;
+                cpF[(size_t)i] = caps[(size_t)i * RAFTX_GC_N + RAFTX_GC_S] / L;
+            }
+    }
+    P.nM = nM; P.nSt = nSt; P.nCap = nCap; P.nP = nP; P.has_caps = capOff != nullptr;
+    P.hS.assign(stationOff, stationOff + nM + 1);
+    if (capOff) P.hC.assign(capOff, capOff + nM + 1);
+    else P.hC.assign((size_t)nM + 1, 0);
+    auto up = [&](const void *h, size_t bytes, void **d) -> int {
+        *d = nullptr;
+        if (!bytes) bytes = 8, h = nullptr;
+        HIPCHK(c, hipMalloc(d, bytes));
+        P.allocs.push_back(*d);
+        if (h) HIPCHK(c, hipMemcpy(*d, h, bytes, hipMemcpyHostToDevice));
+        return 0;
+    };
+    int rc = 0;
+    rc |= up(members, (size_t)nM * RAFTX_GM_N * 8, (void **)&P.gm);
+    rc |= up(stations, (size_t)nSt * RAFTX_GS_N * 8, (void **)&P.gs);
+    rc |= up(nCap ? caps : nullptr, (size_t)nCap * RAFTX_GC_N * 8, (void **)&P.gc);
+    rc |= up(stM.data(), (size_t)nSt * 4, (void **)&P.stMember);
+    rc |= up(nCap ? cpM.data() : nullptr, (size_t)nCap * 4, (void **)&P.capMember);
+    rc |= up(stF.data(), (size_t)nSt * 8, (void **)&P.stFrac);
+    rc |= up(flF.data(), (size_t)nSt * 8, (void **)&P.fillFrac);
+    rc |= up(nCap ? cpF.data() : nullptr, (size_t)nCap * 8, (void **)&P.capFrac);
+    rc |= up(endCoef, (size_t)nM * 6 * (nP + 1) * 8, (void **)&P.endCoef);
+    rc |= up(headCS, (size_t)nM * 2 * 8, (void **)&P.headCS);
+    rc |= up(diaCoef, (size_t)nSt * 2 * (nP + 1) * 8, (void **)&P.diaCoef);
+    rc |= up(endEdit, (size_t)nM * 4, (void **)&P.endEdit);
+    rc |= up(diaEdit, (size_t)nSt * 4, (void **)&P.diaEdit);
+    if (rc) {
+        free_list(c, P.allocs);
+        P = VariantProg();
+        return rc;
+    }
+    return 0;
+}
+// uniform offsets of n variants, cached on the program
+static void variant_offsets(VariantProg &P, int n) {
+    if (P.cachedN == n) return;
+    P.memberOff.resize((size_t)n + 1);
+    P.stationOff.resize((size_t)n * P.nM + 1);
+    P.capOff.resize((size_t)n * P.nM + 1);
+    for (int d = 0; d <= n; d++) P.memberOff[(size_t)d] = (int64_t)d * P.nM;
+    for (int d = 0; d < n; d++)
+        for (int m = 0; m < P.nM; m++) {
+            P.stationOff[(size_t)d * P.nM + m] = (int64_t)d * P.nSt + P.hS[(size_t)m];
+            P.capOff[(size_t)d * P.nM + m] = (int64_t)d * P.nCap + P.hC[(size_t)m];
+        }
+    P.stationOff[(size_t)n * P.nM] = (int64_t)n * P.nSt;
+    P.capOff[(size_t)n * P.nM] = (int64_t)n * P.nCap;
+    P.cachedN = n;
+}
+extern "C" int raftx_expand_variants(raftx_ctx *c, int nDesign, const double *params, double *members, double *stations, double *caps) {
+    if (!c) return -1;
+    const VariantProg &P = c->vprog;
+    if (!P.nM) FAIL(c, "expand_variants: no program (raftx_variant_program first)");
+    if (nDesign < 0 || (!params && nDesign && P.nP) || !members || !stations) FAIL(c, "expand_variants: bad arguments");
+    if (!nDesign) return 0;
+    HIPCHK(c, hipSetDevice(c->device));
+    Scratch sc(c);
+    double *dp = sc.alloc<double>((size_t)nDesign * std::max(P.nP, 1)), *dg = sc.alloc<double>((size_t)nDesign * P.nM * RAFTX_GM_N),
+           *ds_ = sc.alloc<double>((size_t)nDesign * std::max(P.nSt, 1) * RAFTX_GS_N),
+           *dc = sc.alloc<double>((size_t)nDesign * std::max(P.nCap, 1) * RAFTX_GC_N);
+    if (!dp || !dg || !ds_ || !dc) FAIL(c, "expand_variants: device allocation failed");
+    if (P.nP) H2D(c, dp, params, (size_t)nDesign * P.nP * sizeof(double));
+    ExpandArgs E;
+    memset(&E, 0, sizeof(E));
+    E.params = dp;
+    expand_args(P, nDesign, dg, ds_, dc, E);
+    HIPCHK(c, hipEventRecord(c->ev0, c->stream));
+    launch_expand(E, c->stream);
+    if (finish_timed(c)) return -2;
+    D2H(c, members, dg, (size_t)nDesign * P.nM * RAFTX_GM_N * sizeof(double));
+    if (P.nSt) D2H(c, stations, ds_, (size_t)nDesign * P.nSt * RAFTX_GS_N * sizeof(double));
+    if (caps && P.nCap) D2H(c, caps, dc, (size_t)nDesign * P.nCap * RAFTX_GC_N * sizeof(double));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return 0;
+}
+extern "C" int raftx_sweep_prepare_variants(raftx_ctx *c, int slot, int nDesign, const double *params, const double *pose, double rho,
+                                           double g, int add_mask, const double *M0, const double *B0, const double *C0,
+                                           const double *Fz_moor, int nCase, int nHead, int nw, const double *w, const double *k,
+                                           double depth, double rho_wave, double g_wave, const double *zeta, const double *beta,
+                                           int nIter, double tol, double XiStart, int nChunk, double *sd, int32_t *niter,
+                                           int32_t *flags, raftx_c128 *Xi, int64_t *stripOffsets) {
+    if (!c) return -1;
+    VariantProg &P = c->vprog;
+    if (!P.nM) FAIL(c, "sweep_prepare_variants: no program (raftx_variant_program first)");
+    if (nDesign < 0 || (!params && nDesign && P.nP)) FAIL(c, "sweep_prepare_variants: bad arguments");
+    for (int sl = 0; sl < RAFTX_NSLOT; sl++)        // the offset arrays of batches in flight are the cached ones: one batch size at a time
+        if (sl != slot && (c->slots[sl].busy || c->slots[sl].prepared) && c->slots[sl].p1.var.prog && P.cachedN != nDesign)
+            FAIL(c, "sweep_prepare_variants: batches of variants in flight together must have the same size (%d in flight, %d asked)",
+                 P.cachedN, nDesign);
+    variant_offsets(P, nDesign);
+    const VariantSrc var{&P, params};
+    return sweep_prepare_impl(c, slot, nDesign, P.memberOff.data(), nullptr, P.stationOff.data(), nullptr,
+                              P.has_caps ? P.capOff.data() : nullptr, nullptr, pose, rho, g, add_mask, M0, B0, C0, Fz_moor, nCase, nHead,
+                              nw, w, k, depth, rho_wave, g_wave, zeta, beta, nIter, tol, XiStart, nChunk, sd, niter, flags, Xi,
+                              stripOffsets, &var);
 }
 
 extern "C" int raftx_sweep_launch(raftx_ctx *c, int slot) {
@@ -2967,7 +3226,7 @@ extern "C" int raftx_sweep_launch(raftx_ctx *c, int slot) {
             const int rc1 = build_phase1(blk[bn], c->sCopy, c->sPrep, bnd[bn], bnd[bn + 1] - bnd[bn], S.p1.memberOff, S.p1.members,
                                          S.p1.stationOff, S.p1.stations, S.p1.capOff, S.p1.caps, S.p1.pose, S.p1.rho, S.p1.g, nw, S.p1.k,
                                          S.p1.add_mask, S.p1.M0, S.p1.B0, S.p1.C0, nullptr, S.p1.Fz_moor, &S.p1.dOff,
-                                         c->csets[S.cset].T.k);
+                                         c->csets[S.cset].T.k, &S.p1.var);
             if (rc1) {
                 snprintf(sub->err, sizeof(sub->err), "%s", blk[bn]->err);
                 rc = rc1;
@@ -3297,6 +3556,11 @@ extern "C" int raftx_comm_init(raftx_ctx *c, int rank, int world, const char *id
     ncclUniqueId id;
     memcpy(&id, id128, sizeof(id));
     ncclComm_t comm = nullptr;
+    if (!c->commFlag) {                                   // the status word of comm_agree: allocated HERE so that no exchange
+        void *p = nullptr;                                // step can fail on it later, between its peers' collectives
+        HIPCHK(c, hipMalloc(&p, sizeof(int)));
+        c->commFlag = reinterpret_cast<int *>(p);
+    }
     NCCLCHK(c, R, R->CommInitRank(&comm, world, id, rank));
     c->comm = comm;
     c->comm_rank = rank;
@@ -3317,18 +3581,24 @@ static int comm_ready(raftx_ctx *c, RcclApi **R, int root) {
 // A rank that failed locally (bad argument, allocation) therefore fails the call on EVERY rank, with an error, instead of
 // leaving its peers blocked inside a send / receive it never posts.  `local_rc` 0 = ready.
 static int comm_agree(raftx_ctx *c, RcclApi *R, int local_rc) {
-    if (!c->commFlag) {
-        void *p = nullptr;
-        if (hipMalloc(&p, sizeof(int)) != hipSuccess) p = nullptr;     // no flag buffer: the peers time out in the collective below;
-        c->commFlag = reinterpret_cast<int *>(p);                      // nothing smaller than an int can fail here in practice
-        if (!p) FAIL(c, "comm: cannot allocate the status word");
-    }
+    // the status word exists since raftx_comm_init.  A local HIP failure on the way INTO the collective is folded into
+    // this rank's vote, never returned early: the AllReduce below is always posted, so the peers are not left waiting.
+    // What cannot be recovered (documented in include/raftx.h): a rank whose AllReduce itself fails, or that dies.
     int mine = local_rc ? 1 : 0, worst = 0;
-    HIPCHK(c, hipMemcpyAsync(c->commFlag, &mine, sizeof(int), hipMemcpyHostToDevice, c->stream));
+    hipError_t e = hipMemcpyAsync(c->commFlag, &mine, sizeof(int), hipMemcpyHostToDevice, c->stream);
+    if (e != hipSuccess) {                                // vote "failed" through a device-side fill instead (no host source)
+        mine = 1;
+        if (!local_rc) {
+            snprintf(c->err, sizeof(c->err), "comm: status upload failed: %s", hipGetErrorString(e));
+            local_rc = -2;
+        }
+        (void)hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(c->commFlag), 1, 1, c->stream);
+    }
     NCCLCHK(c, R, R->AllReduce(c->commFlag, c->commFlag, 1, ncclInt, ncclMax, reinterpret_cast<ncclComm_t>(c->comm), c->stream));
-    HIPCHK(c, hipMemcpyAsync(&worst, c->commFlag, sizeof(int), hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
+    e = hipMemcpyAsync(&worst, c->commFlag, sizeof(int), hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
     if (local_rc) return local_rc;                    // c->err already says why
+    if (e != hipSuccess) FAIL(c, "comm: status download failed: %s", hipGetErrorString(e));
     if (worst) FAIL(c, "comm: another rank could not take part in this exchange step (see its error)");
     return 0;
 }

@@ -121,8 +121,10 @@ class Engine:
 
     def _solve_general(self, model, case, tol, display):
         """raft_model.py:966-1302 for ONE unit with more than 6 reduced DOFs: the same fixed point with the strip
-        sweeps node by node (raftx_excitation / raftx_linearize) and the nDOF x nDOF impedance solves of every bin on
-        the device (raftx_solve_dense); the T projections between them and the convergence test are host glue."""
+        sweeps node by node, the projections with T, the nDOF x nDOF impedance solves of every bin and the convergence
+        test all on the device (raftx_flex_solve, raft_amd/csrc/raftx_flex.h); the host reduces the inertial excitation
+        once.  A unit WITHOUT wet strips (a dry structure) has no drag to linearise: its response is one batch of
+        dense solves (raftx_solve_dense), which is also what the reference's loop reduces to (B_hydro_drag = 0)."""
         fowts = model.fowtList
         if len(fowts) != 1 or getattr(model, "ms", None):
             raise UnsupportedFOWT("arrays of units with more than 6 reduced DOFs are not on the device path")
@@ -155,8 +157,24 @@ class Engine:
         F_lin = fowt.F_BEM + fowt.F_hydro_iner + fowt.Fhydro_2nd             # :1048, 1212 without the drag excitation
         if tables:
             self._upload([fowt], fowt.zeta, fowt.beta, tables=tables)         # no-op while these tables are resident
-        out = ctx.flex_solve([0, len(rows)], Tn, M_lin[None], B_lin[None], C_lin[None], F_lin[None, None], int(model.nIter), tol,
-                             model.XiStart, want_Z=True)
+            out = ctx.flex_solve([0, len(rows)], Tn, M_lin[None], B_lin[None], C_lin[None], F_lin[None, None], int(model.nIter), tol,
+                                 model.XiStart, want_Z=True)
+        else:
+            # no wet strips: B_hydro_drag = 0 and F_hydro_drag = 0 in every iteration (raft_fowt.py:1905-1936 sums nothing),
+            # so the loop of :1058-1138 solves the same systems until two successive responses agree -- the second pass
+            Xi_d, Z_d = ctx.solve_dense(model.w, M_lin, B_lin, C_lin, F_lin, want_Z=True)
+            # XiLast_k = Xi + 0.2^(k-1) (XiStart - Xi) (:1133 with a constant Xi): the count of :1052,1103 follows in closed form
+            gap = np.abs(Xi_d[0] - model.XiStart) / (np.abs(Xi_d[0]) + tol)
+            nit, ok = 0, False
+            while nit < int(model.nIter) and not ok:
+                ok = bool(np.all(gap * 0.2 ** nit < tol))
+                nit += 1
+            first_ok = ok
+            bad = not np.all(np.isfinite(Xi_d.view(float)))
+            out = {"niter": np.array([[nit]], dtype=np.int32),
+                   "flags": np.array([[2 if bad else (1 if first_ok else 0)]], dtype=np.int32),
+                   "B_drag": np.zeros([1, 1, n, n]), "F_drag": np.zeros([1, 1, nH, n, nw], dtype=complex),
+                   "Xi": Xi_d[None, None], "Z": Z_d[None, None]}
         niter = int(out["niter"][0, 0])
         if int(out["flags"][0, 0]) & 2:
             raise Exception("Nan detected in response vector Xi.")           # :1098-1099
@@ -546,6 +564,7 @@ class Engine:
                 break
         out['niter'] = niter[:, None].copy()
         out['flags'] = (out['flags'] & ~1) | conv[:, None].astype(np.int32)
+        out['XiLast'] = XiLast                                              # what the reference's loop holds at its exit (:1156)
         return out
 
     def solveDynamics(self, model, case, tol=0.01, conv_plot=0, RAO_plot=0, display=0):
@@ -637,7 +656,8 @@ class Engine:
             # and raft_model.py:1210-1211 would reuse the heading-0 matrix): there is no reference behaviour to match
             raise UnsupportedFOWT("internal slender-body QTFs (potSecOrder == 1) with more than one wave heading are not on "
                                   "the device path")
-        if any(internal_qtf):
+        array_dynamic = bool(getattr(model, "ms", None)) and getattr(model, "moorMod", 0) == 2
+        if any(internal_qtf) or array_dynamic:                              # the loop's last linearisation point is needed afterwards
             ctx.set_linearisation_point(None, keep_last=True)
         if any(_dynamic_mooring(f) for f in fowts):
             out = self._solve_stepped(model, fowts, mats, F_extra, tol, display)
@@ -697,15 +717,22 @@ class Engine:
             model.Xi[:nH] = out['Xi'][0, 0]
         else:
             n = 6 * nF
-            Cc = None
+            Mc = Bc = Cc = None
             if ms:                                                          # :1173-1182
                 if getattr(model, "moorMod", 0) in (0, 1):
                     Cc = np.asarray(ms.getCoupledStiffnessA(lines_only=True), dtype=float)[None]
-                else:
-                    raise UnsupportedFOWT("array-level moorMod==2 is not on the device path")
+                elif model.moorMod == 2:
+                    # lumped-mass dynamics of the shared lines, linearised (by MoorPy, on the host) about the motions the
+                    # units' loops ended on (:1156,1178): Z_sys += -w^2 (M + A) + i w B + C (:1181-1182) -- the Mc, Bc, Cc
+                    # of raftx_solve_system
+                    XiLast_all = out['XiLast'] if 'XiLast' in out else ctx.fetch_linearisation_point()
+                    model.updateMooringDynamicMatrices([np.array(XiLast_all[i, 0]) for i in range(nF)], f0.S[0, :])
+                    M_m, A_m, B_m, C_m = (np.asarray(a, dtype=float) for a in ms.getCoupledDynamicMatrices(lines_only=True))
+                    Mc, Bc, Cc = (M_m + A_m)[None], B_m[None], C_m[None]
+                # any other moorMod: upstream adds zeros (:1174)
             Zblk = out['Z'][:, 0][None]                                     # [1,nF,6,6,nw]
             Fw = np.transpose(out['F_wave'][:, 0], (1, 0, 2, 3)).reshape(1, nH, n, nw)
-            model.Xi[:nH] = ctx.solve_system(model.w, Zblk, Fw, Cc=Cc)[0]
+            model.Xi[:nH] = ctx.solve_system(model.w, Zblk, Fw, Mc=Mc, Bc=Bc, Cc=Cc)[0]
         for i, fowt in enumerate(fowts):                                    # :1251-1255
             fowt.Xi = model.Xi[:, i * fowt.nDOF:(i + 1) * fowt.nDOF, :]
             fowt.Xi_fullDOF = np.zeros([fowt.nWaves + 1, fowt.nFullDOF, nw], dtype=complex)

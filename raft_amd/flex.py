@@ -19,6 +19,7 @@ finite-element assembly stays upstream) or from arrays.  All units of a sweep sh
 in everything else, including their number of nodes, but not in nDOF.
 """
 import contextlib
+import weakref
 
 import numpy as np
 
@@ -35,12 +36,16 @@ def _few_blas_threads():
     """The host's share of a sweep is a handful of small products (the inertial excitation reduced with T, once).  On a
     many-core host OpenBLAS starts all its threads for each of them and they keep spinning afterwards, beside the runtime
     threads of the device library: measured on the 256-thread GPU box, calls of FlexSweep.run then take 40-70 ms every few
-    calls instead of 24 (scripts/prof_flex_batch.py).  Eight threads are plenty for 150 x 360 products."""
+    calls instead of 24 (scripts/prof_flex_batch.py).  Eight threads are plenty for 150 x 360 products.  The limit only
+    ever LOWERS the count: a user who runs with OPENBLAS_NUM_THREADS=1 keeps one thread."""
     global _BLAS
     if ThreadpoolController is None:
         return contextlib.nullcontext()
     if _BLAS is None:
         _BLAS = ThreadpoolController()
+    now = [m.get("num_threads") for m in _BLAS.info() if m.get("user_api") == "blas" and m.get("num_threads")]
+    if now and max(now) <= 8:
+        return contextlib.nullcontext()
     return _BLAS.limit(limits=8, user_api="blas")
 
 WAVE_RHO, WAVE_G = 1025.0, 9.81        # hard-wired defaults of Member.calcHydroExcitation (raft_member.py:1940)
@@ -76,6 +81,24 @@ class FlexUnit:
                    fowt.C_struc + fowt.C_hydro + fowt.C_moor + fowt.C_elast)
 
 
+class _Token:
+    """Key of one sweep's page-locked arrays in a context's store (hashable, weak-referenceable, never compared by value)."""
+    __slots__ = ("__weakref__",)
+
+
+def _drop_buffers(ctx_ref, token_id):
+    """weakref.finalize callback of a FlexSweep: give its page-locked arrays back when the sweep is garbage-collected
+    without release(ctx) (the context may already be closed, or gone)."""
+    ctx = ctx_ref()
+    if ctx is None:
+        return
+    for a in ctx.__dict__.get("_flex_bufs", {}).pop(token_id, {}).values():
+        try:
+            ctx.free_pinned(a)
+        except Exception:                                            # noqa: BLE001 -- closed context: its memory is already freed
+            pass
+
+
 class FlexSweep:
     """units: list of FlexUnit (equal nDOF); w, k [nw]; zeta [nCase,nHead,nw]; beta [nCase,nHead] (heading 0 drives the
     linearisation, raft_fowt.py:1910); settings nIter, XiStart, tol as Model.solveDynamics (raft_model.py:49-58,966)."""
@@ -95,14 +118,22 @@ class FlexSweep:
             zeta, beta = zeta[None], beta[None]
         self.zeta, self.beta = np.ascontiguousarray(zeta), np.ascontiguousarray(beta)
         self.nIter, self.XiStart, self.tol = int(nIter), float(XiStart), float(tol)
-        self._token = object()                                       # key of this sweep's page-locked arrays in a context's store
+        self._token = _Token()                                       # key of this sweep's page-locked arrays in a context's store
 
     def _pinned(self, ctx, name, shape, dtype=np.float64, fill=None):
         """A page-locked host array of this sweep on ``ctx``, kept across runs (raftx_host_alloc through ctx.pinned_empty; plain
         NumPy memory where the backend has no such thing).  Blocking calls with pageable arrays of a few MB are what the runtime
         pins and unpins behind the caller's back: on the GPU box every second or third run took 40-65 ms instead of 20 until
         the arrays were page-locked (scripts/prof_flex_batch.py)."""
-        store = self._store(ctx).setdefault(self._token, {})
+        key = id(self._token)
+        stores = self._store(ctx)
+        if key not in stores:
+            stores[key] = {}
+            try:                                                     # a sweep dropped without release(ctx) frees its arrays too
+                weakref.finalize(self._token, _drop_buffers, weakref.ref(ctx), key)
+            except TypeError:                                        # a context type without weak references: release() / close() only
+                pass
+        store = stores[key]
         a = store.get(name)
         if a is None or a.shape != tuple(shape) or a.dtype != np.dtype(dtype):
             if a is not None and hasattr(ctx, "free_pinned"):
@@ -129,7 +160,7 @@ class FlexSweep:
 
     def release(self, ctx):
         """Frees the page-locked arrays this sweep holds on ``ctx`` (ctx.close() does it too)."""
-        for a in self._store(ctx).pop(self._token, {}).values():
+        for a in self._store(ctx).pop(id(self._token), {}).values():
             try:
                 ctx.free_pinned(a)
             except (ValueError, AttributeError):
@@ -149,16 +180,15 @@ class FlexSweep:
         ctx.upload_cases(self.w, self.k, self.depth, WAVE_RHO, WAVE_G, self.zeta, self.beta)
         # stacked node rows of T per unit: T2[d] [nNode_d * 6, nDOF]
         T2 = [u.Tn.reshape(-1, n) for u in self.units]
-        # what does not change from run to run goes into page-locked arrays once
-        fresh = self._token not in self._store(ctx)
+        # the units' own matrices: page-locked arrays kept across runs, REFILLED every run (a few MB: units edited between
+        # runs, or an array reallocated after a shape change, must never leave stale rows behind)
         Tn = self._pinned(ctx, "Tn", (nN, 6, n))
         M = self._pinned(ctx, "M", (nD, n, n))
         B0 = self._pinned(ctx, "B", (nD, n, n))
         C0 = self._pinned(ctx, "C", (nD, n, n))
-        if fresh:
-            Tn[...] = np.concatenate([u.Tn for u in self.units])
-            for d, u in enumerate(self.units):
-                M[d], B0[d], C0[d] = u.M, u.B, u.C
+        np.concatenate([u.Tn for u in self.units], out=Tn)
+        for d, u in enumerate(self.units):
+            M[d], B0[d], C0[d] = u.M, u.B, u.C
         # inertial excitation of every heading, reduced: F_iner[d,c,h] = sum_u T_u^T F_u  (raft_fowt.py:1886-1888)
         Fn = ctx.excitation(out=self._pinned(ctx, "Fn", (nN, nC, nH, 6, nw), np.complex128))
         t_strip += ctx.last_kernel_ms()

@@ -398,3 +398,86 @@ def volturnus_sweep(base_design, scales, heading_adjust=0.0):
         sw.set_diameter(4 + c, np.full(nD, 12.4), pH)
         sw.set_ends(7 + c, col(ccD / 2, z0, 14.545), col(ocR - ocD / 2, z0, 14.545), heading=heads[3][c] + heading_adjust)
     return sw
+
+
+class VariantProgram:
+    """Edit program of a parametric sweep for the DEVICE (raftx_variant_program, include/raftx.h): the base unit's
+    descriptors + edits that are affine in the sweep parameters -- what ``SweepTables.set_ends`` / ``set_diameter`` do in
+    NumPy per batch (14 ms per 10 000 VolturnUS-S variants on one host thread, 66 MB over PCIe), stated once:
+
+      ends(m, A, B, heading)   end points of member m BEFORE its heading rotation [deg]: A, B [3][nParam+1] rows of
+                               coefficients (constant, then one per parameter) -- raft_member.py:41,72-77
+      diameter(m, d, d2=None)  diameter (side pair) of every station of member m: [nParam+1] coefficients each
+
+    The library evaluates value = c0 + c1*p1 + ... left to right without fused multiply-adds, takes the member length from
+    the edited ends, rotates them by the heading and keeps station / ballast / cap positions at their fraction of the
+    length -- bit for bit what ``SweepTables`` computes (tests/test_geometry.py)."""
+
+    def __init__(self, base, n_param):
+        self.base, self.n_param = base, int(n_param)
+        nM, nSt = base.n, len(base.stations)
+        self.end_coef = np.zeros((nM, 6, self.n_param + 1))
+        self.end_edit = np.zeros(nM, dtype=np.int32)
+        self.head_cs = np.tile([1.0, 0.0], (nM, 1))
+        self.dia_coef = np.zeros((nSt, 2, self.n_param + 1))
+        self.dia_edit = np.zeros(nSt, dtype=np.int32)
+
+    def ends(self, m, A, B, heading=0.0):
+        self.end_coef[m, :3] = np.asarray(A, dtype=float).reshape(3, self.n_param + 1)
+        self.end_coef[m, 3:] = np.asarray(B, dtype=float).reshape(3, self.n_param + 1)
+        self.end_edit[m] = 1
+        self.head_cs[m] = [np.cos(np.deg2rad(heading)), np.sin(np.deg2rad(heading))] if heading != 0.0 else [1.0, 0.0]
+
+    def diameter(self, m, d, d2=None):
+        rows = slice(int(self.base.station_off[m]), int(self.base.station_off[m + 1]))
+        d = np.asarray(d, dtype=float).reshape(self.n_param + 1)
+        self.dia_coef[rows, 0] = d
+        self.dia_coef[rows, 1] = d if d2 is None else np.asarray(d2, dtype=float).reshape(self.n_param + 1)
+        self.dia_edit[rows] = 1
+
+    def offsets(self, n_design):
+        """(member_off, station_off, cap_off) of n_design variants: the uniform layout the library writes."""
+        b = self.base
+        nM, nSt, nCap = b.n, len(b.stations), len(b.caps)
+        d = np.arange(n_design, dtype=np.int64)
+        so = (b.station_off[None, :-1] + d[:, None] * nSt).reshape(-1)
+        co = (b.cap_off[None, :-1] + d[:, None] * nCap).reshape(-1)
+        return (np.arange(n_design + 1, dtype=np.int64) * nM, np.concatenate([so, [n_design * nSt]]).astype(np.int64),
+                np.concatenate([co, [n_design * nCap]]).astype(np.int64))
+
+    def tables(self, expanded, n_design):
+        """DesignTables around descriptor arrays the library expanded (Context.expand_variants)."""
+        gm, gs, gc = expanded
+        mo, so, co = self.offsets(n_design)
+        return DesignTables(mo, gm, so, gs, co, gc)
+
+
+VOLTURNUS_PARAMS = ("centre-column diameter", "outer-column diameter", "draft (keel z)", "outer-column radius", "pontoon height")
+
+
+def volturnus_params(scales):
+    """Physical parameter values [nD,5] of the C3 sweep from the U[0.75,1.25] scale factors (raft/parametersweep.py:33-40)."""
+    scales = np.asarray(scales, dtype=float)
+    return np.ascontiguousarray(np.stack([10.0 * scales[:, 0], 12.5 * scales[:, 1], -20.0 * scales[:, 2], 51.75 * scales[:, 3],
+                                          7.0 * scales[:, 4]], axis=1))
+
+
+def volturnus_program(base_design, heading_adjust=0.0):
+    """The dependent-geometry edits of raft/parametersweep.py:56-87 (as ``volturnus_sweep`` applies them) as a
+    VariantProgram over the parameters (ccD, ocD, T, ocR, pH) = ``volturnus_params(scales)``."""
+    base = describe_unit(base_design, heading_adjust=heading_adjust)
+    heads = [np.atleast_1d(np.array(m.get("heading", 0.0), dtype=float)) for m in base_design["platform"]["members"]]
+    assert [len(h) for h in heads] == [1, 3, 3, 3], "not the VolturnUS-S member layout"
+    P = VariantProgram(base, 5)
+    c = lambda c0=0.0, ccD=0.0, ocD=0.0, T=0.0, ocR=0.0, pH=0.0: [c0, ccD, ocD, T, ocR, pH]
+    zero = c()
+    P.ends(0, [zero, zero, c(T=1.0)], [zero, zero, c(15.0)], heading=heads[0][0] + heading_adjust)
+    P.diameter(0, c(ccD=1.0))
+    for k in range(3):
+        P.ends(1 + k, [c(ocR=1.0), zero, c(T=1.0)], [c(ocR=1.0), zero, c(15.0)], heading=heads[1][k] + heading_adjust)
+        P.diameter(1 + k, c(ocD=1.0))
+        P.ends(4 + k, [c(ccD=0.5), zero, c(T=1.0, pH=0.5)], [c(ocD=-0.5, ocR=1.0), zero, c(T=1.0, pH=0.5)],
+               heading=heads[2][k] + heading_adjust)
+        P.diameter(4 + k, c(12.4), c(pH=1.0))
+        P.ends(7 + k, [c(ccD=0.5), zero, c(14.545)], [c(ocD=-0.5, ocR=1.0), zero, c(14.545)], heading=heads[3][k] + heading_adjust)
+    return P

@@ -183,9 +183,13 @@ class Sweep:
         """Arrays: consecutive groups of ``n_unit`` designs are the units of one farm (raft_model.py:1164-1236).
         Two launches: the per-unit fixed points, then the coupled 6N x 6N solves fed from the resident Z / F_wave.
         Returns Xi [nGroup,nCase,nHead,6*n_unit,nw] plus per-unit niter/flags."""
-        from ._abi import WANT_FWAVE, WANT_Z
+        from ._abi import WANT_FWAVE, WANT_Z, WANT_BDRAG
         self.upload(ctx)
-        ctx.solve_dynamics_device(self.nIter, self.tol, self.XiStart, want_mask=WANT_Z | WANT_FWAVE)
+        # units with constant M, B, C: the coupled solve assembles their 6 x 6 impedances itself from the matrices + the
+        # exported B_drag, so the fixed points run as the LEAN kernel with the excitation export and no Z leaves them;
+        # frequency-dependent M(w), B(w) (turbine aerodynamics, BEM) export Z from the full-featured kernel as before
+        lean = getattr(self, "MBw", None) is None
+        ctx.solve_dynamics_device(self.nIter, self.tol, self.XiStart, want_mask=(WANT_BDRAG if lean else WANT_Z) | WANT_FWAVE)
         t_units = ctx.last_kernel_ms()
         Xi = ctx.solve_system_resident(n_unit, Mc, Bc, Cc)
         r = ctx.fetch_results(want_Xi=False)
@@ -395,6 +399,11 @@ def shard_fingerprint(sweep, lo, hi):
             add(getattr(t, name, None))
         add(np.array([sub.add_mask]))
         add(sub.pose)
+        prog = getattr(sub, "program", None)
+        if prog is not None:                                         # VariantSweep: the base unit, the edit program, the parameter rows
+            for a in (prog.base.members, prog.base.stations, prog.base.caps, prog.end_coef, prog.end_edit, prog.head_cs,
+                      prog.dia_coef, prog.dia_edit, sub.params):
+                add(a)
     else:
         add(sub.off)
         add(sub.strips)
@@ -527,7 +536,10 @@ def run_flex_sharded(flex_sweep, ctx, comm=None):
     if hi > lo:
         sub = FlexSweep(flex_sweep.units[lo:hi], flex_sweep.w, flex_sweep.k, flex_sweep.depth, flex_sweep.zeta, flex_sweep.beta,
                         flex_sweep.nIter, flex_sweep.XiStart, flex_sweep.tol)
-        local = sub.run(ctx)
+        try:
+            local = sub.run(ctx)                     # copy=True: the results own their memory ...
+        finally:
+            sub.release(ctx)                         # ... so the throw-away sweep's page-locked arrays go back at once
     nC, nH, nw, nd = flex_sweep.zeta.shape[0], flex_sweep.zeta.shape[1], len(flex_sweep.w), flex_sweep.n
     empty = {"Xi": np.zeros((0, nC, nH, nd, nw), dtype=complex), "niter": np.zeros((0, nC), dtype=np.int32),
              "flags": np.zeros((0, nC), dtype=np.int32), "B_drag": np.zeros((0, nC, nd, nd))}
@@ -616,3 +628,83 @@ def run_pipelined(sweep, lib, n_chunks=8, n_workers=2, device_id=0, fetch="Xi"):
         return pipe.run(sweep, n_chunks, fetch)
     finally:
         pipe.close()
+
+
+class VariantSweep(GeometrySweep):
+    """A sweep whose designs are PARAMETRIC VARIANTS of one base unit (raft_amd/geometry.py VariantProgram;
+    raft/parametersweep.py:39-87): per candidate only its parameter values cross the bus, the member / station / cap
+    descriptors are written on the device (raftx_sweep_prepare_variants -> k_geom_expand) and everything after that is
+    the GeometrySweep path.  ``params`` [nD,nParam]; M_extra / B0 / C_extra as GeometrySweep.
+
+    ``set_params`` swaps in the next batch's candidates (same batch size: the library's slots stay configured).  The
+    crossing calls (prepare / submit / wait, run_crossing) take the device path; ``upload`` / ``solve`` / ``run`` -- the
+    resident forms the checks use -- expand the descriptors through the library once (ctx.expand_variants) and hand them
+    to raftx_build_designs, so both routes see the same rows."""
+
+    def __init__(self, program, params, M_extra, B0, C_extra, w, k, depth, zeta, beta, nIter, XiStart, tol=0.01, pose=None,
+                 add_mask=7, rho=1025.0, g=9.81):
+        self.program = program
+        self.params = np.ascontiguousarray(params, dtype=np.float64).reshape(-1, program.n_param)
+        self._tables = None
+        self._installed = None
+        super().__init__(_VariantTables(self), M_extra, B0, C_extra, w, k, depth, zeta, beta, nIter, XiStart, tol=tol, pose=pose,
+                         add_mask=add_mask, rho=rho, g=g)
+
+    @property
+    def n_design(self):
+        return self.params.shape[0]
+
+    def set_params(self, params):
+        params = np.ascontiguousarray(params, dtype=np.float64).reshape(-1, self.program.n_param)
+        if params.shape != self.params.shape:
+            raise ValueError("set_params: a batch of the same size is expected (%r, got %r)" % (self.params.shape, params.shape))
+        self.params = params
+        self._tables = None
+
+    def _install(self, ctx):
+        if self._installed is not ctx or getattr(ctx, "_vprog_owner", None) is not self.program:
+            ctx.variant_program(self.program)
+            ctx._vprog_owner = self.program
+            self._installed = ctx
+
+    def expanded_tables(self, ctx):
+        """DesignTables of the current params, expanded by the library on ``ctx`` (cached until set_params)."""
+        if self._tables is None:
+            self._install(ctx)
+            self._tables = self.program.tables(ctx.expand_variants(self.params), self.n_design)
+        return self._tables
+
+    def take(self, lo, hi):
+        sub = VariantSweep(self.program, self.params[lo:hi], self.M0[lo:hi], self.B0[lo:hi], self.C0[lo:hi], self.w, self.k, self.depth,
+                           self.zeta, self.beta, self.nIter, self.XiStart, self.tol, None if self.pose is None else self.pose[lo:hi],
+                           self.add_mask, self.rho, self.g)
+        return self._take_bem(sub, lo, hi)
+
+    def prepare_crossing(self, ctx, slot, n_chunk=0, want_Xi=False, Xi_out=None):
+        self._crossing_supported()
+        self._install(ctx)
+        return ctx.sweep_prepare_variants(slot, self.params, self.M0, self.B0, self.C0, self.w, self.k, self.depth, self.zeta, self.beta,
+                                          self.nIter, self.tol, self.XiStart, pose=self.pose, rho=self.rho, g=self.g,
+                                          add_mask=self.add_mask, n_chunk=n_chunk, want_Xi=want_Xi, Xi_out=Xi_out)
+
+    def run_crossing(self, ctx, n_chunk=0, n_worker=0, want_Xi=False, Xi_out=None, slot=0):
+        """One isolated crossing: prepare + launch + wait on ``slot``."""
+        return self.wait_crossing(ctx, self.submit_crossing(ctx, slot, n_chunk=n_chunk, want_Xi=want_Xi, Xi_out=Xi_out))
+
+    def upload(self, ctx):
+        self.tables = self.expanded_tables(ctx)
+        try:
+            super().upload(ctx)
+        finally:
+            self.tables = _VariantTables(self)
+
+
+class _VariantTables:
+    """What GeometrySweep asks its ``tables`` for when the descriptors live on the device: the batch size only."""
+
+    def __init__(self, sweep):
+        self._sweep = sweep
+
+    @property
+    def n_design(self):
+        return self._sweep.params.shape[0]

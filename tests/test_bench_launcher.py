@@ -74,3 +74,19 @@ def test_sharded_qtf_workload_through_bench_itself():
     out = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
     assert out["n_gpus"] == 2 and out["scaling"] == "strong" and out["hermitian"] is True
     assert len(out["per_rank_ms"]["qtf_kernels"]) == 2
+
+
+@pytest.mark.gpu
+def test_strong_scaling_mode_cuts_one_sweep_into_ragged_shards():
+    """--scaling strong: ONE sweep of --designs cut into N contiguous shards (1001 over 3 ranks = 334 + 334 + 333),
+    gathered with ragged counts inside the timed steps; the line says "strong", names the shards and carries every rank's
+    descriptor-expansion time."""
+    r = _bench(["--gpus", "3", "--scaling", "strong", "--designs", "1001", "--steps", "3", "--warmup", "1", "--no-cpu-baseline"],
+               RAFTX_BENCH_DEVICE="0")
+    assert r.returncode == 0, r.stderr[-2000:]
+    out = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert out["n_gpus"] == 3 and out["scaling"] == "strong"
+    assert out["config"]["shard_designs"] == [334, 334, 333] and out["config"]["total_designs"] == 1001
+    assert abs(out["value"] - 1001 * out["config"]["nw"] / (out["ms_per_step"] * 1e-3)) < 1e-6 * out["value"]
+    assert len(out["host_descriptor_ms_per_rank"]["all"]) == 3
+    assert out["parity"]["niter_mismatches_vs_reference"] == 0

@@ -90,16 +90,14 @@ def test_communicator_that_works_is_used():
         _close(out)
 
 
-@pytest.mark.parametrize("fault", ["raise", "hang"])
-def test_ranks_fall_back_together_when_one_cannot_join(fault):
-    """rank 1 fails (or never returns) in ncclCommInitRank; rank 0 is then stuck inside the collective: both must come
-    out of it within the deadline and take the SAME branch"""
+def test_ranks_fall_back_together_when_init_returns_an_error():
+    """ncclCommInitRank RETURNS an error on every rank (what RCCL does for several ranks on one GPU): with fallback="host"
+    both ranks land on the host transport, and it works"""
     bus = _Bus(2)
-    out = _two_ranks(lambda r: _Ctx(r, bus, init=fault if r == 1 else "hang"), "host")
+    out = _two_ranks(lambda r: _Ctx(r, bus, init="raise"), "host")
     try:
         for v in out.values():
             assert isinstance(v, tuple) and v[0].kind == "host-tcp" and v[1].startswith("host-tcp (RCCL unavailable"), out
-        # ... and the transport they fell back to works
         res = {}
         ts = [threading.Thread(target=lambda r=r: res.__setitem__(r, out[r][0].reduce_sum(np.array([r + 1.0])))) for r in range(2)]
         [t.start() for t in ts]
@@ -107,6 +105,25 @@ def test_ranks_fall_back_together_when_one_cannot_join(fault):
         assert res[0][0] == 3.0 and res[1] is None
     finally:
         _close(out)
+
+
+@pytest.mark.parametrize("fault", ["raise", "hang"])
+def test_a_call_that_never_returns_poisons_the_context_and_nobody_falls_back(fault):
+    """rank 1 fails (or never returns) in ncclCommInitRank; rank 0 is then stuck inside the collective.  Both come out
+    within the deadline and take the SAME branch -- and because a thread is still inside the library on the stuck
+    rank's context, that branch is an error even with fallback="host": the context is marked poisoned and never reused."""
+    bus = _Bus(2)
+    ctxs = {}
+
+    def make(r):
+        ctxs[r] = _Ctx(r, bus, init=fault if r == 1 else "hang")
+        return ctxs[r]
+    out = _two_ranks(make, "host")
+    assert all(isinstance(v, rcomm.CommTimeout.__mro__[1]) and "RCCL communicator" in str(v) for v in out.values()), out
+    assert all(isinstance(v.__cause__, rcomm.CommTimeout) for v in out.values()), out
+    assert getattr(ctxs[0], "poisoned", None) and "never returned" in ctxs[0].poisoned
+    if fault == "raise":
+        assert getattr(ctxs[1], "poisoned", None) is None        # rank 1's call returned (with an error): its context is fine
 
 
 def test_ranks_fail_together_when_fallback_is_an_error():

@@ -199,6 +199,31 @@ def test_installed_dynamic_mooring_hook(patch, nIter):
     assert rel_err(fn.Xi_fullDOF, fo.Xi_fullDOF) < 1e-10
 
 
+@pytest.mark.parametrize("unit_lines", [False, True])
+def test_installed_array_level_dynamic_mooring(patch, unit_lines):
+    """Array-level moorMod == 2 on the live farm deck (raft_model.py:1173-1182): the patched solveDynamics hands
+    Model.updateMooringDynamicMatrices the same per-unit motions as the NumPy path (:1156,1178) and adds the same
+    -w^2 (M + A) + i w B + C to the coupled system (a motion-dependent stand-in for the shared MoorPy system)."""
+    from tests.util import attach_fake_array_lines
+    settings = dict(min_freq=0.01, max_freq=0.3, nIter=6, XiStart=0.1)
+    case = rh.make_case(Hs=5.0, Tp=10.0, heading=20.0)
+    m_new, m_old = _model("designs/VolturnUS-S_farm.yaml", settings), _model("designs/VolturnUS-S_farm.yaml", settings)
+    assert len(m_new.fowtList) > 1
+    for m in (m_new, m_old):
+        if unit_lines:
+            attach_fake_lines(m)
+        attach_fake_array_lines(m)
+    Xi_new = m_new.solveDynamics(copy.deepcopy(case)).copy()
+    with patch.unpatched():
+        Xi_old = m_old.solveDynamics(copy.deepcopy(case)).copy()
+    assert m_new.ms.calls == m_old.ms.calls == 1
+    assert all(rel_err(a, b) < 1e-10 for a, b in zip(m_new.ms.seen, m_old.ms.seen))
+    assert m_new.ms.level == pytest.approx(m_old.ms.level, rel=1e-10)
+    assert group_rel_err(Xi_new[:1], Xi_old[:1]) < 1e-10
+    for fn, fo in zip(m_new.fowtList, m_old.fowtList):
+        assert rel_err(fn.Z, fo.Z) < 1e-10 and rel_err(fn.Xi_fullDOF, fo.Xi_fullDOF) < 1e-10
+
+
 def test_installed_calcHydroExcitation_full_dof_and_member_list(patch):
     """FOWT.calcHydroExcitation on live objects: F_hydro_iner_fullDOF (the per-member vectors about each member's own
     node, raft_fowt.py:1853-1857) and F_BEM_fullDOF are set as upstream sets them, and the member list means what it

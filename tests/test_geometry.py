@@ -738,3 +738,103 @@ def check_long_runs(ctx_a, ctx_b, dls):
 @pytest.mark.parametrize("dls,more_than", [(1.6, 64), (0.8, 128)])
 def test_hip_runs_longer_than_the_cap(hip_ctx, oracle_ctx, dls, more_than):
     assert check_long_runs(hip_ctx, oracle_ctx, dls) > more_than
+
+
+# ------------------------------------------------------------------ parametric variants expanded by the library
+# (raftx_variant_program / raftx_expand_variants / raftx_sweep_prepare_variants; raft/parametersweep.py:39-87)
+def _c3_variant_sweep(n, rows=0):
+    from raft_amd import geometry as G
+    from raft_amd.sweep import VariantSweep
+    base = json.loads(FX["c3_base_json"])
+    scales = np.random.default_rng(0).uniform(0.75, 1.25, size=(rows + n, 5))[rows:]
+    _, M0, B0, C0 = _c3_crossing_inputs(1)
+    rep = lambda a: np.repeat(a[:1], n, axis=0)
+    return VariantSweep(G.volturnus_program(base), G.volturnus_params(scales), rep(M0), rep(B0), rep(C0), C3["w"], C3["k"],
+                        float(C3["depth"]), np.asarray(C3["zeta"])[None], np.asarray(C3["beta"])[None], int(C3["nIter"]),
+                        float(C3["XiStart"])), scales
+
+
+def check_variant_expansion(ctx, n):
+    """The library's expansion of the C3 program == raft_amd.geometry.volturnus_sweep (NumPy, the reference's edits
+    parametersweep.py:56-87 vectorised) BIT FOR BIT: members, stations, caps and the uniform offsets."""
+    from tests.util import volturnus_sweep
+    vs, scales = _c3_variant_sweep(n)
+    D = volturnus_sweep(json.loads(FX["c3_base_json"]), scales).tables()
+    T = vs.expanded_tables(ctx)
+    for name in ("members", "stations", "caps"):
+        a, b = np.ascontiguousarray(getattr(T, name)), np.ascontiguousarray(getattr(D, name))
+        assert a.shape == b.shape and np.array_equal(a.view(np.uint64), b.view(np.uint64)), name
+    for name in ("member_off", "station_off", "cap_off"):
+        assert np.array_equal(getattr(T, name), getattr(D, name)), name
+
+
+def check_variant_crossing(ctx, n, n_chunk):
+    """A crossing fed with PARAMETERS (descriptors written by the library) == the crossing fed with the host's descriptor
+    arrays, bit for bit; streamed batches with new parameter rows per batch keep the slots configured."""
+    vs, scales = _c3_variant_sweep(n)
+    D, M0, B0, C0 = _c3_crossing_inputs(n)
+    want = ctx.sweep_stats(D, M0, B0, C0, C3["w"], C3["k"], float(C3["depth"]), np.asarray(C3["zeta"])[None], np.asarray(C3["beta"])[None],
+                           int(C3["nIter"]), 0.01, float(C3["XiStart"]), n_chunk=n_chunk, want_Xi=True)
+    got = vs.run_crossing(ctx, n_chunk=n_chunk, want_Xi=True)
+    assert np.array_equal(got["strip_off"], want["strip_off"])
+    assert np.array_equal(got["Xi"].view(np.uint64), want["Xi"].view(np.uint64))
+    assert np.array_equal(got["std"].view(np.uint64), want["std"].view(np.uint64)) and np.array_equal(got["niter"], want["niter"])
+    # a stream of batches with DISTINCT candidates: submit(i + 1) before wait(i), new parameter rows each time
+    from raft_amd import geometry as G
+    batches = [G.volturnus_params(np.random.default_rng(0).uniform(0.75, 1.25, size=((i + 1) * n, 5))[i * n:]) for i in range(4)]
+    sweeps = [_c3_variant_sweep(n, rows=i * n)[0] for i in range(4)]
+    alone = [s.run_crossing(ctx, n_chunk=n_chunk) for s in sweeps]
+    vs.set_params(batches[0])
+    h = vs.submit_crossing(ctx, 0, n_chunk=n_chunk)
+    for i in range(4):
+        h_next = None
+        if i + 1 < 4:
+            vs.set_params(batches[i + 1])                                # a new parameter array; the handle in flight keeps its own
+            h_next = vs.submit_crossing(ctx, (i + 1) % 2, n_chunk=n_chunk)
+        r = vs.wait_crossing(ctx, h)
+        assert np.array_equal(r["std"].view(np.uint64), alone[i]["std"].view(np.uint64)) and np.array_equal(r["niter"], alone[i]["niter"]), i
+        h = h_next
+    assert not np.array_equal(alone[0]["std"], alone[1]["std"])          # the batches ARE different candidates
+    # a program cannot be replaced under a batch in flight
+    vs.set_params(batches[1])
+    h = vs.submit_crossing(ctx, 0, n_chunk=n_chunk)
+    if ctx.rlib.is_device:
+        with pytest.raises(RaftxError, match="still in flight"):
+            ctx.variant_program(vs.program)
+    vs.wait_crossing(ctx, h)
+    # resident form (upload + solve) sees the same rows
+    vs.set_params(batches[0])
+    res = vs.run(ctx)
+    assert np.array_equal(res["Xi"].reshape(want["Xi"].shape).view(np.uint64), want["Xi"].view(np.uint64))
+
+
+def test_oracle_variant_program(oracle_ctx):
+    check_variant_expansion(oracle_ctx, 40)
+    check_variant_crossing(oracle_ctx, 5, 0)
+
+
+def test_variant_program_argument_errors(oracle_ctx):
+    from raft_amd import geometry as G
+    with pytest.raises(RaftxError, match="no program"):
+        oracle_ctx.variant_program(None)
+        oracle_ctx._vprog = (1, 1, 0, 5)
+        oracle_ctx.expand_variants(np.zeros((2, 5)))
+    P = G.volturnus_program(json.loads(FX["c3_base_json"]))
+    oracle_ctx.variant_program(P)
+    with pytest.raises(ValueError):
+        oracle_ctx.expand_variants(np.zeros((2, 4)))                     # wrong number of parameters
+    vs, _ = _c3_variant_sweep(3)
+    with pytest.raises(ValueError, match="same size"):
+        vs.set_params(np.zeros((4, 5)))
+
+
+@pytest.mark.gpu
+def test_hip_variant_program(hip_ctx, oracle_ctx):
+    check_variant_expansion(hip_ctx, 300)
+    check_variant_crossing(hip_ctx, 70, 0)
+    check_variant_crossing(hip_ctx, 333, 3)
+    # ... and the oracle's expansion of the same program is the same bits
+    vs, _ = _c3_variant_sweep(50)
+    a, b = vs.expanded_tables(hip_ctx), _c3_variant_sweep(50)[0].expanded_tables(oracle_ctx)
+    assert all(np.array_equal(np.ascontiguousarray(getattr(a, k)).view(np.uint64), np.ascontiguousarray(getattr(b, k)).view(np.uint64))
+               for k in ("members", "stations", "caps"))

@@ -55,6 +55,41 @@ def test_single_rank_rccl_communicator_every_entry_point(hip_ctx):
     hip_ctx.comm_destroy()
 
 
+def test_exchange_steps_with_empty_shards_and_refused_arguments(hip_ctx):
+    """What the first N-rank run can meet that the plain single-rank test does not: a rank with ZERO rows (more ranks than
+    designs), an empty reduction, and arguments the local validation refuses -- every one through the path the N-rank call
+    takes (local validation -> the ranks' status vote, comm_agree -> grouped send / receive), and the communicator must
+    stay usable after each refusal (a refused step must not leave half a group behind)."""
+    from raft_amd._abi import RaftxError, _ptr
+    hip_ctx.comm_init(0, 1, hip_ctx.comm_unique_id())
+    L = hip_ctx.rlib.lib
+    try:
+        empty = np.zeros((0, 7))
+        g = hip_ctx.comm_gather_rows(empty, [0], 0)                       # a rank without rows: nothing sent, nothing received
+        assert g.shape == (0, 7)
+        assert hip_ctx.comm_reduce_sum(np.zeros(0), 0).size == 0          # empty reduction
+        one = np.arange(3.0)
+        counts = np.array([-1], dtype=np.int64)
+        assert L.raftx_comm_gather_rows(hip_ctx._h, _ptr(one), _ptr(counts), 24, _ptr(one.copy()), 0) != 0      # negative count
+        assert b"negative count" in L.raftx_last_error(hip_ctx._h)
+        assert L.raftx_comm_gather_rows(hip_ctx._h, _ptr(one), None, 24, _ptr(one.copy()), 0) != 0               # no counts at all
+        counts = np.array([1], dtype=np.int64)
+        assert L.raftx_comm_gather_rows(hip_ctx._h, None, _ptr(counts), 24, _ptr(one.copy()), 0) != 0             # rows promised, none given
+        assert L.raftx_comm_gather_rows(hip_ctx._h, _ptr(one), _ptr(counts), 24, None, 0) != 0                    # root without a landing area
+        assert L.raftx_comm_gather_rows(hip_ctx._h, _ptr(one), _ptr(counts), 24, _ptr(one.copy()), 3) != 0       # root outside the communicator
+        with pytest.raises(RaftxError):
+            hip_ctx.comm_broadcast(np.zeros(4), 2)
+        # ... and after all of that the communicator still works
+        rows = np.arange(10.0).reshape(5, 2)
+        assert np.array_equal(hip_ctx.comm_gather_rows(rows, [5], 0), rows)
+        b = np.linspace(0, 1, 33)
+        assert np.array_equal(hip_ctx.comm_reduce_sum(b.copy(), 0), b)
+        # the sharded drivers with a rank that holds nothing: shard_bounds gives empty blocks when ranks outnumber designs
+        assert [sw.shard_bounds(2, r, 4) for r in range(4)] == [(0, 1), (1, 2), (2, 2), (2, 2)]
+    finally:
+        hip_ctx.comm_destroy()
+
+
 def test_single_rank_rccl_comm_object_drives_the_sharded_sweep(hip_ctx, oracle_ctx):
     """raft_amd.comm.RcclComm (world 1) through every driver call of raft_amd.sweep."""
     from raft_amd.comm import HostComm, RcclComm

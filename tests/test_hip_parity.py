@@ -104,6 +104,36 @@ def test_dynamic_mooring_stepped_solve(name, nIter, hip_ctx, oracle_ctx):
         assert rel_err(fg.B_hydro_drag, fc.B_hydro_drag) < TOL
 
 
+@pytest.mark.parametrize("unit_lines", [False, True])
+def test_array_level_dynamic_mooring(unit_lines, hip_ctx, oracle_ctx):
+    """Array-level moorMod == 2 (raft_model.py:1173-1182): the shared lines' M + A, B, C -- linearised on the host about
+    the motions the units' loops ended on (:1156,1178) -- enter the coupled 24-DOF solve as Mc, Bc, Cc of
+    raftx_solve_system.  Device vs oracle through the same drop-in code (the NumPy path is compared with it on live
+    objects in tests/test_dropin_live_reference.py); with unit-level dynamic lines too, the linearisation point comes from
+    the stepped loop instead of the device's export."""
+    from tests.util import attach_fake_lines, attach_fake_array_lines
+    fx, m_gpu = load_model_fixture("c4_farm.npz")
+    _, m_cpu = load_model_fixture("c4_farm.npz")
+    for m in (m_gpu, m_cpu):
+        m.nIter = 6
+        if unit_lines:
+            attach_fake_lines(m)
+        attach_fake_array_lines(m)
+    case = fx["cases"][1]
+    Xi_gpu = dropin.Engine(hip_ctx).solveDynamics(m_gpu, case_from_fixture(case)).copy()
+    Xi_cpu = dropin.Engine(oracle_ctx).solveDynamics(m_cpu, case_from_fixture(case)).copy()
+    nH = Xi_gpu.shape[0] - 1
+    assert m_gpu.ms.calls == 1 and m_cpu.ms.calls == 1
+    assert m_gpu.ms.level == pytest.approx(m_cpu.ms.level, rel=1e-10) and m_gpu.ms.level > 0
+    assert all(rel_err(a, b) < TOL for a, b in zip(m_gpu.ms.seen, m_cpu.ms.seen))
+    assert group_rel_err(Xi_gpu[:nH], Xi_cpu[:nH]) < TOL
+    # the coupling matters: without it the response is a different one
+    fx0, m0 = load_model_fixture("c4_farm.npz")
+    m0.nIter = 6
+    Xi0 = dropin.Engine(oracle_ctx).solveDynamics(m0, case_from_fixture(case)).copy()
+    assert group_rel_err(Xi_cpu[:nH], Xi0[:nH]) > 1e-3
+
+
 def _both(hip_ctx, oracle_ctx, tables, mats, cases, depth=200.0):
     M0, B0, C0, MBw = mats
     w, k, zeta, beta = cases
@@ -201,6 +231,43 @@ def test_c4_farm_as_one_batch(hip_ctx, oracle_ctx):
         assert group_rel_err(out["Xi"][0, i, :nH], Xr) < TOL
         assert group_rel_err(out["Xi"][0, i], ref["Xi"][0, i]) < TOL
         assert [int(out["niter"][u, i]) for u in range(4)] == [int(c["units"][u]["niter"]) for u in range(4)]
+
+
+@pytest.mark.parametrize("n_unit,n_head,nw", [(4, 1, 200), (2, 2, 200), (3, 3, 200), (6, 1, 200), (2, 1, 96)])
+def test_farm_path_without_Z_is_bit_identical_to_the_path_that_exports_it(hip_ctx, oracle_ctx, n_unit, n_head, nw):
+    """Sweep.run_farm on units with constant matrices: the fixed points run as the LEAN kernel (two waves per SIMD in the
+    200-bin shape) exporting only F_wave and B_drag, and the coupled solve assembles every unit's 6 x 6 impedance itself
+    (k_solve_system_rows<.., ASM>; for shapes without a register-resident solver k_assemble_unit_z + the LDS solver) --
+    the same bits as the path that exports Z from the full-featured kernel and reads it back, and the oracle's numbers."""
+    from raft_amd._abi import WANT_FWAVE, WANT_Z
+    from raft_amd.sweep import Sweep
+    rng = np.random.default_rng(77 + n_unit + n_head)
+    nG = 3
+    tables = [random_strips(rng, S, nw, 0.0) for S in rng.integers(8, 60, size=nG * n_unit)]
+    M0, B0, C0, _ = random_matrices(rng, nG * n_unit, nw, False)
+    w, k, zeta, beta = synthetic_cases(rng, 2, n_head, nw)
+    off = np.concatenate([[0], np.cumsum([len(t.strips) for t in tables])]).astype(np.int64)
+    sweep = Sweep(off, np.concatenate([t.strips for t in tables]), M0, B0, C0, w, k, 200.0, zeta, beta, 5, 0.1)
+    n = 6 * n_unit
+    Cc = rng.normal(size=(nG, n, n)) * 1e5
+    Cc = Cc + np.transpose(Cc, (0, 2, 1))
+    Bc, Mc = 1e3 * rng.normal(size=(nG, n, n)), 1e4 * rng.normal(size=(nG, n, n))
+    lean = sweep.run_farm(hip_ctx, n_unit, Cc=Cc, Mc=Mc, Bc=Bc)
+    sweep.upload(hip_ctx)
+    hip_ctx.solve_dynamics_device(sweep.nIter, sweep.tol, sweep.XiStart, want_mask=WANT_Z | WANT_FWAVE)
+    flags_full, _, _ = hip_ctx.last_solve_kernel()
+    full = hip_ctx.solve_system_resident(n_unit, Mc, Bc, Cc)
+    assert np.array_equal(lean["Xi"].view(np.uint64), full.view(np.uint64))
+    sweep.upload(hip_ctx)
+    from raft_amd._abi import WANT_BDRAG
+    hip_ctx.solve_dynamics_device(sweep.nIter, sweep.tol, sweep.XiStart, want_mask=WANT_BDRAG | WANT_FWAVE)
+    flags_lean, waves_lean, _ = hip_ctx.last_solve_kernel()
+    assert flags_full == 127
+    if nw == 200:                                       # the shape with lean specialisations: F_wave export (4), + headings (32)
+        assert flags_lean == (4 | (32 if n_head > 1 else 0)) and waves_lean == 2
+    ref = sweep.run_farm(oracle_ctx, n_unit, Cc=Cc, Mc=Mc, Bc=Bc)
+    assert np.array_equal(lean["niter"], ref["niter"])
+    assert rel_err(lean["Xi"], ref["Xi"]) < TOL
 
 
 def test_resident_system_solve_many_groups(hip_ctx, oracle_ctx):

@@ -122,3 +122,38 @@ def attach_fake_lines(model):
         f.ms = FakeLines(np.r_[f.r6[:3] + np.array([0.3, -0.2, -1.5]), 0, 0, 0], f.w)
         f.moorMod = 2
         f.updateMooringDynamicMatrices = (lambda Xi, S, ms=f.ms: ms.update(Xi, S))
+
+
+class FakeArrayLines:
+    """Stand-in for the SHARED mooring system of an array with ``moorMod == 2`` (raft_model.py:1173-1182,1305-1316):
+    dense symmetric 6N x 6N matrices whose damping depends on the motions of EVERY unit handed to
+    Model.updateMooringDynamicMatrices (a list of nFOWT [6,nw] arrays + the heading-0 spectrum)."""
+
+    def __init__(self, n_unit, w):
+        self.n, self.w = 6 * n_unit, np.asarray(w)
+        self.level, self.calls, self.seen = 0.0, 0, None
+
+    def update(self, Xi_list, S):
+        self.calls += 1
+        self.seen = [np.array(x) for x in Xi_list]
+        v = [self.w[None, :] * np.abs(np.asarray(x)[:3]) * (1.0 + 0.1 * i) for i, x in enumerate(Xi_list)]
+        self.level = float(np.sqrt(sum(np.sum(a ** 2 * (1.0 + S[None, :])) for a in v)))
+
+    def getCoupledDynamicMatrices(self, lines_only=True):
+        assert lines_only
+        sym = lambda a: 0.5 * (a + a.T)
+        rng = np.random.default_rng(11)
+        n = self.n
+        blk = np.tile([3e5, 3e5, 2e5, 1e7, 1e7, 2e7], n // 6)
+        M = sym(rng.uniform(0, 1, (n, n))) * 2e4 + np.diag(blk)
+        A = sym(rng.uniform(0, 1, (n, n))) * 1e4 + np.diag(blk / 3)
+        B = (sym(rng.uniform(0, 1, (n, n))) * 2e4 + np.diag(blk * 1.5)) * (0.2 + self.level)
+        C = sym(rng.uniform(-1, 1, (n, n))) * 2e4 + np.diag(np.tile([8e4, 8e4, 2e4, 2e8, 2e8, 1.5e8], n // 6))
+        return M, A, B, C
+
+
+def attach_fake_array_lines(model):
+    """Array-level ``moorMod == 2`` on a model (live reference Model or stand-in)."""
+    model.ms = FakeArrayLines(len(model.fowtList), model.w)
+    model.moorMod = 2
+    model.updateMooringDynamicMatrices = (lambda Xi, S, ms=model.ms: ms.update(Xi, S))
