@@ -117,6 +117,17 @@ int raftx_excitation(raftx_ctx *ctx, raftx_c128 *F_iner);
  * Either output may be NULL. */
 int raftx_linearize(raftx_ctx *ctx, const raftx_c128 *Xi, double *B_drag, raftx_c128 *F_drag);
 
+/* Per-strip by-products the reference leaves on its Member objects, for callers that read them after the drop-in ran
+ * (SURVEY.md 8b "side effects"): an un-replaced Member.calcDragExcitation (raft_member.py:2128-2152) reads mem.Bmat and
+ * mem.u; post-processing reads mem.u / ud / pDyn.  The fused kernels never materialise these (979 KB per heading at C2);
+ * these two calls evaluate them on request for ONE resident design and sea state, strips in table order:
+ *   raftx_strip_kinematics  u, ud [nHead,S,3,nw], pDyn [nHead,S,nw]   raft_member.py:1927-1937 + helpers.py:188-236
+ *   raftx_strip_drag        Bmat [S,3,3] of the linearisation about Xi [6,nw] (heading 0, raft_fowt.py:1910;
+ *                           raft_member.py:2075-2117) and F_exc_drag [S,3,nw] = Bmat u[ih] (:2122, 2146)
+ * S = strips of `design` in the resident set; any output may be NULL. */
+int raftx_strip_kinematics(raftx_ctx *ctx, int design, int icase, raftx_c128 *u, raftx_c128 *ud, raftx_c128 *pDyn);
+int raftx_strip_drag(raftx_ctx *ctx, int design, int icase, const raftx_c128 *Xi, int ih, double *Bmat, raftx_c128 *F_exc_drag);
+
 /* The fused fixed-point solve, raft_model.py:994-1155 per unit plus the
  * per-heading response of :1189-1236 for an uncoupled unit:
  *   XiLast <- XiStart; repeat <= nIter+1 times { linearise about XiLast;

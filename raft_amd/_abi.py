@@ -35,6 +35,7 @@ EXPORTS = (
     "raftx_comm_unique_id", "raftx_comm_init", "raftx_comm_destroy", "raftx_comm_broadcast", "raftx_comm_gather_rows",
     "raftx_comm_gather_xi", "raftx_comm_reduce_sum",
     "raftx_variant_program", "raftx_expand_variants", "raftx_sweep_prepare_variants",
+    "raftx_strip_kinematics", "raftx_strip_drag",
 )
 WANT_BDRAG, WANT_FWAVE, WANT_Z = 1, 2, 4
 
@@ -172,6 +173,10 @@ class RaftxLib:
         L.raftx_sweep_submit.restype = C.c_int
         L.raftx_sweep_prepare.argtypes = L.raftx_sweep_submit.argtypes
         L.raftx_sweep_prepare.restype = C.c_int
+        L.raftx_strip_kinematics.argtypes = [_vp, C.c_int, C.c_int, _vp, _vp, _vp]
+        L.raftx_strip_kinematics.restype = C.c_int
+        L.raftx_strip_drag.argtypes = [_vp, C.c_int, C.c_int, _vp, C.c_int, _vp, _vp]
+        L.raftx_strip_drag.restype = C.c_int
         L.raftx_variant_program.argtypes = [_vp, C.c_int, _vp, _vp, _vp, _vp, _vp, C.c_int, _vp, _vp, _vp, _vp, _vp]
         L.raftx_variant_program.restype = C.c_int
         L.raftx_expand_variants.argtypes = [_vp, C.c_int, _vp, _vp, _vp, _vp]
@@ -403,6 +408,29 @@ class Context:
                                                _ptr(out["Xi"]), _ptr(out["strip_off"]))
         self._check(rc, "raftx_sweep_prepare")
         return dict(slot=int(slot), inputs=inputs, out=out)
+
+    # ------------------------------------------------------------- per-strip by-products on request
+    def strip_kinematics(self, design, n_strips, icase=0):
+        """(u, ud [nHead,S,3,nw], pDyn [nHead,S,nw]) of the S = n_strips strips of resident design ``design`` under the
+        resident sea state ``icase`` (raftx_strip_kinematics): what Member.computeWaveKinematics keeps on the member."""
+        S, nH, nw = int(n_strips), self.nHead, self.nw
+        u = np.empty((nH, S, 3, nw), dtype=np.complex128)
+        ud = np.empty((nH, S, 3, nw), dtype=np.complex128)
+        p = np.empty((nH, S, nw), dtype=np.complex128)
+        self._check(self.rlib.lib.raftx_strip_kinematics(self._h, int(design), int(icase), _ptr(u), _ptr(ud), _ptr(p)),
+                    "raftx_strip_kinematics")
+        return u, ud, p
+
+    def strip_drag(self, design, n_strips, Xi, ih=0, icase=0):
+        """(Bmat [S,3,3], F_exc_drag [S,3,nw]) of the linearisation about Xi [6,nw] (raftx_strip_drag): what
+        Member.calcHydroLinearization / calcDragExcitation keep on the member."""
+        S, nw = int(n_strips), self.nw
+        Xi = _c128(Xi, (6, nw), "Xi")
+        B = np.empty((S, 3, 3))
+        F = np.empty((S, 3, nw), dtype=np.complex128)
+        self._check(self.rlib.lib.raftx_strip_drag(self._h, int(design), int(icase), _ptr(Xi), int(ih), _ptr(B), _ptr(F)),
+                    "raftx_strip_drag")
+        return B, F
 
     # ------------------------------------------------------------- parametric variants of one base unit
     def variant_program(self, prog):

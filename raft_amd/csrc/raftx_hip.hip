@@ -1695,6 +1695,60 @@ extern "C" int raftx_linearize(raftx_ctx *c, const raftx_c128 *Xi, double *B_dra
     return 0;
 }
 
+// the resident strips of one design (host copy of its offsets)
+static int strip_count(raftx_ctx *c, int design, int icase, const char *what, int *S) {
+    if (check_ready(c)) return -1;
+    const DevTables &T = c->T;
+    if (design < 0 || design >= T.nDesign || icase < 0 || icase >= T.nCase) FAIL(c, "%s: design / case outside the resident set", what);
+    HIPCHK(c, hipSetDevice(c->device));
+    int64_t o[2] = {0, 0};
+    HIPCHK(c, hipMemcpyAsync(o, T.off + design, 2 * sizeof(int64_t), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    *S = (int)(o[1] - o[0]);
+    return 0;
+}
+extern "C" int raftx_strip_kinematics(raftx_ctx *c, int design, int icase, raftx_c128 *u, raftx_c128 *ud, raftx_c128 *pDyn) {
+    if (!c) return -1;
+    int S = 0;
+    if (int rc = strip_count(c, design, icase, "strip_kinematics", &S)) return rc;
+    const DevTables &T = c->T;
+    const size_t n = (size_t)T.nHead * S * T.nw;
+    if (!n) return 0;
+    Scratch sc(c);
+    cplx *du = u ? sc.alloc<cplx>(n * 3) : nullptr, *dud = ud ? sc.alloc<cplx>(n * 3) : nullptr, *dp = pDyn ? sc.alloc<cplx>(n) : nullptr;
+    if ((u && !du) || (ud && !dud) || (pDyn && !dp)) FAIL(c, "strip_kinematics: device allocation failed");
+    HIPCHK(c, hipEventRecord(c->ev0, c->stream));
+    hipLaunchKernelGGL(k_strip_kinematics, dim3((unsigned)(S * T.nHead)), dim3(256), 0, c->stream, T, design, icase, du, dud, dp);
+    if (finish_timed(c)) return -2;
+    if (du) D2H(c, u, du, n * 3 * sizeof(cplx));
+    if (dud) D2H(c, ud, dud, n * 3 * sizeof(cplx));
+    if (dp) D2H(c, pDyn, dp, n * sizeof(cplx));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return 0;
+}
+extern "C" int raftx_strip_drag(raftx_ctx *c, int design, int icase, const raftx_c128 *Xi, int ih, double *Bmat,
+                                raftx_c128 *F_exc_drag) {
+    if (!c) return -1;
+    int S = 0;
+    if (int rc = strip_count(c, design, icase, "strip_drag", &S)) return rc;
+    const DevTables &T = c->T;
+    if (!Xi) FAIL(c, "strip_drag: Xi is NULL");
+    if (ih < 0 || ih >= T.nHead) FAIL(c, "strip_drag: heading outside the resident sea state");
+    if (!S) return 0;
+    Scratch sc(c);
+    cplx *dXi = sc.alloc<cplx>((size_t)6 * T.nw), *dF = F_exc_drag ? sc.alloc<cplx>((size_t)S * 3 * T.nw) : nullptr;
+    double *dB = Bmat ? sc.alloc<double>((size_t)S * 9) : nullptr;
+    if (!dXi || (F_exc_drag && !dF) || (Bmat && !dB)) FAIL(c, "strip_drag: device allocation failed");
+    H2D(c, dXi, Xi, (size_t)6 * T.nw * sizeof(cplx));
+    HIPCHK(c, hipEventRecord(c->ev0, c->stream));
+    hipLaunchKernelGGL(k_strip_drag, dim3((unsigned)S), dim3(256), 0, c->stream, T, design, icase, ih, dXi, dB, dF);
+    if (finish_timed(c)) return -2;
+    if (dB) D2H(c, Bmat, dB, (size_t)S * 9 * sizeof(double));
+    if (dF) D2H(c, F_exc_drag, dF, (size_t)S * 3 * T.nw * sizeof(cplx));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return 0;
+}
+
 template <typename Tp>
 static Tp *dev_alloc(raftx_ctx *c, size_t n) {
     void *p = nullptr;

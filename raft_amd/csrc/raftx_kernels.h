@@ -2418,6 +2418,126 @@ __global__ void __launch_bounds__(MAXT, MINB) k_linearize(DevTables T, const cpl
     }
 }
 
+// ------------------------------------------------------------------ per-strip by-products on request
+// What the reference keeps on its Member objects and the fused kernels never materialise: wave kinematics per strip
+// (raft_member.py:1927-1937, helpers.py:188-236) and the linearised drag matrix / local drag excitation per strip
+// (raft_member.py:2075-2123), for ONE design and sea state -- raftx_strip_kinematics / raftx_strip_drag.  One workgroup
+// per strip, lanes over the bins, every bin evaluated directly (no rotors: this is an export, 112 B per strip, heading
+// and bin of stores).
+__device__ inline void strip_wave_kin(const DevTables &T, double x, double y, double z, double cb, double sb, int ic, int ih,
+                                      int iw, cplx (&u)[3], cplx &p) {
+    const double k = T.k[iw], w = T.w[iw];
+    const double z0 = T.zeta[((size_t)ic * T.nHead + ih) * T.nw + iw];
+    double s_, c_;
+    fast_sincos(-(k * (cb * x + sb * y)), s_, c_);                          // e^{-i k xi} (helpers.py:201)
+    const bool k0 = k == 0.0;                                               // :211-214  Sh = 1, Ch = Cc = 99999
+    const double P = k0 ? 50000.0 : fast_exp(k * z), Qk = k0 ? 49999.0 : fast_exp(-(k * (z + 2.0 * T.depth)));
+    const double Qv = depth_mode(k, T.depth) == 1 ? 0.0 : Qk;              // :215-218 deep water: Sh = Ch = e^{kz}
+    const double c1 = w * z0 * T.csh[iw];
+    const double ar = c1 * c_, ai = c1 * s_, ps = P + Qv, pd = P - Qv;
+    u[0] = {cb * (ar * ps), cb * (ai * ps)};                                // :225-227
+    u[1] = {sb * (ar * ps), sb * (ai * ps)};
+    u[2] = {-(ai * pd), ar * pd};
+    const double sp = T.rho * T.g * z0 * T.cch[iw] * (P + Qk);              // :231 (the deep-water branch keeps both exponentials)
+    p = {sp * c_, sp * s_};
+}
+__global__ void __launch_bounds__(256) k_strip_kinematics(DevTables T, int d, int ic, cplx *__restrict__ u_out,
+                                                          cplx *__restrict__ ud_out, cplx *__restrict__ p_out) {
+    const int S = (int)(T.off[d + 1] - T.off[d]);
+    const int s = blockIdx.x % S, ih = blockIdx.x / S, nw = T.nw;
+    const double *rec = T.ds + ((size_t)T.off[d] + s) * DS_N;
+    const double beta = T.beta[(size_t)ic * T.nHead + ih], cb = cos(beta), sb = sin(beta);
+    const double x = rec[DS_X], y = rec[DS_X + 1], z = rec[DS_X + 2];
+    for (int iw = threadIdx.x; iw < nw; iw += blockDim.x) {
+        cplx u[3], p;
+        strip_wave_kin(T, x, y, z, cb, sb, ic, ih, iw, u, p);
+        const double w = T.w[iw];
+        const size_t o = ((size_t)ih * S + s) * 3;
+#pragma unroll
+        for (int j = 0; j < 3; j++) {
+            if (u_out) u_out[(o + j) * nw + iw] = u[j];
+            if (ud_out) ud_out[(o + j) * nw + iw] = {-(w * u[j].im), w * u[j].re};      // ud = i w u (:229)
+        }
+        if (p_out) p_out[((size_t)ih * S + s) * nw + iw] = p;
+    }
+}
+__global__ void __launch_bounds__(256) k_strip_drag(DevTables T, int d, int ic, int ih, const cplx *__restrict__ Xi,
+                                                    double *__restrict__ Bmat, cplx *__restrict__ Fexc) {
+    __shared__ double red[3][256];
+    __shared__ double Bm[9];
+    const int s = blockIdx.x, nw = T.nw, tid = threadIdx.x;
+    const size_t row = (size_t)T.off[d] + s;
+    const double *rec = T.ds + row * DS_N;
+    const bool circ = (T.dsi[row] & DSI_CIRC) != 0;
+    const double x = rec[DS_X], y = rec[DS_X + 1], z = rec[DS_X + 2];
+    const double ax = rec[DS_A], ay = rec[DS_A + 1], az = rec[DS_A + 2];
+    double n[3][3];
+#pragma unroll
+    for (int c = 0; c < 3; c++)
+#pragma unroll
+        for (int j = 0; j < 3; j++) n[c][j] = rec[DS_Q + 3 * c + j];
+    {   // sums of the squared relative-velocity components over the bins, heading 0 (raft_fowt.py:1910)
+        const double beta = T.beta[(size_t)ic * T.nHead], cb = cos(beta), sb = sin(beta);
+        double a = 0, c1 = 0, c2 = 0;
+        for (int iw = tid; iw < nw; iw += blockDim.x) {
+            cplx u[3], p;
+            strip_wave_kin(T, x, y, z, cb, sb, ic, 0, iw, u, p);
+            const double w = T.w[iw];
+            cplx X[6];
+#pragma unroll
+            for (int q = 0; q < 6; q++) X[q] = Xi[(size_t)q * nw + iw];
+            // node displacement Xi_t + theta x arm (helpers.py:178-181,396-402), velocity i w (.)
+            const cplx dr[3] = {{X[0].re + (-X[5].re * ay + X[4].re * az), X[0].im + (-X[5].im * ay + X[4].im * az)},
+                                {X[1].re + (X[5].re * ax - X[3].re * az), X[1].im + (X[5].im * ax - X[3].im * az)},
+                                {X[2].re + (-X[4].re * ax + X[3].re * ay), X[2].im + (-X[4].im * ax + X[3].im * ay)}};
+            cplx v[3];
+#pragma unroll
+            for (int j = 0; j < 3; j++) v[j] = {u[j].re + w * dr[j].im, u[j].im - w * dr[j].re};     // u - i w dr (:2075)
+            double sq[3], vv = 0;
+#pragma unroll
+            for (int c = 0; c < 3; c++) {
+                const double pr = v[0].re * n[c][0] + v[1].re * n[c][1] + v[2].re * n[c][2];
+                const double pi = v[0].im * n[c][0] + v[1].im * n[c][1] + v[2].im * n[c][2];
+                sq[c] = pr * pr + pi * pi;
+            }
+#pragma unroll
+            for (int j = 0; j < 3; j++) vv += v[j].re * v[j].re + v[j].im * v[j].im;
+            a += sq[0];
+            c1 += circ ? vv - sq[0] : sq[1];                                 // :2084-2090
+            c2 += sq[2];
+        }
+        red[0][tid] = a; red[1][tid] = c1; red[2][tid] = c2;
+        __syncthreads();
+        for (int h = 128; h > 0; h >>= 1) {
+            if (tid < h)
+#pragma unroll
+                for (int r = 0; r < 3; r++) red[r][tid] += red[r][tid + h];
+            __syncthreads();
+        }
+        if (tid < 9) {
+            const double vRq = sqrt(0.5 * red[0][0]);
+            const double vR1 = circ ? sqrt(0.5 * fmax(red[1][0], 0.0)) : sqrt(0.5 * red[1][0]);
+            const double vR2 = circ ? vR1 : sqrt(0.5 * red[2][0]);
+            const double bc[3] = {rec[DS_DQ] * vRq + rec[DS_DQ + 3] * vRq, rec[DS_DQ + 1] * vR1, rec[DS_DQ + 2] * vR2};   // :2093-2110
+            const int i = tid / 3, j = tid % 3;
+            const double m = bc[0] * n[0][i] * n[0][j] + bc[1] * n[1][i] * n[1][j] + bc[2] * n[2][i] * n[2][j];
+            Bm[tid] = m;
+            if (Bmat) Bmat[(size_t)s * 9 + tid] = m;
+        }
+        __syncthreads();
+    }
+    if (!Fexc) return;
+    const double beta = T.beta[(size_t)ic * T.nHead + ih], cb = cos(beta), sb = sin(beta);
+    for (int iw = tid; iw < nw; iw += blockDim.x) {
+        cplx u[3], p;
+        strip_wave_kin(T, x, y, z, cb, sb, ic, ih, iw, u, p);
+#pragma unroll
+        for (int a = 0; a < 3; a++)
+            Fexc[((size_t)s * 3 + a) * nw + iw] = {Bm[a * 3] * u[0].re + Bm[a * 3 + 1] * u[1].re + Bm[a * 3 + 2] * u[2].re,
+                                                   Bm[a * 3] * u[0].im + Bm[a * 3 + 1] * u[1].im + Bm[a * 3 + 2] * u[2].im};
+    }
+}
+
 struct SolveArgs {
     int nIter;          // loop bound = YAML nIter + 1 (raft_model.py:977)
     double tol, XiStart;

@@ -41,8 +41,14 @@ def _sum_rotors(A):
 class Engine:
     """Binds the host mirror to one raftx context (default: the HIP library)."""
 
-    def __init__(self, ctx=None, qtf_backend=None):
+    def __init__(self, ctx=None, qtf_backend=None, materialise_members=False):
         self._ctx = ctx
+        # materialise_members: also leave on every Member what the reference's per-member methods leave there -- u, ud,
+        # pDyn (raft_member.py:1927-1937), F_hydro_iner (:1991), Bmat and F_exc_drag (:2117,2122) -- through the library's
+        # per-strip export (raftx_strip_kinematics / raftx_strip_drag), so that un-replaced reference code that reads them
+        # (Member.calcDragExcitation, plotting, post-processing) sees current arrays.  Off by default: the arrays are
+        # ~1 MB per heading at C2 and the fused path never needs them.
+        self.materialise_members = bool(materialise_members)
         # qtf_backend(tables, Xi, beta, w2, k2, depth, rho, g, Mstruc, kay) -> qtf [nSet,nw2,nw2,6]; default: the
         # device kernels through the C-ABI (tests inject the numpy oracle to exercise the host logic on CPU)
         self._qtf_backend = qtf_backend
@@ -52,6 +58,51 @@ class Engine:
         if self._ctx is None:
             self._ctx = backend.default_context()
         return self._ctx
+
+    # ------------------------------------------------------------------ per-member side effects, on request
+    @staticmethod
+    def _scatter(table, members, arrays, heading_axis):
+        """Rows of the unit's strip table -> (member, strip) slots of per-member arrays.  arrays: list of (attribute name,
+        per-strip array with the strip axis at ``heading_axis``, trailing shape after the strip axis)."""
+        from .strips import F_MEM, F_IL
+        rows_m = np.asarray(table.strips[:, F_MEM], dtype=int)
+        rows_il = np.asarray(table.strips[:, F_IL], dtype=int)
+        for im, mem in enumerate(members):
+            sel = np.nonzero(rows_m == im)[0]
+            for name, arr, lead in arrays:
+                tgt = getattr(mem, name)
+                if len(sel):
+                    if lead:                                   # [nHead, strip, ...]
+                        tgt[:, rows_il[sel]] = arr[:, sel]
+                    else:                                      # [strip, ...]
+                        tgt[rows_il[sel]] = arr[sel]
+
+    def _materialise_kinematics(self, fowt, members, design=0):
+        """mem.u, mem.ud [nWaves,ns,3,nw], mem.pDyn [nWaves,ns,nw] of every member of ``members`` (zeros for strips above
+        the waterline, raft_member.py:1927-1937) from the device's per-strip export of resident design ``design``."""
+        table = fowt._raftx_table
+        nw, nH = fowt.nw, fowt.nWaves
+        for mem in members:
+            mem.u = np.zeros([nH, mem.ns, 3, nw], dtype=complex)
+            mem.ud = np.zeros([nH, mem.ns, 3, nw], dtype=complex)
+            mem.pDyn = np.zeros([nH, mem.ns, nw], dtype=complex)
+        if len(table.strips):
+            u, ud, p = self.ctx.strip_kinematics(design, len(table.strips))
+            self._scatter(table, members, [("u", u, True), ("ud", ud, True), ("pDyn", p, True)], 1)
+
+    def _materialise_drag(self, fowt, members, Xi, ih, design=0):
+        """mem.Bmat [ns,3,3] of the linearisation about Xi [6,nw] and mem.F_exc_drag [ns,3,nw] = Bmat u[ih]
+        (raft_member.py:2117,2122,2146) from the device's per-strip export."""
+        table = fowt._raftx_table
+        nw = fowt.nw
+        for mem in members:
+            if not hasattr(mem, "Bmat") or np.shape(mem.Bmat) != (mem.ns, 3, 3):
+                mem.Bmat = np.zeros([mem.ns, 3, 3])
+            if not hasattr(mem, "F_exc_drag") or np.shape(mem.F_exc_drag) != (mem.ns, 3, nw):
+                mem.F_exc_drag = np.zeros([mem.ns, 3, nw], dtype=complex)
+        if len(table.strips):
+            B, F = self.ctx.strip_drag(design, len(table.strips), Xi, ih=ih)
+            self._scatter(table, members, [("Bmat", B, False), ("F_exc_drag", F, False)], 0)
 
     # ------------------------------------------------------------------
     def _sea_state(self, fowt, case):
@@ -334,6 +385,12 @@ class Engine:
             F = self.ctx.excitation()[:, 0]                  # [1 + nMembers (+ 2), nWaves, 6, nw]
         else:
             F = np.zeros([1, fowt.nWaves, 6, nw], dtype=complex)
+        if self.materialise_members and members:             # what Member.calcHydroExcitation leaves on each member
+            self._materialise_kinematics(fowt, members, design=0)
+            fowt._raftx_members = members
+            for i, m in enumerate(members):
+                if per_member:
+                    m.F_hydro_iner = np.ascontiguousarray(F[1 + i])
         fowt.F_hydro_iner = np.ascontiguousarray(F[0])
         fowt.F_hydro_iner_fullDOF = np.zeros([fowt.nWaves, nFull, nw], dtype=complex)
         if per_member:
@@ -365,6 +422,9 @@ class Engine:
         fowt.B_hydro_drag = B[0, 0]
         fowt._raftx_Fdrag = F[0, 0]                         # [nWaves,6,nw]
         fowt.F_hydro_drag = F[0, 0, 0].copy()
+        if self.materialise_members and getattr(fowt, "_raftx_members", None):
+            # mem.Bmat of this linearisation and mem.F_exc_drag of heading 0 (raft_fowt.py:1910; raft_member.py:2117,2122)
+            self._materialise_drag(fowt, fowt._raftx_members, np.asarray(Xi, dtype=complex)[:6], 0)
         return fowt.B_hydro_drag
 
     def calcDragExcitation(self, fowt, ih):
@@ -372,6 +432,9 @@ class Engine:
         if not hasattr(fowt, "_raftx_Fdrag"):
             raise RuntimeError("calcHydroLinearization must be called before calcDragExcitation")
         fowt.F_hydro_drag = fowt._raftx_Fdrag[ih].copy()
+        if self.materialise_members and getattr(fowt, "_raftx_members", None) and hasattr(fowt._raftx_members[0], "Bmat"):
+            for mem in fowt._raftx_members:                  # raft_member.py:2146: F_exc_drag <- Bmat u[ih]
+                mem.F_exc_drag = np.einsum("sab,sbw->saw", mem.Bmat, mem.u[ih])
         return fowt.F_hydro_drag
 
     # ------------------------------------------------------------------ second-order loads
@@ -657,7 +720,7 @@ class Engine:
             raise UnsupportedFOWT("internal slender-body QTFs (potSecOrder == 1) with more than one wave heading are not on "
                                   "the device path")
         array_dynamic = bool(getattr(model, "ms", None)) and getattr(model, "moorMod", 0) == 2
-        if any(internal_qtf) or array_dynamic:                              # the loop's last linearisation point is needed afterwards
+        if any(internal_qtf) or array_dynamic or self.materialise_members:  # the loop's last linearisation point is needed afterwards
             ctx.set_linearisation_point(None, keep_last=True)
         if any(_dynamic_mooring(f) for f in fowts):
             out = self._solve_stepped(model, fowts, mats, F_extra, tol, display)
@@ -689,7 +752,7 @@ class Engine:
                 if any(not (internal_qtf[i] and (out['flags'][i, 0] & 1)) for i in range(nF)):
                     raise UnsupportedFOWT("mixed arrays (units with and without converged internal QTFs) are not on the device path")
                 F_extra = np.array(F_extras)[:, None]
-                ctx.set_linearisation_point(XiLast, keep_last=False)
+                ctx.set_linearisation_point(XiLast, keep_last=self.materialise_members)
                 niter1 = out['niter'].copy()
                 out = ctx.solve_dynamics(max(int(model.nIter) - 1, 0), tol=tol, XiStart=model.XiStart, F_extra=F_extra,
                                          want_Xi=True, want_B=True, want_F=True, want_Z=True)
@@ -740,6 +803,14 @@ class Engine:
                 fowt.Xi_fullDOF[ih, :, :] = fowt.T @ fowt.Xi[ih, :, :]
         model.results['response'] = {}                                      # :1300
         model._raftx_niter = out['niter'][:, 0].copy()
+        if self.materialise_members:
+            # what the reference's loop leaves on the members: kinematics of this sea state, Bmat of the LAST linearisation
+            # (about the Xi_last the loop exited with, :1063) and F_exc_drag of the last heading's calcDragExcitation (:1214)
+            XiL = out['XiLast'] if 'XiLast' in out else ctx.fetch_linearisation_point()
+            for i, fowt in enumerate(fowts):
+                fowt._raftx_members = list(fowt.memberList)
+                self._materialise_kinematics(fowt, fowt._raftx_members, design=i)
+                self._materialise_drag(fowt, fowt._raftx_members, np.asarray(XiL[i, 0]), nH - 1, design=i)
         # single-unit models: the unit's responses stay resident on the ctx, which saveTurbineOutputs reads back as
         # statistics; a farm's final responses come from the coupled solve, not from the resident per-unit ones
         self._resident = fowts[0] if nF == 1 else None
@@ -956,11 +1027,15 @@ def solveDynamics(model, case, tol=0.01, conv_plot=0, RAO_plot=0, display=0):
                                          RAO_plot=RAO_plot, display=display)
 
 
-def install(raft_module=None, outputs=False):
+def install(raft_module=None, outputs=False, materialise_members=None):
     """Monkey-patch a loaded reference package so that Model.analyzeCases & co
     run the hot path on the GPU.  Returns the originals for un-patching.
     outputs=True also routes FOWT.saveTurbineOutputs (statistics of the resident responses; rigid single units
-    without MoorPy / controller outputs -- anything else raises UnsupportedFOWT, never a silent fallback)."""
+    without MoorPy / controller outputs -- anything else raises UnsupportedFOWT, never a silent fallback).
+    materialise_members=True / False: switch the default engine's per-member side effects (mem.u, ud, pDyn,
+    F_hydro_iner, Bmat, F_exc_drag: Engine.materialise_members) on / off; None leaves the engine as it is."""
+    if materialise_members is not None:
+        _default_engine.materialise_members = bool(materialise_members)
     if raft_module is None:
         import raft as raft_module
     from raft import raft_model, raft_fowt

@@ -224,6 +224,54 @@ def test_installed_array_level_dynamic_mooring(patch, unit_lines):
         assert rel_err(fn.Z, fo.Z) < 1e-10 and rel_err(fn.Xi_fullDOF, fo.Xi_fullDOF) < 1e-10
 
 
+@pytest.mark.parametrize("deck", ["examples/VolturnUS-S_example.yaml", "tests/test_data/VolturnUS-S.yaml"])
+def test_materialised_member_side_effects(patch, deck):
+    """install(materialise_members=True): the per-member arrays the reference's methods leave behind (SURVEY.md 8b --
+    mem.u, ud, pDyn raft_member.py:1927-1937; mem.F_hydro_iner :1991; mem.Bmat, mem.F_exc_drag :2117,2122) are filled
+    from the library's per-strip export, equal to the NumPy path's, and the UN-REPLACED Member.calcDragExcitation
+    (:2128-2152) run on them after the drop-in's methods gives what the reference's own chain gives."""
+    settings = dict(min_freq=0.01, max_freq=0.3, nIter=6, XiStart=0.1)
+    case = rh.make_case(Hs=[5.0, 2.0], Tp=[11.0, 8.0], heading=[20.0, -50.0], spectrum=["JONSWAP"] * 2, gamma=[0, 0])
+    m_new, m_old = _model(deck, settings), _model(deck, settings)
+    for f in (m_new.fowtList[0], m_old.fowtList[0]):
+        f.potSecOrder = 0
+    patch.dropin.install(materialise_members=True)
+    try:
+        fn, fo = m_new.fowtList[0], m_old.fowtList[0]
+        fn.calcHydroExcitation(copy.deepcopy(case), memberList=fn.memberList)
+        with patch.unpatched():
+            fo.calcHydroExcitation(copy.deepcopy(case), memberList=fo.memberList)
+        for a, b in zip(fn.memberList, fo.memberList):
+            assert a.u.shape == b.u.shape and a.pDyn.shape == b.pDyn.shape
+            assert rel_err(a.u, b.u) < 1e-12 and rel_err(a.ud, b.ud) < 1e-12 and rel_err(a.pDyn, b.pDyn) < 1e-12
+            assert rel_err(a.F_hydro_iner, b.F_hydro_iner) < 1e-11
+        Xi = 0.05 * np.exp(1j * np.linspace(0, 2 * np.pi, 6 * fn.nw)).reshape(6, fn.nw)
+        B_new = fn.calcHydroLinearization(Xi)
+        with patch.unpatched():
+            B_old = fo.calcHydroLinearization(Xi)
+        assert rel_err(B_new, B_old) < 1e-10
+        for a, b in zip(fn.memberList, fo.memberList):
+            assert rel_err(a.Bmat, b.Bmat) < 1e-10 and rel_err(a.F_exc_drag, b.F_exc_drag) < 1e-10
+        # the reference's own Member.calcDragExcitation, un-replaced, on the members the drop-in has just written
+        for ih in (1, 0):
+            with patch.unpatched():
+                F_ref = fo.calcDragExcitation(ih)
+            assert rel_err(fn.calcDragExcitation(ih), F_ref) < 1e-10
+            got = [a.calcDragExcitation(ih) for a in fn.memberList]
+            want = [b.calcDragExcitation(ih) for b in fo.memberList]
+            assert all(rel_err(g, w_) < 1e-10 for g, w_ in zip(got, want) if np.any(w_))
+            assert all(rel_err(a.F_exc_drag, b.F_exc_drag) < 1e-10 for a, b in zip(fn.memberList, fo.memberList))
+        # ... and after a whole solveDynamics: Bmat of the last linearisation, F_exc_drag of the last heading
+        Xi_new = m_new.solveDynamics(copy.deepcopy(case)).copy()
+        with patch.unpatched():
+            Xi_old = m_old.solveDynamics(copy.deepcopy(case)).copy()
+        assert group_rel_err(Xi_new[:2], Xi_old[:2]) < 1e-10
+        for a, b in zip(fn.memberList, fo.memberList):
+            assert rel_err(a.u, b.u) < 1e-12 and rel_err(a.Bmat, b.Bmat) < 1e-9 and rel_err(a.F_exc_drag, b.F_exc_drag) < 1e-9
+    finally:
+        patch.dropin.install(materialise_members=False)
+
+
 def test_installed_calcHydroExcitation_full_dof_and_member_list(patch):
     """FOWT.calcHydroExcitation on live objects: F_hydro_iner_fullDOF (the per-member vectors about each member's own
     node, raft_fowt.py:1853-1857) and F_BEM_fullDOF are set as upstream sets them, and the member list means what it

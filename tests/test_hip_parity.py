@@ -270,6 +270,49 @@ def test_farm_path_without_Z_is_bit_identical_to_the_path_that_exports_it(hip_ct
     assert rel_err(lean["Xi"], ref["Xi"]) < TOL
 
 
+@pytest.mark.parametrize("S_list,nw,nH,mcf", [([40, 7], 200, 2, 0.0), ([53], 300, 1, 0.3), ([5, 0, 12], 48, 3, 0.0)])
+def test_strip_exports_parity(hip_ctx, oracle_ctx, S_list, nw, nH, mcf):
+    """raftx_strip_kinematics / raftx_strip_drag (what the reference keeps on its Member objects: u, ud, pDyn,
+    raft_member.py:1927-1937; Bmat, F_exc_drag, :2117,2122), device vs oracle per strip, every design and sea state of
+    the resident set; and consistent with the device's own linearisation: sum_s translate(Bmat_s) = B_drag."""
+    rng = np.random.default_rng(31 + nw)
+    tables = [random_strips(rng, S, nw, mcf) for S in S_list]
+    mats = random_matrices(rng, len(S_list), nw, False)
+    cases = synthetic_cases(rng, 2, nH, nw)
+    _both(hip_ctx, oracle_ctx, tables, mats, cases)
+    Xi = (rng.normal(size=(len(S_list), 2, 6, nw)) + 1j * rng.normal(size=(len(S_list), 2, 6, nw))) * \
+        np.array([1.0, 1.0, 1.0, 0.02, 0.02, 0.02])[None, None, :, None]
+    Bd, _ = hip_ctx.linearize(Xi)
+    for d, S in enumerate(S_list):
+        for ic in range(2):
+            g, o = hip_ctx.strip_kinematics(d, S, icase=ic), oracle_ctx.strip_kinematics(d, S, icase=ic)
+            for a, b in zip(g, o):
+                assert a.shape == b.shape
+                if S:
+                    assert rel_err(a, b) < 1e-12
+            for ih in range(nH):
+                Bg, Fg = hip_ctx.strip_drag(d, S, Xi[d, ic], ih=ih, icase=ic)
+                Bo, Fo = oracle_ctx.strip_drag(d, S, Xi[d, ic], ih=ih, icase=ic)
+                if S:
+                    assert rel_err(Bg, Bo) < 1e-11 and rel_err(Fg, Fo) < 1e-11
+            if S:                                        # translateMatrix3to6DOF summed over the strips (raft_member.py:2118)
+                from raft_amd.strips import F_AX
+                tot = np.zeros((6, 6))
+                for s in range(S):
+                    r = tables[d].strips[s, F_AX:F_AX + 3]
+                    H = np.array([[0, r[2], -r[1]], [-r[2], 0, r[0]], [r[1], -r[0], 0]])
+                    tot[:3, :3] += Bg[s]
+                    tot[:3, 3:] += Bg[s] @ H
+                    tot[3:, :3] += H.T @ Bg[s]
+                    tot[3:, 3:] += H.T @ Bg[s] @ H
+                assert rel_err(tot, Bd[d, ic]) < 1e-10
+    from raft_amd._abi import RaftxError
+    with pytest.raises(RaftxError):
+        hip_ctx.strip_kinematics(len(S_list), 1)
+    with pytest.raises(RaftxError):
+        hip_ctx.strip_drag(0, S_list[0], Xi[0, 0], ih=nH)
+
+
 def test_resident_system_solve_many_groups(hip_ctx, oracle_ctx):
     """Three arrays of two synthetic units x 3 cases x 2 headings, full coupling matrices."""
     rng = np.random.default_rng(404)
