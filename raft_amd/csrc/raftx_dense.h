@@ -235,16 +235,27 @@ __global__ void __launch_bounds__(32 * TJ) k_solve_dense_reg2(int n, int nRhs, i
                     const double kv = __hiloint2double(__double2hiint(v), (int)(((unsigned)__double2loint(v) & ~255u) | (unsigned)(255 - (ti + 32 * a))));
                     key = fmax(key, (done >> a & 1u) ? -1.0 : kv);
                 }
-#define DPP_MAX_(CTRL, ROWMASK)                                                                                          \
-                {                                                                                                       \
-                    const int lo_ = __builtin_amdgcn_update_dpp(__double2loint(key), __double2loint(key), CTRL, ROWMASK, 0xf, false); \
-                    const int hi_ = __builtin_amdgcn_update_dpp(__double2hiint(key), __double2hiint(key), CTRL, ROWMASK, 0xf, false); \
-                    key = fmax(key, __hiloint2double(hi_, lo_));                                                        \
-                }
-                DPP_MAX_(0x111, 0xf) DPP_MAX_(0x112, 0xf) DPP_MAX_(0x114, 0xf) DPP_MAX_(0x118, 0xf)     // row_shr:1,2,4,8 -> lane 15 of each row
-                DPP_MAX_(0x142, 0xa)                                                                    // row_bcast:15 into rows 1 and 3 -> lanes 31, 63
-#undef DPP_MAX_
-                if (ti == 31) psel = 255 - (__double2loint(key) & 255);
+                // the (magnitude, row) key compared in two 32-bit phases (as in k_solve_system_rows, raftx_hip.hip): v_max_f64
+                // takes no DPP operand -- seven dependent VALU instructions per reduction step -- while v_max_u32 with a
+                // zero-filling row_shr is one.  High words (+1: 0 = no candidate) first, then the low words of the lanes that
+                // tie; the two 16-lane rows of the owners' half-wave meet in scalar registers.  Same pivots, bit for bit.
+                const unsigned khi = key >= 0.0 ? (unsigned)__double2hiint(key) + 1u : 0u, klo = (unsigned)__double2loint(key);
+#define ROW_UMAX_(x)                                                                                   \
+                x = max(x, (unsigned)__builtin_amdgcn_update_dpp(0, (int)x, 0x111, 0xf, 0xf, true));   \
+                x = max(x, (unsigned)__builtin_amdgcn_update_dpp(0, (int)x, 0x112, 0xf, 0xf, true));   \
+                x = max(x, (unsigned)__builtin_amdgcn_update_dpp(0, (int)x, 0x114, 0xf, 0xf, true));   \
+                x = max(x, (unsigned)__builtin_amdgcn_update_dpp(0, (int)x, 0x118, 0xf, 0xf, true));
+                const bool upper = (kk & 1) != 0;         // tid = tj * 32 + ti: the owners (tj == kk) are one half of their wave
+                unsigned mh = khi;
+                ROW_UMAX_(mh)
+                const unsigned hmax = upper ? max((unsigned)__builtin_amdgcn_readlane((int)mh, 47), (unsigned)__builtin_amdgcn_readlane((int)mh, 63))
+                                            : max((unsigned)__builtin_amdgcn_readlane((int)mh, 15), (unsigned)__builtin_amdgcn_readlane((int)mh, 31));
+                unsigned ml = (khi != 0u && khi == hmax) ? klo : 0u;
+                ROW_UMAX_(ml)
+#undef ROW_UMAX_
+                const unsigned lmax = upper ? max((unsigned)__builtin_amdgcn_readlane((int)ml, 47), (unsigned)__builtin_amdgcn_readlane((int)ml, 63))
+                                            : max((unsigned)__builtin_amdgcn_readlane((int)ml, 15), (unsigned)__builtin_amdgcn_readlane((int)ml, 31));
+                if (ti == 31) psel = 255 - (int)(lmax & 255u);
             }
             __syncthreads();
             const int p = __builtin_amdgcn_readfirstlane(psel);   // (uniform: scalar compares below)

@@ -279,18 +279,29 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(RAFTX_S
         // across the two rows of a half, all DPP (no LDS round trips).
         double best = todo ? fabs(a[k].re) + fabs(a[k].im) : -1.0;
         if (todo && !(best >= 0.0)) best = 0.0;          // NaN: comparable, so that a pivot is always found
-        double key = todo ? __hiloint2double(__double2hiint(best), (int)(((unsigned)__double2loint(best) & ~31u) | rkey)) : -1.0;
-#define DPP_MAX_(CTRL, ROWMASK)                                                                                          \
-        {                                                                                                               \
-            const int lo_ = __builtin_amdgcn_update_dpp(__double2loint(key), __double2loint(key), CTRL, ROWMASK, 0xf, false); \
-            const int hi_ = __builtin_amdgcn_update_dpp(__double2hiint(key), __double2hiint(key), CTRL, ROWMASK, 0xf, false); \
-            key = fmax(key, __hiloint2double(hi_, lo_));                                                                \
-        }
-        DPP_MAX_(0x111, 0xf) DPP_MAX_(0x112, 0xf) DPP_MAX_(0x114, 0xf) DPP_MAX_(0x118, 0xf)     // row_shr:1,2,4,8 -> lane 15 of each row
-        DPP_MAX_(0x142, 0xa)                                                                    // row_bcast:15 into rows 1 and 3 -> lanes 31, 63
-#undef DPP_MAX_
-        const int klo0 = __builtin_amdgcn_readlane(__double2loint(key), 31), klo1 = __builtin_amdgcn_readlane(__double2loint(key), 63);
-        const int p = 31 - ((half ? klo1 : klo0) & 31);
+        // The (magnitude, row) key is compared in two 32-bit phases -- `v_max_f64` takes no DPP operand (round 4's form cost
+        // seven VALU instructions per reduction step: two copies, two DPP moves, a canonicalising max, the max), while
+        // `v_max_u32` with a zero-filling row_shr is ONE: first the high words (+1, so that 0 means "no candidate": rows
+        // that are done), then the low words -- five lowest mantissa bits replaced by the row -- of the lanes that tie on
+        // the high word.  Lexicographic (hi, lo) on non-negative doubles is the order of the doubles: the same pivots as
+        // before, bit for bit.  The two 16-lane rows of a half meet in scalar registers (readlane + s_max).
+        const unsigned khi = todo ? (unsigned)__double2hiint(best) + 1u : 0u;
+        const unsigned klo = ((unsigned)__double2loint(best) & ~31u) | rkey;
+#define ROW_UMAX_(x)                                                                                   \
+        x = max(x, (unsigned)__builtin_amdgcn_update_dpp(0, (int)x, 0x111, 0xf, 0xf, true));           \
+        x = max(x, (unsigned)__builtin_amdgcn_update_dpp(0, (int)x, 0x112, 0xf, 0xf, true));           \
+        x = max(x, (unsigned)__builtin_amdgcn_update_dpp(0, (int)x, 0x114, 0xf, 0xf, true));           \
+        x = max(x, (unsigned)__builtin_amdgcn_update_dpp(0, (int)x, 0x118, 0xf, 0xf, true));
+        unsigned mh = khi;
+        ROW_UMAX_(mh)                                    // row_shr:1,2,4,8 -> lane 15 of each 16-lane row
+        const unsigned h0 = max((unsigned)__builtin_amdgcn_readlane((int)mh, 15), (unsigned)__builtin_amdgcn_readlane((int)mh, 31));
+        const unsigned h1 = max((unsigned)__builtin_amdgcn_readlane((int)mh, 47), (unsigned)__builtin_amdgcn_readlane((int)mh, 63));
+        unsigned ml = (todo && khi == (half ? h1 : h0)) ? klo : 0u;
+        ROW_UMAX_(ml)
+#undef ROW_UMAX_
+        const unsigned l0 = max((unsigned)__builtin_amdgcn_readlane((int)ml, 15), (unsigned)__builtin_amdgcn_readlane((int)ml, 31));
+        const unsigned l1 = max((unsigned)__builtin_amdgcn_readlane((int)ml, 47), (unsigned)__builtin_amdgcn_readlane((int)ml, 63));
+        const int p = 31 - (int)((half ? l1 : l0) & 31u);
         const bool mine = todo && r == p;
         const bool upd = todo && r != p;
         if (mine) {

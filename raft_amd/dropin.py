@@ -332,30 +332,38 @@ class Engine:
                     rot.u[ih], rot.ud[ih], rot.pDyn[ih] = waves.wave_kin(fowt.zeta[ih], fowt.beta[ih], fowt.w, fowt.k, fowt.depth, rot.r3)
 
     @staticmethod
-    def _rotor_tables(fowt):
-        """[table about the PRP, table about the reduced-DOF point] of the submerged rotors' pseudo-strips, or []."""
+    def _rotor_tables(fowt, full_dof=True):
+        """Pseudo-strip tables of the unit's submerged rotors (raft_amd/strips.py pack_rotors), or []: first ONE table about
+        the reduced-DOF point with every submerged rotor in it (their forces add in the reduced vector); with
+        ``full_dof`` then one table about the PRP PER submerged rotor (each rotor's vector goes into its own node's slots of
+        the full-DOF array, raft_fowt.py:1864-1883)."""
         from .strips import pack_rotors
-        t0 = pack_rotors(fowt, with_node_arm=False)
-        return [] if t0 is None else [t0, pack_rotors(fowt, with_node_arm=True)]
+        t_red = pack_rotors(fowt, with_node_arm=True)
+        if t_red is None:
+            return []
+        out = [t_red]
+        if full_dof:
+            out += [pack_rotors(fowt, with_node_arm=False, only=ir) for ir, rot in enumerate(fowt.rotorList) if rot.r3[2] < 0]
+        return out
 
     @staticmethod
-    def _add_rotor_excitation(fowt, F_prp, F_red, F_iner, F_full=None):
+    def _add_rotor_excitation(fowt, F_tabs, F_iner, F_full=None):
         """Upstream adds the rotor force to ONE heading only -- the force loop sits behind the heading loop and uses its
-        last index (raft_fowt.py:1868-1883): reproduced.  F_prp / F_red [nWaves,6,nw]: device excitation of the two rotor
-        tables; F_full: the full-DOF array whose rotor-node slots take the PRP-referred vector."""
+        last index (raft_fowt.py:1868-1883): reproduced.  F_tabs: device excitation [nWaves,6,nw] of the tables of
+        ``_rotor_tables`` in their order (reduced first, then one per submerged rotor); F_full: the full-DOF array whose
+        rotor-node slots take each rotor's PRP-referred vector."""
         ih = fowt.nWaves - 1
-        F_iner[ih] += F_red[ih]
+        F_iner[ih] += F_tabs[0][ih]
         if F_full is not None:
-            for rot in fowt.rotorList:
-                if rot.r3[2] < 0:
-                    node = rot.nodeList[0]
-                    nd = int(getattr(node, "nDOF", 6))
-                    i0 = int(getattr(node, "id", 0)) * nd
-                    if F_full.shape[1] < i0 + 6:          # T^T F_full must stay equal to the reduced vector: never skip silently
-                        raise UnsupportedFOWT("submerged rotor on node %d: its slots %d..%d lie outside the %d full DOFs of the unit"
-                                              % (int(getattr(node, "id", 0)), i0, i0 + 5, F_full.shape[1]))
-                    # (with several submerged rotors every rotor's slots would need its own table: one is what exists)
-                    F_full[ih, i0:i0 + 6, :] += F_prp[ih]
+            wet = [rot for rot in fowt.rotorList if rot.r3[2] < 0]
+            for rot, F_prp in zip(wet, F_tabs[1:]):
+                node = rot.nodeList[0]
+                nd = int(getattr(node, "nDOF", 6))
+                i0 = int(getattr(node, "id", 0)) * nd
+                if F_full.shape[1] < i0 + 6:              # T^T F_full must stay equal to the reduced vector: never skip silently
+                    raise UnsupportedFOWT("submerged rotor on node %d: its slots %d..%d lie outside the %d full DOFs of the unit"
+                                          % (int(getattr(node, "id", 0)), i0, i0 + 5, F_full.shape[1]))
+                F_full[ih, i0:i0 + 6, :] += F_prp[ih]
 
     # ------------------------------------------------------------------
     def calcHydroExcitation(self, fowt, case, memberList=[]):
@@ -375,8 +383,6 @@ class Engine:
         per_member = []
         if members and all(i is not None for i in ids):
             per_member = [pack_fowt(fowt, [m], own_node=True) for m in members]
-        if sum(1 for rot in getattr(fowt, "rotorList", []) if rot.r3[2] < 0) > 1:
-            raise UnsupportedFOWT("more than one submerged rotor on a unit")
         self._rotor_kinematics(fowt)
         rotor_tables = self._rotor_tables(fowt)
         self._upload([fowt], fowt.zeta, fowt.beta, tables=[fowt._raftx_table] + per_member + rotor_tables)
@@ -402,7 +408,7 @@ class Engine:
             fowt.F_hydro_iner_fullDOF[:] = F[0]
         if rotor_tables:                                     # :1861-1883 (device sweep over the rotor's pseudo-strips)
             n0 = 1 + len(per_member)
-            self._add_rotor_excitation(fowt, F[n0], F[n0 + 1], fowt.F_hydro_iner, fowt.F_hydro_iner_fullDOF)
+            self._add_rotor_excitation(fowt, [F[n0 + j] for j in range(len(rotor_tables))], fowt.F_hydro_iner, fowt.F_hydro_iner_fullDOF)
         # potential-flow part: needs the unit's own table + sea state resident (one design)
         self._upload([fowt], fowt.zeta, fowt.beta)
         fowt.F_BEM, fowt.F_BEM_fullDOF = self._bem_excitation(fowt)
@@ -687,31 +693,31 @@ class Engine:
                              fowt.B_struc + B_gyro, C_lin, None])
 
         f0 = fowts[0]
-        # submerged rotors (:1861-1883): their pseudo-strip tables ride along as two more designs (benign matrices), the
-        # device evaluates their excitation with everything else and it joins the unit's excitation as part of F_extra
-        rotor_tables = []
-        if any(rot.r3[2] < 0 for f in fowts for rot in getattr(f, "rotorList", [])):
-            if nF > 1:
-                raise UnsupportedFOWT("submerged rotors in an array of units are not on the device path")
-            if sum(1 for rot in f0.rotorList if rot.r3[2] < 0) > 1:
-                raise UnsupportedFOWT("more than one submerged rotor on a unit")
-            self._rotor_kinematics(f0)
-            rotor_tables = self._rotor_tables(f0)
+        # submerged rotors (:1861-1883), any number on any unit of an array: each such unit's pseudo-strip table (all its
+        # rotors, about its reduced-DOF point) rides along as one more design (benign matrices), the device evaluates its
+        # excitation with everything else and it joins that unit's excitation as part of F_extra
+        rotor_tables, rotor_unit = [], []
+        for i, f in enumerate(fowts):
+            self._rotor_kinematics(f)
+            t = self._rotor_tables(f, full_dof=False)
+            if t:
+                rotor_tables += t
+                rotor_unit.append(i)
         if rotor_tables:
             benign = [np.zeros((6, 6)), np.zeros((6, 6)), np.eye(6), None]
-            self._upload(fowts, f0.zeta, f0.beta, mats + [benign, benign], tables=[f._raftx_table for f in fowts] + rotor_tables)
+            self._upload(fowts, f0.zeta, f0.beta, mats + [benign] * len(rotor_tables), tables=[f._raftx_table for f in fowts] + rotor_tables)
         else:
             self._upload(fowts, f0.zeta, f0.beta, mats)
         ctx = self.ctx
         self._bem_excitation_units(fowts, n_pad=len(rotor_tables))          # F_BEM(_fullDOF) of every unit (:1788-1849,1887)
         F_extras = [fowt.F_BEM + fowt.Fhydro_2nd for fowt in fowts]
         F_iner = ctx.excitation()                                            # side effect of :1002
-        F_rotor = None
-        if rotor_tables:
-            F_rotor = np.zeros_like(F_iner[0, 0])
-            self._add_rotor_excitation(f0, F_iner[nF, 0], F_iner[nF + 1, 0], F_rotor)
-            F_extras[0] = F_extras[0] + F_rotor
-            F_extras += [np.zeros_like(F_rotor), np.zeros_like(F_rotor)]
+        F_rotor = {}
+        for j, i in enumerate(rotor_unit):
+            F_rotor[i] = np.zeros_like(F_iner[0, 0])
+            self._add_rotor_excitation(fowts[i], [F_iner[nF + j, 0]], F_rotor[i])
+            F_extras[i] = F_extras[i] + F_rotor[i]
+        F_extras += [np.zeros_like(F_iner[0, 0])] * len(rotor_tables)
         F_extra = np.array(F_extras)[:, None]                               # [nF (+2),1,nH,6,nw]
         internal_qtf = [getattr(f, "potSecOrder", 0) == 1 for f in fowts]
         if any(internal_qtf) and f0.nWaves > 1:
@@ -761,7 +767,7 @@ class Engine:
             raise Exception("Nan detected in response vector Xi.")          # :1098-1099
         nH = f0.nWaves
         for i, fowt in enumerate(fowts):
-            fowt.F_hydro_iner = F_iner[i, 0] if F_rotor is None else F_iner[i, 0] + F_rotor
+            fowt.F_hydro_iner = F_iner[i, 0] if i not in F_rotor else F_iner[i, 0] + F_rotor[i]
             fowt.Z = out['Z'][i, 0]                                         # :1155
             fowt.B_hydro_drag = out['B_drag'][i, 0]
             fowt._raftx_Fdrag = out['F_wave'][i, 0] - F_iner[i, 0] - F_extras[i]
@@ -793,8 +799,8 @@ class Engine:
                     M_m, A_m, B_m, C_m = (np.asarray(a, dtype=float) for a in ms.getCoupledDynamicMatrices(lines_only=True))
                     Mc, Bc, Cc = (M_m + A_m)[None], B_m[None], C_m[None]
                 # any other moorMod: upstream adds zeros (:1174)
-            Zblk = out['Z'][:, 0][None]                                     # [1,nF,6,6,nw]
-            Fw = np.transpose(out['F_wave'][:, 0], (1, 0, 2, 3)).reshape(1, nH, n, nw)
+            Zblk = out['Z'][:nF, 0][None]                                   # [1,nF,6,6,nw] (rotor pseudo-designs, if any, follow the units)
+            Fw = np.transpose(out['F_wave'][:nF, 0], (1, 0, 2, 3)).reshape(1, nH, n, nw)
             model.Xi[:nH] = ctx.solve_system(model.w, Zblk, Fw, Mc=Mc, Bc=Bc, Cc=Cc)[0]
         for i, fowt in enumerate(fowts):                                    # :1251-1255
             fowt.Xi = model.Xi[:, i * fowt.nDOF:(i + 1) * fowt.nDOF, :]

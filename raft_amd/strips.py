@@ -331,7 +331,7 @@ def _sym_couple_basis():
 _COUPLE_PINV, _SYM_IDX = _sym_couple_basis()
 
 
-def pack_rotors(fowt, with_node_arm):
+def pack_rotors(fowt, with_node_arm, only=None):
     """Pseudo-strips that make the device's inertial-excitation sweep produce the force of every SUBMERGED rotor
     (raft_fowt.py:1861-1883):  f3 = I3 ud,  f6 = [f3 ; a x f3 + M3 ud]  with I_hydro = rotateMatrix6(rot.I_hydro, rot.R_q),
     I3 = I_hydro[:3,:3], M3 = I_hydro[3:,:3], ud the wave acceleration at the hub and a = rot.r3 - r6[:3].
@@ -340,11 +340,12 @@ def pack_rotors(fowt, with_node_arm):
     norm) and every term is a couple -- two strips at the hub (same kinematics) with arms a +- e_k / 2 and inertia
     +-S_k: no net force, moment e_k x (S_k ud).  with_node_arm: add the arm of the rotor's node to the reduced-DOF point
     (what T^T applied to the rotor node's slots of the full-DOF vector adds, :1886-1888); without it the table gives the
-    vector about the PRP that goes into those slots.  Returns a StripTable, or None if no rotor is submerged."""
+    vector about the PRP that goes into those slots.  only: index into rotorList of the ONE rotor to pack (default: all
+    submerged rotors in one table -- their forces add).  Returns a StripTable, or None if no rotor is submerged."""
     rows = []
-    for rot in getattr(fowt, "rotorList", []):
+    for ir, rot in enumerate(getattr(fowt, "rotorList", [])):
         r3 = np.asarray(rot.r3, dtype=float)
-        if not r3[2] < 0:
+        if not r3[2] < 0 or (only is not None and ir != only):
             continue
         R = np.asarray(rot.R_q, dtype=float)
         I6 = np.asarray(rot.I_hydro, dtype=float)

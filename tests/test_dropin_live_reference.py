@@ -391,6 +391,46 @@ def _sink_rotor(m):
         rot.I_hydro = I6
 
 
+def _second_sunk_rotor(m):
+    """a second submerged rotor on every unit: a copy of the first one somewhere else, with another inertia matrix"""
+    for f in m.fowtList:
+        rot = copy.copy(f.rotorList[0])
+        rot.r3 = np.array([f.x_ref - 6.0, f.y_ref + 5.0, -11.0])
+        rot.I_hydro = 0.7 * np.asarray(f.rotorList[0].I_hydro).copy()
+        rot.I_hydro[:3, :3] += np.diag([3e5, 1e5, 2e5])
+        f.rotorList.append(rot)
+
+
+@pytest.mark.parametrize("deck,two", [("designs/VolturnUS-S.yaml", True), ("designs/VolturnUS-S_farm.yaml", False),
+                                      ("designs/VolturnUS-S_farm.yaml", True)])
+def test_several_submerged_rotors_and_arrays(patch, deck, two):
+    """raft_fowt.py:1861-1883 for more than one submerged rotor on a unit (each rotor's PRP-referred vector into its own
+    node's slots of the full-DOF array, their sum in the reduced vector) and for the units of an array (one rotor table per
+    unit beside the unit tables): FOWT.calcHydroExcitation and Model.solveDynamics against the NumPy path."""
+    settings = dict(min_freq=0.01, max_freq=0.3, nIter=6, XiStart=0.1)
+    case = rh.make_case(Hs=[4.0, 2.0], Tp=[10.0, 8.0], heading=[10.0, 55.0], spectrum=["JONSWAP"] * 2, gamma=[0, 0])
+    m_new, m_old = _model(deck, settings), _model(deck, settings)
+    for m in (m_new, m_old):
+        _sink_rotor(m)
+        if two:
+            _second_sunk_rotor(m)
+        if len(m.fowtList) > 1:                               # an array: the last unit keeps its rotor in the air
+            for rot in m.fowtList[-1].rotorList:
+                rot.r3 = np.array([rot.r3[0], rot.r3[1], 150.0])
+    for fn, fo in zip(m_new.fowtList, m_old.fowtList):
+        fn.calcHydroExcitation(copy.deepcopy(case), memberList=fn.memberList)
+        with patch.unpatched():
+            fo.calcHydroExcitation(copy.deepcopy(case), memberList=fo.memberList)
+        assert rel_err(fn.F_hydro_iner, fo.F_hydro_iner) < 1e-10
+        assert rel_err(fn.F_hydro_iner_fullDOF, fo.F_hydro_iner_fullDOF) < 1e-10
+    Xi_new = m_new.solveDynamics(copy.deepcopy(case)).copy()
+    with patch.unpatched():
+        Xi_old = m_old.solveDynamics(copy.deepcopy(case)).copy()
+    assert Xi_new.shape == Xi_old.shape and group_rel_err(Xi_new[:2], Xi_old[:2]) < 1e-10
+    for fn, fo in zip(m_new.fowtList, m_old.fowtList):
+        assert rel_err(fn.F_hydro_iner, fo.F_hydro_iner) < 1e-10 and rel_err(fn.B_hydro_drag, fo.B_hydro_drag) < 1e-9
+
+
 @pytest.mark.parametrize("headings", [[15.0], [0.0, 40.0]])
 def test_submerged_rotor_excitation_and_solve_match_the_reference(patch, headings):
     """FOWT.calcHydroExcitation and Model.solveDynamics with a submerged rotor: the device path evaluates the rotor's
