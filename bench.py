@@ -621,7 +621,7 @@ def main():
                                                       "(the gap between fused kernels shrinks 0.35 -> 0.2 ms, the kernels sharing the drain slow each "
                                                       "other by as much), so it is not the default")
     ap.add_argument("--no-extra-legs", action="store_true", help="skip the legs outside the headline (xi-out, featured sweeps)")
-    ap.add_argument("--legs", default="xi,featured,configs", help="which legs outside the headline run (comma list of xi, featured, configs)")
+    ap.add_argument("--legs", default="xi,featured,configs,hostdesc", help="which legs outside the headline run (comma list of xi, featured, configs, hostdesc)")
     ap.add_argument("--profile", action="store_true", help="for runs under rocprofv3: whole-batch launches only (--chunks 1), no isolated / "
                                                             "extra / oracle legs -- ONE population of k_solve_dynamics launches in the trace")
     args = ap.parse_args()
@@ -762,8 +762,12 @@ def main():
     if stream_steps:
         # untimed priming, before the W warm-up steps: the first crossing of a stream is cut into two blocks, the following
         # ones are single blocks, and each slot's block contexts allocate their device buffers the first time they meet a
-        # configuration -- three streamed steps bring both slots to the steady-state one (seven the three of --depth 3)
-        run_steps(3 if args.depth == 2 else 2 * args.depth + 1)
+        # configuration -- three streamed steps bring both slots to the steady-state one (seven the three of --depth 3).
+        # And the chip's clocks: a kernel trace of this loop (profiles/r05_final/kernel_stats.csv, gpurun_out/r05_final) shows
+        # the first fused launches of a process at 3.2, 3.1, 3.06, 3.03, 2.99, 2.92, 2.87, 2.85 ms before they settle at
+        # 2.76-2.80 -- ~9 launches of power-management ramp that a long sweep sees once.  Twelve priming steps (36 ms) put the
+        # W warm-up steps and the K timed ones behind it, whatever W the caller chose.
+        run_steps(max(12, 2 * args.depth + 1))
     run_steps(args.warmup)
     # N > 1: the single-rank yardstick of THIS invocation -- rank 0 alone runs the same K steps (no exchange step) while the
     # other ranks wait at the barrier, so that the N-rank value can be set against N x one rank on the same box and build
@@ -939,6 +943,47 @@ def main():
         return f_
     if rank == 0 and world == 1 and not args.no_extra_legs and not args.xi_out and "featured" in args.legs:
         featured = guarded("featured_sweeps", run_featured)
+    # ---- the rounds-1-4 form of the step on the same box, for comparison: ONE batch expanded by NumPy outside the step and its
+    # 66 MB of descriptors re-uploaded (DMA) every step -- no device-side expansion, but a host that can feed only 1 / 14 ms
+    hostdesc = None
+
+    def run_hostdesc():
+        sw_h, _, geo_h = make_sweep(ctx, args.designs, rank, pinned=True, rows=shard[rank], variants=False)
+
+        def steps(n):
+            out_ = []
+            h_ = sw_h.submit_crossing(ctx, 0, n_chunk=args.chunks) if n > 0 else None
+            for i in range(n):
+                hn = sw_h.submit_crossing(ctx, (i + 1) % 2, n_chunk=args.chunks) if i + 1 < n else None
+                out_.append(sw_h.wait_crossing(ctx, h_))
+                h_ = hn
+            return out_
+        steps(3)
+        steps(args.warmup)
+        ctx.synchronize()
+        t1 = time.perf_counter()
+        rs = steps(args.steps)
+        ctx.synchronize()
+        dt_ = (time.perf_counter() - t1) / args.steps
+        k_ = float(np.mean([x["timing_ms"][2] for x in rs]))
+        fl_ = float(np.mean([algorithmic_flops(x["strip_off"], nw, x["niter"]) for x in rs]))
+        assert np.array_equal(rs[-1]["std"].view(np.uint64), chk["std"].view(np.uint64)), "host-made and device-made descriptors give different statistics"
+        for name in ("members", "stations", "caps", "member_off", "station_off", "cap_off"):
+            a = getattr(sw_h.tables, name, None)
+            if a is not None and a.size:
+                try:
+                    ctx.free_pinned(a)
+                except ValueError:
+                    pass
+        return {"ms_per_step": 1e3 * dt_, "value": nD * nw / dt_, "kernel_ms_per_step": k_,
+                "roofline_frac": fl_ / (k_ * 1e-3) / 1e12 / FP64_VALU_PEAK_TF, "host_descriptor_ms_per_batch": geo_h["host_descriptor_ms"],
+                "descriptor_bytes_per_step": geo_h["descriptor_bytes"], "statistics_bit_identical_to_device_made_descriptors": True,
+                "note": "the step of rounds 1-4 on this box: the STANDARD batch's descriptors, expanded once by NumPy outside the step, "
+                        "uploaded by DMA in every step (same candidates every step); the headline's step writes them on the device "
+                        "for NEW candidates every step -- ~0.09 ms of stores that land inside the running fused kernel"}
+    if variants and rank == 0 and world == 1 and not args.no_extra_legs and not args.xi_out and "hostdesc" in args.legs:
+        hostdesc = guarded("host_descriptors_same_box", run_hostdesc)
+
     # ---- BASELINE configs[1], [3], [4] at their specified sizes, each against its live-reference golden (N = 1)
     cfg_legs = {}
     if rank == 0 and world == 1 and not args.no_extra_legs and "configs" in args.legs:
@@ -1030,6 +1075,8 @@ def main():
         out["xi_out"] = xi_leg
     if featured is not None:
         out["featured_sweeps"] = featured
+    if hostdesc is not None:
+        out["host_descriptors_same_box"] = hostdesc
     out.update(cfg_legs)
     # ---- the CPU baseline (rank 0, N = 1): the UNMODIFIED reference on this host's cores when this host has it (build
     # container: /root/reference; GPU box: oracle/_ref/raft_reference.zip), the vectorised C port beside it

@@ -752,6 +752,8 @@ struct raftx_ctx {
     hipStream_t sCopy, sPrep, sD2H, sGen; // internal streams of raftx_sweep_stats (created on first use)
     hipStream_t sSlab[2] = {nullptr, nullptr}; // with sGen: the streams the slabs of a crossing with responses out go to (SlabPlan)
     hipStream_t sD2Hlow = nullptr;        // bulk download of the responses: a stream of its own priority class, created when first needed
+    hipStream_t sExp = nullptr;           // k_geom_expand of a block (variants): a HIGH-priority stream of its own, created when first needed
+    hipEvent_t evExp = nullptr;
     CaseSet csets[RAFTX_NSLOT + 1];      // sea-state tables of the sweep crossings: one per crossing in flight + one being replaced
     unsigned long long cset_clock = 0;
     char err[512];
@@ -996,7 +998,8 @@ extern "C" void raftx_ctx_destroy(raftx_ctx *c) {
                          c->evMem, c->evRed})
         (void)hipEventDestroy(e);
     if (c->sAux) (void)hipStreamDestroy(c->sAux);
-    for (hipStream_t st : {c->sCopy, c->sPrep, c->sD2H, c->sGen, c->sD2Hlow, c->sSlab[0], c->sSlab[1]})
+    if (c->evExp) (void)hipEventDestroy(c->evExp);
+    for (hipStream_t st : {c->sCopy, c->sPrep, c->sD2H, c->sGen, c->sD2Hlow, c->sSlab[0], c->sSlab[1], c->sExp})
         if (st) (void)hipStreamDestroy(st);
     if (c->owns_stream) (void)hipStreamDestroy(c->stream);
     delete c;
@@ -1235,7 +1238,32 @@ static int build_phase1(raftx_ctx *c, hipStream_t sCopy, hipStream_t sPrep, int 
     A.C0 = J.C0d;
     HIPCHK(c, hipEventRecord(c->evUp, sCopy));
     HIPCHK(c, hipStreamWaitEvent(sPrep, c->evUp, 0));
-    if (var && nDesign > 0) launch_expand(E, sPrep);
+    if (var && nDesign > 0) {
+        // The expansion is 0.09 ms of chip time.  On the preparation stream, beside the fused kernel of the batch before --
+        // whose waves own every register of every CU -- its workgroups are handed out a few at a time over that whole
+        // kernel.  RAFTX_EXPAND_STREAM=1 puts it on a HIGH-priority stream of its own (the dispatcher then takes its
+        // workgroups first as slots free up; the member pass waits for it by event).  Same box, K = 40
+        // (gpurun_out/r05_prio): own stream 3.12 ms per step with the fused kernel at 2.81 ms, preparation stream 3.14 /
+        // 2.785, host-made descriptors uploaded by DMA 3.075 / 2.76 -- the 0.09 ms of stores land inside the running fused
+        // kernel either way; the default keeps that kernel least disturbed.
+        static const bool own_stream = getenv("RAFTX_EXPAND_STREAM") && atoi(getenv("RAFTX_EXPAND_STREAM"));
+        if (own_stream && sPrep != c->stream) {
+            if (!c->sExp) {
+                int least = 0, greatest = 0;
+                if (hipDeviceGetStreamPriorityRange(&least, &greatest) == hipSuccess && least != greatest)
+                    HIPCHK(c, hipStreamCreateWithPriority(&c->sExp, hipStreamNonBlocking, greatest));
+                else
+                    HIPCHK(c, hipStreamCreateWithFlags(&c->sExp, hipStreamNonBlocking));
+                HIPCHK(c, hipEventCreateWithFlags(&c->evExp, hipEventDisableTiming));
+            }
+            HIPCHK(c, hipStreamWaitEvent(c->sExp, c->evUp, 0));
+            launch_expand(E, c->sExp);
+            HIPCHK(c, hipEventRecord(c->evExp, c->sExp));
+            HIPCHK(c, hipStreamWaitEvent(sPrep, c->evExp, 0));
+        } else {
+            launch_expand(E, sPrep);
+        }
+    }
     // device-side scratch; on a pooled block a memset on sPrep is ordered before the kernels that use it
     int *errd = nullptr;
     {

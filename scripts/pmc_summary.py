@@ -11,8 +11,11 @@ for d in sorted(os.listdir(src)):
     if not os.path.exists(p):
         continue
     acc = collections.defaultdict(list)
-    for r in csv.DictReader(open(p)):
-        if "k_solve_dynamics" in r["Kernel_Name"]:
+    rows = [r for r in csv.DictReader(open(p)) if "k_solve_dynamics" in r["Kernel_Name"]]
+    # whole-batch launches only: the closing parity crossing downloads its responses and is cut into slabs of one residency round
+    gmax = max((int(r["Grid_Size"]) for r in rows), default=0)
+    for r in rows:
+        if int(r["Grid_Size"]) == gmax:
             acc[r["Counter_Name"]].append(float(r["Counter_Value"]))
             out["_kernel"] = r["Kernel_Name"]
             out["_vgpr"], out["_agpr"], out["_scratch"] = r["VGPR_Count"], r["Accum_VGPR_Count"], r["Scratch_Size"]
