@@ -13,7 +13,7 @@ import pytest
 from oracle import ref_harness as rh
 from tests.util import group_rel_err, rel_err, attach_fake_lines
 
-pytestmark = pytest.mark.skipif(not rh.reference_available(), reason="reference tree not present")
+pytestmark = pytest.mark.skipif(not rh.tree_available(), reason="reference tree not present (these tests read its decks)")
 
 
 def _numpy_qtf_backend(tabs, Xi, beta, w2, k2, depth, rho, g, Ms, kay):
@@ -306,7 +306,7 @@ def test_installed_calcHydroExcitation_full_dof_and_member_list(patch):
 # every platform deck of the reference tree that the reference itself can build and solve here (MoorPy / CCBlade stubbed,
 # mooring replaced by the injected stiffness of SURVEY 8d): rigid units, farms, internal-QTF decks, the flexible decks
 def _platform_decks():
-    if not rh.reference_available():
+    if not rh.tree_available():
         return []
     import glob
     out = []

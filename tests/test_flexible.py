@@ -398,7 +398,7 @@ def test_hip_flexible_solveDynamics(hip_ctx):
 def test_installed_flexible_solveDynamics_equals_numpy_path(oracle_ctx):
     """The patched package on the live flexible deck vs the reference's NumPy path (container only)."""
     from oracle import ref_harness as rh
-    if not rh.reference_available():
+    if not rh.tree_available():
         pytest.skip("reference tree not present")
     rh.import_raft()
     from raft import raft_model

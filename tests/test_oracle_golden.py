@@ -187,3 +187,29 @@ def test_vectorised_cpu_port_equals_the_checker(oracle_lib):
         for ic in range(2):
             assert group_rel_err(got["Xi"][d, ic], want["Xi"][d, ic]) < 1e-12
     ctx.close()
+
+
+def test_staged_reference_archive_reproduces_the_committed_fixture():
+    """oracle/stage_reference.py: the byte-compiled archive of the pure-Python reference (what bench.py's cpu_baseline leg
+    times on the GPU box, where /root/reference does not exist) is importable as it is and gives the committed
+    live-reference fixture bit for bit.  Built here from the tree when that is present; skipped where neither exists."""
+    import json
+    import os
+    import subprocess
+    import sys
+    from oracle import ref_harness as rh
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    if rh.tree_available():
+        from oracle import stage_reference
+        stage_reference.stage(verbose=False)
+    if not rh.archive_available():
+        pytest.skip("no staged reference archive (and no tree to build it from)")
+    env = dict(os.environ, RAFTX_REF_FORCE_ARCHIVE="1", OMP_NUM_THREADS="1", OPENBLAS_NUM_THREADS="1", MPLBACKEND="Agg")
+    out = subprocess.run([sys.executable, os.path.join(root, "oracle", "time_reference.py"), "--designs", "1"], env=env,
+                         capture_output=True, text=True, timeout=300, check=True).stdout.strip().splitlines()[-1]
+    r = json.loads(out)
+    assert r["reference_from"] == "archive" and r["max_rel_err_vs_committed_reference_fixture"] == 0.0
+    assert r["dcf_per_s_one_core"] > 0
+    import zipfile
+    names = zipfile.ZipFile(rh.ARCHIVE).namelist()
+    assert not any(n.endswith(".py") for n in names), "no reference SOURCE may be staged: %r" % names
