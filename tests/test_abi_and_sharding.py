@@ -214,6 +214,53 @@ def test_two_rank_geometry_sweep(tmp_path, oracle_lib, kind):
             assert group_rel_err(got["Xi"][j, 0, :1], sol["Xi"][:1]) < 1e-10
 
 
+def _variant_sweep(n):
+    """The first n C3 variants as PARAMETERS of an edit program (descriptors written by the library)."""
+    import json
+    from raft_amd import geometry as G
+    g, fx = _geometry_sweep(n)
+    fg = standin.load_fixture("geom_units.npz")
+    prog = G.volturnus_program(json.loads(fg["c3_base_json"]))
+    return sw.VariantSweep(prog, G.volturnus_params(np.asarray(fx["scales"])[:n]), g.M0, g.B0, g.C0, fx["w"], fx["k"],
+                           float(fx["depth"]), fx["zeta"], fx["beta"], int(fx["nIter"]), float(fx["XiStart"])), g
+
+
+def _variant_rank_main(rank, world, port, n, out_path, kind):
+    from raft_amd._abi import RaftxLib
+    comm = _make_comm(kind, rank, world, port)
+    try:
+        s, _ = _variant_sweep(n)
+        ctx = RaftxLib(ORACLE_SO).context(0)
+        res = sw.run_sharded(s, ctx, comm)
+        st = sw.run_stats_sharded(s, ctx, comm)
+        ctx.close()
+        if rank == 0:
+            np.savez(out_path, Xi=res["Xi"], niter=res["niter"], std=st["std"])
+    finally:
+        comm.close()
+
+
+@pytest.mark.parametrize("kind", TRANSPORTS)
+def test_two_rank_variant_sweep(tmp_path, oracle_lib, kind):
+    """Designs given as PARAMETERS of an edit program (VariantSweep) shard by design like the others: every rank expands
+    and generates its own block (params[lo:hi], no collective on the data path), rank 0 gathers; bit-identical to the
+    sweep fed with the host-expanded member descriptions."""
+    import torch.multiprocessing as mp
+    n, world = 5, 2
+    out = str(tmp_path / "variant_gathered.npz")
+    mp.spawn(_variant_rank_main, args=(world, _free_port(), n, out, kind), nprocs=world, join=True)
+    got = np.load(out)
+    s, g = _variant_sweep(n)
+    assert s.take(1, 4).n_design == 3 and np.array_equal(s.take(1, 4).params, s.params[1:4])
+    ctx = oracle_lib.context(0)
+    one = g.run(ctx)
+    std = g.run_stats(ctx)["std"]
+    ctx.close()
+    assert np.array_equal(got["Xi"].view(np.uint64), one["Xi"].view(np.uint64)) and np.array_equal(got["niter"], one["niter"])
+    assert np.array_equal(got["std"].view(np.uint64), std.view(np.uint64))
+    assert sw.shard_fingerprint(s, 0, 3) != sw.shard_fingerprint(s, 1, 4)            # the parameter rows are part of a shard's identity
+
+
 def _qtf_sets():
     from raft_amd import qtf as rq
     fx = standin.load_fixture("refgold_qtf_VolturnUS-S.npz")
