@@ -826,7 +826,9 @@ def main():
         assert np.array_equal(again["std"].view(np.uint64), r["std"].view(np.uint64)) and np.array_equal(again["niter"], r["niter"]), \
             "the same candidates solved twice (streamed / alone) differ"
         sw.set_params(G_.volturnus_params(scale_rows(*shard[rank])))
-    chk = sw.run_crossing(ctx, n_chunk=args.chunks, n_worker=args.workers, want_Xi=True)
+    # (--profile: no download -- a crossing that downloads its responses is cut into slabs of one residency round, ten more
+    # launches of the same kernel name in the rocprofv3 statistics; the parity of the responses is the default run's business)
+    chk = sw.run_crossing(ctx, n_chunk=args.chunks, n_worker=args.workers, want_Xi=not args.profile)
     if not variants:
         for x in res:                                     # every timed step re-solved the same batch: the same bits
             assert np.array_equal(x["std"].view(np.uint64), r["std"].view(np.uint64)) and np.array_equal(x["niter"], r["niter"])
@@ -837,7 +839,7 @@ def main():
     nan += int(np.count_nonzero(chk["flags"] & 2))
     Xi = chk["Xi"]
     parity = {"nan_flags": nan}
-    if rank == 0:                                         # the first 64 designs are the live reference's own variants
+    if rank == 0 and Xi is not None:                      # the first 64 designs are the live reference's own variants
         errs, mism = [], 0
         for j, sol in enumerate(fx["solved"][:min(nD, 64)]):
             errs.append(rao_group_err(Xi[j, 0, 0], np.asarray(sol["Xi"])[0], sw.zeta[0, 0]))

@@ -77,6 +77,13 @@ class Engine:
                     else:                                      # [strip, ...]
                         tgt[rows_il[sel]] = arr[sel]
 
+    def _no_materialise_general(self, fowt):
+        """The per-strip export addresses the strips of ONE rigid table; units with more than 6 reduced DOFs keep a table per
+        structural node -- asked to materialise their members, say so instead of leaving stale arrays behind."""
+        if self.materialise_members and _general(fowt):
+            raise UnsupportedFOWT("materialise_members is available for rigid 6-DOF units only (this unit has %d reduced DOFs)"
+                                  % int(fowt.nDOF))
+
     def _materialise_kinematics(self, fowt, members, design=0):
         """mem.u, mem.ud [nWaves,ns,3,nw], mem.pDyn [nWaves,ns,nw] of every member of ``members`` (zeros for strips above
         the waterline, raft_member.py:1927-1937) from the device's per-strip export of resident design ``design``."""
@@ -372,6 +379,7 @@ class Engine:
         beta, S, zeta, F_BEM(_fullDOF), F_hydro_iner(_fullDOF)."""
         self._check_supported(fowt)
         if _general(fowt):
+            self._no_materialise_general(fowt)
             return self._excitation_general(fowt, case, list(memberList))
         self._sea_state(fowt, case)
         members = list(memberList)
@@ -641,6 +649,8 @@ class Engine:
         iCase = case['iCase'] if 'iCase' in case else None
         fowts = model.fowtList
         if any(_general(f) for f in fowts):
+            for f in fowts:
+                self._no_materialise_general(f)
             return self._solve_general(model, case, tol, display)
         nF = len(fowts)
         nw = model.nw
