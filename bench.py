@@ -627,8 +627,12 @@ def main():
     args = ap.parse_args()
     if args.profile:
         args.chunks, args.no_extra_legs, args.no_cpu_baseline = 1, True, True
-    if args.depth == 0:                                   # default: two batches in flight; three (staged) when the responses are downloaded
-        args.depth = 4 if args.xi_out else 2
+    if args.depth == 0:
+        # default: two batches in flight with host-made descriptors (their upload rides the DMA engines); three, staged, with
+        # device-made ones -- the expansion of batch i+2 then has a whole step to trickle in beside the fused kernels instead
+        # of holding up the member pass of the very next batch (same box, K = 40, gpurun_out/r05_depth: 3.22 / 3.17 / 3.16 ms
+        # at depth 2 / 3 / 4; host-made: 3.08 / 3.09 / 3.16); four when the responses are downloaded
+        args.depth = 4 if args.xi_out else (3 if args.descriptors == "device" else 2)
 
     if args.gpus < 1:
         ap.error("--gpus must be >= 1")

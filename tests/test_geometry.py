@@ -808,9 +808,21 @@ def check_variant_crossing(ctx, n, n_chunk):
     assert np.array_equal(res["Xi"].reshape(want["Xi"].shape).view(np.uint64), want["Xi"].view(np.uint64))
 
 
+def check_variant_edge_batches(ctx):
+    """one candidate, and none at all: a batch of zero variants crosses the boundary and comes back empty"""
+    check_variant_crossing(ctx, 1, 0)
+    vs, _ = _c3_variant_sweep(3)
+    vs0 = vs.take(0, 0)
+    out = vs0.run_crossing(ctx)
+    assert out["std"].shape == (0, 1, 6) and out["niter"].shape == (0, 1) and np.array_equal(out["strip_off"], [0])
+    gm, gs, gc = ctx.expand_variants(np.zeros((0, 5)))
+    assert gm.shape[0] == 0 and gs.shape[0] == 0 and gc.shape[0] == 0
+
+
 def test_oracle_variant_program(oracle_ctx):
     check_variant_expansion(oracle_ctx, 40)
     check_variant_crossing(oracle_ctx, 5, 0)
+    check_variant_edge_batches(oracle_ctx)
 
 
 def test_variant_program_argument_errors(oracle_ctx):
@@ -833,6 +845,7 @@ def test_hip_variant_program(hip_ctx, oracle_ctx):
     check_variant_expansion(hip_ctx, 300)
     check_variant_crossing(hip_ctx, 70, 0)
     check_variant_crossing(hip_ctx, 333, 3)
+    check_variant_edge_batches(hip_ctx)
     # ... and the oracle's expansion of the same program is the same bits
     vs, _ = _c3_variant_sweep(50)
     a, b = vs.expanded_tables(hip_ctx), _c3_variant_sweep(50)[0].expanded_tables(oracle_ctx)
