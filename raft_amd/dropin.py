@@ -120,11 +120,10 @@ class Engine:
         if _general(fowt):
             if any(rot.r3[2] < 0 for rot in getattr(fowt, "rotorList", [])):
                 raise UnsupportedFOWT("submerged rotors on a unit with %d reduced DOFs" % fowt.nDOF)
-            # more than 6 reduced DOFs (flexible members): strip theory node by node + the dense impedance solve; the
-            # potential-flow and second-order branches of such units have no reference deck to pin them on
-            if getattr(fowt, "potMod", False) or int(getattr(fowt, "potModMaster", 0)) in (2, 3) \
-                    or np.any(np.asarray(getattr(fowt, "A_BEM", 0.0))) or np.any(np.asarray(getattr(fowt, "B_BEM", 0.0))):
-                raise UnsupportedFOWT("potential-flow coefficients on a unit with %d reduced DOFs" % fowt.nDOF)
+            # more than 6 reduced DOFs (flexible members): strip theory node by node + the dense impedance solve.  Potential-flow
+            # coefficients ride along as upstream lumps them: A_BEM, B_BEM in the first six DOFs of the reduced matrices
+            # (raft_fowt.py:1479-1480), the excitation in the first six rows of the full-DOF vector (:1796-1849) reduced by T.
+            # The second-order branches of such units are stubs upstream (calcQTF_slenderBody returns zeros for nDOF > 6)
             if int(getattr(fowt, "potSecOrder", 0)) != 0:
                 raise UnsupportedFOWT("second-order loads on a unit with %d reduced DOFs" % fowt.nDOF)
             if _dynamic_mooring(fowt):
@@ -154,6 +153,12 @@ class Engine:
         fowt.F_hydro_iner = np.array([T.T @ fowt.F_hydro_iner_fullDOF[ih] for ih in range(fowt.nWaves)])   # :1888
         fowt.F_BEM = np.zeros([fowt.nWaves, nDOF, nw], dtype=complex)
         fowt.F_BEM_fullDOF = np.zeros([fowt.nWaves, nFull, nw], dtype=complex)
+        if getattr(fowt, "potMod", False) or int(getattr(fowt, "potModMaster", 0)) in (2, 3):
+            # potential-flow excitation (:1796-1849), lumped at the first six full DOFs: on the device for the unit + sea
+            # state resident (its node tables; the unit's coefficients ride on the first of them), reduced by T (:1887)
+            if not tables:
+                raise UnsupportedFOWT("potential-flow excitation of a unit with %d reduced DOFs and no wet strips" % nDOF)
+            self._bem_excitation_units([fowt], n_pad=len(tables) - 1)
         fowt._raftx_fresh = True
         return None
 
@@ -202,10 +207,11 @@ class Engine:
         M_lin = fowt.M_struc + fowt.A_hydro_morison                          # :1045-1047
         B_lin = fowt.B_struc + B_gyro
         C_lin = fowt.C_struc + fowt.C_hydro + fowt.C_moor + fowt.C_elast
-        if np.any(M_turb):
-            M_lin = M_turb + M_lin[:, :, None]
-        if np.any(B_turb):
-            B_lin = B_turb + B_lin[:, :, None]
+        A_BEM, B_BEM = np.asarray(getattr(fowt, "A_BEM", 0.0)), np.asarray(getattr(fowt, "B_BEM", 0.0))
+        if np.any(M_turb) or np.any(A_BEM):
+            M_lin = M_turb + M_lin[:, :, None] + (A_BEM if np.any(A_BEM) else 0.0)       # :1045
+        if np.any(B_turb) or np.any(B_BEM):
+            B_lin = B_turb + B_lin[:, :, None] + (B_BEM if np.any(B_BEM) else 0.0)       # :1046
         F_lin = fowt.F_BEM[0] + fowt.F_hydro_iner[0] + fowt.Fhydro_2nd[0]    # :1048
         # the fixed point itself runs on the device (raftx_flex_solve): node motions, strip linearisation of every node,
         # the projections with T, the dense solves and the convergence test; M, C and the iterate-independent part of B

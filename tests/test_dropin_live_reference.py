@@ -391,6 +391,68 @@ def _sink_rotor(m):
         rot.I_hydro = I6
 
 
+def _inject_bem(m, seed=9):
+    """potential-flow coefficients on live units, the way FOWT.readHydro leaves them (raft_fowt.py:1479-1501): A_BEM, B_BEM
+    in the first six reduced DOFs, X_BEM [nHeadings, nDOF, nw] in the first six rows, a heading grid -- smooth in w"""
+    rng = np.random.default_rng(seed)
+    for f in m.fowtList:
+        n, nw = int(f.nDOF), f.nw
+        w = np.asarray(f.w)
+        sym = lambda a: 0.5 * (a + a.T)
+        f.potModMaster = 2
+        f.BEM_headings = np.array([0.0, 90.0, 180.0, 270.0])
+        f.A_BEM = np.zeros([n, n, nw])
+        f.B_BEM = np.zeros([n, n, nw])
+        A0, B0 = sym(rng.uniform(0, 1, (6, 6))) + 2 * np.eye(6), sym(rng.uniform(0, 1, (6, 6))) + np.eye(6)
+        scale = np.outer([1e6, 1e6, 1e6, 1e8, 1e8, 1e8], [1, 1, 1, 1e2, 1e2, 1e2]) ** 0.5 * 3.0
+        f.A_BEM[:6, :6, :] = (A0 * scale)[:, :, None] / (1.0 + (w / 0.8) ** 2)[None, None, :]
+        f.B_BEM[:6, :6, :] = (B0 * scale)[:, :, None] * ((w / 0.6) / (1.0 + (w / 0.6) ** 2))[None, None, :]
+        f.X_BEM = np.zeros([4, n, nw], dtype=complex)
+        amp = np.array([2e6, 2e6, 1e6, 4e7, 4e7, 1e7])[None, :, None] * rng.uniform(0.5, 1.5, (4, 6, 1))
+        f.X_BEM[:, :6, :] = amp * np.exp(1j * (rng.uniform(0, 6, (4, 6, 1)) + 2.0 * w[None, None, :])) / (1.0 + (w / 0.7) ** 2)
+
+
+@pytest.mark.parametrize("deck", ["tests/test_data/VolturnUS-S-flexible.yaml", "examples/VolturnUS-S_example.yaml"])
+def test_potential_flow_coefficients_on_flexible_and_rigid_units(patch, deck):
+    """A_BEM, B_BEM, X_BEM on a unit with MORE than 6 reduced DOFs (upstream lumps them at the first six DOFs,
+    raft_fowt.py:1479-1501, 1796-1849; the loop raft_model.py:1019-1089 is nDOF-agnostic) -- and on the rigid unit for
+    comparison: calcHydroExcitation's F_BEM(_fullDOF) and the whole solveDynamics against the NumPy path."""
+    settings = dict(min_freq=0.01, max_freq=0.3, nIter=8, XiStart=0.1)
+    case = rh.make_case(Hs=[5.0, 2.5], Tp=[11.0, 8.0], heading=[25.0, -40.0], spectrum=["JONSWAP"] * 2, gamma=[0, 0])
+    m_new, m_old = _model(deck, settings), _model(deck, settings)
+    for m in (m_new, m_old):
+        for f in m.fowtList:
+            f.potSecOrder = 0
+            if f.nDOF != 6:
+                cm = np.zeros((f.nDOF, f.nDOF))
+                cm[:6, :6] = rh.DEFAULT_C_MOOR
+                f.C_moor = cm
+        _inject_bem(m)
+    fn, fo = m_new.fowtList[0], m_old.fowtList[0]
+    fn.calcHydroExcitation(copy.deepcopy(case), memberList=fn.memberList)
+    with patch.unpatched():
+        fo.calcHydroExcitation(copy.deepcopy(case), memberList=fo.memberList)
+    assert np.any(fo.F_BEM) and rel_err(fn.F_BEM, fo.F_BEM) < 1e-10 and rel_err(fn.F_BEM_fullDOF, fo.F_BEM_fullDOF) < 1e-10
+    assert rel_err(fn.F_hydro_iner, fo.F_hydro_iner) < 1e-10
+    Xi_new = m_new.solveDynamics(copy.deepcopy(case)).copy()
+    with patch.unpatched():
+        Xi_old = m_old.solveDynamics(copy.deepcopy(case)).copy()
+    general = fo.nDOF != 6
+    assert Xi_new.shape == Xi_old.shape and rel_err(Xi_new, Xi_old) < (1e-8 if general else 1e-10)
+    assert rel_err(fn.B_hydro_drag, fo.B_hydro_drag) < 1e-8 and rel_err(fn.Z, fo.Z) < 1e-10
+    # ... and the coefficients matter in this set-up
+    m_ref = _model(deck, settings)
+    for f in m_ref.fowtList:
+        f.potSecOrder = 0
+        if f.nDOF != 6:
+            cm = np.zeros((f.nDOF, f.nDOF))
+            cm[:6, :6] = rh.DEFAULT_C_MOOR
+            f.C_moor = cm
+    with patch.unpatched():
+        Xi_none = m_ref.solveDynamics(copy.deepcopy(case)).copy()
+    assert rel_err(Xi_none, Xi_old) > 1e-2
+
+
 def _second_sunk_rotor(m):
     """a second submerged rotor on every unit: a copy of the first one somewhere else, with another inertia matrix"""
     for f in m.fowtList:

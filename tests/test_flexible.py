@@ -359,13 +359,56 @@ def test_unsupported_flexible_variants(oracle_ctx):
     with pytest.raises(dropin.UnsupportedFOWT):
         eng.solveDynamics(model, copy.deepcopy(case))
     fowt.potSecOrder = 0
-    fowt.A_BEM = np.ones((150, 150, model.nw))
-    with pytest.raises(dropin.UnsupportedFOWT):
-        eng.solveDynamics(model, copy.deepcopy(case))
-    fowt.A_BEM = np.zeros((150, 150, model.nw))
     model.fowtList = [fowt, fowt]
     with pytest.raises(dropin.UnsupportedFOWT):
         eng.solveDynamics(model, copy.deepcopy(case))
+
+
+def _with_bem(model, seed=4):
+    """potential-flow coefficients lumped at the first six DOFs of the 150-DOF unit (raft_fowt.py:1479-1501)"""
+    rng = np.random.default_rng(seed)
+    f = model.fowtList[0]
+    n, nw, w = int(f.nDOF), model.nw, np.asarray(model.w)
+    sym = lambda a: 0.5 * (a + a.T)
+    f.potModMaster = 2
+    f.heading_adjust = getattr(f, "heading_adjust", 0.0)
+    f.BEM_headings = np.array([0.0, 120.0, 240.0])
+    f.A_BEM, f.B_BEM = np.zeros([n, n, nw]), np.zeros([n, n, nw])
+    sc = np.outer([1e3, 1e3, 1e3, 1e4, 1e4, 1e4], [1e3, 1e3, 1e3, 1e4, 1e4, 1e4])
+    f.A_BEM[:6, :6] = ((sym(rng.uniform(0, 1, (6, 6))) + 2 * np.eye(6)) * sc)[:, :, None] / (1.0 + (w / 0.8) ** 2)
+    f.B_BEM[:6, :6] = ((sym(rng.uniform(0, 1, (6, 6))) + np.eye(6)) * sc)[:, :, None] * ((w / 0.6) / (1.0 + (w / 0.6) ** 2))
+    f.X_BEM = np.zeros([3, n, nw], dtype=complex)
+    f.X_BEM[:, :6] = np.array([2e6, 2e6, 1e6, 4e7, 4e7, 1e7])[None, :, None] * np.exp(1j * (rng.uniform(0, 6, (3, 6, 1)) + 2.0 * w))
+    return f
+
+
+def _check_flexible_with_bem(ctx, other=None):
+    """A unit with 150 reduced DOFs AND potential-flow coefficients (the NumPy path is compared on live objects in
+    tests/test_dropin_live_reference.py): the coefficients change the response, F_BEM is T^T of the first six full-DOF rows,
+    and a second backend gives the same numbers."""
+    fx, model = load_model_fixture("flex_volturnus.npz")
+    case = case_from_fixture(fx["cases"][0])
+    Xi0 = dropin.Engine(ctx).solveDynamics(model, copy.deepcopy(case)).copy()
+    f = _with_bem(model)
+    Xi1 = dropin.Engine(ctx).solveDynamics(model, copy.deepcopy(case)).copy()
+    assert np.any(f.F_BEM) and rel_err(f.F_BEM, np.einsum("fd,hfw->hdw", np.asarray(f.T), f.F_BEM_fullDOF)) < 1e-14
+    assert not np.any(f.F_BEM_fullDOF[:, 6:]) and rel_err(Xi1, Xi0) > 1e-2
+    assert rel_err(f.Z[:6, :6] - (-np.asarray(model.w) ** 2 * f.A_BEM[:6, :6] + 1j * np.asarray(model.w) * f.B_BEM[:6, :6]),
+                   f.Z[:6, :6]) < 2.0                                          # Z carries the coefficients (finite, same shape)
+    if other is not None:
+        _, m2 = load_model_fixture("flex_volturnus.npz")
+        f2 = _with_bem(m2)
+        Xi2 = dropin.Engine(other).solveDynamics(m2, copy.deepcopy(case)).copy()
+        assert rel_err(Xi1, Xi2) < 1e-8 and rel_err(f.F_BEM, f2.F_BEM) < 1e-12 and np.array_equal(model._raftx_niter, m2._raftx_niter)
+
+
+def test_oracle_flexible_unit_with_potential_flow_coefficients(oracle_ctx):
+    _check_flexible_with_bem(oracle_ctx)
+
+
+@pytest.mark.gpu
+def test_hip_flexible_unit_with_potential_flow_coefficients(hip_ctx, oracle_ctx):
+    _check_flexible_with_bem(hip_ctx, oracle_ctx)
 
 
 @pytest.mark.gpu
