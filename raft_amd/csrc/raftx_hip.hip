@@ -922,7 +922,20 @@ extern "C" int raftx_ctx_create(int device_id, raftx_ctx **out) {
     c->pinRes = nullptr;
     c->pinRes_n = 0;
     c->sCopy = c->sPrep = c->sD2H = c->sGen = nullptr;
-    bool ok = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) == hipSuccess;
+    // RAFTX_CTX_PRIORITY=high (tuning): the ctx stream -- the fused fixed points, table generation, statistics -- in the
+    // highest priority class, so that the dispatcher serves its grids before the preparation kernels of the batches behind.
+    // Measured and NOT the default (gpurun_out/r05_ctxprio, same box, K = 40, two repeats): 3.27 against 3.07 ms per step with
+    // three batches in flight, 3.21 against 3.13 with two, 3.29 against 3.08 with host-made descriptors -- the member pass of
+    // the next batch then cannot use the running kernel's drain and lands behind it.
+    bool ok;
+    {
+        static const char *prio = getenv("RAFTX_CTX_PRIORITY");
+        int least = 0, greatest = 0;
+        if (prio && !strcmp(prio, "high") && hipDeviceGetStreamPriorityRange(&least, &greatest) == hipSuccess && least != greatest)
+            ok = hipStreamCreateWithPriority(&c->stream, hipStreamNonBlocking, greatest) == hipSuccess;
+        else
+            ok = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) == hipSuccess;
+    }
     c->sAux = nullptr;
     for (hipEvent_t *e : {&c->evZ, &c->ev0, &c->ev1, &c->evUp, &c->evTot, &c->evG0, &c->evG1, &c->evG2, &c->evG3, &c->evS0,
                           &c->evS1, &c->evDone, &c->evMem, &c->evRed})
