@@ -270,6 +270,38 @@ def test_farm_path_without_Z_is_bit_identical_to_the_path_that_exports_it(hip_ct
     assert rel_err(lean["Xi"], ref["Xi"]) < TOL
 
 
+@pytest.mark.parametrize("name,icase", [("c2_volturnus.npz", 4), ("pose_volturnus_mcf.npz", 1), ("c4_farm.npz", 0)])
+def test_materialised_members_through_the_dropin(name, icase, hip_ctx, oracle_ctx):
+    """Engine(materialise_members=True): after solveDynamics every member of every unit carries u, ud, pDyn [nWaves,ns,3,nw],
+    Bmat [ns,3,3] of the linearisation the loop exited with and F_exc_drag of the last heading (raft_member.py:1927-1937,
+    2117, 2122; raft_model.py:1063, 1214) -- device vs oracle through the same drop-in code on the stand-in units (live
+    reference objects: tests/test_dropin_live_reference.py); two headings, MacCamy-Fuchs columns at a mean pose, a farm."""
+    fx, m_gpu = load_model_fixture(name)
+    _, m_cpu = load_model_fixture(name)
+    case = fx["cases"][icase]
+    if "coupling_C" in fx:
+        for m in (m_gpu, m_cpu):
+            class _MS:
+                def getCoupledStiffnessA(self, lines_only=True):
+                    return fx["coupling_C"]
+            m.ms, m.moorMod = _MS(), 0
+    Xg = dropin.Engine(hip_ctx, materialise_members=True).solveDynamics(m_gpu, case_from_fixture(case)).copy()
+    Xc = dropin.Engine(oracle_ctx, materialise_members=True).solveDynamics(m_cpu, case_from_fixture(case)).copy()
+    nH = Xg.shape[0] - 1
+    assert group_rel_err(Xg[:nH], Xc[:nH]) < TOL
+    wet = 0
+    for fg, fc in zip(m_gpu.fowtList, m_cpu.fowtList):
+        for a, b in zip(fg.memberList, fc.memberList):
+            assert a.u.shape == (nH, a.ns, 3, m_gpu.nw) and a.Bmat.shape == (a.ns, 3, 3) and a.F_exc_drag.shape == (a.ns, 3, m_gpu.nw)
+            if np.any(b.u):
+                wet += 1
+                assert rel_err(a.u, b.u) < 1e-12 and rel_err(a.ud, b.ud) < 1e-12 and rel_err(a.pDyn, b.pDyn) < 1e-12
+                assert rel_err(a.Bmat, b.Bmat) < 1e-9 and rel_err(a.F_exc_drag, b.F_exc_drag) < 1e-9
+            dry = np.asarray(a.r)[:, 2] >= 0
+            assert not np.any(a.u[:, dry]) and not np.any(a.Bmat[dry])
+    assert wet >= 2
+
+
 @pytest.mark.parametrize("S_list,nw,nH,mcf", [([40, 7], 200, 2, 0.0), ([53], 300, 1, 0.3), ([5, 0, 12], 48, 3, 0.0)])
 def test_strip_exports_parity(hip_ctx, oracle_ctx, S_list, nw, nH, mcf):
     """raftx_strip_kinematics / raftx_strip_drag (what the reference keeps on its Member objects: u, ud, pDyn,
