@@ -291,8 +291,11 @@ class Engine:
             F_full = np.zeros([f.nWaves, nFull, f.nw], dtype=complex)
             if F6 is not None and pot[i]:
                 F_full[:, :6, :] = F6[i, 0]
-            T = np.asarray(f.T, dtype=float)
-            f.F_BEM = np.einsum("fd,hfw->hdw", T, F_full) if T.shape[0] == nFull else F_full[:, :f.nDOF, :].copy()
+            if F6 is None or not pot[i]:                                    # strip-theory unit: zeros, without the reduction
+                f.F_BEM = np.zeros([f.nWaves, int(f.nDOF), f.nw], dtype=complex)
+            else:
+                T = np.asarray(f.T, dtype=float)
+                f.F_BEM = np.einsum("fd,hfw->hdw", T, F_full) if T.shape[0] == nFull else F_full[:, :f.nDOF, :].copy()
             f.F_BEM_fullDOF = F_full
 
     def _upload(self, fowts, case_zeta, case_beta, mats=None, tables=None):
@@ -820,9 +823,12 @@ class Engine:
             model.Xi[:nH] = ctx.solve_system(model.w, Zblk, Fw, Mc=Mc, Bc=Bc, Cc=Cc)[0]
         for i, fowt in enumerate(fowts):                                    # :1251-1255
             fowt.Xi = model.Xi[:, i * fowt.nDOF:(i + 1) * fowt.nDOF, :]
-            fowt.Xi_fullDOF = np.zeros([fowt.nWaves + 1, fowt.nFullDOF, nw], dtype=complex)
-            for ih in range(fowt.nWaves + 1):
-                fowt.Xi_fullDOF[ih, :, :] = fowt.T @ fowt.Xi[ih, :, :]
+            # T @ Xi[ih] for every heading as ONE real product on the interleaved (re, im) view: `T @ Xi[ih]` with a real T
+            # and a complex Xi takes NumPy's mixed-type path (2.3 ms per heading on an 8-core host, 0.75 ms of a 1.36 ms call
+            # on the GPU box as an einsum); a real [nFull,6] x [6,2 nw] product is a dgemm
+            Xc = np.ascontiguousarray(fowt.Xi)
+            Yf = np.matmul(np.asarray(fowt.T, dtype=float), Xc.view(np.float64).reshape(Xc.shape[0], Xc.shape[1], 2 * nw))
+            fowt.Xi_fullDOF = np.ascontiguousarray(Yf).view(np.complex128)
         model.results['response'] = {}                                      # :1300
         model._raftx_niter = out['niter'][:, 0].copy()
         if self.materialise_members:
