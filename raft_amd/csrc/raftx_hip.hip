@@ -304,7 +304,10 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(RAFTX_S
         const int p = 31 - (int)((half ? l1 : l0) & 31u);
         const bool mine = todo && r == p;
         const bool upd = todo && r != p;
-        if (mine) {
+#ifndef RAFTX_SYSROWS_EXP
+#define RAFTX_SYSROWS_EXP 0       // timing experiments (wrong results): 1 = no pivot-row stores, 2 = neither stores nor loads
+#endif
+        if (mine && RAFTX_SYSROWS_EXP == 0) {
 #pragma unroll
             for (int c = k; c < N; c++) rowbuf[c] = a[c];
 #pragma unroll
@@ -312,7 +315,12 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(RAFTX_S
                 rowbuf[N + j] = bR[j];
         }
         wave_lds_fence();
-        const cplx pv = rowbuf[k];
+#if RAFTX_SYSROWS_EXP == 2
+#define ROWBUF_(c) (cplx{a[(c) < N ? (c) : 0].im + 1.0, a[(c) < N ? (c) : 0].re})
+#else
+#define ROWBUF_(c) rowbuf[c]
+#endif
+        const cplx pv = ROWBUF_(k);
         // 1 / |pivot|^2: v_rcp_f64 + two Newton steps (5 instructions; the IEEE division sequence is ~15).  A zero pivot still
         // ends in NaN.
         const double pp = pv.re * pv.re + pv.im * pv.im;
@@ -325,15 +333,16 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(RAFTX_S
         const cplx l = {upd ? lk.re : 0.0, upd ? lk.im : 0.0};
 #pragma unroll
         for (int c = k + 1; c < N; c++) {
-            const cplx u = rowbuf[c];
+            const cplx u = ROWBUF_(c);
             a[c] = cfnma(a[c], l, u);                     // four FMAs (as a difference of a product: six instructions)
         }
 #pragma unroll
         for (int j = 0; j < NR; j++)
         {
-            const cplx u = rowbuf[N + j];
+            const cplx u = ROWBUF_(N + j);
             bR[j] = cfnma(bR[j], l, u);
         }
+#undef ROWBUF_
         if (mine) {
             todo = false;
             mystep = k;
