@@ -29,6 +29,7 @@ from . import waves
 from .rigid import translate_matrix_6to6
 from .strips import pack_fowt, pack_fowt_nodes, pack_fingerprint, UnsupportedFOWT
 from . import backend
+from .hostblas import few_threads
 
 
 def _sum_rotors(A):
@@ -36,6 +37,31 @@ def _sum_rotors(A):
     sum over an axis of length one copies 7 MB per matrix at 150 DOFs to return the same numbers)."""
     A = np.asarray(A)
     return A[:, :, :, 0] if A.shape[3] == 1 else np.sum(A, axis=3)
+
+
+def _nonzero(a):
+    """np.any(a) for the large real tables of a call (rotor / potential-flow matrices [n,n,nw]: 7 MB at 150 DOFs, all zeros
+    for a parked turbine -- np.any scans them at 1 GB/s, 0.75 ms each on the GPU box's host): a BLAS dot product answers
+    "something is there" (NaN included) at memory speed; if it is 0 -- all zeros, or values whose squares underflow -- the
+    bit patterns decide (-0.0 counts as something: adding it changes nothing)."""
+    a = np.asarray(a)
+    if a.dtype != np.float64 or a.size < 65536 or not a.flags.c_contiguous:
+        return bool(np.any(a))
+    f = a.reshape(-1)
+    with few_threads():
+        d = f.dot(f)
+    if d != 0.0:
+        return True
+    return bool(f.view(np.uint64).max() != 0)
+
+
+def _real_times_complex(T, X):
+    """T [m,n] real times X [...,n,nw] complex as ONE real matrix product on the interleaved (re, im) view of X: `T @ X` with
+    mixed types takes NumPy's slow path (no BLAS); T (re, im) = (T re, T im) is the same arithmetic as a dgemm."""
+    Xc = np.ascontiguousarray(X, dtype=complex)
+    with few_threads():
+        Y = np.matmul(np.asarray(T, dtype=float), Xc.view(np.float64).reshape(Xc.shape[:-1] + (2 * Xc.shape[-1],)))
+    return np.ascontiguousarray(Y).view(np.complex128)
 
 
 class Engine:
@@ -132,10 +158,17 @@ class Engine:
     # ------------------------------------------------------------------ units with more than 6 reduced DOFs
     def _node_units(self, fowt, members):
         """Strip tables per structural node + the rows of T that map the reduced DOFs onto each node."""
-        rows, tables = pack_fowt_nodes(fowt, members)
         T = np.asarray(fowt.T, dtype=float)
+        # one packing per pose, not per load case (as pack_fingerprint for the rigid units): everything the node tables
+        # read, the nodes they hang on and the reduction T
+        fp = (pack_fingerprint(fowt, members), tuple(int(nd.id) for mem in members for nd in mem.nodeList), T.tobytes())
+        cached = getattr(fowt, "_raftx_nodes_key", None)
+        if cached is not None and cached == fp and getattr(fowt, "_raftx_nodes", None) is not None:
+            return fowt._raftx_nodes
+        rows, tables = pack_fowt_nodes(fowt, members)
         Tn = np.array([T[r:r + 6, :] for r in rows]).reshape(len(rows), 6, T.shape[1])
         fowt._raftx_nodes = (rows, tables, Tn)
+        fowt._raftx_nodes_key = fp
         return fowt._raftx_nodes
 
     def _excitation_general(self, fowt, case, members):
@@ -150,7 +183,7 @@ class Engine:
             for i, r in enumerate(rows):
                 fowt.F_hydro_iner_fullDOF[:, r:r + 6, :] += F[i]
         T = np.asarray(fowt.T, dtype=float)
-        fowt.F_hydro_iner = np.array([T.T @ fowt.F_hydro_iner_fullDOF[ih] for ih in range(fowt.nWaves)])   # :1888
+        fowt.F_hydro_iner = _real_times_complex(T.T, fowt.F_hydro_iner_fullDOF)                              # :1888
         fowt.F_BEM = np.zeros([fowt.nWaves, nDOF, nw], dtype=complex)
         fowt.F_BEM_fullDOF = np.zeros([fowt.nWaves, nFull, nw], dtype=complex)
         if getattr(fowt, "potMod", False) or int(getattr(fowt, "potModMaster", 0)) in (2, 3):
@@ -173,10 +206,11 @@ class Engine:
             self._upload([fowt], fowt.zeta, fowt.beta, tables=tables)     # no-op while these tables are resident
             nU = len(rows)
             T2 = Tn.reshape(nU * 6, nDOF)                                  # the nodes' rows of T, stacked: plain GEMMs
-            XiN = (T2 @ np.asarray(Xi, dtype=complex)).reshape(nU, 6, nw)
+            XiN = _real_times_complex(T2, Xi).reshape(nU, 6, nw)
             B, F = self.ctx.linearize(XiN[:, None, :, :])                  # [nNode,1,6,6], [nNode,1,nWaves,6,nw]
-            B_red = T2.T @ np.matmul(B[:, 0], Tn).reshape(nU * 6, nDOF)    # sum_u T_u^T B_u T_u
-            F_red = np.array([T2.T @ F[:, 0, ih].reshape(nU * 6, nw) for ih in range(nH)])
+            with few_threads():
+                B_red = T2.T @ np.matmul(B[:, 0], Tn).reshape(nU * 6, nDOF)    # sum_u T_u^T B_u T_u
+            F_red = _real_times_complex(T2.T, np.moveaxis(F[:, 0], 1, 0).reshape(nH, nU * 6, nw))
         fowt.B_hydro_drag = B_red
         fowt._raftx_Fdrag = F_red
         fowt.F_hydro_drag = F_red[0].copy()
@@ -208,10 +242,10 @@ class Engine:
         B_lin = fowt.B_struc + B_gyro
         C_lin = fowt.C_struc + fowt.C_hydro + fowt.C_moor + fowt.C_elast
         A_BEM, B_BEM = np.asarray(getattr(fowt, "A_BEM", 0.0)), np.asarray(getattr(fowt, "B_BEM", 0.0))
-        if np.any(M_turb) or np.any(A_BEM):
-            M_lin = M_turb + M_lin[:, :, None] + (A_BEM if np.any(A_BEM) else 0.0)       # :1045
-        if np.any(B_turb) or np.any(B_BEM):
-            B_lin = B_turb + B_lin[:, :, None] + (B_BEM if np.any(B_BEM) else 0.0)       # :1046
+        if _nonzero(M_turb) or _nonzero(A_BEM):
+            M_lin = M_turb + M_lin[:, :, None] + (A_BEM if _nonzero(A_BEM) else 0.0)       # :1045
+        if _nonzero(B_turb) or _nonzero(B_BEM):
+            B_lin = B_turb + B_lin[:, :, None] + (B_BEM if _nonzero(B_BEM) else 0.0)       # :1046
         F_lin = fowt.F_BEM[0] + fowt.F_hydro_iner[0] + fowt.Fhydro_2nd[0]    # :1048
         # the fixed point itself runs on the device (raftx_flex_solve): node motions, strip linearisation of every node,
         # the projections with T, the dense solves and the convergence test; M, C and the iterate-independent part of B
@@ -253,9 +287,7 @@ class Engine:
         model.Xi[:nH], fowt.Z = out["Xi"][0, 0], out["Z"][0, 0]              # Z: the impedance of the last iteration (:1155)
         fowt.F_hydro_drag = fowt._raftx_Fdrag[nH - 1].copy()
         fowt.Xi = model.Xi[:, :n, :]                                         # :1251-1255
-        fowt.Xi_fullDOF = np.zeros([nH + 1, int(fowt.nFullDOF), nw], dtype=complex)
-        for ih in range(nH + 1):
-            fowt.Xi_fullDOF[ih, :, :] = fowt.T @ fowt.Xi[ih, :, :]
+        fowt.Xi_fullDOF = _real_times_complex(fowt.T, fowt.Xi)
         model.results['response'] = {}                                       # :1300
         model._raftx_niter = np.array([niter], dtype=np.int32)
         model._raftx_flags = np.array([1 if converged else 0], dtype=np.int32)
@@ -702,7 +734,7 @@ class Engine:
             B_BEM = np.asarray(fowt.B_BEM)
             B_gyro = np.sum(fowt.B_gyro, axis=2)
             C_lin = fowt.C_struc + fowt.C_hydro + C_moor + fowt.C_elast    # :1047
-            if np.any(M_turb) or np.any(B_turb) or np.any(A_BEM) or np.any(B_BEM):
+            if _nonzero(M_turb) or _nonzero(B_turb) or _nonzero(A_BEM) or _nonzero(B_BEM):
                 M_lin = M_turb + fowt.M_struc[:, :, None] + A_BEM + fowt.A_hydro_morison[:, :, None]   # :1045
                 B_lin = B_turb + fowt.B_struc[:, :, None] + B_BEM + B_gyro[:, :, None]                 # :1046
                 mats.append([np.zeros((6, 6)) if MA_moor is None else MA_moor, np.zeros((6, 6)), C_lin,
@@ -826,9 +858,7 @@ class Engine:
             # T @ Xi[ih] for every heading as ONE real product on the interleaved (re, im) view: `T @ Xi[ih]` with a real T
             # and a complex Xi takes NumPy's mixed-type path (2.3 ms per heading on an 8-core host, 0.75 ms of a 1.36 ms call
             # on the GPU box as an einsum); a real [nFull,6] x [6,2 nw] product is a dgemm
-            Xc = np.ascontiguousarray(fowt.Xi)
-            Yf = np.matmul(np.asarray(fowt.T, dtype=float), Xc.view(np.float64).reshape(Xc.shape[0], Xc.shape[1], 2 * nw))
-            fowt.Xi_fullDOF = np.ascontiguousarray(Yf).view(np.complex128)
+            fowt.Xi_fullDOF = _real_times_complex(fowt.T, fowt.Xi)
         model.results['response'] = {}                                      # :1300
         model._raftx_niter = out['niter'][:, 0].copy()
         if self.materialise_members:
@@ -904,7 +934,7 @@ def unit_matrices(fowt, nw):
     A_BEM, B_BEM = np.asarray(fowt.A_BEM), np.asarray(fowt.B_BEM)
     B_gyro = np.sum(fowt.B_gyro, axis=2)
     C_lin = fowt.C_struc + fowt.C_hydro + fowt.C_moor + fowt.C_elast
-    if np.any(M_turb) or np.any(B_turb) or np.any(A_BEM) or np.any(B_BEM):
+    if _nonzero(M_turb) or _nonzero(B_turb) or _nonzero(A_BEM) or _nonzero(B_BEM):
         M_lin = M_turb + fowt.M_struc[:, :, None] + A_BEM + fowt.A_hydro_morison[:, :, None]
         B_lin = B_turb + fowt.B_struc[:, :, None] + B_BEM + B_gyro[:, :, None]
         return np.zeros((6, 6)), np.zeros((6, 6)), C_lin, np.array([M_lin, B_lin])

@@ -18,35 +18,13 @@ Units come from live ``FOWT`` objects (``FlexUnit.from_fowt``: the reference's o
 finite-element assembly stays upstream) or from arrays.  All units of a sweep share the frequency grid; they may differ
 in everything else, including their number of nodes, but not in nDOF.
 """
-import contextlib
 import weakref
 
 import numpy as np
 
 from .strips import pack_fowt_nodes
 
-try:
-    from threadpoolctl import ThreadpoolController
-except ImportError:                                  # optional: without it the products below run with BLAS's own thread count
-    ThreadpoolController = None
-_BLAS = None                                         # the controller, made once (it walks the loaded libraries)
-
-
-def _few_blas_threads():
-    """The host's share of a sweep is a handful of small products (the inertial excitation reduced with T, once).  On a
-    many-core host OpenBLAS starts all its threads for each of them and they keep spinning afterwards, beside the runtime
-    threads of the device library: measured on the 256-thread GPU box, calls of FlexSweep.run then take 40-70 ms every few
-    calls instead of 24 (scripts/prof_flex_batch.py).  Eight threads are plenty for 150 x 360 products.  The limit only
-    ever LOWERS the count: a user who runs with OPENBLAS_NUM_THREADS=1 keeps one thread."""
-    global _BLAS
-    if ThreadpoolController is None:
-        return contextlib.nullcontext()
-    if _BLAS is None:
-        _BLAS = ThreadpoolController()
-    now = [m.get("num_threads") for m in _BLAS.info() if m.get("user_api") == "blas" and m.get("num_threads")]
-    if now and max(now) <= 8:
-        return contextlib.nullcontext()
-    return _BLAS.limit(limits=8, user_api="blas")
+from .hostblas import few_threads as _few_blas_threads          # at most eight BLAS threads for the small host products
 
 WAVE_RHO, WAVE_G = 1025.0, 9.81        # hard-wired defaults of Member.calcHydroExcitation (raft_member.py:1940)
 
