@@ -627,6 +627,13 @@ def main():
     args = ap.parse_args()
     if args.profile:
         args.chunks, args.no_extra_legs, args.no_cpu_baseline = 1, True, True
+    # NumPy's BLAS pool on at most eight threads for the life of this process (it only ever lowers the count): the pool's GPU
+    # boxes give a process 16 CPUs by cgroup quota behind 256 logical ones, and OpenBLAS's idle-spinning threads spend that
+    # quota -- the whole process, the thread that feeds the GPU included, is then throttled (raft_amd/hostblas.py)
+    global _BLAS_SCOPE
+    from raft_amd import hostblas
+    _BLAS_SCOPE = hostblas.few_threads()
+    _BLAS_SCOPE.__enter__()
     if args.depth == 0:
         # default: two batches in flight with host-made descriptors (their upload rides the DMA engines); three, staged, with
         # device-made ones -- the expansion of batch i+2 then has a whole step to trickle in beside the fused kernels instead
