@@ -772,6 +772,7 @@ struct raftx_ctx {
     // resident results of the last raftx_solve_dynamics_device
     cplx *rXi, *rFw, *rZ, *rFe;
     double *rB, *rXl;
+    unsigned long long *rXlSlots;
     size_t rXl_n;
     int last_flags = -1, last_minb = 0, last_rc = 0;       // specialisation of the last fused-kernel launch (raftx_last_solve_kernel)
     cplx *rQtf;                          // QTFs of the last raftx_qtf_slender call, kept for raftx_qtf_force
@@ -910,6 +911,7 @@ extern "C" int raftx_ctx_create(int device_id, raftx_ctx **out) {
     c->kay_ready = false;
     c->rXi = c->rFw = c->rZ = c->rFe = nullptr;
     c->rB = c->rXl = nullptr;
+    c->rXlSlots = nullptr;
     c->rXl_n = 0;
     c->rQtf = nullptr;
     c->rQtf_n = 0;
@@ -995,6 +997,7 @@ extern "C" void raftx_ctx_destroy(raftx_ctx *c) {
     for (CaseSet &cs : c->csets) free_list(c, cs.allocs);
     c->pool.trim();
     if (c->rXl) (void)hipFree(c->rXl);
+    if (c->rXlSlots) (void)hipFree(c->rXlSlots);
     if (c->rXl0) (void)hipFree(c->rXl0);
     if (c->rXlOut) (void)hipFree(c->rXlOut);
     if (c->rQtf) (void)hipFree(c->rQtf);
@@ -1954,16 +1957,29 @@ static int solve_enqueue(raftx_ctx *c, int nIter, double tol, double XiStart, co
     c->last_rc = A.rc_n;
     const size_t lds = lds_bytes(c->maxS, xlg ? 0 : T.nw, sh.threads / 64, stage_policy(sh.nb, shape_maxt(sh)),
                                  park_policy(sh.nb, shape_maxt(sh)), A.rc_n, rc_shape ? T.nw : 0);
-    if (xlg && (!c->rXl || c->rXl_n < c->r_npair * 12 * (size_t)T.nw)) {
-        HIPCHK(c, hipStreamSynchronize(c->stream));
-        if (c->rXl) (void)hipFree(c->rXl);
+#ifdef RAFTX_XL_PER_PAIR
+    const size_t xl_regions = std::max<size_t>(XL_SLOTS, c->r_npair);
+#else
+    const size_t xl_regions = XL_SLOTS;
+#endif
+    if (xlg && (!c->rXl || c->rXl_n < xl_regions * 12 * (size_t)T.nw)) {
+        // XiLast scratch: a slot per RUNNING workgroup (xl_slot_acquire), not per pair; the slot bits are cleared once --
+        // every workgroup returns its slot
+        HIPCHK(c, hipDeviceSynchronize());                 // fused kernels of the other streams may hold slots of the old slab
+        if (c->rXl) { (void)hipFree(c->rXl); }
         c->rXl = nullptr;
-        c->rXl_n = c->r_npair * 12 * (size_t)T.nw;
+        c->rXl_n = xl_regions * 12 * (size_t)T.nw;
         void *p_ = nullptr;
-        HIPCHK(c, hipMalloc(&p_, (c->rXl_n ? c->rXl_n : 1) * sizeof(double)));
+        HIPCHK(c, hipMalloc(&p_, c->rXl_n * sizeof(double)));
         c->rXl = reinterpret_cast<double *>(p_);
+        if (!c->rXlSlots) {
+            HIPCHK(c, hipMalloc(&p_, XL_POOLS * XL_POOL_WORDS * sizeof(unsigned long long)));
+            c->rXlSlots = reinterpret_cast<unsigned long long *>(p_);
+            HIPCHK(c, hipMemset(c->rXlSlots, 0, XL_POOLS * XL_POOL_WORDS * sizeof(unsigned long long)));
+        }
     }
     A.Xl = c->rXl;
+    A.slots = c->rXlSlots;
     // restart / export of the linearisation point (the re-entry of raft_model.py:1108-1131)
     const size_t nxl = c->r_npair * 6 * (size_t)T.nw;
     A.Xl0 = nullptr;

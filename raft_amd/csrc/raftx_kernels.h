@@ -2285,6 +2285,60 @@ struct XlStore<true> {
     __device__ __forceinline__ double get(int row, int iw) const { return p[(size_t)row * n + iw]; }
     __device__ __forceinline__ void put(int row, int iw, double v) const { p[(size_t)row * n + iw] = v; }
 };
+// The global XiLast scratch is indexed by a SLOT the workgroup holds while it runs, not by its pair: 2 048 regions of 12 nw
+// doubles (39 MB at 200 bins) whatever the batch size, instead of 19.2 KB per pair (192 MB for 10 000 pairs, 3.8 GB for the
+// 200 000-pair launches).  A slot is re-used by the workgroups that follow each other on the same XCD -- 128 resident ones x
+// 19.2 KB = 2.4 MB of the XCD's 4 MB L2.  Measured (round 5, same box, alternating: scripts/gpu_r5_slots_ab.sh): kernel 2.791-
+// 2.800 ms against 2.800-2.809 with the per-pair slab; the L2 <-> fabric traffic does NOT change (FETCH_SIZE 1.323 GB,
+// WRITE_SIZE 1.451 GB per launch either way, gpurun_out/r05_slots): the stores of a kernel are written through to the fabric
+// whether or not the line stays in the L2 -- 1.451 GB is exactly the XiLast (113 KB), F_lin (19 KB) and Xi (19 KB) stores of
+// 10 000 pairs -- so that figure is a property of keeping XiLast off-chip, not of evictions.
+// Pools are PER XCD (HW_REG_XCC_ID: the L2s of different XCDs are not coherent with each other, so a slot never changes
+// XCD; placement is used for speed only -- any workgroup may run on any XCD), 256 slots each = the most workgroups 32 CUs
+// can hold; a full pool (which cannot happen) would be waited for.  Protocol: lane 0 claims a free bit with an atomic OR at
+// the L2 (start position hashed from blockIdx: the workgroups of a launch's first round do not collide), the slot travels
+// to the other waves through the first LDS word (before anything is staged there); the new owner overwrites every entry
+// before it reads it; release = all waves' stores acknowledged (vmcnt(0)), barrier, atomic AND.
+#define XL_POOLS 8
+#define XL_POOL_WORDS 4
+#define XL_SLOTS (XL_POOLS * XL_POOL_WORDS * 64)
+__device__ __forceinline__ unsigned xl_slot_acquire(unsigned long long *pools, double *smem0) {
+    volatile int *mail = reinterpret_cast<volatile int *>(smem0);
+    if (threadIdx.x == 0) {
+        unsigned xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        xcc &= (unsigned)(XL_POOLS - 1);
+        unsigned long long *pool = pools + xcc * XL_POOL_WORDS;
+        const unsigned h = blockIdx.x >> 3;
+        unsigned w = (h >> 6) % XL_POOL_WORDS;
+        const unsigned rot = h & 63u;
+        int slot = -1;
+        while (slot < 0) {
+            const unsigned long long cur = __hip_atomic_fetch_or(pool + w, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const unsigned long long fr = ~cur;
+            const unsigned long long frr = rot ? ((fr >> rot) | (fr << (64u - rot))) : fr;
+            if (frr) {
+                const unsigned bit = ((unsigned)__builtin_ctzll(frr) + rot) & 63u;
+                const unsigned long long m = 1ull << bit;
+                const unsigned long long old = __hip_atomic_fetch_or(pool + w, m, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (!(old & m)) slot = (int)((xcc * XL_POOL_WORDS + w) * 64u + bit);
+            } else {
+                w = (w + 1) % XL_POOL_WORDS;
+            }
+        }
+        *mail = slot;
+    }
+    __syncthreads();
+    const int slot = *mail;
+    __syncthreads();
+    return (unsigned)__builtin_amdgcn_readfirstlane(slot);
+}
+__device__ __forceinline__ void xl_slot_release(unsigned long long *pools, unsigned slot) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0)
+        (void)__hip_atomic_fetch_and(pools + (slot >> 6), ~(1ull << (slot & 63u)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
 
 // Convergence test of one response entry (raft_model.py:1103): |d| / (|x| + tol) < tol.
 // Two IEEE square roots and a division per entry are ~50 instructions; almost every entry is far from the
@@ -2547,7 +2601,8 @@ struct SolveArgs {
     double *__restrict__ B_drag;         // [pair,36] or null
     cplx *__restrict__ F_wave;           // [pair,nHead,6,nw] or null
     cplx *__restrict__ Z;                // [pair,36,nw] or null
-    double *Xl;                          // [pair,12,nw] XiLast scratch (shapes with more than 1024 bins only)
+    double *Xl;                          // [XL_SLOTS,12,nw] XiLast scratch of the shapes that keep it in global memory (xl_global)
+    unsigned long long *slots;           // [XL_POOLS * XL_POOL_WORDS] bit per slot of Xl: held by a running workgroup
     const cplx *__restrict__ Xl0;        // [pair,6,nw] or null: initial linearisation point instead of XiStart
     cplx *__restrict__ XlOut;            // [pair,6,nw] or null: linearisation point of the LAST iteration
     unsigned long long *dbg;             // RAFTX_PHASE_TIMING builds: [8] accumulated wave-0 cycles per phase
@@ -2585,12 +2640,18 @@ __global__ void __launch_bounds__(MAXT, MINB) k_solve_dynamics(DevTables T, Solv
     constexpr int PARK = park_policy(NB, MAXT);
     constexpr bool RC = PARK != 0 && XLG;            // the shape whose spare LDS is a run-start cache (A.rc_n slots)
     Lds l = carve(smem, S, XLG ? 0 : nw, blockDim.x >> 6, STAGE, PARK, RC ? A.rc_n : 0, RC ? nw : 0);
-    if (STAGE) stage_recA(p.ds, p.dsi, S, l, STAGE);
-    if constexpr (RC) stage_sincos_table(l.sct);
     XlStore<XLG> xl;
     if constexpr (XLG) {
+#ifdef RAFTX_XL_PER_PAIR                                   // tuning build: round 1-4's form, a region per pair
         xl.p = A.Xl + (size_t)pair * 12 * nw;
+#else
+        xl.p = A.Xl + (size_t)xl_slot_acquire(A.slots, smem) * 12 * nw;       // before anything is staged in LDS
+#endif
         xl.n = nw;
+    }
+    if (STAGE) stage_recA(p.ds, p.dsi, S, l, STAGE);
+    if constexpr (RC) stage_sincos_table(l.sct);
+    if constexpr (XLG) {
     } else {
         xl.p = l.xl;
         xl.n = l.nxl;
@@ -2839,6 +2900,9 @@ __global__ void __launch_bounds__(MAXT, MINB) k_solve_dynamics(DevTables T, Solv
         iiter++;
         wg_sync(multi);
     }
+#ifndef RAFTX_XL_PER_PAIR
+    if constexpr (XLG) xl_slot_release(A.slots, (unsigned)((size_t)(xl.p - A.Xl) / ((size_t)12 * nw)));    // XiLast is dead from here on
+#endif
 
     // remaining headings: same impedance, same linearised coefficients (:1200-1236)
     if constexpr (MULTI) {
