@@ -1975,7 +1975,7 @@ static int solve_enqueue(raftx_ctx *c, int nIter, double tol, double XiStart, co
         if (!c->rXlSlots) {
             HIPCHK(c, hipMalloc(&p_, XL_POOLS * XL_POOL_WORDS * sizeof(unsigned long long)));
             c->rXlSlots = reinterpret_cast<unsigned long long *>(p_);
-            HIPCHK(c, hipMemset(c->rXlSlots, 0, XL_POOLS * XL_POOL_WORDS * sizeof(unsigned long long)));
+            HIPCHK(c, hipMemsetAsync(c->rXlSlots, 0, XL_POOLS * XL_POOL_WORDS * sizeof(unsigned long long), c->stream));   // ahead of this ctx's launches, in stream order
         }
     }
     A.Xl = c->rXl;
