@@ -49,6 +49,10 @@ Also on the JSON line:
                     MacCamy-Fuchs columns): resident kernel time per pair-iteration
                     against the plain sweep's, a sample checked against the oracle.
 
+  roofline.traffic  the fused kernel's L2 <-> fabric bytes per launch, measured BY this run (N = 1): two child runs of this script
+                    under `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` (separate passes, counters only; live_traffic);
+                    the committed profile's figure, labelled as such, where that is not possible.
+
   c2_dropin / c4_farm / c5_qtf   BASELINE.json's configs[1], [3], [4] at their specified sizes (bench_legs.py),
                     each against its committed live-reference golden and with the roofline of its own kernel;
   flex_sweep        a batch of units with flexible members (150 reduced DOFs) against the drop-in and its golden.
@@ -183,9 +187,58 @@ def measured_traffic(n_design):
     return float(t["hbm_bytes_per_launch"]) * float(n_design) / n_prof
 
 
+def live_traffic(n_design, timeout_s=120):
+    """`roofline.traffic` measured IN this run: two child runs of this script (five whole-batch steps, `--profile`) under
+    `rocprofv3 --pmc FETCH_SIZE` and `--pmc WRITE_SIZE` -- separate passes, no trace domains beside the counters, run from
+    /tmp with TMPDIR=/tmp -- and the per-launch means of the fused kernel's whole-batch launches, FETCH_SIZE doubled as
+    MI355X_MICROARCH.md prescribes for gfx950 (rocprofv3 reports KB).  Returns (bytes per launch, provenance) or
+    (None, why): no rocprofv3, a pass that fails or takes longer than timeout_s, or this process itself running under a
+    profiler.  The caller then falls back to the committed profile's figure and says so."""
+    import csv, glob, shutil, signal, subprocess, tempfile
+    if any(k.startswith(("ROCPROF", "ROCP_TOOL", "ROCPROFILER")) for k in os.environ) or "rocprof" in os.environ.get("LD_PRELOAD", ""):
+        return None, "this process runs under a profiler"
+    exe = shutil.which("rocprofv3") or ("/opt/rocm/bin/rocprofv3" if os.path.exists("/opt/rocm/bin/rocprofv3") else None)
+    if not exe:
+        return None, "rocprofv3 not found"
+    tmp = tempfile.mkdtemp(prefix="raftx_pmc_", dir="/tmp")
+    env = dict(os.environ, TMPDIR="/tmp")
+    got, t_all = {}, time.perf_counter()
+    try:
+        for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
+            d = os.path.join(tmp, ctr)
+            cmd = [exe, "--pmc", ctr, "--output-format", "csv", "-d", d, "-o", "bench", "--", sys.executable, os.path.join(ROOT, "bench.py"),
+                   "--steps", "5", "--warmup", "1", "--profile", "--designs", str(n_design)]
+            pr = subprocess.Popen(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, start_new_session=True)
+            try:
+                rc = pr.wait(timeout=timeout_s)
+            except subprocess.TimeoutExpired:
+                os.killpg(pr.pid, signal.SIGKILL)             # the session this call started, nothing else
+                pr.wait()
+                return None, "the %s pass took longer than %d s" % (ctr, timeout_s)
+            if rc != 0:
+                return None, "the %s pass ended with rc=%d" % (ctr, rc)
+            rows = []
+            for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+                with open(f) as fh:
+                    rows += [r for r in csv.DictReader(fh) if "k_solve_dynamics" in r["Kernel_Name"] and r["Counter_Name"] == ctr]
+            gmax = max((int(r["Grid_Size"]) for r in rows), default=0)
+            vals = [float(r["Counter_Value"]) for r in rows if int(r["Grid_Size"]) == gmax]
+            if not vals:
+                return None, "the %s pass recorded no launch of the fused kernel" % ctr
+            got[ctr] = (1e3 * float(np.mean(vals)), len(vals), gmax)
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+    f, w_ = got["FETCH_SIZE"][0], got["WRITE_SIZE"][0]
+    return 2.0 * f + w_, {"measured_in_this_run": True, "how": "two child runs of bench.py --steps 5 --warmup 1 --profile under rocprofv3 --pmc FETCH_SIZE / "
+                          "--pmc WRITE_SIZE (separate passes, counters only), means over the whole-batch launches of k_solve_dynamics; "
+                          "traffic = 2 x FETCH_SIZE + WRITE_SIZE (FETCH_SIZE doubled per MI355X_MICROARCH.md for gfx950; Infinity-Cache hits count as traffic)",
+                          "FETCH_SIZE_bytes_raw": f, "WRITE_SIZE_bytes_raw": w_, "launches": [got["FETCH_SIZE"][1], got["WRITE_SIZE"][1]],
+                          "grid_size": got["FETCH_SIZE"][2], "designs_per_launch": int(n_design), "seconds": time.perf_counter() - t_all}
+
+
 def traffic_provenance():
-    """Where `roofline.traffic` comes from: PMC counters need rocprofv3 around the process, so THIS run cannot measure them;
-    the figure is the committed profile's, scaled to the designs of one step."""
+    """Provenance of the FALLBACK figure of `roofline.traffic` (no rocprofv3 on the host, N > 1, a child pass that failed):
+    the committed profile's, scaled to the designs of one step.  The default N = 1 run measures it itself (live_traffic)."""
     path = os.path.join(ROOT, "profiles", "traffic_latest.json")
     if not os.path.exists(path):
         return None
@@ -621,7 +674,8 @@ def main():
                                                       "(the gap between fused kernels shrinks 0.35 -> 0.2 ms, the kernels sharing the drain slow each "
                                                       "other by as much), so it is not the default")
     ap.add_argument("--no-extra-legs", action="store_true", help="skip the legs outside the headline (xi-out, featured sweeps)")
-    ap.add_argument("--legs", default="xi,featured,configs,hostdesc", help="which legs outside the headline run (comma list of xi, featured, configs, hostdesc)")
+    ap.add_argument("--legs", default="xi,featured,configs,hostdesc,traffic", help="which legs outside the headline run (comma list of xi, featured, configs, hostdesc, "
+                                                                            "traffic = the FETCH_SIZE / WRITE_SIZE passes of roofline.traffic, two child runs under rocprofv3)")
     ap.add_argument("--profile", action="store_true", help="for runs under rocprofv3: whole-batch launches only (--chunks 1), no isolated / "
                                                             "extra / oracle legs -- ONE population of k_solve_dynamics launches in the trace")
     args = ap.parse_args()
@@ -1006,6 +1060,15 @@ def main():
         cfg_legs["c5_qtf"] = guarded("c5_qtf", lambda: bench_legs.c5_qtf(ctx))
         cfg_legs["flex_sweep"] = guarded("flex_sweep", lambda: bench_legs.flex_sweep(ctx))
 
+    # ---- roofline.traffic: measured in THIS run where rocprofv3 is at hand (N = 1), else the committed profile's figure
+    traffic_bytes, traffic_prov = measured_traffic(nD), traffic_provenance()
+    if rank == 0 and world == 1 and not args.no_extra_legs and not args.profile and "traffic" in args.legs:
+        tb, tp = live_traffic(nD)
+        if tb is not None:
+            traffic_bytes, traffic_prov = tb, tp
+        else:
+            traffic_prov = dict(traffic_prov or {}, live_measurement="not made: %s" % tp)
+
     n_dcf_rank = nD * 1 * nw
     value = int(counts_all.sum()) * nw * args.steps / elapsed
     k_sum_ms = float(np.mean(tims[:, 2]))                 # k_solve_dynamics: summed HIP-event durations of one step's launches
@@ -1048,7 +1111,7 @@ def main():
         # 10); the HBM view and the measured traffic sit beside it
         "roofline": {"bound": "fp64_valu", "achieved": flops / (k_sum_ms * 1e-3) / 1e12, "peak": FP64_VALU_PEAK_TF, "unit": "TFLOP/s",
                      "frac": flops / (k_sum_ms * 1e-3) / 1e12 / FP64_VALU_PEAK_TF,
-                     "traffic": measured_traffic(nD), "traffic_from_profile": traffic_provenance(),
+                     "traffic": traffic_bytes, "traffic_from_profile": traffic_prov,
                      "kernel": "k_solve_dynamics", "kernel_ms_per_step": k_sum_ms, "algorithmic_flops_per_step": flops,
                      "hbm": {"achieved": A / (k_sum_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                              "frac": A / (k_sum_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "algorithmic_bytes_per_step": A},
@@ -1058,7 +1121,8 @@ def main():
                                                      "(the clock drops to 1.7 GHz under fp64 load): scripts/ubench/valu_mfma_probe.hip, "
                                                      "profiles/r02_valu_mfma_probe.jsonl"},
                      "note": "kernel time = HIP events around every k_solve_dynamics launch of the timed steps, summed per step; "
-                             "traffic = 2 x FETCH_SIZE + WRITE_SIZE of separate rocprofv3 --pmc passes (profiles/traffic_latest.json)"},
+                             "traffic = 2 x FETCH_SIZE + WRITE_SIZE of separate rocprofv3 --pmc passes: made by this run (traffic_from_profile."
+                             "measured_in_this_run) or, where that was not possible, the committed profile's (profiles/traffic_latest.json)"},
         "host_placement": placement,
         "geometry": dict(geo, strips=int(off[-1]), strip_table_bytes_not_uploaded=int(off[-1]) * 256,
                          host_params_ms_per_step=host_params_ms, distinct_candidates_per_step=bool(variants)),
