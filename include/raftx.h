@@ -269,6 +269,15 @@ int raftx_flex_solve(raftx_ctx *ctx, int nUnit, const int64_t *nodeOff, int n, c
                      double XiStart, raftx_c128 *Xi, int32_t *niter, int32_t *flags, double *B_drag, raftx_c128 *F_drag,
                      raftx_c128 *Z);
 
+/* The linearisation point the NEXT raftx_flex_solve starts from, instead of the constant XiStart (raft_model.py:999):
+ * XiLast0 [nUnit,nCase,n,nw], copied to the device; one-shot (consumed by that call, which fails if its shape differs).
+ * With nIter = 0 a call is then ONE pass of the loop body of raft_model.py:1058-1138 about a given iterate -- what a host
+ * step between iterations needs: a unit's own lumped-mass mooring (moorMod == 2) has its line damping re-linearised by the
+ * mooring model about every iterate (:1069-1072), also when the unit has more than 6 reduced DOFs (the matrices are lumped
+ * at its first six, :1019-1030).  The caller relaxes (XiLast <- 0.2 XiLast + 0.8 Xi[heading 0], :1133) and stops on flag
+ * bit 0.  NULL clears a point that was set and not used. */
+int raftx_flex_start(raftx_ctx *ctx, int nUnit, int n, const raftx_c128 *XiLast0);
+
 /* The same coupled solve fed from the RESIDENT results of raftx_solve_dynamics_device (which must have
  * kept Z and F_wave): consecutive groups of nUnit designs are the units of one array; for group g,
  * case c: Z_sys = blockdiag_u(Z[g*nUnit+u, c]) + (-w^2 Mc[g] + i w Bc[g] + Cc[g]),

@@ -725,7 +725,44 @@ def fixture_flexible():
     standin.save_fixture(os.path.join(GOLD, "flex_volturnus.npz"), fx)
 
 
-ALL = {"flexible": fixture_flexible, "f4": fixture_f4, "c5full": fixture_c5_full, "refstatics": fixture_ref_statics, "refmembers": fixture_ref_members, "bem": fixture_bem, "geom": fixture_geom, "c5oc4": fixture_c5_oc4, "c5": fixture_c5, "qtf": fixture_qtf, "c1": fixture_c1, "c2": fixture_c2, "pose": fixture_pose,
+def fixture_flexible_moor():
+    """The flexible deck with a unit-level lumped-mass mooring (moorMod == 2, raft_model.py:1019-1030,1069-1072): the mooring
+    model's matrices are lumped at the unit's first six reduced DOFs and its damping is re-linearised about every iterate.
+    MoorPy is absent here: the stand-in of tests/util.py (FakeLines: matrices that depend on the motions handed to
+    updateMooringDynamicMatrices) plays the mooring system for the LIVE reference; the device path must reproduce its
+    responses and iteration counts call for call.  The model is the one of flex_volturnus.npz."""
+    sys.path.insert(0, os.path.dirname(HERE))
+    from tests.util import FakeLines
+    raft = rh.import_raft()
+    name = "VolturnUS-S-flexible"
+    d = rh.prepare_design(rh.load_design(os.path.join(REF, "tests/test_data", name + ".yaml")))
+    fowt0 = raft.Model(d).fowtList[0]
+    cm = np.zeros((fowt0.nDOF, fowt0.nDOF))
+    cm[:6, :6] = rh.DEFAULT_C_MOOR
+    m = rh.build_model(d, c_moor=cm)
+    f = m.fowtList[0]
+    node_r = np.array(f.nodeList[f.reducedDOF[0][0]].r[:3], dtype=float)
+    arm = np.array([0.3, -0.2, -1.5])
+    f.ms = FakeLines(np.r_[node_r + arm, 0.0, 0.0, 0.0], f.w)
+    f.moorMod = 2
+    f.updateMooringDynamicMatrices = (lambda Xi, S, ms=f.ms: ms.update(Xi, S))
+    sols = []
+    for c, nit in ((rh.make_case(Hs=6.0, Tp=12.0, heading=15.0), 4), (rh.make_case(Hs=9.0, Tp=14.0, heading=200.0), 15),
+                   (rh.make_case(Hs=[6.0, 3.0], Tp=[12.0, 9.0], heading=[0.0, 30.0], spectrum=["JONSWAP", "JONSWAP"], gamma=[0, 0]), 15)):
+        m.nIter = nit
+        f.ms.calls = 0
+        r = run_case(m, c, lean=True)
+        r["nIter"] = nit
+        r["mooring_updates"] = int(f.ms.calls)
+        r["Z"] = np.array(f.Z)
+        sols.append(r)
+    fx = {"config": "VolturnUS-S-flexible with a moorMod == 2 stand-in mooring (tests/util.py FakeLines), live reference solveDynamics; "
+                    "model = tests/golden/flex_volturnus.npz",
+          "moor_arm": arm, "ref_node_r": node_r, "cases": sols}
+    standin.save_fixture(os.path.join(GOLD, "flex_moormod2.npz"), fx)
+
+
+ALL = {"flexmoor": fixture_flexible_moor, "flexible": fixture_flexible, "f4": fixture_f4, "c5full": fixture_c5_full, "refstatics": fixture_ref_statics, "refmembers": fixture_ref_members, "bem": fixture_bem, "geom": fixture_geom, "c5oc4": fixture_c5_oc4, "c5": fixture_c5, "qtf": fixture_qtf, "c1": fixture_c1, "c2": fixture_c2, "pose": fixture_pose,
        "refgold": fixture_ref_goldens, "c4": fixture_c4, "c3": fixture_c3}
 
 if __name__ == "__main__":

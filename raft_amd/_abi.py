@@ -31,7 +31,7 @@ EXPORTS = (
     "raftx_sweep_prepare",
     "raftx_sweep_launch",
     "raftx_sweep_wait",
-    "raftx_sweep_cancel", "raftx_device_count", "raftx_solve_dense_batch", "raftx_dense_resident", "raftx_solve_dense_resident", "raftx_flex_solve", "raftx_debug_flex_gemm",
+    "raftx_sweep_cancel", "raftx_device_count", "raftx_solve_dense_batch", "raftx_dense_resident", "raftx_solve_dense_resident", "raftx_flex_solve", "raftx_flex_start", "raftx_debug_flex_gemm",
     "raftx_comm_unique_id", "raftx_comm_init", "raftx_comm_destroy", "raftx_comm_broadcast", "raftx_comm_gather_rows",
     "raftx_comm_gather_xi", "raftx_comm_reduce_sum",
     "raftx_variant_program", "raftx_expand_variants", "raftx_sweep_prepare_variants",
@@ -127,6 +127,9 @@ class RaftxLib:
         L.raftx_flex_solve.argtypes = [_vp, C.c_int, _vp, C.c_int, _vp, _vp, _vp, _vp, C.c_int, _vp, C.c_int, C.c_double, C.c_double,
                                        _vp, _vp, _vp, _vp, _vp, _vp]
         L.raftx_flex_solve.restype = C.c_int
+        if hasattr(L, "raftx_flex_start"):
+            L.raftx_flex_start.argtypes = [_vp, C.c_int, C.c_int, _vp]
+            L.raftx_flex_start.restype = C.c_int
         L.raftx_debug_flex_gemm.argtypes = [_vp, C.c_int, C.c_int, _vp, _vp, _vp]
         L.raftx_debug_flex_gemm.restype = C.c_int
         L.raftx_device_locality.argtypes = [C.c_int, C.c_char_p, C.c_int, C.POINTER(C.c_int)]
@@ -966,6 +969,17 @@ class Context:
                                             _ptr(Fd), _ptr(Z))
         self._check(rc, "raftx_flex_solve")
         return {"Xi": Xi, "niter": niter, "flags": flags, "B_drag": Bd, "F_drag": Fd, "Z": Z}
+
+    def flex_start(self, XiLast0):
+        """The iterate the NEXT flex_solve starts from instead of XiStart (raftx_flex_start; one-shot): XiLast0
+        [nUnit,nCase,n,nw], or None to clear."""
+        if XiLast0 is None:
+            self._check(self.rlib.lib.raftx_flex_start(self._h, 0, 0, None), "raftx_flex_start")
+            return
+        X = _c128(XiLast0)
+        if X.ndim != 4:
+            raise ValueError("flex_start: XiLast0 must be [nUnit,nCase,n,nw]")
+        self._check(self.rlib.lib.raftx_flex_start(self._h, X.shape[0], X.shape[2], _ptr(X)), "raftx_flex_start")
 
     def debug_flex_gemm(self, A, W):
         """A^T W ([K,n] each, K a multiple of 6) through the projection kernel of raftx_flex_solve (test hook)."""

@@ -772,6 +772,8 @@ struct raftx_ctx {
     // resident results of the last raftx_solve_dynamics_device
     cplx *rXi, *rFw, *rZ, *rFe;
     double *rB, *rXl;
+    cplx *flexXl0;                       // raftx_flex_start: the linearisation point of the next raftx_flex_solve (device copy)
+    size_t flexXl0_n, flexXl0_cap;       // entries set (0: none) / allocated
     unsigned long long *rXlSlots;
     size_t rXl_n;
     int last_flags = -1, last_minb = 0, last_rc = 0;       // specialisation of the last fused-kernel launch (raftx_last_solve_kernel)
@@ -912,6 +914,8 @@ extern "C" int raftx_ctx_create(int device_id, raftx_ctx **out) {
     c->rXi = c->rFw = c->rZ = c->rFe = nullptr;
     c->rB = c->rXl = nullptr;
     c->rXlSlots = nullptr;
+    c->flexXl0 = nullptr;
+    c->flexXl0_n = c->flexXl0_cap = 0;
     c->rXl_n = 0;
     c->rQtf = nullptr;
     c->rQtf_n = 0;
@@ -998,6 +1002,7 @@ extern "C" void raftx_ctx_destroy(raftx_ctx *c) {
     c->pool.trim();
     if (c->rXl) (void)hipFree(c->rXl);
     if (c->rXlSlots) (void)hipFree(c->rXlSlots);
+    if (c->flexXl0) (void)hipFree(c->flexXl0);
     if (c->rXl0) (void)hipFree(c->rXl0);
     if (c->rXlOut) (void)hipFree(c->rXlOut);
     if (c->rQtf) (void)hipFree(c->rQtf);
@@ -2494,6 +2499,32 @@ extern "C" int raftx_solve_dense_resident(raftx_ctx *c, int nPer, const double *
     return 0;
 }
 
+// include/raftx.h raftx_flex_start: the next raftx_flex_solve starts from this iterate (one-shot)
+extern "C" int raftx_flex_start(raftx_ctx *c, int nUnit, int n, const raftx_c128 *XiLast0) {
+    if (!c) return -1;
+    c->flexXl0_n = 0;
+    if (!XiLast0) return 0;
+    if (check_ready(c)) return -1;
+    const DevTables &T = c->T;
+    if (nUnit < 1 || n < 6) FAIL(c, "flex_start: bad arguments (nUnit=%d, n=%d)", nUnit, n);
+    HIPCHK(c, hipSetDevice(c->device));
+    const size_t need = (size_t)nUnit * T.nCase * n * T.nw;
+    if (need > c->flexXl0_cap) {
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        if (c->flexXl0) (void)hipFree(c->flexXl0);
+        c->flexXl0 = nullptr;
+        c->flexXl0_cap = 0;
+        void *p_ = nullptr;
+        HIPCHK(c, hipMalloc(&p_, need * sizeof(cplx)));
+        c->flexXl0 = reinterpret_cast<cplx *>(p_);
+        c->flexXl0_cap = need;
+    }
+    H2D(c, c->flexXl0, XiLast0, need * sizeof(cplx));
+    HIPCHK(c, hipStreamSynchronize(c->stream));           // the caller's array is free again
+    c->flexXl0_n = need;
+    return 0;
+}
+
 // The fixed point of flexible units on the device (raftx_flex.h; include/raftx.h raftx_flex_solve).
 extern "C" int raftx_flex_solve(raftx_ctx *c, int nUnit, const int64_t *nodeOff, int n, const double *Tn, const double *M,
                                 const double *B, const double *C, int freq_mask, const raftx_c128 *F_lin, int nIter, double tol,
@@ -2554,7 +2585,14 @@ extern "C" int raftx_flex_solve(raftx_ctx *c, int nUnit, const int64_t *nodeOff,
         HIPCHK(c, hipStreamSynchronize(c->stream));                       // (the host vectors above go out of scope)
     }
     const size_t nxl = (size_t)nSys * nxs;
-    hipLaunchKernelGGL(k_flex_fill, dim3((unsigned)((nxl + 255) / 256)), dim3(256), 0, c->stream, nxl, cplx{XiStart, 0.0}, dXl);   // :999
+    if (c->flexXl0_n) {                                                   // raftx_flex_start: an explicit iterate, one-shot
+        const size_t had = c->flexXl0_n;
+        c->flexXl0_n = 0;
+        if (had != nxl) FAIL(c, "flex_solve: the linearisation point of raftx_flex_start has %zu entries, this call %zu", had, nxl);
+        HIPCHK(c, hipMemcpyAsync(dXl, c->flexXl0, nxl * sizeof(cplx), hipMemcpyDeviceToDevice, c->stream));
+    } else {
+        hipLaunchKernelGGL(k_flex_fill, dim3((unsigned)((nxl + 255) / 256)), dim3(256), 0, c->stream, nxl, cplx{XiStart, 0.0}, dXl);   // :999
+    }
     hipEvent_t e0 = c->evG2, e1 = c->evG3;                                // (free here: the span of the whole fixed point)
     HIPCHK(c, hipEventRecord(e0, c->stream));
     const int nt = (n + 15) / 16;

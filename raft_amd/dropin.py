@@ -16,12 +16,17 @@ read here (that is how the GPU-box tests run without /root/reference).
 are mirrored too (internal slender-body QTFs, potSecOrder == 1, incl. the re-entry of the drag iteration with the
 second-order force, raft_model.py:1108-1131).
 
-Not covered by the device path (raises, never falls back silently):
-flexible / >6-DOF FOWTs, submerged rotors, array-level moorMod==2.
-A unit's own moorMod==2 mooring (per-iteration line damping from MoorPy, raft_model.py:1022-1030,1069-1072) is
-honoured by stepping the fixed point one device launch per iteration (Engine._solve_stepped).
-Per-member intermediates (mem.u, mem.ud, mem.pDyn, mem.Bmat, mem.F_exc_drag)
-are consumed only inside the replaced methods and are not materialised.
+On the device path too: units with more than 6 reduced DOFs (flexible members; Engine._solve_general, raftx_flex_solve),
+potential-flow coefficients on either kind of unit, submerged rotors on any unit of an array, arrays with a shared
+lumped-mass mooring (array-level moorMod == 2, raft_model.py:1173-1182).  A unit's own moorMod == 2 mooring (per-iteration
+line damping from the mooring model, raft_model.py:1019-1030,1069-1072) is honoured by stepping the fixed point one device
+launch per iteration from an explicit linearisation point (Engine._solve_stepped; for units with more than 6 reduced DOFs
+the stepped branch of Engine._solve_general, raftx_flex_start).
+Per-member intermediates (mem.u, mem.ud, mem.pDyn, mem.F_hydro_iner, mem.Bmat, mem.F_exc_drag) are never needed by the
+replaced methods; ``install(materialise_members=True)`` fills them from a device export for un-replaced callers.
+
+Not covered (raises UnsupportedFOWT, never falls back silently): arrays of units with more than 6 reduced DOFs,
+second-order loads on such units (stubs upstream), moorMod == 2 together with internal QTFs, a dry unit with moorMod == 2.
 """
 import numpy as np
 
@@ -152,8 +157,8 @@ class Engine:
             # The second-order branches of such units are stubs upstream (calcQTF_slenderBody returns zeros for nDOF > 6)
             if int(getattr(fowt, "potSecOrder", 0)) != 0:
                 raise UnsupportedFOWT("second-order loads on a unit with %d reduced DOFs" % fowt.nDOF)
-            if _dynamic_mooring(fowt):
-                raise UnsupportedFOWT("moorMod==2 on a unit with %d reduced DOFs" % fowt.nDOF)
+            # a unit-level lumped-mass mooring (moorMod == 2) is lumped at the first six reduced DOFs (raft_model.py:1019-1030)
+            # and re-linearised about every iterate (:1069-1072): _solve_general steps the fixed point, one launch per iteration
 
     # ------------------------------------------------------------------ units with more than 6 reduced DOFs
     def _node_units(self, fowt, members):
@@ -238,9 +243,19 @@ class Engine:
         fowt.Fhydro_2nd = np.zeros([fowt.nWaves, n, nw], dtype=complex)      # :1035-1036
         fowt.Fhydro_2nd_mean = np.zeros([fowt.nWaves, n])
         B_gyro = np.sum(fowt.B_gyro, axis=2)
+        C_moor, dyn = fowt.C_moor, _dynamic_mooring(fowt)
         M_lin = fowt.M_struc + fowt.A_hydro_morison                          # :1045-1047
+        if dyn:                                                              # :1022-1030: M, A, C of the lines about XiStart
+            XiLast0 = np.zeros([n, nw], dtype=complex) + model.XiStart
+            fowt.updateMooringDynamicMatrices(XiLast0[:6], fowt.S[0, :])
+            M6, A6, _, C6 = fowt.ms.getCoupledDynamicMatrices(lines_only=True)
+            arm = _mooring_arm(fowt)
+            M_moor, C_moor = np.zeros([n, n]), np.zeros([n, n])
+            M_moor[:6, :6] = translate_matrix_6to6(M6, arm) + translate_matrix_6to6(A6, arm)
+            C_moor[:6, :6] = translate_matrix_6to6(C6, arm)
+            M_lin = M_lin + M_moor
         B_lin = fowt.B_struc + B_gyro
-        C_lin = fowt.C_struc + fowt.C_hydro + fowt.C_moor + fowt.C_elast
+        C_lin = fowt.C_struc + fowt.C_hydro + C_moor + fowt.C_elast
         A_BEM, B_BEM = np.asarray(getattr(fowt, "A_BEM", 0.0)), np.asarray(getattr(fowt, "B_BEM", 0.0))
         if _nonzero(M_turb) or _nonzero(A_BEM):
             M_lin = M_turb + M_lin[:, :, None] + (A_BEM if _nonzero(A_BEM) else 0.0)       # :1045
@@ -253,7 +268,34 @@ class Engine:
         rows, tables, Tn = fowt._raftx_nodes
         nH = fowt.nWaves
         F_lin = fowt.F_BEM + fowt.F_hydro_iner + fowt.Fhydro_2nd             # :1048, 1212 without the drag excitation
-        if tables:
+        if dyn and not tables:
+            raise UnsupportedFOWT("moorMod==2 on a unit with %d reduced DOFs and no wet strips" % n)
+        if tables and dyn:
+            # :1069-1072: the lines' damping about every iterate -- a host step between iterations, so the fixed point is
+            # stepped: one launch per iteration (loop bound 1) from an explicit linearisation point (raftx_flex_start), the
+            # relaxation of :1133 here; the launch of the last iteration leaves every heading's response and Z as :1155-1236 do
+            self._upload([fowt], fowt.zeta, fowt.beta, tables=tables)
+            XiLast = np.zeros([1, 1, n, nw], dtype=complex) + model.XiStart
+            conv, nit, out = False, 0, None
+            for iiter in range(int(model.nIter) + 1):                         # :977
+                fowt.updateMooringDynamicMatrices(XiLast[0, 0, :6, :], fowt.S[0, :])          # :1070
+                _, _, B6, _ = fowt.ms.getCoupledDynamicMatrices(lines_only=True)
+                B_moor = np.zeros([n, n])
+                B_moor[:6, :6] = translate_matrix_6to6(B6, arm)                              # :1072
+                B_it = B_lin + (B_moor if B_lin.ndim == 2 else B_moor[:, :, None])            # :1079
+                ctx.flex_start(XiLast)
+                out = ctx.flex_solve([0, len(rows)], Tn, M_lin[None], B_it[None], C_lin[None], F_lin[None, None], 0, tol,
+                                     model.XiStart, want_Z=True)
+                nit = iiter + 1
+                if int(out["flags"][0, 0]) & 2:
+                    break
+                if int(out["flags"][0, 0]) & 1:
+                    conv = True
+                    break
+                XiLast[0, 0] = 0.2 * XiLast[0, 0] + 0.8 * out["Xi"][0, 0, 0]                 # :1133
+            out["niter"][0, 0] = nit
+            out["flags"][0, 0] = (int(out["flags"][0, 0]) & ~1) | (1 if conv else 0)
+        elif tables:
             self._upload([fowt], fowt.zeta, fowt.beta, tables=tables)         # no-op while these tables are resident
             out = ctx.flex_solve([0, len(rows)], Tn, M_lin[None], B_lin[None], C_lin[None], F_lin[None, None], int(model.nIter), tol,
                                  model.XiStart, want_Z=True)

@@ -472,3 +472,52 @@ def test_installed_flexible_solveDynamics_equals_numpy_path(oracle_ctx):
     Bo = fo.calcHydroLinearization(fn.Xi[0])                                    # the reference's own methods again
     Fo = fo.calcDragExcitation(0)
     assert rel_err(Bn, Bo) < 1e-10 and rel_err(Fn, Fo) < 1e-10
+
+
+def _check_flexible_dynamic_mooring(ctx):
+    """A unit with more than 6 reduced DOFs and its own lumped-mass mooring (moorMod == 2, raft_model.py:1019-1030,1069-1072):
+    the mooring model's M, A, C lumped at the first six reduced DOFs about XiStart, its damping re-linearised about EVERY
+    iterate -- the drop-in steps the device fixed point one launch per iteration from an explicit linearisation point
+    (raftx_flex_start).  Against the LIVE reference's solveDynamics on the flexible deck with the same stand-in mooring
+    (tests/golden/flex_moormod2.npz, oracle/make_golden.py flexmoor): responses of every heading, the impedance of the
+    last iteration, iteration counts and the number of mooring updates; the iteration cap."""
+    from tests.util import attach_fake_lines_at
+    from raft_amd.snapshot import load_fixture
+    gold = load_fixture("flex_moormod2.npz")
+    _, model = load_model_fixture("flex_volturnus.npz")
+    ms = attach_fake_lines_at(model, gold["moor_arm"])
+    eng = dropin.Engine(ctx)
+    seen = set()
+    for c in gold["cases"]:
+        model.nIter = int(c["nIter"])
+        ms.calls = 0
+        Xi = eng.solveDynamics(model, case_from_fixture(c))
+        nH = c["Xi"].shape[0]
+        assert Xi.shape == (nH + 1, 150, model.nw) and not np.any(Xi[nH])
+        assert int(model._raftx_niter[0]) == int(c["units"][0]["niter"])
+        assert ms.calls == int(c["mooring_updates"])                          # one about XiStart + one per iteration
+        assert rel_err(Xi[:nH], c["Xi"]) < 1e-8
+        assert rel_err(model.fowtList[0].Z, c["Z"]) < 1e-10
+        assert rel_err(model.fowtList[0].B_hydro_drag, c["units"][0]["B_hydro_drag"]) < 1e-9
+        seen.add(bool(model._raftx_flags[0] & 1))
+    assert seen == {True}
+    model.nIter = 1                                                           # the iteration cap: two passes, flagged unconverged
+    ms.calls = 0
+    eng.solveDynamics(model, case_from_fixture(gold["cases"][1]))
+    assert int(model._raftx_niter[0]) == 2 and not (model._raftx_flags[0] & 1) and ms.calls == 3
+    # the explicit start is one-shot and shape-checked
+    fowt = model.fowtList[0]
+    rows, tables, Tn = fowt._raftx_nodes
+    ctx.flex_start(np.zeros((2, 1, 150, model.nw), dtype=complex))
+    with pytest.raises(Exception, match="linearisation point"):
+        ctx.flex_solve([0, len(rows)], Tn, np.eye(150)[None], np.eye(150)[None], np.eye(150)[None],
+                       np.zeros((1, 1, fowt.nWaves, 150, model.nw), dtype=complex), 0, 0.01, 0.1)
+
+
+def test_oracle_flexible_unit_with_dynamic_mooring(oracle_ctx):
+    _check_flexible_dynamic_mooring(oracle_ctx)
+
+
+@pytest.mark.gpu
+def test_hip_flexible_unit_with_dynamic_mooring(hip_ctx):
+    _check_flexible_dynamic_mooring(hip_ctx)

@@ -157,3 +157,17 @@ def attach_fake_array_lines(model):
     model.ms = FakeArrayLines(len(model.fowtList), model.w)
     model.moorMod = 2
     model.updateMooringDynamicMatrices = (lambda Xi, S, ms=model.ms: ms.update(Xi, S))
+
+
+def attach_fake_lines_at(model, arm):
+    """FakeLines on the (single) unit of ``model`` with the mooring body ``arm`` away from the unit's reduced-DOF reference
+    node (raft_model.py:1027) -- for stand-in units whose golden was made with that arm on the live object
+    (tests/golden/flex_moormod2.npz: the reference's flexible deck)."""
+    f = model.fowtList[0]
+    node = standin.Obj()
+    node.r = np.zeros(3)
+    f.nodeList, f.reducedDOF = [node], [[0, 0]]
+    f.ms = FakeLines(np.r_[np.asarray(arm, dtype=float), 0.0, 0.0, 0.0], f.w)
+    f.moorMod = 2
+    f.updateMooringDynamicMatrices = (lambda Xi, S, ms=f.ms: ms.update(Xi, S))
+    return f.ms
