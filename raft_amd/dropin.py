@@ -25,8 +25,9 @@ the stepped branch of Engine._solve_general, raftx_flex_start).
 Per-member intermediates (mem.u, mem.ud, mem.pDyn, mem.F_hydro_iner, mem.Bmat, mem.F_exc_drag) are never needed by the
 replaced methods; ``install(materialise_members=True)`` fills them from a device export for un-replaced callers.
 
-Not covered (raises UnsupportedFOWT, never falls back silently): arrays of units with more than 6 reduced DOFs,
-second-order loads on such units (stubs upstream), moorMod == 2 together with internal QTFs, a dry unit with moorMod == 2.
+Not covered (raises UnsupportedFOWT, never falls back silently): arrays of units with more than 6 reduced DOFs (upstream
+cannot build them: an array's per-unit design drops `joints`, raft_model.py:113-137, raft_fowt.py:205), second-order loads on
+such units (stubs upstream), moorMod == 2 together with internal QTFs, a dry unit with moorMod == 2.
 """
 import numpy as np
 
