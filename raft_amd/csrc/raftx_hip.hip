@@ -195,14 +195,12 @@ __global__ void __launch_bounds__(256) k_solve_system(int nSys, int nUnit, int n
 // 0-31 and 32-63), the whole row -- n complex entries plus up to four right-hand sides -- in the lane's registers.  The
 // elimination is unrolled over the column k, so every register index is static; partial pivoting is implicit (the pivot
 // row stays where it is and is marked done: the same pivot rows, multipliers and updates as zgetrf's interchanges,
-// raft_model.py:1191), the pivot search is a five-step argmax within the half-wave, the pivot row reaches the other rows
-// by ds_bpermute.  ~3.5 k instructions per PAIR of systems against ~10 k per system of the LDS-resident kernel above
-// (whose update loop spends its time on index arithmetic, and whose assembly through LDS is a chain of dependent loads).
-template <typename T>
-__device__ __forceinline__ T half_bcast(T v, int src_lane) {          // value of lane src_lane (per-lane choice)
-    return __shfl(v, src_lane, 64);
-}
-__device__ __forceinline__ cplx half_bcast(cplx v, int src_lane) { return {__shfl(v.re, src_lane, 64), __shfl(v.im, src_lane, 64)}; }
+// raft_model.py:1191), the pivot search is a two-phase 32-bit DPP argmax within the half-wave, the pivot row reaches the other
+// rows through a row buffer in LDS (its owner lane stores it, everyone reads it back as a broadcast).  ~3.7 k VALU
+// instructions per PAIR of systems against ~10 k per system of the LDS-resident kernel above (whose update loop spends its
+// time on index arithmetic, and whose assembly through LDS is a chain of dependent loads).  What bounds it -- the LDS STORE
+// path: 24 of its 60 ms per 10^7 systems, measured with the stores compiled out; a software-pipelined publication of the
+// next pivot row between the FMAs measured 16 % slower -- is in DESIGN.md 3.3 and profiles/r05_lu_store_experiment.json.
 #define SYSROWS_MAXRHS 4
 // ASM (resident form only): the units' 6 x 6 impedance blocks are ASSEMBLED here, Z = -w^2 M0 + i w (B0 + B_drag) + C0 with the
 // unit kernel's own expression (assemble_and_solve: fma(-w^2, M, C), w * (B0 + Bd) -- the same bits), from 36 x 4 doubles
