@@ -270,7 +270,7 @@ __device__ __forceinline__ ldptr vsq_of(const Lds &l, int wv, int nwv, int S, in
     stride = 12;
     return l.uv + (wv - 1) * 3;
 }
-// shapes that keep XiLast in a per-pair global slab (SolveArgs::Xl) instead of LDS: the largest ones (no room), and the
+// shapes that keep XiLast in global scratch (SolveArgs::Xl, a region per RUNNING workgroup: xl_slot_acquire) instead of LDS: the largest ones (no room), and the
 // two-waves-per-SIMD 200-bin shape, whose LDS goes to the run-start cache instead (XiLast is touched twice per
 // iteration, the run starts fourteen times)
 static __host__ __device__ constexpr bool xl_global(int nb, int maxt) { return (maxt == 512 && nb >= 3) || (maxt == 128 && nb == 2); }
@@ -2612,7 +2612,8 @@ struct SolveArgs {
 };
 
 // The fused fixed point (raft_model.py:1052-1142) + per-heading response (:1189-1236).
-// Storage plan: XiLast lives in LDS (read once per pass A, once per convergence test).
+// Storage plan: XiLast lives in LDS (read once per pass A, once per convergence test) -- or, for the shapes of xl_global(), in a
+// global scratch region the workgroup holds while it runs (read and written once per iteration).
 // F_lin (raft_model.py:1048) is parked in the pair's own heading-0 slab of the Xi OUTPUT
 // buffer until the final iterate overwrites it -- each lane re-reads only what it wrote,
 // so no extra HBM footprint and no synchronisation is needed.  The 6x6 systems of a lane's
