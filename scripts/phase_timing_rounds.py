@@ -21,7 +21,7 @@ for n in (1024, 2048, 10000, 30000):
     out = (ctypes.c_ulonglong * 8)()
     assert lib.lib.raftx_debug_phase_cycles(ctx._h, out) == 0
     pit = float(np.sum(r["niter"]))
-    v = np.array(list(out), dtype=float) / reps / pit
+    v = np.array(list(out), dtype=float) / pit                 # (the counters are zeroed at every launch: the last one's)
     res[n] = v
     print("n = %5d: kernel %.3f ms, %.1f ns per (pair, iteration); cycles per (pair, iteration): %s" %
           (n, ms, 1e6 * ms / pit, "  ".join("%s %.0f" % (nm, x) for nm, x in zip(names, v) if x)))
