@@ -49,6 +49,8 @@ Also on the JSON line:
                     MacCamy-Fuchs columns): resident kernel time per pair-iteration
                     against the plain sweep's, a sample checked against the oracle.
 
+  launch_size       the same fused kernel on resident launches of 20 000 and 40 000 pairs: what a launch costs beyond its pairs
+                    (the shader clock comes up during the first millisecond; DESIGN.md 3.1);
   roofline.traffic  the fused kernel's L2 <-> fabric bytes per launch, measured BY this run (N = 1): two child runs of this script
                     under `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` (separate passes, counters only; live_traffic);
                     the committed profile's figure, labelled as such, where that is not possible.
@@ -674,7 +676,7 @@ def main():
                                                       "(the gap between fused kernels shrinks 0.35 -> 0.2 ms, the kernels sharing the drain slow each "
                                                       "other by as much), so it is not the default")
     ap.add_argument("--no-extra-legs", action="store_true", help="skip the legs outside the headline (xi-out, featured sweeps)")
-    ap.add_argument("--legs", default="xi,featured,configs,hostdesc,traffic", help="which legs outside the headline run (comma list of xi, featured, configs, hostdesc, "
+    ap.add_argument("--legs", default="xi,featured,configs,hostdesc,traffic,launchsize", help="which legs outside the headline run (comma list of xi, featured, configs, hostdesc, launchsize, "
                                                                             "traffic = the FETCH_SIZE / WRITE_SIZE passes of roofline.traffic, two child runs under rocprofv3)")
     ap.add_argument("--profile", action="store_true", help="for runs under rocprofv3: whole-batch launches only (--chunks 1), no isolated / "
                                                             "extra / oracle legs -- ONE population of k_solve_dynamics launches in the trace")
@@ -1060,6 +1062,32 @@ def main():
         cfg_legs["c5_qtf"] = guarded("c5_qtf", lambda: bench_legs.c5_qtf(ctx))
         cfg_legs["flex_sweep"] = guarded("flex_sweep", lambda: bench_legs.flex_sweep(ctx))
 
+    # ---- the fused kernel against the size of its launch (N = 1): the same designs' stream, 20 000 and 40 000 pairs resident.
+    # BASELINE's configuration is 10 000 pairs per GPU = 2.8 ms per launch, most of which the shader clock spends coming up
+    # (profiles/r05_launch_size_scaling.json); these two figures say what the kernel does once it has.
+    launch_size = None
+    if rank == 0 and world == 1 and not args.no_extra_legs and "launchsize" in args.legs:
+        def run_launch_size():
+            res = {}
+            for n_ in (20000, 40000):
+                sw2, _, _ = make_sweep(ctx, n_, 0, pinned=False)
+                sw2.upload(ctx)
+                ks = []
+                for i in range(4):
+                    ctx.solve_dynamics_device(sw2.nIter, sw2.tol, sw2.XiStart)
+                    if i:
+                        ks.append(ctx.last_kernel_ms())
+                r2 = ctx.fetch_results(want_Xi=False)
+                k2 = float(np.mean(ks))
+                fl2 = algorithmic_flops(sw2.off, nw, r2["niter"])
+                res[str(n_)] = {"pairs_per_launch": n_, "kernel_ms": k2, "us_per_pair": 1e3 * k2 / n_, "mean_iterations": float(np.mean(r2["niter"])),
+                                "dcf_per_s": n_ * nw / (k2 * 1e-3), "fp64_valu_frac": fl2 / (k2 * 1e-3) / 1e12 / FP64_VALU_PEAK_TF}
+                del sw2, r2
+            res["note"] = ("the SAME kernel on launches of 20 000 / 40 000 pairs (resident in, resident out): a launch starts at a lower shader clock, "
+                           "which rises after about a millisecond of sustained load -- T(n) ~ 0.33 ms + 0.251 us n (profiles/r05_launch_size_scaling.json)")
+            return res
+        launch_size = guarded("launch_size", run_launch_size)
+
     # ---- roofline.traffic: measured in THIS run where rocprofv3 is at hand (N = 1), else the committed profile's figure
     traffic_bytes, traffic_prov = measured_traffic(nD), traffic_provenance()
     if rank == 0 and world == 1 and not args.no_extra_legs and not args.profile and "traffic" in args.legs:
@@ -1148,6 +1176,8 @@ def main():
                                         "(upload of all descriptors on the critical path)"}
     if resident is not None:
         out["kernel_resident"] = resident
+    if launch_size is not None:
+        out["launch_size"] = launch_size
     if xi_leg is not None:
         out["xi_out"] = xi_leg
     if featured is not None:
