@@ -35,7 +35,7 @@ echo "-- the runtime is live in the python process and the library's accesses ar
 ( LD_PRELOAD="$RT" ASAN_OPTIONS=$ASAN_OPTIONS:verbosity=1:log_path=stderr python -c "import ctypes, os; ctypes.CDLL(os.environ['RAFTX_HIP_LIB'])" 2>&1 | grep -m1 "Init done" )
 nm -D $LIB | grep -c " U __asan_report_\| U __ubsan_handle_" | sed 's/^/   instrumentation call sites: distinct __asan_report_* \/ __ubsan_handle_* imports = /'
 ( LD_PRELOAD="$RT" timeout 1200 python -m pytest tests/test_geometry.py tests/test_hip_comm.py tests/test_hip_parity.py tests/test_flexible.py -m gpu -x -q \
-    -k "streamed or crossing or comm or featured or ragged or singular or dense or flex or variant or farm or strip_exports or exchange" 2>&1 | tail -6 )
+    -k "streamed or crossing or comm or featured or ragged or singular or dense or flex or variant or farm or strip_exports or exchange or mooring" 2>&1 | tail -6 )
 echo "== 300-step soak of the streamed crossing (bench.py --no-cpu-baseline --no-extra-legs --steps 300)"
 ( LD_PRELOAD="$RT" timeout 900 python bench.py --no-cpu-baseline --no-extra-legs --steps 300 --warmup 3 2>&1 | tail -1 | cut -c1-260 )
 echo "== 40 steps with the responses downloaded (four batches in flight)"
