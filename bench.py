@@ -50,7 +50,7 @@ Also on the JSON line:
                     against the plain sweep's, a sample checked against the oracle.
 
   launch_size       the same fused kernel on resident launches of 20 000 and 40 000 pairs: what a launch costs beyond its pairs
-                    (the shader clock comes up during the first millisecond; DESIGN.md 3.1);
+                    (its last residency round drains, and a long launch runs at a few per cent more clock; DESIGN.md 3.1);
   roofline.traffic  the fused kernel's L2 <-> fabric bytes per launch, measured BY this run (N = 1): two child runs of this script
                     under `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` (separate passes, counters only; live_traffic);
                     the committed profile's figure, labelled as such, where that is not possible.
@@ -1063,8 +1063,9 @@ def main():
         cfg_legs["flex_sweep"] = guarded("flex_sweep", lambda: bench_legs.flex_sweep(ctx))
 
     # ---- the fused kernel against the size of its launch (N = 1): the same designs' stream, 20 000 and 40 000 pairs resident.
-    # BASELINE's configuration is 10 000 pairs per GPU = 2.8 ms per launch, most of which the shader clock spends coming up
-    # (profiles/r05_launch_size_scaling.json); these two figures say what the kernel does once it has.
+    # BASELINE's configuration is 10 000 pairs per GPU = 9.77 residency rounds: the last one drains with nothing left to hand out
+    # (914 of 1 024 slots busy on average; DESIGN.md 3.1, profiles/r05_launch_size_scaling.json); these two figures say what the
+    # kernel does when a launch is long enough for that not to matter.
     launch_size = None
     if rank == 0 and world == 1 and not args.no_extra_legs and "launchsize" in args.legs:
         def run_launch_size():
@@ -1083,8 +1084,8 @@ def main():
                 res[str(n_)] = {"pairs_per_launch": n_, "kernel_ms": k2, "us_per_pair": 1e3 * k2 / n_, "mean_iterations": float(np.mean(r2["niter"])),
                                 "dcf_per_s": n_ * nw / (k2 * 1e-3), "fp64_valu_frac": fl2 / (k2 * 1e-3) / 1e12 / FP64_VALU_PEAK_TF}
                 del sw2, r2
-            res["note"] = ("the SAME kernel on launches of 20 000 / 40 000 pairs (resident in, resident out): a launch starts at a lower shader clock, "
-                           "which rises after about a millisecond of sustained load -- T(n) ~ 0.33 ms + 0.251 us n (profiles/r05_launch_size_scaling.json)")
+            res["note"] = ("the SAME kernel on launches of 20 000 / 40 000 pairs (resident in, resident out): the drain of the last residency round and the "
+                           "idle of a slot between workgroups weigh less, the clock is a few per cent higher -- T(n) ~ 0.33 ms + 0.251 us n (profiles/r05_launch_size_scaling.json)")
             return res
         launch_size = guarded("launch_size", run_launch_size)
 

@@ -1909,10 +1909,11 @@ static int solve_enqueue(raftx_ctx *c, int nIter, double tol, double XiStart, co
 #ifdef RAFTX_PHASE_TIMING
     if (!c->dbg) {
         void *p_ = nullptr;
-        HIPCHK(c, hipMalloc(&p_, 8 * sizeof(unsigned long long)));
+        HIPCHK(c, hipMalloc(&p_, (10 + 2 * PT_CLOCK_BUCKETS) * sizeof(unsigned long long)));
         c->dbg = reinterpret_cast<unsigned long long *>(p_);
     }
-    HIPCHK(c, hipMemsetAsync(c->dbg, 0, 8 * sizeof(unsigned long long), c->stream));
+    HIPCHK(c, hipMemsetAsync(c->dbg, 0, (10 + 2 * PT_CLOCK_BUCKETS) * sizeof(unsigned long long), c->stream));
+    HIPCHK(c, hipMemsetAsync(c->dbg + 8, 0xFF, sizeof(unsigned long long), c->stream));      // earliest start: a minimum
     A.dbg = c->dbg;
 #endif
     if (F_extra && c->r_nx) H2D(c, c->rFe, F_extra, c->r_nx * sizeof(cplx));
@@ -3917,6 +3918,13 @@ extern "C" int raftx_comm_reduce_sum(raftx_ctx *c, double *buf, size_t n, int ro
 extern "C" int raftx_debug_phase_cycles(raftx_ctx *c, unsigned long long *out8) {
     if (!c || !out8 || !c->dbg) return -1;
     HIPCHK(c, hipMemcpy(out8, c->dbg, 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    return 0;
+}
+// timing builds: the clock trace of the last fused launch -- out[2 b], out[2 b + 1] = shader cycles, 100 MHz ticks of the
+// workgroups that started in the b-th 125 us of the launch (PT_FLUSH); n_bucket <= 64
+extern "C" int raftx_debug_clock_trace(raftx_ctx *c, unsigned long long *out, int n_bucket) {
+    if (!c || !out || !c->dbg || n_bucket < 1 || n_bucket > PT_CLOCK_BUCKETS) return -1;
+    HIPCHK(c, hipMemcpy(out, c->dbg + 10, 2 * (size_t)n_bucket * sizeof(unsigned long long), hipMemcpyDeviceToHost));
     return 0;
 }
 #endif

@@ -618,7 +618,15 @@ __device__ __forceinline__ void kin_reset(Kin<NB> &K, const RunCache &rc) {
 
 // ------------------------------------------------------------------ strip sweeps
 #ifdef RAFTX_PHASE_TIMING
-#define PT_DECL unsigned long long pt_[8] = {0, 0, 0, 0, 0, 0, 0, 0}, pt_t = __builtin_readcyclecounter()
+#define PT_DECL unsigned long long pt_[8] = {0, 0, 0, 0, 0, 0, 0, 0}, pt_t = __builtin_readcyclecounter(), pt_c0 = pt_t, pt_w0 = wall_clock64()
+// clock trace (timing builds): dbg[8] = earliest workgroup start of the launch (100 MHz ticks), dbg[10 + 2 b], dbg[11 + 2 b] =
+// shader cycles / 100 MHz ticks summed over the workgroups that STARTED in the b-th 125 us of the launch: cycles / ticks x 100 MHz
+// is the shader clock those workgroups lived at
+#define PT_CLOCK_BUCKETS 64
+#define PT_BEGIN(A)                                                                    \
+    do {                                                                               \
+        if ((A).dbg && threadIdx.x == 0) atomicMin((A).dbg + 8, pt_w0);                \
+    } while (0)
 #define PT_MARK(i)                                              \
     do {                                                        \
         unsigned long long n_ = __builtin_readcyclecounter();   \
@@ -627,8 +635,15 @@ __device__ __forceinline__ void kin_reset(Kin<NB> &K, const RunCache &rc) {
     } while (0)
 #define PT_FLUSH(A)                                                                    \
     do {                                                                               \
-        if ((A).dbg && threadIdx.x == 0)                                               \
+        if ((A).dbg && threadIdx.x == 0) {                                             \
             for (int i_ = 0; i_ < 8; i_++) atomicAdd((A).dbg + i_, pt_[i_]);          \
+            const unsigned long long c1_ = __builtin_readcyclecounter(), w1_ = wall_clock64();                       \
+            const unsigned long long t0_ = atomicAdd((A).dbg + 8, 0ull);              \
+            unsigned long long b_ = (pt_w0 - t0_) / 12500ull;                          \
+            if (b_ >= PT_CLOCK_BUCKETS) b_ = PT_CLOCK_BUCKETS - 1;                     \
+            atomicAdd((A).dbg + 10 + 2 * b_, c1_ - pt_c0);                             \
+            atomicAdd((A).dbg + 11 + 2 * b_, w1_ - pt_w0);                             \
+        }                                                                              \
     } while (0)
 #define PT_ARG , unsigned long long *pt_, unsigned long long &pt_t
 #define PT_PASS , pt_, pt_t
@@ -636,6 +651,7 @@ __device__ __forceinline__ void kin_reset(Kin<NB> &K, const RunCache &rc) {
 #define PT_ARG
 #define PT_PASS
 #define PT_DECL
+#define PT_BEGIN(A)
 #define PT_MARK(i)
 #define PT_FLUSH(A)
 #endif
@@ -2632,6 +2648,7 @@ __global__ void __launch_bounds__(MAXT, MINB) k_solve_dynamics(DevTables T, Solv
         if (!pair_ctx(T, p, A.pairs ? A.pairs[idx] : idx)) return;
     }
     PT_DECL;
+    PT_BEGIN(A);
     const bool multi = blockDim.x > 64;
     const int nw = T.nw, nHs = T.nHead, nH = MULTI ? T.nHead : 1;
     const int pair = p.pair, S = p.S;
