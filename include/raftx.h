@@ -494,6 +494,13 @@ int raftx_sweep_submit(raftx_ctx *ctx, int slot, int nDesign, const int64_t *mem
                        int nIter, double tol, double XiStart, int nChunk,
                        double *std, int32_t *niter, int32_t *flags, raftx_c128 *Xi, int64_t *stripOffsets);
 int raftx_sweep_wait(raftx_ctx *ctx, int slot, double *timing_ms);
+/* Where on the device's clock the fused fixed point of the crossing LAST WAITED FOR on `slot` ran: start of its first
+ * launch and end of its last one, in ms since the first crossing of this ctx was launched.  Crossings of consecutive
+ * slots run on alternating streams and their fused kernels overlap (the drain of batch i is the ramp of batch i+1), so
+ * the busy time of k_solve_dynamics over a stream of batches is the UNION of these spans, not the sum of the per-batch
+ * durations of timing_ms[2] (bench.py: roofline.kernel_ms_per_step).  The CPU oracle returns zeros.
+ * (the loop the kernel fuses: raft/raft_model.py:1052-1142) */
+int raftx_sweep_solve_span(raftx_ctx *ctx, int slot, double *start_ms, double *end_ms);
 /* Retires a batch that was prepared and will not be launched (its uploads and member pass are drained, its scratch is
  * released, its outputs are left untouched).  No-op on an idle slot; an error on a launched one (raftx_sweep_wait
  * collects that).  raftx_ctx_destroy retires whatever is still prepared.

@@ -30,7 +30,7 @@ EXPORTS = (
     "raftx_sweep_submit",
     "raftx_sweep_prepare",
     "raftx_sweep_launch",
-    "raftx_sweep_wait",
+    "raftx_sweep_wait", "raftx_sweep_solve_span",
     "raftx_sweep_cancel", "raftx_device_count", "raftx_solve_dense_batch", "raftx_dense_resident", "raftx_solve_dense_resident", "raftx_flex_solve", "raftx_flex_start", "raftx_debug_flex_gemm",
     "raftx_comm_unique_id", "raftx_comm_init", "raftx_comm_destroy", "raftx_comm_broadcast", "raftx_comm_gather_rows",
     "raftx_comm_gather_xi", "raftx_comm_reduce_sum",
@@ -190,6 +190,8 @@ class RaftxLib:
         L.raftx_sweep_prepare_variants.restype = C.c_int
         L.raftx_sweep_wait.argtypes = [_vp, C.c_int, _vp]
         L.raftx_sweep_wait.restype = C.c_int
+        L.raftx_sweep_solve_span.argtypes = [_vp, C.c_int, _vp, _vp]
+        L.raftx_sweep_solve_span.restype = C.c_int
         L.raftx_sweep_cancel.argtypes = [_vp, C.c_int]
         L.raftx_sweep_cancel.restype = C.c_int
         L.raftx_device_count.argtypes = []
@@ -524,6 +526,10 @@ class Context:
         (dict as ``sweep_stats``)."""
         out = handle["out"]
         self._check(self.rlib.lib.raftx_sweep_wait(self._h, int(handle["slot"]), _ptr(out["timing_ms"])), "raftx_sweep_wait")
+        span = np.zeros(2)                                # where the crossing's fused kernels ran on the device's clock (ms)
+        self._check(self.rlib.lib.raftx_sweep_solve_span(self._h, int(handle["slot"]), _ptr(span[0:1]), _ptr(span[1:2])),
+                    "raftx_sweep_solve_span")
+        out["solve_span_ms"] = span
         handle["inputs"] = None
         return out
 

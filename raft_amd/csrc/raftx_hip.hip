@@ -759,6 +759,8 @@ struct raftx_ctx {
     hipStream_t sCopy, sPrep, sD2H, sGen; // internal streams of raftx_sweep_stats (created on first use)
     hipStream_t sSlab[2] = {nullptr, nullptr}; // with sGen: the streams the slabs of a crossing with responses out go to (SlabPlan)
     hipStream_t sD2Hlow = nullptr;        // bulk download of the responses: a stream of its own priority class, created when first needed
+    hipEvent_t evEpoch = nullptr;         // zero of raftx_sweep_solve_span: recorded when the first crossing of the ctx is launched
+    hipStream_t sMainB = nullptr;         // second compute stream of the sweep crossings (odd slots), created when first needed
     hipStream_t sExp = nullptr;           // k_geom_expand of a block (variants): a HIGH-priority stream of its own, created when first needed
     hipEvent_t evExp = nullptr;
     CaseSet csets[RAFTX_NSLOT + 1];      // sea-state tables of the sweep crossings: one per crossing in flight + one being replaced
@@ -774,6 +776,9 @@ struct raftx_ctx {
     size_t flexXl0_n, flexXl0_cap;       // entries set (0: none) / allocated
     unsigned long long *rXlSlots;
     size_t rXl_n;
+    unsigned *kpCtr = nullptr;           // claim counters of the persistent fused launches: a ring of KP_RING sets of 8 (one per XCD slab, 128 B apart)
+    unsigned kpNext = 0;
+    int nCU = 0;                         // compute units of the device (the persistent grid is what they hold at once)
     int last_flags = -1, last_minb = 0, last_rc = 0;       // specialisation of the last fused-kernel launch (raftx_last_solve_kernel)
     cplx *rQtf;                          // QTFs of the last raftx_qtf_slender call, kept for raftx_qtf_force
     size_t rQtf_n;
@@ -784,6 +789,7 @@ struct raftx_ctx {
     int *rNi, *rFl;
     size_t r_npair, r_nx, r_nz;
     int r_mask;
+    int r_last_mask = 0;                 // RAFTX_WANT_* outputs the LAST fused solve wrote (r_mask: what the buffers could hold)
     bool r_fe;
     int maxS;
     std::vector<int> hS;                 // submerged strips of every design (host copy: LDS classes of the fused kernel)
@@ -851,6 +857,7 @@ struct SweepSlot {
     size_t next_p1 = 0;                  // first block whose phase 1 has not been enqueued yet
     std::chrono::steady_clock::time_point t0;
     double tl[4] = {0, 0, 0, 0};
+    double span[2] = {0, 0};             // fused launches of the crossing last waited for: start / end, ms since the ctx epoch
     size_t nSlabEv = 0;
     bool slab = false;                   // this crossing's fused launches were cut into slabs (SlabPlan)
     std::vector<double> tlb;             // RAFTX_SWEEP_DEBUG: host time per block of raftx_sweep_launch (upload enqueued | totals seen | enqueued)
@@ -1000,6 +1007,7 @@ extern "C" void raftx_ctx_destroy(raftx_ctx *c) {
     c->pool.trim();
     if (c->rXl) (void)hipFree(c->rXl);
     if (c->rXlSlots) (void)hipFree(c->rXlSlots);
+    if (c->kpCtr) (void)hipFree(c->kpCtr);
     if (c->flexXl0) (void)hipFree(c->flexXl0);
     if (c->rXl0) (void)hipFree(c->rXl0);
     if (c->rXlOut) (void)hipFree(c->rXlOut);
@@ -1027,7 +1035,8 @@ extern "C" void raftx_ctx_destroy(raftx_ctx *c) {
         (void)hipEventDestroy(e);
     if (c->sAux) (void)hipStreamDestroy(c->sAux);
     if (c->evExp) (void)hipEventDestroy(c->evExp);
-    for (hipStream_t st : {c->sCopy, c->sPrep, c->sD2H, c->sGen, c->sD2Hlow, c->sSlab[0], c->sSlab[1], c->sExp})
+    if (c->evEpoch) (void)hipEventDestroy(c->evEpoch);
+    for (hipStream_t st : {c->sCopy, c->sPrep, c->sD2H, c->sGen, c->sD2Hlow, c->sSlab[0], c->sSlab[1], c->sExp, c->sMainB})
         if (st) (void)hipStreamDestroy(st);
     if (c->owns_stream) (void)hipStreamDestroy(c->stream);
     delete c;
@@ -1887,6 +1896,47 @@ __global__ void k_iota(int n, int *__restrict__ out) {
     if (i < n) out[i] = i;
 }
 
+// ---- persistent fused launches (raftx_kernels.h: raftx_kp_f<FLAGS>)
+typedef void (*kp_fn)(PersistArgs);
+static kp_fn kp_kernel(int flags) {
+#ifdef RAFTX_KP_ONLY
+    return flags == 0 ? raftx_kp_f0 : nullptr;
+#else
+#define X(F) if (flags == F) return raftx_kp_f##F;
+    RAFTX_PERSIST128(X)
+#undef X
+    return nullptr;
+#endif
+}
+#define KP_RING 64
+#define KP_MAX_GRID 2048                 // workgroups of a persistent grid at most (8 per CU x 256 CUs)
+static int launch_persistent(raftx_ctx *c, kp_fn kernel, const DevTables &T, const SolveArgs &A, size_t npairs, int threads, size_t lds,
+                             int wg_per_cu) {
+    if (!c->nCU) {
+        hipDeviceProp_t pr;
+        HIPCHK(c, hipGetDeviceProperties(&pr, c->device));
+        c->nCU = pr.multiProcessorCount > 0 ? pr.multiProcessorCount : 256;
+    }
+    if (!c->kpCtr) {
+        void *p_ = nullptr;
+        HIPCHK(c, hipMalloc(&p_, (size_t)KP_RING * 8 * KP_CTR_STRIDE * sizeof(unsigned)));
+        c->kpCtr = reinterpret_cast<unsigned *>(p_);
+    }
+    if (lds > 64 * 1024)
+        HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    PersistArgs P;
+    P.T = T;
+    P.A = A;
+    P.ctr = c->kpCtr + (size_t)(c->kpNext++ % KP_RING) * 8 * KP_CTR_STRIDE;
+    P.xl_base = XL_SLOTS;
+    HIPCHK(c, hipMemsetAsync(P.ctr, 0, 8 * KP_CTR_STRIDE * sizeof(unsigned), c->stream));
+    static const int grid_env = getenv("RAFTX_KP_GRID") ? atoi(getenv("RAFTX_KP_GRID")) : 0;      // tuning: workgroups of the grid
+    size_t grid = (size_t)(grid_env > 0 ? grid_env : wg_per_cu * c->nCU);
+    grid = std::min<size_t>(std::min<size_t>(grid, KP_MAX_GRID), grid_for_pairs(npairs));
+    hipLaunchKernelGGL(kernel, dim3((unsigned)grid), dim3(threads), lds, c->stream, P);
+    return 0;
+}
+
 static int solve_enqueue(raftx_ctx *c, int nIter, double tol, double XiStart, const raftx_c128 *F_extra, int want_mask,
                          SlabPlan *plan = nullptr) {
     if (check_ready(c)) return -1;
@@ -1905,6 +1955,7 @@ static int solve_enqueue(raftx_ctx *c, int nIter, double tol, double XiStart, co
     A.B_drag = (want_mask & RAFTX_WANT_BDRAG) ? c->rB : nullptr;
     A.F_wave = (want_mask & RAFTX_WANT_FWAVE) ? c->rFw : nullptr;
     A.Z = (want_mask & RAFTX_WANT_Z) ? c->rZ : nullptr;
+    c->r_last_mask = want_mask;          // buffers of a wider earlier request stay allocated (ensure_results) but are NOT rewritten
     A.dbg = nullptr;
 #ifdef RAFTX_PHASE_TIMING
     if (!c->dbg) {
@@ -1947,13 +1998,17 @@ static int solve_enqueue(raftx_ctx *c, int nIter, double tol, double XiStart, co
     c->last_flags = lean >= 0 ? lean : KF_ALL;
     c->last_minb = minb_used;
     const int wg_per_cu = std::max(1, minb_used * 4 / (sh.threads / 64));
+    // the persistent form (raftx_kernels.h k_solve_dynamics_p / raftx_kp_f*): lean 200-bin launches of one LDS class that
+    // are not cut into slabs; RAFTX_PERSIST=0 keeps the one-workgroup-per-pair launches (A/B, tuning)
+    static const bool persist_env = !(getenv("RAFTX_PERSIST") && !atoi(getenv("RAFTX_PERSIST")));
+    const bool persist = persist_env && rc_shape && lean >= 0 && xlg;
     auto rc_slots = [&](int S_) {
         if (!(shape_maxt(sh) == 128 && sh.nb == 2)) return 0;                // (= rc_shape below)
         static const char *env = getenv("RAFTX_RC_SLOTS");                 // tuning: cap (0 = no cache)
         const int cap = env ? atoi(env) : 24;
         const size_t base = lds_bytes(S_, xlg ? 0 : T.nw, sh.threads / 64, stage_policy(sh.nb, shape_maxt(sh)),
                                       park_policy(sh.nb, shape_maxt(sh)), 0, T.nw);
-        const size_t budget = LDS_LIMIT / (size_t)wg_per_cu;
+        const size_t budget = LDS_LIMIT / (size_t)wg_per_cu - (persist ? KP_STASH * sizeof(double) : 0);
         if (budget <= base) return 0;
         return (int)std::min<size_t>((size_t)cap, (budget - base) / (16 * (size_t)xl_row(T.nw)));
     };
@@ -1964,7 +2019,7 @@ static int solve_enqueue(raftx_ctx *c, int nIter, double tol, double XiStart, co
 #ifdef RAFTX_XL_PER_PAIR
     const size_t xl_regions = std::max<size_t>(XL_SLOTS, c->r_npair);
 #else
-    const size_t xl_regions = XL_SLOTS;
+    const size_t xl_regions = XL_SLOTS + KP_MAX_GRID;      // the slot pool + one region per workgroup of a persistent grid
 #endif
     if (xlg && (!c->rXl || c->rXl_n < xl_regions * 12 * (size_t)T.nw)) {
         // XiLast scratch: a slot per RUNNING workgroup (xl_slot_acquire), not per pair; the slot bits are cleared once --
@@ -1972,15 +2027,17 @@ static int solve_enqueue(raftx_ctx *c, int nIter, double tol, double XiStart, co
         HIPCHK(c, hipDeviceSynchronize());                 // fused kernels of the other streams may hold slots of the old slab
         if (c->rXl) { (void)hipFree(c->rXl); }
         c->rXl = nullptr;
-        c->rXl_n = xl_regions * 12 * (size_t)T.nw;
+        c->rXl_n = 0;
         void *p_ = nullptr;
-        HIPCHK(c, hipMalloc(&p_, c->rXl_n * sizeof(double)));
+        HIPCHK(c, hipMalloc(&p_, xl_regions * 12 * (size_t)T.nw * sizeof(double)));
         c->rXl = reinterpret_cast<double *>(p_);
-        if (!c->rXlSlots) {
-            HIPCHK(c, hipMalloc(&p_, XL_POOLS * XL_POOL_WORDS * sizeof(unsigned long long)));
-            c->rXlSlots = reinterpret_cast<unsigned long long *>(p_);
-            HIPCHK(c, hipMemsetAsync(c->rXlSlots, 0, XL_POOLS * XL_POOL_WORDS * sizeof(unsigned long long), c->stream));   // ahead of this ctx's launches, in stream order
-        }
+        c->rXl_n = xl_regions * 12 * (size_t)T.nw;
+    }
+    if (xlg && !c->rXlSlots) {                             // (on its own: a failed allocation above leaves no half-made pair)
+        void *p_ = nullptr;
+        HIPCHK(c, hipMalloc(&p_, XL_POOLS * XL_POOL_WORDS * sizeof(unsigned long long)));
+        c->rXlSlots = reinterpret_cast<unsigned long long *>(p_);
+        HIPCHK(c, hipMemsetAsync(c->rXlSlots, 0, XL_POOLS * XL_POOL_WORDS * sizeof(unsigned long long), c->stream));   // ahead of this ctx's launches, in stream order
     }
     A.Xl = c->rXl;
     A.slots = c->rXlSlots;
@@ -2072,9 +2129,15 @@ static int solve_enqueue(raftx_ctx *c, int nIter, double tol, double XiStart, co
         HIPCHK(c, hipEventRecord(c->ev0, c->stream));                                                                \
         A.pairs = nullptr;                                                                                           \
         A.npairs = 0;                                                                                                \
-        if (c->r_npair && cls.empty() && !slabbed)                                                                   \
-            hipLaunchKernelGGL((k_solve_dynamics<NB_, FL, MT_, MB_>), dim3(grid_for_pairs(c->r_npair)),              \
-                               dim3(sh.threads), lds, c->stream, T, A);                                              \
+        if (c->r_npair && cls.empty() && !slabbed) {                                                                 \
+            kp_fn kp_ = (persist && NB_ == 2 && MT_ == 128 && MB_ == RAFTX_KP_MINB) ? kp_kernel(FL) : nullptr;       \
+            if (kp_) {                                                                                               \
+                if (launch_persistent(c, kp_, T, A, c->r_npair, sh.threads, lds + KP_STASH * sizeof(double), wg_per_cu)) return -1; \
+            } else {                                                                                                 \
+                hipLaunchKernelGGL((k_solve_dynamics<NB_, FL, MT_, MB_>), dim3(grid_for_pairs(c->r_npair)),          \
+                                   dim3(sh.threads), lds, c->stream, T, A);                                          \
+            }                                                                                                        \
+        }                                                                                                            \
         if (slabbed) {                                            /* the tables and the iota list are on the ctx stream */ \
             HIPCHK(c, hipEventRecord(c->evFork, c->stream));                                                         \
             for (size_t k_ = 0; k_ < plan->alts.size() && k_ + 1 < plan->bnd.size(); k_++)                           \
@@ -2177,9 +2240,10 @@ extern "C" int raftx_fetch_results(raftx_ctx *c, raftx_c128 *Xi, int32_t *niter,
     if (!c) return -1;
     if (!c->rXi) FAIL(c, "fetch_results: no resident results");
     HIPCHK(c, hipSetDevice(c->device));
-    if (B_drag && !c->rB) FAIL(c, "fetch_results: B_drag was not kept");
-    if (F_wave && !c->rFw) FAIL(c, "fetch_results: F_wave was not kept");
-    if (Z && !c->rZ) FAIL(c, "fetch_results: Z was not kept");
+    // (kept = written by the LAST solve: a buffer left over from a wider earlier request holds that request's results)
+    if (B_drag && !(c->rB && (c->r_last_mask & RAFTX_WANT_BDRAG))) FAIL(c, "fetch_results: B_drag was not kept");
+    if (F_wave && !(c->rFw && (c->r_last_mask & RAFTX_WANT_FWAVE))) FAIL(c, "fetch_results: F_wave was not kept");
+    if (Z && !(c->rZ && (c->r_last_mask & RAFTX_WANT_Z))) FAIL(c, "fetch_results: Z was not kept");
     if (Xi && c->r_nx) D2H(c, Xi, c->rXi, c->r_nx * sizeof(cplx));
     if (niter && c->r_npair) D2H(c, niter, c->rNi, c->r_npair * sizeof(int));
     if (flags && c->r_npair) D2H(c, flags, c->rFl, c->r_npair * sizeof(int));
@@ -2668,8 +2732,12 @@ extern "C" int raftx_solve_system_resident(raftx_ctx *c, int nUnit, const double
     const DevTables &T = c->T;
     // what the coupled solve is fed from: the exported impedances (RAFTX_WANT_Z), or -- no Z kept -- the units' constant
     // matrices + the exported B_drag (RAFTX_WANT_BDRAG), assembled on the fly; frequency-dependent M(w), B(w) need the export
-    const bool assemble = c->rXi && !c->rZ && c->rB && c->rFw && !T.MBw;
-    if (!c->rXi || !c->rFw || (!c->rZ && !assemble))
+    // -- decided on what the LAST solve wrote, not on which buffers exist: a same-shape solve that asked for less keeps the
+    // wider buffers of the call before it, with that call's contents
+    const int lm = c->r_last_mask;
+    const bool haveZ = c->rZ && (lm & RAFTX_WANT_Z), haveF = c->rFw && (lm & RAFTX_WANT_FWAVE);
+    const bool assemble = c->rXi && !haveZ && c->rB && (lm & RAFTX_WANT_BDRAG) && haveF && !T.MBw;
+    if (!c->rXi || !haveF || (!haveZ && !assemble))
         FAIL(c, "solve_system_resident: needs resident F_wave and either Z or (constant matrices) B_drag "
                 "(raftx_solve_dynamics_device with RAFTX_WANT_FWAVE | RAFTX_WANT_Z, or RAFTX_WANT_FWAVE | RAFTX_WANT_BDRAG)");
     if (nUnit < 1 || T.nDesign % nUnit != 0 || !Xi) FAIL(c, "solve_system_resident: bad arguments (nDesign=%d, nUnit=%d)", T.nDesign, nUnit);
@@ -3268,6 +3336,9 @@ extern "C" int raftx_sweep_prepare_variants(raftx_ctx *c, int slot, int nDesign,
     VariantProg &P = c->vprog;
     if (!P.nM) FAIL(c, "sweep_prepare_variants: no program (raftx_variant_program first)");
     if (nDesign < 0 || (!params && nDesign && P.nP)) FAIL(c, "sweep_prepare_variants: bad arguments");
+    if (slot < 0 || slot >= RAFTX_NSLOT) FAIL(c, "sweep_prepare_variants: slot must be 0 .. %d", RAFTX_NSLOT - 1);
+    if (c->slots[slot].busy || c->slots[slot].prepared)   // before the cached offset arrays are touched: the batch on this slot reads them
+        FAIL(c, "sweep_prepare_variants: slot %d is still in flight (call raftx_sweep_wait first)", slot);
     for (int sl = 0; sl < RAFTX_NSLOT; sl++)        // the offset arrays of batches in flight are the cached ones: one batch size at a time
         if (sl != slot && (c->slots[sl].busy || c->slots[sl].prepared) && c->slots[sl].p1.var.prog && P.cachedN != nDesign)
             FAIL(c, "sweep_prepare_variants: batches of variants in flight together must have the same size (%d in flight, %d asked)",
@@ -3289,6 +3360,22 @@ extern "C" int raftx_sweep_launch(raftx_ctx *c, int slot) {
     if (S.cset < 0 || c->csets[S.cset].T.nCase != S.nCase || c->csets[S.cset].T.nHead != S.nHead || c->csets[S.cset].T.nw != S.nw)
         FAIL(c, "sweep_launch: slot %d has lost its sea-state tables (internal error)", slot);
     HIPCHK(c, hipSetDevice(c->device));
+    // The compute stream of this crossing.  Crossings of consecutive slots ALTERNATE between two streams (RAFTX_SWEEP_STREAMS=1:
+    // one, as until round 5): the fused kernel is a persistent grid (raftx_kp_f*) whose workgroups leave the chip one by one
+    // over its last ~0.25 ms, and the next crossing's grid -- on the other stream, its tables generated a step earlier --
+    // takes their places as they leave instead of waiting for the last of them: the drain of batch i is the ramp of batch
+    // i+1 (T(n) = 0.33 ms + 0.25 us n per launch: the 0.33 is what the overlap hides).  Everything of ONE crossing (table
+    // generation's hand-over, fused kernel, statistics) stays in order on its stream; crossings two apart share a stream.
+    static const int n_streams = getenv("RAFTX_SWEEP_STREAMS") ? std::max(1, std::min(2, atoi(getenv("RAFTX_SWEEP_STREAMS")))) : 2;
+    const bool two_streams = n_streams > 1;
+    if (two_streams && !c->sMainB) HIPCHK(c, hipStreamCreateWithFlags(&c->sMainB, hipStreamNonBlocking));
+    hipStream_t sM = (two_streams && (slot & 1)) ? c->sMainB : c->stream;
+    for (raftx_ctx *sub : S.blk)
+        if (sub) sub->stream = sM;
+    if (!c->evEpoch) {
+        HIPCHK(c, hipEventCreate(&c->evEpoch));
+        HIPCHK(c, hipEventRecord(c->evEpoch, sM));
+    }
     auto since = [&]() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - S.t0).count(); };
     const std::vector<int> &bnd = S.bnd;
     const size_t nB = bnd.size() - 1;
@@ -3354,14 +3441,14 @@ extern "C" int raftx_sweep_launch(raftx_ctx *c, int slot) {
         raftx_ctx *sub = blk[b];
         const int lo = bnd[b];
         const size_t npair = (size_t)(bnd[b + 1] - lo) * nCase;
-        hipError_t e = hipEventRecord(sub->evS0, c->stream);
+        hipError_t e = hipEventRecord(sub->evS0, sM);
         if (npair) {
-            hipLaunchKernelGGL(k_motion_stats, dim3((unsigned)npair), dim3(nw > 128 ? 256 : (nw > 64 ? 128 : 64)), 0, c->stream,
+            hipLaunchKernelGGL(k_motion_stats, dim3((unsigned)npair), dim3(nw > 128 ? 256 : (nw > 64 ? 128 : 64)), 0, sM,
                                (int)npair, nHead, nw, 1.0 / dw, sub->rXi, sub->pinRes, (double *)nullptr, (const int *)sub->rNi,
                                (const int *)sub->rFl, reinterpret_cast<int *>(sub->pinRes + npair * 6));
         }
-        if (e == hipSuccess) e = hipEventRecord(sub->evS1, c->stream);
-        if (e == hipSuccess) e = hipEventRecord(sub->evDone, c->stream);
+        if (e == hipSuccess) e = hipEventRecord(sub->evS1, sM);
+        if (e == hipSuccess) e = hipEventRecord(sub->evDone, sM);
         if (e == hipSuccess && Xi && !slab_mode) {
             const size_t p0 = (size_t)lo * nCase;
             e = hipStreamWaitEvent(sDown, sub->evDone, 0);
@@ -3400,7 +3487,7 @@ extern "C" int raftx_sweep_launch(raftx_ctx *c, int slot) {
                 rc = rc1;
             }
         }
-        if (b == 0 && pipelined && gen_overlap) {
+        if (b == 0 && pipelined && gen_overlap && !two_streams) {
             // When does the generation run?  Enqueued now, beside a fused kernel that has only just started, it would be
             // dispatched at once and take LDS from that kernel for its whole run (measured: +0.25 ms on the kernel).  A
             // small kernel queued BEHIND a running big grid is dispatched when that grid has been handed out -- which is
@@ -3418,7 +3505,7 @@ extern "C" int raftx_sweep_launch(raftx_ctx *c, int slot) {
         S.tlb.push_back(since());
         if (!rc) rc = build_phase2(sub, nullptr, gen_side ? c->sGen : nullptr);
         S.tlb.push_back(since());
-        if (!rc && b == 0 && pipelined && gen_overlap) {
+        if (!rc && b == 0 && pipelined && gen_overlap && !two_streams) {
             // Small kernels are not dispatched while a big grid is being handed out: whatever of the NEXT batch's member pass
             // has not finished when this batch's fused kernel starts would wait for the whole kernel and stall that batch's
             // launch a step later.  So this fused kernel starts only when the member passes already queued (the batches
@@ -3427,7 +3514,7 @@ extern "C" int raftx_sweep_launch(raftx_ctx *c, int slot) {
             for (int sl = 0; sl < RAFTX_NSLOT && !rc; sl++)
                 if (sl != slot && c->slots[sl].prepared)
                     for (raftx_ctx *o : c->slots[sl].blk)
-                        if (o && hipStreamWaitEvent(c->stream, o->evTot, 0) != hipSuccess) rc = -2;
+                        if (o && hipStreamWaitEvent(sM, o->evTot, 0) != hipSuccess) rc = -2;
         }
         if (!rc) {                                                      // the sea states this crossing was prepared with
             DevTables &T = sub->T;
@@ -3487,8 +3574,8 @@ extern "C" int raftx_sweep_launch(raftx_ctx *c, int slot) {
     }
     if (!rc_all && slab_mode) {                                         // the statistics read what the slabs wrote: behind all of them
         if (!blk[0]->evJoin && hipEventCreateWithFlags(&blk[0]->evJoin, hipEventDisableTiming) != hipSuccess) rc_all = -2;
-        if (!rc_all) rc_all = slab_join(blk[0], c->stream, plan.alts);
-        if (!rc_all && hipEventRecord(blk[nB - 1]->ev1, c->stream) != hipSuccess) rc_all = -2;
+        if (!rc_all) rc_all = slab_join(blk[0], sM, plan.alts);
+        if (!rc_all && hipEventRecord(blk[nB - 1]->ev1, sM) != hipSuccess) rc_all = -2;
         for (size_t b = 0; b < nB && !rc_all; b++) {
             rc_all = enqueue_stats(b);
             if (rc_all) snprintf(c->err, sizeof(c->err), "sweep_stats (block %zu): %s", b, blk[b]->err);
@@ -3567,6 +3654,14 @@ extern "C" int raftx_sweep_wait(raftx_ctx *c, int slot, double *timing_ms) {
         HIPCHK(c, es);
     }
     double tb = 0, ts = 0, tst = 0;
+    S.span[0] = S.span[1] = 0;
+    if (nB && c->evEpoch) {
+        float a = 0.f, b_ = 0.f;
+        HIPCHK(c, hipEventElapsedTime(&a, c->evEpoch, S.blk[0]->ev0));
+        HIPCHK(c, hipEventElapsedTime(&b_, c->evEpoch, S.blk[nB - 1]->ev1));
+        S.span[0] = a;
+        S.span[1] = b_;
+    }
     if (S.stripOffsets) S.stripOffsets[0] = 0;
     for (size_t b = 0; b < nB; b++) {
         raftx_ctx *sub = S.blk[b];
@@ -3600,6 +3695,15 @@ extern "C" int raftx_sweep_wait(raftx_ctx *c, int slot, double *timing_ms) {
     }
     if (timing_ms) { timing_ms[0] = wall; timing_ms[1] = tb; timing_ms[2] = ts; timing_ms[3] = tst; }
     c->last_ms = ts;
+    return 0;
+}
+
+extern "C" int raftx_sweep_solve_span(raftx_ctx *c, int slot, double *start_ms, double *end_ms) {
+    if (!c) return -1;
+    if (slot < 0 || slot >= RAFTX_NSLOT) FAIL(c, "sweep_solve_span: slot must be 0 .. %d", RAFTX_NSLOT - 1);
+    if (c->slots[slot].busy) FAIL(c, "sweep_solve_span: slot %d has not been waited for", slot);
+    if (start_ms) *start_ms = c->slots[slot].span[0];
+    if (end_ms) *end_ms = c->slots[slot].span[1];
     return 0;
 }
 

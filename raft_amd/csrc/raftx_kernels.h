@@ -2394,10 +2394,14 @@ __device__ __forceinline__ bool pair_ctx(const DevTables &T, PairCtx &p, int pai
     if (p.pair >= npair) return false;
     p.d = p.pair / T.nCase;
     p.ic = p.pair % T.nCase;
-    p.S = (int)(T.off[p.d + 1] - T.off[p.d]);
-    p.ds = as_const(T.ds + (size_t)T.off[p.d] * DS_N);
-    p.dsi = as_const(T.dsi + (size_t)T.off[p.d]);
-    p.cm = T.cm ? T.cm + (size_t)T.cmoff[p.d] * 2 * T.nw : nullptr;
+    // read-only for the launch: through the constant address space these stay SCALAR loads (and S, the LDS layout and
+    // the table pointers scalar registers) even behind the atomics and LDS traffic of a persistent workgroup's claim
+    const CONST_AS int64_t *off = (const CONST_AS int64_t *)T.off;
+    const int64_t o0 = off[p.d];
+    p.S = (int)(off[p.d + 1] - o0);
+    p.ds = as_const(T.ds + (size_t)o0 * DS_N);
+    p.dsi = as_const(T.dsi + (size_t)o0);
+    p.cm = T.cm ? T.cm + (size_t)((const CONST_AS int64_t *)T.cmoff)[p.d] * 2 * T.nw : nullptr;
     return true;
 }
 
@@ -2475,6 +2479,7 @@ __global__ void __launch_bounds__(MAXT, MINB) k_linearize(DevTables T, const cpl
         for (int ih = 0; ih < T.nHead; ih++) {
             const double beta = T.beta[(size_t)p.ic * T.nHead + ih];
             const double cb = to_sgpr(cos(beta)), sb = to_sgpr(sin(beta));
+            load_bins(T, b, opaque((int)threadIdx.x));    // re-derived (L1 / L2 hits): nothing of b stays live -- and spilled -- through pass A
             set_heading_amp(T, b, p.ic, ih);
             if (ih > 0) {
                 wg_sync(multi);
@@ -2483,7 +2488,18 @@ __global__ void __launch_bounds__(MAXT, MINB) k_linearize(DevTables T, const cpl
             cplx F[NB][6];
             zero6(F);
             drag_excitation<NB, STAGE>(p.ds, p.dsi, p.S, l, b, cb, sb, F);
-            store6(F_drag + (((size_t)p.pair * T.nHead + ih) * 6) * T.nw, T.nw, b, F);
+            {   // bin indices re-derived for the stores: no per-lane address lives through the sweep
+                cplx *__restrict__ base = F_drag + (((size_t)p.pair * T.nHead + ih) * 6) * T.nw;
+                const int t_ = opaque((int)threadIdx.x);
+#pragma unroll
+                for (int j = 0; j < NB; j++) {
+                    const int iw = j * (int)blockDim.x + t_;
+                    if (iw < T.nw) {
+#pragma unroll
+                        for (int q = 0; q < 6; q++) base[(size_t)q * T.nw + iw] = F[j][q];
+                    }
+                }
+            }
         }
     }
 }
@@ -2634,8 +2650,12 @@ struct SolveArgs {
 // buffer until the final iterate overwrites it -- each lane re-reads only what it wrote,
 // so no extra HBM footprint and no synchronisation is needed.  The 6x6 systems of a lane's
 // NB bins are factorised one after the other.
-template <int NB, int FLAGS, int MAXT, int MINB>
-__global__ void __launch_bounds__(MAXT, MINB) k_solve_dynamics(DevTables T, SolveArgs A) {
+#define KP_STASH 4        // doubles at the start of the dynamic LDS that a persistent workgroup keeps for itself (see RAFTX_KP_REENTER)
+// solve_pair: one (design, sea state) pair by the calling workgroup.  `idx` = position in the launch's pair list (or
+// the pair itself without one); PERSIST: the workgroup belongs to a persistent grid (k_solve_dynamics_p) and keeps the
+// XiLast region `xslot` for its whole life instead of claiming one per pair.
+template <int NB, int FLAGS, int MAXT, bool PERSIST>
+__device__ __forceinline__ void solve_pair(const DevTables &T, const SolveArgs &A, int idx, unsigned xslot) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     constexpr bool FDEP = (FLAGS & KF_FDEP) != 0, OUTZ = (FLAGS & KF_OUTZ) != 0, OUTF = (FLAGS & KF_OUTF) != 0;
     constexpr bool EXTRA = (FLAGS & KF_EXTRA) != 0, MCF = (FLAGS & KF_MCF) != 0, MULTI = (FLAGS & KF_MULTI) != 0;
@@ -2643,7 +2663,6 @@ __global__ void __launch_bounds__(MAXT, MINB) k_solve_dynamics(DevTables T, Solv
     PairCtx p;
     {
         const int nl = A.pairs ? A.npairs : T.nDesign * T.nCase;
-        const int idx = pair_of_block(blockIdx.x, nl);
         if (idx >= nl) return;
         if (!pair_ctx(T, p, A.pairs ? A.pairs[idx] : idx)) return;
     }
@@ -2657,13 +2676,14 @@ __global__ void __launch_bounds__(MAXT, MINB) k_solve_dynamics(DevTables T, Solv
     constexpr bool XLG = xl_global(NB, MAXT);
     constexpr int PARK = park_policy(NB, MAXT);
     constexpr bool RC = PARK != 0 && XLG;            // the shape whose spare LDS is a run-start cache (A.rc_n slots)
-    Lds l = carve(smem, S, XLG ? 0 : nw, blockDim.x >> 6, STAGE, PARK, RC ? A.rc_n : 0, RC ? nw : 0);
+    Lds l = carve(smem + (PERSIST ? KP_STASH : 0), S, XLG ? 0 : nw, blockDim.x >> 6, STAGE, PARK, RC ? A.rc_n : 0, RC ? nw : 0);
     XlStore<XLG> xl;
     if constexpr (XLG) {
 #ifdef RAFTX_XL_PER_PAIR                                   // tuning build: round 1-4's form, a region per pair
         xl.p = A.Xl + (size_t)pair * 12 * nw;
 #else
-        xl.p = A.Xl + (size_t)xl_slot_acquire(A.slots, smem) * 12 * nw;       // before anything is staged in LDS
+        if constexpr (PERSIST) xl.p = A.Xl + (size_t)xslot * 12 * nw;
+        else xl.p = A.Xl + (size_t)xl_slot_acquire(A.slots, smem) * 12 * nw;  // before anything is staged in LDS
 #endif
         xl.n = nw;
     }
@@ -2677,10 +2697,11 @@ __global__ void __launch_bounds__(MAXT, MINB) k_solve_dynamics(DevTables T, Solv
     Bins<NB> b;
     load_bins(T, b, threadIdx.x);
     set_heading_amp(T, b, p.ic, 0);
-    for (int i = threadIdx.x; i < 108; i += blockDim.x) {
-        const int e = i % 36, wh = i / 36;
-        const double *src = wh == 0 ? T.M0 : (wh == 1 ? T.B0 : T.C0);
-        l.mat[i] = src[(size_t)p.d * 36 + e];
+    if (threadIdx.x < 36) {                               // (three plain loads: a pointer chosen by index would put T in memory)
+        const size_t e = (size_t)p.d * 36 + threadIdx.x;
+        l.mat[threadIdx.x] = T.M0[e];
+        l.mat[36 + threadIdx.x] = T.B0[e];
+        l.mat[72 + threadIdx.x] = T.C0[e];
     }
     const double beta0 = T.beta[(size_t)p.ic * nHs];
     const double cb0 = to_sgpr(cos(beta0)), sb0 = to_sgpr(sin(beta0));
@@ -2919,7 +2940,7 @@ __global__ void __launch_bounds__(MAXT, MINB) k_solve_dynamics(DevTables T, Solv
         wg_sync(multi);
     }
 #ifndef RAFTX_XL_PER_PAIR
-    if constexpr (XLG) xl_slot_release(A.slots, (unsigned)((size_t)(xl.p - A.Xl) / ((size_t)12 * nw)));    // XiLast is dead from here on
+    if constexpr (XLG && !PERSIST) xl_slot_release(A.slots, (unsigned)((size_t)(xl.p - A.Xl) / ((size_t)12 * nw)));    // XiLast is dead from here on
 #endif
 
     // remaining headings: same impedance, same linearised coefficients (:1200-1236)
@@ -2992,3 +3013,121 @@ __global__ void __launch_bounds__(MAXT, MINB) k_solve_dynamics(DevTables T, Solv
         if (A.flags) A.flags[pair] = (converged ? RAFTX_FLAG_CONVERGED : 0) | (nan ? RAFTX_FLAG_NAN : 0);
     }
 }
+
+template <int NB, int FLAGS, int MAXT, int MINB>
+__global__ void __launch_bounds__(MAXT, MINB) k_solve_dynamics(DevTables T, SolveArgs A) {
+    const int nl = A.pairs ? A.npairs : T.nDesign * T.nCase;
+    solve_pair<NB, FLAGS, MAXT, false>(T, A, pair_of_block(blockIdx.x, nl), 0u);
+}
+
+// ------------------------------------------------------------------ persistent form of the fused fixed point
+// The grid is what the chip holds at once (host: workgroups per CU x CUs); a workgroup CLAIMS positions of the launch's
+// pair list until none is left, instead of being dispatched once per pair: no dispatch gap between two pairs of a
+// slot (~10-15 us of 257 at C3), the XiLast region is the workgroup's own for the launch (no slot pool traffic), and a
+// launch on another queue starts on the slots this one's workgroups leave when they run dry (the host alternates two
+// queues: the drain of batch i is the ramp of batch i+1).
+// Claiming: eight counters (one per XCD slab of the list, as pair_of_block deals them), a workgroup takes from the slab
+// of the XCD it runs on and, when that one is dry, from the others in turn -- placement is for L2 locality only.
+// Registers: the kernel sits at the 256-VGPR wall with ~120 spilled SGPRs; kernel arguments that stay live around the
+// loop tip it into scratch.  They are therefore RE-READ from the kernarg segment for every pair behind an opaque copy
+// of the segment pointer (scalar loads from the constant cache, exactly what the prologue of the one-pair kernel does).
+#define KP_CTR_STRIDE 32                 // unsigned: each slab's counter on a 128-byte line of its own
+struct PersistArgs {
+    DevTables T;
+    SolveArgs A;
+    unsigned *ctr;          // [8][KP_CTR_STRIDE] claimed positions per XCD slab, zeroed by the host before the launch
+    unsigned xl_base;       // first XiLast region of this launch (launches in flight at once use disjoint ranges)
+};
+__device__ __forceinline__ int claim_pair(unsigned *ctr, int nl, LDS_AS int *mail) {
+    __syncthreads();                                    // the previous pair's last LDS reads are over
+    if (threadIdx.x == 0) {
+        unsigned xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        xcc &= 7u;
+        const int per = (nl + 7) >> 3;
+        int idx = -1;
+        for (unsigned t = 0; t < 8u && idx < 0; t++) {
+            const unsigned x = (xcc + t) & 7u;
+            const int lim = min(per, nl - (int)x * per);                  // positions of slab x
+            if (lim <= 0) continue;
+            unsigned *cx = ctr + x * KP_CTR_STRIDE;
+            // a dry slab costs one plain load, not an atomic that keeps counting
+            if ((int)__hip_atomic_load(cx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= lim) continue;
+            const int i = (int)__hip_atomic_fetch_add(cx, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (i < lim) idx = (int)x * per + i;
+        }
+        *mail = idx;
+    }
+    __syncthreads();
+    const int idx = *mail;
+    __syncthreads();                                    // the word is staged over by the pair's set-up
+    return __builtin_amdgcn_readfirstlane(idx);
+}
+// The pair loop is NOT a loop for the compiler (as one, every lane-index-derived address of the 16 000-instruction body is
+// hoisted in front of it and spilled: 168 B of scratch).  A workgroup that has finished a pair RE-ENTERS the kernel at its
+// first instruction with the registers a fresh dispatch would find: nothing is live across pairs, the code is the
+// one-pair kernel's.  What a dispatch hands over besides the lane ids -- queue pointer, kernarg segment pointer,
+// workgroup id -- is stashed in the first 32 bytes of the dynamic LDS at entry (re-stashed, unchanged, on every
+// re-entry) and read back from there at the end, so that it occupies no register in between (the kernel sits at 256
+// VGPRs with ~120 SGPRs spilled to lanes; eight more live scalars cost 72 B of scratch).
+// Entry state of these kernels with this compiler: user SGPRs s[0:1] = queue pointer, s[2:3] = kernarg segment,
+// system SGPRs s4..s6 = workgroup id x, y, z (y = z = 0: the host launches one-dimensional grids), v0 = item ids
+// (x | y << 10 | z << 20 = x for one-dimensional blocks), EXEC = all lanes, no private segment.
+// tests/test_code_object.py reads exactly that back from the kernel descriptors of the built library, and that no
+// persistent specialisation has scratch.  The kernels carry C names (the branch target is spelled in the assembly):
+// raftx_kp_f<FLAGS> for the lean 2 x 128 specialisations, FLAGS as a decimal literal.
+// Stash layout (dwords from the dynamic LDS base): 0 claim mail, 1 workgroup id x, 2-3 queue pointer, 4-5 kernarg pointer.
+#define RAFTX_PERSIST128(X) X(0) X(1) X(16) X(32) X(9) X(17) X(33) X(48) X(41) X(49) X(4) X(36)
+#define RAFTX_KP_REENTER(NAME)                                                                                          \
+    do {                                                                                                                \
+        asm volatile("s_mov_b64 exec, -1\n\t"                                                                           \
+                     "v_mov_b32 v1, %1\n\t"                                                                             \
+                     "v_mov_b32 v0, %0\n\t"                                                                             \
+                     "ds_read_b128 v[2:5], v1\n\t"                                                                      \
+                     "ds_read_b64 v[6:7], v1 offset:16\n\t"                                                             \
+                     "s_waitcnt lgkmcnt(0)\n\t"                                                                         \
+                     "v_readfirstlane_b32 s4, v3\n\t"                                                                   \
+                     "v_readfirstlane_b32 s0, v4\n\t"                                                                   \
+                     "v_readfirstlane_b32 s1, v5\n\t"                                                                   \
+                     "v_readfirstlane_b32 s2, v6\n\t"                                                                   \
+                     "v_readfirstlane_b32 s3, v7\n\t"                                                                   \
+                     "s_mov_b32 s5, 0\n\t"                                                                              \
+                     "s_mov_b32 s6, 0\n\t"                                                                              \
+                     "s_getpc_b64 s[8:9]\n\t"                                                                           \
+                     "s_add_u32 s8, s8, " #NAME "@rel32@lo+4\n\t"                                                       \
+                     "s_addc_u32 s9, s9, " #NAME "@rel32@hi+12\n\t"                                                     \
+                     "s_setpc_b64 s[8:9]"                                                                               \
+                     :                                                                                                  \
+                     : "v"(threadIdx.x), "v"((unsigned)(size_t)(LDS_AS double *)smem)                                   \
+                     : "memory", "v0", "v1", "v2", "v3", "v4", "v5", "v6", "v7", "s0", "s1", "s2", "s3", "s4", "s5",    \
+                       "s6", "s8", "s9");                                                                               \
+        __builtin_unreachable();                                                                                        \
+    } while (0)
+#define RAFTX_KP_DEFINE(NAME, NB, FLAGS, MAXT, MINB)                                                                    \
+    extern "C" __global__ void __launch_bounds__(MAXT, MINB) NAME(PersistArgs P) {                                      \
+        extern __shared__ __attribute__((aligned(16))) double smem[];                                                   \
+        if (threadIdx.x == 0) {                                                                                         \
+            LDS_AS unsigned *st_ = (LDS_AS unsigned *)smem;                                                             \
+            const size_t qp_ = (size_t)__builtin_amdgcn_queue_ptr(), ka_ = (size_t)__builtin_amdgcn_kernarg_segment_ptr(); \
+            st_[1] = blockIdx.x + 0u * (blockIdx.y + blockIdx.z + threadIdx.y + threadIdx.z);                           \
+            st_[2] = (unsigned)qp_;                                                                                     \
+            st_[3] = (unsigned)(qp_ >> 32);                                                                             \
+            st_[4] = (unsigned)ka_;                                                                                     \
+            st_[5] = (unsigned)(ka_ >> 32);                                                                             \
+        }                                                                                                               \
+        const int nl = P.A.pairs ? P.A.npairs : P.T.nDesign * P.T.nCase;                                                \
+        const int idx = claim_pair(P.ctr, nl, (LDS_AS int *)smem);                                                      \
+        if (idx < 0) return;                                                                                            \
+        solve_pair<NB, FLAGS, MAXT, true>(P.T, P.A, idx, P.xl_base + blockIdx.x);                                       \
+        RAFTX_KP_REENTER(NAME);                                                                                         \
+    }
+#ifndef RAFTX_KP_MINB
+#define RAFTX_KP_MINB 2
+#endif
+#define X(F) RAFTX_KP_DEFINE(raftx_kp_f##F, 2, F, 128, RAFTX_KP_MINB)
+#ifdef RAFTX_KP_ONLY          // screening builds: one specialisation
+X(0)
+#else
+RAFTX_PERSIST128(X)
+#endif
+#undef X

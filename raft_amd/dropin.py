@@ -307,7 +307,7 @@ class Engine:
             # XiLast_k = Xi + 0.2^(k-1) (XiStart - Xi) (:1133 with a constant Xi): the count of :1052,1103 follows in closed form
             gap = np.abs(Xi_d[0] - model.XiStart) / (np.abs(Xi_d[0]) + tol)
             nit, ok = 0, False
-            while nit < int(model.nIter) and not ok:
+            while nit < int(model.nIter) + 1 and not ok:                    # nIter + 1 passes at most (raft_model.py:977)
                 ok = bool(np.all(gap * 0.2 ** nit < tol))
                 nit += 1
             first_ok = ok
@@ -889,7 +889,11 @@ class Engine:
                     # units' loops ended on (:1156,1178): Z_sys += -w^2 (M + A) + i w B + C (:1181-1182) -- the Mc, Bc, Cc
                     # of raftx_solve_system
                     XiLast_all = out['XiLast'] if 'XiLast' in out else ctx.fetch_linearisation_point()
-                    model.updateMooringDynamicMatrices([np.array(XiLast_all[i, 0]) for i in range(nF)], f0.S[0, :])
+                    # the kernel exports the point the LAST linearisation was made about; a unit that left its loop
+                    # unconverged has been relaxed once more upstream (:1133 runs before the loop ends, :1156 appends that)
+                    pts = [np.array(XiLast_all[i, 0]) if (out['flags'][i, 0] & 1)
+                           else 0.2 * np.asarray(XiLast_all[i, 0]) + 0.8 * np.asarray(out['Xi'][i, 0, 0]) for i in range(nF)]
+                    model.updateMooringDynamicMatrices(pts, f0.S[0, :])
                     M_m, A_m, B_m, C_m = (np.asarray(a, dtype=float) for a in ms.getCoupledDynamicMatrices(lines_only=True))
                     Mc, Bc, Cc = (M_m + A_m)[None], B_m[None], C_m[None]
                 # any other moorMod: upstream adds zeros (:1174)

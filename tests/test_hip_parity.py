@@ -270,6 +270,38 @@ def test_farm_path_without_Z_is_bit_identical_to_the_path_that_exports_it(hip_ct
     assert rel_err(lean["Xi"], ref["Xi"]) < TOL
 
 
+@pytest.mark.gpu
+def test_lean_farm_after_a_wider_export_does_not_read_the_stale_impedances(hip_ctx, oracle_ctx):
+    """a solve that exported Z leaves its buffer allocated; a same-shape Sweep.run_farm that follows on the
+    same context asks only for B_drag | F_wave, the buffers are kept (superset) and Z is NOT rewritten -- the coupled solve
+    must assemble the impedances of the NEW designs, not read the old ones, and fetching Z must fail."""
+    from raft_amd._abi import WANT_FWAVE, WANT_Z, WANT_BDRAG, RaftxError
+    from raft_amd.sweep import Sweep
+    rng = np.random.default_rng(505)
+    n_unit, nG, nw = 2, 2, 200
+    w, k, zeta, beta = synthetic_cases(rng, 2, 1, nw)
+    S_list = rng.integers(8, 60, size=nG * n_unit)
+
+    def make(seed):
+        r = np.random.default_rng(seed)
+        tables = [random_strips(r, S, nw, 0.0) for S in S_list]                     # same strip counts: same buffer shapes
+        M0, B0, C0, _ = random_matrices(r, nG * n_unit, nw, False)
+        off = np.concatenate([[0], np.cumsum([len(t.strips) for t in tables])]).astype(np.int64)
+        return Sweep(off, np.concatenate([t.strips for t in tables]), M0, B0, C0, w, k, 200.0, zeta, beta, 5, 0.1)
+    first, second = make(1), make(2)
+    n = 6 * n_unit
+    Cc = rng.normal(size=(nG, n, n)) * 1e5
+    Cc = Cc + np.transpose(Cc, (0, 2, 1))
+    first.upload(hip_ctx)
+    hip_ctx.solve_dynamics_device(first.nIter, first.tol, first.XiStart, want_mask=WANT_Z | WANT_FWAVE | WANT_BDRAG)
+    out = second.run_farm(hip_ctx, n_unit, Cc=Cc)                                   # B_drag | F_wave: a subset, nothing reallocated
+    ref = second.run_farm(oracle_ctx, n_unit, Cc=Cc)
+    assert np.array_equal(out["niter"], ref["niter"])
+    assert rel_err(out["Xi"], ref["Xi"]) < TOL
+    with pytest.raises(RaftxError):
+        hip_ctx.fetch_results(want_Xi=False, want_Z=True)
+
+
 @pytest.mark.parametrize("name,icase", [("c2_volturnus.npz", 4), ("pose_volturnus_mcf.npz", 1), ("c4_farm.npz", 0)])
 def test_materialised_members_through_the_dropin(name, icase, hip_ctx, oracle_ctx):
     """Engine(materialise_members=True): after solveDynamics every member of every unit carries u, ud, pDyn [nWaves,ns,3,nw],
