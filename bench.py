@@ -222,7 +222,7 @@ def live_traffic(n_design, timeout_s=120):
             rows = []
             for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
                 with open(f) as fh:
-                    rows += [r for r in csv.DictReader(fh) if "k_solve_dynamics" in r["Kernel_Name"] and r["Counter_Name"] == ctr]
+                    rows += [r for r in csv.DictReader(fh) if ("k_solve_dynamics" in r["Kernel_Name"] or "raftx_kp_f" in r["Kernel_Name"]) and r["Counter_Name"] == ctr]
             gmax = max((int(r["Grid_Size"]) for r in rows), default=0)
             vals = [float(r["Counter_Value"]) for r in rows if int(r["Grid_Size"]) == gmax]
             if not vals:
@@ -676,7 +676,7 @@ def main():
                                                       "(the gap between fused kernels shrinks 0.35 -> 0.2 ms, the kernels sharing the drain slow each "
                                                       "other by as much), so it is not the default")
     ap.add_argument("--no-extra-legs", action="store_true", help="skip the legs outside the headline (xi-out, featured sweeps)")
-    ap.add_argument("--legs", default="xi,featured,configs,hostdesc,traffic,launchsize", help="which legs outside the headline run (comma list of xi, featured, configs, hostdesc, launchsize, "
+    ap.add_argument("--legs", default="xi,featured,configs,hostdesc,traffic,launchsize,shard", help="which legs outside the headline run (comma list of xi, featured, configs, hostdesc, launchsize, shard, "
                                                                             "traffic = the FETCH_SIZE / WRITE_SIZE passes of roofline.traffic, two child runs under rocprofv3)")
     ap.add_argument("--profile", action="store_true", help="for runs under rocprofv3: whole-batch launches only (--chunks 1), no isolated / "
                                                             "extra / oracle legs -- ONE population of k_solve_dynamics launches in the trace")
@@ -1089,6 +1089,71 @@ def main():
             return res
         launch_size = guarded("launch_size", run_launch_size)
 
+    # ---- the shard of BASELINE configs[2]'s strong-scaling shape on ONE GPU: 10 000 designs over 8 ranks = 1 250 per rank
+    # (raft/parametersweep.py:39-100).  The same streamed step at 1 250 designs: what one rank of an 8-GPU
+    # strong-scaling run does, so its ms_per_step against this run's 10 000-design step IS the projected 8-GPU speed-up
+    # (no collective while solving; the gather moves 56 B per design).
+    shard_leg = None
+    if rank == 0 and world == 1 and not args.no_extra_legs and stream_steps and "shard" in args.legs and nD >= 8:
+        def run_shard():
+            n_sh = max(1, nD // 8)
+            sw_s, _, _ = make_sweep(ctx, n_sh, 0, pinned=not args.pageable, rows=(0, n_sh), variants=variants)
+            d = args.depth
+            bno = {"next": 1}
+
+            def fresh_s():
+                if variants:
+                    b = bno["next"]
+                    bno["next"] += 1
+                    sw_s.set_params(G_.volturnus_params(scale_rows(b * n_sh, (b + 1) * n_sh)))
+
+            def steps_s(n):
+                out_ = []
+                def sub(i):
+                    fresh_s()
+                    return sw_s.prepare_crossing(ctx, i % d, n_chunk=1)
+                if d == 2:
+                    def submit(i):
+                        fresh_s()
+                        return sw_s.submit_crossing(ctx, i % 2, n_chunk=1)
+                    h = submit(0) if n > 0 else None
+                    for i in range(n):
+                        hn = submit(i + 1) if i + 1 < n else None
+                        out_.append(sw_s.wait_crossing(ctx, h))
+                        h = hn
+                    return out_
+                hs = {i: sub(i) for i in range(min(n, d - 1))}
+                for i in range(min(n, d - 2)):
+                    sw_s.launch_crossing(ctx, hs[i])
+                for i in range(n):
+                    if i + d - 1 < n:
+                        hs[i + d - 1] = sub(i + d - 1)
+                    if i + d - 2 < n:
+                        sw_s.launch_crossing(ctx, hs[i + d - 2])
+                    out_.append(sw_s.wait_crossing(ctx, hs.pop(i)))
+                return out_
+            steps_s(max(12, 2 * d + 1))
+            n_t = max(args.steps, 60)
+            ctx.synchronize()
+            t1 = time.perf_counter()
+            rs = steps_s(n_t)
+            ctx.synchronize()
+            dt_ = (time.perf_counter() - t1) / n_t
+            k_ = float(np.mean([x["timing_ms"][2] for x in rs]))
+            fl_ = float(np.mean([algorithmic_flops(x["strip_off"], nw, x["niter"]) for x in rs]))
+            t10 = elapsed / args.steps
+            return {"designs_per_step": n_sh, "ms_per_step": 1e3 * dt_, "value": n_sh * nw / dt_, "steps": n_t, "kernel_ms_per_launch": k_,
+                    "roofline_frac": fl_ / (k_ * 1e-3) / 1e12 / FP64_VALU_PEAK_TF,
+                    "step_frac": fl_ / dt_ / 1e12 / FP64_VALU_PEAK_TF,
+                    "ms_per_step_of_the_whole_sweep_on_this_gpu": 1e3 * t10,
+                    "projected_8_gpu_strong_speedup": t10 / dt_,
+                    "ideal_ms_per_step": 1e3 * t10 / 8,
+                    "note": "one rank's share of BASELINE configs[2] cut into 8 shards, streamed like the headline step.  1 250 pairs on "
+                            "1 024 resident workgroup places are two residency rounds whatever the launch form (the persistent grid claims "
+                            "them, the second round runs at a quarter of the chip's occupancy): 0.41 us per pair against 0.26 in a long "
+                            "launch -- DESIGN.md 7, profiles/r06_experiments/"}
+        shard_leg = guarded("shard_1250", run_shard)
+
     # ---- roofline.traffic: measured in THIS run where rocprofv3 is at hand (N = 1), else the committed profile's figure
     traffic_bytes, traffic_prov = measured_traffic(nD), traffic_provenance()
     if rank == 0 and world == 1 and not args.no_extra_legs and not args.profile and "traffic" in args.legs:
@@ -1159,7 +1224,7 @@ def main():
         "roofline": {"bound": "fp64_valu", "achieved": flops / (k_sum_ms * 1e-3) / 1e12, "peak": FP64_VALU_PEAK_TF, "unit": "TFLOP/s",
                      "frac": flops / (k_sum_ms * 1e-3) / 1e12 / FP64_VALU_PEAK_TF,
                      "traffic": traffic_bytes, "traffic_from_profile": traffic_prov,
-                     "kernel": "k_solve_dynamics", "kernel_ms_per_step": k_sum_ms, "algorithmic_flops_per_step": flops,
+                     "kernel": "k_solve_dynamics (persistent form raftx_kp_f0: the same body, pairs claimed by a resident grid)", "kernel_ms_per_step": k_sum_ms, "algorithmic_flops_per_step": flops,
                      "kernel_time_is": ("union of the fused launches' spans over the K timed steps / K (consecutive launches overlap)"
                                         if k_union_ms is not None else "HIP events around each launch"),
                      "kernel_ms_per_launch": k_each_ms,
@@ -1201,6 +1266,8 @@ def main():
         out["kernel_resident"] = resident
     if launch_size is not None:
         out["launch_size"] = launch_size
+    if shard_leg is not None:
+        out["shard_1250"] = shard_leg
     if xi_leg is not None:
         out["xi_out"] = xi_leg
         if isinstance(xi_leg, dict) and "streamed_dcf_per_s" in xi_leg:     # SURVEY 8d's literal step (D2H of Xi), beside `value`

@@ -375,6 +375,174 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(RAFTX_S
             if (j < nRhs) Xi[(((size_t)s * nRhs + j) * N + mystep) * nw + iw] = bR[j];
     }
 }
+__device__ __forceinline__ void rowbuf0_w(double *rowbuf_, int i, cplx v) { reinterpret_cast<cplx *>(rowbuf_)[i] = v; }
+// ---- TWO LANES PER ROW (round 6): the arrays of 4 and 5 units (n = 24, 30).
+// k_solve_system_rows above is latency-bound, not throughput-bound: every elimination step is a chain pivot search ->
+// publication of the pivot row (n - k single-lane ds_write_b128, 13 cycles each, on a store path four waves share) ->
+// read-back -> reciprocal -> multiplier -> update, and at 212-256 VGPRs (a whole row + its staged pivot row per lane) only
+// two waves per SIMD are there to cover it (60 ms per 10^7 systems of 24; 36 ms with the stores compiled out,
+// profiles/r05_lu_store_experiment.json).  Here a row is split over a PAIR of lanes -- lane 2r holds the even columns of
+// row r, lane 2r+1 the odd ones -- one system per wavefront (48 or 60 of 64 lanes):
+//   * half the registers per lane (12-15 complex entries + as many staged): four (n = 24) / three (n = 30) waves per SIMD;
+//   * the two owner lanes of the pivot row publish their halves in the SAME store instruction: half the stores (and
+//     half the reads) on every step's critical path;
+//   * the multiplier crosses the pair by one quad-perm DPP move per dword (static per unrolled step: the pivot column's
+//     parity is k & 1).
+// Same pivots (largest |re| + |im|, ties to the lower row), same multipliers, same four-FMA updates in the same order as the
+// one-lane-per-row kernel: the results are the same bits (tests/test_hip_parity.py).  Right-hand sides live in the even lanes.
+template <int NU, int NR, bool RESIDENT, bool ASM = false>
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu((NU <= 4 && NR == 1) ? 4 : 3, (NU <= 4 && NR == 1) ? 4 : 3)))
+k_solve_system_rows2(int nSys, int nRhs, int nw, int nCase, const double *__restrict__ w, const cplx *__restrict__ Zblk,
+                     const double *__restrict__ Mc, const double *__restrict__ Bc, const double *__restrict__ Cc,
+                     const cplx *__restrict__ F, cplx *__restrict__ Xi, const double *__restrict__ uM = nullptr,
+                     const double *__restrict__ uB = nullptr, const double *__restrict__ uC = nullptr,
+                     const double *__restrict__ uBd = nullptr) {
+    constexpr int N = 6 * NU, NH = N / 2;
+    const int s = blockIdx.x / nw, iw = blockIdx.x % nw;
+    const int lane = threadIdx.x, r = lane >> 1, h = lane & 1;
+    const bool row = r < N;
+    const int rr = row ? r : 0;
+    const int g = RESIDENT ? s / nCase : s, ic = RESIDENT ? s % nCase : 0;
+    // the lane's half of row rr of [Z_sys | F] (raft_model.py:1164-1191): columns 2 j + h, j = 0 .. NH - 1
+    cplx a[NH], bR[NR];
+    const double ww = w[iw];
+    const int u = rr / 6, q = rr % 6;
+    const size_t pair = RESIDENT ? ((size_t)g * NU + u) * nCase + ic : (size_t)s * NU + u;
+    cplx zb[3];                                          // the lane's three entries of the unit's own 6 x 6 block row
+    if constexpr (ASM) {
+        const size_t dsg = ((size_t)g * NU + u) * 36 + q * 6, pr = pair * 36 + q * 6;
+        const double w2 = ww * ww;
+#pragma unroll
+        for (int t = 0; t < 3; t++) {
+            const int c = 2 * t + h;
+            const double Bq = uB[dsg + c] + uBd[pr + c];
+            zb[t] = {fma(-w2, uM[dsg + c], uC[dsg + c]), ww * Bq};
+        }
+    } else {
+#pragma unroll
+        for (int t = 0; t < 3; t++) zb[t] = Zblk[((pair * 6 + q) * 6 + 2 * t + h) * nw + iw];
+    }
+#pragma unroll
+    for (int j = 0; j < NR; j++)
+        bR[j] = (j < nRhs && h == 0) ? (RESIDENT ? F[((pair * nRhs + j) * 6 + q) * nw + iw] : F[(((size_t)s * nRhs + j) * N + rr) * nw + iw])
+                                     : cplx{0.0, 0.0};
+    const size_t o = (size_t)g * N * N + (size_t)rr * N;
+#pragma unroll
+    for (int j = 0; j < NH; j++) {
+        const int c = 2 * j + h;
+        const double m = Mc ? Mc[o + c] : 0.0, bb = Bc ? Bc[o + c] : 0.0, kk = Cc ? Cc[o + c] : 0.0;
+        a[j] = {fma(-(ww * ww), m, kk), ww * bb};
+    }
+#pragma unroll
+    for (int j = 0; j < NH; j++) {                       // the diagonal block of the lane's unit: columns 6 u .. 6 u + 5 = j in 3 u .. 3 u + 2
+        const int cu = j / 3;
+        const cplx z = zb[j % 3];
+        a[j].re += cu == u ? z.re : 0.0;
+        a[j].im += cu == u ? z.im : 0.0;
+    }
+    // pivot row buffer: [half][NH + NR] entries; the two owner lanes store their halves in one instruction, every lane reads
+    // its own half back (two addresses per wave: broadcasts)
+    __shared__ __attribute__((aligned(16))) double rowbuf_[2 * 2 * (NH + NR)];
+    cplx *rowbuf = reinterpret_cast<cplx *>(rowbuf_) + h * (NH + NR);
+    const cplx *rowbuf0 = reinterpret_cast<cplx *>(rowbuf_), *rowbuf1 = rowbuf0 + (NH + NR);
+    bool todo = row;
+    int mystep = N;
+    const unsigned rkey = 31u - (unsigned)r;             // ties go to the lower row (izamax takes the first largest)
+#pragma unroll
+    for (int k = 0; k < N; k++) {
+        const int hk = k & 1, jk = k >> 1;               // where column k lives (compile-time per unrolled step)
+        // pivot search (as k_solve_system_rows: (magnitude, row) as one key, two 32-bit DPP max phases) over the lanes that
+        // hold column k
+        const bool cand = todo && h == hk;
+        double best = cand ? fabs(a[jk].re) + fabs(a[jk].im) : -1.0;
+        if (cand && !(best >= 0.0)) best = 0.0;          // NaN: comparable, so that a pivot is always found
+        const unsigned khi = cand ? (unsigned)__double2hiint(best) + 1u : 0u;
+        const unsigned klo = ((unsigned)__double2loint(best) & ~31u) | rkey;
+#define ROW_UMAX_(x)                                                                                   \
+        x = max(x, (unsigned)__builtin_amdgcn_update_dpp(0, (int)x, 0x111, 0xf, 0xf, true));           \
+        x = max(x, (unsigned)__builtin_amdgcn_update_dpp(0, (int)x, 0x112, 0xf, 0xf, true));           \
+        x = max(x, (unsigned)__builtin_amdgcn_update_dpp(0, (int)x, 0x114, 0xf, 0xf, true));           \
+        x = max(x, (unsigned)__builtin_amdgcn_update_dpp(0, (int)x, 0x118, 0xf, 0xf, true));
+        unsigned mh = khi;
+        ROW_UMAX_(mh)                                    // row_shr:1,2,4,8 -> lane 15 of each 16-lane row
+        const unsigned hm = max(max((unsigned)__builtin_amdgcn_readlane((int)mh, 15), (unsigned)__builtin_amdgcn_readlane((int)mh, 31)),
+                                max((unsigned)__builtin_amdgcn_readlane((int)mh, 47), (unsigned)__builtin_amdgcn_readlane((int)mh, 63)));
+        unsigned ml = (cand && khi == hm) ? klo : 0u;
+        ROW_UMAX_(ml)
+#undef ROW_UMAX_
+        const unsigned lm = max(max((unsigned)__builtin_amdgcn_readlane((int)ml, 15), (unsigned)__builtin_amdgcn_readlane((int)ml, 31)),
+                                max((unsigned)__builtin_amdgcn_readlane((int)ml, 47), (unsigned)__builtin_amdgcn_readlane((int)ml, 63)));
+        const int p = 31 - (int)(lm & 31u);
+        const bool mine = todo && r == p;
+        const bool upd = todo && r != p;
+        if (mine) {
+#pragma unroll
+            for (int j = jk; j < NH; j++) rowbuf[j] = a[j];
+            if (h == 0) {
+#pragma unroll
+                for (int j = 0; j < NR; j++) rowbuf[NH + j] = bR[j];
+            }
+        }
+        wave_lds_fence();
+        const cplx pv = (hk ? rowbuf1 : rowbuf0)[jk];
+        const double pp = pv.re * pv.re + pv.im * pv.im;
+        double dinv = __builtin_amdgcn_rcp(pp);
+        dinv = fma(fma(-pp, dinv, 1.0), dinv, dinv);
+        dinv = fma(fma(-pp, dinv, 1.0), dinv, dinv);
+        const cplx inv = {pv.re * dinv, -pv.im * dinv};
+        // the multiplier of the lane's ROW: formed where column k lives, taken over from the pair's other lane elsewhere
+        const cplx lk = cmul(a[jk], inv);
+        const cplx lx = {dpp_mov<0xB1>(lk.re), dpp_mov<0xB1>(lk.im)};       // quad_perm [1,0,3,2]: the pair partner's value
+        const cplx lr = {h == hk ? lk.re : lx.re, h == hk ? lk.im : lx.im};
+        const cplx l = {upd ? lr.re : 0.0, upd ? lr.im : 0.0};
+        // columns c > k: j >= jk + 1 in both halves when k is odd; when k is even the odd half also has j = jk (c = k + 1) -- the
+        // even half's j = jk is the pivot column itself, whose update is harmless (that entry is dead from here on) and keeps
+        // the code the same for both lanes of a pair
+#pragma unroll
+        for (int j = jk + hk; j < NH; j++) {
+            const cplx uu = rowbuf[j];
+            a[j] = cfnma(a[j], l, uu);
+        }
+#pragma unroll
+        for (int j = 0; j < NR; j++) {
+            const cplx uu = rowbuf0[NH + j];
+            bR[j] = cfnma(bR[j], l, uu);                 // (the odd lanes' copies are never read)
+        }
+        if (mine) {
+            todo = false;
+            mystep = k;
+            if (h == hk) a[jk] = inv;                    // the reciprocal pivot, for the back substitution
+        }
+        wave_lds_fence();                                // the buffer is rewritten in the next step
+    }
+    // back substitution in pivot order, in the even lanes (the odd lanes hand their column-k entries across the pair)
+#pragma unroll
+    for (int k = N - 1; k >= 0; k--) {
+        const int hk = k & 1, jk = k >> 1;
+        cplx ak = a[jk];
+        if (hk) ak = cplx{dpp_mov<0xB1>(ak.re), dpp_mov<0xB1>(ak.im)};     // column k is odd: the even lane takes it from its partner
+        if (mystep == k && h == 0) {
+#pragma unroll
+            for (int j = 0; j < NR; j++) {
+                bR[j] = cmul(bR[j], ak);
+                rowbuf0_w(rowbuf_, NH + j, bR[j]);
+            }
+        }
+        wave_lds_fence();
+        const cplx f = {mystep < k ? ak.re : 0.0, mystep < k ? ak.im : 0.0};
+#pragma unroll
+        for (int j = 0; j < NR; j++) {
+            const cplx xk = rowbuf0[NH + j];
+            bR[j] = cfnma(bR[j], f, xk);
+        }
+        wave_lds_fence();
+    }
+    if (row && h == 0 && mystep < N) {
+#pragma unroll
+        for (int j = 0; j < NR; j++)
+            if (j < nRhs) Xi[(((size_t)s * nRhs + j) * N + mystep) * nw + iw] = bR[j];
+    }
+}
 static bool solve_system_rows_ok(int nUnit, int nRhs) {
     static const char *off = getenv("RAFTX_SYSTEM_LDS");                 // tuning / tests: keep the LDS-resident kernel
     return !(off && atoi(off)) && nUnit >= 2 && nUnit <= 5 && nRhs >= 1 && nRhs <= SYSROWS_MAXRHS;
@@ -388,6 +556,19 @@ static bool launch_solve_system_rows(hipStream_t st, int nSys, int nUnit, int nR
     if (!solve_system_rows_ok(nUnit, nRhs)) return false;
     const dim3 grid((unsigned)((size_t)nSys * ((nw + 1) / 2)));
     const int nr = nRhs == 1 ? 1 : (nRhs == 2 ? 2 : 4);
+    // 4 and 5 units: two lanes per row, one system per wavefront (k_solve_system_rows2); RAFTX_SYSROWS2=0 keeps the one-lane form
+    static const bool rows2 = !(getenv("RAFTX_SYSROWS2") && !atoi(getenv("RAFTX_SYSROWS2")));
+    if (rows2 && nUnit >= 4) {
+        const dim3 grid2((unsigned)((size_t)nSys * nw));
+#define ROWS2_CASE(NU_, NR_)                                                                                            \
+        if (nUnit == NU_ && nr == NR_) {                                                                                \
+            hipLaunchKernelGGL((k_solve_system_rows2<NU_, NR_, RESIDENT, ASM>), grid2, dim3(64), 0, st, nSys, nRhs, nw, nCase, w, Z, Mc, Bc, Cc, F, \
+                               X, uM, uB, uC, uBd);                                                                     \
+            return true;                                                                                                \
+        }
+        ROWS2_CASE(4, 1) ROWS2_CASE(4, 2) ROWS2_CASE(4, 4) ROWS2_CASE(5, 1) ROWS2_CASE(5, 2) ROWS2_CASE(5, 4)
+#undef ROWS2_CASE
+    }
 #define ROWS_CASE(NU_, NR_)                                                                                             \
     if (nUnit == NU_ && nr == NR_) {                                                                                    \
         hipLaunchKernelGGL((k_solve_system_rows<NU_, NR_, RESIDENT, ASM>), grid, dim3(64), 0, st, nSys, nRhs, nw, nCase, w, Z, Mc, Bc, Cc, F, X, \
@@ -1919,17 +2100,18 @@ static int launch_persistent(raftx_ctx *c, kp_fn kernel, const DevTables &T, con
     }
     if (!c->kpCtr) {
         void *p_ = nullptr;
-        HIPCHK(c, hipMalloc(&p_, (size_t)KP_RING * 8 * KP_CTR_STRIDE * sizeof(unsigned)));
+        const size_t bytes = (size_t)KP_RING * 9 * KP_CTR_STRIDE * sizeof(unsigned);
+        HIPCHK(c, hipMalloc(&p_, bytes));
         c->kpCtr = reinterpret_cast<unsigned *>(p_);
+        HIPCHK(c, hipMemsetAsync(c->kpCtr, 0, bytes, c->stream));         // once: every launch leaves its set zeroed (kp_leave)
     }
     if (lds > 64 * 1024)
         HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     PersistArgs P;
     P.T = T;
     P.A = A;
-    P.ctr = c->kpCtr + (size_t)(c->kpNext++ % KP_RING) * 8 * KP_CTR_STRIDE;
+    P.ctr = c->kpCtr + (size_t)(c->kpNext++ % KP_RING) * 9 * KP_CTR_STRIDE;   // (a set is reused KP_RING launches of this ctx later)
     P.xl_base = XL_SLOTS;
-    HIPCHK(c, hipMemsetAsync(P.ctr, 0, 8 * KP_CTR_STRIDE * sizeof(unsigned), c->stream));
     static const int grid_env = getenv("RAFTX_KP_GRID") ? atoi(getenv("RAFTX_KP_GRID")) : 0;      // tuning: workgroups of the grid
     size_t grid = (size_t)(grid_env > 0 ? grid_env : wg_per_cu * c->nCU);
     grid = std::min<size_t>(std::min<size_t>(grid, KP_MAX_GRID), grid_for_pairs(npairs));
@@ -1997,11 +2179,12 @@ static int solve_enqueue(raftx_ctx *c, int nIter, double tol, double XiStart, co
     const int minb_used = lean >= 0 ? shape_minb(sh) : 1;
     c->last_flags = lean >= 0 ? lean : KF_ALL;
     c->last_minb = minb_used;
-    const int wg_per_cu = std::max(1, minb_used * 4 / (sh.threads / 64));
+    static const int wgcu_env = getenv("RAFTX_WG_PER_CU") ? atoi(getenv("RAFTX_WG_PER_CU")) : 0;     // tuning: pairs per CU the LDS is budgeted for
+    const int wg_per_cu = wgcu_env > 0 ? wgcu_env : std::max(1, minb_used * 4 / (sh.threads / 64));
     // the persistent form (raftx_kernels.h k_solve_dynamics_p / raftx_kp_f*): lean 200-bin launches of one LDS class that
     // are not cut into slabs; RAFTX_PERSIST=0 keeps the one-workgroup-per-pair launches (A/B, tuning)
     static const bool persist_env = !(getenv("RAFTX_PERSIST") && !atoi(getenv("RAFTX_PERSIST")));
-    const bool persist = persist_env && rc_shape && lean >= 0 && xlg;
+    const bool persist = persist_env && rc_shape && lean >= 0 && (xlg || RAFTX_XL_LDS);
     auto rc_slots = [&](int S_) {
         if (!(shape_maxt(sh) == 128 && sh.nb == 2)) return 0;                // (= rc_shape below)
         static const char *env = getenv("RAFTX_RC_SLOTS");                 // tuning: cap (0 = no cache)
@@ -3351,6 +3534,20 @@ extern "C" int raftx_sweep_prepare_variants(raftx_ctx *c, int slot, int nDesign,
                               stripOffsets, &var);
 }
 
+// The compute stream of a crossing: the ctx stream -- or, RAFTX_SWEEP_STREAMS=2, one of two that crossings of consecutive slots
+// alternate between, so that their persistent grids can be on the chip together.  Measured in round 6 and NOT the default
+// (profiles/r06_experiments/): the fused grids of consecutive 10 000-design batches do not overlap in practice, because what
+// lies between them is the chain member pass -> host -> table generation of the NEXT batch, whose kernels cannot get onto a
+// chip that a persistent grid fills and so run in its drain whatever the streams (3.06-3.09 ms per step on one stream or
+// two, 4 or 12 hardware queues, pipeline depth 3; depth 4: 3.13-3.3); leaving 32-128 workgroup places of the grid free for
+// them does not help either -- a 256-thread block needs room on all four SIMDs of a CU, and a CU with three of its four
+// pairs still has two SIMDs full (3.14-3.35 ms).  The 1 250-design shard gains 8 % of kernel time and nothing per step.
+static hipStream_t slot_stream(raftx_ctx *c, int slot) {
+    static const int n_streams = getenv("RAFTX_SWEEP_STREAMS") ? std::max(1, std::min(2, atoi(getenv("RAFTX_SWEEP_STREAMS")))) : 1;
+    if (n_streams > 1 && !c->sMainB) (void)hipStreamCreateWithFlags(&c->sMainB, hipStreamNonBlocking);
+    return (n_streams > 1 && c->sMainB && (slot & 1)) ? c->sMainB : c->stream;
+}
+
 extern "C" int raftx_sweep_launch(raftx_ctx *c, int slot) {
     RangeScope range_("raftx_sweep_launch: generation + fused fixed point + statistics (enqueue)");
     if (!c) return -1;
@@ -3360,16 +3557,8 @@ extern "C" int raftx_sweep_launch(raftx_ctx *c, int slot) {
     if (S.cset < 0 || c->csets[S.cset].T.nCase != S.nCase || c->csets[S.cset].T.nHead != S.nHead || c->csets[S.cset].T.nw != S.nw)
         FAIL(c, "sweep_launch: slot %d has lost its sea-state tables (internal error)", slot);
     HIPCHK(c, hipSetDevice(c->device));
-    // The compute stream of this crossing.  Crossings of consecutive slots ALTERNATE between two streams (RAFTX_SWEEP_STREAMS=1:
-    // one, as until round 5): the fused kernel is a persistent grid (raftx_kp_f*) whose workgroups leave the chip one by one
-    // over its last ~0.25 ms, and the next crossing's grid -- on the other stream, its tables generated a step earlier --
-    // takes their places as they leave instead of waiting for the last of them: the drain of batch i is the ramp of batch
-    // i+1 (T(n) = 0.33 ms + 0.25 us n per launch: the 0.33 is what the overlap hides).  Everything of ONE crossing (table
-    // generation's hand-over, fused kernel, statistics) stays in order on its stream; crossings two apart share a stream.
-    static const int n_streams = getenv("RAFTX_SWEEP_STREAMS") ? std::max(1, std::min(2, atoi(getenv("RAFTX_SWEEP_STREAMS")))) : 2;
-    const bool two_streams = n_streams > 1;
-    if (two_streams && !c->sMainB) HIPCHK(c, hipStreamCreateWithFlags(&c->sMainB, hipStreamNonBlocking));
-    hipStream_t sM = (two_streams && (slot & 1)) ? c->sMainB : c->stream;
+    hipStream_t sM = slot_stream(c, slot);
+    const bool two_streams = c->sMainB != nullptr;
     for (raftx_ctx *sub : S.blk)
         if (sub) sub->stream = sM;
     if (!c->evEpoch) {

@@ -273,7 +273,10 @@ __device__ __forceinline__ ldptr vsq_of(const Lds &l, int wv, int nwv, int S, in
 // shapes that keep XiLast in global scratch (SolveArgs::Xl, a region per RUNNING workgroup: xl_slot_acquire) instead of LDS: the largest ones (no room), and the
 // two-waves-per-SIMD 200-bin shape, whose LDS goes to the run-start cache instead (XiLast is touched twice per
 // iteration, the run starts fourteen times)
-static __host__ __device__ constexpr bool xl_global(int nb, int maxt) { return (maxt == 512 && nb >= 3) || (maxt == 128 && nb == 2); }
+#ifndef RAFTX_XL_LDS
+#define RAFTX_XL_LDS 0       // tuning build (profiles/r06_xilast_ab.json): 1 = the 200-bin shape keeps XiLast in LDS too (three pairs per CU)
+#endif
+static __host__ __device__ constexpr bool xl_global(int nb, int maxt) { return (maxt == 512 && nb >= 3) || (!RAFTX_XL_LDS && maxt == 128 && nb == 2); }
 
 // LDS traffic between lanes of ONE wave needs no s_barrier (a wave's LDS instructions
 // execute in order); it only needs the compiler to keep the order.
@@ -2675,7 +2678,7 @@ __device__ __forceinline__ void solve_pair(const DevTables &T, const SolveArgs &
     constexpr int STAGE = stage_policy(NB, MAXT);
     constexpr bool XLG = xl_global(NB, MAXT);
     constexpr int PARK = park_policy(NB, MAXT);
-    constexpr bool RC = PARK != 0 && XLG;            // the shape whose spare LDS is a run-start cache (A.rc_n slots)
+    constexpr bool RC = PARK != 0 && (XLG || RAFTX_XL_LDS);   // the shape whose spare LDS is a run-start cache (A.rc_n slots)
     Lds l = carve(smem + (PERSIST ? KP_STASH : 0), S, XLG ? 0 : nw, blockDim.x >> 6, STAGE, PARK, RC ? A.rc_n : 0, RC ? nw : 0);
     XlStore<XLG> xl;
     if constexpr (XLG) {
@@ -2749,7 +2752,7 @@ __device__ __forceinline__ void solve_pair(const DevTables &T, const SolveArgs &
     // follow the second solve -- one round trip to the slab per iteration, its 24 loads in flight together while
     // the registers of the 6x6 systems are dead -- and w * XiLast of the next linearisation stays in registers (Xc)
     // instead of being fetched again at the top of the loop.
-    constexpr bool DEFER = PARK != 0 && XLG;
+    constexpr bool DEFER = PARK != 0 && (XLG || RAFTX_XL_LDS);
     cplx Xc[DEFER ? NB : 1][6];
     if constexpr (DEFER) {
 #pragma unroll
@@ -3035,9 +3038,20 @@ __global__ void __launch_bounds__(MAXT, MINB) k_solve_dynamics(DevTables T, Solv
 struct PersistArgs {
     DevTables T;
     SolveArgs A;
-    unsigned *ctr;          // [8][KP_CTR_STRIDE] claimed positions per XCD slab, zeroed by the host before the launch
+    unsigned *ctr;          // [9][KP_CTR_STRIDE] claimed positions per XCD slab + workgroups that have left; all zero when the
+                            // launch starts, zeroed again by the last workgroup to leave
     unsigned xl_base;       // first XiLast region of this launch (launches in flight at once use disjoint ranges)
 };
+// a persistent workgroup has found the pair list dry
+__device__ __forceinline__ void kp_leave(const PersistArgs &P) {
+    if (threadIdx.x == 0) {
+        unsigned *left = P.ctr + 8 * KP_CTR_STRIDE;
+        const unsigned n = __hip_atomic_fetch_add(left, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (n + 1 == gridDim.x) {                        // the last one out: every claim has been made, the set is clean for its next launch
+            for (int x = 0; x < 9; x++) __hip_atomic_store(P.ctr + x * KP_CTR_STRIDE, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+}
 __device__ __forceinline__ int claim_pair(unsigned *ctr, int nl, LDS_AS int *mail) {
     __syncthreads();                                    // the previous pair's last LDS reads are over
     if (threadIdx.x == 0) {
@@ -3117,7 +3131,10 @@ __device__ __forceinline__ int claim_pair(unsigned *ctr, int nl, LDS_AS int *mai
         }                                                                                                               \
         const int nl = P.A.pairs ? P.A.npairs : P.T.nDesign * P.T.nCase;                                                \
         const int idx = claim_pair(P.ctr, nl, (LDS_AS int *)smem);                                                      \
-        if (idx < 0) return;                                                                                            \
+        if (idx < 0) {                                                                                                  \
+            kp_leave(P);                                                                                                \
+            return;                                                                                                     \
+        }                                                                                                               \
         solve_pair<NB, FLAGS, MAXT, true>(P.T, P.A, idx, P.xl_base + blockIdx.x);                                       \
         RAFTX_KP_REENTER(NAME);                                                                                         \
     }

@@ -347,20 +347,35 @@ class Engine:
 
     def _bem_excitation_units(self, fowts, n_pad=0):
         """F_BEM / F_BEM_fullDOF of the units resident on the context (Model.solveDynamics): one device launch for all
-        units that carry potential-flow coefficients (they must share their BEM heading grid, as the units of a farm do)."""
+        units that carry potential-flow coefficients and share a BEM heading grid (as the units of a farm do), one more
+        per further grid."""
         pot = [bool(getattr(f, "potMod", False) or getattr(f, "potModMaster", 1) in [2, 3]) for f in fowts]
         F6 = None
         if any(pot):
-            heads = [np.asarray(f.BEM_headings, dtype=float) for f, p in zip(fowts, pot) if p]
-            if any(h.shape != heads[0].shape or not np.array_equal(h, heads[0]) for h in heads):
-                raise UnsupportedFOWT("units with different BEM heading grids are not on the device path")
+            # one launch per DISTINCT heading grid (the units of a farm usually share one): every unit is interpolated
+            # between the neighbours of its own grid, exactly as raft_fowt.py:1804-1831 does per FOWT
             nw = fowts[0].nw
-            X = np.zeros((len(fowts) + n_pad, len(heads[0]), 6, nw), dtype=complex)   # n_pad: further designs resident beside the units
+            groups = []                                                     # [(grid, [unit indices])]
             for i, (f, p) in enumerate(zip(fowts, pot)):
-                if p:
-                    X[i] = np.asarray(f.X_BEM)[:, :6, :]
-            F6 = self.ctx.bem_excitation(heads[0], X, heading_adjust=[float(getattr(f, "heading_adjust", 0.0)) for f in fowts] + [0.0] * n_pad,
-                                         xy_ref=[[float(f.x_ref), float(f.y_ref)] for f in fowts] + [[0.0, 0.0]] * n_pad, fetch=True)
+                if not p:
+                    continue
+                hgrid = np.asarray(f.BEM_headings, dtype=float)
+                for g_, idx in groups:
+                    if g_.shape == hgrid.shape and np.array_equal(g_, hgrid):
+                        idx.append(i)
+                        break
+                else:
+                    groups.append((hgrid, [i]))
+            adj = [float(getattr(f, "heading_adjust", 0.0)) for f in fowts] + [0.0] * n_pad
+            xy = [[float(f.x_ref), float(f.y_ref)] for f in fowts] + [[0.0, 0.0]] * n_pad
+            for hgrid, idx in groups:
+                X = np.zeros((len(fowts) + n_pad, len(hgrid), 6, nw), dtype=complex)   # n_pad: further designs resident beside the units
+                for i in idx:
+                    X[i] = np.asarray(fowts[i].X_BEM)[:, :6, :]
+                Fg = self.ctx.bem_excitation(hgrid, X, heading_adjust=adj, xy_ref=xy, fetch=True)
+                if F6 is None:
+                    F6 = np.zeros_like(Fg)
+                F6[idx] = Fg[idx]
         for i, f in enumerate(fowts):
             nFull = int(getattr(f, "nFullDOF", f.nDOF))
             F_full = np.zeros([f.nWaves, nFull, f.nw], dtype=complex)
@@ -685,24 +700,33 @@ class Engine:
             results[key] = np.zeros(nr)
         return results
 
-    def _solve_stepped(self, model, fowts, mats, F_extra, tol, display):
+    def _solve_stepped(self, model, fowts, mats, F_extra, tol, display, qtf_hook=None):
         """The drag fixed point with a host step between iterations -- raft_model.py:1069-1072: with ``moorMod == 2``
         the mooring system's linearised damping is re-evaluated (by MoorPy, on the host) about every iterate.  One
         device launch per iteration (loop bound 1) from an explicit linearisation point; the relaxation (:1133) is done
-        here.  A unit that has converged keeps its linearisation point (:1104-1106 ``break``), so the launches that
-        the slower units of a farm still need reproduce its converged iterate unchanged."""
+        here.  Every unit keeps the reference's OWN loop state (:1052-1142 is a loop per unit): its pass counter, its
+        linearisation point, and -- ``qtf_hook(i, Xi_i) -> F_extra_i`` given, for units with internal QTFs
+        (potSecOrder == 1) -- the re-entry of :1108-1131: at its first convergence the unit's QTFs and second-order
+        force are computed from that response, the force joins its excitation, the pass counter restarts at 1 and the
+        loop goes on from the SAME linearisation point.  A unit that has left its loop is frozen: its results are the
+        ones of the launch it left with, whatever the slower units of a farm still need."""
         ctx = self.ctx
         nF, nw = len(fowts), model.nw
         f0 = fowts[0]
         nIter = int(model.nIter) + 1                                        # :977
         XiLast = np.zeros([nF, 1, 6, nw], dtype=complex) + model.XiStart    # :999
         B_base = [np.array(m[1], dtype=float) for m in mats]
+        F_extra = np.array(F_extra, dtype=complex)
         conv = np.zeros(nF, dtype=bool)
-        niter = np.zeros(nF, dtype=np.int32)
+        done = np.zeros(nF, dtype=bool)
+        it = np.zeros(nF, dtype=np.int64)                                   # the reference's iiter, per unit
+        niter = np.zeros(nF, dtype=np.int32)                                # launches the unit took part in
+        qtf_pending = [qtf_hook is not None and getattr(f, "potSecOrder", 0) == 1 for f in fowts]
+        final = {}
         out = None
-        for iiter in range(nIter):
+        while not done.all():
             for i, fowt in enumerate(fowts):
-                if _dynamic_mooring(fowt) and not conv[i]:
+                if _dynamic_mooring(fowt) and not done[i]:
                     fowt.updateMooringDynamicMatrices(XiLast[i, 0, :6, :], fowt.S[0, :])        # :1070
                     _, _, B6, _ = fowt.ms.getCoupledDynamicMatrices(lines_only=True)
                     mats[i][1] = B_base[i] + translate_matrix_6to6(B6, _mooring_arm(fowt))        # :1072,:1079
@@ -711,21 +735,35 @@ class Engine:
             out = ctx.solve_dynamics(0, tol=tol, XiStart=model.XiStart,
                                      F_extra=F_extra if np.any(F_extra) else None,
                                      want_Xi=True, want_B=True, want_F=True, want_Z=True)
-            if np.any(out['flags'] & 2):
-                break                                                       # NaN: raised by the caller (:1098-1099)
+            if np.any(out['flags'][:nF][~done] & 2):
+                final = {}                                                  # NaN: raised by the caller (:1098-1099)
+                break
             for i in range(nF):
-                if conv[i]:
+                if done[i]:
                     continue
-                niter[i] = iiter + 1
+                niter[i] += 1
                 if out['flags'][i, 0] & 1:
-                    conv[i] = True
+                    if qtf_pending[i]:                                      # :1108-1131
+                        F_extra[i, 0] = qtf_hook(i, out['Xi'][i, 0, 0])
+                        qtf_pending[i] = False
+                        it[i] = 0                                           # (:1114, then the common iiter += 1)
+                    else:
+                        conv[i] = done[i] = True
                 else:
                     XiLast[i, 0] = 0.2 * XiLast[i, 0] + 0.8 * out['Xi'][i, 0, 0]               # :1133
-            if conv.all():
-                break
+                it[i] += 1
+                if it[i] >= nIter:
+                    done[i] = True
+                if done[i]:
+                    for key in ('Xi', 'B_drag', 'F_wave', 'Z'):
+                        final.setdefault(key, {})[i] = np.array(out[key][i])
+        for key, rows in final.items():                                     # every unit: the launch it left its loop with
+            for i, v in rows.items():
+                out[key][i] = v
         out['niter'] = niter[:, None].copy()
         out['flags'] = (out['flags'] & ~1) | conv[:, None].astype(np.int32)
         out['XiLast'] = XiLast                                              # what the reference's loop holds at its exit (:1156)
+        out['F_extra'] = F_extra
         return out
 
     def solveDynamics(self, model, case, tol=0.01, conv_plot=0, RAO_plot=0, display=0):
@@ -765,8 +803,6 @@ class Engine:
             C_moor = fowt.C_moor
             MA_moor = None
             if _dynamic_mooring(fowt):                                      # :1022-1030
-                if getattr(fowt, "potSecOrder", 0) == 1:
-                    raise UnsupportedFOWT("moorMod==2 together with internal QTFs is not on the device path")
                 XiLast0 = np.zeros([fowt.nDOF, nw], dtype=complex) + model.XiStart
                 fowt.updateMooringDynamicMatrices(XiLast0[:6], fowt.S[0, :])
                 M6, A6, _, C6 = fowt.ms.getCoupledDynamicMatrices(lines_only=True)
@@ -822,13 +858,26 @@ class Engine:
         array_dynamic = bool(getattr(model, "ms", None)) and getattr(model, "moorMod", 0) == 2
         if any(internal_qtf) or array_dynamic or self.materialise_members:  # the loop's last linearisation point is needed afterwards
             ctx.set_linearisation_point(None, keep_last=True)
-        if any(_dynamic_mooring(f) for f in fowts):
-            out = self._solve_stepped(model, fowts, mats, F_extra, tol, display)
+        stepped = any(_dynamic_mooring(f) for f in fowts)
+        if stepped:
+            # moorMod == 2 (:1069-1072), with the re-entry of units that compute their QTFs internally inside the same
+            # per-unit loops (:1108-1131)
+            def qtf_hook(i, Xi_i):
+                fowt = fowts[i]
+                if display > 1:
+                    print("Resolving for system response in primary wave direction, now with second-order wave loads.")
+                Xi0 = waves.get_rao(Xi_i, fowt.zeta[0, :])
+                self.calcQTF_slenderBody(fowt, waveHeadInd=0, Xi0=Xi0, verbose=True, iCase=iCase, iWT=i)
+                fowt.Fhydro_2nd_mean[0, :], fowt.Fhydro_2nd[0, :, :] = \
+                    self.calcHydroForce_2ndOrd(fowt, fowt.beta[0], fowt.S[0, :], iCase=iCase, iWT=i)
+                F_extras[i] = fowt.F_BEM + fowt.Fhydro_2nd + F_rotor.get(i, 0.0)
+                return F_extras[i]
+            out = self._solve_stepped(model, fowts, mats, F_extra, tol, display, qtf_hook=qtf_hook if any(internal_qtf) else None)
         else:
             out = ctx.solve_dynamics(int(model.nIter), tol=tol, XiStart=model.XiStart,
                                      F_extra=F_extra if np.any(F_extra) else None,
                                      want_Xi=True, want_B=True, want_F=True, want_Z=True)
-        if any(internal_qtf) and not np.any(out['flags'] & 2):
+        if any(internal_qtf) and not stepped and not np.any(out['flags'] & 2):
             # raft_model.py:1108-1131: units that converged get their QTFs from the converged first-order motions,
             # the second-order force joins F_lin and the drag iteration continues FROM THE SAME Xi_last with the
             # iteration counter reset to 1.  Units without internal QTFs (or unconverged) simply keep their state:
@@ -846,7 +895,7 @@ class Engine:
                     for ih in range(1, fowt.nWaves):                                       # :1210-1211
                         fowt.Fhydro_2nd_mean[ih, :], fowt.Fhydro_2nd[ih, :, :] = \
                             self.calcHydroForce_2ndOrd(fowt, fowt.beta[ih], fowt.S[ih, :])
-                    F_extras[i] = fowt.F_BEM + fowt.Fhydro_2nd
+                    F_extras[i] = fowt.F_BEM + fowt.Fhydro_2nd + F_rotor.get(i, 0.0)   # (:1129 adds to F_lin: the rotors' share stays)
                     rerun = True
             if rerun:
                 if any(not (internal_qtf[i] and (out['flags'][i, 0] & 1)) for i in range(nF)):

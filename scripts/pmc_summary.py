@@ -11,7 +11,7 @@ for d in sorted(os.listdir(src)):
     if not os.path.exists(p):
         continue
     acc = collections.defaultdict(list)
-    rows = [r for r in csv.DictReader(open(p)) if "k_solve_dynamics" in r["Kernel_Name"]]
+    rows = [r for r in csv.DictReader(open(p)) if "k_solve_dynamics" in r["Kernel_Name"] or "raftx_kp_f" in r["Kernel_Name"]]
     # whole-batch launches only: the closing parity crossing downloads its responses and is cut into slabs of one residency round
     gmax = max((int(r["Grid_Size"]) for r in rows), default=0)
     for r in rows:

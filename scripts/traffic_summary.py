@@ -5,7 +5,7 @@ src, shape, designs, dst = sys.argv[1], sys.argv[2], int(sys.argv[3]), sys.argv[
 vals = {}
 for c in ("FETCH_SIZE", "WRITE_SIZE"):
     p = os.path.join(src, "%s_%s" % (shape, c), "b_counter_collection.csv")
-    v = [float(r["Counter_Value"]) for r in csv.DictReader(open(p)) if "k_solve_dynamics" in r["Kernel_Name"]]
+    v = [float(r["Counter_Value"]) for r in csv.DictReader(open(p)) if "k_solve_dynamics" in r["Kernel_Name"] or "raftx_kp_f" in r["Kernel_Name"]]
     vals[c] = sum(v) / len(v) * 1e3          # rocprofv3 reports KB
 out = {"shape": shape, "designs_per_gpu": designs, "kernel": "k_solve_dynamics",
        "FETCH_SIZE_bytes_raw": vals["FETCH_SIZE"], "WRITE_SIZE_bytes_raw": vals["WRITE_SIZE"],

@@ -137,6 +137,32 @@ def test_c5_internal_qtf_solveDynamics(hip_ctx, fixture):
         assert rel_err(f.Z, u["Z"]) < TOL
 
 
+def test_dynamic_mooring_with_internal_qtf(hip_ctx, oracle_ctx):
+    """moorMod == 2 together with potSecOrder == 1 (raft_model.py:1069-1072 and :1108-1131 in one per-unit loop): the stepped
+    fixed point with the QTF re-entry inside it, device (QTF kernels included) against the oracle chain through the same
+    drop-in code -- same MoorPy stand-in call sequence, same iteration counts (the NumPy path is compared with it on live
+    objects in tests/test_dropin_live_reference.py::test_installed_dynamic_mooring_with_internal_qtf)."""
+    from raft_amd import dropin
+    from tests.util import load_model_fixture, case_from_fixture, group_rel_err, attach_fake_lines
+    from tests.test_qtf import _numpy_qtf_backend
+    fx, m_gpu = load_model_fixture("c5_internal_qtf.npz")
+    _, m_cpu = load_model_fixture("c5_internal_qtf.npz")
+    for m in (m_gpu, m_cpu):
+        m.nIter = 10
+        attach_fake_lines(m)
+    case = fx["cases"][0]
+    Xi_gpu = dropin.Engine(hip_ctx).solveDynamics(m_gpu, case_from_fixture(case)).copy()
+    Xi_cpu = dropin.Engine(oracle_ctx, qtf_backend=_numpy_qtf_backend).solveDynamics(m_cpu, case_from_fixture(case)).copy()
+    fg, fc = m_gpu.fowtList[0], m_cpu.fowtList[0]
+    assert fg.ms.calls == fc.ms.calls and fg.ms.calls >= 3
+    assert np.array_equal(m_gpu._raftx_niter, m_cpu._raftx_niter)
+    assert rel_err(fg.qtf, fc.qtf) < TOL
+    assert rel_err(fg.Fhydro_2nd, fc.Fhydro_2nd) < TOL
+    nH = Xi_gpu.shape[0] - 1
+    assert group_rel_err(Xi_gpu[:nH], Xi_cpu[:nH]) < TOL
+    assert rel_err(fg.Z, fc.Z) < TOL
+
+
 def test_restart_from_linearisation_point(hip_ctx, oracle_ctx):
     """raftx_set/fetch_linearisation_point: a restarted solve from the exported Xi_last reproduces the converged
     response in one iteration, identically on both libraries."""
