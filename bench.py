@@ -525,6 +525,37 @@ def emit(out):
     sys.stdout.flush()
 
 
+def stream_steps(sw_, ctx, n, depth, fresh=None, after=None, chunks=1):
+    """n streamed solver-stage steps of the sweep sw_ through the library's slots: depth 2 = submit(i+1), wait(i); depth d > 2 =
+    prepare(i+d-1), launch(i+d-2), wait(i).  fresh(): new candidates before a batch is prepared; after(result): per-step
+    exchange (the gather).  Returns the per-step results."""
+    out_ = []
+    def sub(i, submit=False):
+        if fresh is not None:
+            fresh()
+        return (sw_.submit_crossing if submit else sw_.prepare_crossing)(ctx, i % max(depth, 2), n_chunk=chunks)
+    def done(r):
+        return after(r) if after is not None else r
+    if depth <= 2:
+        h = sub(0, True) if n > 0 else None
+        for i in range(n):
+            hn = sub(i + 1, True) if i + 1 < n else None
+            out_.append(done(sw_.wait_crossing(ctx, h)))
+            h = hn
+        return out_
+    d = depth
+    hs = {i: sub(i) for i in range(min(n, d - 1))}
+    for i in range(min(n, d - 2)):
+        sw_.launch_crossing(ctx, hs[i])
+    for i in range(n):
+        if i + d - 1 < n:
+            hs[i + d - 1] = sub(i + d - 1)
+        if i + d - 2 < n:
+            sw_.launch_crossing(ctx, hs[i + d - 2])
+        out_.append(done(sw_.wait_crossing(ctx, hs.pop(i))))
+    return out_
+
+
 def guarded(name, fn):
     """A leg OUTSIDE the headline must not cost the run its JSON line: its failure -- a parity assertion included -- is
     reported under the leg's key (and on stderr), the headline and its own all-design parity check stay fatal."""
@@ -849,6 +880,37 @@ def main():
             ctx.synchronize()
             single_rank = (time.perf_counter() - ts) / args.steps
             solo["on"] = False
+    # N > 1, weak scaling (the contract line): ALSO the literal shape of BASELINE configs[2] in the same invocation -- ONE sweep of
+    # --designs cut into N contiguous shards, streamed and gathered like the timed steps
+    strong_same = None
+    if comm is not None and not strong and args.designs >= world:
+        sb_ = [shard_bounds(args.designs, r_, world) for r_ in range(world)]
+        cnt_ = np.array([hi_ - lo_ for lo_, hi_ in sb_], dtype=np.int64)
+        sw_st, _, _ = make_sweep(ctx, int(cnt_[rank]), rank, pinned=not args.pageable, rows=sb_[rank], variants=variants)
+        bno_ = {"next": 1}
+
+        def fresh_st():
+            if variants:
+                b = bno_["next"]
+                bno_["next"] += 1
+                sw_st.set_params(G_.volturnus_params(scale_rows(sb_[rank][0] + b * args.designs, sb_[rank][1] + b * args.designs)))
+
+        def gather_st(r):
+            n_ = int(cnt_[rank])
+            comm.gather_rows(np.concatenate([r["std"].reshape(n_, -1), r["niter"].reshape(n_, -1).astype(np.float64)], axis=1), counts=cnt_)
+            return r
+        stream_steps(sw_st, ctx, max(6, 2 * args.depth + 1), args.depth, fresh=fresh_st, after=gather_st)
+        barrier()
+        ts_ = time.perf_counter()
+        stream_steps(sw_st, ctx, args.steps, args.depth, fresh=fresh_st, after=gather_st)
+        barrier()
+        el_ = comm.all_max(time.perf_counter() - ts_)
+        strong_same = {"scaling": "strong", "total_designs": int(args.designs), "shard_designs": [int(c_) for c_ in cnt_],
+                       "ms_per_step": 1e3 * el_ / args.steps, "value": args.designs * nw * args.steps / el_, "steps": args.steps,
+                       "note": "BASELINE configs[2] literally: ONE sweep of %d designs cut into %d shards (one per GPU), each step = every rank's "
+                               "shard solved and its statistics gathered on rank 0; same ranks, same invocation as the weak-scaling line above"
+                               % (args.designs, world)}
+        del sw_st
     barrier()
     del gather_s[:]
     del host_params_s[:]
@@ -1108,30 +1170,7 @@ def main():
                     sw_s.set_params(G_.volturnus_params(scale_rows(b * n_sh, (b + 1) * n_sh)))
 
             def steps_s(n):
-                out_ = []
-                def sub(i):
-                    fresh_s()
-                    return sw_s.prepare_crossing(ctx, i % d, n_chunk=1)
-                if d == 2:
-                    def submit(i):
-                        fresh_s()
-                        return sw_s.submit_crossing(ctx, i % 2, n_chunk=1)
-                    h = submit(0) if n > 0 else None
-                    for i in range(n):
-                        hn = submit(i + 1) if i + 1 < n else None
-                        out_.append(sw_s.wait_crossing(ctx, h))
-                        h = hn
-                    return out_
-                hs = {i: sub(i) for i in range(min(n, d - 1))}
-                for i in range(min(n, d - 2)):
-                    sw_s.launch_crossing(ctx, hs[i])
-                for i in range(n):
-                    if i + d - 1 < n:
-                        hs[i + d - 1] = sub(i + d - 1)
-                    if i + d - 2 < n:
-                        sw_s.launch_crossing(ctx, hs[i + d - 2])
-                    out_.append(sw_s.wait_crossing(ctx, hs.pop(i)))
-                return out_
+                return stream_steps(sw_s, ctx, n, d, fresh=fresh_s)
             steps_s(max(12, 2 * d + 1))
             n_t = max(args.steps, 60)
             ctx.synchronize()
@@ -1258,6 +1297,8 @@ def main():
                                                           "%s" % (nD, " (strong scaling: a shard, not the whole sweep -- the one-GPU time of the whole "
                                                                       "sweep is the N = 1 run of the same command)" if strong else "")}
             out["scaling_efficiency"] = value / (world * v1)
+    if strong_same is not None and rank == 0:
+        out["strong_same_invocation"] = strong_same
     if isolated is not None:
         out["isolated_call"] = {"ms_per_step": 1e3 * isolated, "dcf_per_s_per_gpu": n_dcf_rank / isolated,
                                 "note": "the same step as one blocking raftx_sweep_stats call with nothing else in flight "

@@ -214,6 +214,20 @@ int raftx_channel_stats(raftx_ctx *ctx, int nChan, const double *L, const int32_
 int raftx_channel_stats_poly(raftx_ctx *ctx, int nChan, const double *L, const raftx_c128 *Gw, double dw,
                              double *std, double *psd);
 
+/* The same statistics for a response the CALLER holds, with any number of degrees of freedom: units with flexible members
+ * (raft_fowt.py's T reduction: 150 reduced DOFs for the flexible VolturnUS-S) are solved by raftx_flex_solve /
+ * raftx_solve_dense, whose responses are returned, not kept.  Channel c:
+ *   y_c(ih,w) = sum_{p=0..2} (i w)^p sum_j L[c,p,j] Xi[ih,j,w]  +  sum_j Gw[c,j,w] Xi[ih,j,w],
+ *   std[c] = sqrt(0.5 sum_{ih,w} |y_c|^2),   psd[c,w] = sum_ih 0.5 |y_c|^2 / dw.
+ * What FOWT.saveTurbineOutputs computes for such a unit: platform motions at the PRP (raft/raft_fowt.py:2299-2355), hub
+ * accelerations (:2422-2444) and -- for a FLEXIBLE tower -- the internal loads at the tower base from the finite-element
+ * stiffness, Fi_base = -(Kf Xi_internal)[base node] (:2540-2601), all linear in the reduced response through the rows of T
+ * (host feeder: raft_amd/dropin.py general_output_rows).
+ * w [nw]; L [nChan,3,nDof] real; Gw [nChan,nDof,nw] complex or NULL; Xi [nResp,nDof,nw] (nResp = wave headings + 1);
+ * std [nChan]; psd [nChan,nw] or NULL.  Independent of the upload_* state of the ctx. */
+int raftx_response_stats(raftx_ctx *ctx, int nChan, int nDof, int nResp, int nw, const double *w, const double *L,
+                         const raftx_c128 *Gw, const raftx_c128 *Xi, double dw, double *std, double *psd);
+
 /* Coupled array solve, raft_model.py:1164-1236: for each system s and bin w
  *   Z_sys = blockdiag_i(Zblk[s,i]) + (-w^2 Mc[s] + i w Bc[s] + Cc[s]);
  *   Xi[s,r] = Z_sys^-1 F[s,r].

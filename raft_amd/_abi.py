@@ -35,7 +35,7 @@ EXPORTS = (
     "raftx_comm_unique_id", "raftx_comm_init", "raftx_comm_destroy", "raftx_comm_broadcast", "raftx_comm_gather_rows",
     "raftx_comm_gather_xi", "raftx_comm_reduce_sum",
     "raftx_variant_program", "raftx_expand_variants", "raftx_sweep_prepare_variants",
-    "raftx_strip_kinematics", "raftx_strip_drag",
+    "raftx_strip_kinematics", "raftx_strip_drag", "raftx_response_stats",
 )
 WANT_BDRAG, WANT_FWAVE, WANT_Z = 1, 2, 4
 
@@ -190,6 +190,8 @@ class RaftxLib:
         L.raftx_sweep_prepare_variants.restype = C.c_int
         L.raftx_sweep_wait.argtypes = [_vp, C.c_int, _vp]
         L.raftx_sweep_wait.restype = C.c_int
+        L.raftx_response_stats.argtypes = [_vp, C.c_int, C.c_int, C.c_int, C.c_int, _vp, _vp, _vp, _vp, C.c_double, _vp, _vp]
+        L.raftx_response_stats.restype = C.c_int
         L.raftx_sweep_solve_span.argtypes = [_vp, C.c_int, _vp, _vp]
         L.raftx_sweep_solve_span.restype = C.c_int
         L.raftx_sweep_cancel.argtypes = [_vp, C.c_int]
@@ -818,6 +820,24 @@ class Context:
         psd = np.empty((self.nDesign, self.nCase, nCh, self.nw), dtype=np.float64) if want_psd else None
         rc = self.rlib.lib.raftx_channel_stats_poly(self._h, nCh, _ptr(L), _ptr(Gw), float(dw), _ptr(std), _ptr(psd))
         self._check(rc, "raftx_channel_stats_poly")
+        return std, psd
+
+    def response_stats(self, w, L, Xi, dw, Gw=None, want_psd=False):
+        """std [nChan] (and PSD [nChan,nw]) of y_c = sum_p (i w)^p L[c,p,:] . Xi + Gw[c,:,w] . Xi for a response the caller
+        holds (raftx_response_stats): Xi [nResp,nDof,nw] with any number of DOFs, L [nChan,3,nDof], Gw [nChan,nDof,nw]."""
+        Xi = _c128(np.ascontiguousarray(Xi), None, "Xi")
+        nResp, nDof, nw = Xi.shape
+        L = _f64(L)
+        nCh = L.shape[0]
+        L = _f64(L, (nCh, 3, nDof), "L")
+        w = _f64(w, (nw,), "w")
+        if Gw is not None:
+            Gw = _c128(np.ascontiguousarray(Gw), (nCh, nDof, nw), "Gw")
+        std = np.empty(nCh, dtype=np.float64)
+        psd = np.empty((nCh, nw), dtype=np.float64) if want_psd else None
+        rc = self.rlib.lib.raftx_response_stats(self._h, nCh, nDof, nResp, nw, _ptr(w), _ptr(L), _ptr(Gw), _ptr(Xi), float(dw),
+                                                _ptr(std), _ptr(psd))
+        self._check(rc, "raftx_response_stats")
         return std, psd
 
     def motion_stats(self, dw, want_psd=False):

@@ -7,7 +7,12 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 SRC = os.path.join(HERE, "raftx_hip.hip")
 OUT = os.path.join(HERE, "libraftx_hip.so")
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", "-fno-gpu-rdc"]
+# -disable-machine-licm: the register-starved kernels of this library (the fused fixed point sits at 256 VGPRs with ~120 SGPRs
+# spilled to lanes) lose more to loop-invariant literals hoisted into registers -- and then spilled -- than they gain:
+# with it off the fused kernel needs 247 VGPRs / 80 spilled SGPRs, 16 of the 41 specialisations that had scratch lose it
+# (k_linearize at the drop-in's shape among them), the fused kernels run 1-2 % faster and the QTF kernels 1 % slower
+# (same-box A/B of the whole bench: profiles/r06_experiments/machine_licm_off_whole_bench_ab.txt).
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", "-fno-gpu-rdc", "-mllvm", "-disable-machine-licm"]
 
 
 def build(force=False, verbose=False, extra=()):

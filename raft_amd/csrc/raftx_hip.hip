@@ -198,9 +198,16 @@ __global__ void __launch_bounds__(256) k_solve_system(int nSys, int nUnit, int n
 // raft_model.py:1191), the pivot search is a two-phase 32-bit DPP argmax within the half-wave, the pivot row reaches the other
 // rows through a row buffer in LDS (its owner lane stores it, everyone reads it back as a broadcast).  ~3.7 k VALU
 // instructions per PAIR of systems against ~10 k per system of the LDS-resident kernel above (whose update loop spends its
-// time on index arithmetic, and whose assembly through LDS is a chain of dependent loads).  What bounds it -- the LDS STORE
-// path: 24 of its 60 ms per 10^7 systems, measured with the stores compiled out; a software-pipelined publication of the
-// next pivot row between the FMAs measured 16 % slower -- is in DESIGN.md 3.3 and profiles/r05_lu_store_experiment.json.
+// time on index arithmetic, and whose assembly through LDS is a chain of dependent loads).  What bounds it -- the LDS itself:
+// a published pivot-row entry costs 8 LDS-array cycles whatever the store's width or active lanes (ds_write_b128 is eight
+// 8-lane groups; 4 x b32 is four times two 32-lane groups) plus 4 to read it back, ~2 100 LDS cycles per system on the ONE
+// LDS of a CU = 37 ms per 10^7 systems before anything else; 24 of the 60 ms go with the stores compiled out
+// (profiles/r05_lu_store_experiment.json); a software-pipelined publication measured 16 % slower.  Round 6 built the
+// variant with TWO LANES PER ROW (half the registers, four waves per SIMD instead of two, both owner lanes storing in one
+// instruction): bit-identical and NOT faster (61.0 against 60.2 ms, profiles/r06_experiments/lu_two_lanes_per_row.txt) --
+// more waves cannot help a kernel bound by LDS-array cycles per system, and the one-lane form already shares every store
+// between its two systems.  Removed again.  What would cut the published volume is a blocked factorisation whose trailing
+// update runs on the matrix pipe (v_mfma_f64_16x16x4), at the price of the pivots' bit-identity: DESIGN.md 3.3.
 #define SYSROWS_MAXRHS 4
 // ASM (resident form only): the units' 6 x 6 impedance blocks are ASSEMBLED here, Z = -w^2 M0 + i w (B0 + B_drag) + C0 with the
 // unit kernel's own expression (assemble_and_solve: fma(-w^2, M, C), w * (B0 + Bd) -- the same bits), from 36 x 4 doubles
@@ -375,174 +382,6 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(RAFTX_S
             if (j < nRhs) Xi[(((size_t)s * nRhs + j) * N + mystep) * nw + iw] = bR[j];
     }
 }
-__device__ __forceinline__ void rowbuf0_w(double *rowbuf_, int i, cplx v) { reinterpret_cast<cplx *>(rowbuf_)[i] = v; }
-// ---- TWO LANES PER ROW (round 6): the arrays of 4 and 5 units (n = 24, 30).
-// k_solve_system_rows above is latency-bound, not throughput-bound: every elimination step is a chain pivot search ->
-// publication of the pivot row (n - k single-lane ds_write_b128, 13 cycles each, on a store path four waves share) ->
-// read-back -> reciprocal -> multiplier -> update, and at 212-256 VGPRs (a whole row + its staged pivot row per lane) only
-// two waves per SIMD are there to cover it (60 ms per 10^7 systems of 24; 36 ms with the stores compiled out,
-// profiles/r05_lu_store_experiment.json).  Here a row is split over a PAIR of lanes -- lane 2r holds the even columns of
-// row r, lane 2r+1 the odd ones -- one system per wavefront (48 or 60 of 64 lanes):
-//   * half the registers per lane (12-15 complex entries + as many staged): four (n = 24) / three (n = 30) waves per SIMD;
-//   * the two owner lanes of the pivot row publish their halves in the SAME store instruction: half the stores (and
-//     half the reads) on every step's critical path;
-//   * the multiplier crosses the pair by one quad-perm DPP move per dword (static per unrolled step: the pivot column's
-//     parity is k & 1).
-// Same pivots (largest |re| + |im|, ties to the lower row), same multipliers, same four-FMA updates in the same order as the
-// one-lane-per-row kernel: the results are the same bits (tests/test_hip_parity.py).  Right-hand sides live in the even lanes.
-template <int NU, int NR, bool RESIDENT, bool ASM = false>
-__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu((NU <= 4 && NR == 1) ? 4 : 3, (NU <= 4 && NR == 1) ? 4 : 3)))
-k_solve_system_rows2(int nSys, int nRhs, int nw, int nCase, const double *__restrict__ w, const cplx *__restrict__ Zblk,
-                     const double *__restrict__ Mc, const double *__restrict__ Bc, const double *__restrict__ Cc,
-                     const cplx *__restrict__ F, cplx *__restrict__ Xi, const double *__restrict__ uM = nullptr,
-                     const double *__restrict__ uB = nullptr, const double *__restrict__ uC = nullptr,
-                     const double *__restrict__ uBd = nullptr) {
-    constexpr int N = 6 * NU, NH = N / 2;
-    const int s = blockIdx.x / nw, iw = blockIdx.x % nw;
-    const int lane = threadIdx.x, r = lane >> 1, h = lane & 1;
-    const bool row = r < N;
-    const int rr = row ? r : 0;
-    const int g = RESIDENT ? s / nCase : s, ic = RESIDENT ? s % nCase : 0;
-    // the lane's half of row rr of [Z_sys | F] (raft_model.py:1164-1191): columns 2 j + h, j = 0 .. NH - 1
-    cplx a[NH], bR[NR];
-    const double ww = w[iw];
-    const int u = rr / 6, q = rr % 6;
-    const size_t pair = RESIDENT ? ((size_t)g * NU + u) * nCase + ic : (size_t)s * NU + u;
-    cplx zb[3];                                          // the lane's three entries of the unit's own 6 x 6 block row
-    if constexpr (ASM) {
-        const size_t dsg = ((size_t)g * NU + u) * 36 + q * 6, pr = pair * 36 + q * 6;
-        const double w2 = ww * ww;
-#pragma unroll
-        for (int t = 0; t < 3; t++) {
-            const int c = 2 * t + h;
-            const double Bq = uB[dsg + c] + uBd[pr + c];
-            zb[t] = {fma(-w2, uM[dsg + c], uC[dsg + c]), ww * Bq};
-        }
-    } else {
-#pragma unroll
-        for (int t = 0; t < 3; t++) zb[t] = Zblk[((pair * 6 + q) * 6 + 2 * t + h) * nw + iw];
-    }
-#pragma unroll
-    for (int j = 0; j < NR; j++)
-        bR[j] = (j < nRhs && h == 0) ? (RESIDENT ? F[((pair * nRhs + j) * 6 + q) * nw + iw] : F[(((size_t)s * nRhs + j) * N + rr) * nw + iw])
-                                     : cplx{0.0, 0.0};
-    const size_t o = (size_t)g * N * N + (size_t)rr * N;
-#pragma unroll
-    for (int j = 0; j < NH; j++) {
-        const int c = 2 * j + h;
-        const double m = Mc ? Mc[o + c] : 0.0, bb = Bc ? Bc[o + c] : 0.0, kk = Cc ? Cc[o + c] : 0.0;
-        a[j] = {fma(-(ww * ww), m, kk), ww * bb};
-    }
-#pragma unroll
-    for (int j = 0; j < NH; j++) {                       // the diagonal block of the lane's unit: columns 6 u .. 6 u + 5 = j in 3 u .. 3 u + 2
-        const int cu = j / 3;
-        const cplx z = zb[j % 3];
-        a[j].re += cu == u ? z.re : 0.0;
-        a[j].im += cu == u ? z.im : 0.0;
-    }
-    // pivot row buffer: [half][NH + NR] entries; the two owner lanes store their halves in one instruction, every lane reads
-    // its own half back (two addresses per wave: broadcasts)
-    __shared__ __attribute__((aligned(16))) double rowbuf_[2 * 2 * (NH + NR)];
-    cplx *rowbuf = reinterpret_cast<cplx *>(rowbuf_) + h * (NH + NR);
-    const cplx *rowbuf0 = reinterpret_cast<cplx *>(rowbuf_), *rowbuf1 = rowbuf0 + (NH + NR);
-    bool todo = row;
-    int mystep = N;
-    const unsigned rkey = 31u - (unsigned)r;             // ties go to the lower row (izamax takes the first largest)
-#pragma unroll
-    for (int k = 0; k < N; k++) {
-        const int hk = k & 1, jk = k >> 1;               // where column k lives (compile-time per unrolled step)
-        // pivot search (as k_solve_system_rows: (magnitude, row) as one key, two 32-bit DPP max phases) over the lanes that
-        // hold column k
-        const bool cand = todo && h == hk;
-        double best = cand ? fabs(a[jk].re) + fabs(a[jk].im) : -1.0;
-        if (cand && !(best >= 0.0)) best = 0.0;          // NaN: comparable, so that a pivot is always found
-        const unsigned khi = cand ? (unsigned)__double2hiint(best) + 1u : 0u;
-        const unsigned klo = ((unsigned)__double2loint(best) & ~31u) | rkey;
-#define ROW_UMAX_(x)                                                                                   \
-        x = max(x, (unsigned)__builtin_amdgcn_update_dpp(0, (int)x, 0x111, 0xf, 0xf, true));           \
-        x = max(x, (unsigned)__builtin_amdgcn_update_dpp(0, (int)x, 0x112, 0xf, 0xf, true));           \
-        x = max(x, (unsigned)__builtin_amdgcn_update_dpp(0, (int)x, 0x114, 0xf, 0xf, true));           \
-        x = max(x, (unsigned)__builtin_amdgcn_update_dpp(0, (int)x, 0x118, 0xf, 0xf, true));
-        unsigned mh = khi;
-        ROW_UMAX_(mh)                                    // row_shr:1,2,4,8 -> lane 15 of each 16-lane row
-        const unsigned hm = max(max((unsigned)__builtin_amdgcn_readlane((int)mh, 15), (unsigned)__builtin_amdgcn_readlane((int)mh, 31)),
-                                max((unsigned)__builtin_amdgcn_readlane((int)mh, 47), (unsigned)__builtin_amdgcn_readlane((int)mh, 63)));
-        unsigned ml = (cand && khi == hm) ? klo : 0u;
-        ROW_UMAX_(ml)
-#undef ROW_UMAX_
-        const unsigned lm = max(max((unsigned)__builtin_amdgcn_readlane((int)ml, 15), (unsigned)__builtin_amdgcn_readlane((int)ml, 31)),
-                                max((unsigned)__builtin_amdgcn_readlane((int)ml, 47), (unsigned)__builtin_amdgcn_readlane((int)ml, 63)));
-        const int p = 31 - (int)(lm & 31u);
-        const bool mine = todo && r == p;
-        const bool upd = todo && r != p;
-        if (mine) {
-#pragma unroll
-            for (int j = jk; j < NH; j++) rowbuf[j] = a[j];
-            if (h == 0) {
-#pragma unroll
-                for (int j = 0; j < NR; j++) rowbuf[NH + j] = bR[j];
-            }
-        }
-        wave_lds_fence();
-        const cplx pv = (hk ? rowbuf1 : rowbuf0)[jk];
-        const double pp = pv.re * pv.re + pv.im * pv.im;
-        double dinv = __builtin_amdgcn_rcp(pp);
-        dinv = fma(fma(-pp, dinv, 1.0), dinv, dinv);
-        dinv = fma(fma(-pp, dinv, 1.0), dinv, dinv);
-        const cplx inv = {pv.re * dinv, -pv.im * dinv};
-        // the multiplier of the lane's ROW: formed where column k lives, taken over from the pair's other lane elsewhere
-        const cplx lk = cmul(a[jk], inv);
-        const cplx lx = {dpp_mov<0xB1>(lk.re), dpp_mov<0xB1>(lk.im)};       // quad_perm [1,0,3,2]: the pair partner's value
-        const cplx lr = {h == hk ? lk.re : lx.re, h == hk ? lk.im : lx.im};
-        const cplx l = {upd ? lr.re : 0.0, upd ? lr.im : 0.0};
-        // columns c > k: j >= jk + 1 in both halves when k is odd; when k is even the odd half also has j = jk (c = k + 1) -- the
-        // even half's j = jk is the pivot column itself, whose update is harmless (that entry is dead from here on) and keeps
-        // the code the same for both lanes of a pair
-#pragma unroll
-        for (int j = jk + hk; j < NH; j++) {
-            const cplx uu = rowbuf[j];
-            a[j] = cfnma(a[j], l, uu);
-        }
-#pragma unroll
-        for (int j = 0; j < NR; j++) {
-            const cplx uu = rowbuf0[NH + j];
-            bR[j] = cfnma(bR[j], l, uu);                 // (the odd lanes' copies are never read)
-        }
-        if (mine) {
-            todo = false;
-            mystep = k;
-            if (h == hk) a[jk] = inv;                    // the reciprocal pivot, for the back substitution
-        }
-        wave_lds_fence();                                // the buffer is rewritten in the next step
-    }
-    // back substitution in pivot order, in the even lanes (the odd lanes hand their column-k entries across the pair)
-#pragma unroll
-    for (int k = N - 1; k >= 0; k--) {
-        const int hk = k & 1, jk = k >> 1;
-        cplx ak = a[jk];
-        if (hk) ak = cplx{dpp_mov<0xB1>(ak.re), dpp_mov<0xB1>(ak.im)};     // column k is odd: the even lane takes it from its partner
-        if (mystep == k && h == 0) {
-#pragma unroll
-            for (int j = 0; j < NR; j++) {
-                bR[j] = cmul(bR[j], ak);
-                rowbuf0_w(rowbuf_, NH + j, bR[j]);
-            }
-        }
-        wave_lds_fence();
-        const cplx f = {mystep < k ? ak.re : 0.0, mystep < k ? ak.im : 0.0};
-#pragma unroll
-        for (int j = 0; j < NR; j++) {
-            const cplx xk = rowbuf0[NH + j];
-            bR[j] = cfnma(bR[j], f, xk);
-        }
-        wave_lds_fence();
-    }
-    if (row && h == 0 && mystep < N) {
-#pragma unroll
-        for (int j = 0; j < NR; j++)
-            if (j < nRhs) Xi[(((size_t)s * nRhs + j) * N + mystep) * nw + iw] = bR[j];
-    }
-}
 static bool solve_system_rows_ok(int nUnit, int nRhs) {
     static const char *off = getenv("RAFTX_SYSTEM_LDS");                 // tuning / tests: keep the LDS-resident kernel
     return !(off && atoi(off)) && nUnit >= 2 && nUnit <= 5 && nRhs >= 1 && nRhs <= SYSROWS_MAXRHS;
@@ -556,19 +395,6 @@ static bool launch_solve_system_rows(hipStream_t st, int nSys, int nUnit, int nR
     if (!solve_system_rows_ok(nUnit, nRhs)) return false;
     const dim3 grid((unsigned)((size_t)nSys * ((nw + 1) / 2)));
     const int nr = nRhs == 1 ? 1 : (nRhs == 2 ? 2 : 4);
-    // 4 and 5 units: two lanes per row, one system per wavefront (k_solve_system_rows2); RAFTX_SYSROWS2=0 keeps the one-lane form
-    static const bool rows2 = !(getenv("RAFTX_SYSROWS2") && !atoi(getenv("RAFTX_SYSROWS2")));
-    if (rows2 && nUnit >= 4) {
-        const dim3 grid2((unsigned)((size_t)nSys * nw));
-#define ROWS2_CASE(NU_, NR_)                                                                                            \
-        if (nUnit == NU_ && nr == NR_) {                                                                                \
-            hipLaunchKernelGGL((k_solve_system_rows2<NU_, NR_, RESIDENT, ASM>), grid2, dim3(64), 0, st, nSys, nRhs, nw, nCase, w, Z, Mc, Bc, Cc, F, \
-                               X, uM, uB, uC, uBd);                                                                     \
-            return true;                                                                                                \
-        }
-        ROWS2_CASE(4, 1) ROWS2_CASE(4, 2) ROWS2_CASE(4, 4) ROWS2_CASE(5, 1) ROWS2_CASE(5, 2) ROWS2_CASE(5, 4)
-#undef ROWS2_CASE
-    }
 #define ROWS_CASE(NU_, NR_)                                                                                             \
     if (nUnit == NU_ && nr == NR_) {                                                                                    \
         hipLaunchKernelGGL((k_solve_system_rows<NU_, NR_, RESIDENT, ASM>), grid, dim3(64), 0, st, nSys, nRhs, nw, nCase, w, Z, Mc, Bc, Cc, F, X, \
@@ -798,6 +624,49 @@ __global__ void __launch_bounds__(256) k_channel_stats_poly(int nCase, int nHead
             for (int q = 0; q < (int)(blockDim.x >> 6); q++) a += part[q];
             sd[(size_t)p * nChan + ch] = sqrt(0.5 * a);
         }
+    }
+}
+
+// The same for a response with any number of DOFs handed over by the caller (raftx_response_stats): one workgroup per channel,
+// lanes over the bins, the DOF loop inside (coalesced reads of the [.,nw] slabs)
+__global__ void __launch_bounds__(256) k_response_stats(int nDof, int nResp, int nw, double inv_dw, const double *__restrict__ w,
+                                                        const cplx *__restrict__ Xi, const double *__restrict__ L,
+                                                        const cplx *__restrict__ Gw, double *__restrict__ sd, double *__restrict__ psd) {
+    __shared__ double part[4];
+    const int ch = blockIdx.x;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const double *row = L + (size_t)ch * 3 * nDof;
+    const cplx *g = Gw ? Gw + (size_t)ch * nDof * nw : nullptr;
+    double acc = 0.0;
+    for (int i = threadIdx.x; i < nw; i += blockDim.x) {
+        const double wi = w[i], w2 = wi * wi;
+        double a2 = 0.0;
+        for (int ih = 0; ih < nResp; ih++) {
+            const cplx *x = Xi + ((size_t)ih * nDof) * nw + i;
+            double yr = 0.0, yi = 0.0;
+            for (int j = 0; j < nDof; j++) {
+                const cplx xj = x[(size_t)j * nw];
+                double cr = row[j] - w2 * row[2 * nDof + j], ci = wi * row[nDof + j];     // L0 + (i w) L1 + (i w)^2 L2
+                if (g) {
+                    const cplx gj = g[(size_t)j * nw + i];
+                    cr += gj.re;
+                    ci += gj.im;
+                }
+                yr += cr * xj.re - ci * xj.im;
+                yi += cr * xj.im + ci * xj.re;
+            }
+            a2 += yr * yr + yi * yi;
+        }
+        acc += a2;
+        if (psd) psd[(size_t)ch * nw + i] = 0.5 * a2 * inv_dw;
+    }
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
+    if (lane == 0) part[wv] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double a = 0.0;
+        for (int q = 0; q < (int)(blockDim.x >> 6); q++) a += part[q];
+        sd[ch] = sqrt(0.5 * a);
     }
 }
 
@@ -2572,6 +2441,33 @@ extern "C" int raftx_channel_stats_poly(raftx_ctx *c, int nChan, const double *L
     if (finish_timed(c)) return -2;
     if (npair && nChan) D2H(c, sd, dS, npair * nChan * sizeof(double));
     if (npair && nChan && psd) D2H(c, psd, dPsd, npair * nChan * T.nw * sizeof(double));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+extern "C" int raftx_response_stats(raftx_ctx *c, int nChan, int nDof, int nResp, int nw, const double *w, const double *L,
+                                    const raftx_c128 *Gw, const raftx_c128 *Xi, double dw, double *sd, double *psd) {
+    RangeScope range_("raftx_response_stats: linear channels of a caller-held response");
+    if (!c) return -1;
+    if (nChan < 0 || nDof < 1 || nResp < 1 || nw < 1 || !w || (nChan && !L) || !Xi || !sd) FAIL(c, "response_stats: bad arguments");
+    if (!nChan) return 0;
+    HIPCHK(c, hipSetDevice(c->device));
+    Scratch sc(c);
+    const size_t nl = (size_t)nChan * 3 * nDof, ng = (size_t)nChan * nDof * nw, nx = (size_t)nResp * nDof * nw;
+    double *dw_ = sc.alloc<double>(nw), *dL = sc.alloc<double>(nl), *dS = sc.alloc<double>(nChan);
+    double *dP = psd ? sc.alloc<double>((size_t)nChan * nw) : nullptr;
+    cplx *dG = Gw ? sc.alloc<cplx>(ng) : nullptr, *dX = sc.alloc<cplx>(nx);
+    if (!dw_ || !dL || !dS || (psd && !dP) || (Gw && !dG) || !dX) FAIL(c, "response_stats: device allocation failed");
+    H2D(c, dw_, w, nw * sizeof(double));
+    H2D(c, dL, L, nl * sizeof(double));
+    if (dG) H2D(c, dG, Gw, ng * sizeof(cplx));
+    H2D(c, dX, Xi, nx * sizeof(cplx));
+    HIPCHK(c, hipEventRecord(c->ev0, c->stream));
+    hipLaunchKernelGGL(k_response_stats, dim3((unsigned)nChan), dim3(nw > 128 ? 256 : (nw > 64 ? 128 : 64)), 0, c->stream, nDof, nResp, nw,
+                       1.0 / dw, dw_, dX, dL, dG, dS, dP);
+    if (finish_timed(c)) return -2;
+    D2H(c, sd, dS, nChan * sizeof(double));
+    if (psd) D2H(c, psd, dP, (size_t)nChan * nw * sizeof(double));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     return 0;
 }

@@ -335,6 +335,7 @@ class Engine:
         model._raftx_niter = np.array([niter], dtype=np.int32)
         model._raftx_flags = np.array([1 if converged else 0], dtype=np.int32)
         self._resident = None
+        self._general_solved = fowt                                          # saveTurbineOutputs of this unit: from fowt.Xi (host)
         return model.Xi
 
     def _bem_excitation(self, fowt):
@@ -627,6 +628,11 @@ class Engine:
         getRMS / getPSD of the method -- are ONE statistics launch over the resident responses
         (raftx_channel_stats_poly); means, +-3 sigma bounds and the response amplitudes are host scalars / views.
         Mooring-tension and rotor-controller blocks need MoorPy / CCBlade state and are outside the device path."""
+        if _general(fowt):
+            if getattr(self, "_general_solved", None) is not fowt:
+                raise UnsupportedFOWT("saveTurbineOutputs: this engine has not solved this FOWT (call solveDynamics of its "
+                                      "single-unit model first)")
+            return self._save_outputs_general(fowt, results, case)
         if getattr(self, "_resident", None) is not fowt:
             raise UnsupportedFOWT("saveTurbineOutputs: the responses of this FOWT are not resident on the device "
                                   "(call solveDynamics of its single-unit model first)")
@@ -690,6 +696,139 @@ class Engine:
             results["Mbase_PSD"][:, ir] = psd[c]
             results["Mbase_max"][ir] = results["Mbase_avg"][ir] + 3 * std[c]
             results["Mbase_min"][ir] = results["Mbase_avg"][ir] - 3 * std[c]
+        zeta = np.asarray(fowt.zeta)
+        results["wave_PSD"] = np.sum(0.5 * np.abs(zeta) ** 2 / fowt.dw, axis=0)                       # getPSD(zeta, dw)
+        for key in ("omega", "torque", "bPitch"):
+            results[key + "_avg"] = np.zeros(nr)
+            results[key + "_std"] = np.zeros(nr)
+            results[key + "_PSD"] = np.zeros([nw, nr])
+        for key in ("omega_max", "omega_min", "power_avg"):
+            results[key] = np.zeros(nr)
+        return results
+
+    def _save_outputs_general(self, fowt, results, case):
+        """raft_fowt.py:2291-2745 for a single unit with MORE than six reduced DOFs (flexible members): every getRMS /
+        getPSD of the method is a linear channel of the reduced response through the rows of T -- PRP motions from the
+        rigid-body node (:2299-2355), hub accelerations (:2422-2444) and the tower-base loads: the finite-element
+        internal loads -Kf Xi_internal at the base node of a FLEXIBLE tower (:2540-2601), the fore-aft moment formula
+        (:2500-2537) of a rigid one -- ONE statistics launch over the response the solve returned
+        (raftx_response_stats).  Means and +-3 sigma bounds are host scalars."""
+        if getattr(fowt, "ms", None):
+            raise UnsupportedFOWT("saveTurbineOutputs: mooring-tension outputs need the MoorPy system (raft_fowt.py:2358-2399)")
+        if any(getattr(rot, "aeroServoMod", 0) > 1 for rot in fowt.rotorList):
+            raise UnsupportedFOWT("saveTurbineOutputs: rotor-controller outputs (raft_fowt.py:2640-2680) are not on the device path")
+        nr, nw, n = int(fowt.nrotors), fowt.nw, int(fowt.nDOF)
+        deg = 57.29577951308232                                              # helpers.rad2deg
+        T = np.asarray(fowt.T, dtype=float)                                  # [nFullDOF, nDOF]
+        nFull = T.shape[0]
+        Xi = np.ascontiguousarray(fowt.Xi, dtype=complex)                    # [nWaves + 1, nDOF, nw]
+        w = np.asarray(fowt.w, dtype=float)
+        rows_full, rows_red, gw_red = [], [], {}                             # channel -> (power, row over full DOFs) / reduced
+
+        def full_row(p, cols, vals):
+            r = np.zeros((3, nFull))
+            r[p, cols] = vals
+            rows_full.append(r)
+            rows_red.append(None)
+            return len(rows_full) - 1
+        # platform motions at the PRP from the rigid-body node (:2299-2307): Xi_t + th x (-r0), th
+        i0 = int(fowt.rigidBodyNode.id)                                      # (upstream slices [id : id + 6])
+        r0 = -np.asarray(fowt.rigidBodyNode.r0[:3], dtype=float)
+        A = np.array([[0.0, r0[2], -r0[1]], [-r0[2], 0.0, r0[0]], [r0[1], -r0[0], 0.0]])   # th x r = A th (helpers.py:396-402)
+        ch_motion = []
+        for j in range(3):
+            ch_motion.append(full_row(0, [i0 + j, i0 + 3, i0 + 4, i0 + 5], [1.0, A[j, 0], A[j, 1], A[j, 2]]))
+        for j in range(3, 6):
+            ch_motion.append(full_row(0, [i0 + j], [deg]))
+        ch_acc = []                                                          # hub accelerations: w^2 x (:2422-2444)
+        for rotor in fowt.rotorList:
+            h0 = int(rotor.nodeList[0].id) * 6
+            ch_acc.append([full_row(2, [h0 + a], [1.0]) for a in range(3)])
+        ch_base, base_mean, rigid_info = [], [], []
+        for ir, rotor in enumerate(fowt.rotorList):
+            mem_tower = fowt.memberList[fowt.nplatmems + ir]
+            if getattr(mem_tower, "type", "rigid") == "rigid":               # :2500-2537 on the reduced DOFs 0 and 4
+                Lt, Gt, info = tower_base_rows(fowt, only=ir)
+                r = np.zeros((3, n))
+                r[:, :6] = Lt[ir]
+                rows_full.append(None)
+                rows_red.append(r)
+                c = len(rows_full) - 1
+                if Gt is not None:
+                    g = np.zeros((n, nw), dtype=complex)
+                    g[:6] = Gt[ir]
+                    gw_red[c] = g
+                ch_base.append(("rigid", [c]))
+                rigid_info.append(info[0])
+                base_mean.append(None)
+            else:                                                            # :2540-2601: internal loads from the FE stiffness
+                Kf = np.asarray(mem_tower.Kf, dtype=float)
+                iF, iL = int(mem_tower.nodeList[0].id), int(mem_tower.nodeList[-1].id)
+                cols = np.arange(iF * 6, (iL + 1) * 6)
+                first = mem_tower.nodeList[0].r0[2] <= mem_tower.nodeList[-1].r0[2]
+                base = slice(0, 6) if first else slice(Kf.shape[0] - 6, Kf.shape[0])
+                Kb = -Kf[base, :]
+                ch_base.append(("flex", [full_row(0, cols, Kb[a]) for a in range(6)]))
+                Xi0_int = np.concatenate([np.asarray(nd.Xi0, dtype=float) for nd in mem_tower.nodeList])
+                base_mean.append((-Kf @ Xi0_int)[base])
+                rigid_info.append(None)
+        L = np.array([rr if rr is not None else rf @ T for rf, rr in zip(rows_full, rows_red)])      # [nCh,3,nDOF]
+        Gw = None
+        if gw_red:
+            Gw = np.zeros((len(L), n, nw), dtype=complex)
+            for c, g in gw_red.items():
+                Gw[c] = g
+        std, psd = self.ctx.response_stats(w, L, Xi, fowt.dw, Gw=Gw, want_psd=True)
+        Xi0 = np.asarray(fowt.r6, dtype=float) - np.array([fowt.x_ref, fowt.y_ref, 0, 0, 0, 0])
+        # response amplitudes of the PRP (the reference stores them): the same rows applied on the host (6 x nDOF x nw)
+        Lm = L[ch_motion, 0, :]
+        Xi_prp = np.einsum("cd,hdw->hcw", Lm, Xi)
+        for j, name in enumerate(("surge", "sway", "heave", "roll", "pitch", "yaw")):
+            c = ch_motion[j]
+            avg = Xi0[j] if j < 3 else Xi0[j] * deg
+            results[name + "_avg"] = avg
+            results[name + "_std"] = std[c]
+            results[name + "_max"] = avg + 3 * std[c]
+            results[name + "_min"] = avg - 3 * std[c]
+            results[name + "_PSD"] = psd[c].copy()
+            results[name + "_RA"] = Xi_prp[:, j, :]
+        for ax_i, ax in enumerate("xyz"):
+            key = "A%sRNA" % ax
+            for suffix in ("std", "avg", "max", "min"):
+                results["%s_%s" % (key, suffix)] = np.zeros(nr)
+            results[key + "_PSD"] = np.zeros([nw, nr])
+            for ir, rotor in enumerate(fowt.rotorList):
+                c = ch_acc[ir][ax_i]
+                rn = rotor.nodeList[0].r
+                avg = abs(np.sin(rn[4]) * fowt.g) if ax == "x" else (abs(np.sin(rn[3]) * fowt.g) if ax == "y" else abs(fowt.g))
+                results[key + "_std"][ir] = std[c]
+                results[key + "_PSD"][:, ir] = psd[c]
+                results[key + "_avg"][ir] = avg
+                results[key + "_max"][ir] = avg + 3 * std[c]
+                results[key + "_min"][ir] = avg - 3 * std[c]
+        bases = ("FbaseX", "FbaseY", "FbaseZ", "MbaseX", "MbaseY", "MbaseZ")
+        for base in ("Mbase",) + bases:
+            for suffix in ("avg", "std", "max", "min"):
+                results["%s_%s" % (base, suffix)] = np.zeros(nr)
+            results[base + "_PSD"] = np.zeros([nw, nr])
+
+        def put(base, ir, avg, c):
+            results[base + "_avg"][ir] = avg
+            results[base + "_std"][ir] = std[c]
+            results[base + "_PSD"][:, ir] = psd[c]
+            results[base + "_max"][ir] = avg + 3 * std[c]
+            results[base + "_min"][ir] = avg - 3 * std[c]
+        for ir, rotor in enumerate(fowt.rotorList):
+            kind, chans = ch_base[ir]
+            if kind == "rigid":
+                m, hArm = rigid_info[ir]
+                f = np.asarray(fowt.rotorList[0].nodeList[0].T, dtype=float) @ np.asarray(fowt.f_aero0)[:, ir]
+                f = transform_force_moment_y(f, hArm)
+                put("Mbase", ir, m * fowt.g * hArm * np.sin(fowt.Xi0[4]) + f, chans[0])             # :2532-2533
+            else:
+                for a, base in enumerate(bases):
+                    put(base, ir, base_mean[ir][a], chans[a])
+                put("Mbase", ir, base_mean[ir][4], chans[4])                                          # :2594-2599 (= MbaseY)
         zeta = np.asarray(fowt.zeta)
         results["wave_PSD"] = np.sum(0.5 * np.abs(zeta) ** 2 / fowt.dw, axis=0)                       # getPSD(zeta, dw)
         for key in ("omega", "torque", "bPitch"):
@@ -968,6 +1107,7 @@ class Engine:
         # single-unit models: the unit's responses stay resident on the ctx, which saveTurbineOutputs reads back as
         # statistics; a farm's final responses come from the coupled solve, not from the resident per-unit ones
         self._resident = fowts[0] if nF == 1 else None
+        self._general_solved = None
         model._raftx_flags = out['flags'][:, 0].copy()
         return model.Xi
 
@@ -987,7 +1127,14 @@ def _mooring_arm(fowt):
     return np.asarray(fowt.ms.bodyList[0].r6[:3], dtype=float) - np.asarray(fowt.nodeList[fowt.reducedDOF[0][0]].r[:3], dtype=float)
 
 
-def tower_base_rows(fowt):
+def transform_force_moment_y(f, hArm):
+    """[4] of helpers.transformForce(f, offset=[0, 0, -hArm]) (:2533): the fore-aft moment of a 6-vector f about a point
+    hArm below its own."""
+    f = np.asarray(f, dtype=float)
+    return f[4] + (-hArm) * f[0]
+
+
+def tower_base_rows(fowt, only=None):
     """Tower-base fore-aft bending moment of every (rigid) tower as linear channels of the platform response --
     raft/raft_fowt.py:2500-2528:  M = M_I + M_w + M_X_aero with
         M_w = m g h Xi_pitch,   M_I = -m a_CG h - I_CG (-w^2 Xi_pitch),  a_CG = -w^2 (Xi_surge + z_CG Xi_pitch),
@@ -999,9 +1146,12 @@ def tower_base_rows(fowt):
     info = []
     w = np.asarray(fowt.w)
     for ir, rotor in enumerate(fowt.rotorList):
+        if only is not None and ir != only:
+            continue
         mem_tower = fowt.memberList[fowt.nplatmems + ir]
         if getattr(mem_tower, "type", "rigid") != "rigid":
-            raise UnsupportedFOWT("flexible tower: base loads come from the FE stiffness (raft_fowt.py:2540-2601)")
+            raise UnsupportedFOWT("flexible tower: base loads come from the FE stiffness (raft_fowt.py:2540-2601): "
+                                  "Engine._save_outputs_general")
         m = fowt.mtower[ir] + rotor.mRNA
         zCG = (fowt.rCG_tow[ir][2] * fowt.mtower[ir] + rotor.r_rel[2] * rotor.mRNA) / m
         zBase = mem_tower.rA[2]

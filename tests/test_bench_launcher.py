@@ -63,6 +63,26 @@ def test_two_ranks_on_one_gpu_through_bench_itself():
     assert len(out["per_rank_ms"]["all"]) == 2 and out["gather_ms"]["rank0"] >= 0.0
     assert 0.2 < out["scaling_efficiency"] < 1.2 and out["single_rank_same_invocation"]["value"] > 0
     assert out["parity"]["niter_mismatches_vs_reference"] == 0
+    # N > 1 weak line ALSO carries configs[2]'s literal shape: ONE sweep of --designs cut into N shards, same invocation
+    st = out["strong_same_invocation"]
+    assert st["scaling"] == "strong" and st["shard_designs"] == [256, 256] and st["total_designs"] == 512
+    assert abs(st["value"] - 512 * out["config"]["nw"] / (st["ms_per_step"] * 1e-3)) < 1e-6 * st["value"]
+
+
+@pytest.mark.gpu
+def test_single_gpu_line_carries_the_numbers_a_reader_needs():
+    """beside `value` the line has the step-level roofline fraction, SURVEY 8d's literal step (responses
+    downloaded) as a top-level key, and the 1/8 shard of the sweep (what one rank of an 8-GPU strong-scaling run does)."""
+    r = _bench(["--steps", "4", "--warmup", "1", "--designs", "2048", "--no-cpu-baseline", "--legs", "xi,shard"], RAFTX_BENCH_XI_STEPS="6")
+    assert r.returncode == 0, r.stderr[-2000:]
+    out = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    rf = out["roofline"]
+    assert 0 < rf["step_frac"] <= rf["frac"] < 1 and rf["kernel_ms_per_step"] <= out["ms_per_step"]
+    assert abs(rf["step_frac"] - rf["algorithmic_flops_per_step"] / (out["ms_per_step"] * 1e-3) / 1e12 / rf["peak"]) < 1e-9
+    assert out["value_xi_out"] == out["xi_out"]["streamed_dcf_per_s"] > 0
+    sh = out["shard_1250"]
+    assert sh["designs_per_step"] == 256 and sh["ms_per_step"] > 0
+    assert abs(sh["projected_8_gpu_strong_speedup"] - out["ms_per_step"] / sh["ms_per_step"]) < 1e-9
 
 
 @pytest.mark.gpu

@@ -100,6 +100,9 @@ NO_SCRATCH = [
     r"^raftx_kp_f(0|4|16)$",                                             # persistent fused fixed point: plain, F_wave out, MacCamy-Fuchs
     r"^_Z16k_solve_dynamicsILi2ELi0ELi128ELi2EE",                        # the one-workgroup-per-pair lean kernel (C3)
     r"^_Z12k_excitationILi2ELi128ELi2EE",                                # calcHydroExcitation at the 200-bin shape
+    r"^_Z11k_linearizeILi2ELi128ELi2EE",                                 # calcHydroLinearization at the 200-bin shape
+    r"^_Z16k_solve_dynamicsILi2ELi(1|4|9|16|17|32|36|48|49)ELi128ELi2EE",   # lean featured sweeps (per-pair launches)
+    r"^raftx_kp_f(1|9|17|48|49)$",                                       # ... and their persistent twins
     r"^_Z11k_qtf_pairs",                                                 # C5
 ]
 
