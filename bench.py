@@ -525,7 +525,7 @@ def emit(out):
     sys.stdout.flush()
 
 
-def stream_steps(sw_, ctx, n, depth, fresh=None, after=None, chunks=1):
+def run_streamed(sw_, ctx, n, depth, fresh=None, after=None, chunks=1):
     """n streamed solver-stage steps of the sweep sw_ through the library's slots: depth 2 = submit(i+1), wait(i); depth d > 2 =
     prepare(i+d-1), launch(i+d-2), wait(i).  fresh(): new candidates before a batch is prepared; after(result): per-step
     exchange (the gather).  Returns the per-step results."""
@@ -899,10 +899,10 @@ def main():
             n_ = int(cnt_[rank])
             comm.gather_rows(np.concatenate([r["std"].reshape(n_, -1), r["niter"].reshape(n_, -1).astype(np.float64)], axis=1), counts=cnt_)
             return r
-        stream_steps(sw_st, ctx, max(6, 2 * args.depth + 1), args.depth, fresh=fresh_st, after=gather_st)
+        run_streamed(sw_st, ctx, max(6, 2 * args.depth + 1), args.depth, fresh=fresh_st, after=gather_st)
         barrier()
         ts_ = time.perf_counter()
-        stream_steps(sw_st, ctx, args.steps, args.depth, fresh=fresh_st, after=gather_st)
+        run_streamed(sw_st, ctx, args.steps, args.depth, fresh=fresh_st, after=gather_st)
         barrier()
         el_ = comm.all_max(time.perf_counter() - ts_)
         strong_same = {"scaling": "strong", "total_designs": int(args.designs), "shard_designs": [int(c_) for c_ in cnt_],
@@ -1170,7 +1170,7 @@ def main():
                     sw_s.set_params(G_.volturnus_params(scale_rows(b * n_sh, (b + 1) * n_sh)))
 
             def steps_s(n):
-                return stream_steps(sw_s, ctx, n, d, fresh=fresh_s)
+                return run_streamed(sw_s, ctx, n, d, fresh=fresh_s)
             steps_s(max(12, 2 * d + 1))
             n_t = max(args.steps, 60)
             ctx.synchronize()

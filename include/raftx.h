@@ -515,6 +515,14 @@ int raftx_sweep_wait(raftx_ctx *ctx, int slot, double *timing_ms);
  * durations of timing_ms[2] (bench.py: roofline.kernel_ms_per_step).  The CPU oracle returns zeros.
  * (the loop the kernel fuses: raft/raft_model.py:1052-1142) */
 int raftx_sweep_solve_span(raftx_ctx *ctx, int slot, double *start_ms, double *end_ms);
+/* Where the strip tables of the crossing LAST LAUNCHED on `slot` were generated: *blocks_fused = the number of its blocks
+ * whose tables were built INSIDE the fused fixed point, by the workgroup that solves the design (raftx_kpg_f0,
+ * raft_amd/csrc/raftx_fusedgen.h: streamed crossings with one sea state per design and no MacCamy-Fuchs rows),
+ * *blocks = all its blocks; the others went through k_geom_design, a kernel of its own.  Either way the tables are what
+ * Member.__init__ / calcHydroConstants produce (raft/raft_member.py:190-271, 1261-1368, 2061-2110), bit for bit.
+ * The fused form is opt-in (RAFTX_FUSED_GEN=1 in the environment): it closes the gap between consecutive fused kernels but
+ * costs the kernel more than it saves (profiles/r06_experiments/fused_generation_ab.txt).  The CPU oracle reports 0. */
+int raftx_sweep_generation(raftx_ctx *ctx, int slot, int *blocks_fused, int *blocks);
 /* Retires a batch that was prepared and will not be launched (its uploads and member pass are drained, its scratch is
  * released, its outputs are left untouched).  No-op on an idle slot; an error on a launched one (raftx_sweep_wait
  * collects that).  raftx_ctx_destroy retires whatever is still prepared.

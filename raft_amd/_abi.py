@@ -30,7 +30,7 @@ EXPORTS = (
     "raftx_sweep_submit",
     "raftx_sweep_prepare",
     "raftx_sweep_launch",
-    "raftx_sweep_wait", "raftx_sweep_solve_span",
+    "raftx_sweep_wait", "raftx_sweep_solve_span", "raftx_sweep_generation",
     "raftx_sweep_cancel", "raftx_device_count", "raftx_solve_dense_batch", "raftx_dense_resident", "raftx_solve_dense_resident", "raftx_flex_solve", "raftx_flex_start", "raftx_debug_flex_gemm",
     "raftx_comm_unique_id", "raftx_comm_init", "raftx_comm_destroy", "raftx_comm_broadcast", "raftx_comm_gather_rows",
     "raftx_comm_gather_xi", "raftx_comm_reduce_sum",
@@ -194,6 +194,8 @@ class RaftxLib:
         L.raftx_response_stats.restype = C.c_int
         L.raftx_sweep_solve_span.argtypes = [_vp, C.c_int, _vp, _vp]
         L.raftx_sweep_solve_span.restype = C.c_int
+        L.raftx_sweep_generation.argtypes = [_vp, C.c_int, _vp, _vp]
+        L.raftx_sweep_generation.restype = C.c_int
         L.raftx_sweep_cancel.argtypes = [_vp, C.c_int]
         L.raftx_sweep_cancel.restype = C.c_int
         L.raftx_device_count.argtypes = []
@@ -532,6 +534,10 @@ class Context:
         self._check(self.rlib.lib.raftx_sweep_solve_span(self._h, int(handle["slot"]), _ptr(span[0:1]), _ptr(span[1:2])),
                     "raftx_sweep_solve_span")
         out["solve_span_ms"] = span
+        nf, nb = C.c_int(0), C.c_int(0)                   # blocks whose tables the fused kernel built itself / all blocks
+        self._check(self.rlib.lib.raftx_sweep_generation(self._h, int(handle["slot"]), C.byref(nf), C.byref(nb)),
+                    "raftx_sweep_generation")
+        out["generation_fused_blocks"] = (nf.value, nb.value)
         handle["inputs"] = None
         return out
 

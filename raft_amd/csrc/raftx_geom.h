@@ -796,12 +796,15 @@ __global__ __launch_bounds__(128) void k_geom_reinertia(GeomArgs A) {
 // (k_geom_design).  Also the largest design (LDS of k_geom_design), and the error flags: this is the last kernel of
 // phase 1.
 #define GSCAN_CH 4096        // designs per pass of k_geom_scan (two 32-bit LDS rows)
-__global__ __launch_bounds__(1024) void k_geom_scan(GeomArgs A) {
+// T threads: 1024 for the shortest pass on an empty chip; 256 fit beside the resident workgroups of a fused kernel (a
+// 16-wave block needs a whole CU to itself)
+template <int T>
+__global__ __launch_bounds__(T) void k_geom_scan_t(GeomArgs A) {
     __shared__ long long part[2][17];
     __shared__ unsigned buf[2][GSCAN_CH];
-    const int t = threadIdx.x, T = 1024;
+    const int t = threadIdx.x;
     const int n = A.nDesign;
-    constexpr int PER = GSCAN_CH / 1024;
+    constexpr int PER = GSCAN_CH / T;
     // Chunks of GSCAN_CH designs go through LDS, so that global memory (and the page-locked copy of the offsets for the
     // host) is read and written by consecutive lanes; a thread then scans PER consecutive entries of the chunk.  (A
     // thread walking its own stretch of the global arrays took 50 us for 10^4 designs, on the path between two batches.)
@@ -818,7 +821,7 @@ __global__ __launch_bounds__(1024) void k_geom_scan(GeomArgs A) {
         __syncthreads();
         long long a = 0, b = 0;
         for (int i = 0; i < PER; i++) { a += buf[0][t * PER + i]; b += buf[1][t * PER + i]; }
-        // exclusive scan of the 1024 partial sums: inside a wave by shuffles, across the 16 waves through LDS
+        // exclusive scan of the T partial sums: inside a wave by shuffles, across the T / 64 waves through LDS
         const int lane = t & 63, wv = t >> 6;
         long long ia = a, ib = b;
         for (int o = 1; o < 64; o <<= 1) {
@@ -828,7 +831,7 @@ __global__ __launch_bounds__(1024) void k_geom_scan(GeomArgs A) {
         if (lane == 63) { part[0][wv] = ia; part[1][wv] = ib; }
         __syncthreads();
         long long ra = carrya, rb = carryb, sa = 0, sb = 0;
-        for (int i = 0; i < 16; i++) {
+        for (int i = 0; i < T / 64; i++) {
             if (i < wv) { ra += part[0][i]; rb += part[1][i]; }
             sa += part[0][i]; sb += part[1][i];
         }
@@ -983,12 +986,15 @@ __device__ unsigned long long geom_phase_cycles[10];
 #define GD_T 128            // threads per design: two wavefronts share the candidate strips and the output loops
 #endif
 static_assert(GD_T % 64 == 0 && GD_T % DS_N == 0 && GD_T <= 256, "k_geom_design: whole wavefronts, a lane keeps its record field");
-__global__ __launch_bounds__(GD_T) void k_geom_design(GeomArgs A) {
+// The tables of design d, by the GD_T threads of the calling workgroup: the body of k_geom_design, and the prologue of the
+// fused fixed point's generating form (raftx_fusedgen.h), where the workgroup that has claimed a pair builds its design's
+// tables itself.  gd_lds: geom_design_lds() bytes of LDS; wcnt: GD_T / 64 ints of LDS.  ABI: also the public-layout copy
+// of the strip records (raftx_fetch_strips).  ADDUP: the design's share of k_geom_addup in the same pass (the member ->
+// platform reductions must have finished).
+template <bool ABI, bool ADDUP>
+__device__ __forceinline__ void geom_design_block(const GeomArgs &A, const int d, double *gd_lds, int *wcnt) {
     GEOM_NOFMA
-    extern __shared__ double gd_lds[];
-    __shared__ int wcnt[GD_T / 64];
-    const int d = blockIdx.x, lane = threadIdx.x;        // lane: thread of the design's workgroup (0 .. GD_T-1)
-    if (d >= A.nDesign) return;
+    const int lane = threadIdx.x;                         // lane: thread of the design's workgroup (0 .. GD_T-1)
     const int64_t i0 = A.off[d], i1 = A.off[d + 1];
     const int S = (int)(i1 - i0);
     double *rec = gd_lds;                                 // [S][GD_ROW]
@@ -1007,9 +1013,24 @@ __global__ __launch_bounds__(GD_T) void k_geom_design(GeomArgs A) {
         const int nSta = (int)(A.so(m1) - s0);
         int *mcum = mfl + S;                              // per member: n + 2 running strip counts of its groups
         int *mbase = mcum + nSta + 2 * nMem;              // [nMem + 1] candidates before each member
+        // The design's descriptors -- member rows, station rows, the member pass's poses, first stations -- are staged in
+        // LDS by consecutive lanes, once: the candidate loop below then looks everything up on chip instead of walking
+        // chains of dependent global loads (member -> first station -> station rows -> interpolation neighbours), which
+        // was most of a workgroup's ~20 us on the path between two fused kernels.
+        int *ssta = mbase + nMem + 1;                     // [nMem + 1] first station of each member, relative to the design's
+        // (okv is 8-byte aligned: an even number of ints from it is too)
+        double *sgm = reinterpret_cast<double *>(okv + (((int)(ssta - okv) + nMem + 2) & ~1));      // [nMem][RAFTX_GM_N]
+        double *sgs = sgm + (size_t)nMem * RAFTX_GM_N;                            // [nSta][RAFTX_GS_N]
+        double *smp = sgs + (size_t)nSta * RAFTX_GS_N;                            // [nMem][MP_N]
+        {
+            const double *g0 = A.gm + (size_t)m0 * RAFTX_GM_N, *g1 = A.gs + (size_t)s0 * RAFTX_GS_N, *g2 = A.mpose + (size_t)m0 * MP_N;
+            for (int t = lane; t < nMem * RAFTX_GM_N; t += GD_T) sgm[t] = g0[t];
+            for (int t = lane; t < nSta * RAFTX_GS_N; t += GD_T) sgs[t] = g1[t];
+            for (int t = lane; t < nMem * MP_N; t += GD_T) smp[t] = g2[t];
+        }
         // groups of all members flattened over the lanes: member mi owns the n + 1 groups [sta0(mi) + mi, sta0(mi + 1) + mi + 1)
         // (mbase doubles as the members' first-station table until the counts are in)
-        for (int mi = lane; mi <= nMem; mi += GD_T) mbase[mi] = (int)(A.so(m0 + mi) - s0);
+        for (int mi = lane; mi <= nMem; mi += GD_T) mbase[mi] = ssta[mi] = (int)(A.so(m0 + mi) - s0);
         __syncthreads();
         for (int u = lane; u < nSta + nMem; u += GD_T) {
             int mi = 0;
@@ -1017,17 +1038,16 @@ __global__ __launch_bounds__(GD_T) void k_geom_design(GeomArgs A) {
             const int sta0 = mbase[mi], n = mbase[mi + 1] - sta0, g = u - (sta0 + mi);
             int cntg = 1;
             if (g > 0 && g < n) {
-                const double *gs = A.gs + (size_t)(s0 + sta0) * RAFTX_GS_N;
+                const double *gs = sgs + (size_t)sta0 * RAFTX_GS_N;
                 cntg = geom_interval_strips(gs[(size_t)g * RAFTX_GS_N + RAFTX_GS_S] - gs[(size_t)(g - 1) * RAFTX_GS_N + RAFTX_GS_S],
-                                            A.gm[(size_t)(m0 + mi) * RAFTX_GM_N + RAFTX_GM_DLSMAX]);
+                                            sgm[(size_t)mi * RAFTX_GM_N + RAFTX_GM_DLSMAX]);
             }
             mcum[sta0 + 2 * mi + g + 1] = cntg;
         }
         __syncthreads();
         for (int mi = lane; mi < nMem; mi += GD_T) {
-            const int64_t m = m0 + mi;
-            const int n = (int)(A.so(m + 1) - A.so(m));
-            int *cum = mcum + (A.so(m) - s0) + 2 * mi;
+            const int n = ssta[mi + 1] - ssta[mi];
+            int *cum = mcum + ssta[mi] + 2 * mi;
             int a = 0;
             cum[0] = 0;
             for (int g = 0; g <= n; g++) { a += cum[g + 1]; cum[g + 1] = a; }
@@ -1055,11 +1075,11 @@ __global__ __launch_bounds__(GD_T) void k_geom_design(GeomArgs A) {
             while (mi + 1 < nMem && mbase[mi + 1] <= tq) mi++;
             const int64_t m = m0 + mi;
             const int tt = tq - mbase[mi];
-            const int n = (int)(A.so(m + 1) - A.so(m));
-            const int *cum = mcum + (A.so(m) - s0) + 2 * mi;
-            const double *gm = A.gm + (size_t)m * RAFTX_GM_N;
-            const double *gs = A.gs + (size_t)A.so(m) * RAFTX_GS_N;
-            const double *mp = A.mpose + (size_t)m * MP_N;
+            const int n = ssta[mi + 1] - ssta[mi];
+            const int *cum = mcum + ssta[mi] + 2 * mi;
+            const double *gm = sgm + (size_t)mi * RAFTX_GM_N;
+            const double *gs = sgs + (size_t)ssta[mi] * RAFTX_GS_N;
+            const double *mp = smp + (size_t)mi * MP_N;
             const bool circ = gm[RAFTX_GM_SHAPE] != 0.0;
             const int flags = (int)gm[RAFTX_GM_FLAGS];
             const bool potMod = flags & RAFTX_GM_FLAG_POTMOD;
@@ -1158,8 +1178,10 @@ __global__ __launch_bounds__(GD_T) void k_geom_design(GeomArgs A) {
         }
         __syncthreads();
         GEOM_PHASE(1);
-        double *abi = A.abi + (size_t)i0 * NF;
-        for (int t = lane; t < S * NF; t += GD_T) abi[t] = rec[(t / NF) * GD_ROW + (t % NF)];
+        if constexpr (ABI) {
+            double *abi = A.abi + (size_t)i0 * NF;
+            for (int t = lane; t < S * NF; t += GD_T) abi[t] = rec[(t / NF) * GD_ROW + (t % NF)];
+        }
     }
     __syncthreads();
     GEOM_PHASE(2);
@@ -1335,11 +1357,27 @@ __global__ __launch_bounds__(GD_T) void k_geom_design(GeomArgs A) {
         __syncthreads();
         if (lane < 36) {
             am = (rec[lane] + rec[36 + lane]) + rec[72 + lane];
-            A.A[(size_t)d * 36 + lane] = am;              // k_geom_addup adds it (and the platform reductions) to M0 / C0
+            const size_t o = (size_t)d * 36 + lane;
+            A.A[o] = am;                                  // k_geom_addup adds it (and the platform reductions) to M0 / C0
+            if constexpr (ADDUP) {                        // ... or this lane does, in k_geom_addup's order
+                double m0 = A.M0[o], c0 = A.C0[o];
+                if (A.add_mask & RAFTX_ADD_MORISON) m0 += am;
+                if (A.add_mask & RAFTX_ADD_HYDROSTATIC) c0 += A.Ch[o];
+                if (A.add_mask & RAFTX_ADD_INERTIA) { m0 += A.Ms[o]; c0 += A.Cs[o]; }
+                A.M0[o] = m0;
+                A.C0[o] = c0;
+            }
         }
     }
     GEOM_PHASE(6);
     (void)mfl;
+}
+__global__ __launch_bounds__(GD_T) void k_geom_design(GeomArgs A) {
+    extern __shared__ double gd_lds[];
+    __shared__ int wcnt[GD_T / 64];
+    if ((int)blockIdx.x >= A.nDesign) return;
+    if (A.abi) geom_design_block<true, false>(A, (int)blockIdx.x, gd_lds, wcnt);
+    else geom_design_block<false, false>(A, (int)blockIdx.x, gd_lds, wcnt);     // (a sweep crossing that fell back from the fused form)
 }
 // What the device adds to the caller's matrices (add_mask), in a fixed order: Morison added mass (k_geom_design), then the
 // member -> platform reductions (k_geom_reduce, which runs beside the generation on its own stream).
@@ -1353,7 +1391,9 @@ __global__ void k_geom_addup(GeomArgs A) {
 // dynamic LDS of k_geom_design for designs of up to maxS strips
 static size_t geom_design_lds(int maxS, int maxSta, int maxMem) {
     const size_t S = (size_t)(maxS > 0 ? maxS : 1);
-    return sizeof(double) * (S * GD_ROW + 2 * S) + sizeof(int) * (3 * S + (size_t)maxSta + 3 * (size_t)maxMem + 1) + 16;
+    return sizeof(double) * (S * GD_ROW + 2 * S) + sizeof(int) * (3 * S + (size_t)maxSta + 3 * (size_t)maxMem + 1) + 16 +
+           sizeof(int) * ((size_t)maxMem + 4) +                                                           // first stations
+           sizeof(double) * ((size_t)maxMem * (RAFTX_GM_N + MP_N) + (size_t)maxSta * RAFTX_GS_N);        // staged descriptors
 }
 
 __global__ __launch_bounds__(64) void k_geom_reduce(GeomArgs A) {

@@ -77,6 +77,7 @@ struct RangeScope {
 #include "raftx_kernels.h"
 #include "raftx_qtf.h"
 #include "raftx_geom.h"
+#include "raftx_fusedgen.h"
 #include "raftx_dense.h"
 #include "raftx_flex.h"
 
@@ -742,6 +743,10 @@ struct BuildJob {
     bool active = false;
     bool reduce_late = false;
     hipStream_t reduce_stream = nullptr; // side stream the member -> platform reductions were launched on (evRed), or null
+    // phase 2 left the tables of the designs to the fused kernel that solves them (raftx_fusedgen.h): nothing has been
+    // written yet; solve_enqueue launches the generating form, or k_geom_design + k_geom_addup if it cannot
+    bool gen_deferred = false;
+    size_t gen_lds = 0;                  // dynamic LDS of geom_design_block for this batch
 };
 
 // One set of sea-state tables resident for the sweep crossings.  A crossing pins the set it was PREPARED with until it has
@@ -865,6 +870,8 @@ struct raftx_ctx {
     int g_n;
     size_t g_nStrips, g_nRows;
     double *g_abi, *g_A, *g_Ch, *g_Wh, *g_props, *g_Ms, *g_Cs, *g_Ws;
+    hipStream_t sStat = nullptr;         // RAFTX_STATS_STREAM=1: the statistics kernels of sweep crossings
+    bool last_gen_fused = false;         // the last fused launch generated its designs' tables itself (raftx_fusedgen.h)
     cplx *g_cm;
     void *comm;                          // ncclComm_t of raftx_comm_init (RCCL), or null
     int comm_rank, comm_world;
@@ -1086,7 +1093,7 @@ extern "C" void raftx_ctx_destroy(raftx_ctx *c) {
     if (c->sAux) (void)hipStreamDestroy(c->sAux);
     if (c->evExp) (void)hipEventDestroy(c->evExp);
     if (c->evEpoch) (void)hipEventDestroy(c->evEpoch);
-    for (hipStream_t st : {c->sCopy, c->sPrep, c->sD2H, c->sGen, c->sD2Hlow, c->sSlab[0], c->sSlab[1], c->sExp, c->sMainB})
+    for (hipStream_t st : {c->sCopy, c->sPrep, c->sD2H, c->sGen, c->sD2Hlow, c->sSlab[0], c->sSlab[1], c->sExp, c->sMainB, c->sStat})
         if (st) (void)hipStreamDestroy(st);
     if (c->owns_stream) (void)hipStreamDestroy(c->stream);
     delete c;
@@ -1231,6 +1238,11 @@ static int upload_on(raftx_ctx *c, hipStream_t st, std::vector<void *> &bag, con
 }
 // Designs [lo, lo + nDesign) of the caller's batch: memberOff / stationOff / capOff are the batch's own (absolute) host
 // arrays, the descriptor arrays are sliced here.  shared == NULL: the offsets of the slice are uploaded by this call.
+static void launch_scan(hipStream_t st, const GeomArgs &A) {
+    static const int scan_t = getenv("RAFTX_SCAN_T") ? atoi(getenv("RAFTX_SCAN_T")) : 1024;     // tuning: 256 | 1024 threads
+    if (scan_t == 256) hipLaunchKernelGGL(k_geom_scan_t<256>, dim3(1), dim3(256), 0, st, A);
+    else hipLaunchKernelGGL(k_geom_scan_t<1024>, dim3(1), dim3(1024), 0, st, A);
+}
 static int build_phase1(raftx_ctx *c, hipStream_t sCopy, hipStream_t sPrep, int lo, int nDesign, const int64_t *memberOff,
                         const double *members, const int64_t *stationOff, const double *stations, const int64_t *capOff,
                         const double *caps, const double *pose, double rho, double g, int nw, const double *k, int add_mask,
@@ -1416,7 +1428,7 @@ static int build_phase1(raftx_ctx *c, hipStream_t sCopy, hipStream_t sPrep, int 
     if (side) HIPCHK(c, hipEventRecord(c->evMem, sPrep));
     // the scan first: streams share hardware queues, and a reduction submitted ahead of it on the same queue would sit on
     // the path to the totals (the host waits for them before it can size and launch the generation)
-    if (nDesign > 0 && side) hipLaunchKernelGGL(k_geom_scan, dim3(1), dim3(1024), 0, sPrep, A);
+    if (nDesign > 0 && side) launch_scan(sPrep, A);
     if (side) {                                           // ... and its markers, for the same reason
         HIPCHK(c, hipEventRecord(c->evG3, sPrep));
         HIPCHK(c, hipEventRecord(c->evTot, sPrep));
@@ -1437,7 +1449,7 @@ static int build_phase1(raftx_ctx *c, hipStream_t sCopy, hipStream_t sPrep, int 
     // totals, error flags and design offsets reach the host through the kernels' own stores into page-locked memory
     // (A.hostOut): a D2H copy of them would queue on the DMA engine behind a bulk download of the previous batch
     if (!side) {
-        if (nDesign > 0) hipLaunchKernelGGL(k_geom_scan, dim3(1), dim3(1024), 0, sPrep, A);
+        if (nDesign > 0) launch_scan(sPrep, A);
         HIPCHK(c, hipEventRecord(c->evG3, sPrep));
         HIPCHK(c, hipEventRecord(c->evTot, sPrep));
     }
@@ -1450,7 +1462,13 @@ static int build_phase1(raftx_ctx *c, hipStream_t sCopy, hipStream_t sPrep, int 
 // sGen: the stream the generation kernels go to (null: the ctx stream).  The sweep crossing gives the preparation stream
 // for every block but the first, so that a block's tables are generated WHILE the fused kernel of the block before it
 // runs (they fill the CUs its last residency round leaves idle); the ctx stream is ordered behind them by evG1.
-static int build_phase2(raftx_ctx *c, int64_t *stripOffsets, hipStream_t sGen = nullptr) {
+static void launch_design(raftx_ctx *c, hipStream_t st) {
+    BuildJob &J = c->job;
+    hipLaunchKernelGGL(k_geom_design, dim3((unsigned)J.nDesign), dim3(GD_T), J.gen_lds, st, J.A);
+}
+// crossing: 0 = raftx_build_designs (tables + ABI copy), 1 = a sweep crossing (no ABI copy), 2 = a crossing whose tables the
+// fused kernel may build itself (RAFTX_FUSED_GEN=1)
+static int build_phase2(raftx_ctx *c, int64_t *stripOffsets, hipStream_t sGen = nullptr, int crossing = 0) {
     RangeScope range_("build phase 2: wait for totals, strip tables + statics (enqueue)");
     BuildJob &J = c->job;
     if (!J.active) FAIL(c, "build_designs: phase 2 without phase 1");
@@ -1473,7 +1491,18 @@ static int build_phase2(raftx_ctx *c, int64_t *stripOffsets, hipStream_t sGen = 
     c->hS.resize((size_t)nDesign);
     for (int d = 0; d < nDesign; d++) c->hS[(size_t)d] = (int)(c->pin[8 + d + 1] - c->pin[8 + d]);
     std::vector<void *> &tmp = J.tmp;
-    if (dev_alloc(c, c->design_allocs, nStrips * NF, &A.abi) || dev_alloc(c, c->design_allocs, nStrips * DS_N, &A.ds) ||
+    // RAFTX_FUSED_GEN=1: sweep crossings build their tables inside the fused kernel (raftx_fusedgen.h).  Measured and NOT
+    // the default (profiles/r06_experiments/fused_generation_ab.txt): bit-identical, the gap between two fused kernels
+    // shrinks from 0.30 to 0.09 ms, but the kernel grows by 0.50 ms -- the ~50 us of dependent loads per design are not
+    // hidden by the seven other waves of the CU (each is bound by its own dependency chains, not by issue slots).
+    const char *fg_ = getenv("RAFTX_FUSED_GEN");          // (read per call: tests switch it inside one process)
+    const bool fused_gen = fg_ && atoi(fg_);
+    const bool defer = crossing == 2 && fused_gen && nDesign > 0 && nRows == 0;
+    J.gen_deferred = false;
+    // the ABI copy of the strip records (raftx_fetch_strips) is for raftx_build_designs; a sweep crossing never
+    // fetches it: 137 MB of stores per 10 000 designs less between two fused kernels (k_geom_design checks the pointer)
+    A.abi = nullptr;
+    if ((!crossing && dev_alloc(c, c->design_allocs, nStrips * NF, &A.abi)) || dev_alloc(c, c->design_allocs, nStrips * DS_N, &A.ds) ||
         dev_alloc(c, c->design_allocs, nStrips, &A.dsi) || dev_alloc(c, c->design_allocs, nRows * 3, &A.mcfaux) ||
         dev_alloc(c, c->design_allocs, nRows * 2 * (size_t)nw, &A.cm) ||
         dev_alloc(c, c->design_allocs, (size_t)nDesign * 36, &A.A))
@@ -1484,12 +1513,19 @@ static int build_phase2(raftx_ctx *c, int64_t *stripOffsets, hipStream_t sGen = 
         FAIL(c, "build_designs: a design has %d submerged strips (at most %d supported)", maxS, (int)((160 * 1024 - 16) / (8 * (GD_ROW + 2) + 12)));
     if (gd_lds > 64 * 1024)
         HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void *>(k_geom_design), hipFuncAttributeMaxDynamicSharedMemorySize, (int)gd_lds));
-    if (!sGen) sGen = c->stream;
+    J.gen_lds = gd_lds;
+    if (!sGen || defer) sGen = c->stream;
     HIPCHK(c, hipStreamWaitEvent(sGen, c->evTot, 0));
     HIPCHK(c, hipEventRecord(c->evG0, sGen));
-    if (nDesign > 0) {
+    if (defer) {
+        // the ctx stream (where the fused kernel goes) behind everything the generation reads: scans, reductions
+        HIPCHK(c, hipStreamWaitEvent(c->stream, c->evTot, 0));
+        if (J.reduce_stream) HIPCHK(c, hipStreamWaitEvent(c->stream, c->evRed, 0));
+        if (J.reduce_late) hipLaunchKernelGGL(k_geom_reduce, dim3((unsigned)(((size_t)nDesign * 3 + 63) / 64)), dim3(64), 0, c->stream, A);
+        J.gen_deferred = true;
+    } else if (nDesign > 0) {
         if (J.reduce_late) hipLaunchKernelGGL(k_geom_reduce, dim3((unsigned)(((size_t)nDesign * 3 + 63) / 64)), dim3(64), 0, sGen, A);
-        hipLaunchKernelGGL(k_geom_design, dim3((unsigned)nDesign), dim3(GD_T), gd_lds, sGen, A);
+        launch_design(c, sGen);
         // the reductions of phase 1 (side stream) are not waited for until their results are added up: streams share
         // hardware queues, and a reduction that ended up behind the scan would otherwise hold the generation back
         if (J.reduce_stream) HIPCHK(c, hipStreamWaitEvent(sGen, c->evRed, 0));
@@ -1567,6 +1603,8 @@ extern "C" int raftx_fetch_strips(raftx_ctx *c, double *strips, raftx_c128 *cm) 
     if (!c) return -1;
     if (!c->g_n || !c->have_designs) FAIL(c, "fetch_strips: no raftx_build_designs call on this ctx");
     HIPCHK(c, hipSetDevice(c->device));
+    if (strips && c->g_nStrips && !c->g_abi)
+        FAIL(c, "fetch_strips: the tables of this batch were generated inside the fused kernel of a sweep crossing (no ABI copy of the strip records)");
     if (strips && c->g_nStrips)
         HIPCHK(c, hipMemcpyAsync(strips, c->g_abi, c->g_nStrips * NF * sizeof(double), hipMemcpyDeviceToHost, c->stream));
     if (cm && c->g_nRows)
@@ -1961,7 +1999,7 @@ static kp_fn kp_kernel(int flags) {
 #define KP_RING 64
 #define KP_MAX_GRID 2048                 // workgroups of a persistent grid at most (8 per CU x 256 CUs)
 static int launch_persistent(raftx_ctx *c, kp_fn kernel, const DevTables &T, const SolveArgs &A, size_t npairs, int threads, size_t lds,
-                             int wg_per_cu) {
+                             int wg_per_cu, const GeomArgs *gen = nullptr) {
     if (!c->nCU) {
         hipDeviceProp_t pr;
         HIPCHK(c, hipGetDeviceProperties(&pr, c->device));
@@ -1975,7 +2013,8 @@ static int launch_persistent(raftx_ctx *c, kp_fn kernel, const DevTables &T, con
         HIPCHK(c, hipMemsetAsync(c->kpCtr, 0, bytes, c->stream));         // once: every launch leaves its set zeroed (kp_leave)
     }
     if (lds > 64 * 1024)
-        HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        HIPCHK(c, hipFuncSetAttribute(gen ? reinterpret_cast<const void *>(raftx_kpg_f0) : reinterpret_cast<const void *>(kernel),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     PersistArgs P;
     P.T = T;
     P.A = A;
@@ -1984,6 +2023,13 @@ static int launch_persistent(raftx_ctx *c, kp_fn kernel, const DevTables &T, con
     static const int grid_env = getenv("RAFTX_KP_GRID") ? atoi(getenv("RAFTX_KP_GRID")) : 0;      // tuning: workgroups of the grid
     size_t grid = (size_t)(grid_env > 0 ? grid_env : wg_per_cu * c->nCU);
     grid = std::min<size_t>(std::min<size_t>(grid, KP_MAX_GRID), grid_for_pairs(npairs));
+    if (gen) {                                            // the generating form: the workgroups build their designs' tables first
+        PersistGenArgs PG;
+        PG.P = P;
+        PG.G = *gen;
+        hipLaunchKernelGGL(raftx_kpg_f0, dim3((unsigned)grid), dim3(threads), lds, c->stream, PG);
+        return 0;
+    }
     hipLaunchKernelGGL(kernel, dim3((unsigned)grid), dim3(threads), lds, c->stream, P);
     return 0;
 }
@@ -2174,6 +2220,21 @@ static int solve_enqueue(raftx_ctx *c, int nIter, double tol, double XiStart, co
         if (!c->evFork) HIPCHK(c, hipEventCreateWithFlags(&c->evFork, hipEventDisableTiming));
         if (!c->evJoin) HIPCHK(c, hipEventCreateWithFlags(&c->evJoin, hipEventDisableTiming));
     }
+    // A generation deferred to this launch (build_phase2): the generating form of the plain persistent kernel builds every
+    // design's tables in the workgroup that solves it -- if this launch is one (every design claimed exactly once);
+    // otherwise the generation kernels go first, here.
+    BuildJob &J = c->job;
+    bool gen_fused = false;
+    if (J.gen_deferred) {
+        J.gen_deferred = false;
+        gen_fused = persist && lean == 0 && T.nCase == 1 && cls.empty() && !slabbed && c->r_npair == (size_t)T.nDesign && c->r_npair > 0 &&
+                    J.nDesign == T.nDesign && J.gen_lds + KP_STASH * sizeof(double) <= LDS_LIMIT / (size_t)wg_per_cu;
+        if (!gen_fused) {
+            launch_design(c, c->stream);
+            hipLaunchKernelGGL(k_geom_addup, dim3((unsigned)(((size_t)J.nDesign * 36 + 255) / 256)), dim3(256), 0, c->stream, J.A);
+        }
+    }
+    c->last_gen_fused = gen_fused;
     int rc_after = 0;
 #define LAUNCH_SOLVE(NB_, MT_, MB_, FL)                                                                              \
     do {                                                                                                             \
@@ -2184,7 +2245,10 @@ static int solve_enqueue(raftx_ctx *c, int nIter, double tol, double XiStart, co
         if (c->r_npair && cls.empty() && !slabbed) {                                                                 \
             kp_fn kp_ = (persist && NB_ == 2 && MT_ == 128 && MB_ == RAFTX_KP_MINB) ? kp_kernel(FL) : nullptr;       \
             if (kp_) {                                                                                               \
-                if (launch_persistent(c, kp_, T, A, c->r_npair, sh.threads, lds + KP_STASH * sizeof(double), wg_per_cu)) return -1; \
+                if (launch_persistent(c, kp_, T, A, c->r_npair, sh.threads,                                          \
+                                      std::max(lds, gen_fused ? J.gen_lds : (size_t)0) + KP_STASH * sizeof(double), wg_per_cu, \
+                                      (gen_fused && FL == 0) ? &J.A : nullptr))                                      \
+                    return -1;                                                                                       \
             } else {                                                                                                 \
                 hipLaunchKernelGGL((k_solve_dynamics<NB_, FL, MT_, MB_>), dim3(grid_for_pairs(c->r_npair)),          \
                                    dim3(sh.threads), lds, c->stream, T, A);                                          \
@@ -3181,7 +3245,16 @@ static int sweep_prepare_impl(raftx_ctx *c, int slot, int nDesign, const int64_t
         HIPCHK(c, hipStreamCreateWithFlags(&c->sCopy, hipStreamNonBlocking));
         HIPCHK(c, hipStreamCreateWithFlags(&c->sPrep, hipStreamNonBlocking));
         HIPCHK(c, hipStreamCreateWithFlags(&c->sD2H, hipStreamNonBlocking));
-        HIPCHK(c, hipStreamCreateWithFlags(&c->sGen, hipStreamNonBlocking));
+        {
+            // RAFTX_GEN_PRIORITY=high (tuning): the generation stream in the highest priority class -- the tables of batch
+            // i+1 are what the next fused kernel waits for, the member pass of batch i+2 beside them is not
+            static const char *gp = getenv("RAFTX_GEN_PRIORITY");
+            int least = 0, greatest = 0;
+            if (gp && !strcmp(gp, "high") && hipDeviceGetStreamPriorityRange(&least, &greatest) == hipSuccess && least != greatest)
+                HIPCHK(c, hipStreamCreateWithPriority(&c->sGen, hipStreamNonBlocking, greatest));
+            else
+                HIPCHK(c, hipStreamCreateWithFlags(&c->sGen, hipStreamNonBlocking));
+        }
     }
     if (!S.evXi) HIPCHK(c, hipEventCreate(&S.evXi));
     // sea-state tables: sets resident on the parent, shared by the blocks of every slot that was prepared with the same
@@ -3522,18 +3595,29 @@ extern "C" int raftx_sweep_launch(raftx_ctx *c, int slot) {
     // statistics, iteration counts and flags of a block go straight into its page-locked landing area (the kernels store
     // there: no small D2H copy that could queue on the DMA engine behind a bulk download); behind them, on the download
     // stream, the block's responses unless they leave slab by slab
+    // RAFTX_STATS_STREAM=1: the statistics of a batch on a stream of their own behind its fused kernel, so that the next
+    // batch's fused kernel (same main stream) does not wait for them
+    const char *ss_ = getenv("RAFTX_STATS_STREAM");
+    const bool stats_side = ss_ && atoi(ss_);
+    if (stats_side && !c->sStat) HIPCHK(c, hipStreamCreateWithFlags(&c->sStat, hipStreamNonBlocking));
     auto enqueue_stats = [&](size_t b) -> int {
         raftx_ctx *sub = blk[b];
         const int lo = bnd[b];
         const size_t npair = (size_t)(bnd[b + 1] - lo) * nCase;
-        hipError_t e = hipEventRecord(sub->evS0, sM);
+        hipStream_t sS = sM;
+        hipError_t e = hipSuccess;
+        if (stats_side && c->sStat && !slab_mode) {
+            sS = c->sStat;
+            e = hipStreamWaitEvent(sS, sub->ev1, 0);                   // the end of the block's fused launch (solve_enqueue)
+        }
+        if (e == hipSuccess) e = hipEventRecord(sub->evS0, sS);
         if (npair) {
-            hipLaunchKernelGGL(k_motion_stats, dim3((unsigned)npair), dim3(nw > 128 ? 256 : (nw > 64 ? 128 : 64)), 0, sM,
+            hipLaunchKernelGGL(k_motion_stats, dim3((unsigned)npair), dim3(nw > 128 ? 256 : (nw > 64 ? 128 : 64)), 0, sS,
                                (int)npair, nHead, nw, 1.0 / dw, sub->rXi, sub->pinRes, (double *)nullptr, (const int *)sub->rNi,
                                (const int *)sub->rFl, reinterpret_cast<int *>(sub->pinRes + npair * 6));
         }
-        if (e == hipSuccess) e = hipEventRecord(sub->evS1, sM);
-        if (e == hipSuccess) e = hipEventRecord(sub->evDone, sM);
+        if (e == hipSuccess) e = hipEventRecord(sub->evS1, sS);
+        if (e == hipSuccess) e = hipEventRecord(sub->evDone, sS);
         if (e == hipSuccess && Xi && !slab_mode) {
             const size_t p0 = (size_t)lo * nCase;
             e = hipStreamWaitEvent(sDown, sub->evDone, 0);
@@ -3588,9 +3672,18 @@ extern "C" int raftx_sweep_launch(raftx_ctx *c, int slot) {
         static const bool xi_gen_overlap = getenv("RAFTX_XI_GEN_OVERLAP") && atoi(getenv("RAFTX_XI_GEN_OVERLAP"));
         const bool gen_side = (pipelined && gen_overlap) || (b > 0 && Xi != nullptr && nB > 2 && xi_gen_overlap);
         S.tlb.push_back(since());
-        if (!rc) rc = build_phase2(sub, nullptr, gen_side ? c->sGen : nullptr);
+        // (a crossing: no ABI copy of the strip records; with RAFTX_FUSED_GEN=1 the tables are left to the fused kernel itself,
+        // raftx_fusedgen.h -- build_phase2 / solve_enqueue decide)
+        if (!rc) rc = build_phase2(sub, nullptr, gen_side ? c->sGen : nullptr, (nCase == 1 && !slab_mode) ? 2 : 1);
         S.tlb.push_back(since());
-        if (!rc && b == 0 && pipelined && gen_overlap && !two_streams) {
+        // (with the generation inside the fused kernel nothing of this batch runs in the drain any more: the fused kernel
+        // follows the one before it at once, and the next batch's member pass takes the places the drain frees beside it;
+        // RAFTX_FUSED_WAIT_MEMBER=1 keeps the wait)
+        const char *fw_ = getenv("RAFTX_FUSED_WAIT_MEMBER");
+        const bool fused_wait_member = fw_ && atoi(fw_);
+        // RAFTX_NO_MEMBER_WAIT=1 (tuning): the fused kernel does not wait for the member passes queued behind it
+        static const bool no_member_wait = getenv("RAFTX_NO_MEMBER_WAIT") && atoi(getenv("RAFTX_NO_MEMBER_WAIT"));
+        if (!rc && b == 0 && pipelined && gen_overlap && !two_streams && !no_member_wait && (!sub->job.gen_deferred || fused_wait_member)) {
             // Small kernels are not dispatched while a big grid is being handed out: whatever of the NEXT batch's member pass
             // has not finished when this batch's fused kernel starts would wait for the whole kernel and stall that batch's
             // launch a step later.  So this fused kernel starts only when the member passes already queued (the batches
@@ -3789,6 +3882,20 @@ extern "C" int raftx_sweep_solve_span(raftx_ctx *c, int slot, double *start_ms, 
     if (c->slots[slot].busy) FAIL(c, "sweep_solve_span: slot %d has not been waited for", slot);
     if (start_ms) *start_ms = c->slots[slot].span[0];
     if (end_ms) *end_ms = c->slots[slot].span[1];
+    return 0;
+}
+
+extern "C" int raftx_sweep_generation(raftx_ctx *c, int slot, int *blocks_fused, int *blocks) {
+    if (!c) return -1;
+    if (slot < 0 || slot >= RAFTX_NSLOT) FAIL(c, "sweep_generation: slot must be 0 .. %d", RAFTX_NSLOT - 1);
+    int nf = 0, nb = 0;
+    for (raftx_ctx *sub : c->slots[slot].blk)
+        if (sub) {
+            nb++;
+            nf += sub->last_gen_fused ? 1 : 0;
+        }
+    if (blocks_fused) *blocks_fused = nf;
+    if (blocks) *blocks = nb;
     return 0;
 }
 

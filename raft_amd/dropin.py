@@ -717,6 +717,10 @@ class Engine:
             raise UnsupportedFOWT("saveTurbineOutputs: mooring-tension outputs need the MoorPy system (raft_fowt.py:2358-2399)")
         if any(getattr(rot, "aeroServoMod", 0) > 1 for rot in fowt.rotorList):
             raise UnsupportedFOWT("saveTurbineOutputs: rotor-controller outputs (raft_fowt.py:2640-2680) are not on the device path")
+        missing = [a for a in ("rigidBodyNode", "memberList", "rotorList", "T", "r6", "nplatmems") if not hasattr(fowt, a)]
+        if missing:
+            raise UnsupportedFOWT("saveTurbineOutputs: this FOWT object does not carry %s (a stand-in without the node / member "
+                                  "structure the output channels are built from)" % ", ".join(missing))
         nr, nw, n = int(fowt.nrotors), fowt.nw, int(fowt.nDOF)
         deg = 57.29577951308232                                              # helpers.rad2deg
         T = np.asarray(fowt.T, dtype=float)                                  # [nFullDOF, nDOF]

@@ -82,7 +82,8 @@ def test_persistent_kernels_entry_state(code_object):
     notes, kds = kernel_notes(code_object), kernel_descriptors(code_object)
     names = sorted(n for n in kds if n.startswith("raftx_kp_f"))
     assert len(names) == 12, names                                       # RAFTX_PERSIST128: one twin per lean specialisation
-    for n in names:
+    assert "raftx_kpg_f0" in kds                                         # the generating form (raftx_fusedgen.h) re-enters the same way
+    for n in names + ["raftx_kpg_f0"]:
         rsrc2, props = kds[n]
         assert (props & 0x7F) == 0b0001100, (n, bin(props))              # QUEUE_PTR + KERNARG_SEGMENT_PTR, nothing else
         assert ((rsrc2 >> 1) & 0x1F) == 4, (n, "user SGPR count")        # s[0:1] queue, s[2:3] kernarg

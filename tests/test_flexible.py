@@ -96,8 +96,8 @@ def _check_solve(ctx):
     Xi = eng.solveDynamics(model, case_from_fixture(c))
     assert rel_err(Xi[:1], ref_headings(c)[0]) < 1e-8
     assert int(model._raftx_niter[0]) == int(c["units"][0]["niter"]) < 16 and int(model._raftx_flags[0]) == 1
-    with pytest.raises(dropin.UnsupportedFOWT):                              # outputs of such a unit: not resident
-        eng.saveTurbineOutputs(fowt, {}, case_from_fixture(fx["cases"][0]))
+    with pytest.raises(dropin.UnsupportedFOWT):                              # outputs need the live object's nodes / members (the
+        eng.saveTurbineOutputs(fowt, {}, case_from_fixture(fx["cases"][0]))  # stand-in has none): tests/test_dropin_live_reference.py
 
 
 def _check_flex_sweep(ctx, n_unit):

@@ -486,6 +486,60 @@ def test_hip_streamed_crossings(hip_ctx):
 
 
 @pytest.mark.gpu
+def test_hip_fused_generation_is_the_generation_kernel_bit_for_bit(hip_ctx):
+    """Streamed crossings with one sea state per design build their strip tables INSIDE the fused fixed point
+    (raftx_kpg_f0, raft_amd/csrc/raftx_fusedgen.h: the workgroup that has claimed a design generates its tables, then solves
+    it) when RAFTX_FUSED_GEN=1; the default keeps k_geom_design + k_geom_addup as kernels of their own (faster, measured).  Same batches both ways, three in
+    flight: responses, statistics, iteration counts and strip offsets agree bit for bit, and raftx_sweep_generation says
+    which form ran.  Two sea states per design (a design claimed twice) never take the fused form."""
+    import os
+    ctx = hip_ctx
+    z0, b0 = np.asarray(C3["zeta"]), np.asarray(C3["beta"])
+    fixed = lambda z, b: (C3["w"], C3["k"], float(C3["depth"]), z, b, int(C3["nIter"]), 0.01, float(C3["XiStart"]))
+    sizes = (61, 300, 7, 1, 129)
+    batches = [_c3_crossing_inputs(n) for n in sizes]
+
+    def stream(sea, want_Xi):
+        hs, got = {}, []
+        sub = lambda i: ctx.sweep_prepare(i % 3, *batches[i], *fixed(*sea), want_Xi=want_Xi)
+        hs[0], hs[1] = sub(0), sub(1)
+        ctx.sweep_launch(hs[0])
+        for i in range(len(batches)):
+            if i + 2 < len(batches):
+                hs[i + 2] = sub(i + 2)
+            if i + 1 < len(batches):
+                ctx.sweep_launch(hs[i + 1])
+            got.append(ctx.sweep_wait(hs.pop(i)))
+        return got
+
+    prev = os.environ.get("RAFTX_FUSED_GEN")
+    try:
+        runs = {}
+        for mode in ("1", "0"):
+            os.environ["RAFTX_FUSED_GEN"] = mode
+            for want_Xi in (False, True):
+                runs[mode, want_Xi] = stream((z0[None], b0[None]), want_Xi)
+        os.environ["RAFTX_FUSED_GEN"] = "1"
+        two = stream((np.stack([0.5 * z0, 1.5 * z0]), np.stack([b0 + 0.3, b0 - 0.7])), False)
+    finally:
+        if prev is None:
+            os.environ.pop("RAFTX_FUSED_GEN", None)
+        else:
+            os.environ["RAFTX_FUSED_GEN"] = prev
+    for want_Xi in (False, True):
+        for i, (a, b) in enumerate(zip(runs["1", want_Xi], runs["0", want_Xi])):
+            assert a["generation_fused_blocks"][1] >= 1
+            assert a["generation_fused_blocks"][0] == a["generation_fused_blocks"][1], (want_Xi, i, a["generation_fused_blocks"])
+            assert b["generation_fused_blocks"][0] == 0
+            for key in ("std",) + (("Xi",) if want_Xi else ()):
+                assert np.array_equal(a[key].view(np.uint64), b[key].view(np.uint64)), (key, i)
+            assert np.array_equal(a["niter"], b["niter"]) and np.array_equal(a["flags"], b["flags"])
+            assert np.array_equal(a["strip_off"], b["strip_off"])
+            assert int(a["niter"].min()) >= 1 and not np.isnan(a["std"]).any()
+    assert all(t["generation_fused_blocks"][0] == 0 for t in two)
+
+
+@pytest.mark.gpu
 def test_hip_soak_of_300_staged_crossings(hip_ctx):
     check_soak(hip_ctx, 300)
 
