@@ -20,18 +20,22 @@ struct PersistGenArgs {
     GeomArgs G;
 };
 
-// What the workgroup has just stored is read back through the scalar cache (strip records, flags: constant address
-// space) and the vector L1 (M0, C0): stores complete and visible at the L2, both caches dropped -- lines of these
-// addresses may survive from the pool's previous use of the memory, or (flags: 4 B per strip) from a neighbour's read
-// of a line this design shares.
+// What the workgroup has just stored is read back by the SAME workgroup only: through the vector L1 of its CU (M0, C0;
+// coherent for the waves of a CU once the stores have left the wave) and through the scalar cache (strip records, flags:
+// constant address space), which is not coherent with vector stores and is dropped -- lines of these addresses may
+// survive from a neighbour's read of a line this design shares (flags: 4 B per strip).  Workgroup scope on purpose: an
+// agent-scope release / acquire pair writes back and invalidates the whole L2 of the XCD on gfx950 -- once per design
+// that cost the kernel 0.5 ms per 10 000 (profiles/r06_experiments/fused_generation_ab.txt).
 __device__ __forceinline__ int opaque_uniform(int x) {       // opaque() for a wave-uniform value: it stays in a scalar register
     asm volatile("" : "+s"(x));
     return x;
 }
 __device__ __forceinline__ void fusedgen_publish() {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // every store of this wave acknowledged by the L2 (the scalar loads
+                                                          // that follow go there, not through this CU's vector L1)
     __syncthreads();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
     asm volatile("s_dcache_inv\n\ts_waitcnt lgkmcnt(0)" ::: "memory");
 }
 

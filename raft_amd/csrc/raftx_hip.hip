@@ -3247,7 +3247,9 @@ static int sweep_prepare_impl(raftx_ctx *c, int slot, int nDesign, const int64_t
         HIPCHK(c, hipStreamCreateWithFlags(&c->sD2H, hipStreamNonBlocking));
         {
             // RAFTX_GEN_PRIORITY=high (tuning): the generation stream in the highest priority class -- the tables of batch
-            // i+1 are what the next fused kernel waits for, the member pass of batch i+2 beside them is not
+            // i+1 are what the next fused kernel waits for, the member pass of batch i+2 beside them is not.  Measured and NOT
+            // the default: the generation then runs INSIDE the running fused kernel and lengthens it (2.93 against 2.71 ms;
+            // step 3.13-3.15 against 3.05-3.07, profiles/r06_experiments/gap_design_staging_priority_ab.txt)
             static const char *gp = getenv("RAFTX_GEN_PRIORITY");
             int least = 0, greatest = 0;
             if (gp && !strcmp(gp, "high") && hipDeviceGetStreamPriorityRange(&least, &greatest) == hipSuccess && least != greatest)
@@ -3681,8 +3683,12 @@ extern "C" int raftx_sweep_launch(raftx_ctx *c, int slot) {
         // RAFTX_FUSED_WAIT_MEMBER=1 keeps the wait)
         const char *fw_ = getenv("RAFTX_FUSED_WAIT_MEMBER");
         const bool fused_wait_member = fw_ && atoi(fw_);
-        // RAFTX_NO_MEMBER_WAIT=1 (tuning): the fused kernel does not wait for the member passes queued behind it
-        static const bool no_member_wait = getenv("RAFTX_NO_MEMBER_WAIT") && atoi(getenv("RAFTX_NO_MEMBER_WAIT"));
+        // Round 6: that wait is OFF by default (RAFTX_MEMBER_WAIT=1 restores it).  With the persistent grid the member pass
+        // queued behind this batch gets onto the chip in the drain of the fused kernel before it either way, and what has
+        // not finished then runs beside this kernel's first workgroups; same box, alternating, three batches in flight:
+        // 3.033-3.043 ms per step without the wait against 3.045-3.062 with it, no difference with two batches in flight
+        // (profiles/r06_experiments/gap_design_staging_priority_ab.txt).
+        static const bool no_member_wait = !(getenv("RAFTX_MEMBER_WAIT") && atoi(getenv("RAFTX_MEMBER_WAIT")));
         if (!rc && b == 0 && pipelined && gen_overlap && !two_streams && !no_member_wait && (!sub->job.gen_deferred || fused_wait_member)) {
             // Small kernels are not dispatched while a big grid is being handed out: whatever of the NEXT batch's member pass
             // has not finished when this batch's fused kernel starts would wait for the whole kernel and stall that batch's
