@@ -3658,7 +3658,10 @@ extern "C" int raftx_sweep_launch(raftx_ctx *c, int slot) {
                 rc = rc1;
             }
         }
-        if (b == 0 && pipelined && gen_overlap && !two_streams) {
+        // RAFTX_GEN_EARLY=1 (tuning): no such wait -- behind a PERSISTENT grid the generation cannot start before the first
+        // workgroups of that grid leave anyway
+        static const bool gen_early = getenv("RAFTX_GEN_EARLY") && atoi(getenv("RAFTX_GEN_EARLY"));
+        if (b == 0 && pipelined && gen_overlap && !two_streams && !gen_early) {
             // When does the generation run?  Enqueued now, beside a fused kernel that has only just started, it would be
             // dispatched at once and take LDS from that kernel for its whole run (measured: +0.25 ms on the kernel).  A
             // small kernel queued BEHIND a running big grid is dispatched when that grid has been handed out -- which is

@@ -1,0 +1,44 @@
+#!/bin/bash
+# Round 6: the table generation of batch i+1 not held back until the member pass of batch i+2 is on the chip (RAFTX_GEN_EARLY=1).
+TAG=${1:-r06_early}
+R=${GRAFT_REPO_ROOT:-$(pwd)}; OUT=$R/gpurun_out/$TAG; mkdir -p $OUT; cd $R
+run() {  # name, env... [-- bench args]
+  local name=$1; shift
+  local envs=() extra=()
+  while [ $# -gt 0 ] && [ "$1" != "--" ]; do envs+=("$1"); shift; done
+  [ $# -gt 0 ] && shift
+  extra=("$@")
+  ( env "${envs[@]}" timeout 300 python bench.py --no-cpu-baseline --no-extra-legs --steps 40 --warmup 10 "${extra[@]}" 2>$OUT/bench_$name.err | tail -1 ) > $OUT/bench_$name.json
+  python - $OUT/bench_$name.json $name <<'PY'
+import json, sys
+try:
+    d = json.load(open(sys.argv[1]))
+    r = d["roofline"]
+    print("%-34s step %.4f ms  kernel(union) %.4f  per-launch %.4f  frac %.4f  step_frac %.4f  value %.1f M" % (sys.argv[2], d["ms_per_step"], r["kernel_ms_per_step"],
+          r.get("kernel_ms_per_launch", 0.0), r["frac"], r.get("step_frac", 0.0), d["value"] / 1e6), flush=True)
+except Exception as e:
+    print(sys.argv[2], "FAILED", e, flush=True)
+PY
+}
+for rep in 1 2 3; do
+  run base_$rep A=1
+  run early_$rep RAFTX_GEN_EARLY=1
+  run early_memwait_$rep RAFTX_GEN_EARLY=1 RAFTX_MEMBER_WAIT=1
+  run early_scan256_$rep RAFTX_GEN_EARLY=1 RAFTX_SCAN_T=256
+  run early_d4_$rep RAFTX_GEN_EARLY=1 -- --depth 4
+done 2>&1 | tee $OUT/ab.txt
+cd /tmp; export TMPDIR=/tmp
+RAFTX_GEN_EARLY=1 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_1 -o bench -- python $R/bench.py --steps 20 --warmup 10 --profile --no-cpu-baseline --no-extra-legs > $OUT/trace_1.log 2>&1
+cd $R
+python - $OUT <<'PY' | tee $OUT/timelines.txt
+import csv, sys, os
+p = os.path.join(sys.argv[1], "trace_1", "bench_kernel_trace.csv")
+rows = list(csv.DictReader(open(p)))
+rows.sort(key=lambda r: int(r["Start_Timestamp"]))
+fused = [i for i, r in enumerate(rows) if r["Kernel_Name"].startswith("raftx_kp")]
+i0 = fused[18]; t0 = int(rows[i0]["Start_Timestamp"])
+for r in rows[i0 - 7:i0 + 20]:
+    s = (int(r["Start_Timestamp"]) - t0) / 1e3; e = (int(r["End_Timestamp"]) - t0) / 1e3
+    print("%-30s start %9.1f end %9.1f dur %8.1f q%s grid %s" % (r["Kernel_Name"][:30], s, e, e - s, r["Queue_Id"], r["Grid_Size_X"]))
+PY
+find $OUT -name '*_kernel_trace.csv' -size +4M -delete
