@@ -156,6 +156,8 @@ struct GeomArgs {
     double *A, *Ch, *Wh, *props; // [nDesign,36] [nDesign,36] [nDesign,6] [nDesign,RAFTX_SP_N]
     double *M0, *C0;             // [nDesign,36] design matrices, updated in place per add_mask
     int add_mask;
+    int addup_in_design;         // k_geom_design also does its design's share of k_geom_addup (the member -> platform reductions
+                                 // have finished when it is launched): sweep crossings, one kernel and one launch gap less
     long long *tot;              // [3] wet strips, MacCamy-Fuchs rows, strips of the largest design (zeroed before the scans)
     // A block of a larger batch reads the batch's own offset arrays (uploaded once, shared by its blocks): the pointers
     // are shifted to the block's first design / member and the bases make the values block-relative.
@@ -386,17 +388,26 @@ __device__ inline void geom_add_submember(double *M, double mass, const double (
 // Zero-length sections re-add the local inertia tensor of the previous section with zero mass, as the reference
 // does (Ixx, Iyy, Izz are not reset between sections, :420-513).  Returns a non-zero code for cap layouts the
 // reference itself cannot handle.
-__device__ inline int geom_member_inertia(const double *gm, const double *gs, int n, const double *gc, int ncap,
-                                          const double *rA, const double *q, const double *p1, const double *p2, double g,
-                                          bool trim, double drho, double *out) {
+// The running sums of Member.getInertia over the sections and caps of one member.  In pieces, so that the member pass can feed
+// the sections from station rows it holds in registers (one pass over the stations for wet strips, hydrostatics and
+// inertia) while k_geom_reinertia walks the table: the arithmetic is the same statements in the same order either way.
+struct GInertia {
+    double M[36], mc[3], I3[3], vfill;
+};
+__device__ inline void geom_inertia_init(GInertia &J) {
+    for (int i = 0; i < 36; i++) J.M[i] = 0.0;
+    for (int c = 0; c < 3; c++) { J.mc[c] = 0.0; J.I3[c] = 0.0; }
+    J.vfill = 0.0;
+}
+// the section between stations a and b (rows of RAFTX_GS_N doubles: registers or memory)
+__device__ inline void geom_inertia_section(GInertia &J, const double *a, const double *b, bool circ, double rho_shell, bool trim,
+                                            double drho, const double *rA, const double *q, const double *p1, const double *p2) {
     GEOM_NOFMA
-    const bool circ = gm[RAFTX_GM_SHAPE] != 0.0;
-    const int c1 = circ ? 0 : 1;
-    const double rho_shell = gm[RAFTX_GM_RHOSHELL];
-    double M[36], mc[3] = {0, 0, 0}, I3[3] = {0, 0, 0}, vfill = 0.0;
-    for (int i = 0; i < 36; i++) M[i] = 0.0;
-    for (int i = 1; i < n; i++) {
-        const double *a = gs + (size_t)(i - 1) * RAFTX_GS_N, *b = gs + (size_t)i * RAFTX_GS_N;
+    double (&M)[36] = J.M;
+    double (&mc)[3] = J.mc;
+    double (&I3)[3] = J.I3;
+    double &vfill = J.vfill;
+    {
         const double l = b[RAFTX_GS_S] - a[RAFTX_GS_S];
         double mass = 0.0, center[3] = {0, 0, 0};
         if (l > 0) {
@@ -404,7 +415,7 @@ __device__ inline int geom_member_inertia(const double *gm, const double *gs, in
             // their fill, every ballasted section gets the design's density correction
             const double l_fill = (trim && a[RAFTX_GS_RHOFILL] == 0.0) ? 0.0 : a[RAFTX_GS_LFILL];
             const double rho_fill = a[RAFTX_GS_RHOFILL] + (l_fill > 0.0 ? drho : 0.0);
-            const double dA0 = a[RAFTX_GS_D], dA1 = a[RAFTX_GS_D + c1], dB0 = b[RAFTX_GS_D], dB1 = b[RAFTX_GS_D + c1];
+            const double dA0 = a[RAFTX_GS_D], dA1 = (circ ? a[RAFTX_GS_D] : a[RAFTX_GS_D + 1]), dB0 = b[RAFTX_GS_D], dB1 = (circ ? b[RAFTX_GS_D] : b[RAFTX_GS_D + 1]);
             const double iA0 = dA0 - 2 * a[RAFTX_GS_T], iA1 = dA1 - 2 * a[RAFTX_GS_T];
             const double iB0 = dB0 - 2 * b[RAFTX_GS_T], iB1 = dB1 - 2 * b[RAFTX_GS_T];
             const double f0 = (iB0 - iA0) * (l_fill / l) + iA0, f1 = (iB1 - iA1) * (l_fill / l) + iA1;
@@ -440,6 +451,17 @@ __device__ inline int geom_member_inertia(const double *gm, const double *gs, in
         for (int c = 0; c < 3; c++) { mc[c] += mass * center[c]; rel[c] = center[c] - rA[c]; }
         geom_add_submember(M, mass, I3, p1, p2, q, rel);
     }
+}
+// the caps and bulkheads of the member (station table in memory: the interpolations look stations up by position), then the
+// totals into out[MI_N].  Non-zero: a cap layout the reference itself cannot handle.
+__device__ inline int geom_inertia_caps_finish(GInertia &J, const double *gs, int n, const double *gc, int ncap, bool circ,
+                                               double rho_shell, const double *rA, const double *q, const double *p1,
+                                               const double *p2, double g, double *out) {
+    GEOM_NOFMA
+    const int c1 = circ ? 0 : 1;
+    double (&M)[36] = J.M;
+    double (&mc)[3] = J.mc;
+    const double vfill = J.vfill;
     const double s0 = gs[RAFTX_GS_S], s1 = gs[(size_t)(n - 1) * RAFTX_GS_N + RAFTX_GS_S];
     for (int i = 0; i < ncap; i++) {
         const double *cp = gc + (size_t)i * RAFTX_GC_N;
@@ -532,6 +554,17 @@ __device__ inline int geom_member_inertia(const double *gm, const double *gs, in
     out[47] = vfill;                                                                 // member.vfill summed (raft_member.py:506)
     return 0;
 }
+__device__ inline int geom_member_inertia(const double *gm, const double *gs, int n, const double *gc, int ncap,
+                                          const double *rA, const double *q, const double *p1, const double *p2, double g,
+                                          bool trim, double drho, double *out) {
+    const bool circ = gm[RAFTX_GM_SHAPE] != 0.0;
+    const double rho_shell = gm[RAFTX_GM_RHOSHELL];
+    GInertia J;
+    geom_inertia_init(J);
+    for (int i = 1; i < n; i++)
+        geom_inertia_section(J, gs + (size_t)(i - 1) * RAFTX_GS_N, gs + (size_t)i * RAFTX_GS_N, circ, rho_shell, trim, drho, rA, q, p1, p2);
+    return geom_inertia_caps_finish(J, gs, n, gc, ncap, circ, rho_shell, rA, q, p1, p2, g, out);
+}
 
 // one thread per member: pose, wet-strip count, hydrostatics and inertia about the member's own node
 // clears what the pass accumulates into (one launch instead of five fills: every launch of the preparation stream has
@@ -565,29 +598,66 @@ __device__ inline int64_t geom_member_of_thread(const GeomArgs &A) {
     const int64_t m = A.mo(d) + k;
     return m < A.mo(d + 1) ? m : -1;
 }
+// a station row into registers: eight 16-byte loads, all in flight together (rows are 128-byte records of 16-byte-aligned
+// tables)
+__device__ __forceinline__ void geom_load_row(const double *gs, int i, double (&r)[RAFTX_GS_N]) {
+    const double2 *p = reinterpret_cast<const double2 *>(gs + (size_t)i * RAFTX_GS_N);
+#pragma unroll
+    for (int k = 0; k < RAFTX_GS_N / 2; k++) {
+        const double2 v = p[k];
+        r[2 * k] = v.x;
+        r[2 * k + 1] = v.y;
+    }
+}
+// Memory-wise the pass is a handful of round trips per member: the member's row and offsets, then ONE pass over its
+// stations -- each row read once into registers (geom_load_row) and used for the wet-strip count, the hydrostatics and the
+// inertia of the section it closes -- then the caps, and every result stored at the end.  (Up to round 5 the three
+// computations walked the station table one 8-byte load at a time, each waited for: ~130 dependent round trips, 149 us
+// for 1 700 wavefronts that issue VALU in 11 % of their cycles.)
 __global__ __launch_bounds__(128) void k_geom_member(GeomArgs A) {
     GEOM_NOFMA
     if (A.mgrid > 0 && A.err[2]) return;                  // member offsets rejected: the grid cannot be walked
     const int64_t m = geom_member_of_thread(A);
     if (m < 0) return;
-    const double *gm = A.gm + (size_t)m * RAFTX_GM_N;
-    const double *gs = A.gs + (size_t)A.so(m) * RAFTX_GS_N;
-    const int n = (int)(A.so(m + 1) - A.so(m));
-    A.cnt[m] = 0;
-    A.cntm[m] = 0;
-    if (A.err[2]) return;                                 // member offsets rejected: mdesign is not valid
+    if (A.err[2]) {                                       // member offsets rejected: mdesign is not valid
+        A.cnt[m] = 0;
+        A.cntm[m] = 0;
+        return;
+    }
+    // ---- first round trip: everything that hangs on m alone
+    double gm[RAFTX_GM_N];
+    {
+        const double2 *p = reinterpret_cast<const double2 *>(A.gm + (size_t)m * RAFTX_GM_N);
+#pragma unroll
+        for (int k = 0; k < RAFTX_GM_N / 2; k++) {
+            const double2 v = p[k];
+            gm[2 * k] = v.x;
+            gm[2 * k + 1] = v.y;
+        }
+    }
+    const int64_t so0 = A.so(m), so1 = A.so(m + 1);
+    const int64_t co0 = A.capOff ? A.co(m) : 0, co1 = A.capOff ? A.co(m + 1) : 0;
+    const int d = A.mdesign[m];
+    const double *gs = A.gs + (size_t)so0 * RAFTX_GS_N;
+    const int n = (int)(so1 - so0);
     if (n < 2 || n > GEOM_MAX_STATIONS || !(gm[RAFTX_GM_DLSMAX] > 0.0) || !(gm[RAFTX_GM_L] > 0.0)) {
+        A.cnt[m] = 0;
+        A.cntm[m] = 0;
         atomicCAS(A.err + 3, 0, (int)(m + 1));            // bad station count / dlsMax / length: the member is skipped
         return;
     }
     if (((int)gm[RAFTX_GM_FLAGS] & RAFTX_GM_FLAG_MCF) && gm[RAFTX_GM_SHAPE] != 0.0 && !A.k) {
+        A.cnt[m] = 0;
+        A.cntm[m] = 0;
         atomicCAS(A.err + 3, 0, -(int)(m + 1));           // MacCamy-Fuchs member without wave numbers
         return;
     }
-    const int d = A.mdesign[m];
+    // ---- second round trip: the unit's pose and the first station row
     double ps[6] = {0, 0, 0, 0, 0, 0};
     if (A.pose)
         for (int i = 0; i < 6; i++) ps[i] = A.pose[(size_t)d * 6 + i];
+    double a[RAFTX_GS_N], b[RAFTX_GS_N];
+    geom_load_row(gs, 0, b);
     const bool circ = gm[RAFTX_GM_SHAPE] != 0.0;
     const int flags = (int)gm[RAFTX_GM_FLAGS];
     // ---- Member.setPosition (raft_member.py:324-372) for a rigid member of a rigid unit
@@ -627,125 +697,154 @@ __global__ __launch_bounds__(128) void k_geom_member(GeomArgs A) {
     for (int i = 0; i < 3; i++) rB[i] = rA[i] + L * q[i];
     for (int i = 0; i < 2; i++)
         for (int j = 0; j < 2; j++) R[i][j] = Rp[i][0] * R0[0][j] + Rp[i][1] * R0[1][j] + Rp[i][2] * R0[2][j];
-    double *mp = A.mpose + (size_t)m * MP_N;
-    for (int i = 0; i < 3; i++) {
-        mp[i] = rA0[i]; mp[3 + i] = rA[i]; mp[6 + i] = q[i]; mp[9 + i] = p1[i]; mp[12 + i] = p2[i];
-    }
-    mp[15] = R[0][0]; mp[16] = R[0][1]; mp[17] = R[1][0]; mp[18] = R[1][1]; mp[19] = L;
-    // ---- wet strips (raft_member.py:1310: r[il,2] < 0)
+    // ---- one pass over the stations.  Wet strips (raft_member.py:1310: r[il,2] < 0): only the position ls of a candidate
+    // matters here -- geom_strip's expressions for it, group by group: end A (ls = 0), the station intervals, end B
     int wet = 0;
-    for (int g = 0; g <= n; g++) {
-        int cntg = 1, nsub = 1;
-        if (g > 0 && g < n) {
-            cntg = geom_interval_strips(gs[(size_t)g * RAFTX_GS_N + RAFTX_GS_S] - gs[(size_t)(g - 1) * RAFTX_GS_N + RAFTX_GS_S],
-                                        gm[RAFTX_GM_DLSMAX]);
-            nsub = cntg;
-        }
-        for (int j = 0; j < cntg; j++) {
-            const GStrip s = geom_strip(gs, n, g, j, nsub, circ);
-            if (geom_along(rA[2], rB[2], s.ls, L) < 0) wet++;
-        }
-    }
-    const int wetm = ((flags & RAFTX_GM_FLAG_MCF) && circ && !(flags & RAFTX_GM_FLAG_POTMOD)) ? wet : 0;
-    A.cnt[m] = wet;
-    A.cntm[m] = wetm;
-    // per-design totals (integer sums: the order of the additions does not matter)
-    if (wet) atomicAdd(reinterpret_cast<unsigned long long *>(A.off + d + 1), (unsigned long long)wet);
-    if (wetm) atomicAdd(reinterpret_cast<unsigned long long *>(A.cmoff + d + 1), (unsigned long long)wetm);
-    // ---- Member.getHydrostatics, rigid branch, about the member's node (raft_member.py:838-1010)
+    if (geom_along(rA[2], rB[2], 0.0, L) < 0) wet++;                                     // group 0: end A
+    // Member.getHydrostatics, rigid branch, about the member's node (raft_member.py:838-1010)
     double C[36], F[6], Vt = 0.0, rcV[3] = {0, 0, 0}, AWPm = 0.0;
     for (int i = 0; i < 36; i++) C[i] = 0.0;
     for (int i = 0; i < 6; i++) F[i] = 0.0;
     const double beta2 = atan2(q[1], q[0]), phi2 = atan2(sqrt(q[0] * q[0] + q[1] * q[1]), q[2]);
     const double cosPhi = cos(phi2), sinPhi = sin(phi2), tanPhi = tan(phi2), cosBeta = cos(beta2), sinBeta = sin(beta2);
     const double rg = A.rho * A.g;
-    const int c1i = circ ? 0 : 1;
+    const bool nostatic = (flags & RAFTX_GM_FLAG_NOSTATIC) != 0;          // nacelle members stay out of the statics (raft_fowt.py:876)
+    const double rho_shell = gm[RAFTX_GM_RHOSHELL];
+    const bool trim = (A.add_mask & RAFTX_TRIM_BALLAST) != 0;
     for (int i = 1; i < n; i++) {
-        const double *a = gs + (size_t)(i - 1) * RAFTX_GS_N, *b = gs + (size_t)i * RAFTX_GS_N;
-        double ra[3], rb[3];
-        for (int c = 0; c < 3; c++) {
-            ra[c] = rA[c] + q[c] * a[RAFTX_GS_S];
-            rb[c] = rA[c] + q[c] * b[RAFTX_GS_S];
-        }
-        if (ra[2] * rb[2] <= 0) {                                   // crosses (or touches) the waterplane
-            const double t = (0 - ra[2]);
-            double xWP = ra[0] + t * (rb[0] - ra[0]) / (rb[2] - ra[2]);
-            double yWP = ra[1] + t * (rb[1] - ra[1]) / (rb[2] - ra[2]);
-            // (sic) interpolated from the UPPER station value at end A's elevation, raft_member.py:899,905
-            const double w0 = b[RAFTX_GS_D] + t * (a[RAFTX_GS_D] - b[RAFTX_GS_D]) / (rb[2] - ra[2]);
-            const double w1 = b[RAFTX_GS_D + c1i] + t * (a[RAFTX_GS_D + c1i] - b[RAFTX_GS_D + c1i]) / (rb[2] - ra[2]);
-            double AWP, IxWP, IyWP;
-            if (circ) {
-                AWP = (M_PI / 4) * w0 * w0;
-                IxWP = IyWP = (M_PI / 64) * w0 * w0 * w0 * w0;
-            } else {
-                AWP = w0 * w1;
-                const double Ix = (1.0 / 12) * w0 * w1 * w1 * w1, Iy = (1.0 / 12) * w0 * w0 * w0 * w1;
-                IxWP = R[0][0] * Ix * R[0][0] + R[0][1] * Iy * R[0][1];      // (R diag(Ix,Iy,0) R^T)[0,0], :909-913
-                IyWP = R[1][0] * Ix * R[1][0] + R[1][1] * Iy * R[1][1];
+#pragma unroll
+        for (int f = 0; f < RAFTX_GS_N; f++) a[f] = b[f];
+        geom_load_row(gs, i, b);
+        {   // wet strips of the interval (group i)
+            const double lstrip = b[RAFTX_GS_S] - a[RAFTX_GS_S];
+            const int cntg = geom_interval_strips(lstrip, gm[RAFTX_GM_DLSMAX]);
+            for (int j = 0; j < cntg; j++) {
+                double ls;
+                if (lstrip > 0.0) {
+                    const double dl = lstrip / cntg;
+                    ls = a[RAFTX_GS_S] + dl * (0.5 + j);
+                } else {
+                    ls = a[RAFTX_GS_S];
+                }
+                if (geom_along(rA[2], rB[2], ls, L) < 0) wet++;
             }
-            const double LWP = fabs(ra[2] / cosPhi);
-            double V, hc;
-            geom_frustum(a[RAFTX_GS_D], a[RAFTX_GS_D + c1i], w0, w1, circ, LWP, V, hc);
-            double M = 0.0;
-            if (circ) M = -rg * M_PI * (w0 * w0 / 32 * (2.0 + tanPhi * tanPhi) + 0.5 * (ra[2] / cosPhi) * (ra[2] / cosPhi)) * sinPhi;
-            const double Fz = rg * V;
-            const double ex = ra[0] - rA[0], ey = ra[1] - rA[1];
-            F[2] += Fz;
-            F[3] += ey * Fz;                     // translateForce3to6DOF of (0,0,Fz) at rA_seg - node
-            F[4] += -ex * Fz;
-            F[3] += M * (-sinBeta);
-            F[4] += M * cosBeta;
-            xWP -= rA[0];
-            yWP -= rA[1];
-            C[2 * 6 + 2] += rg * AWP / cosPhi;
-            C[2 * 6 + 3] += rg * (-AWP * yWP);
-            C[2 * 6 + 4] += rg * (AWP * xWP);
-            C[3 * 6 + 2] += rg * (-AWP * yWP);
-            C[3 * 6 + 3] += rg * (IxWP + AWP * yWP * yWP);
-            C[3 * 6 + 4] += rg * (AWP * xWP * yWP);
-            C[4 * 6 + 2] += rg * (AWP * xWP);
-            C[4 * 6 + 3] += rg * (AWP * xWP * yWP);
-            C[4 * 6 + 4] += rg * (IyWP + AWP * xWP * xWP);
-            double rc[3];
-            for (int c = 0; c < 3; c++) rc[c] = ra[c] + q[c] * hc;
-            C[3 * 6 + 3] += rg * V * (rc[2] - rA[2]);
-            C[4 * 6 + 4] += rg * V * (rc[2] - rA[2]);
-            C[3 * 6 + 5] += -rg * V * (rc[0] - rA[0]);
-            C[4 * 6 + 5] += -rg * V * (rc[1] - rA[1]);
-            Vt += V;
-            for (int c = 0; c < 3; c++) rcV[c] += rc[c] * V;
-            AWPm = AWP;
-        } else if (ra[2] <= 0 && rb[2] <= 0) {                     // fully submerged
-            double V, hc;
-            geom_frustum(a[RAFTX_GS_D], a[RAFTX_GS_D + c1i], b[RAFTX_GS_D], b[RAFTX_GS_D + c1i], circ,
-                         b[RAFTX_GS_S] - a[RAFTX_GS_S], V, hc);
-            double rc[3], rr[3];
-            for (int c = 0; c < 3; c++) { rc[c] = ra[c] + q[c] * hc; rr[c] = rc[c] - rA[c]; }
-            const double Fz = rg * V;
-            F[2] += Fz;
-            F[3] += rr[1] * Fz;
-            F[4] += -rr[0] * Fz;
-            C[3 * 6 + 3] += rg * V * rr[2];
-            C[4 * 6 + 4] += rg * V * rr[2];
-            C[3 * 6 + 5] += -rg * V * rr[0];
-            C[4 * 6 + 5] += -rg * V * rr[1];
-            Vt += V;
-            for (int c = 0; c < 3; c++) rcV[c] += rc[c] * V;
+        }
+        if (nostatic) continue;
+        {   // hydrostatics of the section
+            double ra[3], rb[3];
+            for (int c = 0; c < 3; c++) {
+                ra[c] = rA[c] + q[c] * a[RAFTX_GS_S];
+                rb[c] = rA[c] + q[c] * b[RAFTX_GS_S];
+            }
+            const double aD1 = circ ? a[RAFTX_GS_D] : a[RAFTX_GS_D + 1], bD1 = circ ? b[RAFTX_GS_D] : b[RAFTX_GS_D + 1];
+            if (ra[2] * rb[2] <= 0) {                                   // crosses (or touches) the waterplane
+                const double t = (0 - ra[2]);
+                double xWP = ra[0] + t * (rb[0] - ra[0]) / (rb[2] - ra[2]);
+                double yWP = ra[1] + t * (rb[1] - ra[1]) / (rb[2] - ra[2]);
+                // (sic) interpolated from the UPPER station value at end A's elevation, raft_member.py:899,905
+                const double w0 = b[RAFTX_GS_D] + t * (a[RAFTX_GS_D] - b[RAFTX_GS_D]) / (rb[2] - ra[2]);
+                const double w1 = bD1 + t * (aD1 - bD1) / (rb[2] - ra[2]);
+                double AWP, IxWP, IyWP;
+                if (circ) {
+                    AWP = (M_PI / 4) * w0 * w0;
+                    IxWP = IyWP = (M_PI / 64) * w0 * w0 * w0 * w0;
+                } else {
+                    AWP = w0 * w1;
+                    const double Ix = (1.0 / 12) * w0 * w1 * w1 * w1, Iy = (1.0 / 12) * w0 * w0 * w0 * w1;
+                    IxWP = R[0][0] * Ix * R[0][0] + R[0][1] * Iy * R[0][1];      // (R diag(Ix,Iy,0) R^T)[0,0], :909-913
+                    IyWP = R[1][0] * Ix * R[1][0] + R[1][1] * Iy * R[1][1];
+                }
+                const double LWP = fabs(ra[2] / cosPhi);
+                double V, hc;
+                geom_frustum(a[RAFTX_GS_D], aD1, w0, w1, circ, LWP, V, hc);
+                double M = 0.0;
+                if (circ) M = -rg * M_PI * (w0 * w0 / 32 * (2.0 + tanPhi * tanPhi) + 0.5 * (ra[2] / cosPhi) * (ra[2] / cosPhi)) * sinPhi;
+                const double Fz = rg * V;
+                const double ex = ra[0] - rA[0], ey = ra[1] - rA[1];
+                F[2] += Fz;
+                F[3] += ey * Fz;                     // translateForce3to6DOF of (0,0,Fz) at rA_seg - node
+                F[4] += -ex * Fz;
+                F[3] += M * (-sinBeta);
+                F[4] += M * cosBeta;
+                xWP -= rA[0];
+                yWP -= rA[1];
+                C[2 * 6 + 2] += rg * AWP / cosPhi;
+                C[2 * 6 + 3] += rg * (-AWP * yWP);
+                C[2 * 6 + 4] += rg * (AWP * xWP);
+                C[3 * 6 + 2] += rg * (-AWP * yWP);
+                C[3 * 6 + 3] += rg * (IxWP + AWP * yWP * yWP);
+                C[3 * 6 + 4] += rg * (AWP * xWP * yWP);
+                C[4 * 6 + 2] += rg * (AWP * xWP);
+                C[4 * 6 + 3] += rg * (AWP * xWP * yWP);
+                C[4 * 6 + 4] += rg * (IyWP + AWP * xWP * xWP);
+                double rc[3];
+                for (int c = 0; c < 3; c++) rc[c] = ra[c] + q[c] * hc;
+                C[3 * 6 + 3] += rg * V * (rc[2] - rA[2]);
+                C[4 * 6 + 4] += rg * V * (rc[2] - rA[2]);
+                C[3 * 6 + 5] += -rg * V * (rc[0] - rA[0]);
+                C[4 * 6 + 5] += -rg * V * (rc[1] - rA[1]);
+                Vt += V;
+                for (int c = 0; c < 3; c++) rcV[c] += rc[c] * V;
+                AWPm = AWP;
+            } else if (ra[2] <= 0 && rb[2] <= 0) {                     // fully submerged
+                double V, hc;
+                geom_frustum(a[RAFTX_GS_D], aD1, b[RAFTX_GS_D], bD1, circ, b[RAFTX_GS_S] - a[RAFTX_GS_S], V, hc);
+                double rc[3], rr[3];
+                for (int c = 0; c < 3; c++) { rc[c] = ra[c] + q[c] * hc; rr[c] = rc[c] - rA[c]; }
+                const double Fz = rg * V;
+                F[2] += Fz;
+                F[3] += rr[1] * Fz;
+                F[4] += -rr[0] * Fz;
+                C[3 * 6 + 3] += rg * V * rr[2];
+                C[4 * 6 + 4] += rg * V * rr[2];
+                C[3 * 6 + 5] += -rg * V * rr[0];
+                C[4 * 6 + 5] += -rg * V * rr[1];
+                Vt += V;
+                for (int c = 0; c < 3; c++) rcV[c] += rc[c] * V;
+            }
         }
     }
+    if (geom_along(rA[2], rB[2], b[RAFTX_GS_S], L) < 0) wet++;                           // group n: end B (b = the last station)
     double *mh = A.mhyd + (size_t)m * MH_N, *mi = A.minert + (size_t)m * MI_N;
-    if (flags & RAFTX_GM_FLAG_NOSTATIC) {                // nacelle members stay out of the statics (raft_fowt.py:876)
+    if (!nostatic) {
+        for (int i = 0; i < 36; i++) mh[i] = C[i];
+        for (int i = 0; i < 6; i++) mh[36 + i] = F[i];
+        mh[42] = Vt; mh[43] = rcV[0]; mh[44] = rcV[1]; mh[45] = rcV[2]; mh[46] = AWPm; mh[47] = 0.0;
+    }
+    // ---- Member.getInertia: a second pass over the station rows (its 6 x 6 running sums beside the hydrostatic ones would
+    // cost the pass its two waves per SIMD), then caps and bulkheads and the totals (the station table by position: memory)
+    int code = 0;
+    if (!nostatic) {
+        GInertia J;
+        geom_inertia_init(J);
+        geom_load_row(gs, 0, b);
+        for (int i = 1; i < n; i++) {
+#pragma unroll
+            for (int f = 0; f < RAFTX_GS_N; f++) a[f] = b[f];
+            geom_load_row(gs, i, b);
+            geom_inertia_section(J, a, b, circ, rho_shell, trim, 0.0, rA, q, p1, p2);
+        }
+        const int ncap = A.capOff ? (int)(co1 - co0) : 0;
+        const double *gc = A.capOff ? A.caps + (size_t)co0 * RAFTX_GC_N : nullptr;
+        code = geom_inertia_caps_finish(J, gs, n, gc, ncap, circ, rho_shell, rA, q, p1, p2, A.g, mi);
+    }
+    // ---- everything out
+    double *mp = A.mpose + (size_t)m * MP_N;
+    for (int i = 0; i < 3; i++) {
+        mp[i] = rA0[i]; mp[3 + i] = rA[i]; mp[6 + i] = q[i]; mp[9 + i] = p1[i]; mp[12 + i] = p2[i];
+    }
+    mp[15] = R[0][0]; mp[16] = R[0][1]; mp[17] = R[1][0]; mp[18] = R[1][1]; mp[19] = L;
+    const int wetm = ((flags & RAFTX_GM_FLAG_MCF) && circ && !(flags & RAFTX_GM_FLAG_POTMOD)) ? wet : 0;
+    A.cnt[m] = wet;
+    A.cntm[m] = wetm;
+    // per-design totals (integer sums: the order of the additions does not matter)
+    if (wet) atomicAdd(reinterpret_cast<unsigned long long *>(A.off + d + 1), (unsigned long long)wet);
+    if (wetm) atomicAdd(reinterpret_cast<unsigned long long *>(A.cmoff + d + 1), (unsigned long long)wetm);
+    if (nostatic) {
         for (int i = 0; i < MH_N; i++) mh[i] = 0.0;
         for (int i = 0; i < MI_N; i++) mi[i] = 0.0;
         return;
     }
-    for (int i = 0; i < 36; i++) mh[i] = C[i];
-    for (int i = 0; i < 6; i++) mh[36 + i] = F[i];
-    mh[42] = Vt; mh[43] = rcV[0]; mh[44] = rcV[1]; mh[45] = rcV[2]; mh[46] = AWPm; mh[47] = 0.0;
-    const int ncap = A.capOff ? (int)(A.co(m + 1) - A.co(m)) : 0;
-    const double *gc = A.capOff ? A.caps + (size_t)A.co(m) * RAFTX_GC_N : nullptr;
-    const int code = geom_member_inertia(gm, gs, n, gc, ncap, rA, q, p1, p2, A.g, (A.add_mask & RAFTX_TRIM_BALLAST) != 0, 0.0, mi);
     if (code) {
         for (int i = 0; i < MI_N; i++) mi[i] = 0.0;
         atomicCAS(A.err, 0, (int)(m + 1));
@@ -1023,14 +1122,31 @@ __device__ __forceinline__ void geom_design_block(const GeomArgs &A, const int d
         double *sgs = sgm + (size_t)nMem * RAFTX_GM_N;                            // [nSta][RAFTX_GS_N]
         double *smp = sgs + (size_t)nSta * RAFTX_GS_N;                            // [nMem][MP_N]
         {
+            // (the three tables are one contiguous stretch of LDS: a lane's loads of a round -- ten, enough for a design of 16
+            // members and 48 stations -- and its first-station offset are all in flight before the first of them is waited for)
             const double *g0 = A.gm + (size_t)m0 * RAFTX_GM_N, *g1 = A.gs + (size_t)s0 * RAFTX_GS_N, *g2 = A.mpose + (size_t)m0 * MP_N;
-            for (int t = lane; t < nMem * RAFTX_GM_N; t += GD_T) sgm[t] = g0[t];
-            for (int t = lane; t < nSta * RAFTX_GS_N; t += GD_T) sgs[t] = g1[t];
-            for (int t = lane; t < nMem * MP_N; t += GD_T) smp[t] = g2[t];
+            const int n0 = nMem * RAFTX_GM_N, n01 = n0 + nSta * RAFTX_GS_N, total = n01 + nMem * MP_N;
+            constexpr int SU = 10;
+            const int64_t so_lane = lane <= nMem ? A.so(m0 + lane) : s0;
+            for (int base = 0; base < total; base += SU * GD_T) {
+                double v[SU];
+#pragma unroll
+                for (int u = 0; u < SU; u++) {
+                    const int idx = base + u * GD_T + lane;
+                    const double *src = idx < n0 ? g0 + idx : (idx < n01 ? g1 + (idx - n0) : g2 + (idx - n01));
+                    v[u] = idx < total ? *src : 0.0;
+                }
+#pragma unroll
+                for (int u = 0; u < SU; u++) {
+                    const int idx = base + u * GD_T + lane;
+                    if (idx < total) sgm[idx] = v[u];
+                }
+            }
+            // groups of all members flattened over the lanes: member mi owns the n + 1 groups [sta0(mi) + mi, sta0(mi + 1) + mi + 1)
+            // (mbase doubles as the members' first-station table until the counts are in)
+            if (lane <= nMem) mbase[lane] = ssta[lane] = (int)(so_lane - s0);
+            for (int mi = lane + GD_T; mi <= nMem; mi += GD_T) mbase[mi] = ssta[mi] = (int)(A.so(m0 + mi) - s0);
         }
-        // groups of all members flattened over the lanes: member mi owns the n + 1 groups [sta0(mi) + mi, sta0(mi + 1) + mi + 1)
-        // (mbase doubles as the members' first-station table until the counts are in)
-        for (int mi = lane; mi <= nMem; mi += GD_T) mbase[mi] = ssta[mi] = (int)(A.so(m0 + mi) - s0);
         __syncthreads();
         for (int u = lane; u < nSta + nMem; u += GD_T) {
             int mi = 0;
@@ -1377,7 +1493,8 @@ __global__ __launch_bounds__(GD_T) void k_geom_design(GeomArgs A) {
     __shared__ int wcnt[GD_T / 64];
     if ((int)blockIdx.x >= A.nDesign) return;
     if (A.abi) geom_design_block<true, false>(A, (int)blockIdx.x, gd_lds, wcnt);
-    else geom_design_block<false, false>(A, (int)blockIdx.x, gd_lds, wcnt);     // (a sweep crossing that fell back from the fused form)
+    else if (A.addup_in_design) geom_design_block<false, true>(A, (int)blockIdx.x, gd_lds, wcnt);       // sweep crossings
+    else geom_design_block<false, false>(A, (int)blockIdx.x, gd_lds, wcnt);
 }
 // What the device adds to the caller's matrices (add_mask), in a fixed order: Morison added mass (k_geom_design), then the
 // member -> platform reductions (k_geom_reduce, which runs beside the generation on its own stream).

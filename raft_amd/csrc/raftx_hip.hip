@@ -1466,8 +1466,9 @@ static void launch_design(raftx_ctx *c, hipStream_t st) {
     BuildJob &J = c->job;
     hipLaunchKernelGGL(k_geom_design, dim3((unsigned)J.nDesign), dim3(GD_T), J.gen_lds, st, J.A);
 }
-// crossing: 0 = raftx_build_designs (tables + ABI copy), 1 = a sweep crossing (no ABI copy), 2 = a crossing whose tables the
-// fused kernel may build itself (RAFTX_FUSED_GEN=1)
+// crossing: 0 = raftx_build_designs (tables + ABI copy); bits: 1 = a sweep crossing (no ABI copy), 2 = its tables may be left
+// to the fused kernel (RAFTX_FUSED_GEN=1), 4 = other crossings are in flight (its member pass ran a step ago: the generation
+// adds the design matrices up itself)
 static int build_phase2(raftx_ctx *c, int64_t *stripOffsets, hipStream_t sGen = nullptr, int crossing = 0) {
     RangeScope range_("build phase 2: wait for totals, strip tables + statics (enqueue)");
     BuildJob &J = c->job;
@@ -1497,7 +1498,7 @@ static int build_phase2(raftx_ctx *c, int64_t *stripOffsets, hipStream_t sGen = 
     // hidden by the seven other waves of the CU (each is bound by its own dependency chains, not by issue slots).
     const char *fg_ = getenv("RAFTX_FUSED_GEN");          // (read per call: tests switch it inside one process)
     const bool fused_gen = fg_ && atoi(fg_);
-    const bool defer = crossing == 2 && fused_gen && nDesign > 0 && nRows == 0;
+    const bool defer = (crossing & 2) && fused_gen && nDesign > 0 && nRows == 0;
     J.gen_deferred = false;
     // the ABI copy of the strip records (raftx_fetch_strips) is for raftx_build_designs; a sweep crossing never
     // fetches it: 137 MB of stores per 10 000 designs less between two fused kernels (k_geom_design checks the pointer)
@@ -1525,11 +1526,19 @@ static int build_phase2(raftx_ctx *c, int64_t *stripOffsets, hipStream_t sGen = 
         J.gen_deferred = true;
     } else if (nDesign > 0) {
         if (J.reduce_late) hipLaunchKernelGGL(k_geom_reduce, dim3((unsigned)(((size_t)nDesign * 3 + 63) / 64)), dim3(64), 0, sGen, A);
+        // A sweep crossing in flight behind others (its member pass and reductions ran a step ago): the generation adds its
+        // design's matrices up itself -- one kernel and one launch gap less on the path between two fused kernels (same
+        // additions in the same order: bit-identical).  RAFTX_ADDUP_KERNEL=1 keeps k_geom_addup.
+        static const bool addup_kernel = getenv("RAFTX_ADDUP_KERNEL") && atoi(getenv("RAFTX_ADDUP_KERNEL"));
+        A.addup_in_design = ((crossing & 4) && !addup_kernel && nRows == 0 && !A.abi) ? 1 : 0;
+        if (A.addup_in_design && J.reduce_stream) HIPCHK(c, hipStreamWaitEvent(sGen, c->evRed, 0));
         launch_design(c, sGen);
-        // the reductions of phase 1 (side stream) are not waited for until their results are added up: streams share
-        // hardware queues, and a reduction that ended up behind the scan would otherwise hold the generation back
-        if (J.reduce_stream) HIPCHK(c, hipStreamWaitEvent(sGen, c->evRed, 0));
-        hipLaunchKernelGGL(k_geom_addup, dim3((unsigned)(((size_t)nDesign * 36 + 255) / 256)), dim3(256), 0, sGen, A);
+        if (!A.addup_in_design) {
+            // the reductions of phase 1 (side stream) are not waited for until their results are added up: streams share
+            // hardware queues, and a reduction that ended up behind the scan would otherwise hold the generation back
+            if (J.reduce_stream) HIPCHK(c, hipStreamWaitEvent(sGen, c->evRed, 0));
+            hipLaunchKernelGGL(k_geom_addup, dim3((unsigned)(((size_t)nDesign * 36 + 255) / 256)), dim3(256), 0, sGen, A);
+        }
     }
     if (nRows > 0)                                        // after k_geom_design: it leaves (R, Ca) of the MacCamy-Fuchs strips
         hipLaunchKernelGGL(k_geom_mcf, dim3((unsigned)nRows, (unsigned)((nw + 63) / 64)), dim3(64), 0, sGen, A, (int64_t)nRows);
@@ -2230,6 +2239,7 @@ static int solve_enqueue(raftx_ctx *c, int nIter, double tol, double XiStart, co
         gen_fused = persist && lean == 0 && T.nCase == 1 && cls.empty() && !slabbed && c->r_npair == (size_t)T.nDesign && c->r_npair > 0 &&
                     J.nDesign == T.nDesign && J.gen_lds + KP_STASH * sizeof(double) <= LDS_LIMIT / (size_t)wg_per_cu;
         if (!gen_fused) {
+            J.A.addup_in_design = 0;
             launch_design(c, c->stream);
             hipLaunchKernelGGL(k_geom_addup, dim3((unsigned)(((size_t)J.nDesign * 36 + 255) / 256)), dim3(256), 0, c->stream, J.A);
         }
@@ -3679,7 +3689,7 @@ extern "C" int raftx_sweep_launch(raftx_ctx *c, int slot) {
         S.tlb.push_back(since());
         // (a crossing: no ABI copy of the strip records; with RAFTX_FUSED_GEN=1 the tables are left to the fused kernel itself,
         // raftx_fusedgen.h -- build_phase2 / solve_enqueue decide)
-        if (!rc) rc = build_phase2(sub, nullptr, gen_side ? c->sGen : nullptr, (nCase == 1 && !slab_mode) ? 2 : 1);
+        if (!rc) rc = build_phase2(sub, nullptr, gen_side ? c->sGen : nullptr, 1 | ((nCase == 1 && !slab_mode) ? 2 : 0) | (pipelined ? 4 : 0));
         S.tlb.push_back(since());
         // (with the generation inside the fused kernel nothing of this batch runs in the drain any more: the fused kernel
         // follows the one before it at once, and the next batch's member pass takes the places the drain frees beside it;
