@@ -1067,6 +1067,8 @@ __device__ constexpr int DS_SRC[DS_N] = {
 static_assert(DS_MCF == 2 && DS_X == 4 && DS_U == 7 && DS_A == 10 && DS_Q == 13 && DS_P1 == 16 && DS_P2 == 19 &&
               DS_IQ == 22 && DS_DQ == 27 && DS_N == 32, "DS_SRC follows the device record layout");
 #define GD_ROW (NF + 1)      // LDS row stride of a staged record (odd: lane-per-strip column reads are conflict-free)
+#define GD_GM_N 3            // staged columns of a member row: dlsMax, shape, flags
+#define GD_MP_N 13           // staged columns of a member pose: rA, q, p1, p2 (MP_N 3..14), L (19)
 #ifdef GEOM_PHASE_TIMING     // tuning builds: cycles per phase of k_geom_design, summed over its waves (printed at ctx destroy)
 __device__ unsigned long long geom_phase_cycles[10];
 #define GEOM_PHASE(i)                                                                                   \
@@ -1118,14 +1120,16 @@ __device__ __forceinline__ void geom_design_block(const GeomArgs &A, const int d
         // was most of a workgroup's ~20 us on the path between two fused kernels.
         int *ssta = mbase + nMem + 1;                     // [nMem + 1] first station of each member, relative to the design's
         // (okv is 8-byte aligned: an even number of ints from it is too)
-        double *sgm = reinterpret_cast<double *>(okv + (((int)(ssta - okv) + nMem + 2) & ~1));      // [nMem][RAFTX_GM_N]
-        double *sgs = sgm + (size_t)nMem * RAFTX_GM_N;                            // [nSta][RAFTX_GS_N]
-        double *smp = sgs + (size_t)nSta * RAFTX_GS_N;                            // [nMem][MP_N]
+        // Only the columns the generation reads are staged -- of a member row: dlsMax, shape, flags (GD_GM_N); of a pose:
+        // rA, q, p1, p2, L (GD_MP_N) -- which is what lets SIX workgroups share a CU's LDS at the C3 shape instead of five.
+        double *sgm = reinterpret_cast<double *>(okv + (((int)(ssta - okv) + nMem + 2) & ~1));      // [nMem][GD_GM_N]
+        double *sgs = sgm + (size_t)nMem * GD_GM_N;                               // [nSta][RAFTX_GS_N]
+        double *smp = sgs + (size_t)nSta * RAFTX_GS_N;                            // [nMem][GD_MP_N]
         {
             // (the three tables are one contiguous stretch of LDS: a lane's loads of a round -- ten, enough for a design of 16
-            // members and 48 stations -- and its first-station offset are all in flight before the first of them is waited for)
+            // members and 64 stations -- and its first-station offset are all in flight before the first of them is waited for)
             const double *g0 = A.gm + (size_t)m0 * RAFTX_GM_N, *g1 = A.gs + (size_t)s0 * RAFTX_GS_N, *g2 = A.mpose + (size_t)m0 * MP_N;
-            const int n0 = nMem * RAFTX_GM_N, n01 = n0 + nSta * RAFTX_GS_N, total = n01 + nMem * MP_N;
+            const int n0 = nMem * GD_GM_N, n01 = n0 + nSta * RAFTX_GS_N, total = n01 + nMem * GD_MP_N;
             constexpr int SU = 10;
             const int64_t so_lane = lane <= nMem ? A.so(m0 + lane) : s0;
             for (int base = 0; base < total; base += SU * GD_T) {
@@ -1133,7 +1137,16 @@ __device__ __forceinline__ void geom_design_block(const GeomArgs &A, const int d
 #pragma unroll
                 for (int u = 0; u < SU; u++) {
                     const int idx = base + u * GD_T + lane;
-                    const double *src = idx < n0 ? g0 + idx : (idx < n01 ? g1 + (idx - n0) : g2 + (idx - n01));
+                    const double *src;
+                    if (idx < n0) {
+                        const int row = idx / GD_GM_N, col = idx % GD_GM_N;
+                        src = g0 + (size_t)row * RAFTX_GM_N + (col == 0 ? RAFTX_GM_DLSMAX : (col == 1 ? RAFTX_GM_SHAPE : RAFTX_GM_FLAGS));
+                    } else if (idx < n01) {
+                        src = g1 + (idx - n0);
+                    } else {
+                        const int k = idx - n01, row = k / GD_MP_N, col = k % GD_MP_N;
+                        src = g2 + (size_t)row * MP_N + (col < 12 ? 3 + col : 19);
+                    }
                     v[u] = idx < total ? *src : 0.0;
                 }
 #pragma unroll
@@ -1156,7 +1169,7 @@ __device__ __forceinline__ void geom_design_block(const GeomArgs &A, const int d
             if (g > 0 && g < n) {
                 const double *gs = sgs + (size_t)sta0 * RAFTX_GS_N;
                 cntg = geom_interval_strips(gs[(size_t)g * RAFTX_GS_N + RAFTX_GS_S] - gs[(size_t)(g - 1) * RAFTX_GS_N + RAFTX_GS_S],
-                                            sgm[(size_t)mi * RAFTX_GM_N + RAFTX_GM_DLSMAX]);
+                                            sgm[(size_t)mi * GD_GM_N]);
             }
             mcum[sta0 + 2 * mi + g + 1] = cntg;
         }
@@ -1193,17 +1206,17 @@ __device__ __forceinline__ void geom_design_block(const GeomArgs &A, const int d
             const int tt = tq - mbase[mi];
             const int n = ssta[mi + 1] - ssta[mi];
             const int *cum = mcum + ssta[mi] + 2 * mi;
-            const double *gm = sgm + (size_t)mi * RAFTX_GM_N;
+            const double *gm = sgm + (size_t)mi * GD_GM_N;                     // dlsMax, shape, flags
             const double *gs = sgs + (size_t)ssta[mi] * RAFTX_GS_N;
-            const double *mp = smp + (size_t)mi * MP_N;
-            const bool circ = gm[RAFTX_GM_SHAPE] != 0.0;
-            const int flags = (int)gm[RAFTX_GM_FLAGS];
+            const double *mp = smp + (size_t)mi * GD_MP_N;                     // rA, q, p1, p2, L
+            const bool circ = gm[1] != 0.0;
+            const int flags = (int)gm[2];
             const bool potMod = flags & RAFTX_GM_FLAG_POTMOD;
             const bool mcf = (flags & RAFTX_GM_FLAG_MCF) && circ && !potMod;
-            const double L = mp[19];
+            const double L = mp[12];
             double rA[3], rB[3], q[3], p1[3], p2[3], armN[3];
             for (int i = 0; i < 3; i++) {
-                rA[i] = mp[3 + i]; q[i] = mp[6 + i]; p1[i] = mp[9 + i]; p2[i] = mp[12 + i];
+                rA[i] = mp[i]; q[i] = mp[3 + i]; p1[i] = mp[6 + i]; p2[i] = mp[9 + i];
                 rB[i] = rA[i] + L * q[i];
                 armN[i] = rA[i] - rP[i];
             }
@@ -1510,7 +1523,7 @@ static size_t geom_design_lds(int maxS, int maxSta, int maxMem) {
     const size_t S = (size_t)(maxS > 0 ? maxS : 1);
     return sizeof(double) * (S * GD_ROW + 2 * S) + sizeof(int) * (3 * S + (size_t)maxSta + 3 * (size_t)maxMem + 1) + 16 +
            sizeof(int) * ((size_t)maxMem + 4) +                                                           // first stations
-           sizeof(double) * ((size_t)maxMem * (RAFTX_GM_N + MP_N) + (size_t)maxSta * RAFTX_GS_N);        // staged descriptors
+           sizeof(double) * ((size_t)maxMem * (GD_GM_N + GD_MP_N) + (size_t)maxSta * RAFTX_GS_N);        // staged descriptors
 }
 
 __global__ __launch_bounds__(64) void k_geom_reduce(GeomArgs A) {
