@@ -1011,51 +1011,13 @@ def main():
 
     # ---- legs outside the headline (N = 1): SURVEY 8d's literal step (responses downloaded), featured sweeps
     xi_leg = featured = None
-    def run_xi_leg():
-        Xp = [ctx.pinned_empty((nD, 1, 1, 6, nw)) for _ in range(4)]
-
-        def xi_steps(n):
-            # four batches in flight, staged: batch i downloads (3.4-3.6 ms of PCIe: longer than a batch's kernels), batch
-            # i+1 solves, batch i+2 is queued behind it, batch i+3 uploads its descriptors and runs its member pass.
-            # prepare() never waits; launch(i+2) waits for a member pass that ran a step earlier; wait(i) for the download.
-            # (With three in flight -- prepare(i+2) only after wait(i) -- the chain download -> upload -> member pass ->
-            # fused kernel was serial: 5.0-5.1 ms per step, profiles/r04_xi_timeline.txt.)
-            sub = lambda i: sw.prepare_crossing(ctx, i % 4, n_chunk=args.chunks, Xi_out=Xp[i % 4])
-            hs = {i: sub(i) for i in range(min(n, 3))}
-            for i in range(min(n, 2)):
-                sw.launch_crossing(ctx, hs[i])
-            for i in range(n):
-                if i + 3 < n:
-                    hs[i + 3] = sub(i + 3)
-                if i + 2 < n:
-                    sw.launch_crossing(ctx, hs[i + 2])
-                sw.wait_crossing(ctx, hs.pop(i))
-                if os.environ.get("RAFTX_BENCH_DEBUG"):
-                    print("  xi step %d collected at %.3f ms" % (i, 1e3 * time.perf_counter()), file=sys.stderr)
-        xi_steps(9)                                       # untimed: every one of the four slots reaches its steady-state configuration
-        # a streak of 60 batches (or K if larger): with four batches in flight the fill and the drain of the pipeline are
-        # worth two steps (the first batch's upload and kernels, the last batch's download), which a long sweep does not see
-        n_xi = max(args.steps, int(os.environ.get("RAFTX_BENCH_XI_STEPS", "60")))
-        ctx.synchronize()
-        t1 = time.perf_counter()
-        xi_steps(n_xi)
-        ctx.synchronize()
-        t_xi = (time.perf_counter() - t1) / n_xi
-        t1 = time.perf_counter()
-        for _ in range(3):
-            sw.run_crossing(ctx, n_chunk=args.chunks, n_worker=args.workers, Xi_out=Xp[0])
-        t_xi_iso = (time.perf_counter() - t1) / 3
-        for b_ in Xp:
-            assert np.array_equal(b_.view(np.uint64), Xi.reshape(b_.shape).view(np.uint64)), "xi-out leg: responses differ from the checked batch"
-        leg_ = {"state": "xi out: SURVEY 8d's literal step, H2D of the descriptors + kernels + D2H of Xi (%.0f MB per step, "
-                           "page-locked destination)" % (Xp[0].nbytes / 1e6),
-                  "streamed_ms_per_step": 1e3 * t_xi, "streamed_dcf_per_s": nD * nw / t_xi, "streamed_steps": n_xi, "batches_in_flight": 4,
-                  "isolated_ms_per_step": 1e3 * t_xi_iso, "isolated_dcf_per_s": nD * nw / t_xi_iso}
-        for b_ in Xp:
-            ctx.free_pinned(b_)
-        return leg_
+    import types
+    import bench_legs
+    B = types.SimpleNamespace(ctx=ctx, sw=sw, nD=nD, nw=nw, args=args, Xi=Xi, chk=chk, variants=variants, rank=rank, shard=shard,
+                              make_sweep=make_sweep, run_streamed=run_streamed, algorithmic_flops=algorithmic_flops, scale_rows=scale_rows,
+                              G_=G_)                     # what the legs in bench_legs.py read of this run
     if rank == 0 and world == 1 and not args.no_extra_legs and not args.xi_out and "xi" in args.legs:
-        xi_leg = guarded("xi_out", run_xi_leg)
+        xi_leg = guarded("xi_out", lambda: bench_legs.xi_out(B))
         if "error" in xi_leg:                             # a crossing may still be in flight: drain before the next leg
             try:
                 ctx.synchronize()
@@ -1078,42 +1040,8 @@ def main():
     # 66 MB of descriptors re-uploaded (DMA) every step -- no device-side expansion, but a host that can feed only 1 / 14 ms
     hostdesc = None
 
-    def run_hostdesc():
-        sw_h, _, geo_h = make_sweep(ctx, args.designs, rank, pinned=True, rows=shard[rank], variants=False)
-
-        def steps(n):
-            out_ = []
-            h_ = sw_h.submit_crossing(ctx, 0, n_chunk=args.chunks) if n > 0 else None
-            for i in range(n):
-                hn = sw_h.submit_crossing(ctx, (i + 1) % 2, n_chunk=args.chunks) if i + 1 < n else None
-                out_.append(sw_h.wait_crossing(ctx, h_))
-                h_ = hn
-            return out_
-        steps(3)
-        steps(args.warmup)
-        ctx.synchronize()
-        t1 = time.perf_counter()
-        rs = steps(args.steps)
-        ctx.synchronize()
-        dt_ = (time.perf_counter() - t1) / args.steps
-        k_ = float(np.mean([x["timing_ms"][2] for x in rs]))
-        fl_ = float(np.mean([algorithmic_flops(x["strip_off"], nw, x["niter"]) for x in rs]))
-        assert np.array_equal(rs[-1]["std"].view(np.uint64), chk["std"].view(np.uint64)), "host-made and device-made descriptors give different statistics"
-        for name in ("members", "stations", "caps", "member_off", "station_off", "cap_off"):
-            a = getattr(sw_h.tables, name, None)
-            if a is not None and a.size:
-                try:
-                    ctx.free_pinned(a)
-                except ValueError:
-                    pass
-        return {"ms_per_step": 1e3 * dt_, "value": nD * nw / dt_, "kernel_ms_per_step": k_,
-                "roofline_frac": fl_ / (k_ * 1e-3) / 1e12 / FP64_VALU_PEAK_TF, "host_descriptor_ms_per_batch": geo_h["host_descriptor_ms"],
-                "descriptor_bytes_per_step": geo_h["descriptor_bytes"], "statistics_bit_identical_to_device_made_descriptors": True,
-                "note": "the step of rounds 1-4 on this box: the STANDARD batch's descriptors, expanded once by NumPy outside the step, "
-                        "uploaded by DMA in every step (same candidates every step); the headline's step writes them on the device "
-                        "for NEW candidates every step -- ~0.09 ms of stores that land inside the running fused kernel"}
     if variants and rank == 0 and world == 1 and not args.no_extra_legs and not args.xi_out and "hostdesc" in args.legs:
-        hostdesc = guarded("host_descriptors_same_box", run_hostdesc)
+        hostdesc = guarded("host_descriptors_same_box", lambda: bench_legs.host_descriptors(B))
 
     # ---- BASELINE configs[1], [3], [4] at their specified sizes, each against its live-reference golden (N = 1)
     cfg_legs = {}
@@ -1130,26 +1058,7 @@ def main():
     # kernel does when a launch is long enough for that not to matter.
     launch_size = None
     if rank == 0 and world == 1 and not args.no_extra_legs and "launchsize" in args.legs:
-        def run_launch_size():
-            res = {}
-            for n_ in (20000, 40000):
-                sw2, _, _ = make_sweep(ctx, n_, 0, pinned=False)
-                sw2.upload(ctx)
-                ks = []
-                for i in range(4):
-                    ctx.solve_dynamics_device(sw2.nIter, sw2.tol, sw2.XiStart)
-                    if i:
-                        ks.append(ctx.last_kernel_ms())
-                r2 = ctx.fetch_results(want_Xi=False)
-                k2 = float(np.mean(ks))
-                fl2 = algorithmic_flops(sw2.off, nw, r2["niter"])
-                res[str(n_)] = {"pairs_per_launch": n_, "kernel_ms": k2, "us_per_pair": 1e3 * k2 / n_, "mean_iterations": float(np.mean(r2["niter"])),
-                                "dcf_per_s": n_ * nw / (k2 * 1e-3), "fp64_valu_frac": fl2 / (k2 * 1e-3) / 1e12 / FP64_VALU_PEAK_TF}
-                del sw2, r2
-            res["note"] = ("the SAME kernel on launches of 20 000 / 40 000 pairs (resident in, resident out): the drain of the last residency round and the "
-                           "idle of a slot between workgroups weigh less, the clock is a few per cent higher -- T(n) ~ 0.33 ms + 0.251 us n (profiles/r05_launch_size_scaling.json)")
-            return res
-        launch_size = guarded("launch_size", run_launch_size)
+        launch_size = guarded("launch_size", lambda: bench_legs.launch_size(B))
 
     # ---- the shard of BASELINE configs[2]'s strong-scaling shape on ONE GPU: 10 000 designs over 8 ranks = 1 250 per rank
     # (raft/parametersweep.py:39-100).  The same streamed step at 1 250 designs: what one rank of an 8-GPU
@@ -1157,41 +1066,7 @@ def main():
     # (no collective while solving; the gather moves 56 B per design).
     shard_leg = None
     if rank == 0 and world == 1 and not args.no_extra_legs and stream_steps and "shard" in args.legs and nD >= 8:
-        def run_shard():
-            n_sh = max(1, nD // 8)
-            sw_s, _, _ = make_sweep(ctx, n_sh, 0, pinned=not args.pageable, rows=(0, n_sh), variants=variants)
-            d = args.depth
-            bno = {"next": 1}
-
-            def fresh_s():
-                if variants:
-                    b = bno["next"]
-                    bno["next"] += 1
-                    sw_s.set_params(G_.volturnus_params(scale_rows(b * n_sh, (b + 1) * n_sh)))
-
-            def steps_s(n):
-                return run_streamed(sw_s, ctx, n, d, fresh=fresh_s)
-            steps_s(max(12, 2 * d + 1))
-            n_t = max(args.steps, 60)
-            ctx.synchronize()
-            t1 = time.perf_counter()
-            rs = steps_s(n_t)
-            ctx.synchronize()
-            dt_ = (time.perf_counter() - t1) / n_t
-            k_ = float(np.mean([x["timing_ms"][2] for x in rs]))
-            fl_ = float(np.mean([algorithmic_flops(x["strip_off"], nw, x["niter"]) for x in rs]))
-            t10 = elapsed / args.steps
-            return {"designs_per_step": n_sh, "ms_per_step": 1e3 * dt_, "value": n_sh * nw / dt_, "steps": n_t, "kernel_ms_per_launch": k_,
-                    "roofline_frac": fl_ / (k_ * 1e-3) / 1e12 / FP64_VALU_PEAK_TF,
-                    "step_frac": fl_ / dt_ / 1e12 / FP64_VALU_PEAK_TF,
-                    "ms_per_step_of_the_whole_sweep_on_this_gpu": 1e3 * t10,
-                    "projected_8_gpu_strong_speedup": t10 / dt_,
-                    "ideal_ms_per_step": 1e3 * t10 / 8,
-                    "note": "one rank's share of BASELINE configs[2] cut into 8 shards, streamed like the headline step.  1 250 pairs on "
-                            "1 024 resident workgroup places are two residency rounds whatever the launch form (the persistent grid claims "
-                            "them, the second round runs at a quarter of the chip's occupancy): 0.41 us per pair against 0.26 in a long "
-                            "launch -- DESIGN.md 7, profiles/r06_experiments/"}
-        shard_leg = guarded("shard_1250", run_shard)
+        shard_leg = guarded("shard_1250", lambda: bench_legs.shard_1250(B, 1e3 * elapsed / args.steps))
 
     # ---- roofline.traffic: measured in THIS run where rocprofv3 is at hand (N = 1), else the committed profile's figure
     traffic_bytes, traffic_prov = measured_traffic(nD), traffic_provenance()

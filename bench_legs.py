@@ -1,7 +1,8 @@
 """Legs of bench.py outside the headline: BASELINE.json's configs[1], [3] and [4] at their
 specified sizes, each checked against its committed live-reference golden and carrying the roofline of its own dominant
 kernel.  Every function takes the rank's raftx context (and, for the sharded forms, a raft_amd.comm communicator) and
-returns a JSON-ready dict; nothing here touches the oracle.
+returns a JSON-ready dict; nothing here touches the oracle.  At the end: the legs of the C3 headline run itself (responses out,
+host-made descriptors, launch size, the 1 250-design shard), which take bench.py's state as one namespace `B`.
 
 Roofline accounting:
   k_solve_system_rows   one coupled solve of an n = 6 N system with R right-hand sides = n^3/3 complex multiply-adds of the
@@ -271,3 +272,151 @@ def flex_sweep(ctx, n_unit=16):
                          "algorithmic_flops": float(flops), "note": "n^3/3 + n^2 complex multiply-adds per solve (the pivoted LU's count; the kernel is a Gauss-Jordan sweep: n^3)"},
             "max_rel_err_vs_dropin": float(err), "rel_err_vs_reference": err_ref, "iterations": [int(x) for x in out["niter"][0]],
             "reference_numpy_s_per_case_build_container": float(fx["cases"][0].get("ref_seconds", float("nan")))}
+
+
+# ---------------------------------------------------------------- legs of the C3 headline run (bench.py hands over its state `B`)
+def xi_out(B):
+    """SURVEY 8d's literal step on one GPU: the responses Xi downloaded inside the step (192 MB per 10 000 designs), four
+    batches in flight through the staged calls, and the same step as isolated blocking calls."""
+    import os
+    import sys
+    Xp = [B.ctx.pinned_empty((B.nD, 1, 1, 6, B.nw)) for _ in range(4)]
+
+    def xi_steps(n):
+        # four batches in flight, staged: batch i downloads (3.4-3.6 ms of PCIe: longer than a batch's kernels), batch
+        # i+1 solves, batch i+2 is queued behind it, batch i+3 uploads its descriptors and runs its member pass.
+        # prepare() never waits; launch(i+2) waits for a member pass that ran a step earlier; wait(i) for the download.
+        # (With three in flight -- prepare(i+2) only after wait(i) -- the chain download -> upload -> member pass ->
+        # fused kernel was serial: 5.0-5.1 ms per step, profiles/r04_xi_timeline.txt.)
+        sub = lambda i: B.sw.prepare_crossing(B.ctx, i % 4, n_chunk=B.args.chunks, Xi_out=Xp[i % 4])
+        hs = {i: sub(i) for i in range(min(n, 3))}
+        for i in range(min(n, 2)):
+            B.sw.launch_crossing(B.ctx, hs[i])
+        for i in range(n):
+            if i + 3 < n:
+                hs[i + 3] = sub(i + 3)
+            if i + 2 < n:
+                B.sw.launch_crossing(B.ctx, hs[i + 2])
+            B.sw.wait_crossing(B.ctx, hs.pop(i))
+            if os.environ.get("RAFTX_BENCH_DEBUG"):
+                print("  xi step %d collected at %.3f ms" % (i, 1e3 * time.perf_counter()), file=sys.stderr)
+    xi_steps(9)                                       # untimed: every one of the four slots reaches its steady-state configuration
+    # a streak of 60 batches (or K if larger): with four batches in flight the fill and the drain of the pipeline are
+    # worth two steps (the first batch's upload and kernels, the last batch's download), which a long sweep does not see
+    n_xi = max(B.args.steps, int(os.environ.get("RAFTX_BENCH_XI_STEPS", "60")))
+    B.ctx.synchronize()
+    t1 = time.perf_counter()
+    xi_steps(n_xi)
+    B.ctx.synchronize()
+    t_xi = (time.perf_counter() - t1) / n_xi
+    t1 = time.perf_counter()
+    for _ in range(3):
+        B.sw.run_crossing(B.ctx, n_chunk=B.args.chunks, n_worker=B.args.workers, Xi_out=Xp[0])
+    t_xi_iso = (time.perf_counter() - t1) / 3
+    for b_ in Xp:
+        assert np.array_equal(b_.view(np.uint64), B.Xi.reshape(b_.shape).view(np.uint64)), "xi-out leg: responses differ from the checked batch"
+    leg_ = {"state": "xi out: SURVEY 8d's literal step, H2D of the descriptors + kernels + D2H of Xi (%.0f MB per step, "
+                       "page-locked destination)" % (Xp[0].nbytes / 1e6),
+              "streamed_ms_per_step": 1e3 * t_xi, "streamed_dcf_per_s": B.nD * B.nw / t_xi, "streamed_steps": n_xi, "batches_in_flight": 4,
+              "isolated_ms_per_step": 1e3 * t_xi_iso, "isolated_dcf_per_s": B.nD * B.nw / t_xi_iso}
+    for b_ in Xp:
+        B.ctx.free_pinned(b_)
+    return leg_
+
+
+def host_descriptors(B):
+    """The rounds-1-4 form of the step on the same box: ONE batch expanded by NumPy outside the step, its 66 MB of descriptors
+    uploaded by DMA in every step (no device-side expansion)."""
+    sw_h, _, geo_h = B.make_sweep(B.ctx, B.args.designs, B.rank, pinned=True, rows=B.shard[B.rank], variants=False)
+
+    def steps(n):
+        out_ = []
+        h_ = sw_h.submit_crossing(B.ctx, 0, n_chunk=B.args.chunks) if n > 0 else None
+        for i in range(n):
+            hn = sw_h.submit_crossing(B.ctx, (i + 1) % 2, n_chunk=B.args.chunks) if i + 1 < n else None
+            out_.append(sw_h.wait_crossing(B.ctx, h_))
+            h_ = hn
+        return out_
+    steps(3)
+    steps(B.args.warmup)
+    B.ctx.synchronize()
+    t1 = time.perf_counter()
+    rs = steps(B.args.steps)
+    B.ctx.synchronize()
+    dt_ = (time.perf_counter() - t1) / B.args.steps
+    k_ = float(np.mean([x["timing_ms"][2] for x in rs]))
+    fl_ = float(np.mean([B.algorithmic_flops(x["strip_off"], B.nw, x["niter"]) for x in rs]))
+    assert np.array_equal(rs[-1]["std"].view(np.uint64), B.chk["std"].view(np.uint64)), "host-made and device-made descriptors give different statistics"
+    for name in ("members", "stations", "caps", "member_off", "station_off", "cap_off"):
+        a = getattr(sw_h.tables, name, None)
+        if a is not None and a.size:
+            try:
+                B.ctx.free_pinned(a)
+            except ValueError:
+                pass
+    return {"ms_per_step": 1e3 * dt_, "value": B.nD * B.nw / dt_, "kernel_ms_per_step": k_,
+            "roofline_frac": fl_ / (k_ * 1e-3) / 1e12 / FP64_VALU_PEAK_TF, "host_descriptor_ms_per_batch": geo_h["host_descriptor_ms"],
+            "descriptor_bytes_per_step": geo_h["descriptor_bytes"], "statistics_bit_identical_to_device_made_descriptors": True,
+            "note": "the step of rounds 1-4 on this box: the STANDARD batch's descriptors, expanded once by NumPy outside the step, "
+                    "uploaded by DMA in every step (same candidates every step); the headline's step writes them on the device "
+                    "for NEW candidates every step -- ~0.09 ms of stores that land inside the running fused kernel"}
+
+
+def launch_size(B):
+    """The fused kernel against the size of its launch: the same designs' stream, 20 000 and 40 000 pairs resident."""
+    res = {}
+    for n_ in (20000, 40000):
+        sw2, _, _ = B.make_sweep(B.ctx, n_, 0, pinned=False)
+        sw2.upload(B.ctx)
+        ks = []
+        for i in range(4):
+            B.ctx.solve_dynamics_device(sw2.nIter, sw2.tol, sw2.XiStart)
+            if i:
+                ks.append(B.ctx.last_kernel_ms())
+        r2 = B.ctx.fetch_results(want_Xi=False)
+        k2 = float(np.mean(ks))
+        fl2 = B.algorithmic_flops(sw2.off, B.nw, r2["niter"])
+        res[str(n_)] = {"pairs_per_launch": n_, "kernel_ms": k2, "us_per_pair": 1e3 * k2 / n_, "mean_iterations": float(np.mean(r2["niter"])),
+                        "dcf_per_s": n_ * B.nw / (k2 * 1e-3), "fp64_valu_frac": fl2 / (k2 * 1e-3) / 1e12 / FP64_VALU_PEAK_TF}
+        del sw2, r2
+    res["note"] = ("the SAME kernel on launches of 20 000 / 40 000 pairs (resident in, resident out): the drain of the last residency round and the "
+                   "idle of a slot between workgroups weigh less, the clock is a few per cent higher -- T(n) ~ 0.33 ms + 0.251 us n (profiles/r05_launch_size_scaling.json)")
+    return res
+
+
+def shard_1250(B, ms_whole_sweep):
+    """One rank's share of BASELINE configs[2] cut into 8 shards (raft/parametersweep.py:39-100): the streamed step at
+    nD / 8 designs on ONE GPU; ms_whole_sweep = this run's step of the whole sweep, in ms."""
+    n_sh = max(1, B.nD // 8)
+    sw_s, _, _ = B.make_sweep(B.ctx, n_sh, 0, pinned=not B.args.pageable, rows=(0, n_sh), variants=B.variants)
+    d = B.args.depth
+    bno = {"next": 1}
+
+    def fresh_s():
+        if B.variants:
+            b = bno["next"]
+            bno["next"] += 1
+            sw_s.set_params(B.G_.volturnus_params(B.scale_rows(b * n_sh, (b + 1) * n_sh)))
+
+    def steps_s(n):
+        return B.run_streamed(sw_s, B.ctx, n, d, fresh=fresh_s)
+    steps_s(max(12, 2 * d + 1))
+    n_t = max(B.args.steps, 60)
+    B.ctx.synchronize()
+    t1 = time.perf_counter()
+    rs = steps_s(n_t)
+    B.ctx.synchronize()
+    dt_ = (time.perf_counter() - t1) / n_t
+    k_ = float(np.mean([x["timing_ms"][2] for x in rs]))
+    fl_ = float(np.mean([B.algorithmic_flops(x["strip_off"], B.nw, x["niter"]) for x in rs]))
+    t10 = ms_whole_sweep * 1e-3
+    return {"designs_per_step": n_sh, "ms_per_step": 1e3 * dt_, "value": n_sh * B.nw / dt_, "steps": n_t, "kernel_ms_per_launch": k_,
+            "roofline_frac": fl_ / (k_ * 1e-3) / 1e12 / FP64_VALU_PEAK_TF,
+            "step_frac": fl_ / dt_ / 1e12 / FP64_VALU_PEAK_TF,
+            "ms_per_step_of_the_whole_sweep_on_this_gpu": 1e3 * t10,
+            "projected_8_gpu_strong_speedup": t10 / dt_,
+            "ideal_ms_per_step": 1e3 * t10 / 8,
+            "note": "one rank's share of BASELINE configs[2] cut into 8 shards, streamed like the headline step.  1 250 pairs on "
+                    "1 024 resident workgroup places are two residency rounds whatever the launch form (the persistent grid claims "
+                    "them, the second round runs at a quarter of the chip's occupancy): 0.41 us per pair against 0.26 in a long "
+                    "launch -- DESIGN.md 7, profiles/r06_experiments/"}
