@@ -627,7 +627,10 @@ class Engine:
         solveDynamics): platform motions, nacelle accelerations and the tower-base bending moment -- every
         getRMS / getPSD of the method -- are ONE statistics launch over the resident responses
         (raftx_channel_stats_poly); means, +-3 sigma bounds and the response amplitudes are host scalars / views.
-        Mooring-tension and rotor-controller blocks need MoorPy / CCBlade state and are outside the device path."""
+        Quasi-static mooring tensions (moorMod == 0, :2356-2399) ride on the same launch: the tension Jacobian and the mean
+        tensions are asked of the unit's MoorPy system on the host (third-party input, a dense [2 nLines, 6] matrix), the
+        amplitudes J Xi and their statistics are channels of the device.  Line-dynamics tensions (moorMod != 0: MoorPy's
+        own frequency-domain line solver per line) and rotor-controller blocks (CCBlade state) stay outside."""
         if _general(fowt):
             if getattr(self, "_general_solved", None) is not fowt:
                 raise UnsupportedFOWT("saveTurbineOutputs: this engine has not solved this FOWT (call solveDynamics of its "
@@ -636,8 +639,21 @@ class Engine:
         if getattr(self, "_resident", None) is not fowt:
             raise UnsupportedFOWT("saveTurbineOutputs: the responses of this FOWT are not resident on the device "
                                   "(call solveDynamics of its single-unit model first)")
+        J_moor = T_moor = None
         if getattr(fowt, "ms", None):
-            raise UnsupportedFOWT("saveTurbineOutputs: mooring-tension outputs need the MoorPy system (raft_fowt.py:2358-2399)")
+            if getattr(fowt, "moorMod", 0) != 0:
+                raise UnsupportedFOWT("saveTurbineOutputs: line-dynamics mooring tensions (moorMod != 0, raft_fowt.py:2374-2387: "
+                                      "MoorPy's dynamicSolve per line) are not on the device path")
+            try:                                                             # composite lines -> subsystems, as :2358 does
+                from moorpy.helpers import lines2ss
+                fowt.ms = lines2ss(fowt.ms)
+            except ImportError:                                              # (a stand-in system without MoorPy: nothing to convert)
+                pass
+            _, J_moor = fowt.ms.getCoupledStiffness(lines_only=True, tensions=True)      # :2363
+            J_moor = np.asarray(J_moor, dtype=float)
+            T_moor = np.asarray(fowt.ms.getTensions(), dtype=float)                      # :2364, mean line-end tensions
+            if J_moor.shape != (2 * len(fowt.ms.lineList), 6) or T_moor.shape != (J_moor.shape[0],):
+                raise UnsupportedFOWT("saveTurbineOutputs: the mooring system's tension Jacobian is not [2 nLines, 6]")
         if any(getattr(rot, "aeroServoMod", 0) > 1 for rot in fowt.rotorList):
             raise UnsupportedFOWT("saveTurbineOutputs: rotor-controller outputs (raft_fowt.py:2640-2680) are not on the device path")
         if np.any(np.abs(np.asarray(fowt.rigidBodyNode.r0[:3], dtype=float)) > 0):
@@ -645,8 +661,11 @@ class Engine:
         nr, nw = int(fowt.nrotors), fowt.nw
         deg = 57.29577951308232                                              # helpers.rad2deg
         Lt, Gt, info = tower_base_rows(fowt)
-        nCh = 6 + 4 * nr
+        nT = 0 if J_moor is None else J_moor.shape[0]
+        nCh = 6 + 4 * nr + nT
         L = np.zeros((nCh, 3, 6))
+        if nT:
+            L[6 + 4 * nr:, 0, :] = J_moor                                    # tension amplitudes J Xi_PRP (:2367)
         for j in range(6):
             L[j, 0, j] = 1.0 if j < 3 else deg                               # motions; rotations in degrees (:2332-2354)
         for ir, rotor in enumerate(fowt.rotorList):
@@ -656,7 +675,7 @@ class Engine:
         Gw = None
         if Gt is not None:
             Gw = np.zeros((nCh, 6, nw), dtype=complex)
-            Gw[6 + 3 * nr:] = Gt
+            Gw[6 + 3 * nr:6 + 4 * nr] = Gt
         std, psd = self.ctx.channel_stats_poly(L, fowt.dw, Gw=Gw, want_psd=True)
         std, psd = std[0, 0], psd[0, 0]
         Xi0 = np.asarray(fowt.r6, dtype=float) - np.array([fowt.x_ref, fowt.y_ref, 0, 0, 0, 0])
@@ -696,6 +715,13 @@ class Engine:
             results["Mbase_PSD"][:, ir] = psd[c]
             results["Mbase_max"][ir] = results["Mbase_avg"][ir] + 3 * std[c]
             results["Mbase_min"][ir] = results["Mbase_avg"][ir] - 3 * std[c]
+        if nT:
+            c0 = 6 + 4 * nr
+            results["Tmoor_avg"] = T_moor
+            results["Tmoor_std"] = std[c0:c0 + nT].copy()
+            results["Tmoor_max"] = T_moor + 3 * std[c0:c0 + nT]
+            results["Tmoor_min"] = T_moor - 3 * std[c0:c0 + nT]
+            results["Tmoor_PSD"] = psd[c0:c0 + nT] * (fowt.dw / fowt.w[0])   # (sic) getPSD(.., self.w[0]), :2372,2399
         zeta = np.asarray(fowt.zeta)
         results["wave_PSD"] = np.sum(0.5 * np.abs(zeta) ** 2 / fowt.dw, axis=0)                       # getPSD(zeta, dw)
         for key in ("omega", "torque", "bPitch"):

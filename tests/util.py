@@ -113,6 +113,26 @@ class FakeLines:
         return M, A, B, C
 
 
+class FakeStaticLines:
+    """Stand-in for the MoorPy system of a quasi-static (``moorMod == 0``) unit in FOWT.saveTurbineOutputs
+    (raft_fowt.py:2356-2399): the two calls the method makes -- the coupled stiffness with the tension Jacobian
+    [2 nLines, 6] and the mean line-end tensions -- and a line list of the right length."""
+
+    def __init__(self, n_lines=3, seed=3):
+        rng = np.random.default_rng(seed)
+        self.lineList = [object() for _ in range(n_lines)]
+        self.J = rng.uniform(-1.0, 1.0, (2 * n_lines, 6)) * np.array([4e4, 4e4, 9e4, 2e5, 2e5, 5e4])
+        self.T = rng.uniform(1.5e6, 2.5e6, 2 * n_lines)
+        self.C = np.diag([7e4, 7e4, 0.0, 0.0, 0.0, 1e8])
+
+    def getCoupledStiffness(self, lines_only=True, tensions=False):
+        assert lines_only
+        return (self.C.copy(), self.J.copy()) if tensions else self.C.copy()
+
+    def getTensions(self):
+        return self.T.copy()
+
+
 def attach_fake_lines(model):
     for f in model.fowtList:
         if not hasattr(f, "nodeList"):                      # stand-in units (raft_amd/snapshot.py): PRP-referred rigid body
