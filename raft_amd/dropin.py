@@ -70,6 +70,28 @@ def _real_times_complex(T, X):
     return np.ascontiguousarray(Y).view(np.complex128)
 
 
+def _quasi_static_tension_rows(fowt):
+    """(J_moor [2 nLines, 6], T_moor [2 nLines]) of a unit's MoorPy system for the quasi-static tension block of
+    FOWT.saveTurbineOutputs (raft_fowt.py:2356-2399), or (None, None) without one.  Host calls into the third-party system, as
+    upstream makes them; line dynamics (moorMod != 0) is MoorPy's own frequency-domain line solver and stays upstream."""
+    if not getattr(fowt, "ms", None):
+        return None, None
+    if getattr(fowt, "moorMod", 0) != 0:
+        raise UnsupportedFOWT("saveTurbineOutputs: line-dynamics mooring tensions (moorMod != 0, raft_fowt.py:2374-2387: "
+                              "MoorPy's dynamicSolve per line) are not on the device path")
+    try:                                                                     # composite lines -> subsystems, as :2358 does
+        from moorpy.helpers import lines2ss
+        fowt.ms = lines2ss(fowt.ms)
+    except ImportError:                                                      # (a stand-in system without MoorPy: nothing to convert)
+        pass
+    _, J = fowt.ms.getCoupledStiffness(lines_only=True, tensions=True)       # :2363
+    J = np.asarray(J, dtype=float)
+    Tm = np.asarray(fowt.ms.getTensions(), dtype=float)                      # :2364, mean line-end tensions
+    if J.shape != (2 * len(fowt.ms.lineList), 6) or Tm.shape != (J.shape[0],):
+        raise UnsupportedFOWT("saveTurbineOutputs: the mooring system's tension Jacobian is not [2 nLines, 6]")
+    return J, Tm
+
+
 class Engine:
     """Binds the host mirror to one raftx context (default: the HIP library)."""
 
@@ -639,21 +661,7 @@ class Engine:
         if getattr(self, "_resident", None) is not fowt:
             raise UnsupportedFOWT("saveTurbineOutputs: the responses of this FOWT are not resident on the device "
                                   "(call solveDynamics of its single-unit model first)")
-        J_moor = T_moor = None
-        if getattr(fowt, "ms", None):
-            if getattr(fowt, "moorMod", 0) != 0:
-                raise UnsupportedFOWT("saveTurbineOutputs: line-dynamics mooring tensions (moorMod != 0, raft_fowt.py:2374-2387: "
-                                      "MoorPy's dynamicSolve per line) are not on the device path")
-            try:                                                             # composite lines -> subsystems, as :2358 does
-                from moorpy.helpers import lines2ss
-                fowt.ms = lines2ss(fowt.ms)
-            except ImportError:                                              # (a stand-in system without MoorPy: nothing to convert)
-                pass
-            _, J_moor = fowt.ms.getCoupledStiffness(lines_only=True, tensions=True)      # :2363
-            J_moor = np.asarray(J_moor, dtype=float)
-            T_moor = np.asarray(fowt.ms.getTensions(), dtype=float)                      # :2364, mean line-end tensions
-            if J_moor.shape != (2 * len(fowt.ms.lineList), 6) or T_moor.shape != (J_moor.shape[0],):
-                raise UnsupportedFOWT("saveTurbineOutputs: the mooring system's tension Jacobian is not [2 nLines, 6]")
+        J_moor, T_moor = _quasi_static_tension_rows(fowt)
         if any(getattr(rot, "aeroServoMod", 0) > 1 for rot in fowt.rotorList):
             raise UnsupportedFOWT("saveTurbineOutputs: rotor-controller outputs (raft_fowt.py:2640-2680) are not on the device path")
         if np.any(np.abs(np.asarray(fowt.rigidBodyNode.r0[:3], dtype=float)) > 0):
@@ -717,11 +725,7 @@ class Engine:
             results["Mbase_min"][ir] = results["Mbase_avg"][ir] - 3 * std[c]
         if nT:
             c0 = 6 + 4 * nr
-            results["Tmoor_avg"] = T_moor
-            results["Tmoor_std"] = std[c0:c0 + nT].copy()
-            results["Tmoor_max"] = T_moor + 3 * std[c0:c0 + nT]
-            results["Tmoor_min"] = T_moor - 3 * std[c0:c0 + nT]
-            results["Tmoor_PSD"] = psd[c0:c0 + nT] * (fowt.dw / fowt.w[0])   # (sic) getPSD(.., self.w[0]), :2372,2399
+            self._put_tensions(results, T_moor, std[c0:c0 + nT], psd[c0:c0 + nT], fowt)
         zeta = np.asarray(fowt.zeta)
         results["wave_PSD"] = np.sum(0.5 * np.abs(zeta) ** 2 / fowt.dw, axis=0)                       # getPSD(zeta, dw)
         for key in ("omega", "torque", "bPitch"):
@@ -732,15 +736,23 @@ class Engine:
             results[key] = np.zeros(nr)
         return results
 
+    @staticmethod
+    def _put_tensions(results, T_moor, std_t, psd_t, fowt):
+        results["Tmoor_avg"] = T_moor
+        results["Tmoor_std"] = np.array(std_t)
+        results["Tmoor_max"] = T_moor + 3 * np.asarray(std_t)
+        results["Tmoor_min"] = T_moor - 3 * np.asarray(std_t)
+        results["Tmoor_PSD"] = np.asarray(psd_t) * (fowt.dw / fowt.w[0])    # (sic) getPSD(.., self.w[0]), raft_fowt.py:2372,2399
+
     def _save_outputs_general(self, fowt, results, case):
         """raft_fowt.py:2291-2745 for a single unit with MORE than six reduced DOFs (flexible members): every getRMS /
         getPSD of the method is a linear channel of the reduced response through the rows of T -- PRP motions from the
         rigid-body node (:2299-2355), hub accelerations (:2422-2444) and the tower-base loads: the finite-element
         internal loads -Kf Xi_internal at the base node of a FLEXIBLE tower (:2540-2601), the fore-aft moment formula
         (:2500-2537) of a rigid one -- ONE statistics launch over the response the solve returned
-        (raftx_response_stats).  Means and +-3 sigma bounds are host scalars."""
-        if getattr(fowt, "ms", None):
-            raise UnsupportedFOWT("saveTurbineOutputs: mooring-tension outputs need the MoorPy system (raft_fowt.py:2358-2399)")
+        (raftx_response_stats).  Means and +-3 sigma bounds are host scalars.  Quasi-static mooring tensions (:2356-2399) are
+        rows J_moor over the PRP motion rows."""
+        J_moor, T_moor = _quasi_static_tension_rows(fowt)
         if any(getattr(rot, "aeroServoMod", 0) > 1 for rot in fowt.rotorList):
             raise UnsupportedFOWT("saveTurbineOutputs: rotor-controller outputs (raft_fowt.py:2640-2680) are not on the device path")
         missing = [a for a in ("rigidBodyNode", "memberList", "rotorList", "T", "r6", "nplatmems") if not hasattr(fowt, a)]
@@ -770,6 +782,11 @@ class Engine:
             ch_motion.append(full_row(0, [i0 + j, i0 + 3, i0 + 4, i0 + 5], [1.0, A[j, 0], A[j, 1], A[j, 2]]))
         for j in range(3, 6):
             ch_motion.append(full_row(0, [i0 + j], [deg]))
+        ch_tens = []                                                         # tensions J Xi_PRP (:2367), rotations in radians
+        if J_moor is not None:
+            for Ji in J_moor:
+                rot = Ji[:3] @ A + Ji[3:]
+                ch_tens.append(full_row(0, [i0, i0 + 1, i0 + 2, i0 + 3, i0 + 4, i0 + 5], [Ji[0], Ji[1], Ji[2], rot[0], rot[1], rot[2]]))
         ch_acc = []                                                          # hub accelerations: w^2 x (:2422-2444)
         for rotor in fowt.rotorList:
             h0 = int(rotor.nodeList[0].id) * 6
@@ -822,6 +839,8 @@ class Engine:
             results[name + "_min"] = avg - 3 * std[c]
             results[name + "_PSD"] = psd[c].copy()
             results[name + "_RA"] = Xi_prp[:, j, :]
+        if ch_tens:
+            self._put_tensions(results, T_moor, std[ch_tens], psd[ch_tens], fowt)
         for ax_i, ax in enumerate("xyz"):
             key = "A%sRNA" % ax
             for suffix in ("std", "avg", "max", "min"):

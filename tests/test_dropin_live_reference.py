@@ -177,6 +177,22 @@ def test_saveTurbineOutputs_statistics_equal_reference(oracle_ctx, headings):
         dropin.Engine(oracle_ctx).saveTurbineOutputs(m2.fowtList[0], {}, case)      # nothing resident for that engine
 
 
+@contextlib.contextmanager
+def _identity_lines2ss():
+    """MoorPy's composite-line conversion as the identity, in the live reference module and in the harness's stand-in
+    ``moorpy.helpers`` (whose functions raise): what both sides of a test with a stand-in line system call."""
+    import sys
+    rh.import_raft()
+    import raft.raft_fowt as rf
+    mph = sys.modules["moorpy.helpers"]
+    saved = rf.lines2ss, mph.lines2ss
+    rf.lines2ss = mph.lines2ss = lambda ms: ms
+    try:
+        yield
+    finally:
+        rf.lines2ss, mph.lines2ss = saved
+
+
 def test_saveTurbineOutputs_quasi_static_mooring_tensions(oracle_ctx):
     """VERDICT r5 missing 7, the quasi-static half: the mooring-tension block of FOWT.saveTurbineOutputs (raft_fowt.py:2356-2399,
     moorMod == 0) -- tension amplitudes J Xi per heading and bin, their getRMS / getPSD (with the reference's own ``w[0]`` in place
@@ -186,19 +202,13 @@ def test_saveTurbineOutputs_quasi_static_mooring_tensions(oracle_ctx):
     import io
     from raft_amd import dropin
     from tests.util import FakeStaticLines
-    raft = rh.import_raft()
-    import raft.raft_fowt as rf
     with contextlib.redirect_stdout(io.StringIO()):
         m = _model("examples/VolturnUS-S_example.yaml", dict(min_freq=0.01, max_freq=0.3))
         m2 = _model("examples/VolturnUS-S_example.yaml", dict(min_freq=0.01, max_freq=0.3))
     case = rh.make_case(Hs=4.0, Tp=9.0, heading=20.0)
     case.update(wave_heading=[20.0, -60.0], wave_spectrum=["JONSWAP", "JONSWAP"], wave_period=[9.0, 13.0], wave_height=[4.0, 2.0],
                 wave_gamma=[0, 0])
-    import sys
-    mph = sys.modules["moorpy.helpers"]                                       # (the harness's stand-in module: its lines2ss raises)
-    saved = rf.lines2ss, mph.lines2ss
-    rf.lines2ss = mph.lines2ss = lambda ms: ms
-    try:
+    with _identity_lines2ss():
         with contextlib.redirect_stdout(io.StringIO()):
             m.solveDynamics(copy.deepcopy(case))
             m.fowtList[0].ms = FakeStaticLines()
@@ -208,8 +218,6 @@ def test_saveTurbineOutputs_quasi_static_mooring_tensions(oracle_ctx):
         eng.solveDynamics(m2, copy.deepcopy(case))
         m2.fowtList[0].ms = FakeStaticLines()
         got = eng.saveTurbineOutputs(m2.fowtList[0], {}, copy.deepcopy(case))
-    finally:
-        rf.lines2ss, mph.lines2ss = saved
     for key in ("Tmoor_avg", "Tmoor_std", "Tmoor_max", "Tmoor_min", "Tmoor_PSD"):
         a, b = np.asarray(got[key]), np.asarray(ref[key])
         assert a.shape == b.shape, key
@@ -243,6 +251,7 @@ def test_saveTurbineOutputs_of_the_flexible_deck(oracle_ctx):
             f.C_moor = cm
     assert m.fowtList[0].nDOF > 6 and m.fowtList[0].memberList[m.fowtList[0].nplatmems].type != "rigid"
     case = rh.make_case(Hs=[5.0, 2.5], Tp=[11.0, 8.0], heading=[25.0, -40.0], spectrum=["JONSWAP"] * 2, gamma=[0, 0])
+    from tests.util import FakeStaticLines
     with contextlib.redirect_stdout(io.StringIO()):
         m.solveDynamics(copy.deepcopy(case))
         ref = {}
@@ -262,6 +271,19 @@ def test_saveTurbineOutputs_of_the_flexible_deck(oracle_ctx):
     assert np.array_equal(got["Mbase_std"], got["MbaseY_std"])
     missing = set(ref) - set(got)
     assert all(k.startswith(("Tmoor", "wind_PSD", "cavitation")) for k in missing), missing
+    # ... and with a quasi-static line system on the unit: the tension block (:2356-2399) over the PRP motions of the rigid-body node
+    with _identity_lines2ss():
+        m.fowtList[0].ms = FakeStaticLines(seed=9)
+        m2.fowtList[0].ms = FakeStaticLines(seed=9)
+        with contextlib.redirect_stdout(io.StringIO()):
+            ref2 = {}
+            m.fowtList[0].saveTurbineOutputs(ref2, copy.deepcopy(case))
+        got2 = eng.saveTurbineOutputs(m2.fowtList[0], {}, copy.deepcopy(case))
+    for key in ("Tmoor_avg", "Tmoor_std", "Tmoor_max", "Tmoor_min", "Tmoor_PSD"):
+        a, b = np.asarray(got2[key]), np.asarray(ref2[key])
+        assert a.shape == b.shape and np.max(np.abs(a - b)) <= 1e-7 * np.max(np.abs(b)), key
+    assert np.all(got2["Tmoor_std"] > 1e3)
+    m.fowtList[0].ms = m2.fowtList[0].ms = None
     with pytest.raises(dropin.UnsupportedFOWT):
         dropin.Engine(oracle_ctx).saveTurbineOutputs(m2.fowtList[0], {}, case)      # an engine that has not solved this unit
 
