@@ -1315,24 +1315,30 @@ __device__ __forceinline__ void geom_design_block(const GeomArgs &A, const int d
     __syncthreads();
     GEOM_PHASE(2);
     // ---- run detection (derive_design_tables, same expressions and order; see there for the rules)
+    // (both rows' fields are read up front, unconditionally -- strip 0 reads itself as its predecessor -- so that the LDS reads
+    // of a strip are in flight together instead of one per branch)
     for (int t = lane; t < S; t += GD_T) {
         bool pass = false;
         double pj = 0.0;
+        const double *pr = rec + (size_t)(t > 0 ? t - 1 : 0) * GD_ROW, *cr = rec + (size_t)t * GD_ROW;
+        double pq[3], cq[3], px[3], cx[3];
+        for (int j = 0; j < 3; j++) {
+            pq[j] = pr[RAFTX_F_Q + j]; cq[j] = cr[RAFTX_F_Q + j]; px[j] = pr[RAFTX_F_X + j]; cx[j] = cr[RAFTX_F_X + j];
+        }
         if (t > 0) {
-            const double *pr = rec + (size_t)(t - 1) * GD_ROW, *cr = rec + (size_t)t * GD_ROW;
             bool same = true;
             double dv[3];
             for (int j = 0; j < 3; j++) {
-                same = same && (pr[RAFTX_F_Q + j] == cr[RAFTX_F_Q + j]);
-                dv[j] = cr[RAFTX_F_X + j] - pr[RAFTX_F_X + j];
-                pj += dv[j] * cr[RAFTX_F_Q + j];
+                same = same && (pq[j] == cq[j]);
+                dv[j] = cx[j] - px[j];
+                pj += dv[j] * cq[j];
             }
             if (same && (pj > 0.0) && (fabs(pj) <= 1.797e308)) {
                 double perp2 = 0.0, scale = 1.0;
                 for (int j = 0; j < 3; j++) {
-                    double tt = dv[j] - pj * cr[RAFTX_F_Q + j];
+                    double tt = dv[j] - pj * cq[j];
                     perp2 += tt * tt;
-                    scale += fabs(cr[RAFTX_F_X + j]);
+                    scale += fabs(cx[j]);
                 }
                 pass = !(sqrt(perp2) > 1e-10 * scale);
             }
@@ -1383,35 +1389,42 @@ __device__ __forceinline__ void geom_design_block(const GeomArgs &A, const int d
     for (int t = lane; t < S; t += GD_T) {
         const int s = rsv[t];
         const double unit = unv[s];
-        const double *cr = rec + (size_t)t * GD_ROW;
+        const double *cr = rec + (size_t)t * GD_ROW, *pr = rec + (size_t)(t > 0 ? t - 1 : 0) * GD_ROW;
+        // (the same: the two rows' fields up front)
+        double cX[3], cQ[3], cP1[3], cP2[3], cA[3], pX[3], pP1[3], pP2[3], pA[3];
+        for (int j = 0; j < 3; j++) {
+            cX[j] = cr[RAFTX_F_X + j]; cQ[j] = cr[RAFTX_F_Q + j]; cP1[j] = cr[RAFTX_F_P1 + j]; cP2[j] = cr[RAFTX_F_P2 + j];
+            cA[j] = cr[RAFTX_F_AX + j];
+            pX[j] = pr[RAFTX_F_X + j]; pP1[j] = pr[RAFTX_F_P1 + j]; pP2[j] = pr[RAFTX_F_P2 + j]; pA[j] = pr[RAFTX_F_AX + j];
+        }
+        const double cCirc = cr[RAFTX_F_CIRC], cMcf = cr[RAFTX_F_MCF], pCirc = pr[RAFTX_F_CIRC], pMcf = pr[RAFTX_F_MCF];
+        const double pjt = pjv[t];
         int m = 0;
         if (t > s && unit > 0.0) {
-            double ratio = pjv[t] / unit;
+            double ratio = pjt / unit;
             int mi = (int)floor(ratio + 0.5);
             if (mi >= 1 && mi <= 2 && fabs(ratio - mi) < 1e-9) {
-                const double *pr = cr - GD_ROW;
                 bool ok = true;
                 for (int j = 0; j < 3; j++) {
-                    double pred = pr[RAFTX_F_X + j] + (double)mi * unit * cr[RAFTX_F_Q + j];
-                    if (fabs(pred - cr[RAFTX_F_X + j]) > 1e-10 * (1.0 + fabs(cr[RAFTX_F_X + j]))) ok = false;
+                    double pred = pX[j] + (double)mi * unit * cQ[j];
+                    if (fabs(pred - cX[j]) > 1e-10 * (1.0 + fabs(cX[j]))) ok = false;
                 }
                 if (ok) m = mi;
             }
         }
         if (m != 0) {
-            const double *pr = cr - GD_ROW;
             for (int j = 0; j < 3; j++)
-                if (pr[RAFTX_F_P1 + j] != cr[RAFTX_F_P1 + j] || pr[RAFTX_F_P2 + j] != cr[RAFTX_F_P2 + j]) m = 0;
-            if ((pr[RAFTX_F_CIRC] != 0.0) != (cr[RAFTX_F_CIRC] != 0.0)) m = 0;
-            if ((pr[RAFTX_F_MCF] >= 0.0) != (cr[RAFTX_F_MCF] >= 0.0)) m = 0;
+                if (pP1[j] != cP1[j] || pP2[j] != cP2[j]) m = 0;
+            if ((pCirc != 0.0) != (cCirc != 0.0)) m = 0;
+            if ((pMcf >= 0.0) != (cMcf >= 0.0)) m = 0;
             for (int j = 0; j < 3; j++) {
-                const double da = cr[RAFTX_F_AX + j] - pr[RAFTX_F_AX + j], dx = cr[RAFTX_F_X + j] - pr[RAFTX_F_X + j];
-                if (!(fabs(da - dx) <= 1e-9 * (1.0 + fabs(cr[RAFTX_F_X + j]) + fabs(cr[RAFTX_F_AX + j])))) m = 0;
+                const double da = cA[j] - pA[j], dx = cX[j] - pX[j];
+                if (!(fabs(da - dx) <= 1e-9 * (1.0 + fabs(cX[j]) + fabs(cA[j])))) m = 0;
             }
         }
-        int fl = m | (cr[RAFTX_F_CIRC] != 0.0 ? DSI_CIRC : 0);
-        if (fabs(cr[RAFTX_F_P1]) < 1e-15 && fabs(cr[RAFTX_F_P1 + 1]) < 1e-15 && fabs(cr[RAFTX_F_P2 + 2]) < 1e-15) fl |= DSI_AXAL;
-        if (fabs(cr[RAFTX_F_Q]) < 1e-15 && fabs(cr[RAFTX_F_Q + 1]) < 1e-15 && fabs(cr[RAFTX_F_P1 + 2]) < 1e-15 && fabs(cr[RAFTX_F_P2 + 2]) < 1e-15)
+        int fl = m | (cCirc != 0.0 ? DSI_CIRC : 0);
+        if (fabs(cP1[0]) < 1e-15 && fabs(cP1[1]) < 1e-15 && fabs(cP2[2]) < 1e-15) fl |= DSI_AXAL;
+        if (fabs(cQ[0]) < 1e-15 && fabs(cQ[1]) < 1e-15 && fabs(cP1[2]) < 1e-15 && fabs(cP2[2]) < 1e-15)
             fl |= DSI_VAX;
         A.dsi[(size_t)i0 + t] = fl;
     }
@@ -1419,14 +1432,21 @@ __device__ __forceinline__ void geom_design_block(const GeomArgs &A, const int d
     // ---- device strip records, one 256 B row per strip, written by consecutive lanes (a lane keeps its field)
     {
         double *dso = A.ds + (size_t)i0 * DS_N;
-        const int j = lane % DS_N, f = DS_SRC[j];
-        for (int t = lane; t < S * DS_N; t += GD_T) {
-            const int i = t / DS_N;
+        // (four rows of the table per trip: the LDS reads of a trip are in flight together, then its stores -- one read, one
+        // wait, one store per trip was a fifth of the kernel)
+        const int j = lane % DS_N, f = DS_SRC[j], nT = S * DS_N;
+        constexpr int DU = 4;
+        for (int t0 = lane; t0 < nT; t0 += DU * GD_T) {
+          double vv[DU];
+#pragma unroll
+          for (int u = 0; u < DU; u++) {
+            const int t = t0 + u * GD_T;
+            const int i = t < nT ? t / DS_N : 0;              // (past the end: a valid row, read and dropped)
             const double *cr = rec + (size_t)i * GD_ROW;
             double v = 0.0;
             if (f >= 0) v = cr[f];
             else if (f <= -2) v = unv[rsv[i]] * cr[RAFTX_F_Q + (-2 - f)];
-            if (j == DS_MCF && v >= 0.0) {
+            if (t < nT && j == DS_MCF && v >= 0.0) {
                 // MacCamy-Fuchs row of the DEVICE record: the first row of this design with the same (R, Ca_p1, Ca_p2) --
                 // the strips of a column share them, so the solver's reads of the Cm table fall on a few rows per design
                 // (lines it has just touched) instead of one row per strip, 32 B per strip and bin out of HBM.  The ABI
@@ -1439,7 +1459,13 @@ __device__ __forceinline__ void geom_design_block(const GeomArgs &A, const int d
                         break;
                     }
             }
-            dso[t] = v;
+            vv[u] = v;
+          }
+#pragma unroll
+          for (int u = 0; u < DU; u++) {
+            const int t = t0 + u * GD_T;
+            if (t < nT) dso[t] = vv[u];
+          }
         }
     }
     GEOM_PHASE(4);
