@@ -725,6 +725,33 @@ def fixture_flexible():
     standin.save_fixture(os.path.join(GOLD, "flex_volturnus.npz"), fx)
 
 
+def fixture_flexible_mcf():
+    """MacCamy-Fuchs on FLEXIBLE members (raft_member.py:1415-1420 with the node-by-node sums of :1969-1976): the reference's
+    flexible deck with its three outer columns -- circular, surface-piercing, MCF: True -- turned into beam members (240 reduced /
+    504 full DOFs).  Live F_hydro_iner of two sea states, and one live Model.solveDynamics (35 s of reference time)."""
+    raft = rh.import_raft()
+    d = rh.prepare_design(rh.load_design(os.path.join(REF, "tests/test_data", "VolturnUS-S-flexible.yaml")))
+    for mem in d["platform"]["members"]:
+        if mem["name"] == "outer_column":
+            mem["type"], mem["E"], mem["G"] = "beam", 210e9, 80e9
+    n = raft.Model(copy.deepcopy(d)).fowtList[0].nDOF
+    cm = np.zeros((n, n))
+    cm[:6, :6] = rh.DEFAULT_C_MOOR
+    m = rh.build_model(d, c_moor=cm)
+    fowt = m.fowtList[0]
+    assert any(mm.type != "rigid" and mm.MCF for mm in fowt.memberList)
+    exc_cases = [dict(wave_spectrum="JONSWAP", wave_heading=h, wave_period=T, wave_height=H) for h, T, H in ((0, 10, 2), (135, 6, 1))]
+    exc = []
+    for c in exc_cases:
+        fowt.calcHydroExcitation(dict(c), memberList=fowt.memberList)
+        exc.append(np.array(fowt.F_hydro_iner))
+    r = run_case(m, rh.make_case(Hs=5.0, Tp=11.0, heading=25.0), lean=True)
+    fx = {"config": "VolturnUS-S-flexible with its outer columns (circular, MacCamy-Fuchs) as beam members: %d reduced DOFs; live "
+                    "reference calcHydroExcitation and solveDynamics" % n,
+          "model": standin.snapshot_model(m), "exc_cases": exc_cases, "exc_F_hydro_iner": np.array(exc), "case": r}
+    standin.save_fixture(os.path.join(GOLD, "flex_mcf.npz"), fx)
+
+
 def fixture_flexible_moor():
     """The flexible deck with a unit-level lumped-mass mooring (moorMod == 2, raft_model.py:1019-1030,1069-1072): the mooring
     model's matrices are lumped at the unit's first six reduced DOFs and its damping is re-linearised about every iterate.
@@ -762,7 +789,7 @@ def fixture_flexible_moor():
     standin.save_fixture(os.path.join(GOLD, "flex_moormod2.npz"), fx)
 
 
-ALL = {"flexmoor": fixture_flexible_moor, "flexible": fixture_flexible, "f4": fixture_f4, "c5full": fixture_c5_full, "refstatics": fixture_ref_statics, "refmembers": fixture_ref_members, "bem": fixture_bem, "geom": fixture_geom, "c5oc4": fixture_c5_oc4, "c5": fixture_c5, "qtf": fixture_qtf, "c1": fixture_c1, "c2": fixture_c2, "pose": fixture_pose,
+ALL = {"flexmcf": fixture_flexible_mcf, "flexmoor": fixture_flexible_moor, "flexible": fixture_flexible, "f4": fixture_f4, "c5full": fixture_c5_full, "refstatics": fixture_ref_statics, "refmembers": fixture_ref_members, "bem": fixture_bem, "geom": fixture_geom, "c5oc4": fixture_c5_oc4, "c5": fixture_c5, "qtf": fixture_qtf, "c1": fixture_c1, "c2": fixture_c2, "pose": fixture_pose,
        "refgold": fixture_ref_goldens, "c4": fixture_c4, "c3": fixture_c3}
 
 if __name__ == "__main__":

@@ -300,14 +300,16 @@ def pack_fowt_nodes(fowt, memberList=None):
             rows.append(int(node.id) * int(getattr(node, "nDOF", 6)))
             tables.append(StripTable(rec, np.array(cms) if cms else None))
             continue
-        if mcf:
-            raise UnsupportedFOWT("flexible member '%s' with the MacCamy-Fuchs correction" % getattr(mem, "name", "?"))
         for one in rec:
             node = mem.nodeList[int(one[F_IL])]
             one = one.copy()
             one[F_STEP] = one[F_UNIT] = 0.0                  # a table of one strip has no run
+            cm_one = None
+            if mcf and one[F_MCF] >= 0:                      # MacCamy-Fuchs on a flexible member (raft_member.py:1415-1420, 1969-1976):
+                cm_one = np.array(cms[int(one[F_MCF])])[None]    # the strip's own row of the Cm table goes with its table
+                one[F_MCF] = 0.0
             rows.append(int(node.id) * int(getattr(node, "nDOF", 6)))
-            tables.append(StripTable(one[None, :], None))
+            tables.append(StripTable(one[None, :], cm_one))
     return rows, tables
 
 
